@@ -1,0 +1,285 @@
+/*
+ * shifu_amd.h -- C ABI of the MI355X-native vectorised-env backend.
+ *
+ * This is the drop-in boundary.  The reference has no
+ * FFI: its seam is the Python object returned by `gymapi.acquire_gym()`
+ * (reference shifu/gym/isaac_gym.py:213-221) plus `gymtorch.wrap_tensor /
+ * unwrap_tensor` (isaac_gym.py:108-134).  Every entry point below names the
+ * `gym.*` call(s) it replaces.  Signatures are plain pointers and sizes --
+ * no torch types.  Device buffers are allocated by the host language
+ * (PyTorch-ROCm in this repo) and *bound* to the sim; the library itself only
+ * launches kernels on the stream it is handed and never synchronises.
+ *
+ * All functions return 0 on success, non-zero on error; shf_last_error() gives
+ * the message (Isaac Gym prints and returns None/False; the host wrapper
+ * raises instead -- INTEGRATION.md).
+ */
+#ifndef SHIFU_AMD_H
+#define SHIFU_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHF_ABI_VERSION 1
+
+#define SHF_MAX_BODIES 32 /* reported rigid bodies per articulation        */
+#define SHF_MAX_DOFS 32
+#define SHF_MAX_POINTS 96 /* contact sample points per articulation        */
+#define SHF_MAX_BOXES 4   /* extra single-body box actors per env          */
+#define SHF_MAX_SPHERES 8 /* collision spheres (vs boxes) per articulation */
+
+/* joint types of a reported body's inboard joint */
+enum { SHF_JOINT_ROOT = 0, SHF_JOINT_REVOLUTE = 1, SHF_JOINT_PRISMATIC = 2, SHF_JOINT_WELD = 3 };
+/* drive modes: numeric values follow gymapi.DOF_MODE_* (robot.py:55-64) */
+enum { SHF_DOF_MODE_NONE = 0, SHF_DOF_MODE_POS = 1, SHF_DOF_MODE_VEL = 2, SHF_DOF_MODE_EFFORT = 3 };
+
+/*
+ * Flattened articulation, produced by the model compiler (shifu_amd/model.py)
+ * from a URDF.  Replaces gym.load_asset + get_asset_* (units.py:73-89).
+ * "Reported" bodies are what rigid_body_state / net_contact_force index
+ * (fixed joints collapsed unless dont_collapse, a1.urdf FR_foot_fixed).
+ * Welded bodies (kept fixed-joint children) carry no inertia of their own:
+ * it is merged into dyn[b], their nearest moving ancestor.
+ */
+typedef struct ShfModel {
+  int32_t nb;         /* reported bodies                                   */
+  int32_t nd;         /* degrees of freedom                                */
+  int32_t np;         /* contact sample points                             */
+  int32_t nlevels;    /* max depth of moving bodies below the root         */
+  int32_t fixed_base; /* AssetOptions.fix_base_link                        */
+  int32_t gravity_on; /* !AssetOptions.disable_gravity                     */
+  int32_t nsph;       /* spheres tested against box actors                 */
+  int32_t pad0;
+
+  int32_t parent[SHF_MAX_BODIES]; /* reported parent, -1 for the root      */
+  int32_t jtype[SHF_MAX_BODIES];
+  int32_t dof[SHF_MAX_BODIES];   /* dof index, -1 if none                  */
+  int32_t level[SHF_MAX_BODIES]; /* depth among moving bodies (root = 0)   */
+  int32_t dyn[SHF_MAX_BODIES];   /* moving body that carries my inertia    */
+  int32_t child_start[SHF_MAX_BODIES];
+  int32_t child_count[SHF_MAX_BODIES];
+  int32_t child_list[SHF_MAX_BODIES]; /* moving children, summed in this order */
+  int32_t pt_start[SHF_MAX_BODIES];   /* contact points of a moving body   */
+  int32_t pt_count[SHF_MAX_BODIES];
+
+  float tpos[SHF_MAX_BODIES][3]; /* joint origin in parent frame           */
+  float trot[SHF_MAX_BODIES][9]; /* row-major rotation parent<-child(q=0)  */
+  float axis[SHF_MAX_BODIES][3]; /* joint axis in child frame              */
+  float mass[SHF_MAX_BODIES];
+  float com[SHF_MAX_BODIES][3];
+  float inertia[SHF_MAX_BODIES][6]; /* about com: xx xy xz yy yz zz        */
+
+  float lower[SHF_MAX_DOFS];
+  float upper[SHF_MAX_DOFS];
+  float vel_limit[SHF_MAX_DOFS];
+  float effort[SHF_MAX_DOFS];
+  float kp[SHF_MAX_DOFS]; /* dof_props stiffness (robot.py:35-37)          */
+  float kd[SHF_MAX_DOFS];
+  float armature[SHF_MAX_DOFS];
+  float damping[SHF_MAX_DOFS];
+  int32_t drive_mode[SHF_MAX_DOFS];
+  int32_t dof_body[SHF_MAX_DOFS];
+
+  int32_t pt_body[SHF_MAX_POINTS]; /* reported body the force is logged on */
+  float pt_pos[SHF_MAX_POINTS][3]; /* in pt_body's frame                   */
+  float pt_radius[SHF_MAX_POINTS];
+
+  int32_t sph_body[SHF_MAX_SPHERES];
+  float sph_pos[SHF_MAX_SPHERES][3];
+  float sph_radius[SHF_MAX_SPHERES];
+} ShfModel;
+
+/* A single-body box actor (gym.create_box, object.py:28-39). */
+typedef struct ShfBoxDesc {
+  float dim[3];
+  float mass; /* 0 or fixed!=0 -> static                                  */
+  float friction;
+  int32_t fixed;
+  float pos[3]; /* default pose (reset value)                             */
+  float quat[4];
+} ShfBoxDesc;
+
+/*
+ * Simulation parameters.  Replaces gymapi.SimParams (+.physx)
+ * (shifu/configs/env_config.py:38-58).  The PhysX TGS solver settings have
+ * no counterpart; the contact model is the linearly-implicit compliant
+ * contact described in DESIGN.md and is parameterised here.
+ */
+typedef struct ShfSimParams {
+  float dt;
+  float gravity[3];
+  float contact_k;       /* normal stiffness, N/m                          */
+  float contact_d;       /* normal damping, N s/m                          */
+  float friction_vel;    /* Coulomb regularisation speed, m/s              */
+  float limit_k;         /* joint-limit spring, N m/rad                    */
+  float limit_d;         /* joint-limit damper                             */
+  float angular_damping; /* AssetOptions.angular_damping default 0.5 (root)*/
+  float max_ang_vel;     /* AssetOptions.max_angular_velocity default 64   */
+  float max_depen_vel;   /* physx.max_depenetration_velocity = 1.0 (env_config.py:57) */
+} ShfSimParams;
+
+typedef struct ShfTerrain {
+  int32_t rows, cols; /* height_samples is (rows, cols) int16, x<->row     */
+  float hscale, vscale, border;
+  float friction; /* terrain static==dynamic friction (env_config.py:82)   */
+} ShfTerrain;
+
+/* Tensor ids for shf_sim_bind / shf_sim_layout.  State tensors follow the
+ * Isaac Gym layouts shifu views (isaac_gym.py:108-134, robot.py:48-53). */
+enum {
+  SHF_T_DOF_STATE = 0,   /* (N*nd, 2) f32  pos,vel       acquire_dof_state_tensor          */
+  SHF_T_ROOT_STATE = 1,  /* (N*A, 13) f32                acquire_actor_root_state_tensor   */
+  SHF_T_BODY_STATE = 2,  /* (N*B, 13) f32                acquire_rigid_body_state_tensor   */
+  SHF_T_CONTACT = 3,     /* (N*B, 3)  f32                acquire_net_contact_force_tensor  */
+  SHF_T_JACOBIAN = 4,    /* (N, nb-1|nb, 6, nd|nd+6) f32 acquire_jacobian_tensor           */
+  SHF_T_SIM_DOF = 5,     /* internal copies the solver integrates; refresh_* copies them   */
+  SHF_T_SIM_ROOT = 6,    /*   into the user-visible tensors above                          */
+  SHF_T_EFFORT = 7,      /* (N*nd) f32   set_dof_actuation_force_tensor                    */
+  SHF_T_POS_TARGET = 8,  /* (N*nd) f32   set_dof_position_target_tensor                    */
+  SHF_T_VEL_TARGET = 9,  /* (N*nd) f32   set_dof_velocity_target_tensor                    */
+  SHF_T_BODY_FORCE = 10, /* (N*B, 3) f32 apply_rigid_body_force_at_pos_tensors (CoM)       */
+  SHF_T_FRICTION = 11,   /* (N) f32      per-env shape friction (a1_conditional.py:28-31)  */
+  SHF_T_HEIGHTS = 12,    /* (rows*cols) i16 height samples (isaac_gym.py:349-367)          */
+  SHF_T_MODEL = 13,      /* sizeof(ShfModel) bytes, device copy                            */
+  SHF_T_FORCE_ARMED = 14,/* (1) i32: body forces are consumed by the next step only        */
+  SHF_T_COUNT = 15
+};
+
+/* refresh masks: gym.refresh_*_tensor (isaac_gym.py:139-154) */
+enum {
+  SHF_REFRESH_DOF = 1,
+  SHF_REFRESH_ROOT = 2,
+  SHF_REFRESH_BODY = 4,
+  SHF_REFRESH_CONTACT = 8,
+  SHF_REFRESH_JACOBIAN = 16,
+  SHF_REFRESH_ALL = 31
+};
+
+typedef struct ShfSim ShfSim;
+
+const char* shf_last_error(void);
+int shf_abi_version(void);
+
+/* gym.create_sim (isaac_gym.py:217-220) */
+int shf_sim_create(const ShfSimParams* params, ShfSim** out);
+/* gym.destroy_sim (isaac_gym.py:287) */
+int shf_sim_destroy(ShfSim* sim);
+/* gym.add_ground (isaac_gym.py:197-203): rows==0 -> flat plane z=0.
+ * gym.add_heightfield / add_triangle_mesh (isaac_gym.py:349-385): samples are
+ * bound with SHF_T_HEIGHTS. */
+int shf_sim_set_terrain(ShfSim* sim, const ShfTerrain* terrain);
+/* gym.load_asset + create_actor for the articulated robot (units.py:57-77) */
+int shf_sim_set_articulation(ShfSim* sim, const ShfModel* model);
+/* gym.create_box + create_actor (object.py:28-39) */
+int shf_sim_add_box(ShfSim* sim, const ShfBoxDesc* box);
+/* gym.create_env x N + prepare_sim (isaac_gym.py:94-104).  env_id_offset is
+ * the global id of local env 0 (multi-GPU sharding). */
+int shf_sim_finalize(ShfSim* sim, int32_t num_envs, int64_t env_id_offset);
+/* Shape/dtype the host must allocate for tensor `id`.
+ * dtype: 0 f32, 1 i32, 2 i16, 3 u8, 4 i64. */
+int shf_sim_layout(const ShfSim* sim, int32_t id, int64_t shape[4], int32_t* ndim, int32_t* dtype);
+/* gymtorch.wrap_tensor in reverse: hand the sim a device pointer for `id`. */
+int shf_sim_bind(ShfSim* sim, int32_t id, void* device_ptr);
+/* Writes every exposed tensor from the default poses (after create_actor the
+ * reference sees spawn poses in root_state: units.py:57-70; Q14 fixed). */
+int shf_sim_reset_all(ShfSim* sim, const float* env_origins_dev, void* stream);
+
+/* gym.simulate (a1_conditional.py:69, robot.py:69, isaac_gym.py:140) */
+int shf_sim_step(ShfSim* sim, void* stream);
+/* gym.refresh_{dof_state,actor_root_state,rigid_body_state,jacobian,
+ * net_contact_force}_tensor(s) (isaac_gym.py:145-154, a1_conditional.py:72) */
+int shf_sim_refresh(ShfSim* sim, int32_t mask, void* stream);
+/* gym.set_dof_actuation_force_tensor / set_dof_position_target_tensor /
+ * set_dof_velocity_target_tensor (robot.py:55-64): copies (N*nd) floats. */
+int shf_sim_set_dof_command(ShfSim* sim, int32_t tensor_id, const float* values_dev, void* stream);
+/* gym.set_dof_position_target_tensor_indexed (robot.py:78-82); idx are int32
+ * actor indices in sim domain (isaac_gym.py:67). */
+int shf_sim_set_pos_target_indexed(ShfSim* sim, const float* values_dev, const int32_t* actor_idx_dev,
+                                   int32_t n, void* stream);
+/* gym.apply_rigid_body_force_at_pos_tensors(force, None) (robot.py:231-236) */
+int shf_sim_apply_body_force(ShfSim* sim, const float* force_dev, void* stream);
+/* gym.set_actor_root_state_tensor_indexed (isaac_gym.py:70-73) */
+int shf_sim_commit_root_indexed(ShfSim* sim, const float* root_dev, const int32_t* actor_idx_dev, int32_t n,
+                                void* stream);
+/* gym.set_actor_root_state_tensor (robot.py:99-100) */
+int shf_sim_commit_root_all(ShfSim* sim, const float* root_dev, void* stream);
+/* gym.set_dof_state_tensor_indexed (robot.py:83-86) */
+int shf_sim_commit_dof_indexed(ShfSim* sim, const float* dof_dev, const int32_t* actor_idx_dev, int32_t n,
+                               void* stream);
+
+/* ------------------------------------------------------------------------
+ * Fused A1Conditional env step: everything
+ * ShifuVecEnv.step does for examples/a1_conditional in ONE launch per
+ * vec-step (env.py:85-106, a1_conditional.py:64-75,116-221,
+ * isaac_gym.py:393-433, train.py:12-35), plus one tiny reduction launch for
+ * extras["episode"] (env.py:149-158).
+ * ---------------------------------------------------------------------- */
+typedef struct ShfA1TaskParams {
+  int32_t decimation;        /* cfg.control.decimation = 4                  */
+  int32_t extra_substep;     /* 1: refresh_state's extra simulate (Q1)      */
+  int32_t num_history;       /* 3                                           */
+  int32_t num_height_points; /* 187                                         */
+  int32_t base_body;         /* rigid_body_dict['base']                     */
+  int32_t curriculum;        /* cfg.terrain.curriculum                      */
+  int32_t max_terrain_level; /* cfg.terrain.num_rows                        */
+  int32_t num_terrain_cols;
+  float action_scale;        /* 0.5 (a1_conditional.py:123)                 */
+  float clip_actions;        /* 1.0                                         */
+  float clip_obs;            /* 100.0                                       */
+  float max_episode_length;  /* ceil(episode_length_s / dt) = 500           */
+  float max_episode_length_s;
+  float env_length;          /* terrain.env_length = 8 m                    */
+  float max_push_force;      /* 5 N (a1_conditional.py:83)                  */
+  float spawn_xy;            /* 1 m (a1_conditional.py:47)                  */
+  float default_pos[3];      /* 0,0,0.42                                    */
+  float default_quat[4];
+  float default_dof_pos[SHF_MAX_DOFS];
+  float p_gain[SHF_MAX_DOFS];
+  float d_gain[SHF_MAX_DOFS];
+  int32_t num_leg_bodies;    /* bodies whose name has thigh|calf            */
+  int32_t leg_bodies[SHF_MAX_BODIES];
+  uint64_t seed;             /* counter-based RNG key                       */
+} ShfA1TaskParams;
+
+enum {
+  SHF_A1_ACTIONS = 0,    /* (N,12) f32  clipped actions (env.actions)              */
+  SHF_A1_OBS = 1,        /* (N,259) f32                                            */
+  SHF_A1_REW = 2,        /* (N) f32                                                */
+  SHF_A1_RESET = 3,      /* (N) u8 (torch.bool)                                    */
+  SHF_A1_TIMEOUT = 4,    /* (N) u8                                                 */
+  SHF_A1_EP_LEN = 5,     /* (N) i64                                                */
+  SHF_A1_COMMAND = 6,    /* (N,3) f32                                              */
+  SHF_A1_HISTORY = 7,    /* (N,12,3) f32 HistoryRecorder.history_buf               */
+  SHF_A1_REW_SUMS = 8,   /* (6,N) f32 episode_rewards                              */
+  SHF_A1_TORQUES = 9,    /* (N,12) f32                                             */
+  SHF_A1_BASE_VEL = 10,  /* (N,9) f32 base_lin_vel, base_ang_vel, projected_gravity */
+  SHF_A1_HEIGHTS = 11,   /* (N,187) f32 measured_heights                           */
+  SHF_A1_HPOINTS = 12,   /* (187,2) f32 height sample grid (base frame)            */
+  SHF_A1_PUSH = 13,      /* (N,B,3) f32 rand_force_buf                             */
+  SHF_A1_ORIGINS = 14,   /* (N,3) f32 env_origins                                  */
+  SHF_A1_LEVELS = 15,    /* (N) i64 terrain_levels                                 */
+  SHF_A1_TYPES = 16,     /* (N) i64 terrain_types                                  */
+  SHF_A1_TORIGINS = 17,  /* (rows,cols,3) f32 terrain_origins                      */
+  SHF_A1_RESET_COUNT = 18, /* (N) i32 per-env episode counter (RNG counter)        */
+  SHF_A1_DONE_SUMS = 19, /* (8,N) f32 per-env finished-episode sums (6 terms, level, 1) */
+  SHF_A1_STATS = 20,     /* (R,16) f32 ring of per-step reductions                 */
+  SHF_A1_COUNT = 21
+};
+
+typedef struct ShfA1Task ShfA1Task;
+int shf_a1_create(ShfSim* sim, const ShfA1TaskParams* params, ShfA1Task** out);
+int shf_a1_destroy(ShfA1Task* task);
+int shf_a1_layout(const ShfA1Task* task, int32_t id, int64_t shape[4], int32_t* ndim, int32_t* dtype);
+int shf_a1_bind(ShfA1Task* task, int32_t id, void* device_ptr);
+/* ShifuVecEnv.step for A1Conditional.  raw_actions: (N,12) policy output. */
+int shf_a1_step(ShfA1Task* task, const float* raw_actions_dev, int64_t step_index, void* stream);
+/* ShifuVecEnv.reset_idx(arange(N)) part of reset() (env.py:108-112). */
+int shf_a1_reset_all(ShfA1Task* task, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHIFU_AMD_H */

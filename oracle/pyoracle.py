@@ -1,0 +1,94 @@
+"""ctypes loader for the CPU oracle (oracle/libshf_oracle.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package (shifu_amd/) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libshf_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("shf_oracle.c", "Makefile")] + \
+           [os.path.join(_HERE, "..", "include", "shifu_amd.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libshf_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+    return _LIB
+
+
+def _p(a, ct):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ct))
+
+
+def step(model, params, n, dof_state, root_state, *, nsteps=1, terrain=None, heights=None, effort=None,
+         pos_target=None, vel_target=None, body_force=None, friction=None, want_contact=False,
+         want_body_state=False, f64=False):
+    """Advance `n` envs by `nsteps` simulate() calls, in place.  Arrays are
+    float32 (f64=False) or float64 (f64=True); friction is always float32."""
+    dt = np.float64 if f64 else np.float32
+    ct = C.c_double if f64 else C.c_float
+    for a in (dof_state, root_state, effort, pos_target, vel_target, body_force):
+        assert a is None or (a.dtype == dt and a.flags.c_contiguous)
+    contact = np.zeros((n * model.nb, 3), dt) if want_contact else None
+    bstate = np.zeros((n * model.nb, 13), dt) if want_body_state else None
+    fn = lib().shf_oracle_step_f64 if f64 else lib().shf_oracle_step_f32
+    fn.restype = None
+    fn(C.byref(model), C.byref(params), C.byref(terrain) if terrain is not None else None,
+       _p(heights, C.c_int16), C.c_int(n), C.c_int(nsteps), _p(dof_state, ct), _p(root_state, ct), _p(effort, ct),
+       _p(pos_target, ct), _p(vel_target, ct), _p(body_force, ct), _p(friction, C.c_float), _p(contact, ct),
+       _p(bstate, ct))
+    return contact, bstate
+
+
+def accel(model, params, dof_state, root_state, effort, f64=True):
+    dt = np.float64 if f64 else np.float32
+    ct = C.c_double if f64 else C.c_float
+    qdd = np.zeros(model.nd, dt)
+    racc = np.zeros(6, dt)
+    fn = lib().shf_oracle_accel_f64 if f64 else lib().shf_oracle_accel_f32
+    fn.restype = None
+    fn(C.byref(model), C.byref(params), _p(np.ascontiguousarray(dof_state, dt), ct),
+       _p(np.ascontiguousarray(root_state, dt), ct), _p(np.ascontiguousarray(effort, dt), ct), _p(qdd, ct),
+       _p(racc, ct))
+    return qdd, racc
+
+
+def sincos(x):
+    x = np.ascontiguousarray(x, np.float32)
+    s = np.zeros_like(x); c = np.zeros_like(x)
+    lib().shf_oracle_sincos_f32(C.c_int(x.size), _p(x, C.c_float), _p(s, C.c_float), _p(c, C.c_float))
+    return s, c
+
+
+def exp(x):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.zeros_like(x)
+    lib().shf_oracle_exp_f32(C.c_int(x.size), _p(x, C.c_float), _p(y, C.c_float))
+    return y
+
+
+def terrain_query(terrain, heights, xy, f64=False):
+    dt = np.float64 if f64 else np.float32
+    ct = C.c_double if f64 else C.c_float
+    xy = np.ascontiguousarray(xy, dt)
+    n = xy.shape[0]
+    h = np.zeros(n, dt); nrm = np.zeros((n, 3), dt)
+    fn = lib().shf_oracle_terrain_query_f64 if f64 else lib().shf_oracle_terrain_query_f32
+    fn(C.byref(terrain), _p(heights, C.c_int16), C.c_int(n), _p(xy, ct), _p(h, ct), _p(nrm, ct))
+    return h, nrm

@@ -1,0 +1,77 @@
+"""ctypes mirrors of the PODs in include/shifu_amd.h (keep in lock-step)."""
+import ctypes as C
+
+SHF_ABI_VERSION = 1
+MAX_BODIES = 32
+MAX_DOFS = 32
+MAX_POINTS = 96
+MAX_BOXES = 4
+MAX_SPHERES = 8
+
+JOINT_ROOT, JOINT_REVOLUTE, JOINT_PRISMATIC, JOINT_WELD = 0, 1, 2, 3
+DOF_MODE_NONE, DOF_MODE_POS, DOF_MODE_VEL, DOF_MODE_EFFORT = 0, 1, 2, 3
+
+i32 = C.c_int32
+f32 = C.c_float
+
+
+class ShfModel(C.Structure):
+    _fields_ = [
+        ("nb", i32), ("nd", i32), ("np", i32), ("nlevels", i32),
+        ("fixed_base", i32), ("gravity_on", i32), ("nsph", i32), ("pad0", i32),
+        ("parent", i32 * MAX_BODIES), ("jtype", i32 * MAX_BODIES), ("dof", i32 * MAX_BODIES),
+        ("level", i32 * MAX_BODIES), ("dyn", i32 * MAX_BODIES),
+        ("child_start", i32 * MAX_BODIES), ("child_count", i32 * MAX_BODIES), ("child_list", i32 * MAX_BODIES),
+        ("pt_start", i32 * MAX_BODIES), ("pt_count", i32 * MAX_BODIES),
+        ("tpos", (f32 * 3) * MAX_BODIES), ("trot", (f32 * 9) * MAX_BODIES), ("axis", (f32 * 3) * MAX_BODIES),
+        ("mass", f32 * MAX_BODIES), ("com", (f32 * 3) * MAX_BODIES), ("inertia", (f32 * 6) * MAX_BODIES),
+        ("lower", f32 * MAX_DOFS), ("upper", f32 * MAX_DOFS), ("vel_limit", f32 * MAX_DOFS),
+        ("effort", f32 * MAX_DOFS), ("kp", f32 * MAX_DOFS), ("kd", f32 * MAX_DOFS),
+        ("armature", f32 * MAX_DOFS), ("damping", f32 * MAX_DOFS),
+        ("drive_mode", i32 * MAX_DOFS), ("dof_body", i32 * MAX_DOFS),
+        ("pt_body", i32 * MAX_POINTS), ("pt_pos", (f32 * 3) * MAX_POINTS), ("pt_radius", f32 * MAX_POINTS),
+        ("sph_body", i32 * MAX_SPHERES), ("sph_pos", (f32 * 3) * MAX_SPHERES), ("sph_radius", f32 * MAX_SPHERES),
+    ]
+
+
+class ShfBoxDesc(C.Structure):
+    _fields_ = [("dim", f32 * 3), ("mass", f32), ("friction", f32), ("fixed", i32),
+                ("pos", f32 * 3), ("quat", f32 * 4)]
+
+
+class ShfSimParams(C.Structure):
+    _fields_ = [("dt", f32), ("gravity", f32 * 3), ("contact_k", f32), ("contact_d", f32),
+                ("friction_vel", f32), ("limit_k", f32), ("limit_d", f32),
+                ("angular_damping", f32), ("max_ang_vel", f32), ("max_depen_vel", f32)]
+
+
+class ShfTerrain(C.Structure):
+    _fields_ = [("rows", i32), ("cols", i32), ("hscale", f32), ("vscale", f32), ("border", f32),
+                ("friction", f32)]
+
+
+class ShfA1TaskParams(C.Structure):
+    _fields_ = [
+        ("decimation", i32), ("extra_substep", i32), ("num_history", i32), ("num_height_points", i32),
+        ("base_body", i32), ("curriculum", i32), ("max_terrain_level", i32), ("num_terrain_cols", i32),
+        ("action_scale", f32), ("clip_actions", f32), ("clip_obs", f32), ("max_episode_length", f32),
+        ("max_episode_length_s", f32), ("env_length", f32), ("max_push_force", f32), ("spawn_xy", f32),
+        ("default_pos", f32 * 3), ("default_quat", f32 * 4),
+        ("default_dof_pos", f32 * MAX_DOFS), ("p_gain", f32 * MAX_DOFS), ("d_gain", f32 * MAX_DOFS),
+        ("num_leg_bodies", i32), ("leg_bodies", i32 * MAX_BODIES),
+        ("seed", C.c_uint64),
+    ]
+
+
+# tensor ids (shf_sim_*)
+T_DOF_STATE, T_ROOT_STATE, T_BODY_STATE, T_CONTACT, T_JACOBIAN, T_SIM_DOF, T_SIM_ROOT, T_EFFORT, \
+    T_POS_TARGET, T_VEL_TARGET, T_BODY_FORCE, T_FRICTION, T_HEIGHTS, T_MODEL, T_FORCE_ARMED, T_COUNT = range(16)
+
+REFRESH_DOF, REFRESH_ROOT, REFRESH_BODY, REFRESH_CONTACT, REFRESH_JACOBIAN, REFRESH_ALL = 1, 2, 4, 8, 16, 31
+
+# tensor ids (shf_a1_*)
+(A1_ACTIONS, A1_OBS, A1_REW, A1_RESET, A1_TIMEOUT, A1_EP_LEN, A1_COMMAND, A1_HISTORY, A1_REW_SUMS, A1_TORQUES,
+ A1_BASE_VEL, A1_HEIGHTS, A1_HPOINTS, A1_PUSH, A1_ORIGINS, A1_LEVELS, A1_TYPES, A1_TORIGINS, A1_RESET_COUNT,
+ A1_DONE_SUMS, A1_STATS, A1_COUNT) = range(22)
+
+DTYPE_F32, DTYPE_I32, DTYPE_I16, DTYPE_U8, DTYPE_I64 = range(5)

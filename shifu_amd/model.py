@@ -1,0 +1,369 @@
+"""URDF -> flattened articulation (ShfModel).
+
+Replaces what `gym.load_asset(sim, root, file, AssetOptions)` does inside Isaac
+Gym for the reference (shifu/units/units.py:73-89, asset options
+shifu/configs/asset_config.py:32-46): fixed-joint collapse honouring
+`dont_collapse`, inertial merge, body/DOF ordering, limits, collision
+primitives.  [EXT] Isaac Gym orders bodies depth-first with siblings sorted by
+link name (A1 -> FL, FR, RL, RR); the order chosen here
+is recorded in `CompiledModel.body_names / dof_names` and user code indexes by
+name through `rigid_body_dict` exactly as in the reference (robot.py:198).
+"""
+from __future__ import annotations
+
+import dataclasses
+import os
+import xml.etree.ElementTree as ET
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _abi
+
+ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+
+
+def _rpy(r: float, p: float, y: float) -> np.ndarray:
+    cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    return np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+                     [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+                     [-sp, cp * sr, cp * cr]])
+
+
+def _vec(s: Optional[str], n=3) -> np.ndarray:
+    return np.zeros(n) if s is None else np.array([float(t) for t in s.split()])
+
+
+def _origin(el) -> Tuple[np.ndarray, np.ndarray]:
+    o = None if el is None else el.find("origin")
+    if o is None:
+        return np.zeros(3), np.eye(3)
+    return _vec(o.get("xyz")), _rpy(*_vec(o.get("rpy")))
+
+
+@dataclasses.dataclass
+class _Inertial:
+    mass: float = 0.0
+    com: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(3))
+    I: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros((3, 3)))  # about com, link axes
+
+    def transformed(self, p, R) -> "_Inertial":
+        return _Inertial(self.mass, p + R @ self.com, R @ self.I @ R.T)
+
+    def merged(self, o: "_Inertial") -> "_Inertial":
+        m = self.mass + o.mass
+        if m <= 0.0:
+            return _Inertial()
+        c = (self.mass * self.com + o.mass * o.com) / m
+        I = np.zeros((3, 3))
+        for t in (self, o):
+            d = t.com - c
+            I += t.I + t.mass * (d @ d * np.eye(3) - np.outer(d, d))
+        return _Inertial(m, c, I)
+
+
+@dataclasses.dataclass
+class _Shape:
+    kind: str
+    size: np.ndarray
+    pos: np.ndarray
+    rot: np.ndarray
+
+
+@dataclasses.dataclass
+class _Link:
+    name: str
+    inertial: _Inertial
+    shapes: List[_Shape]
+
+
+@dataclasses.dataclass
+class _Joint:
+    name: str
+    type: str
+    parent: str
+    child: str
+    pos: np.ndarray
+    rot: np.ndarray
+    axis: np.ndarray
+    lower: float
+    upper: float
+    effort: float
+    velocity: float
+    damping: float
+    dont_collapse: bool
+
+
+@dataclasses.dataclass
+class CompiledModel:
+    blob: _abi.ShfModel
+    body_names: List[str]
+    dof_names: List[str]
+    total_mass: float
+
+    @property
+    def rigid_body_dict(self) -> Dict[str, int]:
+        return {n: i for i, n in enumerate(self.body_names)}
+
+    @property
+    def num_bodies(self) -> int:
+        return self.blob.nb
+
+    @property
+    def num_dof(self) -> int:
+        return self.blob.nd
+
+    def dof_properties(self) -> np.ndarray:
+        """NumPy structured array with the fields shifu touches (robot.py:35-42)."""
+        dt = np.dtype([("hasLimits", "?"), ("lower", "f4"), ("upper", "f4"), ("driveMode", "i4"),
+                       ("velocity", "f4"), ("effort", "f4"), ("stiffness", "f4"), ("damping", "f4"),
+                       ("friction", "f4"), ("armature", "f4")])
+        out = np.zeros(self.blob.nd, dtype=dt)
+        for i in range(self.blob.nd):
+            out[i] = (True, self.blob.lower[i], self.blob.upper[i], self.blob.drive_mode[i],
+                      self.blob.vel_limit[i], self.blob.effort[i], self.blob.kp[i], self.blob.kd[i], 0.0,
+                      self.blob.armature[i])
+        return out
+
+
+def parse_urdf(path: str) -> Tuple[Dict[str, _Link], List[_Joint]]:
+    root = ET.parse(path).getroot()
+    links: Dict[str, _Link] = {}
+    for l in root.findall("link"):
+        ine = l.find("inertial")
+        inertial = _Inertial()
+        if ine is not None:
+            p, R = _origin(ine)
+            I = ine.find("inertia")
+            g = lambda k: float(I.get(k, 0.0))
+            It = np.array([[g("ixx"), g("ixy"), g("ixz")], [g("ixy"), g("iyy"), g("iyz")],
+                           [g("ixz"), g("iyz"), g("izz")]])
+            inertial = _Inertial(float(ine.find("mass").get("value")), p, R @ It @ R.T)
+        shapes = []
+        for c in l.findall("collision"):
+            p, R = _origin(c)
+            g = c.find("geometry")
+            if g is None:
+                continue
+            if g.find("box") is not None:
+                shapes.append(_Shape("box", _vec(g.find("box").get("size")), p, R))
+            elif g.find("sphere") is not None:
+                shapes.append(_Shape("sphere", np.array([float(g.find("sphere").get("radius"))]), p, R))
+            elif g.find("cylinder") is not None or g.find("capsule") is not None:
+                e = g.find("cylinder") if g.find("cylinder") is not None else g.find("capsule")
+                shapes.append(_Shape("capsule", np.array([float(e.get("radius")), float(e.get("length"))]), p, R))
+        links[l.get("name")] = _Link(l.get("name"), inertial, shapes)
+    joints = []
+    for j in root.findall("joint"):
+        p, R = _origin(j)
+        a = j.find("axis")
+        lim = j.find("limit")
+        dyn = j.find("dynamics")
+        jt = j.get("type")
+        lo = float(lim.get("lower", 0.0)) if lim is not None else 0.0
+        up = float(lim.get("upper", 0.0)) if lim is not None else 0.0
+        if jt == "continuous":
+            lo, up = -1e9, 1e9
+        joints.append(_Joint(j.get("name"), jt, j.find("parent").get("link"), j.find("child").get("link"), p, R,
+                             _vec(a.get("xyz")) if a is not None else np.array([1.0, 0, 0]), lo, up,
+                             float(lim.get("effort", 0.0)) if lim is not None else 0.0,
+                             float(lim.get("velocity", 0.0)) if lim is not None else 0.0,
+                             float(dyn.get("damping", 0.0)) if dyn is not None else 0.0,
+                             j.get("dont_collapse", "false").lower() == "true"))
+    return links, joints
+
+
+def _shape_points(shape: _Shape) -> List[Tuple[np.ndarray, float]]:
+    """Contact sample points of a primitive in its link frame: box -> 8 corners
+    (radius 0), sphere -> centre, capsule -> 2 end spheres + midpoint."""
+    pts = []
+    if shape.kind == "box":
+        h = 0.5 * shape.size
+        for sx in (-1, 1):
+            for sy in (-1, 1):
+                for sz in (-1, 1):
+                    pts.append((shape.pos + shape.rot @ (h * np.array([sx, sy, sz])), 0.0))
+    elif shape.kind == "sphere":
+        pts.append((shape.pos.copy(), float(shape.size[0])))
+    elif shape.kind == "capsule":
+        r, L = float(shape.size[0]), float(shape.size[1])
+        for z in (-0.5 * L, 0.0, 0.5 * L):
+            pts.append((shape.pos + shape.rot @ np.array([0, 0, z]), r))
+    return pts
+
+
+def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: bool = False,
+                 collapse_fixed_joints: bool = True, default_dof_drive_mode: int = _abi.DOF_MODE_NONE,
+                 armature: float = 0.0,
+                 extra_spheres: Sequence[Tuple[str, Sequence[float], float]] = ()) -> CompiledModel:
+    """Compile `path` with the AssetOptions the reference passes (asset_config.py:32-46).
+
+    extra_spheres: (link name, xyz in that link's frame, radius) collision spheres
+    tested against box actors -- the substitute for mesh colliders (ABB rod)."""
+    links, joints = parse_urdf(path)
+    children: Dict[str, List[_Joint]] = {n: [] for n in links}
+    is_child = set()
+    for j in joints:
+        children[j.parent].append(j)
+        is_child.add(j.child)
+    roots = [n for n in links if n not in is_child]
+    assert len(roots) == 1, f"URDF must have exactly one root link, got {roots}"
+
+    # reported bodies, depth first, siblings by child link name
+    names: List[str] = []
+    parent: List[int] = []
+    jtype: List[int] = []
+    tpos: List[np.ndarray] = []
+    trot: List[np.ndarray] = []
+    axis: List[np.ndarray] = []
+    jref: List[Optional[_Joint]] = []
+    inert: List[_Inertial] = []  # own (collapsed-in) inertia, body frame
+    points: List[Tuple[int, np.ndarray, float]] = []
+    link_frame: Dict[str, Tuple[int, np.ndarray, np.ndarray]] = {}  # urdf link -> (body, p, R) in body frame
+
+    def absorb(body: int, link: _Link, p: np.ndarray, R: np.ndarray):
+        inert[body] = inert[body].merged(link.inertial.transformed(p, R))
+        link_frame[link.name] = (body, p.copy(), R.copy())
+        for s in link.shapes:
+            for q, rad in _shape_points(s):
+                points.append((body, p + R @ q, rad))
+
+    def visit(link_name: str, body: int, p: np.ndarray, R: np.ndarray):
+        """link_name's frame sits at (p, R) inside reported body `body`."""
+        for j in sorted(children[link_name], key=lambda jj: jj.child):
+            cp, cR = p + R @ j.pos, R @ j.rot
+            if j.type == "fixed" and collapse_fixed_joints and not j.dont_collapse:
+                absorb(body, links[j.child], cp, cR)
+                visit(j.child, body, cp, cR)
+                continue
+            names.append(j.child)
+            parent.append(body)
+            if j.type in ("revolute", "continuous"):
+                jtype.append(_abi.JOINT_REVOLUTE)
+            elif j.type == "prismatic":
+                jtype.append(_abi.JOINT_PRISMATIC)
+            elif j.type == "fixed":
+                jtype.append(_abi.JOINT_WELD)
+            else:
+                raise NotImplementedError(f"joint type {j.type}")
+            tpos.append(cp)
+            trot.append(cR)
+            a = j.axis / max(np.linalg.norm(j.axis), 1e-12)
+            axis.append(a)
+            jref.append(j)
+            inert.append(_Inertial())
+            me = len(names) - 1
+            absorb(me, links[j.child], np.zeros(3), np.eye(3))
+            visit(j.child, me, np.zeros(3), np.eye(3))
+
+    names.append(roots[0]); parent.append(-1); jtype.append(_abi.JOINT_ROOT)
+    tpos.append(np.zeros(3)); trot.append(np.eye(3)); axis.append(np.array([0.0, 0, 1])); jref.append(None)
+    inert.append(_Inertial())
+    absorb(0, links[roots[0]], np.zeros(3), np.eye(3))
+    visit(roots[0], 0, np.zeros(3), np.eye(3))
+
+    nb = len(names)
+    assert nb <= _abi.MAX_BODIES, f"{nb} bodies > SHF_MAX_BODIES"
+
+    # moving-body bookkeeping; welded bodies hand their inertia to dyn[b]
+    dyn = list(range(nb))
+    dyn_T: List[Tuple[np.ndarray, np.ndarray]] = [(np.zeros(3), np.eye(3)) for _ in range(nb)]
+    level = [0] * nb
+    for b in range(1, nb):
+        if jtype[b] == _abi.JOINT_WELD:
+            pb = parent[b]
+            pp, pR = dyn_T[pb]
+            dyn[b] = dyn[pb]
+            dyn_T[b] = (pp + pR @ tpos[b], pR @ trot[b])
+            level[b] = level[pb]
+        else:
+            level[b] = level[dyn[parent[b]]] + 1
+    merged = [dataclasses.replace(i) for i in inert]
+    for b in range(1, nb):
+        if dyn[b] != b:
+            p, R = dyn_T[b]
+            merged[dyn[b]] = merged[dyn[b]].merged(inert[b].transformed(p, R))
+            merged[b] = _Inertial()
+
+    m = _abi.ShfModel()
+    m.nb = nb
+    m.fixed_base = int(fix_base_link)
+    m.gravity_on = int(not disable_gravity)
+    m.nlevels = max(level)
+    dof_names: List[str] = []
+    for b in range(nb):
+        m.parent[b] = parent[b]
+        m.jtype[b] = jtype[b]
+        m.level[b] = level[b]
+        m.dyn[b] = dyn[b]
+        m.dof[b] = -1
+        for k in range(3):
+            m.tpos[b][k] = tpos[b][k]
+            m.axis[b][k] = axis[b][k]
+            m.com[b][k] = merged[b].com[k]
+        for k in range(9):
+            m.trot[b][k] = trot[b].reshape(-1)[k]
+        m.mass[b] = merged[b].mass
+        I = merged[b].I
+        for k, (r, c) in enumerate(((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))):
+            m.inertia[b][k] = I[r, c]
+        if jtype[b] in (_abi.JOINT_REVOLUTE, _abi.JOINT_PRISMATIC):
+            d = len(dof_names)
+            assert d < _abi.MAX_DOFS
+            j = jref[b]
+            m.dof[b] = d
+            m.dof_body[d] = b
+            m.lower[d], m.upper[d] = j.lower, j.upper
+            m.vel_limit[d] = j.velocity if j.velocity > 0 else 1e9
+            m.effort[d] = j.effort
+            m.damping[d] = j.damping
+            m.armature[d] = armature
+            m.drive_mode[d] = default_dof_drive_mode
+            dof_names.append(j.name)
+    m.nd = len(dof_names)
+
+    # children of moving bodies (the moving parent of b is dyn[parent[b]])
+    kids: List[List[int]] = [[] for _ in range(nb)]
+    for b in range(1, nb):
+        if dyn[b] == b:
+            kids[dyn[parent[b]]].append(b)
+    k = 0
+    for b in range(nb):
+        m.child_start[b] = k
+        m.child_count[b] = len(kids[b])
+        for c in kids[b]:
+            m.child_list[k] = c
+            k += 1
+
+    # contact points grouped by moving body
+    points.sort(key=lambda t: (dyn[t[0]], t[0]))
+    assert len(points) <= _abi.MAX_POINTS, f"{len(points)} contact points > SHF_MAX_POINTS"
+    m.np = len(points)
+    for b in range(nb):
+        m.pt_start[b] = 0
+        m.pt_count[b] = 0
+    for i, (b, p, rad) in enumerate(points):
+        m.pt_body[i] = b
+        m.pt_radius[i] = rad
+        for kk in range(3):
+            m.pt_pos[i][kk] = p[kk]
+        d = dyn[b]
+        if m.pt_count[d] == 0:
+            m.pt_start[d] = i
+        m.pt_count[d] += 1
+
+    assert len(extra_spheres) <= _abi.MAX_SPHERES
+    m.nsph = len(extra_spheres)
+    for i, (lname, xyz, rad) in enumerate(extra_spheres):
+        body, p, R = link_frame[lname]
+        q = p + R @ np.asarray(xyz, dtype=float)
+        m.sph_body[i] = body
+        m.sph_radius[i] = rad
+        for kk in range(3):
+            m.sph_pos[i][kk] = q[kk]
+
+    return CompiledModel(m, names, dof_names, float(sum(t.mass for t in merged)))
+
+
+def asset_path(name: str) -> str:
+    return os.path.join(ASSET_DIR, name)

@@ -1,0 +1,167 @@
+"""Known-answer tests that pin the oracle's dynamics (the reference
+pins no physics, so these identities are the anchor).  CPU only."""
+import numpy as np
+import pytest
+
+from shifu_amd import _abi
+from tests import helpers as H
+
+
+def _rand_state(m, rng, scale_qd=3.0):
+    q = np.array([rng.uniform(max(m.lower[d], -2.5), min(m.upper[d], 2.5)) for d in range(m.nd)])
+    qd = rng.uniform(-scale_qd, scale_qd, m.nd)
+    quat = rng.normal(size=4); quat /= np.linalg.norm(quat)
+    return q, qd, quat
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_aba_matches_independent_newton_euler_a1(oracle, seed):
+    """ABA(q, qd, tau) -> qdd must satisfy classical Newton-Euler inverse dynamics."""
+    rng = np.random.default_rng(seed)
+    cm = H.a1_model()
+    m = cm.blob
+    sp = H.sim_params()
+    q, qd, quat = _rand_state(m, rng)
+    lin, ang = rng.uniform(-2, 2, 3), rng.uniform(-3, 3, 3)
+    tau = rng.uniform(-20, 20, m.nd)
+    dof = np.stack([q, qd], 1).reshape(-1)
+    root = np.concatenate([[0.3, -0.2, 0.0], quat, lin, ang])
+    qdd, racc = oracle.accel(m, sp, dof, root, tau, f64=True)
+    lin_acc_classical = racc[3:] + np.cross(ang, lin)
+    tau_ne, f0, n0 = H.newton_euler(m, q, qd, qdd, root[:3], quat, lin, ang, lin_acc_classical, racc[:3],
+                                    sp.gravity[:])
+    assert np.allclose(tau_ne, tau, rtol=0, atol=1e-9)
+    assert np.allclose(f0, 0, atol=1e-9) and np.allclose(n0, 0, atol=1e-9)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_aba_matches_newton_euler_fixed_base_arm(oracle, seed):
+    rng = np.random.default_rng(100 + seed)
+    from shifu_amd.model import asset_path, compile_urdf
+    cm = compile_urdf(asset_path("abb_rod.urdf"), fix_base_link=True, disable_gravity=False,
+                      default_dof_drive_mode=_abi.DOF_MODE_EFFORT)
+    m = cm.blob
+    sp = H.sim_params()
+    q, qd, _ = _rand_state(m, rng, 2.0)
+    tau = rng.uniform(-50, 50, m.nd)
+    dof = np.stack([q, qd], 1).reshape(-1)
+    root = np.array([0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0], float)
+    qdd, _ = oracle.accel(m, sp, dof, root, tau, f64=True)
+    tau_ne, _, _ = H.newton_euler(m, q, qd, qdd, root[:3], root[3:7], np.zeros(3), np.zeros(3), np.zeros(3),
+                                  np.zeros(3), sp.gravity[:])
+    assert np.allclose(tau_ne, tau, rtol=0, atol=1e-8)
+
+
+def test_free_fall_is_exact(oracle):
+    """Ballistic root: semi-implicit Euler gives v = g t, z = z0 + g dt^2 n(n+1)/2."""
+    cm = H.a1_model()
+    m = cm.blob
+    sp = H.sim_params(dt=0.005)
+    n = 100
+    dof = np.zeros((m.nd, 2)); root = np.zeros((1, 13)); root[0, 2] = 1000.0; root[0, 6] = 1.0
+    for d in range(m.nd):
+        m.lower[d], m.upper[d] = -1e3, 1e3
+    oracle.step(m, sp, 1, dof, root, nsteps=n, f64=True)
+    g, dt = float(sp.gravity[2]), float(sp.dt)  # the params are float32 fields
+    assert abs(root[0, 9] - g * dt * n) < 1e-9
+    assert abs(root[0, 2] - (1000.0 + g * dt ** 2 * n * (n + 1) / 2)) < 1e-8
+    # zero effort in free fall: no gravity torque in the falling frame
+    assert np.abs(dof).max() < 1e-9
+
+
+def test_momentum_and_energy_conservation_in_flight(oracle):
+    """Flight phase: momentum changes by m g t, CoM angular momentum and energy are
+    conserved.  Semi-implicit Euler is first order, so the residuals must be small
+    AND halve when dt halves (that separates integrator error from a dynamics bug)."""
+    cm = H.a1_model()
+    m = cm.blob
+    for d in range(m.nd):  # keep joints off their limits: the KAT is for the smooth dynamics
+        m.lower[d], m.upper[d] = -1e3, 1e3
+    g = (0.0, 0.0, -9.81)
+    res = []
+    for dt, n in ((2e-4, 2000), (1e-4, 4000)):
+        sp = H.sim_params(dt=dt, gravity=g)
+        rng = np.random.default_rng(7)
+        q, qd, quat = _rand_state(m, rng, 2.0)
+        lin, ang = rng.uniform(-1, 1, 3), rng.uniform(-2, 2, 3)
+        dof = np.stack([q, qd], 1).copy()
+        root = np.concatenate([[0, 0, 500.0], quat, lin, ang])[None].copy()
+        E0, P0, L0, C0 = H.mechanical_state(m, q, qd, root[0, :3], quat, lin, ang, g)
+        oracle.step(m, sp, 1, dof, root, nsteps=n, f64=True)
+        E1, P1, L1, C1 = H.mechanical_state(m, dof[:, 0], dof[:, 1], root[0, :3], root[0, 3:7], root[0, 7:10],
+                                            root[0, 10:13], g)
+        t = n * float(sp.dt)
+        dP = P1 - P0 - cm.total_mass * np.array([0, 0, float(sp.gravity[2])]) * t
+        dL = (L1 - np.cross(C1, P1)) - (L0 - np.cross(C0, P0))
+        res.append((np.abs(dP).max(), abs(E1 - E0) / abs(E0), np.abs(dL).max()))
+    (p1, e1, l1), (p2, e2, l2) = res
+    assert p1 < 5e-4 and e1 < 1e-5 and l1 < 5e-4
+    for coarse, fine in ((p1, p2), (e1, e2), (l1, l2)):
+        assert 0.4 < fine / coarse < 0.6
+
+
+def test_pendulum_small_oscillation_period(oracle):
+    L, mass, I = 0.5, 2.0, 0.01
+    cm = H.pendulum_model(L, mass, I)
+    m = cm.blob
+    sp = H.sim_params(dt=1e-4)
+    dof = np.array([[0.01, 0.0]]); root = np.array([[0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0]], float)
+    period = 2 * np.pi * np.sqrt((I + mass * L * L) / (mass * 9.81 * L))
+    n = int(round(period / sp.dt))
+    oracle.step(m, sp, 1, dof, root, nsteps=n, f64=True)
+    assert abs(dof[0, 0] - 0.01) < 2e-5 and abs(dof[0, 1]) < 2e-3
+
+
+def test_float32_tracks_float64_one_step(oracle):
+    cm = H.a1_model()
+    m = cm.blob
+    sp = H.sim_params()
+    rng = np.random.default_rng(3)
+    n = 32
+    dof64 = np.zeros((n * m.nd, 2)); root64 = np.zeros((n, 13)); eff = rng.uniform(-20, 20, n * m.nd)
+    for e in range(n):
+        q, qd, quat = _rand_state(m, rng)
+        dof64[e * m.nd:(e + 1) * m.nd, 0] = q; dof64[e * m.nd:(e + 1) * m.nd, 1] = qd
+        root64[e] = np.concatenate([[0, 0, 5.0], quat, rng.uniform(-1, 1, 3), rng.uniform(-2, 2, 3)])
+    dof32, root32, eff32 = dof64.astype(np.float32), root64.astype(np.float32), eff.astype(np.float32)
+    dof64 = dof32.astype(np.float64); root64 = root32.astype(np.float64)
+    oracle.step(m, sp, n, dof64, root64, effort=eff32.astype(np.float64), f64=True)
+    oracle.step(m, sp, n, dof32, root32, effort=eff32, f64=False)
+    assert np.allclose(dof32, dof64, rtol=2e-4, atol=2e-4)
+    assert np.allclose(root32, root64, rtol=1e-4, atol=1e-4)
+
+
+def test_a1_stands_on_plane_under_pd(oracle):
+    """A1 dropped from its spawn height under the example's PD gains settles; the
+    feet carry the weight (12.454 kg * g, masses from a1.urdf)."""
+    cm = H.a1_model()
+    m = cm.blob
+    sp = H.sim_params()
+    q0 = np.array([0.1, 0.8, -1.5, 0.1, 0.8, -1.5, -0.1, 0.8, -1.5, -0.1, 0.8, -1.5], np.float32)
+    dof = np.zeros((m.nd, 2), np.float32); dof[:, 0] = q0
+    root = np.zeros((1, 13), np.float32); root[0, 2] = 0.42; root[0, 6] = 1
+    fr = np.array([1.0], np.float32)
+    lim = np.array(m.effort[:m.nd], np.float32)
+    contact = None
+    for it in range(600):
+        tau = np.clip(20 * (q0 - dof[:, 0]) - 0.5 * dof[:, 1], -lim, lim).astype(np.float32)
+        contact, _ = oracle.step(m, sp, 1, dof, root, effort=tau, friction=fr, want_contact=True)
+    assert np.isfinite(root).all() and np.isfinite(dof).all()
+    assert 0.2 < root[0, 2] < 0.42
+    assert np.abs(root[0, 7:]).max() < 0.05 and np.abs(dof[:, 1]).max() < 0.2
+    total_fz = contact[:, 2].sum()
+    assert abs(total_fz - cm.total_mass * 9.81) / (cm.total_mass * 9.81) < 0.02
+    feet = [cm.rigid_body_dict[n] for n in ("FL_foot", "FR_foot", "RL_foot", "RR_foot")]
+    assert contact[feet, 2].sum() > 0.95 * total_fz
+    assert np.linalg.norm(contact[cm.rigid_body_dict["base"]]) == 0.0
+
+
+def test_spec_sincos_exp_accuracy(oracle):
+    x = np.linspace(-7, 7, 20001).astype(np.float32)
+    s, c = oracle.sincos(x)
+    assert np.abs(s - np.sin(x.astype(np.float64))).max() < 3e-7
+    assert np.abs(c - np.cos(x.astype(np.float64))).max() < 3e-7
+    y = np.linspace(-30, 0, 20001).astype(np.float32)
+    e = oracle.exp(y)
+    ref = np.exp(y.astype(np.float64))
+    assert (np.abs(e - ref) / ref).max() < 3e-7
