@@ -52,13 +52,14 @@ typedef struct ShfModel {
   int32_t fixed_base; /* AssetOptions.fix_base_link                        */
   int32_t gravity_on; /* !AssetOptions.disable_gravity                     */
   int32_t nsph;       /* spheres tested against box actors                 */
-  int32_t pad0;
+  int32_t nklevels;   /* max kinematic depth (welded bodies count)         */
 
   int32_t parent[SHF_MAX_BODIES]; /* reported parent, -1 for the root      */
   int32_t jtype[SHF_MAX_BODIES];
   int32_t dof[SHF_MAX_BODIES];   /* dof index, -1 if none                  */
   int32_t level[SHF_MAX_BODIES]; /* depth among moving bodies (root = 0)   */
   int32_t dyn[SHF_MAX_BODIES];   /* moving body that carries my inertia    */
+  int32_t klevel[SHF_MAX_BODIES]; /* kinematic depth: parent's + 1         */
   int32_t child_start[SHF_MAX_BODIES];
   int32_t child_count[SHF_MAX_BODIES];
   int32_t child_list[SHF_MAX_BODIES]; /* moving children, summed in this order */
@@ -144,7 +145,7 @@ enum {
   SHF_T_FRICTION = 11,   /* (N) f32      per-env shape friction (a1_conditional.py:28-31)  */
   SHF_T_HEIGHTS = 12,    /* (rows*cols) i16 height samples (isaac_gym.py:349-367)          */
   SHF_T_MODEL = 13,      /* sizeof(ShfModel) bytes, device copy                            */
-  SHF_T_FORCE_ARMED = 14,/* (1) i32: body forces are consumed by the next step only        */
+  SHF_T_SIM_CONTACT = 14,/* (N*B, 3) f32 internal net contact force of the last step        */
   SHF_T_COUNT = 15
 };
 
@@ -185,7 +186,11 @@ int shf_sim_layout(const ShfSim* sim, int32_t id, int64_t shape[4], int32_t* ndi
 int shf_sim_bind(ShfSim* sim, int32_t id, void* device_ptr);
 /* Writes every exposed tensor from the default poses (after create_actor the
  * reference sees spawn poses in root_state: units.py:57-70; Q14 fixed). */
-int shf_sim_reset_all(ShfSim* sim, const float* env_origins_dev, void* stream);
+int shf_sim_reset_all(ShfSim* sim, const float* default_root_dev /* (A,13) */, const float* default_dof_dev /* (nd) */,
+                      const float* env_origins_dev /* (N,3) or NULL */, void* stream);
+/* Lanes per env for the kernels (64 = one wavefront per env, default; 32/16 pack
+ * 2/4 envs per wavefront).  Not part of the reference API: a tuning knob. */
+int shf_sim_set_group(ShfSim* sim, int32_t lanes);
 
 /* gym.simulate (a1_conditional.py:69, robot.py:69, isaac_gym.py:140) */
 int shf_sim_step(ShfSim* sim, void* stream);
@@ -266,7 +271,8 @@ enum {
   SHF_A1_RESET_COUNT = 18, /* (N) i32 per-env episode counter (RNG counter)        */
   SHF_A1_DONE_SUMS = 19, /* (8,N) f32 per-env finished-episode sums (6 terms, level, 1) */
   SHF_A1_STATS = 20,     /* (R,16) f32 ring of per-step reductions                 */
-  SHF_A1_COUNT = 21
+  SHF_A1_PARAMS = 21,    /* sizeof(ShfA1TaskParams) bytes, device copy             */
+  SHF_A1_COUNT = 22
 };
 
 typedef struct ShfA1Task ShfA1Task;

@@ -92,3 +92,41 @@ def terrain_query(terrain, heights, xy, f64=False):
     fn = lib().shf_oracle_terrain_query_f64 if f64 else lib().shf_oracle_terrain_query_f32
     fn(C.byref(terrain), _p(heights, C.c_int16), C.c_int(n), _p(xy, ct), _p(h, ct), _p(nrm, ct))
     return h, nrm
+
+
+class A1Buffers(C.Structure):
+    """Mirror of ShfOracleA1Buffers (oracle/shf_oracle.c)."""
+    _F = C.POINTER(C.c_float)
+    _fields_ = [("dof_state", _F), ("root_state", _F), ("body_state", _F), ("contact", _F), ("friction", _F),
+                ("actions", _F), ("obs", _F), ("rew", _F),
+                ("reset", C.POINTER(C.c_uint8)), ("timeout", C.POINTER(C.c_uint8)), ("ep_len", C.POINTER(C.c_int64)),
+                ("command", _F), ("history", _F), ("rew_sums", _F), ("torques", _F), ("base_vel", _F), ("heights", _F),
+                ("hpoints", _F), ("push", _F), ("origins", _F),
+                ("levels", C.POINTER(C.c_int64)), ("types", C.POINTER(C.c_int64)), ("torigins", _F),
+                ("reset_count", C.POINTER(C.c_int32)), ("done_sums", _F)]
+
+
+A1_FIELDS = [f[0] for f in A1Buffers._fields_]
+
+
+def a1_step(model, params, task_params, n, env_id_offset, bufs: dict, raw_actions, terrain=None, heights=None,
+            nthreads=1):
+    """One fused A1Conditional env step on NumPy buffers (dict keyed by A1_FIELDS), in place."""
+    B = A1Buffers()
+    for name, ctype in A1Buffers._fields_:
+        a = bufs[name]
+        assert a.flags.c_contiguous, name
+        setattr(B, name, a.ctypes.data_as(ctype))
+    raw = np.ascontiguousarray(raw_actions, np.float32)
+    fn = lib().shf_oracle_a1_step_f32
+    fn.restype = None
+    fn(C.byref(model), C.byref(params), C.byref(terrain) if terrain is not None else None, _p(heights, C.c_int16),
+       C.byref(task_params), C.c_int(n), C.c_int64(env_id_offset), C.byref(B), _p(raw, C.c_float), C.c_int(nthreads))
+
+
+def a1_stats(task_params, n, done_sums):
+    out = np.zeros(16, np.float32)
+    fn = lib().shf_oracle_a1_stats_f32
+    fn.restype = None
+    fn(C.byref(task_params), C.c_int(n), _p(done_sums, C.c_float), _p(out, C.c_float))
+    return out

@@ -18,9 +18,9 @@ f32 = C.c_float
 class ShfModel(C.Structure):
     _fields_ = [
         ("nb", i32), ("nd", i32), ("np", i32), ("nlevels", i32),
-        ("fixed_base", i32), ("gravity_on", i32), ("nsph", i32), ("pad0", i32),
+        ("fixed_base", i32), ("gravity_on", i32), ("nsph", i32), ("nklevels", i32),
         ("parent", i32 * MAX_BODIES), ("jtype", i32 * MAX_BODIES), ("dof", i32 * MAX_BODIES),
-        ("level", i32 * MAX_BODIES), ("dyn", i32 * MAX_BODIES),
+        ("level", i32 * MAX_BODIES), ("dyn", i32 * MAX_BODIES), ("klevel", i32 * MAX_BODIES),
         ("child_start", i32 * MAX_BODIES), ("child_count", i32 * MAX_BODIES), ("child_list", i32 * MAX_BODIES),
         ("pt_start", i32 * MAX_BODIES), ("pt_count", i32 * MAX_BODIES),
         ("tpos", (f32 * 3) * MAX_BODIES), ("trot", (f32 * 9) * MAX_BODIES), ("axis", (f32 * 3) * MAX_BODIES),
@@ -65,13 +65,13 @@ class ShfA1TaskParams(C.Structure):
 
 # tensor ids (shf_sim_*)
 T_DOF_STATE, T_ROOT_STATE, T_BODY_STATE, T_CONTACT, T_JACOBIAN, T_SIM_DOF, T_SIM_ROOT, T_EFFORT, \
-    T_POS_TARGET, T_VEL_TARGET, T_BODY_FORCE, T_FRICTION, T_HEIGHTS, T_MODEL, T_FORCE_ARMED, T_COUNT = range(16)
+    T_POS_TARGET, T_VEL_TARGET, T_BODY_FORCE, T_FRICTION, T_HEIGHTS, T_MODEL, T_SIM_CONTACT, T_COUNT = range(16)
 
 REFRESH_DOF, REFRESH_ROOT, REFRESH_BODY, REFRESH_CONTACT, REFRESH_JACOBIAN, REFRESH_ALL = 1, 2, 4, 8, 16, 31
 
 # tensor ids (shf_a1_*)
 (A1_ACTIONS, A1_OBS, A1_REW, A1_RESET, A1_TIMEOUT, A1_EP_LEN, A1_COMMAND, A1_HISTORY, A1_REW_SUMS, A1_TORQUES,
  A1_BASE_VEL, A1_HEIGHTS, A1_HPOINTS, A1_PUSH, A1_ORIGINS, A1_LEVELS, A1_TYPES, A1_TORIGINS, A1_RESET_COUNT,
- A1_DONE_SUMS, A1_STATS, A1_COUNT) = range(22)
+ A1_DONE_SUMS, A1_STATS, A1_PARAMS, A1_COUNT) = range(23)
 
 DTYPE_F32, DTYPE_I32, DTYPE_I16, DTYPE_U8, DTYPE_I64 = range(5)

@@ -1,0 +1,69 @@
+"""ctypes binding of include/shifu_amd.h.  There is no CPU fallback: if the HIP
+library is missing this module raises, and so does everything built on it."""
+import ctypes as C
+import os
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "libshifu_amd.so")
+_lib = None
+
+vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+_SIGS = {
+    "shf_abi_version": ([], i32),
+    "shf_sim_create": ([C.POINTER(_abi.ShfSimParams), C.POINTER(vp)], i32),
+    "shf_sim_destroy": ([vp], i32),
+    "shf_sim_set_terrain": ([vp, C.POINTER(_abi.ShfTerrain)], i32),
+    "shf_sim_set_articulation": ([vp, C.POINTER(_abi.ShfModel)], i32),
+    "shf_sim_add_box": ([vp, C.POINTER(_abi.ShfBoxDesc)], i32),
+    "shf_sim_finalize": ([vp, i32, i64], i32),
+    "shf_sim_set_group": ([vp, i32], i32),
+    "shf_sim_layout": ([vp, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)], i32),
+    "shf_sim_bind": ([vp, i32, vp], i32),
+    "shf_sim_reset_all": ([vp, vp, vp, vp, vp], i32),
+    "shf_sim_step": ([vp, vp], i32),
+    "shf_sim_refresh": ([vp, i32, vp], i32),
+    "shf_sim_set_dof_command": ([vp, i32, vp, vp], i32),
+    "shf_sim_set_pos_target_indexed": ([vp, vp, vp, i32, vp], i32),
+    "shf_sim_apply_body_force": ([vp, vp, vp], i32),
+    "shf_sim_commit_root_indexed": ([vp, vp, vp, i32, vp], i32),
+    "shf_sim_commit_root_all": ([vp, vp, vp], i32),
+    "shf_sim_commit_dof_indexed": ([vp, vp, vp, i32, vp], i32),
+    "shf_a1_create": ([vp, C.POINTER(_abi.ShfA1TaskParams), C.POINTER(vp)], i32),
+    "shf_a1_destroy": ([vp], i32),
+    "shf_a1_layout": ([vp, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)], i32),
+    "shf_a1_bind": ([vp, i32, vp], i32),
+    "shf_a1_step": ([vp, vp, i64, vp], i32),
+    "shf_a1_reset_all": ([vp, vp], i32),
+}
+EXPORTS = sorted(list(_SIGS) + ["shf_last_error"])
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded HIP library.  torch is imported first so that the HIP runtime
+    already in the process (torch's bundled libamdhip64.so.7) is the one used."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_PATH):
+            raise BackendError(f"{_PATH} is missing: build it with `python -m shifu_amd.build` "
+                               "(there is no CPU fallback for the MI355X backend)")
+        import torch  # noqa: F401  (loads the process-wide HIP runtime)
+        l = C.CDLL(_PATH)
+        for name, (args, res) in _SIGS.items():
+            f = getattr(l, name)
+            f.argtypes, f.restype = args, res
+        l.shf_last_error.restype = C.c_char_p
+        if l.shf_abi_version() != _abi.SHF_ABI_VERSION:
+            raise BackendError("libshifu_amd.so ABI version mismatch: rebuild")
+        _lib = l
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise BackendError(lib().shf_last_error().decode())

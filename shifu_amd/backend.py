@@ -1,0 +1,220 @@
+"""Host-side owner of one simulation: allocates every device buffer with torch,
+binds it to the C-ABI library and exposes the launches.  This is the layer the
+`gym` facade (shifu_amd/isaacgym/gymapi.py) and the fused A1 env sit on.
+
+PyTorch is plumbing here (device memory, current stream); all arithmetic happens
+in the HIP kernels behind include/shifu_amd.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._lib import check, lib
+
+_TORCH_DTYPE = {_abi.DTYPE_F32: torch.float32, _abi.DTYPE_I32: torch.int32, _abi.DTYPE_I16: torch.int16,
+                _abi.DTYPE_U8: torch.uint8, _abi.DTYPE_I64: torch.int64}
+
+
+def default_sim_params(dt: float = 0.005, gravity=(0.0, 0.0, -9.81), **kw) -> _abi.ShfSimParams:
+    p = _abi.ShfSimParams()
+    p.dt = dt
+    p.gravity[:] = gravity
+    p.contact_k = kw.get("contact_k", 5e4)
+    p.contact_d = kw.get("contact_d", 100.0)
+    p.friction_vel = kw.get("friction_vel", 0.02)
+    p.limit_k = kw.get("limit_k", 2000.0)
+    p.limit_d = kw.get("limit_d", 20.0)
+    p.angular_damping = kw.get("angular_damping", 0.5)  # AssetOptions default [EXT]
+    p.max_ang_vel = kw.get("max_ang_vel", 64.0)          # AssetOptions default [EXT]
+    p.max_depen_vel = kw.get("max_depen_vel", 1.0)       # env_config.py:57
+    return p
+
+
+def _stream_ptr(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _struct_to_device(s, device) -> torch.Tensor:
+    return torch.frombuffer(bytearray(bytes(s)), dtype=torch.uint8).to(device)
+
+
+class Sim:
+    """One `gym.create_sim` worth of state on one GPU."""
+
+    def __init__(self, params: _abi.ShfSimParams, device="cuda:0"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("shifu_amd.backend.Sim runs on an MI355X only (device must be cuda:N); "
+                               "there is no CPU fallback")
+        self.params = params
+        self._h = C.c_void_p()
+        check(lib().shf_sim_create(C.byref(params), C.byref(self._h)))
+        self.tensors: Dict[int, torch.Tensor] = {}
+        self.model: Optional[_abi.ShfModel] = None
+        self.terrain = _abi.ShfTerrain()
+        self.terrain.friction = 1.0
+        self.num_envs = 0
+        self.nboxes = 0
+        self._heights: Optional[torch.Tensor] = None
+
+    # -- construction -------------------------------------------------------
+    def set_plane(self, friction: float = 1.0):
+        t = _abi.ShfTerrain()
+        t.rows = t.cols = 0
+        t.hscale, t.vscale, t.border, t.friction = 1.0, 1.0, 0.0, friction
+        self.terrain = t
+        check(lib().shf_sim_set_terrain(self._h, C.byref(t)))
+
+    def set_heightfield(self, samples: np.ndarray, hscale: float, vscale: float, border: float, friction: float):
+        assert samples.dtype == np.int16 and samples.ndim == 2
+        t = _abi.ShfTerrain()
+        t.rows, t.cols = samples.shape
+        t.hscale, t.vscale, t.border, t.friction = hscale, vscale, border, friction
+        self.terrain = t
+        self._heights = torch.from_numpy(np.ascontiguousarray(samples)).to(self.device)
+        check(lib().shf_sim_set_terrain(self._h, C.byref(t)))
+
+    def set_articulation(self, model: _abi.ShfModel):
+        self.model = model
+        check(lib().shf_sim_set_articulation(self._h, C.byref(model)))
+
+    def add_box(self, box: _abi.ShfBoxDesc):
+        check(lib().shf_sim_add_box(self._h, C.byref(box)))
+        self.nboxes += 1
+
+    def layout(self, tid: int):
+        shape = (C.c_int64 * 4)()
+        nd, dt = C.c_int32(), C.c_int32()
+        check(lib().shf_sim_layout(self._h, tid, shape, C.byref(nd), C.byref(dt)))
+        return tuple(shape[:nd.value]), _TORCH_DTYPE[dt.value]
+
+    def bind(self, tid: int, t: torch.Tensor):
+        assert t.is_contiguous() and t.device == self.device
+        self.tensors[tid] = t
+        check(lib().shf_sim_bind(self._h, tid, C.c_void_p(t.data_ptr())))
+
+    def finalize(self, num_envs: int, env_id_offset: int = 0, group: int = 64):
+        self.num_envs = num_envs
+        check(lib().shf_sim_finalize(self._h, num_envs, env_id_offset))
+        if group != 64:
+            check(lib().shf_sim_set_group(self._h, group))
+        for tid in range(_abi.T_COUNT):
+            if tid == _abi.T_HEIGHTS:
+                if self._heights is not None:
+                    self.bind(tid, self._heights)
+                continue
+            if tid == _abi.T_MODEL:
+                self.bind(tid, _struct_to_device(self.model, self.device))
+                continue
+            shape, dt = self.layout(tid)
+            t = torch.zeros(shape, dtype=dt, device=self.device)
+            if tid == _abi.T_FRICTION:
+                t.fill_(1.0)
+            self.bind(tid, t)
+
+    # -- launches -----------------------------------------------------------
+    def step(self):
+        check(lib().shf_sim_step(self._h, _stream_ptr(self.device)))
+
+    def refresh(self, mask: int = _abi.REFRESH_ALL):
+        check(lib().shf_sim_refresh(self._h, mask, _stream_ptr(self.device)))
+
+    def set_dof_command(self, tid: int, values: torch.Tensor):
+        v = values.contiguous()
+        assert v.dtype == torch.float32 and v.numel() == self.num_envs * self.model.nd
+        check(lib().shf_sim_set_dof_command(self._h, tid, C.c_void_p(v.data_ptr()), _stream_ptr(self.device)))
+
+    def set_pos_target_indexed(self, values: torch.Tensor, idx: torch.Tensor):
+        assert idx.dtype == torch.int32
+        check(lib().shf_sim_set_pos_target_indexed(self._h, C.c_void_p(values.data_ptr()), C.c_void_p(idx.data_ptr()),
+                                                   idx.numel(), _stream_ptr(self.device)))
+
+    def apply_body_force(self, force: torch.Tensor):
+        f = force.contiguous()
+        check(lib().shf_sim_apply_body_force(self._h, C.c_void_p(f.data_ptr()), _stream_ptr(self.device)))
+
+    def commit_root_indexed(self, root: torch.Tensor, idx: torch.Tensor):
+        assert idx.dtype == torch.int32 and root.is_contiguous()
+        check(lib().shf_sim_commit_root_indexed(self._h, C.c_void_p(root.data_ptr()), C.c_void_p(idx.data_ptr()),
+                                                idx.numel(), _stream_ptr(self.device)))
+
+    def commit_root_all(self, root: torch.Tensor):
+        check(lib().shf_sim_commit_root_all(self._h, C.c_void_p(root.data_ptr()), _stream_ptr(self.device)))
+
+    def commit_dof_indexed(self, dof: torch.Tensor, idx: torch.Tensor):
+        assert idx.dtype == torch.int32 and dof.is_contiguous()
+        check(lib().shf_sim_commit_dof_indexed(self._h, C.c_void_p(dof.data_ptr()), C.c_void_p(idx.data_ptr()),
+                                               idx.numel(), _stream_ptr(self.device)))
+
+    def reset_all(self, default_root: torch.Tensor, default_dof: torch.Tensor, origins: Optional[torch.Tensor]):
+        check(lib().shf_sim_reset_all(self._h, C.c_void_p(default_root.data_ptr()), C.c_void_p(default_dof.data_ptr()),
+                                      C.c_void_p(origins.data_ptr()) if origins is not None else None,
+                                      _stream_ptr(self.device)))
+
+    def destroy(self):
+        if self._h:
+            lib().shf_sim_destroy(self._h)
+            self._h = C.c_void_p()
+        self.tensors.clear()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class A1Task:
+    """The fused A1Conditional env step (shf_a1_*)."""
+
+    def __init__(self, sim: Sim, params: _abi.ShfA1TaskParams):
+        self.sim = sim
+        self.params = params
+        self._h = C.c_void_p()
+        check(lib().shf_a1_create(sim._h, C.byref(params), C.byref(self._h)))
+        self.tensors: Dict[int, torch.Tensor] = {}
+        self.step_index = 0
+        for tid in range(_abi.A1_COUNT):
+            if tid == _abi.A1_PARAMS:
+                self.bind(tid, _struct_to_device(params, sim.device))
+                continue
+            shape, dt = self.layout(tid)
+            self.bind(tid, torch.zeros(shape, dtype=dt, device=sim.device))
+
+    def layout(self, tid: int):
+        shape = (C.c_int64 * 4)()
+        nd, dt = C.c_int32(), C.c_int32()
+        check(lib().shf_a1_layout(self._h, tid, shape, C.byref(nd), C.byref(dt)))
+        return tuple(shape[:nd.value]), _TORCH_DTYPE[dt.value]
+
+    def bind(self, tid: int, t: torch.Tensor):
+        assert t.is_contiguous()
+        self.tensors[tid] = t
+        check(lib().shf_a1_bind(self._h, tid, C.c_void_p(t.data_ptr())))
+
+    def step(self, raw_actions: torch.Tensor) -> int:
+        a = raw_actions.contiguous()
+        assert a.dtype == torch.float32 and a.shape == (self.sim.num_envs, self.sim.model.nd)
+        idx = self.step_index
+        check(lib().shf_a1_step(self._h, C.c_void_p(a.data_ptr()), idx, _stream_ptr(self.sim.device)))
+        self.step_index += 1
+        return idx % self.tensors[_abi.A1_STATS].shape[0]
+
+    def reset_all(self):
+        check(lib().shf_a1_reset_all(self._h, _stream_ptr(self.sim.device)))
+
+    def destroy(self):
+        if self._h:
+            lib().shf_a1_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -1,0 +1,42 @@
+"""Builds the HIP library in-tree: shifu_amd/libshifu_amd.so (gfx950 only).
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off / no fast-math are part of
+the arithmetic contract documented in csrc/shf_device.h.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libshifu_amd.so")
+SOURCES = ["shf_api.hip"]
+DEPS = ["shf_api.hip", "shf_device.h", os.path.join("..", "..", "include", "shifu_amd.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared"]
+
+
+def hipcc() -> str:
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the MI355X backend cannot be built")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    if force or needs_build():
+        cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_native(force=True, verbose=True))

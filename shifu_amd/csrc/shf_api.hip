@@ -1,0 +1,836 @@
+// shf_api.hip -- kernels and the C-ABI entry points of include/shifu_amd.h.
+//
+// The library owns no device memory: every buffer is bound by the host
+// (shf_sim_bind / shf_a1_bind), kernels are launched on the stream handed in
+// and nothing here synchronises.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <initializer_list>
+#include <string>
+
+#include "shf_device.h"
+
+// ------------------------------------------------------------ host state --
+static thread_local std::string g_err;
+static int fail(const std::string& msg) { g_err = msg; return 1; }
+#define HIP_OK(call)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess) return fail(std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+struct ShfSim {
+  ShfSimParams sp;
+  ShfTerrain terr;
+  ShfModel model;
+  bool has_model = false;
+  int nboxes = 0;
+  ShfBoxDesc boxes[SHF_MAX_BOXES];
+  int32_t n = 0;
+  int64_t env_off = 0;
+  bool finalized = false;
+  bool force_armed = false;
+  void* t[SHF_T_COUNT] = {};
+  int group = 64;  // lanes per env
+};
+
+struct ShfA1Task {
+  ShfSim* sim;
+  ShfA1TaskParams tp;
+  void* t[SHF_A1_COUNT] = {};
+  int stats_ring = 256;
+};
+
+extern "C" const char* shf_last_error(void) { return g_err.c_str(); }
+extern "C" int shf_abi_version(void) { return SHF_ABI_VERSION; }
+
+// ---------------------------------------------------------------- kernels --
+struct SimArgs {
+  ShfSimParams sp;
+  ShfTerrain terr;
+  const int16_t* heights;
+  const ShfModel* model;  // device copy
+  int n;
+  float* dof;            // (n*nd,2)
+  float* root;           // (n*A,13)
+  int actors;            // root rows per env
+  const float* effort;
+  const float* pos_tgt;
+  const float* vel_tgt;
+  const float* body_force;  // nullptr unless armed
+  const float* friction;
+  float* contact;  // (n*B,3)
+};
+
+// cooperative copy of the flattened articulation into LDS
+DEV const ShfModel* stage_model(const ShfModel* gm, float* smem) {
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(gm);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
+  for (int i = threadIdx.x; i < (int)(sizeof(ShfModel) / 4); i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
+  return reinterpret_cast<const ShfModel*>(smem);
+}
+#define MODEL_WORDS ((int)((sizeof(ShfModel) / 4 + 3) & ~3))
+#define TASK_WORDS ((int)((sizeof(ShfA1TaskParams) / 4 + 3) & ~3))
+
+// gym.simulate: one sub-step for every env
+template <int G>
+__global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const ShfModel* m = stage_model(A.model, smem);
+  const int epb = 256 / G, es = threadIdx.x / G, l = threadIdx.x % G;
+  const int e = blockIdx.x * epb + es;
+  if (e >= A.n) return;
+  const int nb = m->nb, nd = m->nd, np = m->np;
+  EnvLds L = env_lds_carve(smem + MODEL_WORDS + es * env_lds_words(nb, nd, np), nb, nd, np);
+  float* dof = A.dof + (size_t)e * nd * 2;
+  float* root = A.root + (size_t)e * A.actors * 13;
+  if (l < 2 * nd) L.dofb[(l >> 1) * DOF_STRIDE + (l & 1)] = dof[l];
+  for (int i = l + G; i < 2 * nd; i += G) L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)] = dof[i];
+  if (l < 13) L.root[l] = root[l];
+  if (l < nd) L.dofb[l * DOF_STRIDE + 5] = A.effort ? A.effort[(size_t)e * nd + l] : 0.0f;
+  GROUP_SYNC();
+  StepCtx C;
+  C.m = m; C.sp = A.sp; C.terr.t = A.terr; C.terr.h = A.heights;
+  const float mu = A.friction ? A.friction[e] : 1.0f;
+  substep<G>(C, L, l, A.pos_tgt ? A.pos_tgt + (size_t)e * nd : nullptr, A.vel_tgt ? A.vel_tgt + (size_t)e * nd : nullptr,
+             A.body_force ? A.body_force + (size_t)e * nb * 3 : nullptr, mu, L.xch);
+  GROUP_SYNC();
+  for (int i = l; i < 2 * nd; i += G) dof[i] = L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)];
+  if (l < 13) root[l] = L.root[l];
+  for (int i = l; i < 3 * nb; i += G) A.contact[(size_t)e * nb * 3 + i] = L.xch[i];
+}
+
+// gym.refresh_rigid_body_state_tensor
+template <int G>
+__global__ __launch_bounds__(256) void k_body_state(const ShfModel* gm, int n, const float* dof, const float* root,
+                                                    int actors, float* body_state) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const ShfModel* m = stage_model(gm, smem);
+  const int epb = 256 / G, es = threadIdx.x / G, l = threadIdx.x % G;
+  const int e = blockIdx.x * epb + es;
+  if (e >= n) return;
+  const int nb = m->nb, nd = m->nd, np = m->np;
+  EnvLds L = env_lds_carve(smem + MODEL_WORDS + es * env_lds_words(nb, nd, np), nb, nd, np);
+  for (int i = l; i < 2 * nd; i += G) L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)] = dof[(size_t)e * nd * 2 + i];
+  if (l < 13) L.root[l] = root[(size_t)e * actors * 13 + l];
+  GROUP_SYNC();
+  body_states<G>(m, L, l, L.xch);
+  for (int i = l; i < 13 * nb; i += G) body_state[(size_t)e * nb * 13 + i] = L.xch[i];
+}
+
+__global__ void k_commit_rows(const float* src, float* dst, const int32_t* idx, int n, int row_words, int idx_div,
+                              int rows_per_idx_words) {
+  // one block row per index entry: copies `rows_per_idx_words` floats of row (idx/idx_div)
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  const size_t r = (size_t)(idx[i] / idx_div) * row_words;
+  for (int k = threadIdx.x; k < rows_per_idx_words; k += blockDim.x) dst[r + k] = src[r + k];
+}
+
+__global__ void k_reset_all(const ShfModel* gm, int n, int actors, const float* default_root, const float* default_dof,
+                            const float* origins, float* dof_a, float* dof_b, float* root_a, float* root_b) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int nd = gm->nd;
+  for (int d = 0; d < nd; d++) {
+    const size_t o = ((size_t)e * nd + d) * 2;
+    dof_a[o] = default_dof[d]; dof_a[o + 1] = 0.0f;
+    dof_b[o] = default_dof[d]; dof_b[o + 1] = 0.0f;
+  }
+  for (int a = 0; a < actors; a++) {
+    const size_t o = ((size_t)e * actors + a) * 13;
+    for (int k = 0; k < 13; k++) {
+      float v = default_root[a * 13 + k];
+      if (k < 3 && origins) v += origins[(size_t)e * 3 + k];
+      root_a[o + k] = v; root_b[o + k] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------- fused A1 step --
+struct A1Args {
+  SimArgs S;
+  const ShfA1TaskParams* tp;  // device copy
+  int64_t env_off;
+  const float* raw_actions;
+  float *actions, *obs, *rew;
+  uint8_t *reset, *timeout;
+  int64_t* ep_len;
+  float *command, *history, *rew_sums, *torques, *base_vel, *heights_out;
+  const float* hpoints;
+  float *push, *origins;
+  int64_t* levels;
+  const int64_t* types;
+  const float* torigins;
+  int32_t* reset_count;
+  float* done_sums;
+  float* body_state;
+};
+
+DEV void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1,
+                   n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+DEV float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
+DEV float urange(uint32_t x, float lo, float hi) { return (hi - lo) * u01(x) + lo; }
+DEV void quat_rotate_inverse(const float* q, const float* v, float* o) {
+  const float w = q[3];
+  const float s = 2.0f * (w * w) - 1.0f;
+  const float cx = q[1] * v[2] - q[2] * v[1], cy = q[2] * v[0] - q[0] * v[2], cz = q[0] * v[1] - q[1] * v[0];
+  const float d = q[0] * v[0] + q[1] * v[1] + q[2] * v[2];
+  o[0] = v[0] * s - cx * w * 2.0f + q[0] * d * 2.0f;
+  o[1] = v[1] * s - cy * w * 2.0f + q[1] * d * 2.0f;
+  o[2] = v[2] * s - cz * w * 2.0f + q[2] * d * 2.0f;
+}
+
+// Everything random or curriculum-dependent about one env's reset
+// (a1_conditional.py:204-221 curriculum, :43-50 spawn, :82-87 push, :194-200 command).
+struct ResetOut {
+  float root[13], cmd[3], push[3], org[3];
+  int64_t level;
+};
+DEV void a1_reset_draw(const ShfA1TaskParams& tp, int64_t gid, uint32_t cnt, const float* root_pos, const float* cmd_old,
+                       const float* org_old, int64_t level, int64_t type, const float* torigins, ResetOut& R) {
+  uint32_t r0[4], r1[4], r2[4];
+  const uint32_t k0 = (uint32_t)tp.seed, k1 = (uint32_t)(tp.seed >> 32);
+  philox4x32((uint32_t)gid, cnt, 0u, (uint32_t)(gid >> 32), k0, k1, r0);
+  philox4x32((uint32_t)gid, cnt, 1u, (uint32_t)(gid >> 32), k0, k1, r1);
+  philox4x32((uint32_t)gid, cnt, 2u, (uint32_t)(gid >> 32), k0, k1, r2);
+  float og[3] = {org_old[0], org_old[1], org_old[2]};
+  if (tp.curriculum) {
+    const float dx = root_pos[0] - og[0], dy = root_pos[1] - og[1];
+    const float dist = sqrtf(dx * dx + dy * dy);
+    const int up = dist > tp.env_length / 2.0f;
+    const float cn = sqrtf(cmd_old[0] * cmd_old[0] + cmd_old[1] * cmd_old[1]);
+    const int down = (dist < cn * tp.max_episode_length_s * 0.5f) && !up;
+    level += up - down;
+    if (level >= tp.max_terrain_level) level = (int64_t)(r2[3] % (uint32_t)tp.max_terrain_level);
+    else if (level < 0) level = 0;
+    const float* to = torigins + ((size_t)level * tp.num_terrain_cols + (size_t)type) * 3;
+    og[0] = to[0]; og[1] = to[1]; og[2] = to[2];
+  }
+  R.level = level;
+#pragma unroll
+  for (int k = 0; k < 3; k++) R.org[k] = og[k];
+  R.root[0] = tp.default_pos[0] + og[0] + urange(r0[0], -tp.spawn_xy, tp.spawn_xy);
+  R.root[1] = tp.default_pos[1] + og[1] + urange(r0[1], -tp.spawn_xy, tp.spawn_xy);
+  R.root[2] = tp.default_pos[2] + og[2];
+#pragma unroll
+  for (int k = 0; k < 4; k++) R.root[3 + k] = tp.default_quat[k];
+#pragma unroll
+  for (int k = 0; k < 6; k++) R.root[7 + k] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    R.push[k] = urange(r1[k], -tp.max_push_force, tp.max_push_force);
+    R.cmd[k] = urange(r2[k], -1.0f, 1.0f);
+  }
+}
+
+// ShifuVecEnv.reset_idx(arange(N)) (env.py:108-130) for the A1 task: one thread per env
+__global__ void k_a1_reset_all(A1Args A) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = A.S.n;
+  if (e >= n) return;
+  const ShfA1TaskParams& tp = *A.tp;
+  const ShfModel* m = A.S.model;
+  const int nd = m->nd, nb = m->nb, H = tp.num_history;
+  float* root = A.S.root + (size_t)e * 13;
+  float cmd[3] = {A.command[(size_t)e * 3], A.command[(size_t)e * 3 + 1], A.command[(size_t)e * 3 + 2]};
+  ResetOut R;
+  a1_reset_draw(tp, A.env_off + e, (uint32_t)A.reset_count[e], root, cmd, A.origins + (size_t)e * 3, A.levels[e],
+                A.types[e], A.torigins, R);
+  A.levels[e] = R.level;
+  for (int k = 0; k < 3; k++) A.origins[(size_t)e * 3 + k] = R.org[k];
+  for (int k = 0; k < 6; k++) { A.done_sums[(size_t)k * n + e] = A.rew_sums[(size_t)k * n + e]; A.rew_sums[(size_t)k * n + e] = 0.0f; }
+  A.done_sums[(size_t)6 * n + e] = (float)R.level;
+  A.done_sums[(size_t)7 * n + e] = 1.0f;
+  for (int d = 0; d < nd; d++) {
+    A.S.dof[((size_t)e * nd + d) * 2] = tp.default_dof_pos[d];
+    A.S.dof[((size_t)e * nd + d) * 2 + 1] = 0.0f;
+  }
+  for (int k = 0; k < 13; k++) root[k] = R.root[k];
+  for (int k = 0; k < 3; k++) A.push[((size_t)e * nb + tp.base_body) * 3 + k] = R.push[k];
+  A.ep_len[e] = 0;
+  A.reset[e] = 1;
+  for (int k = 0; k < nd * H; k++) A.history[(size_t)e * nd * H + k] = 0.0f;
+  for (int k = 0; k < 3; k++) A.command[(size_t)e * 3 + k] = R.cmd[k];
+  A.reset_count[e] += 1;
+}
+
+// scratch carved out of the (then idle) contact-point region of the env's LDS
+#define SCR_BODY 0   /* nb*13 body_state staging (<= 224)      */
+#define SCR_MH 224   /* measured heights (<= 192)              */
+#define SCR_HIST 416 /* action history (nd*H <= 96)            */
+#define SCR_ACT 512  /* clipped actions (<= 32)                */
+#define SCR_OBS 544  /* observation staging                    */
+
+template <int G>
+__global__ __launch_bounds__(256) void k_a1_step(A1Args A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(A.tp);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(smem + MODEL_WORDS);
+    for (int i = threadIdx.x; i < (int)(sizeof(ShfA1TaskParams) / 4); i += blockDim.x) dst[i] = src[i];
+  }
+  const ShfModel* m = stage_model(A.S.model, smem);
+  const ShfA1TaskParams& tp = *reinterpret_cast<const ShfA1TaskParams*>(smem + MODEL_WORDS);
+  const int epb = 256 / G, es = threadIdx.x / G, l = threadIdx.x % G;
+  const int e = blockIdx.x * epb + es;
+  const int n = A.S.n;
+  if (e >= n) return;
+  const int nb = m->nb, nd = m->nd, np = m->np, H = tp.num_history, P = tp.num_height_points;
+  const int nobs = 12 + 2 * nd + nd * H + P;
+  // post-physics scratch reuses the contact-point region (last in the carve)
+  const int env_words = env_lds_words(nb, nd, np, SCR_OBS + nobs);
+  EnvLds L = env_lds_carve(smem + MODEL_WORDS + TASK_WORDS + es * env_words, nb, nd, np);
+  float* scr = L.pt;
+
+  float* dof = A.S.dof + (size_t)e * nd * 2;
+  float* root = A.S.root + (size_t)e * 13;
+  for (int i = l; i < 2 * nd; i += G) L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)] = dof[i];
+  if (l < 13) L.root[l] = root[l];
+  float act = 0.0f;
+  if (l < nd) {
+    act = rclampf(A.raw_actions[(size_t)e * nd + l] * tp.action_scale, -tp.clip_actions, tp.clip_actions);
+    A.actions[(size_t)e * nd + l] = act;
+  }
+  GROUP_SYNC();
+
+  // Q2: base-frame velocities from the pre-physics root state (robot.py:222-229)
+  float blv[3] = {0, 0, 0}, bav[3] = {0, 0, 0};
+  const float gv[3] = {0.0f, 0.0f, -1.0f};
+  if (l == 0) {
+    float pg[3];
+    quat_rotate_inverse(L.root + 3, L.root + 7, blv);
+    quat_rotate_inverse(L.root + 3, L.root + 10, bav);
+    quat_rotate_inverse(L.root + 3, gv, pg);
+    float* o = A.base_vel + (size_t)e * 9;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { o[k] = blv[k]; o[3 + k] = bav[k]; o[6 + k] = pg[k]; }
+  }
+
+  StepCtx C;
+  C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights;
+  const float mu = A.S.friction[e];
+  const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
+  for (int it = 0; it < nsub; it++) {
+    if (it < tp.decimation && l < nd) {
+      float* D = L.dofb + l * DOF_STRIDE;
+      const float t = tp.p_gain[l] * (act + tp.default_dof_pos[l] - D[0]) - tp.d_gain[l] * D[1];
+      D[5] = rclampf(t, -m->effort[l], m->effort[l]);
+    }
+    GROUP_SYNC();
+    substep<G>(C, L, l, nullptr, nullptr, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
+               (it == nsub - 1) ? L.xch : nullptr);
+  }
+  GROUP_SYNC();
+  if (l < nd) A.torques[(size_t)e * nd + l] = L.dofb[l * DOF_STRIDE + 5];
+  for (int i = l; i < 3 * nb; i += G) A.S.contact[(size_t)e * nb * 3 + i] = L.xch[i];
+  // the contact-point region is idle from here on: it becomes scratch
+  for (int i = l; i < nd * H; i += G) scr[SCR_HIST + i] = A.history[(size_t)e * nd * H + i];
+  if (l < nd) scr[SCR_ACT + l] = act;
+  body_states<G>(m, L, l, scr + SCR_BODY);
+  for (int i = l; i < 13 * nb; i += G) A.body_state[(size_t)e * nb * 13 + i] = scr[SCR_BODY + i];
+
+  // get_heights (isaac_gym.py:412-433)
+  {
+    float qz = L.root[5], qw = L.root[6];
+    const float nrm = rmaxf(sqrtf(qz * qz + qw * qw), 1e-9f);
+    qz = qz / nrm; qw = qw / nrm;
+    for (int i = l; i < P; i += G) {
+      const float bx = A.hpoints[2 * i], by = A.hpoints[2 * i + 1];
+      const float tx = (-qz * by) * 2.0f, ty = (qz * bx) * 2.0f;
+      float px = bx + qw * tx + (-qz * ty) + L.root[0];
+      float py = by + qw * ty + (qz * tx) + L.root[1];
+      float hh = 0.0f;
+      if (A.S.terr.rows > 0) {
+        px += A.S.terr.border; py += A.S.terr.border;
+        int ix = (int)truncf(px / A.S.terr.hscale), iy = (int)truncf(py / A.S.terr.hscale);
+        ix = ix < 0 ? 0 : ix; ix = ix > A.S.terr.rows - 2 ? A.S.terr.rows - 2 : ix;
+        iy = iy < 0 ? 0 : iy; iy = iy > A.S.terr.cols - 2 ? A.S.terr.cols - 2 : iy;
+        const int16_t* p0 = A.S.heights + (size_t)ix * A.S.terr.cols + iy;
+        const int16_t h1 = p0[0], h2 = p0[A.S.terr.cols], h3 = p0[1];
+        int16_t hm = h1 < h2 ? h1 : h2;
+        hm = hm < h3 ? hm : h3;
+        hh = (float)hm * A.S.terr.vscale;
+      }
+      scr[SCR_MH + i] = hh;
+      A.heights_out[(size_t)e * P + i] = hh;
+    }
+  }
+  GROUP_SYNC();
+
+  // post_step (env.py:93-106): one lane runs the scalar bookkeeping
+  if (l == 0) {
+    const float* cf = L.xch;
+    int64_t ep = A.ep_len[e] + 1;
+    const float* fb = cf + 3 * tp.base_body;
+    const int contact_term = sqrtf(fb[0] * fb[0] + fb[1] * fb[1] + fb[2] * fb[2]) > 1.0f;
+    const int timeout = (float)ep > tp.max_episode_length;
+    const int reset = timeout | contact_term;
+    A.timeout[e] = (uint8_t)timeout;
+    A.reset[e] = (uint8_t)reset;
+    float cmd[3] = {A.command[(size_t)e * 3], A.command[(size_t)e * 3 + 1], A.command[(size_t)e * 3 + 2]};
+    const float* hist = scr + SCR_HIST;
+    float rterm[6];
+    {
+      const float e0 = cmd[0] - blv[0], e1 = cmd[1] - blv[1];
+      rterm[0] = 1.0f * exp_spec(-(e0 * e0 + e1 * e1) / 0.25f);
+      const float e2 = cmd[2] - bav[2];
+      rterm[1] = 0.5f * exp_spec(-(e2 * e2) / 0.25f);
+      rterm[2] = -2.0f * (blv[2] * blv[2]) + -0.005f * (bav[0] * bav[0] + bav[1] * bav[1]);
+      float first = 0.0f, second = 0.0f;
+      for (int d = 0; d < nd; d++) {
+        const float a0 = hist[d * H + 0], a1 = hist[d * H + 1], a2 = hist[d * H + 2];
+        first += (a1 - a0) * (a1 - a0);
+        const float t = a2 - 2.0f * a1 + a0;
+        second += t * t;
+      }
+      rterm[3] = -0.005f * (first + second);
+      float cnt = 0.0f;
+      for (int k = 0; k < tp.num_leg_bodies; k++) {
+        const float* f = cf + 3 * tp.leg_bodies[k];
+        if (sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]) > 0.1f) cnt += 1.0f;
+      }
+      rterm[4] = -1.0f * cnt;
+      float t2 = 0.0f;
+      for (int d = 0; d < nd; d++) { const float t = L.dofb[d * DOF_STRIDE + 5]; t2 += t * t; }
+      rterm[5] = -2e-5f * t2;
+    }
+    float rew = 0.0f;
+    float sums[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      sums[k] = A.rew_sums[(size_t)k * n + e] + rterm[k];
+      rew += rterm[k];
+    }
+    A.rew[e] = rew;
+    float done[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t level = A.levels[e];
+    if (reset) {
+      ResetOut R;
+      a1_reset_draw(tp, A.env_off + e, (uint32_t)A.reset_count[e], L.root, cmd, A.origins + (size_t)e * 3, level,
+                    A.types[e], A.torigins, R);
+      level = R.level;
+      A.levels[e] = level;
+#pragma unroll
+      for (int k = 0; k < 3; k++) A.origins[(size_t)e * 3 + k] = R.org[k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) { done[k] = sums[k]; sums[k] = 0.0f; }
+      done[7] = 1.0f;
+      for (int d = 0; d < nd; d++) { L.dofb[d * DOF_STRIDE] = tp.default_dof_pos[d]; L.dofb[d * DOF_STRIDE + 1] = 0.0f; }
+#pragma unroll
+      for (int k = 0; k < 13; k++) L.root[k] = R.root[k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) A.push[((size_t)e * nb + tp.base_body) * 3 + k] = R.push[k];
+      ep = 0;
+      for (int k = 0; k < nd * H; k++) scr[SCR_HIST + k] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { cmd[k] = R.cmd[k]; A.command[(size_t)e * 3 + k] = cmd[k]; }
+      A.reset_count[e] += 1;
+    }
+    done[6] = (float)level;
+#pragma unroll
+    for (int k = 0; k < 6; k++) A.rew_sums[(size_t)k * n + e] = sums[k];
+#pragma unroll
+    for (int k = 0; k < 8; k++) A.done_sums[(size_t)k * n + e] = done[k];
+    A.ep_len[e] = ep;
+    const float co = tp.clip_obs;
+    float* o = scr + SCR_OBS;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      o[k] = rclampf(cmd[k], -co, co);
+      o[3 + k] = rclampf(blv[k], -co, co);
+      o[6 + k] = rclampf(bav[k], -co, co);
+      o[9 + k] = rclampf(gv[k], -co, co);
+    }
+  }
+  GROUP_SYNC();
+  {
+    // compute_observations (a1_conditional.py:131-144) staged in LDS, then one coalesced store
+    const float co = tp.clip_obs;
+    float* o = scr + SCR_OBS;
+    if (l < nd) {
+      o[12 + l] = rclampf(L.dofb[l * DOF_STRIDE] - tp.default_dof_pos[l], -co, co);
+      o[12 + nd + l] = rclampf(L.dofb[l * DOF_STRIDE + 1], -co, co);
+    }
+    for (int i = l; i < nd * H; i += G) {
+      const int h = i / nd, d = i % nd;
+      o[12 + 2 * nd + i] = rclampf(scr[SCR_HIST + d * H + h], -co, co);
+    }
+    const float bz = L.root[2];
+    for (int i = l; i < P; i += G)
+      o[12 + 2 * nd + nd * H + i] = rclampf(rclampf(bz - 0.5f - scr[SCR_MH + i], -1.0f, 1.0f), -co, co);
+  }
+  GROUP_SYNC();
+  for (int i = l; i < nobs; i += G) A.obs[(size_t)e * nobs + i] = scr[SCR_OBS + i];
+  // HistoryRecorder.add (train.py:12-14), after the observation was taken (Q12)
+  for (int i = l; i < nd * H; i += G) {
+    const int d = i / H, h = i % H;
+    A.history[(size_t)e * nd * H + i] = h == 0 ? scr[SCR_ACT + d] : scr[SCR_HIST + d * H + h - 1];
+  }
+  for (int i = l; i < 2 * nd; i += G) dof[i] = L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)];
+  if (l < 13) root[l] = L.root[l];
+}
+
+// per-step reduction for extras["episode"] (env.py:149-158), fixed order
+__global__ __launch_bounds__(1024) void k_a1_stats(int n, float max_episode_length_s, const float* done_sums, float* out) {
+  __shared__ float part[1024];
+  __shared__ float res[8];
+  const int t = threadIdx.x;
+  for (int k = 0; k < 8; k++) {
+    float acc = 0.0f;
+    for (int e = t; e < n; e += 1024) acc += done_sums[(size_t)k * n + e];
+    part[t] = acc;
+    __syncthreads();
+    for (int s = 512; s >= 1; s >>= 1) {
+      if (t < s) part[t] += part[t + s];
+      __syncthreads();
+    }
+    if (t == 0) res[k] = part[0];
+    __syncthreads();
+  }
+  if (t < 8) out[t] = res[t];
+  if (t < 6) out[8 + t] = res[7] > 0.0f ? res[t] / res[7] / max_episode_length_s : 0.0f;
+  if (t == 6) out[14] = res[6] / (float)n;
+  if (t == 7) out[15] = (float)n;
+}
+
+// ---------------------------------------------------------------- C ABI --
+static size_t sim_lds_bytes(const ShfSim* s, int head_words, int min_tail) {
+  const int epb = 256 / s->group;
+  return ((size_t)MODEL_WORDS + head_words + (size_t)epb * env_lds_words(s->model.nb, s->model.nd, s->model.np, min_tail)) * 4;
+}
+
+extern "C" int shf_sim_create(const ShfSimParams* params, ShfSim** out) {
+  if (!params || !out) return fail("shf_sim_create: null argument");
+  if (!(params->dt > 0.0f)) return fail("shf_sim_create: dt must be > 0");
+  ShfSim* s = new ShfSim();
+  s->sp = *params;
+  memset(&s->terr, 0, sizeof s->terr);
+  s->terr.friction = 1.0f;
+  *out = s;
+  return 0;
+}
+extern "C" int shf_sim_destroy(ShfSim* sim) {
+  delete sim;
+  return 0;
+}
+extern "C" int shf_sim_set_terrain(ShfSim* sim, const ShfTerrain* terrain) {
+  if (!sim || !terrain) return fail("shf_sim_set_terrain: null argument");
+  if (terrain->rows != 0 && (terrain->rows < 2 || terrain->cols < 2 || !(terrain->hscale > 0.0f)))
+    return fail("shf_sim_set_terrain: bad heightfield shape/scale");
+  sim->terr = *terrain;
+  return 0;
+}
+extern "C" int shf_sim_set_articulation(ShfSim* sim, const ShfModel* model) {
+  if (!sim || !model) return fail("shf_sim_set_articulation: null argument");
+  if (model->nb < 1 || model->nb > SHF_MAX_BODIES || model->nd < 0 || model->nd > SHF_MAX_DOFS || model->np < 0 ||
+      model->np > SHF_MAX_POINTS)
+    return fail("shf_sim_set_articulation: model exceeds SHF_MAX_*");
+  sim->model = *model;
+  sim->has_model = true;
+  return 0;
+}
+extern "C" int shf_sim_add_box(ShfSim* sim, const ShfBoxDesc* box) {
+  if (!sim || !box) return fail("shf_sim_add_box: null argument");
+  if (sim->nboxes >= SHF_MAX_BOXES) return fail("shf_sim_add_box: too many boxes");
+  sim->boxes[sim->nboxes++] = *box;
+  return 0;
+}
+extern "C" int shf_sim_finalize(ShfSim* sim, int32_t num_envs, int64_t env_id_offset) {
+  if (!sim || !sim->has_model) return fail("shf_sim_finalize: no articulation set");
+  if (num_envs <= 0) return fail("shf_sim_finalize: num_envs must be > 0");
+  sim->n = num_envs;
+  sim->env_off = env_id_offset;
+  sim->finalized = true;
+  return 0;
+}
+extern "C" int shf_sim_set_group(ShfSim* sim, int32_t lanes) {
+  if (lanes != 64 && lanes != 32 && lanes != 16) return fail("shf_sim_set_group: lanes must be 16, 32 or 64");
+  if (sim->model.nb > lanes || sim->model.nd * 2 > 2 * lanes) return fail("shf_sim_set_group: model does not fit the group");
+  sim->group = lanes;
+  return 0;
+}
+
+extern "C" int shf_sim_layout(const ShfSim* sim, int32_t id, int64_t shape[4], int32_t* ndim, int32_t* dtype) {
+  if (!sim || !sim->finalized) return fail("shf_sim_layout: sim not finalized");
+  const int64_t N = sim->n, nd = sim->model.nd, nb = sim->model.nb, A = 1 + sim->nboxes, B = nb + sim->nboxes;
+  *dtype = 0;
+  shape[0] = shape[1] = shape[2] = shape[3] = 1;
+  switch (id) {
+    case SHF_T_DOF_STATE: case SHF_T_SIM_DOF: *ndim = 2; shape[0] = N * nd; shape[1] = 2; break;
+    case SHF_T_ROOT_STATE: case SHF_T_SIM_ROOT: *ndim = 2; shape[0] = N * A; shape[1] = 13; break;
+    case SHF_T_BODY_STATE: *ndim = 2; shape[0] = N * B; shape[1] = 13; break;
+    case SHF_T_CONTACT: case SHF_T_SIM_CONTACT: case SHF_T_BODY_FORCE: *ndim = 2; shape[0] = N * B; shape[1] = 3; break;
+    case SHF_T_JACOBIAN:
+      *ndim = 4; shape[0] = N; shape[1] = sim->model.fixed_base ? nb - 1 : nb; shape[2] = 6;
+      shape[3] = sim->model.fixed_base ? nd : nd + 6; break;
+    case SHF_T_EFFORT: case SHF_T_POS_TARGET: case SHF_T_VEL_TARGET: *ndim = 1; shape[0] = N * nd; break;
+    case SHF_T_FRICTION: *ndim = 1; shape[0] = N; break;
+    case SHF_T_HEIGHTS: *ndim = 2; shape[0] = sim->terr.rows > 0 ? sim->terr.rows : 1; shape[1] = sim->terr.rows > 0 ? sim->terr.cols : 1; *dtype = 2; break;
+    case SHF_T_MODEL: *ndim = 1; shape[0] = sizeof(ShfModel); *dtype = 3; break;
+    default: return fail("shf_sim_layout: unknown tensor id");
+  }
+  return 0;
+}
+extern "C" int shf_sim_bind(ShfSim* sim, int32_t id, void* device_ptr) {
+  if (!sim || id < 0 || id >= SHF_T_COUNT) return fail("shf_sim_bind: bad id");
+  sim->t[id] = device_ptr;
+  return 0;
+}
+
+static int need(const ShfSim* s, std::initializer_list<int> ids, const char* who) {
+  if (!s || !s->finalized) return fail(std::string(who) + ": sim not finalized");
+  for (int id : ids)
+    if (!s->t[id]) return fail(std::string(who) + ": tensor " + std::to_string(id) + " not bound");
+  return 0;
+}
+
+static SimArgs sim_args(const ShfSim* s, bool internal) {
+  SimArgs A;
+  A.sp = s->sp; A.terr = s->terr;
+  A.heights = (const int16_t*)s->t[SHF_T_HEIGHTS];
+  A.model = (const ShfModel*)s->t[SHF_T_MODEL];
+  A.n = s->n;
+  A.dof = (float*)s->t[internal ? SHF_T_SIM_DOF : SHF_T_DOF_STATE];
+  A.root = (float*)s->t[internal ? SHF_T_SIM_ROOT : SHF_T_ROOT_STATE];
+  A.actors = 1 + s->nboxes;
+  A.effort = (const float*)s->t[SHF_T_EFFORT];
+  A.pos_tgt = (const float*)s->t[SHF_T_POS_TARGET];
+  A.vel_tgt = (const float*)s->t[SHF_T_VEL_TARGET];
+  A.body_force = nullptr;
+  A.friction = (const float*)s->t[SHF_T_FRICTION];
+  A.contact = (float*)s->t[internal ? SHF_T_SIM_CONTACT : SHF_T_CONTACT];
+  return A;
+}
+
+template <typename K, typename... Args>
+static int launch(K kernel, dim3 grid, dim3 block, size_t lds, void* stream, Args... args) {
+  hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)stream, args...);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int shf_sim_step(ShfSim* sim, void* stream) {
+  if (int r = need(sim, {SHF_T_SIM_DOF, SHF_T_SIM_ROOT, SHF_T_SIM_CONTACT, SHF_T_MODEL}, "shf_sim_step")) return r;
+  if (sim->terr.rows > 0 && !sim->t[SHF_T_HEIGHTS]) return fail("shf_sim_step: heightfield samples not bound");
+  SimArgs A = sim_args(sim, true);
+  if (sim->force_armed) A.body_force = (const float*)sim->t[SHF_T_BODY_FORCE];
+  sim->force_armed = false;
+  const int epb = 256 / sim->group;
+  dim3 grid((sim->n + epb - 1) / epb), block(256);
+  const size_t lds = sim_lds_bytes(sim, 0, 0);
+  switch (sim->group) {
+    case 64: return launch(k_sim_step<64>, grid, block, lds, stream, A);
+    case 32: return launch(k_sim_step<32>, grid, block, lds, stream, A);
+    default: return launch(k_sim_step<16>, grid, block, lds, stream, A);
+  }
+}
+
+extern "C" int shf_sim_refresh(ShfSim* sim, int32_t mask, void* stream) {
+  if (int r = need(sim, {SHF_T_SIM_DOF, SHF_T_SIM_ROOT, SHF_T_MODEL}, "shf_sim_refresh")) return r;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t N = sim->n, nd = sim->model.nd, nb = sim->model.nb, A = 1 + sim->nboxes, B = nb + sim->nboxes;
+  if ((mask & SHF_REFRESH_DOF) && sim->t[SHF_T_DOF_STATE])
+    HIP_OK(hipMemcpyAsync(sim->t[SHF_T_DOF_STATE], sim->t[SHF_T_SIM_DOF], N * nd * 2 * 4, hipMemcpyDeviceToDevice, st));
+  if ((mask & SHF_REFRESH_ROOT) && sim->t[SHF_T_ROOT_STATE])
+    HIP_OK(hipMemcpyAsync(sim->t[SHF_T_ROOT_STATE], sim->t[SHF_T_SIM_ROOT], N * A * 13 * 4, hipMemcpyDeviceToDevice, st));
+  if ((mask & SHF_REFRESH_CONTACT) && sim->t[SHF_T_CONTACT] && sim->t[SHF_T_SIM_CONTACT])
+    HIP_OK(hipMemcpyAsync(sim->t[SHF_T_CONTACT], sim->t[SHF_T_SIM_CONTACT], N * B * 3 * 4, hipMemcpyDeviceToDevice, st));
+  if ((mask & SHF_REFRESH_BODY) && sim->t[SHF_T_BODY_STATE]) {
+    const int epb = 256 / sim->group;
+    dim3 grid((sim->n + epb - 1) / epb), block(256);
+    const size_t lds = sim_lds_bytes(sim, 0, 0);
+    const ShfModel* gm = (const ShfModel*)sim->t[SHF_T_MODEL];
+    const float* dof = (const float*)sim->t[SHF_T_SIM_DOF];
+    const float* root = (const float*)sim->t[SHF_T_SIM_ROOT];
+    float* bs = (float*)sim->t[SHF_T_BODY_STATE];
+    switch (sim->group) {
+      case 64: return launch(k_body_state<64>, grid, block, lds, stream, gm, sim->n, dof, root, (int)A, bs);
+      case 32: return launch(k_body_state<32>, grid, block, lds, stream, gm, sim->n, dof, root, (int)A, bs);
+      default: return launch(k_body_state<16>, grid, block, lds, stream, gm, sim->n, dof, root, (int)A, bs);
+    }
+  }
+  return 0;
+}
+
+extern "C" int shf_sim_set_dof_command(ShfSim* sim, int32_t tensor_id, const float* values_dev, void* stream) {
+  if (tensor_id != SHF_T_EFFORT && tensor_id != SHF_T_POS_TARGET && tensor_id != SHF_T_VEL_TARGET)
+    return fail("shf_sim_set_dof_command: tensor_id must be EFFORT, POS_TARGET or VEL_TARGET");
+  if (int r = need(sim, {tensor_id}, "shf_sim_set_dof_command")) return r;
+  if (!values_dev) return fail("shf_sim_set_dof_command: null values");
+  HIP_OK(hipMemcpyAsync(sim->t[tensor_id], values_dev, (size_t)sim->n * sim->model.nd * 4, hipMemcpyDeviceToDevice,
+                        (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int shf_sim_apply_body_force(ShfSim* sim, const float* force_dev, void* stream) {
+  if (int r = need(sim, {SHF_T_BODY_FORCE}, "shf_sim_apply_body_force")) return r;
+  if (!force_dev) return fail("shf_sim_apply_body_force: null force tensor");
+  HIP_OK(hipMemcpyAsync(sim->t[SHF_T_BODY_FORCE], force_dev, (size_t)sim->n * (sim->model.nb + sim->nboxes) * 3 * 4,
+                        hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  sim->force_armed = true;
+  return 0;
+}
+
+extern "C" int shf_sim_commit_root_indexed(ShfSim* sim, const float* root_dev, const int32_t* actor_idx_dev, int32_t n,
+                                           void* stream) {
+  if (int r = need(sim, {SHF_T_SIM_ROOT}, "shf_sim_commit_root_indexed")) return r;
+  if (n <= 0) return 0;
+  if (!root_dev || !actor_idx_dev) return fail("shf_sim_commit_root_indexed: null argument");
+  return launch(k_commit_rows, dim3(n), dim3(64), 0, stream, root_dev, (float*)sim->t[SHF_T_SIM_ROOT], actor_idx_dev,
+                (int)n, 13, 1, 13);
+}
+extern "C" int shf_sim_commit_root_all(ShfSim* sim, const float* root_dev, void* stream) {
+  if (int r = need(sim, {SHF_T_SIM_ROOT}, "shf_sim_commit_root_all")) return r;
+  HIP_OK(hipMemcpyAsync(sim->t[SHF_T_SIM_ROOT], root_dev, (size_t)sim->n * (1 + sim->nboxes) * 13 * 4,
+                        hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int shf_sim_commit_dof_indexed(ShfSim* sim, const float* dof_dev, const int32_t* actor_idx_dev, int32_t n,
+                                          void* stream) {
+  if (int r = need(sim, {SHF_T_SIM_DOF}, "shf_sim_commit_dof_indexed")) return r;
+  if (n <= 0) return 0;
+  if (!dof_dev || !actor_idx_dev) return fail("shf_sim_commit_dof_indexed: null argument");
+  const int nd = sim->model.nd;
+  return launch(k_commit_rows, dim3(n), dim3(64), 0, stream, dof_dev, (float*)sim->t[SHF_T_SIM_DOF], actor_idx_dev,
+                (int)n, nd * 2, 1 + sim->nboxes, nd * 2);
+}
+extern "C" int shf_sim_set_pos_target_indexed(ShfSim* sim, const float* values_dev, const int32_t* actor_idx_dev,
+                                              int32_t n, void* stream) {
+  if (int r = need(sim, {SHF_T_POS_TARGET}, "shf_sim_set_pos_target_indexed")) return r;
+  if (n <= 0) return 0;
+  if (!values_dev || !actor_idx_dev) return fail("shf_sim_set_pos_target_indexed: null argument");
+  const int nd = sim->model.nd;
+  return launch(k_commit_rows, dim3(n), dim3(64), 0, stream, values_dev, (float*)sim->t[SHF_T_POS_TARGET],
+                actor_idx_dev, (int)n, nd, 1 + sim->nboxes, nd);
+}
+
+extern "C" int shf_sim_reset_all(ShfSim* sim, const float* default_root_dev, const float* default_dof_dev,
+                                 const float* env_origins_dev, void* stream) {
+  if (int r = need(sim, {SHF_T_SIM_DOF, SHF_T_SIM_ROOT, SHF_T_DOF_STATE, SHF_T_ROOT_STATE, SHF_T_MODEL}, "shf_sim_reset_all"))
+    return r;
+  if (!default_root_dev || !default_dof_dev) return fail("shf_sim_reset_all: null defaults");
+  return launch(k_reset_all, dim3((sim->n + 255) / 256), dim3(256), 0, stream, (const ShfModel*)sim->t[SHF_T_MODEL], sim->n,
+                1 + sim->nboxes, default_root_dev, default_dof_dev, env_origins_dev, (float*)sim->t[SHF_T_SIM_DOF],
+                (float*)sim->t[SHF_T_DOF_STATE], (float*)sim->t[SHF_T_SIM_ROOT], (float*)sim->t[SHF_T_ROOT_STATE]);
+}
+
+// ----------------------------------------------------------- A1 task ABI --
+extern "C" int shf_a1_create(ShfSim* sim, const ShfA1TaskParams* params, ShfA1Task** out) {
+  if (!sim || !params || !out) return fail("shf_a1_create: null argument");
+  if (!sim->finalized) return fail("shf_a1_create: sim not finalized");
+  if (sim->nboxes != 0) return fail("shf_a1_create: the fused A1 step supports a single actor per env");
+  if (params->num_history != 3) return fail("shf_a1_create: smoothing_action needs num_history == 3");
+  if (params->num_height_points > 192) return fail("shf_a1_create: at most 192 height points");
+  if (sim->model.nd * params->num_history > 96) return fail("shf_a1_create: action history too large");
+  if (sim->model.nb * 13 > SCR_MH) return fail("shf_a1_create: too many bodies for the staging area");
+  ShfA1Task* t = new ShfA1Task();
+  t->sim = sim;
+  t->tp = *params;
+  *out = t;
+  return 0;
+}
+extern "C" int shf_a1_destroy(ShfA1Task* task) {
+  delete task;
+  return 0;
+}
+extern "C" int shf_a1_layout(const ShfA1Task* task, int32_t id, int64_t shape[4], int32_t* ndim, int32_t* dtype) {
+  if (!task) return fail("shf_a1_layout: null task");
+  const ShfSim* s = task->sim;
+  const int64_t N = s->n, nd = s->model.nd, nb = s->model.nb, H = task->tp.num_history, P = task->tp.num_height_points;
+  *dtype = 0;
+  shape[0] = shape[1] = shape[2] = shape[3] = 1;
+  switch (id) {
+    case SHF_A1_ACTIONS: case SHF_A1_TORQUES: *ndim = 2; shape[0] = N; shape[1] = nd; break;
+    case SHF_A1_OBS: *ndim = 2; shape[0] = N; shape[1] = 12 + 2 * nd + nd * H + P; break;
+    case SHF_A1_REW: *ndim = 1; shape[0] = N; break;
+    case SHF_A1_RESET: case SHF_A1_TIMEOUT: *ndim = 1; shape[0] = N; *dtype = 3; break;
+    case SHF_A1_EP_LEN: case SHF_A1_LEVELS: case SHF_A1_TYPES: *ndim = 1; shape[0] = N; *dtype = 4; break;
+    case SHF_A1_COMMAND: case SHF_A1_ORIGINS: *ndim = 2; shape[0] = N; shape[1] = 3; break;
+    case SHF_A1_HISTORY: *ndim = 3; shape[0] = N; shape[1] = nd; shape[2] = H; break;
+    case SHF_A1_REW_SUMS: *ndim = 2; shape[0] = 6; shape[1] = N; break;
+    case SHF_A1_BASE_VEL: *ndim = 2; shape[0] = N; shape[1] = 9; break;
+    case SHF_A1_HEIGHTS: *ndim = 2; shape[0] = N; shape[1] = P; break;
+    case SHF_A1_HPOINTS: *ndim = 2; shape[0] = P; shape[1] = 2; break;
+    case SHF_A1_PUSH: *ndim = 3; shape[0] = N; shape[1] = nb; shape[2] = 3; break;
+    case SHF_A1_TORIGINS: *ndim = 3; shape[0] = task->tp.max_terrain_level; shape[1] = task->tp.num_terrain_cols; shape[2] = 3; break;
+    case SHF_A1_RESET_COUNT: *ndim = 1; shape[0] = N; *dtype = 1; break;
+    case SHF_A1_DONE_SUMS: *ndim = 2; shape[0] = 8; shape[1] = N; break;
+    case SHF_A1_STATS: *ndim = 2; shape[0] = task->stats_ring; shape[1] = 16; break;
+    case SHF_A1_PARAMS: *ndim = 1; shape[0] = sizeof(ShfA1TaskParams); *dtype = 3; break;
+    default: return fail("shf_a1_layout: unknown tensor id");
+  }
+  return 0;
+}
+extern "C" int shf_a1_bind(ShfA1Task* task, int32_t id, void* device_ptr) {
+  if (!task || id < 0 || id >= SHF_A1_COUNT) return fail("shf_a1_bind: bad id");
+  task->t[id] = device_ptr;
+  return 0;
+}
+
+static int a1_args(ShfA1Task* task, const float* raw_actions_dev, const char* who, A1Args& A) {
+  if (!task) return fail(std::string(who) + ": null task");
+  ShfSim* s = task->sim;
+  if (int r = need(s, {SHF_T_DOF_STATE, SHF_T_ROOT_STATE, SHF_T_BODY_STATE, SHF_T_CONTACT, SHF_T_FRICTION, SHF_T_MODEL}, who))
+    return r;
+  if (s->terr.rows > 0 && !s->t[SHF_T_HEIGHTS]) return fail(std::string(who) + ": heightfield samples not bound");
+  for (int id = 0; id < SHF_A1_COUNT; id++)
+    if (!task->t[id]) return fail(std::string(who) + ": task tensor " + std::to_string(id) + " not bound");
+  A.S = sim_args(s, false);
+  A.tp = (const ShfA1TaskParams*)task->t[SHF_A1_PARAMS];
+  A.env_off = s->env_off;
+  A.raw_actions = raw_actions_dev;
+  A.actions = (float*)task->t[SHF_A1_ACTIONS]; A.obs = (float*)task->t[SHF_A1_OBS]; A.rew = (float*)task->t[SHF_A1_REW];
+  A.reset = (uint8_t*)task->t[SHF_A1_RESET]; A.timeout = (uint8_t*)task->t[SHF_A1_TIMEOUT];
+  A.ep_len = (int64_t*)task->t[SHF_A1_EP_LEN];
+  A.command = (float*)task->t[SHF_A1_COMMAND]; A.history = (float*)task->t[SHF_A1_HISTORY];
+  A.rew_sums = (float*)task->t[SHF_A1_REW_SUMS]; A.torques = (float*)task->t[SHF_A1_TORQUES];
+  A.base_vel = (float*)task->t[SHF_A1_BASE_VEL]; A.heights_out = (float*)task->t[SHF_A1_HEIGHTS];
+  A.hpoints = (const float*)task->t[SHF_A1_HPOINTS];
+  A.push = (float*)task->t[SHF_A1_PUSH]; A.origins = (float*)task->t[SHF_A1_ORIGINS];
+  A.levels = (int64_t*)task->t[SHF_A1_LEVELS]; A.types = (const int64_t*)task->t[SHF_A1_TYPES];
+  A.torigins = (const float*)task->t[SHF_A1_TORIGINS];
+  A.reset_count = (int32_t*)task->t[SHF_A1_RESET_COUNT];
+  A.done_sums = (float*)task->t[SHF_A1_DONE_SUMS];
+  A.body_state = (float*)s->t[SHF_T_BODY_STATE];
+  return 0;
+}
+
+extern "C" int shf_a1_step(ShfA1Task* task, const float* raw_actions_dev, int64_t step_index, void* stream) {
+  if (!raw_actions_dev) return fail("shf_a1_step: null actions");
+  A1Args A;
+  if (int r = a1_args(task, raw_actions_dev, "shf_a1_step", A)) return r;
+  ShfSim* s = task->sim;
+  const int nobs = 12 + 2 * s->model.nd + s->model.nd * task->tp.num_history + task->tp.num_height_points;
+  const int epb = 256 / s->group;
+  dim3 grid((s->n + epb - 1) / epb), block(256);
+  const size_t lds = sim_lds_bytes(s, TASK_WORDS, SCR_OBS + nobs);
+  int r;
+  switch (s->group) {
+    case 64: r = launch(k_a1_step<64>, grid, block, lds, stream, A); break;
+    case 32: r = launch(k_a1_step<32>, grid, block, lds, stream, A); break;
+    default: r = launch(k_a1_step<16>, grid, block, lds, stream, A); break;
+  }
+  if (r) return r;
+  float* out = (float*)task->t[SHF_A1_STATS] + (size_t)(step_index % task->stats_ring) * 16;
+  return launch(k_a1_stats, dim3(1), dim3(1024), 0, stream, (int)s->n, task->tp.max_episode_length_s,
+                (const float*)task->t[SHF_A1_DONE_SUMS], out);
+}
+
+extern "C" int shf_a1_reset_all(ShfA1Task* task, void* stream) {
+  A1Args A;
+  if (int r = a1_args(task, nullptr, "shf_a1_reset_all", A)) return r;
+  return launch(k_a1_reset_all, dim3((A.S.n + 127) / 128), dim3(128), 0, stream, A);
+}

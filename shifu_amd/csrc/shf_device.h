@@ -1,0 +1,721 @@
+// shf_device.h -- gfx950 device code: one lane group (G lanes, G = 64 by default:
+// one wavefront) simulates one environment.
+//
+// Lane roles inside a group:   lane b < nb        <-> reported rigid body b
+//                              lane d < nd        <-> degree of freedom d
+//                              lane i (+k*G) < np <-> contact sample point i
+// The flattened articulation (ShfModel) and the per-env working set live in LDS;
+// parent->child (kinematics, accelerations) and child->parent (articulated
+// inertia) hand-offs go through LDS slots owned by the producing lane, cross-lane
+// scalars through wave shuffles.  HBM is touched only at the start and the end of
+// an env step, in the Isaac-Gym tensor layouts, which are contiguous per env and
+// therefore coalesced across the lanes of a group.
+//
+// ARITHMETIC CONTRACT: every floating-point operation below is written out
+// (explicit fmaf, no contraction: the file is compiled with -ffp-contract=off
+// and without fast-math) in the same order as the float build of the CPU oracle
+// (oracle/shf_oracle.c, test-only), so results are reproducible bit for bit.
+// This file does not include, link or call the oracle.
+//
+// Reference call sites replaced: gym.simulate (shifu/units/robot.py:69,
+// examples/a1_conditional/a1_conditional.py:69, shifu/gym/isaac_gym.py:140).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/shifu_amd.h"
+
+#define DEV __device__ __forceinline__
+
+// LDS hand-offs stay inside one wavefront: LDS requests of a wave are served in
+// order, so only the compiler has to be kept from reordering.
+#define GROUP_SYNC()                                         \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
+  } while (0)
+
+// ------------------------------------------------------------------ math --
+DEV float rminf(float a, float b) { return a < b ? a : b; }
+DEV float rmaxf(float a, float b) { return a > b ? a : b; }
+DEV float rclampf(float x, float lo, float hi) { return rminf(rmaxf(x, lo), hi); }
+DEV float dot3(const float* a, const float* b) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
+DEV void cross3(const float* a, const float* b, float* o) {
+  float x = fmaf(a[1], b[2], -(a[2] * b[1]));
+  float y = fmaf(a[2], b[0], -(a[0] * b[2]));
+  float z = fmaf(a[0], b[1], -(a[1] * b[0]));
+  o[0] = x; o[1] = y; o[2] = z;
+}
+DEV void mv3(const float* M, const float* v, float* o) {
+  float x = dot3(M, v), y = dot3(M + 3, v), z = dot3(M + 6, v);
+  o[0] = x; o[1] = y; o[2] = z;
+}
+DEV void mm3(const float* A, const float* B, float* o) {
+  float t[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) t[3 * i + j] = fmaf(A[3 * i + 2], B[6 + j], fmaf(A[3 * i + 1], B[3 + j], A[3 * i] * B[j]));
+#pragma unroll
+  for (int k = 0; k < 9; k++) o[k] = t[k];
+}
+DEV void sincos_spec(float x, float* s, float* c) {
+  float k = rintf(x * 0.636619772367581343f);
+  float r = fmaf(k, -1.5703125f, x);
+  r = fmaf(k, -4.83751296997070312e-4f, r);
+  r = fmaf(k, -7.54978995489188216e-8f, r);
+  float r2 = r * r;
+  float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = fmaf(r2, ps, -1.6666654611e-1f);
+  float sn = fmaf(r * r2, ps, r);
+  float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = fmaf(r2, pc, 4.166664568298827e-2f);
+  float cs = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
+  int q = ((int)k) & 3;
+  float so = (q & 1) ? cs : sn, co = (q & 1) ? sn : cs;
+  if (q == 1 || q == 2) co = -co;
+  if (q >= 2) so = -so;
+  *s = so; *c = co;
+}
+DEV float exp_spec(float x) {
+  if (x < -87.0f) return 0.0f;
+  float k = rintf(x * 1.44269504088896341f);
+  float r = fmaf(k, -0.693359375f, x);
+  r = fmaf(k, 2.12194440e-4f, r);
+  float p = fmaf(r, 1.9875691500e-4f, 1.3981999507e-3f);
+  p = fmaf(r, p, 8.3334519073e-3f);
+  p = fmaf(r, p, 4.1665795894e-2f);
+  p = fmaf(r, p, 1.6666665459e-1f);
+  p = fmaf(r, p, 5.0000001201e-1f);
+  float e = fmaf(r * r, p, r) + 1.0f;
+  int32_t bits = __float_as_int(e) + (((int32_t)k) << 23);
+  return __int_as_float(bits);
+}
+DEV void quat_to_mat(const float* q, float* M) {
+  float x = q[0], y = q[1], z = q[2], w = q[3];
+  float xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+  M[0] = fmaf(-2.0f, yy + zz, 1.0f); M[1] = 2.0f * (xy - wz);          M[2] = 2.0f * (xz + wy);
+  M[3] = 2.0f * (xy + wz);          M[4] = fmaf(-2.0f, xx + zz, 1.0f); M[5] = 2.0f * (yz - wx);
+  M[6] = 2.0f * (xz - wy);          M[7] = 2.0f * (yz + wx);          M[8] = fmaf(-2.0f, xx + yy, 1.0f);
+}
+DEV void mat_to_quat(const float* M, float* q) {
+  float tr = M[0] + M[4] + M[8];
+  if (tr > 0.0f) {
+    float s = sqrtf(tr + 1.0f) * 2.0f;
+    q[3] = 0.25f * s; q[0] = (M[7] - M[5]) / s; q[1] = (M[2] - M[6]) / s; q[2] = (M[3] - M[1]) / s;
+  } else if (M[0] > M[4] && M[0] > M[8]) {
+    float s = sqrtf(1.0f + M[0] - M[4] - M[8]) * 2.0f;
+    q[3] = (M[7] - M[5]) / s; q[0] = 0.25f * s; q[1] = (M[1] + M[3]) / s; q[2] = (M[2] + M[6]) / s;
+  } else if (M[4] > M[8]) {
+    float s = sqrtf(1.0f + M[4] - M[0] - M[8]) * 2.0f;
+    q[3] = (M[2] - M[6]) / s; q[0] = (M[1] + M[3]) / s; q[1] = 0.25f * s; q[2] = (M[5] + M[7]) / s;
+  } else {
+    float s = sqrtf(1.0f + M[8] - M[0] - M[4]) * 2.0f;
+    q[3] = (M[3] - M[1]) / s; q[0] = (M[2] + M[6]) / s; q[1] = (M[5] + M[7]) / s; q[2] = 0.25f * s;
+  }
+}
+DEV void crm(const float* a, const float* m, float* o) {
+  float t0[3], t1[3], t2[3];
+  cross3(a, m, t0);
+  cross3(a, m + 3, t1);
+  cross3(a + 3, m, t2);
+  o[0] = t0[0]; o[1] = t0[1]; o[2] = t0[2];
+  o[3] = t1[0] + t2[0]; o[4] = t1[1] + t2[1]; o[5] = t1[2] + t2[2];
+}
+
+// packed upper triangle of a symmetric 6x6: (i,j), i<=j
+#define SYM(i, j) ((i) * 6 - ((i) * ((i) - 1)) / 2 + ((j) - (i)))
+#define SYMG(A, i, j) ((i) <= (j) ? (A)[SYM(i, j)] : (A)[SYM(j, i)])
+
+// --------------------------------------------------------------- terrain --
+struct TerrainDev {
+  ShfTerrain t;
+  const int16_t* h;
+};
+
+DEV void terrain_query(const TerrainDev& T, float x, float y, float* h, float* n) {
+  if (T.t.rows == 0) { *h = 0.0f; n[0] = 0.0f; n[1] = 0.0f; n[2] = 1.0f; return; }
+  float inv = 1.0f / T.t.hscale;
+  float fx = (x + T.t.border) * inv, fy = (y + T.t.border) * inv;
+  float fi = rclampf(floorf(fx), 0.0f, (float)(T.t.rows - 2)), fj = rclampf(floorf(fy), 0.0f, (float)(T.t.cols - 2));
+  int i = (int)fi, j = (int)fj;
+  float u = rclampf(fx - fi, 0.0f, 1.0f), v = rclampf(fy - fj, 0.0f, 1.0f);
+  float vs = T.t.vscale;
+  const int16_t* row0 = T.h + (size_t)i * T.t.cols + j;
+  const int16_t* row1 = row0 + T.t.cols;
+  float h00 = (float)row0[0] * vs, h10 = (float)row1[0] * vs, h01 = (float)row0[1] * vs, h11 = (float)row1[1] * vs;
+  float gx, gy, hh;
+  if (u + v <= 1.0f) {
+    gx = h10 - h00; gy = h01 - h00;
+    hh = fmaf(v, gy, fmaf(u, gx, h00));
+  } else {
+    gx = h11 - h01; gy = h11 - h10;
+    hh = fmaf(1.0f - v, -gy, fmaf(1.0f - u, -gx, h11));
+  }
+  gx *= inv; gy *= inv;
+  float nz = 1.0f / sqrtf(fmaf(gy, gy, fmaf(gx, gx, 1.0f)));
+  *h = hh; n[0] = -gx * nz; n[1] = -gy * nz; n[2] = nz;
+}
+
+// ------------------------------------------------------------- LDS views --
+// per-env LDS working set (float offsets); sizes follow the model actually
+// loaded so that four 256-thread blocks fit one CU (160 KiB LDS).
+#define POSE_STRIDE 18 /* Rw[9] p[3] v[6]                                   */
+#define XCH_STRIDE 27  /* Ia[21] pa[6]                                      */
+#define PT_STRIDE 12   /* on r[3] n[3] f[3] ct bn                           */
+#define DOF_STRIDE 6   /* q qd tau0 dex qdd tau_cmd                         */
+#define ROOT_WORDS 16  /* pos[3] quat[4] lin[3] ang[3] spare[3]             */
+
+struct EnvLds {
+  float* pose;
+  float* acc;
+  float* xch;
+  float* pt;
+  float* dofb;
+  float* root;
+};
+
+// The contact-point region comes last: kernels that need post-physics scratch
+// reuse it and may ask for `min_tail` words there.
+__host__ __device__ inline int env_lds_words(int nb, int nd, int np, int min_tail = 0) {
+  int tail = np * PT_STRIDE;
+  if (tail < min_tail) tail = min_tail;
+  int w = nb * POSE_STRIDE + nb * 6 + nb * XCH_STRIDE + nd * DOF_STRIDE + ROOT_WORDS + tail;
+  return (w + 3) & ~3;
+}
+DEV EnvLds env_lds_carve(float* base, int nb, int nd, int np) {
+  EnvLds L;
+  L.pose = base;
+  L.acc = L.pose + nb * POSE_STRIDE;
+  L.xch = L.acc + nb * 6;
+  L.dofb = L.xch + nb * XCH_STRIDE;
+  L.root = L.dofb + nd * DOF_STRIDE;
+  L.pt = L.root + ROOT_WORDS;
+  return L;
+}
+
+// per-lane persistent body registers between phases of one sub-step
+struct BodyRegs {
+  float Rw[9], p[3], S[6], v[6], c[6];
+  float IA[21], pA[6], U[6], invD, u;
+};
+
+// Forward kinematics: pose, motion subspace, velocity, bias acceleration of
+// every reported body, level by level through LDS.
+template <int G>
+DEV void kinematics(const ShfModel* m, const EnvLds& L, int l, BodyRegs& B) {
+  const int nb = m->nb;
+  const bool isbody = l < nb;
+  const int jt = isbody ? m->jtype[l] : -1;
+  if (l == 0) {
+    quat_to_mat(L.root + 3, B.Rw);
+    B.p[0] = B.p[1] = B.p[2] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      B.v[k] = m->fixed_base ? 0.0f : L.root[10 + k];
+      B.v[3 + k] = m->fixed_base ? 0.0f : L.root[7 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) { B.S[k] = 0.0f; B.c[k] = 0.0f; }
+    float* o = L.pose;
+#pragma unroll
+    for (int k = 0; k < 9; k++) o[k] = B.Rw[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) o[9 + k] = B.p[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) o[12 + k] = B.v[k];
+  }
+  const int nk = m->nklevels;
+  for (int lev = 1; lev <= nk; lev++) {
+    GROUP_SYNC();
+    if (isbody && jt != SHF_JOINT_ROOT && m->klevel[l] == lev) {
+      const float* pp = L.pose + m->parent[l] * POSE_STRIDE;
+      float Rp[9], vp[6], tp[3], tr[9], Rj[9], t[3];
+#pragma unroll
+      for (int k = 0; k < 9; k++) Rp[k] = pp[k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) vp[k] = pp[12 + k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) tp[k] = m->tpos[l][k];
+#pragma unroll
+      for (int k = 0; k < 9; k++) tr[k] = m->trot[l][k];
+      mv3(Rp, tp, t);
+#pragma unroll
+      for (int k = 0; k < 3; k++) B.p[k] = pp[9 + k] + t[k];
+      mm3(Rp, tr, Rj);
+      if (jt == SHF_JOINT_WELD) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) B.Rw[k] = Rj[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { B.v[k] = vp[k]; B.S[k] = 0.0f; B.c[k] = 0.0f; }
+      } else {
+        float ax[3], aw[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) ax[k] = m->axis[l][k];
+        mv3(Rj, ax, aw);
+        const int d = m->dof[l];
+        const float qv = L.dofb[d * DOF_STRIDE], qdv = L.dofb[d * DOF_STRIDE + 1];
+        if (jt == SHF_JOINT_REVOLUTE) {
+          float sn, cs;
+          sincos_spec(qv, &sn, &cs);
+          float oc = 1.0f - cs;
+          float Rq[9] = {fmaf(oc, ax[0] * ax[0], cs),           fmaf(oc, ax[0] * ax[1], -(sn * ax[2])), fmaf(oc, ax[0] * ax[2], sn * ax[1]),
+                         fmaf(oc, ax[1] * ax[0], sn * ax[2]),    fmaf(oc, ax[1] * ax[1], cs),            fmaf(oc, ax[1] * ax[2], -(sn * ax[0])),
+                         fmaf(oc, ax[2] * ax[0], -(sn * ax[1])), fmaf(oc, ax[2] * ax[1], sn * ax[0]),    fmaf(oc, ax[2] * ax[2], cs)};
+          mm3(Rj, Rq, B.Rw);
+          cross3(B.p, aw, t);
+#pragma unroll
+          for (int k = 0; k < 3; k++) { B.S[k] = aw[k]; B.S[3 + k] = t[k]; }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 9; k++) B.Rw[k] = Rj[k];
+#pragma unroll
+          for (int k = 0; k < 3; k++) { B.p[k] = fmaf(aw[k], qv, B.p[k]); B.S[k] = 0.0f; B.S[3 + k] = aw[k]; }
+        }
+        float vJ[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) vJ[k] = B.S[k] * qdv;
+        crm(vp, vJ, B.c);
+#pragma unroll
+        for (int k = 0; k < 6; k++) B.v[k] = vp[k] + vJ[k];
+      }
+      float* o = L.pose + l * POSE_STRIDE;
+#pragma unroll
+      for (int k = 0; k < 9; k++) o[k] = B.Rw[k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) o[9 + k] = B.p[k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) o[12 + k] = B.v[k];
+    }
+  }
+  GROUP_SYNC();
+}
+
+// spatial inertia about O in world axes (packed) and velocity-product bias force
+DEV void body_inertia(const ShfModel* m, int b, BodyRegs& B) {
+  float com[3], cw[3], Ic[9], T[9];
+#pragma unroll
+  for (int k = 0; k < 3; k++) com[k] = m->com[b][k];
+  mv3(B.Rw, com, cw);
+#pragma unroll
+  for (int k = 0; k < 3; k++) cw[k] += B.p[k];
+  const float* I6 = m->inertia[b];
+  Ic[0] = I6[0]; Ic[1] = I6[1]; Ic[2] = I6[2];
+  Ic[3] = I6[1]; Ic[4] = I6[3]; Ic[5] = I6[4];
+  Ic[6] = I6[2]; Ic[7] = I6[4]; Ic[8] = I6[5];
+  mm3(B.Rw, Ic, T);
+  const float mass = m->mass[b];
+  const float c2 = dot3(cw, cw);
+#pragma unroll
+  for (int k = 0; k < 21; k++) B.IA[k] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = i; j < 3; j++) {
+      float iw = dot3(T + 3 * i, B.Rw + 3 * j);
+      float par = (i == j ? c2 : 0.0f) - cw[i] * cw[j];
+      B.IA[SYM(i, j)] = fmaf(mass, par, iw);
+    }
+  float h[3] = {mass * cw[0], mass * cw[1], mass * cw[2]};
+  B.IA[SYM(0, 4)] = -h[2]; B.IA[SYM(0, 5)] = h[1];
+  B.IA[SYM(1, 3)] = h[2];  B.IA[SYM(1, 5)] = -h[0];
+  B.IA[SYM(2, 3)] = -h[1]; B.IA[SYM(2, 4)] = h[0];
+  B.IA[SYM(3, 3)] = mass; B.IA[SYM(4, 4)] = mass; B.IA[SYM(5, 5)] = mass;
+  const float* v = B.v;
+  float J[9] = {B.IA[SYM(0, 0)], B.IA[SYM(0, 1)], B.IA[SYM(0, 2)], B.IA[SYM(0, 1)], B.IA[SYM(1, 1)],
+                B.IA[SYM(1, 2)], B.IA[SYM(0, 2)], B.IA[SYM(1, 2)], B.IA[SYM(2, 2)]};
+  float n[3], f[3], t[3], t2[3];
+  mv3(J, v, n);
+  cross3(h, v + 3, t);
+#pragma unroll
+  for (int k = 0; k < 3; k++) n[k] += t[k];
+  cross3(v, h, t);
+#pragma unroll
+  for (int k = 0; k < 3; k++) f[k] = fmaf(mass, v[3 + k], t[k]);
+  cross3(v, n, t);
+  cross3(v + 3, f, t2);
+#pragma unroll
+  for (int k = 0; k < 3; k++) B.pA[k] = t[k] + t2[k];
+  cross3(v, f, t);
+#pragma unroll
+  for (int k = 0; k < 3; k++) B.pA[3 + k] = t[k];
+}
+
+struct StepCtx {
+  const ShfModel* m;   // LDS copy
+  ShfSimParams sp;
+  TerrainDev terr;
+};
+
+// One gym.simulate() for one env, executed by the G lanes of its group.
+//   dofb[d]: q, qd in;  tau_cmd (explicit effort), pos/vel targets via pt_tgt/vt_tgt (LDS, may be null)
+//   fext: world force per reported body (global memory, this env) or nullptr
+//   contact_out: LDS/global float[nb*3] written by body lanes (may be nullptr)
+template <int G>
+DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt, const float* vel_tgt,
+                 const float* fext, float mu_shape, float* contact_out) {
+  const ShfModel* m = C.m;
+  const int nb = m->nb, nd = m->nd, np = m->np;
+  const float dt = C.sp.dt;
+  const float gon = (float)m->gravity_on;
+  const float g[3] = {C.sp.gravity[0] * gon, C.sp.gravity[1] * gon, C.sp.gravity[2] * gon};
+  const bool isbody = l < nb;
+  const bool isdyn = isbody && m->dyn[l] == l;
+  const int jt = isbody ? m->jtype[l] : -1;
+  const bool moving = isdyn && jt != SHF_JOINT_ROOT;
+  const int mylevel = isbody ? m->level[l] : -1;
+
+  BodyRegs B;
+  kinematics<G>(m, L, l, B);
+  if (isdyn) body_inertia(m, l, B);
+
+  // external forces at the CoM of reported bodies, folded in ascending body order
+  if (fext) {
+    if (isbody) {
+      float F[3] = {fext[3 * l], fext[3 * l + 1], fext[3 * l + 2]};
+      float com[3] = {m->com[l][0], m->com[l][1], m->com[l][2]}, cw[3], t[3];
+      mv3(B.Rw, com, cw);
+#pragma unroll
+      for (int k = 0; k < 3; k++) cw[k] += B.p[k];
+      cross3(cw, F, t);
+      float* o = L.xch + l * XCH_STRIDE;
+      o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = F[0]; o[4] = F[1]; o[5] = F[2];
+      o[6] = (F[0] == 0.0f && F[1] == 0.0f && F[2] == 0.0f) ? 0.0f : 1.0f;
+    }
+    GROUP_SYNC();
+    if (isdyn) {
+      for (int b = l; b < nb; b++) {
+        if (m->dyn[b] != l) continue;
+        const float* o = L.xch + b * XCH_STRIDE;
+        if (o[6] == 0.0f) continue;
+#pragma unroll
+        for (int k = 0; k < 6; k++) B.pA[k] -= o[k];
+      }
+    }
+    GROUP_SYNC();
+  }
+
+  // contacts: one lane per sample point, results parked in LDS
+  const float kc = C.sp.contact_k, dc = C.sp.contact_d, veps = C.sp.friction_vel;
+  const float beta = fmaf(kc, dt, dc);
+  const float mu = 0.5f * (mu_shape + C.terr.t.friction);
+  for (int i = l; i < np; i += G) {
+    const int b = m->pt_body[i];
+    const float* pb = L.pose + b * POSE_STRIDE;
+    float Rb[9], lp[3] = {m->pt_pos[i][0], m->pt_pos[i][1], m->pt_pos[i][2]}, r[3], n[3], h;
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rb[k] = pb[k];
+    mv3(Rb, lp, r);
+#pragma unroll
+    for (int k = 0; k < 3; k++) r[k] += pb[9 + k];
+    terrain_query(C.terr, L.root[0] + r[0], L.root[1] + r[1], &h, n);
+    const float rad = m->pt_radius[i];
+    const float phi = fmaf(L.root[2] + r[2] - h, n[2], -rad);
+    float* o = L.pt + i * PT_STRIDE;
+    float on = 0.0f;
+    if (phi < 0.0f) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) r[k] = fmaf(-rad, n[k], r[k]);
+      float vb[6], vp[3], t[3];
+#pragma unroll
+      for (int k = 0; k < 6; k++) vb[k] = pb[12 + k];
+      cross3(vb, r, t);
+#pragma unroll
+      for (int k = 0; k < 3; k++) vp[k] = fmaf(dt, g[k], vb[3 + k] + t[k]);
+      const float vn = dot3(n, vp);
+      const float fn = fmaf(-beta, vn, rminf(-kc * phi, beta * C.sp.max_depen_vel));
+      if (fn > 0.0f) {
+        float vt[3] = {fmaf(-vn, n[0], vp[0]), fmaf(-vn, n[1], vp[1]), fmaf(-vn, n[2], vp[2])};
+        const float vtn = sqrtf(dot3(vt, vt));
+        const float ct = mu * fn / rmaxf(vtn, veps);
+        on = 1.0f;
+        o[10] = ct;
+        o[11] = beta;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          o[1 + k] = r[k];
+          o[4 + k] = n[k];
+          o[7 + k] = fmaf(fn, n[k], -(ct * vt[k]));
+        }
+      }
+    }
+    o[0] = on;
+  }
+  GROUP_SYNC();
+  if (isdyn) {
+    const int i0 = m->pt_start[l], i1 = i0 + m->pt_count[l];
+    for (int i = i0; i < i1; i++) {
+      const float* o = L.pt + i * PT_STRIDE;
+      if (o[0] == 0.0f) continue;
+      const float r[3] = {o[1], o[2], o[3]}, n[3] = {o[4], o[5], o[6]}, f0[3] = {o[7], o[8], o[9]};
+      float t[3], wn[6];
+      cross3(r, f0, t);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { B.pA[k] -= t[k]; B.pA[3 + k] -= f0[k]; }
+      cross3(r, n, t);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { wn[k] = t[k]; wn[3 + k] = n[k]; }
+      const float a = dt * o[10], bb = dt * (o[11] - o[10]);
+      const float r2 = dot3(r, r);
+#pragma unroll
+      for (int i2 = 0; i2 < 3; i2++)
+#pragma unroll
+        for (int j2 = i2; j2 < 3; j2++)
+          B.IA[SYM(i2, j2)] = fmaf(a, (i2 == j2 ? r2 : 0.0f) - r[i2] * r[j2], B.IA[SYM(i2, j2)]);
+      B.IA[SYM(0, 4)] = fmaf(a, -r[2], B.IA[SYM(0, 4)]); B.IA[SYM(0, 5)] = fmaf(a, r[1], B.IA[SYM(0, 5)]);
+      B.IA[SYM(1, 3)] = fmaf(a, r[2], B.IA[SYM(1, 3)]);  B.IA[SYM(1, 5)] = fmaf(a, -r[0], B.IA[SYM(1, 5)]);
+      B.IA[SYM(2, 3)] = fmaf(a, -r[1], B.IA[SYM(2, 3)]); B.IA[SYM(2, 4)] = fmaf(a, r[0], B.IA[SYM(2, 4)]);
+      B.IA[SYM(3, 3)] += a; B.IA[SYM(4, 4)] += a; B.IA[SYM(5, 5)] += a;
+#pragma unroll
+      for (int i2 = 0; i2 < 6; i2++) {
+        const float bw = bb * wn[i2];
+#pragma unroll
+        for (int j2 = i2; j2 < 6; j2++) B.IA[SYM(i2, j2)] = fmaf(bw, wn[j2], B.IA[SYM(i2, j2)]);
+      }
+    }
+  }
+
+  // joint-space efforts: one lane per dof
+  if (l < nd) {
+    float* D = L.dofb + l * DOF_STRIDE;
+    const float q = D[0], qd = D[1];
+    float t0 = 0.0f, de = m->armature[l];
+    const int mode = m->drive_mode[l];
+    if (mode == SHF_DOF_MODE_EFFORT) {
+      t0 = D[5];
+    } else if (mode == SHF_DOF_MODE_POS || mode == SHF_DOF_MODE_VEL) {
+      const float kp = mode == SHF_DOF_MODE_POS ? m->kp[l] : 0.0f, kd = m->kd[l];
+      const float tq = pos_tgt ? pos_tgt[l] : 0.0f, tv = (mode == SHF_DOF_MODE_VEL && vel_tgt) ? vel_tgt[l] : 0.0f;
+      const float bj = fmaf(dt, kp, kd);
+      const float est = fmaf(kp, tq - q, kd * (tv - qd));
+      const float lim = m->effort[l];
+      if (lim > 0.0f && fabsf(est) > lim) {
+        t0 = rclampf(est, -lim, lim);
+      } else {
+        t0 = fmaf(kp, tq - q, fmaf(kd, tv, -(bj * qd)));
+        de = fmaf(dt, bj, de);
+      }
+    }
+    const float jd = m->damping[l];
+    if (jd > 0.0f) { t0 = fmaf(-jd, qd, t0); de = fmaf(dt, jd, de); }
+    const float lo = m->lower[l], up = m->upper[l];
+    const float viol = q < lo ? lo - q : (q > up ? up - q : 0.0f);
+    if (viol != 0.0f) {
+      const float bl = fmaf(dt, C.sp.limit_k, C.sp.limit_d);
+      t0 = fmaf(C.sp.limit_k, viol, fmaf(-bl, qd, t0));
+      de = fmaf(dt, bl, de);
+    }
+    D[2] = t0; D[3] = de;
+  }
+  GROUP_SYNC();
+
+  // inward pass
+  const int nl = m->nlevels;
+  for (int lev = nl; lev >= 1; lev--) {
+    if (moving && mylevel == lev) {
+      const int d = m->dof[l];
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        float acc = SYMG(B.IA, i, 0) * B.S[0];
+#pragma unroll
+        for (int j = 1; j < 6; j++) acc = fmaf(SYMG(B.IA, i, j), B.S[j], acc);
+        B.U[i] = acc;
+      }
+      float D = B.S[0] * B.U[0];
+#pragma unroll
+      for (int j = 1; j < 6; j++) D = fmaf(B.S[j], B.U[j], D);
+      D += L.dofb[d * DOF_STRIDE + 3];
+      float sp = B.S[0] * B.pA[0];
+#pragma unroll
+      for (int j = 1; j < 6; j++) sp = fmaf(B.S[j], B.pA[j], sp);
+      const float invD = 1.0f / D;
+      B.invD = invD;
+      B.u = L.dofb[d * DOF_STRIDE + 2] - sp;
+      float W[6];
+#pragma unroll
+      for (int i = 0; i < 6; i++) W[i] = B.U[i] * invD;
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i; j < 6; j++) B.IA[SYM(i, j)] = fmaf(-B.U[i], W[j], B.IA[SYM(i, j)]);
+      float pa[6];
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        float acc = SYMG(B.IA, i, 0) * B.c[0];
+#pragma unroll
+        for (int j = 1; j < 6; j++) acc = fmaf(SYMG(B.IA, i, j), B.c[j], acc);
+        pa[i] = fmaf(W[i], B.u, B.pA[i] + acc);
+      }
+      float* o = L.xch + l * XCH_STRIDE;
+#pragma unroll
+      for (int k = 0; k < 21; k++) o[k] = B.IA[k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) { B.pA[k] = pa[k]; o[21 + k] = pa[k]; }
+    }
+    GROUP_SYNC();
+    if (isdyn && mylevel == lev - 1) {
+      const int k0 = m->child_start[l], k1 = k0 + m->child_count[l];
+      for (int kk = k0; kk < k1; kk++) {
+        const float* o = L.xch + m->child_list[kk] * XCH_STRIDE;
+#pragma unroll
+        for (int k = 0; k < 21; k++) B.IA[k] += o[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) B.pA[k] += o[21 + k];
+      }
+    }
+    GROUP_SYNC();
+  }
+
+  // root acceleration (primed)
+  float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  if (l == 0) {
+    if (m->fixed_base) {
+      a[3] = -g[0]; a[4] = -g[1]; a[5] = -g[2];
+    } else {
+      float Lm[6][6], Dg[6], y[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        float d = B.IA[SYM(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; k++) d = fmaf(-(Lm[j][k] * Lm[j][k]), Dg[k], d);
+        Dg[j] = d;
+        const float id = 1.0f / d;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+          float v = B.IA[SYM(j, i)];
+#pragma unroll
+          for (int k = 0; k < j; k++) v = fmaf(-(Lm[i][k] * Lm[j][k]), Dg[k], v);
+          Lm[i][j] = v * id;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        float v = -B.pA[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) v = fmaf(-Lm[i][k], y[k], v);
+        y[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < 6; i++) y[i] = y[i] / Dg[i];
+#pragma unroll
+      for (int i = 5; i >= 0; i--) {
+        float v = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) v = fmaf(-Lm[k][i], a[k], v);
+        a[i] = v;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) L.acc[k] = a[k];
+  }
+  // outward pass
+  for (int lev = 1; lev <= nl; lev++) {
+    GROUP_SYNC();
+    if (moving && mylevel == lev) {
+      const float* pa = L.acc + m->dyn[m->parent[l]] * 6;
+      float ap[6];
+#pragma unroll
+      for (int i = 0; i < 6; i++) ap[i] = pa[i] + B.c[i];
+      float ua = B.U[0] * ap[0];
+#pragma unroll
+      for (int j = 1; j < 6; j++) ua = fmaf(B.U[j], ap[j], ua);
+      const float qdd = (B.u - ua) * B.invD;
+      L.dofb[m->dof[l] * DOF_STRIDE + 4] = qdd;
+#pragma unroll
+      for (int i = 0; i < 6; i++) { a[i] = fmaf(B.S[i], qdd, ap[i]); L.acc[l * 6 + i] = a[i]; }
+    }
+  }
+  GROUP_SYNC();
+
+  // net contact force per reported body
+  if (contact_out) {
+    for (int i = l; i < np; i += G) {
+      float* o = L.pt + i * PT_STRIDE;
+      if (o[0] == 0.0f) continue;
+      const float* ab = L.acc + m->dyn[m->pt_body[i]] * 6;
+      const float r[3] = {o[1], o[2], o[3]}, n[3] = {o[4], o[5], o[6]};
+      float al[3] = {ab[0], ab[1], ab[2]}, t[3], ap[3];
+      cross3(al, r, t);
+#pragma unroll
+      for (int k = 0; k < 3; k++) ap[k] = ab[3 + k] + t[k];
+      const float an = dot3(n, ap);
+      const float ct = o[10], bn = o[11];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const float Ba = fmaf(bn - ct, an * n[k], ct * ap[k]);
+        o[7 + k] = fmaf(-dt, Ba, o[7 + k]);
+      }
+    }
+    GROUP_SYNC();
+    if (isbody) {
+      float f[3] = {0.0f, 0.0f, 0.0f};
+      const int dl = m->dyn[l];
+      const int i0 = m->pt_start[dl], i1 = i0 + m->pt_count[dl];
+      for (int i = i0; i < i1; i++) {
+        const float* o = L.pt + i * PT_STRIDE;
+        if (o[0] == 0.0f || m->pt_body[i] != l) continue;
+        f[0] += o[7]; f[1] += o[8]; f[2] += o[9];
+      }
+      contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];
+    }
+  }
+
+  // semi-implicit Euler
+  if (l < nd) {
+    float* D = L.dofb + l * DOF_STRIDE;
+    const float vl = m->vel_limit[l];
+    const float qd = rclampf(fmaf(dt, D[4], D[1]), -vl, vl);
+    D[1] = qd;
+    D[0] = fmaf(dt, qd, D[0]);
+  }
+  if (l == 0 && !m->fixed_base) {
+    float* Rt = L.root;
+    float ang[3] = {Rt[10], Rt[11], Rt[12]}, lin[3] = {Rt[7], Rt[8], Rt[9]}, wxv[3];
+    cross3(ang, lin, wxv);
+    const float damp = 1.0f / fmaf(dt, C.sp.angular_damping, 1.0f);
+    float wn[3], vn[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      wn[k] = fmaf(dt, a[k], ang[k]) * damp;
+      vn[k] = fmaf(dt, a[3 + k] + g[k] + wxv[k], lin[k]);
+    }
+    const float wmag = sqrtf(dot3(wn, wn)), wmax = C.sp.max_ang_vel;
+    if (wmag > wmax) {
+      const float sc2 = wmax / wmag;
+#pragma unroll
+      for (int k = 0; k < 3; k++) wn[k] *= sc2;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { Rt[10 + k] = wn[k]; Rt[7 + k] = vn[k]; Rt[k] = fmaf(dt, vn[k], Rt[k]); }
+    const float hx = 0.5f * dt * wn[0], hy = 0.5f * dt * wn[1], hz = 0.5f * dt * wn[2];
+    const float x = Rt[3], y = Rt[4], z = Rt[5], ww = Rt[6];
+    const float nx = x + fmaf(hx, ww, fmaf(hy, z, -(hz * y)));
+    const float ny = y + fmaf(hy, ww, fmaf(hz, x, -(hx * z)));
+    const float nz = z + fmaf(hz, ww, fmaf(hx, y, -(hy * x)));
+    const float nw = ww - fmaf(hx, x, fmaf(hy, y, hz * z));
+    const float inv = 1.0f / sqrtf(fmaf(nw, nw, fmaf(nz, nz, fmaf(ny, ny, nx * nx))));
+    Rt[3] = nx * inv; Rt[4] = ny * inv; Rt[5] = nz * inv; Rt[6] = nw * inv;
+  }
+  GROUP_SYNC();
+}
+
+// rigid_body_state rows of this env -> `stage` (LDS, nb*13 floats); caller copies out coalesced
+template <int G>
+DEV void body_states(const ShfModel* m, const EnvLds& L, int l, float* stage) {
+  BodyRegs B;
+  kinematics<G>(m, L, l, B);
+  if (l < m->nb) {
+    float* o = stage + 13 * l;
+    float t[3], q[4];
+#pragma unroll
+    for (int k = 0; k < 3; k++) o[k] = L.root[k] + B.p[k];
+    mat_to_quat(B.Rw, q);
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[3 + k] = q[k];
+    cross3(B.v, B.p, t);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { o[7 + k] = B.v[3 + k] + t[k]; o[10 + k] = B.v[k]; }
+  }
+  GROUP_SYNC();
+}

@@ -290,11 +290,16 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
     m.fixed_base = int(fix_base_link)
     m.gravity_on = int(not disable_gravity)
     m.nlevels = max(level)
+    klevel = [0] * nb
+    for b in range(1, nb):
+        klevel[b] = klevel[parent[b]] + 1
+    m.nklevels = max(klevel)
     dof_names: List[str] = []
     for b in range(nb):
         m.parent[b] = parent[b]
         m.jtype[b] = jtype[b]
         m.level[b] = level[b]
+        m.klevel[b] = klevel[b]
         m.dyn[b] = dyn[b]
         m.dof[b] = -1
         for k in range(3):

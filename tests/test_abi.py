@@ -1,0 +1,65 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950,
+loads, and exports every symbol include/shifu_amd.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from shifu_amd.build import build_native
+    return build_native()
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "shifu_amd.h")).read()
+    return sorted(set(re.findall(r"\b(shf_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_are_exported(libpath):
+    lib = ctypes.CDLL(libpath)
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/shifu_amd.h but not exported"
+
+
+def test_binding_table_covers_header(libpath):
+    from shifu_amd import _lib
+    assert set(_declared()) == set(_lib.EXPORTS)
+
+
+def test_struct_sizes_match_header(libpath, tmp_path):
+    """ctypes mirrors in shifu_amd/_abi.py must have the C layout."""
+    import subprocess
+    from shifu_amd import _abi
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "shifu_amd.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n",'
+                   'sizeof(ShfModel),sizeof(ShfSimParams),sizeof(ShfTerrain),sizeof(ShfA1TaskParams),sizeof(ShfBoxDesc));}')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(t) for t in (_abi.ShfModel, _abi.ShfSimParams, _abi.ShfTerrain, _abi.ShfA1TaskParams,
+                                       _abi.ShfBoxDesc)]
+    assert got == want
+
+
+def test_error_path_without_gpu(libpath):
+    """Argument validation happens on the host and reports through shf_last_error."""
+    from shifu_amd import _abi, _lib
+    l = _lib.lib()
+    h = ctypes.c_void_p()
+    p = _abi.ShfSimParams()
+    p.dt = 0.0
+    assert l.shf_sim_create(ctypes.byref(p), ctypes.byref(h)) != 0
+    assert b"dt" in l.shf_last_error()
+    p.dt = 0.005
+    assert l.shf_sim_create(ctypes.byref(p), ctypes.byref(h)) == 0
+    assert l.shf_sim_finalize(h, 4, 0) != 0 and b"articulation" in l.shf_last_error()
+    with pytest.raises(_lib.BackendError):
+        _lib.check(l.shf_sim_step(h, None))
+    l.shf_sim_destroy(h)

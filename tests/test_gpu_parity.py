@@ -1,0 +1,273 @@
+"""HIP kernels vs the CPU oracle on identical inputs, through the C ABI.
+
+The kernels are specified to reproduce the oracle's float arithmetic operation
+for operation (shifu_amd/csrc/shf_device.h), so the comparisons below are
+*bit-exact* for every float tensor, not just within the north-star's 1e-4
+relative tolerance over 1000 steps -- which follows a fortiori and is also
+asserted explicitly in test_a1_1000_steps_within_north_star_tolerance.
+"""
+import numpy as np
+import pytest
+
+from shifu_amd import _abi
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU is visible (these tests never fall back to CPU)")
+
+
+def _terrain(rng, rows=60, cols=70, rough=True):
+    t = _abi.ShfTerrain()
+    t.rows, t.cols, t.hscale, t.vscale, t.border, t.friction = rows, cols, 0.1, 0.005, 2.0, 1.0
+    h = np.zeros((rows, cols), np.int16)
+    if rough:
+        h[:] = rng.integers(-12, 12, size=(rows, cols))
+        h[20:30, 20:40] += 40   # a plateau with vertical faces
+        h[35:50, 10:30] = (np.arange(15)[:, None] * 6).astype(np.int16)  # a ramp
+    return t, h
+
+
+def _random_states(m, n, rng, z_lo=0.15, z_hi=0.45, xy_hi=3.0):
+    dof = np.zeros((n * m.nd, 2), np.float32)
+    root = np.zeros((n, 13), np.float32)
+    q0 = np.array(H_DEFAULT_Q, np.float32)
+    for e in range(n):
+        dof[e * m.nd:(e + 1) * m.nd, 0] = q0 + rng.uniform(-0.4, 0.4, m.nd)
+        dof[e * m.nd:(e + 1) * m.nd, 1] = rng.uniform(-3, 3, m.nd)
+        quat = np.array([0, 0, 0, 1.0]) + rng.normal(0, 0.25, 4)
+        quat /= np.linalg.norm(quat)
+        root[e] = np.concatenate([[rng.uniform(0.5, xy_hi), rng.uniform(0.5, xy_hi), rng.uniform(z_lo, z_hi)], quat,
+                                  rng.uniform(-1, 1, 3), rng.uniform(-2, 2, 3)])
+    return dof, root
+
+
+H_DEFAULT_Q = [0.1, 0.8, -1.5, 0.1, 0.8, -1.5, -0.1, 0.8, -1.5, -0.1, 0.8, -1.5]
+
+
+def _make_sim(cm, sp, n, terrain=None, heights=None, group=64, env_off=0):
+    from shifu_amd.backend import Sim
+    sim = Sim(sp, "cuda:0")
+    if terrain is None:
+        sim.set_plane(1.0)
+    else:
+        sim.set_heightfield(heights, terrain.hscale, terrain.vscale, terrain.border, terrain.friction)
+    sim.set_articulation(cm.blob)
+    sim.finalize(n, env_off, group=group)
+    return sim
+
+
+@pytest.mark.parametrize("group", [64, 32])
+@pytest.mark.parametrize("rough", [False, True])
+def test_simulate_matches_oracle_bitwise(oracle, rough, group):
+    """gym.simulate parity: 64 envs in and out of contact, explicit efforts, external pushes, 30 sub-steps."""
+    _need_gpu()
+    rng = np.random.default_rng(11)
+    cm = H.a1_model()
+    m = cm.blob
+    sp = H.sim_params(angular_damping=0.5)
+    n = 64
+    terr, hs = _terrain(rng, rough=rough)
+    dof, root = _random_states(m, n, rng)
+    fr = rng.uniform(0.5, 1.25, n).astype(np.float32)
+    sim = _make_sim(cm, sp, n, terr if rough else None, hs if rough else None, group=group)
+    T = sim.tensors
+    T[_abi.T_SIM_DOF].copy_(torch.from_numpy(dof))
+    T[_abi.T_SIM_ROOT].copy_(torch.from_numpy(root))
+    T[_abi.T_FRICTION].copy_(torch.from_numpy(fr))
+    for it in range(30):
+        eff = rng.uniform(-25, 25, n * m.nd).astype(np.float32)
+        force = np.zeros((n * m.nb, 3), np.float32)
+        push = it % 3 == 0
+        if push:
+            force[::m.nb] = rng.uniform(-5, 5, (n, 3))
+            force[3::m.nb] = rng.uniform(-2, 2, (n, 3))   # also a leg body
+            sim.apply_body_force(torch.from_numpy(force).cuda())
+        sim.set_dof_command(_abi.T_EFFORT, torch.from_numpy(eff).cuda())
+        sim.step()
+        sim.refresh(_abi.REFRESH_ALL)
+        contact, bstate = oracle.step(m, sp, n, dof, root, terrain=terr if rough else None, heights=hs if rough else None,
+                                      effort=eff, body_force=force if push else None, friction=fr, want_contact=True,
+                                      want_body_state=True)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(T[_abi.T_DOF_STATE].cpu().numpy(), dof, err_msg=f"dof_state step {it}")
+        np.testing.assert_array_equal(T[_abi.T_ROOT_STATE].cpu().numpy(), root, err_msg=f"root_state step {it}")
+        np.testing.assert_array_equal(T[_abi.T_CONTACT].cpu().numpy(), contact, err_msg=f"contact step {it}")
+        np.testing.assert_array_equal(T[_abi.T_BODY_STATE].cpu().numpy(), bstate, err_msg=f"body_state step {it}")
+    assert np.isfinite(root).all()
+    assert (np.abs(contact).sum(1) > 0).any(), "test must exercise contacts"
+
+
+def _a1_buffers(cm, tp, n, rng, terr_rows, terr_cols):
+    m = cm.blob
+    nb, nd = m.nb, m.nd
+    from shifu_amd.a1_task import height_points
+    P = tp.num_height_points
+    b = {}
+    dof = np.zeros((n * nd, 2), np.float32)
+    dof[:, 0] = np.tile(np.array(H_DEFAULT_Q, np.float32), n)
+    torigins = np.zeros((tp.max_terrain_level, tp.num_terrain_cols, 3), np.float32)
+    for i in range(tp.max_terrain_level):
+        for j in range(tp.num_terrain_cols):
+            torigins[i, j] = [1.5 + 0.3 * i, 1.0 + 0.15 * j, 0.02 * ((i + j) % 3)]
+    levels = rng.integers(0, tp.max_terrain_level, n).astype(np.int64)
+    types = (np.arange(n) * tp.num_terrain_cols // n).astype(np.int64)
+    origins = torigins[levels, types].copy()
+    root = np.zeros((n, 13), np.float32)
+    root[:, :3] = origins + np.array([0, 0, 0.42], np.float32)
+    root[:, 6] = 1.0
+    b["dof_state"], b["root_state"] = dof, root
+    b["body_state"] = np.zeros((n * nb, 13), np.float32)
+    b["contact"] = np.zeros((n * nb, 3), np.float32)
+    b["friction"] = rng.uniform(0.5, 1.25, n).astype(np.float32)
+    b["actions"] = np.zeros((n, nd), np.float32)
+    b["obs"] = np.zeros((n, 12 + 2 * nd + 3 * nd + P), np.float32)
+    b["rew"] = np.zeros(n, np.float32)
+    b["reset"] = np.zeros(n, np.uint8)
+    b["timeout"] = np.zeros(n, np.uint8)
+    b["ep_len"] = rng.integers(0, 500, n).astype(np.int64)   # staggered so time-outs happen early
+    b["command"] = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    b["history"] = np.zeros((n, nd, 3), np.float32)
+    b["rew_sums"] = np.zeros((6, n), np.float32)
+    b["torques"] = np.zeros((n, nd), np.float32)
+    b["base_vel"] = np.zeros((n, 9), np.float32)
+    b["heights"] = np.zeros((n, P), np.float32)
+    b["hpoints"] = height_points()
+    push = np.zeros((n, nb, 3), np.float32)
+    push[:, tp.base_body] = rng.uniform(-5, 5, (n, 3))
+    b["push"] = push
+    b["origins"] = origins
+    b["levels"], b["types"], b["torigins"] = levels, types, torigins
+    b["reset_count"] = np.zeros(n, np.int32)
+    b["done_sums"] = np.zeros((8, n), np.float32)
+    return b
+
+
+_SIM_T = {"dof_state": _abi.T_DOF_STATE, "root_state": _abi.T_ROOT_STATE, "body_state": _abi.T_BODY_STATE,
+          "contact": _abi.T_CONTACT, "friction": _abi.T_FRICTION}
+_A1_T = {"actions": _abi.A1_ACTIONS, "obs": _abi.A1_OBS, "rew": _abi.A1_REW, "reset": _abi.A1_RESET,
+         "timeout": _abi.A1_TIMEOUT, "ep_len": _abi.A1_EP_LEN, "command": _abi.A1_COMMAND,
+         "history": _abi.A1_HISTORY, "rew_sums": _abi.A1_REW_SUMS, "torques": _abi.A1_TORQUES,
+         "base_vel": _abi.A1_BASE_VEL, "heights": _abi.A1_HEIGHTS, "hpoints": _abi.A1_HPOINTS, "push": _abi.A1_PUSH,
+         "origins": _abi.A1_ORIGINS, "levels": _abi.A1_LEVELS, "types": _abi.A1_TYPES, "torigins": _abi.A1_TORIGINS,
+         "reset_count": _abi.A1_RESET_COUNT, "done_sums": _abi.A1_DONE_SUMS}
+
+
+def _upload(sim, task, bufs):
+    for k, tid in _SIM_T.items():
+        sim.tensors[tid].copy_(torch.from_numpy(bufs[k]).reshape(sim.tensors[tid].shape))
+    for k, tid in _A1_T.items():
+        task.tensors[tid].copy_(torch.from_numpy(bufs[k]).reshape(task.tensors[tid].shape))
+
+
+def _compare(sim, task, bufs, tag, exact=True, tol=0.0):
+    torch.cuda.synchronize()
+    worst = 0.0
+    for k, tid in list(_SIM_T.items()) + list(_A1_T.items()):
+        t = (sim.tensors if k in _SIM_T else task.tensors)[tid].cpu().numpy().reshape(bufs[k].shape)
+        if exact:
+            np.testing.assert_array_equal(t, bufs[k], err_msg=f"{k} {tag}")
+        elif t.dtype.kind == "f":
+            d = np.abs(t - bufs[k]) / np.maximum(1.0, np.abs(bufs[k]))
+            worst = max(worst, float(d.max()))
+            assert d.max() <= tol, f"{k} {tag}: rel err {d.max()}"
+        else:
+            np.testing.assert_array_equal(t, bufs[k], err_msg=f"{k} {tag}")
+    return worst
+
+
+def _a1_setup(n, rough, seed=5, group=64, env_off=0):
+    from shifu_amd.a1_task import a1_task_params
+    from shifu_amd.backend import A1Task
+    rng = np.random.default_rng(seed)
+    cm = H.a1_model()
+    sp = H.sim_params(angular_damping=0.5)
+    tp = a1_task_params(cm, num_rows=4, num_cols=5, env_length=0.8)
+    terr, hs = _terrain(rng, rows=80, cols=60, rough=rough)
+    bufs = _a1_buffers(cm, tp, n, rng, terr.rows, terr.cols)
+    sim = _make_sim(cm, sp, n, terr, hs, group=group, env_off=env_off)
+    task = A1Task(sim, tp)
+    _upload(sim, task, bufs)
+    return cm, sp, tp, terr, hs, bufs, sim, task, rng
+
+
+@pytest.mark.parametrize("group", [64, 32])
+@pytest.mark.parametrize("rough", [False, True])
+def test_fused_a1_step_matches_oracle_bitwise(oracle, rough, group):
+    """ShifuVecEnv.step for A1Conditional: physics x5, heights, termination, six reward
+    terms, on-device reset with curriculum, observations, history -- 120 vec-steps."""
+    _need_gpu()
+    n = 96
+    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, rough, group=group, env_off=1000)
+    resets = 0
+    for it in range(120):
+        raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32) * 1.5
+        slot = task.step(torch.from_numpy(raw).cuda())
+        oracle.a1_step(cm.blob, sp, tp, n, 1000, bufs, raw, terrain=terr, heights=hs)
+        _compare(sim, task, bufs, f"step {it}")
+        stats = task.tensors[_abi.A1_STATS][slot].cpu().numpy()
+        np.testing.assert_array_equal(stats, oracle.a1_stats(tp, n, bufs["done_sums"]), err_msg=f"stats step {it}")
+        resets += int(bufs["reset"].sum())
+    assert resets > n // 4, "the run must exercise resets (time-outs and base contacts)"
+    assert np.isfinite(bufs["obs"]).all()
+
+
+def test_a1_1000_steps_within_north_star_tolerance(oracle):
+    """North-star bar: per-step dof_pos / dof_vel / root_state within 1e-4 relative of the
+    reference (here: the oracle) over 1000 steps.  Checked every 50 steps."""
+    _need_gpu()
+    n = 32
+    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, seed=9)
+    worst = 0.0
+    for it in range(1000):
+        raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32)
+        task.step(torch.from_numpy(raw).cuda())
+        oracle.a1_step(cm.blob, sp, tp, n, 0, bufs, raw, terrain=terr, heights=hs)
+        if it % 50 == 49:
+            worst = max(worst, _compare(sim, task, bufs, f"step {it}", exact=False, tol=1e-4))
+    assert worst <= 1e-4
+
+
+def test_shard_invariance_of_fused_step():
+    """env e of a shard starting at global id g must evolve exactly like
+    global env g+e of an unsharded run (RNG keyed by global id)."""
+    _need_gpu()
+    n = 64
+    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, seed=21, env_off=0)
+    half = {}
+    for k, v in bufs.items():
+        if k in ("hpoints", "torigins"):
+            half[k] = v.copy()
+        elif k in ("rew_sums", "done_sums"):
+            half[k] = np.ascontiguousarray(v[:, n // 2:])
+        else:
+            rows = v.shape[0] // n
+            half[k] = np.ascontiguousarray(v[n // 2 * rows:])
+    from shifu_amd.backend import A1Task
+    sim2 = _make_sim(cm, sp, n // 2, terr, hs, env_off=n // 2)
+    task2 = A1Task(sim2, tp)
+    _upload(sim2, task2, half)
+    for it in range(150):
+        raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32) * 1.5
+        task.step(torch.from_numpy(raw).cuda())
+        task2.step(torch.from_numpy(raw[n // 2:]).cuda())
+    torch.cuda.synchronize()
+    for tid in (_abi.A1_OBS, _abi.A1_REW, _abi.A1_COMMAND, _abi.A1_EP_LEN, _abi.A1_RESET_COUNT):
+        a = task.tensors[tid][n // 2:].cpu().numpy()
+        b = task2.tensors[tid].cpu().numpy()
+        np.testing.assert_array_equal(a, b)
+    assert int(task.tensors[_abi.A1_RESET_COUNT].sum()) > 0
+
+
+def test_backend_fails_loudly_without_library(monkeypatch):
+    """No silent CPU fallback: a missing .so must raise."""
+    import shifu_amd._lib as L
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "_PATH", "/nonexistent/libshifu_amd.so")
+    with pytest.raises(L.BackendError):
+        L.lib()
