@@ -280,8 +280,14 @@ int shf_a1_create(ShfSim* sim, const ShfA1TaskParams* params, ShfA1Task** out);
 int shf_a1_destroy(ShfA1Task* task);
 int shf_a1_layout(const ShfA1Task* task, int32_t id, int64_t shape[4], int32_t* ndim, int32_t* dtype);
 int shf_a1_bind(ShfA1Task* task, int32_t id, void* device_ptr);
-/* ShifuVecEnv.step for A1Conditional.  raw_actions: (N,12) policy output. */
-int shf_a1_step(ShfA1Task* task, const float* raw_actions_dev, int64_t step_index, void* stream);
+/* ShifuVecEnv.step for A1Conditional (env.py:85-106).  raw_actions: (N,12) policy output. */
+int shf_a1_step(ShfA1Task* task, const float* raw_actions_dev, void* stream);
+/* log_info (env.py:149-158): reduces the episodes that finished in the last step
+ * into ring slot `slot % R` of SHF_A1_STATS: [0..5] sum of the six reward-term
+ * episode sums, [6] sum of terrain levels over all envs, [7] finished count,
+ * [8..13] the reference's extras["episode"] means (/max_episode_length_s),
+ * [14] mean terrain level, [15] N. */
+int shf_a1_episode_stats(ShfA1Task* task, int64_t slot, void* stream);
 /* ShifuVecEnv.reset_idx(arange(N)) part of reset() (env.py:108-112). */
 int shf_a1_reset_all(ShfA1Task* task, void* stream);
 

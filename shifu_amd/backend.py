@@ -197,11 +197,26 @@ class A1Task:
         self.tensors[tid] = t
         check(lib().shf_a1_bind(self._h, tid, C.c_void_p(t.data_ptr())))
 
-    def step(self, raw_actions: torch.Tensor) -> int:
+    def step(self, raw_actions: torch.Tensor, stats: bool = True) -> int:
+        """One fused vec-step; returns the stats ring slot written (or -1)."""
         a = raw_actions.contiguous()
         assert a.dtype == torch.float32 and a.shape == (self.sim.num_envs, self.sim.model.nd)
+        st = _stream_ptr(self.sim.device)
+        check(lib().shf_a1_step(self._h, C.c_void_p(a.data_ptr()), st))
+        if not stats:
+            return -1
         idx = self.step_index
-        check(lib().shf_a1_step(self._h, C.c_void_p(a.data_ptr()), idx, _stream_ptr(self.sim.device)))
+        check(lib().shf_a1_episode_stats(self._h, idx, st))
+        self.step_index += 1
+        return idx % self.tensors[_abi.A1_STATS].shape[0]
+
+    def launch_step(self, raw_actions: torch.Tensor):
+        """Only the fused kernel (bench.py brackets this with HIP events)."""
+        check(lib().shf_a1_step(self._h, C.c_void_p(raw_actions.data_ptr()), _stream_ptr(self.sim.device)))
+
+    def launch_stats(self) -> int:
+        idx = self.step_index
+        check(lib().shf_a1_episode_stats(self._h, idx, _stream_ptr(self.sim.device)))
         self.step_index += 1
         return idx % self.tensors[_abi.A1_STATS].shape[0]
 

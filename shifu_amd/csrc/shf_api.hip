@@ -808,7 +808,7 @@ static int a1_args(ShfA1Task* task, const float* raw_actions_dev, const char* wh
   return 0;
 }
 
-extern "C" int shf_a1_step(ShfA1Task* task, const float* raw_actions_dev, int64_t step_index, void* stream) {
+extern "C" int shf_a1_step(ShfA1Task* task, const float* raw_actions_dev, void* stream) {
   if (!raw_actions_dev) return fail("shf_a1_step: null actions");
   A1Args A;
   if (int r = a1_args(task, raw_actions_dev, "shf_a1_step", A)) return r;
@@ -823,9 +823,14 @@ extern "C" int shf_a1_step(ShfA1Task* task, const float* raw_actions_dev, int64_
     case 32: r = launch(k_a1_step<32>, grid, block, lds, stream, A); break;
     default: r = launch(k_a1_step<16>, grid, block, lds, stream, A); break;
   }
-  if (r) return r;
-  float* out = (float*)task->t[SHF_A1_STATS] + (size_t)(step_index % task->stats_ring) * 16;
-  return launch(k_a1_stats, dim3(1), dim3(1024), 0, stream, (int)s->n, task->tp.max_episode_length_s,
+  return r;
+}
+
+extern "C" int shf_a1_episode_stats(ShfA1Task* task, int64_t slot, void* stream) {
+  if (!task || !task->t[SHF_A1_STATS] || !task->t[SHF_A1_DONE_SUMS]) return fail("shf_a1_episode_stats: tensors not bound");
+  if (slot < 0) return fail("shf_a1_episode_stats: negative slot");
+  float* out = (float*)task->t[SHF_A1_STATS] + (size_t)(slot % task->stats_ring) * 16;
+  return launch(k_a1_stats, dim3(1), dim3(1024), 0, stream, (int)task->sim->n, task->tp.max_episode_length_s,
                 (const float*)task->t[SHF_A1_DONE_SUMS], out);
 }
 

@@ -1,0 +1,173 @@
+"""A1Conditional with the whole ShifuVecEnv.step fused into one HIP launch.
+
+Same observable behaviour as the hook-based examples/a1_conditional env running on
+the `gym` facade (quirks Q1-Q15 of SURVEY.md 3.1 preserved), but nothing between
+`step(actions)` and the returned tensors runs in torch: physics x5, get_heights,
+termination, rewards, on-device reset and observations are shf_a1_step; the
+episode logging reduction is shf_a1_episode_stats.  Buffers keep the reference's
+names (obs_buf, rew_buf, reset_buf, episode_length_buf, extras, ...: env.py:34-58)
+so rsl_rl-style callers work unchanged.
+
+Sharding: rank r of W owns global envs [r*N, (r+1)*N); everything that
+depends on the env index (terrain type column, RNG streams, friction) uses the
+global id, so a sharded run reproduces the unsharded one env for env.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import _abi
+from ..a1_task import MEASURED_POINTS_X, MEASURED_POINTS_Y, a1_task_params, height_points
+from ..backend import A1Task, Sim, default_sim_params
+from ..model import asset_path, compile_urdf
+from ..utils.terrain import Terrain
+
+REWARD_NAMES = ["tracking_lin_vel", "tracking_ang_vel", "stabilizing_base", "smoothing_action", "leg_collision",
+                "torques_penalize"]  # build_reward_functions order, a1_conditional.py:152-160
+
+
+def default_terrain_cfg(mesh_type="heightfield", **kw):
+    """TerrainEnvConfig.terrain defaults (shifu/configs/env_config.py:78-102)."""
+    d = dict(mesh_type=mesh_type, horizontal_scale=0.1, vertical_scale=0.005, border_size=25, static_friction=1.0,
+             dynamic_friction=1.0, restitution=0., measure_heights=True, measured_points_x=MEASURED_POINTS_X,
+             measured_points_y=MEASURED_POINTS_Y, selected=False, terrain_kwargs=None, terrain_length=8.,
+             terrain_width=8., num_rows=10, num_cols=20, terrain_proportions=[0.1, 0.1, 0.35, 0.25, 0.2],
+             slope_treshold=0.75, curriculum=True, max_init_terrain_level=5)
+    d.update(kw)
+    return SimpleNamespace(**d)
+
+
+def _philox_uniform(global_ids: np.ndarray, seed: int, stream: int) -> np.ndarray:
+    """Host mirror of the kernels' counter-based draws, for init-time per-env data."""
+    out = np.empty(len(global_ids), np.float64)
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    for n, g in enumerate(global_ids):
+        c = [int(g) & 0xFFFFFFFF, 0xFFFFFFFF, stream, (int(g) >> 32) & 0xFFFFFFFF]
+        k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+        for _ in range(10):
+            p0, p1 = M0 * c[0], M1 * c[2]
+            c = [((p1 >> 32) ^ c[1] ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k1) & 0xFFFFFFFF,
+                 p0 & 0xFFFFFFFF]
+            k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+        out[n] = (c[0] >> 8) * 2.0 ** -24
+    return out
+
+
+class FusedA1Env:
+    """rsl_rl.env.VecEnv duck type (SURVEY 8b 'upward contract')."""
+
+    def __init__(self, num_envs: int = 4096, device="cuda:0", terrain: str = "heightfield", seed: int = 42,
+                 rank: int = 0, world_size: int = 1, terrain_cfg=None, sim_params: Optional[_abi.ShfSimParams] = None,
+                 group: int = 64, episode_length_s: float = 10.0, dt: float = 0.005, decimation: int = 4,
+                 terrain_seed: int = 42, send_timeouts: bool = True):
+        self.device = torch.device(device)
+        self.num_envs = num_envs
+        self.rank, self.world_size = rank, world_size
+        self.env_id_offset = rank * num_envs
+        total = num_envs * world_size
+        self.cm = compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT)
+        self.sim_params = sim_params or default_sim_params(dt=dt)
+        self.dt = dt * decimation                                         # isaac_gym.py:26
+        self.sim = Sim(self.sim_params, self.device)
+        self.cfg_terrain = terrain_cfg or default_terrain_cfg()
+        ct = self.cfg_terrain
+        if terrain == "flat":
+            # BASELINE config 2: an all-zero height map of the same size (the reference cannot
+            # build a 'plane' TerrainGymEnv: isaac_gym.py:327-334)
+            ct.curriculum_layout_flat = True
+            rows = int(ct.num_rows * ct.terrain_length / ct.horizontal_scale) + 2 * int(ct.border_size / ct.horizontal_scale)
+            cols = int(ct.num_cols * ct.terrain_width / ct.horizontal_scale) + 2 * int(ct.border_size / ct.horizontal_scale)
+            samples = np.zeros((rows, cols), np.int16)
+            origins = np.zeros((ct.num_rows, ct.num_cols, 3))
+            for i in range(ct.num_rows):
+                for j in range(ct.num_cols):
+                    origins[i, j] = [(i + 0.5) * ct.terrain_length, (j + 0.5) * ct.terrain_width, 0.0]
+        elif terrain == "heightfield":
+            state = np.random.get_state()
+            np.random.seed(terrain_seed)          # every rank builds the identical replica
+            self.terrain = Terrain(ct, total)
+            np.random.set_state(state)
+            samples, origins = self.terrain.heightsamples, self.terrain.env_origins
+        else:
+            raise ValueError("terrain must be 'flat' or 'heightfield'")
+        self.sim.set_heightfield(np.ascontiguousarray(samples), ct.horizontal_scale, ct.vertical_scale, ct.border_size,
+                                 ct.static_friction)
+        self.sim.set_articulation(self.cm.blob)
+        self.sim.finalize(num_envs, self.env_id_offset, group=group)
+
+        self.max_episode_length_s = episode_length_s
+        self.task_params = a1_task_params(self.cm, dt=dt, decimation=decimation, episode_length_s=episode_length_s,
+                                          curriculum=ct.curriculum, num_rows=ct.num_rows, num_cols=ct.num_cols,
+                                          env_length=ct.terrain_length, seed=seed,
+                                          num_height_points=len(ct.measured_points_x) * len(ct.measured_points_y))
+        self.max_episode_length = np.ceil(episode_length_s / self.dt)     # env.py:42
+        self.task = A1Task(self.sim, self.task_params)
+        T, S = self.task.tensors, self.sim.tensors
+        gids = np.arange(self.env_id_offset, self.env_id_offset + num_envs)
+        # terrain_types = floor(i / (N/num_cols)) on GLOBAL ids (isaac_gym.py:342-344); levels start at
+        # zero because A1Conditional replaces the sim-side random levels on the first reset (Q13)
+        types = np.floor(gids / (total / ct.num_cols)).astype(np.int64)
+        T[_abi.A1_TYPES].copy_(torch.from_numpy(types))
+        T[_abi.A1_TORIGINS].copy_(torch.from_numpy(origins.astype(np.float32)))
+        T[_abi.A1_ORIGINS].copy_(torch.from_numpy(origins[0, types].astype(np.float32)))
+        T[_abi.A1_HPOINTS].copy_(torch.from_numpy(height_points(ct.measured_points_x, ct.measured_points_y)))
+        # per-env shape friction U(0.5, 1.25) (a1_conditional.py:28-31), keyed by global id
+        fr = 0.5 + 0.75 * _philox_uniform(gids, seed, 7)
+        S[_abi.T_FRICTION].copy_(torch.from_numpy(fr.astype(np.float32)))
+
+        self.num_obs = T[_abi.A1_OBS].shape[1]
+        self.num_privileged_obs = None
+        self.num_actions = self.cm.blob.nd
+        self.obs_buf = T[_abi.A1_OBS]
+        self.privileged_obs_buf = None
+        self.rew_buf = T[_abi.A1_REW]
+        self.reset_buf = T[_abi.A1_RESET].view(torch.bool)
+        self.time_out_buf = T[_abi.A1_TIMEOUT].view(torch.bool)
+        self.episode_length_buf = T[_abi.A1_EP_LEN]
+        self.actions = T[_abi.A1_ACTIONS]
+        self.command_buf = T[_abi.A1_COMMAND]
+        self.episode_rewards = {n: T[_abi.A1_REW_SUMS][k] for k, n in enumerate(REWARD_NAMES)}
+        self.terrain_levels = T[_abi.A1_LEVELS]
+        self.dof_state, self.root_state = S[_abi.T_DOF_STATE], S[_abi.T_ROOT_STATE]
+        self.body_state, self.contact_state = S[_abi.T_BODY_STATE], S[_abi.T_CONTACT]
+        self.measured_heights = T[_abi.A1_HEIGHTS]
+        self.send_timeouts = send_timeouts
+        self.extras = {}
+        self.common_step_counter = 0
+        # place every env (ShifuVecEnv.__init__ leaves reset_buf at ones: env.py:48)
+        self.task.reset_all()
+
+    # -- VecEnv surface ------------------------------------------------------
+    def step(self, actions: torch.Tensor):
+        slot = self.task.step(actions)
+        self.common_step_counter += 1
+        self._fill_extras(slot)
+        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def _fill_extras(self, slot: int):
+        st = self.task.tensors[_abi.A1_STATS][slot]
+        ep = {n: st[8 + k] for k, n in enumerate(REWARD_NAMES)}
+        ep["terrain_levels"] = st[14]                                  # episode_log, a1_conditional.py:126-129
+        self.extras["episode"] = ep
+        self.extras["episode_sums"] = st[:8]                           # (sum, count) form for the all-gather
+        if self.send_timeouts:
+            self.extras["time_outs"] = self.time_out_buf
+
+    def reset(self):
+        self.task.reset_all()
+        obs, priv, _, _, _ = self.step(torch.zeros(self.num_envs, self.num_actions, device=self.device))
+        return obs, priv
+
+    def get_observations(self):
+        return self.obs_buf
+
+    def get_privileged_observations(self):
+        return self.privileged_obs_buf
+
+    def destroy(self):
+        self.task.destroy()
+        self.sim.destroy()

@@ -1,0 +1,146 @@
+"""Sub-terrain generators with the call signatures of `isaacgym.terrain_utils`
+[EXT -- not part of the reference tree], as used by shifu/utils/terrain.py:76,
+106-148.  Restated from the behaviour summarised in SURVEY.md appendix C: all
+generators edit `terrain.height_field_raw` (int16, units of vertical_scale) in
+place.  Host/NumPy, init-time only; bit-parity with Isaac Gym's generators is
+neither possible nor required (the height samples are an *input* of the step
+path), they only have to be deterministic under `np.random.seed`.
+"""
+import numpy as np
+
+
+class SubTerrain:
+    def __init__(self, terrain_name="terrain", width=256, length=256, vertical_scale=1.0, horizontal_scale=1.0):
+        self.terrain_name = terrain_name
+        self.vertical_scale = vertical_scale
+        self.horizontal_scale = horizontal_scale
+        self.width = width
+        self.length = length
+        self.height_field_raw = np.zeros((self.width, self.length), dtype=np.int16)
+
+
+def pyramid_sloped_terrain(terrain, slope=1, platform_size=1.):
+    """Tent h = max_h * xx * yy with a flat centre platform."""
+    w, l = terrain.width, terrain.length
+    cx, cy = w / 2.0, l / 2.0
+    xx = ((cx - np.abs(cx - np.arange(w))) / cx).reshape(w, 1)
+    yy = ((cy - np.abs(cy - np.arange(l))) / cy).reshape(1, l)
+    max_height = int(slope * (terrain.horizontal_scale / terrain.vertical_scale) * (w / 2))
+    terrain.height_field_raw += (max_height * xx * yy).astype(terrain.height_field_raw.dtype)
+    half = int(platform_size / terrain.horizontal_scale / 2)
+    x1, y1 = w // 2 - half, l // 2 - half
+    corner = terrain.height_field_raw[x1, y1]
+    terrain.height_field_raw = np.clip(terrain.height_field_raw, min(corner, 0), max(corner, 0))
+    return terrain
+
+
+def _bilinear_upsample(coarse, out_rows, out_cols):
+    r = np.linspace(0, coarse.shape[0] - 1, out_rows)
+    c = np.linspace(0, coarse.shape[1] - 1, out_cols)
+    r0 = np.clip(np.floor(r).astype(int), 0, coarse.shape[0] - 2)
+    c0 = np.clip(np.floor(c).astype(int), 0, coarse.shape[1] - 2)
+    fr, fc = (r - r0)[:, None], (c - c0)[None, :]
+    a = coarse[r0][:, c0]; b = coarse[r0 + 1][:, c0]; cc = coarse[r0][:, c0 + 1]; d = coarse[r0 + 1][:, c0 + 1]
+    return a * (1 - fr) * (1 - fc) + b * fr * (1 - fc) + cc * (1 - fr) * fc + d * fr * fc
+
+
+def random_uniform_terrain(terrain, min_height, max_height, step=1, downsampled_scale=None):
+    """Coarse grid of heights drawn from {min..max step} upsampled linearly and ADDED."""
+    if downsampled_scale is None:
+        downsampled_scale = terrain.horizontal_scale
+    lo, hi = int(min_height / terrain.vertical_scale), int(max_height / terrain.vertical_scale)
+    st = max(int(step / terrain.vertical_scale), 1)
+    heights_range = np.arange(lo, hi + st, st)
+    rows = max(int(terrain.width * terrain.horizontal_scale / downsampled_scale), 2)
+    cols = max(int(terrain.length * terrain.horizontal_scale / downsampled_scale), 2)
+    coarse = np.random.choice(heights_range, (rows, cols)).astype(np.float64)
+    up = np.rint(_bilinear_upsample(coarse, terrain.width, terrain.length))
+    terrain.height_field_raw += up.astype(np.int16)
+    return terrain
+
+
+def pyramid_stairs_terrain(terrain, step_width, step_height, platform_size=1.):
+    """Concentric square steps rising (or descending) towards the centre platform."""
+    sw = int(step_width / terrain.horizontal_scale)
+    sh = int(step_height / terrain.vertical_scale)
+    plat = int(platform_size / terrain.horizontal_scale)
+    height = 0
+    x0, x1, y0, y1 = 0, terrain.width, 0, terrain.length
+    while (x1 - x0) > plat and (y1 - y0) > plat:
+        x0 += sw; x1 -= sw; y0 += sw; y1 -= sw
+        height += sh
+        terrain.height_field_raw[x0:x1, y0:y1] = height
+    return terrain
+
+
+def discrete_obstacles_terrain(terrain, max_height, min_size, max_size, num_rects, platform_size=1.):
+    """Random rectangles of height in {-h, -h/2, h/2, h}; centre platform cleared."""
+    mh = int(max_height / terrain.vertical_scale)
+    mn, mx = int(min_size / terrain.horizontal_scale), int(max_size / terrain.horizontal_scale)
+    plat = int(platform_size / terrain.horizontal_scale)
+    rows, cols = terrain.height_field_raw.shape
+    height_range = [-mh, -mh // 2, mh // 2, mh]
+    size_range = range(mn, mx, 4)
+    for _ in range(num_rects):
+        w = np.random.choice(size_range)
+        l = np.random.choice(size_range)
+        i = np.random.choice(range(0, rows - w, 4))
+        j = np.random.choice(range(0, cols - l, 4))
+        terrain.height_field_raw[i:i + w, j:j + l] = np.random.choice(height_range)
+    x1, x2 = (rows - plat) // 2, (rows + plat) // 2
+    y1, y2 = (cols - plat) // 2, (cols + plat) // 2
+    terrain.height_field_raw[x1:x2, y1:y2] = 0
+    return terrain
+
+
+def stepping_stones_terrain(terrain, stone_size, stone_distance, max_height, platform_size=1., depth=-10):
+    """Square stones on a `depth` m deep floor (unreachable with the reference's
+    5-entry terrain_proportions, terrain.py:146-152; provided for completeness)."""
+    ss = max(int(stone_size / terrain.horizontal_scale), 1)
+    sd = max(int(stone_distance / terrain.horizontal_scale), 1)
+    mh = int(max_height / terrain.vertical_scale)
+    plat = int(platform_size / terrain.horizontal_scale)
+    height_range = np.arange(-mh - 1, mh, 1)
+    terrain.height_field_raw[:, :] = int(depth / terrain.vertical_scale)
+    rows, cols = terrain.height_field_raw.shape
+    for i in range(0, rows, ss + sd):
+        for j in range(0, cols, ss + sd):
+            terrain.height_field_raw[i:i + ss, j:j + ss] = np.random.choice(height_range)
+    x1, x2 = (rows - plat) // 2, (rows + plat) // 2
+    y1, y2 = (cols - plat) // 2, (cols + plat) // 2
+    terrain.height_field_raw[x1:x2, y1:y2] = 0
+    return terrain
+
+
+def convert_heightfield_to_trimesh(height_field_raw, horizontal_scale, vertical_scale, slope_threshold=None):
+    """(vertices (R*C,3) f32, triangles (2(R-1)(C-1),3) u32).  Where the slope between
+    neighbouring samples exceeds the threshold the upper vertex is pulled over the
+    lower one so steps become vertical walls."""
+    hf = height_field_raw
+    rows, cols = hf.shape
+    y = np.linspace(0, (cols - 1) * horizontal_scale, cols)
+    x = np.linspace(0, (rows - 1) * horizontal_scale, rows)
+    yy, xx = np.meshgrid(y, x)
+    if slope_threshold is not None:
+        thr = slope_threshold * horizontal_scale / vertical_scale
+        move_x = np.zeros((rows, cols)); move_y = np.zeros((rows, cols)); move_c = np.zeros((rows, cols))
+        move_x[:rows - 1, :] += (hf[1:, :] - hf[:rows - 1, :] > thr)
+        move_x[1:, :] -= (hf[:rows - 1, :] - hf[1:, :] > thr)
+        move_y[:, :cols - 1] += (hf[:, 1:] - hf[:, :cols - 1] > thr)
+        move_y[:, 1:] -= (hf[:, :cols - 1] - hf[:, 1:] > thr)
+        move_c[:rows - 1, :cols - 1] += (hf[1:, 1:] - hf[:rows - 1, :cols - 1] > thr)
+        move_c[1:, 1:] -= (hf[:rows - 1, :cols - 1] - hf[1:, 1:] > thr)
+        xx = xx + (move_x + move_c * (move_x == 0)) * horizontal_scale
+        yy = yy + (move_y + move_c * (move_y == 0)) * horizontal_scale
+    vertices = np.zeros((rows * cols, 3), dtype=np.float32)
+    vertices[:, 0] = xx.flatten()
+    vertices[:, 1] = yy.flatten()
+    vertices[:, 2] = hf.flatten() * vertical_scale
+    triangles = -np.ones((2 * (rows - 1) * (cols - 1), 3), dtype=np.uint32)
+    for i in range(rows - 1):
+        ind0 = np.arange(0, cols - 1) + i * cols
+        ind1, ind2, ind3 = ind0 + 1, ind0 + cols, ind0 + cols + 1
+        s, e = 2 * i * (cols - 1), 2 * i * (cols - 1) + 2 * (cols - 1)
+        triangles[s:e:2, 0] = ind0; triangles[s:e:2, 1] = ind3; triangles[s:e:2, 2] = ind1
+        triangles[s + 1:e:2, 0] = ind0; triangles[s + 1:e:2, 1] = ind2; triangles[s + 1:e:2, 2] = ind3
+    return vertices, triangles

@@ -1,0 +1,45 @@
+"""Multi-GPU: envs shard trivially, one process per GPU; the only exchange is the
+episode-statistics all-gather.
+
+The reference is single-process (device 'cuda:0' hard-coded, env_config.py:15); its
+logging computes mean(sum[env_ids]) / T per reward term (shifu/gym/env.py:149-158).
+Across shards the *sums and counts* are gathered -- a mean of per-rank means would be
+wrong for unequal reset counts -- and the global mean is formed from them.  The payload
+is 8 floats per rank: latency-bound on xGMI, no bucketing or overlap to speak of.
+Backend "nccl" is RCCL on ROCm; the same code runs on gloo for the CPU tests.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total_envs: int, rank: int, world_size: int):
+    """Contiguous global env-id slice owned by `rank` (equal shards)."""
+    if total_envs % world_size:
+        raise ValueError("total_envs must be divisible by world_size")
+    n = total_envs // world_size
+    return rank * n, (rank + 1) * n
+
+
+def gather_episode_stats(local: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """all_gather of a small fixed-size stats vector -> (world, len) tensor.
+    Layout of `local` for the A1 task: [6 reward-term sums, level sum, finished count]."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local.unsqueeze(0)
+    world = dist.get_world_size(group)
+    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    return out
+
+
+def global_episode_means(gathered: torch.Tensor, names: List[str], max_episode_length_s: float,
+                         envs_per_rank: int) -> Dict[str, torch.Tensor]:
+    """extras["episode"] for the whole job from per-rank (sums..., level_sum, count)."""
+    tot = gathered.sum(0)
+    cnt = tot[len(names) + 1].clamp(min=1.0)
+    ep = {n: tot[k] / cnt / max_episode_length_s for k, n in enumerate(names)}
+    ep["terrain_levels"] = tot[len(names)] / float(envs_per_rank * gathered.shape[0])
+    return ep
