@@ -41,7 +41,6 @@ def cpu_baseline(workload: str, seconds_budget: float = 15.0):
     from shifu_amd.model import asset_path, compile_urdf
     from shifu_amd.utils.terrain import Terrain
     pyoracle.build()
-    cores = os.cpu_count() or 1
     n = 1024
     cm = compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT)
     m = cm.blob
@@ -76,10 +75,26 @@ def cpu_baseline(workload: str, seconds_budget: float = 15.0):
     b["dof_state"][:, 0] = np.tile(np.array([tp.default_dof_pos[d] for d in range(nd)], np.float32), n)
     b["root_state"][:, :3] = b["origins"] + np.array([0, 0, 0.42], np.float32)
     b["root_state"][:, 6] = 1.0
+    def run(nt, k):
+        t = time.perf_counter()
+        for _ in range(k):
+            raw = (2 * rng.random((n, nd)) - 1).astype(np.float32)
+            pyoracle.a1_step(m, sp, tp, n, 0, b, raw, terrain=terr, heights=hs, nthreads=nt)
+        return time.perf_counter() - t
+
+    # os.cpu_count() can exceed what the container may use: pick the thread count that is fastest
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cands = sorted({c for c in (1, 4, 8, 16, 32, 64, 128, avail) if 1 <= c <= avail})
+    best, best_t = 1, None
+    for c in cands:
+        run(c, 4)  # the first calls at a new team size pay thread start-up
+        t = run(c, 3)
+        if best_t is None or t < best_t:
+            best, best_t = c, t
+    cores = best
     steps, t0 = 0, time.perf_counter()
     while True:
-        raw = (2 * rng.random((n, nd)) - 1).astype(np.float32)
-        pyoracle.a1_step(m, sp, tp, n, 0, b, raw, terrain=terr, heights=hs, nthreads=cores)
+        run(cores, 1)
         steps += 1
         el = time.perf_counter() - t0
         if el > seconds_budget or steps >= 2000:

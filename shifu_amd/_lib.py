@@ -6,7 +6,8 @@ import os
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "libshifu_amd.so")
+# SHIFU_AMD_LIB overrides the in-tree library (kernel A/B experiments only)
+_PATH = os.environ.get("SHIFU_AMD_LIB") or os.path.join(_HERE, "libshifu_amd.so")
 _lib = None
 
 vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64

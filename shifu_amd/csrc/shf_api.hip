@@ -274,8 +274,11 @@ __global__ void k_a1_reset_all(A1Args A) {
 #define SCR_ACT 512  /* clipped actions (<= 32)                */
 #define SCR_OBS 544  /* observation staging                    */
 
+#ifndef SHF_A1_MIN_WAVES
+#define SHF_A1_MIN_WAVES 1
+#endif
 template <int G>
-__global__ __launch_bounds__(256) void k_a1_step(A1Args A) {
+__global__ __launch_bounds__(256, SHF_A1_MIN_WAVES) void k_a1_step(A1Args A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(A.tp);

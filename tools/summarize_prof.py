@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile.sh output directory into a small markdown + csv under profiles/.
+Usage: tools/summarize_prof.py gpurun_out/prof_<tag> profiles/<name>"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+
+def agg(path):
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    if not os.path.exists(path):
+        return d
+    for r in csv.DictReader(open(path)):
+        d[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return d
+
+
+def main(src, dst):
+    os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+    shutil.copy(os.path.join(src, "stats", "a1_kernel_stats.csv"), dst + "_kernel_stats.csv")
+    rows = list(csv.DictReader(open(os.path.join(src, "stats", "a1_kernel_stats.csv"))))
+    out = ["# rocprofv3 summary: " + os.path.basename(src), "",
+           "Command: `tools/profile.sh` (rocprofv3 --kernel-trace --stats, then separate --pmc passes) around",
+           "`python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline ...`; 4096 envs, 1x MI355X.", ""]
+    bj = os.path.join(src, "bench_stats.json")
+    if os.path.exists(bj):
+        try:
+            b = json.loads(open(bj).read().strip().splitlines()[-1])
+            out += ["bench.py line under the profiler: value = %.3e env-steps/s, kernel_ms (HIP events) = %.4f" %
+                    (b["value"], b["roofline"]["kernel_ms"]), ""]
+        except Exception:
+            pass
+    out += ["## Kernel time (--kernel-trace --stats)", "", "| kernel | calls | avg ns | % |", "|---|---|---|---|"]
+    for r in rows[:6]:
+        out.append("| `%s` | %s | %.0f | %s |" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]), r["Percentage"]))
+    out += ["", "## PMC counters, mean per launch (separate passes)", ""]
+    for f in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write"):
+        d = agg(os.path.join(src, f, "a1_counter_collection.csv"))
+        for k, v in d.items():
+            if "k_a1_step" in k or "k_sim_step" in k:
+                out.append("**%s** `%s`" % (f, k[:60]))
+                out.append("")
+                for c, x in sorted(v.items()):
+                    out.append("- %s = %.4g (n=%d)" % (c, sum(x) / len(x), len(x)))
+                out.append("")
+    open(dst + "_summary.md", "w").write("\n".join(out) + "\n")
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
