@@ -1,0 +1,2 @@
+from .isaac_gym import IsaacGymEnv, TerrainGymEnv
+from .env import ShifuVecEnv

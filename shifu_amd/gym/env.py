@@ -1,0 +1,138 @@
+"""ShifuVecEnv (reference shifu/gym/env.py:18-193): the task layer users subclass.
+
+User hooks keep their reference signatures: build_reward_functions() -> list of bound
+methods, compute_observations(), compute_termination(), optional episode_log(env_ids).
+The upward contract is the rsl_rl.env.VecEnv duck type (attributes num_envs, num_obs,
+..., step -> (obs, priv_obs, rew, dones, infos)); rsl_rl itself is not imported, so the
+class works with or without it.
+
+This is the hook-compatible path: physics runs on the HIP kernels, the hooks run as
+ordinary torch code, and `reset_buf.nonzero()` costs the same host sync as in the
+reference (env.py:101,115).  The sync-free, single-launch path for the A1 task is
+shifu_amd.gym.a1_fused.FusedA1Env.
+"""
+import typing
+
+import numpy as np
+import torch
+
+from shifu_amd.configs import TerrainEnvConfig
+from shifu_amd.utils.torch_utils import free_tensor_attrs
+from shifu_amd.utils.train import HistoryRecorder
+
+from .isaac_gym import IsaacGymEnv, TerrainGymEnv
+
+
+class ShifuVecEnv:
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.isg_env = TerrainGymEnv(cfg) if isinstance(cfg, TerrainEnvConfig) else IsaacGymEnv(cfg)
+        n, dev = self.isg_env.num_envs, self.isg_env.device
+        self.num_envs, self.device = n, dev
+        self.num_obs = cfg.num_obs
+        self.num_privileged_obs = cfg.num_privileged_obs
+        self.num_actions = cfg.num_actions
+        self.clip_obs = cfg.normalization.clip_observations
+        self.clip_actions = cfg.normalization.clip_actions
+        self.max_episode_length_s = cfg.episode_length_s
+        self.max_episode_length = np.ceil(self.max_episode_length_s / self.isg_env.dt)
+
+        self.actions = torch.zeros(n, self.num_actions, device=dev, dtype=torch.float, requires_grad=False)
+        self.obs_buf = torch.zeros(n, self.num_obs, device=dev, dtype=torch.float)
+        self.rew_buf = torch.zeros(n, device=dev, dtype=torch.float)
+        self.reset_buf = torch.ones(n, device=dev, dtype=torch.long)      # int64 ones until the first step (Q7)
+        self.episode_length_buf = torch.zeros(n, device=dev, dtype=torch.long)
+        self.time_out_buf = torch.zeros(n, device=dev, dtype=torch.bool)
+        self.extras = {}
+        if cfg.num_actions_history:
+            self.actions_recorder = HistoryRecorder(self.actions.shape, cfg.num_actions_history, device=dev)
+        self.privileged_obs_buf = None if self.num_privileged_obs is None else \
+            torch.zeros(n, self.num_privileged_obs, device=dev, dtype=torch.float)
+        self.common_step_counter = 0
+        self.reward_functions = self.build_reward_functions()
+        self._prepare_reward_functions()
+
+    # -- hooks -------------------------------------------------------------------
+    def build_reward_functions(self) -> typing.List:
+        raise NotImplementedError
+
+    def compute_observations(self):
+        raise NotImplementedError
+
+    def compute_termination(self):
+        """Set self.time_out_buf and self.reset_buf."""
+        raise NotImplementedError
+
+    def episode_log(self, env_ids) -> typing.Dict:
+        """Optional extra scalars for extras["episode"], e.g. a success rate over env_ids."""
+        return None
+
+    # -- VecEnv surface -------------------------------------------------------------
+    def step(self, actions: torch.Tensor):
+        assert self.isg_env.robot, "add robot before step"
+        self.actions = torch.clip(actions, -self.clip_actions, self.clip_actions)
+        self.isg_env.step(self.actions)
+        self.post_step()
+        self.obs_buf = torch.clip(self.obs_buf, -self.clip_obs, self.clip_obs)
+        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def post_step(self):
+        self.episode_length_buf += 1
+        self.common_step_counter += 1
+        self.compute_termination()
+        self.compute_reward()            # rewards of terminating envs are taken BEFORE their reset (Q15)
+        env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()
+        self.reset_idx(env_ids)
+        self.compute_observations()      # ... observations AFTER it
+        self.isg_env.refresh_sensors()
+        if self.cfg.num_actions_history:
+            self.actions_recorder.add(self.actions)   # Q12: the history lags the obs by one step
+
+    def reset(self):
+        self.reset_idx(torch.arange(self.num_envs, device=self.device))
+        obs, priv, _, _, _ = self.step(torch.zeros(self.num_envs, self.num_actions, device=self.device,
+                                                   requires_grad=False))
+        return obs, priv
+
+    def reset_idx(self, env_ids):
+        if len(env_ids) == 0:
+            return
+        self.isg_env.reset_idx(env_ids)
+        self.episode_length_buf[env_ids] = 0
+        self.reset_buf[env_ids] = 1
+        if self.cfg.num_actions_history:
+            self.actions_recorder.reset_idx(env_ids)
+        self.extras["episode"] = {}
+        self.log_info(env_ids)
+        if self.cfg.send_timeouts:
+            self.extras["time_outs"] = self.time_out_buf
+
+    def log_info(self, env_ids):
+        for key, sums in self.episode_rewards.items():
+            self.extras["episode"][key] = torch.mean(sums[env_ids]) / self.max_episode_length_s
+            sums[env_ids] = 0.
+        info = self.episode_log(env_ids)
+        if info:
+            self.extras["episode"].update(info)
+
+    def _prepare_reward_functions(self):
+        assert len(self.reward_functions) > 0
+        self.episode_rewards = {f.__name__: torch.zeros(self.num_envs, device=self.device, dtype=torch.float)
+                                for f in self.reward_functions}
+
+    def compute_reward(self):
+        self.rew_buf[:] = 0.
+        for f in self.reward_functions:
+            r = f()
+            self.episode_rewards[f.__name__] += r
+            self.rew_buf[:] += r
+
+    def get_observations(self):
+        return self.obs_buf
+
+    def get_privileged_observations(self):
+        return self.privileged_obs_buf
+
+    def destroy(self):
+        self.isg_env.destroy()
+        free_tensor_attrs(self)

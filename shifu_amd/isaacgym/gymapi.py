@@ -1,0 +1,472 @@
+"""`gymapi` facade: the names shifu and its examples take from `isaacgym.gymapi`
+[EXT], re-hosted on the MI355X backend.
+
+This is a naming facade, not a CUDA shim: `acquire_gym()` returns a `Gym` whose 69
+methods used by the reference (103 call sites; shifu/gym/isaac_gym.py,
+shifu/units/*.py, examples/*) record the scene while envs are created and, from
+`prepare_sim` on, forward to the C ABI of include/shifu_amd.h through
+shifu_amd.backend.Sim.  Graphics / viewer / camera calls are accepted and ignored
+(no renderer on the MI355X path: SURVEY.md section 2 rows 7, 13).
+
+Semantics kept from Isaac Gym:
+  * state tensors are sim-owned, pointer-stable, viewed once (`acquire_*`), updated
+    in place by `refresh_*`; user writes reach the solver only through
+    `set_*_tensor[_indexed]` (int32 actor indices in sim domain);
+  * `simulate` advances one dt; `apply_rigid_body_force_at_pos_tensors` acts on the
+    next `simulate` only; efforts/targets persist.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from .. import _abi
+
+# -- constants ---------------------------------------------------------------
+SIM_PHYSX = 1
+SIM_FLEX = 2
+UP_AXIS_Y, UP_AXIS_Z = 0, 1
+DOF_MODE_NONE, DOF_MODE_POS, DOF_MODE_VEL, DOF_MODE_EFFORT = (_abi.DOF_MODE_NONE, _abi.DOF_MODE_POS,
+                                                              _abi.DOF_MODE_VEL, _abi.DOF_MODE_EFFORT)
+FROM_ASSET, COMPUTE_PER_VERTEX, COMPUTE_PER_FACE = 0, 1, 2
+DOMAIN_ENV, DOMAIN_SIM, DOMAIN_ACTOR = 0, 1, 2
+MESH_NONE, MESH_COLLISION, MESH_VISUAL, MESH_VISUAL_AND_COLLISION = 0, 1, 2, 3
+IMAGE_COLOR, IMAGE_DEPTH, IMAGE_SEGMENTATION, IMAGE_OPTICAL_FLOW = 0, 1, 2, 3
+KEY_ESCAPE, KEY_V = 256, 86
+ENV_SPACE, LOCAL_SPACE, GLOBAL_SPACE = 0, 1, 2
+
+
+# -- plain value types -------------------------------------------------------
+class Vec3:
+    def __init__(self, x=0.0, y=0.0, z=0.0):
+        self.x, self.y, self.z = float(x), float(y), float(z)
+
+    def __add__(self, o):
+        return Vec3(self.x + o.x, self.y + o.y, self.z + o.z)
+
+    def __sub__(self, o):
+        return Vec3(self.x - o.x, self.y - o.y, self.z - o.z)
+
+    def __iter__(self):
+        return iter((self.x, self.y, self.z))
+
+    def __repr__(self):
+        return f"Vec3({self.x}, {self.y}, {self.z})"
+
+
+class Quat:
+    def __init__(self, x=0.0, y=0.0, z=0.0, w=1.0):
+        self.x, self.y, self.z, self.w = float(x), float(y), float(z), float(w)
+
+    def __iter__(self):
+        return iter((self.x, self.y, self.z, self.w))
+
+
+class Transform:
+    def __init__(self, p: Optional[Vec3] = None, r: Optional[Quat] = None):
+        self.p = p if p is not None else Vec3()
+        self.r = r if r is not None else Quat()
+
+
+class PhysXParams:
+    def __init__(self):
+        self.num_threads = 0
+        self.use_gpu = True
+        self.solver_type = 1
+        self.num_position_iterations = 4
+        self.num_velocity_iterations = 1
+        self.contact_offset = 0.02
+        self.rest_offset = 0.0
+        self.bounce_threshold_velocity = 0.2
+        self.max_depenetration_velocity = 100.0
+        self.max_gpu_contact_pairs = 1024 * 1024
+        self.default_buffer_size_multiplier = 2.0
+        self.contact_collection = 2
+
+
+class SimParams:
+    def __init__(self):
+        self.dt = 1.0 / 60.0
+        self.substeps = 2
+        self.up_axis = UP_AXIS_Y
+        self.gravity = Vec3(0.0, -9.8, 0.0)
+        self.use_gpu_pipeline = False
+        self.physx = PhysXParams()
+
+
+class AssetOptions:
+    def __init__(self):
+        self.fix_base_link = False
+        self.default_dof_drive_mode = DOF_MODE_NONE
+        self.disable_gravity = False
+        self.collapse_fixed_joints = False
+        self.flip_visual_attachments = False
+        self.replace_cylinder_with_capsule = False
+        self.mesh_normal_mode = FROM_ASSET
+        self.use_physx_armature = True
+        self.thickness = 0.02
+        self.armature = 0.0
+        self.angular_damping = 0.5
+        self.linear_damping = 0.0
+        self.max_angular_velocity = 64.0
+        self.max_linear_velocity = 1000.0
+        self.density = 1000.0
+
+
+class PlaneParams:
+    def __init__(self):
+        self.normal = Vec3(0.0, 1.0, 0.0)
+        self.distance = 0.0
+        self.static_friction = 1.0
+        self.dynamic_friction = 1.0
+        self.restitution = 0.0
+
+
+class HeightFieldParams:
+    def __init__(self):
+        self.column_scale = 1.0
+        self.row_scale = 1.0
+        self.vertical_scale = 1.0
+        self.nbRows = 0
+        self.nbColumns = 0
+        self.transform = Transform()
+        self.static_friction = 1.0
+        self.dynamic_friction = 1.0
+        self.restitution = 0.0
+
+
+class TriangleMeshParams:
+    def __init__(self):
+        self.nb_vertices = 0
+        self.nb_triangles = 0
+        self.transform = Transform()
+        self.static_friction = 1.0
+        self.dynamic_friction = 1.0
+        self.restitution = 0.0
+
+
+class CameraProperties:
+    def __init__(self):
+        self.enable_tensors = False
+        self.use_collision_geometry = False
+        self.width, self.height = 1600, 900
+        self.near_plane, self.far_plane = 0.0010000000474974513, 2000000.0
+        self.horizontal_fov = 90.0
+
+
+class RigidShapeProperties:
+    def __init__(self, friction=1.0):
+        self.friction = friction
+        self.rolling_friction = 0.0
+        self.torsion_friction = 0.0
+        self.restitution = 0.0
+        self.compliance = 0.0
+        self.thickness = 0.0
+        self.contact_offset = 0.0
+        self.rest_offset = 0.0
+        self.filter = 0
+
+
+class RigidBodyProperties:
+    def __init__(self, mass=0.0):
+        self.mass = mass
+        self.com = Vec3()
+        self.invMass = 0.0 if mass == 0 else 1.0 / mass
+
+
+# -- scene records -----------------------------------------------------------
+class Asset:
+    """Result of load_asset / create_box."""
+
+    def __init__(self, kind, name, options, model=None, box_dim=None):
+        self.kind, self.name, self.options = kind, name, options
+        self.model = model  # CompiledModel for articulations
+        self.box_dim = box_dim
+        nshapes = model.blob.np if model is not None else 1
+        self.shape_props = [RigidShapeProperties() for _ in range(max(nshapes, 1))]
+
+    @property
+    def num_bodies(self):
+        return self.model.blob.nb if self.model is not None else 1
+
+    @property
+    def num_dofs(self):
+        return self.model.blob.nd if self.model is not None else 0
+
+    @property
+    def body_dict(self) -> Dict[str, int]:
+        return self.model.rigid_body_dict if self.model is not None else {"box": 0}
+
+
+class _Actor:
+    def __init__(self, asset, pose, name, sim_index):
+        self.asset, self.pose, self.name, self.sim_index = asset, pose, name, sim_index
+        self.friction = float(np.mean([p.friction for p in asset.shape_props]))
+        self.mass_override: Optional[float] = None
+        self.dof_props = None
+
+
+class Env:
+    def __init__(self, sim, index):
+        self.sim, self.index = sim, index
+        self.actors: List[_Actor] = []
+
+
+class _TensorHandle:
+    """What acquire_*_tensor returns; gymtorch.wrap_tensor unwraps it."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+
+class SimHandle:
+    def __init__(self, device_id, params: SimParams):
+        self.device_id = device_id
+        self.params = params
+        self.envs: List[Env] = []
+        self.terrain = None          # ("plane", friction) | ("heightfield", samples, hs, vs, border, friction)
+        self.backend = None          # shifu_amd.backend.Sim after prepare_sim
+        self.robot_asset: Optional[Asset] = None
+        self.actors_per_env = 0
+        self.num_actors = 0
+        self.jacobian = None
+
+
+class Gym:
+    """The object `gymapi.acquire_gym()` returns."""
+
+    # ---- lifecycle ---------------------------------------------------------
+    def create_sim(self, compute_device=0, graphics_device=0, physics_engine=SIM_PHYSX, params: SimParams = None):
+        return SimHandle(compute_device, params or SimParams())
+
+    def add_ground(self, sim: SimHandle, params: PlaneParams):
+        sim.terrain = ("plane", 0.5 * (params.static_friction + params.dynamic_friction))
+
+    def add_heightfield(self, sim: SimHandle, samples, params: HeightFieldParams):
+        # shifu passes nbRows = tot_cols / nbColumns = tot_rows with samples laid out (tot_rows, tot_cols),
+        # x <-> first index, shifted by -border (isaac_gym.py:356-367)
+        hs = np.ascontiguousarray(np.asarray(samples, dtype=np.int16).reshape(params.nbColumns, params.nbRows))
+        sim.terrain = ("heightfield", hs, float(params.row_scale), float(params.vertical_scale),
+                       float(-params.transform.p.x), 0.5 * (params.static_friction + params.dynamic_friction))
+
+    def add_triangle_mesh(self, sim: SimHandle, vertices, triangles, params: TriangleMeshParams):
+        """Trimesh terrain (the reference's effective A1 terrain, Q5) is collided as the
+        height map it was triangulated from; the vertices are expected to come from
+        convert_heightfield_to_trimesh.  Exact trimesh contact is SURVEY 8f row f2."""
+        if getattr(params, "height_samples", None) is not None:
+            # hint set by shifu_amd's TerrainGymEnv._create_trimesh: the map the mesh came from
+            hs = np.ascontiguousarray(np.asarray(params.height_samples, dtype=np.int16))
+            sim.terrain = ("heightfield", hs, float(params.horizontal_scale), float(params.vertical_scale),
+                           float(-params.transform.p.x), 0.5 * (params.static_friction + params.dynamic_friction))
+            return
+        v = np.asarray(vertices, dtype=np.float32).reshape(-1, 3)
+        xs = np.unique(np.round(v[:, 0], 4))
+        hs_scale = float(np.median(np.diff(xs))) if len(xs) > 1 else 1.0
+        rows = int(round((v[:, 0].max() - v[:, 0].min()) / hs_scale)) + 1
+        cols = params.nb_vertices // rows
+        z = v[:, 2].reshape(rows, cols)
+        vs = float(getattr(params, "vertical_scale", 0.005))
+        sim.terrain = ("heightfield", np.ascontiguousarray(np.rint(z / vs).astype(np.int16)), hs_scale, vs,
+                       float(-params.transform.p.x), 0.5 * (params.static_friction + params.dynamic_friction))
+
+    def load_asset(self, sim, rootpath, filename, options: AssetOptions = None):
+        import os
+        from ..model import compile_urdf, asset_path
+        options = options or AssetOptions()
+        path = os.path.join(rootpath, filename)
+        if not os.path.exists(path):
+            # the reference's asset tree does not travel; the physics-only URDFs ship in shifu_amd/assets
+            base = os.path.basename(filename)
+            alt = {"a1.urdf": "a1.urdf", "abb_rod_isaac.urdf": "abb_rod.urdf"}.get(base, base)
+            path = asset_path(alt)
+        model = compile_urdf(path, fix_base_link=bool(options.fix_base_link),
+                             disable_gravity=bool(options.disable_gravity),
+                             collapse_fixed_joints=bool(options.collapse_fixed_joints),
+                             default_dof_drive_mode=int(options.default_dof_drive_mode),
+                             armature=float(getattr(options, "armature", 0.0)))
+        return Asset("articulation", filename, options, model=model)
+
+    def create_box(self, sim, x, y, z, options: AssetOptions = None):
+        return Asset("box", "box", options or AssetOptions(), box_dim=(float(x), float(y), float(z)))
+
+    def create_env(self, sim: SimHandle, lower, upper, num_per_row):
+        env = Env(sim, len(sim.envs))
+        sim.envs.append(env)
+        return env
+
+    def create_actor(self, env: Env, asset: Asset, pose: Transform, name="", group=0, filter=0, seg_id=0):
+        idx = env.sim.num_actors
+        env.sim.num_actors += 1
+        a = _Actor(asset, copy.deepcopy(pose), name, idx)
+        env.actors.append(a)
+        return len(env.actors) - 1
+
+    def get_actor_index(self, env: Env, actor_handle, domain=DOMAIN_SIM):
+        return env.actors[actor_handle].sim_index if domain == DOMAIN_SIM else actor_handle
+
+    # ---- asset / actor queries ---------------------------------------------
+    def get_asset_rigid_body_count(self, asset): return asset.num_bodies
+    def get_asset_dof_count(self, asset): return asset.num_dofs
+    def get_asset_rigid_body_dict(self, asset): return dict(asset.body_dict)
+    def get_asset_dof_properties(self, asset):
+        return asset.model.dof_properties() if asset.model is not None else np.zeros(0)
+    def get_asset_rigid_shape_properties(self, asset): return copy.deepcopy(asset.shape_props)
+    def set_asset_rigid_shape_properties(self, asset, props): asset.shape_props = copy.deepcopy(list(props))
+    def get_actor_rigid_body_dict(self, env, actor_handle): return dict(env.actors[actor_handle].asset.body_dict)
+    def find_actor_rigid_body_handle(self, env, actor_handle, name):
+        return env.actors[actor_handle].asset.body_dict.get(name, -1)
+    def get_actor_rigid_shape_properties(self, env, actor_handle):
+        a = env.actors[actor_handle]
+        return [RigidShapeProperties(a.friction) for _ in a.asset.shape_props]
+    def set_actor_rigid_shape_properties(self, env, actor_handle, props):
+        env.actors[actor_handle].friction = float(np.mean([p.friction for p in props]))
+    def get_actor_rigid_body_properties(self, env, actor_handle):
+        a = env.actors[actor_handle]
+        if a.asset.model is None:
+            return [RigidBodyProperties(a.mass_override or 0.0)]
+        return [RigidBodyProperties(a.asset.model.blob.mass[b]) for b in range(a.asset.num_bodies)]
+    def set_actor_rigid_body_properties(self, env, actor_handle, props, recomputeInertia=True):
+        a = env.actors[actor_handle]
+        if a.asset.model is None:
+            a.mass_override = float(props[0].mass)
+        # per-env link masses of articulations are not supported (the reference's call sites only
+        # touch boxes: object.py:35-37)
+    def set_actor_dof_properties(self, env, actor_handle, props):
+        env.actors[actor_handle].dof_props = props
+    def set_rigid_body_segmentation_id(self, *a, **k): pass
+    def set_rigid_body_color(self, *a, **k): pass
+
+    # ---- prepare ---------------------------------------------------------------
+    def prepare_sim(self, sim: SimHandle):
+        import torch
+        from ..backend import Sim, default_sim_params
+        p = sim.params
+        sp = default_sim_params(dt=p.dt, gravity=tuple(p.gravity),
+                                max_depen_vel=min(float(p.physx.max_depenetration_velocity), 10.0))
+        dev = torch.device("cuda", sim.device_id if isinstance(sim.device_id, int) and sim.device_id >= 0 else 0)
+        be = Sim(sp, dev)
+        if sim.terrain is None or sim.terrain[0] == "plane":
+            be.set_plane(sim.terrain[1] if sim.terrain else 1.0)
+        else:
+            _, hs, hscale, vscale, border, mu = sim.terrain
+            be.set_heightfield(hs, hscale, vscale, border, mu)
+        env0 = sim.envs[0]
+        robots = [a for a in env0.actors if a.asset.kind == "articulation"]
+        if len(robots) != 1 or env0.actors[0] is not robots[0]:
+            raise NotImplementedError("each env needs exactly one articulated actor, created first "
+                                      "(shifu assumes only the robot has DOFs: robot.py:51-52)")
+        robot = robots[0]
+        sim.robot_asset = robot.asset
+        m = copy.deepcopy(robot.asset.model.blob)
+        if robot.dof_props is not None:
+            for d in range(m.nd):
+                m.drive_mode[d] = int(robot.dof_props["driveMode"][d])
+                m.kp[d] = float(robot.dof_props["stiffness"][d])
+                m.kd[d] = float(robot.dof_props["damping"][d])
+        be.set_articulation(m)
+        for a in env0.actors[1:]:
+            if a.asset.kind != "box":
+                raise NotImplementedError("extra actors must be boxes (object.py:19-39)")
+            b = _abi.ShfBoxDesc()
+            b.dim[:] = a.asset.box_dim
+            b.mass = a.mass_override if a.mass_override is not None else 0.0
+            b.friction = a.friction
+            b.fixed = int(bool(a.asset.options.fix_base_link) or b.mass == 0.0)
+            b.pos[:] = tuple(a.pose.p)
+            b.quat[:] = tuple(a.pose.r)
+            be.add_box(b)
+        sim.actors_per_env = len(env0.actors)
+        n = len(sim.envs)
+        be.finalize(n, 0)
+        A = sim.actors_per_env
+        root = torch.zeros(n * A, 13)
+        fr = torch.ones(n)
+        for e, env in enumerate(sim.envs):
+            for k, a in enumerate(env.actors):
+                root[e * A + k, :3] = torch.tensor(tuple(a.pose.p))
+                root[e * A + k, 3:7] = torch.tensor(tuple(a.pose.r))
+            fr[e] = env.actors[0].friction
+        root = root.to(dev)
+        for tid in (_abi.T_SIM_ROOT, _abi.T_ROOT_STATE):
+            be.tensors[tid].copy_(root)
+        be.tensors[_abi.T_FRICTION].copy_(fr.to(dev))
+        sim.backend = be
+        return True
+
+    # ---- tensors ---------------------------------------------------------------
+    def _t(self, sim, tid): return _TensorHandle(sim.backend.tensors[tid])
+    def acquire_dof_state_tensor(self, sim): return self._t(sim, _abi.T_DOF_STATE)
+    def acquire_actor_root_state_tensor(self, sim): return self._t(sim, _abi.T_ROOT_STATE)
+    def acquire_rigid_body_state_tensor(self, sim): return self._t(sim, _abi.T_BODY_STATE)
+    def acquire_net_contact_force_tensor(self, sim): return self._t(sim, _abi.T_CONTACT)
+    def acquire_jacobian_tensor(self, sim, name): return self._t(sim, _abi.T_JACOBIAN)
+    def acquire_force_sensor_tensor(self, sim): return None
+
+    def refresh_dof_state_tensor(self, sim): sim.backend.refresh(_abi.REFRESH_DOF)
+    def refresh_actor_root_state_tensor(self, sim): sim.backend.refresh(_abi.REFRESH_ROOT)
+    def refresh_rigid_body_state_tensor(self, sim): sim.backend.refresh(_abi.REFRESH_BODY)
+    def refresh_net_contact_force_tensor(self, sim): sim.backend.refresh(_abi.REFRESH_CONTACT)
+    def refresh_jacobian_tensors(self, sim): sim.backend.refresh(_abi.REFRESH_JACOBIAN)
+    def refresh_force_sensor_tensor(self, sim): pass
+    def refresh_mass_matrix_tensors(self, sim): pass
+
+    # ---- stepping --------------------------------------------------------------
+    def simulate(self, sim): sim.backend.step()
+    def fetch_results(self, sim, wait=True): pass
+
+    def set_dof_actuation_force_tensor(self, sim, t): sim.backend.set_dof_command(_abi.T_EFFORT, t); return True
+    def set_dof_position_target_tensor(self, sim, t): sim.backend.set_dof_command(_abi.T_POS_TARGET, t); return True
+    def set_dof_velocity_target_tensor(self, sim, t): sim.backend.set_dof_command(_abi.T_VEL_TARGET, t); return True
+
+    def apply_rigid_body_force_at_pos_tensors(self, sim, force, pos=None, space=ENV_SPACE):
+        if pos is not None:
+            raise NotImplementedError("forces are applied at the body CoM (the reference passes pos=None: robot.py:231-236)")
+        sim.backend.apply_body_force(force)
+        return True
+
+    def set_actor_root_state_tensor_indexed(self, sim, root, idx, n):
+        sim.backend.commit_root_indexed(root, idx[:n]); return True
+    def set_actor_root_state_tensor(self, sim, root): sim.backend.commit_root_all(root); return True
+    def set_dof_state_tensor_indexed(self, sim, dof, idx, n):
+        sim.backend.commit_dof_indexed(dof, idx[:n]); return True
+    def set_dof_position_target_tensor_indexed(self, sim, tgt, idx, n):
+        sim.backend.set_pos_target_indexed(tgt, idx[:n]); return True
+
+    # ---- teardown ----------------------------------------------------------------
+    def destroy_env(self, env): pass
+    def destroy_viewer(self, viewer): pass
+    def destroy_camera_sensor(self, *a): pass
+    def destroy_sim(self, sim):
+        if sim is not None and sim.backend is not None:
+            sim.backend.destroy()
+            sim.backend = None
+
+    # ---- graphics: accepted and ignored (no renderer on this path) ----------------
+    def create_viewer(self, *a, **k): return None
+    def subscribe_viewer_keyboard_event(self, *a, **k): pass
+    def viewer_camera_look_at(self, *a, **k): pass
+    def query_viewer_has_closed(self, viewer): return False
+    def query_viewer_action_events(self, viewer): return []
+    def step_graphics(self, sim): pass
+    def draw_viewer(self, *a, **k): pass
+    def sync_frame_time(self, sim): pass
+    def poll_viewer_events(self, viewer): pass
+    def set_light_parameters(self, *a, **k): pass
+    def render_all_camera_sensors(self, sim): pass
+    def start_access_image_tensors(self, sim): pass
+    def end_access_image_tensors(self, sim): pass
+    def create_camera_sensor(self, *a, **k):
+        raise NotImplementedError("rasterised camera sensors are out of scope on the MI355X path (SURVEY.md row 7)")
+    get_camera_image_gpu_tensor = set_camera_location = set_camera_transform = create_camera_sensor
+
+
+_GYM = None
+
+
+def acquire_gym() -> Gym:
+    global _GYM
+    if _GYM is None:
+        _GYM = Gym()
+    return _GYM

@@ -1,0 +1,72 @@
+"""run_policy (reference shifu/runner/policy_runner.py:17-73).
+
+`run_mode='random'` -- the benchmark driver shape (:33-41: reset, then
+`2*rand(N, A) - 1` per step) -- runs entirely on this backend.  'train' / 'play' need
+an rsl_rl-compatible OnPolicyRunner (the reference's trainer is the un-vendored rsl_rl
+package); when it is importable they behave as in the reference, otherwise they raise
+with a clear message.  The trainer is SURVEY 8f row f1, not part of this hot path."""
+import torch
+
+from .utils import class_to_dict, datetime_logdir, get_load_path, set_seed
+
+
+def _on_policy_runner_class():
+    try:
+        from rsl_rl.runners import OnPolicyRunner
+    except Exception as e:  # pragma: no cover - rsl_rl is not installed here
+        raise RuntimeError("run_mode 'train'/'play' needs the rsl_rl package (reference README.md:35-37); "
+                           "run_mode 'random' does not") from e
+
+    class _OnPolicyRunner(OnPolicyRunner):
+        def load(self, path, load_optimizer=True):
+            loaded = torch.load(path, map_location=self.device)
+            self.alg.actor_critic.load_state_dict(loaded['model_state_dict'])
+            if load_optimizer:
+                self.alg.optimizer.load_state_dict(loaded['optimizer_state_dict'])
+            self.current_learning_iteration = loaded['iter']
+            return loaded['infos']
+
+    return _OnPolicyRunner
+
+
+def run_policy(run_mode, env_class, env_cfg, policy_cfg, log_root="./logs", play_num_envs=50, play_iterations=3000):
+    if run_mode == 'train':
+        env = env_class(env_cfg)
+        runner = build_policy_runner(env, policy_cfg, log_root)
+        runner.learn(num_learning_iterations=policy_cfg.runner.max_iterations, init_at_random_ep_len=True)
+    elif run_mode == 'play':
+        env_cfg.num_envs = play_num_envs
+        env_cfg.debug.headless = False
+        env = env_class(env_cfg)
+        policy = load_policy(env, policy_cfg, log_root)
+        env.reset()
+        obs = env.get_observations()
+        for _ in range(play_iterations):
+            obs, _, rews, dones, infos = env.step(policy(obs.detach()).detach())
+    elif run_mode == 'random':
+        env_cfg.num_envs = play_num_envs
+        env_cfg.debug.headless = False
+        env = env_class(env_cfg)
+        env.reset()
+        for _ in range(play_iterations):
+            actions = 2 * torch.rand(env.num_envs, env.num_actions, device=env.device) - 1
+            obs, _, rews, dones, infos = env.step(actions.detach())
+        return env
+    else:
+        raise NotImplementedError
+
+
+def load_policy(env, policy_cfg, log_root, device='cuda:0'):
+    return build_policy_runner(env, policy_cfg, log_root, resume=True, device=device).get_inference_policy()
+
+
+def build_policy_runner(env, train_cfg, log_root="./logs", device="cuda:0", resume=False):
+    log_dir = datetime_logdir(log_root, train_cfg.runner.run_name)
+    cfg_dict = class_to_dict(train_cfg)
+    set_seed(train_cfg.seed)
+    runner = _on_policy_runner_class()(env, cfg_dict, log_dir, device=device)
+    if resume:
+        path = get_load_path(log_root, load_run=train_cfg.runner.load_run, checkpoint=train_cfg.runner.checkpoint)
+        print(f"Loading model from: {path}")
+        runner.load(path)
+    return runner

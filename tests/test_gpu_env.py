@@ -1,0 +1,99 @@
+"""The drop-in boundary end to end on the GPU: the hook-based A1Conditional (user code
+in torch, physics through the `gym` facade, exactly the reference's call order) against
+the fused single-launch env on the same initial state and action sequence.
+
+Physics is the same arithmetic in both (k_sim_step vs the sub-steps inside k_a1_step),
+so dof/root state must agree bit for bit; observation/reward go through torch ops in
+one and the spec'd kernel arithmetic in the other (torch.exp vs exp_spec, summation
+order), so they are compared to 1e-5."""
+import numpy as np
+import pytest
+
+from shifu_amd import _abi
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _envs(n=64):
+    from examples.a1_conditional.a1_conditional import A1Conditional
+    from examples.a1_conditional.task_config import A1EnvConfig
+    from shifu_amd.gym.a1_fused import FusedA1Env
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU is visible")
+    cfg = A1EnvConfig()
+    cfg.num_envs = n
+    np.random.seed(42)
+    torch.manual_seed(0)
+    hook = A1Conditional(cfg)
+    fused = FusedA1Env(num_envs=n, terrain="heightfield", terrain_seed=42, seed=3)
+    return hook, fused
+
+
+def _sync_state(hook, fused):
+    """Give the hook env the fused env's post-reset state, commands, pushes, friction."""
+    be = hook.isg_env.sim.backend
+    S, T = fused.sim.tensors, fused.task.tensors
+    for tid in (_abi.T_DOF_STATE, _abi.T_ROOT_STATE):
+        be.tensors[tid].copy_(S[tid])
+    be.tensors[_abi.T_SIM_DOF].copy_(S[_abi.T_DOF_STATE])
+    be.tensors[_abi.T_SIM_ROOT].copy_(S[_abi.T_ROOT_STATE])
+    be.tensors[_abi.T_FRICTION].copy_(S[_abi.T_FRICTION])
+    hook.command_buf.copy_(T[_abi.A1_COMMAND])
+    hook.robot.rand_force_buf.copy_(T[_abi.A1_PUSH])
+    hook.isg_env.env_origins.copy_(T[_abi.A1_ORIGINS])
+    hook.episode_length_buf.copy_(T[_abi.A1_EP_LEN])
+    hook.actions_recorder.history_buf.copy_(T[_abi.A1_HISTORY])
+    for k, name in enumerate(hook.episode_rewards):
+        hook.episode_rewards[name].copy_(T[_abi.A1_REW_SUMS][k])
+    hook.robot.post_step()      # base-frame velocities from the (synced) root_state tensor
+
+
+def test_same_terrain_and_layout():
+    hook, fused = _envs(32)
+    assert torch.equal(hook.isg_env.height_samples, fused.sim.tensors[_abi.T_HEIGHTS])
+    assert torch.equal(hook.isg_env.terrain_types, fused.task.tensors[_abi.A1_TYPES])
+    assert torch.allclose(hook.isg_env.terrain_origins, fused.task.tensors[_abi.A1_TORIGINS])
+    assert hook.robot.rigid_body_dict["base"] == 0 and hook.robot.num_bodies == 17 and hook.robot.num_dof == 12
+    assert hook.obs_buf.shape == fused.obs_buf.shape == (32, 259)
+
+
+def test_hook_env_matches_fused_env_until_first_reset():
+    n = 64
+    hook, fused = _envs(n)
+    fused.task.reset_all()
+    _sync_state(hook, fused)
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(5)
+    compared = 0
+    alive = torch.ones(n, dtype=torch.bool, device="cuda:0")
+    for it in range(60):
+        a = 2 * torch.rand(n, 12, device="cuda:0", generator=g) - 1
+        o1, _, r1, d1, _ = hook.step(a)
+        o2, _, r2, d2, _ = fused.step(a)
+        assert torch.equal(d1.bool(), d2), f"reset masks differ at step {it}"
+        alive &= ~d2          # after an env resets the two RNGs diverge by design
+        if not alive.any():
+            break
+        m = alive
+        assert torch.equal(hook.isg_env.dof_state.view(n, -1)[m], fused.dof_state.view(n, -1)[m]), f"dof step {it}"
+        assert torch.equal(hook.isg_env.root_state[m], fused.root_state[m]), f"root step {it}"
+        assert torch.equal(hook.isg_env.contact_state.view(n, -1)[m], fused.contact_state.view(n, -1)[m])
+        assert torch.allclose(hook.isg_env.body_state.view(n, -1)[m], fused.body_state.view(n, -1)[m], atol=0, rtol=0)
+        assert torch.equal(hook.isg_env.measured_heights[m], fused.measured_heights[m]), f"heights step {it}"
+        assert torch.allclose(o1[m], o2[m], rtol=1e-5, atol=1e-5), f"obs step {it}: {(o1[m]-o2[m]).abs().max()}"
+        assert torch.allclose(r1[m], r2[m], rtol=1e-5, atol=1e-5), f"rew step {it}"
+        compared += int(m.sum())
+    assert compared > 20 * n // 2
+
+
+def test_hook_env_random_run_mode_is_stable():
+    """run_policy(run_mode='random') shape: 200 random steps with resets, everything finite."""
+    hook, _ = _envs(64)
+    hook.reset()
+    for _ in range(200):
+        a = 2 * torch.rand(hook.num_envs, hook.num_actions, device=hook.device) - 1
+        obs, _, rew, done, extras = hook.step(a)
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    assert "episode" in extras and "tracking_lin_vel" in extras["episode"] and "terrain_levels" in extras["episode"]
+    assert extras["time_outs"].dtype == torch.bool
