@@ -110,7 +110,8 @@ class FusedA1Env:
         gids = np.arange(self.env_id_offset, self.env_id_offset + num_envs)
         # terrain_types = floor(i / (N/num_cols)) on GLOBAL ids (isaac_gym.py:342-344); levels start at
         # zero because A1Conditional replaces the sim-side random levels on the first reset (Q13)
-        types = np.floor(gids / (total / ct.num_cols)).astype(np.int64)
+        # (same float32 torch.div as the reference, so e.g. 8 / 1.6 floors to 4, not 5)
+        types = torch.div(torch.from_numpy(gids), (total / ct.num_cols), rounding_mode='floor').to(torch.long).numpy()
         T[_abi.A1_TYPES].copy_(torch.from_numpy(types))
         T[_abi.A1_TORIGINS].copy_(torch.from_numpy(origins.astype(np.float32)))
         T[_abi.A1_ORIGINS].copy_(torch.from_numpy(origins[0, types].astype(np.float32)))

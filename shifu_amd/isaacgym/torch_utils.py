@@ -7,6 +7,8 @@ import torch
 
 
 def to_torch(x, dtype=torch.float, device="cuda:0", requires_grad=False):
+    if isinstance(x, np.ndarray):
+        x = np.ascontiguousarray(x)   # fields of structured arrays (dof_props['lower']) are strided views
     return torch.tensor(x, dtype=dtype, device=device, requires_grad=requires_grad)
 
 
