@@ -130,3 +130,68 @@ def a1_stats(task_params, n, done_sums):
     fn.restype = None
     fn(C.byref(task_params), C.c_int(n), _p(done_sums, C.c_float), _p(out, C.c_float))
     return out
+
+
+# ---- glue pieces, one entry point each (pinned against tests/golden) -------------------
+def _f(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def glue_heights(terrain, heights, hpoints, root_state):
+    root_state, hpoints = _f(root_state), _f(hpoints)
+    n, P = root_state.shape[0], hpoints.shape[0]
+    out = np.zeros((n, P), np.float32)
+    lib().shf_oracle_glue_heights_f32(C.byref(terrain), _p(heights, C.c_int16), C.c_int(n), C.c_int(P),
+                                      _p(hpoints, C.c_float), _p(root_state, C.c_float), _p(out, C.c_float))
+    return out
+
+
+def glue_rewards(cmd, blv, bav, hist, contact, tau, leg_bodies):
+    cmd, blv, bav, hist, contact, tau = map(_f, (cmd, blv, bav, hist, contact, tau))
+    n, nd, H = hist.shape
+    nb = contact.shape[1]
+    legs = np.ascontiguousarray(leg_bodies, np.int32)
+    out = np.zeros((6, n), np.float32)
+    lib().shf_oracle_glue_rewards_f32(C.c_int(n), C.c_int(nd), C.c_int(H), C.c_int(nb), C.c_int(len(legs)),
+                                      _p(legs, C.c_int32), _p(cmd, C.c_float), _p(blv, C.c_float), _p(bav, C.c_float),
+                                      _p(hist, C.c_float), _p(contact, C.c_float), _p(tau, C.c_float), _p(out, C.c_float))
+    return out
+
+
+def glue_termination(contact, ep_len, base_body, max_len):
+    contact = _f(contact)
+    ep = np.ascontiguousarray(ep_len, np.int64)
+    n, nb = contact.shape[0], contact.shape[1]
+    ct, to = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    lib().shf_oracle_glue_termination_f32(C.c_int(n), C.c_int(nb), C.c_int(base_body), C.c_float(max_len),
+                                          _p(contact, C.c_float), _p(ep, C.c_int64), _p(ct, C.c_uint8), _p(to, C.c_uint8))
+    return ct.astype(bool), to.astype(bool)
+
+
+def glue_obs(q0, cmd, blv, bav, dof_state, hist, base_z, mh, clip_obs=100.0):
+    q0, cmd, blv, bav, dof_state, hist, base_z, mh = map(_f, (q0, cmd, blv, bav, dof_state, hist, base_z, mh))
+    n, nd, H = hist.shape
+    P = mh.shape[1]
+    out = np.zeros((n, 12 + 2 * nd + nd * H + P), np.float32)
+    lib().shf_oracle_glue_obs_f32(C.c_int(n), C.c_int(nd), C.c_int(H), C.c_int(P), C.c_float(clip_obs),
+                                  _p(q0, C.c_float), _p(cmd, C.c_float), _p(blv, C.c_float), _p(bav, C.c_float),
+                                  _p(dof_state, C.c_float), _p(hist, C.c_float), _p(base_z, C.c_float), _p(mh, C.c_float),
+                                  _p(out, C.c_float))
+    return out
+
+
+def glue_curriculum(task_params, root_state, origins, cmd, levels, rnd=None):
+    root_state, origins, cmd = _f(root_state), _f(origins), _f(cmd)
+    n = root_state.shape[0]
+    lv = np.ascontiguousarray(levels, np.int64).copy()
+    rnd = np.zeros(n, np.uint32) if rnd is None else np.ascontiguousarray(rnd, np.uint32)
+    lib().shf_oracle_glue_curriculum_f32(C.byref(task_params), C.c_int(n), _p(root_state, C.c_float),
+                                         _p(origins, C.c_float), _p(cmd, C.c_float), _p(rnd, C.c_uint32), _p(lv, C.c_int64))
+    return lv
+
+
+def quat_rotate_inverse(q, v):
+    q, v = _f(q), _f(v)
+    out = np.zeros_like(v)
+    lib().shf_oracle_quat_rotate_inverse_f32(C.c_int(q.shape[0]), _p(q, C.c_float), _p(v, C.c_float), _p(out, C.c_float))
+    return out

@@ -486,27 +486,30 @@ __global__ __launch_bounds__(256, SHF_A1_MIN_WAVES) void k_a1_step(A1Args A) {
   if (l < 13) root[l] = L.root[l];
 }
 
-// per-step reduction for extras["episode"] (env.py:149-158), fixed order
+// per-step reduction for extras["episode"] (env.py:149-158), fixed order: block k reduces
+// row k of done_sums (1024 strided partials, then a binary tree) and, for the means, the
+// finished-episode count (row 7) the same way.
 __global__ __launch_bounds__(1024) void k_a1_stats(int n, float max_episode_length_s, const float* done_sums, float* out) {
-  __shared__ float part[1024];
-  __shared__ float res[8];
-  const int t = threadIdx.x;
-  for (int k = 0; k < 8; k++) {
-    float acc = 0.0f;
-    for (int e = t; e < n; e += 1024) acc += done_sums[(size_t)k * n + e];
-    part[t] = acc;
-    __syncthreads();
-    for (int s = 512; s >= 1; s >>= 1) {
-      if (t < s) part[t] += part[t + s];
-      __syncthreads();
-    }
-    if (t == 0) res[k] = part[0];
+  __shared__ float part[2][1024];
+  const int t = threadIdx.x, k = blockIdx.x;
+  float acc = 0.0f, cnt = 0.0f;
+  for (int e = t; e < n; e += 1024) {
+    acc += done_sums[(size_t)k * n + e];
+    cnt += done_sums[(size_t)7 * n + e];
+  }
+  part[0][t] = acc; part[1][t] = cnt;
+  __syncthreads();
+  for (int s = 512; s >= 1; s >>= 1) {
+    if (t < s) { part[0][t] += part[0][t + s]; part[1][t] += part[1][t + s]; }
     __syncthreads();
   }
-  if (t < 8) out[t] = res[t];
-  if (t < 6) out[8 + t] = res[7] > 0.0f ? res[t] / res[7] / max_episode_length_s : 0.0f;
-  if (t == 6) out[14] = res[6] / (float)n;
-  if (t == 7) out[15] = (float)n;
+  if (t == 0) {
+    const float sum = part[0][0], c = part[1][0];
+    out[k] = sum;
+    if (k < 6) out[8 + k] = c > 0.0f ? sum / c / max_episode_length_s : 0.0f;
+    if (k == 6) out[14] = sum / (float)n;
+    if (k == 7) out[15] = (float)n;
+  }
 }
 
 // ---------------------------------------------------------------- C ABI --
@@ -833,7 +836,7 @@ extern "C" int shf_a1_episode_stats(ShfA1Task* task, int64_t slot, void* stream)
   if (!task || !task->t[SHF_A1_STATS] || !task->t[SHF_A1_DONE_SUMS]) return fail("shf_a1_episode_stats: tensors not bound");
   if (slot < 0) return fail("shf_a1_episode_stats: negative slot");
   float* out = (float*)task->t[SHF_A1_STATS] + (size_t)(slot % task->stats_ring) * 16;
-  return launch(k_a1_stats, dim3(1), dim3(1024), 0, stream, (int)task->sim->n, task->tp.max_episode_length_s,
+  return launch(k_a1_stats, dim3(8), dim3(1024), 0, stream, (int)task->sim->n, task->tp.max_episode_length_s,
                 (const float*)task->t[SHF_A1_DONE_SUMS], out);
 }
 

@@ -470,3 +470,6 @@ def acquire_gym() -> Gym:
     if _GYM is None:
         _GYM = Gym()
     return _GYM
+
+
+Sim = SimHandle  # `gymapi.Sim` is used as a type annotation by the reference (units.py:13)

@@ -30,9 +30,9 @@ def gather_episode_stats(local: torch.Tensor, group: Optional[dist.ProcessGroup]
     if not (dist.is_available() and dist.is_initialized()):
         return local.unsqueeze(0)
     world = dist.get_world_size(group)
-    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-    return out
+    parts = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(parts, local.contiguous(), group=group)
+    return torch.stack(parts)
 
 
 def global_episode_means(gathered: torch.Tensor, names: List[str], max_episode_length_s: float,
