@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--workload", choices=["terrain", "flat"], default="terrain")
-    ap.add_argument("--group", type=int, default=64, help="lanes per env (64 = one wavefront per env)")
+    ap.add_argument("--group", type=int, default=32, help="lanes per env: 64 = one wavefront per env, 32 = two envs per wavefront (fastest measured, DESIGN.md 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--log-interval", type=int, default=24, help="all-gather period (num_steps_per_env)")
     args = ap.parse_args()

@@ -274,11 +274,12 @@ __global__ void k_a1_reset_all(A1Args A) {
 #define SCR_ACT 512  /* clipped actions (<= 32)                */
 #define SCR_OBS 544  /* observation staging                    */
 
-#ifndef SHF_A1_MIN_WAVES
-#define SHF_A1_MIN_WAVES 1
-#endif
+// Occupancy: at one wavefront per env (G = 64) 4096 envs are 4096 waves = 4 per SIMD, so
+// the kernel is held to 128 VGPRs (measured 0.147 ms vs 0.165 ms at 165 VGPRs / 3 waves,
+// profiles/r01_*); at G = 32 the grid is 2 waves per SIMD and the unconstrained
+// allocation is faster (0.104 ms vs 0.112 ms).
 template <int G>
-__global__ __launch_bounds__(256, SHF_A1_MIN_WAVES) void k_a1_step(A1Args A) {
+__global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(A.tp);
