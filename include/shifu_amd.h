@@ -103,6 +103,14 @@ typedef struct ShfBoxDesc {
   float quat[4];
 } ShfBoxDesc;
 
+/* The box actors of one env, in actor order after the articulation (device copy bound as
+ * SHF_T_SCENE). */
+typedef struct ShfScene {
+  int32_t nboxes;
+  int32_t pad[3];
+  ShfBoxDesc box[SHF_MAX_BOXES];
+} ShfScene;
+
 /*
  * Simulation parameters.  Replaces gymapi.SimParams (+.physx)
  * (shifu/configs/env_config.py:38-58).  The PhysX TGS solver settings have
@@ -146,7 +154,8 @@ enum {
   SHF_T_HEIGHTS = 12,    /* (rows*cols) i16 height samples (isaac_gym.py:349-367)          */
   SHF_T_MODEL = 13,      /* sizeof(ShfModel) bytes, device copy                            */
   SHF_T_SIM_CONTACT = 14,/* (N*B, 3) f32 internal net contact force of the last step        */
-  SHF_T_COUNT = 15
+  SHF_T_SCENE = 15,      /* sizeof(ShfScene) bytes, device copy                            */
+  SHF_T_COUNT = 16
 };
 
 /* refresh masks: gym.refresh_*_tensor (isaac_gym.py:139-154) */

@@ -195,3 +195,24 @@ def quat_rotate_inverse(q, v):
     out = np.zeros_like(v)
     lib().shf_oracle_quat_rotate_inverse_f32(C.c_int(q.shape[0]), _p(q, C.c_float), _p(v, C.c_float), _p(out, C.c_float))
     return out
+
+
+def scene_step(model, params, boxes, n, dof_state, root_state, *, nsteps=1, terrain=None, heights=None, effort=None,
+               pos_target=None, vel_target=None, friction=None, want_contact=True, want_body_state=True,
+               want_jacobian=False, f64=False):
+    """simulate() for an articulation + box actors (boxes: list of ShfBoxDesc)."""
+    from shifu_amd import _abi
+    dt = np.float64 if f64 else np.float32
+    ct = C.c_double if f64 else C.c_float
+    nbx = len(boxes)
+    arr = (_abi.ShfBoxDesc * max(nbx, 1))(*boxes)
+    B = model.nb + nbx
+    contact = np.zeros((n * B, 3), dt) if want_contact else None
+    bstate = np.zeros((n * B, 13), dt) if want_body_state else None
+    jac = np.zeros((n, model.nb - 1, 6, model.nd), dt) if want_jacobian else None
+    fn = lib().shf_oracle_scene_step_f64 if f64 else lib().shf_oracle_scene_step_f32
+    fn.restype = None
+    fn(C.byref(model), C.byref(params), C.byref(terrain) if terrain is not None else None, _p(heights, C.c_int16),
+       C.c_int(nbx), arr, C.c_int(n), C.c_int(nsteps), _p(dof_state, ct), _p(root_state, ct), _p(effort, ct),
+       _p(pos_target, ct), _p(vel_target, ct), _p(friction, C.c_float), _p(contact, ct), _p(bstate, ct), _p(jac, ct))
+    return contact, bstate, jac

@@ -39,6 +39,10 @@ class ShfBoxDesc(C.Structure):
                 ("pos", f32 * 3), ("quat", f32 * 4)]
 
 
+class ShfScene(C.Structure):
+    _fields_ = [("nboxes", i32), ("pad", i32 * 3), ("box", ShfBoxDesc * MAX_BOXES)]
+
+
 class ShfSimParams(C.Structure):
     _fields_ = [("dt", f32), ("gravity", f32 * 3), ("contact_k", f32), ("contact_d", f32),
                 ("friction_vel", f32), ("limit_k", f32), ("limit_d", f32),
@@ -65,7 +69,7 @@ class ShfA1TaskParams(C.Structure):
 
 # tensor ids (shf_sim_*)
 T_DOF_STATE, T_ROOT_STATE, T_BODY_STATE, T_CONTACT, T_JACOBIAN, T_SIM_DOF, T_SIM_ROOT, T_EFFORT, \
-    T_POS_TARGET, T_VEL_TARGET, T_BODY_FORCE, T_FRICTION, T_HEIGHTS, T_MODEL, T_SIM_CONTACT, T_COUNT = range(16)
+    T_POS_TARGET, T_VEL_TARGET, T_BODY_FORCE, T_FRICTION, T_HEIGHTS, T_MODEL, T_SIM_CONTACT, T_SCENE, T_COUNT = range(17)
 
 REFRESH_DOF, REFRESH_ROOT, REFRESH_BODY, REFRESH_CONTACT, REFRESH_JACOBIAN, REFRESH_ALL = 1, 2, 4, 8, 16, 31
 

@@ -1,0 +1,40 @@
+"""Scene constants of the ABB push-box task (reference examples/abb_pushbox_vision/
+task_config.py:13-84, a_prior_stage.py:24-73): arm + table + cube + goal pad."""
+from __future__ import annotations
+
+from . import _abi
+from .model import asset_path, compile_urdf
+
+ABB_DEFAULT_DOF_POS = [0., 0.6437, 0.1748, 0., 0.7541, 0.]   # task_config.py:57
+ABB_BASE_POS = [-0.48, 0.0, 0.0]                              # task_config.py:55
+
+# The reference collides the rod as the convex hull of rod.stl (a cylinder r = 0.0194 m,
+# z in [-0.0025, 0.2145] m in the tool0 frame, measured from the STL).  Mesh colliders
+# are not supported here; the lower 12 cm of the rod is covered by eight spheres of that radius
+# spaced 12 mm apart (surface ripple < 1 mm).
+ROD_RADIUS = 0.0194
+ROD_SPHERES = [("tool0", (0.0, 0.0, 0.2145 - ROD_RADIUS - k * 0.012), ROD_RADIUS) for k in range(8)]
+
+
+def abb_model(kp=800.0, kd=40.0):
+    cm = compile_urdf(asset_path("abb_rod.urdf"), fix_base_link=True, disable_gravity=True,
+                      default_dof_drive_mode=_abi.DOF_MODE_POS, extra_spheres=ROD_SPHERES)
+    for d in range(cm.blob.nd):
+        cm.blob.kp[d], cm.blob.kd[d] = kp, kd
+    return cm
+
+
+def box_desc(dim, mass, friction, fixed, pos, quat=(0, 0, 0, 1)) -> _abi.ShfBoxDesc:
+    b = _abi.ShfBoxDesc()
+    b.dim[:] = dim
+    b.mass, b.friction, b.fixed = mass, friction, int(fixed)
+    b.pos[:] = pos
+    b.quat[:] = quat
+    return b
+
+
+def abb_boxes():
+    """table (fixed), cube (free, 0.1 kg, mu 0.5), goal pad (fixed) -- task_config.py:13-46."""
+    return [box_desc([0.6, 0.6, 0.1], 0.0, 0.5, True, [0, 0, 0.05]),
+            box_desc([0.05, 0.05, 0.05], 0.1, 0.5, False, [0, 0, 0.125]),
+            box_desc([0.08, 0.08, 0.002], 0.0, 0.5, True, [0, 0, 0.1])]

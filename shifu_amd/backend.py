@@ -60,6 +60,7 @@ class Sim:
         self.terrain.friction = 1.0
         self.num_envs = 0
         self.nboxes = 0
+        self.boxes = []
         self._heights: Optional[torch.Tensor] = None
 
     # -- construction -------------------------------------------------------
@@ -85,6 +86,7 @@ class Sim:
 
     def add_box(self, box: _abi.ShfBoxDesc):
         check(lib().shf_sim_add_box(self._h, C.byref(box)))
+        self.boxes.append(box)
         self.nboxes += 1
 
     def layout(self, tid: int):
@@ -110,6 +112,13 @@ class Sim:
                 continue
             if tid == _abi.T_MODEL:
                 self.bind(tid, _struct_to_device(self.model, self.device))
+                continue
+            if tid == _abi.T_SCENE:
+                sc = _abi.ShfScene()
+                sc.nboxes = self.nboxes
+                for k, b in enumerate(self.boxes):
+                    sc.box[k] = b
+                self.bind(tid, _struct_to_device(sc, self.device))
                 continue
             shape, dt = self.layout(tid)
             t = torch.zeros(shape, dtype=dt, device=self.device)

@@ -52,6 +52,8 @@ struct SimArgs {
   ShfTerrain terr;
   const int16_t* heights;
   const ShfModel* model;  // device copy
+  const ShfScene* scene;  // device copy (box actors)
+  int nboxes;
   int n;
   float* dof;            // (n*nd,2)
   float* root;           // (n*A,13)
@@ -75,50 +77,103 @@ DEV const ShfModel* stage_model(const ShfModel* gm, float* smem) {
 #define MODEL_WORDS ((int)((sizeof(ShfModel) / 4 + 3) & ~3))
 #define TASK_WORDS ((int)((sizeof(ShfA1TaskParams) / 4 + 3) & ~3))
 
+#define SCENE_WORDS ((int)((sizeof(ShfScene) / 4 + 3) & ~3))
+
+DEV const ShfScene* stage_scene(const ShfScene* gs, float* dst_words) {
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(gs);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(dst_words);
+  for (int i = threadIdx.x; i < (int)(sizeof(ShfScene) / 4); i += blockDim.x) dst[i] = src[i];
+  return reinterpret_cast<const ShfScene*>(dst_words);
+}
+
 // gym.simulate: one sub-step for every env
-template <int G>
+template <int G, bool BOX>
 __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const ShfScene* scene = BOX ? stage_scene(A.scene, smem + MODEL_WORDS) : nullptr;
   const ShfModel* m = stage_model(A.model, smem);
   const int epb = 256 / G, es = threadIdx.x / G, l = threadIdx.x % G;
   const int e = blockIdx.x * epb + es;
   if (e >= A.n) return;
-  const int nb = m->nb, nd = m->nd, np = m->np;
-  EnvLds L = env_lds_carve(smem + MODEL_WORDS + es * env_lds_words(nb, nd, np), nb, nd, np);
+  const int nbx = BOX ? A.nboxes : 0, actors = 1 + nbx;
+  const int nb = m->nb, nd = m->nd, nbt = nb + nbx, nslots = m->np + box_slot_count(nbx, m->nsph);
+  EnvLds L = env_lds_carve(smem + MODEL_WORDS + (BOX ? SCENE_WORDS : 0) + es * env_lds_words(nbt, nd, nslots, 0, actors),
+                           nbt, nd, nslots, actors);
   float* dof = A.dof + (size_t)e * nd * 2;
-  float* root = A.root + (size_t)e * A.actors * 13;
-  if (l < 2 * nd) L.dofb[(l >> 1) * DOF_STRIDE + (l & 1)] = dof[l];
-  for (int i = l + G; i < 2 * nd; i += G) L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)] = dof[i];
-  if (l < 13) L.root[l] = root[l];
+  float* root = A.root + (size_t)e * actors * 13;
+  for (int i = l; i < 2 * nd; i += G) L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)] = dof[i];
+  for (int i = l; i < 13 * actors; i += G) L.root[i] = root[i];
   if (l < nd) L.dofb[l * DOF_STRIDE + 5] = A.effort ? A.effort[(size_t)e * nd + l] : 0.0f;
   GROUP_SYNC();
   StepCtx C;
-  C.m = m; C.sp = A.sp; C.terr.t = A.terr; C.terr.h = A.heights;
+  C.m = m; C.sp = A.sp; C.terr.t = A.terr; C.terr.h = A.heights; C.scene = scene;
   const float mu = A.friction ? A.friction[e] : 1.0f;
-  substep<G>(C, L, l, A.pos_tgt ? A.pos_tgt + (size_t)e * nd : nullptr, A.vel_tgt ? A.vel_tgt + (size_t)e * nd : nullptr,
-             A.body_force ? A.body_force + (size_t)e * nb * 3 : nullptr, mu, L.xch);
+  substep<G, BOX>(C, L, l, A.pos_tgt ? A.pos_tgt + (size_t)e * nd : nullptr, A.vel_tgt ? A.vel_tgt + (size_t)e * nd : nullptr,
+                  A.body_force ? A.body_force + (size_t)e * nbt * 3 : nullptr, mu, L.xch);
   GROUP_SYNC();
   for (int i = l; i < 2 * nd; i += G) dof[i] = L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)];
-  if (l < 13) root[l] = L.root[l];
-  for (int i = l; i < 3 * nb; i += G) A.contact[(size_t)e * nb * 3 + i] = L.xch[i];
+  for (int i = l; i < 13 * actors; i += G) root[i] = L.root[i];
+  for (int i = l; i < 3 * nbt; i += G) A.contact[(size_t)e * nbt * 3 + i] = L.xch[i];
 }
 
-// gym.refresh_rigid_body_state_tensor
+// gym.refresh_rigid_body_state_tensor (+ refresh_jacobian_tensors for fixed bases):
+// body rows from forward kinematics, box rows copied from their root rows; jacobian
+// (N, nb-1, 6, nd), rows [linear; angular] of each link origin (robot.py:125-128).
 template <int G>
 __global__ __launch_bounds__(256) void k_body_state(const ShfModel* gm, int n, const float* dof, const float* root,
-                                                    int actors, float* body_state) {
+                                                    int actors, float* body_state, float* jacobian) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const ShfModel* m = stage_model(gm, smem);
   const int epb = 256 / G, es = threadIdx.x / G, l = threadIdx.x % G;
   const int e = blockIdx.x * epb + es;
   if (e >= n) return;
-  const int nb = m->nb, nd = m->nd, np = m->np;
-  EnvLds L = env_lds_carve(smem + MODEL_WORDS + es * env_lds_words(nb, nd, np), nb, nd, np);
+  const int nb = m->nb, nd = m->nd, np = m->np, nbt = nb + actors - 1;
+  EnvLds L = env_lds_carve(smem + MODEL_WORDS + es * env_lds_words(nb, nd, np, 0, actors), nb, nd, np, actors);
   for (int i = l; i < 2 * nd; i += G) L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)] = dof[(size_t)e * nd * 2 + i];
-  if (l < 13) L.root[l] = root[(size_t)e * actors * 13 + l];
+  for (int i = l; i < 13 * actors; i += G) L.root[i] = root[(size_t)e * actors * 13 + i];
   GROUP_SYNC();
-  body_states<G>(m, L, l, L.xch);
-  for (int i = l; i < 13 * nb; i += G) body_state[(size_t)e * nb * 13 + i] = L.xch[i];
+  BodyRegs B;
+  kinematics<G>(m, L, l, B);
+  if (body_state) {
+    if (l < nb) {
+      float* o = L.xch + 13 * l;
+      float t[3], q[4];
+#pragma unroll
+      for (int k = 0; k < 3; k++) o[k] = L.root[k] + B.p[k];
+      mat_to_quat(B.Rw, q);
+#pragma unroll
+      for (int k = 0; k < 4; k++) o[3 + k] = q[k];
+      cross3(B.v, B.p, t);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { o[7 + k] = B.v[3 + k] + t[k]; o[10 + k] = B.v[k]; }
+    }
+    GROUP_SYNC();
+    for (int i = l; i < 13 * nb; i += G) body_state[(size_t)e * nbt * 13 + i] = L.xch[i];
+    for (int i = l; i < 13 * (actors - 1); i += G) body_state[((size_t)e * nbt + nb) * 13 + i] = L.root[13 + i];
+    GROUP_SYNC();
+  }
+  if (jacobian && m->fixed_base) {
+    if (l < nb) {
+      float* o = L.xch + 6 * l;
+#pragma unroll
+      for (int k = 0; k < 6; k++) o[k] = B.S[k];
+    }
+    GROUP_SYNC();
+    if (l >= 1 && l < nb) {
+      float* J = jacobian + ((size_t)e * (nb - 1) + (l - 1)) * 6 * nd;
+      for (int k = 0; k < 6 * nd; k++) J[k] = 0.0f;
+      for (int b = l; b > 0; b = m->parent[b]) {
+        const int d = m->dof[b];
+        if (d < 0) continue;
+        const float* S = L.xch + 6 * b;
+        const float ax[3] = {S[0], S[1], S[2]};
+        float t[3];
+        cross3(ax, B.p, t);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { J[k * nd + d] = t[k] + S[3 + k]; J[(3 + k) * nd + d] = S[k]; }
+      }
+    }
+  }
 }
 
 __global__ void k_commit_rows(const float* src, float* dst, const int32_t* idx, int n, int row_words, int idx_div,
@@ -324,7 +379,7 @@ __global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) {
   }
 
   StepCtx C;
-  C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights;
+  C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = nullptr;
   const float mu = A.S.friction[e];
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
   for (int it = 0; it < nsub; it++) {
@@ -514,9 +569,12 @@ __global__ __launch_bounds__(1024) void k_a1_stats(int n, float max_episode_leng
 }
 
 // ---------------------------------------------------------------- C ABI --
-static size_t sim_lds_bytes(const ShfSim* s, int head_words, int min_tail) {
+static size_t sim_lds_bytes(const ShfSim* s, int head_words, int min_tail, bool boxes = false) {
   const int epb = 256 / s->group;
-  return ((size_t)MODEL_WORDS + head_words + (size_t)epb * env_lds_words(s->model.nb, s->model.nd, s->model.np, min_tail)) * 4;
+  const int nbx = boxes ? s->nboxes : 0;
+  const int nslots = s->model.np + (boxes ? box_slot_count(nbx, s->model.nsph) : 0);
+  return ((size_t)MODEL_WORDS + head_words + (boxes ? SCENE_WORDS : 0) +
+          (size_t)epb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, min_tail, 1 + (boxes ? nbx : s->nboxes))) * 4;
 }
 
 extern "C" int shf_sim_create(const ShfSimParams* params, ShfSim** out) {
@@ -587,6 +645,7 @@ extern "C" int shf_sim_layout(const ShfSim* sim, int32_t id, int64_t shape[4], i
     case SHF_T_FRICTION: *ndim = 1; shape[0] = N; break;
     case SHF_T_HEIGHTS: *ndim = 2; shape[0] = sim->terr.rows > 0 ? sim->terr.rows : 1; shape[1] = sim->terr.rows > 0 ? sim->terr.cols : 1; *dtype = 2; break;
     case SHF_T_MODEL: *ndim = 1; shape[0] = sizeof(ShfModel); *dtype = 3; break;
+    case SHF_T_SCENE: *ndim = 1; shape[0] = sizeof(ShfScene); *dtype = 3; break;
     default: return fail("shf_sim_layout: unknown tensor id");
   }
   return 0;
@@ -609,6 +668,8 @@ static SimArgs sim_args(const ShfSim* s, bool internal) {
   A.sp = s->sp; A.terr = s->terr;
   A.heights = (const int16_t*)s->t[SHF_T_HEIGHTS];
   A.model = (const ShfModel*)s->t[SHF_T_MODEL];
+  A.scene = (const ShfScene*)s->t[SHF_T_SCENE];
+  A.nboxes = s->nboxes;
   A.n = s->n;
   A.dof = (float*)s->t[internal ? SHF_T_SIM_DOF : SHF_T_DOF_STATE];
   A.root = (float*)s->t[internal ? SHF_T_SIM_ROOT : SHF_T_ROOT_STATE];
@@ -637,11 +698,21 @@ extern "C" int shf_sim_step(ShfSim* sim, void* stream) {
   sim->force_armed = false;
   const int epb = 256 / sim->group;
   dim3 grid((sim->n + epb - 1) / epb), block(256);
+  if (sim->nboxes > 0) {
+    if (!sim->t[SHF_T_SCENE]) return fail("shf_sim_step: scene (box actors) not bound");
+    if (sim->model.nb + sim->nboxes > sim->group) return fail("shf_sim_step: bodies + boxes exceed the lane group");
+    const size_t lds = sim_lds_bytes(sim, 0, 0, true);
+    switch (sim->group) {
+      case 64: return launch(k_sim_step<64, true>, grid, block, lds, stream, A);
+      case 32: return launch(k_sim_step<32, true>, grid, block, lds, stream, A);
+      default: return launch(k_sim_step<16, true>, grid, block, lds, stream, A);
+    }
+  }
   const size_t lds = sim_lds_bytes(sim, 0, 0);
   switch (sim->group) {
-    case 64: return launch(k_sim_step<64>, grid, block, lds, stream, A);
-    case 32: return launch(k_sim_step<32>, grid, block, lds, stream, A);
-    default: return launch(k_sim_step<16>, grid, block, lds, stream, A);
+    case 64: return launch(k_sim_step<64, false>, grid, block, lds, stream, A);
+    case 32: return launch(k_sim_step<32, false>, grid, block, lds, stream, A);
+    default: return launch(k_sim_step<16, false>, grid, block, lds, stream, A);
   }
 }
 
@@ -655,18 +726,19 @@ extern "C" int shf_sim_refresh(ShfSim* sim, int32_t mask, void* stream) {
     HIP_OK(hipMemcpyAsync(sim->t[SHF_T_ROOT_STATE], sim->t[SHF_T_SIM_ROOT], N * A * 13 * 4, hipMemcpyDeviceToDevice, st));
   if ((mask & SHF_REFRESH_CONTACT) && sim->t[SHF_T_CONTACT] && sim->t[SHF_T_SIM_CONTACT])
     HIP_OK(hipMemcpyAsync(sim->t[SHF_T_CONTACT], sim->t[SHF_T_SIM_CONTACT], N * B * 3 * 4, hipMemcpyDeviceToDevice, st));
-  if ((mask & SHF_REFRESH_BODY) && sim->t[SHF_T_BODY_STATE]) {
+  float* bs = (mask & SHF_REFRESH_BODY) ? (float*)sim->t[SHF_T_BODY_STATE] : nullptr;
+  float* jac = ((mask & SHF_REFRESH_JACOBIAN) && sim->model.fixed_base) ? (float*)sim->t[SHF_T_JACOBIAN] : nullptr;
+  if (bs || jac) {
     const int epb = 256 / sim->group;
     dim3 grid((sim->n + epb - 1) / epb), block(256);
     const size_t lds = sim_lds_bytes(sim, 0, 0);
     const ShfModel* gm = (const ShfModel*)sim->t[SHF_T_MODEL];
     const float* dof = (const float*)sim->t[SHF_T_SIM_DOF];
     const float* root = (const float*)sim->t[SHF_T_SIM_ROOT];
-    float* bs = (float*)sim->t[SHF_T_BODY_STATE];
     switch (sim->group) {
-      case 64: return launch(k_body_state<64>, grid, block, lds, stream, gm, sim->n, dof, root, (int)A, bs);
-      case 32: return launch(k_body_state<32>, grid, block, lds, stream, gm, sim->n, dof, root, (int)A, bs);
-      default: return launch(k_body_state<16>, grid, block, lds, stream, gm, sim->n, dof, root, (int)A, bs);
+      case 64: return launch(k_body_state<64>, grid, block, lds, stream, gm, sim->n, dof, root, (int)A, bs, jac);
+      case 32: return launch(k_body_state<32>, grid, block, lds, stream, gm, sim->n, dof, root, (int)A, bs, jac);
+      default: return launch(k_body_state<16>, grid, block, lds, stream, gm, sim->n, dof, root, (int)A, bs, jac);
     }
   }
   return 0;

@@ -1,0 +1,348 @@
+// shf_boxes.h -- single-body box actors (gym.create_box, reference shifu/units/object.py:19-39;
+// the ABB push-box scene of examples/abb_pushbox_vision/task_config.py:13-46: fixed table, free
+// cube, fixed goal pad) and their contacts.  Included by shf_device.h, same arithmetic contract.
+//
+// Lane roles added to a group:   lane nb + k          <-> box actor k
+//                                lane i (+j*G)        <-> one (corner, target) or (sphere, box) slot
+// Free boxes are rigid bodies under the same linearly-implicit contact law as the articulation:
+// 8 corners against the terrain and every static box, the articulation's collision spheres against
+// them.  Arm<->box coupling is staggered (each side sees the other's point moving with its
+// start-of-step velocity); the articulation side is scaled by m_box / (m_box + dt*beta) so that
+// both sides feel about the same force.
+#pragma once
+
+DEV bool box_is_dynamic(const ShfBoxDesc& b) { return !b.fixed && b.mass > 0.0f; }
+
+// slot layout in LDS (PT_STRIDE floats): on r[3] n[3] f0[3] ct bn
+DEV void slot_eval(float* o, float phi, const float* n, const float* r, const float* vp, float mu, float kc,
+                   float beta, float veps, float vdep) {
+  float on = 0.0f;
+  if (phi < 0.0f) {
+    const float vn = dot3(n, vp);
+    const float fn = fmaf(-beta, vn, rminf(-kc * phi, beta * vdep));
+    if (fn > 0.0f) {
+      const float vt[3] = {fmaf(-vn, n[0], vp[0]), fmaf(-vn, n[1], vp[1]), fmaf(-vn, n[2], vp[2])};
+      const float vtn = sqrtf(dot3(vt, vt));
+      const float ct = mu * fn / rmaxf(vtn, veps);
+      on = 1.0f;
+      o[10] = ct;
+      o[11] = beta;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { o[1 + k] = r[k]; o[4 + k] = n[k]; o[7 + k] = fmaf(fn, n[k], -(ct * vt[k])); }
+    }
+  }
+  o[0] = on;
+}
+
+DEV void slot_accumulate(float* IA, float* pA, const float* o, float sign, float dt, float scale) {
+  const float ss = sign * scale, oct = o[10] * scale, obn = o[11] * scale;
+  const float f0[3] = {ss * o[7], ss * o[8], ss * o[9]};
+  const float r[3] = {o[1], o[2], o[3]}, n[3] = {o[4], o[5], o[6]};
+  float t[3], wn[6];
+  cross3(r, f0, t);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { pA[k] -= t[k]; pA[3 + k] -= f0[k]; }
+  cross3(r, n, t);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { wn[k] = t[k]; wn[3 + k] = n[k]; }
+  const float a = dt * oct, bb = dt * (obn - oct);
+  const float r2 = dot3(r, r);
+#pragma unroll
+  for (int i2 = 0; i2 < 3; i2++)
+#pragma unroll
+    for (int j2 = i2; j2 < 3; j2++) IA[SYM(i2, j2)] = fmaf(a, (i2 == j2 ? r2 : 0.0f) - r[i2] * r[j2], IA[SYM(i2, j2)]);
+  IA[SYM(0, 4)] = fmaf(a, -r[2], IA[SYM(0, 4)]); IA[SYM(0, 5)] = fmaf(a, r[1], IA[SYM(0, 5)]);
+  IA[SYM(1, 3)] = fmaf(a, r[2], IA[SYM(1, 3)]);  IA[SYM(1, 5)] = fmaf(a, -r[0], IA[SYM(1, 5)]);
+  IA[SYM(2, 3)] = fmaf(a, -r[1], IA[SYM(2, 3)]); IA[SYM(2, 4)] = fmaf(a, r[0], IA[SYM(2, 4)]);
+  IA[SYM(3, 3)] += a; IA[SYM(4, 4)] += a; IA[SYM(5, 5)] += a;
+#pragma unroll
+  for (int i2 = 0; i2 < 6; i2++) {
+    const float bw = bb * wn[i2];
+#pragma unroll
+    for (int j2 = i2; j2 < 6; j2++) IA[SYM(i2, j2)] = fmaf(bw, wn[j2], IA[SYM(i2, j2)]);
+  }
+}
+
+DEV void slot_force(const float* o, const float* ab, float sign, float dt, float scale, float* f) {
+  const float ss = sign * scale, oct = o[10] * scale, obn = o[11] * scale;
+  const float r[3] = {o[1], o[2], o[3]}, n[3] = {o[4], o[5], o[6]}, al[3] = {ab[0], ab[1], ab[2]};
+  float t[3], ap[3];
+  cross3(al, r, t);
+#pragma unroll
+  for (int k = 0; k < 3; k++) ap[k] = ab[3 + k] + t[k];
+  const float an = dot3(n, ap);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float Ba = fmaf(obn - oct, an * n[k], oct * ap[k]);
+    f[k] += fmaf(-dt, Ba, ss * o[7 + k]);
+  }
+}
+
+DEV float pair_scale(const ShfBoxDesc& b, const float* o, float dt) { return b.mass / fmaf(dt, o[11], b.mass); }
+
+DEV bool point_in_box(const float* bR, const float* bpos, const float* h, const float* r, float* phi, float* n) {
+  const float rel[3] = {r[0] - bpos[0], r[1] - bpos[1], r[2] - bpos[2]};
+  float d[3], pen[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) d[i] = fmaf(bR[6 + i], rel[2], fmaf(bR[3 + i], rel[1], bR[i] * rel[0]));
+#pragma unroll
+  for (int i = 0; i < 3; i++) pen[i] = h[i] - fabsf(d[i]);
+  if (!(pen[0] > 0.0f) || !(pen[1] > 0.0f) || !(pen[2] > 0.0f)) return false;
+  int ax = 0;
+  if (pen[1] < pen[ax]) ax = 1;
+  if (pen[2] < pen[ax]) ax = 2;
+  const float dax = ax == 0 ? d[0] : (ax == 1 ? d[1] : d[2]);
+  const float pax = ax == 0 ? pen[0] : (ax == 1 ? pen[1] : pen[2]);
+  const float sg = dax < 0.0f ? -1.0f : 1.0f;
+  *phi = -pax;
+  n[0] = sg * bR[ax]; n[1] = sg * bR[3 + ax]; n[2] = sg * bR[6 + ax];
+  return true;
+}
+
+DEV void sphere_vs_box(const float* bR, const float* bpos, const float* h, const float* c, float rad, float* phi,
+                       float* n, float* rc) {
+  const float rel[3] = {c[0] - bpos[0], c[1] - bpos[1], c[2] - bpos[2]};
+  float d[3], q[3], nl[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) d[i] = fmaf(bR[6 + i], rel[2], fmaf(bR[3 + i], rel[1], bR[i] * rel[0]));
+  bool outside = false;
+#pragma unroll
+  for (int i = 0; i < 3; i++) { q[i] = rclampf(d[i], -h[i], h[i]); outside = outside || (q[i] != d[i]); }
+  if (outside) {
+    const float df[3] = {d[0] - q[0], d[1] - q[1], d[2] - q[2]};
+    const float dist = sqrtf(dot3(df, df));
+    *phi = dist - rad;
+    const float inv = 1.0f / rmaxf(dist, 1e-12f);
+#pragma unroll
+    for (int i = 0; i < 3; i++) nl[i] = df[i] * inv;
+  } else {
+    const float pen[3] = {h[0] - fabsf(d[0]), h[1] - fabsf(d[1]), h[2] - fabsf(d[2])};
+    int ax = 0;
+    if (pen[1] < pen[ax]) ax = 1;
+    if (pen[2] < pen[ax]) ax = 2;
+    const float dax = ax == 0 ? d[0] : (ax == 1 ? d[1] : d[2]);
+    const float pax = ax == 0 ? pen[0] : (ax == 1 ? pen[1] : pen[2]);
+    const float hax = ax == 0 ? h[0] : (ax == 1 ? h[1] : h[2]);
+    const float sg = dax < 0.0f ? -1.0f : 1.0f;
+    *phi = -pax - rad;
+    nl[0] = ax == 0 ? sg : 0.0f; nl[1] = ax == 1 ? sg : 0.0f; nl[2] = ax == 2 ? sg : 0.0f;
+    if (ax == 0) q[0] = sg * hax; else if (ax == 1) q[1] = sg * hax; else q[2] = sg * hax;
+  }
+  mv3(bR, nl, n);
+  mv3(bR, q, rc);
+#pragma unroll
+  for (int i = 0; i < 3; i++) rc[i] += bpos[i];
+}
+
+// slot indexing inside the env's contact region, after the articulation's np sample points
+DEV int corner_slot(const ShfModel* m, int nbx, int kd, int c, int tg) { return m->np + (kd * 8 + c) * (1 + nbx) + tg; }
+DEV int sphere_slot(const ShfModel* m, int nbx, int si, int kd) { return m->np + nbx * 8 * (1 + nbx) + si * nbx + kd; }
+__host__ __device__ inline int box_slot_count(int nbx, int nsph) { return nbx * 8 * (1 + nbx) + nsph * nbx; }
+
+// Box lanes: pose / spatial velocity about O from the root-state rows, inertia of the free ones.
+template <int G>
+DEV void boxes_pose(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B) {
+  const ShfModel* m = C.m;
+  const int nb = m->nb, nbx = C.scene->nboxes;
+  const int k = l - nb;
+  if (k >= 0 && k < nbx) {
+    const float* row = L.root + 13 * (1 + k);
+    const ShfBoxDesc& bd = C.scene->box[k];
+    quat_to_mat(row + 3, B.Rw);
+#pragma unroll
+    for (int i = 0; i < 3; i++) B.p[i] = row[i] - L.root[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) B.v[i] = 0.0f;
+    if (box_is_dynamic(bd)) {
+      const float ang[3] = {row[10], row[11], row[12]};
+      float t[3];
+      cross3(ang, B.p, t);
+#pragma unroll
+      for (int i = 0; i < 3; i++) { B.v[i] = ang[i]; B.v[3 + i] = row[7 + i] - t[i]; }
+      const float mass = bd.mass, dx = bd.dim[0], dy = bd.dim[1], dz = bd.dim[2];
+      const float I6[6] = {mass * (dy * dy + dz * dz) / 12.0f, 0.0f, 0.0f, mass * (dx * dx + dz * dz) / 12.0f, 0.0f,
+                           mass * (dx * dx + dy * dy) / 12.0f};
+      const float com[3] = {0.0f, 0.0f, 0.0f};
+      rigid_inertia(mass, com, I6, B);
+    }
+    float* o = L.pose + l * POSE_STRIDE;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o[i] = B.Rw[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) o[9 + i] = B.p[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) o[12 + i] = B.v[i];
+  }
+  GROUP_SYNC();
+}
+
+// Evaluate every box contact slot (one lane each), then fold them into the owning bodies.
+template <int G>
+DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, float mu_shape, const float* g_art) {
+  const ShfModel* m = C.m;
+  const SceneDev* S = C.scene;
+  const int nb = m->nb, nbx = S->nboxes, T = 1 + nbx;
+  const float dt = C.sp.dt, kc = C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
+  const float beta = fmaf(kc, dt, C.sp.contact_d);
+  const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
+  // corner slots
+  for (int idx = l; idx < nbx * 8 * T; idx += G) {
+    const int kd = idx / (8 * T), c = (idx / T) % 8, tg = idx % T;
+    float* o = L.pt + corner_slot(m, nbx, kd, c, tg) * PT_STRIDE;
+    o[0] = 0.0f;
+    const ShfBoxDesc& bd = S->box[kd];
+    if (!box_is_dynamic(bd)) continue;
+    const float* pk = L.pose + (nb + kd) * POSE_STRIDE;
+    float Rk[9], lc[3] = {((c & 4) ? 0.5f : -0.5f) * bd.dim[0], ((c & 2) ? 0.5f : -0.5f) * bd.dim[1],
+                          ((c & 1) ? 0.5f : -0.5f) * bd.dim[2]};
+#pragma unroll
+    for (int i = 0; i < 9; i++) Rk[i] = pk[i];
+    float r[3], t[3], vp[3], n[3], h, phi, vb[3] = {pk[12], pk[13], pk[14]};
+    mv3(Rk, lc, r);
+#pragma unroll
+    for (int i = 0; i < 3; i++) r[i] += pk[9 + i];
+    cross3(vb, r, t);
+#pragma unroll
+    for (int i = 0; i < 3; i++) vp[i] = fmaf(dt, gb[i], pk[15 + i] + t[i]);
+    if (tg == 0) {
+      terrain_query(C.terr, L.root[0] + r[0], L.root[1] + r[1], &h, n);
+      phi = (L.root[2] + r[2] - h) * n[2];
+      slot_eval(o, phi, n, r, vp, 0.5f * (bd.friction + C.terr.t.friction), kc, beta, veps, vdep);
+    } else {
+      const int ks = tg - 1;
+      const ShfBoxDesc& bs = S->box[ks];
+      if (ks == kd || box_is_dynamic(bs)) continue;
+      const float* ps = L.pose + (nb + ks) * POSE_STRIDE;
+      float Rs[9], hh[3] = {0.5f * bs.dim[0], 0.5f * bs.dim[1], 0.5f * bs.dim[2]}, bpos[3] = {ps[9], ps[10], ps[11]};
+#pragma unroll
+      for (int i = 0; i < 9; i++) Rs[i] = ps[i];
+      if (!point_in_box(Rs, bpos, hh, r, &phi, n)) continue;
+      slot_eval(o, phi, n, r, vp, 0.5f * (bd.friction + bs.friction), kc, beta, veps, vdep);
+    }
+  }
+  // sphere slots
+  for (int idx = l; idx < m->nsph * nbx; idx += G) {
+    const int si = idx / nbx, kd = idx % nbx;
+    float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
+    o[0] = 0.0f;
+    const ShfBoxDesc& bd = S->box[kd];
+    if (!box_is_dynamic(bd)) continue;
+    const int b = m->sph_body[si];
+    const float* pb = L.pose + b * POSE_STRIDE;
+    const float* pk = L.pose + (nb + kd) * POSE_STRIDE;
+    float Rb[9], Rk[9], lp[3] = {m->sph_pos[si][0], m->sph_pos[si][1], m->sph_pos[si][2]}, c[3];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { Rb[i] = pb[i]; Rk[i] = pk[i]; }
+    mv3(Rb, lp, c);
+#pragma unroll
+    for (int i = 0; i < 3; i++) c[i] += pb[9 + i];
+    const float hh[3] = {0.5f * bd.dim[0], 0.5f * bd.dim[1], 0.5f * bd.dim[2]}, bpos[3] = {pk[9], pk[10], pk[11]};
+    float phi, n[3], rc[3], ta[3], tb[3], vrel[3];
+    sphere_vs_box(Rk, bpos, hh, c, m->sph_radius[si], &phi, n, rc);
+    const float va[3] = {pb[12], pb[13], pb[14]}, vbx[3] = {pk[12], pk[13], pk[14]};
+    cross3(va, rc, ta);
+    cross3(vbx, rc, tb);
+#pragma unroll
+    for (int i = 0; i < 3; i++) vrel[i] = fmaf(dt, g_art[i], pb[15 + i] + ta[i]) - fmaf(dt, gb[i], pk[15 + i] + tb[i]);
+    slot_eval(o, phi, n, rc, vrel, 0.5f * (mu_shape + bd.friction), kc, beta, veps, vdep);
+  }
+  GROUP_SYNC();
+  // fold
+  if (l < nb && m->dyn[l] == l) {
+    for (int si = 0; si < m->nsph; si++) {
+      if (m->dyn[m->sph_body[si]] != l) continue;
+      for (int kd = 0; kd < nbx; kd++) {
+        const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
+        if (o[0] != 0.0f) slot_accumulate(B.IA, B.pA, o, 1.0f, dt, pair_scale(S->box[kd], o, dt));
+      }
+    }
+  }
+  const int kd = l - nb;
+  if (kd >= 0 && kd < nbx && box_is_dynamic(S->box[kd])) {
+    for (int c = 0; c < 8; c++)
+      for (int tg = 0; tg < T; tg++) {
+        const float* o = L.pt + corner_slot(m, nbx, kd, c, tg) * PT_STRIDE;
+        if (o[0] != 0.0f) slot_accumulate(B.IA, B.pA, o, 1.0f, dt, 1.0f);
+      }
+    for (int si = 0; si < m->nsph; si++) {
+      const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
+      if (o[0] != 0.0f) slot_accumulate(B.IA, B.pA, o, -1.0f, dt, 1.0f);
+    }
+  }
+}
+
+// Solve the free boxes, report contact forces (boxes and the articulation's sphere contacts),
+// integrate the boxes.  contact_out has nb + nboxes rows.
+template <int G>
+DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, float* contact_out) {
+  const ShfModel* m = C.m;
+  const SceneDev* S = C.scene;
+  const int nb = m->nb, nbx = S->nboxes, T = 1 + nbx;
+  const float dt = C.sp.dt;
+  const int kd = l - nb;
+  const bool isbox = kd >= 0 && kd < nbx;
+  const bool dynbox = isbox && box_is_dynamic(S->box[kd]);
+  float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  if (dynbox) ldlt_solve6(B.IA, B.pA, a);
+  if (contact_out) {
+    if (l < nb) {
+      float f[3] = {contact_out[3 * l], contact_out[3 * l + 1], contact_out[3 * l + 2]};
+      const float* ab = L.acc + m->dyn[l] * 6;
+      const float abr[6] = {ab[0], ab[1], ab[2], ab[3], ab[4], ab[5]};
+      for (int si = 0; si < m->nsph; si++) {
+        if (m->sph_body[si] != l) continue;
+        for (int k2 = 0; k2 < nbx; k2++) {
+          const float* o = L.pt + sphere_slot(m, nbx, si, k2) * PT_STRIDE;
+          if (o[0] != 0.0f) slot_force(o, abr, 1.0f, dt, pair_scale(S->box[k2], o, dt), f);
+        }
+      }
+      contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];
+    }
+    if (isbox) {
+      float f[3] = {0.0f, 0.0f, 0.0f};
+      if (dynbox) {
+        for (int c = 0; c < 8; c++)
+          for (int tg = 0; tg < T; tg++) {
+            const float* o = L.pt + corner_slot(m, nbx, kd, c, tg) * PT_STRIDE;
+            if (o[0] != 0.0f) slot_force(o, a, 1.0f, dt, 1.0f, f);
+          }
+        for (int si = 0; si < m->nsph; si++) {
+          const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
+          if (o[0] != 0.0f) slot_force(o, a, -1.0f, dt, 1.0f, f);
+        }
+      }
+      contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];
+    }
+  }
+  if (dynbox) {
+    float* row = L.root + 13 * (1 + kd);
+    const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
+    const float ang[3] = {row[10], row[11], row[12]}, lin[3] = {row[7], row[8], row[9]}, al[3] = {a[0], a[1], a[2]};
+    float wxv[3], axp[3];
+    cross3(ang, lin, wxv);
+    cross3(al, B.p, axp);
+    const float damp = 1.0f / fmaf(dt, C.sp.angular_damping, 1.0f);
+    float wn[3], vn[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      wn[k] = fmaf(dt, a[k], ang[k]) * damp;
+      vn[k] = fmaf(dt, a[3 + k] + gb[k] + axp[k] + wxv[k], lin[k]);
+    }
+    const float wmag = sqrtf(dot3(wn, wn)), wmax = C.sp.max_ang_vel;
+    if (wmag > wmax) {
+      const float sc2 = wmax / wmag;
+#pragma unroll
+      for (int k = 0; k < 3; k++) wn[k] *= sc2;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { row[10 + k] = wn[k]; row[7 + k] = vn[k]; row[k] = fmaf(dt, vn[k], row[k]); }
+    const float hx = 0.5f * dt * wn[0], hy = 0.5f * dt * wn[1], hz = 0.5f * dt * wn[2];
+    const float x = row[3], y = row[4], z = row[5], ww = row[6];
+    const float nx = x + fmaf(hx, ww, fmaf(hy, z, -(hz * y)));
+    const float ny = y + fmaf(hy, ww, fmaf(hz, x, -(hx * z)));
+    const float nz = z + fmaf(hz, ww, fmaf(hx, y, -(hy * x)));
+    const float nw = ww - fmaf(hx, x, fmaf(hy, y, hz * z));
+    const float inv = 1.0f / sqrtf(fmaf(nw, nw, fmaf(nz, nz, fmaf(ny, ny, nx * nx))));
+    row[3] = nx * inv; row[4] = ny * inv; row[5] = nz * inv; row[6] = nw * inv;
+  }
+}

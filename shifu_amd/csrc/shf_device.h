@@ -165,7 +165,6 @@ DEV void terrain_query(const TerrainDev& T, float x, float y, float* h, float* n
 #define XCH_STRIDE 27  /* Ia[21] pa[6]                                      */
 #define PT_STRIDE 12   /* on r[3] n[3] f[3] ct bn                           */
 #define DOF_STRIDE 6   /* q qd tau0 dex qdd tau_cmd                         */
-#define ROOT_WORDS 16  /* pos[3] quat[4] lin[3] ang[3] spare[3]             */
 
 struct EnvLds {
   float* pose;
@@ -178,20 +177,23 @@ struct EnvLds {
 
 // The contact-point region comes last: kernels that need post-physics scratch
 // reuse it and may ask for `min_tail` words there.
-__host__ __device__ inline int env_lds_words(int nb, int nd, int np, int min_tail = 0) {
+// `nb` counts pose/acc/xch entries (reported bodies + box actors), `np` contact slots
+// (articulation sample points + box corner/sphere slots), `nactors` root-state rows.
+__host__ __device__ inline int root_words(int nactors) { return (13 * nactors + 3 + 3) & ~3; }
+__host__ __device__ inline int env_lds_words(int nb, int nd, int np, int min_tail = 0, int nactors = 1) {
   int tail = np * PT_STRIDE;
   if (tail < min_tail) tail = min_tail;
-  int w = nb * POSE_STRIDE + nb * 6 + nb * XCH_STRIDE + nd * DOF_STRIDE + ROOT_WORDS + tail;
+  int w = nb * POSE_STRIDE + nb * 6 + nb * XCH_STRIDE + nd * DOF_STRIDE + root_words(nactors) + tail;
   return (w + 3) & ~3;
 }
-DEV EnvLds env_lds_carve(float* base, int nb, int nd, int np) {
+DEV EnvLds env_lds_carve(float* base, int nb, int nd, int np, int nactors = 1) {
   EnvLds L;
   L.pose = base;
   L.acc = L.pose + nb * POSE_STRIDE;
   L.xch = L.acc + nb * 6;
   L.dofb = L.xch + nb * XCH_STRIDE;
   L.root = L.dofb + nd * DOF_STRIDE;
-  L.pt = L.root + ROOT_WORDS;
+  L.pt = L.root + root_words(nactors);
   return L;
 }
 
@@ -293,19 +295,15 @@ DEV void kinematics(const ShfModel* m, const EnvLds& L, int l, BodyRegs& B) {
 }
 
 // spatial inertia about O in world axes (packed) and velocity-product bias force
-DEV void body_inertia(const ShfModel* m, int b, BodyRegs& B) {
-  float com[3], cw[3], Ic[9], T[9];
-#pragma unroll
-  for (int k = 0; k < 3; k++) com[k] = m->com[b][k];
+DEV void rigid_inertia(float mass, const float* com, const float* I6, BodyRegs& B) {
+  float cw[3], Ic[9], T[9];
   mv3(B.Rw, com, cw);
 #pragma unroll
   for (int k = 0; k < 3; k++) cw[k] += B.p[k];
-  const float* I6 = m->inertia[b];
   Ic[0] = I6[0]; Ic[1] = I6[1]; Ic[2] = I6[2];
   Ic[3] = I6[1]; Ic[4] = I6[3]; Ic[5] = I6[4];
   Ic[6] = I6[2]; Ic[7] = I6[4]; Ic[8] = I6[5];
   mm3(B.Rw, Ic, T);
-  const float mass = m->mass[b];
   const float c2 = dot3(cw, cw);
 #pragma unroll
   for (int k = 0; k < 21; k++) B.IA[k] = 0.0f;
@@ -341,18 +339,63 @@ DEV void body_inertia(const ShfModel* m, int b, BodyRegs& B) {
 #pragma unroll
   for (int k = 0; k < 3; k++) B.pA[3 + k] = t[k];
 }
+DEV void body_inertia(const ShfModel* m, int b, BodyRegs& B) {
+  const float com[3] = {m->com[b][0], m->com[b][1], m->com[b][2]};
+  const float I6[6] = {m->inertia[b][0], m->inertia[b][1], m->inertia[b][2], m->inertia[b][3], m->inertia[b][4], m->inertia[b][5]};
+  rigid_inertia(m->mass[b], com, I6, B);
+}
 
+typedef ShfScene SceneDev;  // box actors of the scene (gym.create_box), staged in LDS next to the model
 struct StepCtx {
   const ShfModel* m;   // LDS copy
   ShfSimParams sp;
   TerrainDev terr;
+  const SceneDev* scene;  // LDS copy, may be null when the scene has no boxes
 };
+
+// solve IA x = -pA for a symmetric positive definite 6x6 in packed storage (LDL^T)
+DEV void ldlt_solve6(const float* IA, const float* pA, float* x) {
+  float Lm[6][6], Dg[6], y[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    float d = IA[SYM(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; k++) d = fmaf(-(Lm[j][k] * Lm[j][k]), Dg[k], d);
+    Dg[j] = d;
+    const float id = 1.0f / d;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      float v = IA[SYM(j, i)];
+#pragma unroll
+      for (int k = 0; k < j; k++) v = fmaf(-(Lm[i][k] * Lm[j][k]), Dg[k], v);
+      Lm[i][j] = v * id;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    float v = -pA[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) v = fmaf(-Lm[i][k], y[k], v);
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) y[i] = y[i] / Dg[i];
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    float v = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) v = fmaf(-Lm[k][i], x[k], v);
+    x[i] = v;
+  }
+}
+
+#include "shf_boxes.h"
 
 // One gym.simulate() for one env, executed by the G lanes of its group.
 //   dofb[d]: q, qd in;  tau_cmd (explicit effort), pos/vel targets via pt_tgt/vt_tgt (LDS, may be null)
 //   fext: world force per reported body (global memory, this env) or nullptr
 //   contact_out: LDS/global float[nb*3] written by body lanes (may be nullptr)
-template <int G>
+template <int G, bool BOX = false>
 DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt, const float* vel_tgt,
                  const float* fext, float mu_shape, float* contact_out) {
   const ShfModel* m = C.m;
@@ -369,6 +412,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt,
   BodyRegs B;
   kinematics<G>(m, L, l, B);
   if (isdyn) body_inertia(m, l, B);
+  if (BOX) boxes_pose<G>(C, L, l, B);
 
   // external forces at the CoM of reported bodies, folded in ascending body order
   if (fext) {
@@ -476,6 +520,8 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt,
     }
   }
 
+  if (BOX) boxes_contacts<G>(C, L, l, B, mu_shape, g);
+
   // joint-space efforts: one lane per dof
   if (l < nd) {
     float* D = L.dofb + l * DOF_STRIDE;
@@ -573,38 +619,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt,
     if (m->fixed_base) {
       a[3] = -g[0]; a[4] = -g[1]; a[5] = -g[2];
     } else {
-      float Lm[6][6], Dg[6], y[6];
-#pragma unroll
-      for (int j = 0; j < 6; j++) {
-        float d = B.IA[SYM(j, j)];
-#pragma unroll
-        for (int k = 0; k < j; k++) d = fmaf(-(Lm[j][k] * Lm[j][k]), Dg[k], d);
-        Dg[j] = d;
-        const float id = 1.0f / d;
-#pragma unroll
-        for (int i = j + 1; i < 6; i++) {
-          float v = B.IA[SYM(j, i)];
-#pragma unroll
-          for (int k = 0; k < j; k++) v = fmaf(-(Lm[i][k] * Lm[j][k]), Dg[k], v);
-          Lm[i][j] = v * id;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 6; i++) {
-        float v = -B.pA[i];
-#pragma unroll
-        for (int k = 0; k < i; k++) v = fmaf(-Lm[i][k], y[k], v);
-        y[i] = v;
-      }
-#pragma unroll
-      for (int i = 0; i < 6; i++) y[i] = y[i] / Dg[i];
-#pragma unroll
-      for (int i = 5; i >= 0; i--) {
-        float v = y[i];
-#pragma unroll
-        for (int k = i + 1; k < 6; k++) v = fmaf(-Lm[k][i], a[k], v);
-        a[i] = v;
-      }
+      ldlt_solve6(B.IA, B.pA, a);
     }
 #pragma unroll
     for (int k = 0; k < 6; k++) L.acc[k] = a[k];
@@ -659,6 +674,11 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt,
       }
       contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];
     }
+  }
+
+  if (BOX) {
+    GROUP_SYNC();
+    boxes_finish<G>(C, L, l, B, contact_out);
   }
 
   // semi-implicit Euler

@@ -271,3 +271,64 @@ def test_backend_fails_loudly_without_library(monkeypatch):
     monkeypatch.setattr(L, "_PATH", "/nonexistent/libshifu_amd.so")
     with pytest.raises(L.BackendError):
         L.lib()
+
+
+@pytest.mark.parametrize("group", [64, 32])
+def test_abb_scene_matches_oracle_bitwise(oracle, group):
+    """Config 5 scene (reference examples/abb_pushbox_vision/task_config.py:13-84): fixed-base 6-dof arm
+    under implicit POS drives, fixed table, free cube, fixed goal pad; cube-on-table and rod-vs-cube
+    contacts; rigid_body_state incl. the box rows and the fixed-base Jacobian tensor."""
+    _need_gpu()
+    from shifu_amd.abb_task import ABB_BASE_POS, ABB_DEFAULT_DOF_POS, abb_boxes, abb_model
+    from shifu_amd.backend import Sim
+    rng = np.random.default_rng(17)
+    cm = abb_model()
+    m = cm.blob
+    sp = H.sim_params(dt=0.02, angular_damping=0.5)
+    boxes = abb_boxes()
+    n, A, B = 32, 4, m.nb + 3
+    dof = np.zeros((n * m.nd, 2), np.float32)
+    dof[:, 0] = np.tile(np.array(ABB_DEFAULT_DOF_POS, np.float32), n) + rng.uniform(-0.05, 0.05, n * m.nd)
+    root = np.zeros((n * A, 13), np.float32)
+    root[:, 6] = 1.0
+    root[0::A, :3] = ABB_BASE_POS
+    root[1::A, :3] = [0, 0, 0.05]
+    root[2::A, :3] = np.stack([rng.uniform(0.03, 0.08, n), rng.uniform(-0.03, 0.03, n), rng.uniform(0.125, 0.14, n)], 1)
+    yaw = rng.uniform(-np.pi, np.pi, n)
+    root[2::A, 5], root[2::A, 6] = np.sin(yaw / 2), np.cos(yaw / 2)
+    root[3::A, :3] = np.stack([rng.uniform(-0.1, 0.1, n), rng.uniform(-0.1, 0.1, n), np.full(n, 0.1)], 1)
+    fr = np.ones(n, np.float32)
+    sim = Sim(sp, "cuda:0")
+    sim.set_plane(1.0)
+    sim.set_articulation(m)
+    for b in boxes:
+        sim.add_box(b)
+    sim.finalize(n, 0, group=group)
+    T = sim.tensors
+    T[_abi.T_SIM_DOF].copy_(torch.from_numpy(dof))
+    T[_abi.T_SIM_ROOT].copy_(torch.from_numpy(root))
+    tgt = dof[:, 0].copy()
+    touched = False
+    for it in range(60):
+        if it % 6 == 0:   # drive the rod towards +x: joint_2/joint_3 forward a little each env step
+            tgt = dof[:, 0].copy()
+            tgt[1::m.nd] += 0.02
+            tgt[2::m.nd] -= 0.01
+            tgt += rng.uniform(-0.005, 0.005, tgt.shape).astype(np.float32)
+        sim.set_dof_command(_abi.T_POS_TARGET, torch.from_numpy(tgt).cuda())
+        sim.step()
+        sim.refresh(_abi.REFRESH_ALL)
+        contact, bstate, jac = oracle.scene_step(m, sp, boxes, n, dof, root, pos_target=tgt, friction=fr,
+                                                 want_jacobian=True)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(T[_abi.T_DOF_STATE].cpu().numpy(), dof, err_msg=f"dof step {it}")
+        np.testing.assert_array_equal(T[_abi.T_ROOT_STATE].cpu().numpy(), root, err_msg=f"root step {it}")
+        np.testing.assert_array_equal(T[_abi.T_CONTACT].cpu().numpy(), contact, err_msg=f"contact step {it}")
+        np.testing.assert_array_equal(T[_abi.T_BODY_STATE].cpu().numpy(), bstate, err_msg=f"body step {it}")
+        np.testing.assert_array_equal(T[_abi.T_JACOBIAN].cpu().numpy(), jac, err_msg=f"jacobian step {it}")
+        touched |= bool(np.abs(contact.reshape(n, B, 3)[:, :m.nb]).sum() > 0)
+    assert np.isfinite(root).all() and np.isfinite(dof).all()
+    cube = root[2::A]
+    assert (np.abs(contact.reshape(n, B, 3)[:, m.nb + 1, 2] - 0.981) < 0.2).mean() > 0.5   # cubes rest on the table
+    assert touched, "the rod must have touched a cube"
+    assert (cube[:, 2] > 0.11).all()
