@@ -281,7 +281,12 @@ class Gym:
             base = os.path.basename(filename)
             alt = {"a1.urdf": "a1.urdf", "abb_rod_isaac.urdf": "abb_rod.urdf"}.get(base, base)
             path = asset_path(alt)
-        model = compile_urdf(path, fix_base_link=bool(options.fix_base_link),
+        # mesh colliders are not supported: known assets get their documented substitutes
+        extra = ()
+        if os.path.basename(path) in ("abb_rod.urdf", "abb_rod_isaac.urdf"):
+            from ..abb_task import ROD_SPHERES
+            extra = ROD_SPHERES
+        model = compile_urdf(path, extra_spheres=extra, fix_base_link=bool(options.fix_base_link),
                              disable_gravity=bool(options.disable_gravity),
                              collapse_fixed_joints=bool(options.collapse_fixed_joints),
                              default_dof_drive_mode=int(options.default_dof_drive_mode),

@@ -292,3 +292,22 @@ def test_spec_quat_rotate_inverse_matches_facade(oracle):
     v = rng.uniform(-3, 3, (256, 3)).astype(np.float32)
     np.testing.assert_allclose(oracle.quat_rotate_inverse(q, v), quat_rotate_inverse(tt(q), tt(v)).numpy(),
                                rtol=1e-6, atol=1e-6)
+
+
+def test_mirror_abb_pushbox_g10():
+    from examples.abb_pushbox_vision.a_prior_stage import AbbPushBox
+    g = load("g10_abb")
+    env = object.__new__(AbbPushBox)
+    env.cube, env.goal = NS(base_pose=tt(g["cube"])), NS(base_pose=tt(g["goal"]))
+    env.robot = NS(ee_pose=tt(g["ee"]), min_ee_pos=torch.tensor([-0.2, -0.2, 0.11]), max_ee_pos=torch.tensor([0.2, 0.2, 0.14]))
+    env.episode_length_buf = tt(g["ep_len"])
+    env.max_episode_length = float(g["max_episode_length"])
+    env.compute_observations()
+    env.compute_termination()
+    np.testing.assert_array_equal(env.obs_buf.numpy(), g["obs"])
+    np.testing.assert_array_equal(env.time_out_buf.numpy(), g["time_out"])
+    np.testing.assert_array_equal(env.success_buf.numpy(), g["success"])
+    np.testing.assert_array_equal(env.reset_buf.numpy(), g["reset"])
+    np.testing.assert_array_equal(env.reward_reaching().numpy(), g["reward_reaching"])
+    np.testing.assert_array_equal(env.reward_success().numpy(), g["reward_success"])
+    assert list(g["success"][:4]) == [True, False, True, True]     # 0.02 m threshold, strict '<'

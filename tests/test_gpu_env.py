@@ -102,3 +102,60 @@ def test_hook_env_random_run_mode_is_stable():
     assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
     assert "episode" in extras and "tracking_lin_vel" in extras["episode"] and "terrain_levels" in extras["episode"]
     assert extras["time_outs"].dtype == torch.bool
+
+
+def _abb(n=32):
+    from examples.abb_pushbox_vision.a_prior_stage import AbbPushBox
+    from examples.abb_pushbox_vision.task_config import PriorStageEnvConfig
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU is visible")
+    cfg = PriorStageEnvConfig()
+    cfg.num_envs = n
+    np.random.seed(3)
+    torch.manual_seed(3)
+    return AbbPushBox(cfg)
+
+
+def test_abb_pushbox_random_run_mode():
+    """Config 5 through the boundary: arm + table + cube + goal (4 actors / env), IK on the
+    backend's Jacobian tensor, POS drives, 5+1 sub-steps of 20 ms, resets."""
+    env = _abb(32)
+    assert env.isg_env.root_state.shape == (32 * 4, 13) and env.isg_env.body_state.shape == (32 * 10, 13)
+    assert env.robot.j_ee.shape == (32, 6, 6) and env.robot.num_dof == 6 and env.robot.num_bodies == 7
+    env.reset()
+    ee0 = env.robot.ee_pose[:, 0, :3].clone()
+    assert torch.allclose(ee0[:, 2], torch.full((32,), 0.14, device=ee0.device), atol=0.02)  # clipped into the workspace
+    resets = 0
+    for _ in range(120):
+        a = 2 * torch.rand(env.num_envs, env.num_actions, device=env.device) - 1
+        obs, _, rew, done, extras = env.step(a)
+        resets += int(done.sum())
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    assert obs.shape == (32, 6) and "success_rate" in extras["episode"]
+    cube = env.cube.base_pose
+    assert ((cube[:, 2] > 0.11) & (cube[:, 2] < 0.16)).all(), "cubes must stay on the table"
+    assert resets > 0
+
+
+def test_abb_rod_pushes_the_cube():
+    env = _abb(16)
+    env.reset()
+    be = env.isg_env.sim.backend
+    n, A = 16, 4
+    root = env.isg_env.root_state
+    root[2::A, :3] = torch.tensor([0.07, 0.0, 0.125], device=root.device)      # cube in front of the rod (+x)
+    root[2::A, 3:7] = torch.tensor([0, 0, 0, 1.0], device=root.device)
+    root[2::A, 7:] = 0
+    root[3::A, :3] = torch.tensor([0.18, 0.15, 0.1], device=root.device)       # goal out of the way
+    be.commit_root_all(root)
+    a = torch.tensor([[1.0, 0.0, -1.0]], device=root.device).repeat(n, 1)      # +x, rod tip down to z = 0.11
+    x0 = env.cube.base_pose[:, 0].clone()
+    for _ in range(14):
+        env.step(a)
+        if env.reset_buf.any():
+            break
+    moved = env.cube.base_pose[:, 0] - x0
+    ee = env.robot.ee_pose[:, 0, :3]
+    assert (moved > 0.01).all(), f"cube was not pushed: {moved}"
+    assert (ee[:, 0] + 0.0194 + 0.025 <= env.cube.base_pose[:, 0] + 0.01).all(), "rod must stay behind the cube face"
+    assert torch.isfinite(root).all()
