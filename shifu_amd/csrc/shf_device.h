@@ -531,17 +531,15 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt,
     if (mode == SHF_DOF_MODE_EFFORT) {
       t0 = D[5];
     } else if (mode == SHF_DOF_MODE_POS || mode == SHF_DOF_MODE_VEL) {
-      const float kp = mode == SHF_DOF_MODE_POS ? m->kp[l] : 0.0f, kd = m->kd[l];
+      float kp = mode == SHF_DOF_MODE_POS ? m->kp[l] : 0.0f, kd = m->kd[l];
       const float tq = pos_tgt ? pos_tgt[l] : 0.0f, tv = (mode == SHF_DOF_MODE_VEL && vel_tgt) ? vel_tgt[l] : 0.0f;
-      const float bj = fmaf(dt, kp, kd);
       const float est = fmaf(kp, tq - q, kd * (tv - qd));
       const float lim = m->effort[l];
-      if (lim > 0.0f && fabsf(est) > lim) {
-        t0 = rclampf(est, -lim, lim);
-      } else {
-        t0 = fmaf(kp, tq - q, fmaf(kd, tv, -(bj * qd)));
-        de = fmaf(dt, bj, de);
-      }
+      // drive saturation: scale both gains so the torque starts at the effort limit and stays implicit
+      if (lim > 0.0f && fabsf(est) > lim) { const float sc = lim / fabsf(est); kp *= sc; kd *= sc; }
+      const float bj = fmaf(dt, kp, kd);
+      t0 = fmaf(kp, tq - q, fmaf(kd, tv, -(bj * qd)));
+      de = fmaf(dt, bj, de);
     }
     const float jd = m->damping[l];
     if (jd > 0.0f) { t0 = fmaf(-jd, qd, t0); de = fmaf(dt, jd, de); }

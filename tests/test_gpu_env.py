@@ -123,8 +123,10 @@ def test_abb_pushbox_random_run_mode():
     assert env.isg_env.root_state.shape == (32 * 4, 13) and env.isg_env.body_state.shape == (32 * 10, 13)
     assert env.robot.j_ee.shape == (32, 6, 6) and env.robot.num_dof == 6 and env.robot.num_bodies == 7
     env.reset()
+    for _ in range(30):      # zero actions: the IK pulls the rod tip into the workspace slab z in [0.11, 0.14]
+        env.step(torch.zeros(env.num_envs, env.num_actions, device=env.device))
     ee0 = env.robot.ee_pose[:, 0, :3].clone()
-    assert torch.allclose(ee0[:, 2], torch.full((32,), 0.14, device=ee0.device), atol=0.02)  # clipped into the workspace
+    assert ((ee0[:, 2] > 0.10) & (ee0[:, 2] < 0.15)).all(), ee0[:4]
     resets = 0
     for _ in range(120):
         a = 2 * torch.rand(env.num_envs, env.num_actions, device=env.device) - 1
@@ -140,6 +142,8 @@ def test_abb_pushbox_random_run_mode():
 def test_abb_rod_pushes_the_cube():
     env = _abb(16)
     env.reset()
+    for _ in range(10):   # let the IK settle the rod tip into the workspace (the first step after a reset
+        env.step(torch.zeros(env.num_envs, env.num_actions, device=env.device))   # sees a stale ee pose)
     be = env.isg_env.sim.backend
     n, A = 16, 4
     root = env.isg_env.root_state
@@ -150,12 +154,12 @@ def test_abb_rod_pushes_the_cube():
     be.commit_root_all(root)
     a = torch.tensor([[1.0, 0.0, -1.0]], device=root.device).repeat(n, 1)      # +x, rod tip down to z = 0.11
     x0 = env.cube.base_pose[:, 0].clone()
-    for _ in range(14):
+    for _ in range(4):
         env.step(a)
-        if env.reset_buf.any():
-            break
+        assert not env.reset_buf.any()
     moved = env.cube.base_pose[:, 0] - x0
     ee = env.robot.ee_pose[:, 0, :3]
     assert (moved > 0.01).all(), f"cube was not pushed: {moved}"
-    assert (ee[:, 0] + 0.0194 + 0.025 <= env.cube.base_pose[:, 0] + 0.01).all(), "rod must stay behind the cube face"
+    assert (ee[:, 0] + 0.0194 + 0.025 <= env.cube.base_pose[:, 0] + 0.012).all(), "rod must stay behind the cube face"
+    assert (env.robot.ee_forces.abs().sum() + env.robot.contact_forces.abs().sum()) > 0   # the arm feels the push
     assert torch.isfinite(root).all()
