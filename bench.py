@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--workload", choices=["terrain", "flat"], default="terrain")
     ap.add_argument("--group", type=int, default=32, help="lanes per env: 64 = one wavefront per env, 32 = two envs per wavefront (fastest measured, DESIGN.md 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decimation", type=int, default=4, help="(experiments only) control.decimation")
+    ap.add_argument("--no-extra-substep", action="store_true", help="(experiments only) drop the Q1 sub-step")
     ap.add_argument("--log-interval", type=int, default=24, help="all-gather period (num_steps_per_env)")
     args = ap.parse_args()
 
@@ -135,7 +137,8 @@ def main():
     from shifu_amd.parallel import gather_episode_stats
 
     env = FusedA1Env(num_envs=args.envs, device=dev, terrain="heightfield" if args.workload == "terrain" else "flat",
-                     seed=42, rank=rank, world_size=world, group=args.group)
+                     seed=42, rank=rank, world_size=world, group=args.group, decimation=args.decimation,
+                     extra_substep=not args.no_extra_substep)
     gen = torch.Generator(device=dev)
     gen.manual_seed(42 + rank)
     N, A = env.num_envs, env.num_actions

@@ -203,13 +203,45 @@ struct BodyRegs {
   float IA[21], pA[6], U[6], invD, u;
 };
 
-// Forward kinematics: pose, motion subspace, velocity, bias acceleration of
-// every reported body, level by level through LDS.
+// Forward kinematics: pose, motion subspace, velocity, bias acceleration of every reported
+// body.  Phase 1 (all lanes at once): the joint's local rotation Rl = trot * Rot(axis, q).
+// Phase 2 (level by level through LDS): R = Rp * Rl, p = pp + Rp * tpos, a_w = R * axis.
 template <int G>
 DEV void kinematics(const ShfModel* m, const EnvLds& L, int l, BodyRegs& B) {
   const int nb = m->nb;
   const bool isbody = l < nb;
   const int jt = isbody ? m->jtype[l] : -1;
+  float Rl[9], tp[3], ax[3], qv = 0.0f, qdv = 0.0f;
+  int par = 0, klev = -1;
+  if (isbody && jt != SHF_JOINT_ROOT) {
+    par = m->parent[l];
+    klev = m->klevel[l];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { tp[k] = m->tpos[l][k]; ax[k] = m->axis[l][k]; }
+    float tr[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) tr[k] = m->trot[l][k];
+    if (jt == SHF_JOINT_WELD) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) Rl[k] = tr[k];
+    } else {
+      const int d = m->dof[l];
+      qv = L.dofb[d * DOF_STRIDE];
+      qdv = L.dofb[d * DOF_STRIDE + 1];
+      if (jt == SHF_JOINT_REVOLUTE) {
+        float sn, cs;
+        sincos_spec(qv, &sn, &cs);
+        const float oc = 1.0f - cs;
+        const float Rq[9] = {fmaf(oc, ax[0] * ax[0], cs),           fmaf(oc, ax[0] * ax[1], -(sn * ax[2])), fmaf(oc, ax[0] * ax[2], sn * ax[1]),
+                             fmaf(oc, ax[1] * ax[0], sn * ax[2]),    fmaf(oc, ax[1] * ax[1], cs),            fmaf(oc, ax[1] * ax[2], -(sn * ax[0])),
+                             fmaf(oc, ax[2] * ax[0], -(sn * ax[1])), fmaf(oc, ax[2] * ax[1], sn * ax[0]),    fmaf(oc, ax[2] * ax[2], cs)};
+        mm3(tr, Rq, Rl);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rl[k] = tr[k];
+      }
+    }
+  }
   if (l == 0) {
     quat_to_mat(L.root + 3, B.Rw);
     B.p[0] = B.p[1] = B.p[2] = 0.0f;
@@ -231,47 +263,28 @@ DEV void kinematics(const ShfModel* m, const EnvLds& L, int l, BodyRegs& B) {
   const int nk = m->nklevels;
   for (int lev = 1; lev <= nk; lev++) {
     GROUP_SYNC();
-    if (isbody && jt != SHF_JOINT_ROOT && m->klevel[l] == lev) {
-      const float* pp = L.pose + m->parent[l] * POSE_STRIDE;
-      float Rp[9], vp[6], tp[3], tr[9], Rj[9], t[3];
+    if (klev == lev) {
+      const float* pp = L.pose + par * POSE_STRIDE;
+      float Rp[9], vp[6], t[3];
 #pragma unroll
       for (int k = 0; k < 9; k++) Rp[k] = pp[k];
 #pragma unroll
       for (int k = 0; k < 6; k++) vp[k] = pp[12 + k];
-#pragma unroll
-      for (int k = 0; k < 3; k++) tp[k] = m->tpos[l][k];
-#pragma unroll
-      for (int k = 0; k < 9; k++) tr[k] = m->trot[l][k];
       mv3(Rp, tp, t);
 #pragma unroll
       for (int k = 0; k < 3; k++) B.p[k] = pp[9 + k] + t[k];
-      mm3(Rp, tr, Rj);
+      mm3(Rp, Rl, B.Rw);
       if (jt == SHF_JOINT_WELD) {
-#pragma unroll
-        for (int k = 0; k < 9; k++) B.Rw[k] = Rj[k];
 #pragma unroll
         for (int k = 0; k < 6; k++) { B.v[k] = vp[k]; B.S[k] = 0.0f; B.c[k] = 0.0f; }
       } else {
-        float ax[3], aw[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) ax[k] = m->axis[l][k];
-        mv3(Rj, ax, aw);
-        const int d = m->dof[l];
-        const float qv = L.dofb[d * DOF_STRIDE], qdv = L.dofb[d * DOF_STRIDE + 1];
+        float aw[3];
+        mv3(B.Rw, ax, aw);
         if (jt == SHF_JOINT_REVOLUTE) {
-          float sn, cs;
-          sincos_spec(qv, &sn, &cs);
-          float oc = 1.0f - cs;
-          float Rq[9] = {fmaf(oc, ax[0] * ax[0], cs),           fmaf(oc, ax[0] * ax[1], -(sn * ax[2])), fmaf(oc, ax[0] * ax[2], sn * ax[1]),
-                         fmaf(oc, ax[1] * ax[0], sn * ax[2]),    fmaf(oc, ax[1] * ax[1], cs),            fmaf(oc, ax[1] * ax[2], -(sn * ax[0])),
-                         fmaf(oc, ax[2] * ax[0], -(sn * ax[1])), fmaf(oc, ax[2] * ax[1], sn * ax[0]),    fmaf(oc, ax[2] * ax[2], cs)};
-          mm3(Rj, Rq, B.Rw);
           cross3(B.p, aw, t);
 #pragma unroll
           for (int k = 0; k < 3; k++) { B.S[k] = aw[k]; B.S[3 + k] = t[k]; }
         } else {
-#pragma unroll
-          for (int k = 0; k < 9; k++) B.Rw[k] = Rj[k];
 #pragma unroll
           for (int k = 0; k < 3; k++) { B.p[k] = fmaf(aw[k], qv, B.p[k]); B.S[k] = 0.0f; B.S[3 + k] = aw[k]; }
         }
@@ -355,7 +368,7 @@ struct StepCtx {
 
 // solve IA x = -pA for a symmetric positive definite 6x6 in packed storage (LDL^T)
 DEV void ldlt_solve6(const float* IA, const float* pA, float* x) {
-  float Lm[6][6], Dg[6], y[6];
+  float Lm[6][6], Dg[6], iD[6], y[6];
 #pragma unroll
   for (int j = 0; j < 6; j++) {
     float d = IA[SYM(j, j)];
@@ -363,6 +376,7 @@ DEV void ldlt_solve6(const float* IA, const float* pA, float* x) {
     for (int k = 0; k < j; k++) d = fmaf(-(Lm[j][k] * Lm[j][k]), Dg[k], d);
     Dg[j] = d;
     const float id = 1.0f / d;
+    iD[j] = id;
 #pragma unroll
     for (int i = j + 1; i < 6; i++) {
       float v = IA[SYM(j, i)];
@@ -379,7 +393,7 @@ DEV void ldlt_solve6(const float* IA, const float* pA, float* x) {
     y[i] = v;
   }
 #pragma unroll
-  for (int i = 0; i < 6; i++) y[i] = y[i] / Dg[i];
+  for (int i = 0; i < 6; i++) y[i] = y[i] * iD[i];
 #pragma unroll
   for (int i = 5; i >= 0; i--) {
     float v = y[i];

@@ -63,7 +63,7 @@ class FusedA1Env:
     def __init__(self, num_envs: int = 4096, device="cuda:0", terrain: str = "heightfield", seed: int = 42,
                  rank: int = 0, world_size: int = 1, terrain_cfg=None, sim_params: Optional[_abi.ShfSimParams] = None,
                  group: int = 64, episode_length_s: float = 10.0, dt: float = 0.005, decimation: int = 4,
-                 terrain_seed: int = 42, send_timeouts: bool = True):
+                 terrain_seed: int = 42, send_timeouts: bool = True, extra_substep: bool = True):
         self.device = torch.device(device)
         self.num_envs = num_envs
         self.rank, self.world_size = rank, world_size
@@ -101,7 +101,7 @@ class FusedA1Env:
 
         self.max_episode_length_s = episode_length_s
         self.task_params = a1_task_params(self.cm, dt=dt, decimation=decimation, episode_length_s=episode_length_s,
-                                          curriculum=ct.curriculum, num_rows=ct.num_rows, num_cols=ct.num_cols,
+                                          extra_substep=extra_substep, curriculum=ct.curriculum, num_rows=ct.num_rows, num_cols=ct.num_cols,
                                           env_length=ct.terrain_length, seed=seed,
                                           num_height_points=len(ct.measured_points_x) * len(ct.measured_points_y))
         self.max_episode_length = np.ceil(episode_length_s / self.dt)     # env.py:42
