@@ -333,7 +333,7 @@ __global__ void k_a1_reset_all(A1Args A) {
 // the kernel is held to 128 VGPRs (measured 0.147 ms vs 0.165 ms at 165 VGPRs / 3 waves,
 // profiles/r01_*); at G = 32 the grid is 2 waves per SIMD and the unconstrained
 // allocation is faster (0.104 ms vs 0.112 ms).
-template <int G>
+template <int G, class DM>
 __global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   {
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) {
   const int e = blockIdx.x * epb + es;
   const int n = A.S.n;
   if (e >= n) return;
-  const int nb = m->nb, nd = m->nd, np = m->np, H = tp.num_history, P = tp.num_height_points;
+  const int nb = DM::nb(m), nd = DM::nd(m), np = DM::np(m), H = tp.num_history, P = tp.num_height_points;
   const int nobs = 12 + 2 * nd + nd * H + P;
   // post-physics scratch reuses the contact-point region (last in the carve)
   const int env_words = env_lds_words(nb, nd, np, SCR_OBS + nobs);
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) {
       D[5] = rclampf(t, -m->effort[l], m->effort[l]);
     }
     GROUP_SYNC();
-    substep<G>(C, L, l, nullptr, nullptr, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
+    substep<G, false, DM>(C, L, l, nullptr, nullptr, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
                (it == nsub - 1) ? L.xch : nullptr);
   }
   GROUP_SYNC();
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) {
   // the contact-point region is idle from here on: it becomes scratch
   for (int i = l; i < nd * H; i += G) scr[SCR_HIST + i] = A.history[(size_t)e * nd * H + i];
   if (l < nd) scr[SCR_ACT + l] = act;
-  body_states<G>(m, L, l, scr + SCR_BODY);
+  body_states<G, DM>(m, L, l, scr + SCR_BODY);
   for (int i = l; i < 13 * nb; i += G) A.body_state[(size_t)e * nb * 13 + i] = scr[SCR_BODY + i];
 
   // get_heights (isaac_gym.py:412-433)
@@ -897,10 +897,18 @@ extern "C" int shf_a1_step(ShfA1Task* task, const float* raw_actions_dev, void* 
   dim3 grid((s->n + epb - 1) / epb), block(256);
   const size_t lds = sim_lds_bytes(s, TASK_WORDS, SCR_OBS + nobs);
   int r;
-  switch (s->group) {
-    case 64: r = launch(k_a1_step<64>, grid, block, lds, stream, A); break;
-    case 32: r = launch(k_a1_step<32>, grid, block, lds, stream, A); break;
-    default: r = launch(k_a1_step<16>, grid, block, lds, stream, A); break;
+  if (A1Dims::matches(s->model)) {
+    switch (s->group) {
+      case 64: r = launch(k_a1_step<64, A1Dims>, grid, block, lds, stream, A); break;
+      case 32: r = launch(k_a1_step<32, A1Dims>, grid, block, lds, stream, A); break;
+      default: return fail("shf_a1_step: A1 has 17 bodies, the lane group must be 32 or 64");
+    }
+  } else {
+    switch (s->group) {
+      case 64: r = launch(k_a1_step<64, DynDims>, grid, block, lds, stream, A); break;
+      case 32: r = launch(k_a1_step<32, DynDims>, grid, block, lds, stream, A); break;
+      default: r = launch(k_a1_step<16, DynDims>, grid, block, lds, stream, A); break;
+    }
   }
   return r;
 }

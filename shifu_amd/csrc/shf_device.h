@@ -197,6 +197,29 @@ DEV EnvLds env_lds_carve(float* base, int nb, int nd, int np, int nactors = 1) {
   return L;
 }
 
+// Model dimensions: read from the LDS copy of the model at run time (any URDF), or fixed at
+// compile time for a known robot so that loop bounds and LDS offsets fold to immediates
+// (the A1 instantiation is ~6 % faster; the host picks it only when the model matches).
+struct DynDims {
+  DEV static int nb(const ShfModel* m) { return m->nb; }
+  DEV static int nd(const ShfModel* m) { return m->nd; }
+  DEV static int np(const ShfModel* m) { return m->np; }
+  DEV static int nlevels(const ShfModel* m) { return m->nlevels; }
+  DEV static int nklevels(const ShfModel* m) { return m->nklevels; }
+};
+template <int NB, int ND, int NP, int NL, int NK>
+struct FixedDims {
+  DEV static int nb(const ShfModel*) { return NB; }
+  DEV static int nd(const ShfModel*) { return ND; }
+  DEV static int np(const ShfModel*) { return NP; }
+  DEV static int nlevels(const ShfModel*) { return NL; }
+  DEV static int nklevels(const ShfModel*) { return NK; }
+  static bool matches(const ShfModel& m) {
+    return m.nb == NB && m.nd == ND && m.np == NP && m.nlevels == NL && m.nklevels == NK;
+  }
+};
+typedef FixedDims<17, 12, 76, 3, 4> A1Dims;  // Unitree A1 as compiled from a1.urdf
+
 // per-lane persistent body registers between phases of one sub-step
 struct BodyRegs {
   float Rw[9], p[3], S[6], v[6], c[6];
@@ -206,9 +229,9 @@ struct BodyRegs {
 // Forward kinematics: pose, motion subspace, velocity, bias acceleration of every reported
 // body.  Phase 1 (all lanes at once): the joint's local rotation Rl = trot * Rot(axis, q).
 // Phase 2 (level by level through LDS): R = Rp * Rl, p = pp + Rp * tpos, a_w = R * axis.
-template <int G>
+template <int G, class DM = DynDims>
 DEV void kinematics(const ShfModel* m, const EnvLds& L, int l, BodyRegs& B) {
-  const int nb = m->nb;
+  const int nb = DM::nb(m);
   const bool isbody = l < nb;
   const int jt = isbody ? m->jtype[l] : -1;
   float Rl[9], tp[3], ax[3], qv = 0.0f, qdv = 0.0f;
@@ -260,7 +283,7 @@ DEV void kinematics(const ShfModel* m, const EnvLds& L, int l, BodyRegs& B) {
 #pragma unroll
     for (int k = 0; k < 6; k++) o[12 + k] = B.v[k];
   }
-  const int nk = m->nklevels;
+  const int nk = DM::nklevels(m);
   for (int lev = 1; lev <= nk; lev++) {
     GROUP_SYNC();
     if (klev == lev) {
@@ -409,11 +432,11 @@ DEV void ldlt_solve6(const float* IA, const float* pA, float* x) {
 //   dofb[d]: q, qd in;  tau_cmd (explicit effort), pos/vel targets via pt_tgt/vt_tgt (LDS, may be null)
 //   fext: world force per reported body (global memory, this env) or nullptr
 //   contact_out: LDS/global float[nb*3] written by body lanes (may be nullptr)
-template <int G, bool BOX = false>
+template <int G, bool BOX = false, class DM = DynDims>
 DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt, const float* vel_tgt,
                  const float* fext, float mu_shape, float* contact_out) {
   const ShfModel* m = C.m;
-  const int nb = m->nb, nd = m->nd, np = m->np;
+  const int nb = DM::nb(m), nd = DM::nd(m), np = DM::np(m);
   const float dt = C.sp.dt;
   const float gon = (float)m->gravity_on;
   const float g[3] = {C.sp.gravity[0] * gon, C.sp.gravity[1] * gon, C.sp.gravity[2] * gon};
@@ -424,7 +447,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt,
   const int mylevel = isbody ? m->level[l] : -1;
 
   BodyRegs B;
-  kinematics<G>(m, L, l, B);
+  kinematics<G, DM>(m, L, l, B);
   if (isdyn) body_inertia(m, l, B);
   if (BOX) boxes_pose<G>(C, L, l, B);
 
@@ -569,7 +592,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt,
   GROUP_SYNC();
 
   // inward pass
-  const int nl = m->nlevels;
+  const int nl = DM::nlevels(m);
   for (int lev = nl; lev >= 1; lev--) {
     if (moving && mylevel == lev) {
       const int d = m->dof[l];
@@ -733,11 +756,11 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt,
 }
 
 // rigid_body_state rows of this env -> `stage` (LDS, nb*13 floats); caller copies out coalesced
-template <int G>
+template <int G, class DM = DynDims>
 DEV void body_states(const ShfModel* m, const EnvLds& L, int l, float* stage) {
   BodyRegs B;
-  kinematics<G>(m, L, l, B);
-  if (l < m->nb) {
+  kinematics<G, DM>(m, L, l, B);
+  if (l < DM::nb(m)) {
     float* o = stage + 13 * l;
     float t[3], q[4];
 #pragma unroll

@@ -194,7 +194,7 @@ def _shape_points(shape: _Shape) -> List[Tuple[np.ndarray, float]]:
 
 def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: bool = False,
                  collapse_fixed_joints: bool = True, default_dof_drive_mode: int = _abi.DOF_MODE_NONE,
-                 armature: float = 0.0,
+                 armature: float = 0.0, honour_dont_collapse: bool = True,
                  extra_spheres: Sequence[Tuple[str, Sequence[float], float]] = ()) -> CompiledModel:
     """Compile `path` with the AssetOptions the reference passes (asset_config.py:32-46).
 
@@ -232,7 +232,7 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
         """link_name's frame sits at (p, R) inside reported body `body`."""
         for j in sorted(children[link_name], key=lambda jj: jj.child):
             cp, cR = p + R @ j.pos, R @ j.rot
-            if j.type == "fixed" and collapse_fixed_joints and not j.dont_collapse:
+            if j.type == "fixed" and collapse_fixed_joints and not (j.dont_collapse and honour_dont_collapse):
                 absorb(body, links[j.child], cp, cR)
                 visit(j.child, body, cp, cR)
                 continue
