@@ -12,7 +12,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libshifu_amd.so")
 SOURCES = ["shf_api.hip"]
 DEPS = ["shf_api.hip", "shf_device.h", os.path.join("..", "..", "include", "shifu_amd.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared"]
+# -fno-slp-vectorize: the SLP vectoriser packs neighbouring scalar f32 ops into v_pk_* pairs plus the
+# v_mov shuffles that feed them -- slower for this kernel (measured -6 % at 2 envs/wave, -25 % at one
+# wavefront per env; cf. MI355X_MICROARCH.md "packed f32 VALU ... an anti-lever").
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
+         "-fPIC", "-shared"]
 
 
 def hipcc() -> str:
