@@ -187,6 +187,14 @@ def main():
         value = total_envs * args.steps / elapsed
         b_alg = B_ALG[args.workload]
         achieved = b_alg * N / (kern_ms * 1e-3) / 1e9
+        traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/profile.sh)
+        try:
+            tdb = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            key = "r01_a1_step_g%d" % args.group
+            if args.workload == "terrain" and N == 4096 and key in tdb:
+                traffic = tdb[key]["traffic_bytes"]
+        except Exception:
+            pass
         out = {
             "metric": "env-steps/sec (whole node), A1 12-dof 4096 envs/GPU", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -197,7 +205,7 @@ def main():
                        "lanes_per_env": args.group, "parallelism": f"env-sharded x{world}, all-gather of episode stats every {args.log_interval} steps",
                        "substeps_per_s": value * 5, "obs_finite": finite, "episodes_reset_rank0": resets},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_a1_step", "kernel_ms": kern_ms, "alg_bytes_per_env_step": b_alg,
                          "note": "latency/ALU-bound by design: ~5.5 KB compulsory traffic per env-step (DESIGN.md 5)"},
         }
