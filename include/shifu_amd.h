@@ -300,6 +300,68 @@ int shf_a1_episode_stats(ShfA1Task* task, int64_t slot, void* stream);
 /* ShifuVecEnv.reset_idx(arange(N)) part of reset() (env.py:108-112). */
 int shf_a1_reset_all(ShfA1Task* task, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Fused AbbPushBox env step (BASELINE config 5): everything ShifuVecEnv.step does for
+ * examples/abb_pushbox_vision/a_prior_stage.py in ONE launch per vec-step:
+ * AbbRobot.step (:67-73: EE-delta -> workspace clip -> damped-least-squares IK on the EE
+ * Jacobian, shifu/units/robot.py:162-182 -> POS targets), decimation x simulate + the
+ * refresh_state sub-step, body-state / Jacobian refresh, termination (:104-113), the two
+ * rewards (:121-130), on-device reset of arm / cube / goal (:24-58) and the 6-dim
+ * observation (:97-102).  The scene must be [arm, table, cube, goal] in actor order.
+ * ---------------------------------------------------------------------- */
+typedef struct ShfAbbTaskParams {
+  int32_t decimation;      /* int(0.1 / 0.02) = 5 (task_config.py:84)                   */
+  int32_t extra_substep;   /* refresh_state's simulate (Q1)                             */
+  int32_t ee_body;         /* rigid_body_dict['tip0']                                   */
+  int32_t cube_actor;      /* 2 */
+  int32_t goal_actor;      /* 3 */
+  int32_t pad0;
+  float clip_actions;      /* 1.0                                                       */
+  float clip_obs;          /* 10.0                                                      */
+  float max_episode_length;   /* ceil(20 / 0.1) = 200                                   */
+  float max_episode_length_s; /* 20                                                     */
+  float ee_velocity;       /* 0.2 m/s (task_config.py:61)                               */
+  float env_dt;            /* sim.dt * decimation = 0.1 s                               */
+  float ik_damping;        /* 0.05 (robot.py:162)                                       */
+  float pad1;
+  float min_ee_pos[3];     /* workspace box (task_config.py:63-64)                      */
+  float max_ee_pos[3];
+  float target_quat[4];    /* [0,1,0,0] (a_prior_stage.py:70)                           */
+  float default_dof_pos[SHF_MAX_DOFS];
+  float actor_default[SHF_MAX_BOXES + 1][7]; /* reset pose of each actor (pos, quat)    */
+  float cube_lo[3], cube_hi[3]; /* RandPosBox.pos_range (a_prior_stage.py:30-33)        */
+  float goal_lo[3], goal_hi[3];
+  uint64_t seed;
+} ShfAbbTaskParams;
+
+enum {
+  SHF_ABB_ACTIONS = 0,     /* (N,3) f32 clipped actions                                 */
+  SHF_ABB_OBS = 1,         /* (N,6) f32                                                 */
+  SHF_ABB_REW = 2,         /* (N) f32                                                   */
+  SHF_ABB_RESET = 3,       /* (N) u8                                                    */
+  SHF_ABB_TIMEOUT = 4,     /* (N) u8                                                    */
+  SHF_ABB_SUCCESS = 5,     /* (N) u8  success_buf                                       */
+  SHF_ABB_EP_LEN = 6,      /* (N) i64                                                   */
+  SHF_ABB_REW_SUMS = 7,    /* (2,N) f32 reward_reaching, reward_success                 */
+  SHF_ABB_DOF_TARGETS = 8, /* (N,nd) f32 robot.dof_targets                              */
+  SHF_ABB_RESET_COUNT = 9, /* (N) i32                                                   */
+  SHF_ABB_DONE_SUMS = 10,  /* (4,N) f32: finished-episode sums of the 2 terms, success, 1 */
+  SHF_ABB_STATS = 11,      /* (R,8) f32 ring: [0..3] sums of DONE_SUMS rows, [4,5] episode means / T, [6] success_rate, [7] N */
+  SHF_ABB_PARAMS = 12,     /* sizeof(ShfAbbTaskParams) bytes, device copy               */
+  SHF_ABB_COUNT = 13
+};
+
+typedef struct ShfAbbTask ShfAbbTask;
+int shf_abb_create(ShfSim* sim, const ShfAbbTaskParams* params, ShfAbbTask** out);
+int shf_abb_destroy(ShfAbbTask* task);
+int shf_abb_layout(const ShfAbbTask* task, int32_t id, int64_t shape[4], int32_t* ndim, int32_t* dtype);
+int shf_abb_bind(ShfAbbTask* task, int32_t id, void* device_ptr);
+/* ShifuVecEnv.step for AbbPushBox; raw_actions (N,3). */
+int shf_abb_step(ShfAbbTask* task, const float* raw_actions_dev, void* stream);
+int shf_abb_episode_stats(ShfAbbTask* task, int64_t slot, void* stream);
+/* reset_idx(arange(N)) (env.py:108-112). */
+int shf_abb_reset_all(ShfAbbTask* task, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -216,3 +216,41 @@ def scene_step(model, params, boxes, n, dof_state, root_state, *, nsteps=1, terr
        C.c_int(nbx), arr, C.c_int(n), C.c_int(nsteps), _p(dof_state, ct), _p(root_state, ct), _p(effort, ct),
        _p(pos_target, ct), _p(vel_target, ct), _p(friction, C.c_float), _p(contact, ct), _p(bstate, ct), _p(jac, ct))
     return contact, bstate, jac
+
+
+
+class AbbBuffers(C.Structure):
+    """Mirror of ShfOracleAbbBuffers (oracle/shf_oracle.c)."""
+    _F = C.POINTER(C.c_float)
+    _fields_ = [("dof_state", _F), ("root_state", _F), ("body_state", _F), ("contact", _F), ("jacobian", _F),
+                ("friction", _F), ("actions", _F), ("obs", _F), ("rew", _F),
+                ("reset", C.POINTER(C.c_uint8)), ("timeout", C.POINTER(C.c_uint8)), ("success", C.POINTER(C.c_uint8)),
+                ("ep_len", C.POINTER(C.c_int64)), ("rew_sums", _F), ("dof_targets", _F),
+                ("reset_count", C.POINTER(C.c_int32)), ("done_sums", _F)]
+
+
+ABB_FIELDS = [f[0] for f in AbbBuffers._fields_]
+
+
+def abb_step(model, params, boxes, task_params, n, env_id_offset, bufs: dict, raw_actions, nthreads=1):
+    """One fused AbbPushBox env step on NumPy buffers (dict keyed by ABB_FIELDS), in place."""
+    from shifu_amd import _abi
+    B = AbbBuffers()
+    for name, ctype in AbbBuffers._fields_:
+        a = bufs[name]
+        assert a.flags.c_contiguous, name
+        setattr(B, name, a.ctypes.data_as(ctype))
+    arr = (_abi.ShfBoxDesc * max(len(boxes), 1))(*boxes)
+    raw = np.ascontiguousarray(raw_actions, np.float32)
+    fn = lib().shf_oracle_abb_step_f32
+    fn.restype = None
+    fn(C.byref(model), C.byref(params), None, None, C.c_int(len(boxes)), arr, C.byref(task_params), C.c_int(n),
+       C.c_int64(env_id_offset), C.byref(B), _p(raw, C.c_float), C.c_int(nthreads))
+
+
+def abb_stats(task_params, n, done_sums):
+    out = np.zeros(8, np.float32)
+    fn = lib().shf_oracle_abb_stats_f32
+    fn.restype = None
+    fn(C.byref(task_params), C.c_int(n), _p(done_sums, C.c_float), _p(out, C.c_float))
+    return out

@@ -67,6 +67,21 @@ class ShfA1TaskParams(C.Structure):
     ]
 
 
+class ShfAbbTaskParams(C.Structure):
+    _fields_ = [
+        ("decimation", i32), ("extra_substep", i32), ("ee_body", i32), ("cube_actor", i32), ("goal_actor", i32), ("pad0", i32),
+        ("clip_actions", f32), ("clip_obs", f32), ("max_episode_length", f32), ("max_episode_length_s", f32),
+        ("ee_velocity", f32), ("env_dt", f32), ("ik_damping", f32), ("pad1", f32),
+        ("min_ee_pos", f32 * 3), ("max_ee_pos", f32 * 3), ("target_quat", f32 * 4),
+        ("default_dof_pos", f32 * MAX_DOFS), ("actor_default", (f32 * 7) * (MAX_BOXES + 1)),
+        ("cube_lo", f32 * 3), ("cube_hi", f32 * 3), ("goal_lo", f32 * 3), ("goal_hi", f32 * 3),
+        ("seed", C.c_uint64),
+    ]
+
+
+(ABB_ACTIONS, ABB_OBS, ABB_REW, ABB_RESET, ABB_TIMEOUT, ABB_SUCCESS, ABB_EP_LEN, ABB_REW_SUMS, ABB_DOF_TARGETS,
+ ABB_RESET_COUNT, ABB_DONE_SUMS, ABB_STATS, ABB_PARAMS, ABB_COUNT) = range(14)
+
 # tensor ids (shf_sim_*)
 T_DOF_STATE, T_ROOT_STATE, T_BODY_STATE, T_CONTACT, T_JACOBIAN, T_SIM_DOF, T_SIM_ROOT, T_EFFORT, \
     T_POS_TARGET, T_VEL_TARGET, T_BODY_FORCE, T_FRICTION, T_HEIGHTS, T_MODEL, T_SIM_CONTACT, T_SCENE, T_COUNT = range(17)

@@ -38,3 +38,31 @@ def abb_boxes():
     return [box_desc([0.6, 0.6, 0.1], 0.0, 0.5, True, [0, 0, 0.05]),
             box_desc([0.05, 0.05, 0.05], 0.1, 0.5, False, [0, 0, 0.125]),
             box_desc([0.08, 0.08, 0.002], 0.0, 0.5, True, [0, 0, 0.1])]
+
+
+def abb_task_params(cm, *, dt=0.02, decimation=5, episode_length_s=20.0, extra_substep=True, seed=42,
+                    clip_obs=10.0, clip_actions=1.0) -> _abi.ShfAbbTaskParams:
+    """ShfAbbTaskParams from the reference's numbers (task_config.py:49-93, a_prior_stage.py:24-73)."""
+    import numpy as np
+    tp = _abi.ShfAbbTaskParams()
+    tp.decimation, tp.extra_substep = decimation, int(extra_substep)
+    tp.ee_body = cm.rigid_body_dict["tip0"]
+    tp.cube_actor, tp.goal_actor = 2, 3
+    tp.clip_actions, tp.clip_obs = clip_actions, clip_obs
+    tp.env_dt = dt * decimation
+    tp.max_episode_length = float(np.ceil(episode_length_s / (dt * decimation)))
+    tp.max_episode_length_s = episode_length_s
+    tp.ee_velocity = 0.2
+    tp.ik_damping = 0.05
+    tp.min_ee_pos[:] = [-0.2, -0.2, 0.11]
+    tp.max_ee_pos[:] = [0.2, 0.2, 0.14]
+    tp.target_quat[:] = [0.0, 1.0, 0.0, 0.0]
+    for d in range(cm.blob.nd):
+        tp.default_dof_pos[d] = ABB_DEFAULT_DOF_POS[d]
+    defaults = [ABB_BASE_POS + [0, 0, 0, 1], [0, 0, 0.05, 0, 0, 0, 1], [0, 0, 0.125, 0, 0, 0, 1], [0, 0, 0.1, 0, 0, 0, 1]]
+    for a, row in enumerate(defaults):
+        tp.actor_default[a][:] = row
+    tp.cube_lo[:], tp.cube_hi[:] = [-0.1, -0.1, 0.125], [0.1, 0.1, 0.125]
+    tp.goal_lo[:], tp.goal_hi[:] = [-0.1, -0.1, 0.1], [0.1, 0.1, 0.1]
+    tp.seed = seed
+    return tp

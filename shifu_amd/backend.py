@@ -242,3 +242,54 @@ class A1Task:
             self.destroy()
         except Exception:
             pass
+
+
+class AbbTask:
+    """The fused AbbPushBox env step (shf_abb_*)."""
+
+    def __init__(self, sim: Sim, params: _abi.ShfAbbTaskParams):
+        self.sim = sim
+        self.params = params
+        self._h = C.c_void_p()
+        check(lib().shf_abb_create(sim._h, C.byref(params), C.byref(self._h)))
+        self.tensors: Dict[int, torch.Tensor] = {}
+        self.step_index = 0
+        for tid in range(_abi.ABB_COUNT):
+            if tid == _abi.ABB_PARAMS:
+                self.bind(tid, _struct_to_device(params, sim.device))
+                continue
+            shape = (C.c_int64 * 4)()
+            nd, dt = C.c_int32(), C.c_int32()
+            check(lib().shf_abb_layout(self._h, tid, shape, C.byref(nd), C.byref(dt)))
+            self.bind(tid, torch.zeros(tuple(shape[:nd.value]), dtype=_TORCH_DTYPE[dt.value], device=sim.device))
+
+    def bind(self, tid: int, t: torch.Tensor):
+        assert t.is_contiguous()
+        self.tensors[tid] = t
+        check(lib().shf_abb_bind(self._h, tid, C.c_void_p(t.data_ptr())))
+
+    def step(self, raw_actions: torch.Tensor, stats: bool = True) -> int:
+        a = raw_actions.contiguous()
+        assert a.dtype == torch.float32 and a.shape == (self.sim.num_envs, 3)
+        st = _stream_ptr(self.sim.device)
+        check(lib().shf_abb_step(self._h, C.c_void_p(a.data_ptr()), st))
+        if not stats:
+            return -1
+        idx = self.step_index
+        check(lib().shf_abb_episode_stats(self._h, idx, st))
+        self.step_index += 1
+        return idx % self.tensors[_abi.ABB_STATS].shape[0]
+
+    def reset_all(self):
+        check(lib().shf_abb_reset_all(self._h, _stream_ptr(self.sim.device)))
+
+    def destroy(self):
+        if self._h:
+            lib().shf_abb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -116,22 +116,14 @@ __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
   for (int i = l; i < 3 * nbt; i += G) A.contact[(size_t)e * nbt * 3 + i] = L.xch[i];
 }
 
-// gym.refresh_rigid_body_state_tensor (+ refresh_jacobian_tensors for fixed bases):
+// gym.refresh_rigid_body_state_tensor (+ refresh_jacobian_tensors for fixed bases) for one env:
 // body rows from forward kinematics, box rows copied from their root rows; jacobian
-// (N, nb-1, 6, nd), rows [linear; angular] of each link origin (robot.py:125-128).
+// (nb-1, 6, nd), rows [linear; angular] of each link origin (robot.py:125-128).
+// `body_state` / `jacobian` point at this env's slices (either may be null).  L.xch is scratch.
 template <int G>
-__global__ __launch_bounds__(256) void k_body_state(const ShfModel* gm, int n, const float* dof, const float* root,
-                                                    int actors, float* body_state, float* jacobian) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const ShfModel* m = stage_model(gm, smem);
-  const int epb = 256 / G, es = threadIdx.x / G, l = threadIdx.x % G;
-  const int e = blockIdx.x * epb + es;
-  if (e >= n) return;
-  const int nb = m->nb, nd = m->nd, np = m->np, nbt = nb + actors - 1;
-  EnvLds L = env_lds_carve(smem + MODEL_WORDS + es * env_lds_words(nb, nd, np, 0, actors), nb, nd, np, actors);
-  for (int i = l; i < 2 * nd; i += G) L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)] = dof[(size_t)e * nd * 2 + i];
-  for (int i = l; i < 13 * actors; i += G) L.root[i] = root[(size_t)e * actors * 13 + i];
-  GROUP_SYNC();
+DEV void refresh_body_jac(const ShfModel* m, const EnvLds& L, int l, int actors, float* body_state, float* jacobian,
+                          float* keep_xy = nullptr, int keep_body = 0) {
+  const int nb = m->nb, nd = m->nd;
   BodyRegs B;
   kinematics<G>(m, L, l, B);
   if (body_state) {
@@ -148,8 +140,9 @@ __global__ __launch_bounds__(256) void k_body_state(const ShfModel* gm, int n, c
       for (int k = 0; k < 3; k++) { o[7 + k] = B.v[3 + k] + t[k]; o[10 + k] = B.v[k]; }
     }
     GROUP_SYNC();
-    for (int i = l; i < 13 * nb; i += G) body_state[(size_t)e * nbt * 13 + i] = L.xch[i];
-    for (int i = l; i < 13 * (actors - 1); i += G) body_state[((size_t)e * nbt + nb) * 13 + i] = L.root[13 + i];
+    if (keep_xy && l == 0) { keep_xy[0] = L.xch[13 * keep_body]; keep_xy[1] = L.xch[13 * keep_body + 1]; }
+    for (int i = l; i < 13 * nb; i += G) body_state[i] = L.xch[i];
+    for (int i = l; i < 13 * (actors - 1); i += G) body_state[nb * 13 + i] = L.root[13 + i];
     GROUP_SYNC();
   }
   if (jacobian && m->fixed_base) {
@@ -160,7 +153,7 @@ __global__ __launch_bounds__(256) void k_body_state(const ShfModel* gm, int n, c
     }
     GROUP_SYNC();
     if (l >= 1 && l < nb) {
-      float* J = jacobian + ((size_t)e * (nb - 1) + (l - 1)) * 6 * nd;
+      float* J = jacobian + (size_t)(l - 1) * 6 * nd;
       for (int k = 0; k < 6 * nd; k++) J[k] = 0.0f;
       for (int b = l; b > 0; b = m->parent[b]) {
         const int d = m->dof[b];
@@ -173,7 +166,25 @@ __global__ __launch_bounds__(256) void k_body_state(const ShfModel* gm, int n, c
         for (int k = 0; k < 3; k++) { J[k * nd + d] = t[k] + S[3 + k]; J[(3 + k) * nd + d] = S[k]; }
       }
     }
+    GROUP_SYNC();
   }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void k_body_state(const ShfModel* gm, int n, const float* dof, const float* root,
+                                                    int actors, float* body_state, float* jacobian) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const ShfModel* m = stage_model(gm, smem);
+  const int epb = 256 / G, es = threadIdx.x / G, l = threadIdx.x % G;
+  const int e = blockIdx.x * epb + es;
+  if (e >= n) return;
+  const int nb = m->nb, nd = m->nd, np = m->np, nbt = nb + actors - 1;
+  EnvLds L = env_lds_carve(smem + MODEL_WORDS + es * env_lds_words(nb, nd, np, 0, actors), nb, nd, np, actors);
+  for (int i = l; i < 2 * nd; i += G) L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)] = dof[(size_t)e * nd * 2 + i];
+  for (int i = l; i < 13 * actors; i += G) L.root[i] = root[(size_t)e * actors * 13 + i];
+  GROUP_SYNC();
+  refresh_body_jac<G>(m, L, l, actors, body_state ? body_state + (size_t)e * nbt * 13 : nullptr,
+                      jacobian ? jacobian + (size_t)e * (nb - 1) * 6 * nd : nullptr);
 }
 
 __global__ void k_commit_rows(const float* src, float* dst, const int32_t* idx, int n, int row_words, int idx_div,
@@ -568,6 +579,239 @@ __global__ __launch_bounds__(1024) void k_a1_stats(int n, float max_episode_leng
   }
 }
 
+// ------------------------------------------------------ fused ABB step --
+struct AbbArgs {
+  SimArgs S;
+  const ShfAbbTaskParams* tp;  // device copy
+  int64_t env_off;
+  const float* raw_actions;
+  float *actions, *obs, *rew;
+  uint8_t *reset, *timeout, *success;
+  int64_t* ep_len;
+  float *rew_sums, *dof_targets;
+  int32_t* reset_count;
+  float* done_sums;
+  float *body_state, *jacobian;
+};
+#define ABB_WORDS ((int)((sizeof(ShfAbbTaskParams) / 4 + 3) & ~3))
+
+// shifu/utils/torch_utils.py:12-33 (xyzw)
+DEV void quat_mul_ref(const float* a, const float* b, float* o) {
+  const float x1 = a[0], y1 = a[1], z1 = a[2], w1 = a[3], x2 = b[0], y2 = b[1], z2 = b[2], w2 = b[3];
+  const float ww = (z1 + x1) * (x2 + y2);
+  const float yy = (w1 - y1) * (w2 + z2);
+  const float zz = (w1 + y1) * (w2 - z2);
+  const float xx = ww + yy + zz;
+  const float qq = 0.5f * (xx + (z1 - x1) * (x2 - y2));
+  o[3] = qq - ww + (z1 - y1) * (y2 - z2);
+  o[0] = qq - xx + (x1 + w1) * (x2 + w2);
+  o[1] = qq - yy + (w1 - x1) * (y2 + z2);
+  o[2] = qq - zz + (z1 + y1) * (w2 - x2);
+}
+
+// per-env reset of arm, table, cube, goal into the LDS copies (a_prior_stage.py:24-58, robot.py:74-86)
+DEV void abb_reset_env(const ShfAbbTaskParams& tp, int nd, int nbx, int64_t gid, uint32_t cnt, float* dofb, float* rootl) {
+  uint32_t r0[4], r1[4];
+  const uint32_t k0 = (uint32_t)tp.seed, k1 = (uint32_t)(tp.seed >> 32);
+  philox4x32((uint32_t)gid, cnt, 0u, (uint32_t)(gid >> 32), k0, k1, r0);
+  philox4x32((uint32_t)gid, cnt, 1u, (uint32_t)(gid >> 32), k0, k1, r1);
+  for (int d = 0; d < nd; d++) { dofb[d * DOF_STRIDE] = tp.default_dof_pos[d]; dofb[d * DOF_STRIDE + 1] = 0.0f; }
+  for (int k = 0; k < 7; k++) rootl[k] = tp.actor_default[0][k];
+  for (int k = 7; k < 13; k++) rootl[k] = 0.0f;
+  for (int b = 0; b < nbx; b++) {
+    float* rb = rootl + 13 * (1 + b);
+    for (int k = 7; k < 13; k++) rb[k] = 0.0f;
+    if (b + 1 == tp.cube_actor || b + 1 == tp.goal_actor) {
+      const bool cube = b + 1 == tp.cube_actor;
+      const uint32_t* rr = cube ? r0 : r1;
+      const float* lo = cube ? tp.cube_lo : tp.goal_lo;
+      const float* hi = cube ? tp.cube_hi : tp.goal_hi;
+      for (int k = 0; k < 3; k++) rb[k] = urange(rr[k], lo[k], hi[k]);
+      const float yaw = urange(rr[3], -3.14159265358979323846f, 3.14159265358979323846f);
+      float sn, cs;
+      sincos_spec(yaw * 0.5f, &sn, &cs);
+      rb[3] = 0.0f; rb[4] = 0.0f; rb[5] = sn; rb[6] = cs;
+    } else {
+      for (int k = 0; k < 7; k++) rb[k] = tp.actor_default[b + 1][k];
+    }
+  }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(A.tp);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(smem + MODEL_WORDS + SCENE_WORDS);
+    for (int i = threadIdx.x; i < (int)(sizeof(ShfAbbTaskParams) / 4); i += blockDim.x) dst[i] = src[i];
+  }
+  const ShfScene* scene = stage_scene(A.S.scene, smem + MODEL_WORDS);
+  const ShfModel* m = stage_model(A.S.model, smem);
+  const ShfAbbTaskParams& tp = *reinterpret_cast<const ShfAbbTaskParams*>(smem + MODEL_WORDS + SCENE_WORDS);
+  const int epb = 256 / G, es = threadIdx.x / G, l = threadIdx.x % G;
+  const int e = blockIdx.x * epb + es;
+  const int n = A.S.n;
+  if (e >= n) return;
+  const int nbx = A.S.nboxes, actors = 1 + nbx;
+  const int nb = m->nb, nd = m->nd, nbt = nb + nbx, nslots = m->np + box_slot_count(nbx, m->nsph);
+  const int env_words = env_lds_words(nbt, nd, nslots, nslots * PT_STRIDE + SHF_MAX_DOFS, actors);
+  EnvLds L = env_lds_carve(smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS + es * env_words, nbt, nd, nslots, actors);
+  float* tgtl = L.pt + nslots * PT_STRIDE;  // POS targets of this env step
+
+  float* dof = A.S.dof + (size_t)e * nd * 2;
+  float* root = A.S.root + (size_t)e * actors * 13;
+  float* bstate = A.body_state + (size_t)e * nbt * 13;
+  float* jac = A.jacobian + (size_t)e * (nb - 1) * 6 * nd;
+  for (int i = l; i < 2 * nd; i += G) L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)] = dof[i];
+  for (int i = l; i < 13 * actors; i += G) L.root[i] = root[i];
+  GROUP_SYNC();
+
+  // AbbRobot.step: EE-delta -> clip -> damped least squares on the Jacobian tensor (possibly stale pose)
+  if (l == 0) {
+    float act[3], dpose[6], eq[4], cc[4], qr[4];
+    const float* ee = bstate + 13 * tp.ee_body;
+    float eep[3] = {ee[0], ee[1], ee[2]};
+#pragma unroll
+    for (int k = 0; k < 4; k++) eq[k] = ee[3 + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      act[k] = rclampf(A.raw_actions[(size_t)e * 3 + k], -tp.clip_actions, tp.clip_actions);
+      A.actions[(size_t)e * 3 + k] = act[k];
+      const float tar = rclampf(eep[k] + act[k] * tp.ee_velocity * tp.env_dt, tp.min_ee_pos[k], tp.max_ee_pos[k]);
+      dpose[k] = tar - eep[k];
+    }
+    cc[0] = -eq[0]; cc[1] = -eq[1]; cc[2] = -eq[2]; cc[3] = eq[3];
+    const float tq[4] = {tp.target_quat[0], tp.target_quat[1], tp.target_quat[2], tp.target_quat[3]};
+    quat_mul_ref(tq, cc, qr);
+    const float sg = qr[3] > 0.0f ? 1.0f : (qr[3] < 0.0f ? -1.0f : 0.0f);
+#pragma unroll
+    for (int k = 0; k < 3; k++) dpose[3 + k] = qr[k] * sg;
+    const float* J = jac + (size_t)(tp.ee_body - 1) * 6 * nd;
+    float Am[21], neg[6], x[6];
+    const float lam2 = tp.ik_damping * tp.ik_damping;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = i; j < 6; j++) {
+        float acc = J[i * nd] * J[j * nd];
+        for (int d = 1; d < nd; d++) acc = fmaf(J[i * nd + d], J[j * nd + d], acc);
+        Am[SYM(i, j)] = (i == j) ? acc + lam2 : acc;
+      }
+#pragma unroll
+    for (int k = 0; k < 6; k++) neg[k] = -dpose[k];
+    ldlt_solve6(Am, neg, x);
+    for (int d = 0; d < nd; d++) {
+      float u = J[d] * x[0];
+#pragma unroll
+      for (int k = 1; k < 6; k++) u = fmaf(J[k * nd + d], x[k], u);
+      const float t = L.dofb[d * DOF_STRIDE] + u;
+      tgtl[d] = t;
+      A.dof_targets[(size_t)e * nd + d] = t;
+    }
+  }
+  GROUP_SYNC();
+
+  StepCtx C;
+  C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = scene;
+  const float mu = A.S.friction[e];
+  const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
+  for (int it = 0; it < nsub; it++) substep<G, true>(C, L, l, tgtl, nullptr, nullptr, mu, L.xch);
+  GROUP_SYNC();
+  for (int i = l; i < 3 * nbt; i += G) A.S.contact[(size_t)e * nbt * 3 + i] = L.xch[i];
+  GROUP_SYNC();
+  refresh_body_jac<G>(m, L, l, actors, bstate, jac, tgtl + nd, tp.ee_body);
+
+  // post_step on one lane (env.py:93-106, a_prior_stage.py:97-135)
+  if (l == 0) {
+    int64_t ep = A.ep_len[e] + 1;
+    const float* cube = L.root + 13 * tp.cube_actor;
+    const float* goal = L.root + 13 * tp.goal_actor;
+    // this step's ee position, parked in LDS by refresh_body_jac
+    const float eex = tgtl[nd], eey = tgtl[nd + 1];
+    const int timeout = (float)ep > tp.max_episode_length;
+    const float gx = goal[0] - cube[0], gy = goal[1] - cube[1];
+    const float dgoal = sqrtf(gx * gx + gy * gy);
+    const int success = dgoal < 0.02f;
+    const int outbound = cube[0] < tp.min_ee_pos[0] || cube[1] < tp.min_ee_pos[1] || cube[0] > tp.max_ee_pos[0] ||
+                         cube[1] > tp.max_ee_pos[1] || eex < tp.min_ee_pos[0] || eey < tp.min_ee_pos[1] ||
+                         eex > tp.max_ee_pos[0] || eey > tp.max_ee_pos[1];
+    const int reset = timeout | outbound | success;
+    A.timeout[e] = (uint8_t)timeout; A.success[e] = (uint8_t)success; A.reset[e] = (uint8_t)reset;
+    const float ex = eex - cube[0], ey = eey - cube[1];
+    const float eobj = sqrtf(ex * ex + ey * ey);
+    const float r0 = (eobj < 0.1f) ? exp_spec(-(dgoal * dgoal) / 0.05f) : 0.0f;
+    const float r1 = success ? 200.0f : 0.0f;
+    float sums[2] = {A.rew_sums[e] + r0, A.rew_sums[(size_t)n + e] + r1};
+    A.rew[e] = r0 + r1;
+    float done[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (reset) {
+      done[0] = sums[0]; done[1] = sums[1]; done[2] = success ? 1.0f : 0.0f; done[3] = 1.0f;
+      sums[0] = sums[1] = 0.0f;
+      abb_reset_env(tp, nd, nbx, A.env_off + e, (uint32_t)A.reset_count[e], L.dofb, L.root);
+      ep = 0;
+      A.reset_count[e] += 1;
+    }
+    A.rew_sums[e] = sums[0]; A.rew_sums[(size_t)n + e] = sums[1];
+#pragma unroll
+    for (int k = 0; k < 4; k++) A.done_sums[(size_t)k * n + e] = done[k];
+    A.ep_len[e] = ep;
+    const float co = tp.clip_obs;
+    float* o = A.obs + (size_t)e * 6;
+    o[0] = rclampf(L.root[13 * tp.cube_actor], -co, co); o[1] = rclampf(L.root[13 * tp.cube_actor + 1], -co, co);
+    o[2] = rclampf(L.root[13 * tp.goal_actor], -co, co); o[3] = rclampf(L.root[13 * tp.goal_actor + 1], -co, co);
+    o[4] = rclampf(eex, -co, co); o[5] = rclampf(eey, -co, co);
+  }
+  GROUP_SYNC();
+  for (int i = l; i < 2 * nd; i += G) dof[i] = L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)];
+  for (int i = l; i < 13 * actors; i += G) root[i] = L.root[i];
+}
+
+__global__ void k_abb_reset_all(AbbArgs A) {
+  // reset_idx(arange(N)): state is written straight into the tensors (one thread per env)
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = A.S.n;
+  if (e >= n) return;
+  const ShfAbbTaskParams& tp = *A.tp;
+  const int nd = A.S.model->nd, nbx = A.S.nboxes, actors = 1 + nbx;
+  float dofb[SHF_MAX_DOFS * DOF_STRIDE], rootl[13 * (SHF_MAX_BOXES + 1)];
+  abb_reset_env(tp, nd, nbx, A.env_off + e, (uint32_t)A.reset_count[e], dofb, rootl);
+  for (int d = 0; d < nd; d++) {
+    A.S.dof[((size_t)e * nd + d) * 2] = dofb[d * DOF_STRIDE];
+    A.S.dof[((size_t)e * nd + d) * 2 + 1] = 0.0f;
+  }
+  for (int k = 0; k < 13 * actors; k++) A.S.root[(size_t)e * actors * 13 + k] = rootl[k];
+  A.done_sums[e] = A.rew_sums[e]; A.done_sums[(size_t)n + e] = A.rew_sums[(size_t)n + e];
+  A.done_sums[(size_t)2 * n + e] = (float)A.success[e]; A.done_sums[(size_t)3 * n + e] = 1.0f;
+  A.rew_sums[e] = 0.0f; A.rew_sums[(size_t)n + e] = 0.0f;
+  A.ep_len[e] = 0;
+  A.reset[e] = 1;
+  A.reset_count[e] += 1;
+}
+
+// extras["episode"] for AbbPushBox (env.py:149-158 + episode_log a_prior_stage.py:94-95)
+__global__ __launch_bounds__(1024) void k_abb_stats(int n, float max_episode_length_s, const float* done_sums, float* out) {
+  __shared__ float part[2][1024];
+  const int t = threadIdx.x, k = blockIdx.x;
+  float acc = 0.0f, cnt = 0.0f;
+  for (int e = t; e < n; e += 1024) {
+    acc += done_sums[(size_t)k * n + e];
+    cnt += done_sums[(size_t)3 * n + e];
+  }
+  part[0][t] = acc; part[1][t] = cnt;
+  __syncthreads();
+  for (int s = 512; s >= 1; s >>= 1) {
+    if (t < s) { part[0][t] += part[0][t + s]; part[1][t] += part[1][t + s]; }
+    __syncthreads();
+  }
+  if (t == 0) {
+    const float sum = part[0][0], c = part[1][0];
+    out[k] = sum;
+    if (k < 2) out[4 + k] = c > 0.0f ? sum / c / max_episode_length_s : 0.0f;
+    if (k == 2) out[6] = c > 0.0f ? sum / c : 0.0f;
+    if (k == 3) out[7] = (float)n;
+  }
+}
+
 // ---------------------------------------------------------------- C ABI --
 static size_t sim_lds_bytes(const ShfSim* s, int head_words, int min_tail, bool boxes = false) {
   const int epb = 256 / s->group;
@@ -925,4 +1169,112 @@ extern "C" int shf_a1_reset_all(ShfA1Task* task, void* stream) {
   A1Args A;
   if (int r = a1_args(task, nullptr, "shf_a1_reset_all", A)) return r;
   return launch(k_a1_reset_all, dim3((A.S.n + 127) / 128), dim3(128), 0, stream, A);
+}
+
+// ---------------------------------------------------------- ABB task ABI --
+struct ShfAbbTask {
+  ShfSim* sim;
+  ShfAbbTaskParams tp;
+  void* t[SHF_ABB_COUNT] = {};
+  int stats_ring = 256;
+};
+
+extern "C" int shf_abb_create(ShfSim* sim, const ShfAbbTaskParams* params, ShfAbbTask** out) {
+  if (!sim || !params || !out) return fail("shf_abb_create: null argument");
+  if (!sim->finalized) return fail("shf_abb_create: sim not finalized");
+  if (!sim->model.fixed_base) return fail("shf_abb_create: the arm must have a fixed base (Jacobian rows ee-1)");
+  if (sim->nboxes < 1) return fail("shf_abb_create: the scene needs box actors (table, cube, goal)");
+  if (params->cube_actor < 1 || params->cube_actor > sim->nboxes || params->goal_actor < 1 || params->goal_actor > sim->nboxes)
+    return fail("shf_abb_create: cube/goal actor index out of range");
+  if (params->ee_body < 1 || params->ee_body >= sim->model.nb) return fail("shf_abb_create: bad end-effector body");
+  if (sim->model.nd > 6 * 4) return fail("shf_abb_create: too many dofs");
+  ShfAbbTask* t = new ShfAbbTask();
+  t->sim = sim;
+  t->tp = *params;
+  *out = t;
+  return 0;
+}
+extern "C" int shf_abb_destroy(ShfAbbTask* task) {
+  delete task;
+  return 0;
+}
+extern "C" int shf_abb_layout(const ShfAbbTask* task, int32_t id, int64_t shape[4], int32_t* ndim, int32_t* dtype) {
+  if (!task) return fail("shf_abb_layout: null task");
+  const int64_t N = task->sim->n, nd = task->sim->model.nd;
+  *dtype = 0;
+  shape[0] = shape[1] = shape[2] = shape[3] = 1;
+  switch (id) {
+    case SHF_ABB_ACTIONS: *ndim = 2; shape[0] = N; shape[1] = 3; break;
+    case SHF_ABB_OBS: *ndim = 2; shape[0] = N; shape[1] = 6; break;
+    case SHF_ABB_REW: *ndim = 1; shape[0] = N; break;
+    case SHF_ABB_RESET: case SHF_ABB_TIMEOUT: case SHF_ABB_SUCCESS: *ndim = 1; shape[0] = N; *dtype = 3; break;
+    case SHF_ABB_EP_LEN: *ndim = 1; shape[0] = N; *dtype = 4; break;
+    case SHF_ABB_REW_SUMS: *ndim = 2; shape[0] = 2; shape[1] = N; break;
+    case SHF_ABB_DOF_TARGETS: *ndim = 2; shape[0] = N; shape[1] = nd; break;
+    case SHF_ABB_RESET_COUNT: *ndim = 1; shape[0] = N; *dtype = 1; break;
+    case SHF_ABB_DONE_SUMS: *ndim = 2; shape[0] = 4; shape[1] = N; break;
+    case SHF_ABB_STATS: *ndim = 2; shape[0] = task->stats_ring; shape[1] = 8; break;
+    case SHF_ABB_PARAMS: *ndim = 1; shape[0] = sizeof(ShfAbbTaskParams); *dtype = 3; break;
+    default: return fail("shf_abb_layout: unknown tensor id");
+  }
+  return 0;
+}
+extern "C" int shf_abb_bind(ShfAbbTask* task, int32_t id, void* device_ptr) {
+  if (!task || id < 0 || id >= SHF_ABB_COUNT) return fail("shf_abb_bind: bad id");
+  task->t[id] = device_ptr;
+  return 0;
+}
+
+static int abb_args(ShfAbbTask* task, const float* raw_actions_dev, const char* who, AbbArgs& A) {
+  if (!task) return fail(std::string(who) + ": null task");
+  ShfSim* s = task->sim;
+  if (int r = need(s, {SHF_T_DOF_STATE, SHF_T_ROOT_STATE, SHF_T_BODY_STATE, SHF_T_CONTACT, SHF_T_JACOBIAN, SHF_T_FRICTION,
+                       SHF_T_MODEL, SHF_T_SCENE}, who))
+    return r;
+  for (int id = 0; id < SHF_ABB_COUNT; id++)
+    if (!task->t[id]) return fail(std::string(who) + ": task tensor " + std::to_string(id) + " not bound");
+  if (s->model.nb + s->nboxes > s->group) return fail(std::string(who) + ": bodies + boxes exceed the lane group");
+  A.S = sim_args(s, false);
+  A.tp = (const ShfAbbTaskParams*)task->t[SHF_ABB_PARAMS];
+  A.env_off = s->env_off;
+  A.raw_actions = raw_actions_dev;
+  A.actions = (float*)task->t[SHF_ABB_ACTIONS]; A.obs = (float*)task->t[SHF_ABB_OBS]; A.rew = (float*)task->t[SHF_ABB_REW];
+  A.reset = (uint8_t*)task->t[SHF_ABB_RESET]; A.timeout = (uint8_t*)task->t[SHF_ABB_TIMEOUT];
+  A.success = (uint8_t*)task->t[SHF_ABB_SUCCESS];
+  A.ep_len = (int64_t*)task->t[SHF_ABB_EP_LEN];
+  A.rew_sums = (float*)task->t[SHF_ABB_REW_SUMS]; A.dof_targets = (float*)task->t[SHF_ABB_DOF_TARGETS];
+  A.reset_count = (int32_t*)task->t[SHF_ABB_RESET_COUNT];
+  A.done_sums = (float*)task->t[SHF_ABB_DONE_SUMS];
+  A.body_state = (float*)s->t[SHF_T_BODY_STATE];
+  A.jacobian = (float*)s->t[SHF_T_JACOBIAN];
+  return 0;
+}
+
+extern "C" int shf_abb_step(ShfAbbTask* task, const float* raw_actions_dev, void* stream) {
+  if (!raw_actions_dev) return fail("shf_abb_step: null actions");
+  AbbArgs A;
+  if (int r = abb_args(task, raw_actions_dev, "shf_abb_step", A)) return r;
+  ShfSim* s = task->sim;
+  const int epb = 256 / s->group;
+  dim3 grid((s->n + epb - 1) / epb), block(256);
+  const int nbx = s->nboxes, nslots = s->model.np + box_slot_count(nbx, s->model.nsph);
+  const size_t lds = ((size_t)MODEL_WORDS + SCENE_WORDS + ABB_WORDS +
+                      (size_t)epb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, nslots * PT_STRIDE + SHF_MAX_DOFS, 1 + nbx)) * 4;
+  switch (s->group) {
+    case 64: return launch(k_abb_step<64>, grid, block, lds, stream, A);
+    case 32: return launch(k_abb_step<32>, grid, block, lds, stream, A);
+    default: return launch(k_abb_step<16>, grid, block, lds, stream, A);
+  }
+}
+extern "C" int shf_abb_episode_stats(ShfAbbTask* task, int64_t slot, void* stream) {
+  if (!task || !task->t[SHF_ABB_STATS] || !task->t[SHF_ABB_DONE_SUMS]) return fail("shf_abb_episode_stats: tensors not bound");
+  if (slot < 0) return fail("shf_abb_episode_stats: negative slot");
+  float* out = (float*)task->t[SHF_ABB_STATS] + (size_t)(slot % task->stats_ring) * 8;
+  return launch(k_abb_stats, dim3(4), dim3(1024), 0, stream, (int)task->sim->n, task->tp.max_episode_length_s,
+                (const float*)task->t[SHF_ABB_DONE_SUMS], out);
+}
+extern "C" int shf_abb_reset_all(ShfAbbTask* task, void* stream) {
+  AbbArgs A;
+  if (int r = abb_args(task, nullptr, "shf_abb_reset_all", A)) return r;
+  return launch(k_abb_reset_all, dim3((A.S.n + 127) / 128), dim3(128), 0, stream, A);
 }

@@ -1,0 +1,81 @@
+"""AbbPushBox (BASELINE config 5) with the whole ShifuVecEnv.step in one HIP launch:
+in-kernel damped-least-squares IK, 5+1 sub-steps of 20 ms, refresh of body states / Jacobian /
+contacts, termination, rewards, on-device reset of arm, cube and goal, 6-dim observation.
+Same buffer names as the hook-based examples/abb_pushbox_vision/a_prior_stage.AbbPushBox."""
+from __future__ import annotations
+
+import torch
+
+from .. import _abi
+from ..abb_task import ABB_BASE_POS, ABB_DEFAULT_DOF_POS, abb_boxes, abb_model, abb_task_params
+from ..backend import AbbTask, Sim, default_sim_params
+
+REWARD_NAMES = ["reward_reaching", "reward_success"]   # build_reward_functions order, a_prior_stage.py:115-119
+
+
+class FusedAbbEnv:
+    def __init__(self, num_envs: int = 4096, device="cuda:0", seed: int = 42, rank: int = 0, world_size: int = 1,
+                 group: int = 64, dt: float = 0.02, decimation: int = 5, episode_length_s: float = 20.0):
+        self.device = torch.device(device)
+        self.num_envs = num_envs
+        self.env_id_offset = rank * num_envs
+        self.cm = abb_model()
+        self.sim_params = default_sim_params(dt=dt)
+        self.sim = Sim(self.sim_params, self.device)
+        self.sim.set_plane(1.0)
+        self.sim.set_articulation(self.cm.blob)
+        self.boxes = abb_boxes()
+        for b in self.boxes:
+            self.sim.add_box(b)
+        self.sim.finalize(num_envs, self.env_id_offset, group=group)
+        self.task_params = abb_task_params(self.cm, dt=dt, decimation=decimation, episode_length_s=episode_length_s,
+                                           seed=seed)
+        self.task = AbbTask(self.sim, self.task_params)
+        T, S = self.task.tensors, self.sim.tensors
+        self.num_obs, self.num_privileged_obs, self.num_actions = 6, None, 3
+        self.max_episode_length = self.task_params.max_episode_length
+        self.max_episode_length_s = episode_length_s
+        self.obs_buf, self.privileged_obs_buf, self.rew_buf = T[_abi.ABB_OBS], None, T[_abi.ABB_REW]
+        self.reset_buf = T[_abi.ABB_RESET].view(torch.bool)
+        self.time_out_buf = T[_abi.ABB_TIMEOUT].view(torch.bool)
+        self.success_buf = T[_abi.ABB_SUCCESS].view(torch.bool)
+        self.episode_length_buf = T[_abi.ABB_EP_LEN]
+        self.actions = T[_abi.ABB_ACTIONS]
+        self.episode_rewards = {n: T[_abi.ABB_REW_SUMS][k] for k, n in enumerate(REWARD_NAMES)}
+        self.dof_state, self.root_state = S[_abi.T_DOF_STATE], S[_abi.T_ROOT_STATE]
+        self.body_state, self.contact_state, self.jacobian = S[_abi.T_BODY_STATE], S[_abi.T_CONTACT], S[_abi.T_JACOBIAN]
+        self.extras = {}
+        # spawn poses + the tensors Isaac Gym would show after create_actor/prepare_sim
+        A = 4
+        root = torch.zeros(num_envs * A, 13, device=self.device)
+        root[:, 6] = 1.0
+        root[0::A, :3] = torch.tensor(ABB_BASE_POS, device=self.device)
+        for k, b in enumerate(self.boxes):
+            root[1 + k::A, :3] = torch.tensor(list(b.pos), device=self.device)
+        S[_abi.T_ROOT_STATE].copy_(root)
+        S[_abi.T_SIM_ROOT].copy_(root)
+        self.sim.refresh(_abi.REFRESH_BODY | _abi.REFRESH_JACOBIAN)   # zero-config poses, as after prepare_sim
+        self.task.reset_all()
+
+    def step(self, actions: torch.Tensor):
+        slot = self.task.step(actions)
+        st = self.task.tensors[_abi.ABB_STATS][slot]
+        self.extras["episode"] = {REWARD_NAMES[0]: st[4], REWARD_NAMES[1]: st[5], "success_rate": st[6]}
+        self.extras["episode_sums"] = st[:4]
+        self.extras["time_outs"] = self.time_out_buf
+        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def reset(self):
+        self.task.reset_all()
+        obs, priv, _, _, _ = self.step(torch.zeros(self.num_envs, 3, device=self.device))
+        return obs, priv
+
+    def get_observations(self):
+        return self.obs_buf
+
+    def get_privileged_observations(self):
+        return None
+
+    def destroy(self):
+        self.task.destroy()
+        self.sim.destroy()

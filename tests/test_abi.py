@@ -39,12 +39,13 @@ def test_struct_sizes_match_header(libpath, tmp_path):
     from shifu_amd import _abi
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "shifu_amd.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n",'
-                   'sizeof(ShfModel),sizeof(ShfSimParams),sizeof(ShfTerrain),sizeof(ShfA1TaskParams),sizeof(ShfBoxDesc));}')
+                   'sizeof(ShfModel),sizeof(ShfSimParams),sizeof(ShfTerrain),sizeof(ShfA1TaskParams),sizeof(ShfBoxDesc));'
+                   'printf("%zu %zu\\n",sizeof(ShfScene),sizeof(ShfAbbTaskParams));}')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(t) for t in (_abi.ShfModel, _abi.ShfSimParams, _abi.ShfTerrain, _abi.ShfA1TaskParams,
-                                       _abi.ShfBoxDesc)]
+                                       _abi.ShfBoxDesc, _abi.ShfScene, _abi.ShfAbbTaskParams)]
     assert got == want
 
 

@@ -332,3 +332,44 @@ def test_abb_scene_matches_oracle_bitwise(oracle, group):
     assert (np.abs(contact.reshape(n, B, 3)[:, m.nb + 1, 2] - 0.981) < 0.2).mean() > 0.5   # cubes rest on the table
     assert touched, "the rod must have touched a cube"
     assert (cube[:, 2] > 0.11).all()
+
+
+_ABB_SIM_T = {"dof_state": _abi.T_DOF_STATE, "root_state": _abi.T_ROOT_STATE, "body_state": _abi.T_BODY_STATE,
+              "contact": _abi.T_CONTACT, "jacobian": _abi.T_JACOBIAN, "friction": _abi.T_FRICTION}
+_ABB_T = {"actions": _abi.ABB_ACTIONS, "obs": _abi.ABB_OBS, "rew": _abi.ABB_REW, "reset": _abi.ABB_RESET,
+          "timeout": _abi.ABB_TIMEOUT, "success": _abi.ABB_SUCCESS, "ep_len": _abi.ABB_EP_LEN,
+          "rew_sums": _abi.ABB_REW_SUMS, "dof_targets": _abi.ABB_DOF_TARGETS, "reset_count": _abi.ABB_RESET_COUNT,
+          "done_sums": _abi.ABB_DONE_SUMS}
+
+
+@pytest.mark.parametrize("group", [64, 32])
+def test_fused_abb_step_matches_oracle_bitwise(oracle, group):
+    """ShifuVecEnv.step for AbbPushBox (config 5): in-kernel damped-least-squares IK on the Jacobian
+    tensor, 6 sub-steps with implicit POS drives and box contacts, refresh, termination, rewards,
+    Philox re-spawn of cube / goal, observation -- 150 vec-steps, every tensor compared exactly."""
+    _need_gpu()
+    from shifu_amd.gym.abb_fused import FusedAbbEnv
+    n = 48
+    env = FusedAbbEnv(num_envs=n, seed=11, group=group)
+    env.task.tensors[_abi.ABB_EP_LEN].copy_(torch.randint(0, 200, (n,)))   # staggered time-outs
+    torch.cuda.synchronize()
+    bufs = {k: env.sim.tensors[t].cpu().numpy().copy() for k, t in _ABB_SIM_T.items()}
+    bufs.update({k: env.task.tensors[t].cpu().numpy().copy() for k, t in _ABB_T.items()})
+    rng = np.random.default_rng(2)
+    resets = successes = 0
+    for it in range(150):
+        raw = (2 * rng.random((n, 3)) - 1).astype(np.float32) * 1.3
+        raw[: n // 2, 0] = np.abs(raw[: n // 2, 0])          # half the arms keep pushing +x
+        slot = env.task.step(torch.from_numpy(raw).cuda())
+        oracle.abb_step(env.cm.blob, env.sim_params, env.boxes, env.task_params, n, 0, bufs, raw)
+        torch.cuda.synchronize()
+        for k, t in list(_ABB_SIM_T.items()) + list(_ABB_T.items()):
+            got = (env.sim.tensors if k in _ABB_SIM_T else env.task.tensors)[t].cpu().numpy().reshape(bufs[k].shape)
+            np.testing.assert_array_equal(got, bufs[k], err_msg=f"{k} step {it}")
+        np.testing.assert_array_equal(env.task.tensors[_abi.ABB_STATS][slot].cpu().numpy(),
+                                      oracle.abb_stats(env.task_params, n, bufs["done_sums"]))
+        resets += int(bufs["reset"].sum()); successes += int(bufs["success"].sum())
+    assert resets > 10, "the run must exercise resets"
+    assert np.isfinite(bufs["obs"]).all() and np.isfinite(bufs["root_state"]).all()
+    cube_moved = np.abs(bufs["root_state"].reshape(n, 4, 13)[:, 2, 7:10]).sum() > 0 or resets > 0
+    assert cube_moved
