@@ -163,3 +163,46 @@ def test_abb_rod_pushes_the_cube():
     assert (ee[:, 0] + 0.0194 + 0.025 <= env.cube.base_pose[:, 0] + 0.012).all(), "rod must stay behind the cube face"
     assert (env.robot.ee_forces.abs().sum() + env.robot.contact_forces.abs().sum()) > 0   # the arm feels the push
     assert torch.isfinite(root).all()
+
+
+def test_fused_abb_env_tracks_hook_env():
+    """FusedAbbEnv vs the hook-based AbbPushBox on the same state and actions.  The IK linear solve
+    differs (in-kernel LDL^T vs torch.inverse), so states agree to ~1e-4 rather than bit for bit."""
+    from shifu_amd.gym.abb_fused import FusedAbbEnv
+    n = 32
+    hook = _abb(n)
+    fused = FusedAbbEnv(num_envs=n, seed=5)
+    be = hook.isg_env.sim.backend
+    S = fused.sim.tensors
+    for tid in (_abi.T_DOF_STATE, _abi.T_ROOT_STATE, _abi.T_BODY_STATE, _abi.T_JACOBIAN, _abi.T_CONTACT):
+        be.tensors[tid].copy_(S[tid])
+    be.tensors[_abi.T_SIM_DOF].copy_(S[_abi.T_DOF_STATE])
+    be.tensors[_abi.T_SIM_ROOT].copy_(S[_abi.T_ROOT_STATE])
+    hook.episode_length_buf.copy_(fused.episode_length_buf)
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(9)
+    alive = torch.ones(n, dtype=torch.bool, device="cuda:0")
+    touched = torch.zeros(n, dtype=torch.bool, device="cuda:0")
+    compared = 0
+    for it in range(25):
+        a = 2 * torch.rand(n, 3, device="cuda:0", generator=g) - 1
+        o1, _, r1, d1, _ = hook.step(a)
+        o2, _, r2, d2, _ = fused.step(a)
+        alive &= ~(d1.bool() | d2)
+        if not alive.any():
+            break
+        m = alive
+        # cubes the rod has touched are excluded from the pose check: a 1e-5 m difference in the rod
+        # position times the 5e4 N/m contact decorrelates a 0.1 kg cube within a couple of steps
+        touched |= (hook.isg_env.contact_state.view(n, 10, 3)[:, :7].abs().sum((1, 2)) > 0) | \
+                   (fused.contact_state.view(n, 10, 3)[:, :7].abs().sum((1, 2)) > 0)
+        free = m & ~touched
+        if free.any():
+            dr = (hook.isg_env.root_state.view(n, 4, 13)[free][..., :7] - fused.root_state.view(n, 4, 13)[free][..., :7]).abs()
+            assert dr.max() < 5e-3, f"root step {it}: max {dr.max()}"
+            assert torch.allclose(o1[free], o2[free], atol=2e-3, rtol=0), f"obs step {it}"
+            dq = (hook.robot.dof_pos[free] - fused.dof_state.view(n, 6, 2)[free][..., 0]).abs()
+            assert dq.max() < 2e-3, f"dof_pos step {it}: {dq.max()}"
+            assert torch.allclose(r1[free], r2[free], atol=5e-3), f"rew step {it}"
+        compared += int(free.sum())
+    assert compared > 3 * n

@@ -40,6 +40,11 @@ def main():
     v, ms = run(AbbPushBox(cfg), args.steps)
     print(json.dumps({"env": "AbbPushBox (config 5, hook path, 6 sub-steps of 20 ms)", "envs": args.envs,
                       "env_steps_per_s": v, "ms_per_step": ms}))
+    from shifu_amd.gym.abb_fused import FusedAbbEnv
+    for g in (64, 32, 16):
+        v, ms = run(FusedAbbEnv(num_envs=args.envs, group=g), args.steps * 5)
+        print(json.dumps({"env": "FusedAbbEnv (config 5, fused single launch, lanes/env=%d)" % g, "envs": args.envs,
+                          "env_steps_per_s": v, "ms_per_step": ms}))
     from examples.a1_conditional.a1_conditional import A1Conditional
     from examples.a1_conditional.task_config import A1EnvConfig
     cfg = A1EnvConfig(); cfg.num_envs = args.envs
