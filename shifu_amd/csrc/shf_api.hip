@@ -929,6 +929,9 @@ static SimArgs sim_args(const ShfSim* s, bool internal) {
 
 template <typename K, typename... Args>
 static int launch(K kernel, dim3 grid, dim3 block, size_t lds, void* stream, Args... args) {
+  if (lds > 160 * 1024) return fail("kernel needs " + std::to_string(lds) + " B of LDS per block, the CU has 160 KiB");
+  if (lds > 48 * 1024)  // above the default dynamic-LDS limit the kernel has to opt in
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)stream, args...);
   HIP_OK(hipGetLastError());
   return 0;
