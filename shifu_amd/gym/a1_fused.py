@@ -69,9 +69,7 @@ class FusedA1Env:
         self.rank, self.world_size = rank, world_size
         self.env_id_offset = rank * num_envs
         total = num_envs * world_size
-        import os
-        self.cm = compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT,
-                               honour_dont_collapse=not os.environ.get("SHIFU_EXP_COLLAPSE_FEET"))
+        self.cm = compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT)
         self.sim_params = sim_params or default_sim_params(dt=dt)
         self.dt = dt * decimation                                         # isaac_gym.py:26
         self.sim = Sim(self.sim_params, self.device)
