@@ -108,7 +108,10 @@ __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
   StepCtx C;
   C.m = m; C.sp = A.sp; C.terr.t = A.terr; C.terr.h = A.heights; C.scene = scene;
   const float mu = A.friction ? A.friction[e] : 1.0f;
-  substep<G, BOX>(C, L, l, A.pos_tgt ? A.pos_tgt + (size_t)e * nd : nullptr, A.vel_tgt ? A.vel_tgt + (size_t)e * nd : nullptr,
+  LaneModel M;
+  lane_model_load<DynDims>(m, l, M);
+  LanePoints<1> P;   // unused: point count only known at run time
+  substep<G, BOX>(C, L, l, M, P, A.pos_tgt ? A.pos_tgt + (size_t)e * nd : nullptr, A.vel_tgt ? A.vel_tgt + (size_t)e * nd : nullptr,
                   A.body_force ? A.body_force + (size_t)e * nbt * 3 : nullptr, mu, L.xch);
   GROUP_SYNC();
   for (int i = l; i < 2 * nd; i += G) dof[i] = L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)];
@@ -125,7 +128,9 @@ DEV void refresh_body_jac(const ShfModel* m, const EnvLds& L, int l, int actors,
                           float* keep_xy = nullptr, int keep_body = 0) {
   const int nb = m->nb, nd = m->nd;
   BodyRegs B;
-  kinematics<G>(m, L, l, B);
+  LaneModel M;
+  lane_model_load<DynDims>(m, l, M);
+  kinematics<G>(m, L, l, M, B);
   if (body_state) {
     if (l < nb) {
       float* o = L.xch + 13 * l;
@@ -347,6 +352,7 @@ __global__ void k_a1_reset_all(A1Args A) {
 template <int G, class DM>
 __global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  PHASE_BEGIN();
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(A.tp);
     uint32_t* dst = reinterpret_cast<uint32_t*>(smem + MODEL_WORDS);
@@ -393,6 +399,11 @@ __global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) {
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = nullptr;
   const float mu = A.S.friction[e];
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
+  LaneModel M;
+  lane_model_load<DM>(m, l, M);
+  LanePoints<LANE_ROUNDS(G, DM)> LP;
+  lane_points_load<G>(m, np, l, LP);
+  PHASE_MARK(11);
   for (int it = 0; it < nsub; it++) {
     if (it < tp.decimation && l < nd) {
       float* D = L.dofb + l * DOF_STRIDE;
@@ -400,17 +411,20 @@ __global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) {
       D[5] = rclampf(t, -m->effort[l], m->effort[l]);
     }
     GROUP_SYNC();
-    substep<G, false, DM>(C, L, l, nullptr, nullptr, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
+    substep<G, false, DM>(C, L, l, M, LP, nullptr, nullptr, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
                (it == nsub - 1) ? L.xch : nullptr);
   }
   GROUP_SYNC();
+  PHASE_RESET();
   if (l < nd) A.torques[(size_t)e * nd + l] = L.dofb[l * DOF_STRIDE + 5];
   for (int i = l; i < 3 * nb; i += G) A.S.contact[(size_t)e * nb * 3 + i] = L.xch[i];
   // the contact-point region is idle from here on: it becomes scratch
   for (int i = l; i < nd * H; i += G) scr[SCR_HIST + i] = A.history[(size_t)e * nd * H + i];
   if (l < nd) scr[SCR_ACT + l] = act;
-  body_states<G, DM>(m, L, l, scr + SCR_BODY);
+  PHASE_MARK(12);
+  body_states<G, DM>(m, L, l, M, scr + SCR_BODY);
   for (int i = l; i < 13 * nb; i += G) A.body_state[(size_t)e * nb * 13 + i] = scr[SCR_BODY + i];
+  PHASE_RESET();
 
   // get_heights (isaac_gym.py:412-433)
   {
@@ -439,6 +453,7 @@ __global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) {
     }
   }
   GROUP_SYNC();
+  PHASE_MARK(14);
 
   // post_step (env.py:93-106): one lane runs the scalar bookkeeping
   if (l == 0) {
@@ -526,6 +541,7 @@ __global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) {
     }
   }
   GROUP_SYNC();
+  PHASE_MARK(15);
   {
     // compute_observations (a1_conditional.py:131-144) staged in LDS, then one coalesced store
     const float co = tp.clip_obs;
@@ -551,6 +567,7 @@ __global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) {
   }
   for (int i = l; i < 2 * nd; i += G) dof[i] = L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)];
   if (l < 13) root[l] = L.root[l];
+  PHASE_MARK(16);
 }
 
 // per-step reduction for extras["episode"] (env.py:149-158), fixed order: block k reduces
@@ -715,7 +732,10 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = scene;
   const float mu = A.S.friction[e];
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
-  for (int it = 0; it < nsub; it++) substep<G, true>(C, L, l, tgtl, nullptr, nullptr, mu, L.xch);
+  LaneModel M;
+  lane_model_load<DynDims>(m, l, M);
+  LanePoints<1> P;   // unused: point count only known at run time
+  for (int it = 0; it < nsub; it++) substep<G, true>(C, L, l, M, P, tgtl, nullptr, nullptr, mu, L.xch);
   GROUP_SYNC();
   for (int i = l; i < 3 * nbt; i += G) A.S.contact[(size_t)e * nbt * 3 + i] = L.xch[i];
   GROUP_SYNC();
@@ -1281,3 +1301,17 @@ extern "C" int shf_abb_reset_all(ShfAbbTask* task, void* stream) {
   if (int r = abb_args(task, nullptr, "shf_abb_reset_all", A)) return r;
   return launch(k_abb_reset_all, dim3((A.S.n + 127) / 128), dim3(128), 0, stream, A);
 }
+
+#ifdef SHF_PHASE_CLOCK
+// debug builds only (tools/phase_clock.py): read / clear the per-phase cycle counters
+extern "C" int shf_debug_phase_cycles(unsigned long long* out, int n, int clear) {
+  unsigned long long tmp[32];
+  if (hipMemcpyFromSymbol(tmp, HIP_SYMBOL(g_phase_cycles), sizeof(tmp)) != hipSuccess) return -1;
+  for (int i = 0; i < n && i < 32; i++) out[i] = tmp[i];
+  if (clear) {
+    std::memset(tmp, 0, sizeof(tmp));
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), tmp, sizeof(tmp)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

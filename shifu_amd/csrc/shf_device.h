@@ -36,6 +36,24 @@
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
   } while (0)
 
+// Per-phase cycle accounting for tools/phase_clock.py (debug builds with -DSHF_PHASE_CLOCK only):
+// thread 0 of block 0 adds the s_memtime delta since the previous mark to g_phase_cycles[k].
+#ifdef SHF_PHASE_CLOCK
+__device__ unsigned long long g_phase_cycles[32];
+#define PHASE_BEGIN() unsigned long long _pc = clock64()
+#define PHASE_MARK(k)                                                                    \
+  do {                                                                                   \
+    const unsigned long long _now = clock64();                                           \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_cycles[k] += _now - _pc;            \
+    _pc = clock64();                                                                     \
+  } while (0)
+#define PHASE_RESET() _pc = clock64()
+#else
+#define PHASE_BEGIN() do {} while (0)
+#define PHASE_MARK(k) do {} while (0)
+#define PHASE_RESET() do {} while (0)
+#endif
+
 // ------------------------------------------------------------------ math --
 DEV float rminf(float a, float b) { return a < b ? a : b; }
 DEV float rmaxf(float a, float b) { return a > b ? a : b; }
@@ -145,14 +163,13 @@ DEV void terrain_query(const TerrainDev& T, float x, float y, float* h, float* n
   const int16_t* row0 = T.h + (size_t)i * T.t.cols + j;
   const int16_t* row1 = row0 + T.t.cols;
   float h00 = (float)row0[0] * vs, h10 = (float)row1[0] * vs, h01 = (float)row0[1] * vs, h11 = (float)row1[1] * vs;
-  float gx, gy, hh;
-  if (u + v <= 1.0f) {
-    gx = h10 - h00; gy = h01 - h00;
-    hh = fmaf(v, gy, fmaf(u, gx, h00));
-  } else {
-    gx = h11 - h01; gy = h11 - h10;
-    hh = fmaf(1.0f - v, -gy, fmaf(1.0f - u, -gx, h11));
-  }
+  // lower triangle (u+v <= 1): gx = h10-h00, gy = h01-h00, h = fma(v, gy, fma(u, gx, h00));
+  // upper: gx = h11-h01, gy = h11-h10, h = fma(1-v, -gy, fma(1-u, -gx, h11)).  Written with selects so that
+  // the four loads are issued together instead of one per branch (same operations either way).
+  const bool lo = u + v <= 1.0f;
+  float gx = (lo ? h10 : h11) - (lo ? h00 : h01);
+  float gy = (lo ? h01 : h11) - (lo ? h00 : h10);
+  const float hh = fmaf(lo ? v : 1.0f - v, lo ? gy : -gy, fmaf(lo ? u : 1.0f - u, lo ? gx : -gx, lo ? h00 : h11));
   gx *= inv; gy *= inv;
   float nz = 1.0f / sqrtf(fmaf(gy, gy, fmaf(gx, gx, 1.0f)));
   *h = hh; n[0] = -gx * nz; n[1] = -gy * nz; n[2] = nz;
@@ -206,9 +223,11 @@ struct DynDims {
   DEV static int np(const ShfModel* m) { return m->np; }
   DEV static int nlevels(const ShfModel* m) { return m->nlevels; }
   DEV static int nklevels(const ShfModel* m) { return m->nklevels; }
+  static constexpr int NPC = 0;   // contact-point count unknown at compile time
 };
 template <int NB, int ND, int NP, int NL, int NK>
 struct FixedDims {
+  static constexpr int NPC = NP;
   DEV static int nb(const ShfModel*) { return NB; }
   DEV static int nd(const ShfModel*) { return ND; }
   DEV static int np(const ShfModel*) { return NP; }
@@ -226,29 +245,69 @@ struct BodyRegs {
   float IA[21], pA[6], U[6], invD, u;
 };
 
+// Per-lane model constants.  Lane l is body l, dof l (and its share of the contact points) for the whole
+// launch, so everything the sub-step would re-read from the LDS model copy -- and the dependent
+// index -> data LDS round trips that come with it -- is read once into registers.
+#define LANE_CHILDREN 4
+struct LaneModel {
+  bool isbody, isdyn, moving;
+  int jt, par, klev, level, dofi, dynpar, nchild, child0, child[LANE_CHILDREN], pt0, npt;
+  float tp[3], ax[3], tr[9];
+  float mass, com[3], I6[6];
+  int mode;                                                      // lane l as dof l
+  float armature, kp, kd, effort, damping, lower, upper, vel_limit;
+};
+template <class DM>
+DEV void lane_model_load(const ShfModel* m, int l, LaneModel& M) {
+  const int nb = DM::nb(m), nd = DM::nd(m);
+  M.isbody = l < nb;
+  const int b = M.isbody ? l : 0;
+  M.jt = M.isbody ? m->jtype[b] : -1;
+  M.isdyn = M.isbody && m->dyn[b] == b;
+  M.moving = M.isdyn && M.jt != SHF_JOINT_ROOT;
+  M.par = M.jt > SHF_JOINT_ROOT ? m->parent[b] : 0;
+  M.klev = (M.isbody && M.jt != SHF_JOINT_ROOT) ? m->klevel[b] : -1;
+  M.level = M.isbody ? m->level[b] : -1;
+  M.dofi = m->dof[b];
+  M.dynpar = m->dyn[M.par];
+  M.child0 = m->child_start[b];
+  M.nchild = M.isdyn ? m->child_count[b] : 0;
+#pragma unroll
+  for (int k = 0; k < LANE_CHILDREN; k++) M.child[k] = k < M.nchild ? m->child_list[M.child0 + k] : 0;
+  M.pt0 = m->pt_start[b];
+  M.npt = M.isdyn ? m->pt_count[b] : 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { M.tp[k] = m->tpos[b][k]; M.ax[k] = m->axis[b][k]; M.com[k] = m->com[b][k]; }
+#pragma unroll
+  for (int k = 0; k < 9; k++) M.tr[k] = m->trot[b][k];
+#pragma unroll
+  for (int k = 0; k < 6; k++) M.I6[k] = m->inertia[b][k];
+  M.mass = m->mass[b];
+  const int d = l < nd ? l : 0;
+  M.mode = m->drive_mode[d];
+  M.armature = m->armature[d]; M.kp = m->kp[d]; M.kd = m->kd[d]; M.effort = m->effort[d];
+  M.damping = m->damping[d]; M.lower = m->lower[d]; M.upper = m->upper[d]; M.vel_limit = m->vel_limit[d];
+}
+
 // Forward kinematics: pose, motion subspace, velocity, bias acceleration of every reported
 // body.  Phase 1 (all lanes at once): the joint's local rotation Rl = trot * Rot(axis, q).
 // Phase 2 (level by level through LDS): R = Rp * Rl, p = pp + Rp * tpos, a_w = R * axis.
 template <int G, class DM = DynDims>
-DEV void kinematics(const ShfModel* m, const EnvLds& L, int l, BodyRegs& B) {
-  const int nb = DM::nb(m);
-  const bool isbody = l < nb;
-  const int jt = isbody ? m->jtype[l] : -1;
-  float Rl[9], tp[3], ax[3], qv = 0.0f, qdv = 0.0f;
-  int par = 0, klev = -1;
+DEV void kinematics(const ShfModel* m, const EnvLds& L, int l, const LaneModel& M, BodyRegs& B) {
+  const bool isbody = M.isbody;
+  const int jt = M.jt;
+  PHASE_BEGIN();
+  float Rl[9], qv = 0.0f, qdv = 0.0f;
+  const float* tp = M.tp;
+  const float* ax = M.ax;
+  const float* tr = M.tr;
+  const int par = M.par, klev = M.klev;
   if (isbody && jt != SHF_JOINT_ROOT) {
-    par = m->parent[l];
-    klev = m->klevel[l];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { tp[k] = m->tpos[l][k]; ax[k] = m->axis[l][k]; }
-    float tr[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) tr[k] = m->trot[l][k];
     if (jt == SHF_JOINT_WELD) {
 #pragma unroll
       for (int k = 0; k < 9; k++) Rl[k] = tr[k];
     } else {
-      const int d = m->dof[l];
+      const int d = M.dofi;
       qv = L.dofb[d * DOF_STRIDE];
       qdv = L.dofb[d * DOF_STRIDE + 1];
       if (jt == SHF_JOINT_REVOLUTE) {
@@ -283,6 +342,7 @@ DEV void kinematics(const ShfModel* m, const EnvLds& L, int l, BodyRegs& B) {
 #pragma unroll
     for (int k = 0; k < 6; k++) o[12 + k] = B.v[k];
   }
+  PHASE_MARK(0);
   const int nk = DM::nklevels(m);
   for (int lev = 1; lev <= nk; lev++) {
     GROUP_SYNC();
@@ -328,6 +388,7 @@ DEV void kinematics(const ShfModel* m, const EnvLds& L, int l, BodyRegs& B) {
     }
   }
   GROUP_SYNC();
+  PHASE_MARK(1);
 }
 
 // spatial inertia about O in world axes (packed) and velocity-product bias force
@@ -375,11 +436,7 @@ DEV void rigid_inertia(float mass, const float* com, const float* I6, BodyRegs& 
 #pragma unroll
   for (int k = 0; k < 3; k++) B.pA[3 + k] = t[k];
 }
-DEV void body_inertia(const ShfModel* m, int b, BodyRegs& B) {
-  const float com[3] = {m->com[b][0], m->com[b][1], m->com[b][2]};
-  const float I6[6] = {m->inertia[b][0], m->inertia[b][1], m->inertia[b][2], m->inertia[b][3], m->inertia[b][4], m->inertia[b][5]};
-  rigid_inertia(m->mass[b], com, I6, B);
-}
+DEV void body_inertia(const LaneModel& M, BodyRegs& B) { rigid_inertia(M.mass, M.com, M.I6, B); }
 
 typedef ShfScene SceneDev;  // box actors of the scene (gym.create_box), staged in LDS next to the model
 struct StepCtx {
@@ -428,35 +485,86 @@ DEV void ldlt_solve6(const float* IA, const float* pA, float* x) {
 
 #include "shf_boxes.h"
 
+// Sample-point constants of the lane's contact rounds (point l + k*G in round k), for models whose point
+// count is a compile-time constant.
+template <int NR>
+struct LanePoints {
+  int body[NR];
+  float pos[NR][3], rad[NR];
+};
+template <int G, int NR>
+DEV void lane_points_load(const ShfModel* m, int np, int l, LanePoints<NR>& P) {
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+    const int i = l + k * G < np ? l + k * G : 0;
+    P.body[k] = m->pt_body[i];
+    P.rad[k] = m->pt_radius[i];
+#pragma unroll
+    for (int j = 0; j < 3; j++) P.pos[k][j] = m->pt_pos[i][j];
+  }
+}
+
+struct ContactConsts {
+  float dt, g[3], kc, beta, mu, veps, max_depen;
+};
+// Response of one penetrating sample point (phi < 0): r is moved to the contact point; writes the slot, returns `on`.
+DEV float contact_point_response(const ContactConsts& K, const float* pb, float* r, const float* n, float rad, float phi, float* o) {
+  float on = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 3; k++) r[k] = fmaf(-rad, n[k], r[k]);
+  float vb[6], vp[3], t[3];
+#pragma unroll
+  for (int k = 0; k < 6; k++) vb[k] = pb[12 + k];
+  cross3(vb, r, t);
+#pragma unroll
+  for (int k = 0; k < 3; k++) vp[k] = fmaf(K.dt, K.g[k], vb[3 + k] + t[k]);
+  const float vn = dot3(n, vp);
+  const float fn = fmaf(-K.beta, vn, rminf(-K.kc * phi, K.beta * K.max_depen));
+  if (fn > 0.0f) {
+    float vt[3] = {fmaf(-vn, n[0], vp[0]), fmaf(-vn, n[1], vp[1]), fmaf(-vn, n[2], vp[2])};
+    const float vtn = sqrtf(dot3(vt, vt));
+    const float ct = K.mu * fn / rmaxf(vtn, K.veps);
+    on = 1.0f;
+    o[10] = ct;
+    o[11] = K.beta;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      o[1 + k] = r[k];
+      o[4 + k] = n[k];
+      o[7 + k] = fmaf(fn, n[k], -(ct * vt[k]));
+    }
+  }
+  return on;
+}
+
 // One gym.simulate() for one env, executed by the G lanes of its group.
 //   dofb[d]: q, qd in;  tau_cmd (explicit effort), pos/vel targets via pt_tgt/vt_tgt (LDS, may be null)
 //   fext: world force per reported body (global memory, this env) or nullptr
 //   contact_out: LDS/global float[nb*3] written by body lanes (may be nullptr)
+#define LANE_ROUNDS(G, DM) ((DM::NPC + (G) - 1) / (G) > 0 ? (DM::NPC + (G) - 1) / (G) : 1)
 template <int G, bool BOX = false, class DM = DynDims>
-DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt, const float* vel_tgt,
-                 const float* fext, float mu_shape, float* contact_out) {
+DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LaneModel& M, const LanePoints<LANE_ROUNDS(G, DM)>& P,
+                 const float* pos_tgt, const float* vel_tgt, const float* fext, float mu_shape, float* contact_out) {
   const ShfModel* m = C.m;
   const int nb = DM::nb(m), nd = DM::nd(m), np = DM::np(m);
   const float dt = C.sp.dt;
   const float gon = (float)m->gravity_on;
   const float g[3] = {C.sp.gravity[0] * gon, C.sp.gravity[1] * gon, C.sp.gravity[2] * gon};
-  const bool isbody = l < nb;
-  const bool isdyn = isbody && m->dyn[l] == l;
-  const int jt = isbody ? m->jtype[l] : -1;
-  const bool moving = isdyn && jt != SHF_JOINT_ROOT;
-  const int mylevel = isbody ? m->level[l] : -1;
+  const bool isbody = M.isbody, isdyn = M.isdyn, moving = M.moving;
+  const int mylevel = M.level;
 
   BodyRegs B;
-  kinematics<G, DM>(m, L, l, B);
-  if (isdyn) body_inertia(m, l, B);
+  kinematics<G, DM>(m, L, l, M, B);
+  PHASE_BEGIN();
+  if (isdyn) body_inertia(M, B);
   if (BOX) boxes_pose<G>(C, L, l, B);
 
   // external forces at the CoM of reported bodies, folded in ascending body order
   if (fext) {
     if (isbody) {
       float F[3] = {fext[3 * l], fext[3 * l + 1], fext[3 * l + 2]};
-      float com[3] = {m->com[l][0], m->com[l][1], m->com[l][2]}, cw[3], t[3];
-      mv3(B.Rw, com, cw);
+      float cw[3], t[3];
+      mv3(B.Rw, M.com, cw);
 #pragma unroll
       for (int k = 0; k < 3; k++) cw[k] += B.p[k];
       cross3(cw, F, t);
@@ -477,55 +585,62 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt,
     GROUP_SYNC();
   }
 
+  PHASE_MARK(2);
   // contacts: one lane per sample point, results parked in LDS
   const float kc = C.sp.contact_k, dc = C.sp.contact_d, veps = C.sp.friction_vel;
   const float beta = fmaf(kc, dt, dc);
   const float mu = 0.5f * (mu_shape + C.terr.t.friction);
-  for (int i = l; i < np; i += G) {
-    const int b = m->pt_body[i];
-    const float* pb = L.pose + b * POSE_STRIDE;
-    float Rb[9], lp[3] = {m->pt_pos[i][0], m->pt_pos[i][1], m->pt_pos[i][2]}, r[3], n[3], h;
+  const ContactConsts K = {dt, {g[0], g[1], g[2]}, kc, beta, mu, veps, C.sp.max_depen_vel};
+  if constexpr (DM::NPC > 0) {
+    // known point count: pass 1 places every round's point and queries the terrain without branches, so the
+    // pose reads and height loads of all rounds are in flight together; pass 2 is the (divergent) response
+    constexpr int NR = (DM::NPC + G - 1) / G;
+    float r[NR][3], n[NR][3], phi[NR];
 #pragma unroll
-    for (int k = 0; k < 9; k++) Rb[k] = pb[k];
-    mv3(Rb, lp, r);
+    for (int k = 0; k < NR; k++) {
+      const float* pb = L.pose + P.body[k] * POSE_STRIDE;
+      float Rb[9], h;
 #pragma unroll
-    for (int k = 0; k < 3; k++) r[k] += pb[9 + k];
-    terrain_query(C.terr, L.root[0] + r[0], L.root[1] + r[1], &h, n);
-    const float rad = m->pt_radius[i];
-    const float phi = fmaf(L.root[2] + r[2] - h, n[2], -rad);
-    float* o = L.pt + i * PT_STRIDE;
-    float on = 0.0f;
-    if (phi < 0.0f) {
+      for (int j = 0; j < 9; j++) Rb[j] = pb[j];
+      mv3(Rb, P.pos[k], r[k]);
 #pragma unroll
-      for (int k = 0; k < 3; k++) r[k] = fmaf(-rad, n[k], r[k]);
-      float vb[6], vp[3], t[3];
+      for (int j = 0; j < 3; j++) r[k][j] += pb[9 + j];
+      terrain_query(C.terr, L.root[0] + r[k][0], L.root[1] + r[k][1], &h, n[k]);
+      phi[k] = fmaf(L.root[2] + r[k][2] - h, n[k][2], -P.rad[k]);
+    }
 #pragma unroll
-      for (int k = 0; k < 6; k++) vb[k] = pb[12 + k];
-      cross3(vb, r, t);
-#pragma unroll
-      for (int k = 0; k < 3; k++) vp[k] = fmaf(dt, g[k], vb[3 + k] + t[k]);
-      const float vn = dot3(n, vp);
-      const float fn = fmaf(-beta, vn, rminf(-kc * phi, beta * C.sp.max_depen_vel));
-      if (fn > 0.0f) {
-        float vt[3] = {fmaf(-vn, n[0], vp[0]), fmaf(-vn, n[1], vp[1]), fmaf(-vn, n[2], vp[2])};
-        const float vtn = sqrtf(dot3(vt, vt));
-        const float ct = mu * fn / rmaxf(vtn, veps);
-        on = 1.0f;
-        o[10] = ct;
-        o[11] = beta;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          o[1 + k] = r[k];
-          o[4 + k] = n[k];
-          o[7 + k] = fmaf(fn, n[k], -(ct * vt[k]));
-        }
+    for (int k = 0; k < NR; k++) {
+      const int i = l + k * G;
+      if (i < DM::NPC) {
+        float* o = L.pt + i * PT_STRIDE;
+        float on = 0.0f;
+        if (phi[k] < 0.0f) on = contact_point_response(K, L.pose + P.body[k] * POSE_STRIDE, r[k], n[k], P.rad[k], phi[k], o);
+        o[0] = on;
       }
     }
-    o[0] = on;
+  } else {
+    for (int i = l; i < np; i += G) {
+      const int b = m->pt_body[i];
+      const float* pb = L.pose + b * POSE_STRIDE;
+      float Rb[9], lp[3] = {m->pt_pos[i][0], m->pt_pos[i][1], m->pt_pos[i][2]}, r[3], n[3], h;
+#pragma unroll
+      for (int k = 0; k < 9; k++) Rb[k] = pb[k];
+      mv3(Rb, lp, r);
+#pragma unroll
+      for (int k = 0; k < 3; k++) r[k] += pb[9 + k];
+      terrain_query(C.terr, L.root[0] + r[0], L.root[1] + r[1], &h, n);
+      const float rad = m->pt_radius[i];
+      const float phi = fmaf(L.root[2] + r[2] - h, n[2], -rad);
+      float* o = L.pt + i * PT_STRIDE;
+      float on = 0.0f;
+      if (phi < 0.0f) on = contact_point_response(K, pb, r, n, rad, phi, o);
+      o[0] = on;
+    }
   }
   GROUP_SYNC();
+  PHASE_MARK(3);
   if (isdyn) {
-    const int i0 = m->pt_start[l], i1 = i0 + m->pt_count[l];
+    const int i0 = M.pt0, i1 = i0 + M.npt;
     for (int i = i0; i < i1; i++) {
       const float* o = L.pt + i * PT_STRIDE;
       if (o[0] == 0.0f) continue;
@@ -558,29 +673,30 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt,
   }
 
   if (BOX) boxes_contacts<G>(C, L, l, B, mu_shape, g);
+  PHASE_MARK(4);
 
   // joint-space efforts: one lane per dof
   if (l < nd) {
     float* D = L.dofb + l * DOF_STRIDE;
     const float q = D[0], qd = D[1];
-    float t0 = 0.0f, de = m->armature[l];
-    const int mode = m->drive_mode[l];
+    float t0 = 0.0f, de = M.armature;
+    const int mode = M.mode;
     if (mode == SHF_DOF_MODE_EFFORT) {
       t0 = D[5];
     } else if (mode == SHF_DOF_MODE_POS || mode == SHF_DOF_MODE_VEL) {
-      float kp = mode == SHF_DOF_MODE_POS ? m->kp[l] : 0.0f, kd = m->kd[l];
+      float kp = mode == SHF_DOF_MODE_POS ? M.kp : 0.0f, kd = M.kd;
       const float tq = pos_tgt ? pos_tgt[l] : 0.0f, tv = (mode == SHF_DOF_MODE_VEL && vel_tgt) ? vel_tgt[l] : 0.0f;
       const float est = fmaf(kp, tq - q, kd * (tv - qd));
-      const float lim = m->effort[l];
+      const float lim = M.effort;
       // drive saturation: scale both gains so the torque starts at the effort limit and stays implicit
       if (lim > 0.0f && fabsf(est) > lim) { const float sc = lim / fabsf(est); kp *= sc; kd *= sc; }
       const float bj = fmaf(dt, kp, kd);
       t0 = fmaf(kp, tq - q, fmaf(kd, tv, -(bj * qd)));
       de = fmaf(dt, bj, de);
     }
-    const float jd = m->damping[l];
+    const float jd = M.damping;
     if (jd > 0.0f) { t0 = fmaf(-jd, qd, t0); de = fmaf(dt, jd, de); }
-    const float lo = m->lower[l], up = m->upper[l];
+    const float lo = M.lower, up = M.upper;
     const float viol = q < lo ? lo - q : (q > up ? up - q : 0.0f);
     if (viol != 0.0f) {
       const float bl = fmaf(dt, C.sp.limit_k, C.sp.limit_d);
@@ -590,12 +706,13 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt,
     D[2] = t0; D[3] = de;
   }
   GROUP_SYNC();
+  PHASE_MARK(5);
 
   // inward pass
   const int nl = DM::nlevels(m);
   for (int lev = nl; lev >= 1; lev--) {
     if (moving && mylevel == lev) {
-      const int d = m->dof[l];
+      const int d = M.dofi;
 #pragma unroll
       for (int i = 0; i < 6; i++) {
         float acc = SYMG(B.IA, i, 0) * B.S[0];
@@ -636,9 +753,19 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt,
     }
     GROUP_SYNC();
     if (isdyn && mylevel == lev - 1) {
-      const int k0 = m->child_start[l], k1 = k0 + m->child_count[l];
-      for (int kk = k0; kk < k1; kk++) {
-        const float* o = L.xch + m->child_list[kk] * XCH_STRIDE;
+      // children in child_list order: the first LANE_CHILDREN from registers, any further ones through LDS
+#pragma unroll
+      for (int kk = 0; kk < LANE_CHILDREN; kk++) {
+        if (kk < M.nchild) {
+          const float* o = L.xch + M.child[kk] * XCH_STRIDE;
+#pragma unroll
+          for (int k = 0; k < 21; k++) B.IA[k] += o[k];
+#pragma unroll
+          for (int k = 0; k < 6; k++) B.pA[k] += o[21 + k];
+        }
+      }
+      for (int kk = LANE_CHILDREN; kk < M.nchild; kk++) {
+        const float* o = L.xch + m->child_list[M.child0 + kk] * XCH_STRIDE;
 #pragma unroll
         for (int k = 0; k < 21; k++) B.IA[k] += o[k];
 #pragma unroll
@@ -648,6 +775,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt,
     GROUP_SYNC();
   }
 
+  PHASE_MARK(6);
   // root acceleration (primed)
   float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   if (l == 0) {
@@ -659,11 +787,12 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt,
 #pragma unroll
     for (int k = 0; k < 6; k++) L.acc[k] = a[k];
   }
+  PHASE_MARK(7);
   // outward pass
   for (int lev = 1; lev <= nl; lev++) {
     GROUP_SYNC();
     if (moving && mylevel == lev) {
-      const float* pa = L.acc + m->dyn[m->parent[l]] * 6;
+      const float* pa = L.acc + M.dynpar * 6;
       float ap[6];
 #pragma unroll
       for (int i = 0; i < 6; i++) ap[i] = pa[i] + B.c[i];
@@ -671,12 +800,13 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt,
 #pragma unroll
       for (int j = 1; j < 6; j++) ua = fmaf(B.U[j], ap[j], ua);
       const float qdd = (B.u - ua) * B.invD;
-      L.dofb[m->dof[l] * DOF_STRIDE + 4] = qdd;
+      L.dofb[M.dofi * DOF_STRIDE + 4] = qdd;
 #pragma unroll
       for (int i = 0; i < 6; i++) { a[i] = fmaf(B.S[i], qdd, ap[i]); L.acc[l * 6 + i] = a[i]; }
     }
   }
   GROUP_SYNC();
+  PHASE_MARK(8);
 
   // net contact force per reported body
   if (contact_out) {
@@ -716,10 +846,11 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt,
     boxes_finish<G>(C, L, l, B, contact_out);
   }
 
+  PHASE_MARK(9);
   // semi-implicit Euler
   if (l < nd) {
     float* D = L.dofb + l * DOF_STRIDE;
-    const float vl = m->vel_limit[l];
+    const float vl = M.vel_limit;
     const float qd = rclampf(fmaf(dt, D[4], D[1]), -vl, vl);
     D[1] = qd;
     D[0] = fmaf(dt, qd, D[0]);
@@ -753,13 +884,14 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const float* pos_tgt,
     Rt[3] = nx * inv; Rt[4] = ny * inv; Rt[5] = nz * inv; Rt[6] = nw * inv;
   }
   GROUP_SYNC();
+  PHASE_MARK(10);
 }
 
 // rigid_body_state rows of this env -> `stage` (LDS, nb*13 floats); caller copies out coalesced
 template <int G, class DM = DynDims>
-DEV void body_states(const ShfModel* m, const EnvLds& L, int l, float* stage) {
+DEV void body_states(const ShfModel* m, const EnvLds& L, int l, const LaneModel& M, float* stage) {
   BodyRegs B;
-  kinematics<G, DM>(m, L, l, B);
+  kinematics<G, DM>(m, L, l, M, B);
   if (l < DM::nb(m)) {
     float* o = stage + 13 * l;
     float t[3], q[4];

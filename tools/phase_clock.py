@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Per-phase latency breakdown of k_a1_step from in-kernel s_memtime marks.
+
+    python tools/phase_clock.py build         # here (no GPU): debug library with -DSHF_PHASE_CLOCK
+    python tools/phase_clock.py [G] [steps]   # on the MI355X box
+
+Thread 0 of block 0 accumulates the cycle count between PHASE_MARKs (csrc/shf_device.h); the marks
+serialise the wave a little (s_memtime + waitcnt), so the total is a few % above the production kernel.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+LIB = os.path.join(ROOT, "shifu_amd", "libshifu_amd_phase.so")
+NAMES = ["kin: local rotation", "kin: level loop", "inertia + ext force", "contact eval (3 rounds)", "contact accumulate",
+         "dof efforts", "ABA inward", "root solve", "ABA outward", "contact force out", "integrate",
+         "prologue (stage, load, actions)", "copy-out + history load", "body_states tail", "get_heights", "post_step (lane 0)",
+         "obs + stores"]
+
+
+def build():
+    from shifu_amd import build as b
+    cmd = [b.hipcc()] + b.FLAGS + ["-DSHF_PHASE_CLOCK", os.path.join(b.CSRC, "shf_api.hip"), "-o", LIB]
+    subprocess.check_call(cmd)
+    print(LIB)
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        return build()
+    G = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    os.environ["SHIFU_AMD_LIB"] = LIB
+    import torch
+    from shifu_amd import _lib
+    from shifu_amd.gym.a1_fused import FusedA1Env
+    env = FusedA1Env(num_envs=4096, group=G)
+    lib = _lib.lib()
+    fn = lib.shf_debug_phase_cycles
+    fn.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_int]
+    buf = (ctypes.c_uint64 * 32)()
+    env.reset()
+    act = torch.empty(env.num_envs, env.num_actions, device=env.device)
+    for _ in range(20):
+        env.step(act.uniform_(-1, 1))
+    torch.cuda.synchronize()
+    assert fn(buf, 32, 1) == 0
+    for _ in range(steps):
+        env.step(act.uniform_(-1, 1))
+    torch.cuda.synchronize()
+    assert fn(buf, 32, 0) == 0
+    tot = sum(buf[:17])
+    print(f"G={G}: {tot / steps:.0f} cycles per env-step in block 0 / wave 0 (s_memtime ticks)")
+    for k, nme in enumerate(NAMES):
+        print(f"  {k:2d} {nme:34s} {buf[k] / steps:9.0f}  {100.0 * buf[k] / tot:5.1f} %")
+
+
+if __name__ == "__main__":
+    main()
