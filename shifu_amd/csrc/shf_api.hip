@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) {
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = nullptr;
   const float mu = A.S.friction[e];
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
-  LaneModel M;
+  LaneModelT<(G < 64)> M;
   lane_model_load<DM>(m, l, M);
   LanePoints<LANE_ROUNDS(G, DM)> LP;
   lane_points_load<G>(m, np, l, LP);

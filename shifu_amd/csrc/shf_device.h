@@ -248,17 +248,46 @@ struct BodyRegs {
 // Per-lane model constants.  Lane l is body l, dof l (and its share of the contact points) for the whole
 // launch, so everything the sub-step would re-read from the LDS model copy -- and the dependent
 // index -> data LDS round trips that come with it -- is read once into registers.
+// HOIST = false keeps the float constants in LDS behind the same member names (register-limited
+// instantiations: one wavefront per env has to fit 128 VGPRs to keep 4096 envs resident).
 #define LANE_CHILDREN 4
-struct LaneModel {
+template <int N> struct RegVec {
+  float v[N];
+  DEV operator const float*() const { return v; }
+  DEV float operator[](int k) const { return v[k]; }
+  DEV void load(const float* p) {
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = p[k];
+  }
+};
+template <int N> struct LdsVec {
+  const float* p;
+  DEV operator const float*() const { return p; }
+  DEV float operator[](int k) const { return p[k]; }
+  DEV void load(const float* q) { p = q; }
+};
+struct RegF { float v; DEV operator float() const { return v; } DEV void load(const float* p) { v = *p; } };
+struct LdsF { const float* p; DEV operator float() const { return *p; } DEV void load(const float* q) { p = q; } };
+template <bool C, class A, class B> struct pick { typedef A type; };
+template <class A, class B> struct pick<false, A, B> { typedef B type; };
+template <bool HOIST>
+struct LaneModelT {
+  typedef typename pick<HOIST, RegF, LdsF>::type F;
+  typedef typename pick<HOIST, RegVec<3>, LdsVec<3>>::type V3;
+  typedef typename pick<HOIST, RegVec<6>, LdsVec<6>>::type V6;
+  typedef typename pick<HOIST, RegVec<9>, LdsVec<9>>::type V9;
   bool isbody, isdyn, moving;
   int jt, par, klev, level, dofi, dynpar, nchild, child0, child[LANE_CHILDREN], pt0, npt;
-  float tp[3], ax[3], tr[9];
-  float mass, com[3], I6[6];
+  V3 tp, ax, com;
+  V9 tr;
+  V6 I6;
+  F mass;
   int mode;                                                      // lane l as dof l
-  float armature, kp, kd, effort, damping, lower, upper, vel_limit;
+  F armature, kp, kd, effort, damping, lower, upper, vel_limit;
 };
-template <class DM>
-DEV void lane_model_load(const ShfModel* m, int l, LaneModel& M) {
+typedef LaneModelT<true> LaneModel;
+template <class DM, class LM>
+DEV void lane_model_load(const ShfModel* m, int l, LM& M) {
   const int nb = DM::nb(m), nd = DM::nd(m);
   M.isbody = l < nb;
   const int b = M.isbody ? l : 0;
@@ -276,24 +305,21 @@ DEV void lane_model_load(const ShfModel* m, int l, LaneModel& M) {
   for (int k = 0; k < LANE_CHILDREN; k++) M.child[k] = k < M.nchild ? m->child_list[M.child0 + k] : 0;
   M.pt0 = m->pt_start[b];
   M.npt = M.isdyn ? m->pt_count[b] : 0;
-#pragma unroll
-  for (int k = 0; k < 3; k++) { M.tp[k] = m->tpos[b][k]; M.ax[k] = m->axis[b][k]; M.com[k] = m->com[b][k]; }
-#pragma unroll
-  for (int k = 0; k < 9; k++) M.tr[k] = m->trot[b][k];
-#pragma unroll
-  for (int k = 0; k < 6; k++) M.I6[k] = m->inertia[b][k];
-  M.mass = m->mass[b];
+  M.tp.load(m->tpos[b]); M.ax.load(m->axis[b]); M.com.load(m->com[b]);
+  M.tr.load(m->trot[b]);
+  M.I6.load(m->inertia[b]);
+  M.mass.load(&m->mass[b]);
   const int d = l < nd ? l : 0;
   M.mode = m->drive_mode[d];
-  M.armature = m->armature[d]; M.kp = m->kp[d]; M.kd = m->kd[d]; M.effort = m->effort[d];
-  M.damping = m->damping[d]; M.lower = m->lower[d]; M.upper = m->upper[d]; M.vel_limit = m->vel_limit[d];
+  M.armature.load(&m->armature[d]); M.kp.load(&m->kp[d]); M.kd.load(&m->kd[d]); M.effort.load(&m->effort[d]);
+  M.damping.load(&m->damping[d]); M.lower.load(&m->lower[d]); M.upper.load(&m->upper[d]); M.vel_limit.load(&m->vel_limit[d]);
 }
 
 // Forward kinematics: pose, motion subspace, velocity, bias acceleration of every reported
 // body.  Phase 1 (all lanes at once): the joint's local rotation Rl = trot * Rot(axis, q).
 // Phase 2 (level by level through LDS): R = Rp * Rl, p = pp + Rp * tpos, a_w = R * axis.
-template <int G, class DM = DynDims>
-DEV void kinematics(const ShfModel* m, const EnvLds& L, int l, const LaneModel& M, BodyRegs& B) {
+template <int G, class DM = DynDims, class LM = LaneModel>
+DEV void kinematics(const ShfModel* m, const EnvLds& L, int l, const LM& M, BodyRegs& B) {
   const bool isbody = M.isbody;
   const int jt = M.jt;
   PHASE_BEGIN();
@@ -436,7 +462,8 @@ DEV void rigid_inertia(float mass, const float* com, const float* I6, BodyRegs& 
 #pragma unroll
   for (int k = 0; k < 3; k++) B.pA[3 + k] = t[k];
 }
-DEV void body_inertia(const LaneModel& M, BodyRegs& B) { rigid_inertia(M.mass, M.com, M.I6, B); }
+template <class LM>
+DEV void body_inertia(const LM& M, BodyRegs& B) { rigid_inertia(M.mass, M.com, M.I6, B); }
 
 typedef ShfScene SceneDev;  // box actors of the scene (gym.create_box), staged in LDS next to the model
 struct StepCtx {
@@ -537,13 +564,43 @@ DEV float contact_point_response(const ContactConsts& K, const float* pb, float*
   return on;
 }
 
+// Fold one active contact slot into its body's bias force and articulated inertia:
+// pA -= [r x f0; f0],  IA += dt * (c_t * PointMass(r) + (beta - c_t) * w w^T),  w = [r x n; n].
+DEV void contact_accumulate(const float* o, float dt, BodyRegs& B) {
+  const float r[3] = {o[1], o[2], o[3]}, n[3] = {o[4], o[5], o[6]}, f0[3] = {o[7], o[8], o[9]};
+  float t[3], wn[6];
+  cross3(r, f0, t);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { B.pA[k] -= t[k]; B.pA[3 + k] -= f0[k]; }
+  cross3(r, n, t);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { wn[k] = t[k]; wn[3 + k] = n[k]; }
+  const float a = dt * o[10], bb = dt * (o[11] - o[10]);
+  const float r2 = dot3(r, r);
+#pragma unroll
+  for (int i2 = 0; i2 < 3; i2++)
+#pragma unroll
+    for (int j2 = i2; j2 < 3; j2++)
+      B.IA[SYM(i2, j2)] = fmaf(a, (i2 == j2 ? r2 : 0.0f) - r[i2] * r[j2], B.IA[SYM(i2, j2)]);
+  B.IA[SYM(0, 4)] = fmaf(a, -r[2], B.IA[SYM(0, 4)]); B.IA[SYM(0, 5)] = fmaf(a, r[1], B.IA[SYM(0, 5)]);
+  B.IA[SYM(1, 3)] = fmaf(a, r[2], B.IA[SYM(1, 3)]);  B.IA[SYM(1, 5)] = fmaf(a, -r[0], B.IA[SYM(1, 5)]);
+  B.IA[SYM(2, 3)] = fmaf(a, -r[1], B.IA[SYM(2, 3)]); B.IA[SYM(2, 4)] = fmaf(a, r[0], B.IA[SYM(2, 4)]);
+  B.IA[SYM(3, 3)] += a; B.IA[SYM(4, 4)] += a; B.IA[SYM(5, 5)] += a;
+#pragma unroll
+  for (int i2 = 0; i2 < 6; i2++) {
+    const float bw = bb * wn[i2];
+#pragma unroll
+    for (int j2 = i2; j2 < 6; j2++) B.IA[SYM(i2, j2)] = fmaf(bw, wn[j2], B.IA[SYM(i2, j2)]);
+  }
+}
+
 // One gym.simulate() for one env, executed by the G lanes of its group.
 //   dofb[d]: q, qd in;  tau_cmd (explicit effort), pos/vel targets via pt_tgt/vt_tgt (LDS, may be null)
 //   fext: world force per reported body (global memory, this env) or nullptr
 //   contact_out: LDS/global float[nb*3] written by body lanes (may be nullptr)
 #define LANE_ROUNDS(G, DM) ((DM::NPC + (G) - 1) / (G) > 0 ? (DM::NPC + (G) - 1) / (G) : 1)
-template <int G, bool BOX = false, class DM = DynDims>
-DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LaneModel& M, const LanePoints<LANE_ROUNDS(G, DM)>& P,
+template <int G, bool BOX = false, class DM = DynDims, class LM = LaneModel>
+DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const LanePoints<LANE_ROUNDS(G, DM)>& P,
                  const float* pos_tgt, const float* vel_tgt, const float* fext, float mu_shape, float* contact_out) {
   const ShfModel* m = C.m;
   const int nb = DM::nb(m), nd = DM::nd(m), np = DM::np(m);
@@ -554,7 +611,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LaneModel& M, c
   const int mylevel = M.level;
 
   BodyRegs B;
-  kinematics<G, DM>(m, L, l, M, B);
+  kinematics<G, DM, LM>(m, L, l, M, B);
   PHASE_BEGIN();
   if (isdyn) body_inertia(M, B);
   if (BOX) boxes_pose<G>(C, L, l, B);
@@ -591,7 +648,8 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LaneModel& M, c
   const float beta = fmaf(kc, dt, dc);
   const float mu = 0.5f * (mu_shape + C.terr.t.friction);
   const ContactConsts K = {dt, {g[0], g[1], g[2]}, kc, beta, mu, veps, C.sp.max_depen_vel};
-  if constexpr (DM::NPC > 0) {
+  unsigned long long active[LANE_ROUNDS(G, DM)];
+  if constexpr (DM::NPC > 0 && G < 64) {
     // known point count: pass 1 places every round's point and queries the terrain without branches, so the
     // pose reads and height loads of all rounds are in flight together; pass 2 is the (divergent) response
     constexpr int NR = (DM::NPC + G - 1) / G;
@@ -608,15 +666,18 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LaneModel& M, c
       terrain_query(C.terr, L.root[0] + r[k][0], L.root[1] + r[k][1], &h, n[k]);
       phi[k] = fmaf(L.root[2] + r[k][2] - h, n[k][2], -P.rad[k]);
     }
+    const int lane0 = (int)(threadIdx.x & 63u) - l;   // first lane of this env's group within the wavefront
 #pragma unroll
     for (int k = 0; k < NR; k++) {
       const int i = l + k * G;
+      float on = 0.0f;
       if (i < DM::NPC) {
         float* o = L.pt + i * PT_STRIDE;
-        float on = 0.0f;
         if (phi[k] < 0.0f) on = contact_point_response(K, L.pose + P.body[k] * POSE_STRIDE, r[k], n[k], P.rad[k], phi[k], o);
         o[0] = on;
       }
+      // bit j = point k*G + j of this env is in contact
+      active[k] = (__ballot(on != 0.0f) >> lane0) & (G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull));
     }
   } else {
     for (int i = l; i < np; i += G) {
@@ -639,35 +700,29 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LaneModel& M, c
   }
   GROUP_SYNC();
   PHASE_MARK(3);
-  if (isdyn) {
-    const int i0 = M.pt0, i1 = i0 + M.npt;
-    for (int i = i0; i < i1; i++) {
-      const float* o = L.pt + i * PT_STRIDE;
-      if (o[0] == 0.0f) continue;
-      const float r[3] = {o[1], o[2], o[3]}, n[3] = {o[4], o[5], o[6]}, f0[3] = {o[7], o[8], o[9]};
-      float t[3], wn[6];
-      cross3(r, f0, t);
+  if constexpr (DM::NPC > 0 && G < 64) {
+    // the body lane picks its active points (ascending) out of the ballots: no flag reads, no idle iterations
+    constexpr int NR = (DM::NPC + G - 1) / G;
+    if (isdyn) {
+      const int i0 = M.pt0, i1 = i0 + M.npt;
 #pragma unroll
-      for (int k = 0; k < 3; k++) { B.pA[k] -= t[k]; B.pA[3 + k] -= f0[k]; }
-      cross3(r, n, t);
-#pragma unroll
-      for (int k = 0; k < 3; k++) { wn[k] = t[k]; wn[3 + k] = n[k]; }
-      const float a = dt * o[10], bb = dt * (o[11] - o[10]);
-      const float r2 = dot3(r, r);
-#pragma unroll
-      for (int i2 = 0; i2 < 3; i2++)
-#pragma unroll
-        for (int j2 = i2; j2 < 3; j2++)
-          B.IA[SYM(i2, j2)] = fmaf(a, (i2 == j2 ? r2 : 0.0f) - r[i2] * r[j2], B.IA[SYM(i2, j2)]);
-      B.IA[SYM(0, 4)] = fmaf(a, -r[2], B.IA[SYM(0, 4)]); B.IA[SYM(0, 5)] = fmaf(a, r[1], B.IA[SYM(0, 5)]);
-      B.IA[SYM(1, 3)] = fmaf(a, r[2], B.IA[SYM(1, 3)]);  B.IA[SYM(1, 5)] = fmaf(a, -r[0], B.IA[SYM(1, 5)]);
-      B.IA[SYM(2, 3)] = fmaf(a, -r[1], B.IA[SYM(2, 3)]); B.IA[SYM(2, 4)] = fmaf(a, r[0], B.IA[SYM(2, 4)]);
-      B.IA[SYM(3, 3)] += a; B.IA[SYM(4, 4)] += a; B.IA[SYM(5, 5)] += a;
-#pragma unroll
-      for (int i2 = 0; i2 < 6; i2++) {
-        const float bw = bb * wn[i2];
-#pragma unroll
-        for (int j2 = i2; j2 < 6; j2++) B.IA[SYM(i2, j2)] = fmaf(bw, wn[j2], B.IA[SYM(i2, j2)]);
+      for (int k = 0; k < NR; k++) {
+        const int a0 = (i0 > k * G ? i0 : k * G) - k * G, a1 = (i1 < (k + 1) * G ? i1 : (k + 1) * G) - k * G;
+        unsigned long long bits = a1 > a0 ? (active[k] >> a0) & (a1 - a0 >= 64 ? ~0ull : ((1ull << (a1 - a0)) - 1ull)) : 0ull;
+        while (bits) {
+          const int j = __builtin_ctzll(bits);
+          bits &= bits - 1ull;
+          contact_accumulate(L.pt + (k * G + a0 + j) * PT_STRIDE, dt, B);
+        }
+      }
+    }
+  } else {
+    if (isdyn) {
+      const int i0 = M.pt0, i1 = i0 + M.npt;
+      for (int i = i0; i < i1; i++) {
+        const float* o = L.pt + i * PT_STRIDE;
+        if (o[0] == 0.0f) continue;
+        contact_accumulate(o, dt, B);
       }
     }
   }
@@ -888,10 +943,10 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LaneModel& M, c
 }
 
 // rigid_body_state rows of this env -> `stage` (LDS, nb*13 floats); caller copies out coalesced
-template <int G, class DM = DynDims>
-DEV void body_states(const ShfModel* m, const EnvLds& L, int l, const LaneModel& M, float* stage) {
+template <int G, class DM = DynDims, class LM = LaneModel>
+DEV void body_states(const ShfModel* m, const EnvLds& L, int l, const LM& M, float* stage) {
   BodyRegs B;
-  kinematics<G, DM>(m, L, l, M, B);
+  kinematics<G, DM, LM>(m, L, l, M, B);
   if (l < DM::nb(m)) {
     float* o = stage + 13 * l;
     float t[3], q[4];
