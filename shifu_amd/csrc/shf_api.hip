@@ -66,11 +66,32 @@ struct SimArgs {
   float* contact;  // (n*B,3)
 };
 
-// cooperative copy of the flattened articulation into LDS
+// Cooperative global -> LDS copy of a fixed-size parameter block by the 256 threads of a block: all loads
+// are issued before the first store (one memory round trip instead of one per loop iteration).
+// Both pointers are 16-byte aligned (device allocations; LDS offsets are multiples of 4 words).
+template <int NBYTES>
+DEV void stage_block(const void* gsrc, float* ldst) {
+  constexpr int NV = NBYTES / 16, NT = (NBYTES % 16) / 4, IV = (NV + 255) / 256;
+  const uint4* src = reinterpret_cast<const uint4*>(gsrc);
+  uint4* dst = reinterpret_cast<uint4*>(ldst);
+  uint4 v[IV > 0 ? IV : 1];
+  uint32_t tail = 0;
+#pragma unroll
+  for (int k = 0; k < IV; k++) {
+    const int i = (int)threadIdx.x + k * 256;
+    if (i < NV) v[k] = src[i];
+  }
+  if (NT > 0 && (int)threadIdx.x < NT) tail = reinterpret_cast<const uint32_t*>(gsrc)[NV * 4 + threadIdx.x];
+#pragma unroll
+  for (int k = 0; k < IV; k++) {
+    const int i = (int)threadIdx.x + k * 256;
+    if (i < NV) dst[i] = v[k];
+  }
+  if (NT > 0 && (int)threadIdx.x < NT) reinterpret_cast<uint32_t*>(ldst)[NV * 4 + threadIdx.x] = tail;
+}
+// the flattened articulation
 DEV const ShfModel* stage_model(const ShfModel* gm, float* smem) {
-  const uint32_t* src = reinterpret_cast<const uint32_t*>(gm);
-  uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
-  for (int i = threadIdx.x; i < (int)(sizeof(ShfModel) / 4); i += blockDim.x) dst[i] = src[i];
+  stage_block<(int)sizeof(ShfModel)>(gm, smem);
   __syncthreads();
   return reinterpret_cast<const ShfModel*>(smem);
 }
@@ -80,9 +101,7 @@ DEV const ShfModel* stage_model(const ShfModel* gm, float* smem) {
 #define SCENE_WORDS ((int)((sizeof(ShfScene) / 4 + 3) & ~3))
 
 DEV const ShfScene* stage_scene(const ShfScene* gs, float* dst_words) {
-  const uint32_t* src = reinterpret_cast<const uint32_t*>(gs);
-  uint32_t* dst = reinterpret_cast<uint32_t*>(dst_words);
-  for (int i = threadIdx.x; i < (int)(sizeof(ShfScene) / 4); i += blockDim.x) dst[i] = src[i];
+  stage_block<(int)sizeof(ShfScene)>(gs, dst_words);
   return reinterpret_cast<const ShfScene*>(dst_words);
 }
 
@@ -353,11 +372,7 @@ template <int G, class DM>
 __global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   PHASE_BEGIN();
-  {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(A.tp);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(smem + MODEL_WORDS);
-    for (int i = threadIdx.x; i < (int)(sizeof(ShfA1TaskParams) / 4); i += blockDim.x) dst[i] = src[i];
-  }
+  stage_block<(int)sizeof(ShfA1TaskParams)>(A.tp, smem + MODEL_WORDS);
   const ShfModel* m = stage_model(A.S.model, smem);
   const ShfA1TaskParams& tp = *reinterpret_cast<const ShfA1TaskParams*>(smem + MODEL_WORDS);
   const int epb = 256 / G, es = threadIdx.x / G, l = threadIdx.x % G;
@@ -431,25 +446,48 @@ __global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) {
     float qz = L.root[5], qw = L.root[6];
     const float nrm = rmaxf(sqrtf(qz * qz + qw * qw), 1e-9f);
     qz = qz / nrm; qw = qw / nrm;
-    for (int i = l; i < P; i += G) {
-      const float bx = A.hpoints[2 * i], by = A.hpoints[2 * i + 1];
-      const float tx = (-qz * by) * 2.0f, ty = (qz * bx) * 2.0f;
-      float px = bx + qw * tx + (-qz * ty) + L.root[0];
-      float py = by + qw * ty + (qz * tx) + L.root[1];
-      float hh = 0.0f;
-      if (A.S.terr.rows > 0) {
-        px += A.S.terr.border; py += A.S.terr.border;
-        int ix = (int)truncf(px / A.S.terr.hscale), iy = (int)truncf(py / A.S.terr.hscale);
-        ix = ix < 0 ? 0 : ix; ix = ix > A.S.terr.rows - 2 ? A.S.terr.rows - 2 : ix;
-        iy = iy < 0 ? 0 : iy; iy = iy > A.S.terr.cols - 2 ? A.S.terr.cols - 2 : iy;
-        const int16_t* p0 = A.S.heights + (size_t)ix * A.S.terr.cols + iy;
-        const int16_t h1 = p0[0], h2 = p0[A.S.terr.cols], h3 = p0[1];
-        int16_t hm = h1 < h2 ? h1 : h2;
-        hm = hm < h3 ? hm : h3;
-        hh = (float)hm * A.S.terr.vscale;
+    // HC sample points per lane and trip: their point loads, then their height loads, go out together
+    constexpr int HC = 3;
+    const float rx = L.root[0], ry = L.root[1];
+    for (int base = l; base < P; base += HC * G) {
+      float bx[HC], by[HC], hh[HC];
+#pragma unroll
+      for (int k = 0; k < HC; k++) {
+        const int i = base + k * G < P ? base + k * G : 0;
+        bx[k] = A.hpoints[2 * i]; by[k] = A.hpoints[2 * i + 1];
       }
-      scr[SCR_MH + i] = hh;
-      A.heights_out[(size_t)e * P + i] = hh;
+      int16_t h1[HC], h2[HC], h3[HC];
+      if (A.S.terr.rows > 0) {
+#pragma unroll
+        for (int k = 0; k < HC; k++) {
+          const float tx = (-qz * by[k]) * 2.0f, ty = (qz * bx[k]) * 2.0f;
+          float px = bx[k] + qw * tx + (-qz * ty) + rx;
+          float py = by[k] + qw * ty + (qz * tx) + ry;
+          px += A.S.terr.border; py += A.S.terr.border;
+          int ix = (int)truncf(px / A.S.terr.hscale), iy = (int)truncf(py / A.S.terr.hscale);
+          ix = ix < 0 ? 0 : ix; ix = ix > A.S.terr.rows - 2 ? A.S.terr.rows - 2 : ix;
+          iy = iy < 0 ? 0 : iy; iy = iy > A.S.terr.cols - 2 ? A.S.terr.cols - 2 : iy;
+          const int16_t* p0 = A.S.heights + (size_t)ix * A.S.terr.cols + iy;
+          h1[k] = p0[0]; h2[k] = p0[A.S.terr.cols]; h3[k] = p0[1];
+        }
+#pragma unroll
+        for (int k = 0; k < HC; k++) {
+          int16_t hm = h1[k] < h2[k] ? h1[k] : h2[k];
+          hm = hm < h3[k] ? hm : h3[k];
+          hh[k] = (float)hm * A.S.terr.vscale;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < HC; k++) hh[k] = 0.0f;
+      }
+#pragma unroll
+      for (int k = 0; k < HC; k++) {
+        const int i = base + k * G;
+        if (i < P) {
+          scr[SCR_MH + i] = hh[k];
+          A.heights_out[(size_t)e * P + i] = hh[k];
+        }
+      }
     }
   }
   GROUP_SYNC();
@@ -660,7 +698,7 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(A.tp);
     uint32_t* dst = reinterpret_cast<uint32_t*>(smem + MODEL_WORDS + SCENE_WORDS);
-    for (int i = threadIdx.x; i < (int)(sizeof(ShfAbbTaskParams) / 4); i += blockDim.x) dst[i] = src[i];
+    stage_block<(int)sizeof(ShfAbbTaskParams)>(src, reinterpret_cast<float*>(dst));
   }
   const ShfScene* scene = stage_scene(A.S.scene, smem + MODEL_WORDS);
   const ShfModel* m = stage_model(A.S.model, smem);
