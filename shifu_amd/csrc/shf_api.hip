@@ -79,7 +79,7 @@ DEV void stage_block(const void* gsrc, float* ldst) {
 #pragma unroll
   for (int k = 0; k < IV; k++) {
     const int i = (int)threadIdx.x + k * 256;
-    if (i < NV) v[k] = src[i];
+    v[k] = src[i < NV ? i : 0];
   }
   if (NT > 0 && (int)threadIdx.x < NT) tail = reinterpret_cast<const uint32_t*>(gsrc)[NV * 4 + threadIdx.x];
 #pragma unroll

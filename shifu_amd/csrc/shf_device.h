@@ -224,10 +224,12 @@ struct DynDims {
   DEV static int nlevels(const ShfModel* m) { return m->nlevels; }
   DEV static int nklevels(const ShfModel* m) { return m->nklevels; }
   static constexpr int NPC = 0;   // contact-point count unknown at compile time
+  static constexpr int NKC = 0;   // kinematic depth unknown at compile time
 };
 template <int NB, int ND, int NP, int NL, int NK>
 struct FixedDims {
   static constexpr int NPC = NP;
+  static constexpr int NKC = NK;
   DEV static int nb(const ShfModel*) { return NB; }
   DEV static int nd(const ShfModel*) { return ND; }
   DEV static int np(const ShfModel*) { return NP; }
@@ -251,6 +253,7 @@ struct BodyRegs {
 // HOIST = false keeps the float constants in LDS behind the same member names (register-limited
 // instantiations: one wavefront per env has to fit 128 VGPRs to keep 4096 envs resident).
 #define LANE_CHILDREN 4
+#define LANE_ANCESTORS 4
 template <int N> struct RegVec {
   float v[N];
   DEV operator const float*() const { return v; }
@@ -278,6 +281,7 @@ struct LaneModelT {
   typedef typename pick<HOIST, RegVec<9>, LdsVec<9>>::type V9;
   bool isbody, isdyn, moving;
   int jt, par, klev, level, dofi, dynpar, nchild, child0, child[LANE_CHILDREN], pt0, npt;
+  int anc[LANE_ANCESTORS];   // kinematic chain below the root, anc[klev-1] = this body (fixed-depth models only)
   V3 tp, ax, com;
   V9 tr;
   V6 I6;
@@ -305,6 +309,15 @@ DEV void lane_model_load(const ShfModel* m, int l, LM& M) {
   for (int k = 0; k < LANE_CHILDREN; k++) M.child[k] = k < M.nchild ? m->child_list[M.child0 + k] : 0;
   M.pt0 = m->pt_start[b];
   M.npt = M.isdyn ? m->pt_count[b] : 0;
+  if constexpr (DM::NKC > 0) {
+    static_assert(DM::NKC <= LANE_ANCESTORS, "raise LANE_ANCESTORS");
+    int a = b;
+#pragma unroll
+    for (int k = LANE_ANCESTORS - 1; k >= 0; k--) {
+      M.anc[k] = 0;
+      if (k < M.klev) { M.anc[k] = a; a = m->parent[a]; }
+    }
+  }
   M.tp.load(m->tpos[b]); M.ax.load(m->axis[b]); M.com.load(m->com[b]);
   M.tr.load(m->trot[b]);
   M.I6.load(m->inertia[b]);
@@ -369,6 +382,89 @@ DEV void kinematics(const ShfModel* m, const EnvLds& L, int l, const LM& M, Body
     for (int k = 0; k < 6; k++) o[12 + k] = B.v[k];
   }
   PHASE_MARK(0);
+  if constexpr (DM::NKC > 0) {
+    // Known depth: instead of one LDS hand-off per kinematic level, every lane publishes its joint's local
+    // rotation and state once, then walks its own chain from the root down, repeating the ancestors'
+    // compositions (same operands, same order => the same poses the level loop produces).
+    if (isbody && jt != SHF_JOINT_ROOT) {
+      float* o = L.pose + l * POSE_STRIDE;
+#pragma unroll
+      for (int k = 0; k < 9; k++) o[k] = Rl[k];
+      o[9] = qv; o[10] = qdv;
+    }
+    GROUP_SYNC();
+    if (klev >= 1) {
+      float Rp[9], pp[3], vp[6], Sn[6], cn[6];
+#pragma unroll
+      for (int k = 0; k < 9; k++) Rp[k] = L.pose[k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) pp[k] = L.pose[9 + k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) { vp[k] = L.pose[12 + k]; Sn[k] = 0.0f; cn[k] = 0.0f; }
+#pragma unroll
+      for (int d = 0; d < DM::NKC; d++) {
+        if (d < klev) {
+          const int a = M.anc[d];
+          const float* rec = L.pose + a * POSE_STRIDE;
+          const int ja = m->jtype[a];
+          float Ra[9], ta[3], aa[3], t[3], Rn[9], pn[3];
+#pragma unroll
+          for (int k = 0; k < 9; k++) Ra[k] = rec[k];
+          const float qa = rec[9], qda = rec[10];
+#pragma unroll
+          for (int k = 0; k < 3; k++) { ta[k] = m->tpos[a][k]; aa[k] = m->axis[a][k]; }
+          mv3(Rp, ta, t);
+#pragma unroll
+          for (int k = 0; k < 3; k++) pn[k] = pp[k] + t[k];
+          mm3(Rp, Ra, Rn);
+          if (ja == SHF_JOINT_WELD) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) { Sn[k] = 0.0f; cn[k] = 0.0f; }
+          } else {
+            float aw[3], t2[3];
+            mv3(Rn, aa, aw);
+            if (ja == SHF_JOINT_REVOLUTE) {
+              cross3(pn, aw, t2);
+#pragma unroll
+              for (int k = 0; k < 3; k++) { Sn[k] = aw[k]; Sn[3 + k] = t2[k]; }
+            } else {
+#pragma unroll
+              for (int k = 0; k < 3; k++) { pn[k] = fmaf(aw[k], qa, pn[k]); Sn[k] = 0.0f; Sn[3 + k] = aw[k]; }
+            }
+            float vJ[6], cc[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) vJ[k] = Sn[k] * qda;
+            crm(vp, vJ, cc);
+#pragma unroll
+            for (int k = 0; k < 6; k++) { cn[k] = cc[k]; vp[k] = vp[k] + vJ[k]; }
+          }
+#pragma unroll
+          for (int k = 0; k < 9; k++) Rp[k] = Rn[k];
+#pragma unroll
+          for (int k = 0; k < 3; k++) pp[k] = pn[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 9; k++) B.Rw[k] = Rp[k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) B.p[k] = pp[k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) { B.v[k] = vp[k]; B.S[k] = Sn[k]; B.c[k] = cn[k]; }
+    }
+    GROUP_SYNC();   // every lane has read the records it needs before the slots turn into poses
+    if (klev >= 1) {
+      float* o = L.pose + l * POSE_STRIDE;
+#pragma unroll
+      for (int k = 0; k < 9; k++) o[k] = B.Rw[k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) o[9 + k] = B.p[k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) o[12 + k] = B.v[k];
+    }
+    GROUP_SYNC();
+    PHASE_MARK(1);
+    return;
+  }
   const int nk = DM::nklevels(m);
   for (int lev = 1; lev <= nk; lev++) {
     GROUP_SYNC();
