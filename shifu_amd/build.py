@@ -3,6 +3,7 @@
 hipcc cross-compiles without a GPU.  -ffp-contract=off / no fast-math are part of
 the arithmetic contract documented in csrc/shf_device.h.
 """
+import json
 import os
 import shutil
 import subprocess
@@ -36,12 +37,53 @@ def needs_build() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
+RESOURCES = os.path.join(HERE, "libshifu_amd.resources.json")
+# (kernel-name prefix, max VGPRs, max scratch bytes): the fused A1 step at two envs per wavefront runs two
+# waves per SIMD (4096 envs resident at once) only while it stays within 256 VGPRs, and any scratch use there
+# means an array stopped living in registers -- both have cost >30 % when they slipped in unnoticed.
+BUDGETS = [("_Z9k_a1_stepILi32E9FixedDims", 256, 0)]
+
+
+def parse_resources(remarks: str) -> dict:
+    """kernel -> {vgprs, agprs, sgprs, scratch, spill, occupancy} from -Rpass-analysis=kernel-resource-usage."""
+    out, cur = {}, None
+    keys = {"VGPRs:": "vgprs", "AGPRs:": "agprs", "TotalSGPRs:": "sgprs", "ScratchSize [bytes/lane]:": "scratch",
+            "VGPRs Spill:": "spill", "Occupancy [waves/SIMD]:": "occupancy"}
+    for line in remarks.splitlines():
+        if "remark:" not in line:
+            continue
+        body = line.split("remark:", 1)[1].replace("[-Rpass-analysis=kernel-resource-usage]", "").strip()
+        if body.startswith("Function Name:"):
+            cur = out.setdefault(body.split(":", 1)[1].strip(), {})
+        elif cur is not None:
+            for k, name in keys.items():
+                if body.startswith(k):
+                    cur[name] = int(body[len(k):].strip())
+    return out
+
+
+def check_budgets(res: dict):
+    for prefix, max_vgpr, max_scratch in BUDGETS:
+        hits = [(k, v) for k, v in res.items() if k.startswith(prefix)]
+        if not hits:
+            raise RuntimeError(f"kernel {prefix}* missing from the build")
+        for k, v in hits:
+            if v.get("vgprs", 0) > max_vgpr or v.get("scratch", 0) > max_scratch:
+                raise RuntimeError(f"{k}: {v} exceeds the register budget ({max_vgpr} VGPRs, {max_scratch} B scratch)")
+
+
 def build_native(force: bool = False, verbose: bool = False) -> str:
-    if force or needs_build():
-        cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if force or needs_build() or not os.path.exists(RESOURCES):
+        cmd = [hipcc()] + FLAGS + ["-Rpass-analysis=kernel-resource-usage"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + p.stderr[-4000:])
+        res = parse_resources(p.stderr)
+        with open(RESOURCES, "w") as f:
+            json.dump(res, f, indent=1, sort_keys=True)
+        check_budgets(res)
     return LIB
 
 

@@ -64,3 +64,15 @@ def test_error_path_without_gpu(libpath):
     with pytest.raises(_lib.BackendError):
         _lib.check(l.shf_sim_step(h, None))
     l.shf_sim_destroy(h)
+
+
+def test_register_budgets_of_the_fused_step():
+    """The build records every kernel's register use; the default instantiation of the fused A1 step must stay
+    within two waves per SIMD and out of scratch (shifu_amd/build.py: BUDGETS)."""
+    import json
+    from shifu_amd import build
+    build.build_native()
+    res = json.load(open(build.RESOURCES))
+    build.check_budgets(res)
+    k = [v for n, v in res.items() if n.startswith("_Z9k_a1_stepILi32E9FixedDims")][0]
+    assert k["spill"] == 0 and k["vgprs"] <= 256
