@@ -690,6 +690,22 @@ DEV void contact_accumulate(const float* o, float dt, BodyRegs& B) {
   }
 }
 
+// End-of-step force of an active slot: f = f0 - dt * B * a_point with the body's solved acceleration `ab`.
+DEV void contact_force_final(float* o, const float* ab, float dt) {
+  const float r[3] = {o[1], o[2], o[3]}, n[3] = {o[4], o[5], o[6]};
+  float al[3] = {ab[0], ab[1], ab[2]}, t[3], ap[3];
+  cross3(al, r, t);
+#pragma unroll
+  for (int k = 0; k < 3; k++) ap[k] = ab[3 + k] + t[k];
+  const float an = dot3(n, ap);
+  const float ct = o[10], bn = o[11];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float Ba = fmaf(bn - ct, an * n[k], ct * ap[k]);
+    o[7 + k] = fmaf(-dt, Ba, o[7 + k]);
+  }
+}
+
 // One gym.simulate() for one env, executed by the G lanes of its group.
 //   dofb[d]: q, qd in;  tau_cmd (explicit effort), pos/vel targets via pt_tgt/vt_tgt (LDS, may be null)
 //   fext: world force per reported body (global memory, this env) or nullptr
@@ -961,34 +977,50 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
 
   // net contact force per reported body
   if (contact_out) {
-    for (int i = l; i < np; i += G) {
-      float* o = L.pt + i * PT_STRIDE;
-      if (o[0] == 0.0f) continue;
-      const float* ab = L.acc + m->dyn[m->pt_body[i]] * 6;
-      const float r[3] = {o[1], o[2], o[3]}, n[3] = {o[4], o[5], o[6]};
-      float al[3] = {ab[0], ab[1], ab[2]}, t[3], ap[3];
-      cross3(al, r, t);
+    if constexpr (DM::NPC > 0 && G < 64) {
+      // active points come from the ballots taken in the contact pass
+      constexpr int NR = (DM::NPC + G - 1) / G;
 #pragma unroll
-      for (int k = 0; k < 3; k++) ap[k] = ab[3 + k] + t[k];
-      const float an = dot3(n, ap);
-      const float ct = o[10], bn = o[11];
+      for (int k = 0; k < NR; k++) {
+        if ((active[k] >> l) & 1ull) contact_force_final(L.pt + (l + k * G) * PT_STRIDE, L.acc + m->dyn[P.body[k]] * 6, dt);
+      }
+      GROUP_SYNC();
+      if (isbody) {
+        float f[3] = {0.0f, 0.0f, 0.0f};
+        const int dl = m->dyn[l];
+        const int i0 = m->pt_start[dl], i1 = i0 + m->pt_count[dl];
 #pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const float Ba = fmaf(bn - ct, an * n[k], ct * ap[k]);
-        o[7 + k] = fmaf(-dt, Ba, o[7 + k]);
+        for (int k = 0; k < NR; k++) {
+          const int a0 = (i0 > k * G ? i0 : k * G) - k * G, a1 = (i1 < (k + 1) * G ? i1 : (k + 1) * G) - k * G;
+          unsigned long long bits = a1 > a0 ? (active[k] >> a0) & (a1 - a0 >= 64 ? ~0ull : ((1ull << (a1 - a0)) - 1ull)) : 0ull;
+          while (bits) {
+            const int i = k * G + a0 + __builtin_ctzll(bits);
+            bits &= bits - 1ull;
+            if (m->pt_body[i] != l) continue;
+            const float* o = L.pt + i * PT_STRIDE;
+            f[0] += o[7]; f[1] += o[8]; f[2] += o[9];
+          }
+        }
+        contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];
       }
-    }
-    GROUP_SYNC();
-    if (isbody) {
-      float f[3] = {0.0f, 0.0f, 0.0f};
-      const int dl = m->dyn[l];
-      const int i0 = m->pt_start[dl], i1 = i0 + m->pt_count[dl];
-      for (int i = i0; i < i1; i++) {
-        const float* o = L.pt + i * PT_STRIDE;
-        if (o[0] == 0.0f || m->pt_body[i] != l) continue;
-        f[0] += o[7]; f[1] += o[8]; f[2] += o[9];
+    } else {
+      for (int i = l; i < np; i += G) {
+        float* o = L.pt + i * PT_STRIDE;
+        if (o[0] == 0.0f) continue;
+        contact_force_final(o, L.acc + m->dyn[m->pt_body[i]] * 6, dt);
       }
-      contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];
+      GROUP_SYNC();
+      if (isbody) {
+        float f[3] = {0.0f, 0.0f, 0.0f};
+        const int dl = m->dyn[l];
+        const int i0 = m->pt_start[dl], i1 = i0 + m->pt_count[dl];
+        for (int i = i0; i < i1; i++) {
+          const float* o = L.pt + i * PT_STRIDE;
+          if (o[0] == 0.0f || m->pt_body[i] != l) continue;
+          f[0] += o[7]; f[1] += o[8]; f[2] += o[9];
+        }
+        contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];
+      }
     }
   }
 
