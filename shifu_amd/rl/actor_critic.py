@@ -1,0 +1,71 @@
+"""Gaussian MLP actor + MLP critic (PPOConfig.policy, shifu/configs/policy_config.py:8-16)."""
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+from torch.distributions import Normal
+
+_ACTIVATIONS = {"elu": nn.ELU, "selu": nn.SELU, "relu": nn.ReLU, "lrelu": nn.LeakyReLU, "tanh": nn.Tanh,
+                "sigmoid": nn.Sigmoid}
+
+
+def _mlp(n_in: int, hidden: Sequence[int], n_out: int, act: str) -> nn.Sequential:
+    if act not in _ACTIVATIONS:
+        raise ValueError(f"unknown activation '{act}' (one of {sorted(_ACTIVATIONS)})")
+    layers, last = [], n_in
+    for h in hidden:
+        layers += [nn.Linear(last, h), _ACTIVATIONS[act]()]
+        last = h
+    layers.append(nn.Linear(last, n_out))
+    return nn.Sequential(*layers)
+
+
+class ActorCritic(nn.Module):
+    """A1 default: 259 -> 512 -> 256 -> 128 -> 12 (actor) / -> 1 (critic), ELU; state-independent std."""
+    is_recurrent = False
+
+    def __init__(self, num_actor_obs, num_critic_obs, num_actions, actor_hidden_dims=(256, 256, 256),
+                 critic_hidden_dims=(256, 256, 256), activation="elu", init_noise_std=1.0, **kwargs):
+        if kwargs:
+            print("ActorCritic: ignoring unknown policy keys " + ", ".join(kwargs))
+        super().__init__()
+        self.actor = _mlp(num_actor_obs, actor_hidden_dims, num_actions, activation)
+        self.critic = _mlp(num_critic_obs, critic_hidden_dims, 1, activation)
+        self.std = nn.Parameter(init_noise_std * torch.ones(num_actions))
+        self.distribution = None
+        Normal.set_default_validate_args(False)
+
+    def reset(self, dones=None):
+        pass
+
+    def forward(self):
+        raise NotImplementedError
+
+    @property
+    def action_mean(self):
+        return self.distribution.mean
+
+    @property
+    def action_std(self):
+        return self.distribution.stddev
+
+    @property
+    def entropy(self):
+        return self.distribution.entropy().sum(dim=-1)
+
+    def update_distribution(self, observations):
+        mean = self.actor(observations)
+        self.distribution = Normal(mean, mean * 0.0 + self.std)
+
+    def act(self, observations, **kwargs):
+        self.update_distribution(observations)
+        return self.distribution.sample()
+
+    def get_actions_log_prob(self, actions):
+        return self.distribution.log_prob(actions).sum(dim=-1)
+
+    def act_inference(self, observations):
+        return self.actor(observations)
+
+    def evaluate(self, critic_observations, **kwargs):
+        return self.critic(critic_observations)

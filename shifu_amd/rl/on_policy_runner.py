@@ -1,0 +1,158 @@
+"""OnPolicyRunner: rollout collection + PPO updates + logging / checkpoints.
+
+Bound by the reference at shifu/runner/policy_runner.py:7-14 (`load`), :21-22 (`learn`),
+:47-48 (`get_inference_policy`), :62 (constructor).  `train_cfg` is `class_to_dict(PPOConfig)`:
+keys "policy", "algorithm", "runner".  The env is any rsl_rl-style VecEnv (ShifuVecEnv, FusedA1Env, ...).
+"""
+import json
+import os
+import statistics
+import time
+from collections import deque
+
+import torch
+
+from ..parallel import broadcast_parameters, rank, world_size
+from .actor_critic import ActorCritic
+from .ppo import PPO
+
+
+class OnPolicyRunner:
+    def __init__(self, env, train_cfg, log_dir=None, device="cpu"):
+        self.cfg = train_cfg["runner"]
+        self.alg_cfg = train_cfg["algorithm"]
+        self.policy_cfg = train_cfg["policy"]
+        self.device = device
+        self.env = env
+        num_critic_obs = env.num_privileged_obs if env.num_privileged_obs is not None else env.num_obs
+        name = self.cfg.get("policy_class_name", "ActorCritic")
+        if name != "ActorCritic":
+            raise NotImplementedError(f"policy_class_name '{name}': only the feed-forward ActorCritic is implemented")
+        if self.cfg.get("algorithm_class_name", "PPO") != "PPO":
+            raise NotImplementedError("algorithm_class_name: only PPO is implemented")
+        actor_critic = ActorCritic(env.num_obs, num_critic_obs, env.num_actions, **self.policy_cfg).to(device)
+        broadcast_parameters(actor_critic)
+        self.alg = PPO(actor_critic, device=device, **self.alg_cfg)
+        self.num_steps_per_env = self.cfg["num_steps_per_env"]
+        self.save_interval = self.cfg["save_interval"]
+        self.alg.init_storage(env.num_envs, self.num_steps_per_env, [env.num_obs], [env.num_privileged_obs],
+                              [env.num_actions])
+        self.log_dir = log_dir
+        self.tot_timesteps = 0
+        self.tot_time = 0.0
+        self.current_learning_iteration = 0
+        self.history = []          # one dict per iteration (also appended to <log_dir>/progress.jsonl)
+        self.env.reset()
+
+    # ------------------------------------------------------------------ learn
+    def learn(self, num_learning_iterations, init_at_random_ep_len=False):
+        env, alg, dev = self.env, self.alg, self.device
+        if self.log_dir is not None and rank() == 0:
+            os.makedirs(self.log_dir, exist_ok=True)
+        if init_at_random_ep_len:
+            env.episode_length_buf.copy_(torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length)))
+        obs = env.get_observations()
+        priv = env.get_privileged_observations()
+        critic_obs = priv if priv is not None else obs
+        obs, critic_obs = obs.to(dev), critic_obs.to(dev)
+        alg.actor_critic.train()
+
+        ep_infos = []
+        rewbuffer, lenbuffer = deque(maxlen=100), deque(maxlen=100)
+        cur_reward_sum = torch.zeros(env.num_envs, dtype=torch.float, device=dev)
+        cur_episode_length = torch.zeros(env.num_envs, dtype=torch.float, device=dev)
+
+        first, last = self.current_learning_iteration, self.current_learning_iteration + num_learning_iterations
+        for it in range(first, last):
+            start = time.time()
+            with torch.inference_mode():
+                for _ in range(self.num_steps_per_env):
+                    # the env rewrites its observation buffer in place: the rollout keeps a copy
+                    obs_in = obs.clone()
+                    cobs_in = obs_in if critic_obs.data_ptr() == obs.data_ptr() else critic_obs.clone()
+                    actions = alg.act(obs_in, cobs_in)
+                    obs, priv, rewards, dones, infos = env.step(actions)
+                    critic_obs = priv if priv is not None else obs
+                    obs, critic_obs, rewards, dones = obs.to(dev), critic_obs.to(dev), rewards.to(dev), dones.to(dev)
+                    alg.process_env_step(rewards, dones, infos)
+                    if self.log_dir is not None:
+                        if "episode" in infos:
+                            ep_infos.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in infos["episode"].items()})
+                        cur_reward_sum += rewards
+                        cur_episode_length += 1
+                        new_ids = (dones > 0).nonzero(as_tuple=False)
+                        rewbuffer.extend(cur_reward_sum[new_ids][:, 0].cpu().numpy().tolist())
+                        lenbuffer.extend(cur_episode_length[new_ids][:, 0].cpu().numpy().tolist())
+                        cur_reward_sum[new_ids] = 0
+                        cur_episode_length[new_ids] = 0
+                stop = time.time()
+                collection_time = stop - start
+                start = stop
+                alg.compute_returns(critic_obs.clone())
+            mean_value_loss, mean_surrogate_loss = alg.update()
+            learn_time = time.time() - start
+            if self.log_dir is not None:
+                self.log(locals())
+            if it % self.save_interval == 0 and self.log_dir is not None and rank() == 0:
+                self.save(os.path.join(self.log_dir, f"model_{it}.pt"))
+            ep_infos.clear()
+        self.current_learning_iteration += num_learning_iterations
+        if self.log_dir is not None and rank() == 0:
+            self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
+
+    # -------------------------------------------------------------------- log
+    def log(self, locs, width=80, pad=35):
+        n_samples = self.num_steps_per_env * self.env.num_envs * world_size()
+        self.tot_timesteps += n_samples
+        it_time = locs["collection_time"] + locs["learn_time"]
+        self.tot_time += it_time
+        rec = {"iteration": locs["it"], "fps": n_samples / it_time, "collection_time": locs["collection_time"],
+               "learn_time": locs["learn_time"], "value_loss": locs["mean_value_loss"],
+               "surrogate_loss": locs["mean_surrogate_loss"], "learning_rate": self.alg.learning_rate,
+               "mean_noise_std": float(self.alg.actor_critic.std.mean()), "total_timesteps": self.tot_timesteps,
+               "total_time": self.tot_time}
+        if locs["ep_infos"]:
+            for key in locs["ep_infos"][0]:
+                vals = [torch.as_tensor(e[key], dtype=torch.float32, device=self.device).reshape(-1) for e in locs["ep_infos"]]
+                rec["episode/" + key] = float(torch.cat(vals).mean())
+        if len(locs["rewbuffer"]) > 0:
+            rec["mean_reward"] = statistics.mean(locs["rewbuffer"])
+            rec["mean_episode_length"] = statistics.mean(locs["lenbuffer"])
+        self.history.append(rec)
+        if rank() != 0:
+            return
+        if self.log_dir is not None:
+            with open(os.path.join(self.log_dir, "progress.jsonl"), "a") as f:
+                f.write(json.dumps(rec) + "\n")
+        head = f" Learning iteration {locs['it']}/{locs['last']} "
+        lines = ["#" * width, head.center(width), ""]
+        show = [("Computation:", f"{rec['fps']:.0f} steps/s (collection: {rec['collection_time']:.3f}s, learning {rec['learn_time']:.3f}s)"),
+                ("Value function loss:", f"{rec['value_loss']:.4f}"), ("Surrogate loss:", f"{rec['surrogate_loss']:.4f}"),
+                ("Mean action noise std:", f"{rec['mean_noise_std']:.2f}")]
+        if "mean_reward" in rec:
+            show += [("Mean reward:", f"{rec['mean_reward']:.2f}"), ("Mean episode length:", f"{rec['mean_episode_length']:.2f}")]
+        show += [(f"Mean episode {k[8:]}:", f"{v:.4f}") for k, v in rec.items() if k.startswith("episode/")]
+        show += [("Total timesteps:", str(self.tot_timesteps)), ("Iteration time:", f"{it_time:.2f}s"),
+                 ("Total time:", f"{self.tot_time:.2f}s")]
+        lines += [f"{k:>{pad}} {v}" for k, v in show]
+        print("\n".join(lines))
+
+    # ------------------------------------------------------------ checkpoints
+    def save(self, path, infos=None):
+        torch.save({"model_state_dict": self.alg.actor_critic.state_dict(),
+                    "optimizer_state_dict": self.alg.optimizer.state_dict(),
+                    "iter": self.current_learning_iteration, "infos": infos}, path)
+
+    def load(self, path, load_optimizer=True):
+        loaded = torch.load(path, map_location=self.device)      # shifu/runner/policy_runner.py:8-14
+        self.alg.actor_critic.load_state_dict(loaded["model_state_dict"])
+        if load_optimizer:
+            self.alg.optimizer.load_state_dict(loaded["optimizer_state_dict"])
+        self.current_learning_iteration = loaded["iter"]
+        return loaded["infos"]
+
+    def get_inference_policy(self, device=None):
+        self.alg.actor_critic.eval()
+        if device is not None:
+            self.alg.actor_critic.to(device)
+        return self.alg.actor_critic.act_inference

@@ -1,0 +1,114 @@
+"""PPO update (PPOConfig.algorithm, shifu/configs/policy_config.py:18-32)."""
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from ..parallel import average_, average_gradients, world_size
+from .storage import RolloutStorage
+
+
+class PPO:
+    def __init__(self, actor_critic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
+                 value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True,
+                 schedule="fixed", desired_kl=0.01, device="cpu"):
+        self.device = device
+        self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
+        self.actor_critic = actor_critic.to(device)
+        self.storage = None
+        self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=learning_rate)
+        self.transition = RolloutStorage.Transition()
+        self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
+        self.value_loss_coef, self.entropy_coef = value_loss_coef, entropy_coef
+        self.gamma, self.lam, self.max_grad_norm = gamma, lam, max_grad_norm
+        self.use_clipped_value_loss = use_clipped_value_loss
+
+    def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape):
+        self.storage = RolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape,
+                                      self.device)
+
+    def test_mode(self):
+        self.actor_critic.eval()
+
+    def train_mode(self):
+        self.actor_critic.train()
+
+    def act(self, obs, critic_obs):
+        t = self.transition
+        t.actions = self.actor_critic.act(obs).detach()
+        t.values = self.actor_critic.evaluate(critic_obs).detach()
+        t.actions_log_prob = self.actor_critic.get_actions_log_prob(t.actions).detach()
+        t.action_mean = self.actor_critic.action_mean.detach()
+        t.action_sigma = self.actor_critic.action_std.detach()
+        t.observations = obs                # copied into the rollout buffer by add_transitions
+        t.critic_observations = critic_obs
+        return t.actions
+
+    def process_env_step(self, rewards, dones, infos):
+        t = self.transition
+        t.rewards = rewards.clone()
+        t.dones = dones
+        # an episode cut by the time limit is not a failure: bootstrap its tail with V(s_t)
+        if "time_outs" in infos:
+            t.rewards += self.gamma * torch.squeeze(t.values * infos["time_outs"].unsqueeze(1).to(self.device), 1)
+        self.storage.add_transitions(t)
+        t.clear()
+        self.actor_critic.reset(dones)
+
+    def compute_returns(self, last_critic_obs):
+        last_values = self.actor_critic.evaluate(last_critic_obs).detach()
+        self.storage.compute_returns(last_values, self.gamma, self.lam)
+
+    def losses(self, obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma):
+        """Loss terms of one mini-batch under the current parameters (also what tests/test_rl.py checks)."""
+        ac = self.actor_critic
+        ac.act(obs)
+        logp = ac.get_actions_log_prob(actions)
+        value = ac.evaluate(cobs)
+        mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
+        with torch.no_grad():
+            # KL(old || new) of diagonal Gaussians, averaged over the mini-batch
+            kl = torch.sum(torch.log(sigma / old_sigma + 1.e-5)
+                           + (old_sigma.square() + (old_mu - mu).square()) / (2.0 * sigma.square()) - 0.5, dim=-1).mean()
+        ratio = torch.exp(logp - torch.squeeze(old_logp))
+        adv = torch.squeeze(advantages)
+        surrogate = -adv * ratio
+        surrogate_clipped = -adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)
+        surrogate_loss = torch.max(surrogate, surrogate_clipped).mean()
+        if self.use_clipped_value_loss:
+            value_clipped = target_values + (value - target_values).clamp(-self.clip_param, self.clip_param)
+            value_loss = torch.max((value - returns).square(), (value_clipped - returns).square()).mean()
+        else:
+            value_loss = (returns - value).square().mean()
+        ent = entropy.mean()
+        return {"surrogate": surrogate_loss, "value": value_loss, "entropy": ent, "kl": kl,
+                "loss": surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * ent}
+
+    def adapt_learning_rate(self, kl_mean: float):
+        """schedule='adaptive': keep the policy step near desired_kl (x1.5 / /1.5, clamped to [1e-5, 1e-2])."""
+        if kl_mean > self.desired_kl * 2.0:
+            self.learning_rate = max(1e-5, self.learning_rate / 1.5)
+        elif 0.0 < kl_mean < self.desired_kl / 2.0:
+            self.learning_rate = min(1e-2, self.learning_rate * 1.5)
+        for g in self.optimizer.param_groups:
+            g["lr"] = self.learning_rate
+
+    def update(self):
+        mean_value_loss = mean_surrogate_loss = 0.0
+        ac = self.actor_critic
+        for (obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, _h, _m) in \
+                self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
+            L = self.losses(obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma)
+            if self.desired_kl is not None and self.schedule == "adaptive":
+                # the KL is averaged over ranks first so that every rank takes the same decision
+                self.adapt_learning_rate(float(average_(L["kl"].detach().clone())))
+            self.optimizer.zero_grad(set_to_none=True)
+            L["loss"].backward()
+            if world_size() > 1:
+                average_gradients(ac.parameters())
+            nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
+            self.optimizer.step()
+            mean_value_loss += L["value"].item()
+            mean_surrogate_loss += L["surrogate"].item()
+        n = self.num_learning_epochs * self.num_mini_batches
+        self.storage.clear()
+        return mean_value_loss / n, mean_surrogate_loss / n

@@ -1,0 +1,79 @@
+"""Rollout buffer: (T, N, ...) tensors on the training device, GAE(lambda), shuffled mini-batches."""
+import torch
+
+
+class RolloutStorage:
+    class Transition:
+        def __init__(self):
+            self.clear()
+
+        def clear(self):
+            self.observations = self.critic_observations = self.actions = self.rewards = self.dones = None
+            self.values = self.actions_log_prob = self.action_mean = self.action_sigma = None
+
+    def __init__(self, num_envs, num_transitions_per_env, obs_shape, privileged_obs_shape, actions_shape, device="cpu"):
+        self.device = device
+        T, N = num_transitions_per_env, num_envs
+        self.num_envs, self.num_transitions_per_env = N, T
+        z = lambda *s: torch.zeros(T, N, *s, device=device)
+        self.observations = z(*obs_shape)
+        self.privileged_observations = z(*privileged_obs_shape) if privileged_obs_shape[0] is not None else None
+        self.actions = z(*actions_shape)
+        self.rewards, self.values, self.returns, self.advantages, self.actions_log_prob = z(1), z(1), z(1), z(1), z(1)
+        self.dones = torch.zeros(T, N, 1, device=device, dtype=torch.uint8)
+        self.mu, self.sigma = z(*actions_shape), z(*actions_shape)
+        self.step = 0
+
+    def add_transitions(self, t: "RolloutStorage.Transition"):
+        if self.step >= self.num_transitions_per_env:
+            raise AssertionError("Rollout buffer overflow")
+        k = self.step
+        self.observations[k].copy_(t.observations)
+        if self.privileged_observations is not None:
+            self.privileged_observations[k].copy_(t.critic_observations)
+        self.actions[k].copy_(t.actions)
+        self.rewards[k].copy_(t.rewards.view(-1, 1))
+        self.dones[k].copy_(t.dones.view(-1, 1))
+        self.values[k].copy_(t.values)
+        self.actions_log_prob[k].copy_(t.actions_log_prob.view(-1, 1))
+        self.mu[k].copy_(t.action_mean)
+        self.sigma[k].copy_(t.action_sigma)
+        self.step += 1
+
+    def clear(self):
+        self.step = 0
+
+    def compute_returns(self, last_values, gamma, lam):
+        """delta_t = r_t + gamma (1-d_t) V_{t+1} - V_t;  A_t = delta_t + gamma lam (1-d_t) A_{t+1};  R_t = A_t + V_t;
+        advantages are then standardised over the whole buffer."""
+        adv = 0
+        for k in reversed(range(self.num_transitions_per_env)):
+            nxt = last_values if k == self.num_transitions_per_env - 1 else self.values[k + 1]
+            live = 1.0 - self.dones[k].float()
+            delta = self.rewards[k] + live * gamma * nxt - self.values[k]
+            adv = delta + live * gamma * lam * adv
+            self.returns[k] = adv + self.values[k]
+        self.advantages = self.returns - self.values
+        self.advantages = (self.advantages - self.advantages.mean()) / (self.advantages.std() + 1e-8)
+
+    def get_statistics(self):
+        done = self.dones.clone()
+        done[-1] = 1
+        flat = done.permute(1, 0, 2).reshape(-1, 1)
+        idx = torch.cat((flat.new_tensor([-1], dtype=torch.int64), flat.nonzero(as_tuple=False)[:, 0]))
+        lengths = idx[1:] - idx[:-1]
+        return lengths.float().mean(), self.rewards.mean()
+
+    def mini_batch_generator(self, num_mini_batches, num_epochs=8):
+        B = self.num_envs * self.num_transitions_per_env
+        mb = B // num_mini_batches
+        perm = torch.randperm(num_mini_batches * mb, device=self.device)
+        obs = self.observations.flatten(0, 1)
+        cobs = self.privileged_observations.flatten(0, 1) if self.privileged_observations is not None else obs
+        acts, vals, rets = self.actions.flatten(0, 1), self.values.flatten(0, 1), self.returns.flatten(0, 1)
+        logp, adv = self.actions_log_prob.flatten(0, 1), self.advantages.flatten(0, 1)
+        mu, sg = self.mu.flatten(0, 1), self.sigma.flatten(0, 1)
+        for _ in range(num_epochs):
+            for i in range(num_mini_batches):
+                b = perm[i * mb:(i + 1) * mb]
+                yield obs[b], cobs[b], acts[b], vals[b], adv[b], rets[b], logp[b], mu[b], sg[b], (None, None), None

@@ -1,21 +1,25 @@
 """run_policy (reference shifu/runner/policy_runner.py:17-73).
 
 `run_mode='random'` -- the benchmark driver shape (:33-41: reset, then
-`2*rand(N, A) - 1` per step) -- runs entirely on this backend.  'train' / 'play' need
-an rsl_rl-compatible OnPolicyRunner (the reference's trainer is the un-vendored rsl_rl
-package); when it is importable they behave as in the reference, otherwise they raise
-with a clear message.  The trainer is SURVEY 8f row f1, not part of this hot path."""
+`2*rand(N, A) - 1` per step) -- and 'train' / 'play' all run on this backend.  The
+reference's trainer is the un-vendored rsl_rl package (`OnPolicyRunner`); here the same
+interface is provided by shifu_amd.rl.  Set SHIFU_AMD_TRAINER=rsl_rl
+to use an installed rsl_rl instead."""
+import os
+
 import torch
 
 from .utils import class_to_dict, datetime_logdir, get_load_path, set_seed
 
 
 def _on_policy_runner_class():
+    if os.environ.get("SHIFU_AMD_TRAINER", "native") != "rsl_rl":
+        from ..rl import OnPolicyRunner
+        return OnPolicyRunner        # its load() already has the reference subclass's semantics (:7-14)
     try:
         from rsl_rl.runners import OnPolicyRunner
     except Exception as e:  # pragma: no cover - rsl_rl is not installed here
-        raise RuntimeError("run_mode 'train'/'play' needs the rsl_rl package (reference README.md:35-37); "
-                           "run_mode 'random' does not") from e
+        raise RuntimeError("SHIFU_AMD_TRAINER=rsl_rl but the rsl_rl package is not importable") from e
 
     class _OnPolicyRunner(OnPolicyRunner):
         def load(self, path, load_optimizer=True):

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Train the A1 velocity-tracking policy with the in-tree PPO trainer on the fused env.
+
+    python tools/train_a1.py [--iters 300] [--envs 4096] [--hook] [--log gpurun_out/train_a1]
+    python -m torch.distributed.run --nproc-per-node N tools/train_a1.py ...      # env shards + gradient all-reduce
+
+Prints one JSON line: samples/s (whole job, rollout + update), the reward curve at a few iterations and the
+final episode statistics.  `--hook` trains on the hook-compatible A1Conditional instead (same observations).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=300)
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--hook", action="store_true")
+    ap.add_argument("--log", default=None)
+    ap.add_argument("--quiet", action="store_true")
+    args = ap.parse_args()
+    import torch.distributed as dist
+    world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    from examples.a1_conditional.task_config import A1PPOConfig
+    from shifu_amd.rl import OnPolicyRunner
+    from shifu_amd.runner.utils import class_to_dict, set_seed
+    cfg = class_to_dict(A1PPOConfig())
+    set_seed(A1PPOConfig.seed + rank)
+    if args.hook:
+        from examples.a1_conditional.a1_conditional import A1Conditional
+        from examples.a1_conditional.task_config import A1EnvConfig
+        ec = A1EnvConfig()
+        ec.num_envs = args.envs
+        env = A1Conditional(ec)
+    else:
+        from shifu_amd.gym.a1_fused import FusedA1Env
+        env = FusedA1Env(num_envs=args.envs, device=dev, rank=rank, world_size=world)
+    log_dir = args.log or os.path.join("gpurun_out", "train_a1")
+    runner = OnPolicyRunner(env, cfg, log_dir=log_dir, device=str(dev))
+    if args.quiet:
+        import builtins
+        _print, builtins.print = builtins.print, (lambda *a, **k: None)
+    t0 = time.time()
+    runner.learn(args.iters, init_at_random_ep_len=True)
+    torch.cuda.synchronize()
+    el = time.time() - t0
+    if args.quiet:
+        builtins.print = _print
+    if rank == 0:
+        H = runner.history
+        pick = sorted(set([0, len(H) // 8, len(H) // 4, len(H) // 2, 3 * len(H) // 4, len(H) - 1]))
+        out = {"env": "A1Conditional (hook path)" if args.hook else "FusedA1Env", "envs_per_gpu": args.envs, "n_gpus": world,
+               "iterations": args.iters, "steps_per_env_per_iter": cfg["runner"]["num_steps_per_env"],
+               "samples_per_s": args.iters * cfg["runner"]["num_steps_per_env"] * args.envs * world / el, "seconds": el,
+               "mean_collection_s": sum(h["collection_time"] for h in H) / len(H), "mean_learn_s": sum(h["learn_time"] for h in H) / len(H),
+               "curve": [{"it": H[i]["iteration"], "mean_reward": H[i].get("mean_reward"), "len": H[i].get("mean_episode_length"),
+                          "track_lin": H[i].get("episode/tracking_lin_vel"), "levels": H[i].get("episode/terrain_levels"),
+                          "std": H[i]["mean_noise_std"]} for i in pick]}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
