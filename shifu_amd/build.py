@@ -41,7 +41,7 @@ RESOURCES = os.path.join(HERE, "libshifu_amd.resources.json")
 # (kernel-name prefix, max VGPRs, max scratch bytes): the fused A1 step at two envs per wavefront runs two
 # waves per SIMD (4096 envs resident at once) only while it stays within 256 VGPRs, and any scratch use there
 # means an array stopped living in registers -- both have cost >30 % when they slipped in unnoticed.
-BUDGETS = [("_Z9k_a1_stepILi32E9FixedDims", 256, 0)]
+BUDGETS = [("_Z16k_a1_step_a1_g32", 256, 0)]
 
 
 def parse_resources(remarks: str) -> dict:
@@ -68,7 +68,7 @@ def check_budgets(res: dict):
         if not hits:
             raise RuntimeError(f"kernel {prefix}* missing from the build")
         for k, v in hits:
-            if v.get("vgprs", 0) > max_vgpr or v.get("scratch", 0) > max_scratch:
+            if v.get("vgprs", 0) + v.get("agprs", 0) > max_vgpr or v.get("scratch", 0) > max_scratch:
                 raise RuntimeError(f"{k}: {v} exceeds the register budget ({max_vgpr} VGPRs, {max_scratch} B scratch)")
 
 

@@ -369,7 +369,7 @@ __global__ void k_a1_reset_all(A1Args A) {
 // profiles/r01_*); at G = 32 the grid is 2 waves per SIMD and the unconstrained
 // allocation is faster (0.104 ms vs 0.112 ms).
 template <int G, class DM>
-__global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) {
+DEV void a1_step_body(const A1Args& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   PHASE_BEGIN();
   stage_block<(int)sizeof(ShfA1TaskParams)>(A.tp, smem + MODEL_WORDS);
@@ -398,10 +398,9 @@ __global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) {
   GROUP_SYNC();
 
   // Q2: base-frame velocities from the pre-physics root state (robot.py:222-229)
-  float blv[3] = {0, 0, 0}, bav[3] = {0, 0, 0};
   const float gv[3] = {0.0f, 0.0f, -1.0f};
   if (l == 0) {
-    float pg[3];
+    float pg[3], blv[3], bav[3];
     quat_rotate_inverse(L.root + 3, L.root + 7, blv);
     quat_rotate_inverse(L.root + 3, L.root + 10, bav);
     quat_rotate_inverse(L.root + 3, gv, pg);
@@ -495,6 +494,10 @@ __global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) {
 
   // post_step (env.py:93-106): one lane runs the scalar bookkeeping
   if (l == 0) {
+    // pre-physics base-frame velocities: written to base_vel at the top of the kernel by this lane and read back
+    // here rather than held in six registers across the sub-steps
+    const float* bv = A.base_vel + (size_t)e * 9;
+    const float blv[3] = {bv[0], bv[1], bv[2]}, bav[3] = {bv[3], bv[4], bv[5]};
     const float* cf = L.xch;
     int64_t ep = A.ep_len[e] + 1;
     const float* fb = cf + 3 * tp.base_body;
@@ -606,6 +609,14 @@ __global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) {
   for (int i = l; i < 2 * nd; i += G) dof[i] = L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)];
   if (l < 13) root[l] = L.root[l];
   PHASE_MARK(16);
+}
+template <int G, class DM>
+__global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) { a1_step_body<G, DM>(A); }
+// The default instantiation (A1, two envs per wavefront) has to stay within 256 VGPRs: two blocks per CU = two
+// waves per SIMD keep all 4096 envs resident.  Launch bounds of (256, 2) would say the same but also switch the
+// scheduler to its occupancy-preserving mode (measured +13 %), so the register cap is given directly.
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256))) void k_a1_step_a1_g32(A1Args A) {
+  a1_step_body<32, A1Dims>(A);
 }
 
 // per-step reduction for extras["episode"] (env.py:149-158), fixed order: block k reduces
@@ -1205,7 +1216,7 @@ extern "C" int shf_a1_step(ShfA1Task* task, const float* raw_actions_dev, void* 
   if (A1Dims::matches(s->model)) {
     switch (s->group) {
       case 64: r = launch(k_a1_step<64, A1Dims>, grid, block, lds, stream, A); break;
-      case 32: r = launch(k_a1_step<32, A1Dims>, grid, block, lds, stream, A); break;
+      case 32: r = launch(k_a1_step_a1_g32, grid, block, lds, stream, A); break;
       default: return fail("shf_a1_step: A1 has 17 bodies, the lane group must be 32 or 64");
     }
   } else {

@@ -280,8 +280,17 @@ struct LaneModelT {
   typedef typename pick<HOIST, RegVec<6>, LdsVec<6>>::type V6;
   typedef typename pick<HOIST, RegVec<9>, LdsVec<9>>::type V9;
   bool isbody, isdyn, moving;
-  int jt, par, klev, level, dofi, dynpar, nchild, child0, child[LANE_CHILDREN], pt0, npt;
-  int anc[LANE_ANCESTORS];   // kinematic chain below the root, anc[klev-1] = this body (fixed-depth models only)
+  // small tree indices share one register: jt+1 (3 bits) | klev+1 (5) | level+1 (5) | dof+1 (6) | dyn[parent] (5) | parent (5)
+  unsigned tree;
+  DEV int jt() const { return (int)(tree & 7u) - 1; }
+  DEV int klev() const { return (int)((tree >> 3) & 31u) - 1; }
+  DEV int level() const { return (int)((tree >> 8) & 31u) - 1; }
+  DEV int dofi() const { return (int)((tree >> 13) & 63u) - 1; }
+  DEV int dynpar() const { return (int)((tree >> 19) & 31u); }
+  DEV int par() const { return (int)((tree >> 24) & 31u); }
+  int nchild, child0, child[LANE_CHILDREN], pt0, npt;
+  unsigned ancs;             // kinematic chain below the root in 6-bit fields, field klev-1 = this body (fixed-depth models only)
+  DEV int anc(int k) const { return (int)((ancs >> (6 * k)) & 63u); }
   V3 tp, ax, com;
   V9 tr;
   V6 I6;
@@ -295,14 +304,14 @@ DEV void lane_model_load(const ShfModel* m, int l, LM& M) {
   const int nb = DM::nb(m), nd = DM::nd(m);
   M.isbody = l < nb;
   const int b = M.isbody ? l : 0;
-  M.jt = M.isbody ? m->jtype[b] : -1;
+  const int jt = M.isbody ? m->jtype[b] : -1;
   M.isdyn = M.isbody && m->dyn[b] == b;
-  M.moving = M.isdyn && M.jt != SHF_JOINT_ROOT;
-  M.par = M.jt > SHF_JOINT_ROOT ? m->parent[b] : 0;
-  M.klev = (M.isbody && M.jt != SHF_JOINT_ROOT) ? m->klevel[b] : -1;
-  M.level = M.isbody ? m->level[b] : -1;
-  M.dofi = m->dof[b];
-  M.dynpar = m->dyn[M.par];
+  M.moving = M.isdyn && jt != SHF_JOINT_ROOT;
+  const int par = jt > SHF_JOINT_ROOT ? m->parent[b] : 0;
+  const int klev = (M.isbody && jt != SHF_JOINT_ROOT) ? m->klevel[b] : -1;
+  const int level = M.isbody ? m->level[b] : -1;
+  M.tree = (unsigned)(jt + 1) | (unsigned)(klev + 1) << 3 | (unsigned)(level + 1) << 8 | (unsigned)(m->dof[b] + 1) << 13 |
+           (unsigned)m->dyn[par] << 19 | (unsigned)par << 24;
   M.child0 = m->child_start[b];
   M.nchild = M.isdyn ? m->child_count[b] : 0;
 #pragma unroll
@@ -312,10 +321,10 @@ DEV void lane_model_load(const ShfModel* m, int l, LM& M) {
   if constexpr (DM::NKC > 0) {
     static_assert(DM::NKC <= LANE_ANCESTORS, "raise LANE_ANCESTORS");
     int a = b;
+    M.ancs = 0u;
 #pragma unroll
     for (int k = LANE_ANCESTORS - 1; k >= 0; k--) {
-      M.anc[k] = 0;
-      if (k < M.klev) { M.anc[k] = a; a = m->parent[a]; }
+      if (k < klev) { M.ancs |= (unsigned)a << (6 * k); a = m->parent[a]; }
     }
   }
   M.tp.load(m->tpos[b]); M.ax.load(m->axis[b]); M.com.load(m->com[b]);
@@ -334,19 +343,19 @@ DEV void lane_model_load(const ShfModel* m, int l, LM& M) {
 template <int G, class DM = DynDims, class LM = LaneModel>
 DEV void kinematics(const ShfModel* m, const EnvLds& L, int l, const LM& M, BodyRegs& B) {
   const bool isbody = M.isbody;
-  const int jt = M.jt;
+  const int jt = M.jt();
   PHASE_BEGIN();
   float Rl[9], qv = 0.0f, qdv = 0.0f;
   const float* tp = M.tp;
   const float* ax = M.ax;
   const float* tr = M.tr;
-  const int par = M.par, klev = M.klev;
+  const int par = M.par(), klev = M.klev();
   if (isbody && jt != SHF_JOINT_ROOT) {
     if (jt == SHF_JOINT_WELD) {
 #pragma unroll
       for (int k = 0; k < 9; k++) Rl[k] = tr[k];
     } else {
-      const int d = M.dofi;
+      const int d = M.dofi();
       qv = L.dofb[d * DOF_STRIDE];
       qdv = L.dofb[d * DOF_STRIDE + 1];
       if (jt == SHF_JOINT_REVOLUTE) {
@@ -404,7 +413,7 @@ DEV void kinematics(const ShfModel* m, const EnvLds& L, int l, const LM& M, Body
 #pragma unroll
       for (int d = 0; d < DM::NKC; d++) {
         if (d < klev) {
-          const int a = M.anc[d];
+          const int a = M.anc(d);
           const float* rec = L.pose + a * POSE_STRIDE;
           const int ja = m->jtype[a];
           float Ra[9], ta[3], aa[3], t[3], Rn[9], pn[3];
@@ -612,15 +621,18 @@ DEV void ldlt_solve6(const float* IA, const float* pA, float* x) {
 // count is a compile-time constant.
 template <int NR>
 struct LanePoints {
-  int body[NR];
+  unsigned bodies;   // reported body of round k's point in 6-bit fields (NR <= 5)
   float pos[NR][3], rad[NR];
+  DEV int body(int k) const { return (int)((bodies >> (6 * k)) & 63u); }
 };
 template <int G, int NR>
 DEV void lane_points_load(const ShfModel* m, int np, int l, LanePoints<NR>& P) {
+  static_assert(NR <= 5, "LanePoints packs at most five rounds");
+  P.bodies = 0u;
 #pragma unroll
   for (int k = 0; k < NR; k++) {
     const int i = l + k * G < np ? l + k * G : 0;
-    P.body[k] = m->pt_body[i];
+    P.bodies |= (unsigned)m->pt_body[i] << (6 * k);
     P.rad[k] = m->pt_radius[i];
 #pragma unroll
     for (int j = 0; j < 3; j++) P.pos[k][j] = m->pt_pos[i][j];
@@ -720,7 +732,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
   const float gon = (float)m->gravity_on;
   const float g[3] = {C.sp.gravity[0] * gon, C.sp.gravity[1] * gon, C.sp.gravity[2] * gon};
   const bool isbody = M.isbody, isdyn = M.isdyn, moving = M.moving;
-  const int mylevel = M.level;
+  const int mylevel = M.level();
 
   BodyRegs B;
   kinematics<G, DM, LM>(m, L, l, M, B);
@@ -768,7 +780,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
     float r[NR][3], n[NR][3], phi[NR];
 #pragma unroll
     for (int k = 0; k < NR; k++) {
-      const float* pb = L.pose + P.body[k] * POSE_STRIDE;
+      const float* pb = L.pose + P.body(k) * POSE_STRIDE;
       float Rb[9], h;
 #pragma unroll
       for (int j = 0; j < 9; j++) Rb[j] = pb[j];
@@ -785,7 +797,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
       float on = 0.0f;
       if (i < DM::NPC) {
         float* o = L.pt + i * PT_STRIDE;
-        if (phi[k] < 0.0f) on = contact_point_response(K, L.pose + P.body[k] * POSE_STRIDE, r[k], n[k], P.rad[k], phi[k], o);
+        if (phi[k] < 0.0f) on = contact_point_response(K, L.pose + P.body(k) * POSE_STRIDE, r[k], n[k], P.rad[k], phi[k], o);
         o[0] = on;
       }
       // bit j = point k*G + j of this env is in contact
@@ -879,7 +891,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
   const int nl = DM::nlevels(m);
   for (int lev = nl; lev >= 1; lev--) {
     if (moving && mylevel == lev) {
-      const int d = M.dofi;
+      const int d = M.dofi();
 #pragma unroll
       for (int i = 0; i < 6; i++) {
         float acc = SYMG(B.IA, i, 0) * B.S[0];
@@ -959,7 +971,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
   for (int lev = 1; lev <= nl; lev++) {
     GROUP_SYNC();
     if (moving && mylevel == lev) {
-      const float* pa = L.acc + M.dynpar * 6;
+      const float* pa = L.acc + M.dynpar() * 6;
       float ap[6];
 #pragma unroll
       for (int i = 0; i < 6; i++) ap[i] = pa[i] + B.c[i];
@@ -967,7 +979,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
 #pragma unroll
       for (int j = 1; j < 6; j++) ua = fmaf(B.U[j], ap[j], ua);
       const float qdd = (B.u - ua) * B.invD;
-      L.dofb[M.dofi * DOF_STRIDE + 4] = qdd;
+      L.dofb[M.dofi() * DOF_STRIDE + 4] = qdd;
 #pragma unroll
       for (int i = 0; i < 6; i++) { a[i] = fmaf(B.S[i], qdd, ap[i]); L.acc[l * 6 + i] = a[i]; }
     }
@@ -982,7 +994,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
       constexpr int NR = (DM::NPC + G - 1) / G;
 #pragma unroll
       for (int k = 0; k < NR; k++) {
-        if ((active[k] >> l) & 1ull) contact_force_final(L.pt + (l + k * G) * PT_STRIDE, L.acc + m->dyn[P.body[k]] * 6, dt);
+        if ((active[k] >> l) & 1ull) contact_force_final(L.pt + (l + k * G) * PT_STRIDE, L.acc + m->dyn[P.body(k)] * 6, dt);
       }
       GROUP_SYNC();
       if (isbody) {

@@ -74,5 +74,5 @@ def test_register_budgets_of_the_fused_step():
     build.build_native()
     res = json.load(open(build.RESOURCES))
     build.check_budgets(res)
-    k = [v for n, v in res.items() if n.startswith("_Z9k_a1_stepILi32E9FixedDims")][0]
+    k = [v for n, v in res.items() if n.startswith("_Z16k_a1_step_a1_g32")][0]
     assert k["spill"] == 0 and k["vgprs"] <= 256
