@@ -1,0 +1,72 @@
+"""Simulator-state checkpoints and trajectory export for the fused envs.
+
+All simulation and task state lives in the tensors torch allocated and the library only binds
+(include/shifu_amd.h: shf_sim_bind / shf_a1_bind / shf_abb_bind), plus one host counter (the statistics
+ring index).  A checkpoint is therefore a copy of the mutable tensors; restoring it and replaying the same
+actions reproduces the run bit for bit (tests/test_gpu_env.py), which is what makes a parity failure
+debuggable after the fact.  `TrajectoryRecorder` dumps root / dof (and optionally rigid-body) states per step
+into one .npz a CPU viewer can replay -- the stand-in for the reference's `play` viewer
+(shifu/runner/policy_runner.py:23-32), which needs Isaac Gym's Vulkan renderer.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _abi
+
+_SIM_CONST = (_abi.T_HEIGHTS, _abi.T_MODEL, _abi.T_SCENE)        # replicated read-only data, rebuilt by the env
+
+
+def env_state_dict(env) -> Dict:
+    """Everything needed to continue `env` (FusedA1Env / FusedAbbEnv) from this step."""
+    sim = {k: v.detach().cpu().clone() for k, v in env.sim.tensors.items() if k not in _SIM_CONST}
+    task = {k: v.detach().cpu().clone() for k, v in env.task.tensors.items()}
+    return {"format": 1, "kind": type(env).__name__, "num_envs": env.num_envs,
+            "env_id_offset": getattr(env, "env_id_offset", 0), "step_index": env.task.step_index,
+            "common_step_counter": getattr(env, "common_step_counter", 0), "sim": sim, "task": task}
+
+
+def load_env_state_dict(env, sd: Dict) -> None:
+    if sd.get("format") != 1 or sd.get("kind") != type(env).__name__:
+        raise ValueError(f"checkpoint of a {sd.get('kind')} (format {sd.get('format')}) cannot restore a {type(env).__name__}")
+    if sd["num_envs"] != env.num_envs or sd["env_id_offset"] != getattr(env, "env_id_offset", 0):
+        raise ValueError("checkpoint was taken with a different env count / shard offset")
+    for name, src, dst in (("sim", sd["sim"], env.sim.tensors), ("task", sd["task"], env.task.tensors)):
+        for k, v in src.items():
+            if k not in dst or dst[k].shape != v.shape or dst[k].dtype != v.dtype:
+                raise ValueError(f"{name} tensor {k}: layout mismatch")
+            dst[k].copy_(v)
+    env.task.step_index = sd["step_index"]
+    if hasattr(env, "common_step_counter"):
+        env.common_step_counter = sd["common_step_counter"]
+
+
+class TrajectoryRecorder:
+    """Per-step root / dof (/ rigid-body) states of the first `num_envs` envs -> .npz.
+
+    Arrays: root (T, n, actors*13), dof (T, n, nd, 2), optional body (T, n, nb, 13), reset (T, n); metadata:
+    dt, body_names, dof_names."""
+
+    def __init__(self, env, num_envs: int = 16, bodies: bool = False):
+        self.env, self.n, self.bodies = env, min(num_envs, env.num_envs), bodies
+        self.root, self.dof, self.body, self.reset = [], [], [], []
+
+    def record(self):
+        e, n = self.env, self.n
+        self.root.append(e.root_state.reshape(e.num_envs, -1)[:n].cpu().numpy().copy())
+        self.dof.append(e.dof_state.reshape(e.num_envs, -1, 2)[:n].cpu().numpy().copy())
+        self.reset.append(e.reset_buf[:n].cpu().numpy().copy())
+        if self.bodies:
+            self.body.append(e.body_state.reshape(e.num_envs, -1, 13)[:n].cpu().numpy().copy())
+
+    def save(self, path: str):
+        cm = self.env.cm
+        out = dict(root=np.stack(self.root), dof=np.stack(self.dof), reset=np.stack(self.reset), dt=np.float32(self.env.dt),
+                   body_names=np.array(cm.body_names), dof_names=np.array(cm.dof_names))
+        if self.bodies:
+            out["body"] = np.stack(self.body)
+        np.savez_compressed(path, **out)
+        return path

@@ -951,7 +951,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
         for (int k = 0; k < 6; k++) B.pA[k] += o[21 + k];
       }
     }
-    GROUP_SYNC();
+    // no hand-off here: every exchange slot is written once per sub-step, by its owner, before the sync above
   }
 
   PHASE_MARK(6);

@@ -169,6 +169,15 @@ class FusedA1Env:
     def get_privileged_observations(self):
         return self.privileged_obs_buf
 
+    def state_dict(self):
+        """Checkpoint of the whole simulation + task state (shifu_amd/checkpoint.py)."""
+        from ..checkpoint import env_state_dict
+        return env_state_dict(self)
+
+    def load_state_dict(self, sd):
+        from ..checkpoint import load_env_state_dict
+        load_env_state_dict(self, sd)
+
     def destroy(self):
         self.task.destroy()
         self.sim.destroy()

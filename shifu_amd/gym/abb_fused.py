@@ -19,6 +19,7 @@ class FusedAbbEnv:
         self.device = torch.device(device)
         self.num_envs = num_envs
         self.env_id_offset = rank * num_envs
+        self.dt = dt * decimation                                         # isaac_gym.py:26
         self.cm = abb_model()
         self.sim_params = default_sim_params(dt=dt)
         self.sim = Sim(self.sim_params, self.device)
@@ -75,6 +76,15 @@ class FusedAbbEnv:
 
     def get_privileged_observations(self):
         return None
+
+    def state_dict(self):
+        """Checkpoint of the whole simulation + task state (shifu_amd/checkpoint.py)."""
+        from ..checkpoint import env_state_dict
+        return env_state_dict(self)
+
+    def load_state_dict(self, sd):
+        from ..checkpoint import load_env_state_dict
+        load_env_state_dict(self, sd)
 
     def destroy(self):
         self.task.destroy()

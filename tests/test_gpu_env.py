@@ -229,3 +229,50 @@ def test_ppo_trainer_runs_on_the_fused_env(tmp_path):
     other.load(str(tmp_path / "model_3.pt"))
     obs = env.get_observations()[:16].clone()
     torch.testing.assert_close(other.get_inference_policy()(obs), runner.get_inference_policy()(obs))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["a1", "abb"])
+def test_checkpoint_restore_replays_bit_exact(kind, tmp_path):
+    """state_dict -> (torch.save / load) -> load_state_dict, then the same actions give the same
+    run, including resets drawn after the checkpoint (the Philox counters are part of the state)."""
+    from shifu_amd.checkpoint import TrajectoryRecorder
+    if kind == "a1":
+        from shifu_amd.gym.a1_fused import FusedA1Env
+        env = FusedA1Env(num_envs=96, group=32, episode_length_s=0.6)
+    else:
+        from shifu_amd.gym.abb_fused import FusedAbbEnv
+        env = FusedAbbEnv(num_envs=96, episode_length_s=3.0)      # 30 steps: time-outs fall inside the replayed window
+    g = torch.Generator(device="cuda").manual_seed(3)
+    acts = [torch.rand(env.num_envs, env.num_actions, device="cuda", generator=g) * 2 - 1 for _ in range(60)]
+    env.reset()
+    for a in acts[:20]:
+        env.step(a)
+    path = tmp_path / "ckpt.pt"
+    torch.save(env.state_dict(), path)
+    rec = TrajectoryRecorder(env, num_envs=8, bodies=True)
+
+    def run():
+        out = []
+        for a in acts[20:]:
+            obs, _, rew, done, ex = env.step(a)
+            out.append((obs.clone(), rew.clone(), done.clone(), env.root_state.clone(), env.dof_state.clone()))
+        return out
+    first = run()
+    assert sum(int(o[2].sum()) for o in first) > 0          # resets happened after the checkpoint
+    env.load_state_dict(torch.load(path))
+    second = []
+    for a in acts[20:]:
+        obs, _, rew, done, ex = env.step(a)
+        rec.record()
+        second.append((obs.clone(), rew.clone(), done.clone(), env.root_state.clone(), env.dof_state.clone()))
+    for x, y in zip(first, second):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v)
+    z = np.load(rec.save(str(tmp_path / "traj.npz")))
+    assert z["root"].shape[:2] == (40, 8) and z["dof"].shape[:2] == (40, 8) and z["body"].shape[-1] == 13
+    assert len(z["body_names"]) <= z["body"].shape[2] and float(z["dt"]) > 0     # box actors follow the links
+    # a checkpoint of another shape is refused
+    other = type(env)(num_envs=32)
+    with pytest.raises(ValueError):
+        other.load_state_dict(torch.load(path))
