@@ -178,8 +178,8 @@ DEV void terrain_query(const TerrainDev& T, float x, float y, float* h, float* n
 // ------------------------------------------------------------- LDS views --
 // per-env LDS working set (float offsets); sizes follow the model actually
 // loaded so that four 256-thread blocks fit one CU (160 KiB LDS).
-#define POSE_STRIDE 18 /* Rw[9] p[3] v[6]                                   */
-#define XCH_STRIDE 27  /* Ia[21] pa[6]                                      */
+#define POSE_STRIDE 20 /* Rw[9] p[3] v[6], padded to 16 bytes                */
+#define XCH_STRIDE 28  /* Ia[21] pa[6], padded to 16 bytes                    */
 #define PT_STRIDE 12   /* on r[3] n[3] f[3] ct bn                           */
 #define DOF_STRIDE 6   /* q qd tau0 dex qdd tau_cmd                         */
 
@@ -200,16 +200,16 @@ __host__ __device__ inline int root_words(int nactors) { return (13 * nactors + 
 __host__ __device__ inline int env_lds_words(int nb, int nd, int np, int min_tail = 0, int nactors = 1) {
   int tail = np * PT_STRIDE;
   if (tail < min_tail) tail = min_tail;
-  int w = nb * POSE_STRIDE + nb * 6 + nb * XCH_STRIDE + nd * DOF_STRIDE + root_words(nactors) + tail;
+  int w = nb * POSE_STRIDE + ((nb * 6 + 3) & ~3) + nb * XCH_STRIDE + ((nd * DOF_STRIDE + 3) & ~3) + root_words(nactors) + tail;
   return (w + 3) & ~3;
 }
 DEV EnvLds env_lds_carve(float* base, int nb, int nd, int np, int nactors = 1) {
   EnvLds L;
   L.pose = base;
   L.acc = L.pose + nb * POSE_STRIDE;
-  L.xch = L.acc + nb * 6;
+  L.xch = L.acc + ((nb * 6 + 3) & ~3);
   L.dofb = L.xch + nb * XCH_STRIDE;
-  L.root = L.dofb + nd * DOF_STRIDE;
+  L.root = L.dofb + ((nd * DOF_STRIDE + 3) & ~3);
   L.pt = L.root + root_words(nactors);
   return L;
 }
