@@ -13,7 +13,7 @@
 
 DEV bool box_is_dynamic(const ShfBoxDesc& b) { return !b.fixed && b.mass > 0.0f; }
 
-// slot layout in LDS (PT_STRIDE floats): on r[3] n[3] f0[3] ct bn
+// slot layout in LDS (PT_STRIDE floats): r[3] n[3] f0[3] ct bn on (PT_* offsets, shf_device.h)
 DEV void slot_eval(float* o, float phi, const float* n, const float* r, const float* vp, float mu, float kc,
                    float beta, float veps, float vdep) {
   float on = 0.0f;
@@ -25,19 +25,19 @@ DEV void slot_eval(float* o, float phi, const float* n, const float* r, const fl
       const float vtn = sqrtf(dot3(vt, vt));
       const float ct = mu * fn / rmaxf(vtn, veps);
       on = 1.0f;
-      o[10] = ct;
-      o[11] = beta;
+      o[PT_CT] = ct;
+      o[PT_BN] = beta;
 #pragma unroll
-      for (int k = 0; k < 3; k++) { o[1 + k] = r[k]; o[4 + k] = n[k]; o[7 + k] = fmaf(fn, n[k], -(ct * vt[k])); }
+      for (int k = 0; k < 3; k++) { o[PT_R + k] = r[k]; o[PT_N + k] = n[k]; o[PT_F + k] = fmaf(fn, n[k], -(ct * vt[k])); }
     }
   }
-  o[0] = on;
+  o[PT_ON] = on;
 }
 
 DEV void slot_accumulate(float* IA, float* pA, const float* o, float sign, float dt, float scale) {
-  const float ss = sign * scale, oct = o[10] * scale, obn = o[11] * scale;
-  const float f0[3] = {ss * o[7], ss * o[8], ss * o[9]};
-  const float r[3] = {o[1], o[2], o[3]}, n[3] = {o[4], o[5], o[6]};
+  const float ss = sign * scale, oct = o[PT_CT] * scale, obn = o[PT_BN] * scale;
+  const float f0[3] = {ss * o[PT_F], ss * o[PT_F + 1], ss * o[PT_F + 2]};
+  const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]}, n[3] = {o[PT_N], o[PT_N + 1], o[PT_N + 2]};
   float t[3], wn[6];
   cross3(r, f0, t);
 #pragma unroll
@@ -64,8 +64,8 @@ DEV void slot_accumulate(float* IA, float* pA, const float* o, float sign, float
 }
 
 DEV void slot_force(const float* o, const float* ab, float sign, float dt, float scale, float* f) {
-  const float ss = sign * scale, oct = o[10] * scale, obn = o[11] * scale;
-  const float r[3] = {o[1], o[2], o[3]}, n[3] = {o[4], o[5], o[6]}, al[3] = {ab[0], ab[1], ab[2]};
+  const float ss = sign * scale, oct = o[PT_CT] * scale, obn = o[PT_BN] * scale;
+  const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]}, n[3] = {o[PT_N], o[PT_N + 1], o[PT_N + 2]}, al[3] = {ab[0], ab[1], ab[2]};
   float t[3], ap[3];
   cross3(al, r, t);
 #pragma unroll
@@ -74,11 +74,11 @@ DEV void slot_force(const float* o, const float* ab, float sign, float dt, float
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     const float Ba = fmaf(obn - oct, an * n[k], oct * ap[k]);
-    f[k] += fmaf(-dt, Ba, ss * o[7 + k]);
+    f[k] += fmaf(-dt, Ba, ss * o[PT_F + k]);
   }
 }
 
-DEV float pair_scale(const ShfBoxDesc& b, const float* o, float dt) { return b.mass / fmaf(dt, o[11], b.mass); }
+DEV float pair_scale(const ShfBoxDesc& b, const float* o, float dt) { return b.mass / fmaf(dt, o[PT_BN], b.mass); }
 
 DEV bool point_in_box(const float* bR, const float* bpos, const float* h, const float* r, float* phi, float* n) {
   const float rel[3] = {r[0] - bpos[0], r[1] - bpos[1], r[2] - bpos[2]};
@@ -189,7 +189,7 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
   for (int idx = l; idx < nbx * 8 * T; idx += G) {
     const int kd = idx / (8 * T), c = (idx / T) % 8, tg = idx % T;
     float* o = L.pt + corner_slot(m, nbx, kd, c, tg) * PT_STRIDE;
-    o[0] = 0.0f;
+    o[PT_ON] = 0.0f;
     const ShfBoxDesc& bd = S->box[kd];
     if (!box_is_dynamic(bd)) continue;
     const float* pk = L.pose + (nb + kd) * POSE_STRIDE;
@@ -224,7 +224,7 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
   for (int idx = l; idx < m->nsph * nbx; idx += G) {
     const int si = idx / nbx, kd = idx % nbx;
     float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
-    o[0] = 0.0f;
+    o[PT_ON] = 0.0f;
     const ShfBoxDesc& bd = S->box[kd];
     if (!box_is_dynamic(bd)) continue;
     const int b = m->sph_body[si];
@@ -253,7 +253,7 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
       if (m->dyn[m->sph_body[si]] != l) continue;
       for (int kd = 0; kd < nbx; kd++) {
         const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
-        if (o[0] != 0.0f) slot_accumulate(B.IA, B.pA, o, 1.0f, dt, pair_scale(S->box[kd], o, dt));
+        if (o[PT_ON] != 0.0f) slot_accumulate(B.IA, B.pA, o, 1.0f, dt, pair_scale(S->box[kd], o, dt));
       }
     }
   }
@@ -262,11 +262,11 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
     for (int c = 0; c < 8; c++)
       for (int tg = 0; tg < T; tg++) {
         const float* o = L.pt + corner_slot(m, nbx, kd, c, tg) * PT_STRIDE;
-        if (o[0] != 0.0f) slot_accumulate(B.IA, B.pA, o, 1.0f, dt, 1.0f);
+        if (o[PT_ON] != 0.0f) slot_accumulate(B.IA, B.pA, o, 1.0f, dt, 1.0f);
       }
     for (int si = 0; si < m->nsph; si++) {
       const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
-      if (o[0] != 0.0f) slot_accumulate(B.IA, B.pA, o, -1.0f, dt, 1.0f);
+      if (o[PT_ON] != 0.0f) slot_accumulate(B.IA, B.pA, o, -1.0f, dt, 1.0f);
     }
   }
 }
@@ -293,7 +293,7 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
         if (m->sph_body[si] != l) continue;
         for (int k2 = 0; k2 < nbx; k2++) {
           const float* o = L.pt + sphere_slot(m, nbx, si, k2) * PT_STRIDE;
-          if (o[0] != 0.0f) slot_force(o, abr, 1.0f, dt, pair_scale(S->box[k2], o, dt), f);
+          if (o[PT_ON] != 0.0f) slot_force(o, abr, 1.0f, dt, pair_scale(S->box[k2], o, dt), f);
         }
       }
       contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];
@@ -304,11 +304,11 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
         for (int c = 0; c < 8; c++)
           for (int tg = 0; tg < T; tg++) {
             const float* o = L.pt + corner_slot(m, nbx, kd, c, tg) * PT_STRIDE;
-            if (o[0] != 0.0f) slot_force(o, a, 1.0f, dt, 1.0f, f);
+            if (o[PT_ON] != 0.0f) slot_force(o, a, 1.0f, dt, 1.0f, f);
           }
         for (int si = 0; si < m->nsph; si++) {
           const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
-          if (o[0] != 0.0f) slot_force(o, a, -1.0f, dt, 1.0f, f);
+          if (o[PT_ON] != 0.0f) slot_force(o, a, -1.0f, dt, 1.0f, f);
         }
       }
       contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];

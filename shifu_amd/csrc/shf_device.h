@@ -180,7 +180,13 @@ DEV void terrain_query(const TerrainDev& T, float x, float y, float* h, float* n
 // loaded so that four 256-thread blocks fit one CU (160 KiB LDS).
 #define POSE_STRIDE 20 /* Rw[9] p[3] v[6], padded to 16 bytes                */
 #define XCH_STRIDE 28  /* Ia[21] pa[6], padded to 16 bytes                    */
-#define PT_STRIDE 12   /* on r[3] n[3] f[3] ct bn                           */
+#define PT_STRIDE 12   /* r[3] n[3] f[3] ct bn on: 11 contiguous floats from a 16-byte boundary, flag last */
+#define PT_R 0
+#define PT_N 3
+#define PT_F 6
+#define PT_CT 9
+#define PT_BN 10
+#define PT_ON 11
 #define DOF_STRIDE 6   /* q qd tau0 dex qdd tau_cmd                         */
 
 struct EnvLds {
@@ -660,13 +666,13 @@ DEV float contact_point_response(const ContactConsts& K, const float* pb, float*
     const float vtn = sqrtf(dot3(vt, vt));
     const float ct = K.mu * fn / rmaxf(vtn, K.veps);
     on = 1.0f;
-    o[10] = ct;
-    o[11] = K.beta;
+    o[PT_CT] = ct;
+    o[PT_BN] = K.beta;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      o[1 + k] = r[k];
-      o[4 + k] = n[k];
-      o[7 + k] = fmaf(fn, n[k], -(ct * vt[k]));
+      o[PT_R + k] = r[k];
+      o[PT_N + k] = n[k];
+      o[PT_F + k] = fmaf(fn, n[k], -(ct * vt[k]));
     }
   }
   return on;
@@ -675,7 +681,7 @@ DEV float contact_point_response(const ContactConsts& K, const float* pb, float*
 // Fold one active contact slot into its body's bias force and articulated inertia:
 // pA -= [r x f0; f0],  IA += dt * (c_t * PointMass(r) + (beta - c_t) * w w^T),  w = [r x n; n].
 DEV void contact_accumulate(const float* o, float dt, BodyRegs& B) {
-  const float r[3] = {o[1], o[2], o[3]}, n[3] = {o[4], o[5], o[6]}, f0[3] = {o[7], o[8], o[9]};
+  const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]}, n[3] = {o[PT_N], o[PT_N + 1], o[PT_N + 2]}, f0[3] = {o[PT_F], o[PT_F + 1], o[PT_F + 2]};
   float t[3], wn[6];
   cross3(r, f0, t);
 #pragma unroll
@@ -683,7 +689,7 @@ DEV void contact_accumulate(const float* o, float dt, BodyRegs& B) {
   cross3(r, n, t);
 #pragma unroll
   for (int k = 0; k < 3; k++) { wn[k] = t[k]; wn[3 + k] = n[k]; }
-  const float a = dt * o[10], bb = dt * (o[11] - o[10]);
+  const float a = dt * o[PT_CT], bb = dt * (o[PT_BN] - o[PT_CT]);
   const float r2 = dot3(r, r);
 #pragma unroll
   for (int i2 = 0; i2 < 3; i2++)
@@ -704,17 +710,17 @@ DEV void contact_accumulate(const float* o, float dt, BodyRegs& B) {
 
 // End-of-step force of an active slot: f = f0 - dt * B * a_point with the body's solved acceleration `ab`.
 DEV void contact_force_final(float* o, const float* ab, float dt) {
-  const float r[3] = {o[1], o[2], o[3]}, n[3] = {o[4], o[5], o[6]};
+  const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]}, n[3] = {o[PT_N], o[PT_N + 1], o[PT_N + 2]};
   float al[3] = {ab[0], ab[1], ab[2]}, t[3], ap[3];
   cross3(al, r, t);
 #pragma unroll
   for (int k = 0; k < 3; k++) ap[k] = ab[3 + k] + t[k];
   const float an = dot3(n, ap);
-  const float ct = o[10], bn = o[11];
+  const float ct = o[PT_CT], bn = o[PT_BN];
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     const float Ba = fmaf(bn - ct, an * n[k], ct * ap[k]);
-    o[7 + k] = fmaf(-dt, Ba, o[7 + k]);
+    o[PT_F + k] = fmaf(-dt, Ba, o[PT_F + k]);
   }
 }
 
@@ -798,7 +804,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
       if (i < DM::NPC) {
         float* o = L.pt + i * PT_STRIDE;
         if (phi[k] < 0.0f) on = contact_point_response(K, L.pose + P.body(k) * POSE_STRIDE, r[k], n[k], P.rad[k], phi[k], o);
-        o[0] = on;
+        o[PT_ON] = on;
       }
       // bit j = point k*G + j of this env is in contact
       active[k] = (__ballot(on != 0.0f) >> lane0) & (G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull));
@@ -819,7 +825,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
       float* o = L.pt + i * PT_STRIDE;
       float on = 0.0f;
       if (phi < 0.0f) on = contact_point_response(K, pb, r, n, rad, phi, o);
-      o[0] = on;
+      o[PT_ON] = on;
     }
   }
   GROUP_SYNC();
@@ -845,7 +851,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
       const int i0 = M.pt0, i1 = i0 + M.npt;
       for (int i = i0; i < i1; i++) {
         const float* o = L.pt + i * PT_STRIDE;
-        if (o[0] == 0.0f) continue;
+        if (o[PT_ON] == 0.0f) continue;
         contact_accumulate(o, dt, B);
       }
     }
@@ -1010,7 +1016,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
             bits &= bits - 1ull;
             if (m->pt_body[i] != l) continue;
             const float* o = L.pt + i * PT_STRIDE;
-            f[0] += o[7]; f[1] += o[8]; f[2] += o[9];
+            f[0] += o[PT_F]; f[1] += o[PT_F + 1]; f[2] += o[PT_F + 2];
           }
         }
         contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];
@@ -1018,7 +1024,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
     } else {
       for (int i = l; i < np; i += G) {
         float* o = L.pt + i * PT_STRIDE;
-        if (o[0] == 0.0f) continue;
+        if (o[PT_ON] == 0.0f) continue;
         contact_force_final(o, L.acc + m->dyn[m->pt_body[i]] * 6, dt);
       }
       GROUP_SYNC();
@@ -1028,8 +1034,8 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
         const int i0 = m->pt_start[dl], i1 = i0 + m->pt_count[dl];
         for (int i = i0; i < i1; i++) {
           const float* o = L.pt + i * PT_STRIDE;
-          if (o[0] == 0.0f || m->pt_body[i] != l) continue;
-          f[0] += o[7]; f[1] += o[8]; f[2] += o[9];
+          if (o[PT_ON] == 0.0f || m->pt_body[i] != l) continue;
+          f[0] += o[PT_F]; f[1] += o[PT_F + 1]; f[2] += o[PT_F + 2];
         }
         contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];
       }
