@@ -6,7 +6,6 @@ keys "policy", "algorithm", "runner".  The env is any rsl_rl-style VecEnv (Shifu
 """
 import json
 import os
-import statistics
 import time
 from collections import deque
 
@@ -58,9 +57,13 @@ class OnPolicyRunner:
         alg.actor_critic.train()
 
         ep_infos = []
-        rewbuffer, lenbuffer = deque(maxlen=100), deque(maxlen=100)
+        # Episode statistics stay on the device during the rollout (no nonzero()/cpu() per step: a host sync
+        # per env step would expose every launch latency of the policy's small kernels); one read per iteration.
+        # The printed means cover the most recent >= 100 finished episodes, like the deque of the original runner.
+        rewbuffer, lenbuffer = deque(maxlen=100), deque(maxlen=100)     # entries: (sum, count) per iteration
         cur_reward_sum = torch.zeros(env.num_envs, dtype=torch.float, device=dev)
         cur_episode_length = torch.zeros(env.num_envs, dtype=torch.float, device=dev)
+        fin = torch.zeros(3, dtype=torch.float64, device=dev)           # return sum, length sum, count
 
         first, last = self.current_learning_iteration, self.current_learning_iteration + num_learning_iterations
         for it in range(first, last):
@@ -80,11 +83,12 @@ class OnPolicyRunner:
                             ep_infos.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in infos["episode"].items()})
                         cur_reward_sum += rewards
                         cur_episode_length += 1
-                        new_ids = (dones > 0).nonzero(as_tuple=False)
-                        rewbuffer.extend(cur_reward_sum[new_ids][:, 0].cpu().numpy().tolist())
-                        lenbuffer.extend(cur_episode_length[new_ids][:, 0].cpu().numpy().tolist())
-                        cur_reward_sum[new_ids] = 0
-                        cur_episode_length[new_ids] = 0
+                        d = (dones > 0).to(torch.float32)
+                        fin[0] += (cur_reward_sum * d).sum()
+                        fin[1] += (cur_episode_length * d).sum()
+                        fin[2] += d.sum()
+                        cur_reward_sum *= 1.0 - d
+                        cur_episode_length *= 1.0 - d
                 stop = time.time()
                 collection_time = stop - start
                 start = stop
@@ -92,6 +96,11 @@ class OnPolicyRunner:
             mean_value_loss, mean_surrogate_loss = alg.update()
             learn_time = time.time() - start
             if self.log_dir is not None:
+                rs, ls, cnt = fin.tolist()
+                fin.zero_()
+                if cnt > 0:
+                    rewbuffer.append((rs, cnt))
+                    lenbuffer.append((ls, cnt))
                 self.log(locals())
             if it % self.save_interval == 0 and self.log_dir is not None and rank() == 0:
                 self.save(os.path.join(self.log_dir, f"model_{it}.pt"))
@@ -116,8 +125,8 @@ class OnPolicyRunner:
                 vals = [torch.as_tensor(e[key], dtype=torch.float32, device=self.device).reshape(-1) for e in locs["ep_infos"]]
                 rec["episode/" + key] = float(torch.cat(vals).mean())
         if len(locs["rewbuffer"]) > 0:
-            rec["mean_reward"] = statistics.mean(locs["rewbuffer"])
-            rec["mean_episode_length"] = statistics.mean(locs["lenbuffer"])
+            rec["mean_reward"] = self._recent_mean(locs["rewbuffer"])
+            rec["mean_episode_length"] = self._recent_mean(locs["lenbuffer"])
         self.history.append(rec)
         if rank() != 0:
             return
@@ -136,6 +145,16 @@ class OnPolicyRunner:
                  ("Total time:", f"{self.tot_time:.2f}s")]
         lines += [f"{k:>{pad}} {v}" for k, v in show]
         print("\n".join(lines))
+
+    @staticmethod
+    def _recent_mean(buf, at_least=100):
+        """Mean over the newest iterations that together hold >= `at_least` finished episodes."""
+        s = c = 0.0
+        for rs, cnt in reversed(buf):
+            s, c = s + rs, c + cnt
+            if c >= at_least:
+                break
+        return s / c
 
     # ------------------------------------------------------------ checkpoints
     def save(self, path, infos=None):

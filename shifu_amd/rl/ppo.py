@@ -93,7 +93,7 @@ class PPO:
             g["lr"] = self.learning_rate
 
     def update(self):
-        mean_value_loss = mean_surrogate_loss = 0.0
+        sums = torch.zeros(2, device=self.device)       # value / surrogate loss sums stay on the device
         ac = self.actor_critic
         for (obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, _h, _m) in \
                 self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
@@ -107,8 +107,9 @@ class PPO:
                 average_gradients(ac.parameters())
             nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
             self.optimizer.step()
-            mean_value_loss += L["value"].item()
-            mean_surrogate_loss += L["surrogate"].item()
+            sums[0] += L["value"].detach()
+            sums[1] += L["surrogate"].detach()
         n = self.num_learning_epochs * self.num_mini_batches
         self.storage.clear()
-        return mean_value_loss / n, mean_surrogate_loss / n
+        mean_value_loss, mean_surrogate_loss = (sums / n).tolist()
+        return mean_value_loss, mean_surrogate_loss
