@@ -138,10 +138,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the backend has no CPU fallback")
+    # one rank per GPU; SHIFU_AMD_DIST_BACKEND=gloo (testing only) lets several ranks share a GPU to exercise the
+    # N>1 control flow on a single-GPU box -- RCCL itself refuses two ranks on one device
+    backend = os.environ.get("SHIFU_AMD_DIST_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from shifu_amd import _abi
     from shifu_amd.gym.a1_fused import FusedA1Env
