@@ -8,6 +8,9 @@
 #include <cstdio>
 #include <cstring>
 #include <initializer_list>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <string>
 
 #include "shf_device.h"
@@ -999,8 +1002,22 @@ static SimArgs sim_args(const ShfSim* s, bool internal) {
 template <typename K, typename... Args>
 static int launch(K kernel, dim3 grid, dim3 block, size_t lds, void* stream, Args... args) {
   if (lds > 160 * 1024) return fail("kernel needs " + std::to_string(lds) + " B of LDS per block, the CU has 160 KiB");
-  if (lds > 48 * 1024)  // above the default dynamic-LDS limit the kernel has to opt in
-    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (lds > 48 * 1024) {
+    // above the default dynamic-LDS limit the kernel has to opt in -- once per (device, kernel, size): the
+    // attribute call is not a stream operation and must not recur while the caller's stream is being captured
+    // into a hipGraph (shifu_amd/rl captures whole rollouts)
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> granted;
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = granted[{dev, fn}];
+    if (have < lds) {
+      HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      have = lds;
+    }
+  }
   hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)stream, args...);
   HIP_OK(hipGetLastError());
   return 0;

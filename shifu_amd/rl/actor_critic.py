@@ -59,7 +59,10 @@ class ActorCritic(nn.Module):
 
     def act(self, observations, **kwargs):
         self.update_distribution(observations)
-        return self.distribution.sample()
+        # mean + std * N(0, 1): the same draw as distribution.sample(), but torch.normal(tensor, tensor) cannot be
+        # captured into a hipGraph on this ROCm build and randn_like can
+        with torch.no_grad():
+            return self.distribution.mean + self.distribution.stddev * torch.randn_like(self.distribution.mean)
 
     def get_actions_log_prob(self, actions):
         return self.distribution.log_prob(actions).sum(dim=-1)

@@ -56,39 +56,41 @@ class OnPolicyRunner:
         obs, critic_obs = obs.to(dev), critic_obs.to(dev)
         alg.actor_critic.train()
 
-        ep_infos = []
         # Episode statistics stay on the device during the rollout (no nonzero()/cpu() per step: a host sync
         # per env step would expose every launch latency of the policy's small kernels); one read per iteration.
         # The printed means cover the most recent >= 100 finished episodes, like the deque of the original runner.
         rewbuffer, lenbuffer = deque(maxlen=100), deque(maxlen=100)     # entries: (sum, count) per iteration
-        cur_reward_sum = torch.zeros(env.num_envs, dtype=torch.float, device=dev)
-        cur_episode_length = torch.zeros(env.num_envs, dtype=torch.float, device=dev)
-        fin = torch.zeros(3, dtype=torch.float64, device=dev)           # return sum, length sum, count
+        R = {"ep_infos": [], "cur_reward_sum": torch.zeros(env.num_envs, dtype=torch.float, device=dev),
+             "cur_episode_length": torch.zeros(env.num_envs, dtype=torch.float, device=dev),
+             "fin": torch.zeros(3, dtype=torch.float64, device=dev)}     # return sum, length sum, count
+        fin = R["fin"]
+        graph = None
+        use_graph = bool(self.cfg.get("graph_rollout", False)) and torch.device(dev).type == "cuda"
 
         first, last = self.current_learning_iteration, self.current_learning_iteration + num_learning_iterations
         for it in range(first, last):
             start = time.time()
             with torch.inference_mode():
-                for _ in range(self.num_steps_per_env):
-                    # the env rewrites its observation buffer in place: the rollout keeps a copy
-                    obs_in = obs.clone()
-                    cobs_in = obs_in if critic_obs.data_ptr() == obs.data_ptr() else critic_obs.clone()
-                    actions = alg.act(obs_in, cobs_in)
-                    obs, priv, rewards, dones, infos = env.step(actions)
-                    critic_obs = priv if priv is not None else obs
-                    obs, critic_obs, rewards, dones = obs.to(dev), critic_obs.to(dev), rewards.to(dev), dones.to(dev)
-                    alg.process_env_step(rewards, dones, infos)
-                    if self.log_dir is not None:
-                        if "episode" in infos:
-                            ep_infos.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in infos["episode"].items()})
-                        cur_reward_sum += rewards
-                        cur_episode_length += 1
-                        d = (dones > 0).to(torch.float32)
-                        fin[0] += (cur_reward_sum * d).sum()
-                        fin[1] += (cur_episode_length * d).sum()
-                        fin[2] += d.sum()
-                        cur_reward_sum *= 1.0 - d
-                        cur_episode_length *= 1.0 - d
+                if use_graph and graph is None and it > first:
+                    # the first iteration ran eagerly (warm-up: lazy inits, LDS opt-ins); capture the second and
+                    # replay it from then on.  Everything in the rollout writes static buffers (rollout storage, env
+                    # tensors, the accumulators in R), so one hipGraph of T x (policy + env step) replaces ~2000 launches.
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    R["ep_infos"].clear()
+                    alg.storage.clear()
+                    with torch.cuda.graph(graph):
+                        self._rollout(R)
+                    alg.storage.clear()
+                if graph is not None:
+                    graph.replay()
+                else:
+                    R["ep_infos"].clear()
+                    self._rollout(R)
+                ep_infos = R["ep_infos"]
+                obs = env.get_observations()
+                priv = env.get_privileged_observations()
+                critic_obs = (priv if priv is not None else obs).to(dev)
                 stop = time.time()
                 collection_time = stop - start
                 start = stop
@@ -104,10 +106,34 @@ class OnPolicyRunner:
                 self.log(locals())
             if it % self.save_interval == 0 and self.log_dir is not None and rank() == 0:
                 self.save(os.path.join(self.log_dir, f"model_{it}.pt"))
-            ep_infos.clear()
         self.current_learning_iteration += num_learning_iterations
         if self.log_dir is not None and rank() == 0:
             self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
+
+    def _rollout(self, R):
+        """num_steps_per_env x (policy, env.step, bookkeeping).  Sync-free and shape-static, so it can be captured."""
+        env, alg, dev = self.env, self.alg, self.device
+        for _ in range(self.num_steps_per_env):
+            obs = env.get_observations().to(dev)
+            priv = env.get_privileged_observations()
+            # the env rewrites its observation buffer in place: the rollout keeps a copy
+            obs_in = obs.clone()
+            cobs_in = obs_in if priv is None else priv.to(dev).clone()
+            actions = alg.act(obs_in, cobs_in)
+            _, _, rewards, dones, infos = env.step(actions)
+            rewards, dones = rewards.to(dev), dones.to(dev)
+            alg.process_env_step(rewards, dones, infos)
+            if self.log_dir is not None:
+                if "episode" in infos:
+                    R["ep_infos"].append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in infos["episode"].items()})
+                R["cur_reward_sum"] += rewards
+                R["cur_episode_length"] += 1
+                d = (dones > 0).to(torch.float32)
+                R["fin"][0] += (R["cur_reward_sum"] * d).sum()
+                R["fin"][1] += (R["cur_episode_length"] * d).sum()
+                R["fin"][2] += d.sum()
+                R["cur_reward_sum"] *= 1.0 - d
+                R["cur_episode_length"] *= 1.0 - d
 
     # -------------------------------------------------------------------- log
     def log(self, locs, width=80, pad=35):

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--hook", action="store_true")
     ap.add_argument("--log", default=None)
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="capture the rollout in one hipGraph (runner.graph_rollout)")
     args = ap.parse_args()
     import torch.distributed as dist
     world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
@@ -35,6 +36,7 @@ def main():
     from shifu_amd.rl import OnPolicyRunner
     from shifu_amd.runner.utils import class_to_dict, set_seed
     cfg = class_to_dict(A1PPOConfig())
+    cfg["runner"]["graph_rollout"] = args.graph
     set_seed(A1PPOConfig.seed + rank)
     if args.hook:
         from examples.a1_conditional.a1_conditional import A1Conditional
