@@ -62,7 +62,7 @@ class FusedA1Env:
 
     def __init__(self, num_envs: int = 4096, device="cuda:0", terrain: str = "heightfield", seed: int = 42,
                  rank: int = 0, world_size: int = 1, terrain_cfg=None, sim_params: Optional[_abi.ShfSimParams] = None,
-                 group: int = 64, episode_length_s: float = 10.0, dt: float = 0.005, decimation: int = 4,
+                 group: int = 32, episode_length_s: float = 10.0, dt: float = 0.005, decimation: int = 4,
                  terrain_seed: int = 42, send_timeouts: bool = True, extra_substep: bool = True):
         self.device = torch.device(device)
         self.num_envs = num_envs

@@ -5,6 +5,8 @@ import torch
 import torch.nn as nn
 from torch.distributions import Normal
 
+from .linear import SplitKLinear
+
 _ACTIVATIONS = {"elu": nn.ELU, "selu": nn.SELU, "relu": nn.ReLU, "lrelu": nn.LeakyReLU, "tanh": nn.Tanh,
                 "sigmoid": nn.Sigmoid}
 
@@ -14,9 +16,9 @@ def _mlp(n_in: int, hidden: Sequence[int], n_out: int, act: str) -> nn.Sequentia
         raise ValueError(f"unknown activation '{act}' (one of {sorted(_ACTIVATIONS)})")
     layers, last = [], n_in
     for h in hidden:
-        layers += [nn.Linear(last, h), _ACTIVATIONS[act]()]
+        layers += [SplitKLinear(last, h), _ACTIVATIONS[act]()]
         last = h
-    layers.append(nn.Linear(last, n_out))
+    layers.append(SplitKLinear(last, n_out))
     return nn.Sequential(*layers)
 
 

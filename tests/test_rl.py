@@ -170,3 +170,22 @@ def test_gradient_averaging_two_ranks(tmp_path):
     (((net.actor(x) - y) ** 2).mean() + net.critic(x).square().mean() + net.std.square().sum()).backward()
     for p, g in zip(net.parameters(), r0["grads"]):
         torch.testing.assert_close(p.grad, g, rtol=1e-5, atol=1e-6)
+
+
+def test_split_k_linear_matches_nn_linear():
+    """The weight-gradient re-association (shifu_amd/rl/linear.py) against plain nn.Linear."""
+    from shifu_amd.rl.linear import SplitKLinear
+    torch.manual_seed(3)
+    a, b = torch.nn.Linear(37, 19), SplitKLinear(37, 19)
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(8192, 37, requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    g = torch.randn(8192, 19)
+    (a(x) * g).sum().backward()
+    (b(x2) * g).sum().backward()
+    torch.testing.assert_close(b(x2), a(x), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(x2.grad, x.grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(b.weight.grad, a.weight.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(b.bias.grad, a.bias.grad, rtol=1e-4, atol=1e-4)
+    # small batches take the stock path
+    assert torch.equal(b(x2[:64]), torch.nn.functional.linear(x2[:64], b.weight, b.bias))
