@@ -76,3 +76,40 @@ def test_register_budgets_of_the_fused_step():
     build.check_budgets(res)
     k = [v for n, v in res.items() if n.startswith("_Z16k_a1_step_a1_g32")][0]
     assert k["spill"] == 0 and k["vgprs"] <= 256
+
+
+def test_empty_and_oversize_inputs_are_refused_on_the_host(libpath):
+    """Edge cases of the boundary that need no GPU: zero envs, a model beyond SHF_MAX_*, a model wider than the
+    lane group, a fifth box actor, a bad lane-group size, layouts before finalize."""
+    import copy
+    from shifu_amd import _abi, _lib
+    from shifu_amd.backend import default_sim_params
+    from shifu_amd.model import asset_path, compile_urdf
+    l = _lib.lib()
+    cm = compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT)
+    h = ctypes.c_void_p()
+    sp = default_sim_params()
+    assert l.shf_sim_create(ctypes.byref(sp), ctypes.byref(h)) == 0
+    shape, nd, dt = (ctypes.c_int64 * 4)(), ctypes.c_int32(), ctypes.c_int32()
+    assert l.shf_sim_layout(h, _abi.T_DOF_STATE, shape, ctypes.byref(nd), ctypes.byref(dt)) != 0
+    assert b"finalized" in l.shf_last_error()
+    big = copy.deepcopy(cm.blob)
+    big.nb = 33
+    assert l.shf_sim_set_articulation(h, ctypes.byref(big)) != 0 and b"SHF_MAX" in l.shf_last_error()
+    big.nb, big.np = cm.blob.nb, 97
+    assert l.shf_sim_set_articulation(h, ctypes.byref(big)) != 0
+    assert l.shf_sim_set_articulation(h, ctypes.byref(cm.blob)) == 0
+    assert l.shf_sim_finalize(h, 0, 0) != 0 and b"num_envs" in l.shf_last_error()
+    assert l.shf_sim_finalize(h, -3, 0) != 0
+    assert l.shf_sim_set_group(h, 48) != 0 and b"16, 32 or 64" in l.shf_last_error()
+    assert l.shf_sim_set_group(h, 16) != 0 and b"does not fit" in l.shf_last_error()     # 17 bodies > 16 lanes
+    assert l.shf_sim_set_group(h, 32) == 0
+    box = _abi.ShfBoxDesc()
+    box.dim[0] = box.dim[1] = box.dim[2] = 0.1
+    for _ in range(4):
+        assert l.shf_sim_add_box(h, ctypes.byref(box)) == 0
+    assert l.shf_sim_add_box(h, ctypes.byref(box)) != 0 and b"too many boxes" in l.shf_last_error()
+    assert l.shf_sim_finalize(h, 1, 0) == 0                                            # the smallest legal env count
+    assert l.shf_sim_layout(h, _abi.T_DOF_STATE, shape, ctypes.byref(nd), ctypes.byref(dt)) == 0
+    assert tuple(shape[:nd.value]) == (12, 2)
+    l.shf_sim_destroy(h)
