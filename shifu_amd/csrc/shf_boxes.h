@@ -139,6 +139,48 @@ DEV int corner_slot(const ShfModel* m, int nbx, int kd, int c, int tg) { return 
 DEV int sphere_slot(const ShfModel* m, int nbx, int si, int kd) { return m->np + nbx * 8 * (1 + nbx) + si * nbx + kd; }
 __host__ __device__ inline int box_slot_count(int nbx, int nsph) { return nbx * 8 * (1 + nbx) + nsph * nbx; }
 
+// `in contact` flags of a lane's slots as bit masks, read in one batch: the folds below then visit only the active
+// slots, in the same order as the plain nested loops (ascending bit index = loop order), instead of paying one
+// LDS round trip per slot to find out that almost all of them are idle.
+#define BOX_T (SHF_MAX_BOXES + 1)
+DEV unsigned long long corner_flags(const ShfModel* m, const EnvLds& L, int nbx, int kd) {   // bit c * BOX_T + tg
+  unsigned long long bits = 0ull;
+#pragma unroll
+  for (int c = 0; c < 8; c++)
+#pragma unroll
+    for (int tg = 0; tg < BOX_T; tg++) {
+      const bool ok = tg <= nbx;
+      const float f = L.pt[corner_slot(m, nbx, kd, c, ok ? tg : 0) * PT_STRIDE + PT_ON];
+      if (ok && f != 0.0f) bits |= 1ull << (c * BOX_T + tg);
+    }
+  return bits;
+}
+DEV unsigned box_sphere_flags(const ShfModel* m, const EnvLds& L, int nbx, int kd) {   // bit si
+  unsigned bits = 0u;
+#pragma unroll
+  for (int si = 0; si < SHF_MAX_SPHERES; si++) {
+    const bool ok = si < m->nsph;
+    const float f = L.pt[sphere_slot(m, nbx, ok ? si : 0, kd) * PT_STRIDE + PT_ON];
+    if (ok && f != 0.0f) bits |= 1u << si;
+  }
+  return bits;
+}
+// spheres of the articulation: bit si * SHF_MAX_BOXES + kd, restricted to spheres with owner[si] == l
+DEV unsigned body_sphere_flags(const ShfModel* m, const EnvLds& L, int nbx, int l, bool by_dyn) {
+  unsigned bits = 0u;
+#pragma unroll
+  for (int si = 0; si < SHF_MAX_SPHERES; si++) {
+    const bool mine = si < m->nsph && (by_dyn ? m->dyn[m->sph_body[si]] : m->sph_body[si]) == l;
+#pragma unroll
+    for (int kd = 0; kd < SHF_MAX_BOXES; kd++) {
+      const bool ok = mine && kd < nbx;
+      const float f = L.pt[sphere_slot(m, nbx, ok ? si : 0, ok ? kd : 0) * PT_STRIDE + PT_ON];
+      if (ok && f != 0.0f) bits |= 1u << (si * SHF_MAX_BOXES + kd);
+    }
+  }
+  return bits;
+}
+
 // Box lanes: pose / spatial velocity about O from the root-state rows, inertia of the free ones.
 template <int G>
 DEV void boxes_pose(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B) {
@@ -249,24 +291,27 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
   GROUP_SYNC();
   // fold
   if (l < nb && m->dyn[l] == l) {
-    for (int si = 0; si < m->nsph; si++) {
-      if (m->dyn[m->sph_body[si]] != l) continue;
-      for (int kd = 0; kd < nbx; kd++) {
-        const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
-        if (o[PT_ON] != 0.0f) slot_accumulate(B.IA, B.pA, o, 1.0f, dt, pair_scale(S->box[kd], o, dt));
-      }
+    unsigned bits = body_sphere_flags(m, L, nbx, l, true);
+    while (bits) {
+      const int j = __builtin_ctz(bits), si = j / SHF_MAX_BOXES, kd = j % SHF_MAX_BOXES;
+      bits &= bits - 1u;
+      const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
+      slot_accumulate(B.IA, B.pA, o, 1.0f, dt, pair_scale(S->box[kd], o, dt));
     }
   }
   const int kd = l - nb;
   if (kd >= 0 && kd < nbx && box_is_dynamic(S->box[kd])) {
-    for (int c = 0; c < 8; c++)
-      for (int tg = 0; tg < T; tg++) {
-        const float* o = L.pt + corner_slot(m, nbx, kd, c, tg) * PT_STRIDE;
-        if (o[PT_ON] != 0.0f) slot_accumulate(B.IA, B.pA, o, 1.0f, dt, 1.0f);
-      }
-    for (int si = 0; si < m->nsph; si++) {
-      const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
-      if (o[PT_ON] != 0.0f) slot_accumulate(B.IA, B.pA, o, -1.0f, dt, 1.0f);
+    unsigned long long cb = corner_flags(m, L, nbx, kd);
+    unsigned sb = box_sphere_flags(m, L, nbx, kd);
+    while (cb) {
+      const int j = __builtin_ctzll(cb);
+      cb &= cb - 1ull;
+      slot_accumulate(B.IA, B.pA, L.pt + corner_slot(m, nbx, kd, j / BOX_T, j % BOX_T) * PT_STRIDE, 1.0f, dt, 1.0f);
+    }
+    while (sb) {
+      const int si = __builtin_ctz(sb);
+      sb &= sb - 1u;
+      slot_accumulate(B.IA, B.pA, L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, -1.0f, dt, 1.0f);
     }
   }
 }
@@ -289,26 +334,29 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
       float f[3] = {contact_out[3 * l], contact_out[3 * l + 1], contact_out[3 * l + 2]};
       const float* ab = L.acc + m->dyn[l] * 6;
       const float abr[6] = {ab[0], ab[1], ab[2], ab[3], ab[4], ab[5]};
-      for (int si = 0; si < m->nsph; si++) {
-        if (m->sph_body[si] != l) continue;
-        for (int k2 = 0; k2 < nbx; k2++) {
-          const float* o = L.pt + sphere_slot(m, nbx, si, k2) * PT_STRIDE;
-          if (o[PT_ON] != 0.0f) slot_force(o, abr, 1.0f, dt, pair_scale(S->box[k2], o, dt), f);
-        }
+      unsigned bits = body_sphere_flags(m, L, nbx, l, false);
+      while (bits) {
+        const int j = __builtin_ctz(bits), si = j / SHF_MAX_BOXES, k2 = j % SHF_MAX_BOXES;
+        bits &= bits - 1u;
+        const float* o = L.pt + sphere_slot(m, nbx, si, k2) * PT_STRIDE;
+        slot_force(o, abr, 1.0f, dt, pair_scale(S->box[k2], o, dt), f);
       }
       contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];
     }
     if (isbox) {
       float f[3] = {0.0f, 0.0f, 0.0f};
       if (dynbox) {
-        for (int c = 0; c < 8; c++)
-          for (int tg = 0; tg < T; tg++) {
-            const float* o = L.pt + corner_slot(m, nbx, kd, c, tg) * PT_STRIDE;
-            if (o[PT_ON] != 0.0f) slot_force(o, a, 1.0f, dt, 1.0f, f);
-          }
-        for (int si = 0; si < m->nsph; si++) {
-          const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
-          if (o[PT_ON] != 0.0f) slot_force(o, a, -1.0f, dt, 1.0f, f);
+        unsigned long long cb = corner_flags(m, L, nbx, kd);
+        unsigned sb = box_sphere_flags(m, L, nbx, kd);
+        while (cb) {
+          const int j = __builtin_ctzll(cb);
+          cb &= cb - 1ull;
+          slot_force(L.pt + corner_slot(m, nbx, kd, j / BOX_T, j % BOX_T) * PT_STRIDE, a, 1.0f, dt, 1.0f, f);
+        }
+        while (sb) {
+          const int si = __builtin_ctz(sb);
+          sb &= sb - 1u;
+          slot_force(L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, a, -1.0f, dt, 1.0f, f);
         }
       }
       contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];

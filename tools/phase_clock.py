@@ -2,7 +2,7 @@
 """Per-phase latency breakdown of k_a1_step from in-kernel s_memtime marks.
 
     python tools/phase_clock.py build         # here (no GPU): debug library with -DSHF_PHASE_CLOCK
-    python tools/phase_clock.py [G] [steps]   # on the MI355X box
+    python tools/phase_clock.py [G] [steps] [--abb]   # on the MI355X box
 
 Thread 0 of block 0 accumulates the cycle count between PHASE_MARKs (csrc/shf_device.h); the marks
 serialise the wave a little (s_memtime + waitcnt), so the total is a few % above the production kernel.
@@ -31,13 +31,17 @@ def build():
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "build":
         return build()
-    G = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    abb = "--abb" in sys.argv
+    argv = [a for a in sys.argv if a != "--abb"]
+    G = int(argv[1]) if len(argv) > 1 else 32
+    steps = int(argv[2]) if len(argv) > 2 else 100
     os.environ["SHIFU_AMD_LIB"] = LIB
     import torch
     from shifu_amd import _lib
     from shifu_amd.gym.a1_fused import FusedA1Env
-    env = FusedA1Env(num_envs=4096, group=G)
+    from shifu_amd.gym.abb_fused import FusedAbbEnv
+    # --abb: the sub-step phases (0-10) of the push-box env; its kernel has no marks outside the sub-steps
+    env = FusedAbbEnv(num_envs=4096, group=G) if abb else FusedA1Env(num_envs=4096, group=G)
     lib = _lib.lib()
     fn = lib.shf_debug_phase_cycles
     fn.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_int]
