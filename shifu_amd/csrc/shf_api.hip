@@ -787,7 +787,8 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
   LaneModel M;
   lane_model_load<DynDims>(m, l, M);
   LanePoints<1> P;   // unused: point count only known at run time
-  for (int it = 0; it < nsub; it++) substep<G, true>(C, L, l, M, P, tgtl, nullptr, nullptr, mu, L.xch);
+  // net contact forces are reported for the last sub-step only (what the refreshed tensor shows)
+  for (int it = 0; it < nsub; it++) substep<G, true>(C, L, l, M, P, tgtl, nullptr, nullptr, mu, it == nsub - 1 ? L.xch : nullptr);
   GROUP_SYNC();
   for (int i = l; i < 3 * nbt; i += G) A.S.contact[(size_t)e * nbt * 3 + i] = L.xch[i];
   GROUP_SYNC();

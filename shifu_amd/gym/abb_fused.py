@@ -15,7 +15,7 @@ REWARD_NAMES = ["reward_reaching", "reward_success"]   # build_reward_functions 
 
 class FusedAbbEnv:
     def __init__(self, num_envs: int = 4096, device="cuda:0", seed: int = 42, rank: int = 0, world_size: int = 1,
-                 group: int = 32, dt: float = 0.02, decimation: int = 5, episode_length_s: float = 20.0):
+                 group: int = 16, dt: float = 0.02, decimation: int = 5, episode_length_s: float = 20.0):
         self.device = torch.device(device)
         self.num_envs = num_envs
         self.env_id_offset = rank * num_envs
