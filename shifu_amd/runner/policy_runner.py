@@ -36,13 +36,13 @@ def _on_policy_runner_class():
 def run_policy(run_mode, env_class, env_cfg, policy_cfg, log_root="./logs", play_num_envs=50, play_iterations=3000):
     if run_mode == 'train':
         env = env_class(env_cfg)
-        runner = build_policy_runner(env, policy_cfg, log_root)
+        runner = build_policy_runner(env, policy_cfg, log_root, device=_device_of(env))
         runner.learn(num_learning_iterations=policy_cfg.runner.max_iterations, init_at_random_ep_len=True)
     elif run_mode == 'play':
         env_cfg.num_envs = play_num_envs
         env_cfg.debug.headless = False
         env = env_class(env_cfg)
-        policy = load_policy(env, policy_cfg, log_root)
+        policy = load_policy(env, policy_cfg, log_root, device=_device_of(env))
         env.reset()
         obs = env.get_observations()
         for _ in range(play_iterations):
@@ -58,6 +58,11 @@ def run_policy(run_mode, env_class, env_cfg, policy_cfg, log_root="./logs", play
         return env
     else:
         raise NotImplementedError
+
+
+def _device_of(env):
+    """The reference hard-codes 'cuda:0' (:45, :56); a sharded run trains on the env's own device."""
+    return str(getattr(env, "device", "cuda:0"))
 
 
 def load_policy(env, policy_cfg, log_root, device='cuda:0'):

@@ -189,3 +189,40 @@ def test_split_k_linear_matches_nn_linear():
     torch.testing.assert_close(b.bias.grad, a.bias.grad, rtol=1e-4, atol=1e-4)
     # small batches take the stock path
     assert torch.equal(b(x2[:64]), torch.nn.functional.linear(x2[:64], b.weight, b.bias))
+
+
+def test_run_policy_train_then_play(tmp_path, capsys):
+    """The reference entry point (shifu/runner/policy_runner.py:17-32) end to end on the in-tree trainer:
+    'train' writes <log_root>/<timestamp>_<run_name>/model_*.pt, 'play' finds the newest one and rolls the policy."""
+    from types import SimpleNamespace
+    from shifu_amd.configs.policy_config import PPOConfig
+    from shifu_amd.runner.policy_runner import run_policy
+
+    class Cfg(PPOConfig):
+        seed = 3
+
+        class policy(PPOConfig.policy):
+            actor_hidden_dims = [16]
+            critic_hidden_dims = [16]
+
+        class runner(PPOConfig.runner):
+            num_steps_per_env = 8
+            max_iterations = 3
+            save_interval = 2
+            run_name = "reach"
+
+    made = []
+
+    class Env(ReachEnv):
+        def __init__(self, cfg):
+            super().__init__(n=cfg.num_envs)
+            made.append(self)
+
+    env_cfg = SimpleNamespace(num_envs=32, debug=SimpleNamespace(headless=True))
+    run_policy("train", Env, env_cfg, Cfg(), log_root=str(tmp_path))
+    runs = os.listdir(tmp_path)
+    assert len(runs) == 1 and runs[0].endswith("_reach")
+    assert {"model_0.pt", "model_2.pt", "model_3.pt", "progress.jsonl"} <= set(os.listdir(tmp_path / runs[0]))
+    run_policy("play", Env, env_cfg, Cfg(), log_root=str(tmp_path), play_num_envs=5, play_iterations=4)
+    assert made[-1].num_envs == 5 and env_cfg.debug.headless is False
+    assert "model_3.pt" in capsys.readouterr().out          # "Loading model from: ..."
