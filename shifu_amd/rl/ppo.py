@@ -15,7 +15,9 @@ class PPO:
         self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
         self.actor_critic = actor_critic.to(device)
         self.storage = None
-        self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=learning_rate)
+        # one fused multi-tensor Adam kernel on the GPU (18 parameter tensors), the stock loop on CPU
+        fused = torch.device(device).type == "cuda"
+        self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=learning_rate, fused=fused)
         self.transition = RolloutStorage.Transition()
         self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
         self.value_loss_coef, self.entropy_coef = value_loss_coef, entropy_coef
