@@ -28,10 +28,15 @@ def main():
     args = ap.parse_args()
     import torch.distributed as dist
     world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
+    backend = os.environ.get("SHIFU_AMD_DIST_BACKEND", "nccl")     # gloo: several ranks on one GPU (testing only)
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     from examples.a1_conditional.task_config import A1PPOConfig
     from shifu_amd.rl import OnPolicyRunner
     from shifu_amd.runner.utils import class_to_dict, set_seed
