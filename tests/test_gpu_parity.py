@@ -181,11 +181,11 @@ def _compare(sim, task, bufs, tag, exact=True, tol=0.0):
     return worst
 
 
-def _a1_setup(n, rough, seed=5, group=64, env_off=0):
+def _a1_setup(n, rough, seed=5, group=64, env_off=0, cm=None):
     from shifu_amd.a1_task import a1_task_params
     from shifu_amd.backend import A1Task
     rng = np.random.default_rng(seed)
-    cm = H.a1_model()
+    cm = cm or H.a1_model()
     sp = H.sim_params(angular_damping=0.5)
     tp = a1_task_params(cm, num_rows=4, num_cols=5, env_length=0.8)
     terr, hs = _terrain(rng, rows=80, cols=60, rough=rough)
@@ -420,3 +420,22 @@ def test_full_size_determinism_and_shard_invariance():
         assert torch.equal(cat, full1[k]), f"shard invariance, output {k}"
     assert torch.isfinite(full1[0]).all()
     assert int(full1[3].sum()) > N, "resets must have happened"
+
+
+@pytest.mark.parametrize("group", [16, 32])
+def test_fused_step_generic_dimension_path(oracle, group):
+    """A robot that is not the compiled-in A1 layout (here: the A1 with its feet collapsed into the shanks, 13 bodies)
+    takes the run-time-dimension instantiation of the fused kernel -- level-loop kinematics, rolled contact loops,
+    flag-driven folds -- and, with 13 bodies, also fits four envs per wavefront."""
+    _need_gpu()
+    from shifu_amd.model import asset_path, compile_urdf
+    cm = compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT, honour_dont_collapse=False)
+    assert cm.blob.nb == 13
+    n = 40
+    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, seed=21, group=group, cm=cm)
+    for it in range(60):
+        raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32) * 1.5
+        task.step(torch.from_numpy(raw).cuda())
+        oracle.a1_step(cm.blob, sp, tp, n, 0, bufs, raw, terrain=terr, heights=hs)
+        _compare(sim, task, bufs, f"step {it}")
+    assert np.isfinite(bufs["obs"]).all()
