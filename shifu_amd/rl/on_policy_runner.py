@@ -70,7 +70,7 @@ class OnPolicyRunner:
         first, last = self.current_learning_iteration, self.current_learning_iteration + num_learning_iterations
         for it in range(first, last):
             start = time.time()
-            with torch.inference_mode():
+            with torch.no_grad():     # (not inference_mode: graph-captured RNG state must stay an ordinary tensor)
                 if use_graph and graph is None and it > first:
                     # the first iteration ran eagerly (warm-up: lazy inits, LDS opt-ins); capture the second and
                     # replay it from then on.  Everything in the rollout writes static buffers (rollout storage, env
@@ -193,6 +193,7 @@ class OnPolicyRunner:
         self.alg.actor_critic.load_state_dict(loaded["model_state_dict"])
         if load_optimizer:
             self.alg.optimizer.load_state_dict(loaded["optimizer_state_dict"])
+            self.alg.relink_learning_rate()
         self.current_learning_iteration = loaded["iter"]
         return loaded["infos"]
 

@@ -12,12 +12,15 @@ class PPO:
                  value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True,
                  schedule="fixed", desired_kl=0.01, device="cpu"):
         self.device = device
-        self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
+        self.desired_kl, self.schedule = desired_kl, schedule
         self.actor_critic = actor_critic.to(device)
         self.storage = None
-        # one fused multi-tensor Adam kernel on the GPU (18 parameter tensors), the stock loop on CPU
-        fused = torch.device(device).type == "cuda"
-        self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=learning_rate, fused=fused)
+        # The learning rate is a device tensor shared with the optimizer: the adaptive schedule needs no host
+        # round trip per mini-batch.
+        # One fused multi-tensor Adam kernel on the GPU (18 parameter tensors), the stock loop on CPU.
+        cuda = torch.device(device).type == "cuda"
+        self.lr = torch.tensor(float(learning_rate), dtype=torch.float32, device=device)
+        self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=self.lr, fused=cuda, capturable=cuda)
         self.transition = RolloutStorage.Transition()
         self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
         self.value_loss_coef, self.entropy_coef = value_loss_coef, entropy_coef
@@ -63,7 +66,7 @@ class PPO:
     def losses(self, obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma):
         """Loss terms of one mini-batch under the current parameters (also what tests/test_rl.py checks)."""
         ac = self.actor_critic
-        ac.act(obs)
+        ac.update_distribution(obs)
         logp = ac.get_actions_log_prob(actions)
         value = ac.evaluate(cobs)
         mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
@@ -85,33 +88,52 @@ class PPO:
         return {"surrogate": surrogate_loss, "value": value_loss, "entropy": ent, "kl": kl,
                 "loss": surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * ent}
 
-    def adapt_learning_rate(self, kl_mean: float):
-        """schedule='adaptive': keep the policy step near desired_kl (x1.5 / /1.5, clamped to [1e-5, 1e-2])."""
-        if kl_mean > self.desired_kl * 2.0:
-            self.learning_rate = max(1e-5, self.learning_rate / 1.5)
-        elif 0.0 < kl_mean < self.desired_kl / 2.0:
-            self.learning_rate = min(1e-2, self.learning_rate * 1.5)
+    @property
+    def learning_rate(self) -> float:
+        return float(self.lr)
+
+    def relink_learning_rate(self):
+        """After optimizer.load_state_dict the param groups hold a fresh lr value: share one tensor again."""
+        self.lr.fill_(float(self.optimizer.param_groups[0]["lr"]))
         for g in self.optimizer.param_groups:
-            g["lr"] = self.learning_rate
+            g["lr"] = self.lr
+
+    def adapt_learning_rate(self, kl_mean):
+        """schedule='adaptive': keep the policy step near desired_kl (x1.5 / /1.5, clamped to [1e-5, 1e-2]).
+        `kl_mean` may be a device scalar; the decision is taken on the device."""
+        kl = torch.as_tensor(kl_mean, dtype=torch.float32, device=self.lr.device)
+        lr = self.lr
+        down, up = torch.clamp(lr / 1.5, min=1e-5), torch.clamp(lr * 1.5, max=1e-2)
+        lr.copy_(torch.where(kl > self.desired_kl * 2.0, down,
+                             torch.where((kl > 0.0) & (kl < self.desired_kl / 2.0), up, lr)))
+
+    def _minibatch_step(self, batch, sums):
+        """One optimizer step on one mini-batch (static shapes, no host sync)."""
+        ac = self.actor_critic
+        obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma = batch
+        L = self.losses(obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma)
+        if self.desired_kl is not None and self.schedule == "adaptive":
+            # the KL is averaged over ranks first so that every rank takes the same decision
+            self.adapt_learning_rate(average_(L["kl"].detach().clone()))
+        L["loss"].backward()
+        if world_size() > 1:
+            average_gradients(ac.parameters())
+        nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
+        self.optimizer.step()
+        sums[0] += L["value"].detach()
+        sums[1] += L["surrogate"].detach()
 
     def update(self):
+        st = self.storage
+        B = st.num_envs * st.num_transitions_per_env
+        mb = B // self.num_mini_batches
+        perm = torch.randperm(self.num_mini_batches * mb, device=self.device)
         sums = torch.zeros(2, device=self.device)       # value / surrogate loss sums stay on the device
-        ac = self.actor_critic
-        for (obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, _h, _m) in \
-                self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
-            L = self.losses(obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma)
-            if self.desired_kl is not None and self.schedule == "adaptive":
-                # the KL is averaged over ranks first so that every rank takes the same decision
-                self.adapt_learning_rate(float(average_(L["kl"].detach().clone())))
-            self.optimizer.zero_grad(set_to_none=True)
-            L["loss"].backward()
-            if world_size() > 1:
-                average_gradients(ac.parameters())
-            nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
-            self.optimizer.step()
-            sums[0] += L["value"].detach()
-            sums[1] += L["surrogate"].detach()
+        for _ in range(self.num_learning_epochs):
+            for i in range(self.num_mini_batches):
+                self.optimizer.zero_grad(set_to_none=True)
+                self._minibatch_step(st.mini_batch(perm[i * mb:(i + 1) * mb]), sums)
         n = self.num_learning_epochs * self.num_mini_batches
-        self.storage.clear()
+        st.clear()
         mean_value_loss, mean_surrogate_loss = (sums / n).tolist()
         return mean_value_loss, mean_surrogate_loss

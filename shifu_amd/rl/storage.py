@@ -53,8 +53,9 @@ class RolloutStorage:
             delta = self.rewards[k] + live * gamma * nxt - self.values[k]
             adv = delta + live * gamma * lam * adv
             self.returns[k] = adv + self.values[k]
-        self.advantages = self.returns - self.values
-        self.advantages = (self.advantages - self.advantages.mean()) / (self.advantages.std() + 1e-8)
+        # in place: a captured update graph reads this buffer at a fixed address
+        adv = self.returns - self.values
+        self.advantages.copy_((adv - adv.mean()) / (adv.std() + 1e-8))
 
     def get_statistics(self):
         done = self.dones.clone()
@@ -64,16 +65,11 @@ class RolloutStorage:
         lengths = idx[1:] - idx[:-1]
         return lengths.float().mean(), self.rewards.mean()
 
-    def mini_batch_generator(self, num_mini_batches, num_epochs=8):
-        B = self.num_envs * self.num_transitions_per_env
-        mb = B // num_mini_batches
-        perm = torch.randperm(num_mini_batches * mb, device=self.device)
-        obs = self.observations.flatten(0, 1)
-        cobs = self.privileged_observations.flatten(0, 1) if self.privileged_observations is not None else obs
-        acts, vals, rets = self.actions.flatten(0, 1), self.values.flatten(0, 1), self.returns.flatten(0, 1)
-        logp, adv = self.actions_log_prob.flatten(0, 1), self.advantages.flatten(0, 1)
-        mu, sg = self.mu.flatten(0, 1), self.sigma.flatten(0, 1)
-        for _ in range(num_epochs):
-            for i in range(num_mini_batches):
-                b = perm[i * mb:(i + 1) * mb]
-                yield obs[b], cobs[b], acts[b], vals[b], adv[b], rets[b], logp[b], mu[b], sg[b], (None, None), None
+    def mini_batch(self, idx):
+        """The rollout rows `idx` (flat (t, env) indices) as
+        (obs, critic_obs, actions, values, advantages, returns, log_prob, mu, sigma)."""
+        f = lambda t: t.flatten(0, 1)[idx]
+        obs = f(self.observations)
+        cobs = f(self.privileged_observations) if self.privileged_observations is not None else obs
+        return (obs, cobs, f(self.actions), f(self.values), f(self.advantages), f(self.returns), f(self.actions_log_prob),
+                f(self.mu), f(self.sigma))

@@ -61,7 +61,7 @@ def test_ppo_loss_terms_match_loop_oracle(clipped_value):
 def test_adaptive_learning_rate_rule():
     alg = PPO(ActorCritic(2, 2, 1), learning_rate=1e-3, schedule="adaptive", desired_kl=0.01)
     alg.adapt_learning_rate(0.05)
-    assert alg.learning_rate == pytest.approx(1e-3 / 1.5) and alg.optimizer.param_groups[0]["lr"] == alg.learning_rate
+    assert alg.learning_rate == pytest.approx(1e-3 / 1.5) and float(alg.optimizer.param_groups[0]["lr"]) == alg.learning_rate
     alg.adapt_learning_rate(0.001)
     alg.adapt_learning_rate(0.001)
     assert alg.learning_rate == pytest.approx(1e-3 * 1.5)
