@@ -10,10 +10,9 @@ into one .npz a CPU viewer can replay -- the stand-in for the reference's `play`
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Dict
 
 import numpy as np
-import torch
 
 from . import _abi
 

@@ -7,7 +7,7 @@ from __future__ import annotations
 import torch
 
 from .. import _abi
-from ..abb_task import ABB_BASE_POS, ABB_DEFAULT_DOF_POS, abb_boxes, abb_model, abb_task_params
+from ..abb_task import ABB_BASE_POS, abb_boxes, abb_model, abb_task_params
 from ..backend import AbbTask, Sim, default_sim_params
 
 REWARD_NAMES = ["reward_reaching", "reward_success"]   # build_reward_functions order, a_prior_stage.py:115-119

@@ -10,7 +10,6 @@ import os
 import types
 
 import numpy as np
-import pytest
 import torch
 
 from shifu_amd import _abi

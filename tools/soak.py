@@ -3,7 +3,6 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from shifu_amd import _abi
 from shifu_amd.gym.a1_fused import FusedA1Env
 from shifu_amd.gym.abb_fused import FusedAbbEnv
 
