@@ -227,6 +227,7 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
   const float dt = C.sp.dt, kc = C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
   const float beta = fmaf(kc, dt, C.sp.contact_d);
   const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
+  PHASE_BEGIN();
   // corner slots
   for (int idx = l; idx < nbx * 8 * T; idx += G) {
     const int kd = idx / (8 * T), c = (idx / T) % 8, tg = idx % T;
@@ -262,6 +263,7 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
       slot_eval(o, phi, n, r, vp, 0.5f * (bd.friction + bs.friction), kc, beta, veps, vdep);
     }
   }
+  PHASE_MARK(17);
   // sphere slots
   for (int idx = l; idx < m->nsph * nbx; idx += G) {
     const int si = idx / nbx, kd = idx % nbx;
@@ -289,6 +291,7 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
     slot_eval(o, phi, n, rc, vrel, 0.5f * (mu_shape + bd.friction), kc, beta, veps, vdep);
   }
   GROUP_SYNC();
+  PHASE_MARK(18);
   // fold
   if (l < nb && m->dyn[l] == l) {
     unsigned bits = body_sphere_flags(m, L, nbx, l, true);
@@ -314,6 +317,7 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
       slot_accumulate(B.IA, B.pA, L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, -1.0f, dt, 1.0f);
     }
   }
+  PHASE_MARK(19);
 }
 
 // Solve the free boxes, report contact forces (boxes and the articulation's sphere contacts),

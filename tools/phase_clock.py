@@ -56,9 +56,9 @@ def main():
         env.step(act.uniform_(-1, 1))
     torch.cuda.synchronize()
     assert fn(buf, 32, 0) == 0
-    tot = sum(buf[:17])
+    tot = sum(buf[:17])  # (marks 17-19: inside phase 4 for the box scene)
     print(f"G={G}: {tot / steps:.0f} cycles per env-step in block 0 / wave 0 (s_memtime ticks)")
-    for k, nme in enumerate(NAMES):
+    for k, nme in enumerate(NAMES + ['box: corner slots', 'box: sphere slots', 'box: fold']):
         print(f"  {k:2d} {nme:34s} {buf[k] / steps:9.0f}  {100.0 * buf[k] / tot:5.1f} %")
 
 
