@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # Algorithmic HBM bytes per env-step (restated in DESIGN.md section 5)
-B_ALG = {"terrain": 5539, "flat": 5019}
+B_ALG = {"terrain": 5539, "flat": 5019, "trimesh": 5539}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s achievable)
 
 
@@ -47,7 +47,7 @@ def cpu_baseline(workload: str, seconds_budget: float = 15.0):
     sp = default_sim_params()
     ct = default_terrain_cfg()
     np.random.seed(42)
-    if workload == "terrain":
+    if workload in ("terrain", "trimesh"):
         ter = Terrain(ct, n)
         hs, origins = np.ascontiguousarray(ter.heightsamples), ter.env_origins.astype(np.float32)
     else:
@@ -58,6 +58,10 @@ def cpu_baseline(workload: str, seconds_budget: float = 15.0):
                 origins[i, j] = [(i + 0.5) * 8, (j + 0.5) * 8, 0]
     terr = _abi.ShfTerrain()
     terr.rows, terr.cols, terr.hscale, terr.vscale, terr.border, terr.friction = hs.shape[0], hs.shape[1], 0.1, 0.005, 25.0, 1.0
+    if workload == "trimesh":
+        from shifu_amd.isaacgym.terrain_utils import pack_trimesh_samples, trimesh_warp_map
+        terr.warped = 1
+        hs = pack_trimesh_samples(hs, trimesh_warp_map(hs, 0.1, 0.005, ct.slope_treshold))
     tp = a1_task_params(cm)
     nb, nd, P = m.nb, m.nd, tp.num_height_points
     rng = np.random.default_rng(0)
@@ -110,7 +114,8 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
-    ap.add_argument("--workload", choices=["terrain", "flat"], default="terrain")
+    ap.add_argument("--workload", choices=["terrain", "flat", "trimesh"], default="terrain",
+                    help="terrain = config 3 (height field); trimesh = the same samples as the mesh with vertical risers")
     ap.add_argument("--group", type=int, default=32, help="lanes per env: 64 = one wavefront per env, 32 = two envs per wavefront (fastest measured, DESIGN.md 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decimation", type=int, default=4, help="(experiments only) control.decimation")
@@ -154,7 +159,7 @@ def main():
     from shifu_amd.gym.a1_fused import FusedA1Env
     from shifu_amd.parallel import gather_episode_stats
 
-    env = FusedA1Env(num_envs=args.envs, device=dev, terrain="heightfield" if args.workload == "terrain" else "flat",
+    env = FusedA1Env(num_envs=args.envs, device=dev, terrain={"terrain": "heightfield", "flat": "flat", "trimesh": "trimesh"}[args.workload],
                      seed=42, rank=rank, world_size=world, group=args.group, decimation=args.decimation,
                      extra_substep=not args.no_extra_substep)
     gen = torch.Generator(device=dev)
@@ -204,6 +209,8 @@ def main():
         total_envs = N * world
         value = total_envs * args.steps / elapsed
         b_alg = B_ALG[args.workload]
+        wl_name = {"terrain": "procedural heightfield 1300x2100 (config 3)", "flat": "all-zero heightfield (config 2)",
+                   "trimesh": "procedural terrain 1300x2100 as trimesh with vertical risers (the reference's effective A1 terrain)"}[args.workload]
         achieved = b_alg * N / (kern_ms * 1e-3) / 1e9
         traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/profile.sh)
         try:
@@ -217,7 +224,7 @@ def main():
             "metric": "env-steps/sec (whole node), A1 12-dof 4096 envs/GPU", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"a1_conditional {'procedural heightfield 1300x2100 (config 3)' if args.workload == 'terrain' else 'all-zero heightfield (config 2)'}, "
+            "config": {"workload": f"a1_conditional {wl_name}, "
                                    f"{N} envs/GPU, random actions, 5 substeps/env-step (dt 5 ms), resets on",
                        "envs_per_gpu": N, "total_envs": total_envs, "substeps_per_env_step": 5,
                        "lanes_per_env": args.group, "parallelism": f"env-sharded x{world}, all-gather of episode stats every {args.log_interval} steps",

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SHF_ABI_VERSION 1
+#define SHF_ABI_VERSION 2
 
 #define SHF_MAX_BODIES 32 /* reported rigid bodies per articulation        */
 #define SHF_MAX_DOFS 32
@@ -134,6 +134,15 @@ typedef struct ShfTerrain {
   int32_t rows, cols; /* height_samples is (rows, cols) int16, x<->row     */
   float hscale, vscale, border;
   float friction; /* terrain static==dynamic friction (env_config.py:82)   */
+  /* 0: height field (gym.add_heightfield, cells split along (i+1,j)-(i,j+1)).
+   * 1: the triangle mesh convert_heightfield_to_trimesh builds from the same samples
+   *    (gym.add_triangle_mesh, isaac_gym.py:369-385): cells split along (i,j)-(i+1,j+1)
+   *    and, where a step is steeper than slope_threshold, vertices shifted by one cell
+   *    so that the riser is vertical.  SHF_T_HEIGHTS then carries, after the rows*cols
+   *    int16 samples, rows*cols bytes: bits 0-1 dx+1, bits 2-3 dy+1 (shift of the vertex
+   *    in cells), bit 7 set when no vertex of the 4x4 neighbourhood of the cell whose
+   *    lower corner this is has moved (the query then needs that one cell only).        */
+  int32_t warped;
 } ShfTerrain;
 
 /* Tensor ids for shf_sim_bind / shf_sim_layout.  State tensors follow the

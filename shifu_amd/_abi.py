@@ -1,7 +1,7 @@
 """ctypes mirrors of the PODs in include/shifu_amd.h (keep in lock-step)."""
 import ctypes as C
 
-SHF_ABI_VERSION = 1
+SHF_ABI_VERSION = 2
 MAX_BODIES = 32
 MAX_DOFS = 32
 MAX_POINTS = 96
@@ -51,7 +51,7 @@ class ShfSimParams(C.Structure):
 
 class ShfTerrain(C.Structure):
     _fields_ = [("rows", i32), ("cols", i32), ("hscale", f32), ("vscale", f32), ("border", f32),
-                ("friction", f32)]
+                ("friction", f32), ("warped", i32)]
 
 
 class ShfA1TaskParams(C.Structure):

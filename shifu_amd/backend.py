@@ -71,13 +71,25 @@ class Sim:
         self.terrain = t
         check(lib().shf_sim_set_terrain(self._h, C.byref(t)))
 
-    def set_heightfield(self, samples: np.ndarray, hscale: float, vscale: float, border: float, friction: float):
+    def set_heightfield(self, samples: np.ndarray, hscale: float, vscale: float, border: float, friction: float,
+                        warp: Optional[np.ndarray] = None):
+        """Height-field terrain; with `warp` (isaacgym.terrain_utils.trimesh_warp_map) the trimesh made of the same
+        samples (ShfTerrain.warped: vertical risers at steep steps)."""
         assert samples.dtype == np.int16 and samples.ndim == 2
         t = _abi.ShfTerrain()
         t.rows, t.cols = samples.shape
         t.hscale, t.vscale, t.border, t.friction = hscale, vscale, border, friction
+        t.warped = 0 if warp is None else 1
         self.terrain = t
-        self._heights = torch.from_numpy(np.ascontiguousarray(samples)).to(self.device)
+        self.height_samples = np.ascontiguousarray(samples)
+        if warp is None:
+            payload = self.height_samples
+        else:
+            from .isaacgym.terrain_utils import pack_trimesh_samples
+            assert warp.shape == samples.shape and warp.dtype == np.uint8
+            payload = pack_trimesh_samples(samples, warp)
+        self.terrain_payload = payload                      # what the oracle takes as `heights`
+        self._heights = torch.from_numpy(payload).to(self.device)
         check(lib().shf_sim_set_terrain(self._h, C.byref(t)))
 
     def set_articulation(self, model: _abi.ShfModel):

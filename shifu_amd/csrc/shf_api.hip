@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
   LaneModel M;
   lane_model_load<DynDims>(m, l, M);
   LanePoints<1> P;   // unused: point count only known at run time
-  substep<G, BOX>(C, L, l, M, P, A.pos_tgt ? A.pos_tgt + (size_t)e * nd : nullptr, A.vel_tgt ? A.vel_tgt + (size_t)e * nd : nullptr,
+  substep<G, BOX, DynDims, !BOX>(C, L, l, M, P, A.pos_tgt ? A.pos_tgt + (size_t)e * nd : nullptr, A.vel_tgt ? A.vel_tgt + (size_t)e * nd : nullptr,
                   A.body_force ? A.body_force + (size_t)e * nbt * 3 : nullptr, mu, L.xch);
   GROUP_SYNC();
   for (int i = l; i < 2 * nd; i += G) dof[i] = L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)];
@@ -371,7 +371,7 @@ __global__ void k_a1_reset_all(A1Args A) {
 // the kernel is held to 128 VGPRs (measured 0.147 ms vs 0.165 ms at 165 VGPRs / 3 waves,
 // profiles/r01_*); at G = 32 the grid is 2 waves per SIMD and the unconstrained
 // allocation is faster (0.104 ms vs 0.112 ms).
-template <int G, class DM>
+template <int G, class DM, bool TW>
 DEV void a1_step_body(const A1Args& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   PHASE_BEGIN();
@@ -428,7 +428,7 @@ DEV void a1_step_body(const A1Args& A) {
       D[5] = rclampf(t, -m->effort[l], m->effort[l]);
     }
     GROUP_SYNC();
-    substep<G, false, DM>(C, L, l, M, LP, nullptr, nullptr, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
+    substep<G, false, DM, TW>(C, L, l, M, LP, nullptr, nullptr, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
                (it == nsub - 1) ? L.xch : nullptr);
   }
   GROUP_SYNC();
@@ -614,12 +614,12 @@ DEV void a1_step_body(const A1Args& A) {
   PHASE_MARK(16);
 }
 template <int G, class DM>
-__global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) { a1_step_body<G, DM>(A); }
+__global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) { a1_step_body<G, DM, (G < 64)>(A); }
 // The default instantiation (A1, two envs per wavefront) has to stay within 256 VGPRs: two blocks per CU = two
 // waves per SIMD keep all 4096 envs resident.  Launch bounds of (256, 2) would say the same but also switch the
 // scheduler to its occupancy-preserving mode (measured +13 %), so the register cap is given directly.
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256))) void k_a1_step_a1_g32(A1Args A) {
-  a1_step_body<32, A1Dims>(A);
+  a1_step_body<32, A1Dims, false>(A);
 }
 
 // per-step reduction for extras["episode"] (env.py:149-158), fixed order: block k reduces
@@ -912,6 +912,8 @@ extern "C" int shf_sim_set_terrain(ShfSim* sim, const ShfTerrain* terrain) {
   if (!sim || !terrain) return fail("shf_sim_set_terrain: null argument");
   if (terrain->rows != 0 && (terrain->rows < 2 || terrain->cols < 2 || !(terrain->hscale > 0.0f)))
     return fail("shf_sim_set_terrain: bad heightfield shape/scale");
+  if (terrain->warped && terrain->rows == 0) return fail("shf_sim_set_terrain: a warped (trimesh) terrain needs height samples");
+  if (terrain->warped && sim->nboxes > 0) return fail("shf_sim_set_terrain: trimesh terrain with box actors is not supported");
   sim->terr = *terrain;
   return 0;
 }
@@ -927,6 +929,7 @@ extern "C" int shf_sim_set_articulation(ShfSim* sim, const ShfModel* model) {
 extern "C" int shf_sim_add_box(ShfSim* sim, const ShfBoxDesc* box) {
   if (!sim || !box) return fail("shf_sim_add_box: null argument");
   if (sim->nboxes >= SHF_MAX_BOXES) return fail("shf_sim_add_box: too many boxes");
+  if (sim->terr.warped) return fail("shf_sim_add_box: box actors on a trimesh terrain are not supported");
   sim->boxes[sim->nboxes++] = *box;
   return 0;
 }
@@ -960,7 +963,15 @@ extern "C" int shf_sim_layout(const ShfSim* sim, int32_t id, int64_t shape[4], i
       shape[3] = sim->model.fixed_base ? nd : nd + 6; break;
     case SHF_T_EFFORT: case SHF_T_POS_TARGET: case SHF_T_VEL_TARGET: *ndim = 1; shape[0] = N * nd; break;
     case SHF_T_FRICTION: *ndim = 1; shape[0] = N; break;
-    case SHF_T_HEIGHTS: *ndim = 2; shape[0] = sim->terr.rows > 0 ? sim->terr.rows : 1; shape[1] = sim->terr.rows > 0 ? sim->terr.cols : 1; *dtype = 2; break;
+    case SHF_T_HEIGHTS:
+      *dtype = 2;
+      if (sim->terr.rows > 0 && sim->terr.warped) {   // samples followed by one byte per vertex (ShfTerrain.warped)
+        const int64_t cells = (int64_t)sim->terr.rows * sim->terr.cols;
+        *ndim = 1; shape[0] = cells + (cells + 1) / 2;
+      } else {
+        *ndim = 2; shape[0] = sim->terr.rows > 0 ? sim->terr.rows : 1; shape[1] = sim->terr.rows > 0 ? sim->terr.cols : 1;
+      }
+      break;
     case SHF_T_MODEL: *ndim = 1; shape[0] = sizeof(ShfModel); *dtype = 3; break;
     case SHF_T_SCENE: *ndim = 1; shape[0] = sizeof(ShfScene); *dtype = 3; break;
     default: return fail("shf_sim_layout: unknown tensor id");
@@ -1231,10 +1242,16 @@ extern "C" int shf_a1_step(ShfA1Task* task, const float* raw_actions_dev, void* 
   dim3 grid((s->n + epb - 1) / epb), block(256);
   const size_t lds = sim_lds_bytes(s, TASK_WORDS, SCR_OBS + nobs);
   int r;
+  if (s->terr.warped && s->group == 64)
+    return fail("shf_a1_step: a trimesh terrain needs 16 or 32 lanes per env (the 128-VGPR instantiation has no room for it)");
   if (A1Dims::matches(s->model)) {
     switch (s->group) {
       case 64: r = launch(k_a1_step<64, A1Dims>, grid, block, lds, stream, A); break;
-      case 32: r = launch(k_a1_step_a1_g32, grid, block, lds, stream, A); break;
+      case 32:
+        // the capped-VGPR entry point is height-field only; a trimesh terrain takes the generic instantiation
+        r = s->terr.warped ? launch(k_a1_step<32, A1Dims>, grid, block, lds, stream, A)
+                           : launch(k_a1_step_a1_g32, grid, block, lds, stream, A);
+        break;
       default: return fail("shf_a1_step: A1 has 17 bodies, the lane group must be 32 or 64");
     }
   } else {

@@ -152,8 +152,70 @@ struct TerrainDev {
   const int16_t* h;
 };
 
+// One triangle of the warped mesh against the query point (cell units; Z in metres): keeps the highest surface that
+// covers the point, edges inclusive.
+DEV void warped_triangle(float px, float py, float hs, const float* P0, const float* P1, const float* P2, float* best,
+                         float* bn, bool* found) {
+  const float ax = P0[0] - px, ay = P0[1] - py, bx = P1[0] - px, by = P1[1] - py, cx = P2[0] - px, cy = P2[1] - py;
+  float e0 = fmaf(bx, cy, -(cx * by)), e1 = fmaf(cx, ay, -(ax * cy)), e2 = fmaf(ax, by, -(bx * ay));
+  float area = e0 + e1 + e2;
+  if (area < 0.0f) { e0 = -e0; e1 = -e1; e2 = -e2; area = -area; }
+  if (!(area > 1e-6f)) return;                 // a riser: no extent in the horizontal plane
+  if (e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) return;
+  const float z = fmaf(e2, P2[2], fmaf(e1, P1[2], e0 * P0[2])) / area;
+  if (*found && !(z > *best)) return;
+  const float ux = (P1[0] - P0[0]) * hs, uy = (P1[1] - P0[1]) * hs, uz = P1[2] - P0[2];
+  const float vx = (P2[0] - P0[0]) * hs, vy = (P2[1] - P0[1]) * hs, vz = P2[2] - P0[2];
+  float nx = fmaf(uy, vz, -(uz * vy)), ny = fmaf(uz, vx, -(ux * vz)), nz = fmaf(ux, vy, -(uy * vx));
+  if (nz < 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
+  const float inv = 1.0f / sqrtf(fmaf(nz, nz, fmaf(ny, ny, nx * nx)));
+  *best = z; bn[0] = nx * inv; bn[1] = ny * inv; bn[2] = nz * inv; *found = true;
+}
+
+DEV void terrain_query_heightfield(const TerrainDev& T, float x, float y, float* h, float* n);
+
+// ShfTerrain.warped: the trimesh convert_heightfield_to_trimesh makes of the samples; vertex shifts in
+// the bytes after the samples.  One cell when nothing nearby moved, else the 3 x 3 cells around the point.
+DEV void terrain_query_warped(const TerrainDev& T, float x, float y, float* h, float* n) {
+  const int rows = T.t.rows, cols = T.t.cols;
+  const uint8_t* W = reinterpret_cast<const uint8_t*>(T.h + (size_t)rows * cols);
+  const float hs = T.t.hscale, inv = 1.0f / hs, vs = T.t.vscale;
+  const float fx = (x + T.t.border) * inv, fy = (y + T.t.border) * inv;
+  const int i0 = (int)rclampf(floorf(fx), 0.0f, (float)(rows - 2)), j0 = (int)rclampf(floorf(fy), 0.0f, (float)(cols - 2));
+  const bool plain = (W[(size_t)i0 * cols + j0] & 0x80) != 0;
+  const int ilo = plain ? i0 : (i0 > 0 ? i0 - 1 : 0), ihi = plain ? i0 : (i0 < rows - 2 ? i0 + 1 : rows - 2);
+  const int jlo = plain ? j0 : (j0 > 0 ? j0 - 1 : 0), jhi = plain ? j0 : (j0 < cols - 2 ? j0 + 1 : cols - 2);
+  float best = 0.0f, bn[3] = {0.0f, 0.0f, 1.0f};
+  bool found = false;
+  for (int i = ilo; i <= ihi; i++)
+    for (int j = jlo; j <= jhi; j++) {
+      float P[4][3];
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+          const size_t idx = (size_t)(i + a) * cols + (j + b);
+          const int wv = W[idx];
+          P[2 * a + b][0] = (float)(i + a + (wv & 3) - 1);
+          P[2 * a + b][1] = (float)(j + b + ((wv >> 2) & 3) - 1);
+          P[2 * a + b][2] = (float)T.h[idx] * vs;
+        }
+      warped_triangle(fx, fy, hs, P[0], P[3], P[1], &best, bn, &found);
+      warped_triangle(fx, fy, hs, P[0], P[2], P[3], &best, bn, &found);
+    }
+  if (!found) { terrain_query_heightfield(T, x, y, h, n); return; }   // outside the mesh / numerical gap
+  *h = best; n[0] = bn[0]; n[1] = bn[1]; n[2] = bn[2];
+}
+
+// TW ("trimesh-capable") instantiations look at ShfTerrain.warped; the others are height-field only and the host
+// does not launch them on a warped terrain (the extra path costs the default A1 step 3.5 % just by being compiled in).
+template <bool TW = false>
 DEV void terrain_query(const TerrainDev& T, float x, float y, float* h, float* n) {
   if (T.t.rows == 0) { *h = 0.0f; n[0] = 0.0f; n[1] = 0.0f; n[2] = 1.0f; return; }
+  if (TW && T.t.warped) { terrain_query_warped(T, x, y, h, n); return; }
+  terrain_query_heightfield(T, x, y, h, n);
+}
+DEV void terrain_query_heightfield(const TerrainDev& T, float x, float y, float* h, float* n) {
   float inv = 1.0f / T.t.hscale;
   float fx = (x + T.t.border) * inv, fy = (y + T.t.border) * inv;
   float fi = rclampf(floorf(fx), 0.0f, (float)(T.t.rows - 2)), fj = rclampf(floorf(fy), 0.0f, (float)(T.t.cols - 2));
@@ -729,7 +791,7 @@ DEV void contact_force_final(float* o, const float* ab, float dt) {
 //   fext: world force per reported body (global memory, this env) or nullptr
 //   contact_out: LDS/global float[nb*3] written by body lanes (may be nullptr)
 #define LANE_ROUNDS(G, DM) ((DM::NPC + (G) - 1) / (G) > 0 ? (DM::NPC + (G) - 1) / (G) : 1)
-template <int G, bool BOX = false, class DM = DynDims, class LM = LaneModel>
+template <int G, bool BOX = false, class DM = DynDims, bool TW = false, class LM = LaneModel>
 DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const LanePoints<LANE_ROUNDS(G, DM)>& P,
                  const float* pos_tgt, const float* vel_tgt, const float* fext, float mu_shape, float* contact_out) {
   const ShfModel* m = C.m;
@@ -793,7 +855,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
       mv3(Rb, P.pos[k], r[k]);
 #pragma unroll
       for (int j = 0; j < 3; j++) r[k][j] += pb[9 + j];
-      terrain_query(C.terr, L.root[0] + r[k][0], L.root[1] + r[k][1], &h, n[k]);
+      terrain_query<TW>(C.terr, L.root[0] + r[k][0], L.root[1] + r[k][1], &h, n[k]);
       phi[k] = fmaf(L.root[2] + r[k][2] - h, n[k][2], -P.rad[k]);
     }
     const int lane0 = (int)(threadIdx.x & 63u) - l;   // first lane of this env's group within the wavefront
@@ -819,7 +881,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
       mv3(Rb, lp, r);
 #pragma unroll
       for (int k = 0; k < 3; k++) r[k] += pb[9 + k];
-      terrain_query(C.terr, L.root[0] + r[0], L.root[1] + r[1], &h, n);
+      terrain_query<TW>(C.terr, L.root[0] + r[0], L.root[1] + r[1], &h, n);
       const float rad = m->pt_radius[i];
       const float phi = fmaf(L.root[2] + r[2] - h, n[2], -rad);
       float* o = L.pt + i * PT_STRIDE;

@@ -86,16 +86,22 @@ class FusedA1Env:
             for i in range(ct.num_rows):
                 for j in range(ct.num_cols):
                     origins[i, j] = [(i + 0.5) * ct.terrain_length, (j + 0.5) * ct.terrain_width, 0.0]
-        elif terrain == "heightfield":
+        elif terrain in ("heightfield", "trimesh"):
             state = np.random.get_state()
             np.random.seed(terrain_seed)          # every rank builds the identical replica
             self.terrain = Terrain(ct, total)
             np.random.set_state(state)
             samples, origins = self.terrain.heightsamples, self.terrain.env_origins
         else:
-            raise ValueError("terrain must be 'flat' or 'heightfield'")
+            raise ValueError("terrain must be 'flat', 'heightfield' or 'trimesh'")
+        warp = None
+        if terrain == "trimesh":
+            # the reference's effective A1 terrain (Q5): the same samples as a triangle mesh whose steep steps have
+            # vertical risers (terrain.py:75-79 -> gym.add_triangle_mesh); get_heights still reads the raw samples
+            from ..isaacgym.terrain_utils import trimesh_warp_map
+            warp = trimesh_warp_map(samples, ct.horizontal_scale, ct.vertical_scale, ct.slope_treshold)
         self.sim.set_heightfield(np.ascontiguousarray(samples), ct.horizontal_scale, ct.vertical_scale, ct.border_size,
-                                 ct.static_friction)
+                                 ct.static_friction, warp=warp)
         self.sim.set_articulation(self.cm.blob)
         self.sim.finalize(num_envs, self.env_id_offset, group=group)
 

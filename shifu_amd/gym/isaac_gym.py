@@ -212,9 +212,10 @@ class TerrainGymEnv(IsaacGymEnv):
         t = self.terrain.cfg
         p = self._terrain_params(gymapi.TriangleMeshParams())
         p.nb_vertices, p.nb_triangles = self.terrain.vertices.shape[0], self.terrain.triangles.shape[0]
-        # the backend collides the height map the mesh was triangulated from
+        # the backend collides the mesh as the height map plus the vertex shifts that made it
         p.height_samples = self.terrain.heightsamples
         p.horizontal_scale, p.vertical_scale = t.horizontal_scale, t.vertical_scale
+        p.slope_threshold = t.slope_treshold
         self.gym.add_triangle_mesh(self.sim, self.terrain.vertices.flatten(order='C'),
                                    self.terrain.triangles.flatten(order='C'), p)
 

@@ -252,14 +252,20 @@ class Gym:
                        float(-params.transform.p.x), 0.5 * (params.static_friction + params.dynamic_friction))
 
     def add_triangle_mesh(self, sim: SimHandle, vertices, triangles, params: TriangleMeshParams):
-        """Trimesh terrain (the reference's effective A1 terrain, Q5) is collided as the
-        height map it was triangulated from; the vertices are expected to come from
-        convert_heightfield_to_trimesh.  Exact trimesh contact is SURVEY 8f row f2."""
+        """Trimesh terrain (the reference's effective A1 terrain, Q5).  The mesh is expected to come from
+        convert_heightfield_to_trimesh; it is collided as that warped grid (ShfTerrain.warped) when
+        the caller passes the height map and slope threshold it was made from, else as the height map recovered
+        from the vertices."""
         if getattr(params, "height_samples", None) is not None:
             # hint set by shifu_amd's TerrainGymEnv._create_trimesh: the map the mesh came from
+            from . import terrain_utils
             hs = np.ascontiguousarray(np.asarray(params.height_samples, dtype=np.int16))
+            warp = None
+            if hasattr(params, "slope_threshold"):
+                warp = terrain_utils.trimesh_warp_map(hs, float(params.horizontal_scale), float(params.vertical_scale),
+                                                      params.slope_threshold)
             sim.terrain = ("heightfield", hs, float(params.horizontal_scale), float(params.vertical_scale),
-                           float(-params.transform.p.x), 0.5 * (params.static_friction + params.dynamic_friction))
+                           float(-params.transform.p.x), 0.5 * (params.static_friction + params.dynamic_friction), warp)
             return
         v = np.asarray(vertices, dtype=np.float32).reshape(-1, 3)
         xs = np.unique(np.round(v[:, 0], 4))
@@ -355,8 +361,11 @@ class Gym:
         if sim.terrain is None or sim.terrain[0] == "plane":
             be.set_plane(sim.terrain[1] if sim.terrain else 1.0)
         else:
-            _, hs, hscale, vscale, border, mu = sim.terrain
-            be.set_heightfield(hs, hscale, vscale, border, mu)
+            _, hs, hscale, vscale, border, mu = sim.terrain[:6]
+            warp = sim.terrain[6] if len(sim.terrain) > 6 else None
+            if any(a.asset.kind != "articulation" for a in sim.envs[0].actors):
+                warp = None          # box actors collide with the height-field form only
+            be.set_heightfield(hs, hscale, vscale, border, mu, warp=warp)
         env0 = sim.envs[0]
         robots = [a for a in env0.actors if a.asset.kind == "articulation"]
         if len(robots) != 1 or env0.actors[0] is not robots[0]:

@@ -112,6 +112,51 @@ def stepping_stones_terrain(terrain, stone_size, stone_distance, max_height, pla
     return terrain
 
 
+def vertex_shifts(height_field_raw, horizontal_scale, vertical_scale, slope_threshold):
+    """(dx, dy) in cells, each in {-1, 0, 1}, that convert_heightfield_to_trimesh applies to every vertex: next to a
+    step steeper than the threshold the vertex is pulled over its neighbour so that the riser becomes vertical."""
+    hf = height_field_raw
+    rows, cols = hf.shape
+    thr = slope_threshold * horizontal_scale / vertical_scale
+    move_x = np.zeros((rows, cols)); move_y = np.zeros((rows, cols)); move_c = np.zeros((rows, cols))
+    move_x[:rows - 1, :] += (hf[1:, :] - hf[:rows - 1, :] > thr)
+    move_x[1:, :] -= (hf[:rows - 1, :] - hf[1:, :] > thr)
+    move_y[:, :cols - 1] += (hf[:, 1:] - hf[:, :cols - 1] > thr)
+    move_y[:, 1:] -= (hf[:, :cols - 1] - hf[:, 1:] > thr)
+    move_c[:rows - 1, :cols - 1] += (hf[1:, 1:] - hf[:rows - 1, :cols - 1] > thr)
+    move_c[1:, 1:] -= (hf[:rows - 1, :cols - 1] - hf[1:, 1:] > thr)
+    return move_x + move_c * (move_x == 0), move_y + move_c * (move_y == 0)
+
+
+def trimesh_warp_map(height_field_raw, horizontal_scale, vertical_scale, slope_threshold=None):
+    """The per-vertex byte the backend collides a trimesh terrain with (include/shifu_amd.h, ShfTerrain.warped):
+    bits 0-1 dx+1, bits 2-3 dy+1, bit 7 = no vertex of the surrounding 4x4 block moved (one-cell query)."""
+    hf = np.asarray(height_field_raw)
+    rows, cols = hf.shape
+    if slope_threshold is None:
+        dx = dy = np.zeros((rows, cols))
+    else:
+        dx, dy = vertex_shifts(hf.astype(np.int64), horizontal_scale, vertical_scale, slope_threshold)
+    moved = (dx != 0) | (dy != 0)
+    pad = np.pad(moved, ((1, 2), (1, 2)), mode="constant")
+    near = np.zeros((rows, cols), bool)
+    for a in range(4):
+        for b in range(4):
+            near |= pad[a:a + rows, b:b + cols]
+    w = (dx.astype(np.int64) + 1) | ((dy.astype(np.int64) + 1) << 2) | ((~near).astype(np.int64) << 7)
+    return w.astype(np.uint8)
+
+
+def pack_trimesh_samples(height_field_raw, warp):
+    """int16 samples followed by the per-vertex bytes, as one flat int16 array (the SHF_T_HEIGHTS payload of a
+    warped terrain)."""
+    hf = np.ascontiguousarray(height_field_raw, np.int16).reshape(-1)
+    wb = np.ascontiguousarray(warp, np.uint8).reshape(-1)
+    if wb.size % 2:
+        wb = np.concatenate([wb, np.zeros(1, np.uint8)])
+    return np.concatenate([hf, wb.view(np.int16)])
+
+
 def convert_heightfield_to_trimesh(height_field_raw, horizontal_scale, vertical_scale, slope_threshold=None):
     """(vertices (R*C,3) f32, triangles (2(R-1)(C-1),3) u32).  Where the slope between
     neighbouring samples exceeds the threshold the upper vertex is pulled over the
@@ -122,16 +167,9 @@ def convert_heightfield_to_trimesh(height_field_raw, horizontal_scale, vertical_
     x = np.linspace(0, (rows - 1) * horizontal_scale, rows)
     yy, xx = np.meshgrid(y, x)
     if slope_threshold is not None:
-        thr = slope_threshold * horizontal_scale / vertical_scale
-        move_x = np.zeros((rows, cols)); move_y = np.zeros((rows, cols)); move_c = np.zeros((rows, cols))
-        move_x[:rows - 1, :] += (hf[1:, :] - hf[:rows - 1, :] > thr)
-        move_x[1:, :] -= (hf[:rows - 1, :] - hf[1:, :] > thr)
-        move_y[:, :cols - 1] += (hf[:, 1:] - hf[:, :cols - 1] > thr)
-        move_y[:, 1:] -= (hf[:, :cols - 1] - hf[:, 1:] > thr)
-        move_c[:rows - 1, :cols - 1] += (hf[1:, 1:] - hf[:rows - 1, :cols - 1] > thr)
-        move_c[1:, 1:] -= (hf[:rows - 1, :cols - 1] - hf[1:, 1:] > thr)
-        xx = xx + (move_x + move_c * (move_x == 0)) * horizontal_scale
-        yy = yy + (move_y + move_c * (move_y == 0)) * horizontal_scale
+        dx, dy = vertex_shifts(hf, horizontal_scale, vertical_scale, slope_threshold)
+        xx = xx + dx * horizontal_scale
+        yy = yy + dy * horizontal_scale
     vertices = np.zeros((rows * cols, 3), dtype=np.float32)
     vertices[:, 0] = xx.flatten()
     vertices[:, 1] = yy.flatten()

@@ -144,7 +144,7 @@ class OnPolicyRunner:
         rec = {"iteration": locs["it"], "fps": n_samples / it_time, "collection_time": locs["collection_time"],
                "learn_time": locs["learn_time"], "value_loss": locs["mean_value_loss"],
                "surrogate_loss": locs["mean_surrogate_loss"], "learning_rate": self.alg.learning_rate,
-               "mean_noise_std": float(self.alg.actor_critic.std.mean()), "total_timesteps": self.tot_timesteps,
+               "mean_noise_std": float(self.alg.actor_critic.std.detach().mean()), "total_timesteps": self.tot_timesteps,
                "total_time": self.tot_time}
         if locs["ep_infos"]:
             for key in locs["ep_infos"][0]:

@@ -26,7 +26,8 @@ def _envs(n=64):
     np.random.seed(42)
     torch.manual_seed(0)
     hook = A1Conditional(cfg)
-    fused = FusedA1Env(num_envs=n, terrain="heightfield", terrain_seed=42, seed=3)
+    # A1EnvConfig builds the trimesh terrain (Q5): the fused env is given the same one
+    fused = FusedA1Env(num_envs=n, terrain="trimesh", terrain_seed=42, seed=3)
     return hook, fused
 
 
@@ -51,7 +52,9 @@ def _sync_state(hook, fused):
 
 def test_same_terrain_and_layout():
     hook, fused = _envs(32)
-    assert torch.equal(hook.isg_env.height_samples, fused.sim.tensors[_abi.T_HEIGHTS])
+    assert torch.equal(hook.isg_env.height_samples.cpu(), torch.from_numpy(fused.sim.height_samples))
+    assert hook.isg_env.sim.backend.terrain.warped == 1 and fused.sim.terrain.warped == 1
+    assert torch.equal(hook.isg_env.sim.backend.tensors[_abi.T_HEIGHTS], fused.sim.tensors[_abi.T_HEIGHTS])
     assert torch.equal(hook.isg_env.terrain_types, fused.task.tensors[_abi.A1_TYPES])
     assert torch.allclose(hook.isg_env.terrain_origins, fused.task.tensors[_abi.A1_TORIGINS])
     assert hook.robot.rigid_body_dict["base"] == 0 and hook.robot.num_bodies == 17 and hook.robot.num_dof == 12

@@ -50,13 +50,13 @@ def _random_states(m, n, rng, z_lo=0.15, z_hi=0.45, xy_hi=3.0):
 H_DEFAULT_Q = [0.1, 0.8, -1.5, 0.1, 0.8, -1.5, -0.1, 0.8, -1.5, -0.1, 0.8, -1.5]
 
 
-def _make_sim(cm, sp, n, terrain=None, heights=None, group=64, env_off=0):
+def _make_sim(cm, sp, n, terrain=None, heights=None, group=64, env_off=0, warp=None):
     from shifu_amd.backend import Sim
     sim = Sim(sp, "cuda:0")
     if terrain is None:
         sim.set_plane(1.0)
     else:
-        sim.set_heightfield(heights, terrain.hscale, terrain.vscale, terrain.border, terrain.friction)
+        sim.set_heightfield(heights, terrain.hscale, terrain.vscale, terrain.border, terrain.friction, warp=warp)
     sim.set_articulation(cm.blob)
     sim.finalize(n, env_off, group=group)
     return sim
@@ -439,3 +439,43 @@ def test_fused_step_generic_dimension_path(oracle, group):
         oracle.a1_step(cm.blob, sp, tp, n, 0, bufs, raw, terrain=terr, heights=hs)
         _compare(sim, task, bufs, f"step {it}")
     assert np.isfinite(bufs["obs"]).all()
+
+
+@pytest.mark.parametrize("group", [32, 16])
+def test_trimesh_terrain_matches_oracle_bitwise(oracle, group):
+    """the trimesh form of the terrain (vertical risers at steep steps; ShfTerrain.warped) -- simulate
+    and the fused step against the oracle, on a terrain whose plateau and noise shift many vertices."""
+    _need_gpu()
+    from shifu_amd.a1_task import a1_task_params
+    from shifu_amd.backend import A1Task
+    from shifu_amd.isaacgym.terrain_utils import pack_trimesh_samples, trimesh_warp_map
+    from shifu_amd.model import asset_path, compile_urdf
+    rng = np.random.default_rng(31)
+    cm = H.a1_model() if group == 32 else compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT,
+                                                        honour_dont_collapse=False)
+    sp = H.sim_params(angular_damping=0.5)
+    tp = a1_task_params(cm, num_rows=4, num_cols=5, env_length=0.8)
+    terr, hs = _terrain(rng, rows=80, cols=60, rough=True)
+    warp = trimesh_warp_map(hs, terr.hscale, terr.vscale, 0.75)
+    assert ((warp & 15) != 5).mean() > 0.02, "the test terrain must move vertices"
+    terr.warped = 1
+    packed = pack_trimesh_samples(hs, warp)
+    n = 48
+    bufs = _a1_buffers(cm, tp, n, rng, terr.rows, terr.cols)
+    sim = _make_sim(cm, sp, n, terr, hs, group=group, warp=warp)
+    assert sim.terrain.warped == 1 and sim.tensors[_abi.T_HEIGHTS].numel() == packed.size
+    task = A1Task(sim, tp)
+    _upload(sim, task, bufs)
+    for it in range(60):
+        raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32) * 1.5
+        task.step(torch.from_numpy(raw).cuda())
+        oracle.a1_step(cm.blob, sp, tp, n, 0, bufs, raw, terrain=terr, heights=packed)
+        _compare(sim, task, bufs, f"step {it}")
+    assert np.isfinite(bufs["obs"]).all()
+    # and it is a different surface from the height field: drop the same robots once on each
+    terr0, _ = _terrain(np.random.default_rng(31), rows=80, cols=60, rough=True)
+    dw, rw = _random_states(cm.blob, n, np.random.default_rng(5), z_lo=0.05, z_hi=0.25, xy_hi=5.0)
+    dh, rh = dw.copy(), rw.copy()
+    oracle.step(cm.blob, sp, n, dw, rw, nsteps=3, terrain=terr, heights=packed)
+    oracle.step(cm.blob, sp, n, dh, rh, nsteps=3, terrain=terr0, heights=hs)
+    assert not np.array_equal(rw, rh)

@@ -1,0 +1,87 @@
+"""Trimesh terrain contact: the warped-grid query of the oracle against the explicit triangle mesh
+convert_heightfield_to_trimesh builds (isaac_gym.py:369-385 hands that mesh to gym.add_triangle_mesh)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import pyoracle
+from shifu_amd import _abi
+from shifu_amd.isaacgym import terrain_utils as tu
+
+HS, VS = 0.1, 0.005
+
+
+def _terrain(hf, warped=1, border=0.0):
+    t = _abi.ShfTerrain()
+    t.rows, t.cols = hf.shape
+    t.hscale, t.vscale, t.border, t.friction, t.warped = HS, VS, border, 1.0, warped
+    return t
+
+
+def _brute_force(vertices, triangles, pts):
+    """Highest triangle of the explicit mesh over each point (float64, every triangle)."""
+    out = np.full(len(pts), -np.inf)
+    V = vertices.astype(np.float64)
+    for tri in triangles:
+        p0, p1, p2 = V[tri[0]], V[tri[1]], V[tri[2]]
+        d = (p1[0] - p0[0]) * (p2[1] - p0[1]) - (p2[0] - p0[0]) * (p1[1] - p0[1])
+        if abs(d) < 1e-12:
+            continue
+        for k, (x, y) in enumerate(pts):
+            l1 = ((x - p0[0]) * (p2[1] - p0[1]) - (p2[0] - p0[0]) * (y - p0[1])) / d
+            l2 = ((p1[0] - p0[0]) * (y - p0[1]) - (x - p0[0]) * (p1[1] - p0[1])) / d
+            if l1 >= -1e-9 and l2 >= -1e-9 and l1 + l2 <= 1 + 1e-9:
+                out[k] = max(out[k], p0[2] + l1 * (p1[2] - p0[2]) + l2 * (p2[2] - p0[2]))
+    return out
+
+
+def test_warp_map_reproduces_the_mesh_vertices():
+    rng = np.random.default_rng(0)
+    hf = (rng.integers(0, 4, (14, 11)) * 25).astype(np.int16)
+    v, _ = tu.convert_heightfield_to_trimesh(hf, HS, VS, 0.75)
+    w = tu.trimesh_warp_map(hf, HS, VS, 0.75)
+    ii, jj = np.meshgrid(np.arange(14), np.arange(11), indexing="ij")
+    dx, dy = (w & 3).astype(int) - 1, ((w >> 2) & 3).astype(int) - 1
+    np.testing.assert_allclose(v[:, 0].reshape(14, 11), (ii + dx) * HS, atol=1e-6)
+    np.testing.assert_allclose(v[:, 1].reshape(14, 11), (jj + dy) * HS, atol=1e-6)
+    assert (dx != 0).any() and (dy != 0).any()
+    moved = (dx != 0) | (dy != 0)
+    plain = (w & 0x80) != 0
+    for i in range(14):
+        for j in range(11):
+            assert plain[i, j] == (not moved[max(i - 1, 0):i + 3, max(j - 1, 0):j + 3].any())
+
+
+@pytest.mark.parametrize("threshold", [None, 0.75])
+def test_warped_query_equals_the_explicit_mesh(threshold):
+    rng = np.random.default_rng(1 if threshold else 2)
+    hf = (rng.integers(0, 5, (13, 12)) * 18).astype(np.int16)
+    v, tris = tu.convert_heightfield_to_trimesh(hf, HS, VS, threshold)
+    packed = tu.pack_trimesh_samples(hf, tu.trimesh_warp_map(hf, HS, VS, threshold))
+    pts = np.stack([rng.uniform(0.2, 1.0, 400), rng.uniform(0.2, 0.9, 400)], 1)     # border vertices may move inwards
+    want = _brute_force(v, tris, pts)
+    h64, n64 = pyoracle.terrain_query(_terrain(hf), packed, pts, f64=True)
+    h32, n32 = pyoracle.terrain_query(_terrain(hf), packed, pts)
+    ok = np.isfinite(want)
+    assert ok.all()
+    np.testing.assert_allclose(h64[ok], want[ok], atol=1e-6)       # hscale / vscale and the mesh vertices are float32
+    np.testing.assert_allclose(h32[ok], want[ok], atol=5e-6)
+    np.testing.assert_allclose(np.linalg.norm(n64, axis=1), 1.0, atol=1e-12)
+    assert (n64[:, 2] > 0).all()
+
+
+def test_steep_step_becomes_a_vertical_riser():
+    hf = np.zeros((12, 8), np.int16)
+    hf[5:, :] = 40                                          # 0.2 m step between rows 4 and 5
+    packed = tu.pack_trimesh_samples(hf, tu.trimesh_warp_map(hf, HS, VS, 0.75))
+    xs = np.array([0.30, 0.45, 0.49, 0.499, 0.501, 0.55, 0.80])
+    pts = np.stack([xs, np.full_like(xs, 0.35)], 1)
+    h, n = pyoracle.terrain_query(_terrain(hf), packed, pts, f64=True)
+    np.testing.assert_allclose(h, [0, 0, 0, 0, 0.2, 0.2, 0.2], atol=1e-12)
+    np.testing.assert_allclose(n, np.tile([0, 0, 1.0], (7, 1)), atol=1e-12)
+    # the height field of the same samples has a 63-degree ramp there instead
+    hh, _ = pyoracle.terrain_query(_terrain(hf, warped=0), hf, pts, f64=True)
+    assert 0.05 < hh[1] < 0.15 and hh[0] == 0 and hh[-1] == pytest.approx(0.2)
