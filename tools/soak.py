@@ -7,7 +7,8 @@ from shifu_amd.gym.a1_fused import FusedA1Env
 from shifu_amd.gym.abb_fused import FusedAbbEnv
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
-for name, env in (("a1", FusedA1Env(num_envs=4096, group=32)), ("abb", FusedAbbEnv(num_envs=4096))):
+for name, env in (("a1", FusedA1Env(num_envs=4096, group=32)), ("a1-trimesh", FusedA1Env(num_envs=4096, group=32, terrain="trimesh")),
+                  ("abb", FusedAbbEnv(num_envs=4096))):
     env.reset()
     t0 = time.time()
     bad = 0
