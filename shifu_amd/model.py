@@ -134,11 +134,12 @@ def parse_urdf(path: str) -> Tuple[Dict[str, _Link], List[_Joint]]:
         inertial = _Inertial()
         if ine is not None:
             p, R = _origin(ine)
-            I = ine.find("inertia")
-            g = lambda k: float(I.get(k, 0.0))
+            I = ine.find("inertia")          # URDFs in the wild omit <inertia> or <mass>: zero, like the importer
+            g = lambda k: float(I.get(k, 0.0)) if I is not None else 0.0
             It = np.array([[g("ixx"), g("ixy"), g("ixz")], [g("ixy"), g("iyy"), g("iyz")],
                            [g("ixz"), g("iyz"), g("izz")]])
-            inertial = _Inertial(float(ine.find("mass").get("value")), p, R @ It @ R.T)
+            mass_el = ine.find("mass")
+            inertial = _Inertial(float(mass_el.get("value")) if mass_el is not None else 0.0, p, R @ It @ R.T)
         shapes = []
         for c in l.findall("collision"):
             p, R = _origin(c)
