@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Roll a trained A1 policy (tools/train_a1.py checkpoint) on the fused env: the reference's run_mode='play'
+(shifu/runner/policy_runner.py:23-32) without a viewer.  Prints tracking errors and the fall rate, and can dump
+a trajectory for an offline viewer (shifu_amd/checkpoint.py).
+
+    python tools/play_a1.py gpurun_out/train_a1/model_300.pt [--envs 1024] [--steps 500] [--traj out.npz]
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("checkpoint")
+    ap.add_argument("--envs", type=int, default=1024)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--terrain", default="heightfield", choices=["heightfield", "trimesh", "flat"])
+    ap.add_argument("--traj", default=None)
+    args = ap.parse_args()
+    from examples.a1_conditional.task_config import A1PPOConfig
+    from shifu_amd.checkpoint import TrajectoryRecorder
+    from shifu_amd.gym.a1_fused import FusedA1Env
+    from shifu_amd.rl import OnPolicyRunner
+    from shifu_amd.runner.utils import class_to_dict
+    env = FusedA1Env(num_envs=args.envs, terrain=args.terrain, seed=7)
+    runner = OnPolicyRunner(env, class_to_dict(A1PPOConfig()), log_dir=None, device="cuda:0")
+    runner.load(args.checkpoint, load_optimizer=False)
+    policy = runner.get_inference_policy()
+    rec = TrajectoryRecorder(env, num_envs=8, bodies=True) if args.traj else None
+    env.reset()
+    obs = env.get_observations()
+    lin_err = ang_err = 0.0
+    falls = 0
+    with torch.no_grad():
+        for _ in range(args.steps):
+            obs, _, rew, done, extras = env.step(policy(obs.clone()))
+            bv = env.task.tensors[_abi.A1_BASE_VEL]               # base-frame lin (0:3) / ang (3:6) velocity
+            cmd = env.command_buf
+            lin_err += float((bv[:, :2] - cmd[:, :2]).norm(dim=1).mean())
+            ang_err += float((bv[:, 5] - cmd[:, 2]).abs().mean())
+            falls += int((done & ~env.time_out_buf).sum())
+            if rec:
+                rec.record()
+    out = {"checkpoint": args.checkpoint, "envs": args.envs, "steps": args.steps, "terrain": args.terrain,
+           "mean_lin_vel_error_m_s": lin_err / args.steps, "mean_yaw_rate_error_rad_s": ang_err / args.steps,
+           "falls_per_env_per_1000_steps": falls / args.envs / args.steps * 1000.0,
+           "mean_reward_per_step": float(rew.mean())}
+    if rec:
+        out["trajectory"] = rec.save(args.traj)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    from shifu_amd import _abi
+    main()
