@@ -254,3 +254,48 @@ def abb_stats(task_params, n, done_sums):
     fn.restype = None
     fn(C.byref(task_params), C.c_int(n), _p(done_sums, C.c_float), _p(out, C.c_float))
     return out
+
+
+# ---- golden G4 / G9 / G10 pieces (the static functions the fused oracle steps call) ----
+def glue_history(inputs, reset_after, reset_ids, H=3):
+    """HistoryRecorder.add per step (+ reset_idx after step `reset_after`): returns (bufs (K,n,nd,H), flats (K,n,nd*H))."""
+    x = _f(inputs)
+    K, n, nd = x.shape
+    ids = np.ascontiguousarray(reset_ids, np.int64)
+    bufs, flats = np.zeros((K, n, nd, H), np.float32), np.zeros((K, n, nd * H), np.float32)
+    lib().shf_oracle_glue_history_f32(C.c_int(n), C.c_int(nd), C.c_int(H), C.c_int(K), _p(x, C.c_float),
+                                      C.c_int(int(reset_after)), C.c_int(len(ids)), _p(ids, C.c_int64),
+                                      _p(bufs, C.c_float), _p(flats, C.c_float))
+    return bufs, flats
+
+
+def glue_quat_mul(a, b):
+    a, b = _f(a), _f(b)
+    out = np.zeros_like(a)
+    lib().shf_oracle_glue_quat_mul_f32(C.c_int(a.shape[0]), _p(a, C.c_float), _p(b, C.c_float), _p(out, C.c_float))
+    return out
+
+
+def glue_ik(j_ee, dof_pos, ee_pos, ee_quat, tar_pos, tar_quat, damping=0.05, f64=False):
+    """ArmRobot.inverse_kinematics: inputs float32 (as the tensors are), arithmetic in the build's real type."""
+    j, q, ep, eq, tp, tq = map(_f, (j_ee, dof_pos, ee_pos, ee_quat, tar_pos, tar_quat))
+    n, _, nd = j.shape
+    out = np.zeros((n, nd), np.float64 if f64 else np.float32)
+    fn = lib().shf_oracle_glue_ik_f64 if f64 else lib().shf_oracle_glue_ik_f32
+    fn(C.c_int(n), C.c_int(nd), _p(j, C.c_float), _p(q, C.c_float), _p(ep, C.c_float), _p(eq, C.c_float),
+       _p(tp, C.c_float), _p(tq, C.c_float), C.c_float(damping), _p(out, C.c_double if f64 else C.c_float))
+    return out
+
+
+def glue_abb_post(task_params, cube, goal, ee, ep_len):
+    """AbbPushBox obs / termination / rewards for given cube, goal, ee poses (n,7) and episode lengths."""
+    cube, goal, ee = _f(cube), _f(goal), _f(ee)
+    n = cube.shape[0]
+    ep = np.ascontiguousarray(ep_len, np.int64)
+    obs = np.zeros((n, 6), np.float32)
+    to, su, rs = np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    r0, r1 = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    lib().shf_oracle_glue_abb_post_f32(C.byref(task_params), C.c_int(n), _p(cube, C.c_float), _p(goal, C.c_float),
+                                       _p(ee, C.c_float), _p(ep, C.c_int64), _p(obs, C.c_float), _p(to, C.c_uint8),
+                                       _p(su, C.c_uint8), _p(rs, C.c_uint8), _p(r0, C.c_float), _p(r1, C.c_float))
+    return obs, to.astype(bool), su.astype(bool), rs.astype(bool), r0, r1

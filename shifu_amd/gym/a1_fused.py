@@ -63,13 +63,16 @@ class FusedA1Env:
     def __init__(self, num_envs: int = 4096, device="cuda:0", terrain: str = "heightfield", seed: int = 42,
                  rank: int = 0, world_size: int = 1, terrain_cfg=None, sim_params: Optional[_abi.ShfSimParams] = None,
                  group: int = 32, episode_length_s: float = 10.0, dt: float = 0.005, decimation: int = 4,
-                 terrain_seed: int = 42, send_timeouts: bool = True, extra_substep: bool = True):
+                 terrain_seed: int = 42, send_timeouts: bool = True, extra_substep: bool = True,
+                 model_edit=None, task_overrides: Optional[dict] = None):
         self.device = torch.device(device)
         self.num_envs = num_envs
         self.rank, self.world_size = rank, world_size
         self.env_id_offset = rank * num_envs
         total = num_envs * world_size
         self.cm = compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT)
+        if model_edit is not None:        # experiments: e.g. joint damping / armature the URDF leaves at zero
+            model_edit(self.cm)
         self.sim_params = sim_params or default_sim_params(dt=dt)
         self.dt = dt * decimation                                         # isaac_gym.py:26
         self.sim = Sim(self.sim_params, self.device)
@@ -110,6 +113,10 @@ class FusedA1Env:
                                           extra_substep=extra_substep, curriculum=ct.curriculum, num_rows=ct.num_rows, num_cols=ct.num_cols,
                                           env_length=ct.terrain_length, seed=seed,
                                           num_height_points=len(ct.measured_points_x) * len(ct.measured_points_y))
+        for k, v in (task_overrides or {}).items():
+            if not hasattr(self.task_params, k):
+                raise AttributeError(f"ShfA1TaskParams has no field '{k}'")
+            setattr(self.task_params, k, v)
         self.max_episode_length = np.ceil(episode_length_s / self.dt)     # env.py:42
         self.task = A1Task(self.sim, self.task_params)
         T, S = self.task.tensors, self.sim.tensors

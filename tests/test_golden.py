@@ -111,6 +111,55 @@ def test_oracle_episode_stats_g5(oracle):
     assert out[7] == len(ids)
 
 
+def test_oracle_history_recorder_g4(oracle):
+    """HistoryRecorder add / reset_idx / flatten (shifu/utils/train.py:12-35) as the fused oracle steps do it."""
+    g = load("g4_history")
+    bufs, flats = oracle.glue_history(g["inputs"], int(g["reset_after"]), g["reset_ids"], H=3)
+    np.testing.assert_array_equal(bufs, g["bufs"])
+    np.testing.assert_array_equal(flats, g["flats"])
+    np.testing.assert_array_equal(bufs[-1][:, :, 1], g["last1"])                     # get_last(1) = slot 1 = t-1
+    assert (bufs[int(g["reset_after"])][g["reset_ids"]] == 0).all()                  # rows zeroed AFTER that step's add (Q12)
+
+
+def test_oracle_quaternions_and_ik_g9(oracle):
+    """quat_mul (shifu/utils/torch_utils.py:12-33) bit for bit; damped-least-squares IK (robot.py:162-182):
+    the oracle solves (J J^T + 0.05^2 I) x = dpose by LDL^T where the reference calls torch.inverse, so the
+    float build agrees to the conditioning of the random 6x6 systems (measured worst: 3e-5 of the row's largest entry), and the
+    double build -- same code, same float32 inputs -- to float32 round-off of the reference's own result."""
+    g = load("g9_ik")
+    np.testing.assert_array_equal(oracle.glue_quat_mul(g["qa"], g["qb"]), g["quat_mul"])
+    args = (g["j_ee"], g["dof_pos"], g["ee_pos"], g["qa"], g["tar_pos"], g["qb"])
+    ik64 = oracle.glue_ik(*args, f64=True)
+    ik32 = oracle.glue_ik(*args)
+    scale = np.abs(g["ik"]).max(axis=1, keepdims=True)
+    assert (np.abs(ik64 - g["ik"]) / scale).max() < 1e-4                              # torch.inverse in float32 is the noisy side
+    assert (np.abs(ik32 - g["ik"]) / scale).max() < 1e-4
+    # independent float64 restatement of the reference formula on the same inputs
+    J = g["j_ee"].astype(np.float64)
+    qa, qb = g["qa"].astype(np.float64), g["qb"].astype(np.float64)
+    cc = np.concatenate([-qa[:, :3], qa[:, 3:]], 1)
+    qr = oracle.glue_quat_mul(g["qb"], cc.astype(np.float32)).astype(np.float64)
+    dpose = np.concatenate([g["tar_pos"].astype(np.float64) - g["ee_pos"], qr[:, :3] * np.sign(qr[:, 3:])], 1)[..., None]
+    u = (J.transpose(0, 2, 1) @ np.linalg.inv(J @ J.transpose(0, 2, 1) + np.eye(6) * 0.05 ** 2) @ dpose)[..., 0]
+    np.testing.assert_allclose(ik64, g["dof_pos"] + u, rtol=1e-5, atol=1e-5)
+
+
+def test_oracle_abb_pushbox_g10(oracle):
+    """AbbPushBox.compute_observations / compute_termination / reward_* (a_prior_stage.py:97-130)."""
+    from shifu_amd.abb_task import abb_model, abb_task_params
+    g = load("g10_abb")
+    tp = abb_task_params(abb_model())
+    assert tp.max_episode_length == float(g["max_episode_length"])
+    obs, to, su, rs, r0, r1 = oracle.glue_abb_post(tp, g["cube"], g["goal"], g["ee"][:, 0], g["ep_len"])
+    np.testing.assert_array_equal(obs, g["obs"])
+    np.testing.assert_array_equal(to, g["time_out"])
+    np.testing.assert_array_equal(su, g["success"])
+    np.testing.assert_array_equal(rs, g["reset"])
+    np.testing.assert_allclose(r0, g["reward_reaching"], rtol=2e-6, atol=1e-7)       # exp_spec vs torch.exp
+    np.testing.assert_array_equal(r1, g["reward_success"])
+    assert to.any() and su.any() and (r0 > 0).any() and (rs & ~to & ~su).any()       # every branch exercised
+
+
 # ---------------------------------------------------------- (B) host-side mirror --
 def _my_a1(g, n):
     from examples.a1_conditional.a1_conditional import A1Conditional
