@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SHF_ABI_VERSION 2
+#define SHF_ABI_VERSION 3
 
 #define SHF_MAX_BODIES 32 /* reported rigid bodies per articulation        */
 #define SHF_MAX_DOFS 32
@@ -128,6 +128,10 @@ typedef struct ShfSimParams {
   float angular_damping; /* AssetOptions.angular_damping default 0.5 (root)*/
   float max_ang_vel;     /* AssetOptions.max_angular_velocity default 64   */
   float max_depen_vel;   /* physx.max_depenetration_velocity = 1.0 (env_config.py:57) */
+  float contact_offset;  /* physx.contact_offset = 0.01 m (env_config.py:54): a point this close to a surface is
+                          * tested, and responds if it would be below the surface at the end of the step
+                          * (speculative contact: an impact is stopped at the surface instead of one step later,
+                          * v dt deep)                                                                        */
 } ShfSimParams;
 
 typedef struct ShfTerrain {

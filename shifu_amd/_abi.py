@@ -1,7 +1,7 @@
 """ctypes mirrors of the PODs in include/shifu_amd.h (keep in lock-step)."""
 import ctypes as C
 
-SHF_ABI_VERSION = 2
+SHF_ABI_VERSION = 3
 MAX_BODIES = 32
 MAX_DOFS = 32
 MAX_POINTS = 96
@@ -46,7 +46,7 @@ class ShfScene(C.Structure):
 class ShfSimParams(C.Structure):
     _fields_ = [("dt", f32), ("gravity", f32 * 3), ("contact_k", f32), ("contact_d", f32),
                 ("friction_vel", f32), ("limit_k", f32), ("limit_d", f32),
-                ("angular_damping", f32), ("max_ang_vel", f32), ("max_depen_vel", f32)]
+                ("angular_damping", f32), ("max_ang_vel", f32), ("max_depen_vel", f32), ("contact_offset", f32)]
 
 
 class ShfTerrain(C.Structure):

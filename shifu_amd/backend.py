@@ -25,13 +25,14 @@ def default_sim_params(dt: float = 0.005, gravity=(0.0, 0.0, -9.81), **kw) -> _a
     p.dt = dt
     p.gravity[:] = gravity
     p.contact_k = kw.get("contact_k", 5e4)
-    p.contact_d = kw.get("contact_d", 100.0)
-    p.friction_vel = kw.get("friction_vel", 0.02)
+    p.contact_d = kw.get("contact_d", 300.0)
+    p.friction_vel = kw.get("friction_vel", 0.002)
     p.limit_k = kw.get("limit_k", 2000.0)
     p.limit_d = kw.get("limit_d", 20.0)
     p.angular_damping = kw.get("angular_damping", 0.5)  # AssetOptions default [EXT]
     p.max_ang_vel = kw.get("max_ang_vel", 64.0)          # AssetOptions default [EXT]
     p.max_depen_vel = kw.get("max_depen_vel", 1.0)       # env_config.py:57
+    p.contact_offset = kw.get("contact_offset", 0.01)    # env_config.py:54
     return p
 
 

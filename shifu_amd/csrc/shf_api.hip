@@ -215,11 +215,14 @@ __global__ __launch_bounds__(256) void k_body_state(const ShfModel* gm, int n, c
 }
 
 __global__ void k_commit_rows(const float* src, float* dst, const int32_t* idx, int n, int row_words, int idx_div,
-                              int rows_per_idx_words) {
-  // one block row per index entry: copies `rows_per_idx_words` floats of row (idx/idx_div)
+                              int rows_per_idx_words, int num_rows) {
+  // one block per index entry: copies `rows_per_idx_words` floats of row (idx/idx_div).  Indices come from user
+  // tensors (set_*_tensor_indexed): an entry outside [0, num_rows * idx_div) is skipped rather than written through.
   const int i = blockIdx.x;
   if (i >= n) return;
-  const size_t r = (size_t)(idx[i] / idx_div) * row_words;
+  const int32_t a = idx[i];
+  if (a < 0 || a / idx_div >= num_rows) return;
+  const size_t r = (size_t)(a / idx_div) * row_words;
   for (int k = threadIdx.x; k < rows_per_idx_words; k += blockDim.x) dst[r + k] = src[r + k];
 }
 
@@ -942,8 +945,11 @@ extern "C" int shf_sim_finalize(ShfSim* sim, int32_t num_envs, int64_t env_id_of
   return 0;
 }
 extern "C" int shf_sim_set_group(ShfSim* sim, int32_t lanes) {
+  if (!sim) return fail("shf_sim_set_group: null sim");
   if (lanes != 64 && lanes != 32 && lanes != 16) return fail("shf_sim_set_group: lanes must be 16, 32 or 64");
-  if (sim->model.nb > lanes || sim->model.nd * 2 > 2 * lanes) return fail("shf_sim_set_group: model does not fit the group");
+  if (!sim->has_model) return fail("shf_sim_set_group: set the articulation first");
+  if (sim->model.nb + sim->nboxes > lanes || sim->model.nd > lanes)
+    return fail("shf_sim_set_group: bodies + box actors (or dofs) exceed the lane group");
   sim->group = lanes;
   return 0;
 }
@@ -1114,7 +1120,7 @@ extern "C" int shf_sim_commit_root_indexed(ShfSim* sim, const float* root_dev, c
   if (n <= 0) return 0;
   if (!root_dev || !actor_idx_dev) return fail("shf_sim_commit_root_indexed: null argument");
   return launch(k_commit_rows, dim3(n), dim3(64), 0, stream, root_dev, (float*)sim->t[SHF_T_SIM_ROOT], actor_idx_dev,
-                (int)n, 13, 1, 13);
+                (int)n, 13, 1, 13, (int)(sim->n * (1 + sim->nboxes)));
 }
 extern "C" int shf_sim_commit_root_all(ShfSim* sim, const float* root_dev, void* stream) {
   if (int r = need(sim, {SHF_T_SIM_ROOT}, "shf_sim_commit_root_all")) return r;
@@ -1129,7 +1135,7 @@ extern "C" int shf_sim_commit_dof_indexed(ShfSim* sim, const float* dof_dev, con
   if (!dof_dev || !actor_idx_dev) return fail("shf_sim_commit_dof_indexed: null argument");
   const int nd = sim->model.nd;
   return launch(k_commit_rows, dim3(n), dim3(64), 0, stream, dof_dev, (float*)sim->t[SHF_T_SIM_DOF], actor_idx_dev,
-                (int)n, nd * 2, 1 + sim->nboxes, nd * 2);
+                (int)n, nd * 2, 1 + sim->nboxes, nd * 2, (int)sim->n);
 }
 extern "C" int shf_sim_set_pos_target_indexed(ShfSim* sim, const float* values_dev, const int32_t* actor_idx_dev,
                                               int32_t n, void* stream) {
@@ -1138,7 +1144,7 @@ extern "C" int shf_sim_set_pos_target_indexed(ShfSim* sim, const float* values_d
   if (!values_dev || !actor_idx_dev) return fail("shf_sim_set_pos_target_indexed: null argument");
   const int nd = sim->model.nd;
   return launch(k_commit_rows, dim3(n), dim3(64), 0, stream, values_dev, (float*)sim->t[SHF_T_POS_TARGET],
-                actor_idx_dev, (int)n, nd, 1 + sim->nboxes, nd);
+                actor_idx_dev, (int)n, nd, 1 + sim->nboxes, nd, (int)sim->n);
 }
 
 extern "C" int shf_sim_reset_all(ShfSim* sim, const float* default_root_dev, const float* default_dof_dev,
@@ -1160,6 +1166,8 @@ extern "C" int shf_a1_create(ShfSim* sim, const ShfA1TaskParams* params, ShfA1Ta
   if (params->num_height_points > 192) return fail("shf_a1_create: at most 192 height points");
   if (sim->model.nd * params->num_history > 96) return fail("shf_a1_create: action history too large");
   if (sim->model.nb * 13 > SCR_MH) return fail("shf_a1_create: too many bodies for the staging area");
+  if (sim->terr.warped && sim->group == 64)
+    return fail("shf_a1_create: a trimesh terrain needs 16 or 32 lanes per env (the 128-VGPR instantiation has no room for it)");
   ShfA1Task* t = new ShfA1Task();
   t->sim = sim;
   t->tp = *params;

@@ -14,16 +14,16 @@
 DEV bool box_is_dynamic(const ShfBoxDesc& b) { return !b.fixed && b.mass > 0.0f; }
 
 // slot layout in LDS (PT_STRIDE floats): r[3] n[3] f0[3] ct bn on (PT_* offsets, shf_device.h)
-DEV void slot_eval(float* o, float phi, const float* n, const float* r, const float* vp, float mu, float kc,
-                   float beta, float veps, float vdep) {
+DEV void slot_eval(float* o, float phi, const float* n, const float* r, const float* vs, const float* vp, float mu, float kc,
+                   float beta, float veps, float vdep, float dt, float offset) {
   float on = 0.0f;
-  if (phi < 0.0f) {
+  if (phi < offset) {
     const float vn = dot3(n, vp);
-    const float fn = fmaf(-beta, vn, rminf(-kc * phi, beta * vdep));
-    if (fn > 0.0f) {
+    const float pen = rminf(-kc * phi, beta * vdep);
+    const float fn = fmaf(-beta, vn, pen);
+    if ((phi < 0.0f || fmaf(dt, vn, phi) < 0.0f) && fn > 0.0f) {
       const float vt[3] = {fmaf(-vn, n[0], vp[0]), fmaf(-vn, n[1], vp[1]), fmaf(-vn, n[2], vp[2])};
-      const float vtn = sqrtf(dot3(vt, vt));
-      const float ct = mu * fn / rmaxf(vtn, veps);
+      const float ct = friction_coefficient(n, vs, pen, mu, beta, veps);
       on = 1.0f;
       o[PT_CT] = ct;
       o[PT_BN] = beta;
@@ -225,6 +225,7 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
   const SceneDev* S = C.scene;
   const int nb = m->nb, nbx = S->nboxes, T = 1 + nbx;
   const float dt = C.sp.dt, kc = C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
+  const float offset = C.sp.contact_offset;
   const float beta = fmaf(kc, dt, C.sp.contact_d);
   const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
   PHASE_BEGIN();
@@ -240,17 +241,17 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
                           ((c & 1) ? 0.5f : -0.5f) * bd.dim[2]};
 #pragma unroll
     for (int i = 0; i < 9; i++) Rk[i] = pk[i];
-    float r[3], t[3], vp[3], n[3], h, phi, vb[3] = {pk[12], pk[13], pk[14]};
+    float r[3], t[3], vs[3], vp[3], n[3], h, phi, vb[3] = {pk[12], pk[13], pk[14]};
     mv3(Rk, lc, r);
 #pragma unroll
     for (int i = 0; i < 3; i++) r[i] += pk[9 + i];
     cross3(vb, r, t);
 #pragma unroll
-    for (int i = 0; i < 3; i++) vp[i] = fmaf(dt, gb[i], pk[15 + i] + t[i]);
+    for (int i = 0; i < 3; i++) { vs[i] = pk[15 + i] + t[i]; vp[i] = fmaf(dt, gb[i], vs[i]); }
     if (tg == 0) {
       terrain_query(C.terr, L.root[0] + r[0], L.root[1] + r[1], &h, n);
       phi = (L.root[2] + r[2] - h) * n[2];
-      slot_eval(o, phi, n, r, vp, 0.5f * (bd.friction + C.terr.t.friction), kc, beta, veps, vdep);
+      slot_eval(o, phi, n, r, vs, vp, 0.5f * (bd.friction + C.terr.t.friction), kc, beta, veps, vdep, dt, offset);
     } else {
       const int ks = tg - 1;
       const ShfBoxDesc& bs = S->box[ks];
@@ -260,7 +261,7 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
 #pragma unroll
       for (int i = 0; i < 9; i++) Rs[i] = ps[i];
       if (!point_in_box(Rs, bpos, hh, r, &phi, n)) continue;
-      slot_eval(o, phi, n, r, vp, 0.5f * (bd.friction + bs.friction), kc, beta, veps, vdep);
+      slot_eval(o, phi, n, r, vs, vp, 0.5f * (bd.friction + bs.friction), kc, beta, veps, vdep, dt, offset);
     }
   }
   PHASE_MARK(17);
@@ -281,14 +282,18 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
 #pragma unroll
     for (int i = 0; i < 3; i++) c[i] += pb[9 + i];
     const float hh[3] = {0.5f * bd.dim[0], 0.5f * bd.dim[1], 0.5f * bd.dim[2]}, bpos[3] = {pk[9], pk[10], pk[11]};
-    float phi, n[3], rc[3], ta[3], tb[3], vrel[3];
+    float phi, n[3], rc[3], ta[3], tb[3], vrel[3], vrs[3];
     sphere_vs_box(Rk, bpos, hh, c, m->sph_radius[si], &phi, n, rc);
     const float va[3] = {pb[12], pb[13], pb[14]}, vbx[3] = {pk[12], pk[13], pk[14]};
     cross3(va, rc, ta);
     cross3(vbx, rc, tb);
 #pragma unroll
-    for (int i = 0; i < 3; i++) vrel[i] = fmaf(dt, g_art[i], pb[15 + i] + ta[i]) - fmaf(dt, gb[i], pk[15 + i] + tb[i]);
-    slot_eval(o, phi, n, rc, vrel, 0.5f * (mu_shape + bd.friction), kc, beta, veps, vdep);
+    for (int i = 0; i < 3; i++) {
+      const float pa = pb[15 + i] + ta[i], pq = pk[15 + i] + tb[i];
+      vrs[i] = pa - pq;
+      vrel[i] = fmaf(dt, g_art[i], pa) - fmaf(dt, gb[i], pq);
+    }
+    slot_eval(o, phi, n, rc, vrs, vrel, 0.5f * (mu_shape + bd.friction), kc, beta, veps, vdep, dt, offset);
   }
   GROUP_SYNC();
   PHASE_MARK(18);

@@ -683,6 +683,17 @@ DEV void ldlt_solve6(const float* IA, const float* pA, float* x) {
   }
 }
 
+// Tangential coefficient c_t of the regularised Coulomb law f_t = -c_t v_t(end of step), c_t = mu f_n / max(|v_t|, v_eps),
+// with the bound taken from the START-of-step relative velocity `vs` of the point (normal force k pen - beta v_n and
+// tangential speed as they are now).  The force itself is linearised about the free-fall prediction vp = vs + dt g;
+// taking the bound from vp too would add beta dt g ~ 17 N to the normal force of every touching point.
+DEV float friction_coefficient(const float* n, const float* vs, float pen, float mu, float beta, float veps) {
+  const float vns = dot3(n, vs);
+  const float fns = rmaxf(fmaf(-beta, vns, pen), 0.0f);
+  const float vts[3] = {fmaf(-vns, n[0], vs[0]), fmaf(-vns, n[1], vs[1]), fmaf(-vns, n[2], vs[2])};
+  return mu * fns / rmaxf(sqrtf(dot3(vts, vts)), veps);
+}
+
 #include "shf_boxes.h"
 
 // Sample-point constants of the lane's contact rounds (point l + k*G in round k), for models whose point
@@ -708,25 +719,27 @@ DEV void lane_points_load(const ShfModel* m, int np, int l, LanePoints<NR>& P) {
 }
 
 struct ContactConsts {
-  float dt, g[3], kc, beta, mu, veps, max_depen;
+  float dt, g[3], kc, beta, mu, veps, max_depen, offset;
 };
-// Response of one penetrating sample point (phi < 0): r is moved to the contact point; writes the slot, returns `on`.
+// Response of one sample point within the contact offset (phi < offset): r is moved to the contact point; the point
+// responds if it is below the surface now or would be at the end of the step (speculative contact); writes the slot,
+// returns `on`.
 DEV float contact_point_response(const ContactConsts& K, const float* pb, float* r, const float* n, float rad, float phi, float* o) {
   float on = 0.0f;
 #pragma unroll
   for (int k = 0; k < 3; k++) r[k] = fmaf(-rad, n[k], r[k]);
-  float vb[6], vp[3], t[3];
+  float vb[6], vs[3], vp[3], t[3];
 #pragma unroll
   for (int k = 0; k < 6; k++) vb[k] = pb[12 + k];
   cross3(vb, r, t);
 #pragma unroll
-  for (int k = 0; k < 3; k++) vp[k] = fmaf(K.dt, K.g[k], vb[3 + k] + t[k]);
+  for (int k = 0; k < 3; k++) { vs[k] = vb[3 + k] + t[k]; vp[k] = fmaf(K.dt, K.g[k], vs[k]); }
   const float vn = dot3(n, vp);
-  const float fn = fmaf(-K.beta, vn, rminf(-K.kc * phi, K.beta * K.max_depen));
-  if (fn > 0.0f) {
+  const float pen = rminf(-K.kc * phi, K.beta * K.max_depen);
+  const float fn = fmaf(-K.beta, vn, pen);
+  if ((phi < 0.0f || fmaf(K.dt, vn, phi) < 0.0f) && fn > 0.0f) {
     float vt[3] = {fmaf(-vn, n[0], vp[0]), fmaf(-vn, n[1], vp[1]), fmaf(-vn, n[2], vp[2])};
-    const float vtn = sqrtf(dot3(vt, vt));
-    const float ct = K.mu * fn / rmaxf(vtn, K.veps);
+    const float ct = friction_coefficient(n, vs, pen, K.mu, K.beta, K.veps);
     on = 1.0f;
     o[PT_CT] = ct;
     o[PT_BN] = K.beta;
@@ -839,7 +852,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
   const float kc = C.sp.contact_k, dc = C.sp.contact_d, veps = C.sp.friction_vel;
   const float beta = fmaf(kc, dt, dc);
   const float mu = 0.5f * (mu_shape + C.terr.t.friction);
-  const ContactConsts K = {dt, {g[0], g[1], g[2]}, kc, beta, mu, veps, C.sp.max_depen_vel};
+  const ContactConsts K = {dt, {g[0], g[1], g[2]}, kc, beta, mu, veps, C.sp.max_depen_vel, C.sp.contact_offset};
   unsigned long long active[LANE_ROUNDS(G, DM)];
   if constexpr (DM::NPC > 0 && G < 64) {
     // known point count: pass 1 places every round's point and queries the terrain without branches, so the
@@ -865,7 +878,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
       float on = 0.0f;
       if (i < DM::NPC) {
         float* o = L.pt + i * PT_STRIDE;
-        if (phi[k] < 0.0f) on = contact_point_response(K, L.pose + P.body(k) * POSE_STRIDE, r[k], n[k], P.rad[k], phi[k], o);
+        if (phi[k] < K.offset) on = contact_point_response(K, L.pose + P.body(k) * POSE_STRIDE, r[k], n[k], P.rad[k], phi[k], o);
         o[PT_ON] = on;
       }
       // bit j = point k*G + j of this env is in contact
@@ -886,7 +899,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
       const float phi = fmaf(L.root[2] + r[2] - h, n[2], -rad);
       float* o = L.pt + i * PT_STRIDE;
       float on = 0.0f;
-      if (phi < 0.0f) on = contact_point_response(K, pb, r, n, rad, phi, o);
+      if (phi < K.offset) on = contact_point_response(K, pb, r, n, rad, phi, o);
       o[PT_ON] = on;
     }
   }

@@ -64,14 +64,20 @@ class FusedA1Env:
                  rank: int = 0, world_size: int = 1, terrain_cfg=None, sim_params: Optional[_abi.ShfSimParams] = None,
                  group: int = 32, episode_length_s: float = 10.0, dt: float = 0.005, decimation: int = 4,
                  terrain_seed: int = 42, send_timeouts: bool = True, extra_substep: bool = True,
-                 model_edit=None, task_overrides: Optional[dict] = None):
+                 model_edit=None, task_overrides: Optional[dict] = None, dof_stiffness: float = 20.0,
+                 dof_damping: float = 0.5):
         self.device = torch.device(device)
         self.num_envs = num_envs
         self.rank, self.world_size = rank, world_size
         self.env_id_offset = rank * num_envs
         total = num_envs * world_size
         self.cm = compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT)
-        if model_edit is not None:        # experiments: e.g. joint damping / armature the URDF leaves at zero
+        # A1ActorConfig.dof_damping (task_config.py:22-23) reaches the simulator twice in the reference: as the explicit
+        # PD's d gain (a1_conditional.py:66) and, through dof_props['damping'] (robot.py:35-37), as the joint's passive
+        # damping, which stays active in EFFORT mode ([EXT], see isaacgym/gymapi.py prepare_sim)
+        for d in range(self.cm.blob.nd):
+            self.cm.blob.damping[d] = dof_damping
+        if model_edit is not None:        # experiments: e.g. other joint damping / armature
             model_edit(self.cm)
         self.sim_params = sim_params or default_sim_params(dt=dt)
         self.dt = dt * decimation                                         # isaac_gym.py:26
@@ -111,7 +117,7 @@ class FusedA1Env:
         self.max_episode_length_s = episode_length_s
         self.task_params = a1_task_params(self.cm, dt=dt, decimation=decimation, episode_length_s=episode_length_s,
                                           extra_substep=extra_substep, curriculum=ct.curriculum, num_rows=ct.num_rows, num_cols=ct.num_cols,
-                                          env_length=ct.terrain_length, seed=seed,
+                                          env_length=ct.terrain_length, seed=seed, kp=dof_stiffness, kd=dof_damping,
                                           num_height_points=len(ct.measured_points_x) * len(ct.measured_points_y))
         for k, v in (task_overrides or {}).items():
             if not hasattr(self.task_params, k):

@@ -355,7 +355,8 @@ class Gym:
         from ..backend import Sim, default_sim_params
         p = sim.params
         sp = default_sim_params(dt=p.dt, gravity=tuple(p.gravity),
-                                max_depen_vel=min(float(p.physx.max_depenetration_velocity), 10.0))
+                                max_depen_vel=min(float(p.physx.max_depenetration_velocity), 10.0),
+                                contact_offset=float(p.physx.contact_offset))
         dev = torch.device("cuda", sim.device_id if isinstance(sim.device_id, int) and sim.device_id >= 0 else 0)
         be = Sim(sp, dev)
         if sim.terrain is None or sim.terrain[0] == "plane":
@@ -379,6 +380,16 @@ class Gym:
                 m.drive_mode[d] = int(robot.dof_props["driveMode"][d])
                 m.kp[d] = float(robot.dof_props["stiffness"][d])
                 m.kd[d] = float(robot.dof_props["damping"][d])
+                # [EXT] dof_props['damping'] is the joint's passive damping (it is what <dynamics damping> of the URDF
+                # is imported into); PhysX keeps applying it when the drive is off (DOF_MODE_NONE / EFFORT), where only
+                # the position spring ('stiffness') has no target to act on.  shifu writes dof_stiffness / dof_damping
+                # into the props in every mode (robot.py:35-37), so the torque-controlled A1 carries 0.5 N m s/rad of
+                # implicit joint damping next to its explicit PD -- without it PPO on the reference schedule never
+                # leaves the standing optimum in this simulator (profiles/r02_walk_ablation.json).
+                if m.drive_mode[d] in (DOF_MODE_NONE, DOF_MODE_EFFORT):
+                    m.damping[d] = float(robot.dof_props["damping"][d])
+                if "armature" in robot.dof_props.dtype.names:
+                    m.armature[d] = float(robot.dof_props["armature"][d])
         be.set_articulation(m)
         for a in env0.actors[1:]:
             if a.asset.kind != "box":

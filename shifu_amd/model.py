@@ -193,15 +193,96 @@ def _shape_points(shape: _Shape) -> List[Tuple[np.ndarray, float]]:
     return pts
 
 
+def _shape_inertial(shape: _Shape, density: float) -> _Inertial:
+    """Uniform-density inertial of a collision primitive, in the link frame."""
+    if shape.kind == "box":
+        x, y, z = shape.size
+        m = density * x * y * z
+        I = np.diag([m * (y * y + z * z) / 12.0, m * (x * x + z * z) / 12.0, m * (x * x + y * y) / 12.0])
+    elif shape.kind == "sphere":
+        r = float(shape.size[0])
+        m = density * 4.0 / 3.0 * np.pi * r ** 3
+        I = np.eye(3) * 0.4 * m * r * r
+    else:                                            # capsule along z: cylinder + two half spheres
+        r, L = float(shape.size[0]), float(shape.size[1])
+        mc, ms = density * np.pi * r * r * L, density * 4.0 / 3.0 * np.pi * r ** 3
+        m = mc + ms
+        ixx = mc * (3 * r * r + L * L) / 12.0 + ms * (0.4 * r * r + 0.25 * L * L + 0.375 * r * L)
+        I = np.diag([ixx, ixx, 0.5 * mc * r * r + 0.4 * ms * r * r])
+    return _Inertial(m, shape.pos.copy(), shape.rot @ I @ shape.rot.T)
+
+
+def _fill_missing_inertials(links: Dict[str, _Link], density: float):
+    """[EXT] Isaac Gym derives the mass properties of a link that has none from its collision geometry and
+    AssetOptions.density (default 1000 kg/m^3; asset_config.py:47-51 leaves it alone).  Same here for the collision
+    primitives this backend knows; a link given a mass but no inertia tensor keeps its mass and gets the shape of the
+    geometry's tensor.  Mesh-only links stay as parsed (and are refused by _check_inertia where that matters)."""
+    for l in links.values():
+        if not l.shapes:
+            continue
+        has_I = np.abs(l.inertial.I).max() > 0.0
+        if l.inertial.mass > 0.0 and has_I:
+            continue
+        geo = _Inertial()
+        for sh in l.shapes:
+            geo = geo.merged(_shape_inertial(sh, density))
+        if geo.mass <= 0.0:
+            continue
+        if l.inertial.mass > 0.0:
+            l.inertial = _Inertial(l.inertial.mass, l.inertial.com, geo.I * (l.inertial.mass / geo.mass))
+        else:
+            l.inertial = geo
+
+
+def _check_inertia(names, parent, jtype, dyn, tpos, trot, axis, merged, armature, fixed_base):
+    """Refuse a model whose forward dynamics would divide by zero.  The articulated-body recursion inverts, for every
+    joint, D = S^T I_A S + armature, where I_A contains the inertia of the whole subtree below the joint, and for a
+    floating base the 6x6 articulated inertia of the root.  URDFs may omit <mass>/<inertia> (parsed as zero, like
+    Isaac Gym's importer -- which then derives them from the collision geometry and a density; this compiler does
+    not), so a massless subtree behind a moving joint, or a massless floating root, is rejected here instead of
+    producing inf/NaN for the whole env on the GPU (and in the oracle alike)."""
+    nb = len(names)
+    Rw, pw = [np.eye(3)] * nb, [np.zeros(3)] * nb
+    for b in range(1, nb):                       # zero-configuration world frames
+        pb = parent[b]
+        Rw[b], pw[b] = Rw[pb] @ trot[b], pw[pb] + Rw[pb] @ tpos[b]
+    sub = [_Inertial() for _ in range(nb)]       # composite inertia of the subtree, world frame, about its own com
+    for b in range(nb):
+        if dyn[b] == b:
+            sub[b] = merged[b].transformed(pw[b], Rw[b])
+    for b in range(nb - 1, 0, -1):
+        if dyn[b] == b:
+            a = dyn[parent[b]]
+            sub[a] = sub[a].merged(sub[b])
+    for b in range(1, nb):
+        if dyn[b] != b:
+            continue
+        if jtype[b] == _abi.JOINT_PRISMATIC:
+            d = sub[b].mass
+        else:
+            aw = Rw[b] @ axis[b]
+            c = sub[b].com - pw[b]
+            d = aw @ (sub[b].I + sub[b].mass * (c @ c * np.eye(3) - np.outer(c, c))) @ aw
+        if not (d + armature > 1e-12):
+            raise ValueError(f"link '{names[b]}': the subtree behind its joint has no mass/inertia about the joint axis "
+                             f"(URDF without <mass>/<inertia>?) and armature is 0 -- forward dynamics would divide by zero; "
+                             f"give the link an <inertial> or pass armature > 0")
+    if not fixed_base:
+        if not (sub[0].mass > 1e-12) or np.linalg.eigvalsh(sub[0].I).min() <= 1e-14:
+            raise ValueError(f"floating root '{names[0]}': total mass {sub[0].mass:g} / rotational inertia is not positive "
+                             f"definite -- the 6x6 root solve would divide by zero; give the links <inertial> data")
+
+
 def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: bool = False,
                  collapse_fixed_joints: bool = True, default_dof_drive_mode: int = _abi.DOF_MODE_NONE,
                  armature: float = 0.0, honour_dont_collapse: bool = True,
-                 extra_spheres: Sequence[Tuple[str, Sequence[float], float]] = ()) -> CompiledModel:
+                 extra_spheres: Sequence[Tuple[str, Sequence[float], float]] = (), density: float = 1000.0) -> CompiledModel:
     """Compile `path` with the AssetOptions the reference passes (asset_config.py:32-46).
 
     extra_spheres: (link name, xyz in that link's frame, radius) collision spheres
     tested against box actors -- the substitute for mesh colliders (ABB rod)."""
     links, joints = parse_urdf(path)
+    _fill_missing_inertials(links, density)
     children: Dict[str, List[_Joint]] = {n: [] for n in links}
     is_child = set()
     for j in joints:
@@ -285,6 +366,8 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
             p, R = dyn_T[b]
             merged[dyn[b]] = merged[dyn[b]].merged(inert[b].transformed(p, R))
             merged[b] = _Inertial()
+
+    _check_inertia(names, parent, jtype, dyn, tpos, trot, axis, merged, armature, bool(fix_base_link))
 
     m = _abi.ShfModel()
     m.nb = nb

@@ -1,0 +1,55 @@
+"""Tiny single-purpose models for the contact known-answer tests (tests/test_contact_kats.py and its GPU twin)."""
+import os
+import tempfile
+
+import numpy as np
+
+from shifu_amd import _abi
+from shifu_amd.model import compile_urdf
+
+BOX_URDF = """<robot name="block"><link name="block">
+ <inertial><mass value="{m}"/><inertia ixx="{ixx}" ixy="0" ixz="0" iyy="{iyy}" iyz="0" izz="{izz}"/></inertial>
+ <collision><geometry><box size="{x} {y} {z}"/></geometry></collision></link></robot>"""
+SPHERE_URDF = """<robot name="ball"><link name="ball">
+ <inertial><mass value="{m}"/><inertia ixx="{i}" ixy="0" ixz="0" iyy="{i}" iyz="0" izz="{i}"/></inertial>
+ <collision><geometry><sphere radius="{r}"/></geometry></collision></link></robot>"""
+LIMIT_URDF = """<robot name="lim"><link name="world_link"/>
+ <link name="bar"><inertial><origin xyz="0 0 -0.2"/><mass value="1.0"/>
+  <inertia ixx="0.01" ixy="0" ixz="0" iyy="0.01" iyz="0" izz="0.01"/></inertial></link>
+ <joint name="hinge" type="revolute"><parent link="world_link"/><child link="bar"/><axis xyz="0 1 0"/>
+  <limit effort="{effort}" lower="{lo}" upper="{up}" velocity="100"/></joint></robot>"""
+
+
+def _compile(text, **kw):
+    with tempfile.NamedTemporaryFile("w", suffix=".urdf", delete=False) as f:
+        f.write(text)
+        path = f.name
+    try:
+        return compile_urdf(path, **kw)
+    finally:
+        os.unlink(path)
+
+
+def block_model(x=0.2, y=0.2, z=0.1, m=2.0):
+    return _compile(BOX_URDF.format(m=m, x=x, y=y, z=z, ixx=m * (y * y + z * z) / 12, iyy=m * (x * x + z * z) / 12,
+                                    izz=m * (x * x + y * y) / 12))
+
+
+def ball_model(r=0.05, m=1.0):
+    return _compile(SPHERE_URDF.format(m=m, r=r, i=0.4 * m * r * r))
+
+
+def limit_model(lo=-0.5, up=0.5, effort=30.0):
+    return _compile(LIMIT_URDF.format(lo=lo, up=up, effort=effort), fix_base_link=True, disable_gravity=True,
+                    default_dof_drive_mode=_abi.DOF_MODE_EFFORT)
+
+
+def root_row(pos, quat=(0, 0, 0, 1), lin=(0, 0, 0), ang=(0, 0, 0), dtype=np.float32):
+    r = np.zeros((1, 13), dtype)
+    r[0, :3], r[0, 3:7], r[0, 7:10], r[0, 10:13] = pos, quat, lin, ang
+    return r
+
+
+G = 9.81
+# contact parameters of shifu_amd.backend.default_sim_params (what every env in this repo runs with)
+K_N, D_N, V_EPS, DT = 5e4, 300.0, 0.002, 0.005

@@ -102,8 +102,9 @@ def test_empty_and_oversize_inputs_are_refused_on_the_host(libpath):
     assert l.shf_sim_finalize(h, 0, 0) != 0 and b"num_envs" in l.shf_last_error()
     assert l.shf_sim_finalize(h, -3, 0) != 0
     assert l.shf_sim_set_group(h, 48) != 0 and b"16, 32 or 64" in l.shf_last_error()
-    assert l.shf_sim_set_group(h, 16) != 0 and b"does not fit" in l.shf_last_error()     # 17 bodies > 16 lanes
+    assert l.shf_sim_set_group(h, 16) != 0 and b"exceed the lane group" in l.shf_last_error()     # 17 bodies > 16 lanes
     assert l.shf_sim_set_group(h, 32) == 0
+    assert l.shf_sim_set_group(None, 32) != 0 and b"null" in l.shf_last_error()
     box = _abi.ShfBoxDesc()
     box.dim[0] = box.dim[1] = box.dim[2] = 0.1
     for _ in range(4):

@@ -1,0 +1,160 @@
+"""Known-answer tests of the contact model that replaces PhysX -- the only pins the contact
+physics can have, Isaac Gym being absent: Coulomb stick / slip on an incline, sliding deceleration, impact without
+rebound, resting penetration, the regularisation creep, and the joint-limit spring.  Parameters replaced:
+reference shifu/configs/env_config.py:50-58 (PhysX contact_offset / bounce_threshold / max_depenetration_velocity)
+and :82-84 (terrain friction 1.0, restitution 0); friction combine = average ([EXT] PhysX default).
+
+Each scenario runs on the double AND the float build of the CPU oracle; tests/test_gpu_parity.py::test_contact_kats_*
+runs the same scenarios on the HIP kernels (bit-equal to the float oracle, and against the same analytic numbers)."""
+import numpy as np
+import pytest
+
+from tests import kat_models as K
+from tests.helpers import sim_params
+
+PREC = [pytest.param(True, id="f64"), pytest.param(False, id="f32")]
+
+
+def run_block(oracle, f64, theta, mu_shape, steps, lin=(0, 0, 0), dt_sim=K.DT):
+    """Block resting on the plane under gravity tilted by `theta` about y (an incline of that slope)."""
+    dt = np.float64 if f64 else np.float32
+    cm = K.block_model()
+    sp = sim_params(dt=dt_sim, gravity=(K.G * np.sin(theta), 0.0, -K.G * np.cos(theta)))
+    pen = 2.0 * K.G * np.cos(theta) / (4 * K.K_N)                 # static sag of the four bottom corners
+    root = K.root_row((0, 0, 0.05 - pen), lin=lin, dtype=dt)
+    dof = np.zeros((0, 2), dt)
+    fr = np.full(1, mu_shape, np.float32)
+    traj = []
+    for k in range(steps):
+        oracle.step(cm.blob, sp, 1, dof, root, friction=fr, f64=f64)
+        traj.append(root[0].copy())
+    return np.array(traj)
+
+
+@pytest.mark.parametrize("f64", PREC)
+def test_block_sticks_below_the_friction_angle_and_creeps_at_the_regularisation_speed(oracle, f64):
+    """tan(theta) = 0.3 < mu = 0.6: the block does not slide.  Regularised Coulomb friction holds a tangential load
+    T with a steady creep v = v_eps * T / (mu N) = v_eps * tan(theta) / mu -- 0.01 m/s here, the stated bound on
+    'static' creep being v_eps = 0.02 m/s (reached only at the friction limit)."""
+    mu_shape, mu = 0.2, 0.6
+    th = np.arctan(0.3)
+    tr = run_block(oracle, f64, th, mu_shape, 600)
+    v = tr[-1, 7]
+    assert abs(v - K.V_EPS * 0.3 / mu) < 2e-4, v
+    assert v < K.V_EPS
+    assert np.abs(tr[-200:, 7] - v).max() < 1e-5                   # steady, no stick-slip chatter
+    assert np.abs(tr[-1, 10:13]).max() < 1e-4 and abs(tr[-1, 8]) < 1e-6   # no rotation, no sideways drift
+    assert abs(tr[-1, 2] - tr[0, 2]) < 2e-4                        # stays on the surface
+
+
+@pytest.mark.parametrize("f64", PREC)
+def test_block_slides_above_the_friction_angle_with_coulomb_acceleration(oracle, f64):
+    """tan(theta) = 1 > mu = 0.6: a = g (sin(theta) - mu cos(theta)) along the slope.  The friction force of a sliding
+    point is mu f_n |v_end| / |v_start| (isotropic linearly-implicit law: unconditionally stable, no stick-slip
+    chatter on light links), i.e. mu f_n up to a relative error a dt / v = 1 / (step index) when starting from rest:
+    the acceleration is right once the block moves (within 1.2 % over the second half-second), and the start-up costs
+    a fixed velocity offset of order mu g cos(theta) dt ln(n) (0.17 m/s at dt = 5 ms) that halves with dt."""
+    mu_shape, mu = 0.2, 0.6
+    th = np.arctan(1.0)
+    a = K.G * (np.sin(th) - mu * np.cos(th))
+    off = []
+    for dt_sim in (K.DT, K.DT / 2):
+        n = int(round(1.0 / dt_sim))
+        tr = run_block(oracle, f64, th, mu_shape, n, dt_sim=dt_sim)
+        assert np.abs(tr[-1, 10:13]).max() < 1e-3                  # slides flat, does not tumble
+        acc = (tr[-1, 7] - tr[n // 2 - 1, 7]) / 0.5
+        assert abs(acc - a) < 0.012 * a, (acc, a)
+        off.append(a * 1.0 - tr[-1, 7])
+    assert 0.0 < off[0] < 0.2 and 0.45 < off[1] / off[0] < 0.65, off   # start-up offset: bounded, first order in dt
+
+
+@pytest.mark.parametrize("f64", PREC)
+def test_sliding_block_decelerates_at_mu_g_and_stops(oracle, f64):
+    """Level ground, v0 = 1 m/s: deceleration mu g (to the same first order in dt), stopping distance
+    v0^2 / (2 mu g), then rest -- no creep without load."""
+    mu_shape, mu, v0 = 0.6, 0.8, 1.0
+    tr = run_block(oracle, f64, 0.0, mu_shape, 200, lin=(v0, 0, 0))
+    tr2 = run_block(oracle, f64, 0.0, mu_shape, 400, lin=(v0, 0, 0), dt_sim=K.DT / 2)
+    dec = (v0 - tr[9, 7]) / (10 * K.DT)
+    dec2 = (v0 - tr2[19, 7]) / (10 * K.DT)
+    assert 0.0 < mu * K.G - dec < 0.06 * mu * K.G, dec
+    assert 0.4 < (mu * K.G - dec2) / (mu * K.G - dec) < 0.65       # first order in dt
+    d = v0 * v0 / (2 * mu * K.G)
+    assert d < tr[-1, 0] < 1.08 * d, (tr[-1, 0], d)
+    assert abs(tr[-1, 7]) < 1e-4 and abs(tr2[-1, 7]) < 1e-4        # at rest
+
+
+@pytest.mark.parametrize("f64", PREC)
+def test_dropped_sphere_does_not_rebound_and_rests_at_mg_over_k(oracle, f64):
+    """restitution 0 (env_config.py:84).  A 1 kg sphere dropped from 0.5 m (3.1 m/s at impact): the speculative
+    contact (physx.contact_offset, env_config.py:54) catches it in the step that would cross the surface, it
+    penetrates < 3 mm, never leaves the ground again (depenetration at < 5 % of the impact speed, PhysX caps this with
+    max_depenetration_velocity) and rests m g / k = 0.196 mm deep."""
+    dt = np.float64 if f64 else np.float32
+    cm = K.ball_model()
+    sp = sim_params()
+    root = K.root_row((0, 0, 0.55), dtype=dt)
+    dof = np.zeros((0, 2), dt)
+    fr = np.ones(1, np.float32)
+    z, vz = [], []
+    for k in range(400):
+        oracle.step(cm.blob, sp, 1, dof, root, friction=fr, f64=f64)
+        z.append(root[0, 2] - 0.05); vz.append(root[0, 9])
+    z, vz = np.array(z), np.array(vz)
+    hit = int(np.argmax(z < 0))
+    assert 3.0 < -vz[:hit + 1].min() < 3.2                         # sqrt(2 g 0.5) = 3.13 m/s
+    assert vz[hit:].max() < 0.05 * 3.13, vz[hit:].max()            # outward speed while the spring relaxes
+    assert z[hit:].max() < 0.0, z[hit:].max()                      # never airborne again: no bounce
+    assert z.min() > -0.003, z.min()                               # bounded penetration
+    assert abs(-z[-1] - 1.0 * K.G / K.K_N) < 0.05 * K.G / K.K_N     # static sag
+    assert abs(vz[-1]) < 1e-5
+
+
+@pytest.mark.parametrize("f64", PREC)
+def test_joint_limit_spring_holds_the_effort_limit(oracle, f64):
+    """A hinge driven into its upper limit with its full URDF effort (30 N m; the A1's calf has 55 N m against the
+    same spring): the implicit limit spring k = 2000 N m/rad, d = 20 stops it tau / k = 15 mrad past the limit,
+    without chatter."""
+    dt = np.float64 if f64 else np.float32
+    cm = K.limit_model()
+    sp = sim_params()
+    dof = np.zeros((1, 2), dt)
+    root = K.root_row((0, 0, 1.0), dtype=dt)
+    tau = np.full(1, 30.0, dt)
+    q = []
+    for k in range(600):
+        oracle.step(cm.blob, sp, 1, dof, root, effort=tau, f64=f64)
+        q.append(dof[0, 0])
+    q = np.array(q)
+    assert abs(q[-1] - (0.5 + 30.0 / 2000.0)) < 2e-4, q[-1]
+    assert abs(dof[0, 1]) < 1e-4
+    assert q.max() < 0.5 + 0.08        # it arrives at 24.5 rad/s (30 N m on 0.05 kg m^2 over 0.5 rad): overshoot ~ omega I / (d + dt k)
+    tau[:] = 0
+    for k in range(400):
+        oracle.step(cm.blob, sp, 1, dof, root, effort=tau, f64=f64)
+    assert abs(dof[0, 0] - 0.5) < 2e-3 and abs(dof[0, 1]) < 1e-2   # released: back at the limit, at rest
+
+
+def test_standing_a1_holds_a_horizontal_push_below_the_friction_limit(oracle):
+    """A1 standing on stiff position drives (implicit PD, kp 200 / kd 5) with a sustained horizontal push on the trunk:
+    40 N (mu m g = 0.9 * 122 N = 110 N) -- the feet hold, the trunk drifts slower than v_eps; 150 N -- it is pushed away."""
+    from shifu_amd import _abi
+    from tests.helpers import a1_model
+    cm = a1_model(default_dof_drive_mode=_abi.DOF_MODE_POS)
+    m = cm.blob
+    for d in range(m.nd):
+        m.kp[d], m.kd[d] = 200.0, 5.0
+    q0 = np.array([0.1, 0.8, -1.5, 0.1, 0.8, -1.5, -0.1, 0.8, -1.5, -0.1, 0.8, -1.5], np.float32)
+    out = {}
+    for F in (40.0, 150.0):
+        sp = sim_params()
+        dof = np.zeros((12, 2), np.float32); dof[:, 0] = q0
+        root = K.root_row((0, 0, 0.32))
+        fr = np.full(1, 0.8, np.float32)
+        push = np.zeros((m.nb, 3), np.float32)
+        for k in range(600):
+            push[0, 0] = F if k >= 200 else 0.0
+            oracle.step(m, sp, 1, dof, root, pos_target=q0, friction=fr, body_force=push)
+        out[F] = root[0].copy()
+    assert abs(out[40.0][7]) < K.V_EPS and out[40.0][2] > 0.25 and abs(out[40.0][0]) < 0.05, out[40.0]
+    assert out[150.0][0] > 0.5 or out[150.0][2] < 0.15, out[150.0]

@@ -61,38 +61,76 @@ def test_same_terrain_and_layout():
     assert hook.obs_buf.shape == fused.obs_buf.shape == (32, 259)
 
 
-def test_hook_env_matches_fused_env_until_first_reset():
+def _compare_step(hook, fused, it, m, o1, o2, r1, r2, obs_from=0):
+    n = hook.num_envs
+    assert torch.equal(hook.isg_env.dof_state.view(n, -1)[m], fused.dof_state.view(n, -1)[m]), f"dof step {it}"
+    assert torch.equal(hook.isg_env.contact_state.view(n, -1)[m], fused.contact_state.view(n, -1)[m])
+    assert torch.allclose(hook.isg_env.body_state.view(n, -1)[m], fused.body_state.view(n, -1)[m], atol=0, rtol=0)
+    # get_heights truncates float positions to cell indices: torch's GPU kernels and the spec'd
+    # kernel arithmetic may round a point lying on a cell edge to different sides -- allow 0.2 %
+    hm = hook.isg_env.measured_heights[m] != fused.measured_heights[m]
+    assert hm.float().mean() < 2e-3, f"heights step {it}: {hm.float().mean()}"
+    assert torch.allclose(o1[m][:, obs_from:72], o2[m][:, obs_from:72], rtol=1e-5, atol=1e-5), f"obs step {it}"
+    ho = ~torch.isclose(o1[m][:, 72:], o2[m][:, 72:], rtol=1e-5, atol=1e-5)
+    assert ho.float().mean() < 2e-3, f"height obs step {it}"
+    assert torch.allclose(r1[m], r2[m], rtol=1e-5, atol=1e-5), f"rew step {it}"
+
+
+def test_hook_env_matches_fused_env_through_resets():
+    """The path a user runs (hooks in torch over the `gym` facade, reference call order env.py:93-130) against the
+    fused kernel, THROUGH episode ends: on the step an env resets, rewards are those of the finished episode
+    (computed before the reset), the observation is taken after it -- default joint state, zeroed action history,
+    pre-reset measured heights against the re-spawned base height, and the base-frame velocities of the step
+    before (Q2/Q15) -- and the history then receives the pre-reset action (Q12).  Only the three freshly sampled
+    command entries differ that step (torch's generator vs the kernel's Philox stream); the fused env's draws
+    (spawn xy, command, push) are then copied into the hook env and the comparison goes on, bit for bit in state."""
     n = 64
     hook, fused = _envs(n)
     fused.task.reset_all()
+    T, S = fused.task.tensors, fused.sim.tensors
+    T[_abi.A1_EP_LEN][:8] = 490          # time-outs (ep_len > 500) fall inside the run, next to contact terminations
     _sync_state(hook, fused)
+    be = hook.isg_env.sim.backend
     g = torch.Generator(device="cuda:0")
     g.manual_seed(5)
-    compared = 0
-    alive = torch.ones(n, dtype=torch.bool, device="cuda:0")
-    for it in range(60):
+    resets = timeouts = after_reset = 0
+    was_reset = torch.zeros(n, dtype=torch.bool, device="cuda:0")
+    for it in range(80):
         a = 2 * torch.rand(n, 12, device="cuda:0", generator=g) - 1
-        o1, _, r1, d1, _ = hook.step(a)
-        o2, _, r2, d2, _ = fused.step(a)
+        o1, _, r1, d1, x1 = hook.step(a)
+        o2, _, r2, d2, x2 = fused.step(a)
         assert torch.equal(d1.bool(), d2), f"reset masks differ at step {it}"
-        alive &= ~d2          # after an env resets the two RNGs diverge by design
-        if not alive.any():
-            break
-        m = alive
-        assert torch.equal(hook.isg_env.dof_state.view(n, -1)[m], fused.dof_state.view(n, -1)[m]), f"dof step {it}"
-        assert torch.equal(hook.isg_env.root_state[m], fused.root_state[m]), f"root step {it}"
-        assert torch.equal(hook.isg_env.contact_state.view(n, -1)[m], fused.contact_state.view(n, -1)[m])
-        assert torch.allclose(hook.isg_env.body_state.view(n, -1)[m], fused.body_state.view(n, -1)[m], atol=0, rtol=0)
-        # get_heights truncates float positions to cell indices: torch's GPU kernels and the spec'd
-        # kernel arithmetic may round a point lying on a cell edge to different sides -- allow 0.2 %
-        hm = hook.isg_env.measured_heights[m] != fused.measured_heights[m]
-        assert hm.float().mean() < 2e-3, f"heights step {it}: {hm.float().mean()}"
-        assert torch.allclose(o1[m][:, :72], o2[m][:, :72], rtol=1e-5, atol=1e-5), f"obs step {it}"
-        ho = ~torch.isclose(o1[m][:, 72:], o2[m][:, 72:], rtol=1e-5, atol=1e-5)
-        assert ho.float().mean() < 2e-3, f"height obs step {it}"
-        assert torch.allclose(r1[m], r2[m], rtol=1e-5, atol=1e-5), f"rew step {it}"
-        compared += int(m.sum())
-    assert compared > 20 * n // 2
+        assert torch.equal(hook.time_out_buf, fused.time_out_buf), f"time-outs differ at step {it}"
+        assert torch.equal(hook.episode_length_buf, fused.episode_length_buf)
+        keep = ~d2
+        _compare_step(hook, fused, it, keep, o1, o2, r1, r2)
+        assert torch.equal(hook.isg_env.root_state[keep], fused.root_state[keep]), f"root step {it}"
+        assert torch.equal(hook.actions_recorder.history_buf, T[_abi.A1_HISTORY]), f"history step {it}"
+        if d2.any():
+            ids = d2.nonzero().flatten()
+            # the reset step itself: everything but the new command (obs[0:3]) and the random spawn xy
+            _compare_step(hook, fused, it, d2, o1, o2, r1, r2, obs_from=3)
+            assert torch.equal(hook.isg_env.root_state[ids][:, 2:], fused.root_state[ids][:, 2:])
+            assert (o2[ids][:, 12 + 12:12 + 24] == 0).all() and (o2[ids][:, 36:72] == 0).all()   # dof_vel, history
+            assert torch.equal(T[_abi.A1_HISTORY][ids][:, :, 0], fused.actions[ids])             # then a_k lands in slot 0
+            assert torch.equal(hook.terrain_levels, fused.terrain_levels)
+            assert torch.equal(hook.isg_env.env_origins, T[_abi.A1_ORIGINS])
+            # extras["episode"] = mean(sum[env_ids]) / T_s over the envs that finished this step (env.py:149-158)
+            for k, name in enumerate(hook.episode_rewards):
+                torch.testing.assert_close(x1["episode"][name], x2["episode"][name], rtol=1e-5, atol=1e-6)
+            assert float(x2["episode_sums"][7]) == len(ids)
+            # adopt the fused env's draws and go on
+            for tid in (_abi.T_ROOT_STATE, _abi.T_SIM_ROOT):
+                be.tensors[tid][ids] = S[_abi.T_ROOT_STATE][ids]
+            hook.command_buf[ids] = T[_abi.A1_COMMAND][ids]
+            hook.robot.rand_force_buf[ids] = T[_abi.A1_PUSH][ids]
+            resets += len(ids)
+            timeouts += int(fused.time_out_buf.sum())
+        for k, name in enumerate(hook.episode_rewards):
+            torch.testing.assert_close(hook.episode_rewards[name], T[_abi.A1_REW_SUMS][k], rtol=1e-5, atol=1e-5)
+        after_reset += int((was_reset & keep).sum())
+        was_reset |= d2
+    assert resets > 10 and timeouts >= 8 and after_reset > 100, (resets, timeouts, after_reset)
 
 
 def test_hook_env_random_run_mode_is_stable():

@@ -479,3 +479,71 @@ def test_trimesh_terrain_matches_oracle_bitwise(oracle, group):
     oracle.step(cm.blob, sp, n, dw, rw, nsteps=3, terrain=terr, heights=packed)
     oracle.step(cm.blob, sp, n, dh, rh, nsteps=3, terrain=terr0, heights=hs)
     assert not np.array_equal(rw, rh)
+
+
+# ---------------------------------------------------------------- contact KATs on the GPU --
+def _kat_run(oracle, cm, sp, dof0, root0, steps, mu_shape=1.0, effort=None, group=16):
+    """The same single-env scenario on the HIP kernel (through the C ABI) and on the float oracle: asserts bit-equal
+    state every step and returns the trajectory."""
+    m = cm.blob
+    dof, root = dof0.astype(np.float32).copy(), root0.astype(np.float32).copy()
+    fr = np.full(1, mu_shape, np.float32)
+    sim = _make_sim(cm, sp, 1, group=group)
+    T = sim.tensors
+    T[_abi.T_SIM_DOF].copy_(torch.from_numpy(dof))
+    T[_abi.T_SIM_ROOT].copy_(torch.from_numpy(root))
+    T[_abi.T_FRICTION].copy_(torch.from_numpy(fr))
+    if effort is not None:
+        sim.set_dof_command(_abi.T_EFFORT, torch.from_numpy(effort).cuda())
+    traj_r, traj_q = [], []
+    for k in range(steps):
+        sim.step()
+        oracle.step(m, sp, 1, dof, root, effort=effort, friction=fr)
+        if k % 10 == 9 or k == steps - 1:
+            sim.refresh(_abi.REFRESH_DOF | _abi.REFRESH_ROOT)
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(T[_abi.T_ROOT_STATE].cpu().numpy(), root, err_msg=f"root step {k}")
+            if m.nd:
+                np.testing.assert_array_equal(T[_abi.T_DOF_STATE].cpu().numpy(), dof, err_msg=f"dof step {k}")
+        traj_r.append(root[0].copy()); traj_q.append(dof[:, 0].copy() if m.nd else None)
+    sim.destroy()
+    return np.array(traj_r), traj_q
+
+
+def test_contact_kats_stick_slip_impact_on_the_gpu(oracle):
+    """tests/test_contact_kats.py on the HIP path: the kernel equals the float oracle bit for bit on every scenario,
+    and the analytic answers are asserted on what the GPU produced: creep v_eps tan(theta)/mu below the friction
+    angle, Coulomb acceleration above it, mu g deceleration and stopping distance, inelastic sphere impact with
+    m g / k rest penetration."""
+    _need_gpu()
+    from tests import kat_models as K
+    blk = K.block_model()
+    nodof = np.zeros((0, 2), np.float32)
+
+    def block(theta, mu_shape, steps, lin=(0, 0, 0)):
+        sp = H.sim_params(gravity=(K.G * np.sin(theta), 0.0, -K.G * np.cos(theta)))
+        pen = 2.0 * K.G * np.cos(theta) / (4 * K.K_N)
+        return _kat_run(oracle, blk, sp, nodof, K.root_row((0, 0, 0.05 - pen), lin=lin), steps, mu_shape)[0]
+    tr = block(np.arctan(0.3), 0.2, 600)
+    assert abs(tr[-1, 7] - K.V_EPS * 0.3 / 0.6) < 0.02 * K.V_EPS and np.abs(tr[-1, 10:13]).max() < 1e-4
+    th = np.arctan(1.0)
+    tr = block(th, 0.2, 200)
+    a = K.G * (np.sin(th) - 0.6 * np.cos(th))
+    assert abs((tr[-1, 7] - tr[99, 7]) / 0.5 - a) < 0.012 * a
+    tr = block(0.0, 0.6, 200, lin=(1.0, 0, 0))
+    d = 1.0 / (2 * 0.8 * K.G)
+    assert d < tr[-1, 0] < 1.08 * d and abs(tr[-1, 7]) < 1e-4
+    tr = _kat_run(oracle, K.ball_model(), H.sim_params(), nodof, K.root_row((0, 0, 0.55)), 400)[0]
+    z, vz = tr[:, 2] - 0.05, tr[:, 9]
+    hit = int(np.argmax(z < 0))
+    assert vz[hit:].max() < 0.05 * 3.13 and z[hit:].max() < 0.0 and z.min() > -0.003
+    assert abs(-z[-1] - K.G / K.K_N) < 0.05 * K.G / K.K_N
+
+
+def test_contact_kats_joint_limit_on_the_gpu(oracle):
+    _need_gpu()
+    from tests import kat_models as K
+    cm = K.limit_model()
+    tr, q = _kat_run(oracle, cm, H.sim_params(), np.zeros((1, 2), np.float32), K.root_row((0, 0, 1.0)), 600,
+                     effort=np.full(1, 30.0, np.float32))
+    assert abs(q[-1][0] - (0.5 + 30.0 / 2000.0)) < 2e-4 and max(x[0] for x in q) < 0.58

@@ -27,7 +27,7 @@ def test_vendored_robots():
 def test_every_reference_urdf_compiles_or_is_refused_with_a_reason():
     paths = sorted(glob.glob(os.path.join(REF, "**", "*.urdf"), recursive=True))
     assert len(paths) > 20
-    refused = []
+    refused, massless = [], []
     for p in paths:
         try:
             cm = compile_urdf(p)
@@ -35,8 +35,49 @@ def test_every_reference_urdf_compiles_or_is_refused_with_a_reason():
             assert "SHF_MAX" in str(e), (p, e)
             refused.append(os.path.basename(p))
             continue
+        except ValueError as e:                # a massless subtree behind a moving joint / massless floating root
+            assert "divide by zero" in str(e), (p, e)
+            massless.append(os.path.basename(p))
+            continue
         m = cm.blob
         assert 1 <= m.nb <= _abi.MAX_BODIES and 0 <= m.nd <= 32 and len(cm.body_names) == m.nb and len(cm.dof_names) == m.nd
         assert all(m.parent[b] < b for b in range(1, m.nb)), "bodies are numbered parents-first"
         assert sum(m.pt_count[b] for b in range(m.nb)) == m.np
     assert refused == ["anymal.urdf"]          # 143 collision sample points > SHF_MAX_POINTS (96)
+    print("refused for missing inertia:", massless)
+
+
+MASSLESS = """<robot name="m">
+ <link name="base"><inertial><mass value="1"/><inertia ixx="0.01" ixy="0" ixz="0" iyy="0.01" iyz="0" izz="0.01"/></inertial></link>
+ <link name="arm">{inertial}</link>
+ <joint name="j" type="revolute"><parent link="base"/><child link="arm"/><axis xyz="0 1 0"/>
+  <limit effort="10" lower="-1" upper="1" velocity="10"/></joint>
+</robot>"""
+
+
+def test_massless_moving_body_is_refused_or_steps_finite(tmp_path, oracle):
+    """A link without <mass>/<inertia> behind a revolute joint makes the joint-space inertia D = S^T I S exactly zero:
+    the compiler refuses it (message names the link), accepts it with armature > 0, and a model it accepts steps to
+    finite state."""
+    import numpy as np
+    from tests.helpers import sim_params
+    path = tmp_path / "m.urdf"
+    path.write_text(MASSLESS.format(inertial=""))
+    with pytest.raises(ValueError, match="arm"):
+        compile_urdf(str(path), default_dof_drive_mode=_abi.DOF_MODE_EFFORT)
+    path.write_text(MASSLESS.format(inertial='<inertial><mass value="0"/></inertial>'))
+    with pytest.raises(ValueError, match="divide by zero"):
+        compile_urdf(str(path), default_dof_drive_mode=_abi.DOF_MODE_EFFORT)
+    for kw, text in (({"armature": 0.01}, ""),
+                     ({}, '<inertial><origin xyz="0 0 -0.1"/><mass value="0.2"/><inertia ixx="1e-4" ixy="0" ixz="0" iyy="1e-4" iyz="0" izz="1e-4"/></inertial>')):
+        path.write_text(MASSLESS.format(inertial=text))
+        cm = compile_urdf(str(path), default_dof_drive_mode=_abi.DOF_MODE_EFFORT, **kw)
+        dof = np.zeros((1, 2), np.float32)
+        root = np.zeros((1, 13), np.float32); root[0, 2] = 1.0; root[0, 6] = 1.0
+        oracle.step(cm.blob, sim_params(), 1, dof, root, nsteps=50, effort=np.full(1, 0.5, np.float32))
+        assert np.isfinite(dof).all() and np.isfinite(root).all()
+    # a massless floating root is refused as well
+    path.write_text('<robot name="r"><link name="only"/></robot>')
+    with pytest.raises(ValueError, match="floating root"):
+        compile_urdf(str(path))
+    assert compile_urdf(str(path), fix_base_link=True).blob.nb == 1

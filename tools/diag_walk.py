@@ -16,15 +16,17 @@ import numpy as np
 import torch
 
 
+def joint_edit(d, arm):
+    def edit(cm):
+        for k in range(cm.blob.nd):
+            cm.blob.damping[k] = d
+            cm.blob.armature[k] = arm
+    return edit
+
+
 def variants():
     from shifu_amd.backend import default_sim_params
-
-    def damp(d, arm):
-        def edit(cm):
-            for k in range(cm.blob.nd):
-                cm.blob.damping[k] = d
-                cm.blob.armature[k] = arm
-        return edit
+    damp = joint_edit
     V = {
         "base": {},
         "flat": {"env": {"terrain": "flat"}},
@@ -82,13 +84,19 @@ def main():
     results = {}
     import builtins
     for name in args.variants.split(","):
-        spec = V[name]
+        if name.startswith("jd:"):          # jd:<damping>:<armature>[:seed]
+            f = name.split(":")
+            spec = {"env": {"model_edit": joint_edit(float(f[1]), float(f[2]))}}
+            if len(f) > 3:
+                spec["seed"] = int(f[3])
+        else:
+            spec = V[name]
         cfg = class_to_dict(A1PPOConfig())
         cfg["algorithm"].update(spec.get("alg", {}))
         cfg["runner"]["graph_rollout"] = True
-        set_seed(A1PPOConfig.seed)
-        env = FusedA1Env(num_envs=args.envs, device="cuda:0", **spec.get("env", {}))
-        log_dir = os.path.join("gpurun_out", "diag_walk", name)
+        set_seed(spec.get("seed", A1PPOConfig.seed))
+        env = FusedA1Env(num_envs=args.envs, device="cuda:0", seed=spec.get("seed", 42), **spec.get("env", {}))
+        log_dir = os.path.join("/tmp", "diag_walk", name.replace(":", "_"))
         runner = OnPolicyRunner(env, cfg, log_dir=log_dir, device="cuda:0")
         _print, builtins.print = builtins.print, (lambda *a, **k: None)
         t0 = time.time()
