@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
-"""Headline benchmark: env-steps/s of the vectorised A1 env step (BASELINE.json).
+"""Headline benchmark: env-steps/s of the vectorised env step (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W [--workload terrain|flat] [--envs 4096]
+    python bench.py --gpus N --steps K --warmup W [--workload terrain|flat|trimesh|abb] [--envs 4096]
 
 One "step" = one ShifuVecEnv.step over all envs of this rank with random actions
-`2*rand-1` (the reference's run_mode='random' driver, shifu/runner/policy_runner.py:33-41):
-5 physics sub-steps (Q1), get_heights, termination, 6 reward terms, on-device resets,
-259-dim observation -- all inside shf_a1_step -- plus the episode-stat reduction and,
-for N>1, an RCCL all-gather of the (sum,count) episode statistics every 24 steps
-(the only cross-rank traffic: envs shard with no data-path collective, "weak" scaling).
+`2*rand-1` (the reference's run_mode='random' driver, shifu/runner/policy_runner.py:33-41).
+A1 workloads (configs 2-4): 5 physics sub-steps (Q1), get_heights, termination, 6 reward terms,
+on-device resets, 259-dim observation and the episode-statistics reduction -- all inside
+shf_a1_step.  `abb` (config 5, examples/abb_pushbox_vision/a_prior_stage.py:67-135): in-kernel
+IK, 6 sub-steps of 20 ms with box contacts, refresh, termination, rewards, re-spawn, observation
+inside shf_abb_step.  For N>1 an RCCL all-gather of the (sum,count) episode statistics every 24
+steps is the only cross-rank traffic: envs shard with no data-path collective ("weak" scaling).
 
-Rank 0 prints ONE JSON line.  `roofline.achieved` = B_alg x envs / mean duration of the
-fused kernel, measured with HIP events on the launch stream inside the timed region;
-`cpu_baseline` times the CPU oracle (a port, not the reference: Isaac Gym is not
+Rank 0 prints ONE JSON line.  `roofline.achieved` = B_alg x envs / mean duration of the fused
+kernel, measured with HIP events on the launch stream inside the timed region; `roofline.secondary`
+prices the same launch against the fp32 vector peak with the algorithm's counted flops and states
+the occupancy; `cpu_baseline` times the CPU oracle (a port, not the reference: Isaac Gym is not
 installable) on a bounded sample of the same workload on this box's host cores.
 """
 import argparse
@@ -27,28 +30,67 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # Algorithmic HBM bytes per env-step (restated in DESIGN.md section 5)
-B_ALG = {"terrain": 5539, "flat": 5019, "trimesh": 5539}
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s achievable)
+B_ALG = {"terrain": 5539, "flat": 5019, "trimesh": 5539, "abb": 2140}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s achievable)
+VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector (non-matrix) peak
+NUM_CUS, SIMDS_PER_CU = 256, 4
+WL_NAME = {"terrain": "a1_conditional procedural heightfield 1300x2100 (config 3)",
+           "flat": "a1_conditional all-zero heightfield (config 2)",
+           "trimesh": "a1_conditional procedural terrain 1300x2100 as trimesh with vertical risers (the reference's effective A1 terrain)",
+           "abb": "abb_pushbox prior stage: ABB arm + table + free cube + goal pad (config 5)"}
 
 
-def cpu_baseline(workload: str, seconds_budget: float = 15.0):
-    """The oracle's fused A1 step on host cores, OpenMP over envs.  Bounded sample."""
+# ----------------------------------------------------------------------------- CPU oracle workloads --
+def oracle_workload(workload: str, n: int, seed: int = 0):
+    """The same workload on NumPy buffers for the CPU oracle: returns step(nthreads, count_flops=False) -> None."""
     from oracle import pyoracle
     from shifu_amd import _abi
-    from shifu_amd.a1_task import a1_task_params, height_points
     from shifu_amd.backend import default_sim_params
+    pyoracle.build()
+    rng = np.random.default_rng(seed)
+    if workload == "abb":
+        from shifu_amd.abb_task import ABB_BASE_POS, abb_boxes, abb_model, abb_task_params
+        cm = abb_model()
+        m, boxes = cm.blob, abb_boxes()
+        sp = default_sim_params(dt=0.02)
+        tp = abb_task_params(cm)
+        nb, nd, A = m.nb, m.nd, 4
+        B = nb + 3
+        root = np.zeros((n * A, 13), np.float32)
+        root[:, 6] = 1.0
+        root[0::A, :3] = ABB_BASE_POS
+        for k, b in enumerate(boxes):
+            root[1 + k::A, :3] = list(b.pos)
+        bufs = dict(dof_state=np.zeros((n * nd, 2), np.float32), root_state=root,
+                    body_state=np.zeros((n * B, 13), np.float32), contact=np.zeros((n * B, 3), np.float32),
+                    jacobian=np.zeros((n, nb - 1, 6, nd), np.float32), friction=np.ones(n, np.float32),
+                    actions=np.zeros((n, 3), np.float32), obs=np.zeros((n, 6), np.float32), rew=np.zeros(n, np.float32),
+                    reset=np.zeros(n, np.uint8), timeout=np.zeros(n, np.uint8), success=np.zeros(n, np.uint8),
+                    ep_len=np.zeros(n, np.int64), rew_sums=np.zeros((2, n), np.float32),
+                    dof_targets=np.zeros((n, nd), np.float32), reset_count=np.zeros(n, np.int32),
+                    done_sums=np.zeros((4, n), np.float32))
+        bufs["dof_state"][:, 0] = np.tile(np.array([tp.default_dof_pos[d] for d in range(nd)], np.float32), n)
+        bufs["body_state"][:, 6] = 1.0
+
+        def step(nthreads, count_flops=False):
+            raw = (2 * rng.random((n, 3)) - 1).astype(np.float32)
+            pyoracle.abb_step(m, sp, boxes, tp, n, 0, bufs, raw, nthreads=nthreads, count_flops=count_flops)
+        return step
+    from shifu_amd.a1_task import a1_task_params, height_points
     from shifu_amd.gym.a1_fused import default_terrain_cfg
     from shifu_amd.model import asset_path, compile_urdf
     from shifu_amd.utils.terrain import Terrain
-    pyoracle.build()
-    n = 1024
     cm = compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT)
     m = cm.blob
+    for d in range(m.nd):
+        m.damping[d] = 0.5                       # dof_props['damping'] as FusedA1Env sets it
     sp = default_sim_params()
     ct = default_terrain_cfg()
-    np.random.seed(42)
     if workload in ("terrain", "trimesh"):
+        state = np.random.get_state()
+        np.random.seed(42)
         ter = Terrain(ct, n)
+        np.random.set_state(state)
         hs, origins = np.ascontiguousarray(ter.heightsamples), ter.env_origins.astype(np.float32)
     else:
         hs = np.zeros((1300, 2100), np.int16)
@@ -64,7 +106,6 @@ def cpu_baseline(workload: str, seconds_budget: float = 15.0):
         hs = pack_trimesh_samples(hs, trimesh_warp_map(hs, 0.1, 0.005, ct.slope_treshold))
     tp = a1_task_params(cm)
     nb, nd, P = m.nb, m.nd, tp.num_height_points
-    rng = np.random.default_rng(0)
     types = (np.arange(n) * ct.num_cols // n).astype(np.int64)
     b = dict(dof_state=np.zeros((n * nd, 2), np.float32), root_state=np.zeros((n, 13), np.float32),
              body_state=np.zeros((n * nb, 13), np.float32), contact=np.zeros((n * nb, 3), np.float32),
@@ -79,33 +120,62 @@ def cpu_baseline(workload: str, seconds_budget: float = 15.0):
     b["dof_state"][:, 0] = np.tile(np.array([tp.default_dof_pos[d] for d in range(nd)], np.float32), n)
     b["root_state"][:, :3] = b["origins"] + np.array([0, 0, 0.42], np.float32)
     b["root_state"][:, 6] = 1.0
-    def run(nt, k):
-        t = time.perf_counter()
-        for _ in range(k):
-            raw = (2 * rng.random((n, nd)) - 1).astype(np.float32)
-            pyoracle.a1_step(m, sp, tp, n, 0, b, raw, terrain=terr, heights=hs, nthreads=nt)
-        return time.perf_counter() - t
 
-    # os.cpu_count() can exceed what the container may use: pick the thread count that is fastest
+    def step(nthreads, count_flops=False):
+        raw = (2 * rng.random((n, nd)) - 1).astype(np.float32)
+        pyoracle.a1_step(m, sp, tp, n, 0, b, raw, terrain=terr, heights=hs, nthreads=nthreads, count_flops=count_flops)
+    return step
+
+
+def count_flops(workload: str, n: int = 64, warm: int = 40, steps: int = 20) -> float:
+    """Floating-point operations per env-step of the algorithm (add/sub/mul/div/sqrt = 1, fma = 2), counted by running
+    the oracle compiled with a counting real type (oracle/flopcount.cpp) on `n` envs in the workload's steady state
+    (robots standing / stumbling on the terrain with random actions, resets included)."""
+    from oracle import pyoracle
+    step = oracle_workload(workload, n, seed=1)
+    for _ in range(warm):
+        step(1)
+    L = pyoracle.flop_lib()
+    L.shf_flopcount_read(1)
+    for _ in range(steps):
+        step(1, count_flops=True)
+    return L.shf_flopcount_read(1) / float(n * steps)
+
+
+def cpu_baseline(workload: str, seconds_budget: float = 16.0):
+    """The oracle's fused env step on host cores.  Deterministic thread counts: one thread, and every core this process
+    may use (OpenMP over envs, 4096 envs so that each thread has tens of envs per step).  Bounded sample."""
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cands = sorted({c for c in (1, 4, 8, 16, 32, 64, 128, avail) if 1 <= c <= avail})
-    best, best_t = 1, None
-    for c in cands:
-        run(c, 4)  # the first calls at a new team size pay thread start-up
-        t = run(c, 3)
-        if best_t is None or t < best_t:
-            best, best_t = c, t
-    cores = best
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        run(cores, 1)
-        steps += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget or steps >= 2000:
-            break
-    return {"value": n * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} envs x {steps} vec-steps of the same A1 {workload} workload, oracle/shf_oracle.c (f32, "
-                      f"OpenMP over envs); Isaac Gym CPU PhysX pipeline unavailable (not installable offline)"}
+
+    def timed(n, threads, budget):
+        step = oracle_workload(workload, n)
+        for _ in range(3):
+            step(threads)          # thread start-up, page faults
+        k, t0 = 0, time.perf_counter()
+        while True:
+            step(threads)
+            k += 1
+            el = time.perf_counter() - t0
+            if el > budget or k >= 2000:
+                return n * k / el, k
+    v1, k1 = timed(256, 1, seconds_budget * 0.3)
+    vall, kall = timed(4096, avail, seconds_budget * 0.7)
+    what = "ABB push-box" if workload == "abb" else f"A1 {workload}"
+    return {"value": vall, "unit": "env-steps/s", "cores": avail, "kind": "port", "value_1thread": v1,
+            "sample": f"oracle/shf_oracle.c (f32) on the same {what} workload: 4096 envs x {kall} vec-steps on {avail} threads "
+                      f"(OpenMP over envs) = `value`; 256 envs x {k1} vec-steps on 1 thread = `value_1thread`.  "
+                      f"kind=port because the reference's CPU pipeline (Isaac Gym sim_device=cpu, use_gpu_pipeline=False) "
+                      f"is a closed binary that cannot be installed offline"}
+
+
+def committed_profile(kernel_key: str):
+    """Counter-derived facts that bench.py cannot measure in-run (rocprofv3 --pmc needs its own passes): replayed from
+    the committed summaries under profiles/ and labelled as such."""
+    try:
+        db = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        return db.get(kernel_key)
+    except Exception:
+        return None
 
 
 def main():
@@ -114,10 +184,12 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
-    ap.add_argument("--workload", choices=["terrain", "flat", "trimesh"], default="terrain",
-                    help="terrain = config 3 (height field); trimesh = the same samples as the mesh with vertical risers")
-    ap.add_argument("--group", type=int, default=32, help="lanes per env: 64 = one wavefront per env, 32 = two envs per wavefront (fastest measured, DESIGN.md 6)")
+    ap.add_argument("--workload", choices=["terrain", "flat", "trimesh", "abb"], default="terrain",
+                    help="terrain = config 3 (height field); trimesh = the same samples as the mesh with vertical risers; "
+                         "abb = config 5")
+    ap.add_argument("--group", type=int, default=None, help="lanes per env: 64 = one wavefront per env; default 32 (A1) / 16 (ABB), the fastest measured (DESIGN.md 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the vec-step eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--decimation", type=int, default=4, help="(experiments only) control.decimation")
     ap.add_argument("--no-extra-substep", action="store_true", help="(experiments only) drop the Q1 sub-step")
     ap.add_argument("--log-interval", type=int, default=24, help="all-gather period (num_steps_per_env)")
@@ -156,46 +228,82 @@ def main():
             dist.init_process_group(backend)
 
     from shifu_amd import _abi
-    from shifu_amd.gym.a1_fused import FusedA1Env
     from shifu_amd.parallel import gather_episode_stats
 
-    env = FusedA1Env(num_envs=args.envs, device=dev, terrain={"terrain": "heightfield", "flat": "flat", "trimesh": "trimesh"}[args.workload],
-                     seed=42, rank=rank, world_size=world, group=args.group, decimation=args.decimation,
-                     extra_substep=not args.no_extra_substep)
+    abb = args.workload == "abb"
+    group = args.group or (16 if abb else 32)
+    if abb:
+        from shifu_amd.gym.abb_fused import FusedAbbEnv
+        env = FusedAbbEnv(num_envs=args.envs, device=dev, seed=42, rank=rank, world_size=world, group=group)
+        stats_t, count_t, kernel = _abi.ABB_STATS, _abi.ABB_RESET_COUNT, "k_abb_step"
+        substeps = 6
+    else:
+        from shifu_amd.gym.a1_fused import FusedA1Env
+        env = FusedA1Env(num_envs=args.envs, device=dev, terrain={"terrain": "heightfield", "flat": "flat", "trimesh": "trimesh"}[args.workload],
+                         seed=42, rank=rank, world_size=world, group=group, decimation=args.decimation,
+                         extra_substep=not args.no_extra_substep)
+        stats_t, count_t, kernel = _abi.A1_STATS, _abi.A1_RESET_COUNT, "k_a1_step"
+        substeps = args.decimation + (0 if args.no_extra_substep else 1)
     gen = torch.Generator(device=dev)
     gen.manual_seed(42 + rank)
     N, A = env.num_envs, env.num_actions
     env.reset()
-
     actions = torch.empty(N, A, device=dev)
+    nslots = env.task.tensors[stats_t].shape[0]
 
-    def vec_step(i, ev=None):
+    def eager_step(ev=None):
         actions.uniform_(-1.0, 1.0, generator=gen)   # = 2*rand-1 of policy_runner.py:40, one kernel, no allocation
         if ev is not None:
             ev[0].record()
-        env.task.launch_step(actions)
+        slot = env.task.step(actions)                # the fused kernel (episode statistics included)
         if ev is not None:
             ev[1].record()
-        slot = env.task.launch_stats()
-        if world > 1 and (i + 1) % args.log_interval == 0:
-            gather_episode_stats(env.task.tensors[_abi.A1_STATS][slot][:8])
         return slot
 
+    # The vec-step is two launches (action draw + fused step); replaying them as one captured hipGraph removes the
+    # launch gaps.  HIP events cannot be recorded inside a replay, so the kernel's own duration is measured on the
+    # eager launches of the warm-up + a dedicated eager pass of the same K steps after the timed region.
+    use_graph = not args.no_graph
     for i in range(args.warmup):
-        vec_step(i)
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        eager_step()
+    graph = None
+    if use_graph:
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        graph.register_generator_state(gen)
+        with torch.cuda.graph(graph):
+            actions.uniform_(-1.0, 1.0, generator=gen)
+            env.task.launch_step(actions)
+        env.task.graph_slot_stride = 1
+
+    def vec_step(i):
+        if graph is not None:
+            graph.replay()
+            slot = env.task.advance_slot()
+        else:
+            slot = eager_step()
+        if world > 1 and (i + 1) % args.log_interval == 0:
+            gather_episode_stats(env.task.tensors[stats_t][slot][:env.task.num_sums])
+        return slot
+
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        vec_step(i, events[i])
+        vec_step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+
+    # duration of the fused kernel alone: HIP events on the launch stream around each of K eager launches
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for i in range(args.steps):
+        eager_step(events[i])
+    torch.cuda.synchronize()
     kern_ms = sum(a.elapsed_time(b) for a, b in events) / args.steps
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -203,38 +311,57 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     finite = bool(torch.isfinite(env.obs_buf).all().item())
-    resets = int(env.task.tensors[_abi.A1_RESET_COUNT].sum().item())
+    resets = int(env.task.tensors[count_t].sum().item())
 
     if rank == 0:
         total_envs = N * world
         value = total_envs * args.steps / elapsed
         b_alg = B_ALG[args.workload]
-        wl_name = {"terrain": "procedural heightfield 1300x2100 (config 3)", "flat": "all-zero heightfield (config 2)",
-                   "trimesh": "procedural terrain 1300x2100 as trimesh with vertical risers (the reference's effective A1 terrain)"}[args.workload]
         achieved = b_alg * N / (kern_ms * 1e-3) / 1e9
-        traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/profile.sh)
+        prof = committed_profile(f"{kernel}_{args.workload}_g{group}") if N == 4096 else None
+        res = {}
         try:
-            tdb = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            key = "r01_a1_step_g%d" % args.group
-            if args.workload == "terrain" and N == 4096 and key in tdb:
-                traffic = tdb[key]["traffic_bytes"]
+            res = json.load(open(os.path.join(ROOT, "shifu_amd", "libshifu_amd.resources.json")))
         except Exception:
             pass
+        entry = env.task.kernel_symbol() if hasattr(env.task, "kernel_symbol") else None
+        vg = next((v for k, v in res.items() if entry and k.startswith(entry)), None)
+        waves = (N + (64 // group) - 1) // (64 // group) if group < 64 else N
+        secondary = {"bound": "valu_fp32", "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "waves_per_simd": waves / float(NUM_CUS * SIMDS_PER_CU),
+                     "lanes_per_env": group, "vgprs": None if vg is None else vg.get("vgprs"),
+                     "scratch_bytes_per_lane": None if vg is None else vg.get("scratch")}
+        if prof:
+            secondary.update({"valu_issue_frac": prof.get("valu_issue_frac"), "wait_frac": prof.get("wait_frac"),
+                              "counter_source": prof.get("source")})
         out = {
-            "metric": "env-steps/sec (whole node), A1 12-dof 4096 envs/GPU", "value": value, "unit": "env-steps/s",
+            "metric": ("env-steps/sec (whole node), ABB push-box 6-dof arm + free cube, 4096 envs/GPU" if abb else
+                       "env-steps/sec (whole node), A1 12-dof 4096 envs/GPU"), "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"a1_conditional {wl_name}, "
-                                   f"{N} envs/GPU, random actions, 5 substeps/env-step (dt 5 ms), resets on",
-                       "envs_per_gpu": N, "total_envs": total_envs, "substeps_per_env_step": 5,
-                       "lanes_per_env": args.group, "parallelism": f"env-sharded x{world}, all-gather of episode stats every {args.log_interval} steps",
-                       "substeps_per_s": value * 5, "obs_finite": finite, "episodes_reset_rank0": resets},
+            "config": {"workload": f"{WL_NAME[args.workload]}, {N} envs/GPU, random actions, {substeps} substeps/env-step "
+                                   f"(dt {'20' if abb else '5'} ms), resets on",
+                       "envs_per_gpu": N, "total_envs": total_envs, "substeps_per_env_step": substeps,
+                       "lanes_per_env": group, "vec_step": "hipGraph replay of [uniform_, fused step]" if graph is not None else "eager launches",
+                       "parallelism": f"env-sharded x{world}, all-gather of episode stats every {args.log_interval} steps",
+                       "substeps_per_s": value * substeps, "obs_finite": finite, "episodes_reset_rank0": resets},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_a1_step", "kernel_ms": kern_ms, "alg_bytes_per_env_step": b_alg,
-                         "note": "latency/ALU-bound by design: ~5.5 KB compulsory traffic per env-step (DESIGN.md 5)"},
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None if not prof else prof.get("traffic_bytes"),
+                         "traffic_source": None if not prof else prof.get("source"),
+                         "kernel": kernel, "kernel_ms": kern_ms, "alg_bytes_per_env_step": b_alg,
+                         "note": "latency/ALU-bound by design: a few KB of compulsory traffic per env-step (DESIGN.md 5)",
+                         "secondary": secondary},
         }
         if not args.no_cpu_baseline and world == 1:
+            try:
+                f_alg = count_flops(args.workload)
+                secondary.update({"flops_alg_per_env_step": f_alg, "achieved": f_alg * N / (kern_ms * 1e-3) / 1e12,
+                                  "flops_source": "counted live: oracle/flopcount.cpp (add/sub/mul/div/sqrt = 1, fma = 2)"})
+                secondary["frac"] = secondary["achieved"] / VALU_PEAK_TFLOPS
+            except Exception as e:     # the counting build needs g++ on the box
+                secondary["flops_alg_per_env_step"] = None
+                secondary["flops_source"] = f"unavailable: {e}"
             out["cpu_baseline"] = cpu_baseline(args.workload)
         else:
             out["cpu_baseline"] = None

@@ -292,9 +292,15 @@ enum {
   SHF_A1_TORIGINS = 17,  /* (rows,cols,3) f32 terrain_origins                      */
   SHF_A1_RESET_COUNT = 18, /* (N) i32 per-env episode counter (RNG counter)        */
   SHF_A1_DONE_SUMS = 19, /* (8,N) f32 per-env finished-episode sums (6 terms, level, 1) */
-  SHF_A1_STATS = 20,     /* (R,16) f32 ring of per-step reductions                 */
+  SHF_A1_STATS = 20,     /* (R+1,16) f32 ring of per-step episode statistics, row = vec-step % R; row R = the latest step:
+                          * [0..5] sum of the six reward-term episode sums over the episodes that finished in that
+                          * step, [6] sum of terrain levels over all envs, [7] finished count, [8..13] the reference's
+                          * extras["episode"] means (sum / count / max_episode_length_s, env.py:149-158; 0 when nothing
+                          * finished), [14] mean terrain level, [15] N                                             */
   SHF_A1_PARAMS = 21,    /* sizeof(ShfA1TaskParams) bytes, device copy             */
-  SHF_A1_COUNT = 22
+  SHF_A1_STATS_ACC = 22, /* (R+1,10) i64 exact integer accumulators of the in-kernel reduction (reward sums in 2^-20
+                          * fixed point); row R col 0 = vec-steps completed (selects the ring row; part of the state) */
+  SHF_A1_COUNT = 23
 };
 
 typedef struct ShfA1Task ShfA1Task;
@@ -302,14 +308,10 @@ int shf_a1_create(ShfSim* sim, const ShfA1TaskParams* params, ShfA1Task** out);
 int shf_a1_destroy(ShfA1Task* task);
 int shf_a1_layout(const ShfA1Task* task, int32_t id, int64_t shape[4], int32_t* ndim, int32_t* dtype);
 int shf_a1_bind(ShfA1Task* task, int32_t id, void* device_ptr);
-/* ShifuVecEnv.step for A1Conditional (env.py:85-106).  raw_actions: (N,12) policy output. */
+/* ShifuVecEnv.step for A1Conditional (env.py:85-106), log_info's reduction (env.py:149-158) included: the row
+ * (vec-steps completed so far) % R of SHF_A1_STATS is written by the same launch.  raw_actions: (N,12) policy output.
+ * Nothing about the call depends on the step index, so a captured launch can be replayed from a hipGraph. */
 int shf_a1_step(ShfA1Task* task, const float* raw_actions_dev, void* stream);
-/* log_info (env.py:149-158): reduces the episodes that finished in the last step
- * into ring slot `slot % R` of SHF_A1_STATS: [0..5] sum of the six reward-term
- * episode sums, [6] sum of terrain levels over all envs, [7] finished count,
- * [8..13] the reference's extras["episode"] means (/max_episode_length_s),
- * [14] mean terrain level, [15] N. */
-int shf_a1_episode_stats(ShfA1Task* task, int64_t slot, void* stream);
 /* ShifuVecEnv.reset_idx(arange(N)) part of reset() (env.py:108-112). */
 int shf_a1_reset_all(ShfA1Task* task, void* stream);
 
@@ -359,9 +361,10 @@ enum {
   SHF_ABB_DOF_TARGETS = 8, /* (N,nd) f32 robot.dof_targets                              */
   SHF_ABB_RESET_COUNT = 9, /* (N) i32                                                   */
   SHF_ABB_DONE_SUMS = 10,  /* (4,N) f32: finished-episode sums of the 2 terms, success, 1 */
-  SHF_ABB_STATS = 11,      /* (R,8) f32 ring: [0..3] sums of DONE_SUMS rows, [4,5] episode means / T, [6] success_rate, [7] N */
+  SHF_ABB_STATS = 11,      /* (R+1,8) f32 ring (row R = latest step): [0..3] sums of DONE_SUMS rows, [4,5] episode means / T, [6] success_rate, [7] N */
   SHF_ABB_PARAMS = 12,     /* sizeof(ShfAbbTaskParams) bytes, device copy               */
-  SHF_ABB_COUNT = 13
+  SHF_ABB_STATS_ACC = 13,  /* (R+1,10) i64, as SHF_A1_STATS_ACC                          */
+  SHF_ABB_COUNT = 14
 };
 
 typedef struct ShfAbbTask ShfAbbTask;
@@ -369,9 +372,8 @@ int shf_abb_create(ShfSim* sim, const ShfAbbTaskParams* params, ShfAbbTask** out
 int shf_abb_destroy(ShfAbbTask* task);
 int shf_abb_layout(const ShfAbbTask* task, int32_t id, int64_t shape[4], int32_t* ndim, int32_t* dtype);
 int shf_abb_bind(ShfAbbTask* task, int32_t id, void* device_ptr);
-/* ShifuVecEnv.step for AbbPushBox; raw_actions (N,3). */
+/* ShifuVecEnv.step for AbbPushBox, statistics row included (as shf_a1_step); raw_actions (N,3). */
 int shf_abb_step(ShfAbbTask* task, const float* raw_actions_dev, void* stream);
-int shf_abb_episode_stats(ShfAbbTask* task, int64_t slot, void* stream);
 /* reset_idx(arange(N)) (env.py:108-112). */
 int shf_abb_reset_all(ShfAbbTask* task, void* stream);
 

@@ -32,6 +32,24 @@ def lib():
     return _LIB
 
 
+_FLOP = None
+
+
+def flop_lib():
+    """The oracle compiled with a flop-counting real type (oracle/flopcount.cpp): entry points *_cnt plus
+    shf_flopcount_read(reset).  Built on first use; single-threaded counting (the counter is thread-local)."""
+    global _FLOP
+    if _FLOP is None:
+        so = os.path.join(_HERE, "libshf_flopcount.so")
+        srcs = [os.path.join(_HERE, f) for f in ("shf_oracle.c", "flopcount.cpp")]
+        if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in srcs):
+            subprocess.check_call(["g++", "-O1", "-fPIC", "-shared", "-fpermissive", "-w", "-std=c++17", "-fopenmp",
+                                   os.path.join(_HERE, "flopcount.cpp"), "-o", so])
+        _FLOP = C.CDLL(so)
+        _FLOP.shf_flopcount_read.restype = C.c_ulonglong
+    return _FLOP
+
+
 def _p(a, ct):
     return None if a is None else a.ctypes.data_as(C.POINTER(ct))
 
@@ -110,7 +128,7 @@ A1_FIELDS = [f[0] for f in A1Buffers._fields_]
 
 
 def a1_step(model, params, task_params, n, env_id_offset, bufs: dict, raw_actions, terrain=None, heights=None,
-            nthreads=1):
+            nthreads=1, count_flops=False):
     """One fused A1Conditional env step on NumPy buffers (dict keyed by A1_FIELDS), in place."""
     B = A1Buffers()
     for name, ctype in A1Buffers._fields_:
@@ -118,7 +136,7 @@ def a1_step(model, params, task_params, n, env_id_offset, bufs: dict, raw_action
         assert a.flags.c_contiguous, name
         setattr(B, name, a.ctypes.data_as(ctype))
     raw = np.ascontiguousarray(raw_actions, np.float32)
-    fn = lib().shf_oracle_a1_step_f32
+    fn = flop_lib().shf_oracle_a1_step_cnt if count_flops else lib().shf_oracle_a1_step_f32
     fn.restype = None
     fn(C.byref(model), C.byref(params), C.byref(terrain) if terrain is not None else None, _p(heights, C.c_int16),
        C.byref(task_params), C.c_int(n), C.c_int64(env_id_offset), C.byref(B), _p(raw, C.c_float), C.c_int(nthreads))
@@ -232,7 +250,7 @@ class AbbBuffers(C.Structure):
 ABB_FIELDS = [f[0] for f in AbbBuffers._fields_]
 
 
-def abb_step(model, params, boxes, task_params, n, env_id_offset, bufs: dict, raw_actions, nthreads=1):
+def abb_step(model, params, boxes, task_params, n, env_id_offset, bufs: dict, raw_actions, nthreads=1, count_flops=False):
     """One fused AbbPushBox env step on NumPy buffers (dict keyed by ABB_FIELDS), in place."""
     from shifu_amd import _abi
     B = AbbBuffers()
@@ -242,7 +260,7 @@ def abb_step(model, params, boxes, task_params, n, env_id_offset, bufs: dict, ra
         setattr(B, name, a.ctypes.data_as(ctype))
     arr = (_abi.ShfBoxDesc * max(len(boxes), 1))(*boxes)
     raw = np.ascontiguousarray(raw_actions, np.float32)
-    fn = lib().shf_oracle_abb_step_f32
+    fn = flop_lib().shf_oracle_abb_step_cnt if count_flops else lib().shf_oracle_abb_step_f32
     fn.restype = None
     fn(C.byref(model), C.byref(params), None, None, C.c_int(len(boxes)), arr, C.byref(task_params), C.c_int(n),
        C.c_int64(env_id_offset), C.byref(B), _p(raw, C.c_float), C.c_int(nthreads))

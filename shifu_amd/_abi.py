@@ -80,7 +80,7 @@ class ShfAbbTaskParams(C.Structure):
 
 
 (ABB_ACTIONS, ABB_OBS, ABB_REW, ABB_RESET, ABB_TIMEOUT, ABB_SUCCESS, ABB_EP_LEN, ABB_REW_SUMS, ABB_DOF_TARGETS,
- ABB_RESET_COUNT, ABB_DONE_SUMS, ABB_STATS, ABB_PARAMS, ABB_COUNT) = range(14)
+ ABB_RESET_COUNT, ABB_DONE_SUMS, ABB_STATS, ABB_PARAMS, ABB_STATS_ACC, ABB_COUNT) = range(15)
 
 # tensor ids (shf_sim_*)
 T_DOF_STATE, T_ROOT_STATE, T_BODY_STATE, T_CONTACT, T_JACOBIAN, T_SIM_DOF, T_SIM_ROOT, T_EFFORT, \
@@ -91,6 +91,6 @@ REFRESH_DOF, REFRESH_ROOT, REFRESH_BODY, REFRESH_CONTACT, REFRESH_JACOBIAN, REFR
 # tensor ids (shf_a1_*)
 (A1_ACTIONS, A1_OBS, A1_REW, A1_RESET, A1_TIMEOUT, A1_EP_LEN, A1_COMMAND, A1_HISTORY, A1_REW_SUMS, A1_TORQUES,
  A1_BASE_VEL, A1_HEIGHTS, A1_HPOINTS, A1_PUSH, A1_ORIGINS, A1_LEVELS, A1_TYPES, A1_TORIGINS, A1_RESET_COUNT,
- A1_DONE_SUMS, A1_STATS, A1_PARAMS, A1_COUNT) = range(23)
+ A1_DONE_SUMS, A1_STATS, A1_PARAMS, A1_STATS_ACC, A1_COUNT) = range(24)
 
 DTYPE_F32, DTYPE_I32, DTYPE_I16, DTYPE_U8, DTYPE_I64 = range(5)

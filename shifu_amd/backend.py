@@ -8,6 +8,7 @@ in the HIP kernels behind include/shifu_amd.h.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 from typing import Dict, Optional
 
 import numpy as np
@@ -36,6 +37,17 @@ def default_sim_params(dt: float = 0.005, gravity=(0.0, 0.0, -9.81), **kw) -> _a
     return p
 
 
+def _on_device(method):
+    """Run a launching method with the sim's GPU as the current HIP device: the library launches on, and records LDS
+    opt-ins for, whatever device is current, and the stream handed in belongs to this one."""
+    @functools.wraps(method)
+    def wrapped(self, *a, **k):
+        dev = self.device if hasattr(self, "device") else self.sim.device
+        with torch.cuda.device(dev):
+            return method(self, *a, **k)
+    return wrapped
+
+
 def _stream_ptr(device) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -61,6 +73,7 @@ class Sim:
         self.terrain.friction = 1.0
         self.num_envs = 0
         self.nboxes = 0
+        self.group = 64
         self.boxes = []
         self._heights: Optional[torch.Tensor] = None
 
@@ -115,6 +128,7 @@ class Sim:
 
     def finalize(self, num_envs: int, env_id_offset: int = 0, group: int = 64):
         self.num_envs = num_envs
+        self.group = group
         check(lib().shf_sim_finalize(self._h, num_envs, env_id_offset))
         if group != 64:
             check(lib().shf_sim_set_group(self._h, group))
@@ -140,39 +154,48 @@ class Sim:
             self.bind(tid, t)
 
     # -- launches -----------------------------------------------------------
+    @_on_device
     def step(self):
         check(lib().shf_sim_step(self._h, _stream_ptr(self.device)))
 
+    @_on_device
     def refresh(self, mask: int = _abi.REFRESH_ALL):
         check(lib().shf_sim_refresh(self._h, mask, _stream_ptr(self.device)))
 
+    @_on_device
     def set_dof_command(self, tid: int, values: torch.Tensor):
         v = values.contiguous()
         assert v.dtype == torch.float32 and v.numel() == self.num_envs * self.model.nd
         check(lib().shf_sim_set_dof_command(self._h, tid, C.c_void_p(v.data_ptr()), _stream_ptr(self.device)))
 
+    @_on_device
     def set_pos_target_indexed(self, values: torch.Tensor, idx: torch.Tensor):
         assert idx.dtype == torch.int32
         check(lib().shf_sim_set_pos_target_indexed(self._h, C.c_void_p(values.data_ptr()), C.c_void_p(idx.data_ptr()),
                                                    idx.numel(), _stream_ptr(self.device)))
 
+    @_on_device
     def apply_body_force(self, force: torch.Tensor):
         f = force.contiguous()
         check(lib().shf_sim_apply_body_force(self._h, C.c_void_p(f.data_ptr()), _stream_ptr(self.device)))
 
+    @_on_device
     def commit_root_indexed(self, root: torch.Tensor, idx: torch.Tensor):
         assert idx.dtype == torch.int32 and root.is_contiguous()
         check(lib().shf_sim_commit_root_indexed(self._h, C.c_void_p(root.data_ptr()), C.c_void_p(idx.data_ptr()),
                                                 idx.numel(), _stream_ptr(self.device)))
 
+    @_on_device
     def commit_root_all(self, root: torch.Tensor):
         check(lib().shf_sim_commit_root_all(self._h, C.c_void_p(root.data_ptr()), _stream_ptr(self.device)))
 
+    @_on_device
     def commit_dof_indexed(self, dof: torch.Tensor, idx: torch.Tensor):
         assert idx.dtype == torch.int32 and dof.is_contiguous()
         check(lib().shf_sim_commit_dof_indexed(self._h, C.c_void_p(dof.data_ptr()), C.c_void_p(idx.data_ptr()),
                                                idx.numel(), _stream_ptr(self.device)))
 
+    @_on_device
     def reset_all(self, default_root: torch.Tensor, default_dof: torch.Tensor, origins: Optional[torch.Tensor]):
         check(lib().shf_sim_reset_all(self._h, C.c_void_p(default_root.data_ptr()), C.c_void_p(default_dof.data_ptr()),
                                       C.c_void_p(origins.data_ptr()) if origins is not None else None,
@@ -219,29 +242,36 @@ class A1Task:
         self.tensors[tid] = t
         check(lib().shf_a1_bind(self._h, tid, C.c_void_p(t.data_ptr())))
 
+    num_sums = 8            # leading (sum, count) entries of a statistics row: what the multi-GPU all-gather carries
+
+    @_on_device
     def step(self, raw_actions: torch.Tensor, stats: bool = True) -> int:
-        """One fused vec-step; returns the stats ring slot written (or -1)."""
+        """One fused vec-step (episode statistics included); returns the statistics ring row it writes."""
         a = raw_actions.contiguous()
         assert a.dtype == torch.float32 and a.shape == (self.sim.num_envs, self.sim.model.nd)
-        st = _stream_ptr(self.sim.device)
-        check(lib().shf_a1_step(self._h, C.c_void_p(a.data_ptr()), st))
-        if not stats:
-            return -1
-        idx = self.step_index
-        check(lib().shf_a1_episode_stats(self._h, idx, st))
-        self.step_index += 1
-        return idx % self.tensors[_abi.A1_STATS].shape[0]
+        check(lib().shf_a1_step(self._h, C.c_void_p(a.data_ptr()), _stream_ptr(self.sim.device)))
+        return self.advance_slot()
 
+    @_on_device
     def launch_step(self, raw_actions: torch.Tensor):
-        """Only the fused kernel (bench.py brackets this with HIP events)."""
+        """Only the launch (no host-side bookkeeping): what a hipGraph capture records.  The kernel picks the ring row
+        from its device-side step counter; pair every replay with advance_slot()."""
         check(lib().shf_a1_step(self._h, C.c_void_p(raw_actions.data_ptr()), _stream_ptr(self.sim.device)))
 
-    def launch_stats(self) -> int:
+    def advance_slot(self) -> int:
+        """Host mirror of the device-side step counter: the ring row of the step just launched / replayed."""
         idx = self.step_index
-        check(lib().shf_a1_episode_stats(self._h, idx, _stream_ptr(self.sim.device)))
         self.step_index += 1
-        return idx % self.tensors[_abi.A1_STATS].shape[0]
+        return idx % (self.tensors[_abi.A1_STATS].shape[0] - 1)
 
+    def kernel_symbol(self) -> str:
+        """Mangled-name prefix of the instantiation shf_a1_step launches for this sim (build resource table)."""
+        g, warped = self.sim.group, bool(self.sim.terrain.warped)
+        if self.sim.model.nb == 17 and self.sim.model.nd == 12 and self.sim.model.np == 76:
+            return "_Z16k_a1_step_a1_g32" if (g == 32 and not warped) else f"_Z9k_a1_stepILi{g}E9FixedDims"
+        return f"_Z9k_a1_stepILi{g}E7DynDims"
+
+    @_on_device
     def reset_all(self):
         check(lib().shf_a1_reset_all(self._h, _stream_ptr(self.sim.device)))
 
@@ -281,18 +311,28 @@ class AbbTask:
         self.tensors[tid] = t
         check(lib().shf_abb_bind(self._h, tid, C.c_void_p(t.data_ptr())))
 
+    num_sums = 4
+
+    @_on_device
     def step(self, raw_actions: torch.Tensor, stats: bool = True) -> int:
         a = raw_actions.contiguous()
         assert a.dtype == torch.float32 and a.shape == (self.sim.num_envs, 3)
-        st = _stream_ptr(self.sim.device)
-        check(lib().shf_abb_step(self._h, C.c_void_p(a.data_ptr()), st))
-        if not stats:
-            return -1
-        idx = self.step_index
-        check(lib().shf_abb_episode_stats(self._h, idx, st))
-        self.step_index += 1
-        return idx % self.tensors[_abi.ABB_STATS].shape[0]
+        check(lib().shf_abb_step(self._h, C.c_void_p(a.data_ptr()), _stream_ptr(self.sim.device)))
+        return self.advance_slot()
 
+    @_on_device
+    def launch_step(self, raw_actions: torch.Tensor):
+        check(lib().shf_abb_step(self._h, C.c_void_p(raw_actions.data_ptr()), _stream_ptr(self.sim.device)))
+
+    def advance_slot(self) -> int:
+        idx = self.step_index
+        self.step_index += 1
+        return idx % (self.tensors[_abi.ABB_STATS].shape[0] - 1)
+
+    def kernel_symbol(self) -> str:
+        return f"_Z10k_abb_stepILi{self.sim.group}E"
+
+    @_on_device
     def reset_all(self):
         check(lib().shf_abb_reset_all(self._h, _stream_ptr(self.sim.device)))
 

@@ -246,6 +246,61 @@ __global__ void k_reset_all(const ShfModel* gm, int n, int actors, const float* 
   }
 }
 
+// ------------------------------------------------- episode statistics --
+// log_info (env.py:149-158) folded into the step kernel: no second launch, no host-side slot argument (the vec-step
+// can be replayed from a hipGraph).  Every env contributes integers -- finished-episode reward sums in 2^-20 fixed
+// point, counts and terrain levels as they are -- so the reduction is exact and order-independent: env groups add
+// into LDS, the last group of a block adds the block totals to the slot's global accumulators and takes a ticket, the
+// block holding the last ticket turns the totals into the ring row, clears the slot and advances the step counter.
+// Layout of the accumulator tensor: (ring + 1) rows of STATS_COLS u64; row r < ring = [keys..., col 8 = tickets],
+// row `ring` col 0 = vec-steps completed.
+#define STATS_COLS 10
+#define STATS_LDS_WORDS 24     /* 9 u64 block accumulators + the group counter, 16-byte padded */
+#define STATS_FIX 1048576.0f   /* 2^20 */
+struct StatsArgs {
+  unsigned long long* acc;
+  float* out;          // (ring, out_cols)
+  int ring, out_cols;
+};
+DEV long long stats_fix(float x) { return (long long)rintf(x * STATS_FIX); }
+DEV void stats_block_init(float* lds_words) {
+  if (threadIdx.x < STATS_LDS_WORDS) reinterpret_cast<uint32_t*>(lds_words)[threadIdx.x] = 0u;   // before stage_model's barrier
+}
+// Called by lane 0 of every env group of the block once its NK values are final.  FIN(acc[NK], out) -> ring row.
+template <int NK, class FIN>
+DEV void stats_contribute(const StatsArgs& S, float* lds_words, const long long* v, int envs_in_block, FIN finalize) {
+  unsigned long long* blk = reinterpret_cast<unsigned long long*>(lds_words);
+#pragma unroll
+  for (int k = 0; k < NK; k++)
+    if (v[k] != 0) __hip_atomic_fetch_add(&blk[k], (unsigned long long)v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const unsigned done = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(&blk[9]), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if ((int)done != envs_in_block - 1) return;
+  // last group of this block
+  unsigned long long* ctl = S.acc + (size_t)S.ring * STATS_COLS;
+  const unsigned long long step = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long* row = S.acc + (size_t)(step % (unsigned long long)S.ring) * STATS_COLS;
+#pragma unroll
+  for (int k = 0; k < NK; k++) {
+    const unsigned long long t = __hip_atomic_load(&blk[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (t != 0ull) __hip_atomic_fetch_add(&row[k], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const unsigned long long ticket = __hip_atomic_fetch_add(&row[8], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (ticket != (unsigned long long)gridDim.x - 1ull) return;
+  // last block of the launch
+  long long tot[NK];
+#pragma unroll
+  for (int k = 0; k < NK; k++) {
+    tot[k] = (long long)__hip_atomic_load(&row[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&row[k], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __hip_atomic_store(&row[8], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float* o = S.out + (size_t)(step % (unsigned long long)S.ring) * S.out_cols;
+  finalize(tot, o);
+  float* latest = S.out + (size_t)S.ring * S.out_cols;     // row `ring`: always the step that ran last
+  for (int k = 0; k < S.out_cols; k++) latest[k] = o[k];
+  __hip_atomic_store(ctl, step + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ------------------------------------------------------- fused A1 step --
 struct A1Args {
   SimArgs S;
@@ -264,6 +319,7 @@ struct A1Args {
   int32_t* reset_count;
   float* done_sums;
   float* body_state;
+  StatsArgs stats;
 };
 
 DEV void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
@@ -378,6 +434,8 @@ template <int G, class DM, bool TW>
 DEV void a1_step_body(const A1Args& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   PHASE_BEGIN();
+  float* stats_lds = smem + MODEL_WORDS + TASK_WORDS;
+  stats_block_init(stats_lds);
   stage_block<(int)sizeof(ShfA1TaskParams)>(A.tp, smem + MODEL_WORDS);
   const ShfModel* m = stage_model(A.S.model, smem);
   const ShfA1TaskParams& tp = *reinterpret_cast<const ShfA1TaskParams*>(smem + MODEL_WORDS);
@@ -389,7 +447,7 @@ DEV void a1_step_body(const A1Args& A) {
   const int nobs = 12 + 2 * nd + nd * H + P;
   // post-physics scratch reuses the contact-point region (last in the carve)
   const int env_words = env_lds_words(nb, nd, np, SCR_OBS + nobs);
-  EnvLds L = env_lds_carve(smem + MODEL_WORDS + TASK_WORDS + es * env_words, nb, nd, np);
+  EnvLds L = env_lds_carve(smem + MODEL_WORDS + TASK_WORDS + STATS_LDS_WORDS + es * env_words, nb, nd, np);
   float* scr = L.pt;
 
   float* dof = A.S.dof + (size_t)e * nd * 2;
@@ -577,6 +635,26 @@ DEV void a1_step_body(const A1Args& A) {
 #pragma unroll
     for (int k = 0; k < 8; k++) A.done_sums[(size_t)k * n + e] = done[k];
     A.ep_len[e] = ep;
+    {
+      // extras["episode"] of this vec-step (env.py:149-158)
+      long long sv[8];
+#pragma unroll
+      for (int k = 0; k < 6; k++) sv[k] = stats_fix(done[k]);
+      sv[6] = (long long)level; sv[7] = reset ? 1ll : 0ll;
+      const int first = (int)blockIdx.x * epb, eib = n - first < epb ? n - first : epb;
+      const float Ts = tp.max_episode_length_s;
+      stats_contribute<8>(A.stats, stats_lds, sv, eib, [n, Ts](const long long* t, float* o) {
+        const float c = (float)t[7];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          const float sum = (float)t[k] * (1.0f / STATS_FIX);
+          o[k] = sum;
+          o[8 + k] = c > 0.0f ? sum / c / Ts : 0.0f;
+        }
+        o[6] = (float)t[6]; o[7] = c;
+        o[14] = o[6] / (float)n; o[15] = (float)n;
+      });
+    }
     const float co = tp.clip_obs;
     float* o = scr + SCR_OBS;
 #pragma unroll
@@ -625,32 +703,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256))) void 
   a1_step_body<32, A1Dims, false>(A);
 }
 
-// per-step reduction for extras["episode"] (env.py:149-158), fixed order: block k reduces
-// row k of done_sums (1024 strided partials, then a binary tree) and, for the means, the
-// finished-episode count (row 7) the same way.
-__global__ __launch_bounds__(1024) void k_a1_stats(int n, float max_episode_length_s, const float* done_sums, float* out) {
-  __shared__ float part[2][1024];
-  const int t = threadIdx.x, k = blockIdx.x;
-  float acc = 0.0f, cnt = 0.0f;
-  for (int e = t; e < n; e += 1024) {
-    acc += done_sums[(size_t)k * n + e];
-    cnt += done_sums[(size_t)7 * n + e];
-  }
-  part[0][t] = acc; part[1][t] = cnt;
-  __syncthreads();
-  for (int s = 512; s >= 1; s >>= 1) {
-    if (t < s) { part[0][t] += part[0][t + s]; part[1][t] += part[1][t + s]; }
-    __syncthreads();
-  }
-  if (t == 0) {
-    const float sum = part[0][0], c = part[1][0];
-    out[k] = sum;
-    if (k < 6) out[8 + k] = c > 0.0f ? sum / c / max_episode_length_s : 0.0f;
-    if (k == 6) out[14] = sum / (float)n;
-    if (k == 7) out[15] = (float)n;
-  }
-}
-
 // ------------------------------------------------------ fused ABB step --
 struct AbbArgs {
   SimArgs S;
@@ -664,6 +716,7 @@ struct AbbArgs {
   int32_t* reset_count;
   float* done_sums;
   float *body_state, *jacobian;
+  StatsArgs stats;
 };
 #define ABB_WORDS ((int)((sizeof(ShfAbbTaskParams) / 4 + 3) & ~3))
 
@@ -712,6 +765,8 @@ DEV void abb_reset_env(const ShfAbbTaskParams& tp, int nd, int nbx, int64_t gid,
 template <int G>
 __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* stats_lds = smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS;
+  stats_block_init(stats_lds);
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(A.tp);
     uint32_t* dst = reinterpret_cast<uint32_t*>(smem + MODEL_WORDS + SCENE_WORDS);
@@ -727,7 +782,7 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
   const int nbx = A.S.nboxes, actors = 1 + nbx;
   const int nb = m->nb, nd = m->nd, nbt = nb + nbx, nslots = m->np + box_slot_count(nbx, m->nsph);
   const int env_words = env_lds_words(nbt, nd, nslots, nslots * PT_STRIDE + SHF_MAX_DOFS, actors);
-  EnvLds L = env_lds_carve(smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS + es * env_words, nbt, nd, nslots, actors);
+  EnvLds L = env_lds_carve(smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS + es * env_words, nbt, nd, nslots, actors);
   float* tgtl = L.pt + nslots * PT_STRIDE;  // POS targets of this env step
 
   float* dof = A.S.dof + (size_t)e * nd * 2;
@@ -831,6 +886,21 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
 #pragma unroll
     for (int k = 0; k < 4; k++) A.done_sums[(size_t)k * n + e] = done[k];
     A.ep_len[e] = ep;
+    {
+      // extras["episode"] (env.py:149-158 + episode_log, a_prior_stage.py:94-95)
+      const long long sv[4] = {stats_fix(done[0]), stats_fix(done[1]), (reset && success) ? 1ll : 0ll, reset ? 1ll : 0ll};
+      const int first = (int)blockIdx.x * epb, eib = n - first < epb ? n - first : epb;
+      const float Ts = tp.max_episode_length_s;
+      stats_contribute<4>(A.stats, stats_lds, sv, eib, [n, Ts](const long long* t, float* o) {
+        const float c = (float)t[3];
+        const float s0 = (float)t[0] * (1.0f / STATS_FIX), s1 = (float)t[1] * (1.0f / STATS_FIX);
+        o[0] = s0; o[1] = s1; o[2] = (float)t[2]; o[3] = c;
+        o[4] = c > 0.0f ? s0 / c / Ts : 0.0f;
+        o[5] = c > 0.0f ? s1 / c / Ts : 0.0f;
+        o[6] = c > 0.0f ? o[2] / c : 0.0f;
+        o[7] = (float)n;
+      });
+    }
     const float co = tp.clip_obs;
     float* o = A.obs + (size_t)e * 6;
     o[0] = rclampf(L.root[13 * tp.cube_actor], -co, co); o[1] = rclampf(L.root[13 * tp.cube_actor + 1], -co, co);
@@ -862,30 +932,6 @@ __global__ void k_abb_reset_all(AbbArgs A) {
   A.ep_len[e] = 0;
   A.reset[e] = 1;
   A.reset_count[e] += 1;
-}
-
-// extras["episode"] for AbbPushBox (env.py:149-158 + episode_log a_prior_stage.py:94-95)
-__global__ __launch_bounds__(1024) void k_abb_stats(int n, float max_episode_length_s, const float* done_sums, float* out) {
-  __shared__ float part[2][1024];
-  const int t = threadIdx.x, k = blockIdx.x;
-  float acc = 0.0f, cnt = 0.0f;
-  for (int e = t; e < n; e += 1024) {
-    acc += done_sums[(size_t)k * n + e];
-    cnt += done_sums[(size_t)3 * n + e];
-  }
-  part[0][t] = acc; part[1][t] = cnt;
-  __syncthreads();
-  for (int s = 512; s >= 1; s >>= 1) {
-    if (t < s) { part[0][t] += part[0][t + s]; part[1][t] += part[1][t + s]; }
-    __syncthreads();
-  }
-  if (t == 0) {
-    const float sum = part[0][0], c = part[1][0];
-    out[k] = sum;
-    if (k < 2) out[4 + k] = c > 0.0f ? sum / c / max_episode_length_s : 0.0f;
-    if (k == 2) out[6] = c > 0.0f ? sum / c : 0.0f;
-    if (k == 3) out[7] = (float)n;
-  }
 }
 
 // ---------------------------------------------------------------- C ABI --
@@ -1200,7 +1246,8 @@ extern "C" int shf_a1_layout(const ShfA1Task* task, int32_t id, int64_t shape[4]
     case SHF_A1_TORIGINS: *ndim = 3; shape[0] = task->tp.max_terrain_level; shape[1] = task->tp.num_terrain_cols; shape[2] = 3; break;
     case SHF_A1_RESET_COUNT: *ndim = 1; shape[0] = N; *dtype = 1; break;
     case SHF_A1_DONE_SUMS: *ndim = 2; shape[0] = 8; shape[1] = N; break;
-    case SHF_A1_STATS: *ndim = 2; shape[0] = task->stats_ring; shape[1] = 16; break;
+    case SHF_A1_STATS: *ndim = 2; shape[0] = task->stats_ring + 1; shape[1] = 16; break;
+    case SHF_A1_STATS_ACC: *ndim = 2; shape[0] = task->stats_ring + 1; shape[1] = STATS_COLS; *dtype = 4; break;
     case SHF_A1_PARAMS: *ndim = 1; shape[0] = sizeof(ShfA1TaskParams); *dtype = 3; break;
     default: return fail("shf_a1_layout: unknown tensor id");
   }
@@ -1237,6 +1284,10 @@ static int a1_args(ShfA1Task* task, const float* raw_actions_dev, const char* wh
   A.reset_count = (int32_t*)task->t[SHF_A1_RESET_COUNT];
   A.done_sums = (float*)task->t[SHF_A1_DONE_SUMS];
   A.body_state = (float*)s->t[SHF_T_BODY_STATE];
+  A.stats.acc = (unsigned long long*)task->t[SHF_A1_STATS_ACC];
+  A.stats.out = (float*)task->t[SHF_A1_STATS];
+  A.stats.ring = task->stats_ring;
+  A.stats.out_cols = 16;
   return 0;
 }
 
@@ -1248,7 +1299,7 @@ extern "C" int shf_a1_step(ShfA1Task* task, const float* raw_actions_dev, void* 
   const int nobs = 12 + 2 * s->model.nd + s->model.nd * task->tp.num_history + task->tp.num_height_points;
   const int epb = 256 / s->group;
   dim3 grid((s->n + epb - 1) / epb), block(256);
-  const size_t lds = sim_lds_bytes(s, TASK_WORDS, SCR_OBS + nobs);
+  const size_t lds = sim_lds_bytes(s, TASK_WORDS + STATS_LDS_WORDS, SCR_OBS + nobs);
   int r;
   if (s->terr.warped && s->group == 64)
     return fail("shf_a1_step: a trimesh terrain needs 16 or 32 lanes per env (the 128-VGPR instantiation has no room for it)");
@@ -1270,14 +1321,6 @@ extern "C" int shf_a1_step(ShfA1Task* task, const float* raw_actions_dev, void* 
     }
   }
   return r;
-}
-
-extern "C" int shf_a1_episode_stats(ShfA1Task* task, int64_t slot, void* stream) {
-  if (!task || !task->t[SHF_A1_STATS] || !task->t[SHF_A1_DONE_SUMS]) return fail("shf_a1_episode_stats: tensors not bound");
-  if (slot < 0) return fail("shf_a1_episode_stats: negative slot");
-  float* out = (float*)task->t[SHF_A1_STATS] + (size_t)(slot % task->stats_ring) * 16;
-  return launch(k_a1_stats, dim3(8), dim3(1024), 0, stream, (int)task->sim->n, task->tp.max_episode_length_s,
-                (const float*)task->t[SHF_A1_DONE_SUMS], out);
 }
 
 extern "C" int shf_a1_reset_all(ShfA1Task* task, void* stream) {
@@ -1328,7 +1371,8 @@ extern "C" int shf_abb_layout(const ShfAbbTask* task, int32_t id, int64_t shape[
     case SHF_ABB_DOF_TARGETS: *ndim = 2; shape[0] = N; shape[1] = nd; break;
     case SHF_ABB_RESET_COUNT: *ndim = 1; shape[0] = N; *dtype = 1; break;
     case SHF_ABB_DONE_SUMS: *ndim = 2; shape[0] = 4; shape[1] = N; break;
-    case SHF_ABB_STATS: *ndim = 2; shape[0] = task->stats_ring; shape[1] = 8; break;
+    case SHF_ABB_STATS: *ndim = 2; shape[0] = task->stats_ring + 1; shape[1] = 8; break;
+    case SHF_ABB_STATS_ACC: *ndim = 2; shape[0] = task->stats_ring + 1; shape[1] = STATS_COLS; *dtype = 4; break;
     case SHF_ABB_PARAMS: *ndim = 1; shape[0] = sizeof(ShfAbbTaskParams); *dtype = 3; break;
     default: return fail("shf_abb_layout: unknown tensor id");
   }
@@ -1362,6 +1406,10 @@ static int abb_args(ShfAbbTask* task, const float* raw_actions_dev, const char* 
   A.done_sums = (float*)task->t[SHF_ABB_DONE_SUMS];
   A.body_state = (float*)s->t[SHF_T_BODY_STATE];
   A.jacobian = (float*)s->t[SHF_T_JACOBIAN];
+  A.stats.acc = (unsigned long long*)task->t[SHF_ABB_STATS_ACC];
+  A.stats.out = (float*)task->t[SHF_ABB_STATS];
+  A.stats.ring = task->stats_ring;
+  A.stats.out_cols = 8;
   return 0;
 }
 
@@ -1373,20 +1421,13 @@ extern "C" int shf_abb_step(ShfAbbTask* task, const float* raw_actions_dev, void
   const int epb = 256 / s->group;
   dim3 grid((s->n + epb - 1) / epb), block(256);
   const int nbx = s->nboxes, nslots = s->model.np + box_slot_count(nbx, s->model.nsph);
-  const size_t lds = ((size_t)MODEL_WORDS + SCENE_WORDS + ABB_WORDS +
+  const size_t lds = ((size_t)MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS +
                       (size_t)epb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, nslots * PT_STRIDE + SHF_MAX_DOFS, 1 + nbx)) * 4;
   switch (s->group) {
     case 64: return launch(k_abb_step<64>, grid, block, lds, stream, A);
     case 32: return launch(k_abb_step<32>, grid, block, lds, stream, A);
     default: return launch(k_abb_step<16>, grid, block, lds, stream, A);
   }
-}
-extern "C" int shf_abb_episode_stats(ShfAbbTask* task, int64_t slot, void* stream) {
-  if (!task || !task->t[SHF_ABB_STATS] || !task->t[SHF_ABB_DONE_SUMS]) return fail("shf_abb_episode_stats: tensors not bound");
-  if (slot < 0) return fail("shf_abb_episode_stats: negative slot");
-  float* out = (float*)task->t[SHF_ABB_STATS] + (size_t)(slot % task->stats_ring) * 8;
-  return launch(k_abb_stats, dim3(4), dim3(1024), 0, stream, (int)task->sim->n, task->tp.max_episode_length_s,
-                (const float*)task->t[SHF_ABB_DONE_SUMS], out);
 }
 extern "C" int shf_abb_reset_all(ShfAbbTask* task, void* stream) {
   AbbArgs A;

@@ -3,8 +3,8 @@
 Same observable behaviour as the hook-based examples/a1_conditional env running on
 the `gym` facade (quirks Q1-Q15 of SURVEY.md 3.1 preserved), but nothing between
 `step(actions)` and the returned tensors runs in torch: physics x5, get_heights,
-termination, rewards, on-device reset and observations are shf_a1_step; the
-episode logging reduction is shf_a1_episode_stats.  Buffers keep the reference's
+termination, rewards, on-device reset, observations and the episode logging
+reduction are shf_a1_step.  Buffers keep the reference's
 names (obs_buf, rew_buf, reset_buf, episode_length_buf, extras, ...: env.py:34-58)
 so rsl_rl-style callers work unchanged.
 
@@ -156,20 +156,29 @@ class FusedA1Env:
         self.body_state, self.contact_state = S[_abi.T_BODY_STATE], S[_abi.T_CONTACT]
         self.measured_heights = T[_abi.A1_HEIGHTS]
         self.send_timeouts = send_timeouts
+        self.reward_names = REWARD_NAMES
         self.extras = {}
         self.common_step_counter = 0
+        # actors are created at default_pos + env origin (units.py:57-70 with Q14 fixed), identity pose, at rest: the
+        # first reset_idx(all) then sees distance 0 and zero commands, so no env changes its terrain level (Q13)
+        spawn = torch.zeros(num_envs, 13, device=self.device)
+        spawn[:, :3] = T[_abi.A1_ORIGINS] + torch.tensor(list(self.task_params.default_pos), device=self.device)
+        spawn[:, 3:7] = torch.tensor(list(self.task_params.default_quat), device=self.device)
+        S[_abi.T_ROOT_STATE].copy_(spawn)
         # place every env (ShifuVecEnv.__init__ leaves reset_buf at ones: env.py:48)
         self.task.reset_all()
 
     # -- VecEnv surface ------------------------------------------------------
     def step(self, actions: torch.Tensor):
-        slot = self.task.step(actions)
+        self.task.step(actions)
         self.common_step_counter += 1
-        self._fill_extras(slot)
+        self._fill_extras()
         return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
 
-    def _fill_extras(self, slot: int):
-        st = self.task.tensors[_abi.A1_STATS][slot]
+    def _fill_extras(self):
+        # the last row of the statistics tensor always holds the step that ran last (views: consume before the next
+        # step, like the reference's extras, which are overwritten every step)
+        st = self.task.tensors[_abi.A1_STATS][-1]
         ep = {n: st[8 + k] for k, n in enumerate(REWARD_NAMES)}
         ep["terrain_levels"] = st[14]                                  # episode_log, a1_conditional.py:126-129
         self.extras["episode"] = ep

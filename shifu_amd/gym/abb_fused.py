@@ -46,6 +46,7 @@ class FusedAbbEnv:
         self.dof_state, self.root_state = S[_abi.T_DOF_STATE], S[_abi.T_ROOT_STATE]
         self.body_state, self.contact_state, self.jacobian = S[_abi.T_BODY_STATE], S[_abi.T_CONTACT], S[_abi.T_JACOBIAN]
         self.extras = {}
+        self.reward_names = REWARD_NAMES
         # spawn poses + the tensors Isaac Gym would show after create_actor/prepare_sim
         A = 4
         root = torch.zeros(num_envs * A, 13, device=self.device)
@@ -59,8 +60,8 @@ class FusedAbbEnv:
         self.task.reset_all()
 
     def step(self, actions: torch.Tensor):
-        slot = self.task.step(actions)
-        st = self.task.tensors[_abi.ABB_STATS][slot]
+        self.task.step(actions)
+        st = self.task.tensors[_abi.ABB_STATS][-1]
         self.extras["episode"] = {REWARD_NAMES[0]: st[4], REWARD_NAMES[1]: st[5], "success_rate": st[6]}
         self.extras["episode_sums"] = st[:4]
         self.extras["time_outs"] = self.time_out_buf

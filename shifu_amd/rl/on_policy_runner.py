@@ -126,6 +126,10 @@ class OnPolicyRunner:
             if self.log_dir is not None:
                 if "episode" in infos:
                     R["ep_infos"].append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in infos["episode"].items()})
+                if "episode_sums" in infos:          # (sums..., count) of the episodes that finished in this step
+                    if R.get("ep_sums") is None:
+                        R["ep_sums"] = torch.zeros_like(infos["episode_sums"], dtype=torch.float64)
+                    R["ep_sums"] += infos["episode_sums"]
                 R["cur_reward_sum"] += rewards
                 R["cur_episode_length"] += 1
                 d = (dones > 0).to(torch.float32)
@@ -150,6 +154,17 @@ class OnPolicyRunner:
             for key in locs["ep_infos"][0]:
                 vals = [torch.as_tensor(e[key], dtype=torch.float32, device=self.device).reshape(-1) for e in locs["ep_infos"]]
                 rec["episode/" + key] = float(torch.cat(vals).mean())
+        sums, names = locs["R"].get("ep_sums"), getattr(self.env, "reward_names", None)
+        if sums is not None and names is not None:
+            # An env that reports (sum, count) per step gets the exact rollout mean, sum of sums / sum of counts.  (The
+            # per-step means above weigh every step alike; the fused envs report 0 for a step in which no episode
+            # ended, where the reference keeps the previous value, so that average would be biased towards 0.)
+            tot = sums.tolist()
+            cnt = tot[len(names) + 1] if len(tot) > len(names) + 1 else tot[-1]
+            if cnt > 0:
+                for k, name in enumerate(names):
+                    rec["episode/" + name] = tot[k] / cnt / float(self.env.max_episode_length_s)
+            sums.zero_()
         if len(locs["rewbuffer"]) > 0:
             rec["mean_reward"] = self._recent_mean(locs["rewbuffer"])
             rec["mean_episode_length"] = self._recent_mean(locs["lenbuffer"])

@@ -43,6 +43,8 @@ def _sync_state(hook, fused):
     hook.command_buf.copy_(T[_abi.A1_COMMAND])
     hook.robot.rand_force_buf.copy_(T[_abi.A1_PUSH])
     hook.isg_env.env_origins.copy_(T[_abi.A1_ORIGINS])
+    hook.terrain_levels.copy_(T[_abi.A1_LEVELS])
+    hook.isg_env.terrain_levels.copy_(T[_abi.A1_LEVELS])
     hook.episode_length_buf.copy_(T[_abi.A1_EP_LEN])
     hook.actions_recorder.history_buf.copy_(T[_abi.A1_HISTORY])
     for k, name in enumerate(hook.episode_rewards):
@@ -59,6 +61,10 @@ def test_same_terrain_and_layout():
     assert torch.allclose(hook.isg_env.terrain_origins, fused.task.tensors[_abi.A1_TORIGINS])
     assert hook.robot.rigid_body_dict["base"] == 0 and hook.robot.num_bodies == 17 and hook.robot.num_dof == 12
     assert hook.obs_buf.shape == fused.obs_buf.shape == (32, 259)
+    # Q13: the first reset_idx(all) (distance 0, zero commands) leaves every env on level 0 of its column
+    assert int(fused.terrain_levels.abs().sum()) == 0
+    hook.reset()
+    assert int(hook.terrain_levels.abs().sum()) == 0
 
 
 def _compare_step(hook, fused, it, m, o1, o2, r1, r2, obs_from=0):
