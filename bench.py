@@ -142,10 +142,29 @@ def count_flops(workload: str, n: int = 64, warm: int = 40, steps: int = 20) -> 
     return L.shf_flopcount_read(1) / float(n * steps)
 
 
+def usable_cores() -> int:
+    """Cores this process can actually run on: the affinity mask, capped by the cgroup CPU quota (a container that sees
+    256 logical CPUs but is throttled to a few would otherwise be timed with 256 threads fighting over them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())       # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(workload: str, seconds_budget: float = 16.0):
     """The oracle's fused env step on host cores.  Deterministic thread counts: one thread, and every core this process
     may use (OpenMP over envs, 4096 envs so that each thread has tens of envs per step).  Bounded sample."""
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail = usable_cores()
 
     def timed(n, threads, budget):
         step = oracle_workload(workload, n)
@@ -158,14 +177,21 @@ def cpu_baseline(workload: str, seconds_budget: float = 16.0):
             el = time.perf_counter() - t0
             if el > budget or k >= 2000:
                 return n * k / el, k
-    v1, k1 = timed(256, 1, seconds_budget * 0.3)
-    vall, kall = timed(4096, avail, seconds_budget * 0.7)
+    v1, k1 = timed(256, 1, seconds_budget * 0.25)
+    # every usable core, and half / a quarter of them (SMT siblings and memory-bound phases can make fewer threads
+    # faster): the same three counts on every box, the best one reported, all three listed
+    tried = {}
+    for c in sorted({avail, max(1, avail // 2), max(1, avail // 4)}, reverse=True):
+        tried[c] = timed(4096, c, seconds_budget * 0.25)
+    cores = max(tried, key=lambda c: tried[c][0])
+    vall, kall = tried[cores]
     what = "ABB push-box" if workload == "abb" else f"A1 {workload}"
-    return {"value": vall, "unit": "env-steps/s", "cores": avail, "kind": "port", "value_1thread": v1,
-            "sample": f"oracle/shf_oracle.c (f32) on the same {what} workload: 4096 envs x {kall} vec-steps on {avail} threads "
-                      f"(OpenMP over envs) = `value`; 256 envs x {k1} vec-steps on 1 thread = `value_1thread`.  "
-                      f"kind=port because the reference's CPU pipeline (Isaac Gym sim_device=cpu, use_gpu_pipeline=False) "
-                      f"is a closed binary that cannot be installed offline"}
+    return {"value": vall, "unit": "env-steps/s", "cores": cores, "kind": "port", "value_1thread": v1,
+            "threads_tried": {str(c): v[0] for c, v in tried.items()},
+            "sample": f"oracle/shf_oracle.c (f32) on the same {what} workload: 4096 envs x {kall} vec-steps on {cores} threads "
+                      f"(OpenMP over envs; best of {sorted(tried)} threads, {avail} usable cores) = `value`; 256 envs x {k1} "
+                      f"vec-steps on 1 thread = `value_1thread`.  kind=port because the reference's CPU pipeline (Isaac Gym "
+                      f"sim_device=cpu, use_gpu_pipeline=False) is a closed binary that cannot be installed offline"}
 
 
 def committed_profile(kernel_key: str):

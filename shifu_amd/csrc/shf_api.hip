@@ -267,6 +267,11 @@ DEV void stats_block_init(float* lds_words) {
   if (threadIdx.x < STATS_LDS_WORDS) reinterpret_cast<uint32_t*>(lds_words)[threadIdx.x] = 0u;   // before stage_model's barrier
 }
 // Called by lane 0 of every env group of the block once its NK values are final.  FIN(acc[NK], out) -> ring row.
+// Ordering without agent-scope fences (on a multi-XCD part an agent-scope release writes the XCD's whole dirty L2 back
+// -- here the ~13 MB of outputs the launch has just produced -- once per block): every global operation below is an
+// agent-scope atomic, which is performed at the device's point of coherence; a block waits for its additions to be
+// acknowledged (s_waitcnt through a workgroup-scope fence) before it takes its ticket, so whoever draws the last
+// ticket reads complete totals -- with atomic exchanges, which also clear the slot.
 template <int NK, class FIN>
 DEV void stats_contribute(const StatsArgs& S, float* lds_words, const long long* v, int envs_in_block, FIN finalize) {
   unsigned long long* blk = reinterpret_cast<unsigned long long*>(lds_words);
@@ -284,21 +289,20 @@ DEV void stats_contribute(const StatsArgs& S, float* lds_words, const long long*
     const unsigned long long t = __hip_atomic_load(&blk[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (t != 0ull) __hip_atomic_fetch_add(&row[k], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  const unsigned long long ticket = __hip_atomic_fetch_add(&row[8], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt: the additions above are acknowledged
+  const unsigned long long ticket = __hip_atomic_fetch_add(&row[8], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (ticket != (unsigned long long)gridDim.x - 1ull) return;
   // last block of the launch
   long long tot[NK];
 #pragma unroll
-  for (int k = 0; k < NK; k++) {
-    tot[k] = (long long)__hip_atomic_load(&row[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&row[k], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  for (int k = 0; k < NK; k++)
+    tot[k] = (long long)__hip_atomic_exchange(&row[k], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(&row[8], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   float* o = S.out + (size_t)(step % (unsigned long long)S.ring) * S.out_cols;
   finalize(tot, o);
   float* latest = S.out + (size_t)S.ring * S.out_cols;     // row `ring`: always the step that ran last
   for (int k = 0; k < S.out_cols; k++) latest[k] = o[k];
-  __hip_atomic_store(ctl, step + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(ctl, step + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------- fused A1 step --
@@ -1038,8 +1042,13 @@ extern "C" int shf_sim_bind(ShfSim* sim, int32_t id, void* device_ptr) {
 
 static int need(const ShfSim* s, std::initializer_list<int> ids, const char* who) {
   if (!s || !s->finalized) return fail(std::string(who) + ": sim not finalized");
-  for (int id : ids)
-    if (!s->t[id]) return fail(std::string(who) + ": tensor " + std::to_string(id) + " not bound");
+  for (int id : ids) {
+    // a model without degrees of freedom has zero-sized dof tensors: the host has no pointer to bind for them
+    const bool dof_tensor = id == SHF_T_DOF_STATE || id == SHF_T_SIM_DOF || id == SHF_T_EFFORT || id == SHF_T_POS_TARGET ||
+                            id == SHF_T_VEL_TARGET;
+    if (!s->t[id] && !(dof_tensor && s->model.nd == 0))
+      return fail(std::string(who) + ": tensor " + std::to_string(id) + " not bound");
+  }
   return 0;
 }
 
@@ -1117,7 +1126,7 @@ extern "C" int shf_sim_refresh(ShfSim* sim, int32_t mask, void* stream) {
   if (int r = need(sim, {SHF_T_SIM_DOF, SHF_T_SIM_ROOT, SHF_T_MODEL}, "shf_sim_refresh")) return r;
   hipStream_t st = (hipStream_t)stream;
   const size_t N = sim->n, nd = sim->model.nd, nb = sim->model.nb, A = 1 + sim->nboxes, B = nb + sim->nboxes;
-  if ((mask & SHF_REFRESH_DOF) && sim->t[SHF_T_DOF_STATE])
+  if ((mask & SHF_REFRESH_DOF) && sim->t[SHF_T_DOF_STATE] && nd > 0)
     HIP_OK(hipMemcpyAsync(sim->t[SHF_T_DOF_STATE], sim->t[SHF_T_SIM_DOF], N * nd * 2 * 4, hipMemcpyDeviceToDevice, st));
   if ((mask & SHF_REFRESH_ROOT) && sim->t[SHF_T_ROOT_STATE])
     HIP_OK(hipMemcpyAsync(sim->t[SHF_T_ROOT_STATE], sim->t[SHF_T_SIM_ROOT], N * A * 13 * 4, hipMemcpyDeviceToDevice, st));

@@ -254,8 +254,9 @@ class Gym:
     def add_triangle_mesh(self, sim: SimHandle, vertices, triangles, params: TriangleMeshParams):
         """Trimesh terrain (the reference's effective A1 terrain, Q5).  The mesh is expected to come from
         convert_heightfield_to_trimesh; it is collided as that warped grid (ShfTerrain.warped) when
-        the caller passes the height map and slope threshold it was made from, else as the height map recovered
-        from the vertices."""
+        the caller passes the height map and slope threshold it was made from; without that hint the map, its scales
+        and the vertex shifts are recovered exactly from the vertex / triangle arrays (and any other kind of mesh is
+        refused)."""
         if getattr(params, "height_samples", None) is not None:
             # hint set by shifu_amd's TerrainGymEnv._create_trimesh: the map the mesh came from
             from . import terrain_utils
@@ -267,15 +268,14 @@ class Gym:
             sim.terrain = ("heightfield", hs, float(params.horizontal_scale), float(params.vertical_scale),
                            float(-params.transform.p.x), 0.5 * (params.static_friction + params.dynamic_friction), warp)
             return
-        v = np.asarray(vertices, dtype=np.float32).reshape(-1, 3)
-        xs = np.unique(np.round(v[:, 0], 4))
-        hs_scale = float(np.median(np.diff(xs))) if len(xs) > 1 else 1.0
-        rows = int(round((v[:, 0].max() - v[:, 0].min()) / hs_scale)) + 1
-        cols = params.nb_vertices // rows
-        z = v[:, 2].reshape(rows, cols)
-        vs = float(getattr(params, "vertical_scale", 0.005))
-        sim.terrain = ("heightfield", np.ascontiguousarray(np.rint(z / vs).astype(np.int16)), hs_scale, vs,
-                       float(-params.transform.p.x), 0.5 * (params.static_friction + params.dynamic_friction))
+        # no hint (e.g. the reference's own TerrainGymEnv._create_trimesh, isaac_gym.py:369-385, on this facade): the
+        # generator keeps the vertices in grid order, so samples, scales and vertex shifts are recovered exactly
+        from . import terrain_utils
+        if params.nb_vertices * 3 != np.asarray(vertices).size or params.nb_triangles * 3 != np.asarray(triangles).size:
+            raise ValueError("add_triangle_mesh: nb_vertices / nb_triangles do not match the arrays")
+        hs, hscale, vscale, warp = terrain_utils.heightfield_from_trimesh(vertices, triangles)
+        sim.terrain = ("heightfield", hs, hscale, vscale, float(-params.transform.p.x),
+                       0.5 * (params.static_friction + params.dynamic_friction), warp)
 
     def load_asset(self, sim, rootpath, filename, options: AssetOptions = None):
         import os

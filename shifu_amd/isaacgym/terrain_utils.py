@@ -137,6 +137,13 @@ def trimesh_warp_map(height_field_raw, horizontal_scale, vertical_scale, slope_t
         dx = dy = np.zeros((rows, cols))
     else:
         dx, dy = vertex_shifts(hf.astype(np.int64), horizontal_scale, vertical_scale, slope_threshold)
+    return warp_map_from_shifts(dx, dy)
+
+
+def warp_map_from_shifts(dx, dy):
+    """Per-vertex bytes (see trimesh_warp_map) from explicit vertex shifts in cells."""
+    dx, dy = np.asarray(dx), np.asarray(dy)
+    rows, cols = dx.shape
     moved = (dx != 0) | (dy != 0)
     pad = np.pad(moved, ((1, 2), (1, 2)), mode="constant")
     near = np.zeros((rows, cols), bool)
@@ -145,6 +152,50 @@ def trimesh_warp_map(height_field_raw, horizontal_scale, vertical_scale, slope_t
             near |= pad[a:a + rows, b:b + cols]
     w = (dx.astype(np.int64) + 1) | ((dy.astype(np.int64) + 1) << 2) | ((~near).astype(np.int64) << 7)
     return w.astype(np.uint8)
+
+
+def heightfield_from_trimesh(vertices, triangles):
+    """Inverse of convert_heightfield_to_trimesh: (int16 samples, horizontal_scale, vertical_scale, warp bytes) of a
+    mesh that function made -- exact, because it keeps the vertices in grid order and only shifts some of them by one
+    cell in x / y.  Anything else (another triangulation, off-grid vertices, heights that are not multiples of one
+    vertical scale) raises: the backend collides grid terrains only."""
+    v = np.asarray(vertices, dtype=np.float64).reshape(-1, 3)
+    t = np.asarray(triangles).reshape(-1, 3).astype(np.int64)
+    n = v.shape[0]
+    bad = NotImplementedError("add_triangle_mesh: only meshes made by convert_heightfield_to_trimesh (a grid of height "
+                              "samples, cells split along (i,j)-(i+1,j+1)) can be collided by this backend")
+    if t.shape[0] < 2 or t[0, 0] != 0 or t[0, 2] != 1:
+        raise bad
+    cols = int(t[0, 1]) - 1
+    if cols < 2 or n % cols:
+        raise bad
+    rows = n // cols
+    if t.shape[0] != 2 * (rows - 1) * (cols - 1):
+        raise bad
+    ind0 = (np.arange(rows - 1)[:, None] * cols + np.arange(cols - 1)[None, :]).reshape(-1)
+    exp = np.empty((2 * ind0.size, 3), np.int64)
+    exp[0::2] = np.stack([ind0, ind0 + cols + 1, ind0 + 1], 1)
+    exp[1::2] = np.stack([ind0, ind0 + cols, ind0 + cols + 1], 1)
+    if not np.array_equal(t, exp):
+        raise bad
+    x, y, z = v[:, 0].reshape(rows, cols), v[:, 1].reshape(rows, cols), v[:, 2].reshape(rows, cols)
+    hs = round(float(x.max() - x.min()) / (rows - 1), 6)
+    if not hs > 0 or abs((y.max() - y.min()) / (cols - 1) - hs) > 1e-4 * hs:
+        raise bad
+    dx = (x - x.min() - np.arange(rows)[:, None] * hs) / hs
+    dy = (y - y.min() - np.arange(cols)[None, :] * hs) / hs
+    if np.abs(dx - np.rint(dx)).max() > 1e-3 or np.abs(dy - np.rint(dy)).max() > 1e-3 or \
+            np.abs(np.rint(dx)).max() > 1 or np.abs(np.rint(dy)).max() > 1:
+        raise bad
+    u = np.unique(np.abs(z))
+    steps = np.diff(u)
+    steps = steps[steps > 1e-7]
+    vs = round(float(steps.min()), 6) if steps.size else 0.005
+    k = z / vs
+    if np.abs(k - np.rint(k)).max() > 2e-2 or np.abs(k).max() > 32767:
+        raise bad
+    return (np.ascontiguousarray(np.rint(k).astype(np.int16)), hs, vs,
+            warp_map_from_shifts(np.rint(dx).astype(np.int64), np.rint(dy).astype(np.int64)))
 
 
 def pack_trimesh_samples(height_field_raw, warp):
