@@ -215,7 +215,8 @@ def main():
                          "abb = config 5")
     ap.add_argument("--group", type=int, default=None, help="lanes per env: 64 = one wavefront per env; default 32 (A1) / 16 (ABB), the fastest measured (DESIGN.md 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch the vec-step eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--graph", action="store_true", help="replay the vec-step from a captured hipGraph instead of launching it "
+                    "eagerly (measured slower on ROCm 7.2: 84.7 vs 73.9 us per vec-step, profiles/r02_bench_*.json)")
     ap.add_argument("--decimation", type=int, default=4, help="(experiments only) control.decimation")
     ap.add_argument("--no-extra-substep", action="store_true", help="(experiments only) drop the Q1 sub-step")
     ap.add_argument("--log-interval", type=int, default=24, help="all-gather period (num_steps_per_env)")
@@ -286,10 +287,11 @@ def main():
             ev[1].record()
         return slot
 
-    # The vec-step is two launches (action draw + fused step); replaying them as one captured hipGraph removes the
-    # launch gaps.  HIP events cannot be recorded inside a replay, so the kernel's own duration is measured on the
-    # eager launches of the warm-up + a dedicated eager pass of the same K steps after the timed region.
-    use_graph = not args.no_graph
+    # The vec-step is two launches (action draw + fused step, which now carries the episode statistics).  --graph
+    # replays them as one captured hipGraph (possible because no launch argument depends on the step index).  HIP
+    # events cannot be recorded inside a replay, so the kernel's own duration is always measured on a dedicated eager
+    # pass of the same K steps after the timed region.
+    use_graph = args.graph
     for i in range(args.warmup):
         eager_step()
     graph = None

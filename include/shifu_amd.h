@@ -30,6 +30,9 @@ extern "C" {
 #define SHF_MAX_POINTS 96 /* contact sample points per articulation        */
 #define SHF_MAX_BOXES 4   /* extra single-body box actors per env          */
 #define SHF_MAX_SPHERES 8 /* collision spheres (vs boxes) per articulation */
+#define SHF_MAX_CAPSULES 16 /* self-collision capsules per articulation      */
+#define SHF_MAX_PAIRS 96    /* capsule pairs tested for self-collision       */
+#define SHF_MAX_SELF_CONTACTS 8 /* simultaneously active self-contacts per env (further ones are dropped, in pair order) */
 
 /* joint types of a reported body's inboard joint */
 enum { SHF_JOINT_ROOT = 0, SHF_JOINT_REVOLUTE = 1, SHF_JOINT_PRISMATIC = 2, SHF_JOINT_WELD = 3 };
@@ -91,6 +94,22 @@ typedef struct ShfModel {
   int32_t sph_body[SHF_MAX_SPHERES];
   float sph_pos[SHF_MAX_SPHERES][3];
   float sph_radius[SHF_MAX_SPHERES];
+
+  /* Self-collision (create_actor(..., collision_filter = 0), units.py:68): every collision shape of
+   * the URDF as one or two capsules (a sphere is a capsule of zero length; a box is the capsule -- or the two
+   * side-by-side capsules -- inscribed along its longest axis), and the pairs PhysX would test: all but shapes of
+   * one rigid body and of bodies joined by a joint.  A pair closer than the contact offset responds with the same
+   * contact law as a ground contact, equal and opposite on the two bodies.  self_collide = 0 switches it off. */
+  int32_t self_collide;
+  int32_t ncap;
+  int32_t npair;
+  int32_t pad_sc;
+  int32_t cap_body[SHF_MAX_CAPSULES];
+  float cap_a[SHF_MAX_CAPSULES][3];  /* segment end points in cap_body's frame */
+  float cap_b[SHF_MAX_CAPSULES][3];
+  float cap_radius[SHF_MAX_CAPSULES];
+  uint8_t pair_a[SHF_MAX_PAIRS];     /* capsule indices, pair_a < pair_b */
+  uint8_t pair_b[SHF_MAX_PAIRS];
 } ShfModel;
 
 /* A single-body box actor (gym.create_box, object.py:28-39). */

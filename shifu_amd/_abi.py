@@ -7,6 +7,9 @@ MAX_DOFS = 32
 MAX_POINTS = 96
 MAX_BOXES = 4
 MAX_SPHERES = 8
+MAX_CAPSULES = 16
+MAX_PAIRS = 96
+MAX_SELF_CONTACTS = 8
 
 JOINT_ROOT, JOINT_REVOLUTE, JOINT_PRISMATIC, JOINT_WELD = 0, 1, 2, 3
 DOF_MODE_NONE, DOF_MODE_POS, DOF_MODE_VEL, DOF_MODE_EFFORT = 0, 1, 2, 3
@@ -31,6 +34,9 @@ class ShfModel(C.Structure):
         ("drive_mode", i32 * MAX_DOFS), ("dof_body", i32 * MAX_DOFS),
         ("pt_body", i32 * MAX_POINTS), ("pt_pos", (f32 * 3) * MAX_POINTS), ("pt_radius", f32 * MAX_POINTS),
         ("sph_body", i32 * MAX_SPHERES), ("sph_pos", (f32 * 3) * MAX_SPHERES), ("sph_radius", f32 * MAX_SPHERES),
+        ("self_collide", i32), ("ncap", i32), ("npair", i32), ("pad_sc", i32),
+        ("cap_body", i32 * MAX_CAPSULES), ("cap_a", (f32 * 3) * MAX_CAPSULES), ("cap_b", (f32 * 3) * MAX_CAPSULES),
+        ("cap_radius", f32 * MAX_CAPSULES), ("pair_a", C.c_uint8 * MAX_PAIRS), ("pair_b", C.c_uint8 * MAX_PAIRS),
     ]
 
 

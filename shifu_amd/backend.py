@@ -330,7 +330,8 @@ class AbbTask:
         return idx % (self.tensors[_abi.ABB_STATS].shape[0] - 1)
 
     def kernel_symbol(self) -> str:
-        return f"_Z10k_abb_stepILi{self.sim.group}E"
+        fixed = self.sim.model.nb == 7 and self.sim.model.np == 3 and self.sim.nboxes == 3
+        return f"_Z10k_abb_stepILi{self.sim.group}E" + ("9FixedDims" if fixed else "7DynDims")
 
     @_on_device
     def reset_all(self):

@@ -145,14 +145,14 @@ __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
 // body rows from forward kinematics, box rows copied from their root rows; jacobian
 // (nb-1, 6, nd), rows [linear; angular] of each link origin (robot.py:125-128).
 // `body_state` / `jacobian` point at this env's slices (either may be null).  L.xch is scratch.
-template <int G>
+template <int G, class DM = DynDims>
 DEV void refresh_body_jac(const ShfModel* m, const EnvLds& L, int l, int actors, float* body_state, float* jacobian,
                           float* keep_xy = nullptr, int keep_body = 0) {
-  const int nb = m->nb, nd = m->nd;
+  const int nb = DM::nb(m), nd = DM::nd(m);
   BodyRegs B;
   LaneModel M;
-  lane_model_load<DynDims>(m, l, M);
-  kinematics<G>(m, L, l, M, B);
+  lane_model_load<DM>(m, l, M);
+  kinematics<G, DM>(m, L, l, M, B);
   if (body_state) {
     if (l < nb) {
       float* o = L.xch + 13 * l;
@@ -766,7 +766,9 @@ DEV void abb_reset_env(const ShfAbbTaskParams& tp, int nd, int nbx, int64_t gid,
   }
 }
 
-template <int G>
+// DM / SC: run-time model and scene (any arm, any boxes), or the shipped ABB scene fixed at compile time (ancestor-walk
+// kinematics, compile-time level loops, ballot-driven box folds) -- the host picks the latter only when both match.
+template <int G, class DM, class SC>
 __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* stats_lds = smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS;
@@ -783,8 +785,8 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
   const int e = blockIdx.x * epb + es;
   const int n = A.S.n;
   if (e >= n) return;
-  const int nbx = A.S.nboxes, actors = 1 + nbx;
-  const int nb = m->nb, nd = m->nd, nbt = nb + nbx, nslots = m->np + box_slot_count(nbx, m->nsph);
+  const int nbx = SC::NBX > 0 ? SC::NBX : A.S.nboxes, actors = 1 + nbx;
+  const int nb = DM::nb(m), nd = DM::nd(m), nbt = nb + nbx, nslots = DM::np(m) + box_slot_count(nbx, m->nsph);
   const int env_words = env_lds_words(nbt, nd, nslots, nslots * PT_STRIDE + SHF_MAX_DOFS, actors);
   EnvLds L = env_lds_carve(smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS + es * env_words, nbt, nd, nslots, actors);
   float* tgtl = L.pt + nslots * PT_STRIDE;  // POS targets of this env step
@@ -847,14 +849,17 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
   const float mu = A.S.friction[e];
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
   LaneModel M;
-  lane_model_load<DynDims>(m, l, M);
-  LanePoints<1> P;   // unused: point count only known at run time
+  lane_model_load<DM>(m, l, M);
+  LanePoints<LANE_ROUNDS(G, DM)> P;
+  if constexpr (DM::NPC > 0) lane_points_load<G>(m, DM::np(m), l, P);
+  const BoxLane BL = SC::NBX > 0 ? box_lane_load(m, l) : BoxLane();
   // net contact forces are reported for the last sub-step only (what the refreshed tensor shows)
-  for (int it = 0; it < nsub; it++) substep<G, true>(C, L, l, M, P, tgtl, nullptr, nullptr, mu, it == nsub - 1 ? L.xch : nullptr);
+  for (int it = 0; it < nsub; it++)
+    substep<G, true, DM, false, LaneModel, SC>(C, L, l, M, P, tgtl, nullptr, nullptr, mu, it == nsub - 1 ? L.xch : nullptr, BL);
   GROUP_SYNC();
   for (int i = l; i < 3 * nbt; i += G) A.S.contact[(size_t)e * nbt * 3 + i] = L.xch[i];
   GROUP_SYNC();
-  refresh_body_jac<G>(m, L, l, actors, bstate, jac, tgtl + nd, tp.ee_body);
+  refresh_body_jac<G, DM>(m, L, l, actors, bstate, jac, tgtl + nd, tp.ee_body);
 
   // post_step on one lane (env.py:93-106, a_prior_stage.py:97-135)
   if (l == 0) {
@@ -1432,10 +1437,17 @@ extern "C" int shf_abb_step(ShfAbbTask* task, const float* raw_actions_dev, void
   const int nbx = s->nboxes, nslots = s->model.np + box_slot_count(nbx, s->model.nsph);
   const size_t lds = ((size_t)MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS +
                       (size_t)epb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, nslots * PT_STRIDE + SHF_MAX_DOFS, 1 + nbx)) * 4;
+  if (AbbDims::matches(s->model) && AbbScene::matches(s->nboxes, s->boxes, s->model.nsph)) {
+    switch (s->group) {
+      case 64: return launch(k_abb_step<64, AbbDims, AbbScene>, grid, block, lds, stream, A);
+      case 32: return launch(k_abb_step<32, AbbDims, AbbScene>, grid, block, lds, stream, A);
+      default: return launch(k_abb_step<16, AbbDims, AbbScene>, grid, block, lds, stream, A);
+    }
+  }
   switch (s->group) {
-    case 64: return launch(k_abb_step<64>, grid, block, lds, stream, A);
-    case 32: return launch(k_abb_step<32>, grid, block, lds, stream, A);
-    default: return launch(k_abb_step<16>, grid, block, lds, stream, A);
+    case 64: return launch(k_abb_step<64, DynDims, DynScene>, grid, block, lds, stream, A);
+    case 32: return launch(k_abb_step<32, DynDims, DynScene>, grid, block, lds, stream, A);
+    default: return launch(k_abb_step<16, DynDims, DynScene>, grid, block, lds, stream, A);
   }
 }
 extern "C" int shf_abb_reset_all(ShfAbbTask* task, void* stream) {

@@ -13,6 +13,35 @@
 
 DEV bool box_is_dynamic(const ShfBoxDesc& b) { return !b.fixed && b.mass > 0.0f; }
 
+// Scene shape: read from the LDS scene at run time (any mix of boxes; `in contact` flags travel through LDS), or fixed
+// at compile time for a scene with exactly one free box, so that only its slots are evaluated -- one lane each, in one
+// or two passes -- and the folds pick the active ones out of wave ballots (no flag reads, no idle iterations), like
+// the articulation's own sample points.  Same operations on the same slots in the same order either way.
+struct DynScene { static constexpr int NBX = 0, DYN = 0, NSPH = 0; };
+template <int NBX_, int DYN_, int NSPH_>
+struct FixedScene {
+  static constexpr int NBX = NBX_, DYN = DYN_, NSPH = NSPH_;   // boxes per env, index of the free one, arm spheres
+  static bool matches(int nboxes, const ShfBoxDesc* boxes, int nsph) {
+    if (nboxes != NBX || nsph != NSPH) return false;
+    for (int k = 0; k < nboxes; k++)
+      if ((!boxes[k].fixed && boxes[k].mass > 0.0f) != (k == DYN)) return false;
+    return true;
+  }
+};
+typedef FixedScene<3, 1, 8> AbbScene;   // table (fixed), cube (free), goal pad (fixed); eight rod spheres (abb_task.py)
+// per-lane constants of the fixed-scene path: which of the arm's spheres sit on this lane's body / moving body
+struct BoxLane { unsigned sph_body = 0u, sph_dyn = 0u; };
+DEV BoxLane box_lane_load(const ShfModel* m, int l) {
+  BoxLane K;
+  for (int si = 0; si < m->nsph; si++) {
+    if (m->sph_body[si] == l) K.sph_body |= 1u << si;
+    if (m->dyn[m->sph_body[si]] == l) K.sph_dyn |= 1u << si;
+  }
+  return K;
+}
+// ballots of one sub-step (fixed-scene path): corner bit c * (NBX + 1) + tg, sphere bit si
+struct BoxMasks { unsigned long long corners = 0ull; unsigned spheres = 0u; };
+
 // slot layout in LDS (PT_STRIDE floats): r[3] n[3] f0[3] ct bn on (PT_* offsets, shf_device.h)
 DEV void slot_eval(float* o, float phi, const float* n, const float* r, const float* vs, const float* vp, float mu, float kc,
                    float beta, float veps, float vdep, float dt, float offset) {
@@ -134,6 +163,130 @@ DEV void sphere_vs_box(const float* bR, const float* bpos, const float* h, const
   for (int i = 0; i < 3; i++) rc[i] += bpos[i];
 }
 
+
+// ------------------------------------------------------------ self-collision --
+// Capsule pairs of the articulation itself (ShfModel.self_collide; reference units.py:68, collision filter 0).
+DEV void segment_closest(const float* p1, const float* q1, const float* p2, const float* q2, float* c1, float* c2) {
+  const float eps = 1e-12f;
+  const float d1[3] = {q1[0] - p1[0], q1[1] - p1[1], q1[2] - p1[2]}, d2[3] = {q2[0] - p2[0], q2[1] - p2[1], q2[2] - p2[2]};
+  const float r[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+  const float a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, r);
+  float s = 0.0f, t = 0.0f;
+  if (a <= eps && e <= eps) {
+    s = 0.0f; t = 0.0f;
+  } else if (a <= eps) {
+    t = rclampf(f / e, 0.0f, 1.0f);
+  } else {
+    const float c = dot3(d1, r);
+    if (e <= eps) {
+      s = rclampf(-c / a, 0.0f, 1.0f);
+    } else {
+      const float b = dot3(d1, d2);
+      const float denom = fmaf(a, e, -(b * b));
+      s = denom > eps ? rclampf(fmaf(b, f, -(c * e)) / denom, 0.0f, 1.0f) : 0.0f;
+      t = fmaf(b, s, f) / e;
+      if (t < 0.0f) { t = 0.0f; s = rclampf(-c / a, 0.0f, 1.0f); }
+      else if (t > 1.0f) { t = 1.0f; s = rclampf((b - c) / a, 0.0f, 1.0f); }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) { c1[k] = fmaf(d1[k], s, p1[k]); c2[k] = fmaf(d2[k], t, p2[k]); }
+}
+
+// One lane per capsule pair: pairs closer than the contact offset respond with the shared contact law; the active ones
+// are compacted, in pair order, into at most SHF_MAX_SELF_CONTACTS slots starting at slot `slot0` (their `on` word
+// holds pair index + 1), then folded into the two bodies (+f on a's, -f on b's).  Returns the number of active slots.
+template <int G>
+DEV int self_contacts(const StepCtx& C, const EnvLds& L, int l, bool isdyn, int slot0, BodyRegs& B, float mu_shape) {
+  const ShfModel* m = C.m;
+  const float dt = C.sp.dt, kc = C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
+  const float offset = C.sp.contact_offset;
+  const float beta = fmaf(kc, dt, C.sp.contact_d);
+  const int lane0 = (int)(threadIdx.x & 63u) - l;
+  const unsigned long long gmask = G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
+  const int npair = m->npair;
+  int count = 0;
+  for (int j = 0; j * G < npair; j++) {
+    const int p = l + j * G;
+    float slot[PT_STRIDE];
+    slot[PT_ON] = 0.0f;
+    if (p < npair) {
+      const int ia = m->pair_a[p], ib = m->pair_b[p];
+      const int ba = m->cap_body[ia], bb = m->cap_body[ib];
+      const float* pa = L.pose + ba * POSE_STRIDE;
+      const float* pb = L.pose + bb * POSE_STRIDE;
+      float Ra[9], Rb[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) { Ra[k] = pa[k]; Rb[k] = pb[k]; }
+      const float la[3] = {m->cap_a[ia][0], m->cap_a[ia][1], m->cap_a[ia][2]}, lb[3] = {m->cap_b[ia][0], m->cap_b[ia][1], m->cap_b[ia][2]};
+      const float lc[3] = {m->cap_a[ib][0], m->cap_a[ib][1], m->cap_a[ib][2]}, ld[3] = {m->cap_b[ib][0], m->cap_b[ib][1], m->cap_b[ib][2]};
+      float A0[3], A1[3], B0[3], B1[3], c1[3], c2[3];
+      mv3(Ra, la, A0); mv3(Ra, lb, A1); mv3(Rb, lc, B0); mv3(Rb, ld, B1);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { A0[k] += pa[9 + k]; A1[k] += pa[9 + k]; B0[k] += pb[9 + k]; B1[k] += pb[9 + k]; }
+      segment_closest(A0, A1, B0, B1, c1, c2);
+      const float dv[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
+      const float d = sqrtf(dot3(dv, dv));
+      const float ra = m->cap_radius[ia], rb = m->cap_radius[ib];
+      const float gap = d - ra - rb;
+      if (gap < offset) {
+        float n[3] = {0.0f, 0.0f, 1.0f}, P[3];
+        if (d > 1e-9f) { const float inv = 1.0f / d; n[0] = dv[0] * inv; n[1] = dv[1] * inv; n[2] = dv[2] * inv; }
+        const float hp = fmaf(0.5f, gap, rb);
+#pragma unroll
+        for (int k = 0; k < 3; k++) P[k] = fmaf(n[k], hp, c2[k]);
+        // spatial velocities of the two (moving) bodies: welded links share their carrier's
+        const float* qa = L.pose + m->dyn[ba] * POSE_STRIDE;
+        const float* qb = L.pose + m->dyn[bb] * POSE_STRIDE;
+        const float va[3] = {qa[12], qa[13], qa[14]}, vb[3] = {qb[12], qb[13], qb[14]};
+        float ta[3], tb[3], vs[3];
+        cross3(va, P, ta); cross3(vb, P, tb);
+#pragma unroll
+        for (int k = 0; k < 3; k++) vs[k] = (qa[15 + k] + ta[k]) - (qb[15 + k] + tb[k]);
+        slot_eval(slot, gap, n, P, vs, vs, mu_shape, kc, beta, veps, vdep, dt, offset);
+      }
+    }
+    const bool on = slot[PT_ON] != 0.0f;
+    const unsigned long long mask = (__ballot(on) >> lane0) & gmask;
+    const int mine = count + __builtin_popcountll(mask & ((1ull << l) - 1ull));
+    if (on && mine < SHF_MAX_SELF_CONTACTS) {
+      float* o = L.pt + (slot0 + mine) * PT_STRIDE;
+#pragma unroll
+      for (int k = 0; k < PT_STRIDE - 1; k++) o[k] = slot[k];
+      o[PT_ON] = (float)(p + 1);
+    }
+    count += __builtin_popcountll(mask);
+  }
+  if (count > SHF_MAX_SELF_CONTACTS) count = SHF_MAX_SELF_CONTACTS;
+  GROUP_SYNC();
+  if (isdyn) {
+    for (int k = 0; k < count; k++) {
+      const float* o = L.pt + (slot0 + k) * PT_STRIDE;
+      const int p = (int)o[PT_ON] - 1;
+      const int da = m->dyn[m->cap_body[m->pair_a[p]]], db = m->dyn[m->cap_body[m->pair_b[p]]];
+      if (da == l) slot_accumulate(B.IA, B.pA, o, 1.0f, dt, 1.0f);
+      if (db == l) slot_accumulate(B.IA, B.pA, o, -1.0f, dt, 1.0f);
+    }
+  }
+  return count;
+}
+
+// Adds the end-of-step self-contact forces to the net contact force of reported body l (contact_out row l).
+DEV void self_contact_forces(const StepCtx& C, const EnvLds& L, int l, int slot0, int count, float* contact_out) {
+  const ShfModel* m = C.m;
+  if (l >= m->nb || count == 0) return;
+  float f[3] = {contact_out[3 * l], contact_out[3 * l + 1], contact_out[3 * l + 2]};
+  const float* ab = L.acc + m->dyn[l] * 6;
+  const float abr[6] = {ab[0], ab[1], ab[2], ab[3], ab[4], ab[5]};
+  for (int k = 0; k < count; k++) {
+    const float* o = L.pt + (slot0 + k) * PT_STRIDE;
+    const int p = (int)o[PT_ON] - 1;
+    if (m->cap_body[m->pair_a[p]] == l) slot_force(o, abr, 1.0f, C.sp.dt, 1.0f, f);
+    if (m->cap_body[m->pair_b[p]] == l) slot_force(o, abr, -1.0f, C.sp.dt, 1.0f, f);
+  }
+  contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];
+}
+
 // slot indexing inside the env's contact region, after the articulation's np sample points
 DEV int corner_slot(const ShfModel* m, int nbx, int kd, int c, int tg) { return m->np + (kd * 8 + c) * (1 + nbx) + tg; }
 DEV int sphere_slot(const ShfModel* m, int nbx, int si, int kd) { return m->np + nbx * 8 * (1 + nbx) + si * nbx + kd; }
@@ -218,9 +371,129 @@ DEV void boxes_pose(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B) {
   GROUP_SYNC();
 }
 
+// The fixed-scene form of boxes_contacts: the free box's 8 x (1 + NBX) corner slots and NSPH sphere slots, one lane each.
+template <int G, class SC>
+DEV void boxes_contacts_fixed(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, float mu_shape, const float* g_art,
+                              const BoxLane& BL, BoxMasks& BM) {
+  const ShfModel* m = C.m;
+  const SceneDev* S = C.scene;
+  constexpr int nbx = SC::NBX, T = 1 + SC::NBX, kd = SC::DYN, NS = 8 * T;
+  static_assert(NS <= 64 && SC::NSPH <= 16 && SC::NSPH <= 32, "fixed scene too large for the ballot masks");
+  const int nb = m->nb;
+  const float dt = C.sp.dt, kc = C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
+  const float offset = C.sp.contact_offset;
+  const float beta = fmaf(kc, dt, C.sp.contact_d);
+  const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
+  const int lane0 = (int)(threadIdx.x & 63u) - l;
+  const unsigned long long gmask = G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
+  const ShfBoxDesc& bd = S->box[kd];
+  const float* pk = L.pose + (nb + kd) * POSE_STRIDE;
+  PHASE_BEGIN();
+  BM.corners = 0ull;
+#pragma unroll
+  for (int j = 0; j < (NS + G - 1) / G; j++) {
+    const int idx = l + j * G;
+    const bool valid = idx < NS;
+    const int c = valid ? idx / T : 0, tg = valid ? idx % T : 0;
+    float* o = L.pt + corner_slot(m, nbx, kd, c, tg) * PT_STRIDE;
+    bool on = false;
+    if (valid) {
+      o[PT_ON] = 0.0f;
+      float Rk[9], lc[3] = {((c & 4) ? 0.5f : -0.5f) * bd.dim[0], ((c & 2) ? 0.5f : -0.5f) * bd.dim[1],
+                            ((c & 1) ? 0.5f : -0.5f) * bd.dim[2]};
+#pragma unroll
+      for (int i = 0; i < 9; i++) Rk[i] = pk[i];
+      float r[3], t[3], vs[3], vp[3], n[3], h, phi, vb[3] = {pk[12], pk[13], pk[14]};
+      mv3(Rk, lc, r);
+#pragma unroll
+      for (int i = 0; i < 3; i++) r[i] += pk[9 + i];
+      cross3(vb, r, t);
+#pragma unroll
+      for (int i = 0; i < 3; i++) { vs[i] = pk[15 + i] + t[i]; vp[i] = fmaf(dt, gb[i], vs[i]); }
+      if (tg == 0) {
+        terrain_query(C.terr, L.root[0] + r[0], L.root[1] + r[1], &h, n);
+        phi = (L.root[2] + r[2] - h) * n[2];
+        slot_eval(o, phi, n, r, vs, vp, 0.5f * (bd.friction + C.terr.t.friction), kc, beta, veps, vdep, dt, offset);
+      } else if (tg - 1 != kd) {
+        const int ks = tg - 1;
+        const ShfBoxDesc& bs = S->box[ks];
+        const float* ps = L.pose + (nb + ks) * POSE_STRIDE;
+        float Rs[9], hh[3] = {0.5f * bs.dim[0], 0.5f * bs.dim[1], 0.5f * bs.dim[2]}, bpos[3] = {ps[9], ps[10], ps[11]};
+#pragma unroll
+        for (int i = 0; i < 9; i++) Rs[i] = ps[i];
+        if (point_in_box(Rs, bpos, hh, r, &phi, n))
+          slot_eval(o, phi, n, r, vs, vp, 0.5f * (bd.friction + bs.friction), kc, beta, veps, vdep, dt, offset);
+      }
+      on = o[PT_ON] != 0.0f;
+    }
+    BM.corners |= ((__ballot(on) >> lane0) & gmask) << (j * G);
+  }
+  PHASE_MARK(17);
+  {
+    const bool valid = l < SC::NSPH;
+    const int si = valid ? l : 0;
+    float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
+    bool on = false;
+    if (valid) {
+      const int b = m->sph_body[si];
+      const float* pb = L.pose + b * POSE_STRIDE;
+      float Rb[9], Rk[9], lp[3] = {m->sph_pos[si][0], m->sph_pos[si][1], m->sph_pos[si][2]}, c[3];
+#pragma unroll
+      for (int i = 0; i < 9; i++) { Rb[i] = pb[i]; Rk[i] = pk[i]; }
+      mv3(Rb, lp, c);
+#pragma unroll
+      for (int i = 0; i < 3; i++) c[i] += pb[9 + i];
+      const float hh[3] = {0.5f * bd.dim[0], 0.5f * bd.dim[1], 0.5f * bd.dim[2]}, bpos[3] = {pk[9], pk[10], pk[11]};
+      float phi, n[3], rc[3], ta[3], tb[3], vrel[3], vrs[3];
+      sphere_vs_box(Rk, bpos, hh, c, m->sph_radius[si], &phi, n, rc);
+      const float va[3] = {pb[12], pb[13], pb[14]}, vbx[3] = {pk[12], pk[13], pk[14]};
+      cross3(va, rc, ta);
+      cross3(vbx, rc, tb);
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const float pa = pb[15 + i] + ta[i], pq = pk[15 + i] + tb[i];
+        vrs[i] = pa - pq;
+        vrel[i] = fmaf(dt, g_art[i], pa) - fmaf(dt, gb[i], pq);
+      }
+      slot_eval(o, phi, n, rc, vrs, vrel, 0.5f * (mu_shape + bd.friction), kc, beta, veps, vdep, dt, offset);
+      on = o[PT_ON] != 0.0f;
+    }
+    BM.spheres = (unsigned)((__ballot(on) >> lane0) & gmask);
+  }
+  GROUP_SYNC();
+  PHASE_MARK(18);
+  // fold, in the order of the run-time path: a body's spheres ascending; the box's corners (c, tg) ascending, then spheres
+  if (l < nb && m->dyn[l] == l) {
+    unsigned bits = BM.spheres & BL.sph_dyn;
+    while (bits) {
+      const int si = __builtin_ctz(bits);
+      bits &= bits - 1u;
+      const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
+      slot_accumulate(B.IA, B.pA, o, 1.0f, dt, pair_scale(bd, o, dt));
+    }
+  }
+  if (l == nb + kd) {
+    unsigned long long cb = BM.corners;
+    unsigned sb = BM.spheres;
+    while (cb) {
+      const int j = __builtin_ctzll(cb);
+      cb &= cb - 1ull;
+      slot_accumulate(B.IA, B.pA, L.pt + corner_slot(m, nbx, kd, j / T, j % T) * PT_STRIDE, 1.0f, dt, 1.0f);
+    }
+    while (sb) {
+      const int si = __builtin_ctz(sb);
+      sb &= sb - 1u;
+      slot_accumulate(B.IA, B.pA, L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, -1.0f, dt, 1.0f);
+    }
+  }
+  PHASE_MARK(19);
+}
+
 // Evaluate every box contact slot (one lane each), then fold them into the owning bodies.
-template <int G>
-DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, float mu_shape, const float* g_art) {
+template <int G, class SC>
+DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, float mu_shape, const float* g_art,
+                        const BoxLane& BL, BoxMasks& BM) {
+  if constexpr (SC::NBX > 0) { boxes_contacts_fixed<G, SC>(C, L, l, B, mu_shape, g_art, BL, BM); return; }
   const ShfModel* m = C.m;
   const SceneDev* S = C.scene;
   const int nb = m->nb, nbx = S->nboxes, T = 1 + nbx;
@@ -327,8 +600,9 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
 
 // Solve the free boxes, report contact forces (boxes and the articulation's sphere contacts),
 // integrate the boxes.  contact_out has nb + nboxes rows.
-template <int G>
-DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, float* contact_out) {
+template <int G, class SC>
+DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, float* contact_out, const BoxLane& BL,
+                      const BoxMasks& BM) {
   const ShfModel* m = C.m;
   const SceneDev* S = C.scene;
   const int nb = m->nb, nbx = S->nboxes, T = 1 + nbx;
@@ -343,7 +617,14 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
       float f[3] = {contact_out[3 * l], contact_out[3 * l + 1], contact_out[3 * l + 2]};
       const float* ab = L.acc + m->dyn[l] * 6;
       const float abr[6] = {ab[0], ab[1], ab[2], ab[3], ab[4], ab[5]};
-      unsigned bits = body_sphere_flags(m, L, nbx, l, false);
+      unsigned bits;
+      if constexpr (SC::NBX > 0) {       // ballots of this sub-step: bit si -> the run-time path's bit si * MAX + DYN
+        bits = 0u;
+        unsigned sb = BM.spheres & BL.sph_body;
+        while (sb) { const int si = __builtin_ctz(sb); sb &= sb - 1u; bits |= 1u << (si * SHF_MAX_BOXES + SC::DYN); }
+      } else {
+        bits = body_sphere_flags(m, L, nbx, l, false);
+      }
       while (bits) {
         const int j = __builtin_ctz(bits), si = j / SHF_MAX_BOXES, k2 = j % SHF_MAX_BOXES;
         bits &= bits - 1u;
@@ -355,12 +636,15 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
     if (isbox) {
       float f[3] = {0.0f, 0.0f, 0.0f};
       if (dynbox) {
-        unsigned long long cb = corner_flags(m, L, nbx, kd);
-        unsigned sb = box_sphere_flags(m, L, nbx, kd);
+        unsigned long long cb;
+        unsigned sb;
+        int tdiv = BOX_T;
+        if constexpr (SC::NBX > 0) { cb = BM.corners; sb = BM.spheres; tdiv = 1 + SC::NBX; }
+        else { cb = corner_flags(m, L, nbx, kd); sb = box_sphere_flags(m, L, nbx, kd); }
         while (cb) {
           const int j = __builtin_ctzll(cb);
           cb &= cb - 1ull;
-          slot_force(L.pt + corner_slot(m, nbx, kd, j / BOX_T, j % BOX_T) * PT_STRIDE, a, 1.0f, dt, 1.0f, f);
+          slot_force(L.pt + corner_slot(m, nbx, kd, j / tdiv, j % tdiv) * PT_STRIDE, a, 1.0f, dt, 1.0f, f);
         }
         while (sb) {
           const int si = __builtin_ctz(sb);

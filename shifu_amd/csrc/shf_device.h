@@ -308,6 +308,7 @@ struct FixedDims {
   }
 };
 typedef FixedDims<17, 12, 76, 3, 4> A1Dims;  // Unitree A1 as compiled from a1.urdf
+typedef FixedDims<7, 6, 3, 6, 6> AbbDims;    // ABB IRB1200 + rod as compiled from abb_rod.urdf: a 6-deep chain (appendix A.2)
 
 // per-lane persistent body registers between phases of one sub-step
 struct BodyRegs {
@@ -321,7 +322,7 @@ struct BodyRegs {
 // HOIST = false keeps the float constants in LDS behind the same member names (register-limited
 // instantiations: one wavefront per env has to fit 128 VGPRs to keep 4096 envs resident).
 #define LANE_CHILDREN 4
-#define LANE_ANCESTORS 4
+#define LANE_ANCESTORS 6
 template <int N> struct RegVec {
   float v[N];
   DEV operator const float*() const { return v; }
@@ -357,8 +358,8 @@ struct LaneModelT {
   DEV int dynpar() const { return (int)((tree >> 19) & 31u); }
   DEV int par() const { return (int)((tree >> 24) & 31u); }
   int nchild, child0, child[LANE_CHILDREN], pt0, npt;
-  unsigned ancs;             // kinematic chain below the root in 6-bit fields, field klev-1 = this body (fixed-depth models only)
-  DEV int anc(int k) const { return (int)((ancs >> (6 * k)) & 63u); }
+  unsigned ancs;             // kinematic chain below the root in 5-bit fields, field klev-1 = this body (fixed-depth models only)
+  DEV int anc(int k) const { return (int)((ancs >> (5 * k)) & 31u); }
   V3 tp, ax, com;
   V9 tr;
   V6 I6;
@@ -392,7 +393,7 @@ DEV void lane_model_load(const ShfModel* m, int l, LM& M) {
     M.ancs = 0u;
 #pragma unroll
     for (int k = LANE_ANCESTORS - 1; k >= 0; k--) {
-      if (k < klev) { M.ancs |= (unsigned)a << (6 * k); a = m->parent[a]; }
+      if (k < klev) { M.ancs |= (unsigned)a << (5 * k); a = m->parent[a]; }
     }
   }
   M.tp.load(m->tpos[b]); M.ax.load(m->axis[b]); M.com.load(m->com[b]);
@@ -804,9 +805,10 @@ DEV void contact_force_final(float* o, const float* ab, float dt) {
 //   fext: world force per reported body (global memory, this env) or nullptr
 //   contact_out: LDS/global float[nb*3] written by body lanes (may be nullptr)
 #define LANE_ROUNDS(G, DM) ((DM::NPC + (G) - 1) / (G) > 0 ? (DM::NPC + (G) - 1) / (G) : 1)
-template <int G, bool BOX = false, class DM = DynDims, bool TW = false, class LM = LaneModel>
+template <int G, bool BOX = false, class DM = DynDims, bool TW = false, class LM = LaneModel, class SC = DynScene>
 DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const LanePoints<LANE_ROUNDS(G, DM)>& P,
-                 const float* pos_tgt, const float* vel_tgt, const float* fext, float mu_shape, float* contact_out) {
+                 const float* pos_tgt, const float* vel_tgt, const float* fext, float mu_shape, float* contact_out,
+                 const BoxLane& BL = BoxLane()) {
   const ShfModel* m = C.m;
   const int nb = DM::nb(m), nd = DM::nd(m), np = DM::np(m);
   const float dt = C.sp.dt;
@@ -932,7 +934,8 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
     }
   }
 
-  if (BOX) boxes_contacts<G>(C, L, l, B, mu_shape, g);
+  BoxMasks BM;
+  if (BOX) boxes_contacts<G, SC>(C, L, l, B, mu_shape, g, BL, BM);
   PHASE_MARK(4);
 
   // joint-space efforts: one lane per dof
@@ -1119,7 +1122,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
 
   if (BOX) {
     GROUP_SYNC();
-    boxes_finish<G>(C, L, l, B, contact_out);
+    boxes_finish<G, SC>(C, L, l, B, contact_out, BL, BM);
   }
 
   PHASE_MARK(9);

@@ -15,7 +15,8 @@ REWARD_NAMES = ["reward_reaching", "reward_success"]   # build_reward_functions 
 
 class FusedAbbEnv:
     def __init__(self, num_envs: int = 4096, device="cuda:0", seed: int = 42, rank: int = 0, world_size: int = 1,
-                 group: int = 16, dt: float = 0.02, decimation: int = 5, episode_length_s: float = 20.0):
+                 group: int = 16, dt: float = 0.02, decimation: int = 5, episode_length_s: float = 20.0,
+                 extra_boxes=()):
         self.device = torch.device(device)
         self.num_envs = num_envs
         self.env_id_offset = rank * num_envs
@@ -25,12 +26,16 @@ class FusedAbbEnv:
         self.sim = Sim(self.sim_params, self.device)
         self.sim.set_plane(1.0)
         self.sim.set_articulation(self.cm.blob)
-        self.boxes = abb_boxes()
+        # extra_boxes: further (fixed) box actors after table / cube / goal -- the scene then no longer matches the
+        # compile-time ABB scene and the step runs on the run-time-shaped kernel instantiation (tests use this)
+        self.boxes = abb_boxes() + list(extra_boxes)
         for b in self.boxes:
             self.sim.add_box(b)
         self.sim.finalize(num_envs, self.env_id_offset, group=group)
         self.task_params = abb_task_params(self.cm, dt=dt, decimation=decimation, episode_length_s=episode_length_s,
                                            seed=seed)
+        for k, b in enumerate(extra_boxes):
+            self.task_params.actor_default[4 + k][:] = list(b.pos) + list(b.quat)
         self.task = AbbTask(self.sim, self.task_params)
         T, S = self.task.tensors, self.sim.tensors
         self.num_obs, self.num_privileged_obs, self.num_actions = 6, None, 3
@@ -48,7 +53,7 @@ class FusedAbbEnv:
         self.extras = {}
         self.reward_names = REWARD_NAMES
         # spawn poses + the tensors Isaac Gym would show after create_actor/prepare_sim
-        A = 4
+        A = 1 + len(self.boxes)
         root = torch.zeros(num_envs * A, 13, device=self.device)
         root[:, 6] = 1.0
         root[0::A, :3] = torch.tensor(ABB_BASE_POS, device=self.device)

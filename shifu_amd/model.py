@@ -273,10 +273,34 @@ def _check_inertia(names, parent, jtype, dyn, tpos, trot, axis, merged, armature
                              f"definite -- the 6x6 root solve would divide by zero; give the links <inertial> data")
 
 
+def _shape_capsules(shape: _Shape) -> List[Tuple[np.ndarray, np.ndarray, float]]:
+    """Self-collision capsules (end points a, b in the link frame, radius) of a collision primitive: a sphere is a
+    capsule of zero length; a capsule is itself; a box L >= W >= H gets capsules of radius H/2 along its longest axis
+    -- one (radius (W + H)/4) when the cross-section is nearly square, else as many side by side as cover W."""
+    if shape.kind == "sphere":
+        return [(shape.pos.copy(), shape.pos.copy(), float(shape.size[0]))]
+    if shape.kind == "capsule":
+        r, L = float(shape.size[0]), float(shape.size[1])
+        z = shape.rot @ np.array([0.0, 0.0, 0.5 * L])
+        return [(shape.pos - z, shape.pos + z, r)]
+    order = np.argsort(-shape.size)                     # longest, middle, shortest axis
+    Ld, Wd, Hd = (float(shape.size[k]) for k in order)
+    ex, ew = np.eye(3)[order[0]], np.eye(3)[order[1]]
+    if Wd - Hd < 0.5 * Hd:
+        r, offs = 0.25 * (Wd + Hd), [0.0]
+    else:
+        r = 0.5 * Hd
+        n = int(np.ceil((Wd - Hd) / Hd)) + 1
+        offs = list(np.linspace(-0.5 * (Wd - Hd), 0.5 * (Wd - Hd), n))
+    half = max(0.5 * Ld - r, 0.0)
+    return [(shape.pos + shape.rot @ (ew * o - ex * half), shape.pos + shape.rot @ (ew * o + ex * half), r) for o in offs]
+
+
 def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: bool = False,
                  collapse_fixed_joints: bool = True, default_dof_drive_mode: int = _abi.DOF_MODE_NONE,
                  armature: float = 0.0, honour_dont_collapse: bool = True,
-                 extra_spheres: Sequence[Tuple[str, Sequence[float], float]] = (), density: float = 1000.0) -> CompiledModel:
+                 extra_spheres: Sequence[Tuple[str, Sequence[float], float]] = (), density: float = 1000.0,
+                 self_collision: bool = False) -> CompiledModel:
     """Compile `path` with the AssetOptions the reference passes (asset_config.py:32-46).
 
     extra_spheres: (link name, xyz in that link's frame, radius) collision spheres
@@ -301,6 +325,7 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
     jref: List[Optional[_Joint]] = []
     inert: List[_Inertial] = []  # own (collapsed-in) inertia, body frame
     points: List[Tuple[int, np.ndarray, float]] = []
+    capsules: List[Tuple[int, np.ndarray, np.ndarray, float]] = []
     link_frame: Dict[str, Tuple[int, np.ndarray, np.ndarray]] = {}  # urdf link -> (body, p, R) in body frame
 
     def absorb(body: int, link: _Link, p: np.ndarray, R: np.ndarray):
@@ -309,6 +334,8 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
         for s in link.shapes:
             for q, rad in _shape_points(s):
                 points.append((body, p + R @ q, rad))
+            for ca, cb, rad in _shape_capsules(s):
+                capsules.append((body, p + R @ ca, p + R @ cb, rad))
 
     def visit(link_name: str, body: int, p: np.ndarray, R: np.ndarray):
         """link_name's frame sits at (p, R) inside reported body `body`."""
@@ -452,6 +479,36 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
         m.sph_radius[i] = rad
         for kk in range(3):
             m.sph_pos[i][kk] = q[kk]
+
+    # self-collision: capsules of every shape, and the pairs to test -- all but capsules of one rigid body (same moving
+    # body: welded links included) and of moving bodies joined by a joint ([EXT] PhysX filters those the same way)
+    m.self_collide = int(bool(self_collision))
+    if len(capsules) > _abi.MAX_CAPSULES:
+        if self_collision:
+            raise AssertionError(f"{len(capsules)} self-collision capsules > SHF_MAX_CAPSULES")
+        capsules = []
+    m.ncap = len(capsules)
+    for i, (b, ca, cb, rad) in enumerate(capsules):
+        m.cap_body[i] = b
+        m.cap_radius[i] = rad
+        for kk in range(3):
+            m.cap_a[i][kk], m.cap_b[i][kk] = ca[kk], cb[kk]
+    pairs = []
+    for i in range(m.ncap):
+        for j in range(i + 1, m.ncap):
+            da, db = dyn[capsules[i][0]], dyn[capsules[j][0]]
+            if da == db:
+                continue
+            if (db > 0 and dyn[parent[db]] == da) or (da > 0 and dyn[parent[da]] == db):
+                continue
+            pairs.append((i, j))
+    if len(pairs) > _abi.MAX_PAIRS:
+        if self_collision:
+            raise AssertionError(f"{len(pairs)} self-collision pairs > SHF_MAX_PAIRS")
+        pairs = []
+    m.npair = len(pairs)
+    for k, (i, j) in enumerate(pairs):
+        m.pair_a[k], m.pair_b[k] = i, j
 
     return CompiledModel(m, names, dof_names, float(sum(t.mass for t in merged)))
 

@@ -34,22 +34,30 @@ def main():
     rec = TrajectoryRecorder(env, num_envs=8, bodies=True) if args.traj else None
     env.reset()
     obs = env.get_observations()
-    lin_err = ang_err = 0.0
+    lin_err = ang_err = along = speed = cmdn = 0.0
     falls = 0
     with torch.no_grad():
         for _ in range(args.steps):
             obs, _, rew, done, extras = env.step(policy(obs.clone()))
             bv = env.task.tensors[_abi.A1_BASE_VEL]               # base-frame lin (0:3) / ang (3:6) velocity
             cmd = env.command_buf
-            lin_err += float((bv[:, :2] - cmd[:, :2]).norm(dim=1).mean())
+            c = cmd[:, :2]
+            cn = c.norm(dim=1).clamp(min=1e-6)
+            along += float(((bv[:, :2] * c).sum(1) / cn).mean())  # base speed along the commanded direction
+            speed += float(bv[:, :2].norm(dim=1).mean())
+            cmdn += float(cn.mean())
+            lin_err += float((bv[:, :2] - c).norm(dim=1).mean())
             ang_err += float((bv[:, 5] - cmd[:, 2]).abs().mean())
             falls += int((done & ~env.time_out_buf).sum())
             if rec:
                 rec.record()
+    n = args.steps
     out = {"checkpoint": args.checkpoint, "envs": args.envs, "steps": args.steps, "terrain": args.terrain,
-           "mean_lin_vel_error_m_s": lin_err / args.steps, "mean_yaw_rate_error_rad_s": ang_err / args.steps,
-           "falls_per_env_per_1000_steps": falls / args.envs / args.steps * 1000.0,
-           "mean_reward_per_step": float(rew.mean())}
+           "mean_cmd_speed_m_s": cmdn / n, "mean_base_speed_m_s": speed / n, "mean_speed_along_cmd_m_s": along / n,
+           "speed_along_cmd_over_cmd": along / max(cmdn, 1e-9),
+           "mean_lin_vel_error_m_s": lin_err / n, "mean_yaw_rate_error_rad_s": ang_err / n,
+           "falls_per_env_per_1000_steps": falls / args.envs / n * 1000.0,
+           "mean_reward_per_step": float(rew.mean()), "terrain_levels_mean": float(env.terrain_levels.float().mean())}
     if rec:
         out["trajectory"] = rec.save(args.traj)
     print(json.dumps(out))
