@@ -317,3 +317,13 @@ def glue_abb_post(task_params, cube, goal, ee, ep_len):
                                        _p(ee, C.c_float), _p(ep, C.c_int64), _p(obs, C.c_float), _p(to, C.c_uint8),
                                        _p(su, C.c_uint8), _p(rs, C.c_uint8), _p(r0, C.c_float), _p(r1, C.c_float))
     return obs, to.astype(bool), su.astype(bool), rs.astype(bool), r0, r1
+
+
+def segment_closest(segs, f64=True):
+    """Closest points of segment pairs: segs (n,4,3) = p1, q1, p2, q2 -> (n,2,3) c1, c2 (the self-collision geometry)."""
+    dt, ct = (np.float64, C.c_double) if f64 else (np.float32, C.c_float)
+    s = np.ascontiguousarray(segs, dt)
+    out = np.zeros((s.shape[0], 2, 3), dt)
+    fn = lib().shf_oracle_segment_closest_f64 if f64 else lib().shf_oracle_segment_closest_f32
+    fn(C.c_int(s.shape[0]), _p(s, ct), _p(out, ct))
+    return out

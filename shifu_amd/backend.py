@@ -267,7 +267,13 @@ class A1Task:
     def kernel_symbol(self) -> str:
         """Mangled-name prefix of the instantiation shf_a1_step launches for this sim (build resource table)."""
         g, warped = self.sim.group, bool(self.sim.terrain.warped)
-        if self.sim.model.nb == 17 and self.sim.model.nd == 12 and self.sim.model.np == 76:
+        mdl = self.sim.model
+        a1 = mdl.nb == 17 and mdl.nd == 12 and mdl.np == 76
+        if mdl.self_collide and mdl.npair > 0:
+            if a1:
+                return "_Z21k_a1_step_self_a1_g32" if not warped else "_Z14k_a1_step_selfILi32E9FixedDims"
+            return f"_Z14k_a1_step_selfILi{g}E7DynDims"
+        if a1:
             return "_Z16k_a1_step_a1_g32" if (g == 32 and not warped) else f"_Z9k_a1_stepILi{g}E9FixedDims"
         return f"_Z9k_a1_stepILi{g}E7DynDims"
 

@@ -109,7 +109,7 @@ DEV const ShfScene* stage_scene(const ShfScene* gs, float* dst_words) {
 }
 
 // gym.simulate: one sub-step for every env
-template <int G, bool BOX>
+template <int G, bool BOX, bool SELF>
 __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const ShfScene* scene = BOX ? stage_scene(A.scene, smem + MODEL_WORDS) : nullptr;
@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
   const int e = blockIdx.x * epb + es;
   if (e >= A.n) return;
   const int nbx = BOX ? A.nboxes : 0, actors = 1 + nbx;
-  const int nb = m->nb, nd = m->nd, nbt = nb + nbx, nslots = m->np + box_slot_count(nbx, m->nsph);
+  const int nb = m->nb, nd = m->nd, nbt = nb + nbx;
+  const int nslots = m->np + box_slot_count(nbx, m->nsph) + (SELF ? SHF_MAX_SELF_CONTACTS : 0);
   EnvLds L = env_lds_carve(smem + MODEL_WORDS + (BOX ? SCENE_WORDS : 0) + es * env_lds_words(nbt, nd, nslots, 0, actors),
                            nbt, nd, nslots, actors);
   float* dof = A.dof + (size_t)e * nd * 2;
@@ -133,8 +134,8 @@ __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
   LaneModel M;
   lane_model_load<DynDims>(m, l, M);
   LanePoints<1> P;   // unused: point count only known at run time
-  substep<G, BOX, DynDims, !BOX>(C, L, l, M, P, A.pos_tgt ? A.pos_tgt + (size_t)e * nd : nullptr, A.vel_tgt ? A.vel_tgt + (size_t)e * nd : nullptr,
-                  A.body_force ? A.body_force + (size_t)e * nbt * 3 : nullptr, mu, L.xch);
+  substep<G, BOX, DynDims, !BOX, LaneModel, DynScene, SELF>(C, L, l, M, P, A.pos_tgt ? A.pos_tgt + (size_t)e * nd : nullptr,
+                  A.vel_tgt ? A.vel_tgt + (size_t)e * nd : nullptr, A.body_force ? A.body_force + (size_t)e * nbt * 3 : nullptr, mu, L.xch);
   GROUP_SYNC();
   for (int i = l; i < 2 * nd; i += G) dof[i] = L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)];
   for (int i = l; i < 13 * actors; i += G) root[i] = L.root[i];
@@ -434,7 +435,7 @@ __global__ void k_a1_reset_all(A1Args A) {
 // the kernel is held to 128 VGPRs (measured 0.147 ms vs 0.165 ms at 165 VGPRs / 3 waves,
 // profiles/r01_*); at G = 32 the grid is 2 waves per SIMD and the unconstrained
 // allocation is faster (0.104 ms vs 0.112 ms).
-template <int G, class DM, bool TW>
+template <int G, class DM, bool TW, bool SELF = false>
 DEV void a1_step_body(const A1Args& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   PHASE_BEGIN();
@@ -450,8 +451,9 @@ DEV void a1_step_body(const A1Args& A) {
   const int nb = DM::nb(m), nd = DM::nd(m), np = DM::np(m), H = tp.num_history, P = tp.num_height_points;
   const int nobs = 12 + 2 * nd + nd * H + P;
   // post-physics scratch reuses the contact-point region (last in the carve)
-  const int env_words = env_lds_words(nb, nd, np, SCR_OBS + nobs);
-  EnvLds L = env_lds_carve(smem + MODEL_WORDS + TASK_WORDS + STATS_LDS_WORDS + es * env_words, nb, nd, np);
+  const int nslots = np + (SELF ? SHF_MAX_SELF_CONTACTS : 0);
+  const int env_words = env_lds_words(nb, nd, nslots, SCR_OBS + nobs);
+  EnvLds L = env_lds_carve(smem + MODEL_WORDS + TASK_WORDS + STATS_LDS_WORDS + es * env_words, nb, nd, nslots);
   float* scr = L.pt;
 
   float* dof = A.S.dof + (size_t)e * nd * 2;
@@ -481,7 +483,8 @@ DEV void a1_step_body(const A1Args& A) {
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = nullptr;
   const float mu = A.S.friction[e];
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
-  LaneModelT<(G < 64)> M;
+  // (with self-collision the per-lane model constants stay in LDS: the pair tests need the registers)
+  LaneModelT<(G < 64) && !SELF> M;
   lane_model_load<DM>(m, l, M);
   LanePoints<LANE_ROUNDS(G, DM)> LP;
   lane_points_load<G>(m, np, l, LP);
@@ -493,8 +496,8 @@ DEV void a1_step_body(const A1Args& A) {
       D[5] = rclampf(t, -m->effort[l], m->effort[l]);
     }
     GROUP_SYNC();
-    substep<G, false, DM, TW>(C, L, l, M, LP, nullptr, nullptr, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
-               (it == nsub - 1) ? L.xch : nullptr);
+    substep<G, false, DM, TW, LaneModelT<(G < 64) && !SELF>, DynScene, SELF>(C, L, l, M, LP, nullptr, nullptr,
+               (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu, (it == nsub - 1) ? L.xch : nullptr);
   }
   GROUP_SYNC();
   PHASE_RESET();
@@ -705,6 +708,14 @@ __global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step(A1Args A) { 
 // scheduler to its occupancy-preserving mode (measured +13 %), so the register cap is given directly.
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256))) void k_a1_step_a1_g32(A1Args A) {
   a1_step_body<32, A1Dims, false>(A);
+}
+// The same with self-collision (ShfModel.self_collide: capsule pairs of the articulation), its own instantiations so
+// that the default one keeps its register budget.
+template <int G, class DM>
+__global__ __launch_bounds__(256, (G == 64 ? 4 : 1)) void k_a1_step_self(A1Args A) { a1_step_body<G, DM, (G < 64), true>(A); }
+// A1 with self-collision at two envs per wavefront, held to 256 VGPRs for the same reason as k_a1_step_a1_g32
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256))) void k_a1_step_self_a1_g32(A1Args A) {
+  a1_step_body<32, A1Dims, false, true>(A);
 }
 
 // ------------------------------------------------------ fused ABB step --
@@ -944,10 +955,11 @@ __global__ void k_abb_reset_all(AbbArgs A) {
 }
 
 // ---------------------------------------------------------------- C ABI --
+static bool sim_self(const ShfSim* s) { return s->model.self_collide != 0 && s->model.npair > 0; }
 static size_t sim_lds_bytes(const ShfSim* s, int head_words, int min_tail, bool boxes = false) {
   const int epb = 256 / s->group;
   const int nbx = boxes ? s->nboxes : 0;
-  const int nslots = s->model.np + (boxes ? box_slot_count(nbx, s->model.nsph) : 0);
+  const int nslots = s->model.np + (boxes ? box_slot_count(nbx, s->model.nsph) : 0) + (sim_self(s) ? SHF_MAX_SELF_CONTACTS : 0);
   return ((size_t)MODEL_WORDS + head_words + (boxes ? SCENE_WORDS : 0) +
           (size_t)epb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, min_tail, 1 + (boxes ? nbx : s->nboxes))) * 4;
 }
@@ -1113,17 +1125,31 @@ extern "C" int shf_sim_step(ShfSim* sim, void* stream) {
     if (!sim->t[SHF_T_SCENE]) return fail("shf_sim_step: scene (box actors) not bound");
     if (sim->model.nb + sim->nboxes > sim->group) return fail("shf_sim_step: bodies + boxes exceed the lane group");
     const size_t lds = sim_lds_bytes(sim, 0, 0, true);
+    if (sim_self(sim)) {
+      switch (sim->group) {
+        case 64: return launch(k_sim_step<64, true, true>, grid, block, lds, stream, A);
+        case 32: return launch(k_sim_step<32, true, true>, grid, block, lds, stream, A);
+        default: return launch(k_sim_step<16, true, true>, grid, block, lds, stream, A);
+      }
+    }
     switch (sim->group) {
-      case 64: return launch(k_sim_step<64, true>, grid, block, lds, stream, A);
-      case 32: return launch(k_sim_step<32, true>, grid, block, lds, stream, A);
-      default: return launch(k_sim_step<16, true>, grid, block, lds, stream, A);
+      case 64: return launch(k_sim_step<64, true, false>, grid, block, lds, stream, A);
+      case 32: return launch(k_sim_step<32, true, false>, grid, block, lds, stream, A);
+      default: return launch(k_sim_step<16, true, false>, grid, block, lds, stream, A);
     }
   }
   const size_t lds = sim_lds_bytes(sim, 0, 0);
+  if (sim_self(sim)) {
+    switch (sim->group) {
+      case 64: return launch(k_sim_step<64, false, true>, grid, block, lds, stream, A);
+      case 32: return launch(k_sim_step<32, false, true>, grid, block, lds, stream, A);
+      default: return launch(k_sim_step<16, false, true>, grid, block, lds, stream, A);
+    }
+  }
   switch (sim->group) {
-    case 64: return launch(k_sim_step<64, false>, grid, block, lds, stream, A);
-    case 32: return launch(k_sim_step<32, false>, grid, block, lds, stream, A);
-    default: return launch(k_sim_step<16, false>, grid, block, lds, stream, A);
+    case 64: return launch(k_sim_step<64, false, false>, grid, block, lds, stream, A);
+    case 32: return launch(k_sim_step<32, false, false>, grid, block, lds, stream, A);
+    default: return launch(k_sim_step<16, false, false>, grid, block, lds, stream, A);
   }
 }
 
@@ -1317,6 +1343,17 @@ extern "C" int shf_a1_step(ShfA1Task* task, const float* raw_actions_dev, void* 
   int r;
   if (s->terr.warped && s->group == 64)
     return fail("shf_a1_step: a trimesh terrain needs 16 or 32 lanes per env (the 128-VGPR instantiation has no room for it)");
+  if (sim_self(s)) {
+    // self-collision: its own instantiations (the capped-VGPR default entry point stays as it is)
+    if (s->group == 64) return fail("shf_a1_step: self-collision needs 16 or 32 lanes per env (no register room in the 128-VGPR instantiation)");
+    if (A1Dims::matches(s->model)) {
+      if (s->group != 32) return fail("shf_a1_step: A1 has 17 bodies, the lane group must be 32 or 64");
+      return s->terr.warped ? launch(k_a1_step_self<32, A1Dims>, grid, block, lds, stream, A)
+                            : launch(k_a1_step_self_a1_g32, grid, block, lds, stream, A);
+    }
+    return s->group == 32 ? launch(k_a1_step_self<32, DynDims>, grid, block, lds, stream, A)
+                          : launch(k_a1_step_self<16, DynDims>, grid, block, lds, stream, A);
+  }
   if (A1Dims::matches(s->model)) {
     switch (s->group) {
       case 64: r = launch(k_a1_step<64, A1Dims>, grid, block, lds, stream, A); break;

@@ -63,8 +63,8 @@ DEV void slot_eval(float* o, float phi, const float* n, const float* r, const fl
   o[PT_ON] = on;
 }
 
-DEV void slot_accumulate(float* IA, float* pA, const float* o, float sign, float dt, float scale) {
-  const float ss = sign * scale, oct = o[PT_CT] * scale, obn = o[PT_BN] * scale;
+DEV void slot_accumulate_fb(float* IA, float* pA, const float* o, float sign, float dt, float fscale, float bscale) {
+  const float ss = sign * fscale, oct = o[PT_CT] * bscale, obn = o[PT_BN] * bscale;
   const float f0[3] = {ss * o[PT_F], ss * o[PT_F + 1], ss * o[PT_F + 2]};
   const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]}, n[3] = {o[PT_N], o[PT_N + 1], o[PT_N + 2]};
   float t[3], wn[6];
@@ -92,8 +92,12 @@ DEV void slot_accumulate(float* IA, float* pA, const float* o, float sign, float
   }
 }
 
-DEV void slot_force(const float* o, const float* ab, float sign, float dt, float scale, float* f) {
-  const float ss = sign * scale, oct = o[PT_CT] * scale, obn = o[PT_BN] * scale;
+DEV void slot_accumulate(float* IA, float* pA, const float* o, float sign, float dt, float scale) {
+  slot_accumulate_fb(IA, pA, o, sign, dt, scale, scale);
+}
+
+DEV void slot_force_fb(const float* o, const float* ab, float sign, float dt, float fscale, float bscale, float* f) {
+  const float ss = sign * fscale, oct = o[PT_CT] * bscale, obn = o[PT_BN] * bscale;
   const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]}, n[3] = {o[PT_N], o[PT_N + 1], o[PT_N + 2]}, al[3] = {ab[0], ab[1], ab[2]};
   float t[3], ap[3];
   cross3(al, r, t);
@@ -105,6 +109,10 @@ DEV void slot_force(const float* o, const float* ab, float sign, float dt, float
     const float Ba = fmaf(obn - oct, an * n[k], oct * ap[k]);
     f[k] += fmaf(-dt, Ba, ss * o[PT_F + k]);
   }
+}
+
+DEV void slot_force(const float* o, const float* ab, float sign, float dt, float scale, float* f) {
+  slot_force_fb(o, ab, sign, dt, scale, scale, f);
 }
 
 DEV float pair_scale(const ShfBoxDesc& b, const float* o, float dt) { return b.mass / fmaf(dt, o[PT_BN], b.mass); }
@@ -264,8 +272,10 @@ DEV int self_contacts(const StepCtx& C, const EnvLds& L, int l, bool isdyn, int 
       const float* o = L.pt + (slot0 + k) * PT_STRIDE;
       const int p = (int)o[PT_ON] - 1;
       const int da = m->dyn[m->cap_body[m->pair_a[p]]], db = m->dyn[m->cap_body[m->pair_b[p]]];
-      if (da == l) slot_accumulate(B.IA, B.pA, o, 1.0f, dt, 1.0f);
-      if (db == l) slot_accumulate(B.IA, B.pA, o, -1.0f, dt, 1.0f);
+      // each side implicit in its own acceleration, scaled by 1 + (own mass) / (other mass): see the oracle's self_scales
+      const float ma = m->mass[da], mb = m->mass[db];
+      if (da == l) slot_accumulate_fb(B.IA, B.pA, o, 1.0f, dt, 1.0f, 1.0f + ma / mb);
+      if (db == l) slot_accumulate_fb(B.IA, B.pA, o, -1.0f, dt, 1.0f, 1.0f + mb / ma);
     }
   }
   return count;
@@ -281,8 +291,10 @@ DEV void self_contact_forces(const StepCtx& C, const EnvLds& L, int l, int slot0
   for (int k = 0; k < count; k++) {
     const float* o = L.pt + (slot0 + k) * PT_STRIDE;
     const int p = (int)o[PT_ON] - 1;
-    if (m->cap_body[m->pair_a[p]] == l) slot_force(o, abr, 1.0f, C.sp.dt, 1.0f, f);
-    if (m->cap_body[m->pair_b[p]] == l) slot_force(o, abr, -1.0f, C.sp.dt, 1.0f, f);
+    const int ba = m->cap_body[m->pair_a[p]], bb = m->cap_body[m->pair_b[p]];
+    const float ma = m->mass[m->dyn[ba]], mb = m->mass[m->dyn[bb]];
+    if (ba == l) slot_force_fb(o, abr, 1.0f, C.sp.dt, 1.0f, 1.0f + ma / mb, f);
+    if (bb == l) slot_force_fb(o, abr, -1.0f, C.sp.dt, 1.0f, 1.0f + mb / ma, f);
   }
   contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];
 }

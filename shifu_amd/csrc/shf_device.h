@@ -805,7 +805,8 @@ DEV void contact_force_final(float* o, const float* ab, float dt) {
 //   fext: world force per reported body (global memory, this env) or nullptr
 //   contact_out: LDS/global float[nb*3] written by body lanes (may be nullptr)
 #define LANE_ROUNDS(G, DM) ((DM::NPC + (G) - 1) / (G) > 0 ? (DM::NPC + (G) - 1) / (G) : 1)
-template <int G, bool BOX = false, class DM = DynDims, bool TW = false, class LM = LaneModel, class SC = DynScene>
+template <int G, bool BOX = false, class DM = DynDims, bool TW = false, class LM = LaneModel, class SC = DynScene,
+          bool SELF = false>
 DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const LanePoints<LANE_ROUNDS(G, DM)>& P,
                  const float* pos_tgt, const float* vel_tgt, const float* fext, float mu_shape, float* contact_out,
                  const BoxLane& BL = BoxLane()) {
@@ -934,6 +935,10 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
     }
   }
 
+  // self-collision slots sit behind the articulation's sample points and the box slots
+  int nself = 0;
+  const int self_slot0 = np + (BOX ? box_slot_count(C.scene->nboxes, m->nsph) : 0);
+  if constexpr (SELF) nself = self_contacts<G>(C, L, l, isdyn, self_slot0, B, mu_shape);
   BoxMasks BM;
   if (BOX) boxes_contacts<G, SC>(C, L, l, B, mu_shape, g, BL, BM);
   PHASE_MARK(4);
@@ -1120,6 +1125,12 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
     }
   }
 
+  if constexpr (SELF) {
+    if (contact_out) {
+      GROUP_SYNC();
+      self_contact_forces(C, L, l, self_slot0, nself, contact_out);
+    }
+  }
   if (BOX) {
     GROUP_SYNC();
     boxes_finish<G, SC>(C, L, l, B, contact_out, BL, BM);

@@ -65,13 +65,17 @@ class FusedA1Env:
                  group: int = 32, episode_length_s: float = 10.0, dt: float = 0.005, decimation: int = 4,
                  terrain_seed: int = 42, send_timeouts: bool = True, extra_substep: bool = True,
                  model_edit=None, task_overrides: Optional[dict] = None, dof_stiffness: float = 20.0,
-                 dof_damping: float = 0.5):
+                 dof_damping: float = 0.5, self_collision: bool = False):
         self.device = torch.device(device)
         self.num_envs = num_envs
         self.rank, self.world_size = rank, world_size
         self.env_id_offset = rank * num_envs
         total = num_envs * world_size
-        self.cm = compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT)
+        # self_collision: capsule pairs of the robot's own links (the reference creates actors with collision filter 0,
+        # units.py:68 -- on in Isaac Gym; off by default here: BASELINE's config names height-field contact only, and
+        # the pair tests cost kernel time)
+        self.cm = compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT,
+                               self_collision=self_collision)
         # A1ActorConfig.dof_damping (task_config.py:22-23) reaches the simulator twice in the reference: as the explicit
         # PD's d gain (a1_conditional.py:66) and, through dof_props['damping'] (robot.py:35-37), as the joint's passive
         # damping, which stays active in EFFORT mode ([EXT], see isaacgym/gymapi.py prepare_sim)

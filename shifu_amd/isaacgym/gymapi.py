@@ -18,6 +18,7 @@ Semantics kept from Isaac Gym:
 from __future__ import annotations
 
 import copy
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -311,6 +312,9 @@ class Gym:
         idx = env.sim.num_actors
         env.sim.num_actors += 1
         a = _Actor(asset, copy.deepcopy(pose), name, idx)
+        # [EXT] collision filter: two shapes of one actor collide unless (filter_a & filter_b) != 0; shifu passes 0
+        # (units.py:68), i.e. self-collision on
+        a.self_collide = (int(filter) == 0)
         env.actors.append(a)
         return len(env.actors) - 1
 
@@ -375,6 +379,8 @@ class Gym:
         robot = robots[0]
         sim.robot_asset = robot.asset
         m = copy.deepcopy(robot.asset.model.blob)
+        m.self_collide = int(bool(getattr(robot, "self_collide", False)) and m.npair > 0 and
+                             os.environ.get("SHIFU_AMD_SELF_COLLISION", "1") != "0")
         if robot.dof_props is not None:
             for d in range(m.nd):
                 m.drive_mode[d] = int(robot.dof_props["driveMode"][d])

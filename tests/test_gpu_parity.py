@@ -556,3 +556,63 @@ def test_contact_kats_joint_limit_on_the_gpu(oracle):
     tr, q = _kat_run(oracle, cm, H.sim_params(), np.zeros((1, 2), np.float32), K.root_row((0, 0, 1.0)), 600,
                      effort=np.full(1, 30.0, np.float32))
     assert abs(q[-1][0] - (0.5 + 30.0 / 2000.0)) < 2e-4 and max(x[0] for x in q) < 0.58
+
+
+# -------------------------------------------------------------------- self-collision --
+@pytest.mark.parametrize("group,dyn", [(32, False), (32, True), (16, True)])
+def test_self_collision_matches_oracle_bitwise(oracle, group, dyn):
+    """capsule-pair self-collision (collision filter 0, reference units.py:68) on the HIP path equals the
+    oracle bit for bit -- gym.simulate from states with the legs folded through each other, then the fused A1 step with
+    large actions; A1 instantiation and the run-time-dimension one (a 13-body variant for 16 lanes)."""
+    _need_gpu()
+    from shifu_amd.model import asset_path, compile_urdf
+    kw = dict(default_dof_drive_mode=_abi.DOF_MODE_EFFORT, self_collision=True)
+    if dyn:
+        cm = compile_urdf(asset_path("a1.urdf"), honour_dont_collapse=False, **kw)      # feet merged into the shanks: 13 bodies,
+        assert cm.blob.nb == 13                                                         # not the compile-time A1 shape
+    else:
+        cm = compile_urdf(asset_path("a1.urdf"), **kw)
+    m = cm.blob
+    assert m.self_collide == 1 and m.npair > 40
+    for d in range(m.nd):
+        m.damping[d] = 0.5
+    rng = np.random.default_rng(21)
+    sp = H.sim_params(angular_damping=0.5)
+    n = 48
+    terr, hs = _terrain(rng, rough=False)
+    dof, root = _random_states(m, n, rng, z_lo=0.5, z_hi=0.9)
+    lo, up = np.array(m.lower[:m.nd]), np.array(m.upper[:m.nd])
+    q = rng.uniform(lo, up, (n, m.nd)).astype(np.float32)          # anywhere inside the joint limits: legs cross
+    dof[:, 0] = q.reshape(-1)
+    dof[:, 1] = rng.uniform(-6, 6, n * m.nd)
+    fr = rng.uniform(0.5, 1.25, n).astype(np.float32)
+    sim = _make_sim(cm, sp, n, None, None, group=group)
+    T = sim.tensors
+    T[_abi.T_SIM_DOF].copy_(torch.from_numpy(dof))
+    T[_abi.T_SIM_ROOT].copy_(torch.from_numpy(root))
+    T[_abi.T_FRICTION].copy_(torch.from_numpy(fr))
+    selfhits = 0
+    for it in range(40):
+        eff = rng.uniform(-25, 25, n * m.nd).astype(np.float32)
+        sim.set_dof_command(_abi.T_EFFORT, torch.from_numpy(eff).cuda())
+        sim.step()
+        sim.refresh(_abi.REFRESH_ALL)
+        contact, bstate = oracle.step(m, sp, n, dof, root, effort=eff, friction=fr, want_contact=True, want_body_state=True)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(T[_abi.T_DOF_STATE].cpu().numpy(), dof, err_msg=f"dof step {it}")
+        np.testing.assert_array_equal(T[_abi.T_ROOT_STATE].cpu().numpy(), root, err_msg=f"root step {it}")
+        np.testing.assert_array_equal(T[_abi.T_CONTACT].cpu().numpy(), contact, err_msg=f"contact step {it}")
+        selfhits += int((np.abs(contact).sum(1) > 0).sum())       # the bodies are in the air: every force is a self-contact
+    assert selfhits > 200, selfhits
+    sim.destroy()
+    if group == 16:
+        return
+    # the fused step with self-collision on
+    cm2, sp2, tp, terr, hs, bufs, sim, task, rng = _a1_setup(64, True, group=group, cm=cm)
+    hits = 0
+    for it in range(60):
+        raw = (2 * rng.random((64, m.nd)) - 1).astype(np.float32) * 2.0
+        task.step(torch.from_numpy(raw).cuda())
+        oracle.a1_step(m, sp2, tp, 64, 0, bufs, raw, terrain=terr, heights=hs)
+        _compare(sim, task, bufs, f"fused self-collision step {it}")
+    assert "self" in task.kernel_symbol() and ("DynDims" in task.kernel_symbol()) == dyn
