@@ -215,6 +215,9 @@ def main():
                          "abb = config 5")
     ap.add_argument("--group", type=int, default=None, help="lanes per env: 64 = one wavefront per env; default 32 (A1) / 16 (ABB), the fastest measured (DESIGN.md 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--self-collision", action="store_true",
+                    help="A1 workloads: collide the robot's own links (capsule pairs; the reference's collision filter 0, "
+                         "units.py:68) -- off in the headline configuration, whose BASELINE entry names height-field contact")
     ap.add_argument("--graph", action="store_true", help="replay the vec-step from a captured hipGraph instead of launching it "
                     "eagerly (measured slower on ROCm 7.2: 84.7 vs 73.9 us per vec-step, profiles/r02_bench_*.json)")
     ap.add_argument("--decimation", type=int, default=4, help="(experiments only) control.decimation")
@@ -268,7 +271,7 @@ def main():
         from shifu_amd.gym.a1_fused import FusedA1Env
         env = FusedA1Env(num_envs=args.envs, device=dev, terrain={"terrain": "heightfield", "flat": "flat", "trimesh": "trimesh"}[args.workload],
                          seed=42, rank=rank, world_size=world, group=group, decimation=args.decimation,
-                         extra_substep=not args.no_extra_substep)
+                         extra_substep=not args.no_extra_substep, self_collision=args.self_collision)
         stats_t, count_t, kernel = _abi.A1_STATS, _abi.A1_RESET_COUNT, "k_a1_step"
         substeps = args.decimation + (0 if args.no_extra_substep else 1)
     gen = torch.Generator(device=dev)
@@ -370,7 +373,7 @@ def main():
             "config": {"workload": f"{WL_NAME[args.workload]}, {N} envs/GPU, random actions, {substeps} substeps/env-step "
                                    f"(dt {'20' if abb else '5'} ms), resets on",
                        "envs_per_gpu": N, "total_envs": total_envs, "substeps_per_env_step": substeps,
-                       "lanes_per_env": group, "vec_step": "hipGraph replay of [uniform_, fused step]" if graph is not None else "eager launches",
+                       "lanes_per_env": group, "self_collision": bool(args.self_collision) and not abb, "vec_step": "hipGraph replay of [uniform_, fused step]" if graph is not None else "eager launches",
                        "parallelism": f"env-sharded x{world}, all-gather of episode stats every {args.log_interval} steps",
                        "substeps_per_s": value * substeps, "obs_finite": finite, "episodes_reset_rank0": resets},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

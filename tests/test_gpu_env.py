@@ -27,7 +27,9 @@ def _envs(n=64):
     torch.manual_seed(0)
     hook = A1Conditional(cfg)
     # A1EnvConfig builds the trimesh terrain (Q5): the fused env is given the same one
-    fused = FusedA1Env(num_envs=n, terrain="trimesh", terrain_seed=42, seed=3)
+    # ... and, like every actor the reference creates (collision filter 0, units.py:68), the hook env's robot collides
+    # with itself: the fused env is asked for the same
+    fused = FusedA1Env(num_envs=n, terrain="trimesh", terrain_seed=42, seed=3, self_collision=True)
     return hook, fused
 
 

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + PMC passes of bench.py.
 # Usage: tools/profile.sh <tag> [bench args...]    -> gpurun_out/prof_<tag>/
+# then (here): tools/summarize_prof.py gpurun_out/prof_<tag> profiles/<name> <traffic-key> <kernel-substring>
 set -u
 TAG=${1:-r01}; shift || true
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
