@@ -396,6 +396,24 @@ int shf_abb_step(ShfAbbTask* task, const float* raw_actions_dev, void* stream);
 /* reset_idx(arange(N)) (env.py:108-112). */
 int shf_abb_reset_all(ShfAbbTask* task, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Trainer kernels.  The reference takes its PPO trainer from the un-vendored rsl_rl package
+ * (shifu/runner/policy_runner.py:4,52-73): ActorCritic MLPs of nn.Linear + ELU (shifu/configs/policy_config.py:8-16).
+ * These three entry points are one layer's forward and backward as MFMA GEMMs (bf16 operands converted on the fly from
+ * the fp32 tensors, fp32 accumulation) with bias / ELU / ELU' fused; row-major fp32 tensors, no torch types.
+ *   forward          y[M,N]  = act(x[M,K] w[N,K]^T + b[N])                        act: 0 = identity, 1 = ELU
+ *   backward_input   dx[M,K] = (dy (.) act'(y))[M,N] w[N,K]                       y = the forward's output, or NULL (identity)
+ *   backward_weight  dw[N,K] = (dy (.) act'(y))^T x,  db[N] = column sums          workspace: see *_workspace (floats)
+ * ---------------------------------------------------------------------- */
+const char* shf_mlp_last_error(void);
+int shf_mlp_linear_forward(const float* x, const float* w, const float* b, float* y, int32_t M, int32_t K, int32_t N,
+                           int32_t act, void* stream);
+int shf_mlp_linear_backward_input(const float* dy, const float* y_or_null, const float* w, float* dx, int32_t M, int32_t K,
+                                  int32_t N, void* stream);
+int shf_mlp_backward_weight_workspace(int32_t M, int32_t K, int32_t N, int64_t* floats);
+int shf_mlp_linear_backward_weight(const float* dy, const float* y_or_null, const float* x, float* dw, float* db,
+                                   float* workspace, int32_t M, int32_t K, int32_t N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,8 +43,12 @@ _SIGS = {
     "shf_abb_bind": ([vp, i32, vp], i32),
     "shf_abb_step": ([vp, vp, vp], i32),
     "shf_abb_reset_all": ([vp, vp], i32),
+    "shf_mlp_linear_forward": ([vp, vp, vp, vp, i32, i32, i32, i32, vp], i32),
+    "shf_mlp_linear_backward_input": ([vp, vp, vp, vp, i32, i32, i32, vp], i32),
+    "shf_mlp_backward_weight_workspace": ([i32, i32, i32, C.POINTER(i64)], i32),
+    "shf_mlp_linear_backward_weight": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], i32),
 }
-EXPORTS = sorted(list(_SIGS) + ["shf_last_error"])
+EXPORTS = sorted(list(_SIGS) + ["shf_last_error", "shf_mlp_last_error"])
 
 
 class BackendError(RuntimeError):
@@ -65,6 +69,7 @@ def lib():
             f = getattr(l, name)
             f.argtypes, f.restype = args, res
         l.shf_last_error.restype = C.c_char_p
+        l.shf_mlp_last_error.restype = C.c_char_p
         if l.shf_abi_version() != _abi.SHF_ABI_VERSION:
             raise BackendError("libshifu_amd.so ABI version mismatch: rebuild")
         _lib = l

@@ -25,6 +25,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 8;   // LDS row = 40 bf16 = 80 B: 16-byte aligned fragments, staggered banks
+constexpr int WGRAD_ROWS = 512;                           // rows of the batch per weight-gradient slice (split over M)
 
 MLP_DEV uint16_t to_bf16(float x) {
   uint32_t u = __float_as_uint(x);
@@ -42,44 +43,100 @@ struct Operand {
   int rows;              // extent along the output index
 };
 
-// Stage a [128 x 32] operand tile (bf16, reduction index contiguous) into LDS.  256 threads, 4096 elements = 16 each.
-template <bool RED_CONTIG>
-MLP_DEV void stage_tile(const Operand& O, int r0, int k0, int red, uint16_t* lds) {
+// One thread's share (16 elements) of a [128 x 32] operand tile, fetched from global memory into registers (fp32, with
+// the optional ELU' mask applied), and later written to LDS as bf16 with the reduction index contiguous.  Fetch and
+// commit are separate so that the next tile's loads are in flight while the MFMAs of the current one run.
+//   RED_CONTIG : thread t -> row t / 2, 16 consecutive k (k half t % 2): four 16-byte loads, two 16-byte LDS stores
+//   otherwise  : thread t -> 4 output rows (t % 32) * 4 .. + 3 x 4 k rows (t / 32) * 4 .. + 3: four 16-byte loads
+//                along the output index (coalesced over t % 32), transposed in registers, four 8-byte LDS stores
+// VEC = the operand's rows are 16-byte aligned (ld % 4 == 0, base aligned): else element-wise loads with the same mapping.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+struct TileRegs { float v[16]; };
+
+template <bool RED_CONTIG, bool VEC>
+MLP_DEV void fetch_tile(const Operand& O, int r0, int k0, int red, TileRegs& T) {
   const int t = (int)threadIdx.x;
   if (RED_CONTIG) {
-    // thread -> (row = t / 2 + 0 | 64 ..., 16 consecutive k): two passes of 128 rows x 2 halves
+    const int gr = r0 + (t >> 1), gk0 = k0 + (t & 1) * 16;
+    const bool rok = gr < O.rows;
+    const size_t base = (size_t)gr * O.ld + gk0;
 #pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-      const int row = (t >> 1) + 0, half = t & 1;
-      const int r = r0 + row + 0 * pass;
-      (void)r;
-    }
-    // simple mapping: element e = t + 256 * i, row = e / 32, k = e % 32  (coalesced along k)
+    for (int q = 0; q < 4; q++) {
+      const int gk = gk0 + 4 * q;
+      if (VEC && rok && gk + 3 < red) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(O.p + base + 4 * q);
+        f32x4 y = {1.0f, 1.0f, 1.0f, 1.0f};
+        if (O.mask_y) {
+          const f32x4 m = *reinterpret_cast<const f32x4*>(O.mask_y + base + 4 * q);
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int e = t + 256 * i, row = e >> 5, k = e & 31;
-      const int gr = r0 + row, gk = k0 + k;
-      float v = 0.0f;
-      if (gr < O.rows && gk < red) {
-        const size_t idx = (size_t)gr * O.ld + gk;
-        v = O.p[idx];
-        if (O.mask_y) v *= elu_grad_from_output(O.mask_y[idx]);
+          for (int c = 0; c < 4; c++) y[c] = elu_grad_from_output(m[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) T.v[4 * q + c] = x[c] * y[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          float v = 0.0f;
+          if (rok && gk + c < red) {
+            v = O.p[base + 4 * q + c];
+            if (O.mask_y) v *= elu_grad_from_output(O.mask_y[base + 4 * q + c]);
+          }
+          T.v[4 * q + c] = v;
+        }
       }
-      lds[row * LDT + k] = to_bf16(v);
     }
   } else {
-    // element e = t + 256 * i, k = e / 128, row = e % 128 (coalesced along the output index), transposed into LDS
+    const int gr0 = r0 + (t & 31) * 4, gk0 = k0 + (t >> 5) * 4;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int e = t + 256 * i, k = e >> 7, row = e & 127;
-      const int gr = r0 + row, gk = k0 + k;
-      float v = 0.0f;
-      if (gr < O.rows && gk < red) {
-        const size_t idx = (size_t)gk * O.ld + gr;
-        v = O.p[idx];
-        if (O.mask_y) v *= elu_grad_from_output(O.mask_y[idx]);
+    for (int q = 0; q < 4; q++) {          // q: k row
+      const int gk = gk0 + q;
+      const size_t base = (size_t)gk * O.ld + gr0;
+      if (VEC && gk < red && gr0 + 3 < O.rows) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(O.p + base);
+        f32x4 y = {1.0f, 1.0f, 1.0f, 1.0f};
+        if (O.mask_y) {
+          const f32x4 m = *reinterpret_cast<const f32x4*>(O.mask_y + base);
+#pragma unroll
+          for (int c = 0; c < 4; c++) y[c] = elu_grad_from_output(m[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) T.v[4 * c + q] = x[c] * y[c];      // transposed: v[row c][k q]
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          float v = 0.0f;
+          if (gk < red && gr0 + c < O.rows) {
+            v = O.p[base + c];
+            if (O.mask_y) v *= elu_grad_from_output(O.mask_y[base + c]);
+          }
+          T.v[4 * c + q] = v;
+        }
       }
-      lds[row * LDT + k] = to_bf16(v);
+    }
+  }
+}
+
+template <bool RED_CONTIG>
+MLP_DEV void commit_tile(const TileRegs& T, uint16_t* lds) {
+  const int t = (int)threadIdx.x;
+  if (RED_CONTIG) {
+    uint16_t* dst = lds + (t >> 1) * LDT + (t & 1) * 16;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      bf16x8 o;
+#pragma unroll
+      for (int c = 0; c < 8; c++) o[c] = (__bf16)T.v[8 * h + c];
+      *reinterpret_cast<bf16x8*>(dst + 8 * h) = o;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {          // c: output row
+      bf16x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; q++) o[q] = (__bf16)T.v[4 * c + q];
+      *reinterpret_cast<bf16x4*>(lds + ((t & 31) * 4 + c) * LDT + (t >> 5) * 4) = o;
     }
   }
 }
@@ -93,7 +150,7 @@ struct Epilogue {
 };
 
 // C[rows, cols] (+)= A B^T over the reduction range [red0, red1) handled by this block (blockIdx.z slices for split-K).
-template <bool A_RED_CONTIG, bool B_RED_CONTIG, bool COLSUM_A>
+template <bool A_RED_CONTIG, bool B_RED_CONTIG, bool COLSUM_A, bool A_VEC, bool B_VEC>
 __global__ __launch_bounds__(256) void k_mlp_gemm(Operand A, Operand B, int red, int red_per_slice, Epilogue E, int rows, int cols) {
   __shared__ __attribute__((aligned(16))) uint16_t As[BM * LDT];
   __shared__ __attribute__((aligned(16))) uint16_t Bs[BN * LDT];
@@ -111,11 +168,18 @@ __global__ __launch_bounds__(256) void k_mlp_gemm(Operand A, Operand B, int red,
       for (int k = 0; k < 16; k++) acc[i][j][k] = 0.0f;
   float csum = 0.0f;   // COLSUM_A: column (= A row index) sums, thread t < 128 owns A row t of the tile
 
+  TileRegs ta, tb;
+  fetch_tile<A_RED_CONTIG, A_VEC>(A, r0, red0, red1, ta);
+  fetch_tile<B_RED_CONTIG, B_VEC>(B, c0, red0, red1, tb);
   for (int k0 = red0; k0 < red1; k0 += BK) {
+    __syncthreads();                       // the previous tile's fragment reads are done
+    commit_tile<A_RED_CONTIG>(ta, As);
+    commit_tile<B_RED_CONTIG>(tb, Bs);
     __syncthreads();
-    stage_tile<A_RED_CONTIG>(A, r0, k0, red1, As);
-    stage_tile<B_RED_CONTIG>(B, c0, k0, red1, Bs);
-    __syncthreads();
+    if (k0 + BK < red1) {                  // next tile's global loads fly under this tile's MFMAs
+      fetch_tile<A_RED_CONTIG, A_VEC>(A, r0, k0 + BK, red1, ta);
+      fetch_tile<B_RED_CONTIG, B_VEC>(B, c0, k0 + BK, red1, tb);
+    }
     if (COLSUM_A && blockIdx.y == 0 && threadIdx.x < BM) {
       // db: sum over the reduction index of the (bf16-rounded) G values of A row t -- the values the MFMA multiplies
       const uint16_t* row = As + threadIdx.x * LDT;
@@ -171,6 +235,17 @@ __global__ void k_mlp_reduce_slices(const float* part, float* out, int n, int sl
 
 thread_local std::string g_mlp_err;
 int mlp_fail(const std::string& m) { g_mlp_err = m; return 1; }
+bool vec_ok(const Operand& O) {
+  return O.ld % 4 == 0 && ((uintptr_t)O.p & 15u) == 0 && (!O.mask_y || ((uintptr_t)O.mask_y & 15u) == 0);
+}
+template <bool AR, bool BR, bool CS>
+void launch_gemm(dim3 grid, hipStream_t st, const Operand& A, const Operand& B, int red, int per, const Epilogue& E, int rows, int cols) {
+  const bool av = vec_ok(A), bv = vec_ok(B);
+  if (av && bv) hipLaunchKernelGGL((k_mlp_gemm<AR, BR, CS, true, true>), grid, dim3(256), 0, st, A, B, red, per, E, rows, cols);
+  else if (av) hipLaunchKernelGGL((k_mlp_gemm<AR, BR, CS, true, false>), grid, dim3(256), 0, st, A, B, red, per, E, rows, cols);
+  else if (bv) hipLaunchKernelGGL((k_mlp_gemm<AR, BR, CS, false, true>), grid, dim3(256), 0, st, A, B, red, per, E, rows, cols);
+  else hipLaunchKernelGGL((k_mlp_gemm<AR, BR, CS, false, false>), grid, dim3(256), 0, st, A, B, red, per, E, rows, cols);
+}
 
 }  // namespace
 
@@ -183,7 +258,7 @@ extern "C" int shf_mlp_linear_forward(const float* x, const float* w, const floa
   Operand A{x, nullptr, K, M}, B{w, nullptr, K, N};
   Epilogue E{y, N, b, act, nullptr};
   dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, 1);
-  hipLaunchKernelGGL((k_mlp_gemm<true, true, false>), grid, dim3(256), 0, (hipStream_t)stream, A, B, K, K, E, M, N);
+  launch_gemm<true, true, false>(grid, (hipStream_t)stream, A, B, K, K, E, M, N);
   return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_mlp_linear_forward: launch failed");
 }
 
@@ -194,13 +269,13 @@ extern "C" int shf_mlp_linear_backward_input(const float* dy, const float* y_or_
   Operand A{dy, y_or_null, N, M}, B{w, nullptr, K, K};
   Epilogue E{dx, K, nullptr, 0, nullptr};
   dim3 grid((M + BM - 1) / BM, (K + BN - 1) / BN, 1);
-  hipLaunchKernelGGL((k_mlp_gemm<true, false, false>), grid, dim3(256), 0, (hipStream_t)stream, A, B, N, N, E, M, K);
+  launch_gemm<true, false, false>(grid, (hipStream_t)stream, A, B, N, N, E, M, K);
   return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_mlp_linear_backward_input: launch failed");
 }
 
 extern "C" int shf_mlp_backward_weight_workspace(int32_t M, int32_t K, int32_t N, int64_t* floats) {
   if (!floats) return mlp_fail("shf_mlp_backward_weight_workspace: null");
-  const int slices = (M + 1023) / 1024;
+  const int slices = (M + WGRAD_ROWS - 1) / WGRAD_ROWS;
   *floats = (int64_t)slices * ((int64_t)N * K + N);
   return 0;
 }
@@ -209,13 +284,13 @@ extern "C" int shf_mlp_linear_backward_weight(const float* dy, const float* y_or
                                               float* workspace, int32_t M, int32_t K, int32_t N, void* stream) {
   if (!dy || !x || !dw || !workspace) return mlp_fail("shf_mlp_linear_backward_weight: null tensor");
   // dW[N,K] = G^T X: rows = n, cols = k, reduction over m; both operands are stored with the reduction index as the row
-  const int per = 1024, slices = (M + per - 1) / per;
+  const int per = WGRAD_ROWS, slices = (M + per - 1) / per;
   float* part_w = workspace;
   float* part_b = workspace + (size_t)slices * N * K;
   Operand A{dy, y_or_null, N, N}, B{x, nullptr, K, K};
   Epilogue E{part_w, K, nullptr, 0, part_b};
   dim3 grid((N + BM - 1) / BM, (K + BN - 1) / BN, slices);
-  hipLaunchKernelGGL((k_mlp_gemm<false, false, true>), grid, dim3(256), 0, (hipStream_t)stream, A, B, M, per, E, N, K);
+  launch_gemm<false, false, true>(grid, (hipStream_t)stream, A, B, M, per, E, N, K);
   const int nw = N * K;
   if (slices > 1) {
     hipLaunchKernelGGL(k_mlp_reduce_slices, dim3((nw + 255) / 256), dim3(256), 0, (hipStream_t)stream, part_w, dw, nw, slices);

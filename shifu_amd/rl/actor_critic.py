@@ -11,9 +11,20 @@ _ACTIVATIONS = {"elu": nn.ELU, "selu": nn.SELU, "relu": nn.ReLU, "lrelu": nn.Lea
                 "sigmoid": nn.Sigmoid}
 
 
-def _mlp(n_in: int, hidden: Sequence[int], n_out: int, act: str) -> nn.Sequential:
+def _mlp(n_in: int, hidden: Sequence[int], n_out: int, act: str, backend: str = "torch") -> nn.Sequential:
     if act not in _ACTIVATIONS:
         raise ValueError(f"unknown activation '{act}' (one of {sorted(_ACTIVATIONS)})")
+    if backend == "mfma":
+        if act != "elu":
+            raise ValueError("mlp_backend='mfma' implements ELU only (the activation of every reference config)")
+        # csrc/shf_mlp.hip: bias + ELU fused into the GEMM; an Identity keeps rsl_rl's parameter names (actor.0, actor.2, ...)
+        from .mfma_linear import MfmaLinear
+        layers, last = [], n_in
+        for h in hidden:
+            layers += [MfmaLinear(last, h, elu=True), nn.Identity()]
+            last = h
+        layers.append(MfmaLinear(last, n_out, elu=False))
+        return nn.Sequential(*layers)
     layers, last = [], n_in
     for h in hidden:
         layers += [SplitKLinear(last, h), _ACTIVATIONS[act]()]
@@ -27,12 +38,16 @@ class ActorCritic(nn.Module):
     is_recurrent = False
 
     def __init__(self, num_actor_obs, num_critic_obs, num_actions, actor_hidden_dims=(256, 256, 256),
-                 critic_hidden_dims=(256, 256, 256), activation="elu", init_noise_std=1.0, **kwargs):
+                 critic_hidden_dims=(256, 256, 256), activation="elu", init_noise_std=1.0, mlp_backend=None, **kwargs):
         if kwargs:
             print("ActorCritic: ignoring unknown policy keys " + ", ".join(kwargs))
         super().__init__()
-        self.actor = _mlp(num_actor_obs, actor_hidden_dims, num_actions, activation)
-        self.critic = _mlp(num_critic_obs, critic_hidden_dims, 1, activation)
+        # mlp_backend: "mfma" = the hand-written MFMA layers (bf16 operands, fp32 accumulation), "torch" = stock fp32
+        # library GEMMs; default from SHIFU_AMD_MLP, else "torch"
+        import os
+        self.mlp_backend = mlp_backend or os.environ.get("SHIFU_AMD_MLP", "torch")
+        self.actor = _mlp(num_actor_obs, actor_hidden_dims, num_actions, activation, self.mlp_backend)
+        self.critic = _mlp(num_critic_obs, critic_hidden_dims, 1, activation, self.mlp_backend)
         self.std = nn.Parameter(init_noise_std * torch.ones(num_actions))
         self.distribution = None
         Normal.set_default_validate_args(False)

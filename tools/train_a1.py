@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--log", default=None)
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture the rollout in one hipGraph (runner.graph_rollout)")
+    ap.add_argument("--mlp", choices=["torch", "mfma"], default=None,
+                    help="ActorCritic layers: stock fp32 library GEMMs, or the hand-written MFMA kernels (csrc/shf_mlp.hip)")
+    ap.add_argument("--self-collision", action="store_true", help="collide the robot's own links (reference collision filter 0)")
     args = ap.parse_args()
     import torch.distributed as dist
     world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
@@ -42,6 +45,8 @@ def main():
     from shifu_amd.runner.utils import class_to_dict, set_seed
     cfg = class_to_dict(A1PPOConfig())
     cfg["runner"]["graph_rollout"] = args.graph
+    if args.mlp:
+        cfg["policy"]["mlp_backend"] = args.mlp
     set_seed(A1PPOConfig.seed + rank)
     if args.hook:
         from examples.a1_conditional.a1_conditional import A1Conditional
@@ -51,7 +56,7 @@ def main():
         env = A1Conditional(ec)
     else:
         from shifu_amd.gym.a1_fused import FusedA1Env
-        env = FusedA1Env(num_envs=args.envs, device=dev, rank=rank, world_size=world)
+        env = FusedA1Env(num_envs=args.envs, device=dev, rank=rank, world_size=world, self_collision=args.self_collision)
     log_dir = args.log or os.path.join("gpurun_out", "train_a1")
     runner = OnPolicyRunner(env, cfg, log_dir=log_dir, device=str(dev))
     if args.quiet:
@@ -63,10 +68,20 @@ def main():
     el = time.time() - t0
     if args.quiet:
         builtins.print = _print
+    # every rank must hold the same parameters after synchronised updates: compare a checksum across ranks
+    flat = torch.cat([p.detach().reshape(-1).double() for p in runner.alg.actor_critic.parameters()])
+    checksum = torch.stack([flat.sum(), flat.abs().sum(), (flat * torch.arange(flat.numel(), device=flat.device) % 7).sum()])
+    in_sync = True
+    if world > 1:
+        mine = checksum if backend == "nccl" else checksum.cpu()
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        in_sync = all(torch.equal(g, gathered[0]) for g in gathered)
     if rank == 0:
         H = runner.history
         pick = sorted(set([0, len(H) // 8, len(H) // 4, len(H) // 2, 3 * len(H) // 4, len(H) - 1]))
         out = {"env": "A1Conditional (hook path)" if args.hook else "FusedA1Env", "envs_per_gpu": args.envs, "n_gpus": world,
+               "mlp_backend": runner.alg.actor_critic.mlp_backend, "ranks_in_sync": in_sync, "param_checksum": checksum.tolist(),
                "iterations": args.iters, "steps_per_env_per_iter": cfg["runner"]["num_steps_per_env"],
                "samples_per_s": args.iters * cfg["runner"]["num_steps_per_env"] * args.envs * world / el, "seconds": el,
                "mean_collection_s": sum(h["collection_time"] for h in H) / len(H), "mean_learn_s": sum(h["learn_time"] for h in H) / len(H),
