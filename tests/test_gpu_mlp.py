@@ -110,7 +110,7 @@ def test_two_rank_training_keeps_parameters_in_sync(tmp_path):
     env = dict(os.environ, SHIFU_AMD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "tools", "train_a1.py"), "--iters", "3", "--envs", "256", "--quiet",
-           "--log", str(tmp_path / "log")]
+           "--out", str(tmp_path / "log")]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]

@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--iters", type=int, default=300)
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--hook", action="store_true")
-    ap.add_argument("--log", default=None)
+    ap.add_argument("--log", "--out", dest="log", default=None, help="log / checkpoint directory (--out under torchrun, whose own parser claims --log*)")
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture the rollout in one hipGraph (runner.graph_rollout)")
     ap.add_argument("--mlp", choices=["torch", "mfma"], default=None,
