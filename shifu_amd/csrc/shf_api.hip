@@ -267,20 +267,24 @@ DEV long long stats_fix(float x) { return (long long)rintf(x * STATS_FIX); }
 DEV void stats_block_init(float* lds_words) {
   if (threadIdx.x < STATS_LDS_WORDS) reinterpret_cast<uint32_t*>(lds_words)[threadIdx.x] = 0u;   // before stage_model's barrier
 }
-// Called by lane 0 of every env group of the block once its NK values are final.  FIN(acc[NK], out) -> ring row.
+// stats_contribute: called by lane 0 of every env group of the block once its NK values are final; the last group of the
+// block adds the block totals to the slot's global accumulators and returns the slot's row (else nullptr).
+// stats_finish: called by that same lane at the very end of the kernel with the row (the additions have had the rest
+// of the kernel to be acknowledged): takes the block's ticket; the last block finalises.  FIN(acc[NK], out) -> ring row.
 // Ordering without agent-scope fences (on a multi-XCD part an agent-scope release writes the XCD's whole dirty L2 back
 // -- here the ~13 MB of outputs the launch has just produced -- once per block): every global operation below is an
 // agent-scope atomic, which is performed at the device's point of coherence; a block waits for its additions to be
 // acknowledged (s_waitcnt through a workgroup-scope fence) before it takes its ticket, so whoever draws the last
 // ticket reads complete totals -- with atomic exchanges, which also clear the slot.
-template <int NK, class FIN>
-DEV void stats_contribute(const StatsArgs& S, float* lds_words, const long long* v, int envs_in_block, FIN finalize) {
+template <int NK>
+DEV unsigned long long* stats_contribute(const StatsArgs& S, float* lds_words, const long long* v, int envs_in_block,
+                                         unsigned long long* step_out) {
   unsigned long long* blk = reinterpret_cast<unsigned long long*>(lds_words);
 #pragma unroll
   for (int k = 0; k < NK; k++)
     if (v[k] != 0) __hip_atomic_fetch_add(&blk[k], (unsigned long long)v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   const unsigned done = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(&blk[9]), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-  if ((int)done != envs_in_block - 1) return;
+  if ((int)done != envs_in_block - 1) return nullptr;
   // last group of this block
   unsigned long long* ctl = S.acc + (size_t)S.ring * STATS_COLS;
   const unsigned long long step = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -290,7 +294,13 @@ DEV void stats_contribute(const StatsArgs& S, float* lds_words, const long long*
     const unsigned long long t = __hip_atomic_load(&blk[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (t != 0ull) __hip_atomic_fetch_add(&row[k], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt: the additions above are acknowledged
+  *step_out = step;
+  return row;
+}
+template <int NK, class FIN>
+DEV void stats_finish(const StatsArgs& S, unsigned long long* row, unsigned long long step, FIN finalize) {
+  if (!row) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt: this block's additions are acknowledged
   const unsigned long long ticket = __hip_atomic_fetch_add(&row[8], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (ticket != (unsigned long long)gridDim.x - 1ull) return;
   // last block of the launch
@@ -303,6 +313,7 @@ DEV void stats_contribute(const StatsArgs& S, float* lds_words, const long long*
   finalize(tot, o);
   float* latest = S.out + (size_t)S.ring * S.out_cols;     // row `ring`: always the step that ran last
   for (int k = 0; k < S.out_cols; k++) latest[k] = o[k];
+  unsigned long long* ctl = S.acc + (size_t)S.ring * STATS_COLS;
   __hip_atomic_store(ctl, step + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -564,6 +575,8 @@ DEV void a1_step_body(const A1Args& A) {
   PHASE_MARK(14);
 
   // post_step (env.py:93-106): one lane runs the scalar bookkeeping
+  unsigned long long* stats_row = nullptr;
+  unsigned long long stats_step = 0ull;
   if (l == 0) {
     // pre-physics base-frame velocities: written to base_vel at the top of the kernel by this lane and read back
     // here rather than held in six registers across the sub-steps
@@ -649,18 +662,7 @@ DEV void a1_step_body(const A1Args& A) {
       for (int k = 0; k < 6; k++) sv[k] = stats_fix(done[k]);
       sv[6] = (long long)level; sv[7] = reset ? 1ll : 0ll;
       const int first = (int)blockIdx.x * epb, eib = n - first < epb ? n - first : epb;
-      const float Ts = tp.max_episode_length_s;
-      stats_contribute<8>(A.stats, stats_lds, sv, eib, [n, Ts](const long long* t, float* o) {
-        const float c = (float)t[7];
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-          const float sum = (float)t[k] * (1.0f / STATS_FIX);
-          o[k] = sum;
-          o[8 + k] = c > 0.0f ? sum / c / Ts : 0.0f;
-        }
-        o[6] = (float)t[6]; o[7] = c;
-        o[14] = o[6] / (float)n; o[15] = (float)n;
-      });
+      stats_row = stats_contribute<8>(A.stats, stats_lds, sv, eib, &stats_step);
     }
     const float co = tp.clip_obs;
     float* o = scr + SCR_OBS;
@@ -699,6 +701,21 @@ DEV void a1_step_body(const A1Args& A) {
   }
   for (int i = l; i < 2 * nd; i += G) dof[i] = L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)];
   if (l < 13) root[l] = L.root[l];
+  if (l == 0) {
+    // the block's statistics additions were issued in post_step; by now they have been acknowledged
+    const float Ts = tp.max_episode_length_s;
+    stats_finish<8>(A.stats, stats_row, stats_step, [n, Ts](const long long* t, float* o) {
+      const float c = (float)t[7];
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const float sum = (float)t[k] * (1.0f / STATS_FIX);
+        o[k] = sum;
+        o[8 + k] = c > 0.0f ? sum / c / Ts : 0.0f;
+      }
+      o[6] = (float)t[6]; o[7] = c;
+      o[14] = o[6] / (float)n; o[15] = (float)n;
+    });
+  }
   PHASE_MARK(16);
 }
 template <int G, class DM>
@@ -873,6 +890,8 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
   refresh_body_jac<G, DM>(m, L, l, actors, bstate, jac, tgtl + nd, tp.ee_body);
 
   // post_step on one lane (env.py:93-106, a_prior_stage.py:97-135)
+  unsigned long long* stats_row = nullptr;
+  unsigned long long stats_step = 0ull;
   if (l == 0) {
     int64_t ep = A.ep_len[e] + 1;
     const float* cube = L.root + 13 * tp.cube_actor;
@@ -910,16 +929,7 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
       // extras["episode"] (env.py:149-158 + episode_log, a_prior_stage.py:94-95)
       const long long sv[4] = {stats_fix(done[0]), stats_fix(done[1]), (reset && success) ? 1ll : 0ll, reset ? 1ll : 0ll};
       const int first = (int)blockIdx.x * epb, eib = n - first < epb ? n - first : epb;
-      const float Ts = tp.max_episode_length_s;
-      stats_contribute<4>(A.stats, stats_lds, sv, eib, [n, Ts](const long long* t, float* o) {
-        const float c = (float)t[3];
-        const float s0 = (float)t[0] * (1.0f / STATS_FIX), s1 = (float)t[1] * (1.0f / STATS_FIX);
-        o[0] = s0; o[1] = s1; o[2] = (float)t[2]; o[3] = c;
-        o[4] = c > 0.0f ? s0 / c / Ts : 0.0f;
-        o[5] = c > 0.0f ? s1 / c / Ts : 0.0f;
-        o[6] = c > 0.0f ? o[2] / c : 0.0f;
-        o[7] = (float)n;
-      });
+      stats_row = stats_contribute<4>(A.stats, stats_lds, sv, eib, &stats_step);
     }
     const float co = tp.clip_obs;
     float* o = A.obs + (size_t)e * 6;
@@ -930,6 +940,18 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
   GROUP_SYNC();
   for (int i = l; i < 2 * nd; i += G) dof[i] = L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)];
   for (int i = l; i < 13 * actors; i += G) root[i] = L.root[i];
+  if (l == 0) {
+    const float Ts = tp.max_episode_length_s;
+    stats_finish<4>(A.stats, stats_row, stats_step, [n, Ts](const long long* t, float* o) {
+      const float c = (float)t[3];
+      const float s0 = (float)t[0] * (1.0f / STATS_FIX), s1 = (float)t[1] * (1.0f / STATS_FIX);
+      o[0] = s0; o[1] = s1; o[2] = (float)t[2]; o[3] = c;
+      o[4] = c > 0.0f ? s0 / c / Ts : 0.0f;
+      o[5] = c > 0.0f ? s1 / c / Ts : 0.0f;
+      o[6] = c > 0.0f ? o[2] / c : 0.0f;
+      o[7] = (float)n;
+    });
+  }
 }
 
 __global__ void k_abb_reset_all(AbbArgs A) {
