@@ -349,7 +349,7 @@ def main():
         value = total_envs * args.steps / elapsed
         b_alg = B_ALG[args.workload]
         achieved = b_alg * N / (kern_ms * 1e-3) / 1e9
-        prof = committed_profile(f"{kernel}_{args.workload}_g{group}") if N == 4096 else None
+        prof = committed_profile(f"{kernel}_{args.workload}_g{group}") if (N == 4096 and not args.self_collision) else None
         res = {}
         try:
             res = json.load(open(os.path.join(ROOT, "shifu_amd", "libshifu_amd.resources.json")))

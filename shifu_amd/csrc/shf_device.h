@@ -696,6 +696,9 @@ DEV float friction_coefficient(const float* n, const float* vs, float pen, float
 }
 
 #include "shf_boxes.h"
+#ifdef SHF_EXP_SHUFFLE_HANDOFF
+#include "experiments/shuffle_handoff.h"
+#endif
 
 // Sample-point constants of the lane's contact rounds (point l + k*G in round k), for models whose point
 // count is a compile-time constant.
@@ -1013,6 +1016,13 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
         for (int j = 1; j < 6; j++) acc = fmaf(SYMG(B.IA, i, j), B.c[j], acc);
         pa[i] = fmaf(W[i], B.u, B.pA[i] + acc);
       }
+#ifdef SHF_EXP_SHUFFLE_HANDOFF
+#pragma unroll
+      for (int k = 0; k < 6; k++) B.pA[k] = pa[k];
+    }
+    exp_shuffle_handoff<G>(M, l, isdyn && mylevel == lev - 1, B);   // experiments/shuffle_handoff.h
+    if (false) {
+#else
       float* o = L.xch + l * XCH_STRIDE;
 #pragma unroll
       for (int k = 0; k < 21; k++) o[k] = B.IA[k];
@@ -1021,6 +1031,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
     }
     GROUP_SYNC();
     if (isdyn && mylevel == lev - 1) {
+#endif
       // children in child_list order: the first LANE_CHILDREN from registers, any further ones through LDS
 #pragma unroll
       for (int kk = 0; kk < LANE_CHILDREN; kk++) {

@@ -23,7 +23,7 @@ NAMES = ["kin: local rotation", "kin: level loop", "inertia + ext force", "conta
 
 def build():
     from shifu_amd import build as b
-    cmd = [b.hipcc()] + b.FLAGS + ["-DSHF_PHASE_CLOCK", os.path.join(b.CSRC, "shf_api.hip"), "-o", LIB]
+    cmd = [b.hipcc()] + b.FLAGS + ["-DSHF_PHASE_CLOCK"] + [os.path.join(b.CSRC, s) for s in b.SOURCES] + ["-o", LIB]
     subprocess.check_call(cmd)
     print(LIB)
 
