@@ -346,8 +346,16 @@ class Gym:
         a = env.actors[actor_handle]
         if a.asset.model is None:
             a.mass_override = float(props[0].mass)
-        # per-env link masses of articulations are not supported (the reference's call sites only
-        # touch boxes: object.py:35-37)
+            return True
+        # per-env link masses of articulations are not supported (the reference's call sites only touch boxes,
+        # object.py:35-37; its mass randomisation of robots is commented out, isaac_gym.py:172-185): unchanged values
+        # are accepted, an actual edit is refused rather than silently dropped
+        blob = a.asset.model.blob
+        for b, pr in enumerate(props):
+            if abs(float(pr.mass) - float(blob.mass[b])) > 1e-9 * max(1.0, abs(float(blob.mass[b]))):
+                raise NotImplementedError("set_actor_rigid_body_properties: per-env link masses of an articulation are not "
+                                          "supported by this backend (one compiled model is shared by all envs)")
+        return True
     def set_actor_dof_properties(self, env, actor_handle, props):
         env.actors[actor_handle].dof_props = props
     def set_rigid_body_segmentation_id(self, *a, **k): pass
@@ -454,6 +462,8 @@ class Gym:
     def apply_rigid_body_force_at_pos_tensors(self, sim, force, pos=None, space=ENV_SPACE):
         if pos is not None:
             raise NotImplementedError("forces are applied at the body CoM (the reference passes pos=None: robot.py:231-236)")
+        if space != ENV_SPACE:
+            raise NotImplementedError("forces are taken in env (= world-aligned) axes only, the default the reference uses")
         sim.backend.apply_body_force(force)
         return True
 

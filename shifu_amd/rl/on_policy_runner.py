@@ -200,7 +200,7 @@ class OnPolicyRunner:
     # ------------------------------------------------------------ checkpoints
     def save(self, path, infos=None):
         torch.save({"model_state_dict": self.alg.actor_critic.state_dict(),
-                    "optimizer_state_dict": self.alg.optimizer.state_dict(),
+                    "optimizer_state_dict": self.alg.optimizer_state_dict(),
                     "iter": self.current_learning_iteration, "infos": infos}, path)
 
     def load(self, path, load_optimizer=True):

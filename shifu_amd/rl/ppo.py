@@ -93,10 +93,25 @@ class PPO:
         return float(self.lr)
 
     def relink_learning_rate(self):
-        """After optimizer.load_state_dict the param groups hold a fresh lr value: share one tensor again."""
+        """After optimizer.load_state_dict the param groups hold the checkpoint's lr value AND its implementation flags
+        (a stock rsl_rl checkpoint: python-float lr, no fused / capturable; one of ours saved on the GPU: both set):
+        share one lr tensor again and put this trainer's own flags for the current device back, so that a checkpoint from
+        either side resumes on either device without falling into the per-parameter loop or the capturable assertion."""
         self.lr.fill_(float(self.optimizer.param_groups[0]["lr"]))
+        cuda = torch.device(self.device).type == "cuda"
         for g in self.optimizer.param_groups:
             g["lr"] = self.lr
+            g["fused"], g["capturable"], g["foreach"] = cuda, cuda, None
+        for st in self.optimizer.state.values():
+            if "step" in st and torch.is_tensor(st["step"]):
+                st["step"] = st["step"].to(self.lr.device if cuda else "cpu", dtype=torch.float32)
+
+    def optimizer_state_dict(self):
+        """optimizer.state_dict() with the learning rate as a python float: interchangeable with the stock trainer's."""
+        sd = self.optimizer.state_dict()
+        for g in sd["param_groups"]:
+            g["lr"] = float(g["lr"])
+        return sd
 
     def adapt_learning_rate(self, kl_mean):
         """schedule='adaptive': keep the policy step near desired_kl (x1.5 / /1.5, clamped to [1e-5, 1e-2]).

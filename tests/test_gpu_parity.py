@@ -616,3 +616,70 @@ def test_self_collision_matches_oracle_bitwise(oracle, group, dyn):
         oracle.a1_step(m, sp2, tp, 64, 0, bufs, raw, terrain=terr, heights=hs)
         _compare(sim, task, bufs, f"fused self-collision step {it}")
     assert "self" in task.kernel_symbol() and ("DynDims" in task.kernel_symbol()) == dyn
+
+
+def test_velocity_drive_matches_oracle_bitwise(oracle):
+    """Robot._internal_motor_step's DOF_MODE_VEL branch (reference shifu/units/robot.py:55-64; no shipped config uses it):
+    an implicit velocity drive (kd (v* - qd), effort-limited) on the ABB arm, targets through
+    gym.set_dof_velocity_target_tensor, HIP against the oracle; the joints reach the commanded speeds."""
+    _need_gpu()
+    from shifu_amd.abb_task import ABB_DEFAULT_DOF_POS, abb_model
+    rng = np.random.default_rng(4)
+    cm = abb_model(kp=0.0, kd=60.0)
+    m = cm.blob
+    for d in range(m.nd):
+        m.drive_mode[d] = _abi.DOF_MODE_VEL
+    sp = H.sim_params(dt=0.02)
+    n = 24
+    dof = np.zeros((n * m.nd, 2), np.float32)
+    dof[:, 0] = np.tile(np.array(ABB_DEFAULT_DOF_POS, np.float32), n)
+    root = np.zeros((n, 13), np.float32); root[:, 6] = 1.0
+    vt = rng.uniform(-0.4, 0.4, n * m.nd).astype(np.float32)
+    vt[5::m.nd] = 0.0                                     # the dummy tip joint has effort 0: it cannot be driven
+    sim = _make_sim(cm, sp, n, group=32)
+    T = sim.tensors
+    T[_abi.T_SIM_DOF].copy_(torch.from_numpy(dof))
+    T[_abi.T_SIM_ROOT].copy_(torch.from_numpy(root))
+    sim.set_dof_command(_abi.T_VEL_TARGET, torch.from_numpy(vt).cuda())
+    for it in range(25):
+        sim.step()
+        sim.refresh(_abi.REFRESH_DOF)
+        oracle.step(m, sp, n, dof, root, vel_target=vt)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(T[_abi.T_DOF_STATE].cpu().numpy(), dof, err_msg=f"dof step {it}")
+    qd = dof[:, 1].reshape(n, m.nd)
+    assert np.abs(qd[:, :5] - vt.reshape(n, m.nd)[:, :5]).max() < 0.05, np.abs(qd[:, :5] - vt.reshape(n, m.nd)[:, :5]).max()
+
+
+def test_config5_full_size_is_deterministic_and_shard_invariant():
+    """BASELINE config 5 at its full size (4096 envs), where the oracle would take minutes: size-independent properties --
+    two runs give bit-identical tensors, and two 2048-env shards (ranks 0 / 1 of 2) reproduce the unsharded run."""
+    _need_gpu()
+    from shifu_amd.gym.abb_fused import FusedAbbEnv
+    N, K = 4096, 40
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    acts = [2 * torch.rand(N, 3, device="cuda:0", generator=g) - 1 for _ in range(K)]
+
+    def run(num, rank, world, sl):
+        env = FusedAbbEnv(num_envs=num, seed=3, rank=rank, world_size=world, episode_length_s=2.0)
+        for a in acts:
+            env.step(a[sl])
+        torch.cuda.synchronize()
+        out = {k: v.clone() for k, v in env.task.tensors.items() if k not in (_abi.ABB_PARAMS, _abi.ABB_STATS, _abi.ABB_STATS_ACC)}
+        out.update({100 + k: env.sim.tensors[k].clone() for k in (_abi.T_DOF_STATE, _abi.T_ROOT_STATE, _abi.T_BODY_STATE, _abi.T_CONTACT)})
+        resets = int(env.task.tensors[_abi.ABB_RESET_COUNT].sum())
+        env.destroy()
+        return out, resets
+    a, ra = run(N, 0, 1, slice(0, N))
+    b, _ = run(N, 0, 1, slice(0, N))
+    assert ra > N and all(torch.equal(a[k], b[k]) for k in a)            # run-to-run identical, resets exercised
+    for r in (0, 1):
+        s, _ = run(N // 2, r, 2, slice(r * N // 2, (r + 1) * N // 2))
+        for k, v in s.items():
+            full = a[k]
+            if full.shape[0] == v.shape[0] * 2:
+                assert torch.equal(v, full[r * v.shape[0]:(r + 1) * v.shape[0]]), f"rank {r} tensor {k}"
+            elif full.dim() == 2 and full.shape[1] == v.shape[1] * 2:        # (rows, N) layouts: rew_sums, done_sums
+                assert torch.equal(v, full[:, r * v.shape[1]:(r + 1) * v.shape[1]]), f"rank {r} tensor {k}"
+            else:
+                raise AssertionError(f"unexpected layout for tensor {k}: {tuple(full.shape)} vs {tuple(v.shape)}")

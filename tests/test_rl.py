@@ -226,3 +226,32 @@ def test_run_policy_train_then_play(tmp_path, capsys):
     run_policy("play", Env, env_cfg, Cfg(), log_root=str(tmp_path), play_num_envs=5, play_iterations=4)
     assert made[-1].num_envs == 5 and env_cfg.debug.headless is False
     assert "model_3.pt" in capsys.readouterr().out          # "Loading model from: ..."
+
+
+def test_optimizer_checkpoints_are_interchangeable_with_the_stock_trainer(tmp_path):
+    """The checkpoint keys are rsl_rl's (policy_runner.py:7-14); the optimizer part must round-trip too: the saved lr is a
+    python float without implementation flags baked in from the saving device, and loading -- our own file or a stock
+    Adam state dict (float lr, no fused / capturable) -- leaves the trainer with ITS flags and one shared lr tensor."""
+    from shifu_amd.rl.ppo import PPO
+    torch.manual_seed(0)
+    net = ActorCritic(4, 4, 2, actor_hidden_dims=[8], critic_hidden_dims=[8])
+    alg = PPO(net, learning_rate=3e-4, device="cpu")
+    x = torch.randn(32, 4)
+    (net.actor(x).square().mean() + net.critic(x).square().mean()).backward()
+    alg.optimizer.step()
+    sd = alg.optimizer_state_dict()
+    assert isinstance(sd["param_groups"][0]["lr"], float) and abs(sd["param_groups"][0]["lr"] - 3e-4) < 1e-9
+    torch.save(sd, tmp_path / "opt.pt")
+    # a stock Adam (what rsl_rl builds) loads it, and its own state dict loads back into ours
+    stock = torch.optim.Adam(ActorCritic(4, 4, 2, actor_hidden_dims=[8], critic_hidden_dims=[8]).parameters(), lr=1e-3)
+    stock.load_state_dict(torch.load(tmp_path / "opt.pt"))
+    assert abs(stock.param_groups[0]["lr"] - 3e-4) < 1e-9
+    stock_sd = stock.state_dict()
+    stock_sd["param_groups"][0]["lr"] = 5e-4
+    alg.optimizer.load_state_dict(stock_sd)
+    alg.relink_learning_rate()
+    g = alg.optimizer.param_groups[0]
+    assert g["lr"] is alg.lr and abs(alg.learning_rate - 5e-4) < 1e-9
+    assert g["fused"] is False and g["capturable"] is False          # this trainer's flags for the CPU, whatever the file said
+    (net.actor(x).square().mean()).backward()
+    alg.optimizer.step()                                               # and it still steps
