@@ -23,13 +23,13 @@
 extern "C" {
 #endif
 
-#define SHF_ABI_VERSION 3
+#define SHF_ABI_VERSION 4
 
 #define SHF_MAX_BODIES 32 /* reported rigid bodies per articulation        */
 #define SHF_MAX_DOFS 32
 #define SHF_MAX_POINTS 96 /* contact sample points per articulation        */
 #define SHF_MAX_BOXES 4   /* extra single-body box actors per env          */
-#define SHF_MAX_SPHERES 8 /* collision spheres (vs boxes) per articulation */
+#define SHF_MAX_SPHERES 8 /* collision spheres / capsules (vs boxes) per articulation */
 #define SHF_MAX_CAPSULES 16 /* self-collision capsules per articulation      */
 #define SHF_MAX_PAIRS 96    /* capsule pairs tested for self-collision       */
 #define SHF_MAX_SELF_CONTACTS 8 /* simultaneously active self-contacts per env (further ones are dropped, in pair order) */
@@ -91,8 +91,13 @@ typedef struct ShfModel {
   float pt_pos[SHF_MAX_POINTS][3]; /* in pt_body's frame                   */
   float pt_radius[SHF_MAX_POINTS];
 
+  /* Rounded shapes of the articulation tested against the free box actors: a sphere (sph_seg = 0), or a capsule --
+   * the segment sph_pos + t sph_seg, t in [0,1], swept by sph_radius (the native form of the URDF <cylinder> under
+   * replace_cylinder_with_capsule, asset_config.py:32-46).  A capsule meets a box at the point of its segment
+   * closest to the box (exact minimiser of the convex piecewise-quadratic distance), then as a sphere there. */
   int32_t sph_body[SHF_MAX_SPHERES];
   float sph_pos[SHF_MAX_SPHERES][3];
+  float sph_seg[SHF_MAX_SPHERES][3];
   float sph_radius[SHF_MAX_SPHERES];
 
   /* Self-collision (create_actor(..., collision_filter = 0), units.py:68): every collision shape of

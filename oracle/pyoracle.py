@@ -327,3 +327,15 @@ def segment_closest(segs, f64=True):
     fn = lib().shf_oracle_segment_closest_f64 if f64 else lib().shf_oracle_segment_closest_f32
     fn(C.c_int(s.shape[0]), _p(s, ct), _p(out, ct))
     return out
+
+
+def segment_box_param(bR, bpos, h, c0, s, f64=True):
+    """Capsule vs box: parameter t of the point c0 + t s closest to the box (bR (n,9) row-major world<-box, bpos, half
+    extents h, all (n,3)) -> (n,)."""
+    dt, ct = (np.float64, C.c_double) if f64 else (np.float32, C.c_float)
+    pack = np.ascontiguousarray(np.concatenate([np.reshape(bR, (-1, 9)), bpos, h, c0, s], axis=1), dt)
+    out = np.zeros(pack.shape[0], dt)
+    fn = lib().shf_oracle_segment_box_param_f64 if f64 else lib().shf_oracle_segment_box_param_f32
+    fn.restype = None
+    fn(C.c_int(pack.shape[0]), _p(pack, ct), _p(out, ct))
+    return out

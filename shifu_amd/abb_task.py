@@ -10,15 +10,15 @@ ABB_BASE_POS = [-0.48, 0.0, 0.0]                              # task_config.py:5
 
 # The reference collides the rod as the convex hull of rod.stl (a cylinder r = 0.0194 m,
 # z in [-0.0025, 0.2145] m in the tool0 frame, measured from the STL).  Mesh colliders
-# are not supported here; the lower 12 cm of the rod is covered by eight spheres of that radius
-# spaced 12 mm apart (surface ripple < 1 mm).
+# are not supported here; the rod is one native capsule of that radius over the rod's whole length (its flat end
+# becomes a half sphere: the tip reaches the same z, the rim is rounded off by < r (1 - 1/sqrt 2) = 5.7 mm).
 ROD_RADIUS = 0.0194
-ROD_SPHERES = [("tool0", (0.0, 0.0, 0.2145 - ROD_RADIUS - k * 0.012), ROD_RADIUS) for k in range(8)]
+ROD_CAPSULE = [("tool0", (0.0, 0.0, 0.2145 - ROD_RADIUS), (0.0, 0.0, ROD_RADIUS - 0.0025), ROD_RADIUS)]
 
 
 def abb_model(kp=800.0, kd=40.0):
     cm = compile_urdf(asset_path("abb_rod.urdf"), fix_base_link=True, disable_gravity=True,
-                      default_dof_drive_mode=_abi.DOF_MODE_POS, extra_spheres=ROD_SPHERES)
+                      default_dof_drive_mode=_abi.DOF_MODE_POS, extra_spheres=ROD_CAPSULE)
     for d in range(cm.blob.nd):
         cm.blob.kp[d], cm.blob.kd[d] = kp, kd
     return cm

@@ -269,16 +269,23 @@ DEV void stats_block_init(float* lds_words) {
 }
 // stats_contribute: called by lane 0 of every env group of the block once its NK values are final; the last group of the
 // block adds the block totals to the slot's global accumulators and returns the slot's row (else nullptr).
-// stats_finish: called by that same lane at the very end of the kernel with the row (the additions have had the rest
-// of the kernel to be acknowledged): takes the block's ticket; the last block finalises.  FIN(acc[NK], out) -> ring row.
+// stats_ticket / stats_finish: called by that same lane later in the kernel with the row (the additions have had time to
+// be acknowledged): takes the block's ticket; the block that drew the last one finalises.  FIN(acc[NK], out) -> ring row.
 // Ordering without agent-scope fences (on a multi-XCD part an agent-scope release writes the XCD's whole dirty L2 back
 // -- here the ~13 MB of outputs the launch has just produced -- once per block): every global operation below is an
 // agent-scope atomic, which is performed at the device's point of coherence; a block waits for its additions to be
 // acknowledged (s_waitcnt through a workgroup-scope fence) before it takes its ticket, so whoever draws the last
 // ticket reads complete totals -- with atomic exchanges, which also clear the slot.
+// stats_step_load: the vec-step counter, read once at the top of the kernel (it only changes when the last block of a
+// launch finishes) so that its round trip is not on post_step's critical path; wave-uniform, kept in scalar registers.
+DEV unsigned long long stats_step_load(const StatsArgs& S) {
+  const unsigned long long v = __hip_atomic_load(S.acc + (size_t)S.ring * STATS_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
 template <int NK>
 DEV unsigned long long* stats_contribute(const StatsArgs& S, float* lds_words, const long long* v, int envs_in_block,
-                                         unsigned long long* step_out) {
+                                         unsigned long long step) {
   unsigned long long* blk = reinterpret_cast<unsigned long long*>(lds_words);
 #pragma unroll
   for (int k = 0; k < NK; k++)
@@ -286,22 +293,24 @@ DEV unsigned long long* stats_contribute(const StatsArgs& S, float* lds_words, c
   const unsigned done = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(&blk[9]), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
   if ((int)done != envs_in_block - 1) return nullptr;
   // last group of this block
-  unsigned long long* ctl = S.acc + (size_t)S.ring * STATS_COLS;
-  const unsigned long long step = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   unsigned long long* row = S.acc + (size_t)(step % (unsigned long long)S.ring) * STATS_COLS;
 #pragma unroll
   for (int k = 0; k < NK; k++) {
     const unsigned long long t = __hip_atomic_load(&blk[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (t != 0ull) __hip_atomic_fetch_add(&row[k], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  *step_out = step;
   return row;
 }
-template <int NK, class FIN>
-DEV void stats_finish(const StatsArgs& S, unsigned long long* row, unsigned long long step, FIN finalize) {
-  if (!row) return;
+// stats_ticket: after the block's additions are acknowledged; the returned count is only looked at by stats_finish, at
+// the very end of the kernel, so the atomic's round trip overlaps the output stores in between.
+DEV unsigned long long stats_ticket(unsigned long long* row) {
+  if (!row) return 0ull;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt: this block's additions are acknowledged
-  const unsigned long long ticket = __hip_atomic_fetch_add(&row[8], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_fetch_add(&row[8], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int NK, class FIN>
+DEV void stats_finish(const StatsArgs& S, unsigned long long* row, unsigned long long ticket, unsigned long long step, FIN finalize) {
+  if (!row) return;
   if (ticket != (unsigned long long)gridDim.x - 1ull) return;
   // last block of the launch
   long long tot[NK];
@@ -452,12 +461,26 @@ DEV void a1_step_body(const A1Args& A) {
   PHASE_BEGIN();
   float* stats_lds = smem + MODEL_WORDS + TASK_WORDS;
   stats_block_init(stats_lds);
-  stage_block<(int)sizeof(ShfA1TaskParams)>(A.tp, smem + MODEL_WORDS);
-  const ShfModel* m = stage_model(A.S.model, smem);
-  const ShfA1TaskParams& tp = *reinterpret_cast<const ShfA1TaskParams*>(smem + MODEL_WORDS);
+  const unsigned long long stats_step = stats_step_load(A.stats);
   const int epb = 256 / G, es = threadIdx.x / G, l = threadIdx.x % G;
   const int e = blockIdx.x * epb + es;
   const int n = A.S.n;
+  // compile-time dimensions: the env's state and action loads go out before the model is staged, so their round trip
+  // overlaps the staging copy instead of following its barrier
+  constexpr bool EARLY = DM::NPC > 0;
+  float pre_dof = 0.0f, pre_root = 0.0f, pre_act = 0.0f;
+  if constexpr (EARLY) {
+    static_assert(!EARLY || G >= 24, "one state word per lane");
+    const int ndc = DM::nd(nullptr);
+    if (e < n) {
+      if (l < 2 * ndc) pre_dof = A.S.dof[(size_t)e * ndc * 2 + l];
+      if (l < 13) pre_root = A.S.root[(size_t)e * 13 + l];
+      if (l < ndc) pre_act = A.raw_actions[(size_t)e * ndc + l];
+    }
+  }
+  stage_block<(int)sizeof(ShfA1TaskParams)>(A.tp, smem + MODEL_WORDS);
+  const ShfModel* m = stage_model(A.S.model, smem);
+  const ShfA1TaskParams& tp = *reinterpret_cast<const ShfA1TaskParams*>(smem + MODEL_WORDS);
   if (e >= n) return;
   const int nb = DM::nb(m), nd = DM::nd(m), np = DM::np(m), H = tp.num_history, P = tp.num_height_points;
   const int nobs = 12 + 2 * nd + nd * H + P;
@@ -469,13 +492,17 @@ DEV void a1_step_body(const A1Args& A) {
 
   float* dof = A.S.dof + (size_t)e * nd * 2;
   float* root = A.S.root + (size_t)e * 13;
-  for (int i = l; i < 2 * nd; i += G) L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)] = dof[i];
-  if (l < 13) L.root[l] = root[l];
   float act = 0.0f;
-  if (l < nd) {
-    act = rclampf(A.raw_actions[(size_t)e * nd + l] * tp.action_scale, -tp.clip_actions, tp.clip_actions);
-    A.actions[(size_t)e * nd + l] = act;
+  if constexpr (EARLY) {
+    if (l < 2 * nd) L.dofb[(l >> 1) * DOF_STRIDE + (l & 1)] = pre_dof;
+    if (l < 13) L.root[l] = pre_root;
+    if (l < nd) act = rclampf(pre_act * tp.action_scale, -tp.clip_actions, tp.clip_actions);
+  } else {
+    for (int i = l; i < 2 * nd; i += G) L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)] = dof[i];
+    if (l < 13) L.root[l] = root[l];
+    if (l < nd) act = rclampf(A.raw_actions[(size_t)e * nd + l] * tp.action_scale, -tp.clip_actions, tp.clip_actions);
   }
+  if (l < nd) A.actions[(size_t)e * nd + l] = act;
   GROUP_SYNC();
 
   // Q2: base-frame velocities from the pre-physics root state (robot.py:222-229)
@@ -521,6 +548,23 @@ DEV void a1_step_body(const A1Args& A) {
   body_states<G, DM>(m, L, l, M, scr + SCR_BODY);
   for (int i = l; i < 13 * nb; i += G) A.body_state[(size_t)e * nb * 13 + i] = scr[SCR_BODY + i];
   PHASE_RESET();
+
+  // post_step's inputs (lane 0): requested here so that their round trips overlap the height scan
+  float ps_bv[6] = {0, 0, 0, 0, 0, 0}, ps_cmd[3] = {0, 0, 0}, ps_sums[6] = {0, 0, 0, 0, 0, 0};
+  int64_t ps_ep = 0, ps_level = 0, ps_type = 0;
+  int32_t ps_rc = 0;
+  if (l == 0) {
+    // pre-physics base-frame velocities: written to base_vel at the top of the kernel by this lane and read back
+    // here rather than held in six registers across the sub-steps
+    const float* bv = A.base_vel + (size_t)e * 9;
+#pragma unroll
+    for (int k = 0; k < 6; k++) ps_bv[k] = bv[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) ps_cmd[k] = A.command[(size_t)e * 3 + k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) ps_sums[k] = A.rew_sums[(size_t)k * n + e];
+    ps_ep = A.ep_len[e]; ps_level = A.levels[e]; ps_type = A.types[e]; ps_rc = A.reset_count[e];
+  }
 
   // get_heights (isaac_gym.py:412-433)
   {
@@ -576,21 +620,17 @@ DEV void a1_step_body(const A1Args& A) {
 
   // post_step (env.py:93-106): one lane runs the scalar bookkeeping
   unsigned long long* stats_row = nullptr;
-  unsigned long long stats_step = 0ull;
   if (l == 0) {
-    // pre-physics base-frame velocities: written to base_vel at the top of the kernel by this lane and read back
-    // here rather than held in six registers across the sub-steps
-    const float* bv = A.base_vel + (size_t)e * 9;
-    const float blv[3] = {bv[0], bv[1], bv[2]}, bav[3] = {bv[3], bv[4], bv[5]};
+    const float blv[3] = {ps_bv[0], ps_bv[1], ps_bv[2]}, bav[3] = {ps_bv[3], ps_bv[4], ps_bv[5]};
     const float* cf = L.xch;
-    int64_t ep = A.ep_len[e] + 1;
+    int64_t ep = ps_ep + 1;
     const float* fb = cf + 3 * tp.base_body;
     const int contact_term = sqrtf(fb[0] * fb[0] + fb[1] * fb[1] + fb[2] * fb[2]) > 1.0f;
     const int timeout = (float)ep > tp.max_episode_length;
     const int reset = timeout | contact_term;
     A.timeout[e] = (uint8_t)timeout;
     A.reset[e] = (uint8_t)reset;
-    float cmd[3] = {A.command[(size_t)e * 3], A.command[(size_t)e * 3 + 1], A.command[(size_t)e * 3 + 2]};
+    float cmd[3] = {ps_cmd[0], ps_cmd[1], ps_cmd[2]};
     const float* hist = scr + SCR_HIST;
     float rterm[6];
     {
@@ -621,16 +661,16 @@ DEV void a1_step_body(const A1Args& A) {
     float sums[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
-      sums[k] = A.rew_sums[(size_t)k * n + e] + rterm[k];
+      sums[k] = ps_sums[k] + rterm[k];
       rew += rterm[k];
     }
     A.rew[e] = rew;
     float done[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int64_t level = A.levels[e];
+    int64_t level = ps_level;
     if (reset) {
       ResetOut R;
-      a1_reset_draw(tp, A.env_off + e, (uint32_t)A.reset_count[e], L.root, cmd, A.origins + (size_t)e * 3, level,
-                    A.types[e], A.torigins, R);
+      a1_reset_draw(tp, A.env_off + e, (uint32_t)ps_rc, L.root, cmd, A.origins + (size_t)e * 3, level,
+                    ps_type, A.torigins, R);
       level = R.level;
       A.levels[e] = level;
 #pragma unroll
@@ -647,7 +687,7 @@ DEV void a1_step_body(const A1Args& A) {
       for (int k = 0; k < nd * H; k++) scr[SCR_HIST + k] = 0.0f;
 #pragma unroll
       for (int k = 0; k < 3; k++) { cmd[k] = R.cmd[k]; A.command[(size_t)e * 3 + k] = cmd[k]; }
-      A.reset_count[e] += 1;
+      A.reset_count[e] = ps_rc + 1;
     }
     done[6] = (float)level;
 #pragma unroll
@@ -662,7 +702,7 @@ DEV void a1_step_body(const A1Args& A) {
       for (int k = 0; k < 6; k++) sv[k] = stats_fix(done[k]);
       sv[6] = (long long)level; sv[7] = reset ? 1ll : 0ll;
       const int first = (int)blockIdx.x * epb, eib = n - first < epb ? n - first : epb;
-      stats_row = stats_contribute<8>(A.stats, stats_lds, sv, eib, &stats_step);
+      stats_row = stats_contribute<8>(A.stats, stats_lds, sv, eib, stats_step);
     }
     const float co = tp.clip_obs;
     float* o = scr + SCR_OBS;
@@ -693,6 +733,9 @@ DEV void a1_step_body(const A1Args& A) {
       o[12 + 2 * nd + nd * H + i] = rclampf(rclampf(bz - 0.5f - scr[SCR_MH + i], -1.0f, 1.0f), -co, co);
   }
   GROUP_SYNC();
+  // the block's statistics additions were issued in post_step; by now they have been acknowledged
+  unsigned long long stats_tk = 0ull;
+  if (l == 0) stats_tk = stats_ticket(stats_row);
   for (int i = l; i < nobs; i += G) A.obs[(size_t)e * nobs + i] = scr[SCR_OBS + i];
   // HistoryRecorder.add (train.py:12-14), after the observation was taken (Q12)
   for (int i = l; i < nd * H; i += G) {
@@ -702,9 +745,8 @@ DEV void a1_step_body(const A1Args& A) {
   for (int i = l; i < 2 * nd; i += G) dof[i] = L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)];
   if (l < 13) root[l] = L.root[l];
   if (l == 0) {
-    // the block's statistics additions were issued in post_step; by now they have been acknowledged
     const float Ts = tp.max_episode_length_s;
-    stats_finish<8>(A.stats, stats_row, stats_step, [n, Ts](const long long* t, float* o) {
+    stats_finish<8>(A.stats, stats_row, stats_tk, stats_step, [n, Ts](const long long* t, float* o) {
       const float c = (float)t[7];
 #pragma unroll
       for (int k = 0; k < 6; k++) {
@@ -801,6 +843,7 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* stats_lds = smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS;
   stats_block_init(stats_lds);
+  const unsigned long long stats_step = stats_step_load(A.stats);
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(A.tp);
     uint32_t* dst = reinterpret_cast<uint32_t*>(smem + MODEL_WORDS + SCENE_WORDS);
@@ -891,7 +934,6 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
 
   // post_step on one lane (env.py:93-106, a_prior_stage.py:97-135)
   unsigned long long* stats_row = nullptr;
-  unsigned long long stats_step = 0ull;
   if (l == 0) {
     int64_t ep = A.ep_len[e] + 1;
     const float* cube = L.root + 13 * tp.cube_actor;
@@ -929,7 +971,7 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
       // extras["episode"] (env.py:149-158 + episode_log, a_prior_stage.py:94-95)
       const long long sv[4] = {stats_fix(done[0]), stats_fix(done[1]), (reset && success) ? 1ll : 0ll, reset ? 1ll : 0ll};
       const int first = (int)blockIdx.x * epb, eib = n - first < epb ? n - first : epb;
-      stats_row = stats_contribute<4>(A.stats, stats_lds, sv, eib, &stats_step);
+      stats_row = stats_contribute<4>(A.stats, stats_lds, sv, eib, stats_step);
     }
     const float co = tp.clip_obs;
     float* o = A.obs + (size_t)e * 6;
@@ -938,11 +980,13 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
     o[4] = rclampf(eex, -co, co); o[5] = rclampf(eey, -co, co);
   }
   GROUP_SYNC();
+  unsigned long long stats_tk = 0ull;
+  if (l == 0) stats_tk = stats_ticket(stats_row);
   for (int i = l; i < 2 * nd; i += G) dof[i] = L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)];
   for (int i = l; i < 13 * actors; i += G) root[i] = L.root[i];
   if (l == 0) {
     const float Ts = tp.max_episode_length_s;
-    stats_finish<4>(A.stats, stats_row, stats_step, [n, Ts](const long long* t, float* o) {
+    stats_finish<4>(A.stats, stats_row, stats_tk, stats_step, [n, Ts](const long long* t, float* o) {
       const float c = (float)t[3];
       const float s0 = (float)t[0] * (1.0f / STATS_FIX), s1 = (float)t[1] * (1.0f / STATS_FIX);
       o[0] = s0; o[1] = s1; o[2] = (float)t[2]; o[3] = c;

@@ -28,7 +28,7 @@ struct FixedScene {
     return true;
   }
 };
-typedef FixedScene<3, 1, 8> AbbScene;   // table (fixed), cube (free), goal pad (fixed); eight rod spheres (abb_task.py)
+typedef FixedScene<3, 1, 1> AbbScene;   // table (fixed), cube (free), goal pad (fixed); the rod capsule (abb_task.py)
 // per-lane constants of the fixed-scene path: which of the arm's spheres sit on this lane's body / moving body
 struct BoxLane { unsigned sph_body = 0u, sph_dyn = 0u; };
 DEV BoxLane box_lane_load(const ShfModel* m, int l) {
@@ -171,6 +171,94 @@ DEV void sphere_vs_box(const float* bR, const float* bpos, const float* h, const
   for (int i = 0; i < 3; i++) rc[i] += bpos[i];
 }
 
+
+// Capsule against an oriented box: the parameter t in [0,1] of the point c0 + t s of the capsule's segment closest to the
+// box (oracle: segment_box_param).  g(t) = sum_i d_i (p_i - clamp(p_i, -h_i, h_i)) -- half the derivative of the squared
+// distance, non-decreasing and piecewise linear -- is sampled at the two ends and at the kinks inside (0,1) where a
+// coordinate crosses a face plane; the root is interpolated between the last negative and the first positive sample, and
+// a stretch of exact zeros gives its midpoint.  Sample order: ends, axes 0..2, face -h before +h.
+// sample k of g (k = 0, 1: the ends; 2 + 2 i + f: the kink of axis i at face -h (f = 0) / +h (f = 1)); false: not in (0,1)
+DEV bool seg_box_sample(int k, const float* a, const float* d, const float* h, float* t_out, float* g_out) {
+  float t;
+  bool use = true;
+  if (k == 0) t = 0.0f;
+  else if (k == 1) t = 1.0f;
+  else {
+    const int i = (k - 2) >> 1;
+    const float ai = i == 0 ? a[0] : (i == 1 ? a[1] : a[2]), di = i == 0 ? d[0] : (i == 1 ? d[1] : d[2]);
+    const float hi = i == 0 ? h[0] : (i == 1 ? h[1] : h[2]);
+    t = (((k & 1) ? hi : -hi) - ai) * (1.0f / di);      // +-inf / nan when parallel to the faces: fails the (0,1) test
+    use = t > 0.0f && t < 1.0f;
+  }
+  float g = 0.0f;
+  if (use) {                                            // (one lane per capsule: an unused kink is really skipped)
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const float p = fmaf(t, d[i], a[i]);
+      g = fmaf(d[i], p - rclampf(p, -h[i], h[i]), g);
+    }
+  }
+  *t_out = t; *g_out = g;
+  return use;
+}
+struct SegBoxRoot {
+  float tl = 0.0f, gl = 0.0f, th = 1.0f, gh = 0.0f, zl = 2.0f, zh = -1.0f;
+  bool hasl = false, hash = false;
+  DEV void push(float t, float g, bool use) {       // samples arrive in the order k = 0..7
+    if (!use) return;
+    if (g < 0.0f) { if (!hasl || t > tl) { tl = t; gl = g; hasl = true; } }
+    else if (g > 0.0f) { if (!hash || t < th) { th = t; gh = g; hash = true; } }
+    else { zl = rminf(zl, t); zh = rmaxf(zh, t); }
+  }
+  DEV float root() const {
+    if (zh >= zl) return 0.5f * (zl + zh);
+    if (!hasl) return 0.0f;
+    if (!hash) return 1.0f;
+    return fmaf(th - tl, gl / (gl - gh), tl);
+  }
+};
+DEV void seg_box_frame(const float* bR, const float* bpos, const float* c0, const float* s, float* a, float* d) {
+  const float rel[3] = {c0[0] - bpos[0], c0[1] - bpos[1], c0[2] - bpos[2]};
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    a[i] = fmaf(bR[6 + i], rel[2], fmaf(bR[3 + i], rel[1], bR[i] * rel[0]));
+    d[i] = fmaf(bR[6 + i], s[2], fmaf(bR[3 + i], s[1], bR[i] * s[0]));
+  }
+}
+DEV float segment_box_param(const float* bR, const float* bpos, const float* h, const float* c0, const float* s) {
+  float a[3], d[3];
+  seg_box_frame(bR, bpos, c0, s, a, d);
+  SegBoxRoot Q;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    float t, g;
+    const bool use = seg_box_sample(k, a, d, h, &t, &g);
+    Q.push(t, g, use);
+  }
+  return Q.root();
+}
+// world-frame centre of rounded shape si against box (Rk, bpos, hh): the sphere's centre, or the capsule's closest point.
+// false: the shape's bounding sphere is further than the contact offset (+ 1 cm for the rounding of this test) from the
+// box's bounding sphere -- the slot is off and nothing else is computed (oracle: rounded_far).
+DEV bool rounded_centre(const ShfModel* m, int si, const float* Rb, const float* pbody, const float* Rk, const float* bpos,
+                        const float* hh, float offset, float* c) {
+  const float lp[3] = {m->sph_pos[si][0], m->sph_pos[si][1], m->sph_pos[si][2]};
+  const float ls[3] = {m->sph_seg[si][0], m->sph_seg[si][1], m->sph_seg[si][2]};
+  float sw[3];
+  mv3(Rb, lp, c);
+#pragma unroll
+  for (int i = 0; i < 3; i++) c[i] += pbody[i];
+  mv3(Rb, ls, sw);
+  const float rel[3] = {fmaf(0.5f, sw[0], c[0]) - bpos[0], fmaf(0.5f, sw[1], c[1]) - bpos[1], fmaf(0.5f, sw[2], c[2]) - bpos[2]};
+  const float reach = 0.5f * sqrtf(dot3(sw, sw)) + sqrtf(dot3(hh, hh)) + m->sph_radius[si] + offset + 0.01f;
+  if (dot3(rel, rel) > reach * reach) return false;
+  if (ls[0] != 0.0f || ls[1] != 0.0f || ls[2] != 0.0f) {
+    const float t = segment_box_param(Rk, bpos, hh, c, sw);
+#pragma unroll
+    for (int i = 0; i < 3; i++) c[i] = fmaf(t, sw[i], c[i]);
+  }
+  return true;
+}
 
 // ------------------------------------------------------------ self-collision --
 // Capsule pairs of the articulation itself (ShfModel.self_collide; reference units.py:68, collision filter 0).
@@ -449,26 +537,27 @@ DEV void boxes_contacts_fixed(const StepCtx& C, const EnvLds& L, int l, BodyRegs
     if (valid) {
       const int b = m->sph_body[si];
       const float* pb = L.pose + b * POSE_STRIDE;
-      float Rb[9], Rk[9], lp[3] = {m->sph_pos[si][0], m->sph_pos[si][1], m->sph_pos[si][2]}, c[3];
+      float Rb[9], Rk[9], c[3];
 #pragma unroll
       for (int i = 0; i < 9; i++) { Rb[i] = pb[i]; Rk[i] = pk[i]; }
-      mv3(Rb, lp, c);
-#pragma unroll
-      for (int i = 0; i < 3; i++) c[i] += pb[9 + i];
       const float hh[3] = {0.5f * bd.dim[0], 0.5f * bd.dim[1], 0.5f * bd.dim[2]}, bpos[3] = {pk[9], pk[10], pk[11]};
-      float phi, n[3], rc[3], ta[3], tb[3], vrel[3], vrs[3];
-      sphere_vs_box(Rk, bpos, hh, c, m->sph_radius[si], &phi, n, rc);
-      const float va[3] = {pb[12], pb[13], pb[14]}, vbx[3] = {pk[12], pk[13], pk[14]};
-      cross3(va, rc, ta);
-      cross3(vbx, rc, tb);
+      if (rounded_centre(m, si, Rb, pb + 9, Rk, bpos, hh, offset, c)) {
+        float phi, n[3], rc[3], ta[3], tb[3], vrel[3], vrs[3];
+        sphere_vs_box(Rk, bpos, hh, c, m->sph_radius[si], &phi, n, rc);
+        const float va[3] = {pb[12], pb[13], pb[14]}, vbx[3] = {pk[12], pk[13], pk[14]};
+        cross3(va, rc, ta);
+        cross3(vbx, rc, tb);
 #pragma unroll
-      for (int i = 0; i < 3; i++) {
-        const float pa = pb[15 + i] + ta[i], pq = pk[15 + i] + tb[i];
-        vrs[i] = pa - pq;
-        vrel[i] = fmaf(dt, g_art[i], pa) - fmaf(dt, gb[i], pq);
+        for (int i = 0; i < 3; i++) {
+          const float pa = pb[15 + i] + ta[i], pq = pk[15 + i] + tb[i];
+          vrs[i] = pa - pq;
+          vrel[i] = fmaf(dt, g_art[i], pa) - fmaf(dt, gb[i], pq);
+        }
+        slot_eval(o, phi, n, rc, vrs, vrel, 0.5f * (mu_shape + bd.friction), kc, beta, veps, vdep, dt, offset);
+        on = o[PT_ON] != 0.0f;
+      } else {
+        o[PT_ON] = 0.0f;
       }
-      slot_eval(o, phi, n, rc, vrs, vrel, 0.5f * (mu_shape + bd.friction), kc, beta, veps, vdep, dt, offset);
-      on = o[PT_ON] != 0.0f;
     }
     BM.spheres = (unsigned)((__ballot(on) >> lane0) & gmask);
   }
@@ -560,13 +649,11 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
     const int b = m->sph_body[si];
     const float* pb = L.pose + b * POSE_STRIDE;
     const float* pk = L.pose + (nb + kd) * POSE_STRIDE;
-    float Rb[9], Rk[9], lp[3] = {m->sph_pos[si][0], m->sph_pos[si][1], m->sph_pos[si][2]}, c[3];
+    float Rb[9], Rk[9], c[3];
 #pragma unroll
     for (int i = 0; i < 9; i++) { Rb[i] = pb[i]; Rk[i] = pk[i]; }
-    mv3(Rb, lp, c);
-#pragma unroll
-    for (int i = 0; i < 3; i++) c[i] += pb[9 + i];
     const float hh[3] = {0.5f * bd.dim[0], 0.5f * bd.dim[1], 0.5f * bd.dim[2]}, bpos[3] = {pk[9], pk[10], pk[11]};
+    if (!rounded_centre(m, si, Rb, pb + 9, Rk, bpos, hh, offset, c)) continue;
     float phi, n[3], rc[3], ta[3], tb[3], vrel[3], vrs[3];
     sphere_vs_box(Rk, bpos, hh, c, m->sph_radius[si], &phi, n, rc);
     const float va[3] = {pb[12], pb[13], pb[14]}, vbx[3] = {pk[12], pk[13], pk[14]};

@@ -291,8 +291,8 @@ class Gym:
         # mesh colliders are not supported: known assets get their documented substitutes
         extra = ()
         if os.path.basename(path) in ("abb_rod.urdf", "abb_rod_isaac.urdf"):
-            from ..abb_task import ROD_SPHERES
-            extra = ROD_SPHERES
+            from ..abb_task import ROD_CAPSULE
+            extra = ROD_CAPSULE
         model = compile_urdf(path, extra_spheres=extra, fix_base_link=bool(options.fix_base_link),
                              disable_gravity=bool(options.disable_gravity),
                              collapse_fixed_joints=bool(options.collapse_fixed_joints),

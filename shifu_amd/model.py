@@ -299,12 +299,12 @@ def _shape_capsules(shape: _Shape) -> List[Tuple[np.ndarray, np.ndarray, float]]
 def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: bool = False,
                  collapse_fixed_joints: bool = True, default_dof_drive_mode: int = _abi.DOF_MODE_NONE,
                  armature: float = 0.0, honour_dont_collapse: bool = True,
-                 extra_spheres: Sequence[Tuple[str, Sequence[float], float]] = (), density: float = 1000.0,
+                 extra_spheres: Sequence[tuple] = (), density: float = 1000.0,
                  self_collision: bool = False) -> CompiledModel:
     """Compile `path` with the AssetOptions the reference passes (asset_config.py:32-46).
 
-    extra_spheres: (link name, xyz in that link's frame, radius) collision spheres
-    tested against box actors -- the substitute for mesh colliders (ABB rod)."""
+    extra_spheres: rounded collision shapes tested against box actors -- the substitute for mesh colliders (ABB rod):
+    (link name, xyz in that link's frame, radius) spheres, or (link name, xyz_a, xyz_b, radius) capsules."""
     links, joints = parse_urdf(path)
     _fill_missing_inertials(links, density)
     children: Dict[str, List[_Joint]] = {n: [] for n in links}
@@ -472,13 +472,16 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
 
     assert len(extra_spheres) <= _abi.MAX_SPHERES
     m.nsph = len(extra_spheres)
-    for i, (lname, xyz, rad) in enumerate(extra_spheres):
+    for i, rec in enumerate(extra_spheres):
+        lname, xyz, rad = rec[0], rec[1], rec[-1]
         body, p, R = link_frame[lname]
         q = p + R @ np.asarray(xyz, dtype=float)
+        seg = R @ (np.asarray(rec[2], dtype=float) - np.asarray(xyz, dtype=float)) if len(rec) == 4 else np.zeros(3)
         m.sph_body[i] = body
         m.sph_radius[i] = rad
         for kk in range(3):
             m.sph_pos[i][kk] = q[kk]
+            m.sph_seg[i][kk] = seg[kk]
 
     # self-collision: capsules of every shape, and the pairs to test -- all but capsules of one rigid body (same moving
     # body: welded links included) and of moving bodies joined by a joint ([EXT] PhysX filters those the same way)

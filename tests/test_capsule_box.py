@@ -1,0 +1,70 @@
+"""Capsule-vs-box geometry (capsules as a native shape, asset_config.py:32-46 replace_cylinder_with_capsule;
+the ABB rod, abb_task.ROD_CAPSULE): the oracle's closed-form closest-point parameter against dense sampling."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as O
+
+
+def _rand_rot(rng, n):
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    x, y, z, w = q.T
+    return np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                     2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                     2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], axis=1)
+
+
+def _dist(bR, bpos, h, pts):
+    """distance of world points (n,m,3) to the boxes (n)"""
+    R = bR.reshape(-1, 3, 3)
+    loc = np.einsum("nji,nmj->nmi", R, pts - bpos[:, None, :])            # R^T (p - bpos)
+    e = loc - np.clip(loc, -h[:, None, :], h[:, None, :])
+    return np.linalg.norm(e, axis=2)
+
+
+def _cases(rng, n):
+    bR = _rand_rot(rng, n)
+    bpos = rng.uniform(-0.3, 0.3, (n, 3))
+    h = rng.uniform(0.02, 0.2, (n, 3))
+    c0 = bpos + rng.uniform(-0.5, 0.5, (n, 3))
+    s = rng.uniform(-0.6, 0.6, (n, 3))
+    return bR, bpos, h, c0, s
+
+
+def test_closest_point_parameter_matches_dense_sampling():
+    rng = np.random.default_rng(0)
+    n = 4000
+    bR, bpos, h, c0, s = _cases(rng, n)
+    t = O.segment_box_param(bR, bpos, h, c0, s, f64=True)
+    assert ((t >= 0) & (t <= 1)).all()
+    ts = np.linspace(0, 1, 4001)
+    pts = c0[:, None, :] + ts[None, :, None] * s[:, None, :]
+    dmin = _dist(bR, bpos, h, pts).min(1)
+    dstar = _dist(bR, bpos, h, (c0 + t[:, None] * s)[:, None, :])[:, 0]
+    assert (dstar <= dmin + 1e-12).all(), float((dstar - dmin).max())      # never worse than the best sample
+    assert (dmin - dstar).max() < 2e-4                                      # and the samples come that close (sanity of the checker)
+    assert (dmin == 0).sum() > 100 and (t == 0).sum() > 100 and (t == 1).sum() > 100 and ((t > 0) & (t < 1)).sum() > 1000
+
+
+def test_axis_aligned_and_degenerate_segments():
+    """parallel to a face (a stretch of exact zeros of g gives its midpoint), through the box, zero length"""
+    I = np.eye(3).reshape(1, 9)
+    z3 = np.zeros((1, 3)); h = np.array([[0.1, 0.1, 0.1]])
+    par = O.segment_box_param(I, z3, h, np.array([[-0.05, 0.0, 0.3]]), np.array([[0.1, 0.0, 0.0]]))     # above the top face, inside its footprint
+    assert par[0] == 0.5
+    long = O.segment_box_param(I, z3, h, np.array([[-0.5, 0.0, 0.3]]), np.array([[1.0, 0.0, 0.0]]))     # overhanging both sides: middle of the face stretch
+    assert abs(long[0] - 0.5) < 1e-12
+    thru = O.segment_box_param(I, z3, h, np.array([[-0.5, 0.01, 0.02]]), np.array([[1.0, 0.0, 0.0]]))   # through the box
+    assert 0.4 <= thru[0] <= 0.6
+    pt = O.segment_box_param(I, z3, h, np.array([[0.3, 0.2, 0.1]]), np.zeros((1, 3)))                  # a sphere
+    assert 0.0 <= pt[0] <= 1.0
+
+
+def test_float_build_tracks_the_double_build():
+    rng = np.random.default_rng(1)
+    bR, bpos, h, c0, s = _cases(rng, 2000)
+    t64 = O.segment_box_param(bR, bpos, h, c0, s, f64=True)
+    t32 = O.segment_box_param(bR, bpos, h, c0, s, f64=False)
+    d64 = _dist(bR, bpos, h, (c0 + t64[:, None] * s)[:, None, :])[:, 0]
+    d32 = _dist(bR, bpos, h, (c0 + t32[:, None].astype(np.float64) * s)[:, None, :])[:, 0]
+    assert np.abs(d32 - d64).max() < 2e-6                    # the distance is what enters the contact law; t itself is ill-conditioned when parallel
