@@ -34,6 +34,7 @@ B_ALG = {"terrain": 5539, "flat": 5019, "trimesh": 5539, "abb": 2140}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s achievable)
 VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector (non-matrix) peak
 NUM_CUS, SIMDS_PER_CU = 256, 4
+MAX_CLOCK_HZ = 2.4e9       # MI355X_MICROARCH.md: max clock
 WL_NAME = {"terrain": "a1_conditional procedural heightfield 1300x2100 (config 3)",
            "flat": "a1_conditional all-zero heightfield (config 2)",
            "trimesh": "a1_conditional procedural terrain 1300x2100 as trimesh with vertical risers (the reference's effective A1 terrain)",
@@ -365,6 +366,17 @@ def main():
         if prof:
             secondary.update({"valu_issue_frac": prof.get("valu_issue_frac"), "wait_frac": prof.get("wait_frac"),
                               "counter_source": prof.get("source")})
+            if prof.get("valu_insts_per_launch"):
+                # the roofline that actually binds these kernels: VALU issue slots.  One wave64 VALU instruction holds its
+                # SIMD's vector pipe for 4 clocks, whatever the number of active lanes; peak = SIMDs x clock / 4.
+                # Instruction count: SQ_INSTS_VALU of the committed PMC pass (replayed); duration: measured in this run.
+                issue_peak = NUM_CUS * SIMDS_PER_CU * MAX_CLOCK_HZ / 4.0
+                issued = prof["valu_insts_per_launch"] / (kern_ms * 1e-3)
+                secondary["valu_issue"] = {"wave_instructions_per_launch": prof["valu_insts_per_launch"],
+                                           "achieved": issued, "peak": issue_peak, "unit": "wave-instructions/s",
+                                           "frac": issued / issue_peak,
+                                           "note": "SQ_INSTS_VALU x 4 clocks / (1024 SIMDs x kernel time at 2.4 GHz); "
+                                                   "valu_issue_frac is the same ratio per wave over its lifetime"}
         out = {
             "metric": ("env-steps/sec (whole node), ABB push-box 6-dof arm + free cube, 4096 envs/GPU" if abb else
                        "env-steps/sec (whole node), A1 12-dof 4096 envs/GPU"), "value": value, "unit": "env-steps/s",
