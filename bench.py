@@ -252,7 +252,10 @@ def main():
     local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # SHIFU_AMD_FORCE_DIST=1 (testing only): take the N>1 code path -- process group, barriers, the all-gather of episode
+    # statistics, the MAX all-reduce of the elapsed time -- with a single rank, e.g. to exercise RCCL on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("SHIFU_AMD_FORCE_DIST", "0") == "1"
+    if use_dist:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -314,19 +317,19 @@ def main():
             slot = env.task.advance_slot()
         else:
             slot = eager_step()
-        if world > 1 and (i + 1) % args.log_interval == 0:
+        if use_dist and (i + 1) % args.log_interval == 0:
             gather_episode_stats(env.task.tensors[stats_t][slot][:env.task.num_sums])
         return slot
 
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         vec_step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -339,7 +342,7 @@ def main():
     kern_ms = sum(a.elapsed_time(b) for a, b in events) / args.steps
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     finite = bool(torch.isfinite(env.obs_buf).all().item())
@@ -409,7 +412,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

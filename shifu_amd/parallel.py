@@ -54,9 +54,18 @@ def rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def collectives_on() -> bool:
+    """True when the data-parallel collectives run: more than one rank -- or one rank with SHIFU_AMD_FORCE_DIST=1
+    (testing only: walks the RCCL code path on a single-GPU box)."""
+    import os
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("SHIFU_AMD_FORCE_DIST", "0") == "1"
+
+
 def average_(t: torch.Tensor) -> torch.Tensor:
     """In-place mean over ranks (identity in a single process)."""
-    if world_size() > 1:
+    if collectives_on():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         t /= world_size()
     return t
@@ -67,7 +76,7 @@ def average_gradients(params, bucket_bytes: int = 64 << 20) -> None:
     0.6 M parameters (2.5 MB): one all-reduce per mini-batch -- on xGMI's per-link-bound ring a single large
     message beats one per layer."""
     grads = [p.grad for p in params if p.grad is not None]
-    if not grads or world_size() == 1:
+    if not grads or not collectives_on():
         return
     bucket, size = [], 0
     def flush():
@@ -91,7 +100,7 @@ def average_gradients(params, bucket_bytes: int = 64 << 20) -> None:
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
     """Same initial weights on every rank."""
-    if world_size() == 1:
+    if not collectives_on():
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src)

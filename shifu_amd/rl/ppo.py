@@ -3,7 +3,7 @@ import torch
 import torch.nn as nn
 import torch.optim as optim
 
-from ..parallel import average_, average_gradients, world_size
+from ..parallel import average_, average_gradients, world_size, collectives_on
 from .storage import RolloutStorage
 
 
@@ -131,7 +131,7 @@ class PPO:
             # the KL is averaged over ranks first so that every rank takes the same decision
             self.adapt_learning_rate(average_(L["kl"].detach().clone()))
         L["loss"].backward()
-        if world_size() > 1:
+        if collectives_on():
             average_gradients(ac.parameters())
         nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
         self.optimizer.step()

@@ -35,7 +35,7 @@ def main():
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or os.environ.get("SHIFU_AMD_FORCE_DIST", "0") == "1":    # FORCE_DIST: one-rank RCCL walk-through (testing)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -72,9 +72,9 @@ def main():
     flat = torch.cat([p.detach().reshape(-1).double() for p in runner.alg.actor_critic.parameters()])
     checksum = torch.stack([flat.sum(), flat.abs().sum(), (flat * torch.arange(flat.numel(), device=flat.device) % 7).sum()])
     in_sync = True
-    if world > 1:
+    if dist.is_initialized():
         mine = checksum if backend == "nccl" else checksum.cpu()
-        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        gathered = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
         dist.all_gather(gathered, mine)
         in_sync = all(torch.equal(g, gathered[0]) for g in gathered)
     if rank == 0:
@@ -89,7 +89,7 @@ def main():
                           "track_lin": H[i].get("episode/tracking_lin_vel"), "levels": H[i].get("episode/terrain_levels"),
                           "std": H[i]["mean_noise_std"]} for i in pick]}
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
