@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <string>
 
 #include "../../include/shifu_amd.h"
@@ -24,14 +25,37 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 8;   // LDS row = 40 bf16 = 80 B: 16-byte aligned fragments, staggered banks
-constexpr int WGRAD_ROWS = 512;                           // rows of the batch per weight-gradient slice (split over M)
+#ifdef SHF_MLP_PROBE_CLOCK
+__device__ long long g_mlp_probe[4 * 8192];   // per block: start, loop end, epilogue end, (unused)
+#define MLP_CLOCK(slot) do { const unsigned lb = blockIdx.x + gridDim.x * blockIdx.y; if (threadIdx.x == 0 && blockIdx.z == 0 && lb < 8192) g_mlp_probe[4 * lb + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define MLP_CLOCK(slot)
+#endif
+
+#ifndef SHF_MLP_PREFETCH_DEPTH
+#define SHF_MLP_PREFETCH_DEPTH 1
+#endif
+constexpr int PF = SHF_MLP_PREFETCH_DEPTH;   // operand tiles kept in flight in registers (1: measured faster than 2 -- the
+                                             // registers of a second tile cost a resident block per CU, profiles/r02_mlp_probe.md)
+constexpr int BN = 128, BK = 32, LDT = BK + 8;   // LDS row = 40 bf16 = 80 B: 16-byte aligned fragments, staggered banks
+// rows of the batch per weight-gradient slice (split over M): 512, less for the small layers whose few output tiles would
+// otherwise leave most CUs without a block
+int wgrad_rows(int M, int K, int N) {
+  const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128);
+  int per = 512;
+  while (per > 128 && tiles * ((M + per - 1) / per) < 384) per >>= 1;
+  return per;
+}
 
 MLP_DEV uint16_t to_bf16(float x) {
   uint32_t u = __float_as_uint(x);
   u += 0x7FFFu + ((u >> 16) & 1u);   // round to nearest even (inputs are finite)
   return (uint16_t)(u >> 16);
 }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + barrier, and the fence
+// drains every outstanding *global* load as well (s_waitcnt vmcnt(0)) -- which would serialise the K loop on HBM latency
+// and defeat the register prefetch of the next tiles.  Here only the LDS counter is waited on.
+MLP_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 MLP_DEV float elu_grad_from_output(float y) { return y > 0.0f ? 1.0f : y + 1.0f; }
 
 // How the A ([rows x red]) and B ([cols x red]) operands of  C[rows, cols] = sum_red A[row, red] B[col, red]  sit in
@@ -43,100 +67,104 @@ struct Operand {
   int rows;              // extent along the output index
 };
 
-// One thread's share (16 elements) of a [128 x 32] operand tile, fetched from global memory into registers (fp32, with
-// the optional ELU' mask applied), and later written to LDS as bf16 with the reduction index contiguous.  Fetch and
-// commit are separate so that the next tile's loads are in flight while the MFMAs of the current one run.
-//   RED_CONTIG : thread t -> row t / 2, 16 consecutive k (k half t % 2): four 16-byte loads, two 16-byte LDS stores
-//   otherwise  : thread t -> 4 output rows (t % 32) * 4 .. + 3 x 4 k rows (t / 32) * 4 .. + 3: four 16-byte loads
-//                along the output index (coalesced over t % 32), transposed in registers, four 8-byte LDS stores
-// VEC = the operand's rows are 16-byte aligned (ld % 4 == 0, base aligned): else element-wise loads with the same mapping.
+// One thread's share (16 elements) of a [128 x 32] operand tile: fetch_tile only *issues* the global loads (raw fp32
+// words, plus the raw words of the optional ELU' mask operand) -- no arithmetic on the loaded values and no branches, so no
+// s_waitcnt lands between the loads and they stay in flight under the MFMAs of the tiles before; out-of-range elements
+// are read from a clamped (valid) address and zeroed later.  commit_tile applies range mask and ELU' mask, converts to
+// bf16 and writes LDS with the reduction index contiguous.  Element j of thread t sits at (row, k) of the tile:
+//   RED_CONTIG, VEC  : row = t / 8 + 32 (j / 4), k = 4 (t % 8) + j % 4   -- eight lanes read one whole 128-byte row
+//                      segment with 16-byte loads; four 8-byte LDS stores
+//   RED_CONTIG, !VEC : row = t / 32 + 8 j,       k = t % 32             -- 32 lanes read one row segment word by word
+//                      (rows not 16-byte aligned: the 259-wide observation); sixteen 2-byte LDS stores
+//   !RED_CONTIG      : row = 4 (t % 32) + j % 4, k = 4 (t / 32) + j / 4  -- loads run along the output index
+//                      (coalesced over t % 32), transposed in registers; four 8-byte LDS stores
+// VEC = 16-byte chunks are whole (ld % 4 == 0, extents % 4 == 0, base aligned).
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
-struct TileRegs { float v[16]; };
+template <bool MASK, int NE>   // NE elements per thread: 16 for a 128-row tile, 8 for a 64-row tile
+struct TileRegs {
+  float x[NE];
+  float m[MASK ? NE : 1];
+  uint32_t ok;            // bit j: element j is inside the operand
+};
 
 template <bool RED_CONTIG, bool VEC>
-MLP_DEV void fetch_tile(const Operand& O, int r0, int k0, int red, TileRegs& T) {
-  const int t = (int)threadIdx.x;
-  if (RED_CONTIG) {
-    const int gr = r0 + (t >> 1), gk0 = k0 + (t & 1) * 16;
-    const bool rok = gr < O.rows;
-    const size_t base = (size_t)gr * O.ld + gk0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int gk = gk0 + 4 * q;
-      if (VEC && rok && gk + 3 < red) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(O.p + base + 4 * q);
-        f32x4 y = {1.0f, 1.0f, 1.0f, 1.0f};
-        if (O.mask_y) {
-          const f32x4 m = *reinterpret_cast<const f32x4*>(O.mask_y + base + 4 * q);
-#pragma unroll
-          for (int c = 0; c < 4; c++) y[c] = elu_grad_from_output(m[c]);
-        }
-#pragma unroll
-        for (int c = 0; c < 4; c++) T.v[4 * q + c] = x[c] * y[c];
-      } else {
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          float v = 0.0f;
-          if (rok && gk + c < red) {
-            v = O.p[base + 4 * q + c];
-            if (O.mask_y) v *= elu_grad_from_output(O.mask_y[base + 4 * q + c]);
-          }
-          T.v[4 * q + c] = v;
-        }
-      }
-    }
-  } else {
-    const int gr0 = r0 + (t & 31) * 4, gk0 = k0 + (t >> 5) * 4;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {          // q: k row
-      const int gk = gk0 + q;
-      const size_t base = (size_t)gk * O.ld + gr0;
-      if (VEC && gk < red && gr0 + 3 < O.rows) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(O.p + base);
-        f32x4 y = {1.0f, 1.0f, 1.0f, 1.0f};
-        if (O.mask_y) {
-          const f32x4 m = *reinterpret_cast<const f32x4*>(O.mask_y + base);
-#pragma unroll
-          for (int c = 0; c < 4; c++) y[c] = elu_grad_from_output(m[c]);
-        }
-#pragma unroll
-        for (int c = 0; c < 4; c++) T.v[4 * c + q] = x[c] * y[c];      // transposed: v[row c][k q]
-      } else {
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          float v = 0.0f;
-          if (gk < red && gr0 + c < O.rows) {
-            v = O.p[base + c];
-            if (O.mask_y) v *= elu_grad_from_output(O.mask_y[base + c]);
-          }
-          T.v[4 * c + q] = v;
-        }
-      }
-    }
-  }
+MLP_DEV void tile_elem(int t, int j, int* row, int* k) {
+  if (RED_CONTIG && VEC) { *row = (t >> 3) + 32 * (j >> 2); *k = 4 * (t & 7) + (j & 3); }
+  else if (RED_CONTIG) { *row = (t >> 5) + 8 * j; *k = t & 31; }
+  else { *row = 4 * (t & 31) + (j & 3); *k = 4 * (t >> 5) + (j >> 2); }
 }
 
-template <bool RED_CONTIG>
-MLP_DEV void commit_tile(const TileRegs& T, uint16_t* lds) {
+template <bool RED_CONTIG, bool VEC, bool MASK, int NE>
+MLP_DEV void fetch_tile(const Operand& O, int r0, int k0, int red, TileRegs<MASK, NE>& T) {
+  static_assert(NE == 16 || RED_CONTIG, "64-row tiles only for operands with the reduction index contiguous");
   const int t = (int)threadIdx.x;
-  if (RED_CONTIG) {
-    uint16_t* dst = lds + (t >> 1) * LDT + (t & 1) * 16;
+  uint32_t ok = 0u;
+  uint32_t off[NE];        // element offsets fit 32 bits (the host refuses operands of 2^32 elements or more)
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      bf16x8 o;
+  for (int j = 0; j < NE; j++) {
+    int row, k;
+    tile_elem<RED_CONTIG, VEC>(t, j, &row, &k);
+    const bool in = r0 + row < O.rows && k0 + k < red;
+    ok |= (in ? 1u : 0u) << j;
+    const uint32_t o = RED_CONTIG ? (uint32_t)(r0 + row) * (uint32_t)O.ld + (uint32_t)(k0 + k)
+                                  : (uint32_t)(k0 + k) * (uint32_t)O.ld + (uint32_t)(r0 + row);
+    off[j] = in ? o : 0u;
+  }
+  if (VEC) {
 #pragma unroll
-      for (int c = 0; c < 8; c++) o[c] = (__bf16)T.v[8 * h + c];
-      *reinterpret_cast<bf16x8*>(dst + 8 * h) = o;
+    for (int q = 0; q < NE / 4; q++) {                  // elements 4 q .. 4 q + 3 are contiguous: whole chunk in or out
+      const f32x4 v = *reinterpret_cast<const f32x4*>(O.p + off[4 * q]);
+#pragma unroll
+      for (int c = 0; c < 4; c++) T.x[4 * q + c] = v[c];
+      if (MASK) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(O.mask_y + off[4 * q]);
+#pragma unroll
+        for (int c = 0; c < 4; c++) T.m[4 * q + c] = w[c];
+      }
     }
   } else {
 #pragma unroll
-    for (int c = 0; c < 4; c++) {          // c: output row
+    for (int j = 0; j < NE; j++) {
+      T.x[j] = O.p[off[j]];
+      if (MASK) T.m[j] = O.mask_y[off[j]];
+    }
+  }
+  T.ok = ok;
+}
+
+template <bool RED_CONTIG, bool VEC, bool MASK, int NE>
+MLP_DEV void commit_tile(const TileRegs<MASK, NE>& T, uint16_t* lds) {
+  const int t = (int)threadIdx.x;
+  float v[NE];
+#pragma unroll
+  for (int j = 0; j < NE; j++) {
+    float x = T.x[j];
+    if (MASK) x *= elu_grad_from_output(T.m[j]);
+    v[j] = (T.ok >> j) & 1u ? x : 0.0f;
+  }
+  if (RED_CONTIG && VEC) {
+#pragma unroll
+    for (int q = 0; q < NE / 4; q++) {
       bf16x4 o;
 #pragma unroll
-      for (int q = 0; q < 4; q++) o[q] = (__bf16)T.v[4 * c + q];
-      *reinterpret_cast<bf16x4*>(lds + ((t & 31) * 4 + c) * LDT + (t >> 5) * 4) = o;
+      for (int c = 0; c < 4; c++) o[c] = (__bf16)v[4 * q + c];
+      *reinterpret_cast<bf16x4*>(lds + ((t >> 3) + 32 * q) * LDT + 4 * (t & 7)) = o;
+    }
+  } else if (RED_CONTIG) {
+#pragma unroll
+    for (int j = 0; j < NE; j++) {
+      const __bf16 o = (__bf16)v[j];
+      lds[((t >> 5) + 8 * j) * LDT + (t & 31)] = __builtin_bit_cast(uint16_t, o);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {          // c: output row; elements c, 4 + c, 8 + c, 12 + c are k .. k + 3
+      bf16x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; q++) o[q] = (__bf16)v[(4 * q + c) % NE];
+      *reinterpret_cast<bf16x4*>(lds + (4 * (t & 31) + c) * LDT + 4 * (t >> 5)) = o;
     }
   }
 }
@@ -150,37 +178,53 @@ struct Epilogue {
 };
 
 // C[rows, cols] (+)= A B^T over the reduction range [red0, red1) handled by this block (blockIdx.z slices for split-K).
-template <bool A_RED_CONTIG, bool B_RED_CONTIG, bool COLSUM_A, bool A_VEC, bool B_VEC>
+// BMT x 128 output tile per block: BMT = 128 (four waves of 64 x 64) or 64 (four waves of 32 x 64) -- the smaller tile
+// doubles the number of blocks for the skinny layers, whose 128-row grids leave CUs idle (384 blocks on 256 CUs run as
+// two rounds), and halves the registers so that more blocks are resident to hide the HBM latency of the K loop.
+template <int BMT, bool A_RED_CONTIG, bool B_RED_CONTIG, bool COLSUM_A, bool A_VEC, bool B_VEC, bool A_MASK>
 __global__ __launch_bounds__(256) void k_mlp_gemm(Operand A, Operand B, int red, int red_per_slice, Epilogue E, int rows, int cols) {
-  __shared__ __attribute__((aligned(16))) uint16_t As[BM * LDT];
+  constexpr int TI = BMT / 64, NEA = BMT / 8;     // MFMA tiles per wave along the rows; A elements per thread and K tile
+  __shared__ __attribute__((aligned(16))) uint16_t As[BMT * LDT];
   __shared__ __attribute__((aligned(16))) uint16_t Bs[BN * LDT];
-  const int r0 = (int)blockIdx.x * BM, c0 = (int)blockIdx.y * BN;
+  MLP_CLOCK(0);
+  const int r0 = (int)blockIdx.x * BMT, c0 = (int)blockIdx.y * BN;
   const int red0 = (int)blockIdx.z * red_per_slice;
+#ifdef SHF_MLP_PROBE_NO_LOOP
+  const int red1 = red0;                       // (probe build: epilogue only)
+#else
   const int red1 = red0 + red_per_slice < red ? red0 + red_per_slice : red;
+#endif
   const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;       // this wave's 64 x 64 corner inside the block tile
-  f32x16 acc[2][2];
+  const int wr = (wave >> 1) * (32 * TI), wc = (wave & 1) * 64;   // this wave's corner inside the block tile
+  f32x16 acc[TI][2];
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < TI; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
       for (int k = 0; k < 16; k++) acc[i][j][k] = 0.0f;
-  float csum = 0.0f;   // COLSUM_A: column (= A row index) sums, thread t < 128 owns A row t of the tile
+  float csum = 0.0f;   // COLSUM_A: column (= A row index) sums, thread t < BMT owns A row t of the tile
 
-  TileRegs ta, tb;
-  fetch_tile<A_RED_CONTIG, A_VEC>(A, r0, red0, red1, ta);
-  fetch_tile<B_RED_CONTIG, B_VEC>(B, c0, red0, red1, tb);
-  for (int k0 = red0; k0 < red1; k0 += BK) {
-    __syncthreads();                       // the previous tile's fragment reads are done
-    commit_tile<A_RED_CONTIG>(ta, As);
-    commit_tile<B_RED_CONTIG>(tb, Bs);
-    __syncthreads();
-    if (k0 + BK < red1) {                  // next tile's global loads fly under this tile's MFMAs
-      fetch_tile<A_RED_CONTIG, A_VEC>(A, r0, k0 + BK, red1, ta);
-      fetch_tile<B_RED_CONTIG, B_VEC>(B, c0, k0 + BK, red1, tb);
+  // Two tiles per operand are kept in flight in registers: while tile k is multiplied, the global loads of tiles k + 1
+  // and k + 2 are outstanding (the K loop of these skinny GEMMs is bound by HBM latency, not by the MFMAs).
+  TileRegs<A_MASK, NEA> ta[PF];
+  TileRegs<false, 16> tb[PF];
+#pragma unroll
+  for (int d = 0; d < PF; d++)
+    if (d == 0 || red0 + d * BK < red1) {
+      fetch_tile<A_RED_CONTIG, A_VEC, A_MASK, NEA>(A, r0, red0 + d * BK, red1, ta[d]);
+      fetch_tile<B_RED_CONTIG, B_VEC, false, 16>(B, c0, red0 + d * BK, red1, tb[d]);
     }
-    if (COLSUM_A && blockIdx.y == 0 && threadIdx.x < BM) {
+  auto step = [&](int k0, TileRegs<A_MASK, NEA>& xa, TileRegs<false, 16>& xb) {
+    lds_barrier();                         // the previous tile's fragment reads are done
+    commit_tile<A_RED_CONTIG, A_VEC, A_MASK, NEA>(xa, As);
+    commit_tile<B_RED_CONTIG, B_VEC, false, 16>(xb, Bs);
+    lds_barrier();
+    if (k0 + PF * BK < red1) {             // this register set is free again: tile k + PF
+      fetch_tile<A_RED_CONTIG, A_VEC, A_MASK, NEA>(A, r0, k0 + PF * BK, red1, xa);
+      fetch_tile<B_RED_CONTIG, B_VEC, false, 16>(B, c0, k0 + PF * BK, red1, xb);
+    }
+    if (COLSUM_A && blockIdx.y == 0 && threadIdx.x < BMT) {
       // db: sum over the reduction index of the (bf16-rounded) G values of A row t -- the values the MFMA multiplies
       const uint16_t* row = As + threadIdx.x * LDT;
 #pragma unroll
@@ -188,22 +232,36 @@ __global__ __launch_bounds__(256) void k_mlp_gemm(Operand A, Operand B, int red,
     }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 16) {
-      bf16x8 a[2], b[2];
+      bf16x8 a[TI], b[2];
 #pragma unroll
-      for (int i = 0; i < 2; i++) a[i] = *reinterpret_cast<const bf16x8*>(As + (wr + 32 * i + (lane & 31)) * LDT + kk + 8 * (lane >> 5));
+      for (int i = 0; i < TI; i++) a[i] = *reinterpret_cast<const bf16x8*>(As + (wr + 32 * i + (lane & 31)) * LDT + kk + 8 * (lane >> 5));
 #pragma unroll
       for (int j = 0; j < 2; j++) b[j] = *reinterpret_cast<const bf16x8*>(Bs + (wc + 32 * j + (lane & 31)) * LDT + kk + 8 * (lane >> 5));
+#ifndef SHF_MLP_PROBE_NO_MFMA
 #pragma unroll
-      for (int i = 0; i < 2; i++)
+      for (int i = 0; i < TI; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+#else
+      acc[0][0][0] += (float)a[0][0] + (float)b[0][0] + (float)b[1][0];
+#endif
     }
+  };
+  for (int k0 = red0; k0 < red1; k0 += PF * BK) {
+#pragma unroll
+    for (int d = 0; d < PF; d++)
+      if (d == 0 || k0 + d * BK < red1) step(k0 + d * BK, ta[d], tb[d]);
   }
 
+  MLP_CLOCK(1);
+#ifdef SHF_MLP_PROBE_NO_EPILOGUE
+  if (acc[0][0][0] == 12345.678f) E.c[0] = acc[TI - 1][1][3];   // (probe build: keep the accumulators alive, skip the stores)
+  return;
+#endif
   // epilogue: C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   float* Cout = E.c + (size_t)blockIdx.z * rows * E.ldc * (gridDim.z > 1 ? 1 : 0);   // split-K: slice z writes its own partial
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < TI; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int col = c0 + wc + 32 * j + (lane & 31);
@@ -213,69 +271,118 @@ __global__ __launch_bounds__(256) void k_mlp_gemm(Operand A, Operand B, int red,
         const int row = r0 + wr + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         if (row < rows && col < cols) {
           float v = acc[i][j][reg] + bv;
+#ifndef SHF_MLP_PROBE_NO_ELU
+#ifdef SHF_MLP_PROBE_EXPM1
           if (E.act == 1) v = v > 0.0f ? v : expm1f(v);
+#else
+          if (E.act == 1) v = v > 0.0f ? v : __expf(v) - 1.0f;     // ELU, alpha = 1 (exp(x) - 1, as the stock elu kernel)
+#endif
+#endif
           Cout[(size_t)row * E.ldc + col] = v;
         }
       }
     }
-  if (COLSUM_A && blockIdx.y == 0 && threadIdx.x < BM) {
+  if (COLSUM_A && blockIdx.y == 0 && threadIdx.x < BMT) {
     const int row = r0 + (int)threadIdx.x;
     if (row < rows) E.colsum[(size_t)blockIdx.z * rows + row] = csum;
   }
+  MLP_CLOCK(2);
 }
 
-// out[i] = sum_s part[s][i]  (fixed order: deterministic)
-__global__ void k_mlp_reduce_slices(const float* part, float* out, int n, int slices) {
+// out[i] = sum_s part[s][i], slices in ascending order (deterministic); dW and db of a layer in one launch.  The loads of
+// eight slices go out together (the additions stay in slice order), so a thread pays slices / 8 round trips, not slices.
+__global__ void k_mlp_reduce_slices(const float* part_w, float* dw, int nw, const float* part_b, float* db, int nb, int slices) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (i >= n) return;
+  if (i >= nw + nb) return;
+  const bool isw = i < nw;
+  const float* src = isw ? part_w + i : part_b + (i - nw);
+  const size_t stride = isw ? (size_t)nw : (size_t)nb;
   float acc = 0.0f;
-  for (int s = 0; s < slices; s++) acc += part[(size_t)s * n + i];
-  out[i] = acc;
+  for (int s0 = 0; s0 < slices; s0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = s0 + u < slices ? src[(size_t)(s0 + u) * stride] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc += v[u];
+  }
+  if (isw) dw[i] = acc; else db[i - nw] = acc;
 }
 
 thread_local std::string g_mlp_err;
 int mlp_fail(const std::string& m) { g_mlp_err = m; return 1; }
-bool vec_ok(const Operand& O) {
-  return O.ld % 4 == 0 && ((uintptr_t)O.p & 15u) == 0 && (!O.mask_y || ((uintptr_t)O.mask_y & 15u) == 0);
+bool too_big(int64_t M, int64_t K, int64_t N) { return M * K >= (1ll << 32) || M * N >= (1ll << 32) || N * K >= (1ll << 32); }
+bool vec_ok(const Operand& O, int red, bool red_contig) {
+  // 16-byte chunks must be whole: aligned rows, and the extent along the contiguous index a multiple of 4
+  const int contig_extent = red_contig ? red : O.rows;
+  return O.ld % 4 == 0 && contig_extent % 4 == 0 && ((uintptr_t)O.p & 15u) == 0 && (!O.mask_y || ((uintptr_t)O.mask_y & 15u) == 0);
+}
+template <int BMT, bool AR, bool BR, bool CS, bool AV, bool BV>
+void launch_gemm_m(dim3 grid, hipStream_t st, const Operand& A, const Operand& B, int red, int per, const Epilogue& E, int rows, int cols) {
+  if (A.mask_y) hipLaunchKernelGGL((k_mlp_gemm<BMT, AR, BR, CS, AV, BV, true>), grid, dim3(256), 0, st, A, B, red, per, E, rows, cols);
+  else hipLaunchKernelGGL((k_mlp_gemm<BMT, AR, BR, CS, AV, BV, false>), grid, dim3(256), 0, st, A, B, red, per, E, rows, cols);
+}
+// rows of the output tile: 64 when the A operand allows it (reduction index contiguous) and 128-row tiles would not give
+// every CU at least three blocks
+int pick_bm(bool a_red_contig, int rows, int cols, int slices) {
+  if (!a_red_contig) return 128;
+  static const char* force = getenv("SHF_MLP_FORCE_BM");     // experiments (tools/mlp_probe.py)
+  if (force) return atoi(force) == 64 ? 64 : 128;
+  const long tiles128 = (long)((rows + 127) / 128) * ((cols + BN - 1) / BN) * slices;
+  return tiles128 >= 3 * 256 ? 128 : 64;
 }
 template <bool AR, bool BR, bool CS>
-void launch_gemm(dim3 grid, hipStream_t st, const Operand& A, const Operand& B, int red, int per, const Epilogue& E, int rows, int cols) {
-  const bool av = vec_ok(A), bv = vec_ok(B);
-  if (av && bv) hipLaunchKernelGGL((k_mlp_gemm<AR, BR, CS, true, true>), grid, dim3(256), 0, st, A, B, red, per, E, rows, cols);
-  else if (av) hipLaunchKernelGGL((k_mlp_gemm<AR, BR, CS, true, false>), grid, dim3(256), 0, st, A, B, red, per, E, rows, cols);
-  else if (bv) hipLaunchKernelGGL((k_mlp_gemm<AR, BR, CS, false, true>), grid, dim3(256), 0, st, A, B, red, per, E, rows, cols);
-  else hipLaunchKernelGGL((k_mlp_gemm<AR, BR, CS, false, false>), grid, dim3(256), 0, st, A, B, red, per, E, rows, cols);
+void launch_gemm(hipStream_t st, const Operand& A, const Operand& B, int red, int per, int slices, const Epilogue& E, int rows, int cols) {
+  const bool av = vec_ok(A, red, AR) && per % 4 == 0, bv = vec_ok(B, red, BR) && per % 4 == 0;
+  const int bm = pick_bm(AR, rows, cols, slices);
+  const dim3 grid((rows + bm - 1) / bm, (cols + BN - 1) / BN, slices);
+#define SHF_MLP_LAUNCH(BMV)                                                                               \
+  do {                                                                                                    \
+    if (av && bv) launch_gemm_m<BMV, AR, BR, CS, true, true>(grid, st, A, B, red, per, E, rows, cols);    \
+    else if (av) launch_gemm_m<BMV, AR, BR, CS, true, false>(grid, st, A, B, red, per, E, rows, cols);    \
+    else if (bv) launch_gemm_m<BMV, AR, BR, CS, false, true>(grid, st, A, B, red, per, E, rows, cols);    \
+    else launch_gemm_m<BMV, AR, BR, CS, false, false>(grid, st, A, B, red, per, E, rows, cols);           \
+  } while (0)
+  if constexpr (AR) {
+    if (bm == 64) { SHF_MLP_LAUNCH(64); return; }
+  }
+  SHF_MLP_LAUNCH(128);
+#undef SHF_MLP_LAUNCH
 }
 
 }  // namespace
 
+#ifdef SHF_MLP_PROBE_CLOCK
+extern "C" int shf_mlp_probe_read(long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_probe), sizeof(long long) * n) == hipSuccess ? 0 : 1;
+}
+#endif
 extern "C" const char* shf_mlp_last_error(void) { return g_mlp_err.c_str(); }
 
 extern "C" int shf_mlp_linear_forward(const float* x, const float* w, const float* b, float* y, int32_t M, int32_t K, int32_t N,
                                       int32_t act, void* stream) {
   if (!x || !w || !y) return mlp_fail("shf_mlp_linear_forward: null tensor");
   if (M <= 0 || K <= 0 || N <= 0 || act < 0 || act > 1) return mlp_fail("shf_mlp_linear_forward: bad shape / activation");
+  if (too_big(M, K, N)) return mlp_fail("shf_mlp_linear_forward: a tensor has 2^32 elements or more");
   Operand A{x, nullptr, K, M}, B{w, nullptr, K, N};
   Epilogue E{y, N, b, act, nullptr};
-  dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, 1);
-  launch_gemm<true, true, false>(grid, (hipStream_t)stream, A, B, K, K, E, M, N);
+  launch_gemm<true, true, false>((hipStream_t)stream, A, B, K, K, 1, E, M, N);
   return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_mlp_linear_forward: launch failed");
 }
 
 extern "C" int shf_mlp_linear_backward_input(const float* dy, const float* y_or_null, const float* w, float* dx, int32_t M,
                                              int32_t K, int32_t N, void* stream) {
   if (!dy || !w || !dx) return mlp_fail("shf_mlp_linear_backward_input: null tensor");
+  if (M <= 0 || K <= 0 || N <= 0 || too_big(M, K, N)) return mlp_fail("shf_mlp_linear_backward_input: bad shape");
   // dX[M,K] = G[M,N] W[N,K]: A = G (reduction index n contiguous), B[col = k][red = n] = W[n][k] (transposed access)
   Operand A{dy, y_or_null, N, M}, B{w, nullptr, K, K};
   Epilogue E{dx, K, nullptr, 0, nullptr};
-  dim3 grid((M + BM - 1) / BM, (K + BN - 1) / BN, 1);
-  launch_gemm<true, false, false>(grid, (hipStream_t)stream, A, B, N, N, E, M, K);
+  launch_gemm<true, false, false>((hipStream_t)stream, A, B, N, N, 1, E, M, K);
   return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_mlp_linear_backward_input: launch failed");
 }
 
 extern "C" int shf_mlp_backward_weight_workspace(int32_t M, int32_t K, int32_t N, int64_t* floats) {
   if (!floats) return mlp_fail("shf_mlp_backward_weight_workspace: null");
-  const int slices = (M + WGRAD_ROWS - 1) / WGRAD_ROWS;
+  const int per = wgrad_rows(M, K, N), slices = (M + per - 1) / per;
   *floats = (int64_t)slices * ((int64_t)N * K + N);
   return 0;
 }
@@ -283,21 +390,16 @@ extern "C" int shf_mlp_backward_weight_workspace(int32_t M, int32_t K, int32_t N
 extern "C" int shf_mlp_linear_backward_weight(const float* dy, const float* y_or_null, const float* x, float* dw, float* db,
                                               float* workspace, int32_t M, int32_t K, int32_t N, void* stream) {
   if (!dy || !x || !dw || !workspace) return mlp_fail("shf_mlp_linear_backward_weight: null tensor");
+  if (M <= 0 || K <= 0 || N <= 0 || too_big(M, K, N)) return mlp_fail("shf_mlp_linear_backward_weight: bad shape");
   // dW[N,K] = G^T X: rows = n, cols = k, reduction over m; both operands are stored with the reduction index as the row
-  const int per = WGRAD_ROWS, slices = (M + per - 1) / per;
+  const int per = wgrad_rows(M, K, N), slices = (M + per - 1) / per;
   float* part_w = workspace;
   float* part_b = workspace + (size_t)slices * N * K;
   Operand A{dy, y_or_null, N, N}, B{x, nullptr, K, K};
   Epilogue E{part_w, K, nullptr, 0, part_b};
-  dim3 grid((N + BM - 1) / BM, (K + BN - 1) / BN, slices);
-  launch_gemm<false, false, true>(grid, (hipStream_t)stream, A, B, M, per, E, N, K);
-  const int nw = N * K;
-  if (slices > 1) {
-    hipLaunchKernelGGL(k_mlp_reduce_slices, dim3((nw + 255) / 256), dim3(256), 0, (hipStream_t)stream, part_w, dw, nw, slices);
-  } else {
-    if (hipMemcpyAsync(dw, part_w, (size_t)nw * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
-      return mlp_fail("shf_mlp_linear_backward_weight: copy failed");
-  }
-  if (db) hipLaunchKernelGGL(k_mlp_reduce_slices, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, part_b, db, N, slices);
+  launch_gemm<false, false, true>((hipStream_t)stream, A, B, M, per, slices, E, N, K);
+  const int nw = N * K, nb = db ? N : 0;
+  hipLaunchKernelGGL(k_mlp_reduce_slices, dim3((nw + nb + 255) / 256), dim3(256), 0, (hipStream_t)stream, part_w, dw, nw, part_b, db, nb,
+                     slices);
   return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_mlp_linear_backward_weight: launch failed");
 }

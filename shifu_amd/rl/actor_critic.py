@@ -1,4 +1,5 @@
 """Gaussian MLP actor + MLP critic (PPOConfig.policy, shifu/configs/policy_config.py:8-16)."""
+import os
 from typing import Sequence
 
 import torch
@@ -9,6 +10,13 @@ from .linear import SplitKLinear
 
 _ACTIVATIONS = {"elu": nn.ELU, "selu": nn.SELU, "relu": nn.ReLU, "lrelu": nn.LeakyReLU, "tanh": nn.Tanh,
                 "sigmoid": nn.Sigmoid}
+
+
+def _mfma_output_layer() -> bool:
+    """mlp_backend='mfma': whether the output layers (action means / value, 128 -> 12 / 1: 0.1 % of the flops) run on the
+    MFMA kernels too (bf16 operands) or stay fp32 library GEMMs.  Default on: then the whole update is free of library
+    GEMMs and can be replayed from a hipGraph (PPO.graph_update); SHIFU_AMD_MFMA_OUTPUT_LAYER=0 keeps them in fp32."""
+    return os.environ.get("SHIFU_AMD_MFMA_OUTPUT_LAYER", "1") == "1"
 
 
 def _mlp(n_in: int, hidden: Sequence[int], n_out: int, act: str, backend: str = "torch") -> nn.Sequential:
@@ -23,7 +31,8 @@ def _mlp(n_in: int, hidden: Sequence[int], n_out: int, act: str, backend: str = 
         for h in hidden:
             layers += [MfmaLinear(last, h, elu=True), nn.Identity()]
             last = h
-        layers.append(MfmaLinear(last, n_out, elu=False))
+        # the output layer (action means / value: 128 -> 12 / 1, 0.1 % of the flops) stays in fp32
+        layers.append(MfmaLinear(last, n_out, elu=False) if _mfma_output_layer() else SplitKLinear(last, n_out))
         return nn.Sequential(*layers)
     layers, last = [], n_in
     for h in hidden:
@@ -46,6 +55,7 @@ class ActorCritic(nn.Module):
         # library GEMMs; default from SHIFU_AMD_MLP, else "torch"
         import os
         self.mlp_backend = mlp_backend or os.environ.get("SHIFU_AMD_MLP", "torch")
+        self.all_layers_mfma = self.mlp_backend == "mfma" and _mfma_output_layer()
         self.actor = _mlp(num_actor_obs, actor_hidden_dims, num_actions, activation, self.mlp_backend)
         self.critic = _mlp(num_critic_obs, critic_hidden_dims, 1, activation, self.mlp_backend)
         self.std = nn.Parameter(init_noise_std * torch.ones(num_actions))

@@ -10,8 +10,14 @@ from .storage import RolloutStorage
 class PPO:
     def __init__(self, actor_critic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
                  value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True,
-                 schedule="fixed", desired_kl=0.01, device="cpu"):
+                 schedule="fixed", desired_kl=0.01, device="cpu", graph_update=False):
         self.device = device
+        # graph_update: replay one captured hipGraph per mini-batch step (gather, losses, backward, clip, Adam, lr
+        # schedule: ~280 launches) instead of launching it eagerly; bit-identical to the eager update
+        # (tests/test_gpu_mlp.py).  Only with the MFMA layers (no library GEMM workspaces inside the graph) and one rank.
+        self.graph_update = bool(graph_update)
+        self._upd_graph = self._upd_idx = self._upd_sums = None
+        self._updates_done = 0
         self.desired_kl, self.schedule = desired_kl, schedule
         self.actor_critic = actor_critic.to(device)
         self.storage = None
@@ -138,17 +144,48 @@ class PPO:
         sums[0] += L["value"].detach()
         sums[1] += L["surrogate"].detach()
 
+    def _graph_update_ok(self) -> bool:
+        return (self.graph_update and torch.device(self.device).type == "cuda" and not collectives_on()
+                and getattr(self.actor_critic, "mlp_backend", "torch") == "mfma"
+                and getattr(self.actor_critic, "all_layers_mfma", False))
+
+    def _capture_update(self, mb):
+        self._upd_idx = torch.zeros(mb, dtype=torch.long, device=self.device)
+        self._upd_sums = torch.zeros(2, device=self.device)
+        self.optimizer.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            self.optimizer.zero_grad(set_to_none=True)
+            self._minibatch_step(self.storage.mini_batch(self._upd_idx), self._upd_sums)
+        self._upd_graph = g
+
     def update(self):
         st = self.storage
         B = st.num_envs * st.num_transitions_per_env
         mb = B // self.num_mini_batches
         perm = torch.randperm(self.num_mini_batches * mb, device=self.device)
-        sums = torch.zeros(2, device=self.device)       # value / surrogate loss sums stay on the device
+        # the first update runs eagerly (lazy initialisations, optimizer state); the second is captured
+        use_graph = self._graph_update_ok() and self._updates_done >= 1
+        if use_graph and self._upd_graph is None:
+            self._capture_update(mb)
+        sums = self._upd_sums.zero_() if use_graph else torch.zeros(2, device=self.device)   # loss sums stay on the device
         for _ in range(self.num_learning_epochs):
             for i in range(self.num_mini_batches):
-                self.optimizer.zero_grad(set_to_none=True)
-                self._minibatch_step(st.mini_batch(perm[i * mb:(i + 1) * mb]), sums)
+                if use_graph:
+                    self._upd_idx.copy_(perm[i * mb:(i + 1) * mb])
+                    self._upd_graph.replay()
+                    # On this ROCm build work queued behind a graph launch is not reliably ordered after the graph's last
+                    # node: without this wait the next mini-batch's index copy (and the next replay) can overtake the
+                    # tail of this one -- parameters then drift from the eager update's (measured: identical to the bit
+                    # with the wait, different without; round 1's "corrupted captured update" was the same defect).  The
+                    # host has nothing else to do here, so the wait costs no throughput.
+                    torch.cuda.synchronize()
+                else:
+                    self.optimizer.zero_grad(set_to_none=True)
+                    self._minibatch_step(st.mini_batch(perm[i * mb:(i + 1) * mb]), sums)
         n = self.num_learning_epochs * self.num_mini_batches
         st.clear()
+        self._updates_done += 1
         mean_value_loss, mean_surrogate_loss = (sums / n).tolist()
         return mean_value_loss, mean_surrogate_loss

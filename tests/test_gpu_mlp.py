@@ -117,3 +117,50 @@ def test_two_rank_training_keeps_parameters_in_sync(tmp_path):
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["iterations"] == 3 and rec["ranks_in_sync"] is True
     assert rec["samples_per_s"] > 0 and all(np.isfinite(rec["param_checksum"]))
+
+
+def _ppo_with_filled_storage(seed, graph_update):
+    """A PPO trainer on the MFMA backend whose rollout buffer holds a synthetic rollout (256 envs x 24 steps)."""
+    from shifu_amd.rl.actor_critic import ActorCritic
+    from shifu_amd.rl.ppo import PPO
+    torch.manual_seed(seed)
+    dev = "cuda:0"
+    ac = ActorCritic(259, 259, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128], mlp_backend="mfma")
+    alg = PPO(ac, num_learning_epochs=2, num_mini_batches=4, schedule="adaptive", desired_kl=0.01, learning_rate=1e-3,
+              entropy_coef=0.01, device=dev, graph_update=graph_update)
+    alg.init_storage(256, 24, [259], [259], [12])
+
+    def fill(gen_seed):
+        g = torch.Generator(device=dev).manual_seed(gen_seed)
+        obs = torch.randn(256, 259, device=dev, generator=g)
+        for _ in range(24):
+            with torch.no_grad():
+                alg.act(obs, obs)
+            rew = torch.randn(256, device=dev, generator=g)
+            done = torch.rand(256, device=dev, generator=g) < 0.05
+            alg.process_env_step(rew, done, {})
+            obs = torch.randn(256, 259, device=dev, generator=g)
+        alg.compute_returns(obs)
+    return alg, fill
+
+
+def test_captured_update_equals_the_eager_update():
+    """PPO.graph_update replays one captured hipGraph per mini-batch step; parameters, optimizer state and learning rate
+    after three updates must be bit-identical to the eagerly launched ones."""
+    _need_gpu()
+    res = []
+    for graph in (False, True):
+        alg, fill = _ppo_with_filled_storage(3, graph)
+        for it in range(3):
+            fill(100 + it)
+            torch.manual_seed(7 + it)               # the mini-batch permutation
+            alg.update()
+        assert (alg._upd_graph is not None) == graph
+        res.append(([p.detach().clone() for p in alg.actor_critic.parameters()], float(alg.lr),
+                    [s["exp_avg"].clone() for s in alg.optimizer.state.values()]))
+    (pa, lra, ma), (pb, lrb, mb) = res
+    assert lra == lrb
+    for x, y in zip(pa, pb):
+        assert torch.equal(x, y)
+    for x, y in zip(ma, mb):
+        assert torch.equal(x, y)

@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="capture the rollout in one hipGraph (runner.graph_rollout)")
     ap.add_argument("--mlp", choices=["torch", "mfma"], default=None,
                     help="ActorCritic layers: stock fp32 library GEMMs, or the hand-written MFMA kernels (csrc/shf_mlp.hip)")
+    ap.add_argument("--eager-update", action="store_true", help="with --graph: capture the rollout only, launch the PPO update eagerly")
+    ap.add_argument("--graph-update", action="store_true", help="capture the PPO update only (debugging)")
+    ap.add_argument("--seed", type=int, default=None, help="override A1PPOConfig.seed")
     ap.add_argument("--self-collision", action="store_true", help="collide the robot's own links (reference collision filter 0)")
     args = ap.parse_args()
     import torch.distributed as dist
@@ -45,9 +48,10 @@ def main():
     from shifu_amd.runner.utils import class_to_dict, set_seed
     cfg = class_to_dict(A1PPOConfig())
     cfg["runner"]["graph_rollout"] = args.graph
+    cfg["algorithm"]["graph_update"] = (args.graph or args.graph_update) and not args.eager_update   # with --mlp mfma only (PPO.graph_update)
     if args.mlp:
         cfg["policy"]["mlp_backend"] = args.mlp
-    set_seed(A1PPOConfig.seed + rank)
+    set_seed((A1PPOConfig.seed if args.seed is None else args.seed) + rank)
     if args.hook:
         from examples.a1_conditional.a1_conditional import A1Conditional
         from examples.a1_conditional.task_config import A1EnvConfig
@@ -56,7 +60,8 @@ def main():
         env = A1Conditional(ec)
     else:
         from shifu_amd.gym.a1_fused import FusedA1Env
-        env = FusedA1Env(num_envs=args.envs, device=dev, rank=rank, world_size=world, self_collision=args.self_collision)
+        env = FusedA1Env(num_envs=args.envs, device=dev, rank=rank, world_size=world, self_collision=args.self_collision,
+                         **({} if args.seed is None else {"seed": args.seed}))
     log_dir = args.log or os.path.join("gpurun_out", "train_a1")
     runner = OnPolicyRunner(env, cfg, log_dir=log_dir, device=str(dev))
     if args.quiet:
