@@ -288,7 +288,9 @@ class Gym:
             base = os.path.basename(filename)
             alt = {"a1.urdf": "a1.urdf", "abb_rod_isaac.urdf": "abb_rod.urdf"}.get(base, base)
             path = asset_path(alt)
-        # mesh colliders are not supported: known assets get their documented substitutes
+        # <mesh> colliders become convex hulls where the files are present (they do not ship with this repo: the vendored
+        # URDFs are the physics-only reductions); against box actors only rounded shapes are tested, so the ABB rod gets its
+        # documented capsule either way
         extra = ()
         if os.path.basename(path) in ("abb_rod.urdf", "abb_rod_isaac.urdf"):
             from ..abb_task import ROD_CAPSULE
@@ -297,7 +299,8 @@ class Gym:
                              disable_gravity=bool(options.disable_gravity),
                              collapse_fixed_joints=bool(options.collapse_fixed_joints),
                              default_dof_drive_mode=int(options.default_dof_drive_mode),
-                             armature=float(getattr(options, "armature", 0.0)))
+                             armature=float(getattr(options, "armature", 0.0)),
+                             density=float(getattr(options, "density", 1000.0)), meshes="auto")
         return Asset("articulation", filename, options, model=model)
 
     def create_box(self, sim, x, y, z, options: AssetOptions = None):

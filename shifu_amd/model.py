@@ -20,6 +20,8 @@ import numpy as np
 
 from . import _abi
 
+HULL_POINTS = 8          # contact sample points per convex-hull (mesh) collider, like a box's eight corners
+
 ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
 
 
@@ -64,10 +66,12 @@ class _Inertial:
 
 @dataclasses.dataclass
 class _Shape:
-    kind: str
+    kind: str                    # "box" | "sphere" | "capsule" | "hull" (convex hull of a <mesh>)
     size: np.ndarray
     pos: np.ndarray
     rot: np.ndarray
+    verts: Optional[np.ndarray] = None    # hull: vertices (n,3) in the shape frame, scale applied
+    faces: Optional[np.ndarray] = None    # hull: triangles (m,3) into verts, outward orientation
 
 
 @dataclasses.dataclass
@@ -126,7 +130,108 @@ class CompiledModel:
         return out
 
 
-def parse_urdf(path: str) -> Tuple[Dict[str, _Link], List[_Joint]]:
+def _resolve_mesh(urdf_path: str, filename: str) -> Optional[str]:
+    """<mesh filename>: a path relative to the URDF, or package://<pkg>/<rest> looked up as <ancestor dir>/<pkg>/<rest>
+    and <ancestor dir>/<rest> for the URDF's ancestors (how the reference's asset tree lays its packages out)."""
+    if not filename:
+        return None
+    base = os.path.dirname(os.path.abspath(urdf_path))
+    if filename.startswith("package://"):
+        rest = filename[len("package://"):]
+        tail = rest.split("/", 1)[1] if "/" in rest else rest
+        d = base
+        for _ in range(6):
+            for cand in (os.path.join(d, rest), os.path.join(d, tail)):
+                if os.path.isfile(cand):
+                    return cand
+            d = os.path.dirname(d)
+        return None
+    if filename.startswith("file://"):
+        filename = filename[len("file://"):]
+    cand = filename if os.path.isabs(filename) else os.path.join(base, filename)
+    return cand if os.path.isfile(cand) else None
+
+
+def _load_stl(path: str) -> np.ndarray:
+    """Vertices (n,3) of a collision mesh file: STL (binary or ASCII) or Wavefront OBJ (only the convex hull is used)."""
+    raw = open(path, "rb").read()
+    if path.lower().endswith(".obj"):
+        pts = [list(map(float, ln.split()[1:4])) for ln in raw.decode("utf-8", "ignore").splitlines() if ln.startswith("v ")]
+        if not pts:
+            raise ValueError(f"{path}: no vertices")
+        return np.asarray(pts, dtype=float)
+    if len(raw) >= 84:
+        ntri = int(np.frombuffer(raw, dtype="<u4", count=1, offset=80)[0])
+        if 84 + 50 * ntri == len(raw):
+            rec = np.frombuffer(raw, dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]), count=ntri, offset=84)
+            return rec["v"].reshape(-1, 3).astype(float)
+    pts = [list(map(float, ln.split()[1:4])) for ln in raw.decode("ascii", "ignore").splitlines() if ln.strip().startswith("vertex")]
+    if not pts:
+        raise ValueError(f"{path}: neither a binary nor an ASCII STL")
+    return np.asarray(pts, dtype=float)
+
+
+def _convex_hull(pts: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Convex hull (vertices, outward triangles) -- what PhysX collides a dynamic triangle mesh as (convex decomposition
+    off, asset_config.py:32-46 vhacd_enabled = False)."""
+    from scipy.spatial import ConvexHull
+    pts = np.unique(np.round(pts, 9), axis=0)
+    if len(pts) < 4:
+        raise ValueError("collision mesh with fewer than four distinct vertices")
+    h = ConvexHull(pts)
+    idx = np.unique(h.simplices)
+    remap = -np.ones(len(pts), dtype=int)
+    remap[idx] = np.arange(len(idx))
+    v, t = pts[idx], remap[h.simplices]
+    c = v.mean(0)
+    for k in range(len(t)):                          # orient every triangle outward
+        a, b, d = v[t[k]]
+        if np.dot(np.cross(b - a, d - a), a - c) < 0:
+            t[k] = t[k][::-1]
+    return v, t
+
+
+def _hull_sample(v: np.ndarray, n: int) -> np.ndarray:
+    """At most n hull vertices as contact sample points: the extreme vertices along +-x, +-y, +-z first (a plane contact
+    of an axis-aligned resting pose is then exact), then farthest-point sampling."""
+    if len(v) <= n:
+        return v.copy()
+    pick = []
+    for ax in range(3):
+        for sgn in (-1, 1):
+            k = int(np.argmax(sgn * v[:, ax]))
+            if k not in pick:
+                pick.append(k)
+    pick = pick[:n]
+    d = np.min(np.linalg.norm(v[:, None, :] - v[pick][None, :, :], axis=2), axis=1)
+    while len(pick) < n:
+        k = int(np.argmax(d))
+        pick.append(k)
+        d = np.minimum(d, np.linalg.norm(v - v[k], axis=1))
+    return v[pick]
+
+
+def _hull_inertial(v: np.ndarray, t: np.ndarray, density: float) -> "_Inertial":
+    """Uniform-density mass properties of a closed triangulated convex surface (signed tetrahedra from the origin)."""
+    vol, first, second = 0.0, np.zeros(3), np.zeros((3, 3))
+    canon = (np.ones((3, 3)) + np.eye(3)) / 120.0             # integral of x_i x_j over the unit tetrahedron
+    for tri in t:
+        A = v[tri].T                                          # columns a, b, c
+        det = float(np.linalg.det(A))
+        vol += det / 6.0
+        first += det / 24.0 * A.sum(1)
+        second += det * (A @ canon @ A.T)
+    if vol <= 0:
+        raise ValueError("collision mesh hull has no volume")
+    com = first / vol
+    C = second - vol * np.outer(com, com)                     # covariance about the centre of mass
+    I = density * (np.trace(C) * np.eye(3) - C)
+    return _Inertial(density * vol, com, I)
+
+
+def parse_urdf(path: str, meshes: str = "error", **_unused) -> Tuple[Dict[str, _Link], List[_Joint]]:
+    """meshes: "error" -- <mesh> collisions become convex hulls, a missing file is refused; "auto" -- hulls where the file
+    is found, silently none where it is not; "drop" -- mesh collisions are ignored."""
     root = ET.parse(path).getroot()
     links: Dict[str, _Link] = {}
     for l in root.findall("link"):
@@ -153,6 +258,17 @@ def parse_urdf(path: str) -> Tuple[Dict[str, _Link], List[_Joint]]:
             elif g.find("cylinder") is not None or g.find("capsule") is not None:
                 e = g.find("cylinder") if g.find("cylinder") is not None else g.find("capsule")
                 shapes.append(_Shape("capsule", np.array([float(e.get("radius")), float(e.get("length"))]), p, R))
+            elif g.find("mesh") is not None:
+                e = g.find("mesh")
+                f = _resolve_mesh(path, e.get("filename", ""))
+                if f is None or meshes == "drop":
+                    if f is None and meshes == "error":
+                        raise FileNotFoundError(f"link '{l.get('name')}': collision mesh '{e.get('filename')}' not found "
+                                                f"next to {path} (pass meshes='drop' to ignore mesh colliders)")
+                    continue
+                sc = _vec(e.get("scale")) if e.get("scale") else np.ones(3)
+                v, t = _convex_hull(_load_stl(f) * sc)
+                shapes.append(_Shape("hull", sc, p, R, v, t))
         links[l.get("name")] = _Link(l.get("name"), inertial, shapes)
     joints = []
     for j in root.findall("joint"):
@@ -190,11 +306,17 @@ def _shape_points(shape: _Shape) -> List[Tuple[np.ndarray, float]]:
         r, L = float(shape.size[0]), float(shape.size[1])
         for z in (-0.5 * L, 0.0, 0.5 * L):
             pts.append((shape.pos + shape.rot @ np.array([0, 0, z]), r))
+    elif shape.kind == "hull":
+        for q in _hull_sample(shape.verts, HULL_POINTS):
+            pts.append((shape.pos + shape.rot @ q, 0.0))
     return pts
 
 
 def _shape_inertial(shape: _Shape, density: float) -> _Inertial:
     """Uniform-density inertial of a collision primitive, in the link frame."""
+    if shape.kind == "hull":
+        i = _hull_inertial(shape.verts, shape.faces, density)
+        return _Inertial(i.mass, shape.pos + shape.rot @ i.com, shape.rot @ i.I @ shape.rot.T)
     if shape.kind == "box":
         x, y, z = shape.size
         m = density * x * y * z
@@ -279,6 +401,16 @@ def _shape_capsules(shape: _Shape) -> List[Tuple[np.ndarray, np.ndarray, float]]
     -- one (radius (W + H)/4) when the cross-section is nearly square, else as many side by side as cover W."""
     if shape.kind == "sphere":
         return [(shape.pos.copy(), shape.pos.copy(), float(shape.size[0]))]
+    if shape.kind == "hull":
+        # one capsule along the hull's longest principal axis: radius = RMS distance of the vertices from that axis
+        c = shape.verts.mean(0)
+        _, _, vt = np.linalg.svd(shape.verts - c, full_matrices=False)
+        ax = vt[0]
+        proj = (shape.verts - c) @ ax
+        perp = np.linalg.norm((shape.verts - c) - np.outer(proj, ax), axis=1)
+        r = float(np.sqrt(np.mean(perp ** 2)))
+        lo, hi = min(float(proj.min()) + r, 0.0), max(float(proj.max()) - r, 0.0)
+        return [(shape.pos + shape.rot @ (c + lo * ax), shape.pos + shape.rot @ (c + hi * ax), r)]
     if shape.kind == "capsule":
         r, L = float(shape.size[0]), float(shape.size[1])
         z = shape.rot @ np.array([0.0, 0.0, 0.5 * L])
@@ -300,12 +432,17 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
                  collapse_fixed_joints: bool = True, default_dof_drive_mode: int = _abi.DOF_MODE_NONE,
                  armature: float = 0.0, honour_dont_collapse: bool = True,
                  extra_spheres: Sequence[tuple] = (), density: float = 1000.0,
-                 self_collision: bool = False) -> CompiledModel:
+                 self_collision: bool = False, meshes: str = "error") -> CompiledModel:
     """Compile `path` with the AssetOptions the reference passes (asset_config.py:32-46).
 
+    meshes: <mesh> collision geometry becomes the convex hull of the STL file ("error": a missing file is refused;
+    "auto": a missing file is skipped; "drop": meshes are ignored, what strip_urdf.py did to the vendored assets); a hull
+    contributes HULL_POINTS of its vertices
+    as ground-contact sample points, its uniform-density mass properties when the link has no <inertial>, and one
+    self-collision capsule along its longest principal axis.
     extra_spheres: rounded collision shapes tested against box actors -- the substitute for mesh colliders (ABB rod):
     (link name, xyz in that link's frame, radius) spheres, or (link name, xyz_a, xyz_b, radius) capsules."""
-    links, joints = parse_urdf(path)
+    links, joints = parse_urdf(path, meshes=meshes)
     _fill_missing_inertials(links, density)
     children: Dict[str, List[_Joint]] = {n: [] for n in links}
     is_child = set()

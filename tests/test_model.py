@@ -5,6 +5,7 @@ import glob
 import os
 import sys
 
+import numpy as np
 import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,7 +31,7 @@ def test_every_reference_urdf_compiles_or_is_refused_with_a_reason():
     refused, massless = [], []
     for p in paths:
         try:
-            cm = compile_urdf(p)
+            cm = compile_urdf(p, meshes="auto")
         except AssertionError as e:
             assert "SHF_MAX" in str(e), (p, e)
             refused.append(os.path.basename(p))
@@ -43,7 +44,7 @@ def test_every_reference_urdf_compiles_or_is_refused_with_a_reason():
         assert 1 <= m.nb <= _abi.MAX_BODIES and 0 <= m.nd <= 32 and len(cm.body_names) == m.nb and len(cm.dof_names) == m.nd
         assert all(m.parent[b] < b for b in range(1, m.nb)), "bodies are numbered parents-first"
         assert sum(m.pt_count[b] for b in range(m.nb)) == m.np
-    assert refused == ["anymal.urdf"]          # 143 collision sample points > SHF_MAX_POINTS (96)
+    assert refused == ["anymal.urdf", "sektion_cabinet_2.urdf"]     # 143 / 164 collision sample points > SHF_MAX_POINTS (96)
     print("refused for missing inertia:", massless)
 
 
@@ -81,3 +82,91 @@ def test_massless_moving_body_is_refused_or_steps_finite(tmp_path, oracle):
     with pytest.raises(ValueError, match="floating root"):
         compile_urdf(str(path))
     assert compile_urdf(str(path), fix_base_link=True).blob.nb == 1
+
+
+# ---- mesh colliders: convex hull of the STL / OBJ (the reference's ABB links collide as STL hulls) ----
+def _write_box_stl(path, size, binary=True):
+    import struct
+    h = 0.5 * np.asarray(size, float)
+    v = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], float) * h
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    tris = [(q[0], q[1], q[2]) for q in quads] + [(q[0], q[2], q[3]) for q in quads]
+    if binary:
+        with open(path, "wb") as f:
+            f.write(b"box".ljust(80, b" ") + struct.pack("<I", len(tris)))
+            for t in tris:
+                f.write(struct.pack("<12fH", 0, 0, 0, *v[t[0]], *v[t[1]], *v[t[2]], 0))
+    else:
+        with open(path, "w") as f:
+            f.write("solid box\n")
+            for t in tris:
+                f.write(" facet normal 0 0 0\n  outer loop\n" + "".join(f"   vertex {v[k][0]} {v[k][1]} {v[k][2]}\n" for k in t) + "  endloop\n endfacet\n")
+            f.write("endsolid box\n")
+
+
+MESH_URDF = """<robot name="m"><link name="base">{inertial}
+ <collision><origin xyz="0.1 0 0" rpy="0 0 0.3"/><geometry>{geom}</geometry></collision></link></robot>"""
+
+
+@pytest.mark.parametrize("binary", [True, False])
+def test_mesh_collider_is_the_convex_hull_of_the_stl(tmp_path, binary):
+    size = (0.4, 0.2, 0.1)
+    _write_box_stl(tmp_path / "box.stl", size, binary)
+    (tmp_path / "mesh.urdf").write_text(MESH_URDF.format(inertial="", geom='<mesh filename="box.stl"/>'))
+    (tmp_path / "prim.urdf").write_text(MESH_URDF.format(inertial="", geom=f'<box size="{size[0]} {size[1]} {size[2]}"/>'))
+    a, b = compile_urdf(str(tmp_path / "mesh.urdf")), compile_urdf(str(tmp_path / "prim.urdf"))
+    assert a.blob.np == 8 and b.blob.np == 8
+    pa = sorted(tuple(np.round(a.blob.pt_pos[i][:], 6)) for i in range(8))
+    pb = sorted(tuple(np.round(b.blob.pt_pos[i][:], 6)) for i in range(8))
+    assert pa == pb                                                     # the hull's vertices are the box's corners
+    # no <inertial>: uniform-density mass properties of the hull = those of the box primitive
+    assert abs(a.total_mass - 1000.0 * 0.4 * 0.2 * 0.1) < 1e-6 and abs(a.total_mass - b.total_mass) < 1e-6
+    np.testing.assert_allclose(np.array(a.blob.inertia[0][:]), np.array(b.blob.inertia[0][:]), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(np.array(a.blob.com[0][:]), np.array(b.blob.com[0][:]), atol=1e-7)
+
+
+def test_mesh_collider_scale_obj_missing_file_and_sampling(tmp_path):
+    from shifu_amd.model import HULL_POINTS, _convex_hull, _hull_inertial, _hull_sample
+    # OBJ, scaled: a unit tetrahedron scaled by 2 -> volume 8 / 6
+    (tmp_path / "tet.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nv 0.2 0.2 0.2\nf 1 2 3\n")
+    (tmp_path / "t.urdf").write_text(MESH_URDF.format(inertial="", geom='<mesh filename="tet.obj" scale="2 2 2"/>'))
+    cm = compile_urdf(str(tmp_path / "t.urdf"))
+    assert cm.blob.np == 4 and abs(cm.total_mass - 1000.0 * 8.0 / 6.0) < 1e-6          # the interior vertex is not on the hull
+    # a missing file is refused unless asked otherwise
+    (tmp_path / "gone.urdf").write_text(MESH_URDF.format(inertial='<inertial><mass value="1"/><inertia ixx="1" iyy="1" izz="1"/></inertial>',
+                                                          geom='<mesh filename="package://pkg/meshes/none.stl"/>'))
+    with pytest.raises(FileNotFoundError, match="not found"):
+        compile_urdf(str(tmp_path / "gone.urdf"))
+    assert compile_urdf(str(tmp_path / "gone.urdf"), meshes="auto").blob.np == 0
+    assert compile_urdf(str(tmp_path / "gone.urdf"), meshes="drop").blob.np == 0
+    # many-vertex hull: HULL_POINTS samples, the six axis extremes among them; mass properties of a sphere
+    rng = np.random.default_rng(0)
+    p = rng.normal(size=(4000, 3)); p /= np.linalg.norm(p, axis=1, keepdims=True)
+    v, t = _convex_hull(0.3 * p)
+    sm = _hull_sample(v, HULL_POINTS)
+    assert len(sm) == HULL_POINTS
+    for ax in range(3):
+        assert sm[:, ax].max() == v[:, ax].max() and sm[:, ax].min() == v[:, ax].min()
+    ine = _hull_inertial(v, t, 1000.0)
+    m = 1000.0 * 4.0 / 3.0 * np.pi * 0.3 ** 3
+    assert abs(ine.mass - m) < 0.01 * m and np.abs(ine.com).max() < 1e-3
+    np.testing.assert_allclose(np.diag(ine.I), 0.4 * m * 0.09 * np.ones(3), rtol=0.02)
+
+
+def test_mesh_box_rests_on_the_plane_like_the_primitive_box(tmp_path):
+    """the hull collider in the physics: a mesh box dropped on the ground comes to rest where the <box> does"""
+    from oracle import pyoracle as O
+    from tests import helpers as H
+    size = (0.3, 0.2, 0.1)
+    _write_box_stl(tmp_path / "box.stl", size)
+    geo = {"mesh": '<mesh filename="box.stl"/>', "prim": f'<box size="{size[0]} {size[1]} {size[2]}"/>'}
+    z = {}
+    for k, g in geo.items():
+        (tmp_path / f"{k}.urdf").write_text(MESH_URDF.replace('xyz="0.1 0 0" rpy="0 0 0.3"', 'xyz="0 0 0" rpy="0 0 0"').format(inertial="", geom=g))
+        cm = compile_urdf(str(tmp_path / f"{k}.urdf"))
+        root = np.zeros((1, 13)); root[0, 2] = 0.08; root[0, 6] = 1.0
+        dof = np.zeros((0, 2))
+        O.step(cm.blob, H.sim_params(), 1, dof, root, nsteps=400, f64=True)
+        z[k] = root[0, 2]
+        assert abs(root[0, 9]) < 1e-4                                    # at rest
+    assert 0.045 < z["mesh"] < 0.0501 and abs(z["mesh"] - z["prim"]) < 1e-7
