@@ -409,7 +409,15 @@ int shf_abb_reset_all(ShfAbbTask* task, void* stream);
  *   forward          y[M,N]  = act(x[M,K] w[N,K]^T + b[N])                        act: 0 = identity, 1 = ELU
  *   backward_input   dx[M,K] = (dy (.) act'(y))[M,N] w[N,K]                       y = the forward's output, or NULL (identity)
  *   backward_weight  dw[N,K] = (dy (.) act'(y))^T x,  db[N] = column sums          workspace: see *_workspace (floats)
+ * Operand precision (process-wide, shf_mlp_set_precision): SHF_MLP_BF16X3 (default) splits every fp32 operand value
+ * into a bf16 head and a bf16 tail and accumulates head*head + head*tail + tail*head -- products good to 2^-16
+ * relative, fp32-like results, three MFMAs per tile pair (the layers are HBM-bound, so this costs little);
+ * SHF_MLP_BF16 rounds operands to bf16 once (2^-9 relative), one MFMA per tile pair.
  * ---------------------------------------------------------------------- */
+#define SHF_MLP_BF16 0
+#define SHF_MLP_BF16X3 1
+int shf_mlp_set_precision(int32_t mode);
+int shf_mlp_get_precision(void);
 const char* shf_mlp_last_error(void);
 int shf_mlp_linear_forward(const float* x, const float* w, const float* b, float* y, int32_t M, int32_t K, int32_t N,
                            int32_t act, void* stream);

@@ -46,6 +46,8 @@ _SIGS = {
     "shf_mlp_linear_forward": ([vp, vp, vp, vp, i32, i32, i32, i32, vp], i32),
     "shf_mlp_linear_backward_input": ([vp, vp, vp, vp, i32, i32, i32, vp], i32),
     "shf_mlp_backward_weight_workspace": ([i32, i32, i32, C.POINTER(i64)], i32),
+    "shf_mlp_set_precision": ([i32], i32),
+    "shf_mlp_get_precision": ([], i32),
     "shf_mlp_linear_backward_weight": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], i32),
 }
 EXPORTS = sorted(list(_SIGS) + ["shf_last_error", "shf_mlp_last_error"])

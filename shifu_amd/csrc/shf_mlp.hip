@@ -135,8 +135,11 @@ MLP_DEV void fetch_tile(const Operand& O, int r0, int k0, int red, TileRegs<MASK
 }
 
 template <bool RED_CONTIG, bool VEC, bool MASK, int NE>
-MLP_DEV void commit_tile(const TileRegs<MASK, NE>& T, uint16_t* lds) {
-  const int t = (int)threadIdx.x;
+MLP_DEV void commit_values(const float* v, uint16_t* lds);
+
+// SPLIT: every value goes to LDS twice -- its bf16 head at `lds`, the bf16 of what the head lost at `lds + lo_off`
+template <bool RED_CONTIG, bool VEC, bool MASK, int NE, bool SPLIT>
+MLP_DEV void commit_tile(const TileRegs<MASK, NE>& T, uint16_t* lds, int lo_off) {
   float v[NE];
 #pragma unroll
   for (int j = 0; j < NE; j++) {
@@ -144,6 +147,18 @@ MLP_DEV void commit_tile(const TileRegs<MASK, NE>& T, uint16_t* lds) {
     if (MASK) x *= elu_grad_from_output(T.m[j]);
     v[j] = (T.ok >> j) & 1u ? x : 0.0f;
   }
+  commit_values<RED_CONTIG, VEC, MASK, NE>(v, lds);
+  if (SPLIT) {
+    float w[NE];
+#pragma unroll
+    for (int j = 0; j < NE; j++) w[j] = v[j] - (float)(__bf16)v[j];
+    commit_values<RED_CONTIG, VEC, MASK, NE>(w, lds + lo_off);
+  }
+}
+
+template <bool RED_CONTIG, bool VEC, bool MASK, int NE>
+MLP_DEV void commit_values(const float* v, uint16_t* lds) {
+  const int t = (int)threadIdx.x;
   if (RED_CONTIG && VEC) {
 #pragma unroll
     for (int q = 0; q < NE / 4; q++) {
@@ -181,11 +196,12 @@ struct Epilogue {
 // BMT x 128 output tile per block: BMT = 128 (four waves of 64 x 64) or 64 (four waves of 32 x 64) -- the smaller tile
 // doubles the number of blocks for the skinny layers, whose 128-row grids leave CUs idle (384 blocks on 256 CUs run as
 // two rounds), and halves the registers so that more blocks are resident to hide the HBM latency of the K loop.
-template <int BMT, bool A_RED_CONTIG, bool B_RED_CONTIG, bool COLSUM_A, bool A_VEC, bool B_VEC, bool A_MASK>
+template <int BMT, bool A_RED_CONTIG, bool B_RED_CONTIG, bool COLSUM_A, bool A_VEC, bool B_VEC, bool A_MASK, bool SPLIT>
 __global__ __launch_bounds__(256) void k_mlp_gemm(Operand A, Operand B, int red, int red_per_slice, Epilogue E, int rows, int cols) {
   constexpr int TI = BMT / 64, NEA = BMT / 8;     // MFMA tiles per wave along the rows; A elements per thread and K tile
-  __shared__ __attribute__((aligned(16))) uint16_t As[BMT * LDT];
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[BN * LDT];
+  constexpr int ALO = BMT * LDT, BLO = BN * LDT;  // SPLIT: offsets of the tail tiles behind the head tiles
+  __shared__ __attribute__((aligned(16))) uint16_t As[(SPLIT ? 2 : 1) * BMT * LDT];
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[(SPLIT ? 2 : 1) * BN * LDT];
   MLP_CLOCK(0);
   const int r0 = (int)blockIdx.x * BMT, c0 = (int)blockIdx.y * BN;
   const int red0 = (int)blockIdx.z * red_per_slice;
@@ -217,8 +233,8 @@ __global__ __launch_bounds__(256) void k_mlp_gemm(Operand A, Operand B, int red,
     }
   auto step = [&](int k0, TileRegs<A_MASK, NEA>& xa, TileRegs<false, 16>& xb) {
     lds_barrier();                         // the previous tile's fragment reads are done
-    commit_tile<A_RED_CONTIG, A_VEC, A_MASK, NEA>(xa, As);
-    commit_tile<B_RED_CONTIG, B_VEC, false, 16>(xb, Bs);
+    commit_tile<A_RED_CONTIG, A_VEC, A_MASK, NEA, SPLIT>(xa, As, ALO);
+    commit_tile<B_RED_CONTIG, B_VEC, false, 16, SPLIT>(xb, Bs, BLO);
     lds_barrier();
     if (k0 + PF * BK < red1) {             // this register set is free again: tile k + PF
       fetch_tile<A_RED_CONTIG, A_VEC, A_MASK, NEA>(A, r0, k0 + PF * BK, red1, xa);
@@ -228,7 +244,10 @@ __global__ __launch_bounds__(256) void k_mlp_gemm(Operand A, Operand B, int red,
       // db: sum over the reduction index of the (bf16-rounded) G values of A row t -- the values the MFMA multiplies
       const uint16_t* row = As + threadIdx.x * LDT;
 #pragma unroll
-      for (int k = 0; k < BK; k++) csum += __uint_as_float((uint32_t)row[k] << 16);
+      for (int k = 0; k < BK; k++) {
+        csum += __uint_as_float((uint32_t)row[k] << 16);
+        if (SPLIT) csum += __uint_as_float((uint32_t)row[ALO + k] << 16);
+      }
     }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 16) {
@@ -238,6 +257,21 @@ __global__ __launch_bounds__(256) void k_mlp_gemm(Operand A, Operand B, int red,
 #pragma unroll
       for (int j = 0; j < 2; j++) b[j] = *reinterpret_cast<const bf16x8*>(Bs + (wc + 32 * j + (lane & 31)) * LDT + kk + 8 * (lane >> 5));
 #ifndef SHF_MLP_PROBE_NO_MFMA
+      if (SPLIT) {
+        // the two cross terms first (small), then head * head; tail * tail (2^-18 relative) is dropped
+        bf16x8 al[TI], bl[2];
+#pragma unroll
+        for (int i = 0; i < TI; i++) al[i] = *reinterpret_cast<const bf16x8*>(As + ALO + (wr + 32 * i + (lane & 31)) * LDT + kk + 8 * (lane >> 5));
+#pragma unroll
+        for (int j = 0; j < 2; j++) bl[j] = *reinterpret_cast<const bf16x8*>(Bs + BLO + (wc + 32 * j + (lane & 31)) * LDT + kk + 8 * (lane >> 5));
+#pragma unroll
+        for (int i = 0; i < TI; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], b[j], acc[i][j], 0, 0, 0);
+          }
+      }
 #pragma unroll
       for (int i = 0; i < TI; i++)
 #pragma unroll
@@ -316,10 +350,17 @@ bool vec_ok(const Operand& O, int red, bool red_contig) {
   const int contig_extent = red_contig ? red : O.rows;
   return O.ld % 4 == 0 && contig_extent % 4 == 0 && ((uintptr_t)O.p & 15u) == 0 && (!O.mask_y || ((uintptr_t)O.mask_y & 15u) == 0);
 }
+int g_mlp_precision = SHF_MLP_BF16X3;
 template <int BMT, bool AR, bool BR, bool CS, bool AV, bool BV>
 void launch_gemm_m(dim3 grid, hipStream_t st, const Operand& A, const Operand& B, int red, int per, const Epilogue& E, int rows, int cols) {
-  if (A.mask_y) hipLaunchKernelGGL((k_mlp_gemm<BMT, AR, BR, CS, AV, BV, true>), grid, dim3(256), 0, st, A, B, red, per, E, rows, cols);
-  else hipLaunchKernelGGL((k_mlp_gemm<BMT, AR, BR, CS, AV, BV, false>), grid, dim3(256), 0, st, A, B, red, per, E, rows, cols);
+  const bool split = g_mlp_precision == SHF_MLP_BF16X3;
+  if (A.mask_y) {
+    if (split) hipLaunchKernelGGL((k_mlp_gemm<BMT, AR, BR, CS, AV, BV, true, true>), grid, dim3(256), 0, st, A, B, red, per, E, rows, cols);
+    else hipLaunchKernelGGL((k_mlp_gemm<BMT, AR, BR, CS, AV, BV, true, false>), grid, dim3(256), 0, st, A, B, red, per, E, rows, cols);
+  } else {
+    if (split) hipLaunchKernelGGL((k_mlp_gemm<BMT, AR, BR, CS, AV, BV, false, true>), grid, dim3(256), 0, st, A, B, red, per, E, rows, cols);
+    else hipLaunchKernelGGL((k_mlp_gemm<BMT, AR, BR, CS, AV, BV, false, false>), grid, dim3(256), 0, st, A, B, red, per, E, rows, cols);
+  }
 }
 // rows of the output tile: 64 when the A operand allows it (reduction index contiguous) and 128-row tiles would not give
 // every CU at least three blocks
@@ -357,6 +398,12 @@ extern "C" int shf_mlp_probe_read(long long* out, int n) {
 }
 #endif
 extern "C" const char* shf_mlp_last_error(void) { return g_mlp_err.c_str(); }
+extern "C" int shf_mlp_set_precision(int32_t mode) {
+  if (mode != SHF_MLP_BF16 && mode != SHF_MLP_BF16X3) return mlp_fail("shf_mlp_set_precision: mode must be SHF_MLP_BF16 or SHF_MLP_BF16X3");
+  g_mlp_precision = mode;
+  return 0;
+}
+extern "C" int shf_mlp_get_precision(void) { return g_mlp_precision; }
 
 extern "C" int shf_mlp_linear_forward(const float* x, const float* w, const float* b, float* y, int32_t M, int32_t K, int32_t N,
                                       int32_t act, void* stream) {

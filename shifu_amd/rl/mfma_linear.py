@@ -5,14 +5,43 @@ Operands stay the trainer's fp32 tensors; the kernels convert tiles to bf16 on t
 per layer forward, two per layer backward (+ the deterministic split-M reduction of dW).  `MfmaLinear` has nn.Linear's
 parameters and state_dict keys, so checkpoints are interchangeable with the stock layer.
 
-Precision: bf16 operand rounding (relative 2^-9) with fp32 sums; tests/test_gpu_mlp.py holds every output to the fp32
-torch reference within 2e-2 of the tensor's scale, and the A1 schedule trains to the same tracking rewards."""
+Precision (`set_precision`, env SHIFU_AMD_MFMA_PRECISION): "bf16x3" (default) splits every operand value into a bf16
+head and tail and accumulates three MFMAs per tile pair -- products good to 2^-16, outputs within 1e-4 of the fp32 torch
+reference's scale (tests/test_gpu_mlp.py); "bf16" rounds operands once (2^-9 relative, 2e-2 of scale), one MFMA.  With
+"bf16" two of three 3000-iteration A1 runs lost return late in training (the action-noise std grew faster than with fp32
+layers); "bf16x3" costs a few per cent of the layer time, the layers being HBM-bound."""
+import os
 import ctypes as C
 
 import torch
 import torch.nn as nn
 
 from .._lib import BackendError, lib
+
+
+PRECISIONS = {"bf16": 0, "bf16x3": 1}
+
+
+def set_precision(mode: str) -> None:
+    """Process-wide operand precision of the MFMA layers: "bf16x3" or "bf16" (include/shifu_amd.h SHF_MLP_*)."""
+    _check(lib().shf_mlp_set_precision(PRECISIONS[mode]))
+
+
+def get_precision() -> str:
+    v = lib().shf_mlp_get_precision()
+    return next(k for k, x in PRECISIONS.items() if x == v)
+
+
+_env_precision_applied = False
+
+
+def _apply_env_precision():
+    global _env_precision_applied
+    if not _env_precision_applied:
+        _env_precision_applied = True
+        mode = os.environ.get("SHIFU_AMD_MFMA_PRECISION")
+        if mode:
+            set_precision(mode)
 
 
 def _check(rc):
@@ -73,6 +102,7 @@ class MfmaLinear(nn.Linear):
 
     def forward(self, x):
         if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
+            _apply_env_precision()
             return _MfmaLinearFn.apply(x, self.weight, self.bias, 1 if self.elu else 0)
         y = super().forward(x)
         return nn.functional.elu(y) if self.elu else y

@@ -2,8 +2,10 @@
 the same op -- forward, input gradient, weight / bias gradients -- on the shapes of the A1 ActorCritic
 (259 -> 512 -> 256 -> 128 -> 12 / 1, 24 576-row mini-batches and 4096-row rollout batches) and on ragged ones.
 
-Tolerance: operands are rounded to bf16 (relative 2^-9) and accumulated in fp32, so every output must be within 2e-2 of
-the tensor's largest entry and 3e-3 of it on average; identity / asymmetric-operand checks pin the fragment layouts."""
+Tolerance, by operand precision (shf_mlp_set_precision): "bf16x3" (default: bf16 head + tail, three MFMAs, products good
+to 2^-16) -- every output within 2e-4 of the tensor's largest entry and 2e-5 of it on average; "bf16" (operands rounded
+once, 2^-9) -- 2e-2 / 3e-3.  The torch reference itself runs fp32 library GEMMs whose summation order differs, hence not
+tighter.  Identity / asymmetric-operand checks pin the fragment layouts bit for bit."""
 import numpy as np
 import pytest
 
@@ -16,14 +18,28 @@ def _need_gpu():
         pytest.fail("GPU test selected but no GPU is visible")
 
 
-def _close(got, ref, what):
+TOL = {"bf16x3": (2e-4, 2e-5), "bf16": (2e-2, 3e-3)}
+
+
+def _close(got, ref, what, mode="bf16x3"):
     scale = float(ref.abs().max()) + 1e-12
     err = (got - ref).abs()
-    assert float(err.max()) <= 2e-2 * scale, f"{what}: max err {float(err.max()):.3g} vs scale {scale:.3g}"
-    assert float(err.mean()) <= 3e-3 * scale, f"{what}: mean err {float(err.mean()):.3g} vs scale {scale:.3g}"
+    tmax, tmean = TOL[mode]
+    assert float(err.max()) <= tmax * scale, f"{what} [{mode}]: max err {float(err.max()):.3g} vs scale {scale:.3g}"
+    assert float(err.mean()) <= tmean * scale, f"{what} [{mode}]: mean err {float(err.mean()):.3g} vs scale {scale:.3g}"
 
 
-def test_identity_and_asymmetric_operands_pin_the_fragment_layout():
+@pytest.fixture(params=["bf16x3", "bf16"])
+def precision(request):
+    from shifu_amd.rl import mfma_linear
+    _need_gpu()
+    before = mfma_linear.get_precision()
+    mfma_linear.set_precision(request.param)
+    yield request.param
+    mfma_linear.set_precision(before)
+
+
+def test_identity_and_asymmetric_operands_pin_the_fragment_layout(precision):
     _need_gpu()
     from shifu_amd.rl.mfma_linear import MfmaLinear
     dev = "cuda:0"
@@ -43,7 +59,7 @@ def test_identity_and_asymmetric_operands_pin_the_fragment_layout():
 
 @pytest.mark.parametrize("M,K,N,elu", [(24576, 259, 512, True), (24576, 512, 256, True), (4096, 256, 128, True),
                                        (24576, 128, 12, False), (24576, 128, 1, False), (50, 259, 512, True), (1000, 37, 5, True)])
-def test_forward_and_backward_match_the_fp32_reference(M, K, N, elu):
+def test_forward_and_backward_match_the_fp32_reference(M, K, N, elu, precision):
     _need_gpu()
     from shifu_amd.rl.mfma_linear import MfmaLinear
     torch.manual_seed(0)
@@ -57,13 +73,13 @@ def test_forward_and_backward_match_the_fp32_reference(M, K, N, elu):
     yr = ref(x2)
     if elu:
         yr = torch.nn.functional.elu(yr)
-    _close(y, yr, "forward")
+    _close(y, yr, "forward", precision)
     g = torch.randn(M, N, device=dev)
     y.backward(g)
     yr.backward(g)
-    _close(x1.grad, x2.grad, "input gradient")
-    _close(lin.weight.grad, ref.weight.grad, "weight gradient")
-    _close(lin.bias.grad, ref.bias.grad, "bias gradient")
+    _close(x1.grad, x2.grad, "input gradient", precision)
+    _close(lin.weight.grad, ref.weight.grad, "weight gradient", precision)
+    _close(lin.bias.grad, ref.bias.grad, "bias gradient", precision)
 
 
 def test_actor_critic_on_the_mfma_backend_matches_the_torch_backend_and_trains():
@@ -75,7 +91,7 @@ def test_actor_critic_on_the_mfma_backend_matches_the_torch_backend_and_trains()
     assert list(a.state_dict().keys()) == list(b.state_dict().keys())       # rsl_rl's parameter names either way
     b.load_state_dict(a.state_dict())
     obs = torch.randn(4096, 259, device="cuda:0")
-    _close(a.act_inference(obs), b.act_inference(obs), "actor")
+    _close(a.act_inference(obs), b.act_inference(obs), "actor")         # four layers deep, default precision (bf16x3)
     _close(a.evaluate(obs), b.evaluate(obs), "critic")
     # a few Adam steps on a regression target: the loss falls on the MFMA backend as on the fp32 one
     tgt = torch.tanh(obs[:, :12])
