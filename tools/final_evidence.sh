@@ -1,0 +1,24 @@
+#!/bin/bash
+# On the GPU box (gpurun): everything the round's numbers are quoted from, in one pass -> gpurun_out/final/.
+# Afterwards (here): copy bench_*.json to profiles/r02_bench_*.json, run tools/summarize_prof.py on the two prof_* dirs.
+set -u
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/final
+mkdir -p "$OUT"
+cd "$REPO"
+python -m pytest tests -m gpu -q 2>&1 | tail -3 > "$OUT/pytest_gpu.txt"
+python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.txt" 2>&1
+for W in terrain flat trimesh abb; do
+  python bench.py --workload $W --steps 500 --warmup 50 > "$OUT/bench_$W.json" 2> "$OUT/bench_$W.err"
+done
+python bench.py --self-collision --steps 500 --warmup 50 --no-cpu-baseline > "$OUT/bench_terrain_selfcollision.json" 2>/dev/null
+python bench.py --steps 20 --warmup 5 > "$OUT/bench_terrain_driver_shape.json" 2>/dev/null
+python bench.py --graph --steps 500 --warmup 50 --no-cpu-baseline > "$OUT/bench_terrain_graph.json" 2>/dev/null
+python tools/phase_clock.py 32 200 > "$OUT/phase_a1.txt" 2>&1
+python tools/phase_clock.py 16 200 --abb > "$OUT/phase_abb.txt" 2>&1
+bash tools/profile.sh r02_a1 > /dev/null 2>&1
+bash tools/profile.sh abb --workload abb > /dev/null 2>&1
+find "$REPO/gpurun_out" -name "*kernel_trace.csv" -size +4M -delete     # keep the merge under gpurun's 64 MiB
+cat "$OUT/pytest_gpu.txt"; tail -2 "$OUT/smoke.txt"
+for W in terrain flat trimesh abb terrain_selfcollision terrain_driver_shape terrain_graph; do tail -1 "$OUT/bench_$W.json" | cut -c1-260; done
+du -sh "$REPO/gpurun_out"
