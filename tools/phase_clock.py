@@ -35,6 +35,10 @@ def main():
     argv = [a for a in sys.argv if a != "--abb"]
     G = int(argv[1]) if len(argv) > 1 else 32
     steps = int(argv[2]) if len(argv) > 2 else 100
+    from shifu_amd import build as b
+    deps = [os.path.join(b.CSRC, d) for d in b.DEPS]
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps):
+        build()                                  # a stale debug library would miss symbols the product library has
     os.environ["SHIFU_AMD_LIB"] = LIB
     import torch
     from shifu_amd import _lib
