@@ -84,7 +84,7 @@ class OnPolicyRunner:
                     alg.storage.clear()
                 if graph is not None:
                     graph.replay()
-                    torch.cuda.synchronize()      # work queued behind a graph launch can overtake its tail on this ROCm build (rl/ppo.py)
+                    torch.cuda.synchronize()      # same precaution as after the captured update's replays (rl/ppo.py)
                 else:
                     R["ep_infos"].clear()
                     self._rollout(R)

@@ -135,13 +135,13 @@ def test_two_rank_training_keeps_parameters_in_sync(tmp_path):
     assert rec["samples_per_s"] > 0 and all(np.isfinite(rec["param_checksum"]))
 
 
-def _ppo_with_filled_storage(seed, graph_update):
-    """A PPO trainer on the MFMA backend whose rollout buffer holds a synthetic rollout (256 envs x 24 steps)."""
+def _ppo_with_filled_storage(seed, graph_update, backend="mfma"):
+    """A PPO trainer whose rollout buffer holds a synthetic rollout (256 envs x 24 steps)."""
     from shifu_amd.rl.actor_critic import ActorCritic
     from shifu_amd.rl.ppo import PPO
     torch.manual_seed(seed)
     dev = "cuda:0"
-    ac = ActorCritic(259, 259, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128], mlp_backend="mfma")
+    ac = ActorCritic(259, 259, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128], mlp_backend=backend)
     alg = PPO(ac, num_learning_epochs=2, num_mini_batches=4, schedule="adaptive", desired_kl=0.01, learning_rate=1e-3,
               entropy_coef=0.01, device=dev, graph_update=graph_update)
     alg.init_storage(256, 24, [259], [259], [12])
@@ -160,13 +160,14 @@ def _ppo_with_filled_storage(seed, graph_update):
     return alg, fill
 
 
-def test_captured_update_equals_the_eager_update():
+@pytest.mark.parametrize("backend", ["mfma", "torch"])
+def test_captured_update_equals_the_eager_update(backend):
     """PPO.graph_update replays one captured hipGraph per mini-batch step; parameters, optimizer state and learning rate
-    after three updates must be bit-identical to the eagerly launched ones."""
+    after three updates must be bit-identical to the eagerly launched ones -- with the MFMA layers and with the stock ones."""
     _need_gpu()
     res = []
     for graph in (False, True):
-        alg, fill = _ppo_with_filled_storage(3, graph)
+        alg, fill = _ppo_with_filled_storage(3, graph, backend)
         for it in range(3):
             fill(100 + it)
             torch.manual_seed(7 + it)               # the mini-batch permutation

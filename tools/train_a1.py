@@ -48,7 +48,7 @@ def main():
     from shifu_amd.runner.utils import class_to_dict, set_seed
     cfg = class_to_dict(A1PPOConfig())
     cfg["runner"]["graph_rollout"] = args.graph
-    cfg["algorithm"]["graph_update"] = (args.graph or args.graph_update) and not args.eager_update   # with --mlp mfma only (PPO.graph_update)
+    cfg["algorithm"]["graph_update"] = (args.graph or args.graph_update) and not args.eager_update   # PPO.graph_update
     if args.mlp:
         cfg["policy"]["mlp_backend"] = args.mlp
     set_seed((A1PPOConfig.seed if args.seed is None else args.seed) + rank)
