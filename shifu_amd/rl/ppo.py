@@ -175,14 +175,22 @@ class PPO:
                     self._upd_idx.copy_(perm[i * mb:(i + 1) * mb])
                     self._upd_graph.replay()
                     # Replayed back to back, the captured update is NOT equivalent to the eager one on this stack
-                    # (ROCm 7.2 / torch 2.10): parameters drift from the first iterations on, reproducibly per box, with
-                    # the MFMA layers and with the stock library GEMMs alike (round 1's "corrupted captured update").
-                    # With a host wait after every replay it is identical to the bit (tests/test_gpu_mlp.py, and the
-                    # real schedule: profiles/r02_mlp_probe.md).  Small graphs do not show it
-                    # (tools/hipgraph_order_probe.py: linear and fork-join chains replay correctly back to back), so the
-                    # cause is not pinned down; the wait costs no throughput, the host having nothing else to do.
-                    if os.environ.get("SHIFU_AMD_NO_REPLAY_WAIT", "0") != "1":       # (experiments: reproduce the drift)
+                    # (ROCm 7.2 / torch 2.10): parameters drift from the first iterations on, differently from run to
+                    # run, with the MFMA layers and with the stock library GEMMs alike (round 1's "corrupted captured
+                    # update").  A device-wide wait after every replay makes it identical to the bit
+                    # (tests/test_gpu_mlp.py; the 3000-iteration schedule reproduces the eager run's final return digit
+                    # for digit); waiting on an event recorded on the launch stream behind the replay does NOT -- so part
+                    # of this graph's work is not ordered before later work on the launch stream.  Minimal graphs do not
+                    # show it (tools/hipgraph_order_probe.py).  SHIFU_AMD_REPLAY_MODE=none|event|kernel reproduces the
+                    # experiments of profiles/r02_mlp_probe.md.  The wait costs no throughput: the host has nothing else
+                    # to do here.
+                    mode = os.environ.get("SHIFU_AMD_REPLAY_MODE", "wait")           # (experiments, profiles/r02_mlp_probe.md)
+                    if mode == "wait":
                         torch.cuda.synchronize()
+                    elif mode == "event":
+                        ev = torch.cuda.Event(); ev.record(); ev.synchronize()
+                    elif mode == "kernel":
+                        self._upd_sums.add_(0.0)
                 else:
                     self.optimizer.zero_grad(set_to_none=True)
                     self._minibatch_step(st.mini_batch(perm[i * mb:(i + 1) * mb]), sums)
