@@ -219,7 +219,7 @@ def main():
     ap.add_argument("--self-collision", action="store_true",
                     help="A1 workloads: collide the robot's own links (capsule pairs; the reference's collision filter 0, "
                          "units.py:68) -- off in the headline configuration, whose BASELINE entry names height-field contact")
-    ap.add_argument("--graph", action="store_true", help="replay the vec-step from a captured hipGraph instead of launching it "
+    ap.add_argument("--graph", action="store_true", help="(experiments: slower, and back-to-back graph replays are not trustworthy on this stack, profiles/r02_mlp_probe.md) replay the vec-step from a captured hipGraph instead of launching it "
                     "eagerly (measured slower on ROCm 7.2: 84.7 vs 73.9 us per vec-step, profiles/r02_bench_*.json)")
     ap.add_argument("--decimation", type=int, default=4, help="(experiments only) control.decimation")
     ap.add_argument("--no-extra-substep", action="store_true", help="(experiments only) drop the Q1 sub-step")
