@@ -53,3 +53,20 @@ def root_row(pos, quat=(0, 0, 0, 1), lin=(0, 0, 0), ang=(0, 0, 0), dtype=np.floa
 G = 9.81
 # contact parameters of shifu_amd.backend.default_sim_params (what every env in this repo runs with)
 K_N, D_N, V_EPS, DT = 5e4, 300.0, 0.002, 0.005
+
+
+PUSHER_URDF = """<robot name="pusher"><link name="rail"/>
+ <link name="pusher"><inertial><mass value="5.0"/><inertia ixx="0.05" ixy="0" ixz="0" iyy="0.05" iyz="0" izz="0.05"/></inertial></link>
+ <joint name="slide" type="prismatic"><parent link="rail"/><child link="pusher"/><axis xyz="1 0 0"/>
+  <limit effort="200" lower="-1" upper="1" velocity="10"/></joint></robot>"""
+
+
+def pusher_model(yaw=0.0, z=0.05, half=0.1, r=0.02, kd=2000.0):
+    """A rail-mounted slider carrying one horizontal capsule (axis along y, turned by `yaw` about z) at height z: the
+    capsule-vs-box slot in its simplest setting.  Velocity drive on the slide."""
+    c, s = np.cos(yaw), np.sin(yaw)
+    a, b = (half * s, -half * c, z), (-half * s, half * c, z)
+    cm = _compile(PUSHER_URDF, fix_base_link=True, disable_gravity=True, default_dof_drive_mode=_abi.DOF_MODE_VEL,
+                  extra_spheres=[("pusher", a, b, r)])
+    cm.blob.kd[0] = kd
+    return cm
