@@ -684,3 +684,19 @@ def test_config5_full_size_is_deterministic_and_shard_invariant():
                 assert torch.equal(v, full[:, r * v.shape[1]:(r + 1) * v.shape[1]]), f"rank {r} tensor {k}"
             else:
                 raise AssertionError(f"unexpected layout for tensor {k}: {tuple(full.shape)} vs {tuple(v.shape)}")
+
+
+def test_mesh_collider_model_steps_bit_exact_on_the_gpu(oracle, tmp_path):
+    """SURVEY 8f f3, mesh shapes: a link whose collision geometry is an STL (convex hull -> eight sample points, hull-derived
+    inertia; shifu_amd/model.py) tumbles onto the ground on the HIP path exactly as in the oracle, and comes to rest."""
+    _need_gpu()
+    from shifu_amd.model import compile_urdf
+    from tests.test_model import MESH_URDF, _write_box_stl
+    _write_box_stl(tmp_path / "box.stl", (0.3, 0.2, 0.1))
+    (tmp_path / "m.urdf").write_text(MESH_URDF.format(inertial="", geom='<mesh filename="box.stl"/>'))
+    cm = compile_urdf(str(tmp_path / "m.urdf"))
+    assert cm.blob.np == 8
+    from tests import kat_models as K
+    q = np.array([0.3, 0.2, 0.1, 0.92]); q /= np.linalg.norm(q)
+    tr, _ = _kat_run(oracle, cm, H.sim_params(), np.zeros((0, 2), np.float32), K.root_row((0, 0, 0.4), quat=q, ang=(1.0, -2.0, 0.5)), 500)
+    assert np.abs(tr[-1, 7:13]).max() < 5e-3 and 0.04 < tr[-1, 2] < 0.2          # at rest on one of its faces
