@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SHF_ABI_VERSION 4
+#define SHF_ABI_VERSION 5
 
 #define SHF_MAX_BODIES 32 /* reported rigid bodies per articulation        */
 #define SHF_MAX_DOFS 32
@@ -168,8 +168,10 @@ typedef struct ShfTerrain {
    *    and, where a step is steeper than slope_threshold, vertices shifted by one cell
    *    so that the riser is vertical.  SHF_T_HEIGHTS then carries, after the rows*cols
    *    int16 samples, rows*cols bytes: bits 0-1 dx+1, bits 2-3 dy+1 (shift of the vertex
-   *    in cells), bit 7 set when no vertex of the 4x4 neighbourhood of the cell whose
-   *    lower corner this is has moved (the query then needs that one cell only).        */
+   *    in cells); bits 4-7: for the cell whose lower corner the vertex is, the rows /
+   *    columns of cells a query inside it searches besides the cell itself -- bit 4 row
+   *    i-1, bit 5 row i+1, bit 6 column j-1, bit 7 column j+1 (set where a triangle of a
+   *    neighbouring cell reaches into this one; none set: that one cell only).           */
   int32_t warped;
 } ShfTerrain;
 

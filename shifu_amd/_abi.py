@@ -1,7 +1,7 @@
 """ctypes mirrors of the PODs in include/shifu_amd.h (keep in lock-step)."""
 import ctypes as C
 
-SHF_ABI_VERSION = 4
+SHF_ABI_VERSION = 5
 MAX_BODIES = 32
 MAX_DOFS = 32
 MAX_POINTS = 96

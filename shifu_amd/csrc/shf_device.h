@@ -175,16 +175,17 @@ DEV void warped_triangle(float px, float py, float hs, const float* P0, const fl
 DEV void terrain_query_heightfield(const TerrainDev& T, float x, float y, float* h, float* n);
 
 // ShfTerrain.warped: the trimesh convert_heightfield_to_trimesh makes of the samples; vertex shifts in
-// the bytes after the samples.  One cell when nothing nearby moved, else the 3 x 3 cells around the point.
+// the bytes after the samples, with the per-cell search range (one cell where no neighbour reaches in, up to 3 x 3).
 DEV void terrain_query_warped(const TerrainDev& T, float x, float y, float* h, float* n) {
   const int rows = T.t.rows, cols = T.t.cols;
   const uint8_t* W = reinterpret_cast<const uint8_t*>(T.h + (size_t)rows * cols);
   const float hs = T.t.hscale, inv = 1.0f / hs, vs = T.t.vscale;
   const float fx = (x + T.t.border) * inv, fy = (y + T.t.border) * inv;
   const int i0 = (int)rclampf(floorf(fx), 0.0f, (float)(rows - 2)), j0 = (int)rclampf(floorf(fy), 0.0f, (float)(cols - 2));
-  const bool plain = (W[(size_t)i0 * cols + j0] & 0x80) != 0;
-  const int ilo = plain ? i0 : (i0 > 0 ? i0 - 1 : 0), ihi = plain ? i0 : (i0 < rows - 2 ? i0 + 1 : rows - 2);
-  const int jlo = plain ? j0 : (j0 > 0 ? j0 - 1 : 0), jhi = plain ? j0 : (j0 < cols - 2 ? j0 + 1 : cols - 2);
+  // search range: the cell, plus the neighbouring rows / columns its hint bits ask for (include/shifu_amd.h)
+  const int wc = W[(size_t)i0 * cols + j0];
+  const int ilo = ((wc >> 4) & 1) && i0 > 0 ? i0 - 1 : i0, ihi = ((wc >> 5) & 1) && i0 < rows - 2 ? i0 + 1 : i0;
+  const int jlo = ((wc >> 6) & 1) && j0 > 0 ? j0 - 1 : j0, jhi = ((wc >> 7) & 1) && j0 < cols - 2 ? j0 + 1 : j0;
   float best = 0.0f, bn[3] = {0.0f, 0.0f, 1.0f};
   bool found = false;
   for (int i = ilo; i <= ihi; i++)

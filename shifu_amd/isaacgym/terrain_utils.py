@@ -130,7 +130,8 @@ def vertex_shifts(height_field_raw, horizontal_scale, vertical_scale, slope_thre
 
 def trimesh_warp_map(height_field_raw, horizontal_scale, vertical_scale, slope_threshold=None):
     """The per-vertex byte the backend collides a trimesh terrain with (include/shifu_amd.h, ShfTerrain.warped):
-    bits 0-1 dx+1, bits 2-3 dy+1, bit 7 = no vertex of the surrounding 4x4 block moved (one-cell query)."""
+    bits 0-1 dx+1, bits 2-3 dy+1, bits 4-7 = which neighbouring rows / columns of cells a query has to search
+    (warp_map_from_shifts)."""
     hf = np.asarray(height_field_raw)
     rows, cols = hf.shape
     if slope_threshold is None:
@@ -141,16 +142,43 @@ def trimesh_warp_map(height_field_raw, horizontal_scale, vertical_scale, slope_t
 
 
 def warp_map_from_shifts(dx, dy):
-    """Per-vertex bytes (see trimesh_warp_map) from explicit vertex shifts in cells."""
-    dx, dy = np.asarray(dx), np.asarray(dy)
+    """Per-vertex bytes (see trimesh_warp_map) from explicit vertex shifts in cells: bits 0-1 dx+1, bits 2-3 dy+1, and
+    for the cell whose lower corner the vertex is, which neighbouring rows / columns of cells a query inside that cell has
+    to search besides the cell itself: bit 4 row i-1, bit 5 row i+1, bit 6 column j-1, bit 7 column j+1.  A neighbour row
+    (column) is needed when a triangle of one of its three cells next to this one reaches into the cell's square -- its
+    bounding box overlaps the open square, or touches the closed one with a vertex that was moved (a riser standing
+    exactly on the cell boundary).  Unmoved neighbours only touch along the shared edge, where the surface is the cell's
+    own."""
+    dx, dy = np.asarray(dx).astype(np.int64), np.asarray(dy).astype(np.int64)
     rows, cols = dx.shape
+    R, C = rows - 1, cols - 1
+    X = np.arange(rows)[:, None] + dx
+    Y = np.arange(cols)[None, :] + dy
     moved = (dx != 0) | (dy != 0)
-    pad = np.pad(moved, ((1, 2), (1, 2)), mode="constant")
-    near = np.zeros((rows, cols), bool)
-    for a in range(4):
-        for b in range(4):
-            near |= pad[a:a + rows, b:b + cols]
-    w = (dx.astype(np.int64) + 1) | ((dy.astype(np.int64) + 1) << 2) | ((~near).astype(np.int64) << 7)
+    s00, s10 = (slice(0, R), slice(0, C)), (slice(1, R + 1), slice(0, C))
+    s01, s11 = (slice(0, R), slice(1, C + 1)), (slice(1, R + 1), slice(1, C + 1))
+    tris = []
+    for vs in ((s00, s11, s01), (s00, s10, s11)):             # the two triangles of a cell
+        xs, ys = np.stack([X[v] for v in vs]), np.stack([Y[v] for v in vs])
+        tris.append((xs.min(0), xs.max(0), ys.min(0), ys.max(0), np.stack([moved[v] for v in vs]).any(0)))
+    I, J = np.arange(R)[:, None], np.arange(C)[None, :]
+    need = np.zeros((3, 3, R, C), bool)
+    for a in (-1, 0, 1):
+        for b in (-1, 0, 1):
+            if a == 0 and b == 0:
+                continue
+            ci, cj = np.clip(I + a, 0, R - 1), np.clip(J + b, 0, C - 1)
+            valid = (I + a >= 0) & (I + a < R) & (J + b >= 0) & (J + b < C)
+            ov = np.zeros((R, C), bool)
+            for x0, x1, y0, y1, mv in tris:
+                x0, x1, y0, y1, mv = x0[ci, cj], x1[ci, cj], y0[ci, cj], y1[ci, cj], mv[ci, cj]
+                ov |= (x0 < I + 1) & (x1 > I) & (y0 < J + 1) & (y1 > J)
+                ov |= mv & (x0 <= I + 1) & (x1 >= I) & (y0 <= J + 1) & (y1 >= J)
+            need[a + 1, b + 1] = valid & ov
+    hint = np.zeros((rows, cols), np.int64)
+    hint[:R, :C] = (need[0].any(0).astype(np.int64) << 4) | (need[2].any(0).astype(np.int64) << 5) | \
+                   (need[:, 0].any(0).astype(np.int64) << 6) | (need[:, 2].any(0).astype(np.int64) << 7)
+    w = (dx + 1) | ((dy + 1) << 2) | hint
     return w.astype(np.uint8)
 
 

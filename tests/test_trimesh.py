@@ -48,11 +48,35 @@ def test_warp_map_reproduces_the_mesh_vertices():
     np.testing.assert_allclose(v[:, 0].reshape(14, 11), (ii + dx) * HS, atol=1e-6)
     np.testing.assert_allclose(v[:, 1].reshape(14, 11), (jj + dy) * HS, atol=1e-6)
     assert (dx != 0).any() and (dy != 0).any()
+    # bits 4-7: the rows / columns of neighbouring cells a query inside cell (i, j) has to search.  Conservative: every
+    # neighbour triangle that covers a point strictly inside the cell has its row and column flagged; tight: nothing is
+    # flagged where no vertex of the 4 x 4 neighbourhood moved.
     moved = (dx != 0) | (dy != 0)
-    plain = (w & 0x80) != 0
-    for i in range(14):
-        for j in range(11):
-            assert plain[i, j] == (not moved[max(i - 1, 0):i + 3, max(j - 1, 0):j + 3].any())
+    X, Y = ii + dx, jj + dy
+    fr = np.linspace(0.04, 0.96, 9)
+    for i in range(13):
+        for j in range(10):
+            hint = int(w[i, j]) >> 4
+            if not moved[max(i - 1, 0):i + 3, max(j - 1, 0):j + 3].any():
+                assert hint == 0, (i, j, hint)
+            px, py = np.meshgrid(i + fr, j + fr, indexing="ij")
+            for a in (-1, 0, 1):
+                for b in (-1, 0, 1):
+                    ci, cj = i + a, j + b
+                    if (a == 0 and b == 0) or not (0 <= ci < 13 and 0 <= cj < 10):
+                        continue
+                    covers = False
+                    for vs in (((ci, cj), (ci + 1, cj + 1), (ci, cj + 1)), ((ci, cj), (ci + 1, cj), (ci + 1, cj + 1))):
+                        (x0, y0), (x1, y1), (x2, y2) = [(X[v], Y[v]) for v in vs]
+                        d = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0)
+                        if abs(d) < 1e-12:
+                            continue
+                        l1 = ((px - x0) * (y2 - y0) - (x2 - x0) * (py - y0)) / d
+                        l2 = ((x1 - x0) * (py - y0) - (px - x0) * (y1 - y0)) / d
+                        covers |= bool(((l1 >= 0) & (l2 >= 0) & (l1 + l2 <= 1)).any())
+                    if covers:
+                        need = (1 if a == -1 else 2 if a == 1 else 0) | (4 if b == -1 else 8 if b == 1 else 0)
+                        assert hint & need == need, (i, j, a, b, hint)
 
 
 @pytest.mark.parametrize("threshold", [None, 0.75])
@@ -61,7 +85,7 @@ def test_warped_query_equals_the_explicit_mesh(threshold):
     hf = (rng.integers(0, 5, (13, 12)) * 18).astype(np.int16)
     v, tris = tu.convert_heightfield_to_trimesh(hf, HS, VS, threshold)
     packed = tu.pack_trimesh_samples(hf, tu.trimesh_warp_map(hf, HS, VS, threshold))
-    pts = np.stack([rng.uniform(0.2, 1.0, 400), rng.uniform(0.2, 0.9, 400)], 1)     # border vertices may move inwards
+    pts = np.stack([rng.uniform(0.2, 1.0, 6000), rng.uniform(0.2, 0.9, 6000)], 1)   # border vertices may move inwards
     want = _brute_force(v, tris, pts)
     h64, n64 = pyoracle.terrain_query(_terrain(hf), packed, pts, f64=True)
     h32, n32 = pyoracle.terrain_query(_terrain(hf), packed, pts)
