@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256) void k_mlp_gemm(Operand A, Operand B, int red,
       fetch_tile<A_RED_CONTIG, A_VEC, A_MASK, NEA>(A, r0, k0 + PF * BK, red1, xa);
       fetch_tile<B_RED_CONTIG, B_VEC, false, 16>(B, c0, k0 + PF * BK, red1, xb);
     }
+#ifndef SHF_MLP_PROBE_NO_COLSUM
     if (COLSUM_A && blockIdx.y == 0 && threadIdx.x < BMT) {
       // db: sum over the reduction index of the (bf16-rounded) G values of A row t -- the values the MFMA multiplies
       const uint16_t* row = As + threadIdx.x * LDT;
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(256) void k_mlp_gemm(Operand A, Operand B, int red,
         if (SPLIT) csum += __uint_as_float((uint32_t)row[ALO + k] << 16);
       }
     }
+#endif
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 16) {
       bf16x8 a[TI], b[2];
