@@ -29,6 +29,8 @@ def main():
                     help="ActorCritic layers: stock fp32 library GEMMs, or the hand-written MFMA kernels (csrc/shf_mlp.hip)")
     ap.add_argument("--eager-update", action="store_true", help="with --graph: capture the rollout only, launch the PPO update eagerly")
     ap.add_argument("--graph-update", action="store_true", help="capture the PPO update only (debugging)")
+    ap.add_argument("--terrain", default="heightfield", choices=["heightfield", "trimesh", "flat"],
+                    help="terrain collision form (trimesh = what the reference's A1EnvConfig effectively builds, SURVEY Q5)")
     ap.add_argument("--seed", type=int, default=None, help="override A1PPOConfig.seed")
     ap.add_argument("--self-collision", action="store_true", help="collide the robot's own links (reference collision filter 0)")
     args = ap.parse_args()
@@ -61,6 +63,7 @@ def main():
     else:
         from shifu_amd.gym.a1_fused import FusedA1Env
         env = FusedA1Env(num_envs=args.envs, device=dev, rank=rank, world_size=world, self_collision=args.self_collision,
+                         terrain=args.terrain,
                          **({} if args.seed is None else {"seed": args.seed}))
     log_dir = args.log or os.path.join("gpurun_out", "train_a1")
     runner = OnPolicyRunner(env, cfg, log_dir=log_dir, device=str(dev))
