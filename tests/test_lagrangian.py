@@ -102,5 +102,6 @@ def test_aba_matches_the_lagrangian_manipulator_equation(oracle, tmp_path):
         M, b = f(q, qd)
         want = np.linalg.solve(np.array(M, float), tau - np.array(b, float).reshape(-1))
         got, _ = oracle.accel(m, sp_, np.stack([q, qd], 1).reshape(-1), root, tau, f64=True)
-        # ShfModel holds its constants (frames, masses, inertia tensors) as float32: agreement to that precision
-        np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-6)
+        # ShfModel holds its constants (frames, masses, inertia tensors) as float32: agreement to that precision,
+        # relative to the largest acceleration of the state (the light last link reaches thousands of rad/s^2)
+        assert np.abs(got - want).max() <= 2e-7 * (1.0 + np.abs(want).max()), (got, want)
