@@ -109,3 +109,33 @@ def test_steep_step_becomes_a_vertical_riser():
     # the height field of the same samples has a 63-degree ramp there instead
     hh, _ = pyoracle.terrain_query(_terrain(hf, warped=0), hf, pts, f64=True)
     assert 0.05 < hh[1] < 0.15 and hh[0] == 0 and hh[-1] == pytest.approx(0.2)
+
+
+def test_heightfield_query_equals_its_explicit_triangulation():
+    """gym.add_heightfield's surface (isaac_gym.py:350-367): cells split along (i+1, j)-(i, j+1) -- the oracle's
+    height-field query (heights and unit normals) against a brute-force evaluation of that explicit triangle mesh."""
+    rng = np.random.default_rng(5)
+    hf = (rng.integers(-6, 7, (15, 13)) * 9).astype(np.int16)
+    rows, cols = hf.shape
+    X, Y = np.meshgrid(np.arange(rows) * HS, np.arange(cols) * HS, indexing="ij")
+    V = np.stack([X, Y, hf * VS], -1).reshape(-1, 3)
+    idx = lambda i, j: i * cols + j
+    tris = []
+    for i in range(rows - 1):
+        for j in range(cols - 1):
+            tris.append((idx(i, j), idx(i + 1, j), idx(i, j + 1)))             # lower: u + v <= 1
+            tris.append((idx(i + 1, j + 1), idx(i, j + 1), idx(i + 1, j)))     # upper
+    pts = np.stack([rng.uniform(0.02, (rows - 1) * HS - 0.02, 5000), rng.uniform(0.02, (cols - 1) * HS - 0.02, 5000)], 1)
+    want = _brute_force(V, np.array(tris), pts)
+    h, n = pyoracle.terrain_query(_terrain(hf, warped=0), hf, pts, f64=True)
+    np.testing.assert_allclose(h, want, atol=1e-6)          # (hscale / vscale are float32 in ShfTerrain)
+    # normals: of the triangle under the point
+    i = np.floor(pts[:, 0] / HS).astype(int); j = np.floor(pts[:, 1] / HS).astype(int)
+    u, v = pts[:, 0] / HS - i, pts[:, 1] / HS - j
+    lo = u + v <= 1
+    z = hf.astype(float) * VS
+    gx = np.where(lo, z[i + 1, j] - z[i, j], z[i + 1, j + 1] - z[i, j + 1]) / HS
+    gy = np.where(lo, z[i, j + 1] - z[i, j], z[i + 1, j + 1] - z[i + 1, j]) / HS
+    nn = np.stack([-gx, -gy, np.ones_like(gx)], 1); nn /= np.linalg.norm(nn, axis=1, keepdims=True)
+    edge = np.abs(u + v - 1) < 1e-3                          # on the diagonal either triangle may answer
+    np.testing.assert_allclose(n[~edge], nn[~edge], atol=2e-6)
