@@ -116,6 +116,17 @@ DEV void slot_force(const float* o, const float* ab, float sign, float dt, float
 }
 
 DEV float pair_scale(const ShfBoxDesc& b, const float* o, float dt) { return b.mass / fmaf(dt, o[PT_BN], b.mass); }
+// One side's view of a pair slot (oracle: pair_side): the slot's f0 was linearised about both bodies' gravity-predicted
+// velocities; each side corrects only its own prediction through its implicit term, so it takes the OTHER body's out again:
+// f0 + sign dt K g.  Arm side: sign -1, g = the box's gravity; box side: sign +1, g = the articulation's.
+DEV void pair_side(const float* o, float dt, const float* g, float sign, float* s) {
+#pragma unroll
+  for (int k = 0; k < PT_STRIDE; k++) s[k] = o[k];
+  const float n[3] = {o[PT_N], o[PT_N + 1], o[PT_N + 2]};
+  const float gn = dot3(n, g);
+#pragma unroll
+  for (int k = 0; k < 3; k++) s[PT_F + k] = fmaf(sign * dt, fmaf(o[PT_BN] - o[PT_CT], gn * n[k], o[PT_CT] * g[k]), o[PT_F + k]);
+}
 
 DEV bool point_in_box(const float* bR, const float* bpos, const float* h, const float* r, float* phi, float* n) {
   const float rel[3] = {r[0] - bpos[0], r[1] - bpos[1], r[2] - bpos[2]};
@@ -569,8 +580,9 @@ DEV void boxes_contacts_fixed(const StepCtx& C, const EnvLds& L, int l, BodyRegs
     while (bits) {
       const int si = __builtin_ctz(bits);
       bits &= bits - 1u;
-      const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
-      slot_accumulate(B.IA, B.pA, o, 1.0f, dt, pair_scale(bd, o, dt));
+      float oa[PT_STRIDE];
+      pair_side(L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, gb, -1.0f, oa);
+      slot_accumulate(B.IA, B.pA, oa, 1.0f, dt, pair_scale(bd, oa, dt));
     }
   }
   if (l == nb + kd) {
@@ -584,7 +596,9 @@ DEV void boxes_contacts_fixed(const StepCtx& C, const EnvLds& L, int l, BodyRegs
     while (sb) {
       const int si = __builtin_ctz(sb);
       sb &= sb - 1u;
-      slot_accumulate(B.IA, B.pA, L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, -1.0f, dt, 1.0f);
+      float ob[PT_STRIDE];
+      pair_side(L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, g_art, 1.0f, ob);
+      slot_accumulate(B.IA, B.pA, ob, -1.0f, dt, 1.0f);
     }
   }
   PHASE_MARK(19);
@@ -675,8 +689,9 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
     while (bits) {
       const int j = __builtin_ctz(bits), si = j / SHF_MAX_BOXES, kd = j % SHF_MAX_BOXES;
       bits &= bits - 1u;
-      const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
-      slot_accumulate(B.IA, B.pA, o, 1.0f, dt, pair_scale(S->box[kd], o, dt));
+      float oa[PT_STRIDE];
+      pair_side(L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, gb, -1.0f, oa);
+      slot_accumulate(B.IA, B.pA, oa, 1.0f, dt, pair_scale(S->box[kd], oa, dt));
     }
   }
   const int kd = l - nb;
@@ -691,7 +706,9 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
     while (sb) {
       const int si = __builtin_ctz(sb);
       sb &= sb - 1u;
-      slot_accumulate(B.IA, B.pA, L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, -1.0f, dt, 1.0f);
+      float ob[PT_STRIDE];
+      pair_side(L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, g_art, 1.0f, ob);
+      slot_accumulate(B.IA, B.pA, ob, -1.0f, dt, 1.0f);
     }
   }
   PHASE_MARK(19);
@@ -706,6 +723,8 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
   const SceneDev* S = C.scene;
   const int nb = m->nb, nbx = S->nboxes, T = 1 + nbx;
   const float dt = C.sp.dt;
+  const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
+  const float gon = (float)m->gravity_on, g_art[3] = {gb[0] * gon, gb[1] * gon, gb[2] * gon};
   const int kd = l - nb;
   const bool isbox = kd >= 0 && kd < nbx;
   const bool dynbox = isbox && box_is_dynamic(S->box[kd]);
@@ -727,8 +746,9 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
       while (bits) {
         const int j = __builtin_ctz(bits), si = j / SHF_MAX_BOXES, k2 = j % SHF_MAX_BOXES;
         bits &= bits - 1u;
-        const float* o = L.pt + sphere_slot(m, nbx, si, k2) * PT_STRIDE;
-        slot_force(o, abr, 1.0f, dt, pair_scale(S->box[k2], o, dt), f);
+        float oa[PT_STRIDE];
+        pair_side(L.pt + sphere_slot(m, nbx, si, k2) * PT_STRIDE, dt, gb, -1.0f, oa);
+        slot_force(oa, abr, 1.0f, dt, pair_scale(S->box[k2], oa, dt), f);
       }
       contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];
     }
@@ -748,7 +768,9 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
         while (sb) {
           const int si = __builtin_ctz(sb);
           sb &= sb - 1u;
-          slot_force(L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, a, -1.0f, dt, 1.0f, f);
+          float ob[PT_STRIDE];
+          pair_side(L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, g_art, 1.0f, ob);
+          slot_force(ob, a, -1.0f, dt, 1.0f, f);
         }
       }
       contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];

@@ -188,9 +188,12 @@ def test_capsule_pushes_a_cube_at_the_commanded_speed_against_coulomb_friction(o
 
     The same scenario measures the *staggered* arm <-> box coupling (shf_boxes.h): the cube's side of the
     contact is solved with all its contacts and is right (it moves at the slider's speed, so it receives mu m g); the
-    slider's side treats the cube as a free body of its own mass, so the reaction it feels is smaller than mu m g, and
-    its share of the friction law sees the cube's free-fall prediction dt g as vertical sliding -- a spurious vertical
-    load c_t dt g on the pushing body.  Both are asserted as they are, with the true answers next to them."""
+    slider's side treats the cube as a free body of its own mass, so the reaction it feels is smaller than mu m g --
+    asserted as it is, with the true answer next to it.  Each side takes the OTHER body's gravity prediction out of the
+    shared linearisation (pair_side): without that the slider saw the supported cube's free-fall prediction dt g as
+    vertical sliding, a spurious load c_t dt g = 31 N here; with it the vertical load is ~0.  Parallel to the face the
+    single contact point may sit anywhere on the overlap, and hops along it from step to step: the cube's yaw rate
+    chatters (+-0.1 rad/s) about zero while its yaw stays within 3e-4 rad."""
     m, hist = _push(oracle, 0.0, f64=f64)
     q, qd, cube, contact = hist[-1]
     mu = 0.5 * (0.6 + 1.0)
@@ -208,8 +211,7 @@ def test_capsule_pushes_a_cube_at_the_commanded_speed_against_coulomb_friction(o
     f_pusher = contact[m.nb - 1]
     assert abs(f_pusher[0] + 2000.0 * (0.05 - qd)) < 1e-2                              # consistent with the drive's droop
     assert 0.3 * F < -f_pusher[0] < 0.6 * F                                           # true answer: F = mu m g (3.92 N); felt: ~0.41 F
-    ct = mu * (-f_pusher[0]) / K.V_EPS                                                # pair friction coefficient at rest
-    assert abs(-f_pusher[2] - ct * K.DT * K.G) < 0.05 * ct * K.DT * K.G               # true answer: 0; felt: c_t dt g (~31 N)
+    assert abs(f_pusher[2]) < 0.05 * F                                                # no vertical load (was c_t dt g = 31 N)
 
 
 def test_capsule_end_pushes_off_centre_and_turns_the_cube(oracle):
