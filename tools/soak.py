@@ -8,6 +8,7 @@ from shifu_amd.gym.abb_fused import FusedAbbEnv
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 for name, env in (("a1", FusedA1Env(num_envs=4096, group=32)), ("a1-trimesh", FusedA1Env(num_envs=4096, group=32, terrain="trimesh")),
+                  ("a1-selfcollision", FusedA1Env(num_envs=4096, group=32, self_collision=True)),
                   ("abb", FusedAbbEnv(num_envs=4096))):
     env.reset()
     t0 = time.time()
