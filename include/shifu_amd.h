@@ -23,11 +23,11 @@
 extern "C" {
 #endif
 
-#define SHF_ABI_VERSION 5
+#define SHF_ABI_VERSION 6
 
 #define SHF_MAX_BODIES 32 /* reported rigid bodies per articulation        */
 #define SHF_MAX_DOFS 32
-#define SHF_MAX_POINTS 96 /* contact sample points per articulation        */
+#define SHF_MAX_POINTS 176 /* contact sample points per articulation        */
 #define SHF_MAX_BOXES 4   /* extra single-body box actors per env          */
 #define SHF_MAX_SPHERES 8 /* collision spheres / capsules (vs boxes) per articulation */
 #define SHF_MAX_CAPSULES 16 /* self-collision capsules per articulation      */

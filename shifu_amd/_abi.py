@@ -1,10 +1,10 @@
 """ctypes mirrors of the PODs in include/shifu_amd.h (keep in lock-step)."""
 import ctypes as C
 
-SHF_ABI_VERSION = 5
+SHF_ABI_VERSION = 6
 MAX_BODIES = 32
 MAX_DOFS = 32
-MAX_POINTS = 96
+MAX_POINTS = 176
 MAX_BOXES = 4
 MAX_SPHERES = 8
 MAX_CAPSULES = 16

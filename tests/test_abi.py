@@ -96,7 +96,7 @@ def test_empty_and_oversize_inputs_are_refused_on_the_host(libpath):
     big = copy.deepcopy(cm.blob)
     big.nb = 33
     assert l.shf_sim_set_articulation(h, ctypes.byref(big)) != 0 and b"SHF_MAX" in l.shf_last_error()
-    big.nb, big.np = cm.blob.nb, 97
+    big.nb, big.np = cm.blob.nb, _abi.MAX_POINTS + 1
     assert l.shf_sim_set_articulation(h, ctypes.byref(big)) != 0
     assert l.shf_sim_set_articulation(h, ctypes.byref(cm.blob)) == 0
     assert l.shf_sim_finalize(h, 0, 0) != 0 and b"num_envs" in l.shf_last_error()

@@ -700,3 +700,58 @@ def test_mesh_collider_model_steps_bit_exact_on_the_gpu(oracle, tmp_path):
     q = np.array([0.3, 0.2, 0.1, 0.92]); q /= np.linalg.norm(q)
     tr, _ = _kat_run(oracle, cm, H.sim_params(), np.zeros((0, 2), np.float32), K.root_row((0, 0, 0.4), quat=q, ang=(1.0, -2.0, 0.5)), 500)
     assert np.abs(tr[-1, 7:13]).max() < 5e-3 and 0.04 < tr[-1, 2] < 0.2          # at rest on one of its faces
+
+
+def test_many_contact_points_generic_path(oracle, tmp_path):
+    """SURVEY 8f f3 'arbitrary URDFs': a ten-link floating chain with two boxes per link -- 160 contact sample points, what
+    anymal.urdf (143) or a cabinet of mesh hulls (164) need -- on the run-time-dimensioned kernels, bit-exact with the oracle
+    while it drops onto rough ground and folds up."""
+    _need_gpu()
+    from shifu_amd.model import compile_urdf
+    links = ['<robot name="snake">']
+    for k in range(10):
+        links.append(f'<link name="l{k}"><inertial><mass value="0.8"/><inertia ixx="0.004" ixy="0" ixz="0" iyy="0.004" iyz="0" izz="0.004"/></inertial>'
+                     f'<collision><origin xyz="0.05 0 0"/><geometry><box size="0.08 0.05 0.04"/></geometry></collision>'
+                     f'<collision><origin xyz="0.14 0 0"/><geometry><box size="0.08 0.04 0.05"/></geometry></collision></link>')
+        if k:
+            ax = "0 1 0" if k % 2 else "0 0 1"
+            links.append(f'<joint name="j{k}" type="revolute"><parent link="l{k - 1}"/><child link="l{k}"/><origin xyz="0.2 0 0"/>'
+                         f'<axis xyz="{ax}"/><limit effort="20" lower="-1.2" upper="1.2" velocity="30"/></joint>')
+    links.append("</robot>")
+    (tmp_path / "snake.urdf").write_text("\n".join(links))
+    cm = compile_urdf(str(tmp_path / "snake.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT)
+    m = cm.blob
+    assert m.np == 160 and m.nb == 10 and m.nd == 9
+    for d in range(m.nd):
+        m.damping[d] = 0.2
+    rng = np.random.default_rng(3)
+    sp = H.sim_params(angular_damping=0.5)
+    n = 24
+    terr, hs = _terrain(rng, rough=True)
+    dof = np.zeros((n * m.nd, 2), np.float32)
+    dof[:, 0] = rng.uniform(-0.6, 0.6, n * m.nd); dof[:, 1] = rng.uniform(-2, 2, n * m.nd)
+    root = np.zeros((n, 13), np.float32)
+    root[:, 0:2] = rng.uniform(0.5, 3.0, (n, 2)); root[:, 2] = rng.uniform(0.3, 0.6, n)
+    q = rng.normal(size=(n, 4)); root[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    root[:, 7:13] = rng.uniform(-1, 1, (n, 6))
+    fr = rng.uniform(0.5, 1.25, n).astype(np.float32)
+    sim = _make_sim(cm, sp, n, terr, hs, group=32)
+    T = sim.tensors
+    T[_abi.T_SIM_DOF].copy_(torch.from_numpy(dof))
+    T[_abi.T_SIM_ROOT].copy_(torch.from_numpy(root))
+    T[_abi.T_FRICTION].copy_(torch.from_numpy(fr))
+    touched = 0
+    for it in range(60):
+        eff = rng.uniform(-3, 3, n * m.nd).astype(np.float32)
+        sim.set_dof_command(_abi.T_EFFORT, torch.from_numpy(eff).cuda())
+        sim.step()
+        sim.refresh(_abi.REFRESH_ALL)
+        contact, _ = oracle.step(m, sp, n, dof, root, effort=eff, friction=fr, terrain=terr, heights=hs, want_contact=True,
+                                 want_body_state=True)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(T[_abi.T_DOF_STATE].cpu().numpy(), dof, err_msg=f"dof step {it}")
+        np.testing.assert_array_equal(T[_abi.T_ROOT_STATE].cpu().numpy(), root, err_msg=f"root step {it}")
+        np.testing.assert_array_equal(T[_abi.T_CONTACT].cpu().numpy(), contact, err_msg=f"contact step {it}")
+        touched += int((np.abs(contact).sum(1) > 0).sum())
+    assert touched > 500 and np.isfinite(root).all()
+    sim.destroy()

@@ -44,7 +44,7 @@ def test_every_reference_urdf_compiles_or_is_refused_with_a_reason():
         assert 1 <= m.nb <= _abi.MAX_BODIES and 0 <= m.nd <= 32 and len(cm.body_names) == m.nb and len(cm.dof_names) == m.nd
         assert all(m.parent[b] < b for b in range(1, m.nb)), "bodies are numbered parents-first"
         assert sum(m.pt_count[b] for b in range(m.nb)) == m.np
-    assert refused == ["anymal.urdf", "sektion_cabinet_2.urdf"]     # 143 / 164 collision sample points > SHF_MAX_POINTS (96)
+    assert refused == []          # anymal (143 sample points) and sektion_cabinet_2 (164) fit SHF_MAX_POINTS = 176
     print("refused for missing inertia:", massless)
 
 
