@@ -14,6 +14,9 @@ done
 python bench.py --self-collision --steps 500 --warmup 50 --no-cpu-baseline > "$OUT/bench_terrain_selfcollision.json" 2>/dev/null
 python bench.py --steps 20 --warmup 5 > "$OUT/bench_terrain_driver_shape.json" 2>/dev/null
 python bench.py --graph --steps 500 --warmup 50 --no-cpu-baseline > "$OUT/bench_terrain_graph.json" 2>/dev/null
+python tools/mlp_probe.py > "$OUT/mlp_probe.json" 2>/dev/null
+python tools/mlp_probe.py --bf16 > "$OUT/mlp_probe_bf16.json" 2>/dev/null
+python tools/bench_mlp.py > "$OUT/bench_mlp.json" 2>/dev/null
 python tools/phase_clock.py 32 200 > "$OUT/phase_a1.txt" 2>&1
 python tools/phase_clock.py 16 200 --abb > "$OUT/phase_abb.txt" 2>&1
 bash tools/profile.sh r02_a1 > /dev/null 2>&1

@@ -2,7 +2,7 @@
 """Kernel-only timing of csrc/shf_mlp.hip through the C ABI (no autograd around it): forward, input gradient and weight
 gradient of each A1 ActorCritic layer at the PPO mini-batch size, HIP-event time per call.
 
-    python tools/mlp_probe.py [rows]                 # product library
+    python tools/mlp_probe.py [rows] [--bf16]        # product library (default operand precision bf16x3)
     SHIFU_AMD_LIB=... python tools/mlp_probe.py      # an experiment build (tools/mlp_probe.py build <name> <-Dflags...>)
 """
 import ctypes as C
@@ -25,8 +25,11 @@ def build(name, flags):
 def main():
     import torch
     from shifu_amd._lib import lib
-    M = int(sys.argv[1]) if len(sys.argv) > 1 else 24576
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    M = int(args[0]) if args else 24576
     L = lib()
+    precision = "bf16" if "--bf16" in sys.argv else "bf16x3"
+    L.shf_mlp_set_precision(0 if precision == "bf16" else 1)
     p = lambda t: C.c_void_p(t.data_ptr())
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -42,7 +45,7 @@ def main():
         torch.cuda.synchronize()
         return a.elapsed_time(b) / iters * 1e3
 
-    out = {"rows": M, "layers": []}
+    out = {"rows": M, "precision": precision, "layers": []}
     for K, N, act in ((259, 512, 1), (512, 256, 1), (256, 128, 1), (128, 12, 0)):
         x, w, b = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") * 0.05, torch.randn(N, device="cuda")
         y, g = torch.empty(M, N, device="cuda"), torch.randn(M, N, device="cuda")
