@@ -115,17 +115,106 @@ DEV void slot_force(const float* o, const float* ab, float sign, float dt, float
   slot_force_fb(o, ab, sign, dt, scale, scale, f);
 }
 
-DEV float pair_scale(const ShfBoxDesc& b, const float* o, float dt) { return b.mass / fmaf(dt, o[PT_BN], b.mass); }
-// One side's view of a pair slot (oracle: pair_side): the slot's f0 was linearised about both bodies' gravity-predicted
-// velocities; each side corrects only its own prediction through its implicit term, so it takes the OTHER body's out again:
-// f0 + sign dt K g.  Arm side: sign -1, g = the box's gravity; box side: sign +1, g = the articulation's.
-DEV void pair_side(const float* o, float dt, const float* g, float sign, float* s) {
+// ---- consistent articulation <-> free-box pair law (oracle: pair_accumulate and its comment) ----
+// Force on the articulation's point f = Feff - dt Keff aA_pt, with Keff = (I + dt K W)^-1 K and
+// Feff = (I + dt K W)^-1 (f0 + dt K cfree): W = J IAbox^-1 J^T and cfree = J ba_free are the box's compliance and its
+// supported free acceleration at the point, from its articulated inertia with its own (ground / table) contacts folded in.
+// The box lane computes the law (pair_law) and later hands -f to its own solve; the articulation's lane folds it
+// (pair_accumulate).  PR_F / PR_K: layout of the pair record.
+#define PR_F 0
+#define PR_K 3
+DEV void pair_point_accel(const float* a6, const float* r, float* ap) {
+  float t[3];
+  cross3(a6, r, t);
 #pragma unroll
-  for (int k = 0; k < PT_STRIDE; k++) s[k] = o[k];
-  const float n[3] = {o[PT_N], o[PT_N + 1], o[PT_N + 2]};
-  const float gn = dot3(n, g);
+  for (int k = 0; k < 3; k++) ap[k] = a6[3 + k] + t[k];
+}
+DEV void mat3_inv(const float* A, float* Ai) {
+  const float c00 = fmaf(A[4], A[8], -(A[5] * A[7])), c01 = fmaf(A[5], A[6], -(A[3] * A[8])), c02 = fmaf(A[3], A[7], -(A[4] * A[6]));
+  const float id = 1.0f / fmaf(A[0], c00, fmaf(A[1], c01, A[2] * c02));
+  Ai[0] = c00 * id; Ai[1] = fmaf(A[2], A[7], -(A[1] * A[8])) * id; Ai[2] = fmaf(A[1], A[5], -(A[2] * A[4])) * id;
+  Ai[3] = c01 * id; Ai[4] = fmaf(A[0], A[8], -(A[2] * A[6])) * id; Ai[5] = fmaf(A[2], A[3], -(A[0] * A[5])) * id;
+  Ai[6] = c02 * id; Ai[7] = fmaf(A[1], A[6], -(A[0] * A[7])) * id; Ai[8] = fmaf(A[0], A[4], -(A[1] * A[3])) * id;
+}
+// box lane: IA / pA = the box with its own contacts folded, afree = its solve; o = the pair slot; pr = the pair record
+DEV void pair_law(const float* IA, const float* afree, const float* o, float dt, float* pr) {
+  const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]}, n[3] = {o[PT_N], o[PT_N + 1], o[PT_N + 2]};
+  const float ct = o[PT_CT], bn = o[PT_BN];
+  float W[9], cfree[3];
 #pragma unroll
-  for (int k = 0; k < 3; k++) s[PT_F + k] = fmaf(sign * dt, fmaf(o[PT_BN] - o[PT_CT], gn * n[k], o[PT_CT] * g[k]), o[PT_F + k]);
+  for (int k = 0; k < 3; k++) {
+    const float e[3] = {k == 0 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 2 ? 1.0f : 0.0f};
+    float t[3], rhs[6], y[6], wp[3];
+    cross3(r, e, t);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { rhs[i] = -t[i]; rhs[3 + i] = -e[i]; }
+    ldlt_solve6(IA, rhs, y);
+    pair_point_accel(y, r, wp);
+#pragma unroll
+    for (int i = 0; i < 3; i++) W[3 * i + k] = wp[i];
+  }
+  pair_point_accel(afree, r, cfree);
+  float K[9], Mx[9], S[9], g0[3], Ke[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) K[3 * i + j] = fmaf(bn - ct, n[i] * n[j], i == j ? ct : 0.0f);
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      Mx[3 * i + j] = fmaf(dt, fmaf(K[3 * i + 2], W[6 + j], fmaf(K[3 * i + 1], W[3 + j], K[3 * i] * W[j])), i == j ? 1.0f : 0.0f);
+  mat3_inv(Mx, S);
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+    g0[i] = fmaf(dt, fmaf(K[3 * i + 2], cfree[2], fmaf(K[3 * i + 1], cfree[1], K[3 * i] * cfree[0])), o[PT_F + i]);
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    pr[PR_F + i] = fmaf(S[3 * i + 2], g0[2], fmaf(S[3 * i + 1], g0[1], S[3 * i] * g0[0]));
+#pragma unroll
+    for (int j = 0; j < 3; j++) Ke[3 * i + j] = fmaf(S[3 * i + 2], K[6 + j], fmaf(S[3 * i + 1], K[3 + j], S[3 * i] * K[j]));
+  }
+  // symmetrised upper triangle: 00 01 02 11 12 22
+  pr[PR_K + 0] = Ke[0]; pr[PR_K + 1] = 0.5f * (Ke[1] + Ke[3]); pr[PR_K + 2] = 0.5f * (Ke[2] + Ke[6]);
+  pr[PR_K + 3] = Ke[4]; pr[PR_K + 4] = 0.5f * (Ke[5] + Ke[7]); pr[PR_K + 5] = Ke[8];
+}
+DEV void pair_unpack(const float* pr, float* F, float* K) {
+  F[0] = pr[PR_F]; F[1] = pr[PR_F + 1]; F[2] = pr[PR_F + 2];
+  K[0] = pr[PR_K]; K[1] = pr[PR_K + 1]; K[2] = pr[PR_K + 2]; K[3] = pr[PR_K + 1]; K[4] = pr[PR_K + 3]; K[5] = pr[PR_K + 4];
+  K[6] = pr[PR_K + 2]; K[7] = pr[PR_K + 4]; K[8] = pr[PR_K + 5];
+}
+// articulation lane: fold f = F - dt K a_pt at r into the packed (IA, pA): IA += dt J^T K J, pA -= J^T F, J = [-[r]x, I]
+DEV void pair_accumulate(float* IA, float* pA, const float* r, const float* F, const float* K, float dt) {
+  float t[3];
+  cross3(r, F, t);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { pA[k] -= t[k]; pA[3 + k] -= F[k]; }
+  const float X[9] = {0.0f, r[2], -r[1], -r[2], 0.0f, r[0], r[1], -r[0], 0.0f};
+  float KJ[3][6];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      KJ[i][j] = fmaf(K[3 * i + 2], X[6 + j], fmaf(K[3 * i + 1], X[3 + j], K[3 * i] * X[j]));
+      KJ[i][3 + j] = K[3 * i + j];
+    }
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = i; j < 6; j++) {
+      float v;
+      if (i < 3) v = fmaf(X[6 + i], KJ[2][j], fmaf(X[3 + i], KJ[1][j], X[i] * KJ[0][j]));
+      else v = KJ[i - 3][j];
+      IA[SYM(i, j)] = fmaf(dt, v, IA[SYM(i, j)]);
+    }
+}
+// the pair force once the articulation's acceleration is known
+DEV void pair_force(const float* pr, const float* a_art, const float* r, float dt, float* f) {
+  float F[3], K[9], ap[3];
+  pair_unpack(pr, F, K);
+  pair_point_accel(a_art, r, ap);
+#pragma unroll
+  for (int i = 0; i < 3; i++) f[i] = fmaf(-dt, fmaf(K[3 * i + 2], ap[2], fmaf(K[3 * i + 1], ap[1], K[3 * i] * ap[0])), F[i]);
 }
 
 DEV bool point_in_box(const float* bR, const float* bpos, const float* h, const float* r, float* phi, float* n) {
@@ -401,7 +490,9 @@ DEV void self_contact_forces(const StepCtx& C, const EnvLds& L, int l, int slot0
 // slot indexing inside the env's contact region, after the articulation's np sample points
 DEV int corner_slot(const ShfModel* m, int nbx, int kd, int c, int tg) { return m->np + (kd * 8 + c) * (1 + nbx) + tg; }
 DEV int sphere_slot(const ShfModel* m, int nbx, int si, int kd) { return m->np + nbx * 8 * (1 + nbx) + si * nbx + kd; }
-__host__ __device__ inline int box_slot_count(int nbx, int nsph) { return nbx * 8 * (1 + nbx) + nsph * nbx; }
+// second record of a pair slot: the consistent law's (Feff[3], Keff upper triangle [6]) -- see pair_law
+DEV int pair_slot(const ShfModel* m, int nbx, int si, int kd) { return sphere_slot(m, nbx, si, kd) + m->nsph * nbx; }
+__host__ __device__ inline int box_slot_count(int nbx, int nsph) { return nbx * 8 * (1 + nbx) + 2 * nsph * nbx; }
 
 // `in contact` flags of a lane's slots as bit masks, read in one batch: the folds below then visit only the active
 // slots, in the same order as the plain nested loops (ascending bit index = loop order), instead of paying one
@@ -574,17 +665,8 @@ DEV void boxes_contacts_fixed(const StepCtx& C, const EnvLds& L, int l, BodyRegs
   }
   GROUP_SYNC();
   PHASE_MARK(18);
-  // fold, in the order of the run-time path: a body's spheres ascending; the box's corners (c, tg) ascending, then spheres
-  if (l < nb && m->dyn[l] == l) {
-    unsigned bits = BM.spheres & BL.sph_dyn;
-    while (bits) {
-      const int si = __builtin_ctz(bits);
-      bits &= bits - 1u;
-      float oa[PT_STRIDE];
-      pair_side(L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, gb, -1.0f, oa);
-      slot_accumulate(B.IA, B.pA, oa, 1.0f, dt, pair_scale(bd, oa, dt));
-    }
-  }
+  // fold.  The box lane first: its own contacts (corners ascending), then the consistent law of every active pair slot
+  // (pair_law) into the pair records; after the hand-off the articulation's lanes fold theirs, shapes ascending.
   if (l == nb + kd) {
     unsigned long long cb = BM.corners;
     unsigned sb = BM.spheres;
@@ -593,12 +675,27 @@ DEV void boxes_contacts_fixed(const StepCtx& C, const EnvLds& L, int l, BodyRegs
       cb &= cb - 1ull;
       slot_accumulate(B.IA, B.pA, L.pt + corner_slot(m, nbx, kd, j / T, j % T) * PT_STRIDE, 1.0f, dt, 1.0f);
     }
-    while (sb) {
-      const int si = __builtin_ctz(sb);
-      sb &= sb - 1u;
-      float ob[PT_STRIDE];
-      pair_side(L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, g_art, 1.0f, ob);
-      slot_accumulate(B.IA, B.pA, ob, -1.0f, dt, 1.0f);
+    if (sb) {
+      float afree[6];
+      ldlt_solve6(B.IA, B.pA, afree);
+      while (sb) {
+        const int si = __builtin_ctz(sb);
+        sb &= sb - 1u;
+        pair_law(B.IA, afree, L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE);
+      }
+    }
+  }
+  GROUP_SYNC();
+  if (l < nb && m->dyn[l] == l) {
+    unsigned bits = BM.spheres & BL.sph_dyn;
+    while (bits) {
+      const int si = __builtin_ctz(bits);
+      bits &= bits - 1u;
+      const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
+      const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]};
+      float F[3], K[9];
+      pair_unpack(L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE, F, K);
+      pair_accumulate(B.IA, B.pA, r, F, K, dt);
     }
   }
   PHASE_MARK(19);
@@ -683,17 +780,7 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
   }
   GROUP_SYNC();
   PHASE_MARK(18);
-  // fold
-  if (l < nb && m->dyn[l] == l) {
-    unsigned bits = body_sphere_flags(m, L, nbx, l, true);
-    while (bits) {
-      const int j = __builtin_ctz(bits), si = j / SHF_MAX_BOXES, kd = j % SHF_MAX_BOXES;
-      bits &= bits - 1u;
-      float oa[PT_STRIDE];
-      pair_side(L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, gb, -1.0f, oa);
-      slot_accumulate(B.IA, B.pA, oa, 1.0f, dt, pair_scale(S->box[kd], oa, dt));
-    }
-  }
+  // fold (as the fixed-scene path: box lanes first, with the pair laws; then the articulation's lanes)
   const int kd = l - nb;
   if (kd >= 0 && kd < nbx && box_is_dynamic(S->box[kd])) {
     unsigned long long cb = corner_flags(m, L, nbx, kd);
@@ -703,12 +790,27 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
       cb &= cb - 1ull;
       slot_accumulate(B.IA, B.pA, L.pt + corner_slot(m, nbx, kd, j / BOX_T, j % BOX_T) * PT_STRIDE, 1.0f, dt, 1.0f);
     }
-    while (sb) {
-      const int si = __builtin_ctz(sb);
-      sb &= sb - 1u;
-      float ob[PT_STRIDE];
-      pair_side(L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, g_art, 1.0f, ob);
-      slot_accumulate(B.IA, B.pA, ob, -1.0f, dt, 1.0f);
+    if (sb) {
+      float afree[6];
+      ldlt_solve6(B.IA, B.pA, afree);
+      while (sb) {
+        const int si = __builtin_ctz(sb);
+        sb &= sb - 1u;
+        pair_law(B.IA, afree, L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE);
+      }
+    }
+  }
+  GROUP_SYNC();
+  if (l < nb && m->dyn[l] == l) {
+    unsigned bits = body_sphere_flags(m, L, nbx, l, true);
+    while (bits) {
+      const int j = __builtin_ctz(bits), si = j / SHF_MAX_BOXES, k2 = j % SHF_MAX_BOXES;
+      bits &= bits - 1u;
+      const float* o = L.pt + sphere_slot(m, nbx, si, k2) * PT_STRIDE;
+      const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]};
+      float F[3], K[9];
+      pair_unpack(L.pt + pair_slot(m, nbx, si, k2) * PT_STRIDE, F, K);
+      pair_accumulate(B.IA, B.pA, r, F, K, dt);
     }
   }
   PHASE_MARK(19);
@@ -723,13 +825,29 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
   const SceneDev* S = C.scene;
   const int nb = m->nb, nbx = S->nboxes, T = 1 + nbx;
   const float dt = C.sp.dt;
-  const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
-  const float gon = (float)m->gravity_on, g_art[3] = {gb[0] * gon, gb[1] * gon, gb[2] * gon};
   const int kd = l - nb;
   const bool isbox = kd >= 0 && kd < nbx;
   const bool dynbox = isbox && box_is_dynamic(S->box[kd]);
   float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-  if (dynbox) ldlt_solve6(B.IA, B.pA, a);
+  if (dynbox) {
+    // the articulation's solved acceleration fixes every pair force; the box receives exactly its opposite, then solves
+    unsigned sb;
+    if constexpr (SC::NBX > 0) sb = BM.spheres; else sb = box_sphere_flags(m, L, nbx, kd);
+    while (sb) {
+      const int si = __builtin_ctz(sb);
+      sb &= sb - 1u;
+      const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
+      const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]};
+      const float* ab = L.acc + m->dyn[m->sph_body[si]] * 6;
+      const float abr[6] = {ab[0], ab[1], ab[2], ab[3], ab[4], ab[5]};
+      float f[3], t[3];
+      pair_force(L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE, abr, r, dt, f);
+      cross3(r, f, t);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { B.pA[k] += t[k]; B.pA[3 + k] += f[k]; }
+    }
+    ldlt_solve6(B.IA, B.pA, a);
+  }
   if (contact_out) {
     if (l < nb) {
       float f[3] = {contact_out[3 * l], contact_out[3 * l + 1], contact_out[3 * l + 2]};
@@ -746,9 +864,12 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
       while (bits) {
         const int j = __builtin_ctz(bits), si = j / SHF_MAX_BOXES, k2 = j % SHF_MAX_BOXES;
         bits &= bits - 1u;
-        float oa[PT_STRIDE];
-        pair_side(L.pt + sphere_slot(m, nbx, si, k2) * PT_STRIDE, dt, gb, -1.0f, oa);
-        slot_force(oa, abr, 1.0f, dt, pair_scale(S->box[k2], oa, dt), f);
+        const float* o = L.pt + sphere_slot(m, nbx, si, k2) * PT_STRIDE;
+        const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]};
+        float fp[3];
+        pair_force(L.pt + pair_slot(m, nbx, si, k2) * PT_STRIDE, abr, r, dt, fp);
+#pragma unroll
+        for (int k = 0; k < 3; k++) f[k] += fp[k];
       }
       contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];
     }
@@ -768,9 +889,14 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
         while (sb) {
           const int si = __builtin_ctz(sb);
           sb &= sb - 1u;
-          float ob[PT_STRIDE];
-          pair_side(L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, g_art, 1.0f, ob);
-          slot_force(ob, a, -1.0f, dt, 1.0f, f);
+          const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
+          const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]};
+          const float* ab = L.acc + m->dyn[m->sph_body[si]] * 6;
+          const float abr[6] = {ab[0], ab[1], ab[2], ab[3], ab[4], ab[5]};
+          float fp[3];
+          pair_force(L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE, abr, r, dt, fp);
+#pragma unroll
+          for (int k = 0; k < 3; k++) f[k] -= fp[k];
         }
       }
       contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];

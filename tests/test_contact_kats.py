@@ -161,16 +161,16 @@ def test_standing_a1_holds_a_horizontal_push_below_the_friction_limit(oracle):
 
 
 # ---- capsule vs box (the ABB rod, shf_boxes.h: segment_box_param): a slider pushes a cube over the ground ----
-def _push(oracle, yaw, steps=700, f64=True):
+def _push(oracle, yaw, steps=700, f64=True, x0=0.12):
     from shifu_amd.abb_task import box_desc
     cm = K.pusher_model(yaw=yaw)
     m = cm.blob
     sp = sim_params()
     dt = np.float64 if f64 else np.float32
-    cube = box_desc((0.1, 0.1, 0.1), 0.5, 0.6, False, (0.12, 0.0, 0.05))      # its -x face at x = 0.07; capsule surface at 0.02
+    cube = box_desc((0.1, 0.1, 0.1), 0.5, 0.6, False, (x0, 0.0, 0.05))
     dof = np.zeros((1, 2), dt)
     root = np.zeros((2, 13), dt); root[:, 6] = 1.0
-    root[1, :3] = (0.12, 0.0, 0.05 - 0.5 * K.G / (4 * K.K_N))
+    root[1, :3] = (x0, 0.0, 0.05 - 0.5 * K.G / (4 * K.K_N))
     vt = np.full(1, 0.05, dt)
     fr = np.ones(1, np.float32)
     hist = []
@@ -180,38 +180,40 @@ def _push(oracle, yaw, steps=700, f64=True):
     return m, hist
 
 
-@pytest.mark.parametrize("f64", [True, False])
-def test_capsule_pushes_a_cube_at_the_commanded_speed_against_coulomb_friction(oracle, f64):
-    """Parallel to the face (the closest-point rule's flat stretch: its midpoint, through the cube's centre): once in
-    contact the cube moves with the slider against its ground friction mu m g (mu = the mean of the two materials, as
-    everywhere), neither yaws nor lifts, and the capsule sinks F / k into it.
-
-    The same scenario measures the *staggered* arm <-> box coupling (shf_boxes.h): the cube's side of the
-    contact is solved with all its contacts and is right (it moves at the slider's speed, so it receives mu m g); the
-    slider's side treats the cube as a free body of its own mass, so the reaction it feels is smaller than mu m g --
-    asserted as it is, with the true answer next to it.  Each side takes the OTHER body's gravity prediction out of the
-    shared linearisation (pair_side): without that the slider saw the supported cube's free-fall prediction dt g as
-    vertical sliding, a spurious load c_t dt g = 31 N here; with it the vertical load is ~0.  Parallel to the face the
-    single contact point may sit anywhere on the overlap, and hops along it from step to step: the cube's yaw rate
-    chatters (+-0.1 rad/s) about zero while its yaw stays within 3e-4 rad."""
-    m, hist = _push(oracle, 0.0, f64=f64)
+@pytest.mark.parametrize("f64", PREC)
+def test_capsule_end_pushes_a_cube_with_the_reaction_newton_asks_for(oracle, f64):
+    """End-on (the capsule's axis along the push, its end sphere on the cube's face centre): once in contact the cube moves
+    at the slider's speed against its ground friction mu m g (mu = the mean of the two materials, as everywhere), and the
+    slider feels exactly that reaction -- the pair law is solved consistently (shf_boxes.h: pair_law; the first version
+    treated the cube as a free body on the slider's side and felt 0.41 of it, plus a spurious vertical load).  No lateral
+    or vertical force, no spin, penetration F / k, and the velocity drive's droop kd (v* - qd) equals the reaction."""
+    m, hist = _push(oracle, np.pi / 2, steps=900, f64=f64, x0=0.25)     # leading end at x = 0.1 + q, cube face at 0.2
     q, qd, cube, contact = hist[-1]
-    mu = 0.5 * (0.6 + 1.0)
-    F = mu * 0.5 * K.G
-    assert abs(cube[7] - qd) < 1e-4 and 0.045 < qd <= 0.05 + 1e-6                    # cube and slider move together
-    # the cube: ground normal force = its weight, so its ground friction is mu m g and the push it receives equals it
-    assert abs(contact[m.nb][2] - 0.5 * K.G) < 1e-3 and abs(contact[m.nb][0]) < 0.03 * F
-    yaw = 2.0 * np.arctan2(cube[5], cube[6])
-    assert abs(yaw) < 0.02 and abs(cube[1]) < 1e-3                                    # pushed through its centre: no spin to speak of
-    gap = (cube[0] - 0.05) - (q + 0.02)                                               # face - capsule surface
-    assert -2.5 * F / K.K_N < gap < 0.0, gap                                          # penetration of the order of F / k (0.08 mm)
-    free = [h for h in hist if h[3][m.nb - 1][0] == 0.0]
-    assert len(free) > 100 and all(abs(h[2][7]) < 1e-6 for h in free)                  # untouched until the capsule arrives
-    # the slider's side (known deviation): reaction felt = what its velocity drive supplies, kd (v* - qd)
-    f_pusher = contact[m.nb - 1]
-    assert abs(f_pusher[0] + 2000.0 * (0.05 - qd)) < 1e-2                              # consistent with the drive's droop
-    assert 0.3 * F < -f_pusher[0] < 0.6 * F                                           # true answer: F = mu m g (3.92 N); felt: ~0.41 F
-    assert abs(f_pusher[2]) < 0.05 * F                                                # no vertical load (was c_t dt g = 31 N)
+    F = 0.5 * (0.6 + 1.0) * 0.5 * K.G
+    f_slider, f_cube = contact[m.nb - 1], contact[m.nb]
+    assert abs(cube[7] - qd) < 1e-5 and 0.045 < qd < 0.05
+    assert abs(f_slider[0] + F) < 0.01 * F and abs(f_slider[1]) < 1e-3 * F and abs(f_slider[2]) < 1e-2 * F, f_slider
+    assert abs(2000.0 * (0.05 - qd) - F) < 0.01 * F                                   # what the drive supplies
+    assert abs(f_cube[0]) < 0.01 * F and abs(f_cube[2] - 0.5 * K.G) < 1e-3             # push and friction cancel; weight carried
+    assert abs(2.0 * np.arctan2(cube[5], cube[6])) < 1e-6 and abs(cube[1]) < 1e-7
+    gap = (cube[0] - 0.05) - (q + 0.1 + 0.02)
+    assert -2.5 * F / K.K_N < gap < 0.0, gap
+    first = next(k for k, h in enumerate(hist) if h[3][m.nb - 1][0] != 0.0)
+    assert first > 100 and all(abs(h[2][7]) < 1e-6 for h in hist[:first])               # untouched until the capsule arrives
+
+
+def test_capsule_parallel_to_the_face_pushes_with_one_hopping_contact_point(oracle):
+    """Parallel to the face the closest-point rule has a flat stretch (its midpoint when exactly flat); with the cube a
+    hair off parallel the single contact point sits at an end of the overlap and hops between the ends from step to step:
+    the cube still follows the slider, its yaw stays within 1e-3 rad, but yaw rate and lateral force chatter about zero
+    (a two-point manifold would hold it)."""
+    m, hist = _push(oracle, 0.0)
+    q, qd, cube, contact = hist[-1]
+    F = 0.5 * (0.6 + 1.0) * 0.5 * K.G
+    assert abs(cube[7] - qd) < 2e-3 and 0.045 < qd < 0.05
+    assert abs(2.0 * np.arctan2(cube[5], cube[6])) < 1e-3 and abs(cube[1]) < 1e-3
+    fx = np.array([h[3][m.nb - 1][0] for h in hist[-200:]])
+    assert 0.8 * F < -fx.mean() < 1.4 * F                                            # reaction of the order of mu m g
 
 
 def test_capsule_end_pushes_off_centre_and_turns_the_cube(oracle):
