@@ -278,7 +278,7 @@ DEV void sphere_vs_box(const float* bR, const float* bpos, const float* h, const
 // coordinate crosses a face plane; the root is interpolated between the last negative and the first positive sample, and
 // a stretch of exact zeros gives its midpoint.  Sample order: ends, axes 0..2, face -h before +h.
 // sample k of g (k = 0, 1: the ends; 2 + 2 i + f: the kink of axis i at face -h (f = 0) / +h (f = 1)); false: not in (0,1)
-DEV bool seg_box_sample(int k, const float* a, const float* d, const float* h, float* t_out, float* g_out) {
+DEV bool seg_box_sample(int k, const float* a, const float* d, const float* h, float dd, float* t_out, float* g_out) {
   float t;
   bool use = true;
   if (k == 0) t = 0.0f;
@@ -292,11 +292,17 @@ DEV bool seg_box_sample(int k, const float* a, const float* d, const float* h, f
   }
   float g = 0.0f;
   if (use) {                                            // (one lane per capsule: an unused kink is really skipped)
+    float ee = 0.0f;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       const float p = fmaf(t, d[i], a[i]);
-      g = fmaf(d[i], p - rclampf(p, -h[i], h[i]), g);
+      const float e = p - rclampf(p, -h[i], h[i]);
+      g = fmaf(d[i], e, g);
+      ee = fmaf(e, e, ee);
     }
+    // within 5e-4 rad of perpendicular to the distance vector the sample counts as flat (oracle: same line): a capsule
+    // lying along a face touches at the middle of the overlap instead of hopping between its ends
+    if (g * g <= 2.5e-7f * dd * ee) g = 0.0f;
   }
   *t_out = t; *g_out = g;
   return use;
@@ -328,11 +334,12 @@ DEV void seg_box_frame(const float* bR, const float* bpos, const float* c0, cons
 DEV float segment_box_param(const float* bR, const float* bpos, const float* h, const float* c0, const float* s) {
   float a[3], d[3];
   seg_box_frame(bR, bpos, c0, s, a, d);
+  const float dd = dot3(d, d);
   SegBoxRoot Q;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     float t, g;
-    const bool use = seg_box_sample(k, a, d, h, &t, &g);
+    const bool use = seg_box_sample(k, a, d, h, dd, &t, &g);
     Q.push(t, g, use);
   }
   return Q.root();
