@@ -18,6 +18,9 @@ class PPO:
         # backend (tests/test_gpu_mlp.py), given the host wait after each replay (update()).  One rank only.
         self.graph_update = bool(graph_update)
         self._upd_graph = self._upd_idx = self._upd_sums = None
+        # the critic's forward / backward on a second stream (bit-identical results, learn -25 % with the MFMA layers,
+        # profiles/r02_mlp_probe.md); SHIFU_AMD_TWO_STREAM_UPDATE=0 switches it off
+        self._side = torch.cuda.Stream() if (torch.device(device).type == "cuda" and os.environ.get("SHIFU_AMD_TWO_STREAM_UPDATE", "1") == "1") else None
         self._updates_done = 0
         self.desired_kl, self.schedule = desired_kl, schedule
         self.actor_critic = actor_critic.to(device)
@@ -73,9 +76,20 @@ class PPO:
     def losses(self, obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma):
         """Loss terms of one mini-batch under the current parameters (also what tests/test_rl.py checks)."""
         ac = self.actor_critic
-        ac.update_distribution(obs)
-        logp = ac.get_actions_log_prob(actions)
-        value = ac.evaluate(cobs)
+        if self._side is not None:
+            # actor and critic are independent networks: the critic's forward (and, through autograd's stream bookkeeping,
+            # its backward) runs on a second stream, so the small layers of one fill the CUs the other leaves idle
+            cur = torch.cuda.current_stream()
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                value = ac.evaluate(cobs)
+            ac.update_distribution(obs)
+            logp = ac.get_actions_log_prob(actions)
+            cur.wait_stream(self._side)
+        else:
+            ac.update_distribution(obs)
+            logp = ac.get_actions_log_prob(actions)
+            value = ac.evaluate(cobs)
         mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
         with torch.no_grad():
             # KL(old || new) of diagonal Gaussians, averaged over the mini-batch
