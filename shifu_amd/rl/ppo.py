@@ -83,6 +83,7 @@ class PPO:
             self._side.wait_stream(cur)
             with torch.cuda.stream(self._side):
                 value = ac.evaluate(cobs)
+            value.record_stream(cur)             # consumed on the main stream after the join
             ac.update_distribution(obs)
             logp = ac.get_actions_log_prob(actions)
             cur.wait_stream(self._side)
