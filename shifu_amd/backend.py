@@ -43,13 +43,16 @@ def _on_device(method):
     @functools.wraps(method)
     def wrapped(self, *a, **k):
         dev = self.device if hasattr(self, "device") else self.sim.device
+        if torch.cuda.current_device() == dev.index:       # the common case: no device switch, no context object
+            return method(self, *a, **k)
         with torch.cuda.device(dev):
             return method(self, *a, **k)
     return wrapped
 
 
 def _stream_ptr(device) -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    idx = torch.device(device).index
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx))
 
 
 def _struct_to_device(s, device) -> torch.Tensor:
@@ -61,6 +64,8 @@ class Sim:
 
     def __init__(self, params: _abi.ShfSimParams, device="cuda:0"):
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         if self.device.type != "cuda":
             raise RuntimeError("shifu_amd.backend.Sim runs on an MI355X only (device must be cuda:N); "
                                "there is no CPU fallback")
