@@ -429,6 +429,24 @@ int shf_mlp_backward_weight_workspace(int32_t M, int32_t K, int32_t N, int64_t* 
 int shf_mlp_linear_backward_weight(const float* dy, const float* y_or_null, const float* x, float* dw, float* db,
                                    float* workspace, int32_t M, int32_t K, int32_t N, void* stream);
 
+/* PPO mini-batch loss with its gradient, one pass (rsl_rl's PPO.update loss block [EXT], which the reference's runner
+ * drives: shifu/runner/policy_runner.py:52-73 with PPOConfig.algorithm, shifu/configs/policy_config.py:18-31):
+ *   logp_i   = sum_j log N(actions_ij; mu_ij, std_j)          ratio_i = exp(logp_i - old_logp_i)
+ *   surr     = mean_i max(-adv_i ratio_i, -adv_i clamp(ratio_i, 1 - clip, 1 + clip))
+ *   value    = mean_i max((v_i - R_i)^2, (tv_i + clamp(v_i - tv_i, -clip, clip) - R_i)^2)     (clipped_value != 0)
+ *            = mean_i (R_i - v_i)^2                                                          (clipped_value == 0)
+ *   entropy  = sum_j (0.5 + 0.5 log 2 pi + log std_j)
+ *   kl       = mean_i sum_j log(std_j / old_sigma_ij + 1e-5) + (old_sigma_ij^2 + (old_mu_ij - mu_ij)^2) / (2 std_j^2) - 0.5
+ *   loss     = surr + value_coef * value - entropy_coef * entropy
+ * out5 = {surr, value, entropy, kl, loss}; dmu[B,A], dstd[A], dvalue[B] = d loss / d (mu, std, value), with torch's
+ * conventions at the kinks (max: even split on a tie; clamp: gradient passes on the closed interval).  Row-major fp32,
+ * 1 <= A <= 32; sums are taken in a fixed order (no atomics).  workspace: shf_ppo_loss_workspace floats. */
+int shf_ppo_loss_workspace(int64_t B, int32_t A, int64_t* floats);
+int shf_ppo_loss(const float* mu, const float* std, const float* value, const float* actions, const float* target_values,
+                 const float* advantages, const float* returns, const float* old_logp, const float* old_mu,
+                 const float* old_sigma, int64_t B, int32_t A, float clip, float value_coef, float entropy_coef,
+                 int32_t clipped_value, float* out5, float* dmu, float* dstd, float* dvalue, float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -394,6 +394,114 @@ void launch_gemm(hipStream_t st, const Operand& A, const Operand& B, int red, in
 
 }  // namespace
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PPO mini-batch loss, forward and gradient in one pass (shf_ppo_loss).  One thread per sample walks its A action
+// columns; block sums go through wave shuffles and LDS in a fixed order, the blocks' partial sums are added in block
+// order by k_ppo_loss_finish: no atomics, the same bits on every run.  Gradients follow torch's conventions where the
+// loss is not differentiable: maximum() splits the gradient evenly on a tie, clamp() passes it on the closed interval.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int PPO_MAX_ACTIONS = 32, PPO_BLOCK = 256, PPO_NRED = 3;
+
+struct PpoArgs {
+  const float *mu, *std, *value, *actions, *target_values, *advantages, *returns, *old_logp, *old_mu, *old_sigma;
+  long long B;
+  int A;
+  float clip, value_coef, entropy_coef;
+  int clipped_value;
+  float *out, *dmu, *dstd, *dvalue, *partial;
+};
+
+MLP_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(PPO_BLOCK) void k_ppo_loss(PpoArgs P) {
+  __shared__ float red[PPO_BLOCK / 64][PPO_NRED + PPO_MAX_ACTIONS];
+  const long long i = (long long)blockIdx.x * PPO_BLOCK + threadIdx.x;
+  const bool live = i < P.B;
+  const int A = P.A;
+  const float invB = 1.0f / (float)P.B;
+  float surr = 0.0f, vloss = 0.0f, kl = 0.0f, g_logp = 0.0f;
+  if (live) {
+    float logp = 0.0f;
+    for (int j = 0; j < A; j++) {
+      const float s = P.std[j], var = s * s, m = P.mu[i * A + j], d = P.actions[i * A + j] - m;
+      logp += -(d * d) / (2.0f * var) - logf(s) - 0.91893853320467274178f;
+      const float os = P.old_sigma[i * A + j], dm = P.old_mu[i * A + j] - m;
+      kl += logf(s / os + 1.e-5f) + (os * os + dm * dm) / (2.0f * var) - 0.5f;
+    }
+    const float ratio = expf(logp - P.old_logp[i]), adv = P.advantages[i];
+    const float lo = 1.0f - P.clip, hi = 1.0f + P.clip;
+    const float rc = fminf(fmaxf(ratio, lo), hi);
+    const float s1 = -adv * ratio, s2 = -adv * rc;
+    const bool inside = ratio >= lo && ratio <= hi;
+    surr = fmaxf(s1, s2);
+    const float g_ratio = s1 > s2 ? -adv : (s1 < s2 ? 0.0f : -adv * 0.5f + (inside ? -adv * 0.5f : 0.0f));
+    g_logp = g_ratio * ratio * invB;
+    const float v = P.value[i], R = P.returns[i];
+    float gv;
+    if (P.clipped_value) {
+      const float tv = P.target_values[i], dv = v - tv;
+      const float vc = tv + fminf(fmaxf(dv, -P.clip), P.clip);
+      const bool vin = dv >= -P.clip && dv <= P.clip;
+      const float e1 = v - R, e2 = vc - R, l1 = e1 * e1, l2 = e2 * e2;
+      vloss = fmaxf(l1, l2);
+      const float g2 = vin ? 2.0f * e2 : 0.0f;
+      gv = l1 > l2 ? 2.0f * e1 : (l1 < l2 ? g2 : 0.5f * (2.0f * e1) + 0.5f * g2);
+    } else {
+      const float e1 = R - v;
+      vloss = e1 * e1;
+      gv = -2.0f * e1;
+    }
+    P.dvalue[i] = P.value_coef * gv * invB;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float r0 = wave_sum(surr), r1 = wave_sum(vloss), r2 = wave_sum(kl);
+  if (lane == 0) { red[wave][0] = r0; red[wave][1] = r1; red[wave][2] = r2; }
+  for (int j = 0; j < A; j++) {
+    float ds = 0.0f;
+    if (live) {
+      const float s = P.std[j], var = s * s, d = P.actions[i * A + j] - P.mu[i * A + j];
+      P.dmu[i * A + j] = g_logp * (d / var);               // d logp / d mu = (a - mu) / var
+      ds = g_logp * ((d * d) / (var * s) - 1.0f / s);
+    }
+    ds = wave_sum(ds);
+    if (lane == 0) red[wave][PPO_NRED + j] = ds;
+  }
+  __syncthreads();
+  if (threadIdx.x < PPO_NRED + A) {
+    float t = red[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < PPO_BLOCK / 64; w++) t += red[w][threadIdx.x];
+    P.partial[(size_t)blockIdx.x * (PPO_NRED + PPO_MAX_ACTIONS) + threadIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_ppo_loss_finish(PpoArgs P, int nblocks) {
+  __shared__ float tot[PPO_NRED];
+  const int q = threadIdx.x, A = P.A;
+  float t = 0.0f;
+  if (q < PPO_NRED + A)
+    for (int b = 0; b < nblocks; b++) t += P.partial[(size_t)b * (PPO_NRED + PPO_MAX_ACTIONS) + q];
+  if (q < PPO_NRED) tot[q] = t;
+  if (q >= PPO_NRED && q < PPO_NRED + A) {
+    const float s = P.std[q - PPO_NRED];
+    P.dstd[q - PPO_NRED] = t - P.entropy_coef * (1.0f / s);     // entropy of N(mu, s): 0.5 + 0.5 log(2 pi) + log s per column
+  }
+  __syncthreads();
+  if (q == 0) {
+    const float invB = 1.0f / (float)P.B;
+    float ent = 0.0f;
+    for (int j = 0; j < A; j++) ent += 1.41893853320467274178f + logf(P.std[j]);
+    const float sm = tot[0] * invB, vm = tot[1] * invB, km = tot[2] * invB;
+    P.out[0] = sm; P.out[1] = vm; P.out[2] = ent; P.out[3] = km;
+    P.out[4] = sm + P.value_coef * vm - P.entropy_coef * ent;
+  }
+}
+
 #ifdef SHF_MLP_PROBE_CLOCK
 extern "C" int shf_mlp_probe_read(long long* out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_probe), sizeof(long long) * n) == hipSuccess ? 0 : 1;
@@ -451,4 +559,27 @@ extern "C" int shf_mlp_linear_backward_weight(const float* dy, const float* y_or
   hipLaunchKernelGGL(k_mlp_reduce_slices, dim3((nw + nb + 255) / 256), dim3(256), 0, (hipStream_t)stream, part_w, dw, nw, part_b, db, nb,
                      slices);
   return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_mlp_linear_backward_weight: launch failed");
+}
+
+extern "C" int shf_ppo_loss_workspace(int64_t B, int32_t A, int64_t* floats) {
+  if (!floats || B <= 0 || A <= 0 || A > PPO_MAX_ACTIONS) return mlp_fail("shf_ppo_loss_workspace: bad argument (1 <= A <= 32)");
+  *floats = ((B + PPO_BLOCK - 1) / PPO_BLOCK) * (int64_t)(PPO_NRED + PPO_MAX_ACTIONS);
+  return 0;
+}
+
+extern "C" int shf_ppo_loss(const float* mu, const float* std, const float* value, const float* actions,
+                            const float* target_values, const float* advantages, const float* returns, const float* old_logp,
+                            const float* old_mu, const float* old_sigma, int64_t B, int32_t A, float clip, float value_coef,
+                            float entropy_coef, int32_t clipped_value, float* out5, float* dmu, float* dstd, float* dvalue,
+                            float* workspace, void* stream) {
+  if (!mu || !std || !value || !actions || !advantages || !returns || !old_logp || !old_mu || !old_sigma || !out5 || !dmu ||
+      !dstd || !dvalue || !workspace || (clipped_value && !target_values))
+    return mlp_fail("shf_ppo_loss: null tensor");
+  if (B <= 0 || A <= 0 || A > PPO_MAX_ACTIONS || B * (int64_t)A >= (1ll << 31)) return mlp_fail("shf_ppo_loss: bad shape (1 <= A <= 32)");
+  const int nblocks = (int)((B + PPO_BLOCK - 1) / PPO_BLOCK);
+  PpoArgs P{mu, std, value, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, (long long)B, A, clip,
+            value_coef, entropy_coef, clipped_value, out5, dmu, dstd, dvalue, workspace};
+  hipLaunchKernelGGL(k_ppo_loss, dim3(nblocks), dim3(PPO_BLOCK), 0, (hipStream_t)stream, P);
+  hipLaunchKernelGGL(k_ppo_loss_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, P, nblocks);
+  return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_ppo_loss: launch failed");
 }

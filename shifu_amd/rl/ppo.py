@@ -24,6 +24,12 @@ class PPO:
         self._updates_done = 0
         self.desired_kl, self.schedule = desired_kl, schedule
         self.actor_critic = actor_critic.to(device)
+        # fused_loss: the loss block and its gradient as one HIP pass (rl/fused_loss.py) instead of ~100 small autograd
+        # launches.  Same formulas, sums in another (fixed) order -- so it goes with the MFMA layer backend by default and
+        # the fp32 library path keeps the stock torch expressions; SHIFU_AMD_FUSED_PPO_LOSS=0/1 overrides.
+        want = os.environ.get("SHIFU_AMD_FUSED_PPO_LOSS")
+        self.fused_loss = (torch.device(device).type == "cuda"
+                           and (want == "1" if want in ("0", "1") else getattr(actor_critic, "mlp_backend", "torch") == "mfma"))
         self.storage = None
         # The learning rate is a device tensor shared with the optimizer: the adaptive schedule needs no host
         # round trip per mini-batch.
@@ -76,6 +82,8 @@ class PPO:
     def losses(self, obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma):
         """Loss terms of one mini-batch under the current parameters (also what tests/test_rl.py checks)."""
         ac = self.actor_critic
+        if self.fused_loss:
+            return self._fused_losses(obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma)
         if self._side is not None:
             # actor and critic are independent networks: the critic's forward (and, through autograd's stream bookkeeping,
             # its backward) runs on a second stream, so the small layers of one fill the CUs the other leaves idle
@@ -109,6 +117,25 @@ class PPO:
         ent = entropy.mean()
         return {"surrogate": surrogate_loss, "value": value_loss, "entropy": ent, "kl": kl,
                 "loss": surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * ent}
+
+    def _fused_losses(self, obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma):
+        """losses() with the loss block as one kernel: the two networks as before (critic on the second stream), then
+        shf_ppo_loss on (action means, std, values)."""
+        from .fused_loss import ppo_loss
+        ac = self.actor_critic
+        if self._side is not None:
+            cur = torch.cuda.current_stream()
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                value = ac.evaluate(cobs)
+            value.record_stream(cur)
+            mu = ac.actor(obs)
+            cur.wait_stream(self._side)
+        else:
+            mu, value = ac.actor(obs), ac.evaluate(cobs)
+        loss, stats = ppo_loss(mu, ac.std, value, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma,
+                               self.clip_param, self.value_loss_coef, self.entropy_coef, self.use_clipped_value_loss)
+        return {"surrogate": stats[0], "value": stats[1], "entropy": stats[2], "kl": stats[3], "loss": loss}
 
     @property
     def learning_rate(self) -> float:
