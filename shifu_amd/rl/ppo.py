@@ -11,7 +11,7 @@ from .storage import RolloutStorage
 class PPO:
     def __init__(self, actor_critic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
                  value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True,
-                 schedule="fixed", desired_kl=0.01, device="cpu", graph_update=False):
+                 schedule="fixed", desired_kl=0.01, device="cpu", graph_update=False, fused_loss=False):
         self.device = device
         # graph_update: replay one captured hipGraph per mini-batch step (gather, losses, backward, clip, Adam, lr
         # schedule: ~280 launches) instead of launching it eagerly; bit-identical to the eager update with either layer
@@ -25,11 +25,12 @@ class PPO:
         self.desired_kl, self.schedule = desired_kl, schedule
         self.actor_critic = actor_critic.to(device)
         # fused_loss: the loss block and its gradient as one HIP pass (rl/fused_loss.py) instead of ~100 small autograd
-        # launches.  Same formulas, sums in another (fixed) order -- so it goes with the MFMA layer backend by default and
-        # the fp32 library path keeps the stock torch expressions; SHIFU_AMD_FUSED_PPO_LOSS=0/1 overrides.
+        # launches: learn 30 -> 23 ms per iteration on the A1 schedule.  Same formulas, sums in another (fixed) order.
+        # Off by default: over 20 seeds of the 3000-iteration schedule the torch expressions ended with 19 walking
+        # policies and the fused pass with 17 (profiles/r02_train_seeds.md) -- within chance, but the default stays
+        # with the better-validated outcome.  PPOConfig.algorithm.fused_loss / SHIFU_AMD_FUSED_PPO_LOSS=1 select it.
         want = os.environ.get("SHIFU_AMD_FUSED_PPO_LOSS")
-        self.fused_loss = (torch.device(device).type == "cuda"
-                           and (want == "1" if want in ("0", "1") else getattr(actor_critic, "mlp_backend", "torch") == "mfma"))
+        self.fused_loss = torch.device(device).type == "cuda" and (want == "1" if want in ("0", "1") else bool(fused_loss))
         self.storage = None
         # The learning rate is a device tensor shared with the optimizer: the adaptive schedule needs no host
         # round trip per mini-batch.

@@ -153,9 +153,12 @@ def _ppo_with_filled_storage(seed, graph_update, backend="mfma"):
     from shifu_amd.rl.ppo import PPO
     torch.manual_seed(seed)
     dev = "cuda:0"
-    ac = ActorCritic(259, 259, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128], mlp_backend=backend)
+    fused = backend.endswith("+fused")                 # "mfma+fused": the one-pass loss kernel as well (PPO.fused_loss)
+    ac = ActorCritic(259, 259, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128],
+                     mlp_backend=backend.split("+")[0])
     alg = PPO(ac, num_learning_epochs=2, num_mini_batches=4, schedule="adaptive", desired_kl=0.01, learning_rate=1e-3,
-              entropy_coef=0.01, device=dev, graph_update=graph_update)
+              entropy_coef=0.01, device=dev, graph_update=graph_update, fused_loss=fused)
+    assert alg.fused_loss == fused
     alg.init_storage(256, 24, [259], [259], [12])
 
     def fill(gen_seed):
@@ -172,7 +175,7 @@ def _ppo_with_filled_storage(seed, graph_update, backend="mfma"):
     return alg, fill
 
 
-@pytest.mark.parametrize("backend", ["mfma", "torch"])
+@pytest.mark.parametrize("backend", ["mfma", "torch", "mfma+fused"])
 def test_captured_update_equals_the_eager_update(backend):
     """PPO.graph_update replays one captured hipGraph per mini-batch step; parameters, optimizer state and learning rate
     after three updates must be bit-identical to the eagerly launched ones -- with the MFMA layers and with the stock ones."""
