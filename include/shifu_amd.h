@@ -447,6 +447,14 @@ int shf_ppo_loss(const float* mu, const float* std, const float* value, const fl
                  const float* old_sigma, int64_t B, int32_t A, float clip, float value_coef, float entropy_coef,
                  int32_t clipped_value, float* out5, float* dmu, float* dstd, float* dvalue, float* workspace, void* stream);
 
+/* GAE(lambda) of one rollout (rsl_rl RolloutStorage.compute_returns [EXT], driven by shifu/runner/policy_runner.py:52-73
+ * with PPOConfig.algorithm.gamma / lam, shifu/configs/policy_config.py:18-31), before the advantage standardisation:
+ *   delta_t = r_t + gamma (1 - d_t) V_{t+1} - V_t;  A_t = delta_t + gamma lam (1 - d_t) A_{t+1};  returns_t = A_t + V_t
+ * rewards / values / returns (T, N) row-major fp32, dones (T, N) uint8, last_values (N) = V_T.  Same float32 operations in
+ * the same order as the torch loop it replaces: identical bits. */
+int shf_gae(const float* rewards, const float* values, const unsigned char* dones, const float* last_values, int32_t T,
+            int64_t N, float gamma, float lam, float* returns, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -395,6 +395,25 @@ void launch_gemm(hipStream_t st, const Operand& A, const Operand& B, int red, in
 }  // namespace
 
 
+// GAE(lambda) over a (T, N) rollout, one thread per env walking its T transitions backwards -- the same float32
+// operations, in the same order, as RolloutStorage.compute_returns' torch loop (rl/storage.py), so the results are
+// identical to the bit; it replaces that loop's ~9 launches per transition.
+__global__ __launch_bounds__(256) void k_gae(const float* __restrict__ rew, const float* __restrict__ val,
+                                             const unsigned char* __restrict__ done, const float* __restrict__ last, int T,
+                                             long long N, float gamma, float lam, float* __restrict__ ret) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  float adv = 0.0f;
+  for (int k = T - 1; k >= 0; k--) {
+    const float nxt = k == T - 1 ? last[i] : val[(long long)(k + 1) * N + i];
+    const float live = 1.0f - (float)done[(long long)k * N + i];
+    const float v = val[(long long)k * N + i], lg = live * gamma;
+    const float delta = (rew[(long long)k * N + i] + lg * nxt) - v;
+    adv = delta + (lg * lam) * adv;
+    ret[(long long)k * N + i] = adv + v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // PPO mini-batch loss, forward and gradient in one pass (shf_ppo_loss).  One thread per sample walks its A action
 // columns; block sums go through wave shuffles and LDS in a fixed order, the blocks' partial sums are added in block
@@ -582,4 +601,13 @@ extern "C" int shf_ppo_loss(const float* mu, const float* std, const float* valu
   hipLaunchKernelGGL(k_ppo_loss, dim3(nblocks), dim3(PPO_BLOCK), 0, (hipStream_t)stream, P);
   hipLaunchKernelGGL(k_ppo_loss_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, P, nblocks);
   return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_ppo_loss: launch failed");
+}
+
+extern "C" int shf_gae(const float* rewards, const float* values, const unsigned char* dones, const float* last_values, int32_t T,
+                       int64_t N, float gamma, float lam, float* returns, void* stream) {
+  if (!rewards || !values || !dones || !last_values || !returns) return mlp_fail("shf_gae: null tensor");
+  if (T <= 0 || N <= 0) return mlp_fail("shf_gae: bad shape");
+  hipLaunchKernelGGL(k_gae, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rewards, values, dones, last_values,
+                     (int)T, (long long)N, gamma, lam, returns);
+  return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_gae: launch failed");
 }

@@ -46,16 +46,36 @@ class RolloutStorage:
     def compute_returns(self, last_values, gamma, lam):
         """delta_t = r_t + gamma (1-d_t) V_{t+1} - V_t;  A_t = delta_t + gamma lam (1-d_t) A_{t+1};  R_t = A_t + V_t;
         advantages are then standardised over the whole buffer."""
-        adv = 0
-        for k in reversed(range(self.num_transitions_per_env)):
-            nxt = last_values if k == self.num_transitions_per_env - 1 else self.values[k + 1]
-            live = 1.0 - self.dones[k].float()
-            delta = self.rewards[k] + live * gamma * nxt - self.values[k]
-            adv = delta + live * gamma * lam * adv
-            self.returns[k] = adv + self.values[k]
+        if self.returns.is_cuda:
+            self._gae_kernel(last_values, gamma, lam)
+        else:
+            adv = 0
+            for k in reversed(range(self.num_transitions_per_env)):
+                nxt = last_values if k == self.num_transitions_per_env - 1 else self.values[k + 1]
+                live = 1.0 - self.dones[k].float()
+                delta = self.rewards[k] + live * gamma * nxt - self.values[k]
+                adv = delta + live * gamma * lam * adv
+                self.returns[k] = adv + self.values[k]
         # in place: a captured update graph reads this buffer at a fixed address
         adv = self.returns - self.values
         self.advantages.copy_((adv - adv.mean()) / (adv.std() + 1e-8))
+
+    def _gae_kernel(self, last_values, gamma, lam):
+        """The loop above as one launch (shf_gae, csrc/shf_mlp.hip): the same float32 operations in the same order, so
+        the same bits (tests/test_gpu_mlp.py) -- 1 launch instead of ~9 per transition."""
+        import ctypes as C
+        from .._lib import BackendError, lib
+        T, N = self.num_transitions_per_env, self.num_envs
+        last = last_values.detach().reshape(-1).contiguous()
+        if last.numel() != N or last.dtype != torch.float32 or not all(t.is_contiguous() for t in (self.rewards, self.values, self.dones, self.returns)):
+            raise BackendError("shf_gae: rollout buffers must be contiguous float32 (T, N, 1) and last_values (N, 1)")
+        p = lambda t: C.c_void_p(t.data_ptr())
+        dev = self.returns.device
+        with torch.cuda.device(dev):
+            rc = lib().shf_gae(p(self.rewards), p(self.values), p(self.dones), p(last), T, N, float(gamma), float(lam), p(self.returns),
+                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise BackendError(lib().shf_mlp_last_error().decode())
 
     def get_statistics(self):
         done = self.dones.clone()

@@ -317,3 +317,22 @@ def test_fused_ppo_loss_against_the_numpy_oracle():
         e = np.zeros(A); e[j] = h
         fd = (oracle_loss(n(std) + e)["loss"] - oracle_loss(n(std) - e)["loss"]) / (2 * h)
         assert abs(dstd[j] - fd) < 1e-4 * max(1.0, abs(fd)), (j, dstd[j], fd)
+
+
+@pytest.mark.parametrize("T,N", [(24, 4096), (7, 333), (1, 5)])
+def test_gae_kernel_is_bit_identical_to_the_torch_loop(T, N):
+    """RolloutStorage.compute_returns on the GPU (shf_gae, one launch) against the same class on the CPU (the torch loop
+    that tests/test_rl.py pins to the NumPy oracle): returns identical to the bit, advantages to summation order."""
+    _need_gpu()
+    from shifu_amd.rl.storage import RolloutStorage
+    g = torch.Generator().manual_seed(T * 1000 + N)
+    cpu, gpu = RolloutStorage(N, T, [3], [None], [2], device="cpu"), RolloutStorage(N, T, [3], [None], [2], device="cuda:0")
+    rew, val = torch.randn(T, N, 1, generator=g), torch.randn(T, N, 1, generator=g)
+    done = (torch.rand(T, N, 1, generator=g) < 0.1).to(torch.uint8)
+    last = torch.randn(N, 1, generator=g)
+    for st in (cpu, gpu):
+        st.rewards.copy_(rew); st.values.copy_(val); st.dones.copy_(done)
+        st.compute_returns(last.to(st.returns.device), 0.998, 0.95)
+    assert torch.equal(gpu.returns.cpu(), cpu.returns)
+    if T * N > 1:
+        torch.testing.assert_close(gpu.advantages.cpu(), cpu.advantages, rtol=1e-4, atol=1e-5)
