@@ -455,6 +455,16 @@ int shf_ppo_loss(const float* mu, const float* std, const float* value, const fl
 int shf_gae(const float* rewards, const float* values, const unsigned char* dones, const float* last_values, int32_t T,
             int64_t N, float gamma, float lam, float* returns, void* stream);
 
+/* n <= 16 contiguous device buffers copied by one launch (RolloutStorage.add_transitions' per-step writes, rsl_rl [EXT]);
+ * src / dst / bytes are HOST arrays of n entries; every buffer 4-byte aligned and a multiple of 4 bytes. */
+int shf_copy_many(const void* const* src, void* const* dst, const int64_t* bytes, int32_t n, void* stream);
+/* rsl_rl OnPolicyRunner.learn's per-step episode bookkeeping [EXT] as one launch:
+ *   cur_reward_sum += rewards; cur_episode_length += 1; d = dones != 0;
+ *   fin3 += { sum(cur_reward_sum d), sum(cur_episode_length d), sum(d) };  both buffers *= 1 - d
+ * rewards / buffers (N) fp32, dones (N) of done_itemsize bytes per entry (1, 2, 4 or 8: bool / integer types), fin3 (3) fp64. */
+int shf_episode_bookkeeping(const float* rewards, const void* dones, int32_t done_itemsize, int64_t N,
+                            float* cur_reward_sum, float* cur_episode_length, double* fin3, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

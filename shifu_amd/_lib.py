@@ -49,6 +49,8 @@ _SIGS = {
     "shf_mlp_set_precision": ([i32], i32),
     "shf_mlp_get_precision": ([], i32),
     "shf_mlp_linear_backward_weight": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], i32),
+    "shf_copy_many": ([C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), i32, vp], i32),
+    "shf_episode_bookkeeping": ([vp, vp, i32, i64, vp, vp, vp, vp], i32),
     "shf_gae": ([vp, vp, vp, vp, i32, i64, C.c_float, C.c_float, vp, vp], i32),
     "shf_ppo_loss_workspace": ([i64, i32, C.POINTER(i64)], i32),
     "shf_ppo_loss": ([vp] * 10 + [i64, i32, C.c_float, C.c_float, C.c_float, i32] + [vp] * 6, i32),

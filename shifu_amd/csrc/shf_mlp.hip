@@ -395,6 +395,52 @@ void launch_gemm(hipStream_t st, const Operand& A, const Operand& B, int red, in
 }  // namespace
 
 
+// Several contiguous buffers copied by one launch (the rollout's per-step writes into the RolloutStorage slots: ~8 small
+// device-to-device copies otherwise).  blockIdx.y picks the buffer, 4-byte words.
+constexpr int COPY_MAX = 16;
+struct CopyMany {
+  const unsigned* src[COPY_MAX];
+  unsigned* dst[COPY_MAX];
+  long long words[COPY_MAX];
+};
+__global__ __launch_bounds__(256) void k_copy_many(CopyMany C) {
+  const int b = blockIdx.y;
+  const unsigned* __restrict__ s = C.src[b];
+  unsigned* __restrict__ d = C.dst[b];
+  const long long n = C.words[b];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) d[i] = s[i];
+}
+
+// The runner's per-step episode bookkeeping (rsl_rl OnPolicyRunner.learn: cur_reward_sum / cur_episode_length, and the
+// sums over the episodes that ended in this step) as one single-block launch instead of ~16 element-wise / reduction
+// launches.  The two running buffers get the same float32 values as the torch expressions; the three sums (logging
+// only) are accumulated in double in a fixed order.
+__global__ __launch_bounds__(1024) void k_episode_bookkeeping(const float* __restrict__ rew, const unsigned char* __restrict__ done,
+                                                              int itemsize, long long N, float* __restrict__ crs,
+                                                              float* __restrict__ cel, double* __restrict__ fin) {
+  __shared__ double red[3][1024 / 64];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (long long i = threadIdx.x; i < N; i += 1024) {
+    bool dn = false;
+    for (int k = 0; k < itemsize; k++) dn |= done[i * itemsize + k] != 0;
+    const float d = dn ? 1.0f : 0.0f;
+    const float r = crs[i] + rew[i], l = cel[i] + 1.0f;
+    s0 += (double)(r * d); s1 += (double)(l * d); s2 += (double)d;
+    crs[i] = r * (1.0f - d);
+    cel[i] = l * (1.0f - d);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { s0 += __shfl_down(s0, off, 64); s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; red[2][wave] = s2; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double t = 0.0;
+    for (int w = 0; w < 1024 / 64; w++) t += red[threadIdx.x][w];
+    fin[threadIdx.x] += t;
+  }
+}
+
 // GAE(lambda) over a (T, N) rollout, one thread per env walking its T transitions backwards -- the same float32
 // operations, in the same order, as RolloutStorage.compute_returns' torch loop (rl/storage.py), so the results are
 // identical to the bit; it replaces that loop's ~9 launches per transition.
@@ -610,4 +656,31 @@ extern "C" int shf_gae(const float* rewards, const float* values, const unsigned
   hipLaunchKernelGGL(k_gae, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rewards, values, dones, last_values,
                      (int)T, (long long)N, gamma, lam, returns);
   return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_gae: launch failed");
+}
+
+extern "C" int shf_copy_many(const void* const* src, void* const* dst, const int64_t* bytes, int32_t n, void* stream) {
+  if (!src || !dst || !bytes || n <= 0 || n > COPY_MAX) return mlp_fail("shf_copy_many: 1..16 buffers");
+  CopyMany C{};
+  long long most = 0;
+  for (int i = 0; i < n; i++) {
+    if (!src[i] || !dst[i] || bytes[i] < 0 || (bytes[i] & 3) || ((uintptr_t)src[i] & 3) || ((uintptr_t)dst[i] & 3))
+      return mlp_fail("shf_copy_many: buffers must be non-null, 4-byte aligned, a multiple of 4 bytes");
+    C.src[i] = (const unsigned*)src[i]; C.dst[i] = (unsigned*)dst[i]; C.words[i] = bytes[i] / 4;
+    most = C.words[i] > most ? C.words[i] : most;
+  }
+  if (most == 0) return 0;
+  long long bx = (most + 1023) / 1024;                  // about four words per thread
+  if (bx > 4096) bx = 4096;
+  hipLaunchKernelGGL(k_copy_many, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, C);
+  return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_copy_many: launch failed");
+}
+
+extern "C" int shf_episode_bookkeeping(const float* rewards, const void* dones, int32_t done_itemsize, int64_t N,
+                                       float* cur_reward_sum, float* cur_episode_length, double* fin3, void* stream) {
+  if (!rewards || !dones || !cur_reward_sum || !cur_episode_length || !fin3) return mlp_fail("shf_episode_bookkeeping: null tensor");
+  if (N <= 0 || (done_itemsize != 1 && done_itemsize != 2 && done_itemsize != 4 && done_itemsize != 8))
+    return mlp_fail("shf_episode_bookkeeping: bad shape / dones item size");
+  hipLaunchKernelGGL(k_episode_bookkeeping, dim3(1), dim3(1024), 0, (hipStream_t)stream, rewards, (const unsigned char*)dones,
+                     (int)done_itemsize, (long long)N, cur_reward_sum, cur_episode_length, fin3);
+  return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_episode_bookkeeping: launch failed");
 }

@@ -131,14 +131,32 @@ class OnPolicyRunner:
                     if R.get("ep_sums") is None:
                         R["ep_sums"] = torch.zeros_like(infos["episode_sums"], dtype=torch.float64)
                     R["ep_sums"] += infos["episode_sums"]
-                R["cur_reward_sum"] += rewards
-                R["cur_episode_length"] += 1
-                d = (dones > 0).to(torch.float32)
-                R["fin"][0] += (R["cur_reward_sum"] * d).sum()
-                R["fin"][1] += (R["cur_episode_length"] * d).sum()
-                R["fin"][2] += d.sum()
-                R["cur_reward_sum"] *= 1.0 - d
-                R["cur_episode_length"] *= 1.0 - d
+                if rewards.is_cuda and rewards.dtype == torch.float32 and rewards.is_contiguous() and dones.is_contiguous() \
+                        and not dones.dtype.is_floating_point and dones.numel() == rewards.numel():
+                    self._bookkeeping_kernel(R, rewards, dones)      # one launch (shf_episode_bookkeeping) instead of ~16
+                else:
+                    R["cur_reward_sum"] += rewards
+                    R["cur_episode_length"] += 1
+                    d = (dones > 0).to(torch.float32)
+                    R["fin"][0] += (R["cur_reward_sum"] * d).sum()
+                    R["fin"][1] += (R["cur_episode_length"] * d).sum()
+                    R["fin"][2] += d.sum()
+                    R["cur_reward_sum"] *= 1.0 - d
+                    R["cur_episode_length"] *= 1.0 - d
+
+    @staticmethod
+    def _bookkeeping_kernel(R, rewards, dones):
+        """The block above as one launch: the running buffers get the same float32 values; the three sums (logging only)
+        are accumulated in double in a fixed order.  dones: bool / integer flags (nonzero = episode ended)."""
+        import ctypes as C
+        from .._lib import BackendError, lib
+        p = lambda t: C.c_void_p(t.data_ptr())
+        dev = rewards.device
+        with torch.cuda.device(dev):
+            rc = lib().shf_episode_bookkeeping(p(rewards), p(dones), dones.element_size(), rewards.numel(), p(R["cur_reward_sum"]),
+                                               p(R["cur_episode_length"]), p(R["fin"]), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise BackendError(lib().shf_mlp_last_error().decode())
 
     # -------------------------------------------------------------------- log
     def log(self, locs, width=80, pad=35):

@@ -28,17 +28,32 @@ class RolloutStorage:
         if self.step >= self.num_transitions_per_env:
             raise AssertionError("Rollout buffer overflow")
         k = self.step
-        self.observations[k].copy_(t.observations)
+        pairs = [(self.observations[k], t.observations), (self.actions[k], t.actions), (self.rewards[k], t.rewards),
+                 (self.values[k], t.values), (self.actions_log_prob[k], t.actions_log_prob), (self.mu[k], t.action_mean),
+                 (self.sigma[k], t.action_sigma)]
         if self.privileged_observations is not None:
-            self.privileged_observations[k].copy_(t.critic_observations)
-        self.actions[k].copy_(t.actions)
-        self.rewards[k].copy_(t.rewards.view(-1, 1))
-        self.dones[k].copy_(t.dones.view(-1, 1))
-        self.values[k].copy_(t.values)
-        self.actions_log_prob[k].copy_(t.actions_log_prob.view(-1, 1))
-        self.mu[k].copy_(t.action_mean)
-        self.sigma[k].copy_(t.action_sigma)
+            pairs.append((self.privileged_observations[k], t.critic_observations))
+        self.dones[k].copy_(t.dones.view(-1, 1))                 # (a dtype conversion: stays a torch copy)
+        if self.observations.is_cuda and all(src.dtype == torch.float32 and src.is_cuda and src.is_contiguous() and src.numel() == dst.numel()
+                                              for dst, src in pairs):
+            self._copy_many(pairs)                               # one launch (shf_copy_many) instead of one per tensor
+        else:
+            for dst, src in pairs:
+                dst.copy_(src.view(dst.shape))
         self.step += 1
+
+    def _copy_many(self, pairs):
+        import ctypes as C
+        from .._lib import BackendError, lib
+        n = len(pairs)
+        src = (C.c_void_p * n)(*[s.data_ptr() for _, s in pairs])
+        dst = (C.c_void_p * n)(*[d.data_ptr() for d, _ in pairs])
+        nbytes = (C.c_int64 * n)(*[4 * d.numel() for d, _ in pairs])
+        dev = self.observations.device
+        with torch.cuda.device(dev):
+            rc = lib().shf_copy_many(src, dst, nbytes, n, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise BackendError(lib().shf_mlp_last_error().decode())
 
     def clear(self):
         self.step = 0

@@ -336,3 +336,54 @@ def test_gae_kernel_is_bit_identical_to_the_torch_loop(T, N):
     assert torch.equal(gpu.returns.cpu(), cpu.returns)
     if T * N > 1:
         torch.testing.assert_close(gpu.advantages.cpu(), cpu.advantages, rtol=1e-4, atol=1e-5)
+
+
+def test_rollout_storage_writes_one_launch_equals_the_copies():
+    """RolloutStorage.add_transitions on the GPU (shf_copy_many: one launch for the eight float tensors) fills the slots with
+    exactly what the per-tensor copies write (the CPU path of the same class)."""
+    _need_gpu()
+    from shifu_amd.rl.storage import RolloutStorage
+    N, T = 333, 3
+    g = torch.Generator().manual_seed(1)
+    sts = [RolloutStorage(N, T, [7], [5], [2], device=d) for d in ("cpu", "cuda:0")]
+    for k in range(T):
+        vals = dict(observations=torch.randn(N, 7, generator=g), critic_observations=torch.randn(N, 5, generator=g),
+                    actions=torch.randn(N, 2, generator=g), rewards=torch.randn(N, generator=g), dones=torch.rand(N, generator=g) < 0.3,
+                    values=torch.randn(N, 1, generator=g), actions_log_prob=torch.randn(N, generator=g),
+                    action_mean=torch.randn(N, 2, generator=g), action_sigma=torch.rand(N, 2, generator=g))
+        for st in sts:
+            t = RolloutStorage.Transition()
+            for name, v in vals.items():
+                setattr(t, name, v.to(st.device))
+            st.add_transitions(t)
+    a, b = sts
+    for name in ("observations", "privileged_observations", "actions", "rewards", "dones", "values", "actions_log_prob", "mu", "sigma"):
+        assert torch.equal(getattr(b, name).cpu(), getattr(a, name)), name
+
+
+@pytest.mark.parametrize("dtype", [torch.bool, torch.uint8, torch.int64])
+def test_episode_bookkeeping_kernel_equals_the_torch_expressions(dtype):
+    """shf_episode_bookkeeping against the runner's torch expressions: running buffers identical to the bit, the logged sums
+    equal to float32 summation order (the kernel accumulates them in double)."""
+    _need_gpu()
+    from shifu_amd.rl.on_policy_runner import OnPolicyRunner
+    N, dev = 4099, "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(3)
+    mk = lambda: {"cur_reward_sum": torch.zeros(N, device=dev), "cur_episode_length": torch.zeros(N, device=dev),
+                  "fin": torch.zeros(3, dtype=torch.float64, device=dev)}
+    A, B = mk(), mk()
+    for _ in range(40):
+        rewards = torch.randn(N, device=dev, generator=g)
+        dones = (torch.rand(N, device=dev, generator=g) < 0.05).to(dtype)
+        OnPolicyRunner._bookkeeping_kernel(A, rewards, dones)
+        B["cur_reward_sum"] += rewards
+        B["cur_episode_length"] += 1
+        d = (dones > 0).to(torch.float32)
+        B["fin"][0] += (B["cur_reward_sum"] * d).sum()
+        B["fin"][1] += (B["cur_episode_length"] * d).sum()
+        B["fin"][2] += d.sum()
+        B["cur_reward_sum"] *= 1.0 - d
+        B["cur_episode_length"] *= 1.0 - d
+    assert torch.equal(A["cur_reward_sum"], B["cur_reward_sum"]) and torch.equal(A["cur_episode_length"], B["cur_episode_length"])
+    assert A["fin"][2] == B["fin"][2] and A["fin"][2] > 0
+    torch.testing.assert_close(A["fin"], B["fin"], rtol=1e-5, atol=1e-3)
