@@ -465,6 +465,15 @@ int shf_copy_many(const void* const* src, void* const* dst, const int64_t* bytes
 int shf_episode_bookkeeping(const float* rewards, const void* dones, int32_t done_itemsize, int64_t N,
                             float* cur_reward_sum, float* cur_episode_length, double* fin3, void* stream);
 
+/* RolloutStorage.mini_batch [EXT rsl_rl]: dst_k[i, :] = src_k[idx[i], :] for n <= 16 row-major tensors in one launch; src /
+ * dst / row_bytes are HOST arrays, idx_dev (rows) int64 on the device; rows 4-byte aligned multiples of 4 bytes. */
+int shf_gather_rows(const void* const* src, void* const* dst, const int32_t* row_bytes, int32_t n, const int64_t* idx_dev,
+                    int64_t rows, void* stream);
+/* PPO's adaptive learning-rate rule [EXT rsl_rl PPO.update, schedule == 'adaptive'] on device scalars:
+ *   lr = kl > kl_high ? max(lr * inv_down, lr_min) : (0 < kl < kl_low ? min(lr * up, lr_max) : lr) */
+int shf_adapt_lr(const float* kl_dev, float* lr_dev, float kl_high, float kl_low, float inv_down, float up, float lr_min,
+                 float lr_max, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,8 @@ _SIGS = {
     "shf_mlp_linear_backward_weight": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], i32),
     "shf_copy_many": ([C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), i32, vp], i32),
     "shf_episode_bookkeeping": ([vp, vp, i32, i64, vp, vp, vp, vp], i32),
+    "shf_gather_rows": ([C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), i32, vp, i64, vp], i32),
+    "shf_adapt_lr": ([vp, vp] + [C.c_float] * 6 + [vp], i32),
     "shf_gae": ([vp, vp, vp, vp, i32, i64, C.c_float, C.c_float, vp, vp], i32),
     "shf_ppo_loss_workspace": ([i64, i32, C.POINTER(i64)], i32),
     "shf_ppo_loss": ([vp] * 10 + [i64, i32, C.c_float, C.c_float, C.c_float, i32] + [vp] * 6, i32),

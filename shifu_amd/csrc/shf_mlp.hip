@@ -441,6 +441,34 @@ __global__ __launch_bounds__(1024) void k_episode_bookkeeping(const float* __res
   }
 }
 
+// Rows idx[i] of several row-major tensors gathered by one launch (RolloutStorage.mini_batch: nine index kernels
+// otherwise).  blockIdx.y picks the tensor; 4-byte words.
+struct GatherMany {
+  const unsigned* src[COPY_MAX];
+  unsigned* dst[COPY_MAX];
+  int row_words[COPY_MAX];
+};
+__global__ __launch_bounds__(256) void k_gather_rows(GatherMany G, const long long* __restrict__ idx, long long rows) {
+  const int b = blockIdx.y, w = G.row_words[b];
+  const unsigned* __restrict__ s = G.src[b];
+  unsigned* __restrict__ d = G.dst[b];
+  const long long total = rows * w;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long r = e / w;
+    const int c = (int)(e - r * w);
+    d[e] = s[idx[r] * w + c];
+  }
+}
+
+// PPO's adaptive learning-rate rule on the device scalar (rl/ppo.py: adapt_learning_rate), the torch expressions' float32
+// arithmetic: a tensor divided by a Python scalar is multiplied by the scalar's float32 reciprocal.
+__global__ void k_adapt_lr(const float* __restrict__ kl, float* __restrict__ lr, float kl_high, float kl_low, float inv_down, float up,
+                           float lr_min, float lr_max) {
+  const float k = kl[0], l = lr[0];
+  const float down = fmaxf(l * inv_down, lr_min), upv = fminf(l * up, lr_max);
+  lr[0] = k > kl_high ? down : ((k > 0.0f && k < kl_low) ? upv : l);
+}
+
 // GAE(lambda) over a (T, N) rollout, one thread per env walking its T transitions backwards -- the same float32
 // operations, in the same order, as RolloutStorage.compute_returns' torch loop (rl/storage.py), so the results are
 // identical to the bit; it replaces that loop's ~9 launches per transition.
@@ -683,4 +711,31 @@ extern "C" int shf_episode_bookkeeping(const float* rewards, const void* dones, 
   hipLaunchKernelGGL(k_episode_bookkeeping, dim3(1), dim3(1024), 0, (hipStream_t)stream, rewards, (const unsigned char*)dones,
                      (int)done_itemsize, (long long)N, cur_reward_sum, cur_episode_length, fin3);
   return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_episode_bookkeeping: launch failed");
+}
+
+extern "C" int shf_gather_rows(const void* const* src, void* const* dst, const int32_t* row_bytes, int32_t n, const int64_t* idx_dev,
+                               int64_t rows, void* stream) {
+  if (!src || !dst || !row_bytes || !idx_dev || n <= 0 || n > COPY_MAX) return mlp_fail("shf_gather_rows: 1..16 tensors");
+  if (rows <= 0) return 0;
+  GatherMany G{};
+  long long most = 0;
+  for (int i = 0; i < n; i++) {
+    if (!src[i] || !dst[i] || row_bytes[i] <= 0 || (row_bytes[i] & 3) || ((uintptr_t)src[i] & 3) || ((uintptr_t)dst[i] & 3))
+      return mlp_fail("shf_gather_rows: tensors must be non-null, 4-byte aligned, rows a multiple of 4 bytes");
+    G.src[i] = (const unsigned*)src[i]; G.dst[i] = (unsigned*)dst[i]; G.row_words[i] = row_bytes[i] / 4;
+    const long long t = rows * G.row_words[i];
+    most = t > most ? t : most;
+  }
+  long long bx = (most + 1023) / 1024;
+  if (bx > 8192) bx = 8192;
+  hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, G, (const long long*)idx_dev,
+                     (long long)rows);
+  return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_gather_rows: launch failed");
+}
+
+extern "C" int shf_adapt_lr(const float* kl_dev, float* lr_dev, float kl_high, float kl_low, float inv_down, float up, float lr_min,
+                            float lr_max, void* stream) {
+  if (!kl_dev || !lr_dev) return mlp_fail("shf_adapt_lr: null tensor");
+  hipLaunchKernelGGL(k_adapt_lr, dim3(1), dim3(1), 0, (hipStream_t)stream, kl_dev, lr_dev, kl_high, kl_low, inv_down, up, lr_min, lr_max);
+  return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_adapt_lr: launch failed");
 }

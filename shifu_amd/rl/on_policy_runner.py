@@ -126,7 +126,13 @@ class OnPolicyRunner:
             alg.process_env_step(rewards, dones, infos)
             if self.log_dir is not None:
                 if "episode" in infos:
-                    R["ep_infos"].append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in infos["episode"].items()})
+                    ep = infos["episode"]
+                    vals = list(ep.values())
+                    if vals and all(torch.is_tensor(v) and v.shape == vals[0].shape and v.dtype == vals[0].dtype
+                                    and v.device == vals[0].device for v in vals):
+                        R["ep_infos"].append((tuple(ep.keys()), torch.stack(vals)))      # one launch, not one clone per key
+                    else:
+                        R["ep_infos"].append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in ep.items()})
                 if "episode_sums" in infos:          # (sums..., count) of the episodes that finished in this step
                     if R.get("ep_sums") is None:
                         R["ep_sums"] = torch.zeros_like(infos["episode_sums"], dtype=torch.float64)
@@ -169,9 +175,18 @@ class OnPolicyRunner:
                "surrogate_loss": locs["mean_surrogate_loss"], "learning_rate": self.alg.learning_rate,
                "mean_noise_std": float(self.alg.actor_critic.std.detach().mean()), "total_timesteps": self.tot_timesteps,
                "total_time": self.tot_time}
-        if locs["ep_infos"]:
-            for key in locs["ep_infos"][0]:
-                vals = [torch.as_tensor(e[key], dtype=torch.float32, device=self.device).reshape(-1) for e in locs["ep_infos"]]
+        raw = locs["ep_infos"]
+        if raw and all(isinstance(e, tuple) and e[0] == raw[0][0] for e in raw):
+            # stacked per-step values with one key set: every key's rollout mean from one reduction and one host read
+            keys = raw[0][0]
+            means = torch.stack([e[1].to(torch.float32).reshape(len(keys), -1) for e in raw]).mean(dim=(0, 2)).tolist()
+            rec.update({"episode/" + k: m for k, m in zip(keys, means)})
+            ep_infos = []
+        else:
+            ep_infos = [dict(zip(e[0], e[1].unbind(0))) if isinstance(e, tuple) else e for e in raw]
+        if ep_infos:
+            for key in ep_infos[0]:
+                vals = [torch.as_tensor(e[key], dtype=torch.float32, device=self.device).reshape(-1) for e in ep_infos]
                 rec["episode/" + key] = float(torch.cat(vals).mean())
         sums, names = locs["R"].get("ep_sums"), getattr(self.env, "reward_names", None)
         if sums is not None and names is not None:

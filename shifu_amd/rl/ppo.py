@@ -168,6 +168,18 @@ class PPO:
         `kl_mean` may be a device scalar; the decision is taken on the device."""
         kl = torch.as_tensor(kl_mean, dtype=torch.float32, device=self.lr.device)
         lr = self.lr
+        if lr.is_cuda:
+            # the expressions below as one launch (shf_adapt_lr), same float32 arithmetic (tests/test_gpu_mlp.py)
+            import ctypes as C
+            from .._lib import BackendError, lib
+            f32 = lambda x: float(torch.tensor(x, dtype=torch.float32))
+            with torch.cuda.device(lr.device):
+                rc = lib().shf_adapt_lr(C.c_void_p(kl.data_ptr()), C.c_void_p(lr.data_ptr()), f32(self.desired_kl * 2.0),
+                                        f32(self.desired_kl / 2.0), f32(1.0) / f32(1.5), 1.5, 1e-5, 1e-2,
+                                        C.c_void_p(torch.cuda.current_stream(lr.device).cuda_stream))
+            if rc != 0:
+                raise BackendError(lib().shf_mlp_last_error().decode())
+            return
         down, up = torch.clamp(lr / 1.5, min=1e-5), torch.clamp(lr * 1.5, max=1e-2)
         lr.copy_(torch.where(kl > self.desired_kl * 2.0, down,
                              torch.where((kl > 0.0) & (kl < self.desired_kl / 2.0), up, lr)))

@@ -103,8 +103,29 @@ class RolloutStorage:
     def mini_batch(self, idx):
         """The rollout rows `idx` (flat (t, env) indices) as
         (obs, critic_obs, actions, values, advantages, returns, log_prob, mu, sigma)."""
-        f = lambda t: t.flatten(0, 1)[idx]
-        obs = f(self.observations)
-        cobs = f(self.privileged_observations) if self.privileged_observations is not None else obs
-        return (obs, cobs, f(self.actions), f(self.values), f(self.advantages), f(self.returns), f(self.actions_log_prob),
-                f(self.mu), f(self.sigma))
+        srcs = [self.observations, self.actions, self.values, self.advantages, self.returns, self.actions_log_prob, self.mu, self.sigma]
+        if self.privileged_observations is not None:
+            srcs.append(self.privileged_observations)
+        if self.observations.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous():
+            out = self._gather_rows(srcs, idx)                       # one launch (shf_gather_rows) instead of one per tensor
+        else:
+            out = [t.flatten(0, 1)[idx] for t in srcs]
+        obs, actions, values, adv, ret, logp, mu, sigma = out[:8]
+        cobs = out[8] if self.privileged_observations is not None else obs
+        return (obs, cobs, actions, values, adv, ret, logp, mu, sigma)
+
+    def _gather_rows(self, srcs, idx):
+        import ctypes as C
+        from .._lib import BackendError, lib
+        n, rows = len(srcs), idx.numel()
+        flat = [t.flatten(0, 1) for t in srcs]
+        out = [torch.empty((rows,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype) for t in flat]
+        src = (C.c_void_p * n)(*[t.data_ptr() for t in flat])
+        dst = (C.c_void_p * n)(*[t.data_ptr() for t in out])
+        rb = (C.c_int32 * n)(*[t[0].numel() * t.element_size() for t in flat])
+        dev = idx.device
+        with torch.cuda.device(dev):
+            rc = lib().shf_gather_rows(src, dst, rb, n, C.c_void_p(idx.data_ptr()), rows, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise BackendError(lib().shf_mlp_last_error().decode())
+        return out

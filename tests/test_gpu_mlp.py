@@ -387,3 +387,44 @@ def test_episode_bookkeeping_kernel_equals_the_torch_expressions(dtype):
     assert torch.equal(A["cur_reward_sum"], B["cur_reward_sum"]) and torch.equal(A["cur_episode_length"], B["cur_episode_length"])
     assert A["fin"][2] == B["fin"][2] and A["fin"][2] > 0
     torch.testing.assert_close(A["fin"], B["fin"], rtol=1e-5, atol=1e-3)
+
+
+def test_mini_batch_one_launch_gather_equals_indexing():
+    """RolloutStorage.mini_batch on the GPU (shf_gather_rows) returns exactly t.flatten(0, 1)[idx] for every tensor."""
+    _need_gpu()
+    from shifu_amd.rl.storage import RolloutStorage
+    for priv in ([5], [None]):
+        st = RolloutStorage(37, 6, [7], priv, [3], device="cuda:0")
+        g = torch.Generator(device="cuda:0").manual_seed(2)
+        for name in ("observations", "actions", "values", "advantages", "returns", "actions_log_prob", "mu", "sigma"):
+            getattr(st, name).copy_(torch.randn(getattr(st, name).shape, device="cuda:0", generator=g))
+        if st.privileged_observations is not None:
+            st.privileged_observations.copy_(torch.randn(st.privileged_observations.shape, device="cuda:0", generator=g))
+        idx = torch.randperm(37 * 6, device="cuda:0", generator=g)[:100]
+        got = st.mini_batch(idx)
+        f = lambda t: t.flatten(0, 1)[idx]
+        want = (f(st.observations), f(st.privileged_observations) if st.privileged_observations is not None else f(st.observations),
+                f(st.actions), f(st.values), f(st.advantages), f(st.returns), f(st.actions_log_prob), f(st.mu), f(st.sigma))
+        for a, b in zip(got, want):
+            assert a.shape == b.shape and torch.equal(a, b)
+
+
+def test_adaptive_learning_rate_kernel_equals_the_torch_expressions():
+    """shf_adapt_lr against the torch expressions of PPO.adapt_learning_rate over a grid of (kl, lr), boundaries included."""
+    _need_gpu()
+    from shifu_amd.rl.actor_critic import ActorCritic
+    from shifu_amd.rl.ppo import PPO
+    alg = PPO(ActorCritic(4, 4, 2, actor_hidden_dims=[8], critic_hidden_dims=[8]), schedule="adaptive", desired_kl=0.01, device="cuda:0")
+    kls = [0.0, -1.0, 1e-9, 0.004999, 0.005, 0.0050001, 0.0075, 0.02, 0.0200001, 0.3, float(torch.tensor(0.02, dtype=torch.float32)),
+           float(torch.tensor(0.005, dtype=torch.float32))]
+    lrs = [1e-5, 1.2e-5, 1.5e-5, 1e-3, 3.3e-4, 6.7e-3, 1e-2, 9.9e-3, 7.7777e-4]
+    for kl in kls:
+        for lr0 in lrs:
+            alg.lr.fill_(lr0)
+            alg.adapt_learning_rate(torch.tensor(kl, dtype=torch.float32, device="cuda:0"))
+            got = alg.lr.clone()
+            lr = torch.tensor(lr0, dtype=torch.float32, device="cuda:0")
+            k = torch.tensor(kl, dtype=torch.float32, device="cuda:0")
+            down, up = torch.clamp(lr / 1.5, min=1e-5), torch.clamp(lr * 1.5, max=1e-2)
+            want = torch.where(k > alg.desired_kl * 2.0, down, torch.where((k > 0.0) & (k < alg.desired_kl / 2.0), up, lr))
+            assert torch.equal(got, want), (kl, lr0, float(got), float(want))
