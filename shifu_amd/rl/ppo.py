@@ -26,9 +26,10 @@ class PPO:
         self.actor_critic = actor_critic.to(device)
         # fused_loss: the loss block and its gradient as one HIP pass (rl/fused_loss.py) instead of ~100 small autograd
         # launches: learn 30 -> 23 ms per iteration on the A1 schedule.  Same formulas, sums in another (fixed) order.
-        # Off by default: over 20 seeds of the 3000-iteration schedule the torch expressions ended with 19 walking
-        # policies and the fused pass with 17 (profiles/r02_train_seeds.md) -- within chance, but the default stays
-        # with the better-validated outcome.  PPOConfig.algorithm.fused_loss / SHIFU_AMD_FUSED_PPO_LOSS=1 select it.
+        # Off by default: over 28 seeds of the 3000-iteration schedule the torch expressions ended with 27 walking
+        # policies and the fused pass with 25, mean return 514 vs 498 (profiles/r02_train_seeds.md) -- not distinguishable
+        # at that sample size, but the default stays with the longer-validated form.  PPOConfig.algorithm.fused_loss /
+        # SHIFU_AMD_FUSED_PPO_LOSS=1 select it.
         want = os.environ.get("SHIFU_AMD_FUSED_PPO_LOSS")
         self.fused_loss = torch.device(device).type == "cuda" and (want == "1" if want in ("0", "1") else bool(fused_loss))
         self.storage = None
