@@ -218,7 +218,10 @@ def main():
     ap.add_argument("--workload", choices=["terrain", "flat", "trimesh", "abb"], default="terrain",
                     help="terrain = config 3 (height field); trimesh = the same samples as the mesh with vertical risers; "
                          "abb = config 5")
-    ap.add_argument("--group", type=int, default=None, help="lanes per env: 64 = one wavefront per env; default 32 (A1) / 16 (ABB), the fastest measured (DESIGN.md 6)")
+    ap.add_argument("--group", type=int, default=None, help="lanes per env: 64 = one wavefront per env; default 16 (A1, ABB), the fastest measured (DESIGN.md 6)")
+    ap.add_argument("--mapping", choices=["chain", "body"], default=None,
+                    help="A1 workloads: lane = kinematic chain (default; csrc/shf_chain.h) or lane = rigid body (the general kernels; "
+                         "default with --self-collision).  Kernel selection only: results are bit-identical")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--self-collision", action="store_true",
                     help="A1 workloads: collide the robot's own links (capsule pairs; the reference's collision filter 0, "
@@ -269,7 +272,8 @@ def main():
     from shifu_amd.parallel import gather_episode_stats
 
     abb = args.workload == "abb"
-    group = args.group or (16 if abb else 32)
+    mapping = "body" if abb else (args.mapping or "body")
+    group = args.group or (16 if (abb or mapping == "chain") else 32)
     if abb:
         from shifu_amd.gym.abb_fused import FusedAbbEnv
         env = FusedAbbEnv(num_envs=args.envs, device=dev, seed=42, rank=rank, world_size=world, group=group)
@@ -278,7 +282,7 @@ def main():
     else:
         from shifu_amd.gym.a1_fused import FusedA1Env
         env = FusedA1Env(num_envs=args.envs, device=dev, terrain={"terrain": "heightfield", "flat": "flat", "trimesh": "trimesh"}[args.workload],
-                         seed=42, rank=rank, world_size=world, group=group, decimation=args.decimation,
+                         seed=42, rank=rank, world_size=world, group=group, mapping=mapping, decimation=args.decimation,
                          extra_substep=not args.no_extra_substep, self_collision=args.self_collision)
         stats_t, count_t, kernel = _abi.A1_STATS, _abi.A1_RESET_COUNT, "k_a1_step"
         substeps = args.decimation + (0 if args.no_extra_substep else 1)
@@ -357,7 +361,7 @@ def main():
         value = total_envs * args.steps / elapsed
         b_alg = B_ALG[args.workload]
         achieved = b_alg * N / (kern_ms * 1e-3) / 1e9
-        prof = committed_profile(f"{kernel}_{args.workload}_g{group}") if (N == 4096 and not args.self_collision) else None
+        prof = committed_profile(f"{kernel}_{args.workload}_g{group}" + ("_chain" if mapping == "chain" else "")) if (N == 4096 and not args.self_collision) else None
         res = {}
         try:
             res = json.load(open(os.path.join(ROOT, "shifu_amd", "libshifu_amd.resources.json")))
@@ -392,7 +396,7 @@ def main():
             "config": {"workload": f"{WL_NAME[args.workload]}, {N} envs/GPU, random actions, {substeps} substeps/env-step "
                                    f"(dt {'20' if abb else '5'} ms), resets on",
                        "envs_per_gpu": N, "total_envs": total_envs, "substeps_per_env_step": substeps,
-                       "lanes_per_env": group, "self_collision": bool(args.self_collision) and not abb, "vec_step": "hipGraph replay of [uniform_, fused step]" if graph is not None else "eager launches",
+                       "lanes_per_env": group, "lane_mapping": mapping, "self_collision": bool(args.self_collision) and not abb, "vec_step": "hipGraph replay of [uniform_, fused step]" if graph is not None else "eager launches",
                        "parallelism": f"env-sharded x{world}, all-gather of episode stats every {args.log_interval} steps",
                        "substeps_per_s": value * substeps, "obs_finite": finite, "episodes_reset_rank0": resets},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SHF_ABI_VERSION 6
+#define SHF_ABI_VERSION 7
 
 #define SHF_MAX_BODIES 32 /* reported rigid bodies per articulation        */
 #define SHF_MAX_DOFS 32
@@ -90,6 +90,13 @@ typedef struct ShfModel {
   int32_t pt_body[SHF_MAX_POINTS]; /* reported body the force is logged on */
   float pt_pos[SHF_MAX_POINTS][3]; /* in pt_body's frame                   */
   float pt_radius[SHF_MAX_POINTS];
+  /* Evaluation order hint for kernels that evaluate the points in rounds of one per lane: slot s evaluates point
+   * pt_eval[s] (a permutation of 0..np-1, lowest points of the rest pose first, so that the points that usually touch
+   * the ground share the first round and the later rounds can skip the contact response wave-wide); pt_slot is its
+   * inverse.  Results do not depend on it: contacts are folded into their body in point order whatever the order of
+   * evaluation.  The model compiler fills both; an all-zero pt_eval reads as the identity. */
+  int32_t pt_eval[SHF_MAX_POINTS];
+  int32_t pt_slot[SHF_MAX_POINTS];
 
   /* Rounded shapes of the articulation tested against the free box actors: a sphere (sph_seg = 0), or a capsule --
    * the segment sph_pos + t sph_seg, t in [0,1], swept by sph_radius (the native form of the URDF <cylinder> under
@@ -173,6 +180,12 @@ typedef struct ShfTerrain {
    *    i-1, bit 5 row i+1, bit 6 column j-1, bit 7 column j+1 (set where a triangle of a
    *    neighbouring cell reaches into this one; none set: that one cell only).           */
   int32_t warped;
+  /* Optional hint: a lower bound on the z component of every unit surface normal terrain queries can return (height
+   * field: 1 / sqrt(1 + Gx^2 + Gy^2) with Gx, Gy the largest sample-to-sample slopes along x and y).  A sample point
+   * whose clearance (z - h) * nz_min exceeds contact_offset + radius cannot be within the contact offset, so its
+   * normal need not be evaluated.  0 = unknown: no query is shortened.  A value that is not a true lower bound
+   * silently drops contacts -- leave it 0 unless computed from the samples (shifu_amd/backend.py does). */
+  float nz_min;
 } ShfTerrain;
 
 /* Tensor ids for shf_sim_bind / shf_sim_layout.  State tensors follow the
@@ -239,6 +252,13 @@ int shf_sim_reset_all(ShfSim* sim, const float* default_root_dev /* (A,13) */, c
 /* Lanes per env for the kernels (64 = one wavefront per env, default; 32/16 pack
  * 2/4 envs per wavefront).  Not part of the reference API: a tuning knob. */
 int shf_sim_set_group(ShfSim* sim, int32_t lanes);
+/* Lane mapping of the fused A1 step (shf_a1_step).  SHF_MAP_BODY: lane = reported body, the tree is walked level by
+ * level through LDS hand-offs (any articulation).  SHF_MAP_CHAIN: lane = kinematic chain, its links' state in
+ * registers (csrc/shf_chain.h); only for a floating root with serial revolute chains that end in one welded body --
+ * the Unitree A1 -- without self-collision; 16 or 32 lanes per env (call before shf_sim_set_group).  Same results bit
+ * for bit either way.  Not part of the reference API: a tuning knob.  Fails if the articulation has another shape. */
+enum { SHF_MAP_BODY = 0, SHF_MAP_CHAIN = 1 };
+int shf_sim_set_mapping(ShfSim* sim, int32_t mapping);
 
 /* gym.simulate (a1_conditional.py:69, robot.py:69, isaac_gym.py:140) */
 int shf_sim_step(ShfSim* sim, void* stream);

@@ -1,7 +1,8 @@
 """ctypes mirrors of the PODs in include/shifu_amd.h (keep in lock-step)."""
 import ctypes as C
 
-SHF_ABI_VERSION = 6
+SHF_ABI_VERSION = 7
+MAP_BODY, MAP_CHAIN = 0, 1   # shf_sim_set_mapping
 MAX_BODIES = 32
 MAX_DOFS = 32
 MAX_POINTS = 176
@@ -33,6 +34,7 @@ class ShfModel(C.Structure):
         ("armature", f32 * MAX_DOFS), ("damping", f32 * MAX_DOFS),
         ("drive_mode", i32 * MAX_DOFS), ("dof_body", i32 * MAX_DOFS),
         ("pt_body", i32 * MAX_POINTS), ("pt_pos", (f32 * 3) * MAX_POINTS), ("pt_radius", f32 * MAX_POINTS),
+        ("pt_eval", i32 * MAX_POINTS), ("pt_slot", i32 * MAX_POINTS),
         ("sph_body", i32 * MAX_SPHERES), ("sph_pos", (f32 * 3) * MAX_SPHERES), ("sph_seg", (f32 * 3) * MAX_SPHERES), ("sph_radius", f32 * MAX_SPHERES),
         ("self_collide", i32), ("ncap", i32), ("npair", i32), ("pad_sc", i32),
         ("cap_body", i32 * MAX_CAPSULES), ("cap_a", (f32 * 3) * MAX_CAPSULES), ("cap_b", (f32 * 3) * MAX_CAPSULES),
@@ -57,7 +59,7 @@ class ShfSimParams(C.Structure):
 
 class ShfTerrain(C.Structure):
     _fields_ = [("rows", i32), ("cols", i32), ("hscale", f32), ("vscale", f32), ("border", f32),
-                ("friction", f32), ("warped", i32)]
+                ("friction", f32), ("warped", i32), ("nz_min", f32)]
 
 
 class ShfA1TaskParams(C.Structure):

@@ -20,6 +20,7 @@ _SIGS = {
     "shf_sim_add_box": ([vp, C.POINTER(_abi.ShfBoxDesc)], i32),
     "shf_sim_finalize": ([vp, i32, i64], i32),
     "shf_sim_set_group": ([vp, i32], i32),
+    "shf_sim_set_mapping": ([vp, i32], i32),
     "shf_sim_layout": ([vp, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)], i32),
     "shf_sim_bind": ([vp, i32, vp], i32),
     "shf_sim_reset_all": ([vp, vp, vp, vp, vp], i32),

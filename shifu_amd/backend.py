@@ -59,6 +59,16 @@ def _struct_to_device(s, device) -> torch.Tensor:
     return torch.frombuffer(bytearray(bytes(s)), dtype=torch.uint8).to(device)
 
 
+def heightfield_nz_min(samples: np.ndarray, hscale: float, vscale: float) -> float:
+    """ShfTerrain.nz_min: a lower bound on n_z of every normal a height-field query can return.  The query's gradients
+    are differences of neighbouring samples along x and along y (either triangle of a cell), so the steepest normal is
+    bounded by the largest such differences; 1 % is taken off for the float32 arithmetic of the kernel."""
+    s = samples.astype(np.int64)
+    gx = float(np.abs(np.diff(s, axis=0)).max()) * vscale / hscale if s.shape[0] > 1 else 0.0
+    gy = float(np.abs(np.diff(s, axis=1)).max()) * vscale / hscale if s.shape[1] > 1 else 0.0
+    return float(0.99 / np.sqrt(1.0 + gx * gx + gy * gy))
+
+
 class Sim:
     """One `gym.create_sim` worth of state on one GPU."""
 
@@ -87,6 +97,7 @@ class Sim:
         t = _abi.ShfTerrain()
         t.rows = t.cols = 0
         t.hscale, t.vscale, t.border, t.friction = 1.0, 1.0, 0.0, friction
+        t.nz_min = 0.99          # the plane's normal is (0, 0, 1)
         self.terrain = t
         check(lib().shf_sim_set_terrain(self._h, C.byref(t)))
 
@@ -99,6 +110,7 @@ class Sim:
         t.rows, t.cols = samples.shape
         t.hscale, t.vscale, t.border, t.friction = hscale, vscale, border, friction
         t.warped = 0 if warp is None else 1
+        t.nz_min = 0.0 if warp is not None else heightfield_nz_min(samples, hscale, vscale)
         self.terrain = t
         self.height_samples = np.ascontiguousarray(samples)
         if warp is None:
@@ -131,11 +143,19 @@ class Sim:
         self.tensors[tid] = t
         check(lib().shf_sim_bind(self._h, tid, C.c_void_p(t.data_ptr())))
 
-    def finalize(self, num_envs: int, env_id_offset: int = 0, group: int = 64):
+    def finalize(self, num_envs: int, env_id_offset: int = 0, group: int = 64, mapping: str = "body"):
+        """group: lanes per env; mapping: 'body' (lane = rigid body, any articulation) or 'chain' (lane = kinematic chain,
+        A1-shaped trees only, 16 or 32 lanes; csrc/shf_chain.h) -- kernel selection, identical results."""
         self.num_envs = num_envs
         self.group = group
+        self.mapping = mapping
         check(lib().shf_sim_finalize(self._h, num_envs, env_id_offset))
-        if group != 64:
+        if mapping == "chain":
+            check(lib().shf_sim_set_mapping(self._h, _abi.MAP_CHAIN))
+            check(lib().shf_sim_set_group(self._h, group))
+        elif mapping != "body":
+            raise ValueError("mapping must be 'body' or 'chain'")
+        elif group != 64:
             check(lib().shf_sim_set_group(self._h, group))
         for tid in range(_abi.T_COUNT):
             if tid == _abi.T_HEIGHTS:
@@ -273,6 +293,8 @@ class A1Task:
         """Mangled-name prefix of the instantiation shf_a1_step launches for this sim (build resource table)."""
         g, warped = self.sim.group, bool(self.sim.terrain.warped)
         mdl = self.sim.model
+        if getattr(self.sim, "mapping", "body") == "chain":
+            return f"_Z10k_a1_chainILi{g}ELb{int(warped)}EE"
         a1 = mdl.nb == 17 and mdl.nd == 12 and mdl.np == 76
         if mdl.self_collide and mdl.npair > 0:
             if a1:

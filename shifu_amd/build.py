@@ -11,8 +11,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libshifu_amd.so")
-SOURCES = ["shf_api.hip", "shf_mlp.hip"]
-DEPS = ["shf_api.hip", "shf_mlp.hip", "shf_device.h", "shf_boxes.h", os.path.join("..", "..", "include", "shifu_amd.h")]
+SOURCES = ["shf_api.hip", "shf_a1_chain.hip", "shf_mlp.hip"]
+DEPS = SOURCES + ["shf_device.h", "shf_boxes.h", "shf_task.h", "shf_chain.h", os.path.join("..", "..", "include", "shifu_amd.h")]
 # -fno-slp-vectorize: the SLP vectoriser packs neighbouring scalar f32 ops into v_pk_* pairs plus the
 # v_mov shuffles that feed them -- slower for this kernel (measured -6 % at 2 envs/wave, -25 % at one
 # wavefront per env; cf. MI355X_MICROARCH.md "packed f32 VALU ... an anti-lever").
@@ -20,7 +20,7 @@ DEPS = ["shf_api.hip", "shf_mlp.hip", "shf_device.h", "shf_boxes.h", os.path.joi
 # on every LDS read individually (s_waitcnt lgkmcnt(0) after each ds_read); these kernels run at <= 2 waves per
 # SIMD and are bound by single-wave latency, so batching the reads matters more (measured 0.087 -> 0.079 ms).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
-         "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fPIC", "-shared"]
+         "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fPIC"]
 
 
 def hipcc() -> str:
@@ -74,15 +74,37 @@ def check_budgets(res: dict):
                 raise RuntimeError(f"{k}: {v} exceeds the register budget ({max_vgpr} VGPRs, {max_scratch} B scratch)")
 
 
-def build_native(force: bool = False, verbose: bool = False) -> str:
-    if force or needs_build() or not os.path.exists(RESOURCES):
-        cmd = [hipcc()] + FLAGS + ["-Rpass-analysis=kernel-resource-usage"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+def compile_all(flags, lib, extra=(), verbose=False) -> str:
+    """One object per translation unit (compiled side by side), then the link; returns the resource-usage remarks."""
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(HERE, "build", os.path.basename(lib) + ".obj")
+    os.makedirs(objdir, exist_ok=True)
+
+    def one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc()] + list(flags) + list(extra) + ["-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         if p.returncode != 0:
-            raise RuntimeError("hipcc failed:\n" + p.stderr[-4000:])
-        res = parse_resources(p.stderr)
+            raise RuntimeError("hipcc failed on " + src + ":\n" + p.stderr[-4000:])
+        return obj, p.stderr
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        done = list(ex.map(one, SOURCES))
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _ in done] + ["-o", lib]
+    if verbose:
+        print(" ".join(cmd))
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if p.returncode != 0:
+        raise RuntimeError("link failed:\n" + p.stderr[-4000:])
+    return "\n".join(r for _, r in done)
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    if force or needs_build() or not os.path.exists(RESOURCES):
+        remarks = compile_all(FLAGS, LIB, verbose=verbose)
+        res = parse_resources(remarks)
         with open(RESOURCES, "w") as f:
             json.dump(res, f, indent=1, sort_keys=True)
         check_budgets(res)

@@ -603,34 +603,34 @@ DEV void kinematics(const ShfModel* m, const EnvLds& L, int l, const LM& M, Body
 }
 
 // spatial inertia about O in world axes (packed) and velocity-product bias force
-DEV void rigid_inertia(float mass, const float* com, const float* I6, BodyRegs& B) {
+DEV void rigid_inertia_p(float mass, const float* com, const float* I6, const float* Rw, const float* p, const float* v,
+                         float* IA, float* pA) {
   float cw[3], Ic[9], T[9];
-  mv3(B.Rw, com, cw);
+  mv3(Rw, com, cw);
 #pragma unroll
-  for (int k = 0; k < 3; k++) cw[k] += B.p[k];
+  for (int k = 0; k < 3; k++) cw[k] += p[k];
   Ic[0] = I6[0]; Ic[1] = I6[1]; Ic[2] = I6[2];
   Ic[3] = I6[1]; Ic[4] = I6[3]; Ic[5] = I6[4];
   Ic[6] = I6[2]; Ic[7] = I6[4]; Ic[8] = I6[5];
-  mm3(B.Rw, Ic, T);
+  mm3(Rw, Ic, T);
   const float c2 = dot3(cw, cw);
 #pragma unroll
-  for (int k = 0; k < 21; k++) B.IA[k] = 0.0f;
+  for (int k = 0; k < 21; k++) IA[k] = 0.0f;
 #pragma unroll
   for (int i = 0; i < 3; i++)
 #pragma unroll
     for (int j = i; j < 3; j++) {
-      float iw = dot3(T + 3 * i, B.Rw + 3 * j);
+      float iw = dot3(T + 3 * i, Rw + 3 * j);
       float par = (i == j ? c2 : 0.0f) - cw[i] * cw[j];
-      B.IA[SYM(i, j)] = fmaf(mass, par, iw);
+      IA[SYM(i, j)] = fmaf(mass, par, iw);
     }
   float h[3] = {mass * cw[0], mass * cw[1], mass * cw[2]};
-  B.IA[SYM(0, 4)] = -h[2]; B.IA[SYM(0, 5)] = h[1];
-  B.IA[SYM(1, 3)] = h[2];  B.IA[SYM(1, 5)] = -h[0];
-  B.IA[SYM(2, 3)] = -h[1]; B.IA[SYM(2, 4)] = h[0];
-  B.IA[SYM(3, 3)] = mass; B.IA[SYM(4, 4)] = mass; B.IA[SYM(5, 5)] = mass;
-  const float* v = B.v;
-  float J[9] = {B.IA[SYM(0, 0)], B.IA[SYM(0, 1)], B.IA[SYM(0, 2)], B.IA[SYM(0, 1)], B.IA[SYM(1, 1)],
-                B.IA[SYM(1, 2)], B.IA[SYM(0, 2)], B.IA[SYM(1, 2)], B.IA[SYM(2, 2)]};
+  IA[SYM(0, 4)] = -h[2]; IA[SYM(0, 5)] = h[1];
+  IA[SYM(1, 3)] = h[2];  IA[SYM(1, 5)] = -h[0];
+  IA[SYM(2, 3)] = -h[1]; IA[SYM(2, 4)] = h[0];
+  IA[SYM(3, 3)] = mass; IA[SYM(4, 4)] = mass; IA[SYM(5, 5)] = mass;
+  float J[9] = {IA[SYM(0, 0)], IA[SYM(0, 1)], IA[SYM(0, 2)], IA[SYM(0, 1)], IA[SYM(1, 1)],
+                IA[SYM(1, 2)], IA[SYM(0, 2)], IA[SYM(1, 2)], IA[SYM(2, 2)]};
   float n[3], f[3], t[3], t2[3];
   mv3(J, v, n);
   cross3(h, v + 3, t);
@@ -642,10 +642,13 @@ DEV void rigid_inertia(float mass, const float* com, const float* I6, BodyRegs& 
   cross3(v, n, t);
   cross3(v + 3, f, t2);
 #pragma unroll
-  for (int k = 0; k < 3; k++) B.pA[k] = t[k] + t2[k];
+  for (int k = 0; k < 3; k++) pA[k] = t[k] + t2[k];
   cross3(v, f, t);
 #pragma unroll
-  for (int k = 0; k < 3; k++) B.pA[3 + k] = t[k];
+  for (int k = 0; k < 3; k++) pA[3 + k] = t[k];
+}
+DEV void rigid_inertia(float mass, const float* com, const float* I6, BodyRegs& B) {
+  rigid_inertia_p(mass, com, I6, B.Rw, B.p, B.v, B.IA, B.pA);
 }
 template <class LM>
 DEV void body_inertia(const LM& M, BodyRegs& B) { rigid_inertia(M.mass, M.com, M.I6, B); }
@@ -770,12 +773,12 @@ DEV float contact_point_response(const ContactConsts& K, const float* pb, float*
 
 // Fold one active contact slot into its body's bias force and articulated inertia:
 // pA -= [r x f0; f0],  IA += dt * (c_t * PointMass(r) + (beta - c_t) * w w^T),  w = [r x n; n].
-DEV void contact_accumulate(const float* o, float dt, BodyRegs& B) {
+DEV void contact_accumulate_p(const float* o, float dt, float* IA, float* pA) {
   const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]}, n[3] = {o[PT_N], o[PT_N + 1], o[PT_N + 2]}, f0[3] = {o[PT_F], o[PT_F + 1], o[PT_F + 2]};
   float t[3], wn[6];
   cross3(r, f0, t);
 #pragma unroll
-  for (int k = 0; k < 3; k++) { B.pA[k] -= t[k]; B.pA[3 + k] -= f0[k]; }
+  for (int k = 0; k < 3; k++) { pA[k] -= t[k]; pA[3 + k] -= f0[k]; }
   cross3(r, n, t);
 #pragma unroll
   for (int k = 0; k < 3; k++) { wn[k] = t[k]; wn[3 + k] = n[k]; }
@@ -785,18 +788,19 @@ DEV void contact_accumulate(const float* o, float dt, BodyRegs& B) {
   for (int i2 = 0; i2 < 3; i2++)
 #pragma unroll
     for (int j2 = i2; j2 < 3; j2++)
-      B.IA[SYM(i2, j2)] = fmaf(a, (i2 == j2 ? r2 : 0.0f) - r[i2] * r[j2], B.IA[SYM(i2, j2)]);
-  B.IA[SYM(0, 4)] = fmaf(a, -r[2], B.IA[SYM(0, 4)]); B.IA[SYM(0, 5)] = fmaf(a, r[1], B.IA[SYM(0, 5)]);
-  B.IA[SYM(1, 3)] = fmaf(a, r[2], B.IA[SYM(1, 3)]);  B.IA[SYM(1, 5)] = fmaf(a, -r[0], B.IA[SYM(1, 5)]);
-  B.IA[SYM(2, 3)] = fmaf(a, -r[1], B.IA[SYM(2, 3)]); B.IA[SYM(2, 4)] = fmaf(a, r[0], B.IA[SYM(2, 4)]);
-  B.IA[SYM(3, 3)] += a; B.IA[SYM(4, 4)] += a; B.IA[SYM(5, 5)] += a;
+      IA[SYM(i2, j2)] = fmaf(a, (i2 == j2 ? r2 : 0.0f) - r[i2] * r[j2], IA[SYM(i2, j2)]);
+  IA[SYM(0, 4)] = fmaf(a, -r[2], IA[SYM(0, 4)]); IA[SYM(0, 5)] = fmaf(a, r[1], IA[SYM(0, 5)]);
+  IA[SYM(1, 3)] = fmaf(a, r[2], IA[SYM(1, 3)]);  IA[SYM(1, 5)] = fmaf(a, -r[0], IA[SYM(1, 5)]);
+  IA[SYM(2, 3)] = fmaf(a, -r[1], IA[SYM(2, 3)]); IA[SYM(2, 4)] = fmaf(a, r[0], IA[SYM(2, 4)]);
+  IA[SYM(3, 3)] += a; IA[SYM(4, 4)] += a; IA[SYM(5, 5)] += a;
 #pragma unroll
   for (int i2 = 0; i2 < 6; i2++) {
     const float bw = bb * wn[i2];
 #pragma unroll
-    for (int j2 = i2; j2 < 6; j2++) B.IA[SYM(i2, j2)] = fmaf(bw, wn[j2], B.IA[SYM(i2, j2)]);
+    for (int j2 = i2; j2 < 6; j2++) IA[SYM(i2, j2)] = fmaf(bw, wn[j2], IA[SYM(i2, j2)]);
   }
 }
+DEV void contact_accumulate(const float* o, float dt, BodyRegs& B) { contact_accumulate_p(o, dt, B.IA, B.pA); }
 
 // End-of-step force of an active slot: f = f0 - dt * B * a_point with the body's solved acceleration `ab`.
 DEV void contact_force_final(float* o, const float* ab, float dt) {

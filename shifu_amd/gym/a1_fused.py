@@ -62,10 +62,10 @@ class FusedA1Env:
 
     def __init__(self, num_envs: int = 4096, device="cuda:0", terrain: str = "heightfield", seed: int = 42,
                  rank: int = 0, world_size: int = 1, terrain_cfg=None, sim_params: Optional[_abi.ShfSimParams] = None,
-                 group: int = 32, episode_length_s: float = 10.0, dt: float = 0.005, decimation: int = 4,
+                 group: Optional[int] = None, episode_length_s: float = 10.0, dt: float = 0.005, decimation: int = 4,
                  terrain_seed: int = 42, send_timeouts: bool = True, extra_substep: bool = True,
                  model_edit=None, task_overrides: Optional[dict] = None, dof_stiffness: float = 20.0,
-                 dof_damping: float = 0.5, self_collision: bool = False):
+                 dof_damping: float = 0.5, self_collision: bool = False, mapping: Optional[str] = None):
         self.device = torch.device(device)
         self.num_envs = num_envs
         self.rank, self.world_size = rank, world_size
@@ -116,7 +116,14 @@ class FusedA1Env:
         self.sim.set_heightfield(np.ascontiguousarray(samples), ct.horizontal_scale, ct.vertical_scale, ct.border_size,
                                  ct.static_friction, warp=warp)
         self.sim.set_articulation(self.cm.blob)
-        self.sim.finalize(num_envs, self.env_id_offset, group=group)
+        # kernel selection (same results bit for bit): lane = rigid body (any articulation, 32 lanes for the A1) or
+        # lane = kinematic chain (mapping="chain": A1-shaped trees, 16 lanes per env, no self-collision)
+        if mapping is None:
+            mapping = "body"
+        if group is None:
+            group = 16 if mapping == "chain" else 32
+        self.mapping, self.group = mapping, group
+        self.sim.finalize(num_envs, self.env_id_offset, group=group, mapping=mapping)
 
         self.max_episode_length_s = episode_length_s
         self.task_params = a1_task_params(self.cm, dt=dt, decimation=decimation, episode_length_s=episode_length_s,

@@ -607,6 +607,19 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
             m.pt_start[d] = i
         m.pt_count[d] += 1
 
+    # evaluation order hint (ShfModel.pt_eval): lowest points of the zero pose first
+    R0 = [np.eye(3) for _ in range(nb)]
+    p0 = [np.zeros(3) for _ in range(nb)]
+    for b in range(1, nb):
+        pb = parent[b]
+        R0[b] = R0[pb] @ np.array([[m.trot[b][3 * r + c] for c in range(3)] for r in range(3)], dtype=float)
+        p0[b] = p0[pb] + R0[pb] @ np.array([m.tpos[b][kk] for kk in range(3)], dtype=float)
+    zs = [float((p0[bb] + R0[bb] @ np.asarray(pp, dtype=float))[2] - rr) for (bb, pp, rr) in points]
+    order = sorted(range(len(points)), key=lambda i: (round(zs[i], 4), i))
+    for s_, i in enumerate(order):
+        m.pt_eval[s_] = i
+        m.pt_slot[i] = s_
+
     assert len(extra_spheres) <= _abi.MAX_SPHERES
     m.nsph = len(extra_spheres)
     for i, rec in enumerate(extra_spheres):

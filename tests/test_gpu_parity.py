@@ -51,14 +51,18 @@ H_DEFAULT_Q = [0.1, 0.8, -1.5, 0.1, 0.8, -1.5, -0.1, 0.8, -1.5, -0.1, 0.8, -1.5]
 
 
 def _make_sim(cm, sp, n, terrain=None, heights=None, group=64, env_off=0, warp=None):
+    """group: lanes per env of the body-per-lane kernels, or 'chain16' / 'chain32' for the chain-per-lane fused A1 step."""
     from shifu_amd.backend import Sim
+    mapping = "body"
+    if isinstance(group, str):
+        mapping, group = "chain", int(group[len("chain"):])
     sim = Sim(sp, "cuda:0")
     if terrain is None:
         sim.set_plane(1.0)
     else:
         sim.set_heightfield(heights, terrain.hscale, terrain.vscale, terrain.border, terrain.friction, warp=warp)
     sim.set_articulation(cm.blob)
-    sim.finalize(n, env_off, group=group)
+    sim.finalize(n, env_off, group=group, mapping=mapping)
     return sim
 
 
@@ -196,7 +200,7 @@ def _a1_setup(n, rough, seed=5, group=64, env_off=0, cm=None):
     return cm, sp, tp, terr, hs, bufs, sim, task, rng
 
 
-@pytest.mark.parametrize("group", [64, 32])
+@pytest.mark.parametrize("group", [64, 32, "chain16", "chain32"])
 @pytest.mark.parametrize("rough", [False, True])
 def test_fused_a1_step_matches_oracle_bitwise(oracle, rough, group):
     """ShifuVecEnv.step for A1Conditional: physics x5, heights, termination, six reward
@@ -217,12 +221,31 @@ def test_fused_a1_step_matches_oracle_bitwise(oracle, rough, group):
     assert np.isfinite(bufs["obs"]).all()
 
 
-def test_a1_1000_steps_within_north_star_tolerance(oracle):
-    """North-star bar: per-step dof_pos / dof_vel / root_state within 1e-4 relative of the
-    reference (here: the oracle) over 1000 steps.  Checked every 50 steps."""
+@pytest.mark.parametrize("group", [32, "chain16", "chain32"])
+def test_fused_a1_step_push_on_every_body(oracle, group):
+    """rand_force_buf is (N, bodies, 3) (a1_conditional.py:82-87): a user may push any body, welded feet included --
+    forces on every reported body, folded into its moving body in body order, on both lane mappings."""
+    _need_gpu()
+    n = 40
+    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, seed=77, group=group)
+    bufs["push"][:] = rng.uniform(-4, 4, bufs["push"].shape).astype(np.float32)
+    bufs["push"][::3, 5] = 0.0          # some bodies of some envs unpushed (skipped, not added as zeros)
+    _upload(sim, task, bufs)
+    for it in range(40):
+        raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32)
+        task.step(torch.from_numpy(raw).cuda())
+        oracle.a1_step(cm.blob, sp, tp, n, 0, bufs, raw, terrain=terr, heights=hs)
+        _compare(sim, task, bufs, f"step {it}")
+    assert np.isfinite(bufs["obs"]).all()
+
+
+@pytest.mark.parametrize("group", [64, "chain16"])
+def test_a1_1000_steps_vs_oracle_at_north_star_tolerance(oracle, group):
+    """Per-step dof_pos / dof_vel / root_state within the north-star's 1e-4 relative over 1000 steps -- of the ORACLE
+    (Isaac Gym itself is a closed binary that is absent).  Checked every 50 steps."""
     _need_gpu()
     n = 32
-    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, seed=9)
+    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, seed=9, group=group)
     worst = 0.0
     for it in range(1000):
         raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32)
@@ -384,11 +407,12 @@ def test_fused_abb_step_matches_oracle_bitwise(oracle, group, generic):
     assert cube_moved
 
 
+@pytest.mark.parametrize("group", [32, "chain16"])
 @pytest.mark.parametrize("n", [1, 5, 37])
-def test_ragged_env_counts(oracle, n):
-    """Env counts that do not fill a block (4 or 8 envs per 256-thread block): no out-of-range lanes."""
+def test_ragged_env_counts(oracle, n, group):
+    """Env counts that do not fill a block (4, 8 or 16 envs per 256-thread block): no out-of-range lanes."""
     _need_gpu()
-    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, seed=30 + n, group=32)
+    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, seed=30 + n, group=group)
     for it in range(8):
         raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32)
         task.step(torch.from_numpy(raw).cuda())
@@ -396,16 +420,20 @@ def test_ragged_env_counts(oracle, n):
     _compare(sim, task, bufs, f"n={n}")
 
 
-def test_full_size_determinism_and_shard_invariance():
+@pytest.mark.parametrize("group", [32, "chain"])
+def test_full_size_determinism_and_shard_invariance(group):
     """BASELINE size (4096 envs, procedural 1300x2100 height map): two runs are bit-identical, and
-    two 2048-env shards with global-id offsets reproduce the 4096-env run env for env."""
+    two 2048-env shards with global-id offsets reproduce the 4096-env run env for env.  32: the body-per-lane kernel;
+    "chain": the chain-per-lane kernel at 16 lanes per env."""
     _need_gpu()
     from shifu_amd.gym.a1_fused import FusedA1Env
     N, steps = 4096, 40
     g = torch.Generator(device="cuda:0")
 
     def run(num, rank, world, acts=None):
-        env = FusedA1Env(num_envs=num, rank=rank, world_size=world, seed=42, group=32)
+        env = (FusedA1Env(num_envs=num, rank=rank, world_size=world, seed=42, mapping="chain") if group == "chain" else
+               FusedA1Env(num_envs=num, rank=rank, world_size=world, seed=42, group=group))
+        assert env.mapping == ("chain" if group == "chain" else "body")
         env.reset()
         out = []
         for k in range(steps):
@@ -450,7 +478,7 @@ def test_fused_step_generic_dimension_path(oracle, group):
     assert np.isfinite(bufs["obs"]).all()
 
 
-@pytest.mark.parametrize("group", [32, 16])
+@pytest.mark.parametrize("group", [32, 16, "chain16"])
 def test_trimesh_terrain_matches_oracle_bitwise(oracle, group):
     """the trimesh form of the terrain (vertical risers at steep steps; ShfTerrain.warped) -- simulate
     and the fused step against the oracle, on a terrain whose plateau and noise shift many vertices."""
@@ -460,7 +488,7 @@ def test_trimesh_terrain_matches_oracle_bitwise(oracle, group):
     from shifu_amd.isaacgym.terrain_utils import pack_trimesh_samples, trimesh_warp_map
     from shifu_amd.model import asset_path, compile_urdf
     rng = np.random.default_rng(31)
-    cm = H.a1_model() if group == 32 else compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT,
+    cm = H.a1_model() if group in (32, "chain16") else compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT,
                                                         honour_dont_collapse=False)
     sp = H.sim_params(angular_damping=0.5)
     tp = a1_task_params(cm, num_rows=4, num_cols=5, env_length=0.8)

@@ -22,8 +22,7 @@ def lib(name):
 
 def build(name):
     from shifu_amd import build as b
-    cmd = [b.hipcc()] + b.FLAGS + FLAGS[name] + [os.path.join(b.CSRC, s) for s in b.SOURCES] + ["-o", lib(name)]
-    subprocess.check_call(cmd)
+    b.compile_all(b.FLAGS, lib(name), extra=FLAGS[name])
     print(lib(name))
 
 

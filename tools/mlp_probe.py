@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 def build(name, flags):
     from shifu_amd import build as b
     out = os.path.join(ROOT, "shifu_amd", f"libshifu_amd_exp_{name}.so")
-    subprocess.check_call([b.hipcc()] + b.FLAGS + list(flags) + [os.path.join(b.CSRC, s) for s in b.SOURCES] + ["-o", out])
+    b.compile_all(b.FLAGS, out, extra=list(flags))
     print(out)
 
 

@@ -23,8 +23,7 @@ NAMES = ["kin: local rotation", "kin: level loop", "inertia + ext force", "conta
 
 def build():
     from shifu_amd import build as b
-    cmd = [b.hipcc()] + b.FLAGS + ["-DSHF_PHASE_CLOCK"] + [os.path.join(b.CSRC, s) for s in b.SOURCES] + ["-o", LIB]
-    subprocess.check_call(cmd)
+    b.compile_all(b.FLAGS, LIB, extra=["-DSHF_PHASE_CLOCK"])
     print(LIB)
 
 
@@ -32,7 +31,8 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "build":
         return build()
     abb = "--abb" in sys.argv
-    argv = [a for a in sys.argv if a != "--abb"]
+    chain = "--chain" in sys.argv     # the chain-per-lane A1 step (csrc/shf_chain.h); G = 16 or 32
+    argv = [a for a in sys.argv if a not in ("--abb", "--chain")]
     G = int(argv[1]) if len(argv) > 1 else 32
     steps = int(argv[2]) if len(argv) > 2 else 100
     from shifu_amd import build as b
@@ -45,7 +45,12 @@ def main():
     from shifu_amd.gym.a1_fused import FusedA1Env
     from shifu_amd.gym.abb_fused import FusedAbbEnv
     # --abb: the sub-step phases (0-10) of the push-box env; its kernel has no marks outside the sub-steps
-    env = FusedAbbEnv(num_envs=4096, group=G) if abb else FusedA1Env(num_envs=4096, group=G)
+    env = (FusedAbbEnv(num_envs=4096, group=G) if abb else
+           FusedA1Env(num_envs=4096, group=G, mapping="chain" if chain else "body"))
+    if chain:
+        NAMES[1] = "chain: kinematics + inertias"; NAMES[0] = NAMES[2] = NAMES[5] = "(unused on the chain mapping)"
+        NAMES[6] = "chain: dof efforts + inward"; NAMES[7] = "root: add hips + 6x6 solve"; NAMES[8] = "chain: outward + integrate"
+        NAMES[10] = "root: integrate"
     lib = _lib.lib()
     fn = lib.shf_debug_phase_cycles
     fn.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_int]
