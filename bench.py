@@ -35,6 +35,11 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s achie
 VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector (non-matrix) peak
 NUM_CUS, SIMDS_PER_CU = 256, 4
 MAX_CLOCK_HZ = 2.4e9       # MI355X_MICROARCH.md: max clock
+# tools/valu_microbench (profiles/r03_valu_microbench.md), measured on the MI355X: a SIMD issues one wave64 fp32 VALU
+# instruction per ~2 clocks when two or more waves feed it (2.30 at two waves, 1.93 at four; the guide's "2 cyc (SIMD-32)"),
+# whatever the number of active lanes; ONE wave alone gets one issue slot per 4.57 clocks, dependent or not.
+VALU_ISSUE_CLOCKS_SIMD = 2.0
+VALU_ISSUE_CLOCKS_ONE_WAVE = 4.57
 WL_NAME = {"terrain": "a1_conditional procedural heightfield 1300x2100 (config 3)",
            "flat": "a1_conditional all-zero heightfield (config 2)",
            "trimesh": "a1_conditional procedural terrain 1300x2100 as trimesh with vertical risers (the reference's effective A1 terrain)",
@@ -307,8 +312,17 @@ def main():
     # events cannot be recorded inside a replay, so the kernel's own duration is always measured on a dedicated eager
     # pass of the same K steps after the timed region.
     use_graph = args.graph
+    gathers = {"warmup": 0, "timed": 0}
+
+    def maybe_gather(global_step, slot, phase):
+        # extras["episode"] logging cadence (policy_config.py:36: num_steps_per_env = 24), counted from the first step of
+        # the run so that the driver's shape (--warmup 5 --steps 20) times exactly one all-gather
+        if use_dist and (global_step + 1) % args.log_interval == 0:
+            gather_episode_stats(env.task.tensors[stats_t][slot][:env.task.num_sums])
+            gathers[phase] += 1
+
     for i in range(args.warmup):
-        eager_step()
+        maybe_gather(i, eager_step(), "warmup")
     graph = None
     if use_graph:
         torch.cuda.synchronize()
@@ -325,8 +339,7 @@ def main():
             slot = env.task.advance_slot()
         else:
             slot = eager_step()
-        if use_dist and (i + 1) % args.log_interval == 0:
-            gather_episode_stats(env.task.tensors[stats_t][slot][:env.task.num_sums])
+        maybe_gather(args.warmup + i, slot, "timed")
         return slot
 
     torch.cuda.synchronize()
@@ -378,27 +391,38 @@ def main():
             secondary.update({"valu_issue_frac": prof.get("valu_issue_frac"), "wait_frac": prof.get("wait_frac"),
                               "counter_source": prof.get("source")})
             if prof.get("valu_insts_per_launch"):
-                # the roofline that actually binds these kernels: VALU issue slots.  One wave64 VALU instruction holds its
-                # SIMD's vector pipe for 4 clocks, whatever the number of active lanes; peak = SIMDs x clock / 4.
+                # VALU issue slots, priced with the measured issue rates (tools/valu_microbench): (i) the chip-wide peak,
+                # one wave-instruction per SIMD per 2 clocks; (ii) the floor a single wave's own issue rate puts under the
+                # launch: its VALU instructions x 4.57 clocks (a wave cannot issue faster whatever else the SIMD does).
                 # Instruction count: SQ_INSTS_VALU of the committed PMC pass (replayed); duration: measured in this run.
-                issue_peak = NUM_CUS * SIMDS_PER_CU * MAX_CLOCK_HZ / 4.0
+                issue_peak = NUM_CUS * SIMDS_PER_CU * MAX_CLOCK_HZ / VALU_ISSUE_CLOCKS_SIMD
                 issued = prof["valu_insts_per_launch"] / (kern_ms * 1e-3)
+                per_wave = prof["valu_insts_per_launch"] / float(waves)
+                one_wave_floor_ms = per_wave * VALU_ISSUE_CLOCKS_ONE_WAVE / MAX_CLOCK_HZ * 1e3
                 secondary["valu_issue"] = {"wave_instructions_per_launch": prof["valu_insts_per_launch"],
                                            "achieved": issued, "peak": issue_peak, "unit": "wave-instructions/s",
                                            "frac": issued / issue_peak,
-                                           "note": "SQ_INSTS_VALU x 4 clocks / (1024 SIMDs x kernel time at 2.4 GHz); "
-                                                   "valu_issue_frac is the same ratio per wave over its lifetime"}
+                                           "valu_instructions_per_wave": per_wave,
+                                           "single_wave_issue_floor_ms": one_wave_floor_ms,
+                                           "single_wave_issue_frac": one_wave_floor_ms / kern_ms,
+                                           "peak_source": "profiles/r03_valu_microbench.md: v_fma_f32 wave64 = 4.57 clk per wave alone, "
+                                                          "2.30 / 1.93 clk per SIMD at 2 / 4 waves; peak priced at 2 clk (MI355X_MICROARCH.md) and 2.4 GHz",
+                                           "note": "the launch is bound by the dependent chain of each wave (LDS hand-offs, "
+                                                   "IEEE div/sqrt sequences), not by chip-wide issue slots: see single_wave_issue_frac"}
         out = {
             "metric": ("env-steps/sec (whole node), ABB push-box 6-dof arm + free cube, 4096 envs/GPU" if abb else
                        "env-steps/sec (whole node), A1 12-dof 4096 envs/GPU"), "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{WL_NAME[args.workload]}, {N} envs/GPU, random actions, {substeps} substeps/env-step "
-                                   f"(dt {'20' if abb else '5'} ms), resets on",
+                                   f"(dt {'20' if abb else '5'} ms), resets on"
+                                   + ("" if abb else (", self-collision ON (capsule pairs, the reference's collision filter 0)" if args.self_collision
+                                                      else ", self-collision OFF (the reference has it on: units.py:68; see --self-collision)")),
                        "envs_per_gpu": N, "total_envs": total_envs, "substeps_per_env_step": substeps,
                        "lanes_per_env": group, "lane_mapping": mapping, "self_collision": bool(args.self_collision) and not abb, "vec_step": "hipGraph replay of [uniform_, fused step]" if graph is not None else "eager launches",
                        "parallelism": f"env-sharded x{world}, all-gather of episode stats every {args.log_interval} steps",
-                       "substeps_per_s": value * substeps, "obs_finite": finite, "episodes_reset_rank0": resets},
+                       "substeps_per_s": value * substeps, "obs_finite": finite, "episodes_reset_rank0": resets,
+                       "gathers_in_timed_region": gathers["timed"], "gathers_in_warmup": gathers["warmup"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if not prof else prof.get("traffic_bytes"),

@@ -25,9 +25,11 @@ def build(force: bool = False) -> str:
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libshf_oracle.so")
-        if not os.path.exists(so):
-            build()
+        so = os.environ.get("SHF_ORACLE_LIB")      # e.g. the sanitizer build (make -C oracle asan)
+        if not so:
+            so = os.path.join(_HERE, "libshf_oracle.so")
+            if not os.path.exists(so):
+                build()
         _LIB = C.CDLL(so)
     return _LIB
 

@@ -1,16 +1,20 @@
-// shf_chain.h -- the fused A1 step with one lane per kinematic CHAIN.
+// shf_chain.h -- the fused A1 step with the tree's recursions on one lane per kinematic CHAIN.
 //
 // Tree shape served: a floating root with NCH serial chains of NLK revolute links, each chain ending in one welded
 // reported body (the Unitree A1: trunk + 4 legs of hip / thigh / calf + foot).  The body-per-lane
 // mapping of shf_device.h executes the tree level by level -- every level is one pass of the whole wavefront with a
-// quarter of its lanes active and an LDS hand-off (write, fence, read: ~70 clocks, tools/valu_microbench) on either
-// side -- so one env step is a dependent chain of ~100 LDS round trips.  Here lane c < NCH walks chain c from the
-// root outwards and back with its links' state (S, c, IA, pA, U) in registers: forward kinematics, the three rigid
-// inertias, the inward and outward passes of the articulated-body algorithm need no hand-off at all; lane NCH owns
-// the root (its inertia, the 6x6 solve, the integration of the floating base).  Per sub-step the group synchronises
-// five times: poses -> contact sample points (all G lanes, one point each per round) -> contact slots -> fold;
-// hips -> root; root acceleration -> chains.  G = 16 packs four envs into a wavefront (4096 envs = 1024 waves =
-// one per SIMD, with the whole 512-register file to itself).
+// quarter of its lanes active and an LDS hand-off (write, fence, read: 70-110 clocks, tools/valu_microbench) on either
+// side, ~20 group synchronisations per sub-step.  Here each kind of work runs where it is widest, and the recursions,
+// which are serial whatever the mapping, run without hand-offs:
+//   dof lanes   (lane j < ND)        joint j: integration, drive effort (t0, de), local rotation Rl = trot * Rot(axis, q)
+//   chain lanes (lane c < NCH)       chain c: pose composition root -> tip, the ABA inward pass tip -> root and the
+//                                    outward pass, link after link with (S, c, U, 1/D, u) in registers
+//   body lanes  (lane j <= ND)       moving body j (link j, or the root on lane ND): rigid inertia, external force,
+//                                    fold of its active contacts; the root lane also solves the 6x6 and integrates the base
+//   point lanes (all G lanes)        one contact sample point per lane and round
+// Seven group synchronisations per sub-step.  G = 16 packs four envs into a wavefront (4096 envs = 1024 waves = one
+// per SIMD); a single wave issues one VALU instruction per ~4.6 clocks whatever its active lanes (profiles/
+// r03_valu_microbench.md), so what counts is the length of the instruction stream, not lane utilisation.
 //
 // ARITHMETIC: the same operations in the same order as oracle/shf_oracle.c (and as the body-mapped kernel) -- only
 // which lane executes them changes, so every result stays bit-identical; tests/test_gpu_parity.py holds both mappings to
@@ -22,12 +26,15 @@
 template <int NCH_, int NLK_, int NP_>
 struct ChainDims {
   static constexpr int NCH = NCH_, NLK = NLK_, NB = 1 + NCH_ * (NLK_ + 1), ND = NCH_ * NLK_, NPC = NP_;
+  static constexpr int MAXPT = 9;   // contact points per moving body held as a packed slot list (7 bits each in 64)
   DEV static constexpr int body(int c, int k) { return 1 + c * (NLK_ + 1) + k; }   // k == NLK: the welded end body
   static bool matches(const ShfModel& m) {
     if (m.nb != NB || m.nd != ND || m.np != NPC || m.fixed_base || m.jtype[0] != SHF_JOINT_ROOT) return false;
     if (m.child_count[0] != NCH || m.nlevels != NLK) return false;
     for (int i = 0; i < NPC; i++)   // the evaluation order must be a permutation with its inverse
       if (m.pt_eval[i] < 0 || m.pt_eval[i] >= NPC || m.pt_slot[m.pt_eval[i]] != i) return false;
+    for (int b = 0; b < NB; b++)
+      if (m.pt_count[b] > MAXPT) return false;
     for (int c = 0; c < NCH; c++) {
       if (m.child_list[m.child_start[0] + c] != 1 + c * (NLK + 1)) return false;
       for (int k = 0; k <= NLK; k++) {
@@ -47,23 +54,33 @@ struct ChainDims {
 };
 typedef ChainDims<4, 3, 76> A1Chain;
 
-// LDS of one env: pose records of all reported bodies, accelerations, NCH hip -> root hand-off slots (the region is
-// also the net-contact-force staging, nb x 3 floats), the dof block (epilogue layout), the root state, contact slots.
+// LDS of one env: pose records of all reported bodies, accelerations, one (IA, pA) exchange slot per link (body lane ->
+// chain lane; the chain's first slot then carries its result to the root; the region is also the net-contact-force
+// staging, nb x 3 floats), a record per joint (Rl[9] qd t0 de), the dof block (epilogue layout), the root state,
+// contact slots.
+#define JREC_STRIDE 12
 template <class CD>
 __host__ __device__ inline int chain_lds_words(int min_tail) {
   int tail = CD::NPC * PT_STRIDE;
   if (tail < min_tail) tail = min_tail;
-  const int w = CD::NB * POSE_STRIDE + ((CD::NB * 6 + 3) & ~3) + CD::NCH * XCH_STRIDE + ((CD::ND * DOF_STRIDE + 3) & ~3) + root_words(1) + tail;
+  const int w = CD::NB * POSE_STRIDE + ((CD::NB * 6 + 3) & ~3) + (CD::ND + 1) * XCH_STRIDE + CD::ND * JREC_STRIDE +
+                ((CD::ND * DOF_STRIDE + 3) & ~3) + root_words(1) + tail;
   return (w + 3) & ~3;
 }
+struct ChainLds : EnvLds {
+  float* jrec;
+  float* xroot;   // the root's (IA, pA) for the element-wise sum with the chains' contributions
+};
 template <class CD>
-DEV EnvLds chain_lds_carve(float* base) {
-  static_assert(CD::NCH * XCH_STRIDE >= 3 * CD::NB, "the hand-off slots double as the contact-force staging");
-  EnvLds L;
+DEV ChainLds chain_lds_carve(float* base) {
+  static_assert(CD::ND * XCH_STRIDE >= 3 * CD::NB, "the exchange slots double as the contact-force staging");
+  ChainLds L;
   L.pose = base;
   L.acc = L.pose + CD::NB * POSE_STRIDE;
   L.xch = L.acc + ((CD::NB * 6 + 3) & ~3);
-  L.dofb = L.xch + CD::NCH * XCH_STRIDE;
+  L.xroot = L.xch + CD::ND * XCH_STRIDE;
+  L.jrec = L.xroot + XCH_STRIDE;
+  L.dofb = L.jrec + CD::ND * JREC_STRIDE;
   L.root = L.dofb + ((CD::ND * DOF_STRIDE + 3) & ~3);
   L.pt = L.root + root_words(1);
   return L;
@@ -71,7 +88,7 @@ DEV EnvLds chain_lds_carve(float* base) {
 
 // One link's share of the ABA, kept in the chain lane's registers across the sub-step.
 struct ChainLink {
-  float S[6], c[6], IA[21], pA[6], U[6], invD, u;
+  float S[6], c[6], U[6], invD, u;
 };
 
 DEV void pose_store(float* o, const float* Rw, const float* p, const float* v) {
@@ -83,18 +100,21 @@ DEV void pose_store(float* o, const float* Rw, const float* p, const float* v) {
   for (int k = 0; k < 6; k++) o[12 + k] = v[k];
 }
 
-// Forward kinematics of one revolute link below (Rp, pp, vp) -- the parent's pose and velocity, replaced by the
-// link's own on return -- with its motion subspace and bias acceleration (oracle kinematics(), same operations).
-DEV void chain_kin_link(const float* tp, const float* tr, const float* ax, float qv, float qdv, float* Rp, float* pp,
-                        float* vp, float* S, float* c) {
+// The joint's local rotation Rl = trot * Rot(axis, q): depends on its own angle only (dof lanes, all joints at once).
+DEV void joint_local_rotation(const float* tr, const float* ax, float qv, float* Rl) {
   float sn, cs;
   sincos_spec(qv, &sn, &cs);
   const float oc = 1.0f - cs;
   const float Rq[9] = {fmaf(oc, ax[0] * ax[0], cs),           fmaf(oc, ax[0] * ax[1], -(sn * ax[2])), fmaf(oc, ax[0] * ax[2], sn * ax[1]),
                        fmaf(oc, ax[1] * ax[0], sn * ax[2]),    fmaf(oc, ax[1] * ax[1], cs),            fmaf(oc, ax[1] * ax[2], -(sn * ax[0])),
                        fmaf(oc, ax[2] * ax[0], -(sn * ax[1])), fmaf(oc, ax[2] * ax[1], sn * ax[0]),    fmaf(oc, ax[2] * ax[2], cs)};
-  float Rl[9], t[3], Rn[9], pn[3], aw[3], t2[3], vJ[6], cc[6];
   mm3(tr, Rq, Rl);
+}
+// Composition of one revolute link below (Rp, pp, vp) -- the parent's pose and velocity, replaced by the link's own on
+// return -- with its motion subspace and bias acceleration (oracle kinematics(), same operations).
+DEV void chain_compose_link(const float* tp, const float* ax, const float* Rl, float qdv, float* Rp, float* pp,
+                            float* vp, float* S, float* c) {
+  float t[3], Rn[9], pn[3], aw[3], t2[3], vJ[6], cc[6];
   mv3(Rp, tp, t);
 #pragma unroll
   for (int k = 0; k < 3; k++) pn[k] = pp[k] + t[k];
@@ -168,21 +188,21 @@ DEV void chain_dof_effort(const StepCtx& C, int d, float q, float qd, float tau_
 }
 
 // Inward step of one link: U = IA S, D, u, IA -= U U^T / D, pa = pA + IA c + U u / D  (pa returned, IA updated).
-DEV void chain_inward_link(ChainLink& K, float dex, float tau0, float* pa) {
+DEV void chain_inward_link(ChainLink& K, float* IA, const float* pA, float dex, float tau0, float* pa) {
 #pragma unroll
   for (int i = 0; i < 6; i++) {
-    float acc = SYMG(K.IA, i, 0) * K.S[0];
+    float acc = SYMG(IA, i, 0) * K.S[0];
 #pragma unroll
-    for (int j = 1; j < 6; j++) acc = fmaf(SYMG(K.IA, i, j), K.S[j], acc);
+    for (int j = 1; j < 6; j++) acc = fmaf(SYMG(IA, i, j), K.S[j], acc);
     K.U[i] = acc;
   }
   float D = K.S[0] * K.U[0];
 #pragma unroll
   for (int j = 1; j < 6; j++) D = fmaf(K.S[j], K.U[j], D);
   D += dex;
-  float sp = K.S[0] * K.pA[0];
+  float sp = K.S[0] * pA[0];
 #pragma unroll
-  for (int j = 1; j < 6; j++) sp = fmaf(K.S[j], K.pA[j], sp);
+  for (int j = 1; j < 6; j++) sp = fmaf(K.S[j], pA[j], sp);
   const float invD = 1.0f / D;
   K.invD = invD;
   K.u = tau0 - sp;
@@ -192,13 +212,13 @@ DEV void chain_inward_link(ChainLink& K, float dex, float tau0, float* pa) {
 #pragma unroll
   for (int i = 0; i < 6; i++)
 #pragma unroll
-    for (int j = i; j < 6; j++) K.IA[SYM(i, j)] = fmaf(-K.U[i], W[j], K.IA[SYM(i, j)]);
+    for (int j = i; j < 6; j++) IA[SYM(i, j)] = fmaf(-K.U[i], W[j], IA[SYM(i, j)]);
 #pragma unroll
   for (int i = 0; i < 6; i++) {
-    float acc = SYMG(K.IA, i, 0) * K.c[0];
+    float acc = SYMG(IA, i, 0) * K.c[0];
 #pragma unroll
-    for (int j = 1; j < 6; j++) acc = fmaf(SYMG(K.IA, i, j), K.c[j], acc);
-    pa[i] = fmaf(W[i], K.u, K.pA[i] + acc);
+    for (int j = 1; j < 6; j++) acc = fmaf(SYMG(IA, i, j), K.c[j], acc);
+    pa[i] = fmaf(W[i], K.u, pA[i] + acc);
   }
 }
 
@@ -255,93 +275,136 @@ struct SlotBits {
   unsigned long long w[2];
   DEV bool test(int s) const { return ((s < 64 ? w[0] >> s : w[1] >> (s - 64)) & 1ull) != 0ull; }
 };
-// Slots that evaluate the points [i0, i1) of one body (constant per lane and body: which bits of SlotBits to look at)
-DEV SlotBits body_slot_mask(const ShfModel* m, int i0, int i1) {
-  SlotBits B = {{0ull, 0ull}};
-  for (int i = i0; i < i1; i++) {
-    const int s = m->pt_slot[i];
-    if (s < 64) B.w[0] |= 1ull << s; else B.w[1] |= 1ull << (s - 64);
-  }
-  return B;
-}
-
-// The active contact slots of body range [i0, i1), ascending, picked out of the per-round ballots.
-template <int G, int NR, class F>
-DEV void for_active_points(const unsigned long long (&active)[NR], int i0, int i1, F f) {
+// The evaluation slots of one body's points [i0, i0 + n), in point order, 7 bits each (constant per lane: read once per
+// env step), and the same as a mask over SlotBits.
+template <int MAXPT>
+struct SlotList {
+  unsigned long long list;
+  int i0, n;
+  SlotBits mask;
+  DEV int slot(int j) const { return (int)((list >> (7 * j)) & 127ull); }
+};
+template <int MAXPT>
+DEV SlotList<MAXPT> slot_list_load(const ShfModel* m, int i0, int n) {
+  static_assert(MAXPT * 7 <= 64, "packed slot list");
+  SlotList<MAXPT> S;
+  S.list = 0ull; S.i0 = i0; S.n = n; S.mask.w[0] = 0ull; S.mask.w[1] = 0ull;
+  int sl[MAXPT];
 #pragma unroll
-  for (int k = 0; k < NR; k++) {
-    const int a0 = (i0 > k * G ? i0 : k * G) - k * G, a1 = (i1 < (k + 1) * G ? i1 : (k + 1) * G) - k * G;
-    unsigned long long bits = a1 > a0 ? (active[k] >> a0) & (a1 - a0 >= 64 ? ~0ull : ((1ull << (a1 - a0)) - 1ull)) : 0ull;
-    while (bits) {
-      const int j = __builtin_ctzll(bits);
-      bits &= bits - 1ull;
-      f(k * G + a0 + j);
+  for (int j = 0; j < MAXPT; j++) sl[j] = m->pt_slot[j < n ? i0 + j : 0];
+#pragma unroll
+  for (int j = 0; j < MAXPT; j++) {
+    if (j < n) {
+      const int s = sl[j];
+      S.list |= (unsigned long long)s << (7 * j);
+      if (s < 64) S.mask.w[0] |= 1ull << s; else S.mask.w[1] |= 1ull << (s - 64);
     }
   }
+  return S;
 }
 
-// Per-lane state of a chain lane that lives across the sub-steps of one env step.
-template <class CD>
-struct ChainState {
-  float q[CD::NLK], qd[CD::NLK], tau[CD::NLK];
+// Per-lane state that lives across the sub-steps of one env step: lane j < ND is dof j.
+struct DofLane {
+  float q, qd, tau;   // joint position, velocity, commanded (explicit) effort
 };
 
-// One gym.simulate() for one env on the chain mapping.  Lanes l < NCH: chain l; lane NCH: the root; all G lanes:
-// contact sample points.  contact_out (LDS, nb x 3) is written when non-null.
+// One gym.simulate() for one env.  Lane roles in the file header; contact_out (LDS, nb x 3) is written when non-null.
 template <int G, class CD, bool TW>
-DEV void chain_substep(const StepCtx& C, const EnvLds& L, int l, ChainState<CD>& X,
-                       const ChainPoints<(CD::NPC + G - 1) / G>& P, const SlotBits (&mine)[CD::NLK], const float* fext,
-                       float mu_shape, float* contact_out) {
-  static_assert(G > CD::NCH && G <= 64, "a lane per chain plus one for the root");
-  constexpr int NCH = CD::NCH, NLK = CD::NLK, NB = CD::NB, NR = (CD::NPC + G - 1) / G;
+DEV void chain_substep(const StepCtx& C, const ChainLds& L, int l, DofLane& X, const ChainPoints<(CD::NPC + G - 1) / G>& P,
+                       const SlotList<CD::MAXPT>& mine, const float* fext, float mu_shape, float* contact_out) {
+  static_assert(G > CD::ND && G <= 64, "a lane per dof plus one for the root");
+  constexpr int NCH = CD::NCH, NLK = CD::NLK, NB = CD::NB, ND = CD::ND, NR = (CD::NPC + G - 1) / G;
   const ShfModel* m = C.m;
   const float dt = C.sp.dt;
   const float gon = (float)m->gravity_on;
   const float g[3] = {C.sp.gravity[0] * gon, C.sp.gravity[1] * gon, C.sp.gravity[2] * gon};
-  const bool ischain = l < NCH, isroot = l == NCH;
-  const int b0 = ischain ? CD::body(l, 0) : 0;   // first body of this lane (slot 0); slots 1.. exist on chain lanes only
+  // With 32 lanes per env each moving body has two lanes (lb and lb + 16) that share its 27 accumulators between them
+  // (contact_accumulate_half): the rigid inertia is computed by both, each folds the contacts into the elements it owns.
+  constexpr bool SPLIT = G >= 32;
+  static_assert(!SPLIT || ND < 16, "second-half body lanes start at lane 16");
+  const int lb = SPLIT ? (l & 15) : l;                       // body-lane index: link lb < ND, root lb == ND
+  const int half = SPLIT ? ((l >> 4) & 1) : 0;
+  const bool isdof = l < ND, ischain = l < NCH, isroot = l == ND;
+  const bool isbody = SPLIT ? (lb <= ND && l < 32) : l <= ND;
+  const bool islink = isbody && lb < ND;
+  const int myb = lb < ND ? CD::body(lb / NLK, lb % NLK) : 0;   // moving body of this body lane (lb == ND: the root)
   PHASE_BEGIN();
 
-  // ---- kinematics, rigid inertias, external forces: chains walk outwards from the root
+  // ---- A. dof lanes: drive effort and the joint's local rotation -> joint record
+  if (isdof) {
+    float* rec = L.jrec + l * JREC_STRIDE;
+    float Rl[9], t0, de;
+    chain_dof_effort(C, l, X.q, X.qd, X.tau, &t0, &de);
+    joint_local_rotation(m->trot[myb], m->axis[myb], X.q, Rl);
+#pragma unroll
+    for (int k = 0; k < 9; k++) rec[k] = Rl[k];
+    rec[9] = X.qd; rec[10] = t0; rec[11] = de;
+  }
+  GROUP_SYNC();
+  PHASE_MARK(0);
+
+  // ---- B. chain lanes: poses, velocities, motion subspaces root -> tip; the root lane publishes the root's pose
   ChainLink K[NLK];
-  if (l <= NCH) {
+  if (ischain || isroot) {
     float Rc[9], pc[3] = {0.0f, 0.0f, 0.0f}, vc[6];
     quat_to_mat(L.root + 3, Rc);
 #pragma unroll
     for (int k = 0; k < 3; k++) { vc[k] = L.root[10 + k]; vc[3 + k] = L.root[7 + k]; }
-    if (isroot) pose_store(L.pose, Rc, pc, vc);
+    if (isroot) {
+      pose_store(L.pose, Rc, pc, vc);
+    } else {
+      const int b0 = CD::body(l, 0);
 #pragma unroll
-    for (int k = 0; k < NLK; k++) {
-      const int b = b0 + k;
-      if (ischain) {
-        chain_kin_link(m->tpos[b], m->trot[b], m->axis[b], X.q[k], X.qd[k], Rc, pc, vc, K[k].S, K[k].c);
+      for (int k = 0; k < NLK; k++) {
+        const int b = b0 + k;
+        const float* rec = L.jrec + (l * NLK + k) * JREC_STRIDE;
+        float Rl[9];
+#pragma unroll
+        for (int j = 0; j < 9; j++) Rl[j] = rec[j];
+        chain_compose_link(m->tpos[b], m->axis[b], Rl, rec[9], Rc, pc, vc, K[k].S, K[k].c);
         pose_store(L.pose + b * POSE_STRIDE, Rc, pc, vc);
       }
-      if (ischain || k == 0) {
-        rigid_inertia_p(m->mass[b], m->com[b], m->inertia[b], Rc, pc, vc, K[k].IA, K[k].pA);
-        if (fext) {
-          const float F[3] = {fext[3 * b], fext[3 * b + 1], fext[3 * b + 2]};
-          chain_ext_force(F, m->com[b], Rc, pc, K[k].pA);
-        }
-      }
-    }
-    if (ischain) {
       const int b = b0 + NLK;   // the welded end body: reported pose, contact points and forces; inertia merged into the last link
       chain_kin_weld(m->tpos[b], m->trot[b], Rc, pc);
       pose_store(L.pose + b * POSE_STRIDE, Rc, pc, vc);
-      if (fext) {
-        const float F[3] = {fext[3 * b], fext[3 * b + 1], fext[3 * b + 2]};
-        chain_ext_force(F, m->com[b], Rc, pc, K[NLK - 1].pA);
-      }
     }
   }
   GROUP_SYNC();
   PHASE_MARK(1);
 
+  // ---- C. body lanes: rigid inertia and bias force of their moving body, external forces (body order within a moving body)
+  float IA[21], pA[6];
+  if (isbody) {
+    const float* pb = L.pose + myb * POSE_STRIDE;
+    float Rb[9], pp[3], vb[6];
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rb[k] = pb[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) pp[k] = pb[9 + k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) vb[k] = pb[12 + k];
+    rigid_inertia_p(m->mass[myb], m->com[myb], m->inertia[myb], Rb, pp, vb, IA, pA);
+    if (fext) {
+      const float F[3] = {fext[3 * myb], fext[3 * myb + 1], fext[3 * myb + 2]};
+      chain_ext_force(F, m->com[myb], Rb, pp, pA);
+      if (islink && (lb % NLK) == NLK - 1) {   // the chain's last link also carries its welded end body
+        const int bw = myb + 1;
+        const float* pw = L.pose + bw * POSE_STRIDE;
+        float Rw[9], pq[3];
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rw[k] = pw[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) pq[k] = pw[9 + k];
+        const float Fw[3] = {fext[3 * bw], fext[3 * bw + 1], fext[3 * bw + 2]};
+        chain_ext_force(Fw, m->com[bw], Rw, pq, pA);
+      }
+    }
+  }
+  PHASE_MARK(2);
+
   // ---- contact sample points: one lane per evaluation slot and round.  Pass 1 places every round's point and reads its
   // terrain height (all rounds' loads in flight together); a round none of whose points can be within the contact offset
-  // (clearance x nz_min above offset + radius: exact, ShfTerrain.nz_min) ends there -- with the points evaluated lowest
-  // first (ShfModel.pt_eval) that is every round but the first on a walking robot.  Pass 2: unit normal, gap, response.
+  // (clearance x nz_min above offset + radius: exact, ShfTerrain.nz_min) ends there.  Pass 2: unit normal, gap, response.
   const float kc = C.sp.contact_k, dc = C.sp.contact_d, veps = C.sp.friction_vel;
   const float beta = fmaf(kc, dt, dc);
   const float mu = 0.5f * (mu_shape + C.terr.t.friction);
@@ -394,115 +457,91 @@ DEV void chain_substep(const StepCtx& C, const EnvLds& L, int l, ChainState<CD>&
   GROUP_SYNC();
   PHASE_MARK(3);
 
-  // ---- fold the active slots into their moving bodies, in ascending point order whatever slot evaluated them
-  if (l <= NCH) {
-#pragma unroll
-    for (int k = 0; k < NLK; k++) {
-      if ((ischain || k == 0) && ((act.w[0] & mine[k].w[0]) | (act.w[1] & mine[k].w[1])) != 0ull) {
-        const int b = b0 + k, i0 = m->pt_start[b], i1 = i0 + m->pt_count[b];
-        for (int i = i0; i < i1; i++)
-          if (act.test(m->pt_slot[i])) contact_accumulate_p(L.pt + i * PT_STRIDE, dt, K[k].IA, K[k].pA);
+  // ---- D. body lanes: fold their active contacts, ascending point order whatever slot evaluated them; links hand
+  // (IA, pA) to their chain lane
+  if (isbody) {
+    if (((act.w[0] & mine.mask.w[0]) | (act.w[1] & mine.mask.w[1])) != 0ull) {
+      for (int j = 0; j < mine.n; j++) {
+        if (!act.test(mine.slot(j))) continue;
+        const float* o = L.pt + (mine.i0 + j) * PT_STRIDE;
+        if (!SPLIT) contact_accumulate_p(o, dt, IA, pA);
+        else if (half == 0) contact_accumulate_half<0>(o, dt, IA, pA);
+        else contact_accumulate_half<1>(o, dt, IA, pA);
       }
+    }
+    // links hand (IA, pA) to their chain lane; the root's go to the same kind of slot for the element-wise sum below
+    float* o = (islink ? L.xch + lb * XCH_STRIDE : L.xroot);
+    if (!SPLIT) {
+#pragma unroll
+      for (int j = 0; j < 21; j++) o[j] = IA[j];
+#pragma unroll
+      for (int j = 0; j < 6; j++) o[21 + j] = pA[j];
+    } else if (half == 0) {
+#pragma unroll
+      for (int j = 0; j < 11; j++) o[j] = IA[j];
+    } else {
+#pragma unroll
+      for (int j = 11; j < 21; j++) o[j] = IA[j];
+#pragma unroll
+      for (int j = 0; j < 6; j++) o[21 + j] = pA[j];
     }
   }
+  GROUP_SYNC();
   PHASE_MARK(4);
 
-  // ---- inward pass along the chain, in registers; the first link's result goes to the root through LDS
+  // ---- E. chain lanes: inward pass tip -> root in registers; the first link's result goes to the root through LDS
   if (ischain) {
+    float Ic[21], pc6[6];   // running child contribution
 #pragma unroll
     for (int k = NLK - 1; k >= 0; k--) {
-      float t0, de, pa[6];
-      chain_dof_effort(C, l * NLK + k, X.q[k], X.qd[k], X.tau[k], &t0, &de);
-      chain_inward_link(K[k], de, t0, pa);
-      if (k > 0) {
+      const float* o = L.xch + (l * NLK + k) * XCH_STRIDE;
+      const float* rec = L.jrec + (l * NLK + k) * JREC_STRIDE;
+      float Il[21], pl[6], pa[6];
 #pragma unroll
-        for (int j = 0; j < 21; j++) K[k - 1].IA[j] += K[k].IA[j];
+      for (int j = 0; j < 21; j++) Il[j] = o[j];
 #pragma unroll
-        for (int j = 0; j < 6; j++) K[k - 1].pA[j] += pa[j];
-      } else {
-        float* o = L.xch + l * XCH_STRIDE;
+      for (int j = 0; j < 6; j++) pl[j] = o[21 + j];
+      if (k < NLK - 1) {
 #pragma unroll
-        for (int j = 0; j < 21; j++) o[j] = K[0].IA[j];
+        for (int j = 0; j < 21; j++) Il[j] += Ic[j];
 #pragma unroll
-        for (int j = 0; j < 6; j++) o[21 + j] = pa[j];
+        for (int j = 0; j < 6; j++) pl[j] += pc6[j];
       }
+      chain_inward_link(K[k], Il, pl, rec[11], rec[10], pa);
+#pragma unroll
+      for (int j = 0; j < 21; j++) Ic[j] = Il[j];
+#pragma unroll
+      for (int j = 0; j < 6; j++) pc6[j] = pa[j];
     }
+    float* o = L.xch + (l * NLK) * XCH_STRIDE;
+#pragma unroll
+    for (int j = 0; j < 21; j++) o[j] = Ic[j];
+#pragma unroll
+    for (int j = 0; j < 6; j++) o[21 + j] = pc6[j];
   }
   GROUP_SYNC();
   PHASE_MARK(6);
 
-  // ---- root: children in child_list order (= chain order, ChainDims::matches), 6x6 solve
-  float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-  if (isroot) {
+  // ---- F. root: its 27 accumulators plus the chains' in child_list order (= chain order, ChainDims::matches), one
+  // accumulator per lane (the same additions in the same order as a serial sum); then the root lane: 6x6 solve,
+  // integration of the base
+  for (int j = l; j < 27; j += G) {
+    float v = L.xroot[j];
 #pragma unroll
-    for (int c = 0; c < NCH; c++) {
-      const float* o = L.xch + c * XCH_STRIDE;
-#pragma unroll
-      for (int j = 0; j < 21; j++) K[0].IA[j] += o[j];
-#pragma unroll
-      for (int j = 0; j < 6; j++) K[0].pA[j] += o[21 + j];
-    }
-    ldlt_solve6(K[0].IA, K[0].pA, a);
-#pragma unroll
-    for (int j = 0; j < 6; j++) L.acc[j] = a[j];
+    for (int c = 0; c < NCH; c++) v += L.xch[(c * NLK) * XCH_STRIDE + j];
+    L.xroot[j] = v;
   }
   GROUP_SYNC();
-  PHASE_MARK(7);
-
-  // ---- outward pass and integration of the joints
-  if (ischain) {
-    float ap[6];
-#pragma unroll
-    for (int j = 0; j < 6; j++) ap[j] = L.acc[j];
-#pragma unroll
-    for (int k = 0; k < NLK; k++) {
-#pragma unroll
-      for (int j = 0; j < 6; j++) ap[j] = ap[j] + K[k].c[j];
-      float ua = K[k].U[0] * ap[0];
-#pragma unroll
-      for (int j = 1; j < 6; j++) ua = fmaf(K[k].U[j], ap[j], ua);
-      const float qdd = (K[k].u - ua) * K[k].invD;
-#pragma unroll
-      for (int j = 0; j < 6; j++) ap[j] = fmaf(K[k].S[j], qdd, ap[j]);
-      if (contact_out) {
-        float* o = L.acc + (b0 + k) * 6;
-#pragma unroll
-        for (int j = 0; j < 6; j++) o[j] = ap[j];
-      }
-      const float vl = m->vel_limit[l * NLK + k];
-      const float qdn = rclampf(fmaf(dt, qdd, X.qd[k]), -vl, vl);
-      X.qd[k] = qdn;
-      X.q[k] = fmaf(dt, qdn, X.q[k]);
-    }
-  }
-  PHASE_MARK(8);
-
-  // ---- net contact force per reported body (the sub-step whose forces the task reads)
-  if (contact_out) {
-    GROUP_SYNC();
-#pragma unroll
-    for (int k = 0; k < NR; k++) {
-      if (P.idx[k] >= 0 && act.test(l + k * G)) contact_force_final(L.pt + P.idx[k] * PT_STRIDE, L.acc + m->dyn[P.body[k]] * 6, dt);
-    }
-    GROUP_SYNC();
-    for (int b = l; b < NB; b += G) {
-      float f[3] = {0.0f, 0.0f, 0.0f};
-      const int dl = m->dyn[b];
-      const int i0 = m->pt_start[dl], i1 = i0 + m->pt_count[dl];
-      if ((act.w[0] | act.w[1]) != 0ull) {
-        for (int i = i0; i < i1; i++) {
-          if (m->pt_body[i] != b || !act.test(m->pt_slot[i])) continue;
-          const float* o = L.pt + i * PT_STRIDE;
-          f[0] += o[PT_F]; f[1] += o[PT_F + 1]; f[2] += o[PT_F + 2];
-        }
-      }
-      contact_out[3 * b] = f[0]; contact_out[3 * b + 1] = f[1]; contact_out[3 * b + 2] = f[2];
-    }
-  }
-  PHASE_MARK(9);
-
-  // ---- floating base: semi-implicit Euler (oracle substep(), last block)
   if (isroot) {
+    float a[6];
+#pragma unroll
+    for (int j = 0; j < 21; j++) IA[j] = L.xroot[j];
+#pragma unroll
+    for (int j = 0; j < 6; j++) pA[j] = L.xroot[21 + j];
+    ldlt_solve6(IA, pA, a);
+#pragma unroll
+    for (int j = 0; j < 6; j++) L.acc[j] = a[j];
+    // semi-implicit Euler of the floating base (oracle substep(), last block)
     float* Rt = L.root;
     float ang[3] = {Rt[10], Rt[11], Rt[12]}, lin[3] = {Rt[7], Rt[8], Rt[9]}, wxv[3];
     cross3(ang, lin, wxv);
@@ -531,44 +570,127 @@ DEV void chain_substep(const StepCtx& C, const EnvLds& L, int l, ChainState<CD>&
     Rt[3] = nx * inv; Rt[4] = ny * inv; Rt[5] = nz * inv; Rt[6] = nw * inv;
   }
   GROUP_SYNC();
-  PHASE_MARK(10);
+  PHASE_MARK(7);
+
+  // ---- G. chain lanes: outward pass; joint accelerations to the dof lanes
+  if (ischain) {
+    float ap[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) ap[j] = L.acc[j];
+    const int b0 = CD::body(l, 0);
+#pragma unroll
+    for (int k = 0; k < NLK; k++) {
+#pragma unroll
+      for (int j = 0; j < 6; j++) ap[j] = ap[j] + K[k].c[j];
+      float ua = K[k].U[0] * ap[0];
+#pragma unroll
+      for (int j = 1; j < 6; j++) ua = fmaf(K[k].U[j], ap[j], ua);
+      const float qdd = (K[k].u - ua) * K[k].invD;
+#pragma unroll
+      for (int j = 0; j < 6; j++) ap[j] = fmaf(K[k].S[j], qdd, ap[j]);
+      if (contact_out) {
+        float* o = L.acc + (b0 + k) * 6;
+#pragma unroll
+        for (int j = 0; j < 6; j++) o[j] = ap[j];
+      }
+      L.dofb[(l * NLK + k) * DOF_STRIDE + 4] = qdd;
+    }
+  }
+  GROUP_SYNC();
+  PHASE_MARK(8);
+
+  // ---- H. dof lanes: semi-implicit Euler of the joints
+  if (isdof) {
+    const float vl = m->vel_limit[l];
+    const float qdn = rclampf(fmaf(dt, L.dofb[l * DOF_STRIDE + 4], X.qd), -vl, vl);
+    X.qd = qdn;
+    X.q = fmaf(dt, qdn, X.q);
+  }
+
+  // ---- net contact force per reported body (the sub-step whose forces the task reads)
+  if (contact_out) {
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+      if (P.idx[k] >= 0 && act.test(l + k * G)) contact_force_final(L.pt + P.idx[k] * PT_STRIDE, L.acc + m->dyn[P.body[k]] * 6, dt);
+    }
+    GROUP_SYNC();
+    // a body lane owns the points of its moving body: those of the link itself and, on a chain's last link, those of
+    // the welded end body -- two sums in point order (the oracle adds into contact_out[pt_body] in point order)
+    if (isbody && half == 0) {
+      const bool last = islink && (lb % NLK) == NLK - 1;
+      float f[3] = {0.0f, 0.0f, 0.0f}, fw[3] = {0.0f, 0.0f, 0.0f};
+      if (((act.w[0] & mine.mask.w[0]) | (act.w[1] & mine.mask.w[1])) != 0ull) {
+        for (int j = 0; j < mine.n; j++) {
+          if (!act.test(mine.slot(j))) continue;
+          const int i = mine.i0 + j;
+          const float* o = L.pt + i * PT_STRIDE;
+          if (m->pt_body[i] == myb) { f[0] += o[PT_F]; f[1] += o[PT_F + 1]; f[2] += o[PT_F + 2]; }
+          else { fw[0] += o[PT_F]; fw[1] += o[PT_F + 1]; fw[2] += o[PT_F + 2]; }
+        }
+      }
+      contact_out[3 * myb] = f[0]; contact_out[3 * myb + 1] = f[1]; contact_out[3 * myb + 2] = f[2];
+      if (last) { contact_out[3 * (myb + 1)] = fw[0]; contact_out[3 * (myb + 1) + 1] = fw[1]; contact_out[3 * (myb + 1) + 2] = fw[2]; }
+    }
+    GROUP_SYNC();
+  }
+  PHASE_MARK(9);
 }
 
-// gym.refresh_rigid_body_state_tensor for one env on the chain mapping: rows -> `stage` (LDS, nb x 13)
+// gym.refresh_rigid_body_state_tensor for one env: rows -> `stage` (LDS, nb x 13)
 template <int G, class CD>
-DEV void chain_body_states(const ShfModel* m, const EnvLds& L, int l, const ChainState<CD>& X, float* stage) {
-  constexpr int NCH = CD::NCH, NLK = CD::NLK;
-  auto row = [&](int b, const float* Rw, const float* p, const float* v) {
-    float* o = stage + 13 * b;
-    float t[3], q[4];
+DEV void chain_body_states(const ShfModel* m, const ChainLds& L, int l, const DofLane& X, float* stage) {
+  constexpr int NCH = CD::NCH, NLK = CD::NLK, ND = CD::ND, NB = CD::NB;
+  if (l < ND) {
+    const int b = CD::body(l / NLK, l % NLK);
+    float* rec = L.jrec + l * JREC_STRIDE;
+    float Rl[9];
+    joint_local_rotation(m->trot[b], m->axis[b], X.q, Rl);
 #pragma unroll
-    for (int k = 0; k < 3; k++) o[k] = L.root[k] + p[k];
-    mat_to_quat(Rw, q);
-#pragma unroll
-    for (int k = 0; k < 4; k++) o[3 + k] = q[k];
-    cross3(v, p, t);
-#pragma unroll
-    for (int k = 0; k < 3; k++) { o[7 + k] = v[3 + k] + t[k]; o[10 + k] = v[k]; }
-  };
-  if (l <= NCH) {
+    for (int k = 0; k < 9; k++) rec[k] = Rl[k];
+    rec[9] = X.qd;
+  }
+  GROUP_SYNC();
+  if (l < NCH || l == ND) {
     float Rc[9], pc[3] = {0.0f, 0.0f, 0.0f}, vc[6], S[6], c[6];
     quat_to_mat(L.root + 3, Rc);
 #pragma unroll
     for (int k = 0; k < 3; k++) { vc[k] = L.root[10 + k]; vc[3 + k] = L.root[7 + k]; }
-    if (l == NCH) {
-      row(0, Rc, pc, vc);
+    if (l == ND) {
+      pose_store(L.pose, Rc, pc, vc);
     } else {
       const int b0 = CD::body(l, 0);
 #pragma unroll
       for (int k = 0; k < NLK; k++) {
-        const int b = b0 + k;
-        chain_kin_link(m->tpos[b], m->trot[b], m->axis[b], X.q[k], X.qd[k], Rc, pc, vc, S, c);
-        row(b, Rc, pc, vc);
+        const float* rec = L.jrec + (l * NLK + k) * JREC_STRIDE;
+        float Rl[9];
+#pragma unroll
+        for (int j = 0; j < 9; j++) Rl[j] = rec[j];
+        chain_compose_link(m->tpos[b0 + k], m->axis[b0 + k], Rl, rec[9], Rc, pc, vc, S, c);
+        pose_store(L.pose + (b0 + k) * POSE_STRIDE, Rc, pc, vc);
       }
-      const int b = b0 + NLK;
-      chain_kin_weld(m->tpos[b], m->trot[b], Rc, pc);
-      row(b, Rc, pc, vc);
+      chain_kin_weld(m->tpos[b0 + NLK], m->trot[b0 + NLK], Rc, pc);
+      pose_store(L.pose + (b0 + NLK) * POSE_STRIDE, Rc, pc, vc);
     }
+  }
+  GROUP_SYNC();
+  for (int b = l; b < NB; b += G) {
+    const float* pb = L.pose + b * POSE_STRIDE;
+    float Rw[9], pp[3], v[6], t[3], q[4];
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rw[k] = pb[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) pp[k] = pb[9 + k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) v[k] = pb[12 + k];
+    float* o = stage + 13 * b;
+#pragma unroll
+    for (int k = 0; k < 3; k++) o[k] = L.root[k] + pp[k];
+    mat_to_quat(Rw, q);
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[3 + k] = q[k];
+    cross3(v, pp, t);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { o[7 + k] = v[3 + k] + t[k]; o[10 + k] = v[k]; }
   }
   GROUP_SYNC();
 }
@@ -578,7 +700,7 @@ DEV void chain_body_states(const ShfModel* m, const EnvLds& L, int l, const Chai
 template <int G, class CD, bool TW>
 DEV void a1_chain_step_body(const A1Args& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NLK = CD::NLK, NCH = CD::NCH, nb = CD::NB, nd = CD::ND, np = CD::NPC, NR = (CD::NPC + G - 1) / G;
+  constexpr int NLK = CD::NLK, nb = CD::NB, nd = CD::ND, np = CD::NPC, NR = (CD::NPC + G - 1) / G;
   PHASE_BEGIN();
   float* stats_lds = smem + MODEL_WORDS + TASK_WORDS;
   stats_block_init(stats_lds);
@@ -591,7 +713,7 @@ DEV void a1_chain_step_body(const A1Args& A) {
   float pre_dof[NW], pre_root = 0.0f, pre_act = 0.0f;
 #pragma unroll
   for (int k = 0; k < NW; k++) pre_dof[k] = 0.0f;
-  static_assert(G >= 13 && G >= nd, "one root word and one action per lane");
+  static_assert(G >= 13 && G > nd, "one root word and one action per lane");
   if (e < n) {
 #pragma unroll
     for (int k = 0; k < NW; k++)
@@ -606,7 +728,7 @@ DEV void a1_chain_step_body(const A1Args& A) {
   const int H = tp.num_history, P = tp.num_height_points;
   const int nobs = 12 + 2 * nd + nd * H + P;
   const int env_words = chain_lds_words<CD>(SCR_OBS + nobs);
-  EnvLds L = chain_lds_carve<CD>(smem + MODEL_WORDS + TASK_WORDS + STATS_LDS_WORDS + es * env_words);
+  ChainLds L = chain_lds_carve<CD>(smem + MODEL_WORDS + TASK_WORDS + STATS_LDS_WORDS + es * env_words);
   float* scr = L.pt;
 
 #pragma unroll
@@ -619,7 +741,6 @@ DEV void a1_chain_step_body(const A1Args& A) {
   if (l < nd) {
     act = rclampf(pre_act * tp.action_scale, -tp.clip_actions, tp.clip_actions);
     A.actions[(size_t)e * nd + l] = act;
-    L.dofb[l * DOF_STRIDE + 2] = act;   // parked for the chain lanes (the slot is otherwise unused on this mapping)
   }
   GROUP_SYNC();
 
@@ -639,51 +760,35 @@ DEV void a1_chain_step_body(const A1Args& A) {
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = nullptr;
   const float mu = A.S.friction[e];
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
-  ChainState<CD> X;
-  float acts[NLK], pg_[NLK], dg_[NLK], q0_[NLK], lim_[NLK];
-#pragma unroll
-  for (int k = 0; k < NLK; k++) {
-    const int d = l < NCH ? l * NLK + k : 0;
-    X.q[k] = L.dofb[d * DOF_STRIDE]; X.qd[k] = L.dofb[d * DOF_STRIDE + 1]; X.tau[k] = 0.0f;
-    acts[k] = L.dofb[d * DOF_STRIDE + 2];
-    pg_[k] = tp.p_gain[d]; dg_[k] = tp.d_gain[d]; q0_[k] = tp.default_dof_pos[d]; lim_[k] = m->effort[d];
-  }
+  const int dl = l < nd ? l : 0;
+  DofLane X = {L.dofb[dl * DOF_STRIDE], L.dofb[dl * DOF_STRIDE + 1], 0.0f};
+  const float pg_ = tp.p_gain[dl], dg_ = tp.d_gain[dl], q0_ = tp.default_dof_pos[dl], lim_ = m->effort[dl];
   ChainPoints<NR> LP;
   chain_points_load<G>(m, np, l, C.sp.contact_offset, LP);
-  SlotBits mine[NLK];   // evaluation slots of this lane's bodies (chain lanes: their links; root lane: the root)
-#pragma unroll
-  for (int k = 0; k < NLK; k++) {
-    const int b = l < NCH ? CD::body(l, k) : 0;
-    const bool has = l < NCH || (l == NCH && k == 0);
-    mine[k] = body_slot_mask(m, m->pt_start[b], has ? m->pt_start[b] + m->pt_count[b] : m->pt_start[b]);
-  }
+  // evaluation slots of this body lane's points (lane j < nd: link j; lane nd: the root)
+  const int lb = G >= 32 ? (l & 15) : l;
+  const int mb = lb < nd ? CD::body(lb / NLK, lb % NLK) : 0;
+  const SlotList<CD::MAXPT> mine = slot_list_load<CD::MAXPT>(m, m->pt_start[mb], (lb <= nd && l < 32) ? m->pt_count[mb] : 0);
   PHASE_MARK(11);
   for (int it = 0; it < nsub; it++) {
     if (it < tp.decimation) {
       // A1Robot.step's explicit PD (a1_conditional.py:66-67); the extra refresh_state sub-step keeps the last torque (Q1)
-#pragma unroll
-      for (int k = 0; k < NLK; k++) {
-        const float t = pg_[k] * (acts[k] + q0_[k] - X.q[k]) - dg_[k] * X.qd[k];
-        X.tau[k] = rclampf(t, -lim_[k], lim_[k]);
-      }
+      const float t = pg_ * (act + q0_ - X.q) - dg_ * X.qd;
+      X.tau = rclampf(t, -lim_, lim_);
     }
     chain_substep<G, CD, TW>(C, L, l, X, LP, mine, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
                              (it == nsub - 1) ? L.xch : nullptr);
   }
   PHASE_RESET();
-  if (l < NCH) {
-#pragma unroll
-    for (int k = 0; k < NLK; k++) {
-      float* D = L.dofb + (l * NLK + k) * DOF_STRIDE;
-      D[0] = X.q[k]; D[1] = X.qd[k]; D[5] = X.tau[k];
-    }
+  if (l < nd) {
+    float* D = L.dofb + l * DOF_STRIDE;
+    D[0] = X.q; D[1] = X.qd; D[5] = X.tau;
+    A.torques[(size_t)e * nd + l] = X.tau;
+    scr[SCR_ACT + l] = act;
   }
-  GROUP_SYNC();
-  if (l < nd) A.torques[(size_t)e * nd + l] = L.dofb[l * DOF_STRIDE + 5];
   for (int i = l; i < 3 * nb; i += G) A.S.contact[(size_t)e * nb * 3 + i] = L.xch[i];
   // the contact-point region is idle from here on: it becomes scratch
   for (int i = l; i < nd * H; i += G) scr[SCR_HIST + i] = A.history[(size_t)e * nd * H + i];
-  if (l < nd) scr[SCR_ACT + l] = act;
   PHASE_MARK(12);
   chain_body_states<G, CD>(m, L, l, X, scr + SCR_BODY);
   for (int i = l; i < 13 * nb; i += G) A.body_state[(size_t)e * nb * 13 + i] = scr[SCR_BODY + i];

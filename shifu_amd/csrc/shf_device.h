@@ -107,8 +107,8 @@ DEV float exp_spec(float x) {
   p = fmaf(r, p, 1.6666665459e-1f);
   p = fmaf(r, p, 5.0000001201e-1f);
   float e = fmaf(r * r, p, r) + 1.0f;
-  int32_t bits = __float_as_int(e) + (((int32_t)k) << 23);
-  return __int_as_float(bits);
+  const uint32_t bits = __float_as_uint(e) + ((uint32_t)(int32_t)k << 23);   // unsigned: k may be negative (same bits)
+  return __uint_as_float(bits);
 }
 DEV void quat_to_mat(const float* q, float* M) {
   float x = q[0], y = q[1], z = q[2], w = q[3];
@@ -710,8 +710,14 @@ DEV float friction_coefficient(const float* n, const float* vs, float pen, float
 }
 
 #include "shf_boxes.h"
+// tools/experiment.py builds with -DSHF_EXP_SHUFFLE_HANDOFF: the inward pass's child -> parent hand-off through
+// cross-lane moves (measured slower, profiles/r02_experiments.md); the product build takes the LDS slots
 #ifdef SHF_EXP_SHUFFLE_HANDOFF
 #include "experiments/shuffle_handoff.h"
+#define SHF_HANDOFF_SHUFFLE true
+#else
+#define SHF_HANDOFF_SHUFFLE false
+template <int G, class LM> DEV void exp_shuffle_handoff(const LM&, int, bool, BodyRegs&) {}
 #endif
 
 // Sample-point constants of the lane's contact rounds (point l + k*G in round k), for models whose point
@@ -798,6 +804,46 @@ DEV void contact_accumulate_p(const float* o, float dt, float* IA, float* pA) {
     const float bw = bb * wn[i2];
 #pragma unroll
     for (int j2 = i2; j2 < 6; j2++) IA[SYM(i2, j2)] = fmaf(bw, wn[j2], IA[SYM(i2, j2)]);
+  }
+}
+// The same fold with the 27 accumulators (IA[21], pA[6]) shared between two lanes: half 0 owns IA[0..10], half 1 owns
+// IA[11..20] and pA.  Each accumulator sees exactly the operations contact_accumulate_p applies to it, in the same
+// order; an element a lane does not own is left untouched (and its arithmetic is not generated).
+template <int HALF>
+DEV void contact_accumulate_half(const float* o, float dt, float* IA, float* pA) {
+  auto own = [](int idx) { return HALF == 0 ? idx <= 10 : idx >= 11; };
+  const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]}, n[3] = {o[PT_N], o[PT_N + 1], o[PT_N + 2]}, f0[3] = {o[PT_F], o[PT_F + 1], o[PT_F + 2]};
+  float t[3], wn[6];
+  if (HALF == 1) {
+    cross3(r, f0, t);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { pA[k] -= t[k]; pA[3 + k] -= f0[k]; }
+  }
+  cross3(r, n, t);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { wn[k] = t[k]; wn[3 + k] = n[k]; }
+  const float a = dt * o[PT_CT], bb = dt * (o[PT_BN] - o[PT_CT]);
+  const float r2 = dot3(r, r);
+#pragma unroll
+  for (int i2 = 0; i2 < 3; i2++)
+#pragma unroll
+    for (int j2 = i2; j2 < 3; j2++)
+      if (own(SYM(i2, j2))) IA[SYM(i2, j2)] = fmaf(a, (i2 == j2 ? r2 : 0.0f) - r[i2] * r[j2], IA[SYM(i2, j2)]);
+  if (own(SYM(0, 4))) IA[SYM(0, 4)] = fmaf(a, -r[2], IA[SYM(0, 4)]);
+  if (own(SYM(0, 5))) IA[SYM(0, 5)] = fmaf(a, r[1], IA[SYM(0, 5)]);
+  if (own(SYM(1, 3))) IA[SYM(1, 3)] = fmaf(a, r[2], IA[SYM(1, 3)]);
+  if (own(SYM(1, 5))) IA[SYM(1, 5)] = fmaf(a, -r[0], IA[SYM(1, 5)]);
+  if (own(SYM(2, 3))) IA[SYM(2, 3)] = fmaf(a, -r[1], IA[SYM(2, 3)]);
+  if (own(SYM(2, 4))) IA[SYM(2, 4)] = fmaf(a, r[0], IA[SYM(2, 4)]);
+  if (own(SYM(3, 3))) IA[SYM(3, 3)] += a;
+  if (own(SYM(4, 4))) IA[SYM(4, 4)] += a;
+  if (own(SYM(5, 5))) IA[SYM(5, 5)] += a;
+#pragma unroll
+  for (int i2 = 0; i2 < 6; i2++) {
+    const float bw = bb * wn[i2];
+#pragma unroll
+    for (int j2 = i2; j2 < 6; j2++)
+      if (own(SYM(i2, j2))) IA[SYM(i2, j2)] = fmaf(bw, wn[j2], IA[SYM(i2, j2)]);
   }
 }
 DEV void contact_accumulate(const float* o, float dt, BodyRegs& B) { contact_accumulate_p(o, dt, B.IA, B.pA); }
@@ -1031,39 +1077,40 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
         for (int j = 1; j < 6; j++) acc = fmaf(SYMG(B.IA, i, j), B.c[j], acc);
         pa[i] = fmaf(W[i], B.u, B.pA[i] + acc);
       }
-#ifdef SHF_EXP_SHUFFLE_HANDOFF
 #pragma unroll
       for (int k = 0; k < 6; k++) B.pA[k] = pa[k];
     }
-    exp_shuffle_handoff<G>(M, l, isdyn && mylevel == lev - 1, B);   // experiments/shuffle_handoff.h
-    if (false) {
-#else
-      float* o = L.xch + l * XCH_STRIDE;
+    if constexpr (SHF_HANDOFF_SHUFFLE) {
+      // experiment (profiles/r02_experiments.md): child -> parent through DPP / ds_bpermute instead of LDS slots
+      exp_shuffle_handoff<G>(M, l, isdyn && mylevel == lev - 1, B);
+    } else {
+      if (moving && mylevel == lev) {
+        float* o = L.xch + l * XCH_STRIDE;
 #pragma unroll
-      for (int k = 0; k < 21; k++) o[k] = B.IA[k];
+        for (int k = 0; k < 21; k++) o[k] = B.IA[k];
 #pragma unroll
-      for (int k = 0; k < 6; k++) { B.pA[k] = pa[k]; o[21 + k] = pa[k]; }
-    }
-    GROUP_SYNC();
-    if (isdyn && mylevel == lev - 1) {
-#endif
-      // children in child_list order: the first LANE_CHILDREN from registers, any further ones through LDS
+        for (int k = 0; k < 6; k++) o[21 + k] = B.pA[k];
+      }
+      GROUP_SYNC();
+      if (isdyn && mylevel == lev - 1) {
+        // children in child_list order: the first LANE_CHILDREN from registers, any further ones through LDS
 #pragma unroll
-      for (int kk = 0; kk < LANE_CHILDREN; kk++) {
-        if (kk < M.nchild) {
-          const float* o = L.xch + M.child[kk] * XCH_STRIDE;
+        for (int kk = 0; kk < LANE_CHILDREN; kk++) {
+          if (kk < M.nchild) {
+            const float* o = L.xch + M.child[kk] * XCH_STRIDE;
+#pragma unroll
+            for (int k = 0; k < 21; k++) B.IA[k] += o[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) B.pA[k] += o[21 + k];
+          }
+        }
+        for (int kk = LANE_CHILDREN; kk < M.nchild; kk++) {
+          const float* o = L.xch + m->child_list[M.child0 + kk] * XCH_STRIDE;
 #pragma unroll
           for (int k = 0; k < 21; k++) B.IA[k] += o[k];
 #pragma unroll
           for (int k = 0; k < 6; k++) B.pA[k] += o[21 + k];
         }
-      }
-      for (int kk = LANE_CHILDREN; kk < M.nchild; kk++) {
-        const float* o = L.xch + m->child_list[M.child0 + kk] * XCH_STRIDE;
-#pragma unroll
-        for (int k = 0; k < 21; k++) B.IA[k] += o[k];
-#pragma unroll
-        for (int k = 0; k < 6; k++) B.pA[k] += o[21 + k];
       }
     }
     // no hand-off here: every exchange slot is written once per sub-step, by its owner, before the sync above

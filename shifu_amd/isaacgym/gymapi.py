@@ -239,8 +239,33 @@ class Gym:
     """The object `gymapi.acquire_gym()` returns."""
 
     # ---- lifecycle ---------------------------------------------------------
+    # PhysX solver settings shifu's config sets (shifu/configs/env_config.py:46-58) that have no counterpart in this
+    # backend's compliant, linearly-implicit contact model (DESIGN.md section 2).  contact_offset and
+    # max_depenetration_velocity ARE used (ShfSimParams); the ones below are accepted and ignored -- said once, at
+    # create_sim, instead of only in a document.
+    IGNORED_PHYSX_FIELDS = {
+        "solver_type": "there is one solver: ABA with implicit contact, no TGS / PGS choice",
+        "num_position_iterations": "contacts are solved in one linear-implicit ABA pass, not iteratively",
+        "num_velocity_iterations": "contacts are solved in one linear-implicit ABA pass, not iteratively",
+        "rest_offset": "shapes rest where their compliant contact balances the load (0.6 mm sag per A1 foot)",
+        "bounce_threshold_velocity": "restitution is not modelled: every contact is inelastic",
+        "max_gpu_contact_pairs": "contact slots are fixed per articulation (SHF_MAX_POINTS), no pair buffer",
+        "default_buffer_size_multiplier": "no PhysX buffers",
+    }
+    _warned_physx = False
+
     def create_sim(self, compute_device=0, graphics_device=0, physics_engine=SIM_PHYSX, params: SimParams = None):
-        return SimHandle(compute_device, params or SimParams())
+        params = params or SimParams()
+        if not Gym._warned_physx:
+            Gym._warned_physx = True
+            import warnings
+            ref = PhysXParams()
+            for name, why in Gym.IGNORED_PHYSX_FIELDS.items():
+                val = getattr(params.physx, name, None)
+                if val is not None and val != getattr(ref, name, None):
+                    warnings.warn(f"shifu_amd: sim_params.physx.{name} = {val!r} is ignored by this backend ({why})",
+                                  stacklevel=2)
+        return SimHandle(compute_device, params)
 
     def add_ground(self, sim: SimHandle, params: PlaneParams):
         sim.terrain = ("plane", 0.5 * (params.static_friction + params.dynamic_friction))

@@ -182,11 +182,14 @@ def warp_map_from_shifts(dx, dy):
     return w.astype(np.uint8)
 
 
-def heightfield_from_trimesh(vertices, triangles):
+def heightfield_from_trimesh(vertices, triangles, horizontal_scale=None, vertical_scale=None):
     """Inverse of convert_heightfield_to_trimesh: (int16 samples, horizontal_scale, vertical_scale, warp bytes) of a
     mesh that function made -- exact, because it keeps the vertices in grid order and only shifts some of them by one
     cell in x / y.  Anything else (another triangulation, off-grid vertices, heights that are not multiples of one
-    vertical scale) raises: the backend collides grid terrains only."""
+    vertical scale) raises: the backend collides grid terrains only.  The scales are taken from the caller when given
+    (TriangleMeshParams carries none in the reference); otherwise hs is the median spacing of neighbouring vertices
+    (a shift moves a few of them by a whole cell, never the median) and vs the largest step for which every height is
+    an integer multiple -- the smallest gap between levels divided by 1..4, so levels such as {0, 2, 5} x vs resolve."""
     v = np.asarray(vertices, dtype=np.float64).reshape(-1, 3)
     t = np.asarray(triangles).reshape(-1, 3).astype(np.int64)
     n = v.shape[0]
@@ -207,21 +210,37 @@ def heightfield_from_trimesh(vertices, triangles):
     if not np.array_equal(t, exp):
         raise bad
     x, y, z = v[:, 0].reshape(rows, cols), v[:, 1].reshape(rows, cols), v[:, 2].reshape(rows, cols)
-    hs = round(float(x.max() - x.min()) / (rows - 1), 6)
-    if not hs > 0 or abs((y.max() - y.min()) / (cols - 1) - hs) > 1e-4 * hs:
-        raise bad
-    dx = (x - x.min() - np.arange(rows)[:, None] * hs) / hs
-    dy = (y - y.min() - np.arange(cols)[None, :] * hs) / hs
+    if horizontal_scale is not None:
+        hs = float(horizontal_scale)
+    else:
+        hs = round(float(np.median(np.diff(x, axis=0))), 6)
+        if not hs > 0 or abs(float(np.median(np.diff(y, axis=1))) - hs) > 1e-4 * hs:
+            raise bad
+    # grid origin: the un-shifted vertices sit on origin + i * hs; the median offset is theirs
+    x0 = float(np.median(x - np.arange(rows)[:, None] * hs))
+    y0 = float(np.median(y - np.arange(cols)[None, :] * hs))
+    dx = (x - x0 - np.arange(rows)[:, None] * hs) / hs
+    dy = (y - y0 - np.arange(cols)[None, :] * hs) / hs
     if np.abs(dx - np.rint(dx)).max() > 1e-3 or np.abs(dy - np.rint(dy)).max() > 1e-3 or \
             np.abs(np.rint(dx)).max() > 1 or np.abs(np.rint(dy)).max() > 1:
         raise bad
-    u = np.unique(np.abs(z))
-    steps = np.diff(u)
-    steps = steps[steps > 1e-7]
-    vs = round(float(steps.min()), 6) if steps.size else 0.005
-    k = z / vs
-    if np.abs(k - np.rint(k)).max() > 2e-2 or np.abs(k).max() > 32767:
+    if vertical_scale is not None:
+        cands = [float(vertical_scale)]
+    else:
+        u = np.unique(np.abs(z))
+        steps = np.diff(u)
+        steps = steps[steps > 1e-7]
+        gap = float(steps.min()) if steps.size else 0.005
+        cands = [round(gap / d, 6) for d in (1, 2, 3, 4)]
+    vs = None
+    for c in cands:
+        k = z / c
+        if c > 0 and np.abs(k - np.rint(k)).max() <= 2e-2 and np.abs(k).max() <= 32767:
+            vs = c
+            break
+    if vs is None:
         raise bad
+    k = z / vs
     return (np.ascontiguousarray(np.rint(k).astype(np.int16)), hs, vs,
             warp_map_from_shifts(np.rint(dx).astype(np.int64), np.rint(dy).astype(np.int64)))
 

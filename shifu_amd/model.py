@@ -652,6 +652,11 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
             da, db = dyn[capsules[i][0]], dyn[capsules[j][0]]
             if da == db:
                 continue
+            # the pair law scales each side's implicit part by 1 + m_own / m_other (csrc/shf_boxes.h self_scales): a moving
+            # body without mass of its own (legal when its subtree has inertia, _check_inertia) would turn that into
+            # inf / NaN for the whole env on first touch -- such pairs are not tested
+            if merged[da].mass <= 0.0 or merged[db].mass <= 0.0:
+                continue
             if (db > 0 and dyn[parent[db]] == da) or (da > 0 and dyn[parent[da]] == db):
                 continue
             pairs.append((i, j))

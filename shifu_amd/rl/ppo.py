@@ -20,8 +20,18 @@ class PPO:
         self._upd_graph = self._upd_idx = self._upd_sums = None
         # the critic's forward / backward on a second stream (bit-identical results, learn -25 % with the MFMA layers,
         # profiles/r02_mlp_probe.md); SHIFU_AMD_TWO_STREAM_UPDATE=0 switches it off
-        self._side = torch.cuda.Stream() if (torch.device(device).type == "cuda" and os.environ.get("SHIFU_AMD_TWO_STREAM_UPDATE", "1") == "1") else None
+        # (streams are created on and asked of THIS trainer's device, which need not be the current one)
+        self._side = (torch.cuda.Stream(device=torch.device(device))
+                      if (torch.device(device).type == "cuda" and os.environ.get("SHIFU_AMD_TWO_STREAM_UPDATE", "1") == "1") else None)
         self._updates_done = 0
+        # what follows each replay of the captured update: 'wait' (device-wide host wait, the only mode that reproduces the
+        # eager update on this stack; update()) or one of the experiment modes of profiles/r02_mlp_probe.md -- read once,
+        # and anything but 'wait' is announced because it is known to drift
+        self._replay_mode = os.environ.get("SHIFU_AMD_REPLAY_MODE", "wait")
+        if self._replay_mode != "wait" and self.graph_update:
+            import warnings
+            warnings.warn(f"SHIFU_AMD_REPLAY_MODE={self._replay_mode}: the captured PPO update is NOT equivalent to the eager one "
+                          "in this mode (profiles/r02_mlp_probe.md); experiments only")
         self.desired_kl, self.schedule = desired_kl, schedule
         self.actor_critic = actor_critic.to(device)
         # fused_loss: the loss block and its gradient as one HIP pass (rl/fused_loss.py) instead of ~100 small autograd
@@ -89,7 +99,7 @@ class PPO:
         if self._side is not None:
             # actor and critic are independent networks: the critic's forward (and, through autograd's stream bookkeeping,
             # its backward) runs on a second stream, so the small layers of one fill the CUs the other leaves idle
-            cur = torch.cuda.current_stream()
+            cur = torch.cuda.current_stream(torch.device(self.device))
             self._side.wait_stream(cur)
             with torch.cuda.stream(self._side):
                 value = ac.evaluate(cobs)
@@ -126,7 +136,7 @@ class PPO:
         from .fused_loss import ppo_loss
         ac = self.actor_critic
         if self._side is not None:
-            cur = torch.cuda.current_stream()
+            cur = torch.cuda.current_stream(torch.device(self.device))
             self._side.wait_stream(cur)
             with torch.cuda.stream(self._side):
                 value = ac.evaluate(cobs)
@@ -149,6 +159,11 @@ class PPO:
         share one lr tensor again and put this trainer's own flags for the current device back, so that a checkpoint from
         either side resumes on either device without falling into the per-parameter loop or the capturable assertion."""
         self.lr.fill_(float(self.optimizer.param_groups[0]["lr"]))
+        # a captured update holds the ADDRESSES of the optimizer state it was captured with; load_state_dict has just
+        # replaced those tensors (the old ones went back to the allocator): drop the graph, run the next update eagerly
+        # and capture again against the new state
+        self._upd_graph = self._upd_idx = self._upd_sums = None
+        self._updates_done = 0
         cuda = torch.device(self.device).type == "cuda"
         for g in self.optimizer.param_groups:
             g["lr"] = self.lr
@@ -228,7 +243,10 @@ class PPO:
         for _ in range(self.num_learning_epochs):
             for i in range(self.num_mini_batches):
                 if use_graph:
-                    self._upd_idx.copy_(perm[i * mb:(i + 1) * mb])
+                    if os.environ.get("SHIFU_AMD_IDX_COPY", "memcpy") == "kernel":
+                        torch.add(perm[i * mb:(i + 1) * mb], 0, out=self._upd_idx)      # a compute kernel, not a DMA copy
+                    else:
+                        self._upd_idx.copy_(perm[i * mb:(i + 1) * mb])
                     self._upd_graph.replay()
                     # Replayed back to back, the captured update is NOT equivalent to the eager one on this stack
                     # (ROCm 7.2 / torch 2.10): parameters drift from the first iterations on, differently from run to
@@ -240,7 +258,7 @@ class PPO:
                     # show it (tools/hipgraph_order_probe.py).  SHIFU_AMD_REPLAY_MODE=none|event|kernel reproduces the
                     # experiments of profiles/r02_mlp_probe.md.  The wait costs no throughput: the host has nothing else
                     # to do here.
-                    mode = os.environ.get("SHIFU_AMD_REPLAY_MODE", "wait")           # (experiments, profiles/r02_mlp_probe.md)
+                    mode = self._replay_mode
                     if mode == "wait":
                         torch.cuda.synchronize()
                     elif mode == "event":

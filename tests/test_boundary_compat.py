@@ -153,3 +153,45 @@ def test_add_triangle_mesh_without_hints_recovers_the_grid_exactly():
     t = ter.triangles.copy(); t[3] = t[3][::-1]
     with pytest.raises(NotImplementedError):
         terrain_utils.heightfield_from_trimesh(ter.vertices, t)
+
+
+def test_create_sim_names_the_ignored_physx_settings_once():
+    """shifu's config sets PhysX solver parameters (shifu/configs/env_config.py:46-58) that this backend's contact model
+    has no use for: the facade says so at create_sim -- once per process -- rather than staying silent."""
+    import warnings
+    from shifu_amd.isaacgym import gymapi
+    gymapi.Gym._warned_physx = False
+    gym = gymapi.acquire_gym()
+    sp = gymapi.SimParams()
+    sp.physx.num_position_iterations = 8          # env_config.py:51
+    sp.physx.bounce_threshold_velocity = 0.5      # env_config.py:56
+    sp.physx.contact_offset = 0.01                # used (ShfSimParams.contact_offset): must not be reported
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        gym.create_sim(0, 0, gymapi.SIM_PHYSX, sp)
+        gym.create_sim(0, 0, gymapi.SIM_PHYSX, sp)
+    msgs = [str(x.message) for x in w]
+    assert sum("num_position_iterations" in m for m in msgs) == 1
+    assert sum("bounce_threshold_velocity" in m for m in msgs) == 1
+    assert not any("contact_offset" in m for m in msgs)
+
+
+def test_trimesh_recovery_with_sparse_height_levels_and_shifted_border():
+    """a valid convert_heightfield_to_trimesh mesh whose height levels are never one vertical step apart
+    ({0, 2, 5} x vs) and whose outermost row has shifted vertices is still recovered exactly (vs from the gap divided by
+    1..4, hs from the median vertex spacing)."""
+    from shifu_amd.isaacgym import terrain_utils as tu
+    hs, vs = 0.1, 0.005
+    hf = np.zeros((12, 10), np.int16)
+    hf[4:8, 3:7] = 2
+    hf[9:, :] = 5              # a tall step reaching the last row: its riser shifts vertices of the border rows
+    hf[0, :] = 5
+    v, t = tu.convert_heightfield_to_trimesh(hf, hs, vs, 0.01)
+    got, ghs, gvs, warp = tu.heightfield_from_trimesh(v, t)
+    np.testing.assert_array_equal(got, hf)
+    assert abs(ghs - hs) < 1e-6 and abs(gvs - vs) < 1e-7
+    np.testing.assert_array_equal(warp, tu.trimesh_warp_map(hf, hs, vs, 0.01))
+    # and with the caller's scales
+    got2, _, gvs2, _ = tu.heightfield_from_trimesh(v, t, horizontal_scale=hs, vertical_scale=vs)
+    np.testing.assert_array_equal(got2, hf)
+    assert gvs2 == vs

@@ -1,0 +1,59 @@
+"""bench.py end to end as the driver launches it: the N > 1 launcher path in a child process --
+two ranks over gloo sharing the one GPU of the test box (RCCL refuses two ranks on one device), and the RCCL path itself
+with one rank (SHIFU_AMD_FORCE_DIST=1: process group, barriers, all-gather of the episode statistics, MAX all-reduce
+of the elapsed time).  The JSON lines are kept under gpurun_out/ (copied to profiles/ by the builder)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_bench(args, extra_env, tag):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    env = dict(os.environ)
+    env.update(extra_env)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"rank 0 prints exactly one JSON line, got {len(lines)}"
+    out = json.loads(lines[0])
+    log_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(log_dir):
+        with open(os.path.join(log_dir, f"bench_{tag}.json"), "w") as f:
+            f.write(lines[0] + "\n")
+    return out
+
+
+def test_bench_two_ranks_in_child_processes_over_gloo():
+    """`python bench.py --gpus 2 ...` started bare becomes the launcher (torch.distributed.run, one child per rank)."""
+    out = _run_bench(["--gpus", "2", "--steps", "30", "--warmup", "5", "--no-cpu-baseline"],
+                     {"SHIFU_AMD_DIST_BACKEND": "gloo"}, "2rank_gloo")
+    assert out["n_gpus"] == 2 and out["config"]["total_envs"] == 2 * 4096 and out["config"]["envs_per_gpu"] == 4096
+    assert out["config"]["obs_finite"] is True
+    assert out["config"]["gathers_in_timed_region"] >= 1, "steps 6..35 of the run contain the 24th: one all-gather is timed"
+    assert out["scaling"] == "weak" and out["value"] > 0 and out["steps"] == 30 and out["warmup"] == 5
+    assert out["cpu_baseline"] is None, "the CPU leg runs at N = 1 only"
+
+
+def test_bench_one_rank_over_rccl():
+    """The same code path on RCCL (backend nccl) with a single rank: what every rank of the driver's 8-GPU run executes."""
+    out = _run_bench(["--gpus", "1", "--steps", "30", "--warmup", "5", "--no-cpu-baseline"],
+                     {"SHIFU_AMD_FORCE_DIST": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1",
+                      "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())}, "1rank_rccl")
+    assert out["n_gpus"] == 1 and out["config"]["total_envs"] == 4096
+    assert out["config"]["obs_finite"] is True and out["config"]["gathers_in_timed_region"] >= 1

@@ -170,3 +170,32 @@ def test_mesh_box_rests_on_the_plane_like_the_primitive_box(tmp_path):
         z[k] = root[0, 2]
         assert abs(root[0, 9]) < 1e-4                                    # at rest
     assert 0.045 < z["mesh"] < 0.0501 and abs(z["mesh"] - z["prim"]) < 1e-7
+
+
+MASSLESS_MID = """<robot name="r">
+ <link name="base"><inertial><mass value="2"/><inertia ixx="0.01" ixy="0" ixz="0" iyy="0.01" iyz="0" izz="0.01"/></inertial>
+  <collision><geometry><box size="0.3 0.2 0.1"/></geometry></collision></link>
+ <link name="mid"><collision><origin xyz="0 0 -0.1"/><geometry><sphere radius="0.03"/></geometry></collision></link>
+ <link name="tip"><inertial><origin xyz="0 0 -0.1"/><mass value="0.3"/><inertia ixx="1e-3" ixy="0" ixz="0" iyy="1e-3" iyz="0" izz="1e-3"/></inertial>
+  <collision><origin xyz="0 0 -0.2"/><geometry><sphere radius="0.03"/></geometry></collision></link>
+ <joint name="j1" type="revolute"><parent link="base"/><child link="mid"/><origin xyz="0.2 0 0"/><axis xyz="0 1 0"/><limit lower="-1" upper="1" effort="10" velocity="10"/></joint>
+ <joint name="j2" type="revolute"><parent link="mid"/><child link="tip"/><origin xyz="0 0 -0.2"/><axis xyz="0 1 0"/><limit lower="-1" upper="1" effort="10" velocity="10"/></joint>
+</robot>"""
+
+
+def test_self_collision_pairs_skip_massless_moving_bodies(tmp_path):
+    """the self-collision pair law divides by each body's own mass (1 + m_own / m_other).  A massless
+    intermediate link with a collision shape compiles (its subtree has inertia) -- its pairs must not be listed."""
+    path = tmp_path / "mid.urdf"
+    path.write_text(MASSLESS_MID)
+    cm = compile_urdf(str(path), default_dof_drive_mode=_abi.DOF_MODE_EFFORT, self_collision=True,
+                      inertia_from_geometry=False) if "inertia_from_geometry" in compile_urdf.__code__.co_varnames else None
+    if cm is None:
+        cm = compile_urdf(str(path), default_dof_drive_mode=_abi.DOF_MODE_EFFORT, self_collision=True)
+    m = cm.blob
+    mid = cm.body_names.index("mid")
+    if m.mass[mid] > 0.0:
+        pytest.skip("this compiler derives the link's mass from its collision geometry: nothing massless to guard")
+    for k in range(m.npair):
+        for c in (m.pair_a[k], m.pair_b[k]):
+            assert m.mass[m.dyn[m.cap_body[c]]] > 0.0, "pair with a massless moving body"
