@@ -494,6 +494,53 @@ int shf_gather_rows(const void* const* src, void* const* dst, const int32_t* row
 int shf_adapt_lr(const float* kl_dev, float* lr_dev, float kl_high, float kl_low, float inv_down, float up, float lr_min,
                  float lr_max, void* stream);
 
+/* ---- library glue of the hook-compatible path (ShifuVecEnv with torch hooks), one launch each ----------------------
+ * The fused steps carry these inside their kernels; on the source-compatible path they were dozens of small torch
+ * launches of LIBRARY code per vec-step.  Same arithmetic as the in-kernel versions and as the oracle's glue_*. */
+/* LeggedRobot.post_step (shifu/units/robot.py:222-229): gravity_vec[e] = -1 on up_axis; base_lin_vel / base_ang_vel /
+ * projected_gravity = quat_rotate_inverse(root quat, root lin vel / ang vel / gravity_vec), root row = root_idx[e]
+ * (or e when NULL) of the (num_root_rows, 13) root-state tensor.  Outputs (n, 3). */
+int shf_base_frame_state(const float* root_state, const int64_t* root_idx_or_null, int64_t num_root_rows, int32_t n,
+                         int32_t up_axis, float* base_lin_vel, float* base_ang_vel, float* projected_gravity,
+                         float* gravity_vec, void* stream);
+/* TerrainGymEnv.get_heights (shifu/gym/isaac_gym.py:412-433): yaw-rotate the (num_points, 2) base-frame grid by each
+ * env's root quaternion, add root xy and the border, divide by hscale, truncate toward zero, clip to the map, MIN of the
+ * cell and its +x / +y neighbours, times vscale.  rows == 0 (plane): zeros.  out (n, num_points). */
+int shf_get_heights(const ShfTerrain* terrain, const int16_t* height_samples, const float* root_state,
+                    const int64_t* root_idx_or_null, int64_t num_root_rows, const float* height_points_xy, int32_t n,
+                    int32_t num_points, float* out, void* stream);
+/* HistoryRecorder.add (shifu/utils/train.py:12-14) on a (rows, num_history) view: shift towards the past, x into column 0. */
+int shf_history_add(float* history, const float* x, int64_t rows, int32_t num_history, void* stream);
+/* buf[idx[i], :] = value for i < n_idx, rows of row_words floats (HistoryRecorder.reset_idx, train.py:16-17; the
+ * per-key `sums[env_ids] = 0`); out-of-range indices are skipped. */
+int shf_rows_fill_indexed(float* buf, const int64_t* idx, int32_t n_idx, int64_t num_rows, int32_t row_words, float value,
+                          void* stream);
+/* ShifuVecEnv.log_info (shifu/gym/env.py:149-158) for one reset set: out_means[k] = mean(sums[k][env_ids]) /
+ * episode_length_s, then sums[k][env_ids] = 0, for num_keys <= 16 per-env (num_envs) fp32 tensors (`sums` is a HOST array
+ * of device pointers); env_ids distinct.  Exact 2^-20 fixed-point sums: order-independent.  workspace17: 17 int64 on the
+ * device, zero before the first call (the kernel leaves it zero). */
+int shf_episode_log(float* const* sums, int32_t num_keys, const int64_t* env_ids, int32_t n_ids, int64_t num_envs,
+                    float episode_length_s, int64_t* workspace17, float* out_means, void* stream);
+/* Robot._reset_dof_state (shifu/units/robot.py:74-86) ahead of its two indexed commits: for every env id,
+ * dof_targets[e, :] = dof_state[e, :, 0] = default_dof_pos, dof_state[e, :, 1] = 0 on the (num_envs, num_dof[, 2])
+ * tensors, and actor_ids_out[i] = (int32) root_idx[e] -- the index tensor set_dof_*_tensor_indexed takes. */
+int shf_reset_dof_rows(float* dof_state, float* dof_targets, const float* default_dof_pos, const int64_t* env_ids,
+                       int32_t n_ids, int64_t num_envs, int32_t num_dof, const int64_t* root_idx_or_null,
+                       int32_t* actor_ids_out_or_null, void* stream);
+/* ArmRobot.inverse_kinematics (shifu/units/robot.py:162-182): dof_targets_out[e, :] = dof_pos[e, :] + J^T (J J^T +
+ * damping^2 I)^-1 dpose, dpose = [goal_pos - ee_pos; orientation_error(goal_quat, ee_quat)] (quat_mul / quat_conjugate of
+ * shifu/utils/torch_utils.py:12-40), J = the end effector's (6, num_dof) block at j_ee + e * j_env_stride floats (a view
+ * into the Jacobian tensor), ee_pose row (pos, quat xyzw) at ee_pose + e * ee_env_stride, goal_pose (n, 7), dof_pos element
+ * (e, d) at dof_pos[(e * num_dof + d) * dof_elem_stride] (2 for the position column of dof_state).  LDL^T, not
+ * torch.inverse: the fused ABB step's and the oracle's arithmetic (golden G9: 3e-5 of the row scale against torch). */
+int shf_ik_dls(const float* j_ee, int64_t j_env_stride, const float* dof_pos, int32_t dof_elem_stride, const float* ee_pose,
+               int64_t ee_env_stride, const float* goal_pose, int32_t n, int32_t num_dof, float damping,
+               float* dof_targets_out, void* stream);
+/* ShifuVecEnv.compute_reward's accumulation (env.py:180-185): rew = terms[0] + terms[1] + ... in that order,
+ * sums[k] += terms[k]; HOST arrays of num_keys <= 16 device pointers to (num_envs) fp32 tensors. */
+int shf_reward_accumulate(const float* const* terms, float* const* sums, int32_t num_keys, int64_t num_envs, float* rew,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,15 @@ _SIGS = {
     "shf_episode_bookkeeping": ([vp, vp, i32, i64, vp, vp, vp, vp], i32),
     "shf_gather_rows": ([C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), i32, vp, i64, vp], i32),
     "shf_adapt_lr": ([vp, vp] + [C.c_float] * 6 + [vp], i32),
+    # library glue of the hook-compatible path (csrc/shf_glue.hip)
+    "shf_base_frame_state": ([vp, vp, i64, i32, i32, vp, vp, vp, vp, vp], i32),
+    "shf_get_heights": ([C.POINTER(_abi.ShfTerrain), vp, vp, vp, i64, vp, i32, i32, vp, vp], i32),
+    "shf_history_add": ([vp, vp, i64, i32, vp], i32),
+    "shf_rows_fill_indexed": ([vp, vp, i32, i64, i32, C.c_float, vp], i32),
+    "shf_episode_log": ([C.POINTER(vp), i32, vp, i32, i64, C.c_float, vp, vp, vp], i32),
+    "shf_reset_dof_rows": ([vp, vp, vp, vp, i32, i64, i32, vp, vp, vp], i32),
+    "shf_ik_dls": ([vp, i64, vp, i32, vp, i64, vp, i32, i32, C.c_float, vp, vp], i32),
+    "shf_reward_accumulate": ([C.POINTER(vp), C.POINTER(vp), i32, i64, vp, vp], i32),
     "shf_gae": ([vp, vp, vp, vp, i32, i64, C.c_float, C.c_float, vp, vp], i32),
     "shf_ppo_loss_workspace": ([i64, i32, C.POINTER(i64)], i32),
     "shf_ppo_loss": ([vp] * 10 + [i64, i32, C.c_float, C.c_float, C.c_float, i32] + [vp] * 6, i32),

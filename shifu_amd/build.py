@@ -11,7 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libshifu_amd.so")
-SOURCES = ["shf_api.hip", "shf_a1_chain.hip", "shf_mlp.hip"]
+SOURCES = ["shf_api.hip", "shf_a1_chain.hip", "shf_glue.hip", "shf_mlp.hip"]
 DEPS = SOURCES + ["shf_device.h", "shf_boxes.h", "shf_task.h", "shf_chain.h", os.path.join("..", "..", "include", "shifu_amd.h")]
 # -fno-slp-vectorize: the SLP vectoriser packs neighbouring scalar f32 ops into v_pk_* pairs plus the
 # v_mov shuffles that feed them -- slower for this kernel (measured -6 % at 2 envs/wave, -25 % at one

@@ -19,6 +19,7 @@
 // ------------------------------------------------------------ host state --
 static thread_local std::string g_err;
 static int fail(const std::string& msg) { g_err = msg; return 1; }
+int shf_set_error(const std::string& msg) { return fail(msg); }   // for the other translation units (shf_glue.hip)
 #define HIP_OK(call)                                                              \
   do {                                                                            \
     hipError_t e_ = (call);                                                       \

@@ -108,6 +108,20 @@ class ShifuVecEnv:
             self.extras["time_outs"] = self.time_out_buf
 
     def log_info(self, env_ids):
+        if self.rew_buf.is_cuda and torch.is_tensor(env_ids) and env_ids.is_cuda and env_ids.dtype == torch.int64 \
+                and len(self.episode_rewards) <= 16:
+            # the loop below as one launch (csrc/shf_glue.hip: shf_episode_log; exact fixed-point sums)
+            from shifu_amd import glue
+            if getattr(self, "_episode_log", None) is None:
+                self._episode_log = glue.EpisodeLog(self.rew_buf.device)
+            keys = list(self.episode_rewards.keys())
+            means = self._episode_log([self.episode_rewards[k] for k in keys], env_ids, self.max_episode_length_s)
+            for i, key in enumerate(keys):
+                self.extras["episode"][key] = means[i]
+            info = self.episode_log(env_ids)
+            if info:
+                self.extras["episode"].update(info)
+            return
         for key, sums in self.episode_rewards.items():
             self.extras["episode"][key] = torch.mean(sums[env_ids]) / self.max_episode_length_s
             sums[env_ids] = 0.
@@ -121,6 +135,14 @@ class ShifuVecEnv:
                                 for f in self.reward_functions}
 
     def compute_reward(self):
+        if self.rew_buf.is_cuda and len(self.reward_functions) <= 16:
+            from shifu_amd import glue
+            terms = [f() for f in self.reward_functions]                 # the user's hooks, untouched
+            terms = [r if (r.dtype == torch.float32 and r.is_contiguous() and r.shape == self.rew_buf.shape)
+                     else (r.to(torch.float32) + torch.zeros_like(self.rew_buf)).contiguous() for r in terms]
+            # rew_buf = sum of the terms in their order, episode sums += term: one launch (shf_reward_accumulate)
+            glue.reward_accumulate(terms, [self.episode_rewards[f.__name__] for f in self.reward_functions], self.rew_buf)
+            return
         self.rew_buf[:] = 0.
         for f in self.reward_functions:
             r = f()

@@ -93,6 +93,10 @@ class IsaacGymEnv:
 
     def _refresh_all(self):
         g, s = self.gym, self.sim
+        if hasattr(g, "refresh_all_state_tensors"):
+            # backend extension: the six refreshes below as one call (one kinematics pass for body states + Jacobian)
+            g.refresh_all_state_tensors(s)
+            return
         g.refresh_actor_root_state_tensor(s)
         g.refresh_rigid_body_state_tensor(s)
         g.refresh_dof_state_tensor(s)
@@ -131,7 +135,9 @@ class IsaacGymEnv:
         for actor in actors:
             actor.reset_idx(env_ids)
             rows.append(actor.root_indices[env_ids])
-        rows = torch.unique(torch.cat(rows)).to(dtype=torch.int32)
+        # (the reference de-duplicates with torch.unique -- a sort and a host sync for the output size; the actors' root
+        # rows are disjoint by construction and the indexed commit copies a row named twice twice, to the same effect)
+        rows = (rows[0] if len(rows) == 1 else torch.cat(rows)).to(dtype=torch.int32)
         self.gym.set_actor_root_state_tensor_indexed(self.sim, gymtorch.unwrap_tensor(self.root_state),
                                                      gymtorch.unwrap_tensor(rows), len(rows))
 
@@ -158,6 +164,17 @@ class TerrainGymEnv(IsaacGymEnv):
     def _init_buffers(self):
         super()._init_buffers()
         self.height_points = self._init_height_points()
+        self._glue_terrain = None
+        if self.root_state.is_cuda and self.cfg.terrain.mesh_type in ('heightfield', 'trimesh'):
+            # what shf_get_heights needs: the map's geometry, the samples as int16, the (P, 2) base-frame grid
+            from shifu_amd import _abi
+            t = _abi.ShfTerrain()
+            t.rows, t.cols = self.height_samples.shape
+            c = self.terrain.cfg
+            t.hscale, t.vscale, t.border, t.friction = c.horizontal_scale, c.vertical_scale, c.border_size, c.static_friction
+            self._glue_terrain = t
+            self._glue_samples = self.height_samples.to(torch.int16).contiguous()
+            self._glue_points = self.height_points[0, :, :2].contiguous()
 
     def _init_height_points(self):
         """(N, P, 3) base-frame sample grid, meshgrid(x, y, indexing='xy') flattened."""
@@ -233,6 +250,11 @@ class TerrainGymEnv(IsaacGymEnv):
             return torch.zeros(self.num_envs, self.num_height_points, device=self.device, requires_grad=False)
         if t.mesh_type == 'none':
             raise NameError("Can't measure height with terrain mesh type 'none'")
+        if not env_ids and self.height_samples.is_cuda and getattr(self, "_glue_terrain", None) is not None:
+            # the expressions below as one launch (csrc/shf_glue.hip: shf_get_heights)
+            from shifu_amd import glue
+            return glue.get_heights(self._glue_terrain, self._glue_samples, self.root_state, self.robot.root_indices,
+                                    self._glue_points, self.num_envs)
         pose = self.robot.base_pose
         if env_ids:
             pts = quat_apply_yaw(pose[env_ids, 3:7].repeat(1, self.num_height_points),

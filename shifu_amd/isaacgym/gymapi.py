@@ -477,6 +477,11 @@ class Gym:
     def refresh_net_contact_force_tensor(self, sim): sim.backend.refresh(_abi.REFRESH_CONTACT)
     def refresh_jacobian_tensors(self, sim): sim.backend.refresh(_abi.REFRESH_JACOBIAN)
     def refresh_force_sensor_tensor(self, sim): pass
+
+    def refresh_all_state_tensors(self, sim):
+        """Not an Isaac Gym call: root, rigid-body, dof, Jacobian and net-contact-force tensors refreshed by ONE backend
+        call (shifu's refresh_state issues the six refresh_* calls back to back, shifu/gym/isaac_gym.py:145-154)."""
+        sim.backend.refresh(_abi.REFRESH_ALL)
     def refresh_mass_matrix_tensors(self, sim): pass
 
     # ---- stepping --------------------------------------------------------------

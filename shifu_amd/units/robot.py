@@ -64,10 +64,18 @@ class Robot(Actor):
             self.gym.refresh_dof_state_tensor(self.sim)
 
     def _reset_dof_state(self, env_ids):
-        self.dof_targets[env_ids] = self.default_dof_pos.clone()
-        self.dof_pos[env_ids] = self.default_dof_pos.clone()
-        self.dof_vel[env_ids] = 0.
-        actor_ids = self.root_indices[env_ids].to(torch.int32)
+        ds = self.env.dof_state
+        if ds.is_cuda and torch.is_tensor(env_ids) and env_ids.is_cuda and env_ids.dtype == torch.int64 \
+                and ds.shape[0] == self.env.num_envs * self.num_dof:
+            # the four statements below as one launch (csrc/shf_glue.hip: shf_reset_dof_rows); only a robot owns dofs
+            # (robot.py:51-52 views dof_state as (N, num_dof, 2)), so env e's block starts at e * num_dof
+            from shifu_amd import glue
+            actor_ids = glue.reset_dof_rows(ds, self.dof_targets, self.default_dof_pos, env_ids, self.root_indices)
+        else:
+            self.dof_targets[env_ids] = self.default_dof_pos.clone()
+            self.dof_pos[env_ids] = self.default_dof_pos.clone()
+            self.dof_vel[env_ids] = 0.
+            actor_ids = self.root_indices[env_ids].to(torch.int32)
         self.gym.set_dof_position_target_tensor_indexed(self.sim, gymtorch.unwrap_tensor(self.dof_targets),
                                                         gymtorch.unwrap_tensor(actor_ids), len(actor_ids))
         self.gym.set_dof_state_tensor_indexed(self.sim, gymtorch.unwrap_tensor(self.env.dof_state),
@@ -97,6 +105,7 @@ class ArmRobot(Robot):
         jac = gymtorch.wrap_tensor(self.gym.acquire_jacobian_tensor(self.sim, self.name))
         self.gym.refresh_jacobian_tensors(self.sim)
         self.j_ee = jac[:, ee[0] - 1]   # a fixed base has no Jacobian row (robot.py:128)
+        self._ee0 = int(ee[0])
 
     def load_to(self, env_id, env_handle, seg_id):
         super().load_to(env_id, env_handle, seg_id)
@@ -130,6 +139,13 @@ class ArmRobot(Robot):
 
     def inverse_kinematics(self, goal_pose, damping=0.05):
         """Damped least squares on the EE Jacobian (robot.py:162-182)."""
+        if self.j_ee.is_cuda and self.j_ee.dim() == 3 and self.j_ee.dtype == torch.float32 and goal_pose.is_cuda \
+                and hasattr(self, "_ee0"):
+            # the expressions below as one launch (csrc/shf_glue.hip: shf_ik_dls, LDL^T instead of torch.inverse)
+            from shifu_amd import glue
+            n = self.env.num_envs
+            ee = self.env.body_state.view(n, -1, 13)[:, self._ee0, :7]
+            return glue.ik_dls(self.j_ee, self.dof_pos, ee, goal_pose, damping)
         ee_pos, ee_quat = self.ee_pose[:, 0, :3], self.ee_pose[:, 0, 3:7]
         dpose = torch.cat([goal_pose[:, :3] - ee_pos, self.orientation_error(goal_pose[:, 3:7], ee_quat)],
                           -1).unsqueeze(-1)
@@ -170,6 +186,14 @@ class LeggedRobot(ArmRobot):
         """Base-frame velocities from the root_state TENSOR -- which has not been refreshed
         since the previous env step (Q2)."""
         n = self.env.num_envs
+        rs = self.env.root_state
+        if rs.is_cuda:
+            # the four expressions below as one launch (csrc/shf_glue.hip: shf_base_frame_state)
+            from shifu_amd import glue
+            if glue.usable(rs, self.base_lin_vel, self.base_ang_vel, self.projected_gravity, self.gravity_vec):
+                glue.base_frame_state(rs, self.root_indices, self.env.up_axis_idx, self.base_lin_vel, self.base_ang_vel,
+                                      self.projected_gravity, self.gravity_vec)
+                return
         self.gravity_vec[:] = to_torch(get_axis_params(-1., self.env.up_axis_idx), device=self.device).repeat((n, 1))
         quat = self.base_pose[:, 3:7]
         self.base_lin_vel[:] = quat_rotate_inverse(quat, self.env.root_state[self.root_indices, 7:10])

@@ -14,11 +14,20 @@ class HistoryRecorder:
         self.history_buf = torch.zeros(*shape, num_history, device=device)
 
     def add(self, x):
+        if self.history_buf.is_cuda and x.is_cuda and x.dtype == torch.float32 and self.history_buf.is_contiguous():
+            from shifu_amd import glue              # the two statements below as one launch (shf_history_add)
+            glue.history_add(self.history_buf, x)
+            return
         # shift towards the past, then store the newest at slot 0
         self.history_buf[..., 1:] = self.history_buf[..., :-1].clone()
         self.history_buf[..., 0] = x
 
     def reset_idx(self, idx):
+        if self.history_buf.is_cuda and torch.is_tensor(idx) and idx.is_cuda and idx.dtype == torch.int64 \
+                and self.history_buf.is_contiguous():
+            from shifu_amd import glue
+            glue.rows_fill_indexed(self.history_buf, idx, 0.0)
+            return
         self.history_buf.index_fill_(0, idx, 0.)
 
     def get_last(self, idx):

@@ -226,8 +226,10 @@ def test_abb_rod_pushes_the_cube():
 
 
 def test_fused_abb_env_tracks_hook_env():
-    """FusedAbbEnv vs the hook-based AbbPushBox on the same state and actions.  The IK linear solve
-    differs (in-kernel LDL^T vs torch.inverse), so states agree to ~1e-4 rather than bit for bit."""
+    """FusedAbbEnv vs the hook-based AbbPushBox on the same state and actions.  Round 3: the hook path's
+    ArmRobot.inverse_kinematics runs the same LDL^T kernel arithmetic as the fused step (csrc/shf_glue.hip: shf_ik_dls;
+    it was torch.inverse, which left ~1e-4 between the two paths and forced cubes in contact out of the comparison), so
+    until an env resets the two paths hold IDENTICAL root, dof and observation tensors, cubes in contact included."""
     from shifu_amd.gym.abb_fused import FusedAbbEnv
     n = 32
     hook = _abb(n)
@@ -244,7 +246,7 @@ def test_fused_abb_env_tracks_hook_env():
     alive = torch.ones(n, dtype=torch.bool, device="cuda:0")
     touched = torch.zeros(n, dtype=torch.bool, device="cuda:0")
     cube0 = fused.root_state.view(n, 4, 13)[:, 2, :3].clone()
-    compared = 0
+    compared, worst = 0, 0.0
     for it in range(25):
         a = 2 * torch.rand(n, 3, device="cuda:0", generator=g) - 1
         o1, _, r1, d1, _ = hook.step(a)
@@ -252,24 +254,19 @@ def test_fused_abb_env_tracks_hook_env():
         alive &= ~(d1.bool() | d2)
         if not alive.any():
             break
-        m = alive
-        # cubes the rod has touched are excluded from the pose check: a 1e-5 m difference in the rod
-        # position times the 5e4 N/m contact decorrelates a 0.1 kg cube within a couple of steps.  (The contact
-        # tensor shows the last sub-step only, so a tap that ended earlier is recognised by the cube having moved.)
-        touched |= (hook.isg_env.contact_state.view(n, 10, 3)[:, :7].abs().sum((1, 2)) > 0) | \
-                   (fused.contact_state.view(n, 10, 3)[:, :7].abs().sum((1, 2)) > 0)
-        for rs in (hook.isg_env.root_state, fused.root_state):
-            touched |= (rs.view(n, 4, 13)[:, 2, :3] - cube0).abs().amax(1) > 2e-4
-        free = m & ~touched
+        free = alive                     # every env that has not reset yet, cubes in contact included
         if free.any():
-            dr = (hook.isg_env.root_state.view(n, 4, 13)[free][..., :7] - fused.root_state.view(n, 4, 13)[free][..., :7]).abs()
-            assert dr.max() < 5e-3, f"root step {it}: max {dr.max()}"
-            assert torch.allclose(o1[free], o2[free], atol=2e-3, rtol=0), f"obs step {it}"
-            dq = (hook.robot.dof_pos[free] - fused.dof_state.view(n, 6, 2)[free][..., 0]).abs()
-            assert dq.max() < 2e-3, f"dof_pos step {it}: {dq.max()}"
-            assert torch.allclose(r1[free], r2[free], atol=5e-3), f"rew step {it}"
+            dr = (hook.isg_env.root_state.view(n, 4, 13)[free] - fused.root_state.view(n, 4, 13)[free]).abs()
+            assert dr.max() == 0, f"root step {it}: max {dr.max()}"
+            assert torch.equal(o1[free], o2[free]), f"obs step {it}"
+            dq = (hook.isg_env.dof_state.view(n, 6, 2)[free] - fused.dof_state.view(n, 6, 2)[free]).abs()
+            assert dq.max() == 0, f"dof_state step {it}: {dq.max()}"
+            assert torch.allclose(r1[free], r2[free], atol=1e-6), f"rew step {it}"
+            touched |= (fused.contact_state.view(n, 10, 3)[:, :7].abs().sum((1, 2)) > 0) & free
+            worst = max(worst, float(dr.max()), float(dq.max()))
         compared += int(free.sum())
-    assert compared > 3 * n
+    assert compared > 3 * n and worst == 0.0
+    assert int(touched.sum()) > 0, "the comparison must include envs whose rod was in contact"
 
 
 @pytest.mark.gpu
