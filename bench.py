@@ -231,6 +231,9 @@ def main():
     ap.add_argument("--self-collision", action="store_true",
                     help="A1 workloads: collide the robot's own links (capsule pairs; the reference's collision filter 0, "
                          "units.py:68) -- off in the headline configuration, whose BASELINE entry names height-field contact")
+    ap.add_argument("--link-contacts", action="store_true",
+                    help="abb workload: the arm's links (box stand-ins for their mesh colliders) and the rod also collide with the "
+                         "table, the cube and the goal pad (SURVEY 8f f3, ShfModel.link_collide) -- off in the headline configuration")
     ap.add_argument("--graph", action="store_true", help="(experiments: slower, and back-to-back graph replays are not trustworthy on this stack, profiles/r02_mlp_probe.md) replay the vec-step from a captured hipGraph instead of launching it "
                     "eagerly (measured slower on ROCm 7.2: 84.7 vs 73.9 us per vec-step, profiles/r02_bench_*.json)")
     ap.add_argument("--decimation", type=int, default=4, help="(experiments only) control.decimation")
@@ -278,10 +281,11 @@ def main():
 
     abb = args.workload == "abb"
     mapping = "body" if abb else (args.mapping or "body")
-    group = args.group or (16 if (abb or mapping == "chain") else 32)
+    group = args.group or ((32 if args.link_contacts else 16) if (abb or mapping == "chain") else 32)
     if abb:
         from shifu_amd.gym.abb_fused import FusedAbbEnv
-        env = FusedAbbEnv(num_envs=args.envs, device=dev, seed=42, rank=rank, world_size=world, group=group)
+        env = FusedAbbEnv(num_envs=args.envs, device=dev, seed=42, rank=rank, world_size=world, group=group,
+                          link_contacts=args.link_contacts)
         stats_t, count_t, kernel = _abi.ABB_STATS, _abi.ABB_RESET_COUNT, "k_abb_step"
         substeps = 6
     else:
@@ -416,7 +420,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{WL_NAME[args.workload]}, {N} envs/GPU, random actions, {substeps} substeps/env-step "
                                    f"(dt {'20' if abb else '5'} ms), resets on"
-                                   + ("" if abb else (", self-collision ON (capsule pairs, the reference's collision filter 0)" if args.self_collision
+                                   + ((", link contacts ON (arm links + rod vs table / cube / goal pad)" if args.link_contacts else
+                                       ", arm collider: the rod against the cube (link contacts OFF, see --link-contacts)") if abb else (", self-collision ON (capsule pairs, the reference's collision filter 0)" if args.self_collision
                                                       else ", self-collision OFF (the reference has it on: units.py:68; see --self-collision)")),
                        "envs_per_gpu": N, "total_envs": total_envs, "substeps_per_env_step": substeps,
                        "lanes_per_env": group, "lane_mapping": mapping, "self_collision": bool(args.self_collision) and not abb, "vec_step": "hipGraph replay of [uniform_, fused step]" if graph is not None else "eager launches",

@@ -33,6 +33,9 @@ extern "C" {
 #define SHF_MAX_CAPSULES 16 /* self-collision capsules per articulation      */
 #define SHF_MAX_PAIRS 96    /* capsule pairs tested for self-collision       */
 #define SHF_MAX_SELF_CONTACTS 8 /* simultaneously active self-contacts per env (further ones are dropped, in pair order) */
+#define SHF_MAX_ABOX 16         /* box-shaped collision volumes of the articulation (vs the corners of box actors)   */
+#define SHF_MAX_LINK_CONTACTS 16 /* simultaneously active link <-> box-actor contacts per env (further ones are dropped, in
+                                  * candidate order, and counted: SHF_T_DROPPED)                                     */
 
 /* joint types of a reported body's inboard joint */
 enum { SHF_JOINT_ROOT = 0, SHF_JOINT_REVOLUTE = 1, SHF_JOINT_PRISMATIC = 2, SHF_JOINT_WELD = 3 };
@@ -122,6 +125,25 @@ typedef struct ShfModel {
   float cap_radius[SHF_MAX_CAPSULES];
   uint8_t pair_a[SHF_MAX_PAIRS];     /* capsule indices, pair_a < pair_b */
   uint8_t pair_b[SHF_MAX_PAIRS];
+
+  /* Link contacts (create_actor(..., group = env, filter = 0), units.py:68: every shape of an env
+   * collides with every other actor's): with link_collide != 0 the articulation's collision shapes meet the box actors
+   * beyond the rounded sph_* shapes against free boxes --
+   *   (A) every contact sample point pt_* (box / hull vertices: radius 0; spheres, capsule ends: their radius) against
+   *       every box actor, free or fixed, as a sphere against a box;
+   *   (C) the rounded sph_* shapes against the FIXED boxes (against free ones they always are tested);
+   *   (B) the eight corners of every box actor against the articulation's box volumes abox_* (vertex in box).
+   * Vertex-face manifolds in both directions; edge-edge crossings are not detected.  Against a free box the contact
+   * takes the consistent pair law (the box is eliminated exactly), against a fixed one the ground-contact law.  At most
+   * SHF_MAX_LINK_CONTACTS are active per env and sub-step, in candidate order (A by point then box, C by shape then box,
+   * B by box, corner, volume); more are dropped and counted.  abox: centre and orientation in abox_body's frame. */
+  int32_t link_collide;
+  int32_t nabox;
+  int32_t pad_lc[2];
+  int32_t abox_body[SHF_MAX_ABOX];
+  float abox_pos[SHF_MAX_ABOX][3];
+  float abox_rot[SHF_MAX_ABOX][9]; /* row-major rotation body <- box */
+  float abox_half[SHF_MAX_ABOX][3];
 } ShfModel;
 
 /* A single-body box actor (gym.create_box, object.py:28-39). */
@@ -207,7 +229,9 @@ enum {
   SHF_T_MODEL = 13,      /* sizeof(ShfModel) bytes, device copy                            */
   SHF_T_SIM_CONTACT = 14,/* (N*B, 3) f32 internal net contact force of the last step        */
   SHF_T_SCENE = 15,      /* sizeof(ShfScene) bytes, device copy                            */
-  SHF_T_COUNT = 16
+  SHF_T_DROPPED = 16,    /* (N) i32: contacts dropped since the host last cleared it -- self-contacts beyond
+                          * SHF_MAX_SELF_CONTACTS, link contacts beyond SHF_MAX_LINK_CONTACTS (optional binding)   */
+  SHF_T_COUNT = 17
 };
 
 /* refresh masks: gym.refresh_*_tensor (isaac_gym.py:139-154) */

@@ -52,6 +52,27 @@ def flop_lib():
     return _FLOP
 
 
+def box_primitives(bR, bpos, h, pt, rad=0.0):
+    """point_in_box and sphere_vs_box (float64 build) for one box and one point: (inside, phi, n), (phi_s, n_s, rc)."""
+    a = np.concatenate([np.asarray(bR, np.float64).reshape(9), np.asarray(bpos, np.float64), np.asarray(h, np.float64),
+                        np.asarray(pt, np.float64), [float(rad)]]).reshape(1, 19)
+    out = np.zeros((1, 12))
+    lib().shf_oracle_box_primitives_f64(C.c_int(1), _p(a, C.c_double), _p(out, C.c_double))
+    o = out[0]
+    return (bool(o[0]), float(o[1]), o[2:5].copy()), (float(o[5]), o[6:9].copy(), o[9:12].copy())
+
+
+def point_in_box(bR, bpos, h, pt):
+    return box_primitives(bR, bpos, h, pt)[0]
+
+
+def dropped(reset: bool = True) -> int:
+    """Contacts the float build dropped at the per-env limits (self / link contacts) since the last reset."""
+    f = lib().shf_oracle_dropped
+    f.restype = C.c_long
+    return int(f(C.c_int(1 if reset else 0)))
+
+
 def _p(a, ct):
     return None if a is None else a.ctypes.data_as(C.POINTER(ct))
 

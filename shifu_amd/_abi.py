@@ -11,6 +11,8 @@ MAX_SPHERES = 8
 MAX_CAPSULES = 16
 MAX_PAIRS = 96
 MAX_SELF_CONTACTS = 8
+MAX_ABOX = 16
+MAX_LINK_CONTACTS = 16
 
 JOINT_ROOT, JOINT_REVOLUTE, JOINT_PRISMATIC, JOINT_WELD = 0, 1, 2, 3
 DOF_MODE_NONE, DOF_MODE_POS, DOF_MODE_VEL, DOF_MODE_EFFORT = 0, 1, 2, 3
@@ -39,6 +41,8 @@ class ShfModel(C.Structure):
         ("self_collide", i32), ("ncap", i32), ("npair", i32), ("pad_sc", i32),
         ("cap_body", i32 * MAX_CAPSULES), ("cap_a", (f32 * 3) * MAX_CAPSULES), ("cap_b", (f32 * 3) * MAX_CAPSULES),
         ("cap_radius", f32 * MAX_CAPSULES), ("pair_a", C.c_uint8 * MAX_PAIRS), ("pair_b", C.c_uint8 * MAX_PAIRS),
+        ("link_collide", i32), ("nabox", i32), ("pad_lc", i32 * 2), ("abox_body", i32 * MAX_ABOX),
+        ("abox_pos", (f32 * 3) * MAX_ABOX), ("abox_rot", (f32 * 9) * MAX_ABOX), ("abox_half", (f32 * 3) * MAX_ABOX),
     ]
 
 
@@ -92,7 +96,7 @@ class ShfAbbTaskParams(C.Structure):
 
 # tensor ids (shf_sim_*)
 T_DOF_STATE, T_ROOT_STATE, T_BODY_STATE, T_CONTACT, T_JACOBIAN, T_SIM_DOF, T_SIM_ROOT, T_EFFORT, \
-    T_POS_TARGET, T_VEL_TARGET, T_BODY_FORCE, T_FRICTION, T_HEIGHTS, T_MODEL, T_SIM_CONTACT, T_SCENE, T_COUNT = range(17)
+    T_POS_TARGET, T_VEL_TARGET, T_BODY_FORCE, T_FRICTION, T_HEIGHTS, T_MODEL, T_SIM_CONTACT, T_SCENE, T_DROPPED, T_COUNT = range(18)
 
 REFRESH_DOF, REFRESH_ROOT, REFRESH_BODY, REFRESH_CONTACT, REFRESH_JACOBIAN, REFRESH_ALL = 1, 2, 4, 8, 16, 31
 

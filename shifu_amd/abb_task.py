@@ -16,9 +16,22 @@ ROD_RADIUS = 0.0194
 ROD_CAPSULE = [("tool0", (0.0, 0.0, 0.2145 - ROD_RADIUS), (0.0, 0.0, ROD_RADIUS - 0.0025), ROD_RADIUS)]
 
 
-def abb_model(kp=800.0, kd=40.0):
+def abb_link_boxes():
+    """Box stand-ins for the reference's mesh colliders of the arm's links (asset/urdf/abb_rod_description/meshes/
+    irb1200_5_90/collision/*.stl): the bounding boxes of their convex hulls, tools/make_link_boxes.py."""
+    import json
+    with open(asset_path("abb_link_boxes.json")) as f:
+        return [tuple(b) for b in json.load(f)["boxes"]]
+
+
+def abb_model(kp=800.0, kd=40.0, link_contacts=False):
+    """link_contacts: the arm's links collide with the table, the cube and the goal pad (SURVEY 8f f3;
+    ShfModel.link_collide) through box stand-ins for their mesh colliders -- off for the fused / benchmarked scene, whose
+    only arm collider is the rod (BASELINE config 5), on for `AbbPushBox` through the gym facade (every shape of an env
+    collides there: create_actor(..., group, 0), units.py:68)."""
     cm = compile_urdf(asset_path("abb_rod.urdf"), fix_base_link=True, disable_gravity=True,
-                      default_dof_drive_mode=_abi.DOF_MODE_POS, extra_spheres=ROD_CAPSULE)
+                      default_dof_drive_mode=_abi.DOF_MODE_POS, extra_spheres=ROD_CAPSULE, link_contacts=link_contacts,
+                      extra_boxes=abb_link_boxes() if link_contacts else ())
     for d in range(cm.blob.nd):
         cm.blob.kp[d], cm.blob.kd[d] = kp, kd
     return cm

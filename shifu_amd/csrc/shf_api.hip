@@ -63,7 +63,7 @@ extern "C" int shf_abi_version(void) { return SHF_ABI_VERSION; }
 
 
 // gym.simulate: one sub-step for every env
-template <int G, bool BOX, bool SELF>
+template <int G, bool BOX, bool SELF, bool LINK = false>
 __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const ShfScene* scene = BOX ? stage_scene(A.scene, smem + MODEL_WORDS) : nullptr;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
   if (e >= A.n) return;
   const int nbx = BOX ? A.nboxes : 0, actors = 1 + nbx;
   const int nb = m->nb, nd = m->nd, nbt = nb + nbx;
-  const int nslots = m->np + box_slot_count(nbx, m->nsph) + (SELF ? SHF_MAX_SELF_CONTACTS : 0);
+  const int nslots = m->np + box_slot_count(nbx, m->nsph) + (SELF ? SHF_MAX_SELF_CONTACTS : 0) + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0);
   EnvLds L = env_lds_carve(smem + MODEL_WORDS + (BOX ? SCENE_WORDS : 0) + es * env_lds_words(nbt, nd, nslots, 0, actors),
                            nbt, nd, nslots, actors);
   float* dof = A.dof + (size_t)e * nd * 2;
@@ -84,11 +84,12 @@ __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
   GROUP_SYNC();
   StepCtx C;
   C.m = m; C.sp = A.sp; C.terr.t = A.terr; C.terr.h = A.heights; C.scene = scene;
+  C.dropped = A.dropped ? A.dropped + e : nullptr;
   const float mu = A.friction ? A.friction[e] : 1.0f;
   LaneModel M;
   lane_model_load<DynDims>(m, l, M);
   LanePoints<1> P;   // unused: point count only known at run time
-  substep<G, BOX, DynDims, !BOX, LaneModel, DynScene, SELF>(C, L, l, M, P, A.pos_tgt ? A.pos_tgt + (size_t)e * nd : nullptr,
+  substep<G, BOX, DynDims, !BOX, LaneModel, DynScene, SELF, LINK>(C, L, l, M, P, A.pos_tgt ? A.pos_tgt + (size_t)e * nd : nullptr,
                   A.vel_tgt ? A.vel_tgt + (size_t)e * nd : nullptr, A.body_force ? A.body_force + (size_t)e * nbt * 3 : nullptr, mu, L.xch);
   GROUP_SYNC();
   for (int i = l; i < 2 * nd; i += G) dof[i] = L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)];
@@ -303,6 +304,7 @@ DEV void a1_step_body(const A1Args& A) {
 
   StepCtx C;
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = nullptr;
+  C.dropped = A.S.dropped ? A.S.dropped + e : nullptr;
   const float mu = A.S.friction[e];
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
   // (with self-collision the per-lane model constants stay in LDS: the pair tests need the registers)
@@ -413,7 +415,7 @@ DEV void abb_reset_env(const ShfAbbTaskParams& tp, int nd, int nbx, int64_t gid,
 
 // DM / SC: run-time model and scene (any arm, any boxes), or the shipped ABB scene fixed at compile time (ancestor-walk
 // kinematics, compile-time level loops, ballot-driven box folds) -- the host picks the latter only when both match.
-template <int G, class DM, class SC>
+template <int G, class DM, class SC, bool LINK = false>
 __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* stats_lds = smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS;
@@ -432,7 +434,8 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
   const int n = A.S.n;
   if (e >= n) return;
   const int nbx = SC::NBX > 0 ? SC::NBX : A.S.nboxes, actors = 1 + nbx;
-  const int nb = DM::nb(m), nd = DM::nd(m), nbt = nb + nbx, nslots = DM::np(m) + box_slot_count(nbx, m->nsph);
+  const int nb = DM::nb(m), nd = DM::nd(m), nbt = nb + nbx;
+  const int nslots = DM::np(m) + box_slot_count(nbx, m->nsph) + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0);
   const int env_words = env_lds_words(nbt, nd, nslots, nslots * PT_STRIDE + SHF_MAX_DOFS, actors);
   EnvLds L = env_lds_carve(smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS + es * env_words, nbt, nd, nslots, actors);
   float* tgtl = L.pt + nslots * PT_STRIDE;  // POS targets of this env step
@@ -492,6 +495,7 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
 
   StepCtx C;
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = scene;
+  C.dropped = A.S.dropped ? A.S.dropped + e : nullptr;
   const float mu = A.S.friction[e];
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
   LaneModel M;
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
   const BoxLane BL = SC::NBX > 0 ? box_lane_load(m, l) : BoxLane();
   // net contact forces are reported for the last sub-step only (what the refreshed tensor shows)
   for (int it = 0; it < nsub; it++)
-    substep<G, true, DM, false, LaneModel, SC>(C, L, l, M, P, tgtl, nullptr, nullptr, mu, it == nsub - 1 ? L.xch : nullptr, BL);
+    substep<G, true, DM, false, LaneModel, SC, false, LINK>(C, L, l, M, P, tgtl, nullptr, nullptr, mu, it == nsub - 1 ? L.xch : nullptr, BL);
   GROUP_SYNC();
   for (int i = l; i < 3 * nbt; i += G) A.S.contact[(size_t)e * nbt * 3 + i] = L.xch[i];
   GROUP_SYNC();
@@ -597,10 +601,12 @@ __global__ void k_abb_reset_all(AbbArgs A) {
 
 // ---------------------------------------------------------------- C ABI --
 static bool sim_self(const ShfSim* s) { return s->model.self_collide != 0 && s->model.npair > 0; }
+static bool sim_link(const ShfSim* s) { return s->model.link_collide != 0 && s->nboxes > 0; }
 static size_t sim_lds_bytes(const ShfSim* s, int head_words, int min_tail, bool boxes = false) {
   const int epb = 256 / s->group;
   const int nbx = boxes ? s->nboxes : 0;
-  const int nslots = s->model.np + (boxes ? box_slot_count(nbx, s->model.nsph) : 0) + (sim_self(s) ? SHF_MAX_SELF_CONTACTS : 0);
+  const int nslots = s->model.np + (boxes ? box_slot_count(nbx, s->model.nsph) : 0) + (sim_self(s) ? SHF_MAX_SELF_CONTACTS : 0) +
+                     ((boxes && sim_link(s)) ? 2 * SHF_MAX_LINK_CONTACTS : 0);
   return ((size_t)MODEL_WORDS + head_words + (boxes ? SCENE_WORDS : 0) +
           (size_t)epb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, min_tail, 1 + (boxes ? nbx : s->nboxes))) * 4;
 }
@@ -696,6 +702,7 @@ extern "C" int shf_sim_layout(const ShfSim* sim, int32_t id, int64_t shape[4], i
       shape[3] = sim->model.fixed_base ? nd : nd + 6; break;
     case SHF_T_EFFORT: case SHF_T_POS_TARGET: case SHF_T_VEL_TARGET: *ndim = 1; shape[0] = N * nd; break;
     case SHF_T_FRICTION: *ndim = 1; shape[0] = N; break;
+    case SHF_T_DROPPED: *ndim = 1; shape[0] = N; *dtype = 1; break;
     case SHF_T_HEIGHTS:
       *dtype = 2;
       if (sim->terr.rows > 0 && sim->terr.warped) {   // samples followed by one byte per vertex (ShfTerrain.warped)
@@ -746,6 +753,7 @@ static SimArgs sim_args(const ShfSim* s, bool internal) {
   A.body_force = nullptr;
   A.friction = (const float*)s->t[SHF_T_FRICTION];
   A.contact = (float*)s->t[internal ? SHF_T_SIM_CONTACT : SHF_T_CONTACT];
+  A.dropped = (int32_t*)s->t[SHF_T_DROPPED];
   return A;
 }
 
@@ -810,6 +818,21 @@ extern "C" int shf_sim_step(ShfSim* sim, void* stream) {
     if (!sim->t[SHF_T_SCENE]) return fail("shf_sim_step: scene (box actors) not bound");
     if (sim->model.nb + sim->nboxes > sim->group) return fail("shf_sim_step: bodies + boxes exceed the lane group");
     const size_t lds = sim_lds_bytes(sim, 0, 0, true);
+    if (sim_link(sim)) {
+      // link contacts (ShfModel.link_collide): the run-time-shaped kernels with the candidate pass compiled in
+      if (sim_self(sim)) {
+        switch (sim->group) {
+          case 64: return launch(k_sim_step<64, true, true, true>, grid, block, lds, stream, A);
+          case 32: return launch(k_sim_step<32, true, true, true>, grid, block, lds, stream, A);
+          default: return launch(k_sim_step<16, true, true, true>, grid, block, lds, stream, A);
+        }
+      }
+      switch (sim->group) {
+        case 64: return launch(k_sim_step<64, true, false, true>, grid, block, lds, stream, A);
+        case 32: return launch(k_sim_step<32, true, false, true>, grid, block, lds, stream, A);
+        default: return launch(k_sim_step<16, true, false, true>, grid, block, lds, stream, A);
+      }
+    }
     if (sim_self(sim)) {
       switch (sim->group) {
         case 64: return launch(k_sim_step<64, true, true>, grid, block, lds, stream, A);
@@ -1163,9 +1186,16 @@ extern "C" int shf_abb_step(ShfAbbTask* task, const float* raw_actions_dev, void
   ShfSim* s = task->sim;
   const int epb = 256 / s->group;
   dim3 grid((s->n + epb - 1) / epb), block(256);
-  const int nbx = s->nboxes, nslots = s->model.np + box_slot_count(nbx, s->model.nsph);
+  const int nbx = s->nboxes, nslots = s->model.np + box_slot_count(nbx, s->model.nsph) + (sim_link(s) ? 2 * SHF_MAX_LINK_CONTACTS : 0);
   const size_t lds = ((size_t)MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS +
                       (size_t)epb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, nslots * PT_STRIDE + SHF_MAX_DOFS, 1 + nbx)) * 4;
+  if (sim_link(s)) {
+    switch (s->group) {
+      case 64: return launch(k_abb_step<64, DynDims, DynScene, true>, grid, block, lds, stream, A);
+      case 32: return launch(k_abb_step<32, DynDims, DynScene, true>, grid, block, lds, stream, A);
+      default: return launch(k_abb_step<16, DynDims, DynScene, true>, grid, block, lds, stream, A);
+    }
+  }
   if (AbbDims::matches(s->model) && AbbScene::matches(s->nboxes, s->boxes, s->model.nsph)) {
     switch (s->group) {
       case 64: return launch(k_abb_step<64, AbbDims, AbbScene>, grid, block, lds, stream, A);

@@ -40,7 +40,7 @@ DEV BoxLane box_lane_load(const ShfModel* m, int l) {
   return K;
 }
 // ballots of one sub-step (fixed-scene path): corner bit c * (NBX + 1) + tg, sphere bit si
-struct BoxMasks { unsigned long long corners = 0ull; unsigned spheres = 0u; };
+struct BoxMasks { unsigned long long corners = 0ull; unsigned spheres = 0u; int nlink = 0; };
 
 // slot layout in LDS (PT_STRIDE floats): r[3] n[3] f0[3] ct bn on (PT_* offsets, shf_device.h)
 DEV void slot_eval(float* o, float phi, const float* n, const float* r, const float* vs, const float* vp, float mu, float kc,
@@ -137,7 +137,8 @@ DEV void mat3_inv(const float* A, float* Ai) {
   Ai[6] = c02 * id; Ai[7] = fmaf(A[1], A[6], -(A[0] * A[7])) * id; Ai[8] = fmaf(A[0], A[4], -(A[1] * A[3])) * id;
 }
 // box lane: IA / pA = the box with its own contacts folded, afree = its solve; o = the pair slot; pr = the pair record
-DEV void pair_law(const float* IA, const float* afree, const float* o, float dt, float* pr) {
+// nshare: the number of pair slots active on this box (each sees 1 / n of it: its compliance times n; oracle boxes_pre)
+DEV void pair_law(const float* IA, const float* afree, const float* o, float dt, float* pr, float nshare = 1.0f) {
   const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]}, n[3] = {o[PT_N], o[PT_N + 1], o[PT_N + 2]};
   const float ct = o[PT_CT], bn = o[PT_BN];
   float W[9], cfree[3];
@@ -151,7 +152,7 @@ DEV void pair_law(const float* IA, const float* afree, const float* o, float dt,
     ldlt_solve6(IA, rhs, y);
     pair_point_accel(y, r, wp);
 #pragma unroll
-    for (int i = 0; i < 3; i++) W[3 * i + k] = wp[i];
+    for (int i = 0; i < 3; i++) W[3 * i + k] = wp[i] * nshare;
   }
   pair_point_accel(afree, r, cfree);
   float K[9], Mx[9], S[9], g0[3], Ke[9];
@@ -460,7 +461,10 @@ DEV int self_contacts(const StepCtx& C, const EnvLds& L, int l, bool isdyn, int 
     }
     count += __builtin_popcountll(mask);
   }
-  if (count > SHF_MAX_SELF_CONTACTS) count = SHF_MAX_SELF_CONTACTS;
+  if (count > SHF_MAX_SELF_CONTACTS) {
+    if (l == 0 && C.dropped) *C.dropped += count - SHF_MAX_SELF_CONTACTS;     // dropped in pair order -- and counted (SHF_T_DROPPED)
+    count = SHF_MAX_SELF_CONTACTS;
+  }
   GROUP_SYNC();
   if (isdyn) {
     for (int k = 0; k < count; k++) {
@@ -541,6 +545,149 @@ DEV unsigned body_sphere_flags(const ShfModel* m, const EnvLds& L, int nbx, int 
     }
   }
   return bits;
+}
+
+// ------------------------------------------------------------ link contacts --
+// ShfModel.link_collide (include/shifu_amd.h; oracle boxes_pre "link contacts"): the articulation's collision shapes
+// against the box actors of its env beyond the rounded-shape pair slots -- (A) sample points x boxes, (C) rounded shapes
+// x fixed boxes, (B) box corners x articulation box volumes -- one lane per candidate and round, the active ones
+// compacted in candidate order into at most SHF_MAX_LINK_CONTACTS slots from `slot0` on (their `on` word holds
+// 1 + body * SHF_MAX_BOXES + box; the pair record of slot k sits at slot0 + SHF_MAX_LINK_CONTACTS + k).  A slot's
+// normal points towards the articulation, which receives +f.  Returns the number of active slots.
+DEV int link_code(int body, int box) { return 1 + body * SHF_MAX_BOXES + box; }
+DEV int link_code_body(float on) { return ((int)on - 1) / SHF_MAX_BOXES; }
+DEV int link_code_box(float on) { return ((int)on - 1) % SHF_MAX_BOXES; }
+template <int G>
+DEV int link_contacts(const StepCtx& C, const EnvLds& L, int l, int slot0, float mu_shape, const float* g_art) {
+  const ShfModel* m = C.m;
+  const SceneDev* S = C.scene;
+  const int nb = m->nb, nbx = S->nboxes, np = m->np, nsph = m->nsph, nabox = m->nabox;
+  const float dt = C.sp.dt, kc = C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
+  const float offset = C.sp.contact_offset;
+  const float beta = fmaf(kc, dt, C.sp.contact_d);
+  const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
+  const int lane0 = (int)(threadIdx.x & 63u) - l;
+  const unsigned long long gmask = G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
+  const int nA = np * nbx, nC = nsph * nbx, nB = nbx * 8 * nabox, ncand = nA + nC + nB;
+  int count = 0;
+  for (int j = 0; j * G < ncand; j++) {
+    const int p = l + j * G;
+    float slot[PT_STRIDE];
+    slot[PT_ON] = 0.0f;
+    int body = 0, box = 0;
+    if (p < ncand) {
+      if (p < nA + nC) {
+        // a rounded shape of the articulation (a sample point: segment 0) against box kd
+        const bool isA = p < nA;
+        const int q = isA ? p : p - nA;
+        const int sh = q / nbx, kd = q % nbx;
+        const ShfBoxDesc& bd = S->box[kd];
+        const bool dynb = box_is_dynamic(bd);
+        body = isA ? m->pt_body[sh] : m->sph_body[sh];
+        box = kd;
+        if (isA || !dynb) {
+          const float* pb = L.pose + body * POSE_STRIDE;
+          const float* pk = L.pose + (nb + kd) * POSE_STRIDE;
+          const float* qa = L.pose + m->dyn[body] * POSE_STRIDE;
+          float Rb[9], Rk[9], c[3], sw[3];
+#pragma unroll
+          for (int i = 0; i < 9; i++) { Rb[i] = pb[i]; Rk[i] = pk[i]; }
+          const float lp[3] = {isA ? m->pt_pos[sh][0] : m->sph_pos[sh][0], isA ? m->pt_pos[sh][1] : m->sph_pos[sh][1],
+                               isA ? m->pt_pos[sh][2] : m->sph_pos[sh][2]};
+          const float ls[3] = {isA ? 0.0f : m->sph_seg[sh][0], isA ? 0.0f : m->sph_seg[sh][1], isA ? 0.0f : m->sph_seg[sh][2]};
+          const float rad = isA ? m->pt_radius[sh] : m->sph_radius[sh];
+          const float hh[3] = {0.5f * bd.dim[0], 0.5f * bd.dim[1], 0.5f * bd.dim[2]}, bpos[3] = {pk[9], pk[10], pk[11]};
+          mv3(Rb, lp, c);
+#pragma unroll
+          for (int i = 0; i < 3; i++) c[i] += pb[9 + i];
+          mv3(Rb, ls, sw);
+          const float rel[3] = {fmaf(0.5f, sw[0], c[0]) - bpos[0], fmaf(0.5f, sw[1], c[1]) - bpos[1], fmaf(0.5f, sw[2], c[2]) - bpos[2]};
+          const float reach = 0.5f * sqrtf(dot3(sw, sw)) + sqrtf(dot3(hh, hh)) + rad + offset + 0.01f;
+          if (!(dot3(rel, rel) > reach * reach)) {
+            if (ls[0] != 0.0f || ls[1] != 0.0f || ls[2] != 0.0f) {
+              const float t = segment_box_param(Rk, bpos, hh, c, sw);
+#pragma unroll
+              for (int i = 0; i < 3; i++) c[i] = fmaf(t, sw[i], c[i]);
+            }
+            float phi, n[3], rc[3], ta[3], tb[3], vrel[3], vrs[3];
+            sphere_vs_box(Rk, bpos, hh, c, rad, &phi, n, rc);
+            const float va[3] = {qa[12], qa[13], qa[14]}, vbx[3] = {pk[12], pk[13], pk[14]};
+            cross3(va, rc, ta);
+            cross3(vbx, rc, tb);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+              const float pa = qa[15 + i] + ta[i];
+              if (isA) {
+                const float pq = pk[15 + i] + tb[i];
+                vrs[i] = pa - pq;
+                vrel[i] = fmaf(dt, g_art[i], pa) - (dynb ? fmaf(dt, gb[i], pq) : pq);
+              } else {                       // (C): the box is fixed, the relative velocity is the articulation point's own
+                vrs[i] = pa;
+                vrel[i] = fmaf(dt, g_art[i], pa);
+              }
+            }
+            slot_eval(slot, phi, n, rc, vrs, vrel, 0.5f * (mu_shape + bd.friction), kc, beta, veps, vdep, dt, offset);
+          }
+        }
+      } else {
+        // (B) corner cn of box kd inside the articulation's box volume jb
+        const int q = p - nA - nC;
+        const int kd = q / (8 * nabox), cn = (q / nabox) % 8, jb = q % nabox;
+        const ShfBoxDesc& bd = S->box[kd];
+        const bool dynb = box_is_dynamic(bd);
+        body = m->abox_body[jb];
+        box = kd;
+        const float* pb = L.pose + body * POSE_STRIDE;
+        const float* pk = L.pose + (nb + kd) * POSE_STRIDE;
+        const float* qa = L.pose + m->dyn[body] * POSE_STRIDE;
+        float Rb[9], Rk[9], lr[9], ar[9], ac[3], r[3], tb[3];
+#pragma unroll
+        for (int i = 0; i < 9; i++) { Rb[i] = pb[i]; Rk[i] = pk[i]; lr[i] = m->abox_rot[jb][i]; }
+        const float lc[3] = {((cn & 4) ? 0.5f : -0.5f) * bd.dim[0], ((cn & 2) ? 0.5f : -0.5f) * bd.dim[1],
+                             ((cn & 1) ? 0.5f : -0.5f) * bd.dim[2]};
+        mv3(Rk, lc, r);
+#pragma unroll
+        for (int i = 0; i < 3; i++) r[i] += pk[9 + i];
+        const float vbx[3] = {pk[12], pk[13], pk[14]};
+        cross3(vbx, r, tb);
+        const float lp[3] = {m->abox_pos[jb][0], m->abox_pos[jb][1], m->abox_pos[jb][2]};
+        const float hh[3] = {m->abox_half[jb][0], m->abox_half[jb][1], m->abox_half[jb][2]};
+        mm3(Rb, lr, ar);
+        mv3(Rb, lp, ac);
+#pragma unroll
+        for (int i = 0; i < 3; i++) ac[i] += pb[9 + i];
+        float phi, n[3];
+        if (point_in_box(ar, ac, hh, r, &phi, n)) {
+          const float va[3] = {qa[12], qa[13], qa[14]};
+          float ta[3], nn[3], vrel[3], vrs[3];
+          cross3(va, r, ta);
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            const float pa = qa[15 + i] + ta[i], pq = pk[15 + i] + tb[i];
+            nn[i] = -n[i];
+            vrs[i] = pa - pq;
+            vrel[i] = fmaf(dt, g_art[i], pa) - (dynb ? fmaf(dt, gb[i], pq) : pq);
+          }
+          slot_eval(slot, phi, nn, r, vrs, vrel, 0.5f * (mu_shape + bd.friction), kc, beta, veps, vdep, dt, offset);
+        }
+      }
+    }
+    const bool on = slot[PT_ON] != 0.0f;
+    const unsigned long long mask = (__ballot(on) >> lane0) & gmask;
+    const int mine = count + __builtin_popcountll(mask & ((1ull << l) - 1ull));
+    if (on && mine < SHF_MAX_LINK_CONTACTS) {
+      float* o = L.pt + (slot0 + mine) * PT_STRIDE;
+#pragma unroll
+      for (int k = 0; k < PT_STRIDE - 1; k++) o[k] = slot[k];
+      o[PT_ON] = (float)link_code(body, box);
+    }
+    count += __builtin_popcountll(mask);
+  }
+  if (count > SHF_MAX_LINK_CONTACTS) {
+    if (l == 0 && C.dropped) *C.dropped += count - SHF_MAX_LINK_CONTACTS;
+    count = SHF_MAX_LINK_CONTACTS;
+  }
+  return count;
 }
 
 // Box lanes: pose / spatial velocity about O from the root-state rows, inertia of the free ones.
@@ -685,10 +832,11 @@ DEV void boxes_contacts_fixed(const StepCtx& C, const EnvLds& L, int l, BodyRegs
     if (sb) {
       float afree[6];
       ldlt_solve6(B.IA, B.pA, afree);
+      const float nshare = (float)__builtin_popcount(sb);
       while (sb) {
         const int si = __builtin_ctz(sb);
         sb &= sb - 1u;
-        pair_law(B.IA, afree, L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE);
+        pair_law(B.IA, afree, L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE, nshare);
       }
     }
   }
@@ -709,9 +857,10 @@ DEV void boxes_contacts_fixed(const StepCtx& C, const EnvLds& L, int l, BodyRegs
 }
 
 // Evaluate every box contact slot (one lane each), then fold them into the owning bodies.
-template <int G, class SC>
+template <int G, class SC, bool LINK = false>
 DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, float mu_shape, const float* g_art,
-                        const BoxLane& BL, BoxMasks& BM) {
+                        const BoxLane& BL, BoxMasks& BM, int link_slot0 = 0) {
+  static_assert(!(LINK && SC::NBX > 0), "link contacts run on the run-time-shaped scene path");
   if constexpr (SC::NBX > 0) { boxes_contacts_fixed<G, SC>(C, L, l, B, mu_shape, g_art, BL, BM); return; }
   const ShfModel* m = C.m;
   const SceneDev* S = C.scene;
@@ -785,6 +934,9 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
     }
     slot_eval(o, phi, n, rc, vrs, vrel, 0.5f * (mu_shape + bd.friction), kc, beta, veps, vdep, dt, offset);
   }
+  int nlink = 0;
+  if constexpr (LINK) nlink = link_contacts<G>(C, L, l, link_slot0, mu_shape, g_art);
+  BM.nlink = nlink;
   GROUP_SYNC();
   PHASE_MARK(18);
   // fold (as the fixed-scene path: box lanes first, with the pair laws; then the articulation's lanes)
@@ -797,13 +949,22 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
       cb &= cb - 1ull;
       slot_accumulate(B.IA, B.pA, L.pt + corner_slot(m, nbx, kd, j / BOX_T, j % BOX_T) * PT_STRIDE, 1.0f, dt, 1.0f);
     }
-    if (sb) {
+    unsigned lb = 0u;     // this box's link contacts (bit k = slot k)
+    for (int k = 0; k < nlink; k++)
+      if (link_code_box(L.pt[(link_slot0 + k) * PT_STRIDE + PT_ON]) == kd) lb |= 1u << k;
+    if (sb || lb) {
       float afree[6];
       ldlt_solve6(B.IA, B.pA, afree);
+      const float nshare = (float)(__builtin_popcount(sb) + __builtin_popcount(lb));
       while (sb) {
         const int si = __builtin_ctz(sb);
         sb &= sb - 1u;
-        pair_law(B.IA, afree, L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE);
+        pair_law(B.IA, afree, L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE, nshare);
+      }
+      while (lb) {
+        const int k = __builtin_ctz(lb);
+        lb &= lb - 1u;
+        pair_law(B.IA, afree, L.pt + (link_slot0 + k) * PT_STRIDE, dt, L.pt + (link_slot0 + SHF_MAX_LINK_CONTACTS + k) * PT_STRIDE, nshare);
       }
     }
   }
@@ -819,15 +980,43 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
       pair_unpack(L.pt + pair_slot(m, nbx, si, k2) * PT_STRIDE, F, K);
       pair_accumulate(B.IA, B.pA, r, F, K, dt);
     }
+    // ... then its link contacts, slot order: pair law against a free box, the plain contact law against a fixed one
+    for (int k = 0; k < nlink; k++) {
+      const float* o = L.pt + (link_slot0 + k) * PT_STRIDE;
+      if (m->dyn[link_code_body(o[PT_ON])] != l) continue;
+      if (box_is_dynamic(S->box[link_code_box(o[PT_ON])])) {
+        const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]};
+        float F[3], K[9];
+        pair_unpack(L.pt + (link_slot0 + SHF_MAX_LINK_CONTACTS + k) * PT_STRIDE, F, K);
+        pair_accumulate(B.IA, B.pA, r, F, K, dt);
+      } else {
+        slot_accumulate(B.IA, B.pA, o, 1.0f, dt, 1.0f);
+      }
+    }
   }
   PHASE_MARK(19);
 }
 
 // Solve the free boxes, report contact forces (boxes and the articulation's sphere contacts),
 // integrate the boxes.  contact_out has nb + nboxes rows.
+// force of link slot k on the articulation once its acceleration is known (oracle boxes_post: flink)
+DEV void link_force(const StepCtx& C, const EnvLds& L, int link_slot0, int k, float* f) {
+  const ShfModel* m = C.m;
+  const float* o = L.pt + (link_slot0 + k) * PT_STRIDE;
+  const float* ab = L.acc + m->dyn[link_code_body(o[PT_ON])] * 6;
+  const float abr[6] = {ab[0], ab[1], ab[2], ab[3], ab[4], ab[5]};
+  if (box_is_dynamic(C.scene->box[link_code_box(o[PT_ON])])) {
+    const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]};
+    pair_force(L.pt + (link_slot0 + SHF_MAX_LINK_CONTACTS + k) * PT_STRIDE, abr, r, C.sp.dt, f);
+  } else {
+    f[0] = f[1] = f[2] = 0.0f;
+    slot_force(o, abr, 1.0f, C.sp.dt, 1.0f, f);
+  }
+}
+
 template <int G, class SC>
 DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, float* contact_out, const BoxLane& BL,
-                      const BoxMasks& BM) {
+                      const BoxMasks& BM, int link_slot0 = 0) {
   const ShfModel* m = C.m;
   const SceneDev* S = C.scene;
   const int nb = m->nb, nbx = S->nboxes, T = 1 + nbx;
@@ -853,6 +1042,16 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
 #pragma unroll
       for (int k = 0; k < 3; k++) { B.pA[k] += t[k]; B.pA[3 + k] += f[k]; }
     }
+    for (int k = 0; k < BM.nlink; k++) {
+      const float* o = L.pt + (link_slot0 + k) * PT_STRIDE;
+      if (link_code_box(o[PT_ON]) != kd) continue;
+      const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]};
+      float f[3], t[3];
+      link_force(C, L, link_slot0, k, f);
+      cross3(r, f, t);
+#pragma unroll
+      for (int i = 0; i < 3; i++) { B.pA[i] += t[i]; B.pA[3 + i] += f[i]; }
+    }
     ldlt_solve6(B.IA, B.pA, a);
   }
   if (contact_out) {
@@ -877,6 +1076,13 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
         pair_force(L.pt + pair_slot(m, nbx, si, k2) * PT_STRIDE, abr, r, dt, fp);
 #pragma unroll
         for (int k = 0; k < 3; k++) f[k] += fp[k];
+      }
+      for (int k = 0; k < BM.nlink; k++) {
+        if (link_code_body(L.pt[(link_slot0 + k) * PT_STRIDE + PT_ON]) != l) continue;
+        float fp[3];
+        link_force(C, L, link_slot0, k, fp);
+#pragma unroll
+        for (int i = 0; i < 3; i++) f[i] += fp[i];
       }
       contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];
     }
@@ -904,6 +1110,13 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
           pair_force(L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE, abr, r, dt, fp);
 #pragma unroll
           for (int k = 0; k < 3; k++) f[k] -= fp[k];
+        }
+        for (int k = 0; k < BM.nlink; k++) {
+          if (link_code_box(L.pt[(link_slot0 + k) * PT_STRIDE + PT_ON]) != kd) continue;
+          float fp[3];
+          link_force(C, L, link_slot0, k, fp);
+#pragma unroll
+          for (int i = 0; i < 3; i++) f[i] -= fp[i];
         }
       }
       contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];

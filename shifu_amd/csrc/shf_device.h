@@ -659,6 +659,7 @@ struct StepCtx {
   ShfSimParams sp;
   TerrainDev terr;
   const SceneDev* scene;  // LDS copy, may be null when the scene has no boxes
+  int32_t* dropped = nullptr;   // this env's word of SHF_T_DROPPED (contacts beyond the per-env limits), may be null
 };
 
 // solve IA x = -pA for a symmetric positive definite 6x6 in packed storage (LDL^T)
@@ -870,7 +871,7 @@ DEV void contact_force_final(float* o, const float* ab, float dt) {
 //   contact_out: LDS/global float[nb*3] written by body lanes (may be nullptr)
 #define LANE_ROUNDS(G, DM) ((DM::NPC + (G) - 1) / (G) > 0 ? (DM::NPC + (G) - 1) / (G) : 1)
 template <int G, bool BOX = false, class DM = DynDims, bool TW = false, class LM = LaneModel, class SC = DynScene,
-          bool SELF = false>
+          bool SELF = false, bool LINK = false>
 DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const LanePoints<LANE_ROUNDS(G, DM)>& P,
                  const float* pos_tgt, const float* vel_tgt, const float* fext, float mu_shape, float* contact_out,
                  const BoxLane& BL = BoxLane()) {
@@ -1004,7 +1005,8 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
   const int self_slot0 = np + (BOX ? box_slot_count(C.scene->nboxes, m->nsph) : 0);
   if constexpr (SELF) nself = self_contacts<G>(C, L, l, isdyn, self_slot0, B, mu_shape);
   BoxMasks BM;
-  if (BOX) boxes_contacts<G, SC>(C, L, l, B, mu_shape, g, BL, BM);
+  const int link_slot0 = self_slot0 + (SELF ? SHF_MAX_SELF_CONTACTS : 0);   // 2 x SHF_MAX_LINK_CONTACTS slots when LINK
+  if (BOX) boxes_contacts<G, SC, LINK && BOX>(C, L, l, B, mu_shape, g, BL, BM, link_slot0);
   PHASE_MARK(4);
 
   // joint-space efforts: one lane per dof
@@ -1206,7 +1208,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
   }
   if (BOX) {
     GROUP_SYNC();
-    boxes_finish<G, SC>(C, L, l, B, contact_out, BL, BM);
+    boxes_finish<G, SC>(C, L, l, B, contact_out, BL, BM, link_slot0);
   }
 
   PHASE_MARK(9);

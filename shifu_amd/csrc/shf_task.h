@@ -22,6 +22,7 @@ struct SimArgs {
   const float* body_force;  // nullptr unless armed
   const float* friction;
   float* contact;  // (n*B,3)
+  int32_t* dropped;  // (n) contacts dropped at the per-env limits, accumulated (SHF_T_DROPPED), may be null
 };
 
 // Cooperative global -> LDS copy of a fixed-size parameter block by the 256 threads of a block: all loads

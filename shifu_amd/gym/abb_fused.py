@@ -15,13 +15,20 @@ REWARD_NAMES = ["reward_reaching", "reward_success"]   # build_reward_functions 
 
 class FusedAbbEnv:
     def __init__(self, num_envs: int = 4096, device="cuda:0", seed: int = 42, rank: int = 0, world_size: int = 1,
-                 group: int = 16, dt: float = 0.02, decimation: int = 5, episode_length_s: float = 20.0,
-                 extra_boxes=()):
+                 group: int = None, dt: float = 0.02, decimation: int = 5, episode_length_s: float = 20.0,
+                 extra_boxes=(), link_contacts: bool = False):
         self.device = torch.device(device)
         self.num_envs = num_envs
         self.env_id_offset = rank * num_envs
         self.dt = dt * decimation                                         # isaac_gym.py:26
-        self.cm = abb_model()
+        # link_contacts: the arm's links (box stand-ins for their mesh colliders) and the rod also collide with the table,
+        # the cube and the goal pad (ShfModel.link_collide) -- what `AbbPushBox` through the gym facade
+        # does; off here by default: BASELINE config 5's arm collider is the rod against the cube
+        self.cm = abb_model(link_contacts=link_contacts)
+        if group is None:
+            # 16 lanes per env is the fastest for the plain scene; with link contacts the 59 sample points and the link
+            # slots need 12.5 KB of LDS per env: eight envs per block (32 lanes each), not sixteen
+            group = 32 if link_contacts else 16
         self.sim_params = default_sim_params(dt=dt)
         self.sim = Sim(self.sim_params, self.device)
         self.sim.set_plane(1.0)
@@ -50,7 +57,9 @@ class FusedAbbEnv:
         self.episode_rewards = {n: T[_abi.ABB_REW_SUMS][k] for k, n in enumerate(REWARD_NAMES)}
         self.dof_state, self.root_state = S[_abi.T_DOF_STATE], S[_abi.T_ROOT_STATE]
         self.body_state, self.contact_state, self.jacobian = S[_abi.T_BODY_STATE], S[_abi.T_CONTACT], S[_abi.T_JACOBIAN]
-        self.extras = {}
+        # contacts dropped at the per-env limits since the tensor was last cleared (link contacts beyond
+        # SHF_MAX_LINK_CONTACTS); the live device tensor, (N,) int32
+        self.extras = {"dropped_contacts": S[_abi.T_DROPPED]}
         self.reward_names = REWARD_NAMES
         # spawn poses + the tensors Isaac Gym would show after create_actor/prepare_sim
         A = 1 + len(self.boxes)

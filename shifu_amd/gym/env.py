@@ -108,12 +108,12 @@ class ShifuVecEnv:
             self.extras["time_outs"] = self.time_out_buf
 
     def log_info(self, env_ids):
-        if self.rew_buf.is_cuda and torch.is_tensor(env_ids) and env_ids.is_cuda and env_ids.dtype == torch.int64 \
-                and len(self.episode_rewards) <= 16:
+        if torch.is_tensor(env_ids) and env_ids.is_cuda and env_ids.dtype == torch.int64 and 0 < len(self.episode_rewards) <= 16 \
+                and all(v.is_cuda for v in self.episode_rewards.values()):
             # the loop below as one launch (csrc/shf_glue.hip: shf_episode_log; exact fixed-point sums)
             from shifu_amd import glue
             if getattr(self, "_episode_log", None) is None:
-                self._episode_log = glue.EpisodeLog(self.rew_buf.device)
+                self._episode_log = glue.EpisodeLog(env_ids.device)
             keys = list(self.episode_rewards.keys())
             means = self._episode_log([self.episode_rewards[k] for k in keys], env_ids, self.max_episode_length_s)
             for i, key in enumerate(keys):
@@ -135,7 +135,7 @@ class ShifuVecEnv:
                                 for f in self.reward_functions}
 
     def compute_reward(self):
-        if self.rew_buf.is_cuda and len(self.reward_functions) <= 16:
+        if getattr(self, "rew_buf", None) is not None and self.rew_buf.is_cuda and len(self.reward_functions) <= 16:
             from shifu_amd import glue
             terms = [f() for f in self.reward_functions]                 # the user's hooks, untouched
             terms = [r if (r.dtype == torch.float32 and r.is_contiguous() and r.shape == self.rew_buf.shape)

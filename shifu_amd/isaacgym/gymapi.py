@@ -316,11 +316,16 @@ class Gym:
         # <mesh> colliders become convex hulls where the files are present (they do not ship with this repo: the vendored
         # URDFs are the physics-only reductions); against box actors only rounded shapes are tested, so the ABB rod gets its
         # documented capsule either way
-        extra = ()
+        extra, boxes = (), ()
         if os.path.basename(path) in ("abb_rod.urdf", "abb_rod_isaac.urdf"):
-            from ..abb_task import ROD_CAPSULE
+            from ..abb_task import ROD_CAPSULE, abb_link_boxes
             extra = ROD_CAPSULE
-        model = compile_urdf(path, extra_spheres=extra, fix_base_link=bool(options.fix_base_link),
+            # box stand-ins for the links' mesh colliders (their files do not ship): only when the URDF brought no hulls
+            boxes = abb_link_boxes() if os.path.basename(path) == "abb_rod.urdf" else ()
+        # every shape of an env collides with every other actor's (create_actor(..., group = env, filter = 0),
+        # units.py:68): link contacts on (ShfModel.link_collide; a scene without box actors never looks at it)
+        model = compile_urdf(path, extra_spheres=extra, extra_boxes=boxes, link_contacts=True,
+                             fix_base_link=bool(options.fix_base_link),
                              disable_gravity=bool(options.disable_gravity),
                              collapse_fixed_joints=bool(options.collapse_fixed_joints),
                              default_dof_drive_mode=int(options.default_dof_drive_mode),

@@ -432,7 +432,8 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
                  collapse_fixed_joints: bool = True, default_dof_drive_mode: int = _abi.DOF_MODE_NONE,
                  armature: float = 0.0, honour_dont_collapse: bool = True,
                  extra_spheres: Sequence[tuple] = (), density: float = 1000.0,
-                 self_collision: bool = False, meshes: str = "error") -> CompiledModel:
+                 self_collision: bool = False, meshes: str = "error", link_contacts: bool = False,
+                 extra_boxes: Sequence[tuple] = ()) -> CompiledModel:
     """Compile `path` with the AssetOptions the reference passes (asset_config.py:32-46).
 
     meshes: <mesh> collision geometry becomes the convex hull of the STL file ("error": a missing file is refused;
@@ -441,8 +442,18 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
     as ground-contact sample points, its uniform-density mass properties when the link has no <inertial>, and one
     self-collision capsule along its longest principal axis.
     extra_spheres: rounded collision shapes tested against box actors -- the substitute for mesh colliders (ABB rod):
-    (link name, xyz in that link's frame, radius) spheres, or (link name, xyz_a, xyz_b, radius) capsules."""
+    (link name, xyz in that link's frame, radius) spheres, or (link name, xyz_a, xyz_b, radius) capsules.
+    extra_boxes: (link name, xyz, rpy, size) box collision shapes added to links before compilation -- the box-shaped
+    stand-ins for mesh colliders whose files do not ship (shifu_amd/assets/abb_link_boxes.json: the bounding boxes of the
+    reference's ABB link hulls).
+    link_contacts: ShfModel.link_collide -- every collision shape of the articulation also meets the box actors of its env
+    (SURVEY 8f f3): sample points against boxes, box corners against the articulation's box volumes (abox_*: the <box>
+    primitives and, for hulls, their bounding boxes in the shape frame)."""
     links, joints = parse_urdf(path, meshes=meshes)
+    for (lname, xyz, rpy, size) in extra_boxes:
+        if lname not in links:
+            raise ValueError(f"extra_boxes: no link '{lname}'")
+        links[lname].shapes.append(_Shape("box", np.asarray(size, float), np.asarray(xyz, float), _rpy(*rpy)))
     _fill_missing_inertials(links, density)
     children: Dict[str, List[_Joint]] = {n: [] for n in links}
     is_child = set()
@@ -463,6 +474,7 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
     inert: List[_Inertial] = []  # own (collapsed-in) inertia, body frame
     points: List[Tuple[int, np.ndarray, float]] = []
     capsules: List[Tuple[int, np.ndarray, np.ndarray, float]] = []
+    aboxes: List[Tuple[int, np.ndarray, np.ndarray, np.ndarray]] = []   # (body, centre, rot, half extents) in the body frame
     link_frame: Dict[str, Tuple[int, np.ndarray, np.ndarray]] = {}  # urdf link -> (body, p, R) in body frame
 
     def absorb(body: int, link: _Link, p: np.ndarray, R: np.ndarray):
@@ -473,6 +485,11 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
                 points.append((body, p + R @ q, rad))
             for ca, cb, rad in _shape_capsules(s):
                 capsules.append((body, p + R @ ca, p + R @ cb, rad))
+            if s.kind == "box":
+                aboxes.append((body, p + R @ s.pos, R @ s.rot, 0.5 * np.asarray(s.size, float)))
+            elif s.kind == "hull":
+                lo, hi = s.verts.min(0), s.verts.max(0)
+                aboxes.append((body, p + R @ (s.pos + s.rot @ (0.5 * (lo + hi))), R @ s.rot, 0.5 * (hi - lo)))
 
     def visit(link_name: str, body: int, p: np.ndarray, R: np.ndarray):
         """link_name's frame sits at (p, R) inside reported body `body`."""
@@ -632,6 +649,21 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
         for kk in range(3):
             m.sph_pos[i][kk] = q[kk]
             m.sph_seg[i][kk] = seg[kk]
+
+    # link contacts: the articulation's box volumes (vertex-in-box against the corners of box actors)
+    m.link_collide = int(bool(link_contacts))
+    if len(aboxes) > _abi.MAX_ABOX:
+        if link_contacts:
+            raise AssertionError(f"{len(aboxes)} box volumes > SHF_MAX_ABOX")
+        aboxes = []
+    m.nabox = len(aboxes)
+    for j, (b, c, Rb, hh) in enumerate(aboxes):
+        m.abox_body[j] = b
+        for kk in range(3):
+            m.abox_pos[j][kk] = c[kk]
+            m.abox_half[j][kk] = hh[kk]
+        for kk in range(9):
+            m.abox_rot[j][kk] = Rb[kk // 3, kk % 3]
 
     # self-collision: capsules of every shape, and the pairs to test -- all but capsules of one rigid body (same moving
     # body: welded links included) and of moving bodies joined by a joint ([EXT] PhysX filters those the same way)

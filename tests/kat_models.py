@@ -70,3 +70,22 @@ def pusher_model(yaw=0.0, z=0.05, half=0.1, r=0.02, kd=2000.0):
                   extra_spheres=[("pusher", a, b, r)])
     cm.blob.kd[0] = kd
     return cm
+
+
+BOX_PUSHER_URDF = """<robot name="boxpusher"><link name="rail"/>
+ <link name="ram"><inertial><mass value="5.0"/><inertia ixx="0.05" ixy="0" ixz="0" iyy="0.05" iyz="0" izz="0.05"/></inertial>
+  {shapes}</link>
+ <joint name="slide" type="prismatic"><parent link="rail"/><child link="ram"/><axis xyz="{axis}"/>
+  <limit effort="200" lower="-1" upper="1" velocity="10"/></joint></robot>"""
+
+
+def box_pusher_model(size=(0.06, 0.06, 0.06), centre=(0.0, 0.0, 0.05), axis="1 0 0", kd=2000.0, extra_shapes="", capsule=None):
+    """A rail-mounted ram carrying box collision shape(s) (link contacts on: ShfModel.link_collide) -- the box-vs-box
+    cases of SURVEY 8f f3 in their simplest setting.  Velocity drive on the slide."""
+    shapes = ('<collision><origin xyz="%g %g %g"/><geometry><box size="%g %g %g"/></geometry></collision>'
+              % (tuple(centre) + tuple(size))) if size is not None else ""
+    cm = _compile(BOX_PUSHER_URDF.format(shapes=shapes + extra_shapes, axis=axis), fix_base_link=True, disable_gravity=True,
+                  default_dof_drive_mode=_abi.DOF_MODE_VEL, link_contacts=True,
+                  extra_spheres=[("ram",) + tuple(capsule)] if capsule else ())
+    cm.blob.kd[0] = kd
+    return cm

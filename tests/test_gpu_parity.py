@@ -361,6 +361,118 @@ def test_abb_scene_matches_oracle_bitwise(oracle, group):
     assert (cube[:, 2] > 0.12).mean() >= 0.9 and (cube[:, 2] > 0.10).all(), cube[:, 2]
 
 
+def _scene_on_gpu(cm, sp, boxes, roots, n, group):
+    from shifu_amd.backend import Sim
+    m = cm.blob
+    A = 1 + len(boxes)
+    dof = np.zeros((n * m.nd, 2), np.float32)
+    root = np.zeros((n * A, 13), np.float32)
+    root[:, 6] = 1.0
+    for k, p in enumerate(roots):
+        root[1 + k::A, :3] = p
+    sim = Sim(sp, "cuda:0")
+    sim.set_plane(1.0)
+    sim.set_articulation(m)
+    for b in boxes:
+        sim.add_box(b)
+    sim.finalize(n, 0, group=group)
+    sim.tensors[_abi.T_SIM_DOF].copy_(torch.from_numpy(dof))
+    sim.tensors[_abi.T_SIM_ROOT].copy_(torch.from_numpy(root))
+    return sim, dof, root
+
+
+@pytest.mark.parametrize("group", [16, 64])
+def test_link_contacts_match_oracle_bitwise(oracle, group):
+    """SURVEY 8f f3 (ShfModel.link_collide): link box corners against a free cube (pair law, several slots on one box) and
+    against a fixed table, cube corners inside a link's box volume, a capsule against the fixed table, more contacts than
+    slots (dropped and counted per env) -- the scenes of tests/test_link_contacts.py through shf_sim_step, every tensor
+    against the oracle bit for bit, per-env perturbed so that the envs of a wavefront differ."""
+    _need_gpu()
+    from shifu_amd.abb_task import box_desc
+    from tests import kat_models as K
+    sp = H.sim_params(angular_damping=0.5)
+    more = "".join('<collision><origin xyz="%g 0 0.5"/><geometry><box size="0.04 0.04 0.04"/></geometry></collision>' % x for x in (0.1, -0.1))
+    scenes = [
+        ("ram pushes cube", K.box_pusher_model(), [box_desc((0.1, 0.1, 0.1), 0.5, 0.6, False, (0.2, 0.0, 0.05))], [(0.2, 0.0, 0.0499)], 0.4, 160),
+        ("ram on table", K.box_pusher_model(centre=(0.0, 0.0, 0.5), axis="0 0 -1"), [box_desc((0.6, 0.6, 0.1), 0.0, 0.5, True, (0.0, 0.0, 0.3))], [(0.0, 0.0, 0.3)], 0.5, 120),
+        ("cube on anvil", K.box_pusher_model(size=(0.3, 0.3, 0.1), centre=(0.0, 0.0, 0.05)), [box_desc((0.05, 0.05, 0.05), 0.2, 0.6, False, (0.0, 0.0, 0.125))], [(0.02, 0.01, 0.1249)], 0.05, 120),
+        ("capsule on table", K.box_pusher_model(size=None, axis="0 0 -1", capsule=((0.0, 0.0, 0.5), (0.0, 0.0, 0.4), 0.02)), [box_desc((0.6, 0.6, 0.1), 0.0, 0.5, True, (0.0, 0.0, 0.2))], [(0.0, 0.0, 0.2)], 0.5, 120),
+        ("24 corners in a box", K.box_pusher_model(size=(0.04, 0.04, 0.04), centre=(0.0, 0.0, 0.5), extra_shapes=more), [box_desc((1.0, 1.0, 0.2), 0.0, 0.5, True, (0.0, 0.0, 0.43))], [(0.0, 0.0, 0.43)], 0.0, 6),
+    ]
+    rng = np.random.default_rng(3)
+    for name, cm, boxes, roots, v, steps in scenes:
+        n = 9
+        m = cm.blob
+        assert m.link_collide == 1
+        sim, dof, root = _scene_on_gpu(cm, sp, boxes, roots, n, group)
+        A = 1 + len(boxes)
+        # the envs of a wavefront must differ: shift the free boxes a little, vary the drive speed
+        root[1::A, 0] += rng.uniform(-0.004, 0.004, n).astype(np.float32)
+        vt = (v * rng.uniform(0.6, 1.0, n * m.nd)).astype(np.float32)
+        sim.tensors[_abi.T_SIM_ROOT].copy_(torch.from_numpy(root))
+        oracle.dropped(reset=True)
+        sim.tensors[_abi.T_DROPPED].zero_()
+        seen = False
+        for it in range(steps):
+            sim.set_dof_command(_abi.T_VEL_TARGET, torch.from_numpy(vt).cuda())
+            sim.step()
+            sim.refresh(_abi.REFRESH_ALL)
+            contact, bstate, _ = oracle.scene_step(m, sp, boxes, n, dof, root, vel_target=vt, friction=np.ones(n, np.float32))
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(sim.tensors[_abi.T_DOF_STATE].cpu().numpy(), dof, err_msg=f"{name}: dof step {it}")
+            np.testing.assert_array_equal(sim.tensors[_abi.T_ROOT_STATE].cpu().numpy(), root, err_msg=f"{name}: root step {it}")
+            np.testing.assert_array_equal(sim.tensors[_abi.T_CONTACT].cpu().numpy(), contact, err_msg=f"{name}: contact step {it}")
+            seen |= bool(np.abs(contact.reshape(n, -1, 3)[:, m.nb - 1]).sum() > 0)
+        assert seen, f"{name}: the link never touched"
+        assert int(sim.tensors[_abi.T_DROPPED].sum()) == oracle.dropped(reset=True), name
+        if name.startswith("24"):
+            assert (sim.tensors[_abi.T_DROPPED].cpu().numpy() == steps * 8).all()
+        sim.destroy() if hasattr(sim, "destroy") else None
+
+
+def test_abb_scene_with_link_contacts_matches_oracle_bitwise(oracle):
+    """The config-5 scene with the arm's links (box stand-ins for their mesh colliders, shifu_amd/assets/
+    abb_link_boxes.json) and the rod colliding with table, cube and goal pad: the blind joint ramp that drove every rod
+    tip through the table top in the plain scene is now stopped by it, bit for bit as the oracle says."""
+    _need_gpu()
+    from shifu_amd.abb_task import ABB_BASE_POS, ABB_DEFAULT_DOF_POS, abb_boxes, abb_model
+    rng = np.random.default_rng(17)
+    cm = abb_model(link_contacts=True)
+    m = cm.blob
+    assert m.link_collide == 1 and m.nabox == 7 and m.np == 59
+    sp = H.sim_params(dt=0.02, angular_damping=0.5)
+    boxes = abb_boxes()
+    n, A, B = 24, 4, m.nb + 3
+    sim, dof, root = _scene_on_gpu(cm, sp, boxes, [b.pos for b in boxes], n, 32)
+    dof[:, 0] = np.tile(np.array(ABB_DEFAULT_DOF_POS, np.float32), n) + rng.uniform(-0.05, 0.05, n * m.nd)
+    root[0::A, :3] = ABB_BASE_POS
+    root[2::A, :3] = np.stack([rng.uniform(0.03, 0.08, n), rng.uniform(-0.03, 0.03, n), rng.uniform(0.125, 0.14, n)], 1)
+    sim.tensors[_abi.T_SIM_DOF].copy_(torch.from_numpy(dof))
+    sim.tensors[_abi.T_SIM_ROOT].copy_(torch.from_numpy(root))
+    fr = np.ones(n, np.float32)
+    tgt = dof[:, 0].copy()
+    table_touch = False
+    for it in range(90):
+        if it % 6 == 0:
+            tgt = dof[:, 0].copy()
+            tgt[1::m.nd] += 0.02
+            tgt[2::m.nd] -= 0.01
+        sim.set_dof_command(_abi.T_POS_TARGET, torch.from_numpy(tgt).cuda())
+        sim.step()
+        sim.refresh(_abi.REFRESH_ALL)
+        contact, bstate, jac = oracle.scene_step(m, sp, boxes, n, dof, root, pos_target=tgt, friction=fr, want_jacobian=True)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(sim.tensors[_abi.T_DOF_STATE].cpu().numpy(), dof, err_msg=f"dof step {it}")
+        np.testing.assert_array_equal(sim.tensors[_abi.T_ROOT_STATE].cpu().numpy(), root, err_msg=f"root step {it}")
+        np.testing.assert_array_equal(sim.tensors[_abi.T_CONTACT].cpu().numpy(), contact, err_msg=f"contact step {it}")
+        np.testing.assert_array_equal(sim.tensors[_abi.T_BODY_STATE].cpu().numpy(), bstate, err_msg=f"body step {it}")
+        table_touch |= bool((contact.reshape(n, B, 3)[:, :m.nb, 2] > 1.0).any())
+    assert table_touch, "the ramp must have pressed the arm onto the table"
+    tip = bstate.reshape(n, B, 13)[:, m.nb - 1, 2]
+    assert (tip > 0.1 - 0.02).all(), f"rod tips stay above the table top (z = 0.1): {tip.min()}"
+    assert np.isfinite(root).all() and np.isfinite(dof).all()
+
+
 _ABB_SIM_T = {"dof_state": _abi.T_DOF_STATE, "root_state": _abi.T_ROOT_STATE, "body_state": _abi.T_BODY_STATE,
               "contact": _abi.T_CONTACT, "jacobian": _abi.T_JACOBIAN, "friction": _abi.T_FRICTION}
 _ABB_T = {"actions": _abi.ABB_ACTIONS, "obs": _abi.ABB_OBS, "rew": _abi.ABB_REW, "reset": _abi.ABB_RESET,
@@ -369,7 +481,7 @@ _ABB_T = {"actions": _abi.ABB_ACTIONS, "obs": _abi.ABB_OBS, "rew": _abi.ABB_REW,
           "done_sums": _abi.ABB_DONE_SUMS}
 
 
-@pytest.mark.parametrize("group,generic", [(64, False), (32, False), (16, False), (32, True), (64, True)])
+@pytest.mark.parametrize("group,generic", [(64, False), (32, False), (16, False), (32, True), (64, True), (32, "link"), (64, "link")])
 def test_fused_abb_step_matches_oracle_bitwise(oracle, group, generic):
     """ShifuVecEnv.step for AbbPushBox (config 5): in-kernel damped-least-squares IK on the Jacobian
     tensor, 6 sub-steps with implicit POS drives and box contacts, refresh, termination, rewards,
@@ -380,9 +492,12 @@ def test_fused_abb_step_matches_oracle_bitwise(oracle, group, generic):
     # generic: a fourth (fixed, out of reach) box makes the scene differ from the compile-time ABB scene, so the step
     # runs on k_abb_step<G, DynDims, DynScene> (LDS flags) instead of <G, AbbDims, AbbScene> (ballots): same results
     from shifu_amd.abb_task import box_desc
-    extra = [box_desc([0.05, 0.05, 0.02], 0.0, 0.5, True, [0.25, 0.25, 0.11])] if generic else []
-    env = FusedAbbEnv(num_envs=n, seed=11, group=group, extra_boxes=extra)
-    assert ("FixedDims" in env.task.kernel_symbol()) != generic
+    # "link": the arm's links and rod also collide with table / cube / goal pad (ShfModel.link_collide): the run-time-shaped
+    # kernel with the link-contact pass
+    link = generic == "link"
+    extra = [box_desc([0.05, 0.05, 0.02], 0.0, 0.5, True, [0.25, 0.25, 0.11])] if (generic and not link) else []
+    env = FusedAbbEnv(num_envs=n, seed=11, group=group, extra_boxes=extra, link_contacts=link)
+    assert ("FixedDims" in env.task.kernel_symbol()) != bool(generic)
     env.task.tensors[_abi.ABB_EP_LEN].copy_(torch.randint(0, 200, (n,)))   # staggered time-outs
     torch.cuda.synchronize()
     bufs = {k: env.sim.tensors[t].cpu().numpy().copy() for k, t in _ABB_SIM_T.items()}
