@@ -280,12 +280,12 @@ def main():
     from shifu_amd.parallel import gather_episode_stats
 
     abb = args.workload == "abb"
-    mapping = "body" if abb else (args.mapping or "body")
+    mapping = args.mapping or ("chain" if (abb and not args.link_contacts and (args.group or 16) < 64) else "body")
     group = args.group or ((32 if args.link_contacts else 16) if (abb or mapping == "chain") else 32)
     if abb:
         from shifu_amd.gym.abb_fused import FusedAbbEnv
         env = FusedAbbEnv(num_envs=args.envs, device=dev, seed=42, rank=rank, world_size=world, group=group,
-                          link_contacts=args.link_contacts)
+                          link_contacts=args.link_contacts, mapping=mapping)
         stats_t, count_t, kernel = _abi.ABB_STATS, _abi.ABB_RESET_COUNT, "k_abb_step"
         substeps = 6
     else:

@@ -276,11 +276,13 @@ int shf_sim_reset_all(ShfSim* sim, const float* default_root_dev /* (A,13) */, c
 /* Lanes per env for the kernels (64 = one wavefront per env, default; 32/16 pack
  * 2/4 envs per wavefront).  Not part of the reference API: a tuning knob. */
 int shf_sim_set_group(ShfSim* sim, int32_t lanes);
-/* Lane mapping of the fused A1 step (shf_a1_step).  SHF_MAP_BODY: lane = reported body, the tree is walked level by
- * level through LDS hand-offs (any articulation).  SHF_MAP_CHAIN: lane = kinematic chain, its links' state in
- * registers (csrc/shf_chain.h); only for a floating root with serial revolute chains that end in one welded body --
- * the Unitree A1 -- without self-collision; 16 or 32 lanes per env (call before shf_sim_set_group).  Same results bit
- * for bit either way.  Not part of the reference API: a tuning knob.  Fails if the articulation has another shape. */
+/* Lane mapping of the fused task steps (shf_a1_step, shf_abb_step).  SHF_MAP_BODY: lane = reported body, the tree is
+ * walked level by level through LDS hand-offs (any articulation).  SHF_MAP_CHAIN: lane = kinematic chain, the tree's
+ * recursions run link after link on the chain's lane.  Two shapes are compiled: a floating root with 4 serial chains of
+ * 3 revolute links that end in one welded body -- the Unitree A1, single actor (csrc/shf_chain.h; call before
+ * shf_sim_set_group) -- and a fixed base with one chain of 6 revolute links -- the ABB arm in its table / cube / pad
+ * scene (csrc/shf_arm.h; shf_abb_step checks the scene).  No self-collision or link contacts; 16 or 32 lanes per env.
+ * Same results bit for bit either way.  Not part of the reference API: a tuning knob.  Fails for another shape. */
 enum { SHF_MAP_BODY = 0, SHF_MAP_CHAIN = 1 };
 int shf_sim_set_mapping(ShfSim* sim, int32_t mapping);
 

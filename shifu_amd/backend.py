@@ -144,8 +144,9 @@ class Sim:
         check(lib().shf_sim_bind(self._h, tid, C.c_void_p(t.data_ptr())))
 
     def finalize(self, num_envs: int, env_id_offset: int = 0, group: int = 64, mapping: str = "body"):
-        """group: lanes per env; mapping: 'body' (lane = rigid body, any articulation) or 'chain' (lane = kinematic chain,
-        A1-shaped trees only, 16 or 32 lanes; csrc/shf_chain.h) -- kernel selection, identical results."""
+        """group: lanes per env; mapping: 'body' (lane = rigid body, any articulation) or 'chain' (lane = kinematic chain:
+        the A1's tree, csrc/shf_chain.h, or the ABB's serial arm, csrc/shf_arm.h; 16 or 32 lanes) -- kernel selection,
+        identical results."""
         self.num_envs = num_envs
         self.group = group
         self.mapping = mapping
@@ -363,8 +364,14 @@ class AbbTask:
         return idx % (self.tensors[_abi.ABB_STATS].shape[0] - 1)
 
     def kernel_symbol(self) -> str:
-        fixed = self.sim.model.nb == 7 and self.sim.model.np == 3 and self.sim.nboxes == 3
-        return f"_Z10k_abb_stepILi{self.sim.group}E" + ("9FixedDims" if fixed else "7DynDims")
+        """Mangled-name prefix of the instantiation shf_abb_step launches for this sim (build resource table)."""
+        mdl = self.sim.model
+        fixed = mdl.nb == 7 and mdl.np == 3 and self.sim.nboxes == 3 and not (mdl.link_collide and self.sim.nboxes > 0)
+        pre = f"_Z10k_abb_stepILi{self.sim.group}E"
+        if not fixed:
+            return pre + "7DynDims"
+        arm = 6 if getattr(self.sim, "mapping", "body") == "chain" else 0
+        return pre + f"9FixedDimsILi7ELi6ELi3ELi6ELi6EE10FixedSceneILi3ELi1ELi1EELb0ELi{arm}EE"
 
     @_on_device
     def reset_all(self):

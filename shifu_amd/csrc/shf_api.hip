@@ -15,6 +15,7 @@
 
 #include "shf_device.h"
 #include "shf_task.h"
+#include "shf_arm.h"
 
 // ------------------------------------------------------------ host state --
 static thread_local std::string g_err;
@@ -415,9 +416,15 @@ DEV void abb_reset_env(const ShfAbbTaskParams& tp, int nd, int nbx, int64_t gid,
 
 // DM / SC: run-time model and scene (any arm, any boxes), or the shipped ABB scene fixed at compile time (ancestor-walk
 // kinematics, compile-time level loops, ballot-driven box folds) -- the host picks the latter only when both match.
-template <int G, class DM, class SC, bool LINK = false>
+// ARM: number of links when the articulation is a fixed-base serial chain (ArmChain<ARM>::matches) in a compile-time
+// scene -- its recursions then run on one lane (shf_arm.h); 0: the body-per-lane sub-step.
+// LDS tail of an env: POS targets, this step's ee position, the arm's per-link records.
+#define SHF_ARM_MAX_LINKS 8
+#define ABB_TAIL_WORDS(nslots) ((nslots) * PT_STRIDE + SHF_MAX_DOFS + ARM_KREC_WORDS(SHF_ARM_MAX_LINKS))
+template <int G, class DM, class SC, bool LINK = false, int ARM = 0>
 __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  PHASE_BEGIN();
   float* stats_lds = smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS;
   stats_block_init(stats_lds);
   const unsigned long long stats_step = stats_step_load(A.stats);
@@ -436,9 +443,10 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
   const int nbx = SC::NBX > 0 ? SC::NBX : A.S.nboxes, actors = 1 + nbx;
   const int nb = DM::nb(m), nd = DM::nd(m), nbt = nb + nbx;
   const int nslots = DM::np(m) + box_slot_count(nbx, m->nsph) + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0);
-  const int env_words = env_lds_words(nbt, nd, nslots, nslots * PT_STRIDE + SHF_MAX_DOFS, actors);
+  const int env_words = env_lds_words(nbt, nd, nslots, ABB_TAIL_WORDS(nslots), actors);
   EnvLds L = env_lds_carve(smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS + es * env_words, nbt, nd, nslots, actors);
   float* tgtl = L.pt + nslots * PT_STRIDE;  // POS targets of this env step
+  float* krec = tgtl + SHF_MAX_DOFS;
 
   float* dof = A.S.dof + (size_t)e * nd * 2;
   float* root = A.S.root + (size_t)e * actors * 13;
@@ -492,6 +500,7 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
     }
   }
   GROUP_SYNC();
+  PHASE_MARK(11);
 
   StepCtx C;
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = scene;
@@ -504,12 +513,18 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
   if constexpr (DM::NPC > 0) lane_points_load<G>(m, DM::np(m), l, P);
   const BoxLane BL = SC::NBX > 0 ? box_lane_load(m, l) : BoxLane();
   // net contact forces are reported for the last sub-step only (what the refreshed tensor shows)
-  for (int it = 0; it < nsub; it++)
-    substep<G, true, DM, false, LaneModel, SC, false, LINK>(C, L, l, M, P, tgtl, nullptr, nullptr, mu, it == nsub - 1 ? L.xch : nullptr, BL);
+  for (int it = 0; it < nsub; it++) {
+    if constexpr (ARM > 0)
+      arm_substep<G, DM, SC, ARM>(C, L, krec, l, M, P, tgtl, mu, it == nsub - 1 ? L.xch : nullptr, BL);
+    else
+      substep<G, true, DM, false, LaneModel, SC, false, LINK>(C, L, l, M, P, tgtl, nullptr, nullptr, mu, it == nsub - 1 ? L.xch : nullptr, BL);
+  }
   GROUP_SYNC();
+  PHASE_RESET();
   for (int i = l; i < 3 * nbt; i += G) A.S.contact[(size_t)e * nbt * 3 + i] = L.xch[i];
   GROUP_SYNC();
   refresh_body_jac<G, DM>(m, L, l, actors, bstate, jac, tgtl + nd, tp.ee_body);
+  PHASE_MARK(13);
 
   // post_step on one lane (env.py:93-106, a_prior_stage.py:97-135)
   unsigned long long* stats_row = nullptr;
@@ -559,6 +574,7 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
     o[4] = rclampf(eex, -co, co); o[5] = rclampf(eey, -co, co);
   }
   GROUP_SYNC();
+  PHASE_MARK(15);
   unsigned long long stats_tk = 0ull;
   if (l == 0) stats_tk = stats_ticket(stats_row);
   for (int i = l; i < 2 * nd; i += G) dof[i] = L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)];
@@ -575,6 +591,7 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
       o[7] = (float)n;
     });
   }
+  PHASE_MARK(16);
 }
 
 __global__ void k_abb_reset_all(AbbArgs A) {
@@ -663,10 +680,12 @@ extern "C" int shf_sim_set_group(ShfSim* sim, int32_t lanes) {
   if (lanes != 64 && lanes != 32 && lanes != 16) return fail("shf_sim_set_group: lanes must be 16, 32 or 64");
   if (!sim->has_model) return fail("shf_sim_set_group: set the articulation first");
   if (sim->mapping == SHF_MAP_CHAIN) {
-    // the chain-mapped fused step takes the knob; gym.simulate / refresh_* stay body-mapped at their own width
     if (lanes != 16 && lanes != 32) return fail("shf_sim_set_group: the chain mapping runs at 16 or 32 lanes per env");
-    sim->chain_group = lanes;
-    return 0;
+    if (shf_a1_chain_matches(sim->model)) {
+      // the chain-mapped fused A1 step takes the knob; gym.simulate / refresh_* stay body-mapped at their own width
+      sim->chain_group = lanes;
+      return 0;
+    }
   }
   if (sim->model.nb + sim->nboxes > lanes || sim->model.nd > lanes)
     return fail("shf_sim_set_group: bodies + box actors (or dofs) exceed the lane group");
@@ -678,10 +697,12 @@ extern "C" int shf_sim_set_mapping(ShfSim* sim, int32_t mapping) {
   if (mapping != SHF_MAP_BODY && mapping != SHF_MAP_CHAIN) return fail("shf_sim_set_mapping: unknown mapping");
   if (mapping == SHF_MAP_CHAIN) {
     if (!sim->has_model) return fail("shf_sim_set_mapping: set the articulation first");
-    if (!shf_a1_chain_matches(sim->model))
-      return fail("shf_sim_set_mapping: the chain mapping needs a floating root with 4 serial chains of 3 revolute links and a welded end body (the A1)");
+    const bool a1 = shf_a1_chain_matches(sim->model), arm = ArmChain<6>::matches(sim->model);
+    if (!a1 && !arm)
+      return fail("shf_sim_set_mapping: the chain mapping needs a floating root with 4 serial chains of 3 revolute links and a "
+                  "welded end body (the A1), or a fixed base with one serial chain of 6 revolute links (the ABB arm)");
     if (sim_self(sim)) return fail("shf_sim_set_mapping: the chain mapping has no self-collision");
-    if (sim->nboxes != 0) return fail("shf_sim_set_mapping: the chain mapping supports a single actor per env");
+    if (a1 && sim->nboxes != 0) return fail("shf_sim_set_mapping: the chain-mapped A1 step supports a single actor per env");
   }
   sim->mapping = mapping;
   return 0;
@@ -1188,13 +1209,22 @@ extern "C" int shf_abb_step(ShfAbbTask* task, const float* raw_actions_dev, void
   dim3 grid((s->n + epb - 1) / epb), block(256);
   const int nbx = s->nboxes, nslots = s->model.np + box_slot_count(nbx, s->model.nsph) + (sim_link(s) ? 2 * SHF_MAX_LINK_CONTACTS : 0);
   const size_t lds = ((size_t)MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS +
-                      (size_t)epb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, nslots * PT_STRIDE + SHF_MAX_DOFS, 1 + nbx)) * 4;
+                      (size_t)epb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, ABB_TAIL_WORDS(nslots), 1 + nbx)) * 4;
   if (sim_link(s)) {
     switch (s->group) {
       case 64: return launch(k_abb_step<64, DynDims, DynScene, true>, grid, block, lds, stream, A);
       case 32: return launch(k_abb_step<32, DynDims, DynScene, true>, grid, block, lds, stream, A);
       default: return launch(k_abb_step<16, DynDims, DynScene, true>, grid, block, lds, stream, A);
     }
+  }
+  if (s->mapping == SHF_MAP_CHAIN) {
+    // the arm's recursions on one lane (shf_arm.h): compiled for the shipped arm in the shipped scene only
+    if (sim_link(s) || !ArmChain<6>::matches(s->model) || !AbbDims::matches(s->model) ||
+        !AbbScene::matches(s->nboxes, s->boxes, s->model.nsph) || s->group == 64)
+      return fail("shf_abb_step: the chain mapping needs the 6-link arm with 3 sample points and one capsule, the table / cube / pad "
+                  "scene, no link contacts, and 16 or 32 lanes per env");
+    return s->group == 32 ? launch(k_abb_step<32, AbbDims, AbbScene, false, 6>, grid, block, lds, stream, A)
+                          : launch(k_abb_step<16, AbbDims, AbbScene, false, 6>, grid, block, lds, stream, A);
   }
   if (AbbDims::matches(s->model) && AbbScene::matches(s->nboxes, s->boxes, s->model.nsph)) {
     switch (s->group) {

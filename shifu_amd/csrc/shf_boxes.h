@@ -39,8 +39,21 @@ DEV BoxLane box_lane_load(const ShfModel* m, int l) {
   }
   return K;
 }
-// ballots of one sub-step (fixed-scene path): corner bit c * (NBX + 1) + tg, sphere bit si
-struct BoxMasks { unsigned long long corners = 0ull; unsigned spheres = 0u; int nlink = 0; };
+// ballots of one sub-step (fixed-scene path): the free box's corners against the terrain (bit c) and against the other
+// boxes (bit c * (NBX - 1) + t, t counting the other boxes in ascending order), sphere bit si
+struct BoxMasks { unsigned cplane = 0u; unsigned long long cbox = 0ull; unsigned spheres = 0u; int nlink = 0; };
+// Next active corner slot in fold order -- corner ascending, within a corner the terrain (tg = 0) before the boxes
+// (tg = 1 + box, ascending): the order of the run-time path's flag scan and of the oracle's loops.
+template <int NO, int KD>
+DEV bool corner_next(unsigned& pl, unsigned long long& bx, int* c, int* tg) {
+  if (!pl && !bx) return false;
+  const int cp = pl ? __builtin_ctz(pl) : 64;
+  const int jb = bx ? __builtin_ctzll(bx) : 64 * NO;
+  const int cb = jb / NO;
+  if (cp <= cb) { *c = cp; *tg = 0; pl &= pl - 1u; }
+  else { const int t = jb - cb * NO; *c = cb; *tg = 1 + t + (t >= KD ? 1 : 0); bx &= bx - 1ull; }
+  return true;
+}
 
 // slot layout in LDS (PT_STRIDE floats): r[3] n[3] f0[3] ct bn on (PT_* offsets, shf_device.h)
 DEV void slot_eval(float* o, float phi, const float* n, const float* r, const float* vs, const float* vp, float mu, float kc,
@@ -745,44 +758,72 @@ DEV void boxes_contacts_fixed(const StepCtx& C, const EnvLds& L, int l, BodyRegs
   const ShfBoxDesc& bd = S->box[kd];
   const float* pk = L.pose + (nb + kd) * POSE_STRIDE;
   PHASE_BEGIN();
-  BM.corners = 0ull;
+  // Corner slots of the free box.  Round(s) 1: corner x other box, one code path for every lane.  Round 2: corner x
+  // terrain -- skipped (slots off) when the terrain is the plane z = 0 and the box's bounding sphere clears it by more
+  // than the contact offset: every corner's gap then exceeds the offset and slot_eval would switch the slot off.
+  constexpr int NO = nbx - 1, NBS = 8 * NO;
+  static_assert(NO >= 0 && NBS <= 64, "corner ballots");
+  float Rk[9], pcen[3], vb[3], vlin[3];
 #pragma unroll
-  for (int j = 0; j < (NS + G - 1) / G; j++) {
+  for (int i = 0; i < 9; i++) Rk[i] = pk[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) { pcen[i] = pk[9 + i]; vb[i] = pk[12 + i]; vlin[i] = pk[15 + i]; }
+  auto corner_place = [&](int c, float* r, float* vs, float* vp) {
+    const float lc[3] = {((c & 4) ? 0.5f : -0.5f) * bd.dim[0], ((c & 2) ? 0.5f : -0.5f) * bd.dim[1], ((c & 1) ? 0.5f : -0.5f) * bd.dim[2]};
+    float t[3];
+    mv3(Rk, lc, r);
+#pragma unroll
+    for (int i = 0; i < 3; i++) r[i] += pcen[i];
+    cross3(vb, r, t);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { vs[i] = vlin[i] + t[i]; vp[i] = fmaf(dt, gb[i], vs[i]); }
+  };
+  BM.cbox = 0ull;
+#pragma unroll
+  for (int j = 0; j < (NBS + G - 1) / G; j++) {
     const int idx = l + j * G;
-    const bool valid = idx < NS;
-    const int c = valid ? idx / T : 0, tg = valid ? idx % T : 0;
-    float* o = L.pt + corner_slot(m, nbx, kd, c, tg) * PT_STRIDE;
+    const bool valid = idx < NBS;
+    const int c = valid ? idx / (NO > 0 ? NO : 1) : 0, t = valid ? idx % (NO > 0 ? NO : 1) : 0;
+    const int ks = t + (t >= kd ? 1 : 0);
     bool on = false;
     if (valid) {
+      float* o = L.pt + corner_slot(m, nbx, kd, c, 1 + ks) * PT_STRIDE;
       o[PT_ON] = 0.0f;
-      float Rk[9], lc[3] = {((c & 4) ? 0.5f : -0.5f) * bd.dim[0], ((c & 2) ? 0.5f : -0.5f) * bd.dim[1],
-                            ((c & 1) ? 0.5f : -0.5f) * bd.dim[2]};
+      float r[3], vs[3], vp[3], n[3], phi;
+      corner_place(c, r, vs, vp);
+      const ShfBoxDesc& bs = S->box[ks];
+      const float* ps = L.pose + (nb + ks) * POSE_STRIDE;
+      float Rs[9], hh[3] = {0.5f * bs.dim[0], 0.5f * bs.dim[1], 0.5f * bs.dim[2]}, bpos[3] = {ps[9], ps[10], ps[11]};
 #pragma unroll
-      for (int i = 0; i < 9; i++) Rk[i] = pk[i];
-      float r[3], t[3], vs[3], vp[3], n[3], h, phi, vb[3] = {pk[12], pk[13], pk[14]};
-      mv3(Rk, lc, r);
-#pragma unroll
-      for (int i = 0; i < 3; i++) r[i] += pk[9 + i];
-      cross3(vb, r, t);
-#pragma unroll
-      for (int i = 0; i < 3; i++) { vs[i] = pk[15 + i] + t[i]; vp[i] = fmaf(dt, gb[i], vs[i]); }
-      if (tg == 0) {
-        terrain_query(C.terr, L.root[0] + r[0], L.root[1] + r[1], &h, n);
-        phi = (L.root[2] + r[2] - h) * n[2];
-        slot_eval(o, phi, n, r, vs, vp, 0.5f * (bd.friction + C.terr.t.friction), kc, beta, veps, vdep, dt, offset);
-      } else if (tg - 1 != kd) {
-        const int ks = tg - 1;
-        const ShfBoxDesc& bs = S->box[ks];
-        const float* ps = L.pose + (nb + ks) * POSE_STRIDE;
-        float Rs[9], hh[3] = {0.5f * bs.dim[0], 0.5f * bs.dim[1], 0.5f * bs.dim[2]}, bpos[3] = {ps[9], ps[10], ps[11]};
-#pragma unroll
-        for (int i = 0; i < 9; i++) Rs[i] = ps[i];
-        if (point_in_box(Rs, bpos, hh, r, &phi, n))
-          slot_eval(o, phi, n, r, vs, vp, 0.5f * (bd.friction + bs.friction), kc, beta, veps, vdep, dt, offset);
-      }
+      for (int i = 0; i < 9; i++) Rs[i] = ps[i];
+      if (point_in_box(Rs, bpos, hh, r, &phi, n))
+        slot_eval(o, phi, n, r, vs, vp, 0.5f * (bd.friction + bs.friction), kc, beta, veps, vdep, dt, offset);
       on = o[PT_ON] != 0.0f;
     }
-    BM.corners |= ((__ballot(on) >> lane0) & gmask) << (j * G);
+    BM.cbox |= ((__ballot(on) >> lane0) & gmask) << (j * G);
+  }
+  {
+    static_assert(G >= 8, "one lane per corner");
+    const bool valid = l < 8;
+    bool on = false;
+    if (valid) {
+      float* o = L.pt + corner_slot(m, nbx, kd, l, 0) * PT_STRIDE;
+      L.pt[corner_slot(m, nbx, kd, l, 1 + kd) * PT_STRIDE + PT_ON] = 0.0f;   // the box against itself: never a contact
+      const float reach = 0.5f * sqrtf(fmaf(bd.dim[2], bd.dim[2], fmaf(bd.dim[1], bd.dim[1], bd.dim[0] * bd.dim[0])));
+      // 1 % and a millimetre over the exact bound (the corner's own rounding cannot bridge it)
+      const bool clear = C.terr.t.rows == 0 && (L.root[2] + pcen[2]) - reach * 1.01f - 1e-3f > offset;
+      if (clear) {
+        o[PT_ON] = 0.0f;
+      } else {
+        float r[3], vs[3], vp[3], n[3], h;
+        corner_place(l, r, vs, vp);
+        terrain_query(C.terr, L.root[0] + r[0], L.root[1] + r[1], &h, n);
+        const float phi = (L.root[2] + r[2] - h) * n[2];
+        slot_eval(o, phi, n, r, vs, vp, 0.5f * (bd.friction + C.terr.t.friction), kc, beta, veps, vdep, dt, offset);
+        on = o[PT_ON] != 0.0f;
+      }
+    }
+    BM.cplane = (unsigned)((__ballot(on) >> lane0) & gmask);
   }
   PHASE_MARK(17);
   {
@@ -822,13 +863,16 @@ DEV void boxes_contacts_fixed(const StepCtx& C, const EnvLds& L, int l, BodyRegs
   // fold.  The box lane first: its own contacts (corners ascending), then the consistent law of every active pair slot
   // (pair_law) into the pair records; after the hand-off the articulation's lanes fold theirs, shapes ascending.
   if (l == nb + kd) {
-    unsigned long long cb = BM.corners;
+    unsigned pl = BM.cplane;
+    unsigned long long bx = BM.cbox;
     unsigned sb = BM.spheres;
-    while (cb) {
-      const int j = __builtin_ctzll(cb);
-      cb &= cb - 1ull;
-      slot_accumulate(B.IA, B.pA, L.pt + corner_slot(m, nbx, kd, j / T, j % T) * PT_STRIDE, 1.0f, dt, 1.0f);
-    }
+    int c, tg;
+    while (corner_next<NO, kd>(pl, bx, &c, &tg))
+      slot_accumulate(B.IA, B.pA, L.pt + corner_slot(m, nbx, kd, c, tg) * PT_STRIDE, 1.0f, dt, 1.0f);
+  }
+  PHASE_MARK(20);
+  if (l == nb + kd) {
+    unsigned sb = BM.spheres;
     if (sb) {
       float afree[6];
       ldlt_solve6(B.IA, B.pA, afree);
@@ -840,7 +884,9 @@ DEV void boxes_contacts_fixed(const StepCtx& C, const EnvLds& L, int l, BodyRegs
       }
     }
   }
+  PHASE_MARK(21);
   GROUP_SYNC();
+  PHASE_MARK(22);
   if (l < nb && m->dyn[l] == l) {
     unsigned bits = BM.spheres & BL.sph_dyn;
     while (bits) {
@@ -853,7 +899,7 @@ DEV void boxes_contacts_fixed(const StepCtx& C, const EnvLds& L, int l, BodyRegs
       pair_accumulate(B.IA, B.pA, r, F, K, dt);
     }
   }
-  PHASE_MARK(19);
+  PHASE_MARK(23);
 }
 
 // Evaluate every box contact slot (one lane each), then fold them into the owning bodies.
@@ -1089,15 +1135,22 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
     if (isbox) {
       float f[3] = {0.0f, 0.0f, 0.0f};
       if (dynbox) {
-        unsigned long long cb;
         unsigned sb;
-        int tdiv = BOX_T;
-        if constexpr (SC::NBX > 0) { cb = BM.corners; sb = BM.spheres; tdiv = 1 + SC::NBX; }
-        else { cb = corner_flags(m, L, nbx, kd); sb = box_sphere_flags(m, L, nbx, kd); }
-        while (cb) {
-          const int j = __builtin_ctzll(cb);
-          cb &= cb - 1ull;
-          slot_force(L.pt + corner_slot(m, nbx, kd, j / tdiv, j % tdiv) * PT_STRIDE, a, 1.0f, dt, 1.0f, f);
+        if constexpr (SC::NBX > 0) {
+          unsigned pl = BM.cplane;
+          unsigned long long bx = BM.cbox;
+          int c, tg;
+          sb = BM.spheres;
+          while (corner_next<SC::NBX - 1, SC::DYN>(pl, bx, &c, &tg))
+            slot_force(L.pt + corner_slot(m, nbx, kd, c, tg) * PT_STRIDE, a, 1.0f, dt, 1.0f, f);
+        } else {
+          unsigned long long cb = corner_flags(m, L, nbx, kd);
+          sb = box_sphere_flags(m, L, nbx, kd);
+          while (cb) {
+            const int j = __builtin_ctzll(cb);
+            cb &= cb - 1ull;
+            slot_force(L.pt + corner_slot(m, nbx, kd, j / BOX_T, j % BOX_T) * PT_STRIDE, a, 1.0f, dt, 1.0f, f);
+          }
         }
         while (sb) {
           const int si = __builtin_ctz(sb);

@@ -16,7 +16,7 @@ REWARD_NAMES = ["reward_reaching", "reward_success"]   # build_reward_functions 
 class FusedAbbEnv:
     def __init__(self, num_envs: int = 4096, device="cuda:0", seed: int = 42, rank: int = 0, world_size: int = 1,
                  group: int = None, dt: float = 0.02, decimation: int = 5, episode_length_s: float = 20.0,
-                 extra_boxes=(), link_contacts: bool = False):
+                 extra_boxes=(), link_contacts: bool = False, mapping: str = None):
         self.device = torch.device(device)
         self.num_envs = num_envs
         self.env_id_offset = rank * num_envs
@@ -29,6 +29,11 @@ class FusedAbbEnv:
             # 16 lanes per env is the fastest for the plain scene; with link contacts the 59 sample points and the link
             # slots need 12.5 KB of LDS per env: eight envs per block (32 lanes each), not sixteen
             group = 32 if link_contacts else 16
+        if mapping is None:
+            # 'chain': the arm's kinematic / ABA recursions on one lane (csrc/shf_arm.h), compiled for the shipped arm in
+            # the shipped scene; 'body': the level-by-level sub-step (any arm, any boxes).  Identical results.
+            mapping = "chain" if (not link_contacts and not extra_boxes and group in (16, 32)) else "body"
+        self.mapping = mapping
         self.sim_params = default_sim_params(dt=dt)
         self.sim = Sim(self.sim_params, self.device)
         self.sim.set_plane(1.0)
@@ -38,7 +43,7 @@ class FusedAbbEnv:
         self.boxes = abb_boxes() + list(extra_boxes)
         for b in self.boxes:
             self.sim.add_box(b)
-        self.sim.finalize(num_envs, self.env_id_offset, group=group)
+        self.sim.finalize(num_envs, self.env_id_offset, group=group, mapping=mapping)
         self.task_params = abb_task_params(self.cm, dt=dt, decimation=decimation, episode_length_s=episode_length_s,
                                            seed=seed)
         for k, b in enumerate(extra_boxes):
