@@ -224,7 +224,7 @@ def main():
                     help="terrain = config 3 (height field); trimesh = the same samples as the mesh with vertical risers; "
                          "abb = config 5")
     ap.add_argument("--group", type=int, default=None, help="lanes per env: 64 = one wavefront per env; default 16 (A1, ABB), the fastest measured (DESIGN.md 6)")
-    ap.add_argument("--mapping", choices=["chain", "body"], default=None,
+    ap.add_argument("--mapping", choices=["chain", "body", "split"], default=None,
                     help="A1 workloads: lane = kinematic chain (default; csrc/shf_chain.h) or lane = rigid body (the general kernels; "
                          "default with --self-collision).  Kernel selection only: results are bit-identical")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -280,7 +280,7 @@ def main():
     from shifu_amd.parallel import gather_episode_stats
 
     abb = args.workload == "abb"
-    mapping = args.mapping or ("chain" if (abb and not args.link_contacts and (args.group or 16) < 64) else "body")
+    mapping = args.mapping or ((("split" if (args.group or 16) == 16 else "chain") if (abb and not args.link_contacts and (args.group or 16) < 64) else "body"))
     group = args.group or ((32 if args.link_contacts else 16) if (abb or mapping == "chain") else 32)
     if abb:
         from shifu_amd.gym.abb_fused import FusedAbbEnv
@@ -378,7 +378,7 @@ def main():
         value = total_envs * args.steps / elapsed
         b_alg = B_ALG[args.workload]
         achieved = b_alg * N / (kern_ms * 1e-3) / 1e9
-        prof = committed_profile(f"{kernel}_{args.workload}_g{group}" + ("_chain" if mapping == "chain" else "")) if (N == 4096 and not args.self_collision) else None
+        prof = committed_profile(f"{kernel}_{args.workload}_g{group}" + ("_" + mapping if mapping != "body" else "")) if (N == 4096 and not args.self_collision) else None
         res = {}
         try:
             res = json.load(open(os.path.join(ROOT, "shifu_amd", "libshifu_amd.resources.json")))
@@ -387,6 +387,8 @@ def main():
         entry = env.task.kernel_symbol() if hasattr(env.task, "kernel_symbol") else None
         vg = next((v for k, v in res.items() if entry and k.startswith(entry)), None)
         waves = (N + (64 // group) - 1) // (64 // group) if group < 64 else N
+        if mapping == "split":
+            waves *= 2          # every env group has an arm wave and a box wave (k_abb_step_ws)
         secondary = {"bound": "valu_fp32", "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "waves_per_simd": waves / float(NUM_CUS * SIMDS_PER_CU),
                      "lanes_per_env": group, "vgprs": None if vg is None else vg.get("vgprs"),

@@ -283,7 +283,9 @@ int shf_sim_set_group(ShfSim* sim, int32_t lanes);
  * shf_sim_set_group) -- and a fixed base with one chain of 6 revolute links -- the ABB arm in its table / cube / pad
  * scene (csrc/shf_arm.h; shf_abb_step checks the scene).  No self-collision or link contacts; 16 or 32 lanes per env.
  * Same results bit for bit either way.  Not part of the reference API: a tuning knob.  Fails for another shape. */
-enum { SHF_MAP_BODY = 0, SHF_MAP_CHAIN = 1 };
+/* SHF_MAP_CHAIN_SPLIT (the ABB arm at 16 lanes per env only): the chain mapping with the arm and the box actors of an env
+ * on different wavefronts of one workgroup, synchronised by workgroup barriers (csrc/shf_api.hip: k_abb_step_ws). */
+enum { SHF_MAP_BODY = 0, SHF_MAP_CHAIN = 1, SHF_MAP_CHAIN_SPLIT = 2 };
 int shf_sim_set_mapping(ShfSim* sim, int32_t mapping);
 
 /* gym.simulate (a1_conditional.py:69, robot.py:69, isaac_gym.py:140) */

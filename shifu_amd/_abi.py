@@ -2,7 +2,7 @@
 import ctypes as C
 
 SHF_ABI_VERSION = 7
-MAP_BODY, MAP_CHAIN = 0, 1   # shf_sim_set_mapping
+MAP_BODY, MAP_CHAIN, MAP_CHAIN_SPLIT = 0, 1, 2   # shf_sim_set_mapping
 MAX_BODIES = 32
 MAX_DOFS = 32
 MAX_POINTS = 176

@@ -151,11 +151,12 @@ class Sim:
         self.group = group
         self.mapping = mapping
         check(lib().shf_sim_finalize(self._h, num_envs, env_id_offset))
-        if mapping == "chain":
-            check(lib().shf_sim_set_mapping(self._h, _abi.MAP_CHAIN))
+        if mapping in ("chain", "split"):
+            # 'split': the chain mapping with arm and boxes on different waves of a workgroup (the ABB step at 16 lanes)
+            check(lib().shf_sim_set_mapping(self._h, _abi.MAP_CHAIN if mapping == "chain" else _abi.MAP_CHAIN_SPLIT))
             check(lib().shf_sim_set_group(self._h, group))
         elif mapping != "body":
-            raise ValueError("mapping must be 'body' or 'chain'")
+            raise ValueError("mapping must be 'body', 'chain' or 'split'")
         elif group != 64:
             check(lib().shf_sim_set_group(self._h, group))
         for tid in range(_abi.T_COUNT):
@@ -370,7 +371,10 @@ class AbbTask:
         pre = f"_Z10k_abb_stepILi{self.sim.group}E"
         if not fixed:
             return pre + "7DynDims"
-        arm = 6 if getattr(self.sim, "mapping", "body") == "chain" else 0
+        mp = getattr(self.sim, "mapping", "body")
+        if mp == "split":
+            return "_Z13k_abb_step_wsILi"
+        arm = 6 if mp == "chain" else 0
         return pre + f"9FixedDimsILi7ELi6ELi3ELi6ELi6EE10FixedSceneILi3ELi1ELi1EELb0ELi{arm}EE"
 
     @_on_device

@@ -41,6 +41,7 @@ struct ShfSim {
   void* t[SHF_T_COUNT] = {};
   int group = 64;  // lanes per env
   int mapping = SHF_MAP_BODY;
+  int mapping_split = 0;   // SHF_MAP_CHAIN_SPLIT: threads per block of the wave-specialised arm step (256 / 512), else 0
   int chain_group = 16;  // lanes per env of the chain-mapped fused A1 step (the other kernels keep `group`)
 };
 
@@ -414,50 +415,10 @@ DEV void abb_reset_env(const ShfAbbTaskParams& tp, int nd, int nbx, int64_t gid,
   }
 }
 
-// DM / SC: run-time model and scene (any arm, any boxes), or the shipped ABB scene fixed at compile time (ancestor-walk
-// kinematics, compile-time level loops, ballot-driven box folds) -- the host picks the latter only when both match.
-// ARM: number of links when the articulation is a fixed-base serial chain (ArmChain<ARM>::matches) in a compile-time
-// scene -- its recursions then run on one lane (shf_arm.h); 0: the body-per-lane sub-step.
-// LDS tail of an env: POS targets, this step's ee position, the arm's per-link records.
-#define SHF_ARM_MAX_LINKS 8
-#define ABB_TAIL_WORDS(nslots) ((nslots) * PT_STRIDE + SHF_MAX_DOFS + ARM_KREC_WORDS(SHF_ARM_MAX_LINKS))
-template <int G, class DM, class SC, bool LINK = false, int ARM = 0>
-__global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  PHASE_BEGIN();
-  float* stats_lds = smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS;
-  stats_block_init(stats_lds);
-  const unsigned long long stats_step = stats_step_load(A.stats);
-  {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(A.tp);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(smem + MODEL_WORDS + SCENE_WORDS);
-    stage_block<(int)sizeof(ShfAbbTaskParams)>(src, reinterpret_cast<float*>(dst));
-  }
-  const ShfScene* scene = stage_scene(A.S.scene, smem + MODEL_WORDS);
-  const ShfModel* m = stage_model(A.S.model, smem);
-  const ShfAbbTaskParams& tp = *reinterpret_cast<const ShfAbbTaskParams*>(smem + MODEL_WORDS + SCENE_WORDS);
-  const int epb = 256 / G, es = threadIdx.x / G, l = threadIdx.x % G;
-  const int e = blockIdx.x * epb + es;
-  const int n = A.S.n;
-  if (e >= n) return;
-  const int nbx = SC::NBX > 0 ? SC::NBX : A.S.nboxes, actors = 1 + nbx;
-  const int nb = DM::nb(m), nd = DM::nd(m), nbt = nb + nbx;
-  const int nslots = DM::np(m) + box_slot_count(nbx, m->nsph) + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0);
-  const int env_words = env_lds_words(nbt, nd, nslots, ABB_TAIL_WORDS(nslots), actors);
-  EnvLds L = env_lds_carve(smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS + es * env_words, nbt, nd, nslots, actors);
-  float* tgtl = L.pt + nslots * PT_STRIDE;  // POS targets of this env step
-  float* krec = tgtl + SHF_MAX_DOFS;
-
-  float* dof = A.S.dof + (size_t)e * nd * 2;
-  float* root = A.S.root + (size_t)e * actors * 13;
-  float* bstate = A.body_state + (size_t)e * nbt * 13;
-  float* jac = A.jacobian + (size_t)e * (nb - 1) * 6 * nd;
-  for (int i = l; i < 2 * nd; i += G) L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)] = dof[i];
-  for (int i = l; i < 13 * actors; i += G) L.root[i] = root[i];
-  GROUP_SYNC();
-
-  // AbbRobot.step: EE-delta -> clip -> damped least squares on the Jacobian tensor (possibly stale pose)
-  if (l == 0) {
+// AbbRobot.step (shifu/units/robot.py:103-160) on one lane: EE-delta -> clip -> damped least squares on the Jacobian tensor
+// (possibly stale pose) -> POS targets of this env step (tgtl: LDS; also written to the dof_targets tensor)
+DEV void abb_ik_targets(const AbbArgs& A, const ShfAbbTaskParams& tp, const EnvLds& L, int e, int nd, const float* bstate,
+                        const float* jac, float* tgtl) {
     float act[3], dpose[6], eq[4], cc[4], qr[4];
     const float* ee = bstate + 13 * tp.ee_body;
     float eep[3] = {ee[0], ee[1], ee[2]};
@@ -499,28 +460,20 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
       A.dof_targets[(size_t)e * nd + d] = t;
     }
   }
-  GROUP_SYNC();
-  PHASE_MARK(11);
 
-  StepCtx C;
-  C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = scene;
-  C.dropped = A.S.dropped ? A.S.dropped + e : nullptr;
-  const float mu = A.S.friction[e];
-  const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
-  LaneModel M;
-  lane_model_load<DM>(m, l, M);
-  LanePoints<LANE_ROUNDS(G, DM)> P;
-  if constexpr (DM::NPC > 0) lane_points_load<G>(m, DM::np(m), l, P);
-  const BoxLane BL = SC::NBX > 0 ? box_lane_load(m, l) : BoxLane();
-  // net contact forces are reported for the last sub-step only (what the refreshed tensor shows)
-  for (int it = 0; it < nsub; it++) {
-    if constexpr (ARM > 0)
-      arm_substep<G, DM, SC, ARM>(C, L, krec, l, M, P, tgtl, mu, it == nsub - 1 ? L.xch : nullptr, BL);
-    else
-      substep<G, true, DM, false, LaneModel, SC, false, LINK>(C, L, l, M, P, tgtl, nullptr, nullptr, mu, it == nsub - 1 ? L.xch : nullptr, BL);
-  }
+// Everything of the AbbPushBox env step after the sub-steps: contact-force copy-out, state refresh (body states, Jacobian),
+// post_step on one lane (env.py:93-106, a_prior_stage.py:97-135), statistics, state stores.
+template <int G, class DM>
+DEV void abb_after_physics(const AbbArgs& A, const ShfAbbTaskParams& tp, const ShfModel* m, const EnvLds& L, int l, int e, int epb,
+                           int nbx, float* tgtl, float* stats_lds, unsigned long long stats_step) {
+  const int n = A.S.n, actors = 1 + nbx;
+  const int nb = DM::nb(m), nd = DM::nd(m), nbt = nb + nbx;
+  float* dof = A.S.dof + (size_t)e * nd * 2;
+  float* root = A.S.root + (size_t)e * actors * 13;
+  float* bstate = A.body_state + (size_t)e * nbt * 13;
+  float* jac = A.jacobian + (size_t)e * (nb - 1) * 6 * nd;
+  PHASE_BEGIN();
   GROUP_SYNC();
-  PHASE_RESET();
   for (int i = l; i < 3 * nbt; i += G) A.S.contact[(size_t)e * nbt * 3 + i] = L.xch[i];
   GROUP_SYNC();
   refresh_body_jac<G, DM>(m, L, l, actors, bstate, jac, tgtl + nd, tp.ee_body);
@@ -592,6 +545,213 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
     });
   }
   PHASE_MARK(16);
+}
+
+// DM / SC: run-time model and scene (any arm, any boxes), or the shipped ABB scene fixed at compile time (ancestor-walk
+// kinematics, compile-time level loops, ballot-driven box folds) -- the host picks the latter only when both match.
+// ARM: number of links when the articulation is a fixed-base serial chain (ArmChain<ARM>::matches) in a compile-time
+// scene -- its recursions then run on one lane (shf_arm.h); 0: the body-per-lane sub-step.
+// LDS tail of an env: POS targets, this step's ee position, the arm's per-link records.
+#define SHF_ARM_MAX_LINKS 8
+#define ABB_TAIL_WORDS(nslots) ((nslots) * PT_STRIDE + SHF_MAX_DOFS + ARM_KREC_WORDS(SHF_ARM_MAX_LINKS))
+template <int G, class DM, class SC, bool LINK = false, int ARM = 0>
+__global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  PHASE_BEGIN();
+  float* stats_lds = smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS;
+  stats_block_init(stats_lds);
+  const unsigned long long stats_step = stats_step_load(A.stats);
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(A.tp);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(smem + MODEL_WORDS + SCENE_WORDS);
+    stage_block<(int)sizeof(ShfAbbTaskParams)>(src, reinterpret_cast<float*>(dst));
+  }
+  const ShfScene* scene = stage_scene(A.S.scene, smem + MODEL_WORDS);
+  const ShfModel* m = stage_model(A.S.model, smem);
+  const ShfAbbTaskParams& tp = *reinterpret_cast<const ShfAbbTaskParams*>(smem + MODEL_WORDS + SCENE_WORDS);
+  const int epb = 256 / G, es = threadIdx.x / G, l = threadIdx.x % G;
+  const int e = blockIdx.x * epb + es;
+  const int n = A.S.n;
+  if (e >= n) return;
+  const int nbx = SC::NBX > 0 ? SC::NBX : A.S.nboxes, actors = 1 + nbx;
+  const int nb = DM::nb(m), nd = DM::nd(m), nbt = nb + nbx;
+  const int nslots = DM::np(m) + box_slot_count(nbx, m->nsph) + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0);
+  const int env_words = env_lds_words(nbt, nd, nslots, ABB_TAIL_WORDS(nslots), actors);
+  EnvLds L = env_lds_carve(smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS + es * env_words, nbt, nd, nslots, actors);
+  float* tgtl = L.pt + nslots * PT_STRIDE;  // POS targets of this env step
+  float* krec = tgtl + SHF_MAX_DOFS;
+
+  float* dof = A.S.dof + (size_t)e * nd * 2;
+  float* root = A.S.root + (size_t)e * actors * 13;
+  float* bstate = A.body_state + (size_t)e * nbt * 13;
+  float* jac = A.jacobian + (size_t)e * (nb - 1) * 6 * nd;
+  for (int i = l; i < 2 * nd; i += G) L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)] = dof[i];
+  for (int i = l; i < 13 * actors; i += G) L.root[i] = root[i];
+  GROUP_SYNC();
+
+  // AbbRobot.step: EE-delta -> clip -> damped least squares on the Jacobian tensor (possibly stale pose)
+  if (l == 0) abb_ik_targets(A, tp, L, e, nd, bstate, jac, tgtl);
+  GROUP_SYNC();
+  PHASE_MARK(11);
+
+  StepCtx C;
+  C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = scene;
+  C.dropped = A.S.dropped ? A.S.dropped + e : nullptr;
+  const float mu = A.S.friction[e];
+  const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
+  LaneModel M;
+  lane_model_load<DM>(m, l, M);
+  LanePoints<LANE_ROUNDS(G, DM)> P;
+  if constexpr (DM::NPC > 0) lane_points_load<G>(m, DM::np(m), l, P);
+  const BoxLane BL = SC::NBX > 0 ? box_lane_load(m, l) : BoxLane();
+  // net contact forces are reported for the last sub-step only (what the refreshed tensor shows)
+  for (int it = 0; it < nsub; it++) {
+    if constexpr (ARM > 0)
+      arm_substep<G, DM, SC, ARM>(C, L, krec, l, M, P, tgtl, mu, it == nsub - 1 ? L.xch : nullptr, BL);
+    else
+      substep<G, true, DM, false, LaneModel, SC, false, LINK>(C, L, l, M, P, tgtl, nullptr, nullptr, mu, it == nsub - 1 ? L.xch : nullptr, BL);
+  }
+  abb_after_physics<G, DM>(A, tp, m, L, l, e, epb, nbx, tgtl, stats_lds, stats_step);
+}
+
+// Wave-specialised form of the shipped ABB step (AbbDims arm, AbbScene boxes, 16 lanes per env).  A single wave issues
+// one VALU instruction per ~4.6 clocks while its SIMD could issue one per ~2 (profiles/r03_valu_microbench.md), and at 4
+// envs per wave 4096 envs are one wave per SIMD -- half the issue slots idle.  The arm's work (a serial chain) and the
+// box actors' work (corner contacts, their fold, the boxes' 6x6 solves and integration) only meet at the rod's contact
+// with the cube, so the workgroup's first WT/128 waves run the ARM of WT/32 envs and the other half the BOXES of the same
+// envs, side by side, through the same LDS working set:
+//     arm wave                                   |  box wave
+//     joints, drives, chain composition,         |  box poses, corner slots, fold of the corners
+//     inertias, terrain points                   |
+//                                                |  the free box's folded (IA, pA) -> LDS
+//   ---- S1 (workgroup barrier): box poses, the box's folded inertia and the arm's poses visible to both
+//     rod-capsule slot vs the free box, its pair |
+//     law (when it touches), pair fold,          |
+//     hand-over, ABA inward / outward            |
+//   ---- S4: the arm's accelerations, the slot's ballot and the pair records visible
+//     (a four-barrier form with the pair law on the box wave measured the same: 0.0937 vs 0.0945 ms)
+//     terrain-contact forces, arm contact rows,  |  pair forces, box solves, box contact rows,
+//     joint integration                          |  box integration
+// Same operations in the same order as the one-wave kernels (and the oracle): bit-identical results.
+template <int WT>
+__global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
+  constexpr int G = 16, NL = 6, HALF = WT / 2, EPB = HALF / G;
+  typedef AbbDims DM;
+  typedef AbbScene SC;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  PHASE_BEGIN();
+  float* stats_lds = smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS;
+  stats_block_init(stats_lds);
+  const unsigned long long stats_step = stats_step_load(A.stats);
+  stage_block<(int)sizeof(ShfAbbTaskParams), WT>(A.tp, smem + MODEL_WORDS + SCENE_WORDS);
+  const ShfScene* scene = stage_scene<WT>(A.S.scene, smem + MODEL_WORDS);
+  const ShfModel* m = stage_model<WT>(A.S.model, smem);
+  const ShfAbbTaskParams& tp = *reinterpret_cast<const ShfAbbTaskParams*>(smem + MODEL_WORDS + SCENE_WORDS);
+  const bool arm = (int)threadIdx.x < HALF;
+  const int t = (int)threadIdx.x - (arm ? 0 : HALF), es = t / G, l = t % G;
+  const int e = blockIdx.x * EPB + es;
+  const int n = A.S.n;
+  const bool live = e < n;                       // no early return: every wave meets every workgroup barrier
+  constexpr int nbx = SC::NBX, actors = 1 + nbx, nb = NL + 1, nd = NL, nbt = nb + nbx;
+  const int nslots = DM::np(m) + box_slot_count(nbx, m->nsph);
+  const int env_words = env_lds_words(nbt, nd, nslots, ABB_TAIL_WORDS(nslots), actors);
+  EnvLds L = env_lds_carve(smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS + es * env_words, nbt, nd, nslots, actors);
+  float* tgtl = L.pt + nslots * PT_STRIDE;       // POS targets of this env step
+  float* krec = tgtl + SHF_MAX_DOFS;
+  unsigned* sphere_bits = reinterpret_cast<unsigned*>(krec + ARM_KREC_WORDS(NL));   // the rod slot's ballot, arm wave -> box wave
+
+  if (arm && live) {
+    const float* dof = A.S.dof + (size_t)e * nd * 2;
+    const float* root = A.S.root + (size_t)e * actors * 13;
+    for (int i = l; i < 2 * nd; i += G) L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)] = dof[i];
+    for (int i = l; i < 13 * actors; i += G) L.root[i] = root[i];
+    GROUP_SYNC();
+    if (l == 0) abb_ik_targets(A, tp, L, e, nd, A.body_state + (size_t)e * nbt * 13, A.jacobian + (size_t)e * (nb - 1) * 6 * nd, tgtl);
+    GROUP_SYNC();
+  }
+  __syncthreads();                               // S0: the box wave sees the root rows
+  PHASE_MARK(11);
+
+  StepCtx C;
+  C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = scene;
+  C.dropped = nullptr;
+  const float mu = live ? A.S.friction[e] : 0.0f;
+  const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
+  LaneModel M;
+  lane_model_load<DM>(m, l, M);
+  LanePoints<LANE_ROUNDS(G, DM)> P;
+  lane_points_load<G>(m, DM::np(m), l, P);
+  const BoxLane BL = box_lane_load(m, l);
+  ArmLane<G, DM, NL> AL(C, L, krec, l, M, P);
+  BodyRegs B;                                    // arm wave: the lane's link; box wave: the lane's box
+  BoxMasks BM;
+  for (int it = 0; it < nsub; it++) {
+    float* contact_out = it == nsub - 1 ? L.xch : nullptr;   // reported for the last sub-step only
+    if (live) {
+      if (arm) {
+        AL.joints_and_drives(tgtl);
+        GROUP_SYNC();
+        AL.compose();
+        GROUP_SYNC();
+        AL.inertia_and_points(B, mu);
+      } else {
+        boxes_pose<G>(C, L, l, B);
+        fixed_corner_slots<G, SC>(C, L, l, BM);
+        GROUP_SYNC();
+        fixed_box_fold<G, SC>(C, L, l, B, BM);
+        if (l == nb + SC::DYN) {                 // the free box with its own contacts folded in: what the pair law eliminates
+          float* o = L.xch + l * XCH_STRIDE;
+#pragma unroll
+          for (int k = 0; k < 21; k++) o[k] = B.IA[k];
+#pragma unroll
+          for (int k = 0; k < 6; k++) o[21 + k] = B.pA[k];
+        }
+      }
+    }
+    PHASE_MARK(24);
+    __syncthreads();                             // S1
+    PHASE_MARK(25);
+    if (live && arm) {
+      fixed_sphere_slots<G, SC>(C, L, l, mu, AL.g, BM);
+      if (l == 0) {
+        *sphere_bits = BM.spheres;
+        if (BM.spheres) {                        // rare: the pair laws on the lane that evaluated the slot
+          const float* o = L.xch + (nb + SC::DYN) * XCH_STRIDE;
+          float IAb[21], pAb[6];
+#pragma unroll
+          for (int k = 0; k < 21; k++) IAb[k] = o[k];
+#pragma unroll
+          for (int k = 0; k < 6; k++) pAb[k] = o[21 + k];
+          fixed_pair_laws<G, SC>(C, L, true, IAb, pAb, BM.spheres);
+        }
+      }
+      GROUP_SYNC();
+      fixed_arm_fold<G, SC>(C, L, l, B, BL, BM.spheres);
+      AL.hand_over(B);
+      GROUP_SYNC();
+      AL.recursions();
+      GROUP_SYNC();
+    }
+    PHASE_MARK(26);
+    __syncthreads();                             // S4
+    PHASE_MARK(27);
+    if (live) {
+      if (arm) {
+        if (contact_out) { AL.point_forces(contact_out); GROUP_SYNC(); }
+        boxes_finish<G, SC, 2>(C, L, l, B, contact_out, BL, BM, 0);
+        AL.integrate();
+        GROUP_SYNC();
+      } else {
+        BM.spheres = *sphere_bits;
+        boxes_finish<G, SC, 1>(C, L, l, B, contact_out, BL, BM, 0);
+      }
+    }
+  }
+  PHASE_MARK(28);
+  __syncthreads();                               // the boxes' final root rows and contact rows are in LDS
+  PHASE_MARK(29);
+  if (!arm || !live) return;
+  abb_after_physics<G, DM>(A, tp, m, L, l, e, EPB, nbx, tgtl, stats_lds, stats_step);
 }
 
 __global__ void k_abb_reset_all(AbbArgs A) {
@@ -694,7 +854,16 @@ extern "C" int shf_sim_set_group(ShfSim* sim, int32_t lanes) {
 }
 extern "C" int shf_sim_set_mapping(ShfSim* sim, int32_t mapping) {
   if (!sim) return fail("shf_sim_set_mapping: null sim");
-  if (mapping != SHF_MAP_BODY && mapping != SHF_MAP_CHAIN) return fail("shf_sim_set_mapping: unknown mapping");
+  if (mapping != SHF_MAP_BODY && mapping != SHF_MAP_CHAIN && mapping != SHF_MAP_CHAIN_SPLIT)
+    return fail("shf_sim_set_mapping: unknown mapping");
+  int split = 0;
+  if (mapping == SHF_MAP_CHAIN_SPLIT) {
+    if (!sim->has_model || !ArmChain<6>::matches(sim->model))
+      return fail("shf_sim_set_mapping: the split chain mapping is compiled for a fixed base with one chain of 6 revolute links (the ABB arm)");
+    split = 256;   // threads per workgroup: 2 arm waves + 2 box waves for 8 envs (512: 0.100 ms, 128: 0.159 ms, 256: 0.094 ms)
+    mapping = SHF_MAP_CHAIN;
+  }
+  sim->mapping_split = split;
   if (mapping == SHF_MAP_CHAIN) {
     if (!sim->has_model) return fail("shf_sim_set_mapping: set the articulation first");
     const bool a1 = shf_a1_chain_matches(sim->model), arm = ArmChain<6>::matches(sim->model);
@@ -1223,6 +1392,14 @@ extern "C" int shf_abb_step(ShfAbbTask* task, const float* raw_actions_dev, void
         !AbbScene::matches(s->nboxes, s->boxes, s->model.nsph) || s->group == 64)
       return fail("shf_abb_step: the chain mapping needs the 6-link arm with 3 sample points and one capsule, the table / cube / pad "
                   "scene, no link contacts, and 16 or 32 lanes per env");
+    if (s->group == 16 && s->mapping_split) {
+      // arm and boxes on different waves of the workgroup (k_abb_step_ws): WT / 32 envs per block
+      const int wt = s->mapping_split, wepb = wt / 32;
+      const size_t wlds = ((size_t)MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS +
+                           (size_t)wepb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, ABB_TAIL_WORDS(nslots), 1 + nbx)) * 4;
+      const dim3 wgrid((s->n + wepb - 1) / wepb);
+      return launch(k_abb_step_ws<256>, wgrid, dim3(wt), wlds, stream, A);
+    }
     return s->group == 32 ? launch(k_abb_step<32, AbbDims, AbbScene, false, 6>, grid, block, lds, stream, A)
                           : launch(k_abb_step<16, AbbDims, AbbScene, false, 6>, grid, block, lds, stream, A);
   }

@@ -740,29 +740,35 @@ DEV void boxes_pose(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B) {
   GROUP_SYNC();
 }
 
-// The fixed-scene form of boxes_contacts: the free box's 8 x (1 + NBX) corner slots and NSPH sphere slots, one lane each.
+// The fixed-scene form of boxes_contacts -- the free box's corner slots and NSPH sphere slots, one lane each -- in five
+// pieces, so that the wave-specialised ABB step (shf_api.hip: k_abb_step_ws) can run the box's pieces and the
+// articulation's on different waves; boxes_contacts_fixed below strings them together for one wave.
 template <int G, class SC>
-DEV void boxes_contacts_fixed(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, float mu_shape, const float* g_art,
-                              const BoxLane& BL, BoxMasks& BM) {
+struct FixedSceneConsts {
+  static constexpr int nbx = SC::NBX, T = 1 + SC::NBX, kd = SC::DYN, NO = SC::NBX - 1, NBS = 8 * (SC::NBX - 1);
+  static_assert(8 * T <= 64 && SC::NSPH <= 16, "fixed scene too large for the ballot masks");
+  static_assert(NO >= 0 && NBS <= 64, "corner ballots");
+  DEV static int lane0(int l) { return (int)(threadIdx.x & 63u) - l; }
+  DEV static unsigned long long gmask() { return G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull); }
+};
+// Corner slots of the free box.  Round(s) 1: corner x other box, one code path for every lane.  Round 2: corner x
+// terrain -- skipped (slots off) when the terrain is the plane z = 0 and the box's bounding sphere clears it by more
+// than the contact offset: every corner's gap then exceeds the offset and slot_eval would switch the slot off.
+template <int G, class SC>
+DEV void fixed_corner_slots(const StepCtx& C, const EnvLds& L, int l, BoxMasks& BM) {
+  typedef FixedSceneConsts<G, SC> F;
+  constexpr int nbx = F::nbx, kd = F::kd, NO = F::NO, NBS = F::NBS;
   const ShfModel* m = C.m;
   const SceneDev* S = C.scene;
-  constexpr int nbx = SC::NBX, T = 1 + SC::NBX, kd = SC::DYN, NS = 8 * T;
-  static_assert(NS <= 64 && SC::NSPH <= 16 && SC::NSPH <= 32, "fixed scene too large for the ballot masks");
   const int nb = m->nb;
   const float dt = C.sp.dt, kc = C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
   const float offset = C.sp.contact_offset;
   const float beta = fmaf(kc, dt, C.sp.contact_d);
   const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
-  const int lane0 = (int)(threadIdx.x & 63u) - l;
-  const unsigned long long gmask = G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
+  const int lane0 = F::lane0(l);
+  const unsigned long long gmask = F::gmask();
   const ShfBoxDesc& bd = S->box[kd];
   const float* pk = L.pose + (nb + kd) * POSE_STRIDE;
-  PHASE_BEGIN();
-  // Corner slots of the free box.  Round(s) 1: corner x other box, one code path for every lane.  Round 2: corner x
-  // terrain -- skipped (slots off) when the terrain is the plane z = 0 and the box's bounding sphere clears it by more
-  // than the contact offset: every corner's gap then exceeds the offset and slot_eval would switch the slot off.
-  constexpr int NO = nbx - 1, NBS = 8 * NO;
-  static_assert(NO >= 0 && NBS <= 64, "corner ballots");
   float Rk[9], pcen[3], vb[3], vlin[3];
 #pragma unroll
   for (int i = 0; i < 9; i++) Rk[i] = pk[i];
@@ -825,80 +831,119 @@ DEV void boxes_contacts_fixed(const StepCtx& C, const EnvLds& L, int l, BodyRegs
     }
     BM.cplane = (unsigned)((__ballot(on) >> lane0) & gmask);
   }
-  PHASE_MARK(17);
-  {
-    const bool valid = l < SC::NSPH;
-    const int si = valid ? l : 0;
-    float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
-    bool on = false;
-    if (valid) {
-      const int b = m->sph_body[si];
-      const float* pb = L.pose + b * POSE_STRIDE;
-      float Rb[9], Rk[9], c[3];
+}
+// Rounded shapes of the articulation (sphere / capsule) against the free box: lane si < NSPH
+template <int G, class SC>
+DEV void fixed_sphere_slots(const StepCtx& C, const EnvLds& L, int l, float mu_shape, const float* g_art, BoxMasks& BM) {
+  typedef FixedSceneConsts<G, SC> F;
+  constexpr int nbx = F::nbx, kd = F::kd;
+  const ShfModel* m = C.m;
+  const int nb = m->nb;
+  const float dt = C.sp.dt, kc = C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
+  const float offset = C.sp.contact_offset;
+  const float beta = fmaf(kc, dt, C.sp.contact_d);
+  const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
+  const ShfBoxDesc& bd = C.scene->box[kd];
+  const float* pk = L.pose + (nb + kd) * POSE_STRIDE;
+  const bool valid = l < SC::NSPH;
+  const int si = valid ? l : 0;
+  float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
+  bool on = false;
+  if (valid) {
+    const int b = m->sph_body[si];
+    const float* pb = L.pose + b * POSE_STRIDE;
+    float Rb[9], Rk[9], c[3];
 #pragma unroll
-      for (int i = 0; i < 9; i++) { Rb[i] = pb[i]; Rk[i] = pk[i]; }
-      const float hh[3] = {0.5f * bd.dim[0], 0.5f * bd.dim[1], 0.5f * bd.dim[2]}, bpos[3] = {pk[9], pk[10], pk[11]};
-      if (rounded_centre(m, si, Rb, pb + 9, Rk, bpos, hh, offset, c)) {
-        float phi, n[3], rc[3], ta[3], tb[3], vrel[3], vrs[3];
-        sphere_vs_box(Rk, bpos, hh, c, m->sph_radius[si], &phi, n, rc);
-        const float va[3] = {pb[12], pb[13], pb[14]}, vbx[3] = {pk[12], pk[13], pk[14]};
-        cross3(va, rc, ta);
-        cross3(vbx, rc, tb);
+    for (int i = 0; i < 9; i++) { Rb[i] = pb[i]; Rk[i] = pk[i]; }
+    const float hh[3] = {0.5f * bd.dim[0], 0.5f * bd.dim[1], 0.5f * bd.dim[2]}, bpos[3] = {pk[9], pk[10], pk[11]};
+    if (rounded_centre(m, si, Rb, pb + 9, Rk, bpos, hh, offset, c)) {
+      float phi, n[3], rc[3], ta[3], tb[3], vrel[3], vrs[3];
+      sphere_vs_box(Rk, bpos, hh, c, m->sph_radius[si], &phi, n, rc);
+      const float va[3] = {pb[12], pb[13], pb[14]}, vbx[3] = {pk[12], pk[13], pk[14]};
+      cross3(va, rc, ta);
+      cross3(vbx, rc, tb);
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-          const float pa = pb[15 + i] + ta[i], pq = pk[15 + i] + tb[i];
-          vrs[i] = pa - pq;
-          vrel[i] = fmaf(dt, g_art[i], pa) - fmaf(dt, gb[i], pq);
-        }
-        slot_eval(o, phi, n, rc, vrs, vrel, 0.5f * (mu_shape + bd.friction), kc, beta, veps, vdep, dt, offset);
-        on = o[PT_ON] != 0.0f;
-      } else {
-        o[PT_ON] = 0.0f;
+      for (int i = 0; i < 3; i++) {
+        const float pa = pb[15 + i] + ta[i], pq = pk[15 + i] + tb[i];
+        vrs[i] = pa - pq;
+        vrel[i] = fmaf(dt, g_art[i], pa) - fmaf(dt, gb[i], pq);
       }
+      slot_eval(o, phi, n, rc, vrs, vrel, 0.5f * (mu_shape + bd.friction), kc, beta, veps, vdep, dt, offset);
+      on = o[PT_ON] != 0.0f;
+    } else {
+      o[PT_ON] = 0.0f;
     }
-    BM.spheres = (unsigned)((__ballot(on) >> lane0) & gmask);
   }
-  GROUP_SYNC();
-  PHASE_MARK(18);
-  // fold.  The box lane first: its own contacts (corners ascending), then the consistent law of every active pair slot
-  // (pair_law) into the pair records; after the hand-off the articulation's lanes fold theirs, shapes ascending.
-  if (l == nb + kd) {
+  BM.spheres = (unsigned)((__ballot(on) >> F::lane0(l)) & F::gmask());
+}
+// fold, the box lane: its own contacts (corners ascending, terrain before boxes) ...
+template <int G, class SC>
+DEV void fixed_box_fold(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, const BoxMasks& BM) {
+  typedef FixedSceneConsts<G, SC> F;
+  const ShfModel* m = C.m;
+  if (l == m->nb + F::kd) {
     unsigned pl = BM.cplane;
     unsigned long long bx = BM.cbox;
-    unsigned sb = BM.spheres;
     int c, tg;
-    while (corner_next<NO, kd>(pl, bx, &c, &tg))
-      slot_accumulate(B.IA, B.pA, L.pt + corner_slot(m, nbx, kd, c, tg) * PT_STRIDE, 1.0f, dt, 1.0f);
+    while (corner_next<F::NO, F::kd>(pl, bx, &c, &tg))
+      slot_accumulate(B.IA, B.pA, L.pt + corner_slot(m, F::nbx, F::kd, c, tg) * PT_STRIDE, 1.0f, C.sp.dt, 1.0f);
   }
-  PHASE_MARK(20);
-  if (l == nb + kd) {
-    unsigned sb = BM.spheres;
+}
+// ... then the consistent law of every active pair slot (pair_law) into the pair records, by the lane `mine` that holds
+// (or has read) the box's folded (IA, pA)
+template <int G, class SC>
+DEV void fixed_pair_laws(const StepCtx& C, const EnvLds& L, bool mine, const float* IA, const float* pA, unsigned spheres) {
+  typedef FixedSceneConsts<G, SC> F;
+  const ShfModel* m = C.m;
+  if (mine) {
+    unsigned sb = spheres;
     if (sb) {
       float afree[6];
-      ldlt_solve6(B.IA, B.pA, afree);
+      ldlt_solve6(IA, pA, afree);
       const float nshare = (float)__builtin_popcount(sb);
       while (sb) {
         const int si = __builtin_ctz(sb);
         sb &= sb - 1u;
-        pair_law(B.IA, afree, L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE, nshare);
+        pair_law(IA, afree, L.pt + sphere_slot(m, F::nbx, si, F::kd) * PT_STRIDE, C.sp.dt,
+                 L.pt + pair_slot(m, F::nbx, si, F::kd) * PT_STRIDE, nshare);
       }
     }
   }
-  PHASE_MARK(21);
-  GROUP_SYNC();
-  PHASE_MARK(22);
-  if (l < nb && m->dyn[l] == l) {
-    unsigned bits = BM.spheres & BL.sph_dyn;
+}
+// after the hand-off the articulation's lanes fold their pair records, shapes ascending
+template <int G, class SC>
+DEV void fixed_arm_fold(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, const BoxLane& BL, unsigned spheres) {
+  typedef FixedSceneConsts<G, SC> F;
+  const ShfModel* m = C.m;
+  if (l < m->nb && m->dyn[l] == l) {
+    unsigned bits = spheres & BL.sph_dyn;
     while (bits) {
       const int si = __builtin_ctz(bits);
       bits &= bits - 1u;
-      const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
+      const float* o = L.pt + sphere_slot(m, F::nbx, si, F::kd) * PT_STRIDE;
       const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]};
-      float F[3], K[9];
-      pair_unpack(L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE, F, K);
-      pair_accumulate(B.IA, B.pA, r, F, K, dt);
+      float Fp[3], K[9];
+      pair_unpack(L.pt + pair_slot(m, F::nbx, si, F::kd) * PT_STRIDE, Fp, K);
+      pair_accumulate(B.IA, B.pA, r, Fp, K, C.sp.dt);
     }
   }
+}
+template <int G, class SC>
+DEV void boxes_contacts_fixed(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, float mu_shape, const float* g_art,
+                              const BoxLane& BL, BoxMasks& BM) {
+  PHASE_BEGIN();
+  fixed_corner_slots<G, SC>(C, L, l, BM);
+  PHASE_MARK(17);
+  fixed_sphere_slots<G, SC>(C, L, l, mu_shape, g_art, BM);
+  GROUP_SYNC();
+  PHASE_MARK(18);
+  fixed_box_fold<G, SC>(C, L, l, B, BM);
+  PHASE_MARK(20);
+  fixed_pair_laws<G, SC>(C, L, l == C.m->nb + SC::DYN, B.IA, B.pA, BM.spheres);
+  PHASE_MARK(21);
+  GROUP_SYNC();
+  PHASE_MARK(22);
+  fixed_arm_fold<G, SC>(C, L, l, B, BL, BM.spheres);
   PHASE_MARK(23);
 }
 
@@ -1060,7 +1105,9 @@ DEV void link_force(const StepCtx& C, const EnvLds& L, int link_slot0, int k, fl
   }
 }
 
-template <int G, class SC>
+// PART: 1 = the boxes' lanes (pair forces, solve, their contact rows, integration), 2 = the articulation's contact rows,
+// 3 = both (one wave does everything).
+template <int G, class SC, int PART = 3>
 DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, float* contact_out, const BoxLane& BL,
                       const BoxMasks& BM, int link_slot0 = 0) {
   const ShfModel* m = C.m;
@@ -1071,7 +1118,7 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
   const bool isbox = kd >= 0 && kd < nbx;
   const bool dynbox = isbox && box_is_dynamic(S->box[kd]);
   float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-  if (dynbox) {
+  if ((PART & 1) && dynbox) {
     // the articulation's solved acceleration fixes every pair force; the box receives exactly its opposite, then solves
     unsigned sb;
     if constexpr (SC::NBX > 0) sb = BM.spheres; else sb = box_sphere_flags(m, L, nbx, kd);
@@ -1101,7 +1148,7 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
     ldlt_solve6(B.IA, B.pA, a);
   }
   if (contact_out) {
-    if (l < nb) {
+    if ((PART & 2) && l < nb) {
       float f[3] = {contact_out[3 * l], contact_out[3 * l + 1], contact_out[3 * l + 2]};
       const float* ab = L.acc + m->dyn[l] * 6;
       const float abr[6] = {ab[0], ab[1], ab[2], ab[3], ab[4], ab[5]};
@@ -1132,7 +1179,7 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
       }
       contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];
     }
-    if (isbox) {
+    if ((PART & 1) && isbox) {
       float f[3] = {0.0f, 0.0f, 0.0f};
       if (dynbox) {
         unsigned sb;
@@ -1175,7 +1222,7 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
       contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];
     }
   }
-  if (dynbox) {
+  if ((PART & 1) && dynbox) {
     float* row = L.root + 13 * (1 + kd);
     const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
     const float ang[3] = {row[10], row[11], row[12]}, lin[3] = {row[7], row[8], row[9]}, al[3] = {a[0], a[1], a[2]};

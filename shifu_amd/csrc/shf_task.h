@@ -28,29 +28,30 @@ struct SimArgs {
 // Cooperative global -> LDS copy of a fixed-size parameter block by the 256 threads of a block: all loads
 // are issued before the first store (one memory round trip instead of one per loop iteration).
 // Both pointers are 16-byte aligned (device allocations; LDS offsets are multiples of 4 words).
-template <int NBYTES>
+template <int NBYTES, int THREADS = 256>
 DEV void stage_block(const void* gsrc, float* ldst) {
-  constexpr int NV = NBYTES / 16, NT = (NBYTES % 16) / 4, IV = (NV + 255) / 256;
+  constexpr int NV = NBYTES / 16, NT = (NBYTES % 16) / 4, IV = (NV + THREADS - 1) / THREADS;
   const uint4* src = reinterpret_cast<const uint4*>(gsrc);
   uint4* dst = reinterpret_cast<uint4*>(ldst);
   uint4 v[IV > 0 ? IV : 1];
   uint32_t tail = 0;
 #pragma unroll
   for (int k = 0; k < IV; k++) {
-    const int i = (int)threadIdx.x + k * 256;
+    const int i = (int)threadIdx.x + k * THREADS;
     v[k] = src[i < NV ? i : 0];
   }
   if (NT > 0 && (int)threadIdx.x < NT) tail = reinterpret_cast<const uint32_t*>(gsrc)[NV * 4 + threadIdx.x];
 #pragma unroll
   for (int k = 0; k < IV; k++) {
-    const int i = (int)threadIdx.x + k * 256;
+    const int i = (int)threadIdx.x + k * THREADS;
     if (i < NV) dst[i] = v[k];
   }
   if (NT > 0 && (int)threadIdx.x < NT) reinterpret_cast<uint32_t*>(ldst)[NV * 4 + threadIdx.x] = tail;
 }
 // the flattened articulation
+template <int THREADS = 256>
 DEV const ShfModel* stage_model(const ShfModel* gm, float* smem) {
-  stage_block<(int)sizeof(ShfModel)>(gm, smem);
+  stage_block<(int)sizeof(ShfModel), THREADS>(gm, smem);
   __syncthreads();
   return reinterpret_cast<const ShfModel*>(smem);
 }
@@ -59,8 +60,9 @@ DEV const ShfModel* stage_model(const ShfModel* gm, float* smem) {
 
 #define SCENE_WORDS ((int)((sizeof(ShfScene) / 4 + 3) & ~3))
 
+template <int THREADS = 256>
 DEV const ShfScene* stage_scene(const ShfScene* gs, float* dst_words) {
-  stage_block<(int)sizeof(ShfScene)>(gs, dst_words);
+  stage_block<(int)sizeof(ShfScene), THREADS>(gs, dst_words);
   return reinterpret_cast<const ShfScene*>(dst_words);
 }
 

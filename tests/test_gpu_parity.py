@@ -481,8 +481,8 @@ _ABB_T = {"actions": _abi.ABB_ACTIONS, "obs": _abi.ABB_OBS, "rew": _abi.ABB_REW,
           "done_sums": _abi.ABB_DONE_SUMS}
 
 
-@pytest.mark.parametrize("group,generic", [(64, False), (32, False), (16, False), (32, "levels"), (16, "levels"), (32, True), (64, True),
-                                           (32, "link"), (64, "link")])
+@pytest.mark.parametrize("group,generic", [(64, False), (32, False), (16, False), (16, "chain"), (32, "levels"), (16, "levels"), (32, True),
+                                           (64, True), (32, "link"), (64, "link")])
 def test_fused_abb_step_matches_oracle_bitwise(oracle, group, generic):
     """ShifuVecEnv.step for AbbPushBox (config 5): in-kernel damped-least-squares IK on the Jacobian
     tensor, 6 sub-steps with implicit POS drives and box contacts, refresh, termination, rewards,
@@ -499,11 +499,15 @@ def test_fused_abb_step_matches_oracle_bitwise(oracle, group, generic):
     # "levels": the compile-time arm and scene on the level-by-level sub-step (mapping 'body'); False at 16 / 32 lanes takes
     # the default, the arm's recursions on one lane (csrc/shf_arm.h)
     levels = generic == "levels"
+    # False at 16 lanes takes the default there: arm and boxes of an env on different waves of the workgroup
+    # (k_abb_step_ws, mapping 'split'); "chain": the one-wave form of the same at 16 lanes
+    chain = generic == "chain"
+    split = generic is False and group == 16
     generic = generic is True or link
     extra = [box_desc([0.05, 0.05, 0.02], 0.0, 0.5, True, [0.25, 0.25, 0.11])] if (generic and not link) else []
-    env = FusedAbbEnv(num_envs=n, seed=11, group=group, extra_boxes=extra, link_contacts=link, mapping="body" if levels else None)
-    assert env.mapping == ("chain" if (not generic and not levels and group < 64) else "body")
-    assert ("FixedDims" in env.task.kernel_symbol()) != bool(generic)
+    env = FusedAbbEnv(num_envs=n, seed=11, group=group, extra_boxes=extra, link_contacts=link, mapping="body" if levels else ("chain" if chain else None))
+    assert env.mapping == ("split" if split else "chain" if (not generic and not levels and group < 64) else "body")
+    assert ("FixedDims" in env.task.kernel_symbol() or split) != bool(generic)
     assert env.task.kernel_symbol().endswith("Li6EE") == (env.mapping == "chain")
     env.task.tensors[_abi.ABB_EP_LEN].copy_(torch.randint(0, 200, (n,)))   # staggered time-outs
     torch.cuda.synchronize()

@@ -33,7 +33,8 @@ def main():
     abb = "--abb" in sys.argv
     chain = "--chain" in sys.argv     # the chain-per-lane A1 step (csrc/shf_chain.h); G = 16 or 32
     levels = "--levels" in sys.argv   # --abb: the level-by-level sub-step instead of the arm's recursions on one lane
-    argv = [a for a in sys.argv if a not in ("--abb", "--chain", "--levels")]
+    split = "--split" in sys.argv     # --abb: arm and boxes on different waves (k_abb_step_ws); marks 24-29 are the arm wave's
+    argv = [a for a in sys.argv if a not in ("--abb", "--chain", "--levels", "--split")]
     G = int(argv[1]) if len(argv) > 1 else 32
     steps = int(argv[2]) if len(argv) > 2 else 100
     from shifu_amd import build as b
@@ -46,7 +47,7 @@ def main():
     from shifu_amd.gym.a1_fused import FusedA1Env
     from shifu_amd.gym.abb_fused import FusedAbbEnv
     # --abb: the sub-step phases (0-10) of the push-box env; its kernel has no marks outside the sub-steps
-    env = (FusedAbbEnv(num_envs=4096, group=G, mapping="body" if levels else None) if abb else
+    env = (FusedAbbEnv(num_envs=4096, group=G, mapping="body" if levels else ("split" if split else "chain")) if abb else
            FusedA1Env(num_envs=4096, group=G, mapping="chain" if chain else "body"))
     if chain:
         NAMES[1] = "chain: kinematics + inertias"; NAMES[0] = NAMES[2] = NAMES[5] = "(unused on the chain mapping)"
@@ -66,9 +67,9 @@ def main():
         env.step(act.uniform_(-1, 1))
     torch.cuda.synchronize()
     assert fn(buf, 32, 0) == 0
-    tot = sum(buf[:17])  # (marks 17-19: inside phase 4 for the box scene)
+    tot = sum(buf[:17]) if not split else sum(buf[11:17]) + sum(buf[24:30])  # (marks 17-23: inside phase 4 for the box scene)
     print(f"G={G}: {tot / steps:.0f} cycles per env-step in block 0 / wave 0 (s_memtime ticks)")
-    for k, nme in enumerate(NAMES + ['box: corner slots', 'box: sphere slots', 'box: fold', 'fold: box lane corners', 'fold: pair law', 'fold: sync', 'fold: arm lanes']):
+    for k, nme in enumerate(NAMES + ['box: corner slots', 'box: sphere slots', 'box: fold', 'fold: box lane corners', 'fold: pair law', 'fold: sync', 'fold: arm lanes', 'split: arm wave before S1', 'split: wait at S1', 'split: arm wave S1 -> S4', 'split: wait at S4', 'split: arm wave after S4', 'split: final barrier']):
         print(f"  {k:2d} {nme:34s} {buf[k] / steps:9.0f}  {100.0 * buf[k] / tot:5.1f} %")
 
 
