@@ -150,8 +150,9 @@ DEV void mat3_inv(const float* A, float* Ai) {
   Ai[6] = c02 * id; Ai[7] = fmaf(A[1], A[6], -(A[0] * A[7])) * id; Ai[8] = fmaf(A[0], A[4], -(A[1] * A[3])) * id;
 }
 // box lane: IA / pA = the box with its own contacts folded, afree = its solve; o = the pair slot; pr = the pair record
-// nshare: the number of pair slots active on this box (each sees 1 / n of it: its compliance times n; oracle boxes_pre)
-DEV void pair_law(const float* IA, const float* afree, const float* o, float dt, float* pr, float nshare = 1.0f) {
+// rsum, nshare: sum of the contact points and number of the pair slots active on this box -- each slot is eliminated as if
+// the others pushed with the same force as itself (mass splitting with the true geometry; oracle boxes_pre)
+DEV void pair_law(const float* IA, const float* afree, const float* o, float dt, float* pr, const float* rsum, float nshare) {
   const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]}, n[3] = {o[PT_N], o[PT_N + 1], o[PT_N + 2]};
   const float ct = o[PT_CT], bn = o[PT_BN];
   float W[9], cfree[3];
@@ -159,13 +160,13 @@ DEV void pair_law(const float* IA, const float* afree, const float* o, float dt,
   for (int k = 0; k < 3; k++) {
     const float e[3] = {k == 0 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 2 ? 1.0f : 0.0f};
     float t[3], rhs[6], y[6], wp[3];
-    cross3(r, e, t);
+    cross3(rsum, e, t);
 #pragma unroll
-    for (int i = 0; i < 3; i++) { rhs[i] = -t[i]; rhs[3 + i] = -e[i]; }
+    for (int i = 0; i < 3; i++) { rhs[i] = -t[i]; rhs[3 + i] = -(e[i] * nshare); }
     ldlt_solve6(IA, rhs, y);
     pair_point_accel(y, r, wp);
 #pragma unroll
-    for (int i = 0; i < 3; i++) W[3 * i + k] = wp[i] * nshare;
+    for (int i = 0; i < 3; i++) W[3 * i + k] = wp[i];
   }
   pair_point_accel(afree, r, cfree);
   float K[9], Mx[9], S[9], g0[3], Ke[9];
@@ -901,11 +902,17 @@ DEV void fixed_pair_laws(const StepCtx& C, const EnvLds& L, bool mine, const flo
       float afree[6];
       ldlt_solve6(IA, pA, afree);
       const float nshare = (float)__builtin_popcount(sb);
+      float rsum[3] = {0.0f, 0.0f, 0.0f};
+      for (unsigned bb = sb; bb; bb &= bb - 1u) {
+        const float* o = L.pt + sphere_slot(m, F::nbx, __builtin_ctz(bb), F::kd) * PT_STRIDE;
+#pragma unroll
+        for (int i = 0; i < 3; i++) rsum[i] += o[PT_R + i];
+      }
       while (sb) {
         const int si = __builtin_ctz(sb);
         sb &= sb - 1u;
         pair_law(IA, afree, L.pt + sphere_slot(m, F::nbx, si, F::kd) * PT_STRIDE, C.sp.dt,
-                 L.pt + pair_slot(m, F::nbx, si, F::kd) * PT_STRIDE, nshare);
+                 L.pt + pair_slot(m, F::nbx, si, F::kd) * PT_STRIDE, rsum, nshare);
       }
     }
   }
@@ -1047,15 +1054,26 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
       float afree[6];
       ldlt_solve6(B.IA, B.pA, afree);
       const float nshare = (float)(__builtin_popcount(sb) + __builtin_popcount(lb));
+      float rsum[3] = {0.0f, 0.0f, 0.0f};
+      for (unsigned bb = sb; bb; bb &= bb - 1u) {
+        const float* o = L.pt + sphere_slot(m, nbx, __builtin_ctz(bb), kd) * PT_STRIDE;
+#pragma unroll
+        for (int i = 0; i < 3; i++) rsum[i] += o[PT_R + i];
+      }
+      for (unsigned bb = lb; bb; bb &= bb - 1u) {
+        const float* o = L.pt + (link_slot0 + __builtin_ctz(bb)) * PT_STRIDE;
+#pragma unroll
+        for (int i = 0; i < 3; i++) rsum[i] += o[PT_R + i];
+      }
       while (sb) {
         const int si = __builtin_ctz(sb);
         sb &= sb - 1u;
-        pair_law(B.IA, afree, L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE, nshare);
+        pair_law(B.IA, afree, L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE, rsum, nshare);
       }
       while (lb) {
         const int k = __builtin_ctz(lb);
         lb &= lb - 1u;
-        pair_law(B.IA, afree, L.pt + (link_slot0 + k) * PT_STRIDE, dt, L.pt + (link_slot0 + SHF_MAX_LINK_CONTACTS + k) * PT_STRIDE, nshare);
+        pair_law(B.IA, afree, L.pt + (link_slot0 + k) * PT_STRIDE, dt, L.pt + (link_slot0 + SHF_MAX_LINK_CONTACTS + k) * PT_STRIDE, rsum, nshare);
       }
     }
   }
