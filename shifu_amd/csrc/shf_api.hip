@@ -417,7 +417,8 @@ DEV void abb_reset_env(const ShfAbbTaskParams& tp, int nd, int nbx, int64_t gid,
 
 // AbbRobot.step (shifu/units/robot.py:103-160) on one lane: EE-delta -> clip -> damped least squares on the Jacobian tensor
 // (possibly stale pose) -> POS targets of this env step (tgtl: LDS; also written to the dof_targets tensor)
-DEV void abb_ik_targets(const AbbArgs& A, const ShfAbbTaskParams& tp, const EnvLds& L, int e, int nd, const float* bstate,
+// q, qstride: the joint positions (LDS dof block, DOF_STRIDE; or this env's rows of the dof_state tensor, 2)
+DEV void abb_ik_targets(const AbbArgs& A, const ShfAbbTaskParams& tp, const float* q, int qstride, int e, int nd, const float* bstate,
                         const float* jac, float* tgtl) {
     float act[3], dpose[6], eq[4], cc[4], qr[4];
     const float* ee = bstate + 13 * tp.ee_body;
@@ -455,21 +456,22 @@ DEV void abb_ik_targets(const AbbArgs& A, const ShfAbbTaskParams& tp, const EnvL
       float u = J[d] * x[0];
 #pragma unroll
       for (int k = 1; k < 6; k++) u = fmaf(J[k * nd + d], x[k], u);
-      const float t = L.dofb[d * DOF_STRIDE] + u;
+      const float t = q[d * qstride] + u;
       tgtl[d] = t;
       A.dof_targets[(size_t)e * nd + d] = t;
     }
   }
 
 // Everything of the AbbPushBox env step after the sub-steps: contact-force copy-out, state refresh (body states, Jacobian),
-// post_step on one lane (env.py:93-106, a_prior_stage.py:97-135), statistics, state stores.
+// then abb_post_step.
+template <int G, class DM>
+DEV void abb_post_step(const AbbArgs& A, const ShfAbbTaskParams& tp, const ShfModel* m, const EnvLds& L, float* rootl, int l, int e,
+                       int epb, int nbx, float* tgtl, float* stats_lds, unsigned long long stats_step);
 template <int G, class DM>
 DEV void abb_after_physics(const AbbArgs& A, const ShfAbbTaskParams& tp, const ShfModel* m, const EnvLds& L, int l, int e, int epb,
                            int nbx, float* tgtl, float* stats_lds, unsigned long long stats_step) {
-  const int n = A.S.n, actors = 1 + nbx;
+  const int actors = 1 + nbx;
   const int nb = DM::nb(m), nd = DM::nd(m), nbt = nb + nbx;
-  float* dof = A.S.dof + (size_t)e * nd * 2;
-  float* root = A.S.root + (size_t)e * actors * 13;
   float* bstate = A.body_state + (size_t)e * nbt * 13;
   float* jac = A.jacobian + (size_t)e * (nb - 1) * 6 * nd;
   PHASE_BEGIN();
@@ -478,13 +480,25 @@ DEV void abb_after_physics(const AbbArgs& A, const ShfAbbTaskParams& tp, const S
   GROUP_SYNC();
   refresh_body_jac<G, DM>(m, L, l, actors, bstate, jac, tgtl + nd, tp.ee_body);
   PHASE_MARK(13);
-
+  abb_post_step<G, DM>(A, tp, m, L, L.root, l, e, epb, nbx, tgtl, stats_lds, stats_step);
+}
+// post_step on one lane (env.py:93-106, a_prior_stage.py:97-135), statistics, state stores.  tgtl[nd], tgtl[nd + 1]: this
+// step's end-effector x, y.  rootl: the root-state rows in LDS that a reset rewrites and the stores read (L.root, or a
+// private copy when another wave still reads L.root).
+template <int G, class DM>
+DEV void abb_post_step(const AbbArgs& A, const ShfAbbTaskParams& tp, const ShfModel* m, const EnvLds& L, float* rootl, int l, int e,
+                       int epb, int nbx, float* tgtl, float* stats_lds, unsigned long long stats_step) {
+  const int n = A.S.n, actors = 1 + nbx;
+  const int nd = DM::nd(m);
+  float* dof = A.S.dof + (size_t)e * nd * 2;
+  float* root = A.S.root + (size_t)e * actors * 13;
+  PHASE_BEGIN();
   // post_step on one lane (env.py:93-106, a_prior_stage.py:97-135)
   unsigned long long* stats_row = nullptr;
   if (l == 0) {
     int64_t ep = A.ep_len[e] + 1;
-    const float* cube = L.root + 13 * tp.cube_actor;
-    const float* goal = L.root + 13 * tp.goal_actor;
+    const float* cube = rootl + 13 * tp.cube_actor;
+    const float* goal = rootl + 13 * tp.goal_actor;
     // this step's ee position, parked in LDS by refresh_body_jac
     const float eex = tgtl[nd], eey = tgtl[nd + 1];
     const int timeout = (float)ep > tp.max_episode_length;
@@ -506,7 +520,7 @@ DEV void abb_after_physics(const AbbArgs& A, const ShfAbbTaskParams& tp, const S
     if (reset) {
       done[0] = sums[0]; done[1] = sums[1]; done[2] = success ? 1.0f : 0.0f; done[3] = 1.0f;
       sums[0] = sums[1] = 0.0f;
-      abb_reset_env(tp, nd, nbx, A.env_off + e, (uint32_t)A.reset_count[e], L.dofb, L.root);
+      abb_reset_env(tp, nd, nbx, A.env_off + e, (uint32_t)A.reset_count[e], L.dofb, rootl);
       ep = 0;
       A.reset_count[e] += 1;
     }
@@ -522,8 +536,8 @@ DEV void abb_after_physics(const AbbArgs& A, const ShfAbbTaskParams& tp, const S
     }
     const float co = tp.clip_obs;
     float* o = A.obs + (size_t)e * 6;
-    o[0] = rclampf(L.root[13 * tp.cube_actor], -co, co); o[1] = rclampf(L.root[13 * tp.cube_actor + 1], -co, co);
-    o[2] = rclampf(L.root[13 * tp.goal_actor], -co, co); o[3] = rclampf(L.root[13 * tp.goal_actor + 1], -co, co);
+    o[0] = rclampf(rootl[13 * tp.cube_actor], -co, co); o[1] = rclampf(rootl[13 * tp.cube_actor + 1], -co, co);
+    o[2] = rclampf(rootl[13 * tp.goal_actor], -co, co); o[3] = rclampf(rootl[13 * tp.goal_actor + 1], -co, co);
     o[4] = rclampf(eex, -co, co); o[5] = rclampf(eey, -co, co);
   }
   GROUP_SYNC();
@@ -531,7 +545,7 @@ DEV void abb_after_physics(const AbbArgs& A, const ShfAbbTaskParams& tp, const S
   unsigned long long stats_tk = 0ull;
   if (l == 0) stats_tk = stats_ticket(stats_row);
   for (int i = l; i < 2 * nd; i += G) dof[i] = L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)];
-  for (int i = l; i < 13 * actors; i += G) root[i] = L.root[i];
+  for (int i = l; i < 13 * actors; i += G) root[i] = rootl[i];
   if (l == 0) {
     const float Ts = tp.max_episode_length_s;
     stats_finish<4>(A.stats, stats_row, stats_tk, stats_step, [n, Ts](const long long* t, float* o) {
@@ -590,7 +604,7 @@ __global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
   GROUP_SYNC();
 
   // AbbRobot.step: EE-delta -> clip -> damped least squares on the Jacobian tensor (possibly stale pose)
-  if (l == 0) abb_ik_targets(A, tp, L, e, nd, bstate, jac, tgtl);
+  if (l == 0) abb_ik_targets(A, tp, L.dofb, DOF_STRIDE, e, nd, bstate, jac, tgtl);
   GROUP_SYNC();
   PHASE_MARK(11);
 
@@ -665,11 +679,12 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
     const float* root = A.S.root + (size_t)e * actors * 13;
     for (int i = l; i < 2 * nd; i += G) L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)] = dof[i];
     for (int i = l; i < 13 * actors; i += G) L.root[i] = root[i];
-    GROUP_SYNC();
-    if (l == 0) abb_ik_targets(A, tp, L, e, nd, A.body_state + (size_t)e * nbt * 13, A.jacobian + (size_t)e * (nb - 1) * 6 * nd, tgtl);
-    GROUP_SYNC();
   }
-  __syncthreads();                               // S0: the box wave sees the root rows
+  // AbbRobot.step's inverse kinematics on the box wave, beside the arm wave's loads (it reads the tensors directly)
+  if (!arm && live && l == 0)
+    abb_ik_targets(A, tp, A.S.dof + (size_t)e * nd * 2, 2, e, nd, A.body_state + (size_t)e * nbt * 13,
+                   A.jacobian + (size_t)e * (nb - 1) * 6 * nd, tgtl);
+  __syncthreads();                               // S0: root rows and POS targets visible to both
   PHASE_MARK(11);
 
   StepCtx C;
@@ -750,8 +765,70 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
   PHASE_MARK(28);
   __syncthreads();                               // the boxes' final root rows and contact rows are in LDS
   PHASE_MARK(29);
-  if (!arm || !live) return;
-  abb_after_physics<G, DM>(A, tp, m, L, l, e, EPB, nbx, tgtl, stats_lds, stats_step);
+  // State refresh and post_step, again side by side: the arm wave composes the end-of-step poses and goes on to post_step,
+  // the box wave turns them into the rigid-body-state rows and the Jacobian tensor (gym.refresh_rigid_body_state_tensor /
+  // refresh_jacobian_tensors: the values refresh_body_jac writes, from the same poses and motion subspaces).
+  float* bstate = A.body_state + (size_t)(live ? e : 0) * nbt * 13;
+  if (live && arm) {
+    for (int i = l; i < 3 * nbt; i += G) A.S.contact[(size_t)e * nbt * 3 + i] = L.xch[i];
+    GROUP_SYNC();
+    AL.joints();
+    GROUP_SYNC();
+    AL.compose();
+    if (l == 0) {
+      const float* pe = L.pose + tp.ee_body * POSE_STRIDE;
+      tgtl[nd] = L.root[0] + pe[9]; tgtl[nd + 1] = L.root[1] + pe[10];
+    }
+    GROUP_SYNC();
+  }
+  __syncthreads();
+  if (!live) return;
+  if (arm) {
+    // a reset rewrites the root rows while the box wave still copies them out: post_step works on a private copy (the
+    // contact slots are free by now)
+    float* rootl = L.pt;
+    for (int i = l; i < 13 * actors; i += G) rootl[i] = L.root[i];
+    GROUP_SYNC();
+    abb_post_step<G, DM>(A, tp, m, L, rootl, l, e, EPB, nbx, tgtl, stats_lds, stats_step);
+    return;
+  }
+  if (l < nb) {
+    const float* pb = L.pose + l * POSE_STRIDE;
+    float Rw[9], p[3], v[6], t[3], q[4];
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rw[k] = pb[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) p[k] = pb[9 + k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) v[k] = pb[12 + k];
+    float* o = L.xch + 13 * l;
+#pragma unroll
+    for (int k = 0; k < 3; k++) o[k] = L.root[k] + p[k];
+    mat_to_quat(Rw, q);
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[3 + k] = q[k];
+    cross3(v, p, t);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { o[7 + k] = v[3 + k] + t[k]; o[10 + k] = v[k]; }
+  }
+  GROUP_SYNC();
+  for (int i = l; i < 13 * nb; i += G) bstate[i] = L.xch[i];
+  for (int i = l; i < 13 * (actors - 1); i += G) bstate[nb * 13 + i] = L.root[13 + i];
+  if (l >= 1 && l < nb) {
+    float* J = A.jacobian + (size_t)e * (nb - 1) * 6 * nd + (size_t)(l - 1) * 6 * nd;
+    const float* pb = L.pose + l * POSE_STRIDE;
+    const float p[3] = {pb[9], pb[10], pb[11]};
+    for (int k = 0; k < 6 * nd; k++) J[k] = 0.0f;
+    for (int b = l; b > 0; b--) {
+      const float* S = krec + (b - 1) * KREC_STRIDE;
+      const float ax[3] = {S[0], S[1], S[2]};
+      const int d = b - 1;
+      float t[3];
+      cross3(ax, p, t);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { J[k * nd + d] = t[k] + S[3 + k]; J[(3 + k) * nd + d] = S[k]; }
+    }
+  }
 }
 
 __global__ void k_abb_reset_all(AbbArgs A) {

@@ -60,8 +60,7 @@ struct ArmLane {
 
   // A. joint lanes: local rotation -> the link's exchange slot (free until its (IA, pA) go there); dof lanes: drive
   //    effort.  pos_tgt: LDS, POS-drive targets of this env step.  A group sync has to follow.
-  DEV void joints_and_drives(const float* pos_tgt) const {
-    const float dt = C.sp.dt;
+  DEV void joints() const {
     if (islink) {
       const int d = l - 1;
       float* rec = L.xch + l * XCH_STRIDE;
@@ -71,6 +70,10 @@ struct ArmLane {
       for (int k = 0; k < 9; k++) rec[k] = Rl[k];
       rec[9] = L.dofb[d * DOF_STRIDE + 1];
     }
+  }
+  DEV void joints_and_drives(const float* pos_tgt) const {
+    const float dt = C.sp.dt;
+    joints();
     if (l < nd) {
       float* D = L.dofb + l * DOF_STRIDE;
       const float q = D[0], qd = D[1];
