@@ -569,7 +569,7 @@ DEV void abb_post_step(const AbbArgs& A, const ShfAbbTaskParams& tp, const ShfMo
 #define SHF_ARM_MAX_LINKS 8
 #define ABB_TAIL_WORDS(nslots) ((nslots) * PT_STRIDE + SHF_MAX_DOFS + ARM_KREC_WORDS(SHF_ARM_MAX_LINKS))
 template <int G, class DM, class SC, bool LINK = false, int ARM = 0>
-__global__ __launch_bounds__(256) void k_abb_step(AbbArgs A) {
+__global__ __launch_bounds__(256, (G >= 32 && SC::NBX > 0) ? 2 : 1) void k_abb_step(AbbArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   PHASE_BEGIN();
   float* stats_lds = smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS;

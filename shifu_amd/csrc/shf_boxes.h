@@ -1033,10 +1033,11 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
     slot_eval(o, phi, n, rc, vrs, vrel, 0.5f * (mu_shape + bd.friction), kc, beta, veps, vdep, dt, offset);
   }
   int nlink = 0;
+  PHASE_MARK(18);
   if constexpr (LINK) nlink = link_contacts<G>(C, L, l, link_slot0, mu_shape, g_art);
   BM.nlink = nlink;
   GROUP_SYNC();
-  PHASE_MARK(18);
+  PHASE_MARK(20);
   // fold (as the fixed-scene path: box lanes first, with the pair laws; then the articulation's lanes)
   const int kd = l - nb;
   if (kd >= 0 && kd < nbx && box_is_dynamic(S->box[kd])) {

@@ -34,7 +34,8 @@ def main():
     chain = "--chain" in sys.argv     # the chain-per-lane A1 step (csrc/shf_chain.h); G = 16 or 32
     levels = "--levels" in sys.argv   # --abb: the level-by-level sub-step instead of the arm's recursions on one lane
     split = "--split" in sys.argv     # --abb: arm and boxes on different waves (k_abb_step_ws); marks 24-29 are the arm wave's
-    argv = [a for a in sys.argv if a not in ("--abb", "--chain", "--levels", "--split")]
+    link = "--link" in sys.argv       # --abb: with link contacts (the run-time-shaped kernel)
+    argv = [a for a in sys.argv if a not in ("--abb", "--chain", "--levels", "--split", "--link")]
     G = int(argv[1]) if len(argv) > 1 else 32
     steps = int(argv[2]) if len(argv) > 2 else 100
     from shifu_amd import build as b
@@ -47,7 +48,7 @@ def main():
     from shifu_amd.gym.a1_fused import FusedA1Env
     from shifu_amd.gym.abb_fused import FusedAbbEnv
     # --abb: the sub-step phases (0-10) of the push-box env; its kernel has no marks outside the sub-steps
-    env = (FusedAbbEnv(num_envs=4096, group=G, mapping="body" if levels else ("split" if split else "chain")) if abb else
+    env = (FusedAbbEnv(num_envs=4096, group=G, link_contacts=link, mapping="body" if (levels or link) else ("split" if split else "chain")) if abb else
            FusedA1Env(num_envs=4096, group=G, mapping="chain" if chain else "body"))
     if chain:
         NAMES[1] = "chain: kinematics + inertias"; NAMES[0] = NAMES[2] = NAMES[5] = "(unused on the chain mapping)"
