@@ -546,6 +546,43 @@ def test_ragged_env_counts(oracle, n, group):
     _compare(sim, task, bufs, f"n={n}")
 
 
+@pytest.mark.parametrize("mapping,group", [("split", 16), ("chain", 16), ("chain", 32)])
+@pytest.mark.parametrize("n", [1, 5, 13])
+def test_ragged_env_counts_abb(oracle, n, mapping, group):
+    """The fused ABB step with env counts that leave lanes -- and, in the two-wave kernel, whole waves -- without an env
+    (8 envs per workgroup there: the waves of dead envs still have to meet every workgroup barrier)."""
+    _need_gpu()
+    from shifu_amd.gym.abb_fused import FusedAbbEnv
+    env = FusedAbbEnv(num_envs=n, seed=17 + n, group=group, mapping=mapping)
+    assert env.mapping == mapping
+    bufs = {k: env.sim.tensors[t].cpu().numpy().copy() for k, t in _ABB_SIM_T.items()}
+    bufs.update({k: env.task.tensors[t].cpu().numpy().copy() for k, t in _ABB_T.items()})
+    rng = np.random.default_rng(n)
+    for it in range(12):
+        raw = (2 * rng.random((n, 3)) - 1).astype(np.float32)
+        env.task.step(torch.from_numpy(raw).cuda())
+        oracle.abb_step(env.cm.blob, env.sim_params, env.boxes, env.task_params, n, 0, bufs, raw)
+    torch.cuda.synchronize()
+    for k, t in list(_ABB_SIM_T.items()) + list(_ABB_T.items()):
+        got = (env.sim.tensors if k in _ABB_SIM_T else env.task.tensors)[t].cpu().numpy().reshape(bufs[k].shape)
+        np.testing.assert_array_equal(got, bufs[k], err_msg=f"{k} n={n}")
+
+
+def test_split_mapping_is_refused_for_other_shapes():
+    """SHF_MAP_CHAIN_SPLIT is compiled for the ABB arm in its scene: the A1 is refused when the mapping is set, the ABB with a
+    fourth box at its first step -- loudly, not by falling back."""
+    _need_gpu()
+    from shifu_amd._lib import BackendError
+    from shifu_amd.abb_task import box_desc
+    from shifu_amd.gym.a1_fused import FusedA1Env
+    from shifu_amd.gym.abb_fused import FusedAbbEnv
+    with pytest.raises(BackendError, match="split chain mapping"):
+        FusedA1Env(num_envs=8, group=16, mapping="split")
+    env = FusedAbbEnv(num_envs=8, group=16, mapping="split", extra_boxes=[box_desc([0.05, 0.05, 0.02], 0.0, 0.5, True, [0.25, 0.25, 0.11])])
+    with pytest.raises(BackendError, match="chain mapping needs"):
+        env.task.step(torch.zeros(8, 3, device="cuda"))
+
+
 @pytest.mark.parametrize("group", [32, "chain"])
 def test_full_size_determinism_and_shard_invariance(group):
     """BASELINE size (4096 envs, procedural 1300x2100 height map): two runs are bit-identical, and
