@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SHF_ABI_VERSION 7
+#define SHF_ABI_VERSION 8
 
 #define SHF_MAX_BODIES 32 /* reported rigid bodies per articulation        */
 #define SHF_MAX_DOFS 32
@@ -104,11 +104,16 @@ typedef struct ShfModel {
   /* Rounded shapes of the articulation tested against the free box actors: a sphere (sph_seg = 0), or a capsule --
    * the segment sph_pos + t sph_seg, t in [0,1], swept by sph_radius (the native form of the URDF <cylinder> under
    * replace_cylinder_with_capsule, asset_config.py:32-46).  A capsule meets a box at the point of its segment
-   * closest to the box (exact minimiser of the convex piecewise-quadratic distance), then as a sphere there. */
+   * closest to the box (exact minimiser of the convex piecewise-quadratic distance), then as a sphere there -- or,
+   * when it lies along a face (a stretch of the segment is equally close: line contact), at BOTH ends of that stretch:
+   * a capsule is two consecutive records of the same geometry, sph_part = 0 (the closest point, or the first end of the
+   * stretch) and sph_part = 1 (the second end; off unless there is a stretch).  Against a free box the two ends are
+   * solved together (a joint pair law: one 6x6 elimination of the box for both points).  Spheres: one record, part 0. */
   int32_t sph_body[SHF_MAX_SPHERES];
   float sph_pos[SHF_MAX_SPHERES][3];
   float sph_seg[SHF_MAX_SPHERES][3];
   float sph_radius[SHF_MAX_SPHERES];
+  int32_t sph_part[SHF_MAX_SPHERES];
 
   /* Self-collision (create_actor(..., collision_filter = 0), units.py:68): every collision shape of
    * the URDF as one or two capsules (a sphere is a capsule of zero length; a box is the capsule -- or the two

@@ -352,6 +352,19 @@ def segment_closest(segs, f64=True):
     return out
 
 
+def segment_box_contact(bR, bpos, h, c0, s, part, f64=True):
+    """Capsule vs box contact point `part` (0 / 1, ShfModel.sph_part): (exists (n,) bool, t (n,)).  A line contact (the
+    segment runs along a face) has two: the ends of the stretch; otherwise part 0 is the closest point."""
+    dt, ct = (np.float64, C.c_double) if f64 else (np.float32, C.c_float)
+    n = np.reshape(bR, (-1, 9)).shape[0]
+    pack = np.ascontiguousarray(np.concatenate([np.reshape(bR, (-1, 9)), bpos, h, c0, s, np.full((n, 1), float(part))], axis=1), dt)
+    out = np.zeros((n, 3), dt)
+    fn = lib().shf_oracle_segment_box_contact_f64 if f64 else lib().shf_oracle_segment_box_contact_f32
+    fn.restype = None
+    fn(C.c_int(n), _p(pack, ct), _p(out, ct))
+    return out[:, 0] > 0, out[:, 1]
+
+
 def segment_box_param(bR, bpos, h, c0, s, f64=True):
     """Capsule vs box: parameter t of the point c0 + t s closest to the box (bR (n,9) row-major world<-box, bpos, half
     extents h, all (n,3)) -> (n,)."""

@@ -1,7 +1,7 @@
 """ctypes mirrors of the PODs in include/shifu_amd.h (keep in lock-step)."""
 import ctypes as C
 
-SHF_ABI_VERSION = 7
+SHF_ABI_VERSION = 8
 MAP_BODY, MAP_CHAIN, MAP_CHAIN_SPLIT = 0, 1, 2   # shf_sim_set_mapping
 MAX_BODIES = 32
 MAX_DOFS = 32
@@ -37,7 +37,7 @@ class ShfModel(C.Structure):
         ("drive_mode", i32 * MAX_DOFS), ("dof_body", i32 * MAX_DOFS),
         ("pt_body", i32 * MAX_POINTS), ("pt_pos", (f32 * 3) * MAX_POINTS), ("pt_radius", f32 * MAX_POINTS),
         ("pt_eval", i32 * MAX_POINTS), ("pt_slot", i32 * MAX_POINTS),
-        ("sph_body", i32 * MAX_SPHERES), ("sph_pos", (f32 * 3) * MAX_SPHERES), ("sph_seg", (f32 * 3) * MAX_SPHERES), ("sph_radius", f32 * MAX_SPHERES),
+        ("sph_body", i32 * MAX_SPHERES), ("sph_pos", (f32 * 3) * MAX_SPHERES), ("sph_seg", (f32 * 3) * MAX_SPHERES), ("sph_radius", f32 * MAX_SPHERES), ("sph_part", i32 * MAX_SPHERES),
         ("self_collide", i32), ("ncap", i32), ("npair", i32), ("pad_sc", i32),
         ("cap_body", i32 * MAX_CAPSULES), ("cap_a", (f32 * 3) * MAX_CAPSULES), ("cap_b", (f32 * 3) * MAX_CAPSULES),
         ("cap_radius", f32 * MAX_CAPSULES), ("pair_a", C.c_uint8 * MAX_PAIRS), ("pair_b", C.c_uint8 * MAX_PAIRS),

@@ -375,7 +375,7 @@ class AbbTask:
         if mp == "split":
             return "_Z13k_abb_step_wsILi"
         arm = 6 if mp == "chain" else 0
-        return pre + f"9FixedDimsILi7ELi6ELi3ELi6ELi6EE10FixedSceneILi3ELi1ELi1EELb0ELi{arm}EE"
+        return pre + f"9FixedDimsILi7ELi6ELi3ELi6ELi6EE10FixedSceneILi3ELi1ELi2EELb0ELi{arm}EE"
 
     @_on_device
     def reset_all(self):

@@ -566,8 +566,10 @@ DEV void abb_post_step(const AbbArgs& A, const ShfAbbTaskParams& tp, const ShfMo
 // ARM: number of links when the articulation is a fixed-base serial chain (ArmChain<ARM>::matches) in a compile-time
 // scene -- its recursions then run on one lane (shf_arm.h); 0: the body-per-lane sub-step.
 // LDS tail of an env: POS targets, this step's ee position, the arm's per-link records.
-#define SHF_ARM_MAX_LINKS 8
-#define ABB_TAIL_WORDS(nslots) ((nslots) * PT_STRIDE + SHF_MAX_DOFS + ARM_KREC_WORDS(SHF_ARM_MAX_LINKS))
+// (sized to the word: two workgroups of the two-wave kernel have to share a CU's 160 KiB)
+#define SHF_ARM_MAX_LINKS 6
+#define ABB_TGT_WORDS(nd) (((nd) + 2 + 3) & ~3)                     /* POS targets + the end effector's x, y */
+#define ABB_TAIL_WORDS(nslots, nd) ((nslots) * PT_STRIDE + ABB_TGT_WORDS(nd) + ARM_KREC_WORDS(SHF_ARM_MAX_LINKS) + 4)
 template <int G, class DM, class SC, bool LINK = false, int ARM = 0>
 __global__ __launch_bounds__(256, (G >= 32 && SC::NBX > 0) ? 2 : 1) void k_abb_step(AbbArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -590,10 +592,10 @@ __global__ __launch_bounds__(256, (G >= 32 && SC::NBX > 0) ? 2 : 1) void k_abb_s
   const int nbx = SC::NBX > 0 ? SC::NBX : A.S.nboxes, actors = 1 + nbx;
   const int nb = DM::nb(m), nd = DM::nd(m), nbt = nb + nbx;
   const int nslots = DM::np(m) + box_slot_count(nbx, m->nsph) + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0);
-  const int env_words = env_lds_words(nbt, nd, nslots, ABB_TAIL_WORDS(nslots), actors);
+  const int env_words = env_lds_words(nbt, nd, nslots, ABB_TAIL_WORDS(nslots, nd), actors);
   EnvLds L = env_lds_carve(smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS + es * env_words, nbt, nd, nslots, actors);
   float* tgtl = L.pt + nslots * PT_STRIDE;  // POS targets of this env step
-  float* krec = tgtl + SHF_MAX_DOFS;
+  float* krec = tgtl + ABB_TGT_WORDS(nd);
 
   float* dof = A.S.dof + (size_t)e * nd * 2;
   float* root = A.S.root + (size_t)e * actors * 13;
@@ -668,10 +670,10 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
   const bool live = e < n;                       // no early return: every wave meets every workgroup barrier
   constexpr int nbx = SC::NBX, actors = 1 + nbx, nb = NL + 1, nd = NL, nbt = nb + nbx;
   const int nslots = DM::np(m) + box_slot_count(nbx, m->nsph);
-  const int env_words = env_lds_words(nbt, nd, nslots, ABB_TAIL_WORDS(nslots), actors);
+  const int env_words = env_lds_words(nbt, nd, nslots, ABB_TAIL_WORDS(nslots, nd), actors);
   EnvLds L = env_lds_carve(smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS + es * env_words, nbt, nd, nslots, actors);
   float* tgtl = L.pt + nslots * PT_STRIDE;       // POS targets of this env step
-  float* krec = tgtl + SHF_MAX_DOFS;
+  float* krec = tgtl + ABB_TGT_WORDS(nd);
   unsigned* sphere_bits = reinterpret_cast<unsigned*>(krec + ARM_KREC_WORDS(NL));   // the rod slot's ballot, arm wave -> box wave
 
   if (arm && live) {
@@ -728,6 +730,7 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
     PHASE_MARK(25);
     if (live && arm) {
       fixed_sphere_slots<G, SC>(C, L, l, mu, AL.g, BM);
+      GROUP_SYNC();                              // the capsule's two slots come from two lanes
       if (l == 0) {
         *sphere_bits = BM.spheres;
         if (BM.spheres) {                        // rare: the pair laws on the lane that evaluated the slot
@@ -1455,7 +1458,7 @@ extern "C" int shf_abb_step(ShfAbbTask* task, const float* raw_actions_dev, void
   dim3 grid((s->n + epb - 1) / epb), block(256);
   const int nbx = s->nboxes, nslots = s->model.np + box_slot_count(nbx, s->model.nsph) + (sim_link(s) ? 2 * SHF_MAX_LINK_CONTACTS : 0);
   const size_t lds = ((size_t)MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS +
-                      (size_t)epb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, ABB_TAIL_WORDS(nslots), 1 + nbx)) * 4;
+                      (size_t)epb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, ABB_TAIL_WORDS(nslots, s->model.nd), 1 + nbx)) * 4;
   if (sim_link(s)) {
     switch (s->group) {
       case 64: return launch(k_abb_step<64, DynDims, DynScene, true>, grid, block, lds, stream, A);
@@ -1473,7 +1476,7 @@ extern "C" int shf_abb_step(ShfAbbTask* task, const float* raw_actions_dev, void
       // arm and boxes on different waves of the workgroup (k_abb_step_ws): WT / 32 envs per block
       const int wt = s->mapping_split, wepb = wt / 32;
       const size_t wlds = ((size_t)MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS +
-                           (size_t)wepb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, ABB_TAIL_WORDS(nslots), 1 + nbx)) * 4;
+                           (size_t)wepb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, ABB_TAIL_WORDS(nslots, s->model.nd), 1 + nbx)) * 4;
       const dim3 wgrid((s->n + wepb - 1) / wepb);
       return launch(k_abb_step_ws<256>, wgrid, dim3(wt), wlds, stream, A);
     }

@@ -28,7 +28,7 @@ struct FixedScene {
     return true;
   }
 };
-typedef FixedScene<3, 1, 1> AbbScene;   // table (fixed), cube (free), goal pad (fixed); the rod capsule (abb_task.py)
+typedef FixedScene<3, 1, 2> AbbScene;   // table (fixed), cube (free), goal pad (fixed); the rod capsule's two records (abb_task.py)
 // per-lane constants of the fixed-scene path: which of the arm's spheres sit on this lane's body / moving body
 struct BoxLane { unsigned sph_body = 0u, sph_dyn = 0u; };
 DEV BoxLane box_lane_load(const ShfModel* m, int l) {
@@ -152,7 +152,7 @@ DEV void mat3_inv(const float* A, float* Ai) {
 // box lane: IA / pA = the box with its own contacts folded, afree = its solve; o = the pair slot; pr = the pair record
 // rsum, nshare: sum of the contact points and number of the pair slots active on this box -- each slot is eliminated as if
 // the others pushed with the same force as itself (mass splitting with the true geometry; oracle boxes_pre)
-DEV void pair_law(const float* IA, const float* afree, const float* o, float dt, float* pr, const float* rsum, float nshare) {
+DEV void pair_law(const Ldlt6& FIA, const float* afree, const float* o, float dt, float* pr, const float* rsum, float nshare) {
   const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]}, n[3] = {o[PT_N], o[PT_N + 1], o[PT_N + 2]};
   const float ct = o[PT_CT], bn = o[PT_BN];
   float W[9], cfree[3];
@@ -163,7 +163,7 @@ DEV void pair_law(const float* IA, const float* afree, const float* o, float dt,
     cross3(rsum, e, t);
 #pragma unroll
     for (int i = 0; i < 3; i++) { rhs[i] = -t[i]; rhs[3 + i] = -(e[i] * nshare); }
-    ldlt_solve6(IA, rhs, y);
+    ldlt_substitute6(FIA, rhs, y);
     pair_point_accel(y, r, wp);
 #pragma unroll
     for (int i = 0; i < 3; i++) W[3 * i + k] = wp[i];
@@ -230,6 +230,148 @@ DEV void pair_force(const float* pr, const float* a_art, const float* r, float d
   pair_point_accel(a_art, r, ap);
 #pragma unroll
   for (int i = 0; i < 3; i++) f[i] = fmaf(-dt, fmaf(K[3 * i + 2], ap[2], fmaf(K[3 * i + 1], ap[1], K[3 * i] * ap[0])), F[i]);
+}
+
+// ---- joint pair law: the two ends of one capsule in line contact with a free box (ShfModel.sph_part; oracle
+// pair_law_joint and its comment).  (K^-1 + dt W) f = K^-1 f0 + dt c - dt a over both points: Keff = (K^-1 + dt W)^-1
+// (symmetric 6x6, packed), Feff = Keff (K^-1 f0 + dt c); the record is Keff[21] Feff[6] flag (one exchange slot).
+#define JR_K 0
+#define JR_F 21
+#define JR_ON 27
+DEV void pair_law_joint(const Ldlt6& FIA, const float* afree, const float* o1, const float* o2, float dt, float* rec) {
+  const float* o[2] = {o1, o2};
+  float Kinv[2][9], Wc[6][6], g[6], negg[6], A[21], Feff[6];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const float ict = 1.0f / o[j][PT_CT], ibn = 1.0f / o[j][PT_BN];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) Kinv[j][3 * r + c] = fmaf(ibn - ict, o[j][PT_N + r] * o[j][PT_N + c], r == c ? ict : 0.0f);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float e[3] = {k == 0 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 2 ? 1.0f : 0.0f};
+      const float rj[3] = {o[j][PT_R], o[j][PT_R + 1], o[j][PT_R + 2]};
+      float t[3], rhs[6], y[6];
+      cross3(rj, e, t);
+#pragma unroll
+      for (int i = 0; i < 3; i++) { rhs[i] = -t[i]; rhs[3 + i] = -e[i]; }
+      ldlt_substitute6(FIA, rhs, y);
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const float ri[3] = {o[i][PT_R], o[i][PT_R + 1], o[i][PT_R + 2]};
+        pair_point_accel(y, ri, &Wc[3 * j + k][3 * i]);
+      }
+    }
+#pragma unroll
+  for (int p = 0; p < 6; p++)
+#pragma unroll
+    for (int q = p; q < 6; q++) {
+      const float kinv = (p / 3 == q / 3) ? Kinv[p / 3][3 * (p % 3) + (q % 3)] : 0.0f;
+      A[SYM(p, q)] = fmaf(dt, Wc[q][p], kinv);
+    }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const float ri[3] = {o[i][PT_R], o[i][PT_R + 1], o[i][PT_R + 2]};
+    float cf[3];
+    pair_point_accel(afree, ri, cf);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+      g[3 * i + r] = fmaf(dt, cf[r], fmaf(Kinv[i][3 * r + 2], o[i][PT_F + 2], fmaf(Kinv[i][3 * r + 1], o[i][PT_F + 1], Kinv[i][3 * r] * o[i][PT_F])));
+  }
+#pragma unroll
+  for (int p = 0; p < 6; p++) negg[p] = -g[p];
+  Ldlt6 FA;
+  ldlt_factor6(A, FA);
+  ldlt_substitute6(FA, negg, Feff);
+#pragma unroll
+  for (int p = 0; p < 6; p++) rec[JR_F + p] = Feff[p];
+#pragma unroll
+  for (int q = 0; q < 6; q++) {
+    float rhs[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, x[6];
+    rhs[q] = -1.0f;
+    ldlt_substitute6(FA, rhs, x);
+#pragma unroll
+    for (int p = 0; p <= q; p++) rec[JR_K + SYM(p, q)] = x[p];
+  }
+  rec[JR_ON] = 1.0f;
+}
+DEV void pair_joint_jacobian(const float* r1, const float* r2, float J[6][6]) {
+  const float* rr[2] = {r1, r2};
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const float* r = rr[i];
+    const float X[9] = {0.0f, r[2], -r[1], -r[2], 0.0f, r[0], r[1], -r[0], 0.0f};
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) { J[3 * i + a][c] = X[3 * a + c]; J[3 * i + a][3 + c] = a == c ? 1.0f : 0.0f; }
+  }
+}
+// the articulation's body folds the joint law: IA += dt J^T Keff J, pA -= J^T Feff
+DEV void pair_accumulate_joint(float* IA, float* pA, const float* r1, const float* r2, const float* rec, float dt) {
+  const float* rr[2] = {r1, r2};
+  float Kf[21], Feff[6];
+#pragma unroll
+  for (int k = 0; k < 21; k++) Kf[k] = rec[JR_K + k];
+#pragma unroll
+  for (int k = 0; k < 6; k++) Feff[k] = rec[JR_F + k];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    float t[3];
+    cross3(rr[i], Feff + 3 * i, t);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { pA[k] -= t[k]; pA[3 + k] -= Feff[3 * i + k]; }
+  }
+  float J[6][6], T[6][6];
+  pair_joint_jacobian(r1, r2, J);
+#pragma unroll
+  for (int p = 0; p < 6; p++)
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      float acc = SYMG(Kf, p, 0) * J[0][c];
+#pragma unroll
+      for (int q = 1; q < 6; q++) acc = fmaf(SYMG(Kf, p, q), J[q][c], acc);
+      T[p][c] = acc;
+    }
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int c = a; c < 6; c++) {
+      float acc = J[0][a] * T[0][c];
+#pragma unroll
+      for (int p = 1; p < 6; p++) acc = fmaf(J[p][a], T[p][c], acc);
+      IA[SYM(a, c)] = fmaf(dt, acc, IA[SYM(a, c)]);
+    }
+}
+// the two forces once the body's acceleration is known: f = Feff - dt Keff [a_pt1; a_pt2]
+DEV void pair_force_joint(const float* rec, const float* a_body, const float* r1, const float* r2, float dt, float* f1, float* f2) {
+  float ap[6], f[6];
+  pair_point_accel(a_body, r1, ap);
+  pair_point_accel(a_body, r2, ap + 3);
+#pragma unroll
+  for (int p = 0; p < 6; p++) {
+    float acc = SYMG(rec + JR_K, p, 0) * ap[0];
+#pragma unroll
+    for (int q = 1; q < 6; q++) acc = fmaf(SYMG(rec + JR_K, p, q), ap[q], acc);
+    f[p] = fmaf(-dt, acc, rec[JR_F + p]);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) { f1[k] = f[k]; f2[k] = f[3 + k]; }
+}
+// Which capsule (first record) has exactly its two ends, and nothing else, as the active pair slots `sb` (bit si) of a
+// box whose link slots are `nlink_on_box`: -1 if none (oracle boxes_pre: w->joint).  cts: PT_CT of sphere slot si.
+template <class CT>
+DEV int joint_pair_of(const ShfModel* m, unsigned sb, int nlink_on_box, CT ct_of) {
+  if (nlink_on_box != 0 || __builtin_popcount(sb) != 2) return -1;
+  const int si = __builtin_ctz(sb);
+  if (si + 1 >= m->nsph || !((sb >> (si + 1)) & 1u)) return -1;
+  if (m->sph_part[si] != 0 || m->sph_part[si + 1] != 1 || m->sph_body[si] != m->sph_body[si + 1]) return -1;
+  if (!(ct_of(si) > 0.0f) || !(ct_of(si + 1) > 0.0f)) return -1;
+  return si;
 }
 
 DEV bool point_in_box(const float* bR, const float* bpos, const float* h, const float* r, float* phi, float* n) {
@@ -337,6 +479,14 @@ struct SegBoxRoot {
     if (!hash) return 1.0f;
     return fmaf(th - tl, gl / (gl - gh), tl);
   }
+  // contact point `part` (ShfModel.sph_part; oracle segment_box_contact): a flat stretch of non-zero length is a line
+  // contact held at both of its ends; otherwise part 0 is the closest point and part 1 does not exist
+  DEV bool contact(int part, float* t) const {
+    if (zh > zl) { *t = part == 0 ? zl : zh; return true; }
+    if (part != 0) return false;
+    *t = root();
+    return true;
+  }
 };
 DEV void seg_box_frame(const float* bR, const float* bpos, const float* c0, const float* s, float* a, float* d) {
   const float rel[3] = {c0[0] - bpos[0], c0[1] - bpos[1], c0[2] - bpos[2]};
@@ -346,7 +496,7 @@ DEV void seg_box_frame(const float* bR, const float* bpos, const float* c0, cons
     d[i] = fmaf(bR[6 + i], s[2], fmaf(bR[3 + i], s[1], bR[i] * s[0]));
   }
 }
-DEV float segment_box_param(const float* bR, const float* bpos, const float* h, const float* c0, const float* s) {
+DEV bool segment_box_contact(const float* bR, const float* bpos, const float* h, const float* c0, const float* s, int part, float* tc) {
   float a[3], d[3];
   seg_box_frame(bR, bpos, c0, s, a, d);
   const float dd = dot3(d, d);
@@ -357,7 +507,7 @@ DEV float segment_box_param(const float* bR, const float* bpos, const float* h, 
     const bool use = seg_box_sample(k, a, d, h, dd, &t, &g);
     Q.push(t, g, use);
   }
-  return Q.root();
+  return Q.contact(part, tc);
 }
 // world-frame centre of rounded shape si against box (Rk, bpos, hh): the sphere's centre, or the capsule's closest point.
 // false: the shape's bounding sphere is further than the contact offset (+ 1 cm for the rounding of this test) from the
@@ -375,7 +525,8 @@ DEV bool rounded_centre(const ShfModel* m, int si, const float* Rb, const float*
   const float reach = 0.5f * sqrtf(dot3(sw, sw)) + sqrtf(dot3(hh, hh)) + m->sph_radius[si] + offset + 0.01f;
   if (dot3(rel, rel) > reach * reach) return false;
   if (ls[0] != 0.0f || ls[1] != 0.0f || ls[2] != 0.0f) {
-    const float t = segment_box_param(Rk, bpos, hh, c, sw);
+    float t;
+    if (!segment_box_contact(Rk, bpos, hh, c, sw, m->sph_part[si], &t)) return false;   // the second end of no line contact
 #pragma unroll
     for (int i = 0; i < 3; i++) c[i] = fmaf(t, sw[i], c[i]);
   }
@@ -518,6 +669,29 @@ DEV int sphere_slot(const ShfModel* m, int nbx, int si, int kd) { return m->np +
 // second record of a pair slot: the consistent law's (Feff[3], Keff upper triangle [6]) -- see pair_law
 DEV int pair_slot(const ShfModel* m, int nbx, int si, int kd) { return sphere_slot(m, nbx, si, kd) + m->nsph * nbx; }
 __host__ __device__ inline int box_slot_count(int nbx, int nsph) { return nbx * 8 * (1 + nbx) + 2 * nsph * nbx; }
+// joint pair law (pair_law_joint): which capsule, if any, has exactly its two ends as box kd's active pair slots; where the
+// record lives (the box's exchange slot: boxes hand nothing to a parent); the force of sphere slot si either way
+DEV int box_joint_pair(const ShfModel* m, const EnvLds& L, int nbx, int kd, unsigned sb, int nlink_on_box) {
+  return joint_pair_of(m, sb, nlink_on_box, [&](int si) { return L.pt[sphere_slot(m, nbx, si, kd) * PT_STRIDE + PT_CT]; });
+}
+DEV float* joint_record(const ShfModel* m, const EnvLds& L, int kd) { return L.xch + (m->nb + kd) * XCH_STRIDE; }
+DEV void sphere_pair_force(const ShfModel* m, const EnvLds& L, int nbx, int si, int kd, int jp, float dt, float* f) {
+  const float* ab = L.acc + m->dyn[m->sph_body[si]] * 6;
+  const float abr[6] = {ab[0], ab[1], ab[2], ab[3], ab[4], ab[5]};
+  if (jp < 0) {
+    const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
+    const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]};
+    pair_force(L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE, abr, r, dt, f);
+  } else {
+    const float* o1 = L.pt + sphere_slot(m, nbx, jp, kd) * PT_STRIDE;
+    const float* o2 = L.pt + sphere_slot(m, nbx, jp + 1, kd) * PT_STRIDE;
+    const float r1[3] = {o1[PT_R], o1[PT_R + 1], o1[PT_R + 2]}, r2[3] = {o2[PT_R], o2[PT_R + 1], o2[PT_R + 2]};
+    float f1[3], f2[3];
+    pair_force_joint(joint_record(m, L, kd), abr, r1, r2, dt, f1, f2);
+#pragma unroll
+    for (int k = 0; k < 3; k++) f[k] = si == jp ? f1[k] : f2[k];
+  }
+}
 
 // `in contact` flags of a lane's slots as bit masks, read in one batch: the folds below then visit only the active
 // slots, in the same order as the plain nested loops (ascending bit index = loop order), instead of paying one
@@ -571,6 +745,11 @@ DEV unsigned body_sphere_flags(const ShfModel* m, const EnvLds& L, int nbx, int 
 DEV int link_code(int body, int box) { return 1 + body * SHF_MAX_BOXES + box; }
 DEV int link_code_body(float on) { return ((int)on - 1) / SHF_MAX_BOXES; }
 DEV int link_code_box(float on) { return ((int)on - 1) % SHF_MAX_BOXES; }
+DEV int link_slots_on_box(const EnvLds& L, int link_slot0, int nlink, int kd) {
+  int c = 0;
+  for (int k = 0; k < nlink; k++) c += link_code_box(L.pt[(link_slot0 + k) * PT_STRIDE + PT_ON]) == kd ? 1 : 0;
+  return c;
+}
 template <int G>
 DEV int link_contacts(const StepCtx& C, const EnvLds& L, int l, int slot0, float mu_shape, const float* g_art) {
   const ShfModel* m = C.m;
@@ -617,12 +796,14 @@ DEV int link_contacts(const StepCtx& C, const EnvLds& L, int l, int slot0, float
           mv3(Rb, ls, sw);
           const float rel[3] = {fmaf(0.5f, sw[0], c[0]) - bpos[0], fmaf(0.5f, sw[1], c[1]) - bpos[1], fmaf(0.5f, sw[2], c[2]) - bpos[2]};
           const float reach = 0.5f * sqrtf(dot3(sw, sw)) + sqrtf(dot3(hh, hh)) + rad + offset + 0.01f;
-          if (!(dot3(rel, rel) > reach * reach)) {
-            if (ls[0] != 0.0f || ls[1] != 0.0f || ls[2] != 0.0f) {
-              const float t = segment_box_param(Rk, bpos, hh, c, sw);
+          bool exists = !(dot3(rel, rel) > reach * reach);
+          if (exists && (ls[0] != 0.0f || ls[1] != 0.0f || ls[2] != 0.0f)) {
+            float t = 0.0f;
+            exists = segment_box_contact(Rk, bpos, hh, c, sw, m->sph_part[sh], &t);   // part 1: only for a line contact
 #pragma unroll
-              for (int i = 0; i < 3; i++) c[i] = fmaf(t, sw[i], c[i]);
-            }
+            for (int i = 0; i < 3; i++) c[i] = fmaf(t, sw[i], c[i]);
+          }
+          if (exists) {
             float phi, n[3], rc[3], ta[3], tb[3], vrel[3], vrs[3];
             sphere_vs_box(Rk, bpos, hh, c, rad, &phi, n, rc);
             const float va[3] = {qa[12], qa[13], qa[14]}, vbx[3] = {pk[12], pk[13], pk[14]};
@@ -898,9 +1079,19 @@ DEV void fixed_pair_laws(const StepCtx& C, const EnvLds& L, bool mine, const flo
   const ShfModel* m = C.m;
   if (mine) {
     unsigned sb = spheres;
-    if (sb) {
+    const int jp = box_joint_pair(m, L, F::nbx, F::kd, sb, 0);
+    if (jp >= 0) {                                // the two ends of one capsule: eliminated together
       float afree[6];
-      ldlt_solve6(IA, pA, afree);
+      Ldlt6 FIA;
+      ldlt_factor6(IA, FIA);
+      ldlt_substitute6(FIA, pA, afree);
+      pair_law_joint(FIA, afree, L.pt + sphere_slot(m, F::nbx, jp, F::kd) * PT_STRIDE, L.pt + sphere_slot(m, F::nbx, jp + 1, F::kd) * PT_STRIDE,
+                     C.sp.dt, joint_record(m, L, F::kd));
+    } else if (sb) {
+      float afree[6];
+      Ldlt6 FIA;
+      ldlt_factor6(IA, FIA);
+      ldlt_substitute6(FIA, pA, afree);
       const float nshare = (float)__builtin_popcount(sb);
       float rsum[3] = {0.0f, 0.0f, 0.0f};
       for (unsigned bb = sb; bb; bb &= bb - 1u) {
@@ -911,7 +1102,7 @@ DEV void fixed_pair_laws(const StepCtx& C, const EnvLds& L, bool mine, const flo
       while (sb) {
         const int si = __builtin_ctz(sb);
         sb &= sb - 1u;
-        pair_law(IA, afree, L.pt + sphere_slot(m, F::nbx, si, F::kd) * PT_STRIDE, C.sp.dt,
+        pair_law(FIA, afree, L.pt + sphere_slot(m, F::nbx, si, F::kd) * PT_STRIDE, C.sp.dt,
                  L.pt + pair_slot(m, F::nbx, si, F::kd) * PT_STRIDE, rsum, nshare);
       }
     }
@@ -924,11 +1115,20 @@ DEV void fixed_arm_fold(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, c
   const ShfModel* m = C.m;
   if (l < m->nb && m->dyn[l] == l) {
     unsigned bits = spheres & BL.sph_dyn;
+    const int jp = bits ? box_joint_pair(m, L, F::nbx, F::kd, spheres, 0) : -1;
     while (bits) {
       const int si = __builtin_ctz(bits);
       bits &= bits - 1u;
       const float* o = L.pt + sphere_slot(m, F::nbx, si, F::kd) * PT_STRIDE;
       const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]};
+      if (jp >= 0) {
+        if (si == jp) {                           // both ends at once; the second end's bit is skipped
+          const float* o2 = L.pt + sphere_slot(m, F::nbx, jp + 1, F::kd) * PT_STRIDE;
+          const float r2[3] = {o2[PT_R], o2[PT_R + 1], o2[PT_R + 2]};
+          pair_accumulate_joint(B.IA, B.pA, r, r2, joint_record(m, L, F::kd), C.sp.dt);
+        }
+        continue;
+      }
       float Fp[3], K[9];
       pair_unpack(L.pt + pair_slot(m, F::nbx, si, F::kd) * PT_STRIDE, Fp, K);
       pair_accumulate(B.IA, B.pA, r, Fp, K, C.sp.dt);
@@ -1051,9 +1251,19 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
     unsigned lb = 0u;     // this box's link contacts (bit k = slot k)
     for (int k = 0; k < nlink; k++)
       if (link_code_box(L.pt[(link_slot0 + k) * PT_STRIDE + PT_ON]) == kd) lb |= 1u << k;
-    if (sb || lb) {
+    const int jp = box_joint_pair(m, L, nbx, kd, sb, __builtin_popcount(lb));
+    if (jp >= 0) {                                // the two ends of one capsule: eliminated together
       float afree[6];
-      ldlt_solve6(B.IA, B.pA, afree);
+      Ldlt6 FIA;
+      ldlt_factor6(B.IA, FIA);
+      ldlt_substitute6(FIA, B.pA, afree);
+      pair_law_joint(FIA, afree, L.pt + sphere_slot(m, nbx, jp, kd) * PT_STRIDE, L.pt + sphere_slot(m, nbx, jp + 1, kd) * PT_STRIDE, dt,
+                     joint_record(m, L, kd));
+    } else if (sb || lb) {
+      float afree[6];
+      Ldlt6 FIA;
+      ldlt_factor6(B.IA, FIA);
+      ldlt_substitute6(FIA, B.pA, afree);
       const float nshare = (float)(__builtin_popcount(sb) + __builtin_popcount(lb));
       float rsum[3] = {0.0f, 0.0f, 0.0f};
       for (unsigned bb = sb; bb; bb &= bb - 1u) {
@@ -1069,12 +1279,12 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
       while (sb) {
         const int si = __builtin_ctz(sb);
         sb &= sb - 1u;
-        pair_law(B.IA, afree, L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE, rsum, nshare);
+        pair_law(FIA, afree, L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE, rsum, nshare);
       }
       while (lb) {
         const int k = __builtin_ctz(lb);
         lb &= lb - 1u;
-        pair_law(B.IA, afree, L.pt + (link_slot0 + k) * PT_STRIDE, dt, L.pt + (link_slot0 + SHF_MAX_LINK_CONTACTS + k) * PT_STRIDE, rsum, nshare);
+        pair_law(FIA, afree, L.pt + (link_slot0 + k) * PT_STRIDE, dt, L.pt + (link_slot0 + SHF_MAX_LINK_CONTACTS + k) * PT_STRIDE, rsum, nshare);
       }
     }
   }
@@ -1086,6 +1296,15 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
       bits &= bits - 1u;
       const float* o = L.pt + sphere_slot(m, nbx, si, k2) * PT_STRIDE;
       const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]};
+      const int jp = box_joint_pair(m, L, nbx, k2, box_sphere_flags(m, L, nbx, k2), link_slots_on_box(L, link_slot0, nlink, k2));
+      if (jp >= 0) {
+        if (si == jp) {
+          const float* o2 = L.pt + sphere_slot(m, nbx, jp + 1, k2) * PT_STRIDE;
+          const float r2[3] = {o2[PT_R], o2[PT_R + 1], o2[PT_R + 2]};
+          pair_accumulate_joint(B.IA, B.pA, r, r2, joint_record(m, L, k2), dt);
+        }
+        continue;
+      }
       float F[3], K[9];
       pair_unpack(L.pt + pair_slot(m, nbx, si, k2) * PT_STRIDE, F, K);
       pair_accumulate(B.IA, B.pA, r, F, K, dt);
@@ -1141,15 +1360,14 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
     // the articulation's solved acceleration fixes every pair force; the box receives exactly its opposite, then solves
     unsigned sb;
     if constexpr (SC::NBX > 0) sb = BM.spheres; else sb = box_sphere_flags(m, L, nbx, kd);
+    const int jp = box_joint_pair(m, L, nbx, kd, sb, SC::NBX > 0 ? 0 : link_slots_on_box(L, link_slot0, BM.nlink, kd));
     while (sb) {
       const int si = __builtin_ctz(sb);
       sb &= sb - 1u;
       const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
       const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]};
-      const float* ab = L.acc + m->dyn[m->sph_body[si]] * 6;
-      const float abr[6] = {ab[0], ab[1], ab[2], ab[3], ab[4], ab[5]};
       float f[3], t[3];
-      pair_force(L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE, abr, r, dt, f);
+      sphere_pair_force(m, L, nbx, si, kd, jp, dt, f);
       cross3(r, f, t);
 #pragma unroll
       for (int k = 0; k < 3; k++) { B.pA[k] += t[k]; B.pA[3 + k] += f[k]; }
@@ -1182,10 +1400,11 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
       while (bits) {
         const int j = __builtin_ctz(bits), si = j / SHF_MAX_BOXES, k2 = j % SHF_MAX_BOXES;
         bits &= bits - 1u;
-        const float* o = L.pt + sphere_slot(m, nbx, si, k2) * PT_STRIDE;
-        const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]};
+        unsigned sall;
+        if constexpr (SC::NBX > 0) sall = BM.spheres; else sall = box_sphere_flags(m, L, nbx, k2);
+        const int jp = box_joint_pair(m, L, nbx, k2, sall, SC::NBX > 0 ? 0 : link_slots_on_box(L, link_slot0, BM.nlink, k2));
         float fp[3];
-        pair_force(L.pt + pair_slot(m, nbx, si, k2) * PT_STRIDE, abr, r, dt, fp);
+        sphere_pair_force(m, L, nbx, si, k2, jp, dt, fp);
 #pragma unroll
         for (int k = 0; k < 3; k++) f[k] += fp[k];
       }
@@ -1218,15 +1437,12 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
             slot_force(L.pt + corner_slot(m, nbx, kd, j / BOX_T, j % BOX_T) * PT_STRIDE, a, 1.0f, dt, 1.0f, f);
           }
         }
+        const int jp_rows = box_joint_pair(m, L, nbx, kd, sb, SC::NBX > 0 ? 0 : link_slots_on_box(L, link_slot0, BM.nlink, kd));
         while (sb) {
           const int si = __builtin_ctz(sb);
           sb &= sb - 1u;
-          const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
-          const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]};
-          const float* ab = L.acc + m->dyn[m->sph_body[si]] * 6;
-          const float abr[6] = {ab[0], ab[1], ab[2], ab[3], ab[4], ab[5]};
           float fp[3];
-          pair_force(L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE, abr, r, dt, fp);
+          sphere_pair_force(m, L, nbx, si, kd, jp_rows, dt, fp);
 #pragma unroll
           for (int k = 0; k < 3; k++) f[k] -= fp[k];
         }

@@ -662,41 +662,51 @@ struct StepCtx {
   int32_t* dropped = nullptr;   // this env's word of SHF_T_DROPPED (contacts beyond the per-env limits), may be null
 };
 
-// solve IA x = -pA for a symmetric positive definite 6x6 in packed storage (LDL^T)
-DEV void ldlt_solve6(const float* IA, const float* pA, float* x) {
-  float Lm[6][6], Dg[6], iD[6], y[6];
+// solve IA x = -pA for a symmetric positive definite 6x6 in packed storage (LDL^T).  Factorisation and substitution are
+// separate so that several right-hand sides share one factorisation (the pair laws: up to 13 solves with two matrices);
+// ldlt_solve6 = both, the same operations in the same order as the oracle's ldlt_solve6.
+struct Ldlt6 { float Lm[6][6], Dg[6], iD[6]; };
+DEV void ldlt_factor6(const float* IA, Ldlt6& F) {
 #pragma unroll
   for (int j = 0; j < 6; j++) {
     float d = IA[SYM(j, j)];
 #pragma unroll
-    for (int k = 0; k < j; k++) d = fmaf(-(Lm[j][k] * Lm[j][k]), Dg[k], d);
-    Dg[j] = d;
+    for (int k = 0; k < j; k++) d = fmaf(-(F.Lm[j][k] * F.Lm[j][k]), F.Dg[k], d);
+    F.Dg[j] = d;
     const float id = 1.0f / d;
-    iD[j] = id;
+    F.iD[j] = id;
 #pragma unroll
     for (int i = j + 1; i < 6; i++) {
       float v = IA[SYM(j, i)];
 #pragma unroll
-      for (int k = 0; k < j; k++) v = fmaf(-(Lm[i][k] * Lm[j][k]), Dg[k], v);
-      Lm[i][j] = v * id;
+      for (int k = 0; k < j; k++) v = fmaf(-(F.Lm[i][k] * F.Lm[j][k]), F.Dg[k], v);
+      F.Lm[i][j] = v * id;
     }
   }
+}
+DEV void ldlt_substitute6(const Ldlt6& F, const float* pA, float* x) {
+  float y[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     float v = -pA[i];
 #pragma unroll
-    for (int k = 0; k < i; k++) v = fmaf(-Lm[i][k], y[k], v);
+    for (int k = 0; k < i; k++) v = fmaf(-F.Lm[i][k], y[k], v);
     y[i] = v;
   }
 #pragma unroll
-  for (int i = 0; i < 6; i++) y[i] = y[i] * iD[i];
+  for (int i = 0; i < 6; i++) y[i] = y[i] * F.iD[i];
 #pragma unroll
   for (int i = 5; i >= 0; i--) {
     float v = y[i];
 #pragma unroll
-    for (int k = i + 1; k < 6; k++) v = fmaf(-Lm[k][i], x[k], v);
+    for (int k = i + 1; k < 6; k++) v = fmaf(-F.Lm[k][i], x[k], v);
     x[i] = v;
   }
+}
+DEV void ldlt_solve6(const float* IA, const float* pA, float* x) {
+  Ldlt6 F;
+  ldlt_factor6(IA, F);
+  ldlt_substitute6(F, pA, x);
 }
 
 // Tangential coefficient c_t of the regularised Coulomb law f_t = -c_t v_t(end of step), c_t = mu f_n / max(|v_t|, v_eps),

@@ -637,15 +637,22 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
         m.pt_eval[s_] = i
         m.pt_slot[i] = s_
 
-    assert len(extra_spheres) <= _abi.MAX_SPHERES
-    m.nsph = len(extra_spheres)
-    for i, rec in enumerate(extra_spheres):
+    # rounded shapes vs box actors: a sphere is one record, a capsule two consecutive ones (ShfModel.sph_part: the closest
+    # point / first end of a line contact, and the second end)
+    recs = []
+    for rec in extra_spheres:
         lname, xyz, rad = rec[0], rec[1], rec[-1]
         body, p, R = link_frame[lname]
         q = p + R @ np.asarray(xyz, dtype=float)
         seg = R @ (np.asarray(rec[2], dtype=float) - np.asarray(xyz, dtype=float)) if len(rec) == 4 else np.zeros(3)
+        for part in ((0, 1) if np.any(seg != 0.0) else (0,)):
+            recs.append((body, q, seg, rad, part))
+    assert len(recs) <= _abi.MAX_SPHERES, f"{len(recs)} rounded-shape records > SHF_MAX_SPHERES"
+    m.nsph = len(recs)
+    for i, (body, q, seg, rad, part) in enumerate(recs):
         m.sph_body[i] = body
         m.sph_radius[i] = rad
+        m.sph_part[i] = part
         for kk in range(3):
             m.sph_pos[i][kk] = q[kk]
             m.sph_seg[i][kk] = seg[kk]

@@ -70,3 +70,35 @@ def test_float_build_tracks_the_double_build():
     d64 = _dist(bR, bpos, h, (c0 + t64[:, None] * s)[:, None, :])[:, 0]
     d32 = _dist(bR, bpos, h, (c0 + t32[:, None].astype(np.float64) * s)[:, None, :])[:, 0]
     assert np.abs(d32 - d64).max() < 2e-6                    # the distance is what enters the contact law; t itself is ill-conditioned when parallel
+
+
+def test_line_contact_has_two_points_the_ends_of_the_flat_stretch():
+    """ShfModel.sph_part (oracle segment_box_contact): a capsule lying along a face is a LINE contact held at both ends of
+    the stretch over which the segment is equally close -- the face's edges or the segment's own ends, whichever come
+    first; anything else is the single closest point (part 0) and part 1 does not exist."""
+    I = np.eye(3).reshape(1, 9)
+    z3 = np.zeros((1, 3)); h = np.array([[0.1, 0.1, 0.1]])
+    inside = (np.array([[-0.05, 0.0, 0.3]]), np.array([[0.1, 0.0, 0.0]]))        # above the top face, within its footprint
+    over = (np.array([[-0.5, 0.0, 0.3]]), np.array([[1.0, 0.0, 0.0]]))           # overhanging both edges
+    half = (np.array([[0.0, 0.0, 0.3]]), np.array([[0.4, 0.0, 0.0]]))            # from the middle out over one edge
+    for (c0, s), want in ((inside, (0.0, 1.0)), (over, (0.4, 0.6)), (half, (0.0, 0.25))):
+        for part in (0, 1):
+            ok, t = O.segment_box_contact(I, z3, h, c0, s, part)
+            assert ok[0] and abs(t[0] - want[part]) < 1e-12, (c0, s, part, t)
+    # tilted by 1e-2 rad: a point contact at the low end, no second point
+    c0, s = np.array([[-0.05, 0.0, 0.3]]), np.array([[0.1, 0.0, 1e-3]])
+    ok0, t0 = O.segment_box_contact(I, z3, h, c0, s, 0)
+    ok1, _ = O.segment_box_contact(I, z3, h, c0, s, 1)
+    assert ok0[0] and t0[0] == 0.0 and not ok1[0]
+    # generic skew segments: part 0 is segment_box_param's point and there is no part 1; where a stretch exists its ends
+    # bracket the classic midpoint
+    rng = np.random.default_rng(5)
+    bR, bpos, hh, cc, ss = _cases(rng, 500)
+    ok0, t0 = O.segment_box_contact(bR, bpos, hh, cc, ss, 0)
+    ok1, t1 = O.segment_box_contact(bR, bpos, hh, cc, ss, 1)
+    tp = O.segment_box_param(bR, bpos, hh, cc, ss)
+    assert ok0.all()
+    single = ~ok1
+    assert single.sum() > 400 and np.array_equal(t0[single], tp[single])
+    both = ok1
+    assert (t0[both] <= tp[both]).all() and (tp[both] <= t1[both]).all() and np.allclose(0.5 * (t0[both] + t1[both]), tp[both])

@@ -161,16 +161,16 @@ def test_standing_a1_holds_a_horizontal_push_below_the_friction_limit(oracle):
 
 
 # ---- capsule vs box (the ABB rod, shf_boxes.h: segment_box_param): a slider pushes a cube over the ground ----
-def _push(oracle, yaw, steps=700, f64=True, x0=0.12):
+def _push(oracle, yaw, steps=700, f64=True, x0=0.12, y0=0.0):
     from shifu_amd.abb_task import box_desc
     cm = K.pusher_model(yaw=yaw)
     m = cm.blob
     sp = sim_params()
     dt = np.float64 if f64 else np.float32
-    cube = box_desc((0.1, 0.1, 0.1), 0.5, 0.6, False, (x0, 0.0, 0.05))
+    cube = box_desc((0.1, 0.1, 0.1), 0.5, 0.6, False, (x0, y0, 0.05))
     dof = np.zeros((1, 2), dt)
     root = np.zeros((2, 13), dt); root[:, 6] = 1.0
-    root[1, :3] = (x0, 0.0, 0.05 - 0.5 * K.G / (4 * K.K_N))
+    root[1, :3] = (x0, y0, 0.05 - 0.5 * K.G / (4 * K.K_N))
     vt = np.full(1, 0.05, dt)
     fr = np.ones(1, np.float32)
     hist = []
@@ -202,11 +202,12 @@ def test_capsule_end_pushes_a_cube_with_the_reaction_newton_asks_for(oracle, f64
     assert first > 100 and all(abs(h[2][7]) < 1e-6 for h in hist[:first])               # untouched until the capsule arrives
 
 
-def test_capsule_parallel_to_the_face_pushes_through_the_middle_of_the_overlap(oracle):
-    """Lying along the face the capsule's distance to the box is flat over the overlap: the closest-point rule takes the
-    middle of that stretch, and keeps taking it while the cube is within 5e-4 rad of parallel (segment_box_param's flat-
-    sample tolerance; without it the point hopped between the overlap's ends from step to step and the cube's yaw rate
-    chattered at +-0.1 rad/s).  Same clean answers as the end-on push."""
+def test_capsule_parallel_to_the_face_pushes_with_a_line_contact(oracle):
+    """Lying along the face the capsule's distance to the box is flat over the overlap: a line contact, held at both ends
+    of that stretch (ShfModel.sph_part; one point at its middle until round 3) and solved for both ends together
+    (pair_law_joint); it stays a line contact while the cube is within 5e-4 rad of parallel (the flat-sample tolerance;
+    without it the contact hopped between the overlap's ends from step to step and the cube's yaw rate chattered at
+    +-0.1 rad/s).  Same clean answers as the end-on push."""
     m, hist = _push(oracle, 0.0, steps=900)
     q, qd, cube, contact = hist[-1]
     F = 0.5 * (0.6 + 1.0) * 0.5 * K.G
@@ -215,6 +216,27 @@ def test_capsule_parallel_to_the_face_pushes_through_the_middle_of_the_overlap(o
     assert abs(f_slider[0] + F) < 0.01 * F and abs(f_slider[1]) < 1e-3 * F and abs(f_slider[2]) < 1e-2 * F, f_slider
     assert abs(2.0 * np.arctan2(cube[5], cube[6])) < 1e-6 and abs(cube[12]) < 1e-6 and abs(cube[1]) < 1e-7
     wz = np.array([h[2][12] for h in hist[-300:]])
+    assert np.abs(wz).max() < 1e-5                                                    # no chatter
+
+
+def test_line_contact_keeps_an_off_centre_cube_flush(oracle):
+    """The cube sits 8 cm to the side: the rod (y in [-0.1, 0.1]) overlaps its face over y in [0.03, 0.10], a stretch that
+    still contains the cube's centre line (0.08).  The two ends of the stretch carry unequal shares -- their moments about
+    the centre line balance: the end 0.02 away carries 2.5 x what the end 0.05 away does -- and the cube travels flush
+    against the rod at the rod's speed without turning.  A single contact at the middle of the stretch pushes 1.5 cm off
+    the centre line: it hovered at the flat-sample tolerance with a chattering yaw rate of +-0.04 rad/s ("one
+    contact point, no torque"), and so did two points eliminated one by one, which cannot share a load unequally."""
+    m, hist = _push(oracle, 0.0, steps=900, y0=0.08)
+    q, qd, cube, contact = hist[-1]
+    F = 0.5 * (0.6 + 1.0) * 0.5 * K.G
+    f_slider = contact[m.nb - 1]
+    yaw = 2.0 * np.arctan2(cube[5], cube[6])
+    assert abs(cube[7] - qd) < 1e-6 and 0.045 < qd < 0.05
+    assert abs(cube[12]) < 1e-6 and abs(cube[8]) < 5e-6, (cube[12], cube[8])          # not turning; sideways creep ~ 1 um/s
+    assert 0.0 < yaw < 6e-4                          # a static tilt: the heavier-loaded end sinks F_i / k deeper
+    assert abs(cube[1] - 0.08) < 1e-4
+    assert abs(f_slider[0] + F) < 0.01 * F and abs(f_slider[1]) < 1e-3 * F and abs(f_slider[2]) < 1e-2 * F, f_slider
+    wz = np.array([h[2][12] for h in hist[-400:]])
     assert np.abs(wz).max() < 1e-5                                                    # no chatter
 
 

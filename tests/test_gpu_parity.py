@@ -430,6 +430,44 @@ def test_link_contacts_match_oracle_bitwise(oracle, group):
         sim.destroy() if hasattr(sim, "destroy") else None
 
 
+@pytest.mark.parametrize("group", [16, 64])
+def test_capsule_line_contact_joint_law_matches_oracle_bitwise(oracle, group):
+    """The capsule pusher of tests/test_contact_kats.py lying along the cube's face -- a line contact: two contact points
+    (ShfModel.sph_part) eliminated against the cube together (pair_law_joint) -- centred and 8 cm off the centre line, and
+    turned by 25 degrees (a single point, the independent law): shf_sim_step against the oracle, every tensor bit for bit."""
+    _need_gpu()
+    from shifu_amd.abb_task import box_desc
+    from tests import kat_models as K
+    sp = H.sim_params()
+    rng = np.random.default_rng(11)
+    for name, yaw, y0, steps in (("parallel", 0.0, 0.0, 420), ("parallel, off centre", 0.0, 0.08, 420), ("turned", np.deg2rad(25.0), 0.0, 300)):
+        cm = K.pusher_model(yaw=yaw)
+        m = cm.blob
+        assert m.nsph == 2 and [m.sph_part[0], m.sph_part[1]] == [0, 1]
+        n = 9
+        boxes = [box_desc((0.1, 0.1, 0.1), 0.5, 0.6, False, (0.12, y0, 0.05))]
+        sim, dof, root = _scene_on_gpu(cm, sp, boxes, [(0.12, y0, 0.05 - 0.5 * K.G / (4 * K.K_N))], n, group)
+        root[1::2, 1] += rng.uniform(-0.003, 0.003, n).astype(np.float32)       # the envs of a wavefront differ
+        vt = (0.05 * rng.uniform(0.7, 1.0, n * m.nd)).astype(np.float32)
+        sim.tensors[_abi.T_SIM_ROOT].copy_(torch.from_numpy(root))
+        both = 0
+        for it in range(steps):
+            sim.set_dof_command(_abi.T_VEL_TARGET, torch.from_numpy(vt).cuda())
+            sim.step()
+            sim.refresh(_abi.REFRESH_ALL)
+            contact, bstate, _ = oracle.scene_step(m, sp, boxes, n, dof, root, vel_target=vt, friction=np.ones(n, np.float32))
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(sim.tensors[_abi.T_DOF_STATE].cpu().numpy(), dof, err_msg=f"{name}: dof step {it}")
+            np.testing.assert_array_equal(sim.tensors[_abi.T_ROOT_STATE].cpu().numpy(), root, err_msg=f"{name}: root step {it}")
+            np.testing.assert_array_equal(sim.tensors[_abi.T_CONTACT].cpu().numpy(), contact, err_msg=f"{name}: contact step {it}")
+            both += int((np.abs(contact.reshape(n, -1, 3)[:, m.nb - 1]).sum(1) > 0).sum())
+        assert both > n * 50, f"{name}: the capsule never pushed"
+        cube = root.reshape(n, 2, 13)[:, 1]
+        if yaw == 0.0:     # (float32, perturbed envs: the float64 known answer is tests/test_contact_kats.py's)
+            assert (np.abs(cube[:, 12]) < 2e-2).all(), f"{name}: a line contact does not turn the cube: {cube[:, 12]}"
+        sim.destroy() if hasattr(sim, "destroy") else None
+
+
 def test_abb_scene_with_link_contacts_matches_oracle_bitwise(oracle):
     """The config-5 scene with the arm's links (box stand-ins for their mesh colliders, shifu_amd/assets/
     abb_link_boxes.json) and the rod colliding with table, cube and goal pad: the blind joint ramp that drove every rod

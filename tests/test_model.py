@@ -21,7 +21,8 @@ def test_vendored_robots():
     assert abs(a1.total_mass - 12.454) < 1e-3 and a1.body_names[0] == "base" and "FL_foot" in a1.body_names
     from shifu_amd.abb_task import abb_model
     abb = abb_model()
-    assert abb.blob.nd == 6 and abb.blob.fixed_base == 1 and abb.blob.nsph == 1 and sum(x * x for x in abb.blob.sph_seg[0]) ** 0.5 > 0.15
+    assert abb.blob.nd == 6 and abb.blob.fixed_base == 1 and abb.blob.nsph == 2 and sum(x * x for x in abb.blob.sph_seg[0]) ** 0.5 > 0.15
+    assert [abb.blob.sph_part[i] for i in range(2)] == [0, 1] and list(abb.blob.sph_seg[0]) == list(abb.blob.sph_seg[1])   # the rod capsule: two contact parts
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is only present in the build container")
