@@ -224,6 +224,8 @@ def main():
                     help="terrain = config 3 (height field); trimesh = the same samples as the mesh with vertical risers; "
                          "abb = config 5")
     ap.add_argument("--group", type=int, default=None, help="lanes per env: 64 = one wavefront per env; default 16 (A1, ABB), the fastest measured (DESIGN.md 6)")
+    ap.add_argument("--actions", choices=["kernel", "torch"], default="kernel",
+                    help="random actions drawn inside the fused launch (default) or by a torch uniform_ launch before it")
     ap.add_argument("--mapping", choices=["chain", "body", "split"], default=None,
                     help="A1 workloads: lane = kinematic chain (default; csrc/shf_chain.h) or lane = rigid body (the general kernels; "
                          "default with --self-collision).  Kernel selection only: results are bit-identical")
@@ -280,8 +282,12 @@ def main():
     from shifu_amd.parallel import gather_episode_stats
 
     abb = args.workload == "abb"
-    mapping = args.mapping or ((("split" if (args.group or 16) == 16 else "chain") if (abb and not args.link_contacts and (args.group or 16) < 64) else "body"))
-    group = args.group or ((32 if args.link_contacts else 16) if (abb or mapping == "chain") else 32)
+    if abb:
+        mapping = args.mapping or (("split" if (args.group or 16) == 16 else "chain") if (not args.link_contacts and (args.group or 16) < 64) else "body")
+        group = args.group or (32 if args.link_contacts else 16)
+    else:    # the fused A1 env's own default: the chain-per-lane kernel at 32 lanes when there is no self-collision
+        mapping = args.mapping or ("chain" if (not args.self_collision and (args.group or 32) < 64) else "body")
+        group = args.group or 32
     if abb:
         from shifu_amd.gym.abb_fused import FusedAbbEnv
         env = FusedAbbEnv(num_envs=args.envs, device=dev, seed=42, rank=rank, world_size=world, group=group,
@@ -303,10 +309,17 @@ def main():
     nslots = env.task.tensors[stats_t].shape[0]
 
     def eager_step(ev=None):
-        actions.uniform_(-1.0, 1.0, generator=gen)   # = 2*rand-1 of policy_runner.py:40, one kernel, no allocation
-        if ev is not None:
-            ev[0].record()
-        slot = env.task.step(actions)                # the fused kernel (episode statistics included)
+        if args.actions == "kernel":
+            # run_policy('random'): U(-1, 1) drawn inside the fused launch (counter-based, keyed by global env id and
+            # vec-step: BASELINE.md section 3) -- one launch per vec-step
+            if ev is not None:
+                ev[0].record()
+            slot = env.task.step_random()
+        else:
+            actions.uniform_(-1.0, 1.0, generator=gen)   # = 2*rand-1 of policy_runner.py:40, one kernel, no allocation
+            if ev is not None:
+                ev[0].record()
+            slot = env.task.step(actions)                # the fused kernel (episode statistics included)
         if ev is not None:
             ev[1].record()
         return slot
@@ -329,6 +342,7 @@ def main():
         maybe_gather(i, eager_step(), "warmup")
     graph = None
     if use_graph:
+        assert args.actions == "torch", "--graph captures [uniform_, fused step]: use --actions torch"
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         graph.register_generator_state(gen)
@@ -361,10 +375,20 @@ def main():
 
     # duration of the fused kernel alone: HIP events on the launch stream around each of K eager launches
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for i in range(args.steps):
-        eager_step(events[i])
-    torch.cuda.synchronize()
-    kern_ms = sum(a.elapsed_time(b) for a, b in events) / args.steps
+    if args.actions == "kernel":
+        # the vec-step IS the kernel launch: one pair of events around K back-to-back launches (an event pair around every
+        # launch adds ~2 us of event processing to each and reads higher than rocprofv3's per-kernel duration)
+        events[0][0].record()
+        for i in range(args.steps):
+            eager_step()
+        events[0][1].record()
+        torch.cuda.synchronize()
+        kern_ms = events[0][0].elapsed_time(events[0][1]) / args.steps
+    else:
+        for i in range(args.steps):
+            eager_step(events[i])
+        torch.cuda.synchronize()
+        kern_ms = sum(a.elapsed_time(b) for a, b in events) / args.steps
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if use_dist:
@@ -426,7 +450,7 @@ def main():
                                        ", arm collider: the rod against the cube (link contacts OFF, see --link-contacts)") if abb else (", self-collision ON (capsule pairs, the reference's collision filter 0)" if args.self_collision
                                                       else ", self-collision OFF (the reference has it on: units.py:68; see --self-collision)")),
                        "envs_per_gpu": N, "total_envs": total_envs, "substeps_per_env_step": substeps,
-                       "lanes_per_env": group, "lane_mapping": mapping, "self_collision": bool(args.self_collision) and not abb, "vec_step": "hipGraph replay of [uniform_, fused step]" if graph is not None else "eager launches",
+                       "lanes_per_env": group, "lane_mapping": mapping, "self_collision": bool(args.self_collision) and not abb, "vec_step": "hipGraph replay of [uniform_, fused step]" if graph is not None else ("one launch: fused step with the U(-1,1) actions of run_policy('random') drawn in-kernel (counter-based, keyed by global env id and vec-step)" if args.actions == "kernel" else "two eager launches: torch uniform_ + fused step"),
                        "parallelism": f"env-sharded x{world}, all-gather of episode stats every {args.log_interval} steps",
                        "substeps_per_s": value * substeps, "obs_finite": finite, "episodes_reset_rank0": resets,
                        "gathers_in_timed_region": gathers["timed"], "gathers_in_warmup": gathers["warmup"]},
@@ -434,7 +458,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if not prof else prof.get("traffic_bytes"),
                          "traffic_source": None if not prof else prof.get("source"),
-                         "kernel": kernel, "kernel_ms": kern_ms, "alg_bytes_per_env_step": b_alg,
+                         "kernel": ("k_a1_chain" if (kernel == "k_a1_step" and mapping == "chain") else "k_abb_step_ws" if (kernel == "k_abb_step" and mapping == "split") else kernel), "kernel_ms": kern_ms, "alg_bytes_per_env_step": b_alg,
                          "note": "latency/ALU-bound by design: a few KB of compulsory traffic per env-step (DESIGN.md 5)",
                          "secondary": secondary},
         }

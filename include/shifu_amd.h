@@ -391,6 +391,11 @@ int shf_a1_bind(ShfA1Task* task, int32_t id, void* device_ptr);
  * (vec-steps completed so far) % R of SHF_A1_STATS is written by the same launch.  raw_actions: (N,12) policy output.
  * Nothing about the call depends on the step index, so a captured launch can be replayed from a hipGraph. */
 int shf_a1_step(ShfA1Task* task, const float* raw_actions_dev, void* stream);
+/* The same with the actions of run_policy('random') (shifu/runner/policy_runner.py:38-41: 2 * rand - 1) drawn inside the
+ * launch: U(-1, 1) per dof from the task's counter-based generator (Philox4x32-10, seed ShfA1TaskParams.seed, counter =
+ * global env id, vec-step index, dof), so that a random-action roll-out is one launch per vec-step and a sharded run
+ * draws what the unsharded one does.  The clipped, scaled actions land in SHF_A1_ACTIONS as usual. */
+int shf_a1_step_random(ShfA1Task* task, void* stream);
 /* ShifuVecEnv.reset_idx(arange(N)) part of reset() (env.py:108-112). */
 int shf_a1_reset_all(ShfA1Task* task, void* stream);
 
@@ -453,6 +458,8 @@ int shf_abb_layout(const ShfAbbTask* task, int32_t id, int64_t shape[4], int32_t
 int shf_abb_bind(ShfAbbTask* task, int32_t id, void* device_ptr);
 /* ShifuVecEnv.step for AbbPushBox, statistics row included (as shf_a1_step); raw_actions (N,3). */
 int shf_abb_step(ShfAbbTask* task, const float* raw_actions_dev, void* stream);
+/* run_policy('random') for the ABB task: as shf_a1_step_random (three end-effector action components per env). */
+int shf_abb_step_random(ShfAbbTask* task, void* stream);
 /* reset_idx(arange(N)) (env.py:108-112). */
 int shf_abb_reset_all(ShfAbbTask* task, void* stream);
 

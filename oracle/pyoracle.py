@@ -73,6 +73,16 @@ def dropped(reset: bool = True) -> int:
     return int(f(C.c_int(1 if reset else 0)))
 
 
+def random_actions(seed: int, n: int, env_off: int, step: int, nd: int) -> np.ndarray:
+    """run_policy('random') raw actions as shf_a1_step_random / shf_abb_step_random draw them in-kernel: (n, nd) float32,
+    U(-1, 1), Philox4x32-10 keyed by `seed`, counter (global env id, vec-step index, dof)."""
+    out = np.zeros((n, nd), np.float32)
+    f = lib().shf_oracle_random_actions
+    f.restype = None
+    f(C.c_uint64(seed), C.c_int(n), C.c_int64(env_off), C.c_uint64(step), C.c_int(nd), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
 def _p(a, ct):
     return None if a is None else a.ctypes.data_as(C.POINTER(ct))
 

@@ -37,12 +37,14 @@ _SIGS = {
     "shf_a1_layout": ([vp, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)], i32),
     "shf_a1_bind": ([vp, i32, vp], i32),
     "shf_a1_step": ([vp, vp, vp], i32),
+    "shf_a1_step_random": ([vp, vp], i32),
     "shf_a1_reset_all": ([vp, vp], i32),
     "shf_abb_create": ([vp, C.POINTER(_abi.ShfAbbTaskParams), C.POINTER(vp)], i32),
     "shf_abb_destroy": ([vp], i32),
     "shf_abb_layout": ([vp, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)], i32),
     "shf_abb_bind": ([vp, i32, vp], i32),
     "shf_abb_step": ([vp, vp, vp], i32),
+    "shf_abb_step_random": ([vp, vp], i32),
     "shf_abb_reset_all": ([vp, vp], i32),
     "shf_mlp_linear_forward": ([vp, vp, vp, vp, i32, i32, i32, i32, vp], i32),
     "shf_mlp_linear_backward_input": ([vp, vp, vp, vp, i32, i32, i32, vp], i32),

@@ -280,6 +280,13 @@ class A1Task:
         return self.advance_slot()
 
     @_on_device
+    def step_random(self) -> int:
+        """One fused vec-step of run_policy('random') (policy_runner.py:38-41): the U(-1, 1) actions are drawn inside the
+        launch from the task's counter-based generator -- no per-step RNG launch; returns the statistics ring row."""
+        check(lib().shf_a1_step_random(self._h, _stream_ptr(self.sim.device)))
+        return self.advance_slot()
+
+    @_on_device
     def launch_step(self, raw_actions: torch.Tensor):
         """Only the launch (no host-side bookkeeping): what a hipGraph capture records.  The kernel picks the ring row
         from its device-side step counter; pair every replay with advance_slot()."""
@@ -353,6 +360,12 @@ class AbbTask:
         a = raw_actions.contiguous()
         assert a.dtype == torch.float32 and a.shape == (self.sim.num_envs, 3)
         check(lib().shf_abb_step(self._h, C.c_void_p(a.data_ptr()), _stream_ptr(self.sim.device)))
+        return self.advance_slot()
+
+    @_on_device
+    def step_random(self) -> int:
+        """As A1Task.step_random: run_policy('random') with the actions drawn inside the launch."""
+        check(lib().shf_abb_step_random(self._h, _stream_ptr(self.sim.device)))
         return self.advance_slot()
 
     @_on_device

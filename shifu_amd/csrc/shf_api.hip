@@ -262,7 +262,7 @@ DEV void a1_step_body(const A1Args& A) {
     if (e < n) {
       if (l < 2 * ndc) pre_dof = A.S.dof[(size_t)e * ndc * 2 + l];
       if (l < 13) pre_root = A.S.root[(size_t)e * 13 + l];
-      if (l < ndc) pre_act = A.raw_actions[(size_t)e * ndc + l];
+      if (l < ndc) pre_act = raw_action(A, e, l, ndc, stats_step);
     }
   }
   stage_block<(int)sizeof(ShfA1TaskParams)>(A.tp, smem + MODEL_WORDS);
@@ -287,7 +287,7 @@ DEV void a1_step_body(const A1Args& A) {
   } else {
     for (int i = l; i < 2 * nd; i += G) L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)] = dof[i];
     if (l < 13) L.root[l] = root[l];
-    if (l < nd) act = rclampf(A.raw_actions[(size_t)e * nd + l] * tp.action_scale, -tp.clip_actions, tp.clip_actions);
+    if (l < nd) act = rclampf(raw_action(A, e, l, nd, stats_step) * tp.action_scale, -tp.clip_actions, tp.clip_actions);
   }
   if (l < nd) A.actions[(size_t)e * nd + l] = act;
   GROUP_SYNC();
@@ -419,7 +419,7 @@ DEV void abb_reset_env(const ShfAbbTaskParams& tp, int nd, int nbx, int64_t gid,
 // (possibly stale pose) -> POS targets of this env step (tgtl: LDS; also written to the dof_targets tensor)
 // q, qstride: the joint positions (LDS dof block, DOF_STRIDE; or this env's rows of the dof_state tensor, 2)
 DEV void abb_ik_targets(const AbbArgs& A, const ShfAbbTaskParams& tp, const float* q, int qstride, int e, int nd, const float* bstate,
-                        const float* jac, float* tgtl) {
+                        const float* jac, float* tgtl, unsigned long long step) {
     float act[3], dpose[6], eq[4], cc[4], qr[4];
     const float* ee = bstate + 13 * tp.ee_body;
     float eep[3] = {ee[0], ee[1], ee[2]};
@@ -427,7 +427,7 @@ DEV void abb_ik_targets(const AbbArgs& A, const ShfAbbTaskParams& tp, const floa
     for (int k = 0; k < 4; k++) eq[k] = ee[3 + k];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      act[k] = rclampf(A.raw_actions[(size_t)e * 3 + k], -tp.clip_actions, tp.clip_actions);
+      act[k] = rclampf(raw_action(A, e, k, 3, step), -tp.clip_actions, tp.clip_actions);
       A.actions[(size_t)e * 3 + k] = act[k];
       const float tar = rclampf(eep[k] + act[k] * tp.ee_velocity * tp.env_dt, tp.min_ee_pos[k], tp.max_ee_pos[k]);
       dpose[k] = tar - eep[k];
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256, (G >= 32 && SC::NBX > 0) ? 2 : 1) void k_abb_s
   GROUP_SYNC();
 
   // AbbRobot.step: EE-delta -> clip -> damped least squares on the Jacobian tensor (possibly stale pose)
-  if (l == 0) abb_ik_targets(A, tp, L.dofb, DOF_STRIDE, e, nd, bstate, jac, tgtl);
+  if (l == 0) abb_ik_targets(A, tp, L.dofb, DOF_STRIDE, e, nd, bstate, jac, tgtl, stats_step);
   GROUP_SYNC();
   PHASE_MARK(11);
 
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
   // AbbRobot.step's inverse kinematics on the box wave, beside the arm wave's loads (it reads the tensors directly)
   if (!arm && live && l == 0)
     abb_ik_targets(A, tp, A.S.dof + (size_t)e * nd * 2, 2, e, nd, A.body_state + (size_t)e * nbt * 13,
-                   A.jacobian + (size_t)e * (nb - 1) * 6 * nd, tgtl);
+                   A.jacobian + (size_t)e * (nb - 1) * 6 * nd, tgtl, stats_step);
   __syncthreads();                               // S0: root rows and POS targets visible to both
   PHASE_MARK(11);
 
@@ -1309,8 +1309,13 @@ static int a1_args(ShfA1Task* task, const float* raw_actions_dev, const char* wh
   return 0;
 }
 
+static int a1_step_launch(ShfA1Task* task, const float* raw_actions_dev, void* stream);
 extern "C" int shf_a1_step(ShfA1Task* task, const float* raw_actions_dev, void* stream) {
   if (!raw_actions_dev) return fail("shf_a1_step: null actions");
+  return a1_step_launch(task, raw_actions_dev, stream);
+}
+extern "C" int shf_a1_step_random(ShfA1Task* task, void* stream) { return a1_step_launch(task, nullptr, stream); }
+static int a1_step_launch(ShfA1Task* task, const float* raw_actions_dev, void* stream) {
   A1Args A;
   if (int r = a1_args(task, raw_actions_dev, "shf_a1_step", A)) return r;
   ShfSim* s = task->sim;
@@ -1449,8 +1454,13 @@ static int abb_args(ShfAbbTask* task, const float* raw_actions_dev, const char* 
   return 0;
 }
 
+static int abb_step_launch(ShfAbbTask* task, const float* raw_actions_dev, void* stream);
 extern "C" int shf_abb_step(ShfAbbTask* task, const float* raw_actions_dev, void* stream) {
   if (!raw_actions_dev) return fail("shf_abb_step: null actions");
+  return abb_step_launch(task, raw_actions_dev, stream);
+}
+extern "C" int shf_abb_step_random(ShfAbbTask* task, void* stream) { return abb_step_launch(task, nullptr, stream); }
+static int abb_step_launch(ShfAbbTask* task, const float* raw_actions_dev, void* stream) {
   AbbArgs A;
   if (int r = abb_args(task, raw_actions_dev, "shf_abb_step", A)) return r;
   ShfSim* s = task->sim;

@@ -627,7 +627,7 @@ DEV void a1_chain_step_body(const A1Args& A) {
     for (int k = 0; k < NW; k++)
       if (l + k * G < 2 * nd) pre_dof[k] = A.S.dof[(size_t)e * nd * 2 + l + k * G];
     if (l < 13) pre_root = A.S.root[(size_t)e * 13 + l];
-    if (l < nd) pre_act = A.raw_actions[(size_t)e * nd + l];
+    if (l < nd) pre_act = raw_action(A, e, l, nd, stats_step);
   }
   stage_block<(int)sizeof(ShfA1TaskParams)>(A.tp, smem + MODEL_WORDS);
   const ShfModel* m = stage_model(A.S.model, smem);

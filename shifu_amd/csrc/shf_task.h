@@ -179,6 +179,22 @@ DEV void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t
 }
 DEV float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
 DEV float urange(uint32_t x, float lo, float hi) { return (hi - lo) * u01(x) + lo; }
+// run_policy('random') (shifu/runner/policy_runner.py:38-41) without a per-step RNG launch: the raw action of dof d of
+// global env gid at vec-step `step` is U(-1, 1) from the counter-based generator that also drives the resets
+// (Philox4x32-10 keyed by the task seed; counter words gid, step, 0x40000000 + d / 4 -- the reset draws use 0, 1, 2 there),
+// so a sharded run draws what the unsharded one does.  Oracle: shf_oracle_random_actions.
+DEV float random_action(int64_t seed, int64_t gid, unsigned long long step, int d) {
+  uint32_t r[4];
+  philox4x32((uint32_t)gid, (uint32_t)step, 0x40000000u + (uint32_t)(d >> 2), (uint32_t)(gid >> 32) ^ ((uint32_t)(step >> 32) << 16),
+             (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  return urange(r[d & 3], -1.0f, 1.0f);
+}
+// the policy's raw action: the caller's tensor, or (null) the generator above
+template <class ARGS>
+DEV float raw_action(const ARGS& A, int e, int d, int nd, unsigned long long step) {
+  if (A.raw_actions) return A.raw_actions[(size_t)e * nd + d];
+  return random_action(A.tp->seed, A.env_off + e, step, d);
+}
 DEV void quat_rotate_inverse(const float* q, const float* v, float* o) {
   const float w = q[3];
   const float s = 2.0f * (w * w) - 1.0f;

@@ -116,12 +116,14 @@ class FusedA1Env:
         self.sim.set_heightfield(np.ascontiguousarray(samples), ct.horizontal_scale, ct.vertical_scale, ct.border_size,
                                  ct.static_friction, warp=warp)
         self.sim.set_articulation(self.cm.blob)
-        # kernel selection (same results bit for bit): lane = rigid body (any articulation, 32 lanes for the A1) or
-        # lane = kinematic chain (mapping="chain": A1-shaped trees, 16 lanes per env, no self-collision)
+        # kernel selection (same results bit for bit): lane = kinematic chain (mapping="chain", csrc/shf_chain.h: A1-shaped
+        # trees at 16 or 32 lanes per env, no self-collision -- the measured-fastest at 32 lanes: 71.0 vs 72.6 us per
+        # vec-step, profiles/r03_bench_terrain*.json) or lane = rigid body (mapping="body": any articulation, 32 lanes
+        # for the A1, also 64; self-collision)
         if mapping is None:
-            mapping = "body"
+            mapping = "chain" if (not self_collision and group in (None, 16, 32)) else "body"
         if group is None:
-            group = 16 if mapping == "chain" else 32
+            group = 32
         self.mapping, self.group = mapping, group
         self.sim.finalize(num_envs, self.env_id_offset, group=group, mapping=mapping)
 
@@ -182,6 +184,14 @@ class FusedA1Env:
     # -- VecEnv surface ------------------------------------------------------
     def step(self, actions: torch.Tensor):
         self.task.step(actions)
+        self.common_step_counter += 1
+        self._fill_extras()
+        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def step_random(self):
+        """run_policy('random') (policy_runner.py:38-41) in one launch: the U(-1, 1) actions are drawn inside the fused
+        step from the task's counter-based generator (csrc/shf_task.h: random_action); same return as step()."""
+        self.task.step_random()
         self.common_step_counter += 1
         self._fill_extras()
         return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras

@@ -83,6 +83,15 @@ class FusedAbbEnv:
 
     def step(self, actions: torch.Tensor):
         self.task.step(actions)
+        return self._after_step()
+
+    def step_random(self):
+        """run_policy('random') in one launch: U(-1, 1) actions drawn inside the fused step (A1 counterpart:
+        FusedA1Env.step_random)."""
+        self.task.step_random()
+        return self._after_step()
+
+    def _after_step(self):
         st = self.task.tensors[_abi.ABB_STATS][-1]
         self.extras["episode"] = {REWARD_NAMES[0]: st[4], REWARD_NAMES[1]: st[5], "success_rate": st[6]}
         self.extras["episode_sums"] = st[:4]

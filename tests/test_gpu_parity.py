@@ -584,6 +584,62 @@ def test_ragged_env_counts(oracle, n, group):
     _compare(sim, task, bufs, f"n={n}")
 
 
+@pytest.mark.parametrize("kind", ["a1", "a1-chain", "abb-split", "abb-levels"])
+def test_random_action_step_matches_oracle_bitwise(oracle, kind):
+    """shf_a1_step_random / shf_abb_step_random -- run_policy('random') with the U(-1, 1) actions drawn inside the launch
+    (Philox4x32-10, counter = global env id, vec-step index, dof) -- against the oracle fed with the actions the oracle's
+    own restatement of that generator gives (oracle.random_actions): every tensor bit for bit, global ids offset as on
+    rank 1 of a sharded run."""
+    _need_gpu()
+    n, off = 21, 4096
+    if kind.startswith("a1"):
+        from shifu_amd.gym.a1_fused import FusedA1Env
+        env = FusedA1Env(num_envs=n, rank=1, world_size=2, seed=9, group=32, mapping="chain" if kind.endswith("chain") else "body")
+        off = env.env_id_offset
+        env.reset()
+    else:
+        from shifu_amd.gym.abb_fused import FusedAbbEnv
+        env = FusedAbbEnv(num_envs=n, rank=1, world_size=2, seed=9, group=16, mapping="split" if kind.endswith("split") else "body")
+        off = env.env_id_offset
+    # the generator itself: two runs of the oracle's restatement agree with each other and differ between steps / envs
+    a0 = oracle.random_actions(9, n, off, 0, env.num_actions)
+    a1 = oracle.random_actions(9, n, off, 1, env.num_actions)
+    assert a0.shape == (n, env.num_actions) and (np.abs(a0) <= 1).all() and not np.array_equal(a0, a1)
+    assert len(np.unique(a0)) > 0.9 * a0.size
+    if kind.startswith("abb"):
+        bufs = {k: env.sim.tensors[t].cpu().numpy().copy() for k, t in _ABB_SIM_T.items()}
+        bufs.update({k: env.task.tensors[t].cpu().numpy().copy() for k, t in _ABB_T.items()})
+        for it in range(20):
+            step = env.task.step_index
+            env.task.step_random()
+            raw = oracle.random_actions(env.task_params.seed, n, off, step, 3)
+            oracle.abb_step(env.cm.blob, env.sim_params, env.boxes, env.task_params, n, off, bufs, raw)
+        torch.cuda.synchronize()
+        for k, t in list(_ABB_SIM_T.items()) + list(_ABB_T.items()):
+            got = (env.sim.tensors if k in _ABB_SIM_T else env.task.tensors)[t].cpu().numpy().reshape(bufs[k].shape)
+            np.testing.assert_array_equal(got, bufs[k], err_msg=f"{kind}: {k}")
+        return
+    # A1: two envs built alike -- one stepped with in-kernel actions, the other fed the oracle's actions through the
+    # tensor entry point (itself held to the oracle by the tests above): identical tensors
+    ref = FusedA1Env(num_envs=n, rank=1, world_size=2, seed=9, group=32, mapping="body")
+    ref.reset()
+    for it in range(25):
+        step = env.task.step_index
+        assert step == ref.task.step_index
+        env.step_random()
+        raw = oracle.random_actions(env.task_params.seed, n, off, step, 12)
+        ref.step(torch.from_numpy(raw).cuda())
+    torch.cuda.synchronize()
+    for tid in range(_abi.A1_COUNT):
+        if tid in (_abi.A1_PARAMS,):
+            continue
+        a, b = env.task.tensors[tid], ref.task.tensors[tid]
+        assert torch.equal(a, b), f"{kind}: task tensor {tid}"
+    for tid in (_abi.T_DOF_STATE, _abi.T_ROOT_STATE, _abi.T_BODY_STATE, _abi.T_CONTACT):
+        assert torch.equal(env.sim.tensors[tid], ref.sim.tensors[tid]), f"{kind}: sim tensor {tid}"
+    assert int(ref.task.tensors[_abi.A1_RESET_COUNT].sum()) >= 0
+
+
 @pytest.mark.parametrize("mapping,group", [("split", 16), ("chain", 16), ("chain", 32)])
 @pytest.mark.parametrize("n", [1, 5, 13])
 def test_ragged_env_counts_abb(oracle, n, mapping, group):
@@ -632,8 +688,8 @@ def test_full_size_determinism_and_shard_invariance(group):
     g = torch.Generator(device="cuda:0")
 
     def run(num, rank, world, acts=None):
-        env = (FusedA1Env(num_envs=num, rank=rank, world_size=world, seed=42, mapping="chain") if group == "chain" else
-               FusedA1Env(num_envs=num, rank=rank, world_size=world, seed=42, group=group))
+        env = (FusedA1Env(num_envs=num, rank=rank, world_size=world, seed=42, mapping="chain", group=16) if group == "chain" else
+               FusedA1Env(num_envs=num, rank=rank, world_size=world, seed=42, group=group, mapping="body"))
         assert env.mapping == ("chain" if group == "chain" else "body")
         env.reset()
         out = []
