@@ -169,3 +169,19 @@ def test_spec_sincos_exp_accuracy(oracle):
     e = oracle.exp(y)
     ref = np.exp(y.astype(np.float64))
     assert (np.abs(e - ref) / ref).max() < 3e-7
+
+
+def test_random_action_generator_is_counter_based_and_uniform(oracle):
+    """oracle.random_actions -- the restatement of csrc/shf_task.h: random_action, run_policy('random')'s 2 * rand - 1 drawn
+    in-kernel (shf_a1_step_random): U(-1, 1) to the statistics of 10^6 draws, a pure function of (seed, global env id,
+    vec-step, dof) -- so a shard (env_off) draws exactly what the same envs draw in an unsharded run."""
+    a = oracle.random_actions(42, 4096, 0, 7, 12)
+    assert a.shape == (4096, 12) and a.dtype == np.float32 and (a >= -1).all() and (a < 1).all()
+    big = np.concatenate([oracle.random_actions(42, 4096, 0, s, 12) for s in range(20)])
+    assert abs(big.mean()) < 3e-3 and abs(big.var() - 1.0 / 3.0) < 3e-3
+    assert abs(np.corrcoef(big[:-1].ravel(), big[1:].ravel())[0, 1]) < 5e-3           # neighbouring envs uncorrelated
+    assert np.array_equal(a, oracle.random_actions(42, 4096, 0, 7, 12))               # deterministic
+    assert np.array_equal(a[1000:1064], oracle.random_actions(42, 64, 1000, 7, 12))   # shard == slice of the whole
+    assert not np.array_equal(a, oracle.random_actions(42, 4096, 0, 8, 12))           # next vec-step
+    assert not np.array_equal(a, oracle.random_actions(43, 4096, 0, 7, 12))           # another seed
+    assert np.array_equal(a[:, :3], oracle.random_actions(42, 4096, 0, 7, 3))         # the ABB's three components: the same stream
