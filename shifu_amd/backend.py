@@ -181,19 +181,45 @@ class Sim:
             self.bind(tid, t)
 
     # -- launches -----------------------------------------------------------
-    @_on_device
+    # step / refresh / set_dof_command are what a user's control loop calls decimation x 3 times per vec-step
+    # (a1_conditional.py:64-75): they skip the generic wrapper when the sim's GPU is already current (bound library
+    # functions, the raw stream handle as an int) -- ~3 us less host time per call, same calls into the library.
+    def _fast(self):
+        f = getattr(self, "_fast_fns", None)
+        if f is None:
+            L = lib()
+            f = self._fast_fns = (L.shf_sim_step, L.shf_sim_refresh, L.shf_sim_set_dof_command, self.device.index,
+                                  torch._C._cuda_getCurrentRawStream)
+        return f
+
     def step(self):
-        check(lib().shf_sim_step(self._h, _stream_ptr(self.device)))
+        f_step, _, _, idx, raw_stream = self._fast()
+        if torch.cuda.current_device() == idx:
+            if f_step(self._h, raw_stream(idx)):
+                check(1)
+            return
+        with torch.cuda.device(self.device):
+            check(f_step(self._h, _stream_ptr(self.device)))
 
-    @_on_device
     def refresh(self, mask: int = _abi.REFRESH_ALL):
-        check(lib().shf_sim_refresh(self._h, mask, _stream_ptr(self.device)))
+        _, f_refresh, _, idx, raw_stream = self._fast()
+        if torch.cuda.current_device() == idx:
+            if f_refresh(self._h, mask, raw_stream(idx)):
+                check(1)
+            return
+        with torch.cuda.device(self.device):
+            check(f_refresh(self._h, mask, _stream_ptr(self.device)))
 
-    @_on_device
     def set_dof_command(self, tid: int, values: torch.Tensor):
-        v = values.contiguous()
+        v = values if values.is_contiguous() else values.contiguous()
         assert v.dtype == torch.float32 and v.numel() == self.num_envs * self.model.nd
-        check(lib().shf_sim_set_dof_command(self._h, tid, C.c_void_p(v.data_ptr()), _stream_ptr(self.device)))
+        _, _, f_cmd, idx, raw_stream = self._fast()
+        if torch.cuda.current_device() == idx:
+            if f_cmd(self._h, tid, v.data_ptr(), raw_stream(idx)):
+                check(1)
+            return
+        with torch.cuda.device(self.device):
+            check(f_cmd(self._h, tid, C.c_void_p(v.data_ptr()), _stream_ptr(self.device)))
 
     @_on_device
     def set_pos_target_indexed(self, values: torch.Tensor, idx: torch.Tensor):
