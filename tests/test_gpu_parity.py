@@ -221,6 +221,52 @@ def test_fused_a1_step_matches_oracle_bitwise(oracle, rough, group):
     assert np.isfinite(bufs["obs"]).all()
 
 
+@pytest.mark.parametrize("group", [32, "chain32"])
+def test_fused_a1_step_matches_oracle_bitwise_at_full_size(oracle, group):
+    """BASELINE's env count (4096 per GPU): the fused A1 step against the oracle (OpenMP over envs), every tensor bit for
+    bit, 30 vec-steps with resets -- not only through size-independent properties."""
+    _need_gpu()
+    n = 4096
+    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, seed=91, group=group, env_off=8192)
+    bufs["ep_len"][:] = rng.integers(900, 1001, n)       # time-outs inside the window for a good share of the envs
+    _upload(sim, task, bufs)
+    resets = 0
+    for it in range(30):
+        raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32)
+        slot = task.step(torch.from_numpy(raw).cuda())
+        oracle.a1_step(cm.blob, sp, tp, n, 8192, bufs, raw, terrain=terr, heights=hs)
+        if it % 10 == 9:
+            _compare(sim, task, bufs, f"step {it}")
+            np.testing.assert_array_equal(task.tensors[_abi.A1_STATS][slot].cpu().numpy(), oracle.a1_stats(tp, n, bufs["done_sums"]))
+        resets += int(bufs["reset"].sum())
+    assert resets > 100
+
+
+def test_fused_abb_step_matches_oracle_bitwise_at_full_size(oracle):
+    """The same for config 5 on its default kernel (arm wave + box wave per env group): 4096 envs, 30 vec-steps."""
+    _need_gpu()
+    from shifu_amd.gym.abb_fused import FusedAbbEnv
+    n = 4096
+    env = FusedAbbEnv(num_envs=n, seed=23)
+    assert env.mapping == "split"
+    env.task.tensors[_abi.ABB_EP_LEN].copy_(torch.randint(150, 201, (n,)))
+    torch.cuda.synchronize()
+    bufs = {k: env.sim.tensors[t].cpu().numpy().copy() for k, t in _ABB_SIM_T.items()}
+    bufs.update({k: env.task.tensors[t].cpu().numpy().copy() for k, t in _ABB_T.items()})
+    rng = np.random.default_rng(4)
+    resets = 0
+    for it in range(30):
+        raw = (2 * rng.random((n, 3)) - 1).astype(np.float32)
+        env.task.step(torch.from_numpy(raw).cuda())
+        oracle.abb_step(env.cm.blob, env.sim_params, env.boxes, env.task_params, n, 0, bufs, raw)
+        resets += int(bufs["reset"].sum())
+    torch.cuda.synchronize()
+    for k, t in list(_ABB_SIM_T.items()) + list(_ABB_T.items()):
+        got = (env.sim.tensors if k in _ABB_SIM_T else env.task.tensors)[t].cpu().numpy().reshape(bufs[k].shape)
+        np.testing.assert_array_equal(got, bufs[k], err_msg=k)
+    assert resets > 100
+
+
 @pytest.mark.parametrize("group", [32, "chain16", "chain32"])
 def test_fused_a1_step_push_on_every_body(oracle, group):
     """rand_force_buf is (N, bodies, 3) (a1_conditional.py:82-87): a user may push any body, welded feet included --
