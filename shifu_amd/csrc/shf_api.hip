@@ -1482,6 +1482,7 @@ static int abb_step_launch(ShfAbbTask* task, const float* raw_actions_dev, void*
         !AbbScene::matches(s->nboxes, s->boxes, s->model.nsph) || s->group == 64)
       return fail("shf_abb_step: the chain mapping needs the 6-link arm with 3 sample points and one capsule, the table / cube / pad "
                   "scene, no link contacts, and 16 or 32 lanes per env");
+    if (s->mapping_split && s->group != 16) return fail("shf_abb_step: the split chain mapping runs at 16 lanes per env");
     if (s->group == 16 && s->mapping_split) {
       // arm and boxes on different waves of the workgroup (k_abb_step_ws): WT / 32 envs per block
       const int wt = s->mapping_split, wepb = wt / 32;
