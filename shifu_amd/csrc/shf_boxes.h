@@ -672,6 +672,9 @@ __host__ __device__ inline int box_slot_count(int nbx, int nsph) { return nbx * 
 // joint pair law (pair_law_joint): which capsule, if any, has exactly its two ends as box kd's active pair slots; where the
 // record lives (the box's exchange slot: boxes hand nothing to a parent); the force of sphere slot si either way
 DEV int box_joint_pair(const ShfModel* m, const EnvLds& L, int nbx, int kd, unsigned sb, int nlink_on_box) {
+#ifdef SHF_EXP_NO_JOINT_LAW   /* timing experiment only (tools/mlp_probe.py-style build): the independent laws everywhere */
+  return -1;
+#endif
   return joint_pair_of(m, sb, nlink_on_box, [&](int si) { return L.pt[sphere_slot(m, nbx, si, kd) * PT_STRIDE + PT_CT]; });
 }
 DEV float* joint_record(const ShfModel* m, const EnvLds& L, int kd) { return L.xch + (m->nb + kd) * XCH_STRIDE; }
