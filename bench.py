@@ -31,7 +31,8 @@ sys.path.insert(0, ROOT)
 
 # Algorithmic HBM bytes per env-step (restated in DESIGN.md section 5)
 B_ALG = {"terrain": 5539, "flat": 5019, "trimesh": 5539, "abb": 2140}
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s achievable)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0   # MI355X_MICROARCH.md: 6.29 TB/s measured (float4 copy) -- the figure BASELINE.md section 2 quotes fractions of
 VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector (non-matrix) peak
 NUM_CUS, SIMDS_PER_CU = 256, 4
 MAX_CLOCK_HZ = 2.4e9       # MI355X_MICROARCH.md: max clock
@@ -223,7 +224,7 @@ def main():
     ap.add_argument("--workload", choices=["terrain", "flat", "trimesh", "abb"], default="terrain",
                     help="terrain = config 3 (height field); trimesh = the same samples as the mesh with vertical risers; "
                          "abb = config 5")
-    ap.add_argument("--group", type=int, default=None, help="lanes per env: 64 = one wavefront per env; default 16 (A1, ABB), the fastest measured (DESIGN.md 6)")
+    ap.add_argument("--group", type=int, default=None, help="lanes per env: 64 = one wavefront per env; default 32 for the A1 workloads and for abb --link-contacts, 16 for abb: the fastest measured (DESIGN.md 6)")
     ap.add_argument("--actions", choices=["kernel", "torch"], default="kernel",
                     help="random actions drawn inside the fused launch (default) or by a torch uniform_ launch before it")
     ap.add_argument("--mapping", choices=["chain", "body", "split"], default=None,
@@ -390,10 +391,16 @@ def main():
         torch.cuda.synchronize()
         kern_ms = sum(a.elapsed_time(b) for a, b in events) / args.steps
 
+    # every rank's own elapsed time: the MAX is the job's time (the contract), MIN / MAX together show the spread
+    rank_elapsed = elapsed
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    tmin = t.clone()
+    dist_world = 1
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        dist_world = dist.get_world_size()
+    elapsed, elapsed_min = float(t.item()), float(tmin.item())
     finite = bool(torch.isfinite(env.obs_buf).all().item())
     resets = int(env.task.tensors[count_t].sum().item())
 
@@ -443,6 +450,12 @@ def main():
             "metric": ("env-steps/sec (whole node), ABB push-box 6-dof arm + free cube, 4096 envs/GPU" if abb else
                        "env-steps/sec (whole node), A1 12-dof 4096 envs/GPU"), "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            # what the process group itself reports (proves that the collective backend saw N ranks) and the spread of the
+            # per-rank clocks around the same K steps; `ms_per_step` is the slowest rank's
+            "rccl_world_size": (dist_world if (use_dist and backend == "nccl") else None),
+            "dist": {"backend": (backend if use_dist else None), "world_size": dist_world,
+                     "ms_per_step_rank_min": elapsed_min / args.steps * 1e3, "ms_per_step_rank_max": elapsed / args.steps * 1e3,
+                     "ms_per_step_rank0": rank_elapsed / args.steps * 1e3},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{WL_NAME[args.workload]}, {N} envs/GPU, random actions, {substeps} substeps/env-step "
                                    f"(dt {'20' if abb else '5'} ms), resets on"
@@ -456,12 +469,19 @@ def main():
                        "gathers_in_timed_region": gathers["timed"], "gathers_in_warmup": gathers["warmup"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
+                         "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
                          "traffic": None if not prof else prof.get("traffic_bytes"),
                          "traffic_source": None if not prof else prof.get("source"),
                          "kernel": ("k_a1_chain" if (kernel == "k_a1_step" and mapping == "chain") else "k_abb_step_ws" if (kernel == "k_abb_step" and mapping == "split") else kernel), "kernel_ms": kern_ms, "alg_bytes_per_env_step": b_alg,
                          "note": "latency/ALU-bound by design: a few KB of compulsory traffic per env-step (DESIGN.md 5)",
                          "secondary": secondary},
         }
+        if kern_ms > out["ms_per_step"]:
+            # a kernel cannot take longer than the step that contains it: the two are different passes of K launches (the
+            # timed region by the host clock, then a second pass bracketed by HIP events) and differ by run-to-run noise
+            out["roofline"]["kernel_ms_note"] = ("kernel_ms (HIP events, second pass of K launches) reads above ms_per_step (host clock, "
+                                                 "timed pass): pass-to-pass noise, not a longer kernel; roofline.achieved uses kernel_ms, "
+                                                 "the more conservative of the two")
         if not args.no_cpu_baseline and world == 1:
             cb = out["cpu_baseline"] = cpu_baseline(args.workload)     # the only leg that touches oracle/
             f_alg = cb["flops_per_env_step"]

@@ -97,7 +97,9 @@ typedef struct ShfModel {
    * pt_eval[s] (a permutation of 0..np-1, lowest points of the rest pose first, so that the points that usually touch
    * the ground share the first round and the later rounds can skip the contact response wave-wide); pt_slot is its
    * inverse.  Results do not depend on it: contacts are folded into their body in point order whatever the order of
-   * evaluation.  The model compiler fills both; an all-zero pt_eval reads as the identity. */
+   * evaluation.  The model compiler fills both; a model built by hand through the C API has to as well (the identity is
+   * fine): shf_sim_set_mapping(SHF_MAP_CHAIN) refuses a pt_eval that is not a permutation with pt_slot its inverse, and
+   * the body-mapped kernels do not read either. */
   int32_t pt_eval[SHF_MAX_POINTS];
   int32_t pt_slot[SHF_MAX_POINTS];
 

@@ -146,7 +146,8 @@ class Sim:
     def finalize(self, num_envs: int, env_id_offset: int = 0, group: int = 64, mapping: str = "body"):
         """group: lanes per env; mapping: 'body' (lane = rigid body, any articulation) or 'chain' (lane = kinematic chain:
         the A1's tree, csrc/shf_chain.h, or the ABB's serial arm, csrc/shf_arm.h; 16 or 32 lanes) -- kernel selection,
-        identical results."""
+        identical results.  For the A1's chain mapping `group` is the width of the fused step only: gym.simulate, refresh_*
+        and the reset kernels keep the library's body-mapped width (64 lanes), whatever self.group says."""
         self.num_envs = num_envs
         self.group = group
         self.mapping = mapping

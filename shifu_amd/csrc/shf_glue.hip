@@ -60,7 +60,10 @@ __global__ void k_get_heights(ShfTerrain t, const int16_t* h, const float* root_
     float px = bx + qw * tx + (-qz * ty) + r[0];
     float py = by + qw * ty + (qz * tx) + r[1];
     px += t.border; py += t.border;
-    int ix = (int)truncf(px / t.hscale), iy = (int)truncf(py / t.hscale);
+    // `points / horizontal_scale` as torch evaluates it on a GPU tensor with a Python-float divisor: x * (1 / s)
+    // (ATen BinaryDivTrueKernel.cu); tests/test_gpu_glue.py holds this to the torch expression on cell-boundary points
+    const float inv_hs = 1.0f / t.hscale;
+    int ix = (int)truncf(px * inv_hs), iy = (int)truncf(py * inv_hs);
     ix = ix < 0 ? 0 : ix; ix = ix > t.rows - 2 ? t.rows - 2 : ix;
     iy = iy < 0 ? 0 : iy; iy = iy > t.cols - 2 ? t.cols - 2 : iy;
     const int16_t* p0 = h + (size_t)ix * t.cols + iy;

@@ -295,6 +295,8 @@ DEV void a1_post_step(const A1Args& A, const ShfModel* m, const ShfA1TaskParams&
     // HC sample points per lane and trip: their point loads, then their height loads, go out together
     constexpr int HC = 3;
     const float rx = L.root[0], ry = L.root[1];
+    // `points / horizontal_scale` as torch evaluates it on a GPU tensor with a Python-float divisor: x * (1 / s)
+    const float inv_hs = 1.0f / A.S.terr.hscale;
     for (int base = l; base < P; base += HC * G) {
       float bx[HC], by[HC], hh[HC];
 #pragma unroll
@@ -310,7 +312,7 @@ DEV void a1_post_step(const A1Args& A, const ShfModel* m, const ShfA1TaskParams&
           float px = bx[k] + qw * tx + (-qz * ty) + rx;
           float py = by[k] + qw * ty + (qz * tx) + ry;
           px += A.S.terr.border; py += A.S.terr.border;
-          int ix = (int)truncf(px / A.S.terr.hscale), iy = (int)truncf(py / A.S.terr.hscale);
+          int ix = (int)truncf(px * inv_hs), iy = (int)truncf(py * inv_hs);
           ix = ix < 0 ? 0 : ix; ix = ix > A.S.terr.rows - 2 ? A.S.terr.rows - 2 : ix;
           iy = iy < 0 ? 0 : iy; iy = iy > A.S.terr.cols - 2 ? A.S.terr.cols - 2 : iy;
           const int16_t* p0 = A.S.heights + (size_t)ix * A.S.terr.cols + iy;

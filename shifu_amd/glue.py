@@ -81,6 +81,8 @@ class EpisodeLog:
 
     def __call__(self, sums_list, env_ids, episode_length_s):
         K, dev = len(sums_list), self.ws.device
+        if env_ids.numel() == 0:          # torch.mean over an empty selection (the kernel returns before writing)
+            return torch.full((K,), float("nan"), dtype=torch.float32, device=dev)
         out = torch.empty(K, dtype=torch.float32, device=dev)
         ptrs = (_vp * K)(*[t.data_ptr() for t in sums_list])
         ids = env_ids.contiguous()

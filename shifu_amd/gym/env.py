@@ -137,9 +137,13 @@ class ShifuVecEnv:
     def compute_reward(self):
         if getattr(self, "rew_buf", None) is not None and self.rew_buf.is_cuda and len(self.reward_functions) <= 16:
             from shifu_amd import glue
-            terms = [f() for f in self.reward_functions]                 # the user's hooks, untouched
-            terms = [r if (r.dtype == torch.float32 and r.is_contiguous() and r.shape == self.rew_buf.shape)
-                     else (r.to(torch.float32) + torch.zeros_like(self.rew_buf)).contiguous() for r in terms]
+            def as_term(r):      # a hook may return a Python number or a 0-d / broadcastable tensor (`rew_buf += r` took those)
+                if not torch.is_tensor(r):
+                    r = torch.as_tensor(r, dtype=torch.float32, device=self.rew_buf.device)
+                if r.dtype == torch.float32 and r.is_contiguous() and r.shape == self.rew_buf.shape and r.device == self.rew_buf.device:
+                    return r
+                return (r.to(device=self.rew_buf.device, dtype=torch.float32) + torch.zeros_like(self.rew_buf)).contiguous()
+            terms = [as_term(f()) for f in self.reward_functions]        # the user's hooks, untouched
             # rew_buf = sum of the terms in their order, episode sums += term: one launch (shf_reward_accumulate)
             glue.reward_accumulate(terms, [self.episode_rewards[f.__name__] for f in self.reward_functions], self.rew_buf)
             return

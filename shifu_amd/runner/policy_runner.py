@@ -3,34 +3,17 @@
 `run_mode='random'` -- the benchmark driver shape (:33-41: reset, then
 `2*rand(N, A) - 1` per step) -- and 'train' / 'play' all run on this backend.  The
 reference's trainer is the un-vendored rsl_rl package (`OnPolicyRunner`); here the same
-interface is provided by shifu_amd.rl.  Set SHIFU_AMD_TRAINER=rsl_rl
-to use an installed rsl_rl instead."""
-import os
-
+interface is provided by shifu_amd.rl."""
 import torch
 
 from .utils import class_to_dict, datetime_logdir, get_load_path, set_seed
 
 
 def _on_policy_runner_class():
-    if os.environ.get("SHIFU_AMD_TRAINER", "native") != "rsl_rl":
-        from ..rl import OnPolicyRunner
-        return OnPolicyRunner        # its load() already has the reference subclass's semantics (:7-14)
-    try:
-        from rsl_rl.runners import OnPolicyRunner
-    except Exception as e:  # pragma: no cover - rsl_rl is not installed here
-        raise RuntimeError("SHIFU_AMD_TRAINER=rsl_rl but the rsl_rl package is not importable") from e
-
-    class _OnPolicyRunner(OnPolicyRunner):
-        def load(self, path, load_optimizer=True):
-            loaded = torch.load(path, map_location=self.device)
-            self.alg.actor_critic.load_state_dict(loaded['model_state_dict'])
-            if load_optimizer:
-                self.alg.optimizer.load_state_dict(loaded['optimizer_state_dict'])
-            self.current_learning_iteration = loaded['iter']
-            return loaded['infos']
-
-    return _OnPolicyRunner
+    """The one trainer of this backend (shifu_amd.rl); its load() already has the semantics of the reference's
+    OnPolicyRunner subclass (policy_runner.py:7-14).  INTEGRATION.md shows how a site with rsl_rl installed binds it."""
+    from ..rl import OnPolicyRunner
+    return OnPolicyRunner
 
 
 def run_policy(run_mode, env_class, env_cfg, policy_cfg, log_root="./logs", play_num_envs=50, play_iterations=3000):

@@ -14,7 +14,9 @@ class HistoryRecorder:
         self.history_buf = torch.zeros(*shape, num_history, device=device)
 
     def add(self, x):
-        if self.history_buf.is_cuda and x.is_cuda and x.dtype == torch.float32 and self.history_buf.is_contiguous():
+        # (anything else -- a broadcastable or differently typed x, as `history_buf[..., 0] = x` accepts -- takes the torch lines)
+        if self.history_buf.is_cuda and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 \
+                and self.history_buf.is_contiguous() and tuple(x.shape) == tuple(self.history_buf.shape[:-1]):
             from shifu_amd import glue              # the two statements below as one launch (shf_history_add)
             glue.history_add(self.history_buf, x)
             return

@@ -48,6 +48,9 @@ def test_bench_two_ranks_in_child_processes_over_gloo():
     assert out["config"]["gathers_in_timed_region"] >= 1, "steps 6..35 of the run contain the 24th: one all-gather is timed"
     assert out["scaling"] == "weak" and out["value"] > 0 and out["steps"] == 30 and out["warmup"] == 5
     assert out["cpu_baseline"] is None, "the CPU leg runs at N = 1 only"
+    # the process group's own count and the spread of the per-rank clocks
+    assert out["dist"]["backend"] == "gloo" and out["dist"]["world_size"] == 2 and out["rccl_world_size"] is None
+    assert out["dist"]["ms_per_step_rank_min"] <= out["dist"]["ms_per_step_rank_max"] == out["ms_per_step"]
 
 
 def test_bench_one_rank_over_rccl():
@@ -57,3 +60,7 @@ def test_bench_one_rank_over_rccl():
                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())}, "1rank_rccl")
     assert out["n_gpus"] == 1 and out["config"]["total_envs"] == 4096
     assert out["config"]["obs_finite"] is True and out["config"]["gathers_in_timed_region"] >= 1
+    assert out["rccl_world_size"] == 1 and out["dist"]["backend"] == "nccl"
+    rf = out["roofline"]
+    assert abs(rf["frac"] * rf["peak"] - rf["frac_of_achievable"] * rf["peak_achievable"]) < 1e-6 * rf["achieved"] + 1e-9
+    assert ("kernel_ms_note" in rf) == (rf["kernel_ms"] > out["ms_per_step"])

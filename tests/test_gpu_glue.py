@@ -79,6 +79,48 @@ def test_get_heights_matches_oracle_bitwise(oracle, plane):
     assert plane or np.unique(want).size > 50
 
 
+def test_get_heights_lands_in_the_cells_torch_picks_on_cell_boundaries(oracle):
+    """`(points / horizontal_scale).long()` (isaac_gym.py:425) on a GPU tensor is x * (1 / s) in torch (a Python-float
+    divisor), not a division: sample points one float either side of every cell boundary must land in the cell the torch
+    expression -- evaluated here on the GPU, as the reference would -- picks, and the oracle in the same one.  The map is
+    strictly increasing in both indices, so the 3-neighbour minimum is the cell's own sample and identifies it."""
+    _need_gpu()
+    from shifu_amd import glue
+    rows, cols = 90, 70
+    hs = (np.arange(rows)[:, None] * cols + np.arange(cols)[None, :]).astype(np.int16)
+    terr = _abi.ShfTerrain()
+    terr.rows, terr.cols = rows, cols
+    terr.hscale, terr.vscale, terr.border, terr.friction = 0.1, 1.0, 2.0, 1.0
+    # one sample point per env at the env's own (x, y); identity attitude, so the yaw rotation is exact
+    pts = np.zeros((1, 2), np.float32)
+    k = np.arange(5, 80, dtype=np.float32)
+    edge = (k * np.float32(0.1)).astype(np.float32)               # the float nearest to each boundary ...
+    cand = np.concatenate([edge, np.nextafter(edge, np.float32(0)), np.nextafter(edge, np.float32(99)),
+                           (k / np.float32(10)).astype(np.float32)])
+    xs = (cand - np.float32(2.0)).astype(np.float32)              # ... minus the border the kernel adds back
+    n = xs.size
+    root = np.zeros((n, 13), np.float32)
+    root[:, 6] = 1.0
+    root[:, 0] = xs
+    root[:, 1] = xs[::-1] * np.float32(0.7)
+    dev = "cuda:0"
+    rt = torch.from_numpy(root).to(dev)
+    got = glue.get_heights(terr, torch.from_numpy(hs).to(dev), rt, None, torch.from_numpy(pts).to(dev), n)
+    # the reference's statements on the GPU (isaac_gym.py:418-433)
+    points = torch.zeros(n, 1, 3, device=dev) + rt[:, :3].unsqueeze(1)
+    points += 2.0
+    points = (points / 0.1).long()
+    px = torch.clip(points[:, :, 0].view(-1), 0, rows - 2)
+    py = torch.clip(points[:, :, 1].view(-1), 0, cols - 2)
+    hst = torch.from_numpy(hs).to(dev)
+    want = torch.min(torch.min(hst[px, py], hst[px + 1, py]), hst[px, py + 1]).view(n, -1) * 1.0
+    assert torch.equal(got, want.to(torch.float32))
+    np.testing.assert_array_equal(got.cpu().numpy(), oracle.glue_heights(terr, hs, pts, root))
+    # the division the CPU pipeline performs lands elsewhere for some of these samples: the test has teeth
+    cpu = np.clip(np.trunc((root[:, 0] + np.float32(2.0)) / np.float32(0.1)), 0, rows - 2)
+    assert (cpu != px.cpu().numpy()).any()
+
+
 def test_history_add_and_reset_match_oracle_and_torch(oracle):
     """K9, HistoryRecorder (train.py:12-35) through the mirror class: GPU kernels vs the oracle's glue_history and vs the
     class's own torch statements on CPU."""

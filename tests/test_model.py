@@ -200,3 +200,20 @@ def test_self_collision_pairs_skip_massless_moving_bodies(tmp_path):
     for k in range(m.npair):
         for c in (m.pair_a[k], m.pair_b[k]):
             assert m.mass[m.dyn[m.cap_body[c]]] > 0.0, "pair with a massless moving body"
+
+
+def test_link_contacts_on_a_robot_with_many_box_volumes_loads_with_a_warning(tmp_path):
+    """gym.load_asset asks for link contacts on every URDF (the reference's collision filter 0, units.py:68): a robot with
+    more box collision volumes than SHF_MAX_ABOX has to load -- family (B), box-actor corners against its volumes, is
+    dropped with a warning; its own vertices and rounded shapes keep colliding."""
+    n = _abi.MAX_ABOX + 3
+    links = ["<link name='base'><inertial><mass value='1'/><inertia ixx='0.01' iyy='0.01' izz='0.01' ixy='0' ixz='0' iyz='0'/></inertial>"
+             + "".join(f"<collision><origin xyz='{0.05 * k} 0 0'/><geometry><box size='0.04 0.04 0.04'/></geometry></collision>" for k in range(n))
+             + "</link>"]
+    p = tmp_path / "many_boxes.urdf"
+    p.write_text("<robot name='r'>" + "".join(links) + "</robot>")
+    with pytest.warns(UserWarning, match="SHF_MAX_ABOX"):
+        cm = compile_urdf(str(p), link_contacts=True)
+    assert cm.blob.link_collide == 1 and cm.blob.nabox == 0 and cm.blob.np == 8 * n
+    few = compile_urdf(str(p), link_contacts=False)
+    assert few.blob.link_collide == 0 and few.blob.nabox == 0
