@@ -6,6 +6,9 @@ for operation (shifu_amd/csrc/shf_device.h), so the comparisons below are
 relative tolerance over 1000 steps -- which follows a fortiori and is also
 asserted explicitly in test_a1_1000_steps_within_north_star_tolerance.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -240,6 +243,58 @@ def test_fused_a1_step_matches_oracle_bitwise_at_full_size(oracle, group):
             np.testing.assert_array_equal(task.tensors[_abi.A1_STATS][slot].cpu().numpy(), oracle.a1_stats(tp, n, bufs["done_sums"]))
         resets += int(bufs["reset"].sum())
     assert resets > 100
+
+
+@pytest.mark.parametrize("terrain", ["heightfield", "flat"])
+def test_fused_a1_env_on_the_benchmark_scene_matches_oracle_bitwise_at_full_size(oracle, terrain):
+    """BASELINE configs 3 and 2 exactly as bench.py builds them -- FusedA1Env(4096) on the procedural 1300 x 2100 height
+    field (NumPy seed 42, curriculum layout) / on the all-zero map, default kernel (chain per lane, 32 lanes) -- against the
+    oracle for 30 vec-steps with time-outs and falls: every tensor, bit for bit."""
+    _need_gpu()
+    from shifu_amd.gym.a1_fused import FusedA1Env
+    n = 4096
+    env = FusedA1Env(num_envs=n, terrain=terrain, seed=42)
+    assert env.mapping == "chain" and env.group == 32
+    S, T = env.sim.tensors, env.task.tensors
+    assert tuple(S[_abi.T_HEIGHTS].shape) == (1300, 2100)
+    g = torch.Generator().manual_seed(3)
+    # spread the envs over the curriculum's rows so that every sub-terrain kind is stood on, and bring time-outs into the window
+    T[_abi.A1_LEVELS].copy_(torch.randint(0, 10, (n,), generator=g))
+    lv, ty = T[_abi.A1_LEVELS].cpu(), T[_abi.A1_TYPES].cpu()
+    T[_abi.A1_ORIGINS].copy_(T[_abi.A1_TORIGINS].cpu()[lv, ty])
+    env.task.reset_all()
+    T[_abi.A1_EP_LEN].copy_(torch.randint(470, 501, (n,), generator=g))
+    torch.cuda.synchronize()
+    bufs = {k: S[t].cpu().numpy().copy() for k, t in _SIM_T.items()}
+    bufs.update({k: T[t].cpu().numpy().copy() for k, t in _A1_T.items()})
+    hs = S[_abi.T_HEIGHTS].cpu().numpy().copy()
+    assert (terrain == "flat") == (not hs.any())
+    rng = np.random.default_rng(17)
+    resets, timeouts = 0, 0
+    for it in range(30):
+        raw = (2 * rng.random((n, 12)) - 1).astype(np.float32)
+        slot = env.task.step(torch.from_numpy(raw).cuda())
+        oracle.a1_step(env.cm.blob, env.sim_params, env.task_params, n, 0, bufs, raw, terrain=env.sim.terrain, heights=hs)
+        if it % 10 == 9:
+            _compare(env.sim, env.task, bufs, f"{terrain} step {it}")
+            np.testing.assert_array_equal(T[_abi.A1_STATS][slot].cpu().numpy(), oracle.a1_stats(env.task_params, n, bufs["done_sums"]))
+        resets += int(bufs["reset"].sum())
+        timeouts += int(bufs["timeout"].sum())
+    assert resets > 500 and timeouts > 200
+    if terrain == "heightfield":
+        assert np.unique(bufs["heights"]).size > 100, "the robots stand on real relief"
+
+
+def test_long_differential_run_of_every_kernel_form(oracle):
+    """tools/fuzz_parity.py trimmed to fit the suite: 320 vec-steps x 192 envs (64 with link contacts) of all nine kernel
+    forms of both tasks against the oracle, every tensor compared every 80 steps, through hundreds of resets
+    (the 2000-step run is profiles/r03_fuzz_parity.txt)."""
+    _need_gpu()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity
+    out = fuzz_parity.run(steps=320, envs=192, every=80, link_envs=64)
+    assert len(out) == 9 and all(r["equal"] for r in out)
+    assert sum(r["resets"] for r in out if r["task"] == "a1") > 300 and sum(r["resets"] for r in out if r["task"] == "abb") > 300
 
 
 def test_fused_abb_step_matches_oracle_bitwise_at_full_size(oracle):

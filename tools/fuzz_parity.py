@@ -19,12 +19,11 @@ import numpy as np
 import torch
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--envs", type=int, default=384)
-    ap.add_argument("--every", type=int, default=100)
-    args = ap.parse_args()
+def run(steps=2000, envs=384, every=100, link_envs=128):
+    """Every kernel form of both tasks against the oracle for `steps` vec-steps; returns one record per form (raises on the
+    first tensor that differs).  tests/test_gpu_parity.py runs a trimmed version under `pytest -m gpu`."""
+    from types import SimpleNamespace
+    args = SimpleNamespace(steps=steps, envs=envs, every=every)
     from oracle import pyoracle as oracle
     import test_gpu_parity as T
     from shifu_amd import _abi
@@ -50,7 +49,7 @@ def main():
                      ("levels16", dict(group=16, mapping="body")), ("generic32", dict(group=32, extra_boxes=extra)),
                      ("link32", dict(group=32, link_contacts=True))):
         t0 = time.time()
-        n = args.envs if "link" not in name else min(args.envs, 128)
+        n = args.envs if "link" not in name else min(args.envs, link_envs)
         env = FusedAbbEnv(num_envs=n, seed=31, **kw)
         bufs = {k: env.sim.tensors[t].cpu().numpy().copy() for k, t in T._ABB_SIM_T.items()}
         bufs.update({k: env.task.tensors[t].cpu().numpy().copy() for k, t in T._ABB_T.items()})
@@ -70,6 +69,16 @@ def main():
         out.append({"task": "abb", "kernel": name, "mapping": env.mapping, "envs": n, "steps": args.steps, "resets": resets, "equal": True,
                     "seconds": round(time.time() - t0, 1)})
         print(json.dumps(out[-1]), flush=True)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--envs", type=int, default=384)
+    ap.add_argument("--every", type=int, default=100)
+    args = ap.parse_args()
+    run(args.steps, args.envs, args.every)
 
 
 if __name__ == "__main__":
