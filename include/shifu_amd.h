@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SHF_ABI_VERSION 8
+#define SHF_ABI_VERSION 9
 
 #define SHF_MAX_BODIES 32 /* reported rigid bodies per articulation        */
 #define SHF_MAX_DOFS 32
@@ -238,7 +238,8 @@ enum {
   SHF_T_SCENE = 15,      /* sizeof(ShfScene) bytes, device copy                            */
   SHF_T_DROPPED = 16,    /* (N) i32: contacts dropped since the host last cleared it -- self-contacts beyond
                           * SHF_MAX_SELF_CONTACTS, link contacts beyond SHF_MAX_LINK_CONTACTS (optional binding)   */
-  SHF_T_COUNT = 17
+  SHF_T_BODY_FORCE_POS = 17, /* (N*B, 3) f32 apply_rigid_body_force_at_pos_tensors: world points of application */
+  SHF_T_COUNT = 18
 };
 
 /* refresh masks: gym.refresh_*_tensor (isaac_gym.py:139-154) */
@@ -309,6 +310,11 @@ int shf_sim_set_pos_target_indexed(ShfSim* sim, const float* values_dev, const i
                                    int32_t n, void* stream);
 /* gym.apply_rigid_body_force_at_pos_tensors(force, None) (robot.py:231-236) */
 int shf_sim_apply_body_force(ShfSim* sim, const float* force_dev, void* stream);
+/* gym.apply_rigid_body_force_at_pos_tensors(force, pos) (robot.py:231-236, LeggedRobot.apply_force_on_base(force, pos)):
+ * forces (N*B, 3) at the world points pos_dev (N*B, 3), consumed by the next shf_sim_step: each acts on its body as the
+ * force plus the moment of its arm about the body's origin.  pos_dev == NULL: at the centres of mass, as above.  Rows of
+ * box actors are ignored, like there. */
+int shf_sim_apply_body_force_at_pos(ShfSim* sim, const float* force_dev, const float* pos_dev, void* stream);
 /* gym.set_actor_root_state_tensor_indexed (isaac_gym.py:70-73) */
 int shf_sim_commit_root_indexed(ShfSim* sim, const float* root_dev, const int32_t* actor_idx_dev, int32_t n,
                                 void* stream);

@@ -89,21 +89,22 @@ def _p(a, ct):
 
 def step(model, params, n, dof_state, root_state, *, nsteps=1, terrain=None, heights=None, effort=None,
          pos_target=None, vel_target=None, body_force=None, friction=None, want_contact=False,
-         want_body_state=False, f64=False):
+         want_body_state=False, f64=False, body_force_pos=None):
     """Advance `n` envs by `nsteps` simulate() calls, in place.  Arrays are
     float32 (f64=False) or float64 (f64=True); friction is always float32."""
     dt = np.float64 if f64 else np.float32
     ct = C.c_double if f64 else C.c_float
-    for a in (dof_state, root_state, effort, pos_target, vel_target, body_force):
+    for a in (dof_state, root_state, effort, pos_target, vel_target, body_force, body_force_pos):
         assert a is None or (a.dtype == dt and a.flags.c_contiguous)
     contact = np.zeros((n * model.nb, 3), dt) if want_contact else None
     bstate = np.zeros((n * model.nb, 13), dt) if want_body_state else None
-    fn = lib().shf_oracle_step_f64 if f64 else lib().shf_oracle_step_f32
+    # body_force_pos: world-space points of application (gym.apply_rigid_body_force_at_pos_tensors(force, pos)); None = CoM
+    fn = lib().shf_oracle_step_at_pos_f64 if f64 else lib().shf_oracle_step_at_pos_f32
     fn.restype = None
     fn(C.byref(model), C.byref(params), C.byref(terrain) if terrain is not None else None,
        _p(heights, C.c_int16), C.c_int(n), C.c_int(nsteps), _p(dof_state, ct), _p(root_state, ct), _p(effort, ct),
-       _p(pos_target, ct), _p(vel_target, ct), _p(body_force, ct), _p(friction, C.c_float), _p(contact, ct),
-       _p(bstate, ct))
+       _p(pos_target, ct), _p(vel_target, ct), _p(body_force, ct), _p(body_force_pos, ct), _p(friction, C.c_float),
+       _p(contact, ct), _p(bstate, ct))
     return contact, bstate
 
 

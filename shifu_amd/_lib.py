@@ -29,6 +29,7 @@ _SIGS = {
     "shf_sim_set_dof_command": ([vp, i32, vp, vp], i32),
     "shf_sim_set_pos_target_indexed": ([vp, vp, vp, i32, vp], i32),
     "shf_sim_apply_body_force": ([vp, vp, vp], i32),
+    "shf_sim_apply_body_force_at_pos": ([vp, vp, vp, vp], i32),
     "shf_sim_commit_root_indexed": ([vp, vp, vp, i32, vp], i32),
     "shf_sim_commit_root_all": ([vp, vp, vp], i32),
     "shf_sim_commit_dof_indexed": ([vp, vp, vp, i32, vp], i32),

@@ -229,9 +229,16 @@ class Sim:
                                                    idx.numel(), _stream_ptr(self.device)))
 
     @_on_device
-    def apply_body_force(self, force: torch.Tensor):
+    def apply_body_force(self, force: torch.Tensor, pos: Optional[torch.Tensor] = None):
+        """gym.apply_rigid_body_force_at_pos_tensors(force, pos): pos None = at the centres of mass."""
         f = force.contiguous()
-        check(lib().shf_sim_apply_body_force(self._h, C.c_void_p(f.data_ptr()), _stream_ptr(self.device)))
+        assert f.dtype == torch.float32 and f.numel() == self.num_envs * (self.model.nb + self.nboxes) * 3
+        if pos is None:
+            check(lib().shf_sim_apply_body_force(self._h, C.c_void_p(f.data_ptr()), _stream_ptr(self.device)))
+            return
+        p = pos.contiguous()
+        assert p.dtype == torch.float32 and p.numel() == f.numel()
+        check(lib().shf_sim_apply_body_force_at_pos(self._h, C.c_void_p(f.data_ptr()), C.c_void_p(p.data_ptr()), _stream_ptr(self.device)))
 
     @_on_device
     def commit_root_indexed(self, root: torch.Tensor, idx: torch.Tensor):

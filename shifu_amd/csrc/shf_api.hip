@@ -38,6 +38,7 @@ struct ShfSim {
   int64_t env_off = 0;
   bool finalized = false;
   bool force_armed = false;
+  bool force_at_pos = false;   // the armed force comes with points of application (SHF_T_BODY_FORCE_POS)
   void* t[SHF_T_COUNT] = {};
   int group = 64;  // lanes per env
   int mapping = SHF_MAP_BODY;
@@ -92,7 +93,8 @@ __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
   lane_model_load<DynDims>(m, l, M);
   LanePoints<1> P;   // unused: point count only known at run time
   substep<G, BOX, DynDims, !BOX, LaneModel, DynScene, SELF, LINK>(C, L, l, M, P, A.pos_tgt ? A.pos_tgt + (size_t)e * nd : nullptr,
-                  A.vel_tgt ? A.vel_tgt + (size_t)e * nd : nullptr, A.body_force ? A.body_force + (size_t)e * nbt * 3 : nullptr, mu, L.xch);
+                  A.vel_tgt ? A.vel_tgt + (size_t)e * nd : nullptr, A.body_force ? A.body_force + (size_t)e * nbt * 3 : nullptr, mu, L.xch,
+                  BoxLane(), (A.body_force && A.body_force_pos) ? A.body_force_pos + (size_t)e * nbt * 3 : nullptr);
   GROUP_SYNC();
   for (int i = l; i < 2 * nd; i += G) dof[i] = L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)];
   for (int i = l; i < 13 * actors; i += G) root[i] = L.root[i];
@@ -966,7 +968,7 @@ extern "C" int shf_sim_layout(const ShfSim* sim, int32_t id, int64_t shape[4], i
     case SHF_T_DOF_STATE: case SHF_T_SIM_DOF: *ndim = 2; shape[0] = N * nd; shape[1] = 2; break;
     case SHF_T_ROOT_STATE: case SHF_T_SIM_ROOT: *ndim = 2; shape[0] = N * A; shape[1] = 13; break;
     case SHF_T_BODY_STATE: *ndim = 2; shape[0] = N * B; shape[1] = 13; break;
-    case SHF_T_CONTACT: case SHF_T_SIM_CONTACT: case SHF_T_BODY_FORCE: *ndim = 2; shape[0] = N * B; shape[1] = 3; break;
+    case SHF_T_CONTACT: case SHF_T_SIM_CONTACT: case SHF_T_BODY_FORCE: case SHF_T_BODY_FORCE_POS: *ndim = 2; shape[0] = N * B; shape[1] = 3; break;
     case SHF_T_JACOBIAN:
       *ndim = 4; shape[0] = N; shape[1] = sim->model.fixed_base ? nb - 1 : nb; shape[2] = 6;
       shape[3] = sim->model.fixed_base ? nd : nd + 6; break;
@@ -1021,6 +1023,7 @@ static SimArgs sim_args(const ShfSim* s, bool internal) {
   A.pos_tgt = (const float*)s->t[SHF_T_POS_TARGET];
   A.vel_tgt = (const float*)s->t[SHF_T_VEL_TARGET];
   A.body_force = nullptr;
+  A.body_force_pos = nullptr;
   A.friction = (const float*)s->t[SHF_T_FRICTION];
   A.contact = (float*)s->t[internal ? SHF_T_SIM_CONTACT : SHF_T_CONTACT];
   A.dropped = (int32_t*)s->t[SHF_T_DROPPED];
@@ -1080,8 +1083,12 @@ extern "C" int shf_sim_step(ShfSim* sim, void* stream) {
   if (int r = need(sim, {SHF_T_SIM_DOF, SHF_T_SIM_ROOT, SHF_T_SIM_CONTACT, SHF_T_MODEL}, "shf_sim_step")) return r;
   if (sim->terr.rows > 0 && !sim->t[SHF_T_HEIGHTS]) return fail("shf_sim_step: heightfield samples not bound");
   SimArgs A = sim_args(sim, true);
-  if (sim->force_armed) A.body_force = (const float*)sim->t[SHF_T_BODY_FORCE];
+  if (sim->force_armed) {
+    A.body_force = (const float*)sim->t[SHF_T_BODY_FORCE];
+    if (sim->force_at_pos) A.body_force_pos = (const float*)sim->t[SHF_T_BODY_FORCE_POS];
+  }
   sim->force_armed = false;
+  sim->force_at_pos = false;
   const int epb = 256 / sim->group;
   dim3 grid((sim->n + epb - 1) / epb), block(256);
   if (sim->nboxes > 0) {
@@ -1175,6 +1182,18 @@ extern "C" int shf_sim_apply_body_force(ShfSim* sim, const float* force_dev, voi
   HIP_OK(hipMemcpyAsync(sim->t[SHF_T_BODY_FORCE], force_dev, (size_t)sim->n * (sim->model.nb + sim->nboxes) * 3 * 4,
                         hipMemcpyDeviceToDevice, (hipStream_t)stream));
   sim->force_armed = true;
+  sim->force_at_pos = false;
+  return 0;
+}
+extern "C" int shf_sim_apply_body_force_at_pos(ShfSim* sim, const float* force_dev, const float* pos_dev, void* stream) {
+  if (!pos_dev) return shf_sim_apply_body_force(sim, force_dev, stream);
+  if (int r = need(sim, {SHF_T_BODY_FORCE, SHF_T_BODY_FORCE_POS}, "shf_sim_apply_body_force_at_pos")) return r;
+  if (!force_dev) return fail("shf_sim_apply_body_force_at_pos: null force tensor");
+  const size_t bytes = (size_t)sim->n * (sim->model.nb + sim->nboxes) * 3 * 4;
+  HIP_OK(hipMemcpyAsync(sim->t[SHF_T_BODY_FORCE], force_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  HIP_OK(hipMemcpyAsync(sim->t[SHF_T_BODY_FORCE_POS], pos_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  sim->force_armed = true;
+  sim->force_at_pos = true;
   return 0;
 }
 

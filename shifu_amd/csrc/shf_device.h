@@ -877,14 +877,14 @@ DEV void contact_force_final(float* o, const float* ab, float dt) {
 
 // One gym.simulate() for one env, executed by the G lanes of its group.
 //   dofb[d]: q, qd in;  tau_cmd (explicit effort), pos/vel targets via pt_tgt/vt_tgt (LDS, may be null)
-//   fext: world force per reported body (global memory, this env) or nullptr
+//   fext: world force per reported body (global memory, this env) or nullptr; fpos: its world point of application or nullptr (CoM)
 //   contact_out: LDS/global float[nb*3] written by body lanes (may be nullptr)
 #define LANE_ROUNDS(G, DM) ((DM::NPC + (G) - 1) / (G) > 0 ? (DM::NPC + (G) - 1) / (G) : 1)
 template <int G, bool BOX = false, class DM = DynDims, bool TW = false, class LM = LaneModel, class SC = DynScene,
           bool SELF = false, bool LINK = false>
 DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const LanePoints<LANE_ROUNDS(G, DM)>& P,
                  const float* pos_tgt, const float* vel_tgt, const float* fext, float mu_shape, float* contact_out,
-                 const BoxLane& BL = BoxLane()) {
+                 const BoxLane& BL = BoxLane(), const float* fpos = nullptr) {
   const ShfModel* m = C.m;
   const int nb = DM::nb(m), nd = DM::nd(m), np = DM::np(m);
   const float dt = C.sp.dt;
@@ -899,14 +899,20 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
   if (isdyn) body_inertia(M, B);
   if (BOX) boxes_pose<G>(C, L, l, B);
 
-  // external forces at the CoM of reported bodies, folded in ascending body order
+  // external forces on reported bodies -- at the CoM, or at the world point fpos[3 b ..] when given
+  // (gym.apply_rigid_body_force_at_pos_tensors(force, pos | None), robot.py:231-236) -- folded in ascending body order
   if (fext) {
     if (isbody) {
       float F[3] = {fext[3 * l], fext[3 * l + 1], fext[3 * l + 2]};
       float cw[3], t[3];
-      mv3(B.Rw, M.com, cw);
+      if (fpos) {
 #pragma unroll
-      for (int k = 0; k < 3; k++) cw[k] += B.p[k];
+        for (int k = 0; k < 3; k++) cw[k] = fpos[3 * l + k] - L.root[k];   // its arm about O, the root's position
+      } else {
+        mv3(B.Rw, M.com, cw);
+#pragma unroll
+        for (int k = 0; k < 3; k++) cw[k] += B.p[k];
+      }
       cross3(cw, F, t);
       float* o = L.xch + l * XCH_STRIDE;
       o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = F[0]; o[4] = F[1]; o[5] = F[2];

@@ -20,6 +20,7 @@ struct SimArgs {
   const float* pos_tgt;
   const float* vel_tgt;
   const float* body_force;  // nullptr unless armed
+  const float* body_force_pos;  // world points of application, nullptr = at the centres of mass
   const float* friction;
   float* contact;  // (n*B,3)
   int32_t* dropped;  // (n) contacts dropped at the per-env limits, accumulated (SHF_T_DROPPED), may be null

@@ -498,11 +498,12 @@ class Gym:
     def set_dof_velocity_target_tensor(self, sim, t): sim.backend.set_dof_command(_abi.T_VEL_TARGET, t); return True
 
     def apply_rigid_body_force_at_pos_tensors(self, sim, force, pos=None, space=ENV_SPACE):
-        if pos is not None:
-            raise NotImplementedError("forces are applied at the body CoM (the reference passes pos=None: robot.py:231-236)")
+        """force (N*B, 3) on every rigid body, at its centre of mass (pos None) or at the points pos (N*B, 3) -- both in env
+        space, which here is the frame of the state tensors: the facade places every env at the sim's origin (create_env
+        ignores the grid spacing -- envs never interact -- and TerrainGymEnv sets it to 0 anyway, isaac_gym.py:301)."""
         if space != ENV_SPACE:
             raise NotImplementedError("forces are taken in env (= world-aligned) axes only, the default the reference uses")
-        sim.backend.apply_body_force(force)
+        sim.backend.apply_body_force(force, pos)
         return True
 
     def set_actor_root_state_tensor_indexed(self, sim, root, idx, n):

@@ -110,6 +110,39 @@ def test_simulate_matches_oracle_bitwise(oracle, rough, group):
     assert (np.abs(contact).sum(1) > 0).any(), "test must exercise contacts"
 
 
+def test_force_at_position_matches_oracle_bitwise(oracle):
+    """gym.apply_rigid_body_force_at_pos_tensors(force, pos) (robot.py:231-236, apply_force_on_base(force, pos)): the force
+    acts at the given world point -- on the base off its centre, and on a leg body -- for the sub-step that consumes it."""
+    _need_gpu()
+    rng = np.random.default_rng(12)
+    cm = H.a1_model()
+    m = cm.blob
+    sp = H.sim_params(angular_damping=0.5)
+    n = 48
+    dof, root = _random_states(m, n, rng)
+    root[:, 2] += 1.0                                    # in flight: what moves the bodies is the applied wrench
+    sim = _make_sim(cm, sp, n, None, None, group=32)
+    T = sim.tensors
+    T[_abi.T_SIM_DOF].copy_(torch.from_numpy(dof))
+    T[_abi.T_SIM_ROOT].copy_(torch.from_numpy(root))
+    for it in range(12):
+        force = np.zeros((n * m.nb, 3), np.float32)
+        pos = np.zeros((n * m.nb, 3), np.float32)
+        force[::m.nb] = rng.uniform(-20, 20, (n, 3))
+        pos[::m.nb] = root[:, :3] + rng.uniform(-0.3, 0.3, (n, 3)).astype(np.float32)
+        force[5::m.nb] = rng.uniform(-5, 5, (n, 3))
+        pos[5::m.nb] = root[:, :3] + rng.uniform(-0.4, 0.4, (n, 3)).astype(np.float32)
+        at_pos = it % 2 == 0                              # alternate with the centre-of-mass form: the switch must not stick
+        sim.apply_body_force(torch.from_numpy(force).cuda(), torch.from_numpy(pos).cuda() if at_pos else None)
+        sim.step()
+        sim.refresh(_abi.REFRESH_ALL)
+        oracle.step(m, sp, n, dof, root, body_force=force, body_force_pos=pos if at_pos else None)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(T[_abi.T_DOF_STATE].cpu().numpy(), dof, err_msg=f"dof_state step {it}")
+        np.testing.assert_array_equal(T[_abi.T_ROOT_STATE].cpu().numpy(), root, err_msg=f"root_state step {it}")
+    assert np.isfinite(root).all() and np.abs(root[:, 10:13]).max() > 0.5, "off-centre pushes must spin the trunk"
+
+
 def _a1_buffers(cm, tp, n, rng, terr_rows, terr_cols):
     m = cm.blob
     nb, nd = m.nb, m.nd

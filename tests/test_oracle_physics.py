@@ -185,3 +185,41 @@ def test_random_action_generator_is_counter_based_and_uniform(oracle):
     assert not np.array_equal(a, oracle.random_actions(42, 4096, 0, 8, 12))           # next vec-step
     assert not np.array_equal(a, oracle.random_actions(43, 4096, 0, 7, 12))           # another seed
     assert np.array_equal(a[:, :3], oracle.random_actions(42, 4096, 0, 7, 3))         # the ABB's three components: the same stream
+
+
+def test_force_at_a_point_delivers_its_impulse_and_its_moment(oracle):
+    """gym.apply_rigid_body_force_at_pos_tensors(force, pos): a robot at rest in zero gravity receives, in one step, the
+    linear impulse F dt and the angular impulse (p x F) dt about the world origin -- wherever on the tree the body sits --
+    and with pos = None the moment arm is the body's centre of mass."""
+    cm = H.a1_model()
+    m = cm.blob
+    for d in range(m.nd):
+        m.lower[d], m.upper[d] = -1e3, 1e3
+        m.damping[d] = 0.0
+    g = (0.0, 0.0, 0.0)
+    sp = H.sim_params(dt=0.005, gravity=g, angular_damping=0.0)
+    rng = np.random.default_rng(3)
+    q, _, quat = _rand_state(m, rng, 0.0)
+    for body in (0, 6):                     # the base, and a leg link
+        for at_pos in (True, False):
+            dof = np.stack([q, np.zeros(m.nd)], 1).copy()
+            root = np.concatenate([[0.3, -0.2, 5.0], quat, np.zeros(6)])[None].copy()
+            F = rng.uniform(-10, 10, 3)
+            p = root[0, :3] + rng.uniform(-0.3, 0.3, 3)
+            force = np.zeros((m.nb, 3)); pos = np.zeros((m.nb, 3))
+            force[body], pos[body] = F, p
+            if not at_pos:                  # the centre of mass of that reported body, from the oracle's own body states
+                _, bs = oracle.step(m, sp, 1, dof.copy(), root.copy(), nsteps=0, want_body_state=True, f64=True)
+                x, y, z, w = bs[body, 3:7]
+                Rb = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                               [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                               [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+                p = bs[body, :3] + Rb @ np.array([m.com[body][k] for k in range(3)])
+            q0, root0 = dof[:, 0].copy(), root[0].copy()
+            oracle.step(m, sp, 1, dof, root, nsteps=1, f64=True, body_force=force, body_force_pos=pos if at_pos else None)
+            # the step's velocities in the configuration the accelerations were computed in (the integrator then moves the
+            # bodies by dt v: a second-order difference that is not what this test is about)
+            _, P1, L1, _ = H.mechanical_state(m, q0, dof[:, 1], root0[:3], root0[3:7], root[0, 7:10], root[0, 10:13], g)
+            dt = float(sp.dt)
+            assert np.abs(P1 - F * dt).max() < 1e-9, (body, at_pos)
+            assert np.abs(L1 - np.cross(p, F) * dt).max() < 1e-9, (body, at_pos)
