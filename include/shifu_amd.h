@@ -93,13 +93,15 @@ typedef struct ShfModel {
   int32_t pt_body[SHF_MAX_POINTS]; /* reported body the force is logged on */
   float pt_pos[SHF_MAX_POINTS][3]; /* in pt_body's frame                   */
   float pt_radius[SHF_MAX_POINTS];
-  /* Evaluation order hint for kernels that evaluate the points in rounds of one per lane: slot s evaluates point
-   * pt_eval[s] (a permutation of 0..np-1, lowest points of the rest pose first, so that the points that usually touch
-   * the ground share the first round and the later rounds can skip the contact response wave-wide); pt_slot is its
-   * inverse.  Results do not depend on it: contacts are folded into their body in point order whatever the order of
-   * evaluation.  The model compiler fills both; a model built by hand through the C API has to as well (the identity is
-   * fine): shf_sim_set_mapping(SHF_MAP_CHAIN) refuses a pt_eval that is not a permutation with pt_slot its inverse, and
-   * the body-mapped kernels do not read either. */
+  /* Evaluation slots for kernels that evaluate the points in rounds of one per lane: slot s < neval evaluates point
+   * pt_eval[s], or nothing when pt_eval[s] = -1; pt_slot[i] is the slot of point i.  Results do not depend on the
+   * assignment: contacts are folded into their body in point order whatever slot evaluated them.  The model compiler
+   * packs the points of each moving body into consecutive slots, in point order, never across a multiple of 32 (empty
+   * slots pad the blocks; neval >= np), bodies with the lowest rest pose first: a body lane of the chain-mapped kernel
+   * then finds its body's active contacts as one bit field of the round's ballot, and rounds whose points are all far
+   * from the ground skip the contact response wave-wide.  shf_sim_set_mapping(SHF_MAP_CHAIN) refuses a model whose
+   * pt_eval / pt_slot are not each other's inverse over the occupied slots; the 32-lane chain kernel also needs the
+   * packed form.  A model built by hand may use the identity (neval = np) with the other kernels. */
   int32_t pt_eval[SHF_MAX_POINTS];
   int32_t pt_slot[SHF_MAX_POINTS];
 
@@ -125,7 +127,7 @@ typedef struct ShfModel {
   int32_t self_collide;
   int32_t ncap;
   int32_t npair;
-  int32_t pad_sc;
+  int32_t neval;   /* evaluation slots in use (pt_eval above); 0 reads as np */
   int32_t cap_body[SHF_MAX_CAPSULES];
   float cap_a[SHF_MAX_CAPSULES][3];  /* segment end points in cap_body's frame */
   float cap_b[SHF_MAX_CAPSULES][3];

@@ -38,7 +38,7 @@ class ShfModel(C.Structure):
         ("pt_body", i32 * MAX_POINTS), ("pt_pos", (f32 * 3) * MAX_POINTS), ("pt_radius", f32 * MAX_POINTS),
         ("pt_eval", i32 * MAX_POINTS), ("pt_slot", i32 * MAX_POINTS),
         ("sph_body", i32 * MAX_SPHERES), ("sph_pos", (f32 * 3) * MAX_SPHERES), ("sph_seg", (f32 * 3) * MAX_SPHERES), ("sph_radius", f32 * MAX_SPHERES), ("sph_part", i32 * MAX_SPHERES),
-        ("self_collide", i32), ("ncap", i32), ("npair", i32), ("pad_sc", i32),
+        ("self_collide", i32), ("ncap", i32), ("npair", i32), ("neval", i32),
         ("cap_body", i32 * MAX_CAPSULES), ("cap_a", (f32 * 3) * MAX_CAPSULES), ("cap_b", (f32 * 3) * MAX_CAPSULES),
         ("cap_radius", f32 * MAX_CAPSULES), ("pair_a", C.c_uint8 * MAX_PAIRS), ("pair_b", C.c_uint8 * MAX_PAIRS),
         ("link_collide", i32), ("nabox", i32), ("pad_lc", i32 * 2), ("abox_body", i32 * MAX_ABOX),

@@ -7,8 +7,10 @@
 // side, ~20 group synchronisations per sub-step.  Here each kind of work runs where it is widest, and the recursions,
 // which are serial whatever the mapping, run without hand-offs:
 //   dof lanes   (lane j < ND)        joint j: integration, drive effort (t0, de), local rotation Rl = trot * Rot(axis, q)
-//   chain lanes (lane c < NCH)       chain c: pose composition root -> tip, the ABA inward pass tip -> root and the
-//                                    outward pass, link after link with (S, c, U, 1/D, u) in registers
+//   chain lanes (lane c < NCH;       chain c: pose composition root -> tip, the ABA inward pass tip -> root and the
+//    at 32 lanes: lanes 8 c)         outward pass, link after link with (S, c, U, 1/D, u) in registers
+//   row lanes   (32 lanes per env:   the inward pass row-parallel: lane 8 c + i holds row i of chain c's articulated inertia
+//    lanes 8 c + i, i < 6)           (6 fused operations per product / update instead of 36 / 21; chain_substep)
 //   body lanes  (lane j <= ND)       moving body j (link j, or the root on lane ND): rigid inertia, external force,
 //                                    fold of its active contacts; the root lane also solves the 6x6 and integrates the base
 //   point lanes (all G lanes)        one contact sample point per lane and round
@@ -24,18 +26,35 @@
 #include "shf_task.h"
 #include "shf_link.h"
 
-template <int NCH_, int NLK_, int NP_>
+template <int NCH_, int NLK_, int NP_, int NEV_>
 struct ChainDims {
   static constexpr int NCH = NCH_, NLK = NLK_, NB = 1 + NCH_ * (NLK_ + 1), ND = NCH_ * NLK_, NPC = NP_;
+  static constexpr int NEV = NEV_;  // evaluation slots (ShfModel.neval): the points plus the padding of the 32-slot blocks
   static constexpr int MAXPT = 9;   // contact points per moving body held as a packed slot list (7 bits each in 64)
+  static_assert(NEV_ >= NP_ && NEV_ <= 128, "evaluation slots: two 64-bit ballot words");
   DEV static constexpr int body(int c, int k) { return 1 + c * (NLK_ + 1) + k; }   // k == NLK: the welded end body
   static bool matches(const ShfModel& m) {
     if (m.nb != NB || m.nd != ND || m.np != NPC || m.fixed_base || m.jtype[0] != SHF_JOINT_ROOT) return false;
     if (m.child_count[0] != NCH || m.nlevels != NLK) return false;
-    for (int i = 0; i < NPC; i++)   // the evaluation order must be a permutation with its inverse
-      if (m.pt_eval[i] < 0 || m.pt_eval[i] >= NPC || m.pt_slot[m.pt_eval[i]] != i) return false;
-    for (int b = 0; b < NB; b++)
-      if (m.pt_count[b] > MAXPT) return false;
+    if ((m.neval > 0 ? m.neval : m.np) != NEV) return false;
+    int occupied = 0;
+    for (int s = 0; s < NEV; s++) {   // pt_eval and pt_slot: each other's inverse over the occupied slots
+      const int i = m.pt_eval[s];
+      if (i == -1) continue;
+      if (i < 0 || i >= NPC || m.pt_slot[i] != s) return false;
+      occupied++;
+    }
+    if (occupied != NPC) return false;
+    for (int b = 0; b < NB; b++) {
+      const int n = m.pt_count[b], i0 = m.pt_start[b];
+      if (n > MAXPT) return false;
+      if (n == 0 || m.dyn[b] != b) continue;
+      // the packed form: a moving body's points in consecutive slots, in point order, inside one block of 32
+      const int s0 = m.pt_slot[i0];
+      for (int j = 0; j < n; j++)
+        if (m.pt_slot[i0 + j] != s0 + j) return false;
+      if ((s0 >> 5) != ((s0 + n - 1) >> 5)) return false;
+    }
     for (int c = 0; c < NCH; c++) {
       if (m.child_list[m.child_start[0] + c] != 1 + c * (NLK + 1)) return false;
       for (int k = 0; k <= NLK; k++) {
@@ -53,13 +72,19 @@ struct ChainDims {
     return true;
   }
 };
-typedef ChainDims<4, 3, 76> A1Chain;
+typedef ChainDims<4, 3, 76, 88> A1Chain;   // the A1: 76 sample points in 88 slots (three blocks: 27 + 25 + 24)
 
 // LDS of one env: pose records of all reported bodies, accelerations, one (IA, pA) exchange slot per link (body lane ->
 // chain lane; the chain's first slot then carries its result to the root; the region is also the net-contact-force
-// staging, nb x 3 floats), a record per joint (Rl[9] qd t0 de), the dof block (epilogue layout), the root state,
-// contact slots.
-#define JREC_STRIDE 12
+// staging, nb x 3 floats), a record per joint, the dof block (epilogue layout), the root state, contact slots.
+// Joint record: Rl[9] qd . . t0 de -- and, once the chain lane has composed the link (32 lanes per env), S[6] c[6] in the
+// place of Rl and qd, for the row lanes of the inward pass and for the outward pass.
+#define JREC_STRIDE 16
+#define JREC_QD 9
+#define JREC_T0 12
+#define JREC_DE 13
+#define JREC_S 0
+#define JREC_C 6
 template <class CD>
 __host__ __device__ inline int chain_lds_words(int min_tail) {
   int tail = CD::NPC * PT_STRIDE;
@@ -138,12 +163,13 @@ struct ChainPoints {
   float pos[NR][3], rad[NR], thr[NR];   // thr: clearance x nz_min above which the point cannot be within the contact offset
 };
 template <int G, int NR>
-DEV void chain_points_load(const ShfModel* m, int np, int l, float offset, ChainPoints<NR>& P) {
+DEV void chain_points_load(const ShfModel* m, int nev, int l, float offset, ChainPoints<NR>& P) {
 #pragma unroll
   for (int k = 0; k < NR; k++) {
     const int s = l + k * G;
-    const int i = s < np ? m->pt_eval[s] : 0;
-    P.idx[k] = s < np ? i : -1;
+    const int e = s < nev ? m->pt_eval[s] : -1;   // -1: padding of a 32-slot block
+    const int i = e < 0 ? 0 : e;
+    P.idx[k] = e;
     P.body[k] = m->pt_body[i];
     P.rad[k] = m->pt_radius[i];
     // 1 % and a micrometre of slack over the exact bound: float rounding in the exact test cannot bridge it
@@ -182,13 +208,18 @@ DEV void terrain_normal_from_gradient(const TerrainDev& T, float gx, float gy, f
 struct SlotBits {
   unsigned long long w[2];
   DEV bool test(int s) const { return ((s < 64 ? w[0] >> s : w[1] >> (s - 64)) & 1ull) != 0ull; }
+  // the n < 32 slots from s0 on, which lie inside one block of 32 (the packed form of ShfModel.pt_eval): bit j = slot s0 + j
+  DEV unsigned field(int s0, int n) const {
+    const unsigned long long ww = s0 < 64 ? w[0] : w[1];
+    return (unsigned)(ww >> (s0 & 63)) & ((1u << n) - 1u);
+  }
 };
 // The evaluation slots of one body's points [i0, i0 + n), in point order, 7 bits each (constant per lane: read once per
 // env step), and the same as a mask over SlotBits.
 template <int MAXPT>
 struct SlotList {
   unsigned long long list;
-  int i0, n;
+  int i0, n, s0;       // s0: slot of the first point (the packed form: point i0 + j sits in slot s0 + j)
   SlotBits mask;
   DEV int slot(int j) const { return (int)((list >> (7 * j)) & 127ull); }
 };
@@ -196,7 +227,7 @@ template <int MAXPT>
 DEV SlotList<MAXPT> slot_list_load(const ShfModel* m, int i0, int n) {
   static_assert(MAXPT * 7 <= 64, "packed slot list");
   SlotList<MAXPT> S;
-  S.list = 0ull; S.i0 = i0; S.n = n; S.mask.w[0] = 0ull; S.mask.w[1] = 0ull;
+  S.list = 0ull; S.i0 = i0; S.n = n; S.s0 = m->pt_slot[n > 0 ? i0 : 0]; S.mask.w[0] = 0ull; S.mask.w[1] = 0ull;
   int sl[MAXPT];
 #pragma unroll
   for (int j = 0; j < MAXPT; j++) sl[j] = m->pt_slot[j < n ? i0 + j : 0];
@@ -216,12 +247,37 @@ struct DofLane {
   float q, qd, tau;   // joint position, velocity, commanded (explicit) effort
 };
 
+// Row lanes of the inward pass at 32 lanes per env: lane 8 c + i (i < 6) holds row i of chain c's 6x6 articulated inertia.
+// off[j]: the packed-storage index of element (i, j).
+struct RowLane {
+  int c, i;
+  bool on;
+  int off[6];
+};
+template <class CD>
+DEV RowLane row_lane_load(int l) {
+  RowLane R;
+  R.c = l >> 3; R.i = l & 7;
+  R.on = R.i < 6 && R.c < CD::NCH;
+  const int i = R.on ? R.i : 0;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    R.off[j] = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);
+  }
+  return R;
+}
+
 // One gym.simulate() for one env.  Lane roles in the file header; contact_out (LDS, nb x 3) is written when non-null.
+// At 32 lanes per env (ROWS) the chain lanes are lanes 0, 8, 16, 24 and the ABA inward pass runs row-parallel: the six lanes
+// 8 c .. 8 c + 5 each hold one row of chain c's articulated inertia, so that IA S, the rank-1 update and IA c cost 6 fused
+// operations per link instead of 36 + 21 + 36; U and pA travel between the rows through LDS.  Every element still sees the
+// operations of chain_inward_link in its order (an element below the diagonal repeats its mirror image's: same operands).
 template <int G, class CD, bool TW>
-DEV void chain_substep(const StepCtx& C, const ChainLds& L, int l, DofLane& X, const ChainPoints<(CD::NPC + G - 1) / G>& P,
-                       const SlotList<CD::MAXPT>& mine, const float* fext, float mu_shape, float* contact_out) {
+DEV void chain_substep(const StepCtx& C, const ChainLds& L, int l, DofLane& X, const ChainPoints<(CD::NEV + G - 1) / G>& P,
+                       const SlotList<CD::MAXPT>& mine, const RowLane& RL, const float* fext, float mu_shape, float* contact_out) {
   static_assert(G > CD::ND && G <= 64, "a lane per dof plus one for the root");
-  constexpr int NCH = CD::NCH, NLK = CD::NLK, NB = CD::NB, ND = CD::ND, NR = (CD::NPC + G - 1) / G;
+  constexpr int NCH = CD::NCH, NLK = CD::NLK, NB = CD::NB, ND = CD::ND, NR = (CD::NEV + G - 1) / G;
   const ShfModel* m = C.m;
   const float dt = C.sp.dt;
   const float gon = (float)m->gravity_on;
@@ -229,10 +285,14 @@ DEV void chain_substep(const StepCtx& C, const ChainLds& L, int l, DofLane& X, c
   // With 32 lanes per env each moving body has two lanes (lb and lb + 16) that share its 27 accumulators between them
   // (contact_accumulate_half): the rigid inertia is computed by both, each folds the contacts into the elements it owns.
   constexpr bool SPLIT = G >= 32;
+  constexpr bool ROWS = G == 32;
   static_assert(!SPLIT || ND < 16, "second-half body lanes start at lane 16");
+  static_assert(!ROWS || (NCH * 8 <= G && NB * 6 >= NCH * 12), "row lanes: eight lanes per chain; U / pA exchange in the acc region");
   const int lb = SPLIT ? (l & 15) : l;                       // body-lane index: link lb < ND, root lb == ND
   const int half = SPLIT ? ((l >> 4) & 1) : 0;
-  const bool isdof = l < ND, ischain = l < NCH, isroot = l == ND;
+  const bool isdof = l < ND, isroot = l == ND;
+  const bool ischain = ROWS ? ((l & 7) == 0 && (l >> 3) < NCH) : l < NCH;
+  const int ci = ROWS ? (l >> 3) : l;                        // chain of a chain lane
   const bool isbody = SPLIT ? (lb <= ND && l < 32) : l <= ND;
   const bool islink = isbody && lb < ND;
   const int myb = lb < ND ? CD::body(lb / NLK, lb % NLK) : 0;   // moving body of this body lane (lb == ND: the root)
@@ -246,30 +306,37 @@ DEV void chain_substep(const StepCtx& C, const ChainLds& L, int l, DofLane& X, c
     joint_local_rotation(m->trot[myb], m->axis[myb], X.q, Rl);
 #pragma unroll
     for (int k = 0; k < 9; k++) rec[k] = Rl[k];
-    rec[9] = X.qd; rec[10] = t0; rec[11] = de;
+    rec[JREC_QD] = X.qd; rec[JREC_T0] = t0; rec[JREC_DE] = de;
   }
   GROUP_SYNC();
   PHASE_MARK(0);
 
   // ---- B. chain lanes: poses, velocities, motion subspaces root -> tip; the root lane publishes the root's pose
-  ChainLink K[NLK];
+  ChainLink K[ROWS ? 1 : NLK];   // (ROWS: S and c go to the joint records instead)
   if (ischain || isroot) {
     float Rc[9], pc[3] = {0.0f, 0.0f, 0.0f}, vc[6];
     quat_to_mat(L.root + 3, Rc);
 #pragma unroll
     for (int k = 0; k < 3; k++) { vc[k] = L.root[10 + k]; vc[3 + k] = L.root[7 + k]; }
-    if (isroot) {
+    if (isroot && !(ROWS && ischain)) {
       pose_store(L.pose, Rc, pc, vc);
     } else {
-      const int b0 = CD::body(l, 0);
+      const int b0 = CD::body(ci, 0);
 #pragma unroll
       for (int k = 0; k < NLK; k++) {
         const int b = b0 + k;
-        const float* rec = L.jrec + (l * NLK + k) * JREC_STRIDE;
+        float* rec = L.jrec + (ci * NLK + k) * JREC_STRIDE;
         float Rl[9];
 #pragma unroll
         for (int j = 0; j < 9; j++) Rl[j] = rec[j];
-        chain_compose_link(m->tpos[b], m->axis[b], Rl, rec[9], Rc, pc, vc, K[k].S, K[k].c);
+        if constexpr (ROWS) {
+          float Sx[6], cx[6];
+          chain_compose_link(m->tpos[b], m->axis[b], Rl, rec[JREC_QD], Rc, pc, vc, Sx, cx);
+#pragma unroll
+          for (int j = 0; j < 6; j++) { rec[JREC_S + j] = Sx[j]; rec[JREC_C + j] = cx[j]; }
+        } else {
+          chain_compose_link(m->tpos[b], m->axis[b], Rl, rec[JREC_QD], Rc, pc, vc, K[k].S, K[k].c);
+        }
         pose_store(L.pose + b * POSE_STRIDE, Rc, pc, vc);
       }
       const int b = b0 + NLK;   // the welded end body: reported pose, contact points and forces; inertia merged into the last link
@@ -366,15 +433,22 @@ DEV void chain_substep(const StepCtx& C, const ChainLds& L, int l, DofLane& X, c
   PHASE_MARK(3);
 
   // ---- D. body lanes: fold their active contacts, ascending point order whatever slot evaluated them; links hand
-  // (IA, pA) to their chain lane
+  // (IA, pA) to their chain lane.  SPLIT: the body's slots are one bit field of the ballot words (ShfModel.pt_eval packs
+  // them), so a lane visits exactly its active points -- the wave runs as many rounds as its busiest body has contacts.
   if (isbody) {
-    if (((act.w[0] & mine.mask.w[0]) | (act.w[1] & mine.mask.w[1])) != 0ull) {
+    if constexpr (SPLIT) {
+      unsigned bits = act.field(mine.s0, mine.n);
+      while (bits) {
+        const int j = __builtin_ctz(bits);
+        bits &= bits - 1u;
+        const float* o = L.pt + (mine.i0 + j) * PT_STRIDE;
+        if (half == 0) contact_accumulate_half<0>(o, dt, IA, pA);
+        else contact_accumulate_half<1>(o, dt, IA, pA);
+      }
+    } else if (((act.w[0] & mine.mask.w[0]) | (act.w[1] & mine.mask.w[1])) != 0ull) {
       for (int j = 0; j < mine.n; j++) {
         if (!act.test(mine.slot(j))) continue;
-        const float* o = L.pt + (mine.i0 + j) * PT_STRIDE;
-        if (!SPLIT) contact_accumulate_p(o, dt, IA, pA);
-        else if (half == 0) contact_accumulate_half<0>(o, dt, IA, pA);
-        else contact_accumulate_half<1>(o, dt, IA, pA);
+        contact_accumulate_p(L.pt + (mine.i0 + j) * PT_STRIDE, dt, IA, pA);
       }
     }
     // links hand (IA, pA) to their chain lane; the root's go to the same kind of slot for the element-wise sum below
@@ -397,8 +471,66 @@ DEV void chain_substep(const StepCtx& C, const ChainLds& L, int l, DofLane& X, c
   GROUP_SYNC();
   PHASE_MARK(4);
 
-  // ---- E. chain lanes: inward pass tip -> root in registers; the first link's result goes to the root through LDS
-  if (ischain) {
+  // ---- E. inward pass tip -> root; the first link's result goes to the root through LDS
+  float Ug[ROWS ? NLK : 1][6], invDk[ROWS ? NLK : 1], uk[ROWS ? NLK : 1];   // ROWS: what the outward pass needs, per link
+  if constexpr (ROWS) {
+    if (RL.on) {
+      float Ic[6], pc = 0.0f;   // this row of the running child contribution
+      float* sx = L.acc + RL.c * 12;   // U[6] pA[6] of the link in hand, row lanes -> every row lane (acc is idle until F)
+#pragma unroll
+      for (int k = NLK - 1; k >= 0; k--) {
+        const float* o = L.xch + (RL.c * NLK + k) * XCH_STRIDE;
+        const float* rec = L.jrec + (RL.c * NLK + k) * JREC_STRIDE;
+        float row[6], S[6], cc[6], plg[6], Wg[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) row[j] = o[RL.off[j]];
+        float pl = o[21 + RL.i];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { S[j] = rec[JREC_S + j]; cc[j] = rec[JREC_C + j]; }
+        const float dex = rec[JREC_DE], tau0 = rec[JREC_T0];
+        if (k < NLK - 1) {
+#pragma unroll
+          for (int j = 0; j < 6; j++) row[j] += Ic[j];
+          pl += pc;
+        }
+        float Ui = row[0] * S[0];
+#pragma unroll
+        for (int j = 1; j < 6; j++) Ui = fmaf(row[j], S[j], Ui);
+        sx[RL.i] = Ui; sx[6 + RL.i] = pl;
+        GROUP_SYNC();
+#pragma unroll
+        for (int j = 0; j < 6; j++) { Ug[k][j] = sx[j]; plg[j] = sx[6 + j]; }
+        GROUP_SYNC();   // every row has read before the next link's values are written
+        float D = S[0] * Ug[k][0];
+#pragma unroll
+        for (int j = 1; j < 6; j++) D = fmaf(S[j], Ug[k][j], D);
+        D += dex;
+        float sp = S[0] * plg[0];
+#pragma unroll
+        for (int j = 1; j < 6; j++) sp = fmaf(S[j], plg[j], sp);
+        const float invD = 1.0f / D;
+        invDk[k] = invD;
+        uk[k] = tau0 - sp;
+#pragma unroll
+        for (int j = 0; j < 6; j++) Wg[j] = Ug[k][j] * invD;
+        const float Wi = Ui * invD;
+        // element (i, j): above the diagonal IA[i][j] -= U[i] W[j]; below it the mirror image's operands, IA[j][i] -= U[j] W[i]
+#pragma unroll
+        for (int j = 0; j < 6; j++) row[j] = j < RL.i ? fmaf(-Ug[k][j], Wi, row[j]) : fmaf(-Ui, Wg[j], row[j]);
+        float acc = row[0] * cc[0];
+#pragma unroll
+        for (int j = 1; j < 6; j++) acc = fmaf(row[j], cc[j], acc);
+        pc = fmaf(Wi, uk[k], pl + acc);
+#pragma unroll
+        for (int j = 0; j < 6; j++) Ic[j] = row[j];
+      }
+      float* o = L.xch + (RL.c * NLK) * XCH_STRIDE;   // packed upper triangle: row i writes its elements (i, j >= i)
+#pragma unroll
+      for (int j = 0; j < 6; j++)
+        if (j >= RL.i) o[RL.off[j]] = Ic[j];
+      o[21 + RL.i] = pc;
+    }
+  } else if (ischain) {
     float Ic[21], pc6[6];   // running child contribution
 #pragma unroll
     for (int k = NLK - 1; k >= 0; k--) {
@@ -415,7 +547,7 @@ DEV void chain_substep(const StepCtx& C, const ChainLds& L, int l, DofLane& X, c
 #pragma unroll
         for (int j = 0; j < 6; j++) pl[j] += pc6[j];
       }
-      chain_inward_link(K[k], Il, pl, rec[11], rec[10], pa);
+      chain_inward_link(K[k], Il, pl, rec[JREC_DE], rec[JREC_T0], pa);
 #pragma unroll
       for (int j = 0; j < 21; j++) Ic[j] = Il[j];
 #pragma unroll
@@ -485,23 +617,34 @@ DEV void chain_substep(const StepCtx& C, const ChainLds& L, int l, DofLane& X, c
     float ap[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) ap[j] = L.acc[j];
-    const int b0 = CD::body(l, 0);
+    const int b0 = CD::body(ci, 0);
 #pragma unroll
     for (int k = 0; k < NLK; k++) {
+      float Sk[6], ck[6], Uk[6], invD, uu;
+      if constexpr (ROWS) {
+        const float* rec = L.jrec + (ci * NLK + k) * JREC_STRIDE;
 #pragma unroll
-      for (int j = 0; j < 6; j++) ap[j] = ap[j] + K[k].c[j];
-      float ua = K[k].U[0] * ap[0];
+        for (int j = 0; j < 6; j++) { Sk[j] = rec[JREC_S + j]; ck[j] = rec[JREC_C + j]; Uk[j] = Ug[k][j]; }
+        invD = invDk[k]; uu = uk[k];
+      } else {
 #pragma unroll
-      for (int j = 1; j < 6; j++) ua = fmaf(K[k].U[j], ap[j], ua);
-      const float qdd = (K[k].u - ua) * K[k].invD;
+        for (int j = 0; j < 6; j++) { Sk[j] = K[k].S[j]; ck[j] = K[k].c[j]; Uk[j] = K[k].U[j]; }
+        invD = K[k].invD; uu = K[k].u;
+      }
 #pragma unroll
-      for (int j = 0; j < 6; j++) ap[j] = fmaf(K[k].S[j], qdd, ap[j]);
+      for (int j = 0; j < 6; j++) ap[j] = ap[j] + ck[j];
+      float ua = Uk[0] * ap[0];
+#pragma unroll
+      for (int j = 1; j < 6; j++) ua = fmaf(Uk[j], ap[j], ua);
+      const float qdd = (uu - ua) * invD;
+#pragma unroll
+      for (int j = 0; j < 6; j++) ap[j] = fmaf(Sk[j], qdd, ap[j]);
       if (contact_out) {
         float* o = L.acc + (b0 + k) * 6;
 #pragma unroll
         for (int j = 0; j < 6; j++) o[j] = ap[j];
       }
-      L.dofb[(l * NLK + k) * DOF_STRIDE + 4] = qdd;
+      L.dofb[(ci * NLK + k) * DOF_STRIDE + 4] = qdd;
     }
   }
   GROUP_SYNC();
@@ -527,7 +670,16 @@ DEV void chain_substep(const StepCtx& C, const ChainLds& L, int l, DofLane& X, c
     if (isbody && half == 0) {
       const bool last = islink && (lb % NLK) == NLK - 1;
       float f[3] = {0.0f, 0.0f, 0.0f}, fw[3] = {0.0f, 0.0f, 0.0f};
-      if (((act.w[0] & mine.mask.w[0]) | (act.w[1] & mine.mask.w[1])) != 0ull) {
+      if constexpr (SPLIT) {
+        unsigned bits = act.field(mine.s0, mine.n);
+        while (bits) {
+          const int i = mine.i0 + __builtin_ctz(bits);
+          bits &= bits - 1u;
+          const float* o = L.pt + i * PT_STRIDE;
+          if (m->pt_body[i] == myb) { f[0] += o[PT_F]; f[1] += o[PT_F + 1]; f[2] += o[PT_F + 2]; }
+          else { fw[0] += o[PT_F]; fw[1] += o[PT_F + 1]; fw[2] += o[PT_F + 2]; }
+        }
+      } else if (((act.w[0] & mine.mask.w[0]) | (act.w[1] & mine.mask.w[1])) != 0ull) {
         for (int j = 0; j < mine.n; j++) {
           if (!act.test(mine.slot(j))) continue;
           const int i = mine.i0 + j;
@@ -608,7 +760,7 @@ DEV void chain_body_states(const ShfModel* m, const ChainLds& L, int l, const Do
 template <int G, class CD, bool TW>
 DEV void a1_chain_step_body(const A1Args& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NLK = CD::NLK, nb = CD::NB, nd = CD::ND, np = CD::NPC, NR = (CD::NPC + G - 1) / G;
+  constexpr int NLK = CD::NLK, nb = CD::NB, nd = CD::ND, NR = (CD::NEV + G - 1) / G;
   PHASE_BEGIN();
   float* stats_lds = smem + MODEL_WORDS + TASK_WORDS;
   stats_block_init(stats_lds);
@@ -672,11 +824,12 @@ DEV void a1_chain_step_body(const A1Args& A) {
   DofLane X = {L.dofb[dl * DOF_STRIDE], L.dofb[dl * DOF_STRIDE + 1], 0.0f};
   const float pg_ = tp.p_gain[dl], dg_ = tp.d_gain[dl], q0_ = tp.default_dof_pos[dl], lim_ = m->effort[dl];
   ChainPoints<NR> LP;
-  chain_points_load<G>(m, np, l, C.sp.contact_offset, LP);
+  chain_points_load<G>(m, CD::NEV, l, C.sp.contact_offset, LP);
   // evaluation slots of this body lane's points (lane j < nd: link j; lane nd: the root)
   const int lb = G >= 32 ? (l & 15) : l;
   const int mb = lb < nd ? CD::body(lb / NLK, lb % NLK) : 0;
   const SlotList<CD::MAXPT> mine = slot_list_load<CD::MAXPT>(m, m->pt_start[mb], (lb <= nd && l < 32) ? m->pt_count[mb] : 0);
+  const RowLane RL = row_lane_load<CD>(l);
   PHASE_MARK(11);
   for (int it = 0; it < nsub; it++) {
     if (it < tp.decimation) {
@@ -684,7 +837,7 @@ DEV void a1_chain_step_body(const A1Args& A) {
       const float t = pg_ * (act + q0_ - X.q) - dg_ * X.qd;
       X.tau = rclampf(t, -lim_, lim_);
     }
-    chain_substep<G, CD, TW>(C, L, l, X, LP, mine, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
+    chain_substep<G, CD, TW>(C, L, l, X, LP, mine, RL, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
                              (it == nsub - 1) ? L.xch : nullptr);
   }
   PHASE_RESET();

@@ -624,7 +624,9 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
             m.pt_start[d] = i
         m.pt_count[d] += 1
 
-    # evaluation order hint (ShfModel.pt_eval): lowest points of the zero pose first
+    # evaluation slots (ShfModel.pt_eval / pt_slot / neval): the points of a moving body in consecutive slots, in point order,
+    # never across a multiple of 32; bodies whose rest pose reaches lowest first (they are the ones that usually touch the
+    # ground: the later rounds can then skip the contact response); first-fit into the 32-slot blocks
     R0 = [np.eye(3) for _ in range(nb)]
     p0 = [np.zeros(3) for _ in range(nb)]
     for b in range(1, nb):
@@ -632,10 +634,31 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
         R0[b] = R0[pb] @ np.array([[m.trot[b][3 * r + c] for c in range(3)] for r in range(3)], dtype=float)
         p0[b] = p0[pb] + R0[pb] @ np.array([m.tpos[b][kk] for kk in range(3)], dtype=float)
     zs = [float((p0[bb] + R0[bb] @ np.asarray(pp, dtype=float))[2] - rr) for (bb, pp, rr) in points]
-    order = sorted(range(len(points)), key=lambda i: (round(zs[i], 4), i))
-    for s_, i in enumerate(order):
-        m.pt_eval[s_] = i
-        m.pt_slot[i] = s_
+    groups = [(int(m.pt_start[d]), int(m.pt_count[d])) for d in range(nb) if m.dyn[d] == d and m.pt_count[d] > 0]
+    groups.sort(key=lambda g_: (round(min(zs[g_[0]:g_[0] + g_[1]]), 4), g_[0]))
+    for s_ in range(_abi.MAX_POINTS):
+        m.pt_eval[s_] = -1
+    blocks = []                                     # free slots left in each 32-slot block
+    packed = all(c <= 32 for _, c in groups)
+    if packed:
+        for i0, c in groups:
+            k = next((k for k, free in enumerate(blocks) if free >= c), None)
+            if k is None:
+                blocks.append(32)
+                k = len(blocks) - 1
+            s0 = 32 * k + (32 - blocks[k])
+            blocks[k] -= c
+            for j in range(c):
+                m.pt_eval[s0 + j] = i0 + j
+                m.pt_slot[i0 + j] = s0 + j
+        neval = max((s_ + 1 for s_ in range(32 * len(blocks)) if m.pt_eval[s_] >= 0), default=0)
+        packed = neval <= _abi.MAX_POINTS
+    if not packed:                                  # a body with more than 32 points, or no room for the padding: the identity
+        neval = len(points)
+        for i in range(len(points)):
+            m.pt_eval[i] = i
+            m.pt_slot[i] = i
+    m.neval = neval
 
     # rounded shapes vs box actors: a sphere is one record, a capsule two consecutive ones (ShfModel.sph_part: the closest
     # point / first end of a line contact, and the second end)
