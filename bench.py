@@ -224,7 +224,7 @@ def main():
     ap.add_argument("--workload", choices=["terrain", "flat", "trimesh", "abb"], default="terrain",
                     help="terrain = config 3 (height field); trimesh = the same samples as the mesh with vertical risers; "
                          "abb = config 5")
-    ap.add_argument("--group", type=int, default=None, help="lanes per env: 64 = one wavefront per env; default 32 for the A1 workloads and for abb --link-contacts, 16 for abb: the fastest measured (DESIGN.md 6)")
+    ap.add_argument("--group", type=int, default=None, help="lanes per env: 64 = one wavefront per env; default 32 for the A1 workloads, 16 for abb: the fastest measured (DESIGN.md 6)")
     ap.add_argument("--actions", choices=["kernel", "torch"], default="kernel",
                     help="random actions drawn inside the fused launch (default) or by a torch uniform_ launch before it")
     ap.add_argument("--mapping", choices=["chain", "body", "split"], default=None,
@@ -234,9 +234,12 @@ def main():
     ap.add_argument("--self-collision", action="store_true",
                     help="A1 workloads: collide the robot's own links (capsule pairs; the reference's collision filter 0, "
                          "units.py:68) -- off in the headline configuration, whose BASELINE entry names height-field contact")
+    ap.add_argument("--no-link-contacts", action="store_true",
+                    help="abb workload: the rod against the cube only (the scene benchmarked in rounds 1-3) instead of the "
+                         "reference's scene with every link colliding; implied by --mapping chain / split, which are compiled for it")
     ap.add_argument("--link-contacts", action="store_true",
                     help="abb workload: the arm's links (box stand-ins for their mesh colliders) and the rod also collide with the "
-                         "table, the cube and the goal pad (SURVEY 8f f3, ShfModel.link_collide) -- off in the headline configuration")
+                         "table, the cube and the goal pad (SURVEY 8f f3, ShfModel.link_collide) -- the default for this workload since round 4 (the flag is kept for old command lines)")
     ap.add_argument("--graph", action="store_true", help="(experiments: slower, and back-to-back graph replays are not trustworthy on this stack, profiles/r02_mlp_probe.md) replay the vec-step from a captured hipGraph instead of launching it "
                     "eagerly (measured slower on ROCm 7.2: 84.7 vs 73.9 us per vec-step, profiles/r02_bench_*.json)")
     ap.add_argument("--decimation", type=int, default=4, help="(experiments only) control.decimation")
@@ -284,8 +287,11 @@ def main():
 
     abb = args.workload == "abb"
     if abb:
+        if args.link_contacts and (args.no_link_contacts or args.mapping in ("chain", "split")):
+            raise SystemExit("bench.py: --link-contacts contradicts --no-link-contacts / --mapping chain|split (compiled for the rod-only scene)")
+        args.link_contacts = not (args.no_link_contacts or args.mapping in ("chain", "split"))
         mapping = args.mapping or (("split" if (args.group or 16) == 16 else "chain") if (not args.link_contacts and (args.group or 16) < 64) else "body")
-        group = args.group or (32 if args.link_contacts else 16)
+        group = args.group or 16
     else:    # the fused A1 env's own default: the chain-per-lane kernel at 32 lanes when there is no self-collision
         mapping = args.mapping or ("chain" if (not args.self_collision and (args.group or 32) < 64) else "body")
         group = args.group or 32
@@ -409,7 +415,7 @@ def main():
         value = total_envs * args.steps / elapsed
         b_alg = B_ALG[args.workload]
         achieved = b_alg * N / (kern_ms * 1e-3) / 1e9
-        prof = committed_profile(f"{kernel}_{args.workload}_g{group}" + ("_" + mapping if mapping != "body" else "")) if (N == 4096 and not args.self_collision) else None
+        prof = committed_profile(f"{kernel}_{args.workload}_g{group}" + ("_" + mapping if mapping != "body" else "") + ("_link" if (abb and args.link_contacts) else "")) if (N == 4096 and not args.self_collision) else None
         res = {}
         try:
             res = json.load(open(os.path.join(ROOT, "shifu_amd", "libshifu_amd.resources.json")))

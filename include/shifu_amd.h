@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SHF_ABI_VERSION 9
+#define SHF_ABI_VERSION 10
 
 #define SHF_MAX_BODIES 32 /* reported rigid bodies per articulation        */
 #define SHF_MAX_DOFS 32
@@ -144,16 +144,32 @@ typedef struct ShfModel {
    *   (B) the eight corners of every box actor against the articulation's box volumes abox_* (vertex in box).
    * Vertex-face manifolds in both directions; edge-edge crossings are not detected.  Against a free box the contact
    * takes the consistent pair law (the box is eliminated exactly), against a fixed one the ground-contact law.  At most
-   * SHF_MAX_LINK_CONTACTS are active per env and sub-step, in candidate order (A by point then box, C by shape then box,
-   * B by box, corner, volume); more are dropped and counted.  abox: centre and orientation in abox_body's frame. */
+   * SHF_MAX_LINK_CONTACTS are active per env and sub-step, in candidate order -- (body, box actor) pair by pair, body ascending
+   * then box ascending; within a pair A (points ascending), C (shapes ascending), B (volume ascending, corner
+   * ascending) -- more are dropped and counted.  abox: centre and orientation in abox_body's frame. */
   int32_t link_collide;
   int32_t nabox;
-  int32_t pad_lc[2];
+  int32_t bounds_ok; /* SHF_BOUNDS_MAGIC once shf_model_bounds() has filled bbox; anything else: the kernels test every candidate */
+  int32_t pad_lc;
   int32_t abox_body[SHF_MAX_ABOX];
   float abox_pos[SHF_MAX_ABOX][3];
   float abox_rot[SHF_MAX_ABOX][9]; /* row-major rotation body <- box */
   float abox_half[SHF_MAX_ABOX][3];
+  /* Derived (shf_model_bounds): per reported body, the box (centre[3], half extents[3], body frame, axis-aligned there)
+   * around every shape of that body that takes part in link contacts -- its sample points and rounded sph_* shapes grown
+   * by their radii, its abox_* volumes; half[0] < 0: the body has none.  The link-contact broad phase: a (body, box actor)
+   * pair whose two oriented boxes are separated along one of their six face normals by more than the contact offset
+   * (+ 1 cm for rounding) cannot produce an active candidate of any family, so its candidates are never evaluated --
+   * results are those of testing every candidate, as the oracle does. */
+  float bbox[SHF_MAX_BODIES][6];
+  /* Derived too: the sample points and box volumes grouped by reported body, each group ascending, so that a kernel finds
+   * the candidates of one (body, box actor) pair as a range -- lc_pt[lc_range[b][0] .. + lc_range[b][1]) are body b's
+   * points, lc_abox[lc_range[b][2] .. + lc_range[b][3]) its volumes. */
+  int16_t lc_range[SHF_MAX_BODIES][4];
+  int16_t lc_pt[SHF_MAX_POINTS];
+  int16_t lc_abox[SHF_MAX_ABOX];
 } ShfModel;
+#define SHF_BOUNDS_MAGIC 0x42534831 /* "BSH1" */
 
 /* A single-body box actor (gym.create_box, object.py:28-39). */
 typedef struct ShfBoxDesc {
@@ -235,7 +251,7 @@ enum {
   SHF_T_BODY_FORCE = 10, /* (N*B, 3) f32 apply_rigid_body_force_at_pos_tensors (CoM)       */
   SHF_T_FRICTION = 11,   /* (N) f32      per-env shape friction (a1_conditional.py:28-31)  */
   SHF_T_HEIGHTS = 12,    /* (rows*cols) i16 height samples (isaac_gym.py:349-367)          */
-  SHF_T_MODEL = 13,      /* sizeof(ShfModel) bytes, device copy                            */
+  SHF_T_MODEL = 13,      /* sizeof(ShfModel) bytes; shf_sim_bind writes the library's copy into it */
   SHF_T_SIM_CONTACT = 14,/* (N*B, 3) f32 internal net contact force of the last step        */
   SHF_T_SCENE = 15,      /* sizeof(ShfScene) bytes, device copy                            */
   SHF_T_DROPPED = 16,    /* (N) i32: contacts dropped since the host last cleared it -- self-contacts beyond
@@ -269,6 +285,11 @@ int shf_sim_destroy(ShfSim* sim);
 int shf_sim_set_terrain(ShfSim* sim, const ShfTerrain* terrain);
 /* gym.load_asset + create_actor for the articulated robot (units.py:57-77) */
 int shf_sim_set_articulation(ShfSim* sim, const ShfModel* model);
+/* Part of gym.load_asset (units.py:73): fills the model's derived broad-phase data (ShfModel.bbox, bounds_ok) from its
+ * shape records, in place.  Host only, no GPU.  shf_sim_set_articulation does the same on its own copy, and
+ * shf_sim_bind(SHF_T_MODEL, ptr) writes that copy into the bound buffer, so a binding never has to call this; it is
+ * exported for tools that inspect the derived data. */
+int shf_model_bounds(ShfModel* model);
 /* gym.create_box + create_actor (object.py:28-39) */
 int shf_sim_add_box(ShfSim* sim, const ShfBoxDesc* box);
 /* gym.create_env x N + prepare_sim (isaac_gym.py:94-104).  env_id_offset is

@@ -1,7 +1,7 @@
 """ctypes mirrors of the PODs in include/shifu_amd.h (keep in lock-step)."""
 import ctypes as C
 
-SHF_ABI_VERSION = 9
+SHF_ABI_VERSION = 10
 MAP_BODY, MAP_CHAIN, MAP_CHAIN_SPLIT = 0, 1, 2   # shf_sim_set_mapping
 MAX_BODIES = 32
 MAX_DOFS = 32
@@ -41,8 +41,10 @@ class ShfModel(C.Structure):
         ("self_collide", i32), ("ncap", i32), ("npair", i32), ("neval", i32),
         ("cap_body", i32 * MAX_CAPSULES), ("cap_a", (f32 * 3) * MAX_CAPSULES), ("cap_b", (f32 * 3) * MAX_CAPSULES),
         ("cap_radius", f32 * MAX_CAPSULES), ("pair_a", C.c_uint8 * MAX_PAIRS), ("pair_b", C.c_uint8 * MAX_PAIRS),
-        ("link_collide", i32), ("nabox", i32), ("pad_lc", i32 * 2), ("abox_body", i32 * MAX_ABOX),
+        ("link_collide", i32), ("nabox", i32), ("bounds_ok", i32), ("pad_lc", i32), ("abox_body", i32 * MAX_ABOX),
         ("abox_pos", (f32 * 3) * MAX_ABOX), ("abox_rot", (f32 * 9) * MAX_ABOX), ("abox_half", (f32 * 3) * MAX_ABOX),
+        ("bbox", (f32 * 6) * MAX_BODIES),
+        ("lc_range", (C.c_int16 * 4) * MAX_BODIES), ("lc_pt", C.c_int16 * MAX_POINTS), ("lc_abox", C.c_int16 * MAX_ABOX),
     ]
 
 

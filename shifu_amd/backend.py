@@ -124,6 +124,7 @@ class Sim:
         check(lib().shf_sim_set_terrain(self._h, C.byref(t)))
 
     def set_articulation(self, model: _abi.ShfModel):
+        check(lib().shf_model_bounds(C.byref(model)))      # derived broad-phase data: the blob uploaded as SHF_T_MODEL carries it
         self.model = model
         check(lib().shf_sim_set_articulation(self._h, C.byref(model)))
 
@@ -414,10 +415,13 @@ class AbbTask:
     def kernel_symbol(self) -> str:
         """Mangled-name prefix of the instantiation shf_abb_step launches for this sim (build resource table)."""
         mdl = self.sim.model
-        fixed = mdl.nb == 7 and mdl.np == 3 and self.sim.nboxes == 3 and not (mdl.link_collide and self.sim.nboxes > 0)
+        link = bool(mdl.link_collide and self.sim.nboxes > 0)
+        fixed = mdl.nb == 7 and mdl.np == (59 if link else 3) and self.sim.nboxes == 3
         pre = f"_Z10k_abb_stepILi{self.sim.group}E"
         if not fixed:
             return pre + "7DynDims"
+        if link:    # the shipped arm with its link volumes in the shipped scene (AbbLinkDims, AbbScene)
+            return pre + "9FixedDimsILi7ELi6ELi59ELi6ELi6EE10FixedSceneILi3ELi1ELi2EELb1ELi0EE"
         mp = getattr(self.sim, "mapping", "body")
         if mp == "split":
             return "_Z13k_abb_step_wsILi"

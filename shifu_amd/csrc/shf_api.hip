@@ -11,6 +11,9 @@
 #include <map>
 #include <mutex>
 #include <utility>
+#include <vector>
+#include <algorithm>
+#include <cmath>
 #include <string>
 
 #include "shf_device.h"
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
   if (e >= A.n) return;
   const int nbx = BOX ? A.nboxes : 0, actors = 1 + nbx;
   const int nb = m->nb, nd = m->nd, nbt = nb + nbx;
-  const int nslots = m->np + box_slot_count(nbx, m->nsph) + (SELF ? SHF_MAX_SELF_CONTACTS : 0) + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0);
+  const int nslots = m->np + (BOX ? box_slots(slot_lay<DynScene>(m, scene)) : 0) + (SELF ? SHF_MAX_SELF_CONTACTS : 0) + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0);
   EnvLds L = env_lds_carve(smem + MODEL_WORDS + (BOX ? SCENE_WORDS : 0) + es * env_lds_words(nbt, nd, nslots, 0, actors),
                            nbt, nd, nslots, actors);
   float* dof = A.dof + (size_t)e * nd * 2;
@@ -593,7 +596,7 @@ __global__ __launch_bounds__(256, (G >= 32 && SC::NBX > 0) ? 2 : 1) void k_abb_s
   if (e >= n) return;
   const int nbx = SC::NBX > 0 ? SC::NBX : A.S.nboxes, actors = 1 + nbx;
   const int nb = DM::nb(m), nd = DM::nd(m), nbt = nb + nbx;
-  const int nslots = DM::np(m) + box_slot_count(nbx, m->nsph) + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0);
+  const int nslots = DM::np(m) + box_slots(slot_lay<SC>(m, scene)) + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0);
   const int env_words = env_lds_words(nbt, nd, nslots, ABB_TAIL_WORDS(nslots, nd), actors);
   EnvLds L = env_lds_carve(smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS + es * env_words, nbt, nd, nslots, actors);
   float* tgtl = L.pt + nslots * PT_STRIDE;  // POS targets of this env step
@@ -671,7 +674,7 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
   const int n = A.S.n;
   const bool live = e < n;                       // no early return: every wave meets every workgroup barrier
   constexpr int nbx = SC::NBX, actors = 1 + nbx, nb = NL + 1, nd = NL, nbt = nb + nbx;
-  const int nslots = DM::np(m) + box_slot_count(nbx, m->nsph);
+  const int nslots = DM::np(m) + box_slot_count(nbx, 1, m->nsph);   // the fixed scene has one free box
   const int env_words = env_lds_words(nbt, nd, nslots, ABB_TAIL_WORDS(nslots, nd), actors);
   EnvLds L = env_lds_carve(smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS + es * env_words, nbt, nd, nslots, actors);
   float* tgtl = L.pt + nslots * PT_STRIDE;       // POS targets of this env step
@@ -861,10 +864,15 @@ __global__ void k_abb_reset_all(AbbArgs A) {
 // ---------------------------------------------------------------- C ABI --
 static bool sim_self(const ShfSim* s) { return s->model.self_collide != 0 && s->model.npair > 0; }
 static bool sim_link(const ShfSim* s) { return s->model.link_collide != 0 && s->nboxes > 0; }
+static int sim_ndyn(const ShfSim* s) {   // free boxes: the only ones that own contact slots (SlotLay)
+  int n = 0;
+  for (int k = 0; k < s->nboxes; k++) n += (!s->boxes[k].fixed && s->boxes[k].mass > 0.0f) ? 1 : 0;
+  return n;
+}
 static size_t sim_lds_bytes(const ShfSim* s, int head_words, int min_tail, bool boxes = false) {
   const int epb = 256 / s->group;
   const int nbx = boxes ? s->nboxes : 0;
-  const int nslots = s->model.np + (boxes ? box_slot_count(nbx, s->model.nsph) : 0) + (sim_self(s) ? SHF_MAX_SELF_CONTACTS : 0) +
+  const int nslots = s->model.np + (boxes ? box_slot_count(nbx, sim_ndyn(s), s->model.nsph) : 0) + (sim_self(s) ? SHF_MAX_SELF_CONTACTS : 0) +
                      ((boxes && sim_link(s)) ? 2 * SHF_MAX_LINK_CONTACTS : 0);
   return ((size_t)MODEL_WORDS + head_words + (boxes ? SCENE_WORDS : 0) +
           (size_t)epb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, min_tail, 1 + (boxes ? nbx : s->nboxes))) * 4;
@@ -899,7 +907,61 @@ extern "C" int shf_sim_set_articulation(ShfSim* sim, const ShfModel* model) {
       model->np > SHF_MAX_POINTS)
     return fail("shf_sim_set_articulation: model exceeds SHF_MAX_*");
   sim->model = *model;
+  shf_model_bounds(&sim->model);
   sim->has_model = true;
+  return 0;
+}
+// ShfModel.bbox: the bounding box (body frame) of everything a body contributes to link contacts -- sample points grown
+// by their radii, the rounded shapes' segments grown by theirs, the eight vertices of each box volume -- rounded outwards
+extern "C" int shf_model_bounds(ShfModel* m) {
+  if (!m) return fail("shf_model_bounds: null model");
+  if (m->nb < 1 || m->nb > SHF_MAX_BODIES || m->np < 0 || m->np > SHF_MAX_POINTS || m->nsph < 0 || m->nsph > SHF_MAX_SPHERES ||
+      m->nabox < 0 || m->nabox > SHF_MAX_ABOX)
+    return fail("shf_model_bounds: model exceeds SHF_MAX_*");
+  struct Ball { double c[3], r; int body; };
+  std::vector<Ball> balls;
+  for (int i = 0; i < m->np; i++) balls.push_back({{m->pt_pos[i][0], m->pt_pos[i][1], m->pt_pos[i][2]}, m->pt_radius[i], m->pt_body[i]});
+  for (int i = 0; i < m->nsph; i++)
+    for (int e = 0; e < 2; e++)
+      balls.push_back({{m->sph_pos[i][0] + e * m->sph_seg[i][0], m->sph_pos[i][1] + e * m->sph_seg[i][1], m->sph_pos[i][2] + e * m->sph_seg[i][2]},
+                       m->sph_radius[i], m->sph_body[i]});
+  for (int j = 0; j < m->nabox; j++)
+    for (int c = 0; c < 8; c++) {
+      const double lc[3] = {((c & 4) ? 1.0 : -1.0) * m->abox_half[j][0], ((c & 2) ? 1.0 : -1.0) * m->abox_half[j][1], ((c & 1) ? 1.0 : -1.0) * m->abox_half[j][2]};
+      Ball b = {{0, 0, 0}, 0.0, m->abox_body[j]};
+      for (int r = 0; r < 3; r++)
+        b.c[r] = m->abox_pos[j][r] + m->abox_rot[j][3 * r] * lc[0] + m->abox_rot[j][3 * r + 1] * lc[1] + m->abox_rot[j][3 * r + 2] * lc[2];
+      balls.push_back(b);
+    }
+  for (int b = 0; b < SHF_MAX_BODIES; b++) {
+    double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};
+    bool any = false;
+    for (const Ball& s : balls)
+      if (s.body == b) {
+        any = true;
+        for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], s.c[k] - s.r); hi[k] = std::max(hi[k], s.c[k] + s.r); }
+      }
+    for (int k = 0; k < 6; k++) m->bbox[b][k] = 0.0f;
+    if (!any || b >= m->nb) { m->bbox[b][3] = -1.0f; continue; }
+    for (int k = 0; k < 3; k++) {
+      m->bbox[b][k] = (float)(0.5 * (lo[k] + hi[k]));
+      const double reach = std::max(hi[k] - (double)m->bbox[b][k], (double)m->bbox[b][k] - lo[k]);
+      m->bbox[b][3 + k] = (float)(reach * (1.0 + 1e-5) + 1e-6);   // rounded up
+    }
+  }
+  // shapes grouped by body (each group ascending): lc_range / lc_pt / lc_abox
+  int npt = 0, nab = 0;
+  for (int b = 0; b < SHF_MAX_BODIES; b++) {
+    m->lc_range[b][0] = (int16_t)npt; m->lc_range[b][2] = (int16_t)nab;
+    if (b < m->nb) {
+      for (int i = 0; i < m->np; i++) if (m->pt_body[i] == b) m->lc_pt[npt++] = (int16_t)i;
+      for (int j = 0; j < m->nabox; j++) if (m->abox_body[j] == b) m->lc_abox[nab++] = (int16_t)j;
+    }
+    m->lc_range[b][1] = (int16_t)(npt - m->lc_range[b][0]); m->lc_range[b][3] = (int16_t)(nab - m->lc_range[b][2]);
+  }
+  for (int i = npt; i < SHF_MAX_POINTS; i++) m->lc_pt[i] = 0;
+  for (int j = nab; j < SHF_MAX_ABOX; j++) m->lc_abox[j] = 0;
+  m->bounds_ok = SHF_BOUNDS_MAGIC;
   return 0;
 }
 extern "C" int shf_sim_add_box(ShfSim* sim, const ShfBoxDesc* box) {
@@ -992,6 +1054,13 @@ extern "C" int shf_sim_layout(const ShfSim* sim, int32_t id, int64_t shape[4], i
 }
 extern "C" int shf_sim_bind(ShfSim* sim, int32_t id, void* device_ptr) {
   if (!sim || id < 0 || id >= SHF_T_COUNT) return fail("shf_sim_bind: bad id");
+  if (id == SHF_T_MODEL && device_ptr) {
+    // the library's own copy -- the caller's model plus the derived fields of shf_model_bounds() -- is what the kernels
+    // read: a blob uploaded by a binding that did not derive them is completed here (one blocking copy, at set-up)
+    if (!sim->has_model) return fail("shf_sim_bind: SHF_T_MODEL before shf_sim_set_articulation");
+    if (hipMemcpy(device_ptr, &sim->model, sizeof(ShfModel), hipMemcpyHostToDevice) != hipSuccess)
+      return fail("shf_sim_bind: could not write the model to the bound SHF_T_MODEL buffer");
+  }
   sim->t[id] = device_ptr;
   return 0;
 }
@@ -1485,9 +1554,17 @@ static int abb_step_launch(ShfAbbTask* task, const float* raw_actions_dev, void*
   ShfSim* s = task->sim;
   const int epb = 256 / s->group;
   dim3 grid((s->n + epb - 1) / epb), block(256);
-  const int nbx = s->nboxes, nslots = s->model.np + box_slot_count(nbx, s->model.nsph) + (sim_link(s) ? 2 * SHF_MAX_LINK_CONTACTS : 0);
+  const int nbx = s->nboxes, nslots = s->model.np + box_slot_count(nbx, sim_ndyn(s), s->model.nsph) + (sim_link(s) ? 2 * SHF_MAX_LINK_CONTACTS : 0);
   const size_t lds = ((size_t)MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS +
                       (size_t)epb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, ABB_TAIL_WORDS(nslots, s->model.nd), 1 + nbx)) * 4;
+  if (sim_link(s) && s->mapping != SHF_MAP_CHAIN && AbbLinkDims::matches(s->model) && AbbScene::matches(s->nboxes, s->boxes, s->model.nsph)) {
+    // the shipped arm with its link volumes in the shipped scene: compile-time loop bounds, ballot-driven folds
+    switch (s->group) {
+      case 64: return launch(k_abb_step<64, AbbLinkDims, AbbScene, true>, grid, block, lds, stream, A);
+      case 32: return launch(k_abb_step<32, AbbLinkDims, AbbScene, true>, grid, block, lds, stream, A);
+      default: return launch(k_abb_step<16, AbbLinkDims, AbbScene, true>, grid, block, lds, stream, A);
+    }
+  }
   if (sim_link(s)) {
     switch (s->group) {
       case 64: return launch(k_abb_step<64, DynDims, DynScene, true>, grid, block, lds, stream, A);

@@ -663,31 +663,49 @@ DEV void self_contact_forces(const StepCtx& C, const EnvLds& L, int l, int slot0
   contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];
 }
 
-// slot indexing inside the env's contact region, after the articulation's np sample points
-DEV int corner_slot(const ShfModel* m, int nbx, int kd, int c, int tg) { return m->np + (kd * 8 + c) * (1 + nbx) + tg; }
-DEV int sphere_slot(const ShfModel* m, int nbx, int si, int kd) { return m->np + nbx * 8 * (1 + nbx) + si * nbx + kd; }
+// Slot indexing inside the env's contact region, after the articulation's np sample points.  Only the FREE boxes own
+// slots -- 8 corners x (terrain + every box) each, then one slot per (rounded shape, free box) and one pair record per such
+// slot -- numbered by the free box's rank among the free boxes (a fixed box has no contacts of its own to fold).
+struct SlotLay { int np, nbx, ndyn, nsph; unsigned ranks, dynmask; };   // ranks: 2 bits per box; dynmask: bit kd = box kd is free
+__host__ __device__ inline int box_slot_count(int nbx, int ndyn, int nsph) { return ndyn * 8 * (1 + nbx) + 2 * nsph * ndyn; }
+template <class SC>
+DEV SlotLay slot_lay(const ShfModel* m, const ShfScene* S) {
+  SlotLay Q;
+  Q.np = m->np; Q.nsph = m->nsph;
+  if constexpr (SC::NBX > 0) {
+    Q.nbx = SC::NBX; Q.ndyn = 1; Q.ranks = 0u; Q.dynmask = 1u << SC::DYN;
+  } else {
+    Q.nbx = S ? S->nboxes : 0; Q.ndyn = 0; Q.ranks = 0u; Q.dynmask = 0u;
+    for (int k = 0; k < Q.nbx; k++)
+      if (box_is_dynamic(S->box[k])) { Q.ranks |= (unsigned)Q.ndyn << (2 * k); Q.dynmask |= 1u << k; Q.ndyn++; }
+  }
+  return Q;
+}
+DEV int lay_rank(const SlotLay& Q, int kd) { return (int)((Q.ranks >> (2 * kd)) & 3u); }
+DEV int corner_slot(const SlotLay& Q, int kd, int c, int tg) { return Q.np + (lay_rank(Q, kd) * 8 + c) * (1 + Q.nbx) + tg; }
+DEV int sphere_slot(const SlotLay& Q, int si, int kd) { return Q.np + Q.ndyn * 8 * (1 + Q.nbx) + si * Q.ndyn + lay_rank(Q, kd); }
 // second record of a pair slot: the consistent law's (Feff[3], Keff upper triangle [6]) -- see pair_law
-DEV int pair_slot(const ShfModel* m, int nbx, int si, int kd) { return sphere_slot(m, nbx, si, kd) + m->nsph * nbx; }
-__host__ __device__ inline int box_slot_count(int nbx, int nsph) { return nbx * 8 * (1 + nbx) + 2 * nsph * nbx; }
+DEV int pair_slot(const SlotLay& Q, int si, int kd) { return sphere_slot(Q, si, kd) + Q.nsph * Q.ndyn; }
+DEV int box_slots(const SlotLay& Q) { return box_slot_count(Q.nbx, Q.ndyn, Q.nsph); }
 // joint pair law (pair_law_joint): which capsule, if any, has exactly its two ends as box kd's active pair slots; where the
 // record lives (the box's exchange slot: boxes hand nothing to a parent); the force of sphere slot si either way
-DEV int box_joint_pair(const ShfModel* m, const EnvLds& L, int nbx, int kd, unsigned sb, int nlink_on_box) {
+DEV int box_joint_pair(const ShfModel* m, const EnvLds& L, const SlotLay& Q, int kd, unsigned sb, int nlink_on_box) {
 #ifdef SHF_EXP_NO_JOINT_LAW   /* timing experiment only (tools/mlp_probe.py-style build): the independent laws everywhere */
   return -1;
 #endif
-  return joint_pair_of(m, sb, nlink_on_box, [&](int si) { return L.pt[sphere_slot(m, nbx, si, kd) * PT_STRIDE + PT_CT]; });
+  return joint_pair_of(m, sb, nlink_on_box, [&](int si) { return L.pt[sphere_slot(Q, si, kd) * PT_STRIDE + PT_CT]; });
 }
 DEV float* joint_record(const ShfModel* m, const EnvLds& L, int kd) { return L.xch + (m->nb + kd) * XCH_STRIDE; }
-DEV void sphere_pair_force(const ShfModel* m, const EnvLds& L, int nbx, int si, int kd, int jp, float dt, float* f) {
+DEV void sphere_pair_force(const ShfModel* m, const EnvLds& L, const SlotLay& Q, int si, int kd, int jp, float dt, float* f) {
   const float* ab = L.acc + m->dyn[m->sph_body[si]] * 6;
   const float abr[6] = {ab[0], ab[1], ab[2], ab[3], ab[4], ab[5]};
   if (jp < 0) {
-    const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
+    const float* o = L.pt + sphere_slot(Q, si, kd) * PT_STRIDE;
     const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]};
-    pair_force(L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE, abr, r, dt, f);
+    pair_force(L.pt + pair_slot(Q, si, kd) * PT_STRIDE, abr, r, dt, f);
   } else {
-    const float* o1 = L.pt + sphere_slot(m, nbx, jp, kd) * PT_STRIDE;
-    const float* o2 = L.pt + sphere_slot(m, nbx, jp + 1, kd) * PT_STRIDE;
+    const float* o1 = L.pt + sphere_slot(Q, jp, kd) * PT_STRIDE;
+    const float* o2 = L.pt + sphere_slot(Q, jp + 1, kd) * PT_STRIDE;
     const float r1[3] = {o1[PT_R], o1[PT_R + 1], o1[PT_R + 2]}, r2[3] = {o2[PT_R], o2[PT_R + 1], o2[PT_R + 2]};
     float f1[3], f2[3];
     pair_force_joint(joint_record(m, L, kd), abr, r1, r2, dt, f1, f2);
@@ -700,38 +718,38 @@ DEV void sphere_pair_force(const ShfModel* m, const EnvLds& L, int nbx, int si, 
 // slots, in the same order as the plain nested loops (ascending bit index = loop order), instead of paying one
 // LDS round trip per slot to find out that almost all of them are idle.
 #define BOX_T (SHF_MAX_BOXES + 1)
-DEV unsigned long long corner_flags(const ShfModel* m, const EnvLds& L, int nbx, int kd) {   // bit c * BOX_T + tg
+DEV unsigned long long corner_flags(const ShfModel* m, const EnvLds& L, const SlotLay& Q, int kd) {   // bit c * BOX_T + tg
   unsigned long long bits = 0ull;
 #pragma unroll
   for (int c = 0; c < 8; c++)
 #pragma unroll
     for (int tg = 0; tg < BOX_T; tg++) {
-      const bool ok = tg <= nbx;
-      const float f = L.pt[corner_slot(m, nbx, kd, c, ok ? tg : 0) * PT_STRIDE + PT_ON];
+      const bool ok = tg <= Q.nbx;
+      const float f = L.pt[corner_slot(Q, kd, c, ok ? tg : 0) * PT_STRIDE + PT_ON];
       if (ok && f != 0.0f) bits |= 1ull << (c * BOX_T + tg);
     }
   return bits;
 }
-DEV unsigned box_sphere_flags(const ShfModel* m, const EnvLds& L, int nbx, int kd) {   // bit si
+DEV unsigned box_sphere_flags(const ShfModel* m, const EnvLds& L, const SlotLay& Q, int kd) {   // bit si
   unsigned bits = 0u;
 #pragma unroll
   for (int si = 0; si < SHF_MAX_SPHERES; si++) {
     const bool ok = si < m->nsph;
-    const float f = L.pt[sphere_slot(m, nbx, ok ? si : 0, kd) * PT_STRIDE + PT_ON];
+    const float f = L.pt[sphere_slot(Q, ok ? si : 0, kd) * PT_STRIDE + PT_ON];
     if (ok && f != 0.0f) bits |= 1u << si;
   }
   return bits;
 }
 // spheres of the articulation: bit si * SHF_MAX_BOXES + kd, restricted to spheres with owner[si] == l
-DEV unsigned body_sphere_flags(const ShfModel* m, const EnvLds& L, int nbx, int l, bool by_dyn) {
+DEV unsigned body_sphere_flags(const ShfModel* m, const EnvLds& L, const SlotLay& Q, int l, bool by_dyn) {
   unsigned bits = 0u;
 #pragma unroll
   for (int si = 0; si < SHF_MAX_SPHERES; si++) {
     const bool mine = si < m->nsph && (by_dyn ? m->dyn[m->sph_body[si]] : m->sph_body[si]) == l;
 #pragma unroll
     for (int kd = 0; kd < SHF_MAX_BOXES; kd++) {
-      const bool ok = mine && kd < nbx;
-      const float f = L.pt[sphere_slot(m, nbx, ok ? si : 0, ok ? kd : 0) * PT_STRIDE + PT_ON];
+      const bool ok = mine && ((Q.dynmask >> kd) & 1u) != 0u;   // only free boxes own sphere slots
+      const float f = L.pt[sphere_slot(Q, ok ? si : 0, ok ? kd : 0) * PT_STRIDE + PT_ON];
       if (ok && f != 0.0f) bits |= 1u << (si * SHF_MAX_BOXES + kd);
     }
   }
@@ -753,134 +771,269 @@ DEV int link_slots_on_box(const EnvLds& L, int link_slot0, int nlink, int kd) {
   for (int k = 0; k < nlink; k++) c += link_code_box(L.pt[(link_slot0 + k) * PT_STRIDE + PT_ON]) == kd ? 1 : 0;
   return c;
 }
+// Candidates pair by pair (reported body ascending, box actor ascending; oracle boxes_pre "link contacts"); within a pair
+// three homogeneous passes -- (A) the body's sample points, (C) its rounded shapes when the box is fixed, (B) the box's
+// corners in the body's volumes -- one lane per candidate and round.
+// Stage 0, the broad phase: one lane per body, its bounding box (ShfModel.bbox) against every box actor, two oriented
+// boxes tested along their six face normals; a pair separated by more than the contact offset (+ 1 cm) has no active
+// candidate in any family -- every shape of the body lies inside its box, and a corner of the box actor inside one of the
+// body's volumes lies inside it too -- and is skipped without touching the order of what is left.
+struct LinkCtx {
+  const StepCtx& C; const EnvLds& L;
+  int l, lane0, slot0, count;
+  unsigned long long gmask, below;
+  float mu_shape; const float* g_art;
+};
+// append the lanes' active slots, in lane order
+DEV void link_append(LinkCtx& X, const float* slot, int body, int box) {
+  const bool on = slot[PT_ON] != 0.0f;
+  const unsigned long long mask = (__ballot(on) >> X.lane0) & X.gmask;
+  const int mine = X.count + __builtin_popcountll(mask & X.below);
+  if (on && mine < SHF_MAX_LINK_CONTACTS) {
+    float* o = X.L.pt + (X.slot0 + mine) * PT_STRIDE;
+#pragma unroll
+    for (int k = 0; k < PT_STRIDE - 1; k++) o[k] = slot[k];
+    o[PT_ON] = (float)link_code(body, box);
+  }
+  X.count += __builtin_popcountll(mask);
+}
 template <int G>
 DEV int link_contacts(const StepCtx& C, const EnvLds& L, int l, int slot0, float mu_shape, const float* g_art) {
   const ShfModel* m = C.m;
   const SceneDev* S = C.scene;
-  const int nb = m->nb, nbx = S->nboxes, np = m->np, nsph = m->nsph, nabox = m->nabox;
+  const int nb = m->nb, nbx = S->nboxes;
   const float dt = C.sp.dt, kc = C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
   const float offset = C.sp.contact_offset;
   const float beta = fmaf(kc, dt, C.sp.contact_d);
   const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
-  const int lane0 = (int)(threadIdx.x & 63u) - l;
-  const unsigned long long gmask = G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
-  const int nA = np * nbx, nC = nsph * nbx, nB = nbx * 8 * nabox, ncand = nA + nC + nB;
-  int count = 0;
-  for (int j = 0; j * G < ncand; j++) {
-    const int p = l + j * G;
-    float slot[PT_STRIDE];
-    slot[PT_ON] = 0.0f;
-    int body = 0, box = 0;
-    if (p < ncand) {
-      if (p < nA + nC) {
-        // a rounded shape of the articulation (a sample point: segment 0) against box kd
-        const bool isA = p < nA;
-        const int q = isA ? p : p - nA;
-        const int sh = q / nbx, kd = q % nbx;
-        const ShfBoxDesc& bd = S->box[kd];
-        const bool dynb = box_is_dynamic(bd);
-        body = isA ? m->pt_body[sh] : m->sph_body[sh];
-        box = kd;
-        if (isA || !dynb) {
-          const float* pb = L.pose + body * POSE_STRIDE;
-          const float* pk = L.pose + (nb + kd) * POSE_STRIDE;
-          const float* qa = L.pose + m->dyn[body] * POSE_STRIDE;
-          float Rb[9], Rk[9], c[3], sw[3];
+  PHASE_BEGIN();
+  LinkCtx X = {C, L, l, (int)(threadIdx.x & 63u) - l, slot0, 0, G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull), (1ull << l) - 1ull,
+               mu_shape, g_art};
+  // (0) live: bit kd * 32 + b = body b may touch box kd.  (Run-time loops over the boxes here and below: unrolled four
+  // times this function alone was 50 KB of code, and the step kernels already overflow the 64 KB instruction cache.)
+  static_assert(SHF_MAX_BOXES * 32 <= 128 && SHF_MAX_BODIES <= 32, "live-pair masks");
+  unsigned long long live[2] = {0ull, 0ull};
+  for (int j = 0; j * G < nb; j++) {
+    const int b = l + j * G;
+    const bool has = b < nb && m->bbox[b][3] >= 0.0f;
+    // the body's box (columns of Rb, centre ca, half extents ha) against box actor kd (columns of Rk, pk, hk):
+    // separated along a face normal of either by more than the margin?
+    const float* pb = L.pose + (has ? b : 0) * POSE_STRIDE;
+    float Rb[9], ca[3];
 #pragma unroll
-          for (int i = 0; i < 9; i++) { Rb[i] = pb[i]; Rk[i] = pk[i]; }
-          const float lp[3] = {isA ? m->pt_pos[sh][0] : m->sph_pos[sh][0], isA ? m->pt_pos[sh][1] : m->sph_pos[sh][1],
-                               isA ? m->pt_pos[sh][2] : m->sph_pos[sh][2]};
-          const float ls[3] = {isA ? 0.0f : m->sph_seg[sh][0], isA ? 0.0f : m->sph_seg[sh][1], isA ? 0.0f : m->sph_seg[sh][2]};
-          const float rad = isA ? m->pt_radius[sh] : m->sph_radius[sh];
-          const float hh[3] = {0.5f * bd.dim[0], 0.5f * bd.dim[1], 0.5f * bd.dim[2]}, bpos[3] = {pk[9], pk[10], pk[11]};
+    for (int i = 0; i < 9; i++) Rb[i] = pb[i];
+    const float* bx = m->bbox[has ? b : 0];
+    const float lc[3] = {bx[0], bx[1], bx[2]}, ha[3] = {bx[3], bx[4], bx[5]};
+    mv3(Rb, lc, ca);
+#pragma unroll
+    for (int i = 0; i < 3; i++) ca[i] += pb[9 + i];
+    const float margin = offset + 0.01f;
+#pragma unroll 1
+    for (int kd = 0; kd < nbx; kd++) {
+      const float* pk = L.pose + (nb + kd) * POSE_STRIDE;
+      const ShfBoxDesc& bd = S->box[kd];
+      const float hk[3] = {0.5f * bd.dim[0], 0.5f * bd.dim[1], 0.5f * bd.dim[2]};
+      const float t[3] = {pk[9] - ca[0], pk[10] - ca[1], pk[11] - ca[2]};
+      float Rq[3][3];   // |a_i . b_j|
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int jj = 0; jj < 3; jj++) Rq[i][jj] = fabsf(fmaf(Rb[6 + i], pk[6 + jj], fmaf(Rb[3 + i], pk[3 + jj], Rb[i] * pk[jj])));
+      bool apart = false;
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const float ta = fabsf(fmaf(Rb[6 + i], t[2], fmaf(Rb[3 + i], t[1], Rb[i] * t[0])));
+        const float ra = ha[i] + fmaf(hk[2], Rq[i][2], fmaf(hk[1], Rq[i][1], hk[0] * Rq[i][0]));
+        apart = apart || ta > (ra + margin) * 1.0001f;
+        const float tb = fabsf(fmaf(pk[6 + i], t[2], fmaf(pk[3 + i], t[1], pk[i] * t[0])));
+        const float rb = hk[i] + fmaf(ha[2], Rq[2][i], fmaf(ha[1], Rq[1][i], ha[0] * Rq[0][i]));
+        apart = apart || tb > (rb + margin) * 1.0001f;
+      }
+      const unsigned long long near = ((__ballot(has && !apart) >> X.lane0) & X.gmask) << (j * G + (kd & 1) * 32);
+      if (kd < 2) live[0] |= near; else live[1] |= near;
+    }
+  }
+  if (m->bounds_ok != SHF_BOUNDS_MAGIC) live[0] = live[1] = ~0ull;   // (cannot happen through shf_sim_bind) test every pair
+  // the pairs some env group of this wavefront has to look at: the loops below are wave-uniform
+  unsigned long long any[2];
+#pragma unroll
+  for (int w = 0; w < 2; w++) {
+    unsigned lo = (unsigned)live[w], hi = (unsigned)(live[w] >> 32);
+    if (G < 64) {
+#pragma unroll
+      for (int sh = G; sh < 64; sh <<= 1) { lo |= (unsigned)__shfl_xor((int)lo, sh, 64); hi |= (unsigned)__shfl_xor((int)hi, sh, 64); }
+    }
+    any[w] = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)lo) |
+             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)hi) << 32);
+  }
+#ifdef SHF_PHASE_CLOCK
+  if (blockIdx.x == 0 && threadIdx.x == 0) {   // tools/phase_clock.py --link: live pairs of this wavefront / of its first env, calls
+    g_phase_cycles[29] += __builtin_popcountll(any[0]) + __builtin_popcountll(any[1]);
+    g_phase_cycles[30] += __builtin_popcountll(live[0]) + __builtin_popcountll(live[1]);
+    g_phase_cycles[31] += 1;
+  }
+#endif
+  PHASE_MARK(24);
+#pragma unroll 1
+  for (int b = 0; b < nb; b++) {
+#pragma unroll 1
+    for (int kd = 0; kd < nbx; kd++) {
+      const int bit = (kd & 1) * 32 + b;
+      if (!(((kd < 2 ? any[0] : any[1]) >> bit) & 1ull)) continue;
+      const bool mine = ((kd < 2 ? live[0] : live[1]) >> bit) & 1ull;
+      const ShfBoxDesc& bd = S->box[kd];
+      const bool dynb = box_is_dynamic(bd);
+      const float* pb = L.pose + b * POSE_STRIDE;
+      const float* pk = L.pose + (nb + kd) * POSE_STRIDE;
+      const float* qa = L.pose + m->dyn[b] * POSE_STRIDE;
+      float Rb[9], Rk[9];
+#pragma unroll
+      for (int i = 0; i < 9; i++) { Rb[i] = pb[i]; Rk[i] = pk[i]; }
+      const float hh[3] = {0.5f * bd.dim[0], 0.5f * bd.dim[1], 0.5f * bd.dim[2]}, bpos[3] = {pk[9], pk[10], pk[11]};
+      const float va[3] = {qa[12], qa[13], qa[14]}, vla[3] = {qa[15], qa[16], qa[17]};
+      const float vbx[3] = {pk[12], pk[13], pk[14]}, vlb[3] = {pk[15], pk[16], pk[17]};
+      const float mu_pair = 0.5f * (mu_shape + bd.friction);
+      const float hdiag = sqrtf(dot3(hh, hh));
+      const int p0 = m->lc_range[b][0], pn = m->lc_range[b][1], a0 = m->lc_range[b][2], an = m->lc_range[b][3];
+      PHASE_MARK(25);
+      // (A) the body's sample points against the box, each a sphere
+      for (int j = 0; j * G < pn; j++) {
+        const int q = l + j * G;
+        float slot[PT_STRIDE];
+        slot[PT_ON] = 0.0f;
+        if (mine && q < pn) {
+          const int i = m->lc_pt[p0 + q];
+          const float lp[3] = {m->pt_pos[i][0], m->pt_pos[i][1], m->pt_pos[i][2]}, rad = m->pt_radius[i];
+          float c[3];
           mv3(Rb, lp, c);
 #pragma unroll
-          for (int i = 0; i < 3; i++) c[i] += pb[9 + i];
-          mv3(Rb, ls, sw);
-          const float rel[3] = {fmaf(0.5f, sw[0], c[0]) - bpos[0], fmaf(0.5f, sw[1], c[1]) - bpos[1], fmaf(0.5f, sw[2], c[2]) - bpos[2]};
-          const float reach = 0.5f * sqrtf(dot3(sw, sw)) + sqrtf(dot3(hh, hh)) + rad + offset + 0.01f;
-          bool exists = !(dot3(rel, rel) > reach * reach);
-          if (exists && (ls[0] != 0.0f || ls[1] != 0.0f || ls[2] != 0.0f)) {
-            float t = 0.0f;
-            exists = segment_box_contact(Rk, bpos, hh, c, sw, m->sph_part[sh], &t);   // part 1: only for a line contact
+          for (int k = 0; k < 3; k++) c[k] += pb[9 + k];
+          const float rel[3] = {c[0] - bpos[0], c[1] - bpos[1], c[2] - bpos[2]};
+          const float reach = hdiag + rad + offset + 0.01f;       // oracle: rounded_far with a zero segment
+          // squared distance from the box, a centimetre of slack: a point further away than its radius + the contact offset
+          // has a gap > offset, slot_eval would switch it off -- the expensive part (square root, normal, velocities) is skipped
+          float d2 = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 3; i++) c[i] = fmaf(t, sw[i], c[i]);
+          for (int k = 0; k < 3; k++) {
+            const float d = fmaf(Rk[6 + k], rel[2], fmaf(Rk[3 + k], rel[1], Rk[k] * rel[0]));
+            const float e = rmaxf(fabsf(d) - hh[k], 0.0f);
+            d2 = fmaf(e, e, d2);
           }
-          if (exists) {
+          const float rs = rad + offset + 0.01f;
+          if (!(dot3(rel, rel) > reach * reach) && !(d2 > rs * rs * 1.0001f)) {
             float phi, n[3], rc[3], ta[3], tb[3], vrel[3], vrs[3];
             sphere_vs_box(Rk, bpos, hh, c, rad, &phi, n, rc);
-            const float va[3] = {qa[12], qa[13], qa[14]}, vbx[3] = {pk[12], pk[13], pk[14]};
-            cross3(va, rc, ta);
-            cross3(vbx, rc, tb);
+            if (phi < offset) {                    // (slot_eval's own first test: further away the slot is off)
+              cross3(va, rc, ta);
+              cross3(vbx, rc, tb);
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
-              const float pa = qa[15 + i] + ta[i];
-              if (isA) {
-                const float pq = pk[15 + i] + tb[i];
-                vrs[i] = pa - pq;
-                vrel[i] = fmaf(dt, g_art[i], pa) - (dynb ? fmaf(dt, gb[i], pq) : pq);
-              } else {                       // (C): the box is fixed, the relative velocity is the articulation point's own
-                vrs[i] = pa;
-                vrel[i] = fmaf(dt, g_art[i], pa);
+              for (int k = 0; k < 3; k++) {
+                const float pa = vla[k] + ta[k], pq = vlb[k] + tb[k];
+                vrs[k] = pa - pq;
+                vrel[k] = fmaf(dt, g_art[k], pa) - (dynb ? fmaf(dt, gb[k], pq) : pq);
               }
+              slot_eval(slot, phi, n, rc, vrs, vrel, mu_pair, kc, beta, veps, vdep, dt, offset);
             }
-            slot_eval(slot, phi, n, rc, vrs, vrel, 0.5f * (mu_shape + bd.friction), kc, beta, veps, vdep, dt, offset);
           }
         }
-      } else {
-        // (B) corner cn of box kd inside the articulation's box volume jb
-        const int q = p - nA - nC;
-        const int kd = q / (8 * nabox), cn = (q / nabox) % 8, jb = q % nabox;
-        const ShfBoxDesc& bd = S->box[kd];
-        const bool dynb = box_is_dynamic(bd);
-        body = m->abox_body[jb];
-        box = kd;
-        const float* pb = L.pose + body * POSE_STRIDE;
-        const float* pk = L.pose + (nb + kd) * POSE_STRIDE;
-        const float* qa = L.pose + m->dyn[body] * POSE_STRIDE;
-        float Rb[9], Rk[9], lr[9], ar[9], ac[3], r[3], tb[3];
-#pragma unroll
-        for (int i = 0; i < 9; i++) { Rb[i] = pb[i]; Rk[i] = pk[i]; lr[i] = m->abox_rot[jb][i]; }
-        const float lc[3] = {((cn & 4) ? 0.5f : -0.5f) * bd.dim[0], ((cn & 2) ? 0.5f : -0.5f) * bd.dim[1],
-                             ((cn & 1) ? 0.5f : -0.5f) * bd.dim[2]};
-        mv3(Rk, lc, r);
-#pragma unroll
-        for (int i = 0; i < 3; i++) r[i] += pk[9 + i];
-        const float vbx[3] = {pk[12], pk[13], pk[14]};
-        cross3(vbx, r, tb);
-        const float lp[3] = {m->abox_pos[jb][0], m->abox_pos[jb][1], m->abox_pos[jb][2]};
-        const float hh[3] = {m->abox_half[jb][0], m->abox_half[jb][1], m->abox_half[jb][2]};
-        mm3(Rb, lr, ar);
-        mv3(Rb, lp, ac);
-#pragma unroll
-        for (int i = 0; i < 3; i++) ac[i] += pb[9 + i];
-        float phi, n[3];
-        if (point_in_box(ar, ac, hh, r, &phi, n)) {
-          const float va[3] = {qa[12], qa[13], qa[14]};
-          float ta[3], nn[3], vrel[3], vrs[3];
-          cross3(va, r, ta);
-#pragma unroll
-          for (int i = 0; i < 3; i++) {
-            const float pa = qa[15 + i] + ta[i], pq = pk[15 + i] + tb[i];
-            nn[i] = -n[i];
-            vrs[i] = pa - pq;
-            vrel[i] = fmaf(dt, g_art[i], pa) - (dynb ? fmaf(dt, gb[i], pq) : pq);
-          }
-          slot_eval(slot, phi, nn, r, vrs, vrel, 0.5f * (mu_shape + bd.friction), kc, beta, veps, vdep, dt, offset);
-        }
+        if (__ballot(slot[PT_ON] != 0.0f) != 0ull) link_append(X, slot, b, kd);
       }
-    }
-    const bool on = slot[PT_ON] != 0.0f;
-    const unsigned long long mask = (__ballot(on) >> lane0) & gmask;
-    const int mine = count + __builtin_popcountll(mask & ((1ull << l) - 1ull));
-    if (on && mine < SHF_MAX_LINK_CONTACTS) {
-      float* o = L.pt + (slot0 + mine) * PT_STRIDE;
+      PHASE_MARK(26);
+      // (C) its rounded shapes against a fixed box (a free box has the pair slots)
+      if (!dynb && m->nsph > 0) {
+        static_assert(SHF_MAX_SPHERES <= 16, "one round of rounded shapes");
+        float slot[PT_STRIDE];
+        slot[PT_ON] = 0.0f;
+        if (mine && l < m->nsph && m->sph_body[l] == b) {
+          const int si = l;
+          const float lp[3] = {m->sph_pos[si][0], m->sph_pos[si][1], m->sph_pos[si][2]};
+          const float ls[3] = {m->sph_seg[si][0], m->sph_seg[si][1], m->sph_seg[si][2]}, rad = m->sph_radius[si];
+          float c[3], sw[3];
+          mv3(Rb, lp, c);
 #pragma unroll
-      for (int k = 0; k < PT_STRIDE - 1; k++) o[k] = slot[k];
-      o[PT_ON] = (float)link_code(body, box);
+          for (int k = 0; k < 3; k++) c[k] += pb[9 + k];
+          mv3(Rb, ls, sw);
+          const float rel[3] = {fmaf(0.5f, sw[0], c[0]) - bpos[0], fmaf(0.5f, sw[1], c[1]) - bpos[1], fmaf(0.5f, sw[2], c[2]) - bpos[2]};
+          const float reach = 0.5f * sqrtf(dot3(sw, sw)) + hdiag + rad + offset + 0.01f;
+          bool exists = !(dot3(rel, rel) > reach * reach);
+          if (exists) {
+            // not in the oracle, and no need to be: the shape's bounding sphere (centre: the middle of its segment) further
+            // from the box than its radius + the contact offset + 1 cm means a gap > offset wherever the closest point is
+            float d2 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+              const float d = fmaf(Rk[6 + k], rel[2], fmaf(Rk[3 + k], rel[1], Rk[k] * rel[0]));
+              const float e = rmaxf(fabsf(d) - hh[k], 0.0f);
+              d2 = fmaf(e, e, d2);
+            }
+            const float rs = 0.5f * sqrtf(dot3(sw, sw)) + rad + offset + 0.01f;
+            exists = !(d2 > rs * rs * 1.0001f);
+          }
+          if (exists && (ls[0] != 0.0f || ls[1] != 0.0f || ls[2] != 0.0f)) {
+            float t = 0.0f;
+            exists = segment_box_contact(Rk, bpos, hh, c, sw, m->sph_part[si], &t);   // part 1: only for a line contact
+#pragma unroll
+            for (int k = 0; k < 3; k++) c[k] = fmaf(t, sw[k], c[k]);
+          }
+          if (exists) {
+            float phi, n[3], rc[3], ta[3], vrel[3], vrs[3];
+            sphere_vs_box(Rk, bpos, hh, c, rad, &phi, n, rc);
+            cross3(va, rc, ta);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { vrs[k] = vla[k] + ta[k]; vrel[k] = fmaf(dt, g_art[k], vrs[k]); }   // the box does not move
+            slot_eval(slot, phi, n, rc, vrs, vrel, mu_pair, kc, beta, veps, vdep, dt, offset);
+          }
+        }
+        if (__ballot(slot[PT_ON] != 0.0f) != 0ull) link_append(X, slot, b, kd);
+      }
+      PHASE_MARK(27);
+      // (B) the box's corners inside the body's volumes: candidate q = volume * 8 + corner
+      for (int j = 0; j * G < an * 8; j++) {
+        const int q = l + j * G;
+        float slot[PT_STRIDE];
+        slot[PT_ON] = 0.0f;
+        if (mine && q < an * 8) {
+          const int jb = m->lc_abox[a0 + (q >> 3)], cn = q & 7;
+          float lr[9], ar[9], ac[3], r[3], tb[3];
+          const float lc[3] = {((cn & 4) ? 0.5f : -0.5f) * bd.dim[0], ((cn & 2) ? 0.5f : -0.5f) * bd.dim[1],
+                               ((cn & 1) ? 0.5f : -0.5f) * bd.dim[2]};
+          mv3(Rk, lc, r);
+#pragma unroll
+          for (int k = 0; k < 3; k++) r[k] += bpos[k];
+          const float lp[3] = {m->abox_pos[jb][0], m->abox_pos[jb][1], m->abox_pos[jb][2]};
+          const float ah[3] = {m->abox_half[jb][0], m->abox_half[jb][1], m->abox_half[jb][2]};
+          mv3(Rb, lp, ac);
+#pragma unroll
+          for (int k = 0; k < 3; k++) ac[k] += pb[9 + k];
+          const float rel[3] = {r[0] - ac[0], r[1] - ac[1], r[2] - ac[2]};
+          float phi, n[3];
+          bool inside = !(dot3(rel, rel) > fmaf(dot3(ah, ah), 1.01f, 1e-8f));   // outside the volume's bounding sphere: outside the volume
+          if (inside) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) lr[k] = m->abox_rot[jb][k];
+            mm3(Rb, lr, ar);
+            inside = point_in_box(ar, ac, ah, r, &phi, n);
+          }
+          if (inside) {
+            float ta[3], nn[3], vrel[3], vrs[3];
+            cross3(vbx, r, tb);
+            cross3(va, r, ta);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+              const float pa = vla[k] + ta[k], pq = vlb[k] + tb[k];
+              nn[k] = -n[k];
+              vrs[k] = pa - pq;
+              vrel[k] = fmaf(dt, g_art[k], pa) - (dynb ? fmaf(dt, gb[k], pq) : pq);
+            }
+            slot_eval(slot, phi, nn, r, vrs, vrel, mu_pair, kc, beta, veps, vdep, dt, offset);
+          }
+        }
+        if (__ballot(slot[PT_ON] != 0.0f) != 0ull) link_append(X, slot, b, kd);
+      }
+      PHASE_MARK(28);
     }
-    count += __builtin_popcountll(mask);
   }
+  int count = X.count;
   if (count > SHF_MAX_LINK_CONTACTS) {
     if (l == 0 && C.dropped) *C.dropped += count - SHF_MAX_LINK_CONTACTS;
     count = SHF_MAX_LINK_CONTACTS;
@@ -944,6 +1097,7 @@ DEV void fixed_corner_slots(const StepCtx& C, const EnvLds& L, int l, BoxMasks& 
   typedef FixedSceneConsts<G, SC> F;
   constexpr int nbx = F::nbx, kd = F::kd, NO = F::NO, NBS = F::NBS;
   const ShfModel* m = C.m;
+  const SlotLay Q = slot_lay<SC>(m, C.scene);
   const SceneDev* S = C.scene;
   const int nb = m->nb;
   const float dt = C.sp.dt, kc = C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
@@ -978,7 +1132,7 @@ DEV void fixed_corner_slots(const StepCtx& C, const EnvLds& L, int l, BoxMasks& 
     const int ks = t + (t >= kd ? 1 : 0);
     bool on = false;
     if (valid) {
-      float* o = L.pt + corner_slot(m, nbx, kd, c, 1 + ks) * PT_STRIDE;
+      float* o = L.pt + corner_slot(Q, kd, c, 1 + ks) * PT_STRIDE;
       o[PT_ON] = 0.0f;
       float r[3], vs[3], vp[3], n[3], phi;
       corner_place(c, r, vs, vp);
@@ -998,8 +1152,8 @@ DEV void fixed_corner_slots(const StepCtx& C, const EnvLds& L, int l, BoxMasks& 
     const bool valid = l < 8;
     bool on = false;
     if (valid) {
-      float* o = L.pt + corner_slot(m, nbx, kd, l, 0) * PT_STRIDE;
-      L.pt[corner_slot(m, nbx, kd, l, 1 + kd) * PT_STRIDE + PT_ON] = 0.0f;   // the box against itself: never a contact
+      float* o = L.pt + corner_slot(Q, kd, l, 0) * PT_STRIDE;
+      L.pt[corner_slot(Q, kd, l, 1 + kd) * PT_STRIDE + PT_ON] = 0.0f;   // the box against itself: never a contact
       const float reach = 0.5f * sqrtf(fmaf(bd.dim[2], bd.dim[2], fmaf(bd.dim[1], bd.dim[1], bd.dim[0] * bd.dim[0])));
       // 1 % and a millimetre over the exact bound (the corner's own rounding cannot bridge it)
       const bool clear = C.terr.t.rows == 0 && (L.root[2] + pcen[2]) - reach * 1.01f - 1e-3f > offset;
@@ -1023,6 +1177,7 @@ DEV void fixed_sphere_slots(const StepCtx& C, const EnvLds& L, int l, float mu_s
   typedef FixedSceneConsts<G, SC> F;
   constexpr int nbx = F::nbx, kd = F::kd;
   const ShfModel* m = C.m;
+  const SlotLay Q = slot_lay<SC>(m, C.scene);
   const int nb = m->nb;
   const float dt = C.sp.dt, kc = C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
   const float offset = C.sp.contact_offset;
@@ -1032,7 +1187,7 @@ DEV void fixed_sphere_slots(const StepCtx& C, const EnvLds& L, int l, float mu_s
   const float* pk = L.pose + (nb + kd) * POSE_STRIDE;
   const bool valid = l < SC::NSPH;
   const int si = valid ? l : 0;
-  float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
+  float* o = L.pt + sphere_slot(Q, si, kd) * PT_STRIDE;
   bool on = false;
   if (valid) {
     const int b = m->sph_body[si];
@@ -1066,94 +1221,133 @@ template <int G, class SC>
 DEV void fixed_box_fold(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, const BoxMasks& BM) {
   typedef FixedSceneConsts<G, SC> F;
   const ShfModel* m = C.m;
+  const SlotLay Q = slot_lay<SC>(m, C.scene);
   if (l == m->nb + F::kd) {
     unsigned pl = BM.cplane;
     unsigned long long bx = BM.cbox;
     int c, tg;
     while (corner_next<F::NO, F::kd>(pl, bx, &c, &tg))
-      slot_accumulate(B.IA, B.pA, L.pt + corner_slot(m, F::nbx, F::kd, c, tg) * PT_STRIDE, 1.0f, C.sp.dt, 1.0f);
+      slot_accumulate(B.IA, B.pA, L.pt + corner_slot(Q, F::kd, c, tg) * PT_STRIDE, 1.0f, C.sp.dt, 1.0f);
   }
 }
 // ... then the consistent law of every active pair slot (pair_law) into the pair records, by the lane `mine` that holds
 // (or has read) the box's folded (IA, pA)
 template <int G, class SC>
-DEV void fixed_pair_laws(const StepCtx& C, const EnvLds& L, bool mine, const float* IA, const float* pA, unsigned spheres) {
+DEV void fixed_pair_laws(const StepCtx& C, const EnvLds& L, bool mine, const float* IA, const float* pA, unsigned spheres,
+                         unsigned lb = 0u, int link_slot0 = 0) {
   typedef FixedSceneConsts<G, SC> F;
   const ShfModel* m = C.m;
+  const SlotLay Q = slot_lay<SC>(m, C.scene);
   if (mine) {
     unsigned sb = spheres;
-    const int jp = box_joint_pair(m, L, F::nbx, F::kd, sb, 0);
+    const int jp = box_joint_pair(m, L, Q, F::kd, sb, __builtin_popcount(lb));
     if (jp >= 0) {                                // the two ends of one capsule: eliminated together
       float afree[6];
       Ldlt6 FIA;
       ldlt_factor6(IA, FIA);
       ldlt_substitute6(FIA, pA, afree);
-      pair_law_joint(FIA, afree, L.pt + sphere_slot(m, F::nbx, jp, F::kd) * PT_STRIDE, L.pt + sphere_slot(m, F::nbx, jp + 1, F::kd) * PT_STRIDE,
+      pair_law_joint(FIA, afree, L.pt + sphere_slot(Q, jp, F::kd) * PT_STRIDE, L.pt + sphere_slot(Q, jp + 1, F::kd) * PT_STRIDE,
                      C.sp.dt, joint_record(m, L, F::kd));
-    } else if (sb) {
+    } else if (sb || lb) {
       float afree[6];
       Ldlt6 FIA;
       ldlt_factor6(IA, FIA);
       ldlt_substitute6(FIA, pA, afree);
-      const float nshare = (float)__builtin_popcount(sb);
+      const float nshare = (float)(__builtin_popcount(sb) + __builtin_popcount(lb));
       float rsum[3] = {0.0f, 0.0f, 0.0f};
       for (unsigned bb = sb; bb; bb &= bb - 1u) {
-        const float* o = L.pt + sphere_slot(m, F::nbx, __builtin_ctz(bb), F::kd) * PT_STRIDE;
+        const float* o = L.pt + sphere_slot(Q, __builtin_ctz(bb), F::kd) * PT_STRIDE;
+#pragma unroll
+        for (int i = 0; i < 3; i++) rsum[i] += o[PT_R + i];
+      }
+      for (unsigned bb = lb; bb; bb &= bb - 1u) {
+        const float* o = L.pt + (link_slot0 + __builtin_ctz(bb)) * PT_STRIDE;
 #pragma unroll
         for (int i = 0; i < 3; i++) rsum[i] += o[PT_R + i];
       }
       while (sb) {
         const int si = __builtin_ctz(sb);
         sb &= sb - 1u;
-        pair_law(FIA, afree, L.pt + sphere_slot(m, F::nbx, si, F::kd) * PT_STRIDE, C.sp.dt,
-                 L.pt + pair_slot(m, F::nbx, si, F::kd) * PT_STRIDE, rsum, nshare);
+        pair_law(FIA, afree, L.pt + sphere_slot(Q, si, F::kd) * PT_STRIDE, C.sp.dt,
+                 L.pt + pair_slot(Q, si, F::kd) * PT_STRIDE, rsum, nshare);
+      }
+      while (lb) {                                // the link contacts on the free box, slot order
+        const int k = __builtin_ctz(lb);
+        lb &= lb - 1u;
+        pair_law(FIA, afree, L.pt + (link_slot0 + k) * PT_STRIDE, C.sp.dt, L.pt + (link_slot0 + SHF_MAX_LINK_CONTACTS + k) * PT_STRIDE, rsum, nshare);
       }
     }
   }
 }
 // after the hand-off the articulation's lanes fold their pair records, shapes ascending
 template <int G, class SC>
-DEV void fixed_arm_fold(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, const BoxLane& BL, unsigned spheres) {
+DEV void fixed_arm_fold(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, const BoxLane& BL, unsigned spheres,
+                        int nlink = 0, unsigned lb = 0u, int link_slot0 = 0) {
   typedef FixedSceneConsts<G, SC> F;
   const ShfModel* m = C.m;
+  const SlotLay Q = slot_lay<SC>(m, C.scene);
   if (l < m->nb && m->dyn[l] == l) {
     unsigned bits = spheres & BL.sph_dyn;
-    const int jp = bits ? box_joint_pair(m, L, F::nbx, F::kd, spheres, 0) : -1;
+    const int jp = bits ? box_joint_pair(m, L, Q, F::kd, spheres, __builtin_popcount(lb)) : -1;
     while (bits) {
       const int si = __builtin_ctz(bits);
       bits &= bits - 1u;
-      const float* o = L.pt + sphere_slot(m, F::nbx, si, F::kd) * PT_STRIDE;
+      const float* o = L.pt + sphere_slot(Q, si, F::kd) * PT_STRIDE;
       const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]};
       if (jp >= 0) {
         if (si == jp) {                           // both ends at once; the second end's bit is skipped
-          const float* o2 = L.pt + sphere_slot(m, F::nbx, jp + 1, F::kd) * PT_STRIDE;
+          const float* o2 = L.pt + sphere_slot(Q, jp + 1, F::kd) * PT_STRIDE;
           const float r2[3] = {o2[PT_R], o2[PT_R + 1], o2[PT_R + 2]};
           pair_accumulate_joint(B.IA, B.pA, r, r2, joint_record(m, L, F::kd), C.sp.dt);
         }
         continue;
       }
       float Fp[3], K[9];
-      pair_unpack(L.pt + pair_slot(m, F::nbx, si, F::kd) * PT_STRIDE, Fp, K);
+      pair_unpack(L.pt + pair_slot(Q, si, F::kd) * PT_STRIDE, Fp, K);
       pair_accumulate(B.IA, B.pA, r, Fp, K, C.sp.dt);
+    }
+    // ... then its link contacts, slot order: the pair law against the free box, the plain contact law against a fixed one
+    for (int k = 0; k < nlink; k++) {
+      const float* o = L.pt + (link_slot0 + k) * PT_STRIDE;
+      if (m->dyn[link_code_body(o[PT_ON])] != l) continue;
+      if ((lb >> k) & 1u) {
+        const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]};
+        float Fp[3], K[9];
+        pair_unpack(L.pt + (link_slot0 + SHF_MAX_LINK_CONTACTS + k) * PT_STRIDE, Fp, K);
+        pair_accumulate(B.IA, B.pA, r, Fp, K, C.sp.dt);
+      } else {
+        slot_accumulate(B.IA, B.pA, o, 1.0f, C.sp.dt, 1.0f);
+      }
     }
   }
 }
-template <int G, class SC>
+// bit k: link slot k sits on box kd
+DEV unsigned link_box_bits(const EnvLds& L, int link_slot0, int nlink, int kd) {
+  unsigned lb = 0u;
+  for (int k = 0; k < nlink; k++)
+    if (link_code_box(L.pt[(link_slot0 + k) * PT_STRIDE + PT_ON]) == kd) lb |= 1u << k;
+  return lb;
+}
+template <int G, class SC, bool LINK = false>
 DEV void boxes_contacts_fixed(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, float mu_shape, const float* g_art,
-                              const BoxLane& BL, BoxMasks& BM) {
+                              const BoxLane& BL, BoxMasks& BM, int link_slot0 = 0) {
   PHASE_BEGIN();
   fixed_corner_slots<G, SC>(C, L, l, BM);
   PHASE_MARK(17);
   fixed_sphere_slots<G, SC>(C, L, l, mu_shape, g_art, BM);
-  GROUP_SYNC();
   PHASE_MARK(18);
+  if constexpr (LINK) BM.nlink = link_contacts<G>(C, L, l, link_slot0, mu_shape, g_art);
+  GROUP_SYNC();
+  PHASE_MARK(19);
+  unsigned lb = 0u;
+  if constexpr (LINK) lb = link_box_bits(L, link_slot0, BM.nlink, SC::DYN);
   fixed_box_fold<G, SC>(C, L, l, B, BM);
   PHASE_MARK(20);
-  fixed_pair_laws<G, SC>(C, L, l == C.m->nb + SC::DYN, B.IA, B.pA, BM.spheres);
+  fixed_pair_laws<G, SC>(C, L, l == C.m->nb + SC::DYN, B.IA, B.pA, BM.spheres, lb, link_slot0);
   PHASE_MARK(21);
   GROUP_SYNC();
   PHASE_MARK(22);
-  fixed_arm_fold<G, SC>(C, L, l, B, BL, BM.spheres);
+  fixed_arm_fold<G, SC>(C, L, l, B, BL, BM.spheres, BM.nlink, lb, link_slot0);
   PHASE_MARK(23);
 }
 
@@ -1161,10 +1355,10 @@ DEV void boxes_contacts_fixed(const StepCtx& C, const EnvLds& L, int l, BodyRegs
 template <int G, class SC, bool LINK = false>
 DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, float mu_shape, const float* g_art,
                         const BoxLane& BL, BoxMasks& BM, int link_slot0 = 0) {
-  static_assert(!(LINK && SC::NBX > 0), "link contacts run on the run-time-shaped scene path");
-  if constexpr (SC::NBX > 0) { boxes_contacts_fixed<G, SC>(C, L, l, B, mu_shape, g_art, BL, BM); return; }
+  if constexpr (SC::NBX > 0) { boxes_contacts_fixed<G, SC, LINK>(C, L, l, B, mu_shape, g_art, BL, BM, link_slot0); return; }
   const ShfModel* m = C.m;
   const SceneDev* S = C.scene;
+  const SlotLay Q = slot_lay<SC>(m, S);
   const int nb = m->nb, nbx = S->nboxes, T = 1 + nbx;
   const float dt = C.sp.dt, kc = C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
   const float offset = C.sp.contact_offset;
@@ -1174,10 +1368,10 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
   // corner slots
   for (int idx = l; idx < nbx * 8 * T; idx += G) {
     const int kd = idx / (8 * T), c = (idx / T) % 8, tg = idx % T;
-    float* o = L.pt + corner_slot(m, nbx, kd, c, tg) * PT_STRIDE;
-    o[PT_ON] = 0.0f;
     const ShfBoxDesc& bd = S->box[kd];
-    if (!box_is_dynamic(bd)) continue;
+    if (!box_is_dynamic(bd)) continue;           // a fixed box owns no slots (SlotLay)
+    float* o = L.pt + corner_slot(Q, kd, c, tg) * PT_STRIDE;
+    o[PT_ON] = 0.0f;
     const float* pk = L.pose + (nb + kd) * POSE_STRIDE;
     float Rk[9], lc[3] = {((c & 4) ? 0.5f : -0.5f) * bd.dim[0], ((c & 2) ? 0.5f : -0.5f) * bd.dim[1],
                           ((c & 1) ? 0.5f : -0.5f) * bd.dim[2]};
@@ -1210,10 +1404,10 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
   // sphere slots
   for (int idx = l; idx < m->nsph * nbx; idx += G) {
     const int si = idx / nbx, kd = idx % nbx;
-    float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
-    o[PT_ON] = 0.0f;
     const ShfBoxDesc& bd = S->box[kd];
     if (!box_is_dynamic(bd)) continue;
+    float* o = L.pt + sphere_slot(Q, si, kd) * PT_STRIDE;
+    o[PT_ON] = 0.0f;
     const int b = m->sph_body[si];
     const float* pb = L.pose + b * POSE_STRIDE;
     const float* pk = L.pose + (nb + kd) * POSE_STRIDE;
@@ -1244,23 +1438,23 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
   // fold (as the fixed-scene path: box lanes first, with the pair laws; then the articulation's lanes)
   const int kd = l - nb;
   if (kd >= 0 && kd < nbx && box_is_dynamic(S->box[kd])) {
-    unsigned long long cb = corner_flags(m, L, nbx, kd);
-    unsigned sb = box_sphere_flags(m, L, nbx, kd);
+    unsigned long long cb = corner_flags(m, L, Q, kd);
+    unsigned sb = box_sphere_flags(m, L, Q, kd);
     while (cb) {
       const int j = __builtin_ctzll(cb);
       cb &= cb - 1ull;
-      slot_accumulate(B.IA, B.pA, L.pt + corner_slot(m, nbx, kd, j / BOX_T, j % BOX_T) * PT_STRIDE, 1.0f, dt, 1.0f);
+      slot_accumulate(B.IA, B.pA, L.pt + corner_slot(Q, kd, j / BOX_T, j % BOX_T) * PT_STRIDE, 1.0f, dt, 1.0f);
     }
     unsigned lb = 0u;     // this box's link contacts (bit k = slot k)
     for (int k = 0; k < nlink; k++)
       if (link_code_box(L.pt[(link_slot0 + k) * PT_STRIDE + PT_ON]) == kd) lb |= 1u << k;
-    const int jp = box_joint_pair(m, L, nbx, kd, sb, __builtin_popcount(lb));
+    const int jp = box_joint_pair(m, L, Q, kd, sb, __builtin_popcount(lb));
     if (jp >= 0) {                                // the two ends of one capsule: eliminated together
       float afree[6];
       Ldlt6 FIA;
       ldlt_factor6(B.IA, FIA);
       ldlt_substitute6(FIA, B.pA, afree);
-      pair_law_joint(FIA, afree, L.pt + sphere_slot(m, nbx, jp, kd) * PT_STRIDE, L.pt + sphere_slot(m, nbx, jp + 1, kd) * PT_STRIDE, dt,
+      pair_law_joint(FIA, afree, L.pt + sphere_slot(Q, jp, kd) * PT_STRIDE, L.pt + sphere_slot(Q, jp + 1, kd) * PT_STRIDE, dt,
                      joint_record(m, L, kd));
     } else if (sb || lb) {
       float afree[6];
@@ -1270,7 +1464,7 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
       const float nshare = (float)(__builtin_popcount(sb) + __builtin_popcount(lb));
       float rsum[3] = {0.0f, 0.0f, 0.0f};
       for (unsigned bb = sb; bb; bb &= bb - 1u) {
-        const float* o = L.pt + sphere_slot(m, nbx, __builtin_ctz(bb), kd) * PT_STRIDE;
+        const float* o = L.pt + sphere_slot(Q, __builtin_ctz(bb), kd) * PT_STRIDE;
 #pragma unroll
         for (int i = 0; i < 3; i++) rsum[i] += o[PT_R + i];
       }
@@ -1282,7 +1476,7 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
       while (sb) {
         const int si = __builtin_ctz(sb);
         sb &= sb - 1u;
-        pair_law(FIA, afree, L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE, dt, L.pt + pair_slot(m, nbx, si, kd) * PT_STRIDE, rsum, nshare);
+        pair_law(FIA, afree, L.pt + sphere_slot(Q, si, kd) * PT_STRIDE, dt, L.pt + pair_slot(Q, si, kd) * PT_STRIDE, rsum, nshare);
       }
       while (lb) {
         const int k = __builtin_ctz(lb);
@@ -1293,23 +1487,23 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
   }
   GROUP_SYNC();
   if (l < nb && m->dyn[l] == l) {
-    unsigned bits = body_sphere_flags(m, L, nbx, l, true);
+    unsigned bits = body_sphere_flags(m, L, Q, l, true);
     while (bits) {
       const int j = __builtin_ctz(bits), si = j / SHF_MAX_BOXES, k2 = j % SHF_MAX_BOXES;
       bits &= bits - 1u;
-      const float* o = L.pt + sphere_slot(m, nbx, si, k2) * PT_STRIDE;
+      const float* o = L.pt + sphere_slot(Q, si, k2) * PT_STRIDE;
       const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]};
-      const int jp = box_joint_pair(m, L, nbx, k2, box_sphere_flags(m, L, nbx, k2), link_slots_on_box(L, link_slot0, nlink, k2));
+      const int jp = box_joint_pair(m, L, Q, k2, box_sphere_flags(m, L, Q, k2), link_slots_on_box(L, link_slot0, nlink, k2));
       if (jp >= 0) {
         if (si == jp) {
-          const float* o2 = L.pt + sphere_slot(m, nbx, jp + 1, k2) * PT_STRIDE;
+          const float* o2 = L.pt + sphere_slot(Q, jp + 1, k2) * PT_STRIDE;
           const float r2[3] = {o2[PT_R], o2[PT_R + 1], o2[PT_R + 2]};
           pair_accumulate_joint(B.IA, B.pA, r, r2, joint_record(m, L, k2), dt);
         }
         continue;
       }
       float F[3], K[9];
-      pair_unpack(L.pt + pair_slot(m, nbx, si, k2) * PT_STRIDE, F, K);
+      pair_unpack(L.pt + pair_slot(Q, si, k2) * PT_STRIDE, F, K);
       pair_accumulate(B.IA, B.pA, r, F, K, dt);
     }
     // ... then its link contacts, slot order: pair law against a free box, the plain contact law against a fixed one
@@ -1353,6 +1547,7 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
                       const BoxMasks& BM, int link_slot0 = 0) {
   const ShfModel* m = C.m;
   const SceneDev* S = C.scene;
+  const SlotLay Q = slot_lay<SC>(m, S);
   const int nb = m->nb, nbx = S->nboxes, T = 1 + nbx;
   const float dt = C.sp.dt;
   const int kd = l - nb;
@@ -1362,15 +1557,15 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
   if ((PART & 1) && dynbox) {
     // the articulation's solved acceleration fixes every pair force; the box receives exactly its opposite, then solves
     unsigned sb;
-    if constexpr (SC::NBX > 0) sb = BM.spheres; else sb = box_sphere_flags(m, L, nbx, kd);
-    const int jp = box_joint_pair(m, L, nbx, kd, sb, SC::NBX > 0 ? 0 : link_slots_on_box(L, link_slot0, BM.nlink, kd));
+    if constexpr (SC::NBX > 0) sb = BM.spheres; else sb = box_sphere_flags(m, L, Q, kd);
+    const int jp = box_joint_pair(m, L, Q, kd, sb, link_slots_on_box(L, link_slot0, BM.nlink, kd));
     while (sb) {
       const int si = __builtin_ctz(sb);
       sb &= sb - 1u;
-      const float* o = L.pt + sphere_slot(m, nbx, si, kd) * PT_STRIDE;
+      const float* o = L.pt + sphere_slot(Q, si, kd) * PT_STRIDE;
       const float r[3] = {o[PT_R], o[PT_R + 1], o[PT_R + 2]};
       float f[3], t[3];
-      sphere_pair_force(m, L, nbx, si, kd, jp, dt, f);
+      sphere_pair_force(m, L, Q, si, kd, jp, dt, f);
       cross3(r, f, t);
 #pragma unroll
       for (int k = 0; k < 3; k++) { B.pA[k] += t[k]; B.pA[3 + k] += f[k]; }
@@ -1398,16 +1593,16 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
         unsigned sb = BM.spheres & BL.sph_body;
         while (sb) { const int si = __builtin_ctz(sb); sb &= sb - 1u; bits |= 1u << (si * SHF_MAX_BOXES + SC::DYN); }
       } else {
-        bits = body_sphere_flags(m, L, nbx, l, false);
+        bits = body_sphere_flags(m, L, Q, l, false);
       }
       while (bits) {
         const int j = __builtin_ctz(bits), si = j / SHF_MAX_BOXES, k2 = j % SHF_MAX_BOXES;
         bits &= bits - 1u;
         unsigned sall;
-        if constexpr (SC::NBX > 0) sall = BM.spheres; else sall = box_sphere_flags(m, L, nbx, k2);
-        const int jp = box_joint_pair(m, L, nbx, k2, sall, SC::NBX > 0 ? 0 : link_slots_on_box(L, link_slot0, BM.nlink, k2));
+        if constexpr (SC::NBX > 0) sall = BM.spheres; else sall = box_sphere_flags(m, L, Q, k2);
+        const int jp = box_joint_pair(m, L, Q, k2, sall, link_slots_on_box(L, link_slot0, BM.nlink, k2));
         float fp[3];
-        sphere_pair_force(m, L, nbx, si, k2, jp, dt, fp);
+        sphere_pair_force(m, L, Q, si, k2, jp, dt, fp);
 #pragma unroll
         for (int k = 0; k < 3; k++) f[k] += fp[k];
       }
@@ -1430,22 +1625,22 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
           int c, tg;
           sb = BM.spheres;
           while (corner_next<SC::NBX - 1, SC::DYN>(pl, bx, &c, &tg))
-            slot_force(L.pt + corner_slot(m, nbx, kd, c, tg) * PT_STRIDE, a, 1.0f, dt, 1.0f, f);
+            slot_force(L.pt + corner_slot(Q, kd, c, tg) * PT_STRIDE, a, 1.0f, dt, 1.0f, f);
         } else {
-          unsigned long long cb = corner_flags(m, L, nbx, kd);
-          sb = box_sphere_flags(m, L, nbx, kd);
+          unsigned long long cb = corner_flags(m, L, Q, kd);
+          sb = box_sphere_flags(m, L, Q, kd);
           while (cb) {
             const int j = __builtin_ctzll(cb);
             cb &= cb - 1ull;
-            slot_force(L.pt + corner_slot(m, nbx, kd, j / BOX_T, j % BOX_T) * PT_STRIDE, a, 1.0f, dt, 1.0f, f);
+            slot_force(L.pt + corner_slot(Q, kd, j / BOX_T, j % BOX_T) * PT_STRIDE, a, 1.0f, dt, 1.0f, f);
           }
         }
-        const int jp_rows = box_joint_pair(m, L, nbx, kd, sb, SC::NBX > 0 ? 0 : link_slots_on_box(L, link_slot0, BM.nlink, kd));
+        const int jp_rows = box_joint_pair(m, L, Q, kd, sb, link_slots_on_box(L, link_slot0, BM.nlink, kd));
         while (sb) {
           const int si = __builtin_ctz(sb);
           sb &= sb - 1u;
           float fp[3];
-          sphere_pair_force(m, L, nbx, si, kd, jp_rows, dt, fp);
+          sphere_pair_force(m, L, Q, si, kd, jp_rows, dt, fp);
 #pragma unroll
           for (int k = 0; k < 3; k++) f[k] -= fp[k];
         }

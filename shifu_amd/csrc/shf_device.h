@@ -320,6 +320,7 @@ struct FixedDims {
 };
 typedef FixedDims<17, 12, 76, 3, 4> A1Dims;  // Unitree A1 as compiled from a1.urdf
 typedef FixedDims<7, 6, 3, 6, 6> AbbDims;    // ABB IRB1200 + rod as compiled from abb_rod.urdf: a 6-deep chain (appendix A.2)
+typedef FixedDims<7, 6, 59, 6, 6> AbbLinkDims;   // the same arm with link contacts: its seven box volumes' vertices are sample points too
 
 // per-lane persistent body registers between phases of one sub-step
 struct BodyRegs {
@@ -1018,7 +1019,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
 
   // self-collision slots sit behind the articulation's sample points and the box slots
   int nself = 0;
-  const int self_slot0 = np + (BOX ? box_slot_count(C.scene->nboxes, m->nsph) : 0);
+  const int self_slot0 = np + (BOX ? box_slots(slot_lay<SC>(m, C.scene)) : 0);
   if constexpr (SELF) nself = self_contacts<G>(C, L, l, isdyn, self_slot0, B, mu_shape);
   BoxMasks BM;
   const int link_slot0 = self_slot0 + (SELF ? SHF_MAX_SELF_CONTACTS : 0);   // 2 x SHF_MAX_LINK_CONTACTS slots when LINK

@@ -16,19 +16,24 @@ REWARD_NAMES = ["reward_reaching", "reward_success"]   # build_reward_functions 
 class FusedAbbEnv:
     def __init__(self, num_envs: int = 4096, device="cuda:0", seed: int = 42, rank: int = 0, world_size: int = 1,
                  group: int = None, dt: float = 0.02, decimation: int = 5, episode_length_s: float = 20.0,
-                 extra_boxes=(), link_contacts: bool = False, mapping: str = None):
+                 extra_boxes=(), link_contacts: bool = None, mapping: str = None):
         self.device = torch.device(device)
         self.num_envs = num_envs
         self.env_id_offset = rank * num_envs
         self.dt = dt * decimation                                         # isaac_gym.py:26
         # link_contacts: the arm's links (box stand-ins for their mesh colliders) and the rod also collide with the table,
-        # the cube and the goal pad (ShfModel.link_collide) -- what `AbbPushBox` through the gym facade
-        # does; off here by default: BASELINE config 5's arm collider is the rod against the cube
+        # the cube and the goal pad (ShfModel.link_collide) -- the reference's scene (every shape of an env
+        # collides, units.py:68), what `AbbPushBox` through the gym facade does too, and the default here since round 4.
+        # False: the rod against the cube only (the scene benchmarked in rounds 1-3); also what the 'chain' / 'split'
+        # mappings are compiled for, so asking for one of those without saying otherwise means the rod-only scene.
+        if link_contacts is None:
+            link_contacts = mapping not in ("chain", "split")
+        self.link_contacts = bool(link_contacts)
         self.cm = abb_model(link_contacts=link_contacts)
         if group is None:
-            # 16 lanes per env is the fastest for the plain scene; with link contacts the 59 sample points and the link
-            # slots need 12.5 KB of LDS per env: eight envs per block (32 lanes each), not sixteen
-            group = 32 if link_contacts else 16
+            # 16 lanes per env: sixteen envs per workgroup share one LDS copy of the model, and 4096 envs are resident at once
+            # -- with link contacts too, now that only the free box owns corner slots (9.2 KB of LDS per env, was 12.6)
+            group = 16
         if mapping is None:
             # 'chain': the arm's kinematic / ABA recursions on one lane (csrc/shf_arm.h), compiled for the shipped arm in
             # the shipped scene; 'split' (16 lanes per env): the same with the arm and the box actors of an env on

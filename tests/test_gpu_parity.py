@@ -319,24 +319,26 @@ def test_fused_a1_env_on_the_benchmark_scene_matches_oracle_bitwise_at_full_size
 
 
 def test_long_differential_run_of_every_kernel_form(oracle):
-    """tools/fuzz_parity.py trimmed to fit the suite: 320 vec-steps x 192 envs (64 with link contacts) of all nine kernel
+    """tools/fuzz_parity.py trimmed to fit the suite: 320 vec-steps x 192 envs (64 with link contacts) of all eleven kernel
     forms of both tasks against the oracle, every tensor compared every 80 steps, through hundreds of resets
     (the 2000-step run is profiles/r03_fuzz_parity.txt)."""
     _need_gpu()
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_parity
     out = fuzz_parity.run(steps=320, envs=192, every=80, link_envs=64)
-    assert len(out) == 9 and all(r["equal"] for r in out)
+    assert len(out) == 11 and all(r["equal"] for r in out)
     assert sum(r["resets"] for r in out if r["task"] == "a1") > 300 and sum(r["resets"] for r in out if r["task"] == "abb") > 300
 
 
-def test_fused_abb_step_matches_oracle_bitwise_at_full_size(oracle):
-    """The same for config 5 on its default kernel (arm wave + box wave per env group): 4096 envs, 30 vec-steps."""
+@pytest.mark.parametrize("link", [True, False])
+def test_fused_abb_step_matches_oracle_bitwise_at_full_size(oracle, link):
+    """The same for config 5 -- the reference's scene, every link colliding (the default of FusedAbbEnv and of
+    bench.py --workload abb), and the rod-only scene on the arm wave + box wave kernel: 4096 envs, 30 vec-steps."""
     _need_gpu()
     from shifu_amd.gym.abb_fused import FusedAbbEnv
     n = 4096
-    env = FusedAbbEnv(num_envs=n, seed=23)
-    assert env.mapping == "split"
+    env = FusedAbbEnv(num_envs=n, seed=23, link_contacts=link)
+    assert env.mapping == ("body" if link else "split") and env.link_contacts == link and env.sim.group == 16
     env.task.tensors[_abi.ABB_EP_LEN].copy_(torch.randint(150, 201, (n,)))
     torch.cuda.synchronize()
     bufs = {k: env.sim.tensors[t].cpu().numpy().copy() for k, t in _ABB_SIM_T.items()}
@@ -654,7 +656,7 @@ _ABB_T = {"actions": _abi.ABB_ACTIONS, "obs": _abi.ABB_OBS, "rew": _abi.ABB_REW,
 
 
 @pytest.mark.parametrize("group,generic", [(64, False), (32, False), (16, False), (16, "chain"), (32, "levels"), (16, "levels"), (32, True),
-                                           (64, True), (32, "link"), (64, "link")])
+                                           (64, True), (16, "link"), (32, "link"), (64, "link"), (32, "link-generic")])
 def test_fused_abb_step_matches_oracle_bitwise(oracle, group, generic):
     """ShifuVecEnv.step for AbbPushBox (config 5): in-kernel damped-least-squares IK on the Jacobian
     tensor, 6 sub-steps with implicit POS drives and box contacts, refresh, termination, rewards,
@@ -667,7 +669,10 @@ def test_fused_abb_step_matches_oracle_bitwise(oracle, group, generic):
     from shifu_amd.abb_task import box_desc
     # "link": the arm's links and rod also collide with table / cube / goal pad (ShfModel.link_collide): the run-time-shaped
     # kernel with the link-contact pass
-    link = generic == "link"
+    # ("link": the shipped arm and scene, compile-time shaped -- the default of FusedAbbEnv since round 4; "link-generic": a
+    # fourth box puts the same on the run-time-shaped instantiation)
+    link_generic = generic == "link-generic"
+    link = generic == "link" or link_generic
     # "levels": the compile-time arm and scene on the level-by-level sub-step (mapping 'body'); False at 16 / 32 lanes takes
     # the default, the arm's recursions on one lane (csrc/shf_arm.h)
     levels = generic == "levels"
@@ -675,11 +680,12 @@ def test_fused_abb_step_matches_oracle_bitwise(oracle, group, generic):
     # (k_abb_step_ws, mapping 'split'); "chain": the one-wave form of the same at 16 lanes
     chain = generic == "chain"
     split = generic is False and group == 16
-    generic = generic is True or link
-    extra = [box_desc([0.05, 0.05, 0.02], 0.0, 0.5, True, [0.25, 0.25, 0.11])] if (generic and not link) else []
+    generic = generic is True or link_generic
+    extra = [box_desc([0.05, 0.05, 0.02], 0.0, 0.5, True, [0.25, 0.25, 0.11])] if generic else []
     env = FusedAbbEnv(num_envs=n, seed=11, group=group, extra_boxes=extra, link_contacts=link, mapping="body" if levels else ("chain" if chain else None))
-    assert env.mapping == ("split" if split else "chain" if (not generic and not levels and group < 64) else "body")
+    assert env.mapping == ("split" if split else "chain" if (not generic and not link and not levels and group < 64) else "body")
     assert ("FixedDims" in env.task.kernel_symbol() or split) != bool(generic)
+    assert ("Lb1ELi0EE" in env.task.kernel_symbol()) == (link and not generic)
     assert env.task.kernel_symbol().endswith("Li6EE") == (env.mapping == "chain")
     env.task.tensors[_abi.ABB_EP_LEN].copy_(torch.randint(0, 200, (n,)))   # staggered time-outs
     torch.cuda.synchronize()
@@ -733,7 +739,7 @@ def test_random_action_step_matches_oracle_bitwise(oracle, kind):
         env.reset()
     else:
         from shifu_amd.gym.abb_fused import FusedAbbEnv
-        env = FusedAbbEnv(num_envs=n, rank=1, world_size=2, seed=9, group=16, mapping="split" if kind.endswith("split") else "body")
+        env = FusedAbbEnv(num_envs=n, rank=1, world_size=2, seed=9, group=16, link_contacts=False, mapping="split" if kind.endswith("split") else "body")
         off = env.env_id_offset
     # the generator itself: two runs of the oracle's restatement agree with each other and differ between steps / envs
     a0 = oracle.random_actions(9, n, off, 0, env.num_actions)

@@ -217,3 +217,41 @@ def test_link_contacts_on_a_robot_with_many_box_volumes_loads_with_a_warning(tmp
     assert cm.blob.link_collide == 1 and cm.blob.nabox == 0 and cm.blob.np == 8 * n
     few = compile_urdf(str(p), link_contacts=False)
     assert few.blob.link_collide == 0 and few.blob.nabox == 0
+
+
+def test_model_bounds_enclose_every_link_contact_shape():
+    """shf_model_bounds (the kernels' link-contact broad phase, ShfModel.bbox): every sample point and rounded shape, grown by
+    its radius, and every vertex of every box volume lies inside its body's box; bodies without shapes are marked."""
+    import ctypes as C
+    from shifu_amd import _lib
+    from shifu_amd.abb_task import abb_model
+    for cm in (abb_model(link_contacts=True), abb_model(link_contacts=False),
+               compile_urdf(asset_path("a1.urdf"), link_contacts=True)):
+        m = cm.blob
+        m.bounds_ok = 0
+        assert _lib.lib().shf_model_bounds(C.byref(m)) == 0
+        assert m.bounds_ok == 0x42534831
+        balls = [(m.pt_body[i], np.array(m.pt_pos[i][:]), m.pt_radius[i]) for i in range(m.np)]
+        for i in range(m.nsph):
+            for e in (0.0, 1.0):
+                balls.append((m.sph_body[i], np.array(m.sph_pos[i][:]) + e * np.array(m.sph_seg[i][:]), m.sph_radius[i]))
+        for j in range(m.nabox):
+            Rj = np.array(m.abox_rot[j][:]).reshape(3, 3)
+            for c in range(8):
+                s = np.array([1.0 if c & 4 else -1.0, 1.0 if c & 2 else -1.0, 1.0 if c & 1 else -1.0])
+                balls.append((m.abox_body[j], np.array(m.abox_pos[j][:]) + Rj @ (s * np.array(m.abox_half[j][:])), 0.0))
+        have = set()
+        for b, c, r in balls:
+            bb = np.array(m.bbox[b][:])
+            have.add(b)
+            assert bb[3] >= 0.0
+            assert np.all(np.abs(c - bb[:3]) + r <= bb[3:] + 1e-7), (b, c, r, bb)
+        for b in range(_abi.MAX_BODIES):
+            if b not in have:
+                assert m.bbox[b][3] < 0.0
+        # tight: the box is the bounding box of the shapes, not an arbitrary superset
+        for b in have:
+            pts = np.array([c for bb_, c, r in balls if bb_ == b])
+            rad = np.array([r for bb_, c, r in balls if bb_ == b])
+            ext = 0.5 * ((pts + rad[:, None]).max(0) - (pts - rad[:, None]).min(0))
+            assert np.all(np.array(m.bbox[b][3:]) <= ext * 1.001 + 1e-5)

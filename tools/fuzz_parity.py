@@ -45,9 +45,12 @@ def run(steps=2000, envs=384, every=100, link_envs=128):
     from shifu_amd.abb_task import box_desc
     from shifu_amd.gym.abb_fused import FusedAbbEnv
     extra = [box_desc([0.05, 0.05, 0.02], 0.0, 0.5, True, [0.25, 0.25, 0.11])]
-    for name, kw in (("split", dict(group=16)), ("chain16", dict(group=16, mapping="chain")), ("chain32", dict(group=32)),
-                     ("levels16", dict(group=16, mapping="body")), ("generic32", dict(group=32, extra_boxes=extra)),
-                     ("link32", dict(group=32, link_contacts=True))):
+    for name, kw in (("split", dict(group=16, link_contacts=False)), ("chain16", dict(group=16, mapping="chain")),
+                     ("chain32", dict(group=32, link_contacts=False)),
+                     ("levels16", dict(group=16, mapping="body", link_contacts=False)),
+                     ("generic32", dict(group=32, extra_boxes=extra, link_contacts=False)),
+                     ("link16", dict(group=16, link_contacts=True)), ("link32", dict(group=32, link_contacts=True)),
+                     ("link32-generic", dict(group=32, link_contacts=True, extra_boxes=extra))):
         t0 = time.time()
         n = args.envs if "link" not in name else min(args.envs, link_envs)
         env = FusedAbbEnv(num_envs=n, seed=31, **kw)
