@@ -128,6 +128,14 @@ def sincos(x):
     return s, c
 
 
+def rcp_rsqrt(x):
+    """rcp_spec / rsqrt_spec of the float build (the Newton sequences the HIP kernels share)."""
+    x = np.ascontiguousarray(x, np.float32)
+    r = np.zeros_like(x); q = np.zeros_like(x)
+    lib().shf_oracle_rcp_rsqrt_f32(C.c_int(x.size), _p(x, C.c_float), _p(r, C.c_float), _p(q, C.c_float))
+    return r, q
+
+
 def exp(x):
     x = np.ascontiguousarray(x, np.float32)
     y = np.zeros_like(x)

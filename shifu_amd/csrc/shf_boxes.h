@@ -1669,9 +1669,9 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
       wn[k] = fmaf(dt, a[k], ang[k]) * damp;
       vn[k] = fmaf(dt, a[3 + k] + gb[k] + axp[k] + wxv[k], lin[k]);
     }
-    const float wmag = sqrtf(dot3(wn, wn)), wmax = C.sp.max_ang_vel;
-    if (wmag > wmax) {
-      const float sc2 = wmax / wmag;
+    const float w2 = dot3(wn, wn), wmax = C.sp.max_ang_vel;
+    if (w2 > wmax * wmax) {
+      const float sc2 = wmax * rsqrt_spec(w2);
 #pragma unroll
       for (int k = 0; k < 3; k++) wn[k] *= sc2;
     }
@@ -1683,7 +1683,7 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
     const float ny = y + fmaf(hy, ww, fmaf(hz, x, -(hx * z)));
     const float nz = z + fmaf(hz, ww, fmaf(hx, y, -(hy * x)));
     const float nw = ww - fmaf(hx, x, fmaf(hy, y, hz * z));
-    const float inv = 1.0f / sqrtf(fmaf(nw, nw, fmaf(nz, nz, fmaf(ny, ny, nx * nx))));
+    const float inv = rsqrt_spec(fmaf(nw, nw, fmaf(nz, nz, fmaf(ny, ny, nx * nx))));
     row[3] = nx * inv; row[4] = ny * inv; row[5] = nz * inv; row[6] = nw * inv;
   }
 }

@@ -200,7 +200,7 @@ DEV void terrain_height_gradient(const TerrainDev& T, float x, float y, float* h
 }
 DEV void terrain_normal_from_gradient(const TerrainDev& T, float gx, float gy, float* n) {
   if (T.t.rows == 0) { n[0] = 0.0f; n[1] = 0.0f; n[2] = 1.0f; return; }
-  const float nz = 1.0f / sqrtf(fmaf(gy, gy, fmaf(gx, gx, 1.0f)));
+  const float nz = rsqrt_spec(fmaf(gy, gy, fmaf(gx, gx, 1.0f)));
   n[0] = -gx * nz; n[1] = -gy * nz; n[2] = nz;
 }
 
@@ -508,7 +508,7 @@ DEV void chain_substep(const StepCtx& C, const ChainLds& L, int l, DofLane& X, c
         float sp = S[0] * plg[0];
 #pragma unroll
         for (int j = 1; j < 6; j++) sp = fmaf(S[j], plg[j], sp);
-        const float invD = 1.0f / D;
+        const float invD = rcp_spec(D);
         invDk[k] = invD;
         uk[k] = tau0 - sp;
 #pragma unroll
@@ -592,9 +592,9 @@ DEV void chain_substep(const StepCtx& C, const ChainLds& L, int l, DofLane& X, c
       wn[k] = fmaf(dt, a[k], ang[k]) * damp;
       vn[k] = fmaf(dt, a[3 + k] + g[k] + wxv[k], lin[k]);
     }
-    const float wmag = sqrtf(dot3(wn, wn)), wmax = C.sp.max_ang_vel;
-    if (wmag > wmax) {
-      const float sc2 = wmax / wmag;
+    const float w2 = dot3(wn, wn), wmax = C.sp.max_ang_vel;
+    if (w2 > wmax * wmax) {
+      const float sc2 = wmax * rsqrt_spec(w2);
 #pragma unroll
       for (int k = 0; k < 3; k++) wn[k] *= sc2;
     }
@@ -606,7 +606,7 @@ DEV void chain_substep(const StepCtx& C, const ChainLds& L, int l, DofLane& X, c
     const float ny = y + fmaf(hy, ww, fmaf(hz, x, -(hx * z)));
     const float nz = z + fmaf(hz, ww, fmaf(hx, y, -(hy * x)));
     const float nw = ww - fmaf(hx, x, fmaf(hy, y, hz * z));
-    const float inv = 1.0f / sqrtf(fmaf(nw, nw, fmaf(nz, nz, fmaf(ny, ny, nx * nx))));
+    const float inv = rsqrt_spec(fmaf(nw, nw, fmaf(nz, nz, fmaf(ny, ny, nx * nx))));
     Rt[3] = nx * inv; Rt[4] = ny * inv; Rt[5] = nz * inv; Rt[6] = nw * inv;
   }
   GROUP_SYNC();

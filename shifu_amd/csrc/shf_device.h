@@ -54,6 +54,22 @@ __device__ unsigned long long g_phase_cycles[32];
 #define PHASE_RESET() do {} while (0)
 #endif
 
+// 1/x (x > 0) and 1/sqrt(x) (x > 0) by Newton's iteration from an integer seed: the fixed operation sequences of the
+// oracle's rcp_spec / rsqrt_spec (7 and 12 dependent operations; IEEE `1.0f / x` and `sqrtf` are 11 and ~20 on gfx950).
+DEV float rcp_spec(float x) {
+  float y = __uint_as_float(0x7EF311C7u - __float_as_uint(x));
+#pragma unroll
+  for (int k = 0; k < 3; k++) { const float e = fmaf(-x, y, 1.0f); y = fmaf(y, e, y); }
+  return y;
+}
+DEV float rsqrt_spec(float x) {
+  float y = __uint_as_float(0x5F375A86u - (__float_as_uint(x) >> 1));
+  const float hx = 0.5f * x;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { const float t = y * y; const float w = fmaf(-hx, t, 1.5f); y = y * w; }
+  return y;
+}
+
 // ------------------------------------------------------------------ math --
 DEV float rminf(float a, float b) { return a < b ? a : b; }
 DEV float rmaxf(float a, float b) { return a > b ? a : b; }
@@ -177,7 +193,7 @@ DEV void warped_normal(float hs, const float* BP, float* bn) {
   const float vx = (P2[0] - P0[0]) * hs, vy = (P2[1] - P0[1]) * hs, vz = P2[2] - P0[2];
   float nx = fmaf(uy, vz, -(uz * vy)), ny = fmaf(uz, vx, -(ux * vz)), nz = fmaf(ux, vy, -(uy * vx));
   if (nz < 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
-  const float inv = 1.0f / sqrtf(fmaf(nz, nz, fmaf(ny, ny, nx * nx)));
+  const float inv = rsqrt_spec(fmaf(nz, nz, fmaf(ny, ny, nx * nx)));
   bn[0] = nx * inv; bn[1] = ny * inv; bn[2] = nz * inv;
 }
 
@@ -244,7 +260,7 @@ DEV void terrain_query_heightfield(const TerrainDev& T, float x, float y, float*
   float gy = (lo ? h01 : h11) - (lo ? h00 : h10);
   const float hh = fmaf(lo ? v : 1.0f - v, lo ? gy : -gy, fmaf(lo ? u : 1.0f - u, lo ? gx : -gx, lo ? h00 : h11));
   gx *= inv; gy *= inv;
-  float nz = 1.0f / sqrtf(fmaf(gy, gy, fmaf(gx, gx, 1.0f)));
+  float nz = rsqrt_spec(fmaf(gy, gy, fmaf(gx, gx, 1.0f)));
   *h = hh; n[0] = -gx * nz; n[1] = -gy * nz; n[2] = nz;
 }
 
@@ -674,7 +690,7 @@ DEV void ldlt_factor6(const float* IA, Ldlt6& F) {
 #pragma unroll
     for (int k = 0; k < j; k++) d = fmaf(-(F.Lm[j][k] * F.Lm[j][k]), F.Dg[k], d);
     F.Dg[j] = d;
-    const float id = 1.0f / d;
+    const float id = rcp_spec(d);
     F.iD[j] = id;
 #pragma unroll
     for (int i = j + 1; i < 6; i++) {
@@ -718,7 +734,7 @@ DEV float friction_coefficient(const float* n, const float* vs, float pen, float
   const float vns = dot3(n, vs);
   const float fns = rmaxf(fmaf(-beta, vns, pen), 0.0f);
   const float vts[3] = {fmaf(-vns, n[0], vs[0]), fmaf(-vns, n[1], vs[1]), fmaf(-vns, n[2], vs[2])};
-  return mu * fns / rmaxf(sqrtf(dot3(vts, vts)), veps);
+  return mu * fns * rsqrt_spec(rmaxf(dot3(vts, vts), veps * veps));   // = mu fns / max(|v_t|, v_eps)
 }
 
 #include "shf_boxes.h"
@@ -1078,7 +1094,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
       float sp = B.S[0] * B.pA[0];
 #pragma unroll
       for (int j = 1; j < 6; j++) sp = fmaf(B.S[j], B.pA[j], sp);
-      const float invD = 1.0f / D;
+      const float invD = rcp_spec(D);
       B.invD = invD;
       B.u = L.dofb[d * DOF_STRIDE + 2] - sp;
       float W[6];
@@ -1248,9 +1264,9 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
       wn[k] = fmaf(dt, a[k], ang[k]) * damp;
       vn[k] = fmaf(dt, a[3 + k] + g[k] + wxv[k], lin[k]);
     }
-    const float wmag = sqrtf(dot3(wn, wn)), wmax = C.sp.max_ang_vel;
-    if (wmag > wmax) {
-      const float sc2 = wmax / wmag;
+    const float w2 = dot3(wn, wn), wmax = C.sp.max_ang_vel;
+    if (w2 > wmax * wmax) {
+      const float sc2 = wmax * rsqrt_spec(w2);
 #pragma unroll
       for (int k = 0; k < 3; k++) wn[k] *= sc2;
     }
@@ -1262,7 +1278,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
     const float ny = y + fmaf(hy, ww, fmaf(hz, x, -(hx * z)));
     const float nz = z + fmaf(hz, ww, fmaf(hx, y, -(hy * x)));
     const float nw = ww - fmaf(hx, x, fmaf(hy, y, hz * z));
-    const float inv = 1.0f / sqrtf(fmaf(nw, nw, fmaf(nz, nz, fmaf(ny, ny, nx * nx))));
+    const float inv = rsqrt_spec(fmaf(nw, nw, fmaf(nz, nz, fmaf(ny, ny, nx * nx))));
     Rt[3] = nx * inv; Rt[4] = ny * inv; Rt[5] = nz * inv; Rt[6] = nw * inv;
   }
   GROUP_SYNC();

@@ -184,6 +184,12 @@ static __device__ __forceinline__ void glue_quat_mul(const float* a, const float
   o[1] = qq - yy + (w1 - x1) * (y2 + z2);
   o[2] = qq - zz + (z1 + y1) * (w2 - x2);
 }
+static __device__ __forceinline__ float glue_rcp_spec(float x) {   // the oracle's rcp_spec (csrc/shf_device.h has the same)
+  float y = __uint_as_float(0x7EF311C7u - __float_as_uint(x));
+#pragma unroll
+  for (int k = 0; k < 3; k++) { const float e = fmaf(-x, y, 1.0f); y = fmaf(y, e, y); }
+  return y;
+}
 static __device__ __forceinline__ void glue_ldlt_solve6(const float* IA, const float* pA, float* x) {   // IA x = -pA
   float Lm[6][6], Dg[6], iD[6], y[6];
 #pragma unroll
@@ -192,7 +198,7 @@ static __device__ __forceinline__ void glue_ldlt_solve6(const float* IA, const f
 #pragma unroll
     for (int k = 0; k < j; k++) d = fmaf(-(Lm[j][k] * Lm[j][k]), Dg[k], d);
     Dg[j] = d;
-    const float id = 1.0f / d;
+    const float id = glue_rcp_spec(d);
     iD[j] = id;
 #pragma unroll
     for (int i = j + 1; i < 6; i++) {

@@ -79,7 +79,7 @@ DEV void chain_inward_link(ChainLink& K, float* IA, const float* pA, float dex, 
   float sp = K.S[0] * pA[0];
 #pragma unroll
   for (int j = 1; j < 6; j++) sp = fmaf(K.S[j], pA[j], sp);
-  const float invD = 1.0f / D;
+  const float invD = rcp_spec(D);
   K.invD = invD;
   K.u = tau0 - sp;
   float W[6];

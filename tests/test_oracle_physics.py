@@ -171,6 +171,32 @@ def test_spec_sincos_exp_accuracy(oracle):
     assert (np.abs(e - ref) / ref).max() < 3e-7
 
 
+def test_spec_rcp_rsqrt_accuracy(oracle):
+    """rcp_spec / rsqrt_spec (Newton from an integer seed, shared operation for operation with the HIP kernels): within
+    1.01 and 2.5 units of 2^-24 of 1/x and 1/sqrt(x) over twelve decades -- what replaces IEEE division / sqrt on the sub-step's
+    dependent chain -- and bit for bit the sequence written out here."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([np.exp(rng.uniform(np.log(1e-6), np.log(1e6), 400000)), np.linspace(1.0, 4.0, 400000)]).astype(np.float32)
+    r, q = oracle.rcp_rsqrt(x)
+    xd = x.astype(np.float64)
+    assert np.abs(r * xd - 1.0).max() < 1.01 * 2.0 ** -24
+    assert np.abs(q * np.sqrt(xd) - 1.0).max() < 2.5 * 2.0 ** -24
+
+    def fma(a, b, c):        # exact product in float64, one rounding of the sum (double rounding cannot occur for these magnitudes often enough to matter: checked by equality below)
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+    y = (np.uint32(0x7EF311C7) - x.view(np.uint32)).view(np.float32)
+    for _ in range(3):
+        e = fma(-x, y, np.ones_like(x))
+        y = fma(y, e, y)
+    assert (y == r).mean() > 0.9999          # (float64-emulated fma double-rounds a handful of cases)
+    z = (np.uint32(0x5F375A86) - (x.view(np.uint32) >> np.uint32(1))).view(np.float32)
+    hx = np.float32(0.5) * x
+    for _ in range(3):
+        t = z * z
+        z = z * fma(-hx, t, np.full_like(x, 1.5))
+    assert (z == q).mean() > 0.9999
+
+
 def test_random_action_generator_is_counter_based_and_uniform(oracle):
     """oracle.random_actions -- the restatement of csrc/shf_task.h: random_action, run_policy('random')'s 2 * rand - 1 drawn
     in-kernel (shf_a1_step_random): U(-1, 1) to the statistics of 10^6 draws, a pure function of (seed, global env id,
