@@ -228,8 +228,8 @@ def main():
     ap.add_argument("--actions", choices=["kernel", "torch"], default="kernel",
                     help="random actions drawn inside the fused launch (default) or by a torch uniform_ launch before it")
     ap.add_argument("--mapping", choices=["chain", "body", "split"], default=None,
-                    help="A1 workloads: lane = kinematic chain (default; csrc/shf_chain.h) or lane = rigid body (the general kernels; "
-                         "default with --self-collision).  Kernel selection only: results are bit-identical")
+                    help="A1 workloads: lane = kinematic chain (default, with --self-collision too at 32 lanes per env; csrc/shf_chain.h) "
+                         "or lane = rigid body (the general kernels).  Kernel selection only: results are bit-identical")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--self-collision", action="store_true",
                     help="A1 workloads: collide the robot's own links (capsule pairs; the reference's collision filter 0, "
@@ -293,7 +293,7 @@ def main():
         mapping = args.mapping or (("split" if (args.group or 16) == 16 else "chain") if (not args.link_contacts and (args.group or 16) < 64) else "body")
         group = args.group or 16
     else:    # the fused A1 env's own default: the chain-per-lane kernel at 32 lanes when there is no self-collision
-        mapping = args.mapping or ("chain" if (not args.self_collision and (args.group or 32) < 64) else "body")
+        mapping = args.mapping or ("chain" if ((args.group or 32) == 32 or ((args.group or 32) == 16 and not args.self_collision)) else "body")
         group = args.group or 32
     if abb:
         from shifu_amd.gym.abb_fused import FusedAbbEnv

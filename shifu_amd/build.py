@@ -47,7 +47,7 @@ BUDGETS = [("_Z16k_a1_step_a1_g32", 256, 0),          # default: A1, two envs pe
            # the kernels the fused envs launch by default since round 3 -- the chain-mapped A1 step (two waves per SIMD at 32
            # lanes per env, four envs per wave at 16) and the two-wave ABB step: a spill or a 257th register there has cost
            # more than 30 % before it was noticed
-           ("_Z10k_a1_chainILi32ELb0E", 256, 0), ("_Z10k_a1_chainILi32ELb1E", 256, 0),
+           ("_Z10k_a1_chainILi32ELb0E", 256, 0), ("_Z10k_a1_chainILi32ELb1E", 256, 0),   # (all four: height field / trimesh, without / with self-collision)
            ("_Z10k_a1_chainILi16ELb0E", 512, 0),      # four envs per wave = one wave per SIMD: no occupancy step to lose below 512
 
            ("_Z13k_abb_step_wsILi256EE", 256, 0),

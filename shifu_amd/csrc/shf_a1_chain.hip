@@ -4,16 +4,21 @@
 
 #include "shf_chain.h"
 
-template <int G, bool TW>
-__global__ __launch_bounds__(256, (G == 32 ? 2 : 1)) void k_a1_chain(A1Args A) { a1_chain_step_body<G, A1Chain, TW>(A); }
+template <int G, bool TW, bool SELF = false>
+__global__ __launch_bounds__(256, (G == 32 ? 2 : 1)) void k_a1_chain(A1Args A) { a1_chain_step_body<G, A1Chain, TW, SELF>(A); }
 
 bool shf_a1_chain_matches(const ShfModel& m) { return A1Chain::matches(m); }
 // dynamic LDS of one 256-thread block at G lanes per env
-size_t shf_a1_chain_lds_bytes(int G, int nobs) {
+size_t shf_a1_chain_lds_bytes(int G, int nobs, bool self) {
   const int epb = 256 / G;
-  return ((size_t)MODEL_WORDS + TASK_WORDS + STATS_LDS_WORDS + (size_t)epb * chain_lds_words<A1Chain>(SCR_OBS + nobs)) * 4;
+  return ((size_t)CHAIN_MODEL_WORDS + TASK_WORDS + STATS_LDS_WORDS + (size_t)epb * chain_lds_words<A1Chain>(SCR_OBS + nobs, self)) * 4;
 }
-const void* shf_a1_chain_kernel(int G, bool warped) {
+// self: with the capsule-pair self-collision pass (32 lanes per env only: the pair tests want the lanes)
+const void* shf_a1_chain_kernel(int G, bool warped, bool self) {
+  if (self) {
+    if (G != 32) return nullptr;
+    return warped ? reinterpret_cast<const void*>(k_a1_chain<32, true, true>) : reinterpret_cast<const void*>(k_a1_chain<32, false, true>);
+  }
   switch (G) {
     case 16: return warped ? reinterpret_cast<const void*>(k_a1_chain<16, true>) : reinterpret_cast<const void*>(k_a1_chain<16, false>);
     case 32: return warped ? reinterpret_cast<const void*>(k_a1_chain<32, true>) : reinterpret_cast<const void*>(k_a1_chain<32, false>);

@@ -58,8 +58,8 @@ struct ShfA1Task {
 
 // shf_a1_chain.hip: the chain-mapped fused A1 step (its own translation unit)
 bool shf_a1_chain_matches(const ShfModel& m);
-size_t shf_a1_chain_lds_bytes(int G, int nobs);
-const void* shf_a1_chain_kernel(int G, bool warped);
+size_t shf_a1_chain_lds_bytes(int G, int nobs, bool self);
+const void* shf_a1_chain_kernel(int G, bool warped, bool self);
 #ifdef SHF_PHASE_CLOCK
 int shf_a1_chain_phase_cycles(unsigned long long* out, int n, int reset);
 #endif
@@ -1014,7 +1014,7 @@ extern "C" int shf_sim_set_mapping(ShfSim* sim, int32_t mapping) {
     if (!a1 && !arm)
       return fail("shf_sim_set_mapping: the chain mapping needs a floating root with 4 serial chains of 3 revolute links and a "
                   "welded end body (the A1), or a fixed base with one serial chain of 6 revolute links (the ABB arm)");
-    if (sim_self(sim)) return fail("shf_sim_set_mapping: the chain mapping has no self-collision");
+    if (sim_self(sim) && !a1) return fail("shf_sim_set_mapping: only the A1's chain mapping has a self-collision pass");
     if (a1 && sim->nboxes != 0) return fail("shf_sim_set_mapping: the chain-mapped A1 step supports a single actor per env");
   }
   sim->mapping = mapping;
@@ -1413,11 +1413,12 @@ static int a1_step_launch(ShfA1Task* task, const float* raw_actions_dev, void* s
   const size_t lds = sim_lds_bytes(s, TASK_WORDS + STATS_LDS_WORDS, SCR_OBS + nobs);
   int r;
   if (s->mapping == SHF_MAP_CHAIN) {
-    if (!shf_a1_chain_matches(s->model) || sim_self(s)) return fail("shf_a1_step: the articulation does not fit the chain mapping");
-    const void* fn = shf_a1_chain_kernel(s->chain_group, s->terr.warped != 0);
-    if (!fn) return fail("shf_a1_step: the chain mapping runs at 16 or 32 lanes per env");
+    if (!shf_a1_chain_matches(s->model)) return fail("shf_a1_step: the articulation does not fit the chain mapping");
+    const void* fn = shf_a1_chain_kernel(s->chain_group, s->terr.warped != 0, sim_self(s));
+    if (!fn) return fail(sim_self(s) ? "shf_a1_step: the chain mapping with self-collision runs at 32 lanes per env"
+                                     : "shf_a1_step: the chain mapping runs at 16 or 32 lanes per env");
     const int cepb = 256 / s->chain_group;
-    return launch_ptr(fn, dim3((s->n + cepb - 1) / cepb), block, shf_a1_chain_lds_bytes(s->chain_group, nobs), stream, A);
+    return launch_ptr(fn, dim3((s->n + cepb - 1) / cepb), block, shf_a1_chain_lds_bytes(s->chain_group, nobs, sim_self(s)), stream, A);
   }
   if (s->terr.warped && s->group == 64)
     return fail("shf_a1_step: a trimesh terrain needs 16 or 32 lanes per env (the 128-VGPR instantiation has no room for it)");

@@ -105,6 +105,28 @@ DEV void slot_accumulate_fb(float* IA, float* pA, const float* o, float sign, fl
   }
 }
 
+// The same for a lane that owns half of a body's accumulators (the chain-mapped A1 kernel at 32 lanes per env: HALF 0 owns
+// IA[0..10], HALF 1 owns IA[11..20] and pA): every element sees the operations of slot_accumulate_fb, the other half's are
+// dead code.
+template <int HALF>
+DEV void slot_accumulate_fb_half(float* IA, float* pA, const float* o, float sign, float dt, float fscale, float bscale) {
+  float tI[21], tp[6];
+#pragma unroll
+  for (int k = 0; k < 21; k++) tI[k] = IA[k];
+#pragma unroll
+  for (int k = 0; k < 6; k++) tp[k] = pA[k];
+  slot_accumulate_fb(tI, tp, o, sign, dt, fscale, bscale);
+  if (HALF == 0) {
+#pragma unroll
+    for (int k = 0; k < 11; k++) IA[k] = tI[k];
+  } else {
+#pragma unroll
+    for (int k = 11; k < 21; k++) IA[k] = tI[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) pA[k] = tp[k];
+  }
+}
+
 DEV void slot_accumulate(float* IA, float* pA, const float* o, float sign, float dt, float scale) {
   slot_accumulate_fb(IA, pA, o, sign, dt, scale, scale);
 }
@@ -565,8 +587,9 @@ DEV void segment_closest(const float* p1, const float* q1, const float* p2, cons
 // One lane per capsule pair: pairs closer than the contact offset respond with the shared contact law; the active ones
 // are compacted, in pair order, into at most SHF_MAX_SELF_CONTACTS slots starting at slot `slot0` (their `on` word
 // holds pair index + 1), then folded into the two bodies (+f on a's, -f on b's).  Returns the number of active slots.
+// (self_contacts_eval: evaluation and compaction only -- the chain-mapped A1 kernel folds them itself, shf_chain.h)
 template <int G>
-DEV int self_contacts(const StepCtx& C, const EnvLds& L, int l, bool isdyn, int slot0, BodyRegs& B, float mu_shape) {
+DEV int self_contacts_eval(const StepCtx& C, const EnvLds& L, int l, int slot0, float mu_shape) {
   const ShfModel* m = C.m;
   const float dt = C.sp.dt, kc = C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
   const float offset = C.sp.contact_offset;
@@ -579,6 +602,12 @@ DEV int self_contacts(const StepCtx& C, const EnvLds& L, int l, bool isdyn, int 
     const int p = l + j * G;
     float slot[PT_STRIDE];
     slot[PT_ON] = 0.0f;
+    // Broad phase (not in the oracle, and no need to be): the two capsules' bounding spheres -- centre the middle of the
+    // segment, radius half its length + the capsule's -- further apart than the contact offset + 1 cm means gap > offset
+    // wherever the closest points are, and the slot stays off.  A round none of whose pairs is near (the usual case: a
+    // walking robot's links are apart) skips the closest-point search wave-wide.
+    float A0[3], A1[3], B0[3], B1[3];
+    bool near = false;
     if (p < npair) {
       const int ia = m->pair_a[p], ib = m->pair_b[p];
       const int ba = m->cap_body[ia], bb = m->cap_body[ib];
@@ -589,10 +618,22 @@ DEV int self_contacts(const StepCtx& C, const EnvLds& L, int l, bool isdyn, int 
       for (int k = 0; k < 9; k++) { Ra[k] = pa[k]; Rb[k] = pb[k]; }
       const float la[3] = {m->cap_a[ia][0], m->cap_a[ia][1], m->cap_a[ia][2]}, lb[3] = {m->cap_b[ia][0], m->cap_b[ia][1], m->cap_b[ia][2]};
       const float lc[3] = {m->cap_a[ib][0], m->cap_a[ib][1], m->cap_a[ib][2]}, ld[3] = {m->cap_b[ib][0], m->cap_b[ib][1], m->cap_b[ib][2]};
-      float A0[3], A1[3], B0[3], B1[3], c1[3], c2[3];
       mv3(Ra, la, A0); mv3(Ra, lb, A1); mv3(Rb, lc, B0); mv3(Rb, ld, B1);
 #pragma unroll
       for (int k = 0; k < 3; k++) { A0[k] += pa[9 + k]; A1[k] += pa[9 + k]; B0[k] += pb[9 + k]; B1[k] += pb[9 + k]; }
+      const float dm[3] = {(A0[0] + A1[0]) - (B0[0] + B1[0]), (A0[1] + A1[1]) - (B0[1] + B1[1]), (A0[2] + A1[2]) - (B0[2] + B1[2])};   // 2 x (centre a - centre b)
+      const float da[3] = {A1[0] - A0[0], A1[1] - A0[1], A1[2] - A0[2]}, db[3] = {B1[0] - B0[0], B1[1] - B0[1], B1[2] - B0[2]};
+      // 2 x reach <= |da| + |db| + 2 (ra + rb + offset + 0.01); compared squared, with (x + y)^2 <= 2 x^2 + 2 y^2 for the lengths
+      const float rr = 2.0f * (m->cap_radius[ia] + m->cap_radius[ib] + offset + 0.01f);
+      const float len2 = 2.0f * (dot3(da, da) + dot3(db, db));            // >= (|da| + |db|)^2
+      const float bound = 2.0f * (len2 + rr * rr);                        // >= (|da| + |db| + rr)^2
+      near = !(dot3(dm, dm) > bound * 1.0001f);
+    }
+    if (__ballot(near) == 0ull) continue;
+    if (near) {
+      const int ia = m->pair_a[p], ib = m->pair_b[p];
+      const int ba = m->cap_body[ia], bb = m->cap_body[ib];
+      float c1[3], c2[3];
       segment_closest(A0, A1, B0, B1, c1, c2);
       const float dv[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
       const float d = sqrtf(dot3(dv, dv));
@@ -630,6 +671,13 @@ DEV int self_contacts(const StepCtx& C, const EnvLds& L, int l, bool isdyn, int 
     if (l == 0 && C.dropped) *C.dropped += count - SHF_MAX_SELF_CONTACTS;     // dropped in pair order -- and counted (SHF_T_DROPPED)
     count = SHF_MAX_SELF_CONTACTS;
   }
+  return count;
+}
+template <int G>
+DEV int self_contacts(const StepCtx& C, const EnvLds& L, int l, bool isdyn, int slot0, BodyRegs& B, float mu_shape) {
+  const ShfModel* m = C.m;
+  const float dt = C.sp.dt;
+  const int count = self_contacts_eval<G>(C, L, l, slot0, mu_shape);
   GROUP_SYNC();
   if (isdyn) {
     for (int k = 0; k < count; k++) {

@@ -85,9 +85,14 @@ typedef ChainDims<4, 3, 76, 88> A1Chain;   // the A1: 76 sample points in 88 slo
 #define JREC_DE 13
 #define JREC_S 0
 #define JREC_C 6
+// The chain kernels stage the model up to (not including) its link-contact records -- a single actor per env has no box
+// actors to meet -- which leaves room for the self-collision slots in the 80 KB a workgroup may use at two per CU.
+#define CHAIN_MODEL_BYTES ((int)offsetof(ShfModel, link_collide))
+#define CHAIN_MODEL_WORDS ((CHAIN_MODEL_BYTES / 4 + 3) & ~3)
+static_assert(CHAIN_MODEL_BYTES % 16 == 0, "stage_block copies 16-byte words");
 template <class CD>
-__host__ __device__ inline int chain_lds_words(int min_tail) {
-  int tail = CD::NPC * PT_STRIDE;
+__host__ __device__ inline int chain_lds_words(int min_tail, bool self = false) {
+  int tail = (CD::NPC + (self ? SHF_MAX_SELF_CONTACTS : 0)) * PT_STRIDE;
   if (tail < min_tail) tail = min_tail;
   const int w = CD::NB * POSE_STRIDE + ((CD::NB * 6 + 3) & ~3) + (CD::ND + 1) * XCH_STRIDE + CD::ND * JREC_STRIDE +
                 ((CD::ND * DOF_STRIDE + 3) & ~3) + root_words(1) + tail;
@@ -273,7 +278,7 @@ DEV RowLane row_lane_load(int l) {
 // 8 c .. 8 c + 5 each hold one row of chain c's articulated inertia, so that IA S, the rank-1 update and IA c cost 6 fused
 // operations per link instead of 36 + 21 + 36; U and pA travel between the rows through LDS.  Every element still sees the
 // operations of chain_inward_link in its order (an element below the diagonal repeats its mirror image's: same operands).
-template <int G, class CD, bool TW>
+template <int G, class CD, bool TW, bool SELF = false>
 DEV void chain_substep(const StepCtx& C, const ChainLds& L, int l, DofLane& X, const ChainPoints<(CD::NEV + G - 1) / G>& P,
                        const SlotList<CD::MAXPT>& mine, const RowLane& RL, const float* fext, float mu_shape, float* contact_out) {
   static_assert(G > CD::ND && G <= 64, "a lane per dof plus one for the root");
@@ -429,6 +434,10 @@ DEV void chain_substep(const StepCtx& C, const ChainLds& L, int l, DofLane& X, c
       if (k * G < 64) act.w[0] |= bits << ((k * G) & 63); else act.w[1] |= bits << ((k * G - 64) & 63);
     }
   }
+  // self-collision (ShfModel.self_collide; csrc/shf_boxes.h): capsule pairs, one lane each, the active ones in the slots
+  // behind the sample points
+  int nself = 0;
+  if constexpr (SELF) nself = self_contacts_eval<G>(C, L, l, CD::NPC, mu_shape);
   GROUP_SYNC();
   PHASE_MARK(3);
 
@@ -449,6 +458,29 @@ DEV void chain_substep(const StepCtx& C, const ChainLds& L, int l, DofLane& X, c
       for (int j = 0; j < mine.n; j++) {
         if (!act.test(mine.slot(j))) continue;
         contact_accumulate_p(L.pt + (mine.i0 + j) * PT_STRIDE, dt, IA, pA);
+      }
+    }
+    if constexpr (SELF) {
+      // ... then the self-contacts of its body, slot order, +f on capsule a's body and -f on b's, each side scaled by
+      // 1 + (own mass) / (other mass) (oracle: self_scales)
+      for (int k = 0; k < nself; k++) {
+        const float* o = L.pt + (CD::NPC + k) * PT_STRIDE;
+        const int p = (int)o[PT_ON] - 1;
+        const int da = m->dyn[m->cap_body[m->pair_a[p]]], db = m->dyn[m->cap_body[m->pair_b[p]]];
+        if (da != myb && db != myb) continue;
+        const float ma = m->mass[da], mb = m->mass[db];
+        if constexpr (SPLIT) {
+          if (half == 0) {
+            if (da == myb) slot_accumulate_fb_half<0>(IA, pA, o, 1.0f, dt, 1.0f, 1.0f + ma / mb);
+            if (db == myb) slot_accumulate_fb_half<0>(IA, pA, o, -1.0f, dt, 1.0f, 1.0f + mb / ma);
+          } else {
+            if (da == myb) slot_accumulate_fb_half<1>(IA, pA, o, 1.0f, dt, 1.0f, 1.0f + ma / mb);
+            if (db == myb) slot_accumulate_fb_half<1>(IA, pA, o, -1.0f, dt, 1.0f, 1.0f + mb / ma);
+          }
+        } else {
+          if (da == myb) slot_accumulate_fb(IA, pA, o, 1.0f, dt, 1.0f, 1.0f + ma / mb);
+          if (db == myb) slot_accumulate_fb(IA, pA, o, -1.0f, dt, 1.0f, 1.0f + mb / ma);
+        }
       }
     }
     // links hand (IA, pA) to their chain lane; the root's go to the same kind of slot for the element-wise sum below
@@ -692,6 +724,11 @@ DEV void chain_substep(const StepCtx& C, const ChainLds& L, int l, DofLane& X, c
       if (last) { contact_out[3 * (myb + 1)] = fw[0]; contact_out[3 * (myb + 1) + 1] = fw[1]; contact_out[3 * (myb + 1) + 2] = fw[2]; }
     }
     GROUP_SYNC();
+    if constexpr (SELF) {
+      static_assert(!SELF || G >= CD::NB, "self_contact_forces: a lane per reported body");
+      self_contact_forces(C, L, l, CD::NPC, nself, contact_out);
+      GROUP_SYNC();
+    }
   }
   PHASE_MARK(9);
 }
@@ -757,12 +794,12 @@ DEV void chain_body_states(const ShfModel* m, const ChainLds& L, int l, const Do
 
 // ShifuVecEnv.step for the A1 task (env.py:85-106) on the chain mapping; the task glue after the physics is shared
 // with the body-mapped kernel (a1_post_step, shf_task.h).
-template <int G, class CD, bool TW>
+template <int G, class CD, bool TW, bool SELF = false>
 DEV void a1_chain_step_body(const A1Args& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NLK = CD::NLK, nb = CD::NB, nd = CD::ND, NR = (CD::NEV + G - 1) / G;
   PHASE_BEGIN();
-  float* stats_lds = smem + MODEL_WORDS + TASK_WORDS;
+  float* stats_lds = smem + CHAIN_MODEL_WORDS + TASK_WORDS;
   stats_block_init(stats_lds);
   const unsigned long long stats_step = stats_step_load(A.stats);
   const int epb = 256 / G, es = threadIdx.x / G, l = threadIdx.x % G;
@@ -781,14 +818,16 @@ DEV void a1_chain_step_body(const A1Args& A) {
     if (l < 13) pre_root = A.S.root[(size_t)e * 13 + l];
     if (l < nd) pre_act = raw_action(A, e, l, nd, stats_step);
   }
-  stage_block<(int)sizeof(ShfA1TaskParams)>(A.tp, smem + MODEL_WORDS);
-  const ShfModel* m = stage_model(A.S.model, smem);
-  const ShfA1TaskParams& tp = *reinterpret_cast<const ShfA1TaskParams*>(smem + MODEL_WORDS);
+  stage_block<(int)sizeof(ShfA1TaskParams)>(A.tp, smem + CHAIN_MODEL_WORDS);
+  stage_block<CHAIN_MODEL_BYTES>(A.S.model, smem);   // the model without its link-contact records (CHAIN_MODEL_BYTES)
+  __syncthreads();
+  const ShfModel* m = reinterpret_cast<const ShfModel*>(smem);
+  const ShfA1TaskParams& tp = *reinterpret_cast<const ShfA1TaskParams*>(smem + CHAIN_MODEL_WORDS);
   if (e >= n) return;
   const int H = tp.num_history, P = tp.num_height_points;
   const int nobs = 12 + 2 * nd + nd * H + P;
-  const int env_words = chain_lds_words<CD>(SCR_OBS + nobs);
-  ChainLds L = chain_lds_carve<CD>(smem + MODEL_WORDS + TASK_WORDS + STATS_LDS_WORDS + es * env_words);
+  const int env_words = chain_lds_words<CD>(SCR_OBS + nobs, SELF);
+  ChainLds L = chain_lds_carve<CD>(smem + CHAIN_MODEL_WORDS + TASK_WORDS + STATS_LDS_WORDS + es * env_words);
   float* scr = L.pt;
 
 #pragma unroll
@@ -837,7 +876,7 @@ DEV void a1_chain_step_body(const A1Args& A) {
       const float t = pg_ * (act + q0_ - X.q) - dg_ * X.qd;
       X.tau = rclampf(t, -lim_, lim_);
     }
-    chain_substep<G, CD, TW>(C, L, l, X, LP, mine, RL, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
+    chain_substep<G, CD, TW, SELF>(C, L, l, X, LP, mine, RL, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
                              (it == nsub - 1) ? L.xch : nullptr);
   }
   PHASE_RESET();

@@ -121,7 +121,7 @@ class FusedA1Env:
         # vec-step, profiles/r03_bench_terrain*.json) or lane = rigid body (mapping="body": any articulation, 32 lanes
         # for the A1, also 64; self-collision)
         if mapping is None:
-            mapping = "chain" if (not self_collision and group in (None, 16, 32)) else "body"
+            mapping = "chain" if (group in (None, 32) or (group == 16 and not self_collision)) else "body"
         if group is None:
             group = 32
         self.mapping, self.group = mapping, group

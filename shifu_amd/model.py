@@ -728,6 +728,17 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
             if (db > 0 and dyn[parent[db]] == da) or (da > 0 and dyn[parent[da]] == db):
                 continue
             pairs.append((i, j))
+    # pairs that are close in the rest pose (q = 0) first: the kernels test the pairs in rounds of one per lane and skip a
+    # round's closest-point search wave-wide when every pair in it is far apart (csrc/shf_boxes.h self_contacts_eval) --
+    # with the neighbours up front, the later rounds of a walking robot are all far.  (The order is part of the model: active
+    # pairs are folded in pair order by the oracle and the kernels alike.)
+    def _rest_gap(ij):
+        (ba, a0, a1, ra), (bb, b0, b1, rb) = capsules[ij[0]], capsules[ij[1]]
+        ca = p0[ba] + R0[ba] @ (0.5 * (np.asarray(a0, float) + np.asarray(a1, float)))
+        cb = p0[bb] + R0[bb] @ (0.5 * (np.asarray(b0, float) + np.asarray(b1, float)))
+        reach = 0.5 * (np.linalg.norm(np.asarray(a1, float) - np.asarray(a0, float)) + np.linalg.norm(np.asarray(b1, float) - np.asarray(b0, float))) + ra + rb
+        return round(float(np.linalg.norm(ca - cb) - reach), 4)
+    pairs.sort(key=lambda ij: (_rest_gap(ij), ij))
     if len(pairs) > _abi.MAX_PAIRS:
         if self_collision:
             raise AssertionError(f"{len(pairs)} self-collision pairs > SHF_MAX_PAIRS")

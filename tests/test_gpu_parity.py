@@ -875,7 +875,7 @@ def test_fused_step_generic_dimension_path(oracle, group):
     assert np.isfinite(bufs["obs"]).all()
 
 
-@pytest.mark.parametrize("group", [32, 16, "chain16"])
+@pytest.mark.parametrize("group", [32, 16, "chain16", "chain32", "chain32-self"])
 def test_trimesh_terrain_matches_oracle_bitwise(oracle, group):
     """the trimesh form of the terrain (vertical risers at steep steps; ShfTerrain.warped) -- simulate
     and the fused step against the oracle, on a terrain whose plateau and noise shift many vertices."""
@@ -885,8 +885,19 @@ def test_trimesh_terrain_matches_oracle_bitwise(oracle, group):
     from shifu_amd.isaacgym.terrain_utils import pack_trimesh_samples, trimesh_warp_map
     from shifu_amd.model import asset_path, compile_urdf
     rng = np.random.default_rng(31)
-    cm = H.a1_model() if group in (32, "chain16") else compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT,
-                                                        honour_dont_collapse=False)
+    # "chain32-self": the reference's effective A1 scene -- trimesh terrain (task_config.py:53) with every link colliding
+    # (units.py:68) -- on the chain-per-lane kernel
+    selfc = group == "chain32-self"
+    if selfc:
+        group = "chain32"
+    if selfc:
+        cm = compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT, self_collision=True)
+        for d in range(cm.blob.nd):
+            cm.blob.damping[d] = 0.5
+    elif group in (32, "chain16", "chain32"):
+        cm = H.a1_model()
+    else:
+        cm = compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT, honour_dont_collapse=False)
     sp = H.sim_params(angular_damping=0.5)
     tp = a1_task_params(cm, num_rows=4, num_cols=5, env_length=0.8)
     terr, hs = _terrain(rng, rows=80, cols=60, rough=True)
@@ -899,9 +910,11 @@ def test_trimesh_terrain_matches_oracle_bitwise(oracle, group):
     sim = _make_sim(cm, sp, n, terr, hs, group=group, warp=warp)
     assert sim.terrain.warped == 1 and sim.tensors[_abi.T_HEIGHTS].numel() == packed.size
     task = A1Task(sim, tp)
+    if selfc:
+        assert task.kernel_symbol() == "_Z10k_a1_chainILi32ELb1ELb1EE"
     _upload(sim, task, bufs)
     for it in range(60):
-        raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32) * 1.5
+        raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32) * (2.0 if selfc else 1.5)
         task.step(torch.from_numpy(raw).cuda())
         oracle.a1_step(cm.blob, sp, tp, n, 0, bufs, raw, terrain=terr, heights=packed)
         _compare(sim, task, bufs, f"step {it}")
@@ -984,7 +997,7 @@ def test_contact_kats_joint_limit_on_the_gpu(oracle):
 
 
 # -------------------------------------------------------------------- self-collision --
-@pytest.mark.parametrize("group,dyn", [(32, False), (32, True), (16, True)])
+@pytest.mark.parametrize("group,dyn", [(32, False), ("chain32", False), (32, True), (16, True)])
 def test_self_collision_matches_oracle_bitwise(oracle, group, dyn):
     """capsule-pair self-collision (collision filter 0, reference units.py:68) on the HIP path equals the
     oracle bit for bit -- gym.simulate from states with the legs folded through each other, then the fused A1 step with
@@ -1040,7 +1053,10 @@ def test_self_collision_matches_oracle_bitwise(oracle, group, dyn):
         task.step(torch.from_numpy(raw).cuda())
         oracle.a1_step(m, sp2, tp, 64, 0, bufs, raw, terrain=terr, heights=hs)
         _compare(sim, task, bufs, f"fused self-collision step {it}")
-    assert "self" in task.kernel_symbol() and ("DynDims" in task.kernel_symbol()) == dyn
+    if group == "chain32":     # the chain-per-lane kernel with the self-collision pass (round 4): k_a1_chain<32, TW, true>
+        assert task.kernel_symbol() == "_Z10k_a1_chainILi32ELb0ELb1EE"
+    else:
+        assert "self" in task.kernel_symbol() and ("DynDims" in task.kernel_symbol()) == dyn
 
 
 def test_velocity_drive_matches_oracle_bitwise(oracle):
