@@ -141,12 +141,17 @@ typedef struct ShfModel {
    *   (A) every contact sample point pt_* (box / hull vertices: radius 0; spheres, capsule ends: their radius) against
    *       every box actor, free or fixed, as a sphere against a box;
    *   (C) the rounded sph_* shapes against the FIXED boxes (against free ones they always are tested);
-   *   (B) the eight corners of every box actor against the articulation's box volumes abox_* (vertex in box).
-   * Vertex-face manifolds in both directions; edge-edge crossings are not detected.  Against a free box the contact
+   *   (B) the eight corners of every box actor against the articulation's box volumes abox_* (vertex in box);
+   *   (E) every box volume abox_* against every box actor, edge across edge: the separating-axis test over the 6 face
+   *       normals and the 9 edge cross products; when the axis of least overlap is a cross product (by a clear margin:
+   *       faces are preferred) the two boxes touch where one edge of each cross -- one contact there.
+   * Vertex-face manifolds in both directions plus the edge-edge point; an edge lying flat on a face (no vertex of either
+   * box inside the other) is still not detected.  The same edge-edge test runs between every free box actor and every
+   * fixed one.  Against a free box the contact
    * takes the consistent pair law (the box is eliminated exactly), against a fixed one the ground-contact law.  At most
    * SHF_MAX_LINK_CONTACTS are active per env and sub-step, in candidate order -- (body, box actor) pair by pair, body ascending
    * then box ascending; within a pair A (points ascending), C (shapes ascending), B (volume ascending, corner
-   * ascending) -- more are dropped and counted.  abox: centre and orientation in abox_body's frame. */
+   * ascending), E (volume ascending) -- more are dropped and counted.  abox: centre and orientation in abox_body's frame. */
   int32_t link_collide;
   int32_t nabox;
   int32_t bounds_ok; /* SHF_BOUNDS_MAGIC once shf_model_bounds() has filled bbox; anything else: the kernels test every candidate */

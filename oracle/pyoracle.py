@@ -62,6 +62,17 @@ def box_primitives(bR, bpos, h, pt, rad=0.0):
     return (bool(o[0]), float(o[1]), o[2:5].copy()), (float(o[5]), o[6:9].copy(), o[9:12].copy())
 
 
+def box_box_edge(RA, cA, hA, RB, cB, hB, offset=0.01, f64=True):
+    """box_box_edge (edge-edge contact of two oriented boxes by the separating-axis test): (hit, phi, n, r)."""
+    dt, ct, suf = (np.float64, C.c_double, "f64") if f64 else (np.float32, C.c_float, "f32")
+    a = np.concatenate([np.asarray(RA, dt).reshape(9), np.asarray(cA, dt), np.asarray(hA, dt), np.asarray(RB, dt).reshape(9),
+                        np.asarray(cB, dt), np.asarray(hB, dt), [offset]]).astype(dt).reshape(1, 31)
+    out = np.zeros((1, 8), dt)
+    getattr(lib(), "shf_oracle_box_box_edge_" + suf)(C.c_int(1), _p(a, ct), _p(out, ct))
+    o = out[0]
+    return bool(o[0]), float(o[1]), o[2:5].copy(), o[5:8].copy()
+
+
 def point_in_box(bR, bpos, h, pt):
     return box_primitives(bR, bpos, h, pt)[0]
 

@@ -41,17 +41,22 @@ DEV BoxLane box_lane_load(const ShfModel* m, int l) {
 }
 // ballots of one sub-step (fixed-scene path): the free box's corners against the terrain (bit c) and against the other
 // boxes (bit c * (NBX - 1) + t, t counting the other boxes in ascending order), sphere bit si
-struct BoxMasks { unsigned cplane = 0u; unsigned long long cbox = 0ull; unsigned spheres = 0u; int nlink = 0; };
+struct BoxMasks { unsigned cplane = 0u; unsigned long long cbox = 0ull; unsigned cedge = 0u; unsigned spheres = 0u; int nlink = 0; };
 // Next active corner slot in fold order -- corner ascending, within a corner the terrain (tg = 0) before the boxes
 // (tg = 1 + box, ascending): the order of the run-time path's flag scan and of the oracle's loops.
+// (ed: bit ks = the edge-edge slot against fixed box ks, which sits at corner ks, target 1 + KD)
 template <int NO, int KD>
-DEV bool corner_next(unsigned& pl, unsigned long long& bx, int* c, int* tg) {
-  if (!pl && !bx) return false;
+DEV bool corner_next(unsigned& pl, unsigned long long& bx, unsigned& ed, int* c, int* tg) {
+  if (!pl && !bx && !ed) return false;
   const int cp = pl ? __builtin_ctz(pl) : 64;
   const int jb = bx ? __builtin_ctzll(bx) : 64 * NO;
-  const int cb = jb / NO;
-  if (cp <= cb) { *c = cp; *tg = 0; pl &= pl - 1u; }
-  else { const int t = jb - cb * NO; *c = cb; *tg = 1 + t + (t >= KD ? 1 : 0); bx &= bx - 1ull; }
+  const int cb = jb / NO, tb = jb - cb * NO, tgb = 1 + tb + (tb >= KD ? 1 : 0);
+  const int ce = ed ? __builtin_ctz(ed) : 64;
+  // keys (corner, target): the smallest goes first
+  const int kp = cp * 8, kb = cb * 8 + tgb, ke = ce * 8 + 1 + KD;
+  if (kp <= kb && kp <= ke) { *c = cp; *tg = 0; pl &= pl - 1u; }
+  else if (kb <= ke) { *c = cb; *tg = tgb; bx &= bx - 1ull; }
+  else { *c = ce; *tg = 1 + KD; ed &= ed - 1u; }
   return true;
 }
 
@@ -584,6 +589,88 @@ DEV void segment_closest(const float* p1, const float* q1, const float* p2, cons
   for (int k = 0; k < 3; k++) { c1[k] = fmaf(d1[k], s, p1[k]); c2[k] = fmaf(d2[k], t, p2[k]); }
 }
 
+// Edge-edge contact of two oriented boxes by the separating-axis test: the oracle's box_box_edge, operation for operation
+// (A: the receiver, axes = columns of RA).  Run-time axis choices are selects, not indexed registers.
+DEV float sel3(int i, float x0, float x1, float x2) { return i == 0 ? x0 : (i == 1 ? x1 : x2); }
+DEV bool box_box_edge(const float* RA, const float* cA, const float* hA, const float* RB, const float* cB, const float* hB,
+                      float offset, float* phi, float* n, float* r) {
+  const float t[3] = {cA[0] - cB[0], cA[1] - cB[1], cA[2] - cB[2]};     // from B to A
+  float Rm[3][3], Q[3][3], tA[3], tB[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    tA[i] = fmaf(RA[6 + i], t[2], fmaf(RA[3 + i], t[1], RA[i] * t[0]));
+    tB[i] = fmaf(RB[6 + i], t[2], fmaf(RB[3 + i], t[1], RB[i] * t[0]));
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      Rm[i][j] = fmaf(RA[6 + i], RB[6 + j], fmaf(RA[3 + i], RB[3 + j], RA[i] * RB[j]));
+      Q[i][j] = fabsf(Rm[i][j]) + 1e-6f;
+    }
+  }
+  float amax = 0.0f;     // an axis of A within 0.8 degrees of an axis of B: the cross products repeat face normals
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) amax = rmaxf(amax, fabsf(Rm[i][j]));
+  if (amax > 0.9999f) return false;
+  float sface = -1e30f;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const float sa = fabsf(tA[i]) - (hA[i] + fmaf(hB[2], Q[i][2], fmaf(hB[1], Q[i][1], hB[0] * Q[i][0])));
+    const float sb = fabsf(tB[i]) - (hB[i] + fmaf(hA[2], Q[2][i], fmaf(hA[1], Q[1][i], hA[0] * Q[0][i])));
+    sface = rmaxf(sface, rmaxf(sa, sb));
+  }
+  if (!(sface < offset)) return false;
+  float sedge = -1e30f, sg = 1.0f, il = 1.0f;
+  int bi = -1, bj = -1;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const float l2 = fmaf(-Rm[i][j], Rm[i][j], 1.0f);
+      const float tl = fmaf(tA[i2], Rm[i1][j], -(tA[i1] * Rm[i2][j]));
+      const float ra = fmaf(hA[i1], Q[i2][j], hA[i2] * Q[i1][j]), rb = fmaf(hB[j1], Q[i][j2], hB[j2] * Q[i][j1]);
+      const float inv = rsqrt_spec(rmaxf(l2, 1e-4f));          // (the clamp only keeps the unused branch finite)
+      const float se = (fabsf(tl) - (ra + rb)) * inv;
+      if (l2 > 1e-4f && se > sedge) { sedge = se; bi = i; bj = j; sg = tl < 0.0f ? -1.0f : 1.0f; il = inv; }
+    }
+  }
+  if (bi < 0 || !(sedge < offset)) return false;
+  if (!(sedge > sface + fmaf(0.05f, fabsf(sface), 1e-5f))) return false;   // a face axis wins
+  const int i1 = (bi + 1) % 3, i2 = (bi + 2) % 3, j1 = (bj + 1) % 3, j2 = (bj + 2) % 3;
+  const float a[3] = {sel3(bi, RA[0], RA[1], RA[2]), sel3(bi, RA[3], RA[4], RA[5]), sel3(bi, RA[6], RA[7], RA[8])};
+  const float b[3] = {sel3(bj, RB[0], RB[1], RB[2]), sel3(bj, RB[3], RB[4], RB[5]), sel3(bj, RB[6], RB[7], RB[8])};
+  float nn[3];
+  cross3(a, b, nn);
+#pragma unroll
+  for (int k = 0; k < 3; k++) nn[k] = sg * il * nn[k];
+  float pA[3] = {cA[0], cA[1], cA[2]}, pB[3] = {cB[0], cB[1], cB[2]};
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int ka = q == 0 ? i1 : i2, kb = q == 0 ? j1 : j2;
+    const float ax[3] = {sel3(ka, RA[0], RA[1], RA[2]), sel3(ka, RA[3], RA[4], RA[5]), sel3(ka, RA[6], RA[7], RA[8])};
+    const float bx[3] = {sel3(kb, RB[0], RB[1], RB[2]), sel3(kb, RB[3], RB[4], RB[5]), sel3(kb, RB[6], RB[7], RB[8])};
+    const float hka = sel3(ka, hA[0], hA[1], hA[2]), hkb = sel3(kb, hB[0], hB[1], hB[2]);
+    const float sa = dot3(nn, ax) > 0.0f ? -hka : hka, sb = dot3(nn, bx) > 0.0f ? hkb : -hkb;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { pA[k] = fmaf(sa, ax[k], pA[k]); pB[k] = fmaf(sb, bx[k], pB[k]); }
+  }
+  const float w[3] = {pA[0] - pB[0], pA[1] - pB[1], pA[2] - pB[2]};
+  const float bb = sel3(bi, sel3(bj, Rm[0][0], Rm[0][1], Rm[0][2]), sel3(bj, Rm[1][0], Rm[1][1], Rm[1][2]), sel3(bj, Rm[2][0], Rm[2][1], Rm[2][2]));
+  const float d = dot3(a, w), e = dot3(b, w);
+  const float idn = il * il;
+  const float alpha = fmaf(bb, e, -d) * idn, beta = fmaf(-bb, d, e) * idn;
+  if (fabsf(alpha) > sel3(bi, hA[0], hA[1], hA[2]) || fabsf(beta) > sel3(bj, hB[0], hB[1], hB[2])) return false;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    r[k] = 0.5f * (fmaf(alpha, a[k], pA[k]) + fmaf(beta, b[k], pB[k]));
+    n[k] = nn[k];
+  }
+  *phi = sedge;
+  return true;
+}
+
 // One lane per capsule pair: pairs closer than the contact offset respond with the shared contact law; the active ones
 // are compacted, in pair order, into at most SHF_MAX_SELF_CONTACTS slots starting at slot `slot0` (their `on` word
 // holds pair index + 1), then folded into the two bodies (+f on a's, -f on b's).  Returns the number of active slots.
@@ -820,8 +907,8 @@ DEV int link_slots_on_box(const EnvLds& L, int link_slot0, int nlink, int kd) {
   return c;
 }
 // Candidates pair by pair (reported body ascending, box actor ascending; oracle boxes_pre "link contacts"); within a pair
-// three homogeneous passes -- (A) the body's sample points, (C) its rounded shapes when the box is fixed, (B) the box's
-// corners in the body's volumes -- one lane per candidate and round.
+// four homogeneous passes -- (A) the body's sample points, (C) its rounded shapes when the box is fixed, (B) the box's
+// corners in the body's volumes, (E) edge-edge crossings of its volumes with the box -- one lane per candidate and round.
 // Stage 0, the broad phase: one lane per body, its bounding box (ShfModel.bbox) against every box actor, two oriented
 // boxes tested along their six face normals; a pair separated by more than the contact offset (+ 1 cm) has no active
 // candidate in any family -- every shape of the body lies inside its box, and a corner of the box actor inside one of the
@@ -943,6 +1030,7 @@ DEV int link_contacts(const StepCtx& C, const EnvLds& L, int l, int slot0, float
       const float mu_pair = 0.5f * (mu_shape + bd.friction);
       const float hdiag = sqrtf(dot3(hh, hh));
       const int p0 = m->lc_range[b][0], pn = m->lc_range[b][1], a0 = m->lc_range[b][2], an = m->lc_range[b][3];
+      const int count0 = X.count;      // (E) runs only for a pair without an active vertex / rounded-shape contact
       PHASE_MARK(25);
       // (A) the body's sample points against the box, each a sphere
       for (int j = 0; j * G < pn; j++) {
@@ -1035,8 +1123,16 @@ DEV int link_contacts(const StepCtx& C, const EnvLds& L, int l, int slot0, float
         if (__ballot(slot[PT_ON] != 0.0f) != 0ull) link_append(X, slot, b, kd);
       }
       PHASE_MARK(27);
-      // (B) the box's corners inside the body's volumes: candidate q = volume * 8 + corner
-      for (int j = 0; j * G < an * 8; j++) {
+      // (B) the box's corners inside the body's volumes: candidate q = volume * 8 + corner; and behind them, in the same
+      // rounds, (E) an edge of one of the body's volumes across an edge of the box actor (box_box_edge): candidate
+      // q = 8 x volumes + volume -- only for a pair none of whose points / rounded shapes (A, C) is in contact
+#ifdef SHF_EXP_NO_ELINK   /* timing experiment only (tools/experiment.py) */
+      const bool edges = false;
+#else
+      const bool edges = mine && X.count == count0;
+#endif
+      const int nbe = an * 8 + ((__ballot(edges) != 0ull) ? an : 0);      // wave-uniform trip count
+      for (int j = 0; j * G < nbe; j++) {
         const int q = l + j * G;
         float slot[PT_STRIDE];
         slot[PT_ON] = 0.0f;
@@ -1074,6 +1170,30 @@ DEV int link_contacts(const StepCtx& C, const EnvLds& L, int l, int slot0, float
               vrel[k] = fmaf(dt, g_art[k], pa) - (dynb ? fmaf(dt, gb[k], pq) : pq);
             }
             slot_eval(slot, phi, nn, r, vrs, vrel, mu_pair, kc, beta, veps, vdep, dt, offset);
+          }
+        } else if (edges && q >= an * 8 && q < an * 9) {
+          const int jb = m->lc_abox[a0 + (q - an * 8)];
+          float lr[9], ar[9], ac[3];
+#pragma unroll
+          for (int k = 0; k < 9; k++) lr[k] = m->abox_rot[jb][k];
+          const float lp[3] = {m->abox_pos[jb][0], m->abox_pos[jb][1], m->abox_pos[jb][2]};
+          const float ah[3] = {m->abox_half[jb][0], m->abox_half[jb][1], m->abox_half[jb][2]};
+          mm3(Rb, lr, ar);
+          mv3(Rb, lp, ac);
+#pragma unroll
+          for (int k = 0; k < 3; k++) ac[k] += pb[9 + k];
+          float phi, n[3], r[3];
+          if (box_box_edge(ar, ac, ah, Rk, bpos, hh, offset, &phi, n, r)) {
+            float ta[3], tb[3], vrel[3], vrs[3];
+            cross3(va, r, ta);
+            cross3(vbx, r, tb);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+              const float pa = vla[k] + ta[k], pq = vlb[k] + tb[k];
+              vrs[k] = pa - pq;
+              vrel[k] = fmaf(dt, g_art[k], pa) - (dynb ? fmaf(dt, gb[k], pq) : pq);
+            }
+            slot_eval(slot, phi, n, r, vrs, vrel, mu_pair, kc, beta, veps, vdep, dt, offset);
           }
         }
         if (__ballot(slot[PT_ON] != 0.0f) != 0ull) link_append(X, slot, b, kd);
@@ -1196,12 +1316,46 @@ DEV void fixed_corner_slots(const StepCtx& C, const EnvLds& L, int l, BoxMasks& 
     BM.cbox |= ((__ballot(on) >> lane0) & gmask) << (j * G);
   }
   {
-    static_assert(G >= 8, "one lane per corner");
+    static_assert(G >= 8 + nbx, "one lane per corner, one per edge-edge slot");
     const bool valid = l < 8;
     bool on = false;
+    // lanes 8 .. 8 + NBX - 1: the free box's edge-edge contact with fixed box ks = l - 8 (box_box_edge), kept in the slot
+    // corner ks would have against its own box
+    bool eon = false;
+    if (l >= 8 && l < 8 + nbx && l - 8 != kd) {
+      const int ks = l - 8;
+      float* o = L.pt + corner_slot(Q, kd, ks, 1 + kd) * PT_STRIDE;
+      o[PT_ON] = 0.0f;
+      // a corner of the free box already in contact with box ks (a vertex-face situation): the edge test is not run
+      unsigned long long vmask = 0ull;
+#pragma unroll
+      for (int c = 0; c < 8; c++) vmask |= 1ull << (c * (NO > 0 ? NO : 1) + (ks - (ks > kd ? 1 : 0)));
+      const ShfBoxDesc& bs = S->box[ks];
+#ifdef SHF_EXP_NO_EBOX   /* timing experiment only (tools/experiment.py) */
+      if (false) {
+#else
+      if ((BM.cbox & vmask) == 0ull) {
+#endif
+      const float* ps = L.pose + (nb + ks) * POSE_STRIDE;
+      float Rs[9];
+#pragma unroll
+      for (int i = 0; i < 9; i++) Rs[i] = ps[i];
+      const float hd[3] = {0.5f * bd.dim[0], 0.5f * bd.dim[1], 0.5f * bd.dim[2]}, hs[3] = {0.5f * bs.dim[0], 0.5f * bs.dim[1], 0.5f * bs.dim[2]};
+      const float cs[3] = {ps[9], ps[10], ps[11]};
+      float phi, n[3], re[3], t[3], vs[3], vp[3];
+      if (box_box_edge(Rk, pcen, hd, Rs, cs, hs, offset, &phi, n, re)) {
+        cross3(vb, re, t);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { vs[i] = vlin[i] + t[i]; vp[i] = fmaf(dt, gb[i], vs[i]); }
+        slot_eval(o, phi, n, re, vs, vp, 0.5f * (bd.friction + bs.friction), kc, beta, veps, vdep, dt, offset);
+        eon = o[PT_ON] != 0.0f;
+      }
+      }
+    }
+    BM.cedge = (unsigned)(((__ballot(eon) >> lane0) & gmask) >> 8);
     if (valid) {
       float* o = L.pt + corner_slot(Q, kd, l, 0) * PT_STRIDE;
-      L.pt[corner_slot(Q, kd, l, 1 + kd) * PT_STRIDE + PT_ON] = 0.0f;   // the box against itself: never a contact
+      if (l >= nbx || l == kd) L.pt[corner_slot(Q, kd, l, 1 + kd) * PT_STRIDE + PT_ON] = 0.0f;   // no box l to cross edges with
       const float reach = 0.5f * sqrtf(fmaf(bd.dim[2], bd.dim[2], fmaf(bd.dim[1], bd.dim[1], bd.dim[0] * bd.dim[0])));
       // 1 % and a millimetre over the exact bound (the corner's own rounding cannot bridge it)
       const bool clear = C.terr.t.rows == 0 && (L.root[2] + pcen[2]) - reach * 1.01f - 1e-3f > offset;
@@ -1271,10 +1425,10 @@ DEV void fixed_box_fold(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, c
   const ShfModel* m = C.m;
   const SlotLay Q = slot_lay<SC>(m, C.scene);
   if (l == m->nb + F::kd) {
-    unsigned pl = BM.cplane;
+    unsigned pl = BM.cplane, ed = BM.cedge;
     unsigned long long bx = BM.cbox;
     int c, tg;
-    while (corner_next<F::NO, F::kd>(pl, bx, &c, &tg))
+    while (corner_next<F::NO, F::kd>(pl, bx, ed, &c, &tg))
       slot_accumulate(B.IA, B.pA, L.pt + corner_slot(Q, F::kd, c, tg) * PT_STRIDE, 1.0f, C.sp.dt, 1.0f);
   }
 }
@@ -1436,10 +1590,12 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
       terrain_query(C.terr, L.root[0] + r[0], L.root[1] + r[1], &h, n);
       phi = (L.root[2] + r[2] - h) * n[2];
       slot_eval(o, phi, n, r, vs, vp, 0.5f * (bd.friction + C.terr.t.friction), kc, beta, veps, vdep, dt, offset);
+    } else if (tg - 1 == kd) {
+      continue;       // the box against itself: this slot carries an edge-edge contact, evaluated below
     } else {
       const int ks = tg - 1;
       const ShfBoxDesc& bs = S->box[ks];
-      if (ks == kd || box_is_dynamic(bs)) continue;
+      if (box_is_dynamic(bs)) continue;
       const float* ps = L.pose + (nb + ks) * POSE_STRIDE;
       float Rs[9], hh[3] = {0.5f * bs.dim[0], 0.5f * bs.dim[1], 0.5f * bs.dim[2]}, bpos[3] = {ps[9], ps[10], ps[11]};
 #pragma unroll
@@ -1447,6 +1603,34 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
       if (!point_in_box(Rs, bpos, hh, r, &phi, n)) continue;
       slot_eval(o, phi, n, r, vs, vp, 0.5f * (bd.friction + bs.friction), kc, beta, veps, vdep, dt, offset);
     }
+  }
+  // edge-edge contacts of the free boxes with the fixed ones (oracle boxes_pre; box_box_edge): one per (free kd, fixed ks),
+  // kept in the slot corner ks of kd would have against its own box -- folded, reported and sized like any corner slot --
+  // and only when no corner of kd is in contact with ks (then it is a vertex-face situation)
+  GROUP_SYNC();
+  for (int idx = l; idx < nbx * nbx; idx += G) {
+    const int kd = idx / nbx, ks = idx % nbx;
+    const ShfBoxDesc& bd = S->box[kd];
+    const ShfBoxDesc& bs = S->box[ks];
+    if (ks == kd || ks >= 8 || !box_is_dynamic(bd) || box_is_dynamic(bs)) continue;
+    bool vertex = false;
+#pragma unroll
+    for (int c = 0; c < 8; c++) vertex = vertex || L.pt[corner_slot(Q, kd, c, 1 + ks) * PT_STRIDE + PT_ON] != 0.0f;
+    if (vertex) continue;
+    float* o = L.pt + corner_slot(Q, kd, ks, 1 + kd) * PT_STRIDE;
+    const float* pk = L.pose + (nb + kd) * POSE_STRIDE;
+    const float* ps = L.pose + (nb + ks) * POSE_STRIDE;
+    float Rk[9], Rs[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { Rk[i] = pk[i]; Rs[i] = ps[i]; }
+    const float hd[3] = {0.5f * bd.dim[0], 0.5f * bd.dim[1], 0.5f * bd.dim[2]}, hs[3] = {0.5f * bs.dim[0], 0.5f * bs.dim[1], 0.5f * bs.dim[2]};
+    const float cd[3] = {pk[9], pk[10], pk[11]}, cs[3] = {ps[9], ps[10], ps[11]}, vb[3] = {pk[12], pk[13], pk[14]};
+    float phi, n[3], re[3], t[3], vs[3], vp[3];
+    if (!box_box_edge(Rk, cd, hd, Rs, cs, hs, offset, &phi, n, re)) continue;
+    cross3(vb, re, t);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { vs[i] = pk[15 + i] + t[i]; vp[i] = fmaf(dt, gb[i], vs[i]); }
+    slot_eval(o, phi, n, re, vs, vp, 0.5f * (bd.friction + bs.friction), kc, beta, veps, vdep, dt, offset);
   }
   PHASE_MARK(17);
   // sphere slots
@@ -1668,11 +1852,11 @@ DEV void boxes_finish(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, flo
       if (dynbox) {
         unsigned sb;
         if constexpr (SC::NBX > 0) {
-          unsigned pl = BM.cplane;
+          unsigned pl = BM.cplane, ed = BM.cedge;
           unsigned long long bx = BM.cbox;
           int c, tg;
           sb = BM.spheres;
-          while (corner_next<SC::NBX - 1, SC::DYN>(pl, bx, &c, &tg))
+          while (corner_next<SC::NBX - 1, SC::DYN>(pl, bx, ed, &c, &tg))
             slot_force(L.pt + corner_slot(Q, kd, c, tg) * PT_STRIDE, a, 1.0f, dt, 1.0f, f);
         } else {
           unsigned long long cb = corner_flags(m, L, Q, kd);

@@ -79,11 +79,12 @@ BOX_PUSHER_URDF = """<robot name="boxpusher"><link name="rail"/>
   <limit effort="200" lower="-1" upper="1" velocity="10"/></joint></robot>"""
 
 
-def box_pusher_model(size=(0.06, 0.06, 0.06), centre=(0.0, 0.0, 0.05), axis="1 0 0", kd=2000.0, extra_shapes="", capsule=None):
+def box_pusher_model(size=(0.06, 0.06, 0.06), centre=(0.0, 0.0, 0.05), axis="1 0 0", kd=2000.0, extra_shapes="", capsule=None,
+                     shape_rpy=(0.0, 0.0, 0.0)):
     """A rail-mounted ram carrying box collision shape(s) (link contacts on: ShfModel.link_collide) -- the box-vs-box
     cases of SURVEY 8f f3 in their simplest setting.  Velocity drive on the slide."""
-    shapes = ('<collision><origin xyz="%g %g %g"/><geometry><box size="%g %g %g"/></geometry></collision>'
-              % (tuple(centre) + tuple(size))) if size is not None else ""
+    shapes = ('<collision><origin xyz="%g %g %g" rpy="%.17g %.17g %.17g"/><geometry><box size="%g %g %g"/></geometry></collision>'
+              % (tuple(centre) + tuple(shape_rpy) + tuple(size))) if size is not None else ""
     cm = _compile(BOX_PUSHER_URDF.format(shapes=shapes + extra_shapes, axis=axis), fix_base_link=True, disable_gravity=True,
                   default_dof_drive_mode=_abi.DOF_MODE_VEL, link_contacts=True,
                   extra_spheres=[("ram",) + tuple(capsule)] if capsule else ())

@@ -566,6 +566,73 @@ def test_link_contacts_match_oracle_bitwise(oracle, group):
         sim.destroy() if hasattr(sim, "destroy") else None
 
 
+@pytest.mark.parametrize("group", [16, 32, 64])
+def test_edge_edge_contacts_match_oracle_bitwise(oracle, group):
+    """SURVEY 8f f3, edge-edge box contact (box_box_edge: the separating-axis edge case), the GPU twin of
+    tests/test_link_contacts.py::test_a_box_rests_crosswise_on_another_boxs_edge: (1) a free bar set down crosswise, ridge to
+    ridge, on a fixed box turned 45 degrees -- no vertex of either inside the other, only the crossing edges carry it; (2) the
+    ram's box, turned 45 degrees about its travel axis, driven down onto the ridge of a fixed box turned 45 degrees the other
+    way: a link volume's edge across a box actor's edge (family E of the link contacts).  shf_sim_step against the oracle,
+    every tensor bit for bit, the envs of a wavefront perturbed; both scenes must have carried load through the edge slot."""
+    _need_gpu()
+    from shifu_amd.abb_task import box_desc
+    from tests import kat_models as K
+    from tests.test_link_contacts import _quat
+    sp = H.sim_params(angular_damping=0.5)
+    s2 = np.sqrt(2.0)
+    rng = np.random.default_rng(8)
+    # (1) bar on ridge
+    ridge = box_desc((0.4, 0.1, 0.1), 0.0, 0.8, True, (0.0, 0.0, 0.3), _quat([1, 0, 0], np.pi / 4))
+    bar = box_desc((0.1, 0.4, 0.1), 0.5, 0.8, False, (0.0, 0.0, 0.0), _quat([0, 1, 0], np.pi / 4))
+    cm = K.box_pusher_model(centre=(2.0, 0.0, 0.5))
+    m = cm.blob
+    n = 9
+    z0 = 0.3 + 0.1 * s2 + 0.002
+    sim, dof, root = _scene_on_gpu(cm, sp, [ridge, bar], [(0.0, 0.0, 0.3), (0.01, 0.0, z0)], n, group)
+    root[1::3, 3:7] = ridge.quat[:]
+    root[2::3, 3:7] = bar.quat[:]
+    root[2::3, 0] += rng.uniform(-0.05, 0.05, n).astype(np.float32)          # anywhere along the ridge
+    root[2::3, 1] += rng.uniform(-0.002, 0.002, n).astype(np.float32)        # slightly off balance: the bars tip over at different times
+    sim.tensors[_abi.T_SIM_ROOT].copy_(torch.from_numpy(root))
+    vt = np.zeros(n * m.nd, np.float32)
+    carried = 0
+    for it in range(150):
+        sim.set_dof_command(_abi.T_VEL_TARGET, torch.from_numpy(vt).cuda())
+        sim.step()
+        sim.refresh(_abi.REFRESH_ALL)
+        contact, bstate, _ = oracle.scene_step(m, sp, [ridge, bar], n, dof, root, vel_target=vt, friction=np.ones(n, np.float32))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(sim.tensors[_abi.T_ROOT_STATE].cpu().numpy(), root, err_msg=f"bar on ridge: root step {it}")
+        np.testing.assert_array_equal(sim.tensors[_abi.T_CONTACT].cpu().numpy(), contact, err_msg=f"bar on ridge: contact step {it}")
+        carried += int((contact.reshape(n, -1, 3)[:, m.nb + 1, 2] > 2.0).sum())
+    assert carried > 40 * n, carried                          # (m g = 4.9 N through the one edge-edge slot, for most of the run)
+    assert (root[2::3, 2] > 0.3).all()                        # nobody fell through the ridge
+    sim.destroy() if hasattr(sim, "destroy") else None
+    # (2) a link volume's edge across a fixed box's edge
+    cm = K.box_pusher_model(size=(0.3, 0.06, 0.06), centre=(0.0, 0.0, 0.5), axis="0 0 -1", shape_rpy=(np.pi / 4, 0.0, 0.0))
+    m = cm.blob
+    assert m.link_collide == 1 and m.nabox == 1
+    anvil = box_desc((0.06, 0.4, 0.06), 0.0, 0.5, True, (0.0, 0.0, 0.3), _quat([0, 1, 0], np.pi / 4))
+    sim, dof, root = _scene_on_gpu(cm, sp, [anvil], [(0.0, 0.0, 0.3)], n, group)
+    root[1::2, 3:7] = anvil.quat[:]
+    root[1::2, 0] += rng.uniform(-0.02, 0.02, n).astype(np.float32)
+    sim.tensors[_abi.T_SIM_ROOT].copy_(torch.from_numpy(root))
+    vt = (0.5 * rng.uniform(0.6, 1.0, n * m.nd)).astype(np.float32)
+    pushed = 0
+    for it in range(140):
+        sim.set_dof_command(_abi.T_VEL_TARGET, torch.from_numpy(vt).cuda())
+        sim.step()
+        sim.refresh(_abi.REFRESH_ALL)
+        contact, bstate, _ = oracle.scene_step(m, sp, [anvil], n, dof, root, vel_target=vt, friction=np.ones(n, np.float32))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(sim.tensors[_abi.T_DOF_STATE].cpu().numpy(), dof, err_msg=f"ram edge on ridge: dof step {it}")
+        np.testing.assert_array_equal(sim.tensors[_abi.T_CONTACT].cpu().numpy(), contact, err_msg=f"ram edge on ridge: contact step {it}")
+        pushed += int((contact.reshape(n, -1, 3)[:, m.nb - 1, 2] > 10.0).sum())
+    assert pushed > 20 * n, pushed
+    qd = dof.reshape(n, m.nd, 2)[:, 0, 1]
+    assert (np.abs(qd) < 0.05).all(), qd                      # stalled on the ridge (without the edge pass it sails through)
+
+
 @pytest.mark.parametrize("group", [16, 64])
 def test_capsule_line_contact_joint_law_matches_oracle_bitwise(oracle, group):
     """The capsule pusher of tests/test_contact_kats.py lying along the cube's face -- a line contact: two contact points

@@ -156,3 +156,93 @@ def test_box_primitives_against_brute_force(oracle):
             gap = (-(best[0]) if inside else best[0]) - rad
             assert abs(phs - gap) < 0.02 * float(h.max()) + 1e-9, (phs, gap, inside)        # grid resolution h / 40
             assert np.linalg.norm(R.T @ (rc - c) - best[1]) < 0.06 * float(h.max()) or inside
+
+
+def _rot(ax, a):
+    ax = np.asarray(ax, float)
+    Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    return np.eye(3) + np.sin(a) * Kx + (1 - np.cos(a)) * Kx @ Kx
+
+
+def _quat(ax, a):
+    ax = np.asarray(ax, float)
+    return tuple(np.sin(0.5 * a) * ax) + (float(np.cos(0.5 * a)),)
+
+
+def test_box_box_edge_against_brute_force(oracle):
+    """box_box_edge (the separating-axis edge case): on random pairs of oriented boxes, whenever it reports a contact the
+    normal is the common perpendicular of one edge of each box, unit, pointing from B to A; the reported gap equals the
+    signed distance between those two supporting edges along it; the contact point lies within |gap| of both boxes; and no
+    face axis has less overlap (the boxes' extents projected on the 6 face normals overlap by more than on the contact
+    normal).  Separated boxes (a face axis clears the offset) never report one."""
+    rng = np.random.default_rng(3)
+    hits = 0
+    for it in range(4000):
+        def rq():
+            q = rng.normal(size=4); q /= np.linalg.norm(q)
+            x, y, z, w = q
+            return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                             [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                             [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        RA, RB = rq(), rq()
+        hA, hB = rng.uniform(0.03, 0.3, 3), rng.uniform(0.03, 0.3, 3)
+        cB = rng.uniform(-0.2, 0.2, 3)
+        cA = cB + rng.normal(size=3) * 0.25
+        hit, phi, n, r = oracle.box_box_edge(RA, cA, hA, RB, cB, hB, 0.01)
+
+        def overlap(L):      # signed separation of the two boxes' projections on unit axis L (< 0: overlap)
+            return abs(L @ (cA - cB)) - (np.abs(RA.T @ L) @ hA + np.abs(RB.T @ L) @ hB)
+        faces = [overlap(RA[:, i]) for i in range(3)] + [overlap(RB[:, j]) for j in range(3)]
+        if max(faces) >= 0.01:
+            assert not hit
+            continue
+        if not hit:
+            continue
+        hits += 1
+        assert abs(np.linalg.norm(n) - 1.0) < 1e-9 and n @ (cA - cB) > 0
+        perp = sorted((abs(n @ RA[:, i]), i) for i in range(3))[0], sorted((abs(n @ RB[:, j]), j) for j in range(3))[0]
+        assert perp[0][0] < 1e-6 and perp[1][0] < 1e-6                        # perpendicular to one edge direction of each box
+        assert abs(phi - overlap(n)) < 2e-5 and phi < 0.01                      # (the 1e-6 added to |R| in the test inflates the radii slightly)
+        assert phi > max(faces)                                                  # the least-overlap axis is this one
+        for (Rm, c, h) in ((RA, cA, hA), (RB, cB, hB)):
+            d = Rm.T @ (r - c)
+            assert np.all(np.abs(d) <= h + abs(phi) + 1e-6)
+    assert hits > 150, hits
+
+
+def test_a_box_rests_crosswise_on_another_boxs_edge(oracle):
+    """Edge-edge contact: a fixed box turned 45 degrees about x shows a ridge along x; a free box turned 45
+    degrees about y is set down on it ridge to ridge, crosswise.  No vertex of either lies in the other -- the vertex-in-volume
+    families see nothing and the box would fall through -- the two edges cross at one point, which carries the weight: the
+    box stays, sagging m g / k into the ridge, with the contact force m g on its row.  (Balanced on a point it is an unstable
+    equilibrium; the float64 build holds it for the 0.6 s simulated here.)"""
+    cm = K.box_pusher_model(centre=(2.0, 0.0, 0.5))                            # an articulation far away (the scene needs one)
+    s2 = np.sqrt(2.0)
+    ridge = _box((0.4, 0.1, 0.1), 0.0, 0.8, True, (0.0, 0.0, 0.3))
+    ridge.quat[:] = _quat([1, 0, 0], np.pi / 4)
+    bar = _box((0.1, 0.4, 0.1), 0.5, 0.8, False, (0.0, 0.0, 0.0))
+    bar.quat[:] = _quat([0, 1, 0], np.pi / 4)
+    m, sp = cm.blob, sim_params()
+    top = 0.3 + 0.05 * s2                                                       # the ridge line
+    z0 = top + 0.05 * s2 + 0.002                                                 # bar's centre: its lower ridge 2 mm above
+    dof = np.zeros((m.nd, 2)); root = np.zeros((3, 13)); root[:, 6] = 1.0
+    root[0, :3] = (0, 0, 0)
+    root[1, :3] = (0.0, 0.0, 0.3); root[1, 3:7] = ridge.quat[:]
+    root[2, :3] = (0.01, 0.0, z0); root[2, 3:7] = bar.quat[:]        # centre of mass over the crossing point
+    zs = []
+    for it in range(120):
+        contact, _, _ = oracle.scene_step(m, sp, [ridge, bar], 1, dof, root, vel_target=np.zeros(m.nd), friction=np.ones(1, np.float32), f64=True)
+        zs.append(root[2, 2])
+    sag = 0.5 * K.G / K.K_N
+    assert abs(root[2, 2] - (top + 0.05 * s2 - sag)) < 3e-5, (root[2, 2], top + 0.05 * s2 - sag)
+    assert abs(root[2, 9]) < 1e-4 and np.abs(root[2, 10:13]).max() < 1e-3       # at rest, not rolling off (yet)
+    assert abs(contact[m.nb + 1][2] - 0.5 * K.G) < 0.01 * 0.5 * K.G and np.abs(contact[m.nb + 1][:2]).max() < 1e-3
+    assert min(zs) > top + 0.05 * s2 - 5 * sag - 1e-4                           # it never dipped through
+    # the counterfactual: the same drop with the ridge turned away (flat top 5 cm lower): it falls until the FACE contact
+    # (vertex-in-volume) catches it -- the two mechanisms hand over
+    flat = _box((0.4, 0.1, 0.1), 0.0, 0.8, True, (0.0, 0.0, 0.3))
+    root[1, 3:7] = (0, 0, 0, 1)
+    root[2, :3] = (0.01, 0.0, z0); root[2, 7:13] = 0.0
+    for it in range(160):
+        contact, _, _ = oracle.scene_step(m, sp, [flat, bar], 1, dof, root, vel_target=np.zeros(m.nd), friction=np.ones(1, np.float32), f64=True)
+    assert root[2, 2] < z0 - 0.015

@@ -13,7 +13,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-FLAGS = {"shuffle_handoff": ["-DSHF_EXP_SHUFFLE_HANDOFF"]}
+FLAGS = {"shuffle_handoff": ["-DSHF_EXP_SHUFFLE_HANDOFF"], "no_elink": ["-DSHF_EXP_NO_ELINK"], "no_ebox": ["-DSHF_EXP_NO_EBOX"],
+         "no_edge": ["-DSHF_EXP_NO_ELINK", "-DSHF_EXP_NO_EBOX"]}
 
 
 def lib(name):
