@@ -144,7 +144,8 @@ typedef struct ShfModel {
    *   (B) the eight corners of every box actor against the articulation's box volumes abox_* (vertex in box);
    *   (E) every box volume abox_* against every box actor, edge across edge: the separating-axis test over the 6 face
    *       normals and the 9 edge cross products; when the axis of least overlap is a cross product (by a clear margin:
-   *       faces are preferred) the two boxes touch where one edge of each cross -- one contact there.
+   *       faces are preferred; and never when an axis of one box lies within 10 degrees of an axis of the other) the two
+   *       boxes touch where one edge of each cross -- one contact there.
    * Vertex-face manifolds in both directions plus the edge-edge point; an edge lying flat on a face (no vertex of either
    * box inside the other) is still not detected.  The same edge-edge test runs between every free box actor and every
    * fixed one.  Against a free box the contact

@@ -606,12 +606,12 @@ DEV bool box_box_edge(const float* RA, const float* cA, const float* hA, const f
       Q[i][j] = fabsf(Rm[i][j]) + 1e-6f;
     }
   }
-  float amax = 0.0f;     // an axis of A within 0.8 degrees of an axis of B: the cross products repeat face normals
+  float amax = 0.0f;     // an axis of A within 10 degrees of an axis of B: the cross products nearly repeat face normals
 #pragma unroll
   for (int i = 0; i < 3; i++)
 #pragma unroll
     for (int j = 0; j < 3; j++) amax = rmaxf(amax, fabsf(Rm[i][j]));
-  if (amax > 0.9999f) return false;
+  if (amax > 0.985f) return false;
   float sface = -1e30f;
 #pragma unroll
   for (int i = 0; i < 3; i++) {
