@@ -1131,11 +1131,15 @@ DEV int link_contacts(const StepCtx& C, const EnvLds& L, int l, int slot0, float
 #else
       const bool edges = mine && X.count == count0;
 #endif
-      const int nbe = an * 8 + ((__ballot(edges) != 0ull) ? an : 0);      // wave-uniform trip count
+      // (when all corner candidates fit one round the edge tests ride in it, on the lanes of each volume's corner 0; otherwise
+      // they take the lanes behind the corners)
+      const bool oneround = an * 8 <= G;
+      const int nbe = an * 8 + ((!oneround && __ballot(edges) != 0ull) ? an : 0);      // wave-uniform trip count
       for (int j = 0; j * G < nbe; j++) {
         const int q = l + j * G;
-        float slot[PT_STRIDE];
+        float slot[PT_STRIDE], slotE[PT_STRIDE];
         slot[PT_ON] = 0.0f;
+        slotE[PT_ON] = 0.0f;
         if (mine && q < an * 8) {
           const int jb = m->lc_abox[a0 + (q >> 3)], cn = q & 7;
           float lr[9], ar[9], ac[3], r[3], tb[3];
@@ -1171,8 +1175,9 @@ DEV int link_contacts(const StepCtx& C, const EnvLds& L, int l, int slot0, float
             }
             slot_eval(slot, phi, nn, r, vrs, vrel, mu_pair, kc, beta, veps, vdep, dt, offset);
           }
-        } else if (edges && q >= an * 8 && q < an * 9) {
-          const int jb = m->lc_abox[a0 + (q - an * 8)];
+        }
+        if (edges && (oneround ? (q < an * 8 && (q & 7) == 0) : (q >= an * 8 && q < an * 9))) {
+          const int jb = m->lc_abox[a0 + (oneround ? (q >> 3) : (q - an * 8))];
           float lr[9], ar[9], ac[3];
 #pragma unroll
           for (int k = 0; k < 9; k++) lr[k] = m->abox_rot[jb][k];
@@ -1193,10 +1198,11 @@ DEV int link_contacts(const StepCtx& C, const EnvLds& L, int l, int slot0, float
               vrs[k] = pa - pq;
               vrel[k] = fmaf(dt, g_art[k], pa) - (dynb ? fmaf(dt, gb[k], pq) : pq);
             }
-            slot_eval(slot, phi, n, r, vrs, vrel, mu_pair, kc, beta, veps, vdep, dt, offset);
+            slot_eval(slotE, phi, n, r, vrs, vrel, mu_pair, kc, beta, veps, vdep, dt, offset);
           }
         }
         if (__ballot(slot[PT_ON] != 0.0f) != 0ull) link_append(X, slot, b, kd);
+        if (__ballot(slotE[PT_ON] != 0.0f) != 0ull) link_append(X, slotE, b, kd);
       }
       PHASE_MARK(28);
     }
