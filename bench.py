@@ -287,9 +287,9 @@ def main():
 
     abb = args.workload == "abb"
     if abb:
-        if args.link_contacts and (args.no_link_contacts or args.mapping in ("chain", "split")):
-            raise SystemExit("bench.py: --link-contacts contradicts --no-link-contacts / --mapping chain|split (compiled for the rod-only scene)")
-        args.link_contacts = not (args.no_link_contacts or args.mapping in ("chain", "split"))
+        if args.link_contacts and (args.no_link_contacts or args.mapping == "chain"):
+            raise SystemExit("bench.py: --link-contacts contradicts --no-link-contacts / --mapping chain (compiled for the rod-only scene)")
+        args.link_contacts = not (args.no_link_contacts or args.mapping == "chain")
         mapping = args.mapping or (("split" if (args.group or 16) == 16 else "chain") if (not args.link_contacts and (args.group or 16) < 64) else "body")
         group = args.group or 16
     else:    # the fused A1 env's own default: the chain-per-lane kernel at 32 lanes when there is no self-collision

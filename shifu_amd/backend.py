@@ -421,10 +421,12 @@ class AbbTask:
         if not fixed:
             return pre + "7DynDims"
         if link:    # the shipped arm with its link volumes in the shipped scene (AbbLinkDims, AbbScene)
+            if getattr(self.sim, "mapping", "body") == "split":
+                return "_Z13k_abb_step_wsILi512ELb1EE"
             return pre + "9FixedDimsILi7ELi6ELi59ELi6ELi6EE10FixedSceneILi3ELi1ELi2EELb1ELi0EE"
         mp = getattr(self.sim, "mapping", "body")
         if mp == "split":
-            return "_Z13k_abb_step_wsILi"
+            return "_Z13k_abb_step_wsILi256ELb0EE"
         arm = 6 if mp == "chain" else 0
         return pre + f"9FixedDimsILi7ELi6ELi3ELi6ELi6EE10FixedSceneILi3ELi1ELi2EELb0ELi{arm}EE"
 

@@ -50,7 +50,7 @@ BUDGETS = [("_Z16k_a1_step_a1_g32", 256, 0),          # default: A1, two envs pe
            ("_Z10k_a1_chainILi32ELb0E", 256, 0), ("_Z10k_a1_chainILi32ELb1E", 256, 0),   # (all four: height field / trimesh, without / with self-collision)
            ("_Z10k_a1_chainILi16ELb0E", 512, 0),      # four envs per wave = one wave per SIMD: no occupancy step to lose below 512
 
-           ("_Z13k_abb_step_wsILi256EE", 256, 0),
+           ("_Z13k_abb_step_wsILi256ELb0EE", 256, 0),
            # FusedAbbEnv's default since round 4: the arm with link contacts at 16 lanes per env, one wave per SIMD (all 4096 envs
            # resident: 16 envs per CU share the 160 KB of LDS) -- 512 registers, and the 20 B of scratch every body-mapped
            # ABB instantiation has had since round 3

@@ -10,6 +10,7 @@
 #include <initializer_list>
 #include <map>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 #include <vector>
 #include <algorithm>
@@ -654,10 +655,15 @@ __global__ __launch_bounds__(256, (G >= 32 && SC::NBX > 0) ? 2 : 1) void k_abb_s
 //     terrain-contact forces, arm contact rows,  |  pair forces, box solves, box contact rows,
 //     joint integration                          |  box integration
 // Same operations in the same order as the one-wave kernels (and the oracle): bit-identical results.
-template <int WT>
+// LINK: with link contacts (ShfModel.link_collide: the arm's 59 sample points, its box volumes and the rod against every box
+// actor) -- the box wave evaluates them (broad phase, candidate passes: csrc/shf_boxes.h link_contacts) between a barrier
+// S0' behind the arm's chain composition and S1, while the arm wave computes inertias and the 59 points' terrain contacts;
+// the arm wave then folds them with the rod slot.  512 threads = 16 envs per workgroup (one CU holds one: 9.2 KB of LDS per
+// env), two waves per SIMD.
+template <int WT, bool LINK = false>
 __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
   constexpr int G = 16, NL = 6, HALF = WT / 2, EPB = HALF / G;
-  typedef AbbDims DM;
+  typedef typename std::conditional<LINK, AbbLinkDims, AbbDims>::type DM;
   typedef AbbScene SC;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   PHASE_BEGIN();
@@ -674,12 +680,14 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
   const int n = A.S.n;
   const bool live = e < n;                       // no early return: every wave meets every workgroup barrier
   constexpr int nbx = SC::NBX, actors = 1 + nbx, nb = NL + 1, nd = NL, nbt = nb + nbx;
-  const int nslots = DM::np(m) + box_slot_count(nbx, 1, m->nsph);   // the fixed scene has one free box
+  const int link_slot0 = DM::np(m) + box_slot_count(nbx, 1, m->nsph);   // the fixed scene has one free box
+  const int nslots = link_slot0 + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0);
   const int env_words = env_lds_words(nbt, nd, nslots, ABB_TAIL_WORDS(nslots, nd), actors);
   EnvLds L = env_lds_carve(smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS + es * env_words, nbt, nd, nslots, actors);
   float* tgtl = L.pt + nslots * PT_STRIDE;       // POS targets of this env step
   float* krec = tgtl + ABB_TGT_WORDS(nd);
   unsigned* sphere_bits = reinterpret_cast<unsigned*>(krec + ARM_KREC_WORDS(NL));   // the rod slot's ballot, arm wave -> box wave
+  int* link_count = reinterpret_cast<int*>(sphere_bits + 1);                          // active link slots, box wave -> arm wave
 
   if (arm && live) {
     const float* dof = A.S.dof + (size_t)e * nd * 2;
@@ -696,7 +704,7 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
 
   StepCtx C;
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = scene;
-  C.dropped = nullptr;
+  C.dropped = (LINK && live && !arm && A.S.dropped) ? A.S.dropped + e : nullptr;   // (the box wave counts the dropped link contacts)
   const float mu = live ? A.S.friction[e] : 0.0f;
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
   LaneModel M;
@@ -715,41 +723,63 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
         GROUP_SYNC();
         AL.compose();
         GROUP_SYNC();
-        AL.inertia_and_points(B, mu);
+        if constexpr (!LINK) AL.inertia_and_points(B, mu);
       } else {
         boxes_pose<G>(C, L, l, B);
-        fixed_corner_slots<G, SC>(C, L, l, BM);
-        GROUP_SYNC();
-        fixed_box_fold<G, SC>(C, L, l, B, BM);
-        if (l == nb + SC::DYN) {                 // the free box with its own contacts folded in: what the pair law eliminates
-          float* o = L.xch + l * XCH_STRIDE;
-#pragma unroll
-          for (int k = 0; k < 21; k++) o[k] = B.IA[k];
-#pragma unroll
-          for (int k = 0; k < 6; k++) o[21 + k] = B.pA[k];
+        if constexpr (!LINK) {
+          fixed_corner_slots<G, SC>(C, L, l, BM);
+          GROUP_SYNC();
+          fixed_box_fold<G, SC>(C, L, l, B, BM);
         }
       }
+    }
+    if constexpr (LINK) {
+      __syncthreads();                           // S0': the arm's poses and the boxes' are in LDS for both waves
+      if (live) {
+        if (arm) {
+          AL.inertia_and_points(B, mu);
+        } else {
+          fixed_corner_slots<G, SC>(C, L, l, BM);
+          GROUP_SYNC();
+          fixed_box_fold<G, SC>(C, L, l, B, BM);
+          const int nl = link_contacts<G>(C, L, l, link_slot0, mu, AL.g);
+          if (l == 0) *link_count = nl;
+        }
+      }
+    }
+    if (live && !arm && l == nb + SC::DYN) {     // the free box with its own contacts folded in: what the pair law eliminates
+      float* o = L.xch + l * XCH_STRIDE;
+#pragma unroll
+      for (int k = 0; k < 21; k++) o[k] = B.IA[k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) o[21 + k] = B.pA[k];
     }
     PHASE_MARK(24);
     __syncthreads();                             // S1
     PHASE_MARK(25);
+    int nlink = 0;
+    unsigned lb = 0u;                            // link slots on the free box
+    if constexpr (LINK) {
+      if (live) { nlink = *link_count; lb = link_box_bits(L, link_slot0, nlink, SC::DYN); }
+    }
+    BM.nlink = nlink;
     if (live && arm) {
       fixed_sphere_slots<G, SC>(C, L, l, mu, AL.g, BM);
       GROUP_SYNC();                              // the capsule's two slots come from two lanes
       if (l == 0) {
         *sphere_bits = BM.spheres;
-        if (BM.spheres) {                        // rare: the pair laws on the lane that evaluated the slot
+        if (BM.spheres || lb) {                  // rare: the pair laws on the lane that evaluated the slot
           const float* o = L.xch + (nb + SC::DYN) * XCH_STRIDE;
           float IAb[21], pAb[6];
 #pragma unroll
           for (int k = 0; k < 21; k++) IAb[k] = o[k];
 #pragma unroll
           for (int k = 0; k < 6; k++) pAb[k] = o[21 + k];
-          fixed_pair_laws<G, SC>(C, L, true, IAb, pAb, BM.spheres);
+          fixed_pair_laws<G, SC>(C, L, true, IAb, pAb, BM.spheres, lb, link_slot0);
         }
       }
       GROUP_SYNC();
-      fixed_arm_fold<G, SC>(C, L, l, B, BL, BM.spheres);
+      fixed_arm_fold<G, SC>(C, L, l, B, BL, BM.spheres, nlink, lb, link_slot0);
       AL.hand_over(B);
       GROUP_SYNC();
       AL.recursions();
@@ -761,12 +791,12 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
     if (live) {
       if (arm) {
         if (contact_out) { AL.point_forces(contact_out); GROUP_SYNC(); }
-        boxes_finish<G, SC, 2>(C, L, l, B, contact_out, BL, BM, 0);
+        boxes_finish<G, SC, 2>(C, L, l, B, contact_out, BL, BM, link_slot0);
         AL.integrate();
         GROUP_SYNC();
       } else {
         BM.spheres = *sphere_bits;
-        boxes_finish<G, SC, 1>(C, L, l, B, contact_out, BL, BM, 0);
+        boxes_finish<G, SC, 1>(C, L, l, B, contact_out, BL, BM, link_slot0);
       }
     }
   }
@@ -1558,6 +1588,16 @@ static int abb_step_launch(ShfAbbTask* task, const float* raw_actions_dev, void*
   const int nbx = s->nboxes, nslots = s->model.np + box_slot_count(nbx, sim_ndyn(s), s->model.nsph) + (sim_link(s) ? 2 * SHF_MAX_LINK_CONTACTS : 0);
   const size_t lds = ((size_t)MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS +
                       (size_t)epb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, ABB_TAIL_WORDS(nslots, s->model.nd), 1 + nbx)) * 4;
+  if (sim_link(s) && s->mapping == SHF_MAP_CHAIN && s->mapping_split) {
+    // arm wave + box wave with the link contacts on the box wave: 512 threads = 16 envs per workgroup
+    if (!ArmChain<6>::matches(s->model) || !AbbLinkDims::matches(s->model) || !AbbScene::matches(s->nboxes, s->boxes, s->model.nsph) || s->group != 16)
+      return fail("shf_abb_step: the split mapping with link contacts needs the shipped arm (59 sample points), the table / cube / pad "
+                  "scene and 16 lanes per env");
+    const int wt = 512, wepb = wt / 32;
+    const size_t wlds = ((size_t)MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS +
+                         (size_t)wepb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, ABB_TAIL_WORDS(nslots, s->model.nd), 1 + nbx)) * 4;
+    return launch(k_abb_step_ws<512, true>, dim3((s->n + wepb - 1) / wepb), dim3(wt), wlds, stream, A);
+  }
   if (sim_link(s) && s->mapping != SHF_MAP_CHAIN && AbbLinkDims::matches(s->model) && AbbScene::matches(s->nboxes, s->boxes, s->model.nsph)) {
     // the shipped arm with its link volumes in the shipped scene: compile-time loop bounds, ballot-driven folds
     switch (s->group) {

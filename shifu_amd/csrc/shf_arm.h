@@ -39,8 +39,8 @@ struct ArmChain {
 // actors (k_abb_step_ws in shf_api.hip).  krec: ARM_KREC_WORDS(NL) floats of this env's LDS, 16-byte aligned.
 template <int G, class DM, int NL>
 struct ArmLane {
-  static_assert(DM::NPC > 0 && DM::NPC <= G && G < 64, "the arm's sample points take one round");
-  static constexpr int nb = NL + 1, nd = NL;
+  static_assert(DM::NPC > 0 && G < 64, "compile-time point count; lane groups inside one wavefront");
+  static constexpr int nb = NL + 1, nd = NL, NR = LANE_ROUNDS(G, DM);   // NR rounds of one sample point per lane
   const StepCtx& C;
   const EnvLds& L;
   float* krec;
@@ -49,7 +49,7 @@ struct ArmLane {
   const LanePoints<LANE_ROUNDS(G, DM)>& P;
   float g[3];
   bool islink;
-  unsigned long long active = 0ull;   // ballot of this sub-step's terrain contacts (bit i = sample point i)
+  unsigned long long active[LANE_ROUNDS(G, DM)];   // ballots of this sub-step's terrain contacts (round k, bit j = sample point k G + j)
 
   DEV ArmLane(const StepCtx& C_, const EnvLds& L_, float* krec_, int l_, const LaneModel& M_, const LanePoints<LANE_ROUNDS(G, DM)>& P_)
       : C(C_), L(L_), krec(krec_), l(l_), M(M_), P(P_) {
@@ -146,32 +146,37 @@ struct ArmLane {
     const float mu = 0.5f * (mu_shape + C.terr.t.friction);
     const ContactConsts K = {dt, {g[0], g[1], g[2]}, kc, beta, mu, veps, C.sp.max_depen_vel, C.sp.contact_offset};
     const int lane0 = (int)(threadIdx.x & 63u) - l;
-    {
-      const float* pb = L.pose + P.body(0) * POSE_STRIDE;
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+      const float* pb = L.pose + P.body(k) * POSE_STRIDE;
       float Rb[9], r[3], n[3], h, on = 0.0f;
 #pragma unroll
       for (int j = 0; j < 9; j++) Rb[j] = pb[j];
-      mv3(Rb, P.pos[0], r);
+      mv3(Rb, P.pos[k], r);
 #pragma unroll
       for (int j = 0; j < 3; j++) r[j] += pb[9 + j];
       terrain_query<false>(C.terr, L.root[0] + r[0], L.root[1] + r[1], &h, n);
-      const float phi = fmaf(L.root[2] + r[2] - h, n[2], -P.rad[0]);
-      if (l < DM::NPC) {
-        float* o = L.pt + l * PT_STRIDE;
-        if (phi < K.offset) on = contact_point_response(K, pb, r, n, P.rad[0], phi, o);
+      const float phi = fmaf(L.root[2] + r[2] - h, n[2], -P.rad[k]);
+      if (l + k * G < DM::NPC) {
+        float* o = L.pt + (l + k * G) * PT_STRIDE;
+        if (phi < K.offset) on = contact_point_response(K, pb, r, n, P.rad[k], phi, o);
         o[PT_ON] = on;
       }
-      active = (__ballot(on != 0.0f) >> lane0) & ((1ull << (G & 63)) - 1ull);
+      active[k] = (__ballot(on != 0.0f) >> lane0) & ((1ull << (G & 63)) - 1ull);
     }
     GROUP_SYNC();
     PHASE_MARK(3);
     if (islink) {
-      const int i0 = M.pt0, i1 = i0 + M.npt;
-      unsigned long long bits = i1 > i0 ? (active >> i0) & ((1ull << (i1 - i0)) - 1ull) : 0ull;
-      while (bits) {
-        const int j = __builtin_ctzll(bits);
-        bits &= bits - 1ull;
-        contact_accumulate(L.pt + (i0 + j) * PT_STRIDE, dt, B);
+      const int i0 = M.pt0, i1 = i0 + M.npt;     // the link's points, ascending -- whatever round evaluated them
+#pragma unroll
+      for (int k = 0; k < NR; k++) {
+        const int a0 = (i0 > k * G ? i0 : k * G) - k * G, a1 = (i1 < (k + 1) * G ? i1 : (k + 1) * G) - k * G;
+        unsigned long long bits = a1 > a0 ? (active[k] >> a0) & ((1ull << (a1 - a0)) - 1ull) : 0ull;
+        while (bits) {
+          const int j = __builtin_ctzll(bits);
+          bits &= bits - 1ull;
+          contact_accumulate(L.pt + (k * G + a0 + j) * PT_STRIDE, dt, B);
+        }
       }
     }
   }
@@ -238,19 +243,25 @@ struct ArmLane {
   // E. net terrain-contact force per reported body (contact_out: LDS, rows of 3).  A group sync has to follow.
   DEV void point_forces(float* contact_out) const {
     const ShfModel* m = C.m;
-    if ((active >> l) & 1ull) contact_force_final(L.pt + l * PT_STRIDE, L.acc + m->dyn[P.body(0)] * 6, C.sp.dt);
+#pragma unroll
+    for (int k = 0; k < NR; k++)
+      if ((active[k] >> l) & 1ull) contact_force_final(L.pt + (l + k * G) * PT_STRIDE, L.acc + m->dyn[P.body(k)] * 6, C.sp.dt);
     GROUP_SYNC();
     if (l < nb) {
       float f[3] = {0.0f, 0.0f, 0.0f};
       const int dl = m->dyn[l];
       const int i0 = m->pt_start[dl], i1 = i0 + m->pt_count[dl];
-      unsigned long long bits = i1 > i0 ? (active >> i0) & ((1ull << (i1 - i0)) - 1ull) : 0ull;
-      while (bits) {
-        const int i = i0 + __builtin_ctzll(bits);
-        bits &= bits - 1ull;
-        if (m->pt_body[i] != l) continue;
-        const float* o = L.pt + i * PT_STRIDE;
-        f[0] += o[PT_F]; f[1] += o[PT_F + 1]; f[2] += o[PT_F + 2];
+#pragma unroll
+      for (int k = 0; k < NR; k++) {
+        const int a0 = (i0 > k * G ? i0 : k * G) - k * G, a1 = (i1 < (k + 1) * G ? i1 : (k + 1) * G) - k * G;
+        unsigned long long bits = a1 > a0 ? (active[k] >> a0) & ((1ull << (a1 - a0)) - 1ull) : 0ull;
+        while (bits) {
+          const int i = k * G + a0 + __builtin_ctzll(bits);
+          bits &= bits - 1ull;
+          if (m->pt_body[i] != l) continue;
+          const float* o = L.pt + i * PT_STRIDE;
+          f[0] += o[PT_F]; f[1] += o[PT_F + 1]; f[2] += o[PT_F + 2];
+        }
       }
       contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2];
     }

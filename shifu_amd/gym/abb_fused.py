@@ -24,10 +24,10 @@ class FusedAbbEnv:
         # link_contacts: the arm's links (box stand-ins for their mesh colliders) and the rod also collide with the table,
         # the cube and the goal pad (ShfModel.link_collide) -- the reference's scene (every shape of an env
         # collides, units.py:68), what `AbbPushBox` through the gym facade does too, and the default here since round 4.
-        # False: the rod against the cube only (the scene benchmarked in rounds 1-3); also what the 'chain' / 'split'
-        # mappings are compiled for, so asking for one of those without saying otherwise means the rod-only scene.
+        # False: the rod against the cube only (the scene benchmarked in rounds 1-3); also what the 'chain' mapping
+        # is compiled for, so asking for it without saying otherwise means the rod-only scene ('split' exists for both).
         if link_contacts is None:
-            link_contacts = mapping not in ("chain", "split")
+            link_contacts = mapping != "chain"
         self.link_contacts = bool(link_contacts)
         self.cm = abb_model(link_contacts=link_contacts)
         if group is None:

@@ -723,7 +723,7 @@ _ABB_T = {"actions": _abi.ABB_ACTIONS, "obs": _abi.ABB_OBS, "rew": _abi.ABB_REW,
 
 
 @pytest.mark.parametrize("group,generic", [(64, False), (32, False), (16, False), (16, "chain"), (32, "levels"), (16, "levels"), (32, True),
-                                           (64, True), (16, "link"), (32, "link"), (64, "link"), (32, "link-generic")])
+                                           (64, True), (16, "link"), (16, "link-split"), (32, "link"), (64, "link"), (32, "link-generic")])
 def test_fused_abb_step_matches_oracle_bitwise(oracle, group, generic):
     """ShifuVecEnv.step for AbbPushBox (config 5): in-kernel damped-least-squares IK on the Jacobian
     tensor, 6 sub-steps with implicit POS drives and box contacts, refresh, termination, rewards,
@@ -739,7 +739,8 @@ def test_fused_abb_step_matches_oracle_bitwise(oracle, group, generic):
     # ("link": the shipped arm and scene, compile-time shaped -- the default of FusedAbbEnv since round 4; "link-generic": a
     # fourth box puts the same on the run-time-shaped instantiation)
     link_generic = generic == "link-generic"
-    link = generic == "link" or link_generic
+    link_split = generic == "link-split"          # arm wave + box wave, the link passes on the box wave (k_abb_step_ws<512, true>)
+    link = generic in ("link", "link-split") or link_generic
     # "levels": the compile-time arm and scene on the level-by-level sub-step (mapping 'body'); False at 16 / 32 lanes takes
     # the default, the arm's recursions on one lane (csrc/shf_arm.h)
     levels = generic == "levels"
@@ -749,10 +750,11 @@ def test_fused_abb_step_matches_oracle_bitwise(oracle, group, generic):
     split = generic is False and group == 16
     generic = generic is True or link_generic
     extra = [box_desc([0.05, 0.05, 0.02], 0.0, 0.5, True, [0.25, 0.25, 0.11])] if generic else []
-    env = FusedAbbEnv(num_envs=n, seed=11, group=group, extra_boxes=extra, link_contacts=link, mapping="body" if levels else ("chain" if chain else None))
-    assert env.mapping == ("split" if split else "chain" if (not generic and not link and not levels and group < 64) else "body")
-    assert ("FixedDims" in env.task.kernel_symbol() or split) != bool(generic)
-    assert ("Lb1ELi0EE" in env.task.kernel_symbol()) == (link and not generic)
+    env = FusedAbbEnv(num_envs=n, seed=11, group=group, extra_boxes=extra, link_contacts=link,
+                      mapping="body" if (levels or (link and not link_split)) else ("chain" if chain else ("split" if link_split else None)))
+    assert env.mapping == ("split" if (split or link_split) else "chain" if (not generic and not link and not levels and group < 64) else "body")
+    assert ("FixedDims" in env.task.kernel_symbol() or split or link_split) != bool(generic)
+    assert ("Lb1ELi0EE" in env.task.kernel_symbol()) == (link and not generic and not link_split)
     assert env.task.kernel_symbol().endswith("Li6EE") == (env.mapping == "chain")
     env.task.tensors[_abi.ABB_EP_LEN].copy_(torch.randint(0, 200, (n,)))   # staggered time-outs
     torch.cuda.synchronize()

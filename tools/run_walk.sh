@@ -2,12 +2,12 @@
 # On the GPU box (gpurun): the reference's A1 training schedule (A1PPOConfig.runner.max_iterations = 3000, 24 steps x 4096
 # envs per iteration; usage: run_walk.sh [iterations] [torch|mfma]; reference README.md:49 "A1 conditional walking ... 47.97 minutes") on the fused env, then the
 # deterministic policy rolled for 500 steps (run_mode='play').  Checkpoints stay in /tmp (they exceed what gpurun copies
-# back); the curve, the final model and the play reports land in gpurun_out/train_a1_r02/.
+# back); the curve, the final model and the play reports land in gpurun_out/train_a1_r04/.
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 ITERS=${1:-3000}
 MLP=${2:-torch}        # torch: stock fp32 GEMMs; mfma: csrc/shf_mlp.hip layers + captured PPO update
-OUT=$REPO/gpurun_out/train_a1_r02_$MLP
+OUT=$REPO/gpurun_out/train_a1_r04_$MLP
 mkdir -p "$OUT" /tmp/train_a1
 cd "$REPO"
 python tools/train_a1.py --iters "$ITERS" --graph --quiet --mlp "$MLP" --log /tmp/train_a1 > "$OUT/train_summary.json" 2> "$OUT/train.err"
