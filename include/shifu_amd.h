@@ -318,10 +318,12 @@ int shf_sim_set_group(ShfSim* sim, int32_t lanes);
  * recursions run link after link on the chain's lane.  Two shapes are compiled: a floating root with 4 serial chains of
  * 3 revolute links that end in one welded body -- the Unitree A1, single actor (csrc/shf_chain.h; call before
  * shf_sim_set_group) -- and a fixed base with one chain of 6 revolute links -- the ABB arm in its table / cube / pad
- * scene (csrc/shf_arm.h; shf_abb_step checks the scene).  No self-collision or link contacts; 16 or 32 lanes per env.
- * Same results bit for bit either way.  Not part of the reference API: a tuning knob.  Fails for another shape. */
+ * scene (csrc/shf_arm.h; shf_abb_step checks the scene).  The A1's chain mapping also runs with self-collision (32 lanes
+ * per env) and on the trimesh terrain; the arm's not with link contacts (but see SHF_MAP_CHAIN_SPLIT).  16 or 32 lanes per
+ * env.  Same results bit for bit either way.  Not part of the reference API: a tuning knob.  Fails for another shape. */
 /* SHF_MAP_CHAIN_SPLIT (the ABB arm at 16 lanes per env only): the chain mapping with the arm and the box actors of an env
- * on different wavefronts of one workgroup, synchronised by workgroup barriers (csrc/shf_api.hip: k_abb_step_ws). */
+ * on different wavefronts of one workgroup, synchronised by workgroup barriers (csrc/shf_api.hip: k_abb_step_ws); with
+ * link contacts (ShfModel.link_collide) the box wave evaluates them, 16 envs per 512-thread workgroup. */
 enum { SHF_MAP_BODY = 0, SHF_MAP_CHAIN = 1, SHF_MAP_CHAIN_SPLIT = 2 };
 int shf_sim_set_mapping(ShfSim* sim, int32_t mapping);
 

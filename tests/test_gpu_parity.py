@@ -881,8 +881,12 @@ def test_split_mapping_is_refused_for_other_shapes():
     from shifu_amd.gym.abb_fused import FusedAbbEnv
     with pytest.raises(BackendError, match="split chain mapping"):
         FusedA1Env(num_envs=8, group=16, mapping="split")
-    env = FusedAbbEnv(num_envs=8, group=16, mapping="split", extra_boxes=[box_desc([0.05, 0.05, 0.02], 0.0, 0.5, True, [0.25, 0.25, 0.11])])
+    extra = [box_desc([0.05, 0.05, 0.02], 0.0, 0.5, True, [0.25, 0.25, 0.11])]
+    env = FusedAbbEnv(num_envs=8, group=16, mapping="split", link_contacts=False, extra_boxes=extra)
     with pytest.raises(BackendError, match="chain mapping needs"):
+        env.task.step(torch.zeros(8, 3, device="cuda"))
+    env = FusedAbbEnv(num_envs=8, group=16, mapping="split", link_contacts=True, extra_boxes=extra)     # (k_abb_step_ws<512, true>)
+    with pytest.raises(BackendError, match="split mapping with link contacts needs"):
         env.task.step(torch.zeros(8, 3, device="cuda"))
 
 
