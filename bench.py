@@ -290,7 +290,7 @@ def main():
         if args.link_contacts and (args.no_link_contacts or args.mapping == "chain"):
             raise SystemExit("bench.py: --link-contacts contradicts --no-link-contacts / --mapping chain (compiled for the rod-only scene)")
         args.link_contacts = not (args.no_link_contacts or args.mapping == "chain")
-        mapping = args.mapping or (("split" if (args.group or 16) == 16 else "chain") if (not args.link_contacts and (args.group or 16) < 64) else "body")
+        mapping = args.mapping or ("split" if (args.group or 16) == 16 else ("chain" if (not args.link_contacts and (args.group or 16) == 32) else "body"))
         group = args.group or 16
     else:    # the fused A1 env's own default: the chain-per-lane kernel at 32 lanes when there is no self-collision
         mapping = args.mapping or ("chain" if ((args.group or 32) == 32 or ((args.group or 32) == 16 and not args.self_collision)) else "body")

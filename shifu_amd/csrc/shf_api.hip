@@ -575,6 +575,7 @@ DEV void abb_post_step(const AbbArgs& A, const ShfAbbTaskParams& tp, const ShfMo
 // (sized to the word: two workgroups of the two-wave kernel have to share a CU's 160 KiB)
 #define SHF_ARM_MAX_LINKS 6
 #define ABB_TGT_WORDS(nd) (((nd) + 2 + 3) & ~3)                     /* POS targets + the end effector's x, y */
+#define WS_LINK_STASH_WORDS 28   /* k_abb_step_ws<512, true>: the free box's (IA, pA) parked per env */
 #define ABB_TAIL_WORDS(nslots, nd) ((nslots) * PT_STRIDE + ABB_TGT_WORDS(nd) + ARM_KREC_WORDS(SHF_ARM_MAX_LINKS) + 4)
 template <int G, class DM, class SC, bool LINK = false, int ARM = 0>
 __global__ __launch_bounds__(256, (G >= 32 && SC::NBX > 0) ? 2 : 1) void k_abb_step(AbbArgs A) {
@@ -682,12 +683,15 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
   constexpr int nbx = SC::NBX, actors = 1 + nbx, nb = NL + 1, nd = NL, nbt = nb + nbx;
   const int link_slot0 = DM::np(m) + box_slot_count(nbx, 1, m->nsph);   // the fixed scene has one free box
   const int nslots = link_slot0 + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0);
-  const int env_words = env_lds_words(nbt, nd, nslots, ABB_TAIL_WORDS(nslots, nd), actors);
+  const int env_words = env_lds_words(nbt, nd, nslots, ABB_TAIL_WORDS(nslots, nd) + (LINK ? WS_LINK_STASH_WORDS : 0), actors);
   EnvLds L = env_lds_carve(smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS + es * env_words, nbt, nd, nslots, actors);
   float* tgtl = L.pt + nslots * PT_STRIDE;       // POS targets of this env step
   float* krec = tgtl + ABB_TGT_WORDS(nd);
   unsigned* sphere_bits = reinterpret_cast<unsigned*>(krec + ARM_KREC_WORDS(NL));   // the rod slot's ballot, arm wave -> box wave
   int* link_count = reinterpret_cast<int*>(sphere_bits + 1);                          // active link slots, box wave -> arm wave
+  // LINK: the free box's folded (IA, pA), parked while the box wave runs the link passes (the exchange slot the pair law reads
+  // them from is overwritten by a joint-law record) -- 27 accumulators less in the box wave's registers across link_contacts
+  float* box_stash = reinterpret_cast<float*>(sphere_bits + 4);
 
   if (arm && live) {
     const float* dof = A.S.dof + (size_t)e * nd * 2;
@@ -707,52 +711,89 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
   C.dropped = (LINK && live && !arm && A.S.dropped) ? A.S.dropped + e : nullptr;   // (the box wave counts the dropped link contacts)
   const float mu = live ? A.S.friction[e] : 0.0f;
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
+  // Per-lane model constants.  Without link contacts they are loaded once and stay in registers.  With them the kernel has 256
+  // registers (two waves per SIMD) and the box wave's link passes need most: the arm wave re-reads its constants from the LDS
+  // model at the head of each of its phases (WS_ARM_LOCALS), so that they are not live across the other wave's code.
+  constexpr int NRP = LANE_ROUNDS(G, DM);
   LaneModel M;
-  lane_model_load<DM>(m, l, M);
-  LanePoints<LANE_ROUNDS(G, DM)> P;
-  lane_points_load<G>(m, DM::np(m), l, P);
+  LanePoints<NRP> P;
+  if constexpr (!LINK) {
+    lane_model_load<DM>(m, l, M);
+    lane_points_load<G>(m, DM::np(m), l, P);
+  }
+#define WS_ARM_LOCALS()                                  \
+  LaneModel Ml;                                          \
+  lane_model_load<DM>(m, l, Ml);                         \
+  LanePoints<NRP> Pl;                                    \
+  lane_points_load<G>(m, DM::np(m), l, Pl);              \
+  ArmLane<G, DM, NL> ALl(C, L, krec, l, Ml, Pl)
   const BoxLane BL = box_lane_load(m, l);
-  ArmLane<G, DM, NL> AL(C, L, krec, l, M, P);
+  ArmLane<G, DM, NL> AL(C, L, krec, l, M, P);    // (LINK: used for its gravity vector only)
+  unsigned long long act[NRP];                   // LINK: the terrain-contact ballots, from the points phase to the force phase
+#pragma unroll
+  for (int k = 0; k < NRP; k++) act[k] = 0ull;
   BodyRegs B;                                    // arm wave: the lane's link; box wave: the lane's box
   BoxMasks BM;
   for (int it = 0; it < nsub; it++) {
     float* contact_out = it == nsub - 1 ? L.xch : nullptr;   // reported for the last sub-step only
-    if (live) {
-      if (arm) {
-        AL.joints_and_drives(tgtl);
-        GROUP_SYNC();
-        AL.compose();
-        GROUP_SYNC();
-        if constexpr (!LINK) AL.inertia_and_points(B, mu);
-      } else {
-        boxes_pose<G>(C, L, l, B);
-        if constexpr (!LINK) {
+    if constexpr (!LINK) {
+      if (live) {
+        if (arm) {
+          AL.joints_and_drives(tgtl);
+          GROUP_SYNC();
+          AL.compose();
+          GROUP_SYNC();
+          AL.inertia_and_points(B, mu);
+        } else {
+          boxes_pose<G>(C, L, l, B);
           fixed_corner_slots<G, SC>(C, L, l, BM);
           GROUP_SYNC();
           fixed_box_fold<G, SC>(C, L, l, B, BM);
         }
       }
-    }
-    if constexpr (LINK) {
-      __syncthreads();                           // S0': the arm's poses and the boxes' are in LDS for both waves
+    } else {
       if (live) {
         if (arm) {
-          AL.inertia_and_points(B, mu);
+          WS_ARM_LOCALS();
+          ALl.joints_and_drives(tgtl);
+          GROUP_SYNC();
+          ALl.compose();
+          GROUP_SYNC();
         } else {
+          boxes_pose<G>(C, L, l, B);             // (the boxes' own contacts need no arm pose: done beside the arm's composition)
           fixed_corner_slots<G, SC>(C, L, l, BM);
           GROUP_SYNC();
           fixed_box_fold<G, SC>(C, L, l, B, BM);
+          if (l == nb + SC::DYN) {               // the free box with its own contacts folded in: for the pair law, and parked
+            float* o = L.xch + l * XCH_STRIDE;
+#pragma unroll
+            for (int k = 0; k < 21; k++) { o[k] = B.IA[k]; box_stash[k] = B.IA[k]; }
+#pragma unroll
+            for (int k = 0; k < 6; k++) { o[21 + k] = B.pA[k]; box_stash[21 + k] = B.pA[k]; }
+          }
+        }
+      }
+      __syncthreads();                           // S0': the arm's poses and the boxes' are in LDS for both waves
+      if (live) {
+        if (arm) {
+          WS_ARM_LOCALS();
+          ALl.inertia_and_points(B, mu);
+#pragma unroll
+          for (int k = 0; k < NRP; k++) act[k] = ALl.active[k];
+        } else {
           const int nl = link_contacts<G>(C, L, l, link_slot0, mu, AL.g);
           if (l == 0) *link_count = nl;
         }
       }
     }
-    if (live && !arm && l == nb + SC::DYN) {     // the free box with its own contacts folded in: what the pair law eliminates
-      float* o = L.xch + l * XCH_STRIDE;
+    if constexpr (!LINK) {
+      if (live && !arm && l == nb + SC::DYN) {   // the free box with its own contacts folded in: what the pair law eliminates
+        float* o = L.xch + l * XCH_STRIDE;
 #pragma unroll
-      for (int k = 0; k < 21; k++) o[k] = B.IA[k];
+        for (int k = 0; k < 21; k++) o[k] = B.IA[k];
 #pragma unroll
-      for (int k = 0; k < 6; k++) o[21 + k] = B.pA[k];
+        for (int k = 0; k < 6; k++) o[21 + k] = B.pA[k];
+      }
     }
     PHASE_MARK(24);
     __syncthreads();                             // S1
@@ -780,7 +821,7 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
       }
       GROUP_SYNC();
       fixed_arm_fold<G, SC>(C, L, l, B, BL, BM.spheres, nlink, lb, link_slot0);
-      AL.hand_over(B);
+      AL.hand_over(B);                           // (uses no model constants: AL serves both variants here)
       GROUP_SYNC();
       AL.recursions();
       GROUP_SYNC();
@@ -790,12 +831,33 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
     PHASE_MARK(27);
     if (live) {
       if (arm) {
-        if (contact_out) { AL.point_forces(contact_out); GROUP_SYNC(); }
-        boxes_finish<G, SC, 2>(C, L, l, B, contact_out, BL, BM, link_slot0);
-        AL.integrate();
-        GROUP_SYNC();
+        if constexpr (LINK) {
+          WS_ARM_LOCALS();
+#pragma unroll
+          for (int k = 0; k < NRP; k++) ALl.active[k] = act[k];
+          if (contact_out) { ALl.point_forces(contact_out); GROUP_SYNC(); }
+          boxes_finish<G, SC, 2>(C, L, l, B, contact_out, BL, BM, link_slot0);
+          ALl.integrate();
+          GROUP_SYNC();
+        } else {
+          if (contact_out) { AL.point_forces(contact_out); GROUP_SYNC(); }
+          boxes_finish<G, SC, 2>(C, L, l, B, contact_out, BL, BM, link_slot0);
+          AL.integrate();
+          GROUP_SYNC();
+        }
       } else {
         BM.spheres = *sphere_bits;
+        if constexpr (LINK) {                     // the box lane's state back from LDS (it was not kept across the link passes)
+          if (l == nb + SC::DYN) {
+#pragma unroll
+            for (int k = 0; k < 21; k++) B.IA[k] = box_stash[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) B.pA[k] = box_stash[21 + k];
+            const float* pk = L.pose + l * POSE_STRIDE;
+#pragma unroll
+            for (int k = 0; k < 3; k++) B.p[k] = pk[9 + k];
+          }
+        }
         boxes_finish<G, SC, 1>(C, L, l, B, contact_out, BL, BM, link_slot0);
       }
     }
@@ -810,9 +872,16 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
   if (live && arm) {
     for (int i = l; i < 3 * nbt; i += G) A.S.contact[(size_t)e * nbt * 3 + i] = L.xch[i];
     GROUP_SYNC();
-    AL.joints();
-    GROUP_SYNC();
-    AL.compose();
+    if constexpr (LINK) {
+      WS_ARM_LOCALS();
+      ALl.joints();
+      GROUP_SYNC();
+      ALl.compose();
+    } else {
+      AL.joints();
+      GROUP_SYNC();
+      AL.compose();
+    }
     if (l == 0) {
       const float* pe = L.pose + tp.ee_body * POSE_STRIDE;
       tgtl[nd] = L.root[0] + pe[9]; tgtl[nd + 1] = L.root[1] + pe[10];
@@ -868,6 +937,8 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
     }
   }
 }
+
+#undef WS_ARM_LOCALS
 
 __global__ void k_abb_reset_all(AbbArgs A) {
   // reset_idx(arange(N)): state is written straight into the tensors (one thread per env)
@@ -1595,7 +1666,7 @@ static int abb_step_launch(ShfAbbTask* task, const float* raw_actions_dev, void*
                   "scene and 16 lanes per env");
     const int wt = 512, wepb = wt / 32;
     const size_t wlds = ((size_t)MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS +
-                         (size_t)wepb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, ABB_TAIL_WORDS(nslots, s->model.nd), 1 + nbx)) * 4;
+                         (size_t)wepb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, ABB_TAIL_WORDS(nslots, s->model.nd) + WS_LINK_STASH_WORDS, 1 + nbx)) * 4;
     return launch(k_abb_step_ws<512, true>, dim3((s->n + wepb - 1) / wepb), dim3(wt), wlds, stream, A);
   }
   if (sim_link(s) && s->mapping != SHF_MAP_CHAIN && AbbLinkDims::matches(s->model) && AbbScene::matches(s->nboxes, s->boxes, s->model.nsph)) {

@@ -49,7 +49,8 @@ def run(steps=2000, envs=384, every=100, link_envs=128):
                      ("chain32", dict(group=32, link_contacts=False)),
                      ("levels16", dict(group=16, mapping="body", link_contacts=False)),
                      ("generic32", dict(group=32, extra_boxes=extra, link_contacts=False)),
-                     ("link16", dict(group=16, link_contacts=True)), ("link32", dict(group=32, link_contacts=True)),
+                     ("link16", dict(group=16, link_contacts=True)), ("link16-body", dict(group=16, link_contacts=True, mapping="body")),
+                     ("link32", dict(group=32, link_contacts=True)),
                      ("link32-generic", dict(group=32, link_contacts=True, extra_boxes=extra))):
         t0 = time.time()
         n = args.envs if "link" not in name else min(args.envs, link_envs)
