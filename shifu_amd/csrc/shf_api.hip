@@ -575,7 +575,7 @@ DEV void abb_post_step(const AbbArgs& A, const ShfAbbTaskParams& tp, const ShfMo
 // (sized to the word: two workgroups of the two-wave kernel have to share a CU's 160 KiB)
 #define SHF_ARM_MAX_LINKS 6
 #define ABB_TGT_WORDS(nd) (((nd) + 2 + 3) & ~3)                     /* POS targets + the end effector's x, y */
-#define WS_LINK_STASH_WORDS 28   /* k_abb_step_ws<512, true>: the free box's (IA, pA) parked per env */
+#define WS_LINK_STASH_WORDS 32   /* k_abb_step_ws<512, true>: the free box's (IA, pA) and its corner ballots, parked per env */
 #define ABB_TAIL_WORDS(nslots, nd) ((nslots) * PT_STRIDE + ABB_TGT_WORDS(nd) + ARM_KREC_WORDS(SHF_ARM_MAX_LINKS) + 4)
 template <int G, class DM, class SC, bool LINK = false, int ARM = 0>
 __global__ __launch_bounds__(256, (G >= 32 && SC::NBX > 0) ? 2 : 1) void k_abb_step(AbbArgs A) {
@@ -668,6 +668,7 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
   typedef AbbScene SC;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   PHASE_BEGIN();
+  PHASE_BEGIN_T();
   float* stats_lds = smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS;
   stats_block_init(stats_lds);
   const unsigned long long stats_step = stats_step_load(A.stats);
@@ -760,29 +761,60 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
           ALl.compose();
           GROUP_SYNC();
         } else {
+          PHASE_MARK_T(17, HALF);                // (box wave's clock: time since its last mark = the finish of the sub-step before)
           boxes_pose<G>(C, L, l, B);             // (the boxes' own contacts need no arm pose: done beside the arm's composition)
           fixed_corner_slots<G, SC>(C, L, l, BM);
-          GROUP_SYNC();
-          fixed_box_fold<G, SC>(C, L, l, B, BM);
-          if (l == nb + SC::DYN) {               // the free box with its own contacts folded in: for the pair law, and parked
-            float* o = L.xch + l * XCH_STRIDE;
+          PHASE_MARK_T(18, HALF);
+          // the fold of the free box's own contacts is left to a spare lane of the ARM wave (which idles while this wave
+          // runs the link passes): its rigid inertia and bias and the slots' ballots go to LDS
+          if (l == nb + SC::DYN) {
 #pragma unroll
-            for (int k = 0; k < 21; k++) { o[k] = B.IA[k]; box_stash[k] = B.IA[k]; }
+            for (int k = 0; k < 21; k++) box_stash[k] = B.IA[k];
 #pragma unroll
-            for (int k = 0; k < 6; k++) { o[21 + k] = B.pA[k]; box_stash[21 + k] = B.pA[k]; }
+            for (int k = 0; k < 6; k++) box_stash[21 + k] = B.pA[k];
+            unsigned* bs = reinterpret_cast<unsigned*>(box_stash + 27);
+            bs[0] = BM.cplane; bs[1] = (unsigned)BM.cbox; bs[2] = (unsigned)(BM.cbox >> 32); bs[3] = BM.cedge;
           }
+          PHASE_MARK_T(19, HALF);
         }
       }
       __syncthreads();                           // S0': the arm's poses and the boxes' are in LDS for both waves
+      PHASE_MARK_T(20, HALF);                    // (box wave: waiting at S0')
       if (live) {
         if (arm) {
           WS_ARM_LOCALS();
           ALl.inertia_and_points(B, mu);
 #pragma unroll
           for (int k = 0; k < NRP; k++) act[k] = ALl.active[k];
+          // the rod's slot against the cube needs the poses only: evaluated here, while the box wave runs the link passes
+          fixed_sphere_slots<G, SC>(C, L, l, mu, AL.g, BM);
+          GROUP_SYNC();                          // the capsule's two slots come from two lanes
+          // ... and the free box's own contacts folded into its inertia (fixed_box_fold's loop, on a lane that has no body):
+          // corners ascending, terrain before boxes, the edge-edge slot at its place
+          if (l == G - 1) {
+            static_assert(G - 1 > NL + SC::NBX, "a lane without a body or a box");
+            const SlotLay Q = slot_lay<SC>(m, scene);
+            float IAf[21], pAf[6];
+#pragma unroll
+            for (int k = 0; k < 21; k++) IAf[k] = box_stash[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) pAf[k] = box_stash[21 + k];
+            const unsigned* bs = reinterpret_cast<const unsigned*>(box_stash + 27);
+            unsigned pl = bs[0], ed = bs[3];
+            unsigned long long bx = (unsigned long long)bs[1] | ((unsigned long long)bs[2] << 32);
+            int c, tg;
+            while (corner_next<SC::NBX - 1, SC::DYN>(pl, bx, ed, &c, &tg))
+              slot_accumulate(IAf, pAf, L.pt + corner_slot(Q, SC::DYN, c, tg) * PT_STRIDE, 1.0f, C.sp.dt, 1.0f);
+            float* o = L.xch + (nb + SC::DYN) * XCH_STRIDE;   // for the pair law (after S1), and parked for the box wave's finish
+#pragma unroll
+            for (int k = 0; k < 21; k++) { o[k] = IAf[k]; box_stash[k] = IAf[k]; }
+#pragma unroll
+            for (int k = 0; k < 6; k++) { o[21 + k] = pAf[k]; box_stash[21 + k] = pAf[k]; }
+          }
         } else {
           const int nl = link_contacts<G>(C, L, l, link_slot0, mu, AL.g);
           if (l == 0) *link_count = nl;
+          PHASE_MARK_T(21, HALF);                // (box wave: the link passes)
         }
       }
     }
@@ -805,8 +837,10 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
     }
     BM.nlink = nlink;
     if (live && arm) {
-      fixed_sphere_slots<G, SC>(C, L, l, mu, AL.g, BM);
-      GROUP_SYNC();                              // the capsule's two slots come from two lanes
+      if constexpr (!LINK) {
+        fixed_sphere_slots<G, SC>(C, L, l, mu, AL.g, BM);
+        GROUP_SYNC();                            // the capsule's two slots come from two lanes
+      }
       if (l == 0) {
         *sphere_bits = BM.spheres;
         if (BM.spheres || lb) {                  // rare: the pair laws on the lane that evaluated the slot
@@ -829,6 +863,7 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
     PHASE_MARK(26);
     __syncthreads();                             // S4
     PHASE_MARK(27);
+    PHASE_MARK_T(22, HALF);                      // (box wave: from the end of its link passes through S1 to S4: idle)
     if (live) {
       if (arm) {
         if constexpr (LINK) {

@@ -48,7 +48,17 @@ __device__ unsigned long long g_phase_cycles[32];
     _pc = clock64();                                                                     \
   } while (0)
 #define PHASE_RESET() _pc = clock64()
+// the same for one other thread of block 0 (the first lane of the box wave in k_abb_step_ws): its own running clock
+#define PHASE_BEGIN_T() unsigned long long _pct = clock64()
+#define PHASE_MARK_T(k, tid)                                                             \
+  do {                                                                                   \
+    const unsigned long long _now = clock64();                                           \
+    if (blockIdx.x == 0 && (int)threadIdx.x == (tid)) g_phase_cycles[k] += _now - _pct;  \
+    _pct = clock64();                                                                    \
+  } while (0)
 #else
+#define PHASE_BEGIN_T() do {} while (0)
+#define PHASE_MARK_T(k, tid) do {} while (0)
 #define PHASE_BEGIN() do {} while (0)
 #define PHASE_MARK(k) do {} while (0)
 #define PHASE_RESET() do {} while (0)

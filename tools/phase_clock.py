@@ -70,11 +70,17 @@ def main():
     assert fn(buf, 32, 0) == 0
     tot = sum(buf[:17]) if not split else sum(buf[11:17]) + sum(buf[24:30])  # (marks 17-23: inside phase 4 for the box scene)
     print(f"G={G}: {tot / steps:.0f} cycles per env-step in block 0 / wave 0 (s_memtime ticks)")
-    if link:
+    extra_names = ['box: corner slots', 'box: sphere slots', 'box: fold', 'fold: box lane corners', 'fold: pair law', 'fold: sync', 'fold: arm lanes', 'split: arm wave before S1', 'split: wait at S1', 'split: arm wave S1 -> S4', 'split: wait at S4', 'split: arm wave after S4', 'split: final barrier']
+    if link and split:
+        # k_abb_step_ws<512, true>: marks 17-22 are the BOX wave's own clock (its first lane), 24-28 the arm wave's
+        extra_names[0:6] = ['box wave: finish of the sub-step before (+ prologue)', 'box wave: poses + corner / edge slots', 'box wave: parking inertia and ballots',
+                            'box wave: wait at S0\'', 'box wave: link passes', 'box wave: idle from its link passes to S4']
+        extra_names[12] = '(debug counter, not a time)'
+    if link and not split:
         print(f"  link contacts: {buf[29] / max(buf[31], 1):.2f} live (body, box) pairs per wavefront and sub-step, "
               f"{buf[30] / max(buf[31], 1):.2f} in its first env; stage 0 (broad phase) = mark 24")
-    for k, nme in enumerate(NAMES + ['box: corner slots', 'box: sphere slots', 'box: fold', 'fold: box lane corners', 'fold: pair law', 'fold: sync', 'fold: arm lanes', 'split: arm wave before S1', 'split: wait at S1', 'split: arm wave S1 -> S4', 'split: wait at S4', 'split: arm wave after S4', 'split: final barrier']):
-        print(f"  {k:2d} {nme:34s} {buf[k] / steps:9.0f}  {100.0 * buf[k] / tot:5.1f} %")
+    for k, nme in enumerate(NAMES + extra_names):
+        print(f"  {k:2d} {nme:52s} {buf[k] / steps:9.0f}  {100.0 * buf[k] / tot:5.1f} %")
 
 
 if __name__ == "__main__":
