@@ -70,6 +70,8 @@ class ShifuVecEnv:
     # -- VecEnv surface -------------------------------------------------------------
     def step(self, actions: torch.Tensor):
         assert self.isg_env.robot, "add robot before step"
+        if getattr(self, "_hook_graphs", None) is not None:
+            return self._step_replayed(actions)
         self.actions = torch.clip(actions, -self.clip_actions, self.clip_actions)
         self.isg_env.step(self.actions)
         self.post_step()
@@ -77,16 +79,76 @@ class ShifuVecEnv:
         return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def post_step(self):
+        self._post_step_before_reset()
+        env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()
+        self.reset_idx(env_ids)
+        self._post_step_after_reset()
+
+    def _post_step_before_reset(self):
         self.episode_length_buf += 1
         self.common_step_counter += 1
         self.compute_termination()
         self.compute_reward()            # rewards of terminating envs are taken BEFORE their reset (Q15)
-        env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()
-        self.reset_idx(env_ids)
+
+    def _post_step_after_reset(self):
         self.compute_observations()      # ... observations AFTER it
         self.isg_env.refresh_sensors()
         if self.cfg.num_actions_history:
             self.actions_recorder.add(self.actions)   # Q12: the history lags the obs by one step
+
+    # -- optional execution mode: the shape-static parts of a step replayed from two hipGraphs -----------------------
+    def enable_graph_hooks(self, warmup: int = 2):
+        """Opt in: capture everything of `step` that does not depend on which envs reset -- the action clip, the robot's
+        `step` (the user's control loop over gym.simulate), termination, rewards (graph 1); observations, sensors, action
+        history, observation clip (graph 2) -- into two hipGraphs and replay them, with `reset_buf.nonzero()` and `reset_idx`
+        in between as ordinary eager code.  The user's hooks are not modified, only launched differently: on this path a
+        step is ~150 eager torch launches of 5-8 us of host time each (profiles/r04_hook_path.md).
+
+        Contract for the hooks (the shipped examples keep it): between steps they may update tensors IN PLACE (index
+        assignment, `+=`, ...) but must not rebind an attribute that a captured hook reads to a NEW tensor (`self.x =
+        torch.zeros(...)` inside `reset_idx`), draw no random numbers and take no data-dependent Python branches inside the
+        captured hooks.  Call after construction and before `reset()`: the capture runs the hooks a few times on whatever
+        state is there.  Not the default: a misbehaving hook fails silently under replay, and graph replays have misbehaved
+        on this stack before (profiles/r03_graph_replay.md) -- tests/test_gpu_env.py holds this mode to the fused kernel."""
+        assert self.obs_buf.is_cuda, "graph replay needs the GPU path"
+        dev = self.obs_buf.device
+        self._static_actions = torch.zeros(self.num_envs, self.num_actions, device=dev, dtype=torch.float)
+
+        def before():
+            self.actions = torch.clip(self._static_actions, -self.clip_actions, self.clip_actions)
+            self.isg_env.step(self.actions)
+            self._post_step_before_reset()
+
+        def after():
+            self._post_step_after_reset()
+            self.obs_buf = torch.clip(self.obs_buf, -self.clip_obs, self.clip_obs)
+
+        counter = self.common_step_counter
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                before()
+                after()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            before()
+        with torch.cuda.graph(g2, pool=g1.pool()):
+            after()
+        self.common_step_counter = counter
+        self._hook_graphs = (g1, g2)
+
+    def _step_replayed(self, actions: torch.Tensor):
+        g1, g2 = self._hook_graphs
+        self._static_actions.copy_(actions)
+        g1.replay()
+        self.common_step_counter += 1
+        env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()       # (the host sync of env.py:101, as in eager mode)
+        self.reset_idx(env_ids)
+        g2.replay()
+        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def reset(self):
         self.reset_idx(torch.arange(self.num_envs, device=self.device))

@@ -84,7 +84,8 @@ def _compare_step(hook, fused, it, m, o1, o2, r1, r2, obs_from=0):
     assert torch.allclose(r1[m], r2[m], rtol=1e-5, atol=1e-5), f"rew step {it}"
 
 
-def test_hook_env_matches_fused_env_through_resets():
+@pytest.mark.parametrize("replayed", [False, True])
+def test_hook_env_matches_fused_env_through_resets(replayed):
     """The path a user runs (hooks in torch over the `gym` facade, reference call order env.py:93-130) against the
     fused kernel, THROUGH episode ends: on the step an env resets, rewards are those of the finished episode
     (computed before the reset), the observation is taken after it -- default joint state, zeroed action history,
@@ -94,6 +95,10 @@ def test_hook_env_matches_fused_env_through_resets():
     (spawn xy, command, push) are then copied into the hook env and the comparison goes on, bit for bit in state."""
     n = 64
     hook, fused = _envs(n)
+    if replayed:
+        # ShifuVecEnv.enable_graph_hooks: the shape-static hooks replayed from two hipGraphs, reset_idx eager in between --
+        # the same step, launched differently; held to the fused kernel exactly like the eager mode
+        hook.enable_graph_hooks()
     fused.task.reset_all()
     T, S = fused.task.tensors, fused.sim.tensors
     T[_abi.A1_EP_LEN][:8] = 490          # time-outs (ep_len > 500) fall inside the run, next to contact terminations

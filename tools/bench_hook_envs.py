@@ -32,6 +32,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--graph-hooks", action="store_true",
+                    help="also time the hook envs with ShifuVecEnv.enable_graph_hooks(): the shape-static hooks replayed from hipGraphs")
+    ap.add_argument("--only-hooks", action="store_true", help="skip the fused envs")
     args = ap.parse_args()
     np.random.seed(0); torch.manual_seed(0)
     from examples.abb_pushbox_vision.a_prior_stage import AbbPushBox
@@ -40,8 +43,10 @@ def main():
     v, ms = run(AbbPushBox(cfg), args.steps)
     print(json.dumps({"env": "AbbPushBox (config 5, hook path, 6 sub-steps of 20 ms)", "envs": args.envs,
                       "env_steps_per_s": v, "ms_per_step": ms}))
+    # (AbbPushBox's hooks build tensors from Python lists inside `step` -- host-to-device copies, which a stream capture
+    # refuses: enable_graph_hooks is for hooks that are pure tensor code, like A1Conditional's)
     from shifu_amd.gym.abb_fused import FusedAbbEnv
-    for g in (64, 32, 16):
+    for g in (() if args.only_hooks else (64, 32, 16)):
         v, ms = run(FusedAbbEnv(num_envs=args.envs, group=g, link_contacts=False), args.steps * 5)
         print(json.dumps({"env": "FusedAbbEnv (config 5, fused single launch, lanes/env=%d)" % g, "envs": args.envs,
                           "env_steps_per_s": v, "ms_per_step": ms}))
@@ -51,6 +56,12 @@ def main():
     v, ms = run(A1Conditional(cfg), args.steps)
     print(json.dumps({"env": "A1Conditional (config 3, hook path)", "envs": args.envs, "env_steps_per_s": v,
                       "ms_per_step": ms}))
+    if args.graph_hooks:
+        env = A1Conditional(cfg)
+        env.enable_graph_hooks()
+        v, ms = run(env, args.steps)
+        print(json.dumps({"env": "A1Conditional (config 3, hook path, hooks replayed from hipGraphs)", "envs": args.envs,
+                          "env_steps_per_s": v, "ms_per_step": ms}))
 
 
 if __name__ == "__main__":
