@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SHF_ABI_VERSION 10
+#define SHF_ABI_VERSION 11
 
 #define SHF_MAX_BODIES 32 /* reported rigid bodies per articulation        */
 #define SHF_MAX_DOFS 32
@@ -524,6 +524,18 @@ int shf_mlp_linear_forward(const float* x, const float* w, const float* b, float
                            int32_t act, void* stream);
 int shf_mlp_linear_backward_input(const float* dy, const float* y_or_null, const float* w, float* dx, int32_t M, int32_t K,
                                   int32_t N, void* stream);
+/* Row-panel forms of forward / backward_input (round 4; results equal the two calls above bit for bit).  The weights
+ * are first laid out in MFMA fragment order as bf16 heads and tails, plain and transposed, by shf_mlp_pack_weights into
+ * a caller-owned device buffer of shf_mlp_pack_bytes(K, N) bytes (16-byte aligned) -- once per change of w, i.e. once per
+ * optimizer step; the panel kernels then read each activation row once (a block owns whole rows, M is the only grid
+ * dimension), take the weight fragments straight from that buffer, and have no barrier in their reduction loop.
+ * x / dy / y must be 16-byte aligned, contiguous. */
+int shf_mlp_pack_bytes(int32_t K, int32_t N, int64_t* bytes);
+int shf_mlp_pack_weights(const float* w, void* pack, int32_t K, int32_t N, void* stream);
+int shf_mlp_panel_forward(const float* x, const void* pack, const float* b, float* y, int32_t M, int32_t K, int32_t N,
+                          int32_t act, void* stream);
+int shf_mlp_panel_backward_input(const float* dy, const float* y_or_null, const void* pack, float* dx, int32_t M, int32_t K,
+                                 int32_t N, void* stream);
 int shf_mlp_backward_weight_workspace(int32_t M, int32_t K, int32_t N, int64_t* floats);
 int shf_mlp_linear_backward_weight(const float* dy, const float* y_or_null, const float* x, float* dw, float* db,
                                    float* workspace, int32_t M, int32_t K, int32_t N, void* stream);

@@ -51,6 +51,10 @@ _SIGS = {
     "shf_mlp_linear_forward": ([vp, vp, vp, vp, i32, i32, i32, i32, vp], i32),
     "shf_mlp_linear_backward_input": ([vp, vp, vp, vp, i32, i32, i32, vp], i32),
     "shf_mlp_backward_weight_workspace": ([i32, i32, i32, C.POINTER(i64)], i32),
+    "shf_mlp_pack_bytes": ([i32, i32, C.POINTER(i64)], i32),
+    "shf_mlp_pack_weights": ([vp, vp, i32, i32, vp], i32),
+    "shf_mlp_panel_forward": ([vp, vp, vp, vp, i32, i32, i32, i32, vp], i32),
+    "shf_mlp_panel_backward_input": ([vp, vp, vp, vp, i32, i32, i32, vp], i32),
     "shf_mlp_set_precision": ([i32], i32),
     "shf_mlp_get_precision": ([], i32),
     "shf_mlp_linear_backward_weight": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], i32),

@@ -392,6 +392,297 @@ void launch_gemm(hipStream_t st, const Operand& A, const Operand& B, int red, in
 #undef SHF_MLP_LAUNCH
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-panel kernels (round 4): forward and input gradient of a layer as  C[M, cols] = A[M, red] B[cols, red]^T  with M as
+// the only grid dimension.  These GEMMs are skinny (red, cols <= 512 against M = 24 576) and HBM-bound on A and C, so:
+//   * a block owns BM whole rows of A: the panel [BM x red] is one contiguous range of memory, read ONCE with 16-byte
+//     loads (many in flight, no K loop around them), converted to bf16 head (+ tail) and parked in LDS;
+//   * B (the weights, <= 0.5 MB, L2-resident) is not staged through LDS at all: a tiny pack kernel lays it out once per
+//     optimizer step in MFMA fragment order -- [column tile][k step][lane] -> 8 bf16 = 16 bytes -- so that a wave's B
+//     fragment is one contiguous 1 KB load straight into registers (next k step's fragments in flight under this step's
+//     MFMAs); head and tail arrays, plain and transposed (the input gradient multiplies by W, not W^T);
+//   * after the one barrier behind the panel store there is no barrier in the loop: each wave owns column tiles and runs
+//     its own reduction over the whole panel, epilogue (bias, ELU) straight from the accumulators.
+// The k steps and the order of the three MFMAs per step are those of k_mlp_gemm, so results equal that kernel's bit for bit.
+constexpr int PANEL_PAD = 8;     // bf16 of padding per LDS row: row stride = (redp + 8) / 2 words = 4 mod 8 -> conflict-free fragments
+
+struct PanelArgs {
+  const float* a;        // [M, red] row-major, ld = red
+  const float* mask_y;   // optional, same shape: A is multiplied by act'(mask_y)
+  int M, red, redp;      // redp = red rounded up to 16 (the pack's k extent)
+  uint32_t red_magic;    // floor(2^32 / red) + 1:  e / red = umulhi(e, magic) for e * red < 2^32
+  const uint4* bhi;      // [ceil(cols / 32)][redp / 16][64] fragments of the bf16 heads
+  const uint4* blo;      // ... of the tails (bf16x3 only)
+  float* c;              // [M, cols], ld = ldc
+  int ldc, cols;
+  const float* bias;     // per column or null
+  int act;
+};
+
+// Streaming form: the block's BM rows of A pass through LDS in chunks of KC reduction indices, two buffers: the loads of
+// chunk c + 1 are issued (into registers) before the MFMAs of chunk c and committed to the other buffer after them -- one
+// barrier per chunk, HBM latency under a chunk's 50 - 200 MFMAs per wave.  Each wave keeps the accumulators of ALL its
+// column tiles for the whole reduction (CT = ceil(column tiles / 4) <= 4), so A is read once.
+constexpr int KC = 128, KCS = KC + PANEL_PAD;   // chunk row stride 136 bf16 = 68 words = 4 mod 64: conflict-free 16-byte fragments
+
+template <int BM, int CT, bool MASK, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void k_mlp_panel(PanelArgs P) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t panel_lds[];
+  constexpr int RT = BM / 32;
+  constexpr int BUF = (SPLIT ? 2 : 1) * BM * KCS;            // one buffer: heads, then tails
+  constexpr int NV = BM * KC / 4 / 256;                      // 16-byte chunks per thread and K chunk (8 for 64 rows)
+  const int t = (int)threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int r0 = (int)blockIdx.x * BM;
+  const int red = P.red;
+  const bool vec = (red & 3) == 0;                           // rows 16-byte aligned (the host checked the base)
+  const int nchunks = (P.redp + KC - 1) / KC;
+  const int nks = P.redp >> 4, nct = (P.cols + 31) >> 5;
+
+  // element (row, k) of 16-byte chunk u of this thread inside a K chunk: 32 lanes cover one row's 512 bytes
+  f32x4 v[NV], m[MASK ? NV : 1];
+  auto issue = [&](int kc0) {
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+      const int idx = t + 256 * u, row = idx >> 5, k = kc0 + 4 * (idx & 31);
+      const bool rin = r0 + row < P.M;
+      const size_t off = (size_t)(r0 + row) * red + k;
+      v[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (MASK) m[u] = v[u];
+      if (vec) {
+#ifdef SHF_PANEL_NO_ALOAD
+        if (rin && k < red && P.act == 77) {
+#else
+        if (rin && k < red) {
+#endif
+          v[u] = *reinterpret_cast<const f32x4*>(P.a + off);
+          if (MASK) m[u] = *reinterpret_cast<const f32x4*>(P.mask_y + off);
+        }
+      } else if (rin) {
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+          if (k + c < red) { v[u][c] = P.a[off + c]; if (MASK) m[u][c] = P.mask_y[off + c]; }
+      }
+    }
+  };
+  auto commit = [&](uint16_t* buf) {
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+      const int idx = t + 256 * u, row = idx >> 5, k = 4 * (idx & 31);
+      bf16x4 h, l;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const float x = MASK ? v[u][c] * elu_grad_from_output(m[u][c]) : v[u][c];
+        h[c] = (__bf16)x;
+        if (SPLIT) l[c] = (__bf16)(x - (float)h[c]);
+      }
+      *reinterpret_cast<bf16x4*>(buf + row * KCS + k) = h;
+      if (SPLIT) *reinterpret_cast<bf16x4*>(buf + BM * KCS + row * KCS + k) = l;
+    }
+  };
+
+  const int ct0 = wave * CT;
+  const bool wave_on = ct0 < nct;                             // a wave without column tiles only helps moving A
+  f32x16 acc[RT][CT];
+#pragma unroll
+  for (int i = 0; i < RT; i++)
+#pragma unroll
+    for (int j = 0; j < CT; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+  size_t boff[CT];
+#pragma unroll
+  for (int j = 0; j < CT; j++) boff[j] = (size_t)(ct0 + j < nct ? ct0 + j : nct - 1) * nks * 64 + lane;
+  // B fragments: a ring of D k steps in flight (straight from the pack in L2), refilled as each step is consumed
+  constexpr int D = 8 / CT;
+  uint4 rh[D][CT], rl[D][SPLIT ? CT : 1];
+  if (wave_on) {
+#pragma unroll
+    for (int d = 0; d < D; d++)
+      if (d < nks) {
+#pragma unroll
+        for (int j = 0; j < CT; j++) { rh[d][j] = P.bhi[boff[j] + (size_t)d * 64]; if (SPLIT) rl[d][j] = P.blo[boff[j] + (size_t)d * 64]; }
+      }
+  }
+  MLP_CLOCK(0);
+  issue(0);
+  commit(panel_lds);
+  __syncthreads();
+  MLP_CLOCK(1);
+  const int frag = (lane & 31) * KCS + 8 * (lane >> 5);
+  for (int c = 0; c < nchunks; c++) {
+    const uint16_t* Ah = panel_lds + (c & 1) * BUF;
+    const uint16_t* Al = Ah + BM * KCS;
+    if (c + 1 < nchunks) issue((c + 1) * KC);
+    if (wave_on) {
+      const int ks_end = (c + 1) * (KC / 16) < nks ? (c + 1) * (KC / 16) : nks;
+      static_assert((KC / 16) % D == 0, "the ring position of a chunk's first k step must be 0");
+      for (int ks0 = c * (KC / 16); ks0 < ks_end; ks0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+          const int ks = ks0 + d;
+          if (ks >= ks_end) break;
+          bf16x8 bh[CT], bl[CT];
+#pragma unroll
+          for (int j = 0; j < CT; j++) { bh[j] = __builtin_bit_cast(bf16x8, rh[d][j]); if (SPLIT) bl[j] = __builtin_bit_cast(bf16x8, rl[d][j]); }
+#ifdef SHF_PANEL_NO_BLOAD
+          if (ks + D < nks && P.act == 77) {
+#else
+          if (ks + D < nks) {
+#endif
+#pragma unroll
+            for (int j = 0; j < CT; j++) {
+              rh[d][j] = P.bhi[boff[j] + (size_t)(ks + D) * 64];
+              if (SPLIT) rl[d][j] = P.blo[boff[j] + (size_t)(ks + D) * 64];
+            }
+          }
+          const int kl = 16 * (ks - c * (KC / 16));
+          bf16x8 ah[RT], al[RT];
+#pragma unroll
+          for (int i = 0; i < RT; i++) {
+            ah[i] = *reinterpret_cast<const bf16x8*>(Ah + 32 * i * KCS + frag + kl);
+            if (SPLIT) al[i] = *reinterpret_cast<const bf16x8*>(Al + 32 * i * KCS + frag + kl);
+          }
+#ifdef SHF_PANEL_NO_MFMA
+#pragma unroll
+          for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int j = 0; j < CT; j++) acc[i][j][0] += (float)ah[i][0] + (float)bh[j][0] + (SPLIT ? (float)al[i][0] + (float)bl[j][0] : 0.0f);
+#else
+          if (SPLIT) {
+#pragma unroll
+            for (int i = 0; i < RT; i++)
+#pragma unroll
+              for (int j = 0; j < CT; j++) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+              }
+          }
+#pragma unroll
+          for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int j = 0; j < CT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#endif
+        }
+      }
+    }
+    if (c + 1 < nchunks) {
+      commit(panel_lds + ((c + 1) & 1) * BUF);
+      lds_barrier();          // chunk c + 1 is in LDS, and every wave is done reading chunk c's buffer (rewritten next round)
+    }
+  }
+  MLP_CLOCK(2);
+  if (!wave_on) return;
+#pragma unroll
+  for (int i = 0; i < RT; i++)
+#pragma unroll
+    for (int j = 0; j < CT; j++) {
+      const int col = 32 * (ct0 + j) + (lane & 31);
+      const bool colok = ct0 + j < nct && col < P.cols;
+      const float bv = (P.bias && colok) ? P.bias[col] : 0.0f;
+#ifdef SHF_PANEL_STORE16
+      // (probe: the cost of the same bytes as 16-byte stores, eight lanes per 128-byte row segment -- wrong values)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int row = r0 + 32 * i + (lane >> 3) + 8 * g, c4 = 32 * (ct0 + j) + 4 * (lane & 7);
+        if (ct0 + j < nct && c4 + 3 < P.cols && row < P.M) {
+          f32x4 o;
+#pragma unroll
+          for (int c = 0; c < 4; c++) { float v = acc[i][j][4 * g + c] + bv; if (P.act == 1) v = v > 0.0f ? v : __expf(v) - 1.0f; o[c] = v; }
+          *reinterpret_cast<f32x4*>(P.c + (size_t)row * P.ldc + c4) = o;
+        }
+      }
+      continue;
+#endif
+#pragma unroll
+      for (int reg = 0; reg < 16; reg++) {
+        const int row = r0 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+#ifdef SHF_PANEL_NO_STORE
+        if (colok && row < P.M && acc[i][j][reg] == 12345.678f) {
+#else
+        if (colok && row < P.M) {
+#endif
+          float v = acc[i][j][reg] + bv;
+          if (P.act == 1) v = v > 0.0f ? v : __expf(v) - 1.0f;
+          P.c[(size_t)row * P.ldc + col] = v;
+        }
+      }
+    }
+  MLP_CLOCK(3);
+}
+
+// W[N, K] (fp32) -> four fragment-ordered bf16 arrays: plain (column = n, reduction = k) head / tail, then transposed
+// (column = k, reduction = n) head / tail.  One thread per 16-byte fragment entry.
+struct PackDims { int nct, nks; size_t entries; };
+PackDims pack_dims(int cols, int red) { PackDims d; d.nct = (cols + 31) / 32; d.nks = (red + 15) / 16; d.entries = (size_t)d.nct * d.nks * 64; return d; }
+
+__global__ __launch_bounds__(256) void k_mlp_pack(const float* __restrict__ w, uint4* __restrict__ out, int K, int N, int plain_entries, int nks_p,
+                                                   int t_entries, int nks_t) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= plain_entries + t_entries) return;
+  const bool tr = i >= plain_entries;
+  const int e = tr ? i - plain_entries : i, nks = tr ? nks_t : nks_p;
+  const int lane = e & 63, ks = (e >> 6) % nks, ct = (e >> 6) / nks;
+  const int col = 32 * ct + (lane & 31), k0 = 16 * ks + 8 * (lane >> 5);
+  const int cols = tr ? K : N, red = tr ? N : K;
+  uint16_t h[8], l[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    float x = 0.0f;
+    if (col < cols && k0 + c < red) x = tr ? w[(size_t)(k0 + c) * K + col] : w[(size_t)col * K + k0 + c];
+    const __bf16 hb = (__bf16)x;
+    const __bf16 lb = (__bf16)(x - (float)hb);
+    h[c] = __builtin_bit_cast(uint16_t, hb);
+    l[c] = __builtin_bit_cast(uint16_t, lb);
+  }
+  uint4 H, L;
+  H.x = h[0] | ((uint32_t)h[1] << 16); H.y = h[2] | ((uint32_t)h[3] << 16); H.z = h[4] | ((uint32_t)h[5] << 16); H.w = h[6] | ((uint32_t)h[7] << 16);
+  L.x = l[0] | ((uint32_t)l[1] << 16); L.y = l[2] | ((uint32_t)l[3] << 16); L.z = l[4] | ((uint32_t)l[5] << 16); L.w = l[6] | ((uint32_t)l[7] << 16);
+  // layout: [plain head | plain tail | transposed head | transposed tail]
+  uint4* head = tr ? out + 2 * (size_t)plain_entries : out;
+  const size_t n = tr ? (size_t)t_entries : (size_t)plain_entries;
+  head[e] = H;
+  head[n + e] = L;
+}
+
+int panel_env(const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; }
+
+template <int BM, int CT>
+int launch_panel_bc(hipStream_t st, const PanelArgs& P, bool split, size_t lds) {
+  const dim3 grid((P.M + BM - 1) / BM);
+#define SHF_PANEL_GO(MASKV, SPLITV)                                                                              \
+  do {                                                                                                           \
+    auto fn = k_mlp_panel<BM, CT, MASKV, SPLITV>;                                                                \
+    static bool attr = false;                                                                                    \
+    if (!attr) {                                                                                                 \
+      if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
+        return mlp_fail("k_mlp_panel: cannot raise the dynamic LDS limit");                                      \
+      attr = true;                                                                                               \
+    }                                                                                                            \
+    hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, P);                                                         \
+  } while (0)
+  if (P.mask_y) { if (split) SHF_PANEL_GO(true, true); else SHF_PANEL_GO(true, false); }
+  else { if (split) SHF_PANEL_GO(false, true); else SHF_PANEL_GO(false, false); }
+#undef SHF_PANEL_GO
+  return 0;
+}
+
+// CT = ceil(column tiles / 4) (1, 2 or 4: every wave holds all its column tiles' accumulators); BM: 64 rows, 32 when the
+// accumulators of 64 would not leave room for two blocks per CU (CT = 4) or the grid would not cover the CUs.
+int launch_panel(hipStream_t st, PanelArgs& P) {
+  const bool split = g_mlp_precision == SHF_MLP_BF16X3;
+  static const int force_bm = panel_env("SHF_MLP_PANEL_BM");
+  const int nct = (P.cols + 31) / 32;
+  if (nct > 16) return mlp_fail("k_mlp_panel: more than 512 output columns");
+  const int ct = nct > 8 ? 4 : nct > 4 ? 2 : 1;
+  int bm = (ct == 4 || (P.M + 63) / 64 < 256) ? 32 : 64;
+  if ((force_bm == 32 || force_bm == 64) && !(force_bm == 64 && ct == 4)) bm = force_bm;
+  const size_t lds = (size_t)2 * (split ? 2 : 1) * bm * KCS * 2;
+  if (bm == 64) return ct == 2 ? launch_panel_bc<64, 2>(st, P, split, lds) : launch_panel_bc<64, 1>(st, P, split, lds);
+  return ct == 4 ? launch_panel_bc<32, 4>(st, P, split, lds) : ct == 2 ? launch_panel_bc<32, 2>(st, P, split, lds) : launch_panel_bc<32, 1>(st, P, split, lds);
+}
+uint32_t div_magic(int d) { return (uint32_t)((1ull << 32) / (uint64_t)d) + 1u; }
+
 }  // namespace
 
 
@@ -628,6 +919,43 @@ extern "C" int shf_mlp_linear_backward_input(const float* dy, const float* y_or_
   Epilogue E{dx, K, nullptr, 0, nullptr};
   launch_gemm<true, false, false>((hipStream_t)stream, A, B, N, N, 1, E, M, K);
   return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_mlp_linear_backward_input: launch failed");
+}
+
+extern "C" int shf_mlp_pack_bytes(int32_t K, int32_t N, int64_t* bytes) {
+  if (!bytes || K <= 0 || N <= 0) return mlp_fail("shf_mlp_pack_bytes: bad argument");
+  *bytes = (int64_t)(2 * (pack_dims(N, K).entries + pack_dims(K, N).entries) * sizeof(uint4));
+  return 0;
+}
+extern "C" int shf_mlp_pack_weights(const float* w, void* pack, int32_t K, int32_t N, void* stream) {
+  if (!w || !pack || K <= 0 || N <= 0) return mlp_fail("shf_mlp_pack_weights: bad argument");
+  if (((uintptr_t)pack & 15u) != 0) return mlp_fail("shf_mlp_pack_weights: pack must be 16-byte aligned");
+  const PackDims p = pack_dims(N, K), q = pack_dims(K, N);
+  const int total = (int)(p.entries + q.entries);
+  hipLaunchKernelGGL(k_mlp_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (uint4*)pack, K, N, (int)p.entries, p.nks,
+                     (int)q.entries, q.nks);
+  return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_mlp_pack_weights: launch failed");
+}
+extern "C" int shf_mlp_panel_forward(const float* x, const void* pack, const float* b, float* y, int32_t M, int32_t K, int32_t N,
+                                     int32_t act, void* stream) {
+  if (!x || !pack || !y) return mlp_fail("shf_mlp_panel_forward: null tensor");
+  if (M <= 0 || K <= 0 || N <= 0 || act < 0 || act > 1) return mlp_fail("shf_mlp_panel_forward: bad shape / activation");
+  if (too_big(M, K, N)) return mlp_fail("shf_mlp_panel_forward: a tensor has 2^32 elements or more");
+  if (((uintptr_t)x & 15u) != 0) return mlp_fail("shf_mlp_panel_forward: x must be 16-byte aligned");
+  const PackDims p = pack_dims(N, K);
+  PanelArgs P{x, nullptr, M, K, p.nks * 16, div_magic(K), (const uint4*)pack, (const uint4*)pack + p.entries, y, N, N, b, act};
+  if (launch_panel((hipStream_t)stream, P)) return 1;
+  return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_mlp_panel_forward: launch failed");
+}
+extern "C" int shf_mlp_panel_backward_input(const float* dy, const float* y_or_null, const void* pack, float* dx, int32_t M,
+                                            int32_t K, int32_t N, void* stream) {
+  if (!dy || !pack || !dx) return mlp_fail("shf_mlp_panel_backward_input: null tensor");
+  if (M <= 0 || K <= 0 || N <= 0 || too_big(M, K, N)) return mlp_fail("shf_mlp_panel_backward_input: bad shape");
+  if (((uintptr_t)dy & 15u) != 0 || ((uintptr_t)y_or_null & 15u) != 0) return mlp_fail("shf_mlp_panel_backward_input: dy / y must be 16-byte aligned");
+  const PackDims p = pack_dims(N, K), q = pack_dims(K, N);
+  const uint4* th = (const uint4*)pack + 2 * p.entries;
+  PanelArgs P{dy, y_or_null, M, N, q.nks * 16, div_magic(N), th, th + q.entries, dx, K, K, nullptr, 0};
+  if (launch_panel((hipStream_t)stream, P)) return 1;
+  return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_mlp_panel_backward_input: launch failed");
 }
 
 extern "C" int shf_mlp_backward_weight_workspace(int32_t M, int32_t K, int32_t N, int64_t* floats) {

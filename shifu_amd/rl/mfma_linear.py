@@ -57,6 +57,25 @@ def _stream(t):
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+# Rows from which the row-panel kernels (k_mlp_panel: one block per 32 / 64 whole rows, at most 512 columns) replace the
+# tiled GEMM for forward and input gradient -- same bits, 10-25 % less time per call at 24 576 rows (profiles/r04_mlp_panel.md);
+# below it their grid does not fill the 256 CUs (the 4096-row rollout batches stay on the tiled kernel).
+# SHIFU_AMD_MLP_PANEL_ROWS overrides (0 = never).
+PANEL_MIN_ROWS = int(os.environ.get("SHIFU_AMD_MLP_PANEL_ROWS", "8192"))
+
+
+def _pack_weights(weight):
+    """The layer's weights in MFMA fragment order (bf16 heads and tails, plain and transposed): shf_mlp_pack_weights.
+    Packed on every forward that uses the panel kernels -- the weights change every optimizer step, and a cached pack
+    inside a captured graph would go stale without notice; the launch is a few microseconds."""
+    N, K = weight.shape
+    n = C.c_int64()
+    _check(lib().shf_mlp_pack_bytes(K, N, C.byref(n)))
+    pack = torch.empty(n.value, device=weight.device, dtype=torch.uint8)
+    _check(lib().shf_mlp_pack_weights(_ptr(weight), _ptr(pack), K, N, _stream(weight)))
+    return pack
+
+
 class _MfmaLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act):
@@ -64,9 +83,15 @@ class _MfmaLinearFn(torch.autograd.Function):
         M, K = x.shape
         N = weight.shape[0]
         y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        pack = None
         with torch.cuda.device(x.device):
-            _check(lib().shf_mlp_linear_forward(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), M, K, N, act, _stream(x)))
+            if PANEL_MIN_ROWS and M >= PANEL_MIN_ROWS and N <= 512 and K <= 512 and x.data_ptr() % 16 == 0:
+                pack = _pack_weights(weight)
+                _check(lib().shf_mlp_panel_forward(_ptr(x), _ptr(pack), _ptr(bias), _ptr(y), M, K, N, act, _stream(x)))
+            else:
+                _check(lib().shf_mlp_linear_forward(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), M, K, N, act, _stream(x)))
         ctx.save_for_backward(x, weight, y)
+        ctx.pack = pack
         ctx.act = act
         return y
 
@@ -81,7 +106,10 @@ class _MfmaLinearFn(torch.autograd.Function):
         with torch.cuda.device(x.device):
             if ctx.needs_input_grad[0]:
                 gx = torch.empty_like(x)
-                _check(lib().shf_mlp_linear_backward_input(_ptr(gy), yp, _ptr(weight), _ptr(gx), M, K, N, _stream(x)))
+                if ctx.pack is not None and gy.data_ptr() % 16 == 0:
+                    _check(lib().shf_mlp_panel_backward_input(_ptr(gy), yp, _ptr(ctx.pack), _ptr(gx), M, K, N, _stream(x)))
+                else:
+                    _check(lib().shf_mlp_linear_backward_input(_ptr(gy), yp, _ptr(weight), _ptr(gx), M, K, N, _stream(x)))
             if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
                 n = C.c_int64()
                 _check(lib().shf_mlp_backward_weight_workspace(M, K, N, C.byref(n)))

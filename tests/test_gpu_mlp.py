@@ -82,6 +82,38 @@ def test_forward_and_backward_match_the_fp32_reference(M, K, N, elu, precision):
     _close(lin.bias.grad, ref.bias.grad, "bias gradient", precision)
 
 
+@pytest.mark.parametrize("M,K,N,elu", [(24576, 259, 512, True), (24576, 512, 256, True), (8192, 256, 128, True), (24576, 128, 12, False),
+                                       (24576, 128, 1, False), (50, 259, 512, True), (1000, 37, 5, True), (333, 100, 259, True)])
+def test_row_panel_kernels_equal_the_tiled_kernels_bitwise(M, K, N, elu, precision):
+    """shf_mlp_panel_forward / _backward_input (weights packed in fragment order, a block owns whole rows) run the same k
+    steps and the same three MFMAs per step as the tiled GEMM: every output bit equal, on the A1 shapes and on ragged ones
+    (rows not a multiple of the panel, reduction not a multiple of 16, 259-wide unaligned rows, 1 to 512 columns)."""
+    _need_gpu()
+    import ctypes as C
+    from shifu_amd._lib import lib
+    L = lib()
+    torch.manual_seed(3)
+    dev = "cuda:0"
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x, w, b = torch.randn(M, K, device=dev) * 1.5, torch.randn(N, K, device=dev) * 0.1, torch.randn(N, device=dev)
+    g = torch.randn(M, N, device=dev)
+    nb = C.c_int64()
+    assert L.shf_mlp_pack_bytes(K, N, C.byref(nb)) == 0
+    pack = torch.empty(nb.value, device=dev, dtype=torch.uint8)
+    assert L.shf_mlp_pack_weights(p(w), p(pack), K, N, st) == 0
+    y1, y2 = torch.full((M, N), 7.0, device=dev), torch.full((M, N), -7.0, device=dev)
+    act = 1 if elu else 0
+    assert L.shf_mlp_linear_forward(p(x), p(w), p(b), p(y1), M, K, N, act, st) == 0
+    assert L.shf_mlp_panel_forward(p(x), p(pack), p(b), p(y2), M, K, N, act, st) == 0, L.shf_mlp_last_error()
+    assert torch.equal(y1, y2)
+    gx1, gx2 = torch.full((M, K), 7.0, device=dev), torch.full((M, K), -7.0, device=dev)
+    yp = p(y1) if elu else None
+    assert L.shf_mlp_linear_backward_input(p(g), yp, p(w), p(gx1), M, K, N, st) == 0
+    assert L.shf_mlp_panel_backward_input(p(g), yp, p(pack), p(gx2), M, K, N, st) == 0, L.shf_mlp_last_error()
+    assert torch.equal(gx1, gx2)
+
+
 def test_actor_critic_on_the_mfma_backend_matches_the_torch_backend_and_trains():
     _need_gpu()
     from shifu_amd.rl.actor_critic import ActorCritic
