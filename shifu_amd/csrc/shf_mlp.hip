@@ -203,8 +203,22 @@ __global__ __launch_bounds__(256) void k_mlp_gemm(Operand A, Operand B, int red,
   __shared__ __attribute__((aligned(16))) uint16_t As[(SPLIT ? 2 : 1) * BMT * LDT];
   __shared__ __attribute__((aligned(16))) uint16_t Bs[(SPLIT ? 2 : 1) * BN * LDT];
   MLP_CLOCK(0);
-  const int r0 = (int)blockIdx.x * BMT, c0 = (int)blockIdx.y * BN;
-  const int red0 = (int)blockIdx.z * red_per_slice;
+  // Workgroups go to the eight XCDs round-robin by linear id, and each XCD has its own L2.  With a split reduction
+  // (weight gradient) the tiles of one slice share that slice's rows of both operands: renumber so that an XCD works
+  // through whole slices -- consecutive tiles of a slice on the same L2 -- instead of every XCD fetching every slice.
+  int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z;
+#ifndef SHF_MLP_NO_XCD_SWIZZLE
+  if (gridDim.z > 1) {
+    const int gx = (int)gridDim.x, gy = (int)gridDim.y, nblk = gx * gy * (int)gridDim.z;
+    if ((nblk & 7) == 0) {
+      const int lin = bx + gx * (by + gy * bz);
+      const int ren = (lin & 7) * (nblk >> 3) + (lin >> 3);
+      bx = ren % gx; by = (ren / gx) % gy; bz = ren / (gx * gy);
+    }
+  }
+#endif
+  const int r0 = bx * BMT, c0 = by * BN;
+  const int red0 = bz * red_per_slice;
 #ifdef SHF_MLP_PROBE_NO_LOOP
   const int red1 = red0;                       // (probe build: epilogue only)
 #else
@@ -241,7 +255,7 @@ __global__ __launch_bounds__(256) void k_mlp_gemm(Operand A, Operand B, int red,
       fetch_tile<B_RED_CONTIG, B_VEC, false, 16>(B, c0, k0 + PF * BK, red1, xb);
     }
 #ifndef SHF_MLP_PROBE_NO_COLSUM
-    if (COLSUM_A && blockIdx.y == 0 && threadIdx.x < BMT) {
+    if (COLSUM_A && by == 0 && threadIdx.x < BMT) {
       // db: sum over the reduction index of the (bf16-rounded) G values of A row t -- the values the MFMA multiplies
       const uint16_t* row = As + threadIdx.x * LDT;
 #pragma unroll
@@ -295,7 +309,7 @@ __global__ __launch_bounds__(256) void k_mlp_gemm(Operand A, Operand B, int red,
   return;
 #endif
   // epilogue: C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  float* Cout = E.c + (size_t)blockIdx.z * rows * E.ldc * (gridDim.z > 1 ? 1 : 0);   // split-K: slice z writes its own partial
+  float* Cout = E.c + (size_t)bz * rows * E.ldc * (gridDim.z > 1 ? 1 : 0);   // split-K: slice z writes its own partial
 #pragma unroll
   for (int i = 0; i < TI; i++)
 #pragma unroll
@@ -318,9 +332,9 @@ __global__ __launch_bounds__(256) void k_mlp_gemm(Operand A, Operand B, int red,
         }
       }
     }
-  if (COLSUM_A && blockIdx.y == 0 && threadIdx.x < BMT) {
+  if (COLSUM_A && by == 0 && threadIdx.x < BMT) {
     const int row = r0 + (int)threadIdx.x;
-    if (row < rows) E.colsum[(size_t)blockIdx.z * rows + row] = csum;
+    if (row < rows) E.colsum[(size_t)bz * rows + row] = csum;
   }
   MLP_CLOCK(2);
 }
@@ -494,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_panel(PanelArgs P) {
 #pragma unroll
   for (int j = 0; j < CT; j++) boff[j] = (size_t)(ct0 + j < nct ? ct0 + j : nct - 1) * nks * 64 + lane;
   // B fragments: a ring of D k steps in flight (straight from the pack in L2), refilled as each step is consumed
-  constexpr int D = 8 / CT;
+  constexpr int D = (MASK && SPLIT && BM == 64 && CT == 2) ? 2 : 8 / CT;   // (that form would spill 21 registers at depth 4)
   uint4 rh[D][CT], rl[D][SPLIT ? CT : 1];
   if (wave_on) {
 #pragma unroll
@@ -572,41 +586,48 @@ __global__ __launch_bounds__(256, 2) void k_mlp_panel(PanelArgs P) {
     }
   }
   MLP_CLOCK(2);
+  // Epilogue: the accumulator layout gives a lane one column and 16 rows -- stores of 4 bytes per lane, 128 bytes per row
+  // segment.  Each wave turns its 32 x 32 tiles through a private LDS patch instead (the chunk buffers are idle now) and
+  // writes 16 bytes per lane, eight lanes per row segment: 5 - 10 us per call on the 24 576-row layers
+  // (profiles/r04_mlp_panel.md).  Same values, so the outputs still equal the tiled kernel's bit for bit.
+  __syncthreads();                                            // every wave is done with the chunk buffers
   if (!wave_on) return;
+  constexpr int TS = 36;                                      // patch row stride (floats): 16-byte aligned rows, staggered banks
+  float* T = reinterpret_cast<float*>(panel_lds) + wave * 32 * TS;
+  const bool vec_out = (P.ldc & 3) == 0 && ((uintptr_t)P.c & 15u) == 0;
 #pragma unroll
   for (int i = 0; i < RT; i++)
 #pragma unroll
     for (int j = 0; j < CT; j++) {
+      if (ct0 + j >= nct) continue;                           // wave-uniform
       const int col = 32 * (ct0 + j) + (lane & 31);
-      const bool colok = ct0 + j < nct && col < P.cols;
-      const float bv = (P.bias && colok) ? P.bias[col] : 0.0f;
-#ifdef SHF_PANEL_STORE16
-      // (probe: the cost of the same bytes as 16-byte stores, eight lanes per 128-byte row segment -- wrong values)
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int row = r0 + 32 * i + (lane >> 3) + 8 * g, c4 = 32 * (ct0 + j) + 4 * (lane & 7);
-        if (ct0 + j < nct && c4 + 3 < P.cols && row < P.M) {
-          f32x4 o;
-#pragma unroll
-          for (int c = 0; c < 4; c++) { float v = acc[i][j][4 * g + c] + bv; if (P.act == 1) v = v > 0.0f ? v : __expf(v) - 1.0f; o[c] = v; }
-          *reinterpret_cast<f32x4*>(P.c + (size_t)row * P.ldc + c4) = o;
-        }
-      }
-      continue;
-#endif
+      const float bv = (P.bias && col < P.cols) ? P.bias[col] : 0.0f;
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) {
-        const int row = r0 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        float v = acc[i][j][reg] + bv;
+        if (P.act == 1) v = v > 0.0f ? v : __expf(v) - 1.0f;
+        T[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * TS + (lane & 31)] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int tr = (lane >> 3) + 8 * g, row = r0 + 32 * i + tr, c4 = 32 * (ct0 + j) + 4 * (lane & 7);
+        const f32x4 o = *reinterpret_cast<const f32x4*>(T + tr * TS + 4 * (lane & 7));
 #ifdef SHF_PANEL_NO_STORE
-        if (colok && row < P.M && acc[i][j][reg] == 12345.678f) {
+        if (row < P.M && o[0] == 12345.678f) {
 #else
-        if (colok && row < P.M) {
+        if (row < P.M) {
 #endif
-          float v = acc[i][j][reg] + bv;
-          if (P.act == 1) v = v > 0.0f ? v : __expf(v) - 1.0f;
-          P.c[(size_t)row * P.ldc + col] = v;
+          float* dst = P.c + (size_t)row * P.ldc + c4;
+          if (vec_out && c4 + 3 < P.cols) *reinterpret_cast<f32x4*>(dst) = o;
+          else {
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+              if (c4 + c < P.cols) dst[c] = o[c];
+          }
         }
       }
+      __builtin_amdgcn_wave_barrier();                        // the patch is rewritten by the next tile
     }
   MLP_CLOCK(3);
 }
@@ -677,7 +698,8 @@ int launch_panel(hipStream_t st, PanelArgs& P) {
   const int ct = nct > 8 ? 4 : nct > 4 ? 2 : 1;
   int bm = (ct == 4 || (P.M + 63) / 64 < 256) ? 32 : 64;
   if ((force_bm == 32 || force_bm == 64) && !(force_bm == 64 && ct == 4)) bm = force_bm;
-  const size_t lds = (size_t)2 * (split ? 2 : 1) * bm * KCS * 2;
+  size_t lds = (size_t)2 * (split ? 2 : 1) * bm * KCS * 2;
+  if (lds < 4 * 32 * 36 * sizeof(float)) lds = 4 * 32 * 36 * sizeof(float);   // the epilogue's four 32 x 36 patches
   if (bm == 64) return ct == 2 ? launch_panel_bc<64, 2>(st, P, split, lds) : launch_panel_bc<64, 1>(st, P, split, lds);
   return ct == 4 ? launch_panel_bc<32, 4>(st, P, split, lds) : ct == 2 ? launch_panel_bc<32, 2>(st, P, split, lds) : launch_panel_bc<32, 1>(st, P, split, lds);
 }
