@@ -42,6 +42,8 @@ constexpr int BN = 128, BK = 32, LDT = BK + 8;   // LDS row = 40 bf16 = 80 B: 16
 // otherwise leave most CUs without a block
 int wgrad_rows(int M, int K, int N) {
   const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128);
+  static const char* force = getenv("SHF_MLP_WGRAD_ROWS");       // experiments (tools/mlp_probe.py)
+  if (force && atoi(force) >= 32) return atoi(force) / 32 * 32;
   int per = 512;
   while (per > 128 && tiles * ((M + per - 1) / per) < 384) per >>= 1;
   return per;
@@ -200,8 +202,13 @@ template <int BMT, bool A_RED_CONTIG, bool B_RED_CONTIG, bool COLSUM_A, bool A_V
 __global__ __launch_bounds__(256) void k_mlp_gemm(Operand A, Operand B, int red, int red_per_slice, Epilogue E, int rows, int cols) {
   constexpr int TI = BMT / 64, NEA = BMT / 8;     // MFMA tiles per wave along the rows; A elements per thread and K tile
   constexpr int ALO = BMT * LDT, BLO = BN * LDT;  // SPLIT: offsets of the tail tiles behind the head tiles
-  __shared__ __attribute__((aligned(16))) uint16_t As[(SPLIT ? 2 : 1) * BMT * LDT];
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[(SPLIT ? 2 : 1) * BN * LDT];
+  // one array: the operand tiles, and -- after the loop -- the epilogue's four 32 x 36 float patches (EPI_WORDS)
+  constexpr int AS_WORDS = (SPLIT ? 2 : 1) * BMT * LDT, BS_WORDS = (SPLIT ? 2 : 1) * BN * LDT;
+  constexpr int EPI_TS = 36, EPI_BYTES = 4 * 32 * EPI_TS * 4;
+  constexpr int LDS_BYTES = (AS_WORDS + BS_WORDS) * 2 > EPI_BYTES ? (AS_WORDS + BS_WORDS) * 2 : EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_all[LDS_BYTES];
+  uint16_t* As = reinterpret_cast<uint16_t*>(lds_all);
+  uint16_t* Bs = As + AS_WORDS;
   MLP_CLOCK(0);
   // Workgroups go to the eight XCDs round-robin by linear id, and each XCD has its own L2.  With a split reduction
   // (weight gradient) the tiles of one slice share that slice's rows of both operands: renumber so that an XCD works
@@ -308,8 +315,13 @@ __global__ __launch_bounds__(256) void k_mlp_gemm(Operand A, Operand B, int red,
   if (acc[0][0][0] == 12345.678f) E.c[0] = acc[TI - 1][1][3];   // (probe build: keep the accumulators alive, skip the stores)
   return;
 #endif
-  // epilogue: C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  // epilogue: C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) -- turned
+  // through a wave-private LDS patch so that a lane stores 16 bytes and eight lanes cover a 128-byte row segment
+  // (4-byte stores in the accumulator layout cost 5 - 10 us per call on the large layers, profiles/r04_mlp_panel.md)
   float* Cout = E.c + (size_t)bz * rows * E.ldc * (gridDim.z > 1 ? 1 : 0);   // split-K: slice z writes its own partial
+  __syncthreads();                                                            // the operand tiles are dead
+  float* T = reinterpret_cast<float*>(lds_all) + wave * 32 * EPI_TS;
+  const bool vec_out = (E.ldc & 3) == 0 && ((uintptr_t)Cout & 15u) == 0;
 #pragma unroll
   for (int i = 0; i < TI; i++)
 #pragma unroll
@@ -318,19 +330,32 @@ __global__ __launch_bounds__(256) void k_mlp_gemm(Operand A, Operand B, int red,
       const float bv = (E.bias && col < cols) ? E.bias[col] : 0.0f;
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) {
-        const int row = r0 + wr + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        if (row < rows && col < cols) {
-          float v = acc[i][j][reg] + bv;
+        float v = acc[i][j][reg] + bv;
 #ifndef SHF_MLP_PROBE_NO_ELU
 #ifdef SHF_MLP_PROBE_EXPM1
-          if (E.act == 1) v = v > 0.0f ? v : expm1f(v);
+        if (E.act == 1) v = v > 0.0f ? v : expm1f(v);
 #else
-          if (E.act == 1) v = v > 0.0f ? v : __expf(v) - 1.0f;     // ELU, alpha = 1 (exp(x) - 1, as the stock elu kernel)
+        if (E.act == 1) v = v > 0.0f ? v : __expf(v) - 1.0f;     // ELU, alpha = 1 (exp(x) - 1, as the stock elu kernel)
 #endif
 #endif
-          Cout[(size_t)row * E.ldc + col] = v;
+        T[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * EPI_TS + (lane & 31)] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int tr = (lane >> 3) + 8 * g, row = r0 + wr + 32 * i + tr, c4 = c0 + wc + 32 * j + 4 * (lane & 7);
+        const f32x4 o = *reinterpret_cast<const f32x4*>(T + tr * EPI_TS + 4 * (lane & 7));
+        if (row < rows) {
+          float* dst = Cout + (size_t)row * E.ldc + c4;
+          if (vec_out && c4 + 3 < cols) *reinterpret_cast<f32x4*>(dst) = o;
+          else {
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+              if (c4 + c < cols) dst[c] = o[c];
+          }
         }
       }
+      __builtin_amdgcn_wave_barrier();                                        // the patch is rewritten by the next tile
     }
   if (COLSUM_A && by == 0 && threadIdx.x < BMT) {
     const int row = r0 + (int)threadIdx.x;

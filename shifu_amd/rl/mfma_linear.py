@@ -120,17 +120,74 @@ class _MfmaLinearFn(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+# Inference batches (no autograd) from this many rows use the row-panel kernel with the layer's KEPT pack (see
+# MfmaLinear.refresh_pack): at 4096 rows it is 13 - 50 % faster per layer than the tiled kernel once the pack launch is
+# not paid per call (profiles/r04_mlp_panel.md).
+PANEL_INFER_MIN_ROWS = int(os.environ.get("SHIFU_AMD_MLP_PANEL_INFER_ROWS", "1024"))
+
+
 class MfmaLinear(nn.Linear):
     """y = act(x W^T + b) on the MFMA kernels (CUDA fp32 2-D inputs); anything else falls back to the stock ops of
-    nn.Linear -- same maths in fp32 -- so the module also works on CPU (tests, checkpoints)."""
+    nn.Linear -- same maths in fp32 -- so the module also works on CPU (tests, checkpoints).
+
+    A rollout calls the layer dozens of times between two optimizer steps: `refresh_pack()` lays the weights out once
+    (shf_mlp_pack_weights into a buffer the layer keeps) and marks it valid; until `invalidate_pack()` every no-grad
+    forward uses it.  The flag is the CALLER's promise that the weights have not changed since (OnPolicyRunner refreshes
+    at the start of every rollout -- inside the captured rollout graph, so a replay re-packs -- and invalidates before
+    the update); without it every call packs for itself, which is always correct."""
 
     def __init__(self, in_features, out_features, elu: bool = False):
         super().__init__(in_features, out_features)
         self.elu = bool(elu)
+        self._pack = None
+        self._pack_valid = False
+
+    def refresh_pack(self):
+        if not self.weight.is_cuda or self.in_features > 512 or self.out_features > 512:
+            return
+        with torch.no_grad(), torch.cuda.device(self.weight.device):
+            if self._pack is None or self._pack.device != self.weight.device:
+                n = C.c_int64()
+                _check(lib().shf_mlp_pack_bytes(self.in_features, self.out_features, C.byref(n)))
+                self._pack = torch.empty(n.value, device=self.weight.device, dtype=torch.uint8)
+            _check(lib().shf_mlp_pack_weights(_ptr(self.weight), _ptr(self._pack), self.in_features, self.out_features,
+                                              _stream(self.weight)))
+        self._pack_valid = True
+
+    def invalidate_pack(self):
+        self._pack_valid = False
 
     def forward(self, x):
         if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
             _apply_env_precision()
+            if self._pack_valid and not torch.is_grad_enabled() and x.shape[0] >= PANEL_INFER_MIN_ROWS:
+                x = x.contiguous()
+                if x.data_ptr() % 16 == 0:
+                    y = torch.empty(x.shape[0], self.out_features, device=x.device, dtype=torch.float32)
+                    with torch.cuda.device(x.device):
+                        _check(lib().shf_mlp_panel_forward(_ptr(x), _ptr(self._pack), _ptr(self.bias), _ptr(y), x.shape[0],
+                                                           self.in_features, self.out_features, 1 if self.elu else 0, _stream(x)))
+                    return y
             return _MfmaLinearFn.apply(x, self.weight, self.bias, 1 if self.elu else 0)
         y = super().forward(x)
         return nn.functional.elu(y) if self.elu else y
+
+
+def refresh_packs(module: nn.Module) -> None:
+    """MfmaLinear.refresh_pack on every such layer of `module` (a no-op for other layers)."""
+    for m in module.modules():
+        if isinstance(m, MfmaLinear):
+            m.refresh_pack()
+
+
+def invalidate_packs(module: nn.Module) -> None:
+    for m in module.modules():
+        if isinstance(m, MfmaLinear):
+            m.invalidate_pack()
+
+
+def mark_packs_valid(module: nn.Module) -> None:
+    """After replaying a captured graph that contains the refresh: the pack kernels ran, only the Python flag is stale."""
+    for m in module.modules():
+        if isinstance(m, MfmaLinear) and m._pack is not None:
+            m._pack_valid = True

@@ -13,6 +13,7 @@ import torch
 
 from ..parallel import broadcast_parameters, rank, world_size
 from .actor_critic import ActorCritic
+from .mfma_linear import invalidate_packs, mark_packs_valid, refresh_packs
 from .ppo import PPO
 
 
@@ -85,6 +86,7 @@ class OnPolicyRunner:
                 if graph is not None:
                     graph.replay()
                     torch.cuda.synchronize()      # same precaution as after the captured update's replays (rl/ppo.py)
+                    mark_packs_valid(alg.actor_critic)     # (the replay re-ran _rollout's refresh_packs)
                 else:
                     R["ep_infos"].clear()
                     self._rollout(R)
@@ -96,6 +98,7 @@ class OnPolicyRunner:
                 collection_time = stop - start
                 start = stop
                 alg.compute_returns(critic_obs.clone())
+            invalidate_packs(alg.actor_critic)             # the update changes the weights
             mean_value_loss, mean_surrogate_loss = alg.update()
             learn_time = time.time() - start
             if self.log_dir is not None:
@@ -114,6 +117,7 @@ class OnPolicyRunner:
     def _rollout(self, R):
         """num_steps_per_env x (policy, env.step, bookkeeping).  Sync-free and shape-static, so it can be captured."""
         env, alg, dev = self.env, self.alg, self.device
+        refresh_packs(alg.actor_critic)      # MFMA layers: the weights laid out once for the rollout's 2 x T inference passes
         for _ in range(self.num_steps_per_env):
             obs = env.get_observations().to(dev)
             priv = env.get_privileged_observations()

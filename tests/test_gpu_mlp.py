@@ -114,6 +114,33 @@ def test_row_panel_kernels_equal_the_tiled_kernels_bitwise(M, K, N, elu, precisi
     assert torch.equal(gx1, gx2)
 
 
+def test_kept_pack_inference_equals_the_per_call_forward(precision):
+    """MfmaLinear.refresh_pack: no-grad forwards between a refresh and an invalidate reuse the kept weight layout (the
+    rollout's 2 x 24 inference passes); same bits as the per-call path, and stale-proof once invalidated."""
+    _need_gpu()
+    from shifu_amd.rl.mfma_linear import MfmaLinear, invalidate_packs, refresh_packs
+    torch.manual_seed(5)
+    dev = "cuda:0"
+    net = torch.nn.Sequential(MfmaLinear(259, 512, elu=True), MfmaLinear(512, 12, elu=False)).to(dev)
+    x = torch.randn(4096, 259, device=dev)
+    with torch.no_grad():
+        ref = net(x)                       # per-call path (tiled kernel at 4096 rows)
+        refresh_packs(net)
+        assert all(m._pack_valid for m in net)
+        got = net(x)
+        assert torch.equal(got, ref)
+        with torch.enable_grad():          # autograd passes never use the kept pack
+            y = net(x)
+            assert y.requires_grad and torch.equal(y.detach(), ref)
+        invalidate_packs(net)
+        net[0].weight.mul_(0.5)
+        assert torch.equal(net(x), torch.nn.Sequential(*[m for m in net])(x))
+        refresh_packs(net)
+        after = net(x)
+        invalidate_packs(net)
+        assert torch.equal(after, net(x)) and not torch.equal(after, ref)
+
+
 def test_actor_critic_on_the_mfma_backend_matches_the_torch_backend_and_trains():
     _need_gpu()
     from shifu_amd.rl.actor_critic import ActorCritic
