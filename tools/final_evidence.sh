@@ -20,6 +20,11 @@ python bench.py --mapping body --group 32 --steps 500 --warmup 50 --no-cpu-basel
 python bench.py --mapping chain --group 16 --steps 500 --warmup 50 --no-cpu-baseline > "$OUT/bench_terrain_chain_g16.json" 2>/dev/null
 python bench.py --workload abb --no-link-contacts --mapping chain --steps 500 --warmup 50 --no-cpu-baseline > "$OUT/bench_abb_rod_only_chain.json" 2>/dev/null
 python bench.py --workload abb --group 32 --steps 300 --warmup 30 --no-cpu-baseline > "$OUT/bench_abb_g32.json" 2>/dev/null
+python tools/mlp_probe.py --check > "$OUT/mlp_probe.json" 2> "$OUT/mlp_probe_check.txt"
+python tools/mlp_probe.py --bf16 > "$OUT/mlp_probe_bf16.json" 2>/dev/null
+python tools/mlp_probe.py --tiled > "$OUT/mlp_probe_tiled.json" 2>/dev/null
+python tools/mlp_probe.py 4096 > "$OUT/mlp_probe_4096.json" 2>/dev/null
+for k in 1 2 3; do python tools/bench_hook_envs.py --steps 300 --graph-hooks 2>/dev/null | grep "^{"; done > "$OUT/hook_envs.txt"
 python tools/phase_clock.py 32 200 --chain > "$OUT/phase_a1_chain_g32.txt" 2>&1
 python tools/phase_clock.py 16 200 --abb --link > "$OUT/phase_abb_link_g16.txt" 2>&1
 python tools/phase_clock.py 16 200 --abb --split > "$OUT/phase_abb_split.txt" 2>&1
