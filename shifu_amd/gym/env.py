@@ -16,6 +16,7 @@ import typing
 import numpy as np
 import torch
 
+from shifu_amd._lib import BackendError
 from shifu_amd.configs import TerrainEnvConfig
 from shifu_amd.utils.torch_utils import free_tensor_attrs
 from shifu_amd.utils.train import HistoryRecorder
@@ -133,10 +134,17 @@ class ShifuVecEnv:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
-            before()
-        with torch.cuda.graph(g2, pool=g1.pool()):
-            after()
+        try:
+            with torch.cuda.graph(g1):
+                before()
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                after()
+        except Exception as exc:      # a hook copied from the host, synchronised or branched on device data
+            self.common_step_counter = counter
+            self._hook_graphs = None
+            raise BackendError("enable_graph_hooks: this env's hooks cannot be captured into a hipGraph -- they must be pure "
+                               f"tensor code with fixed shapes (no host-to-device copies, .item(), Python branches on device "
+                               f"values); the env stays on the eager path.  Cause: {exc}") from exc
         self.common_step_counter = counter
         self._hook_graphs = (g1, g2)
 

@@ -193,6 +193,21 @@ def test_abb_pushbox_random_run_mode():
     assert resets > 0
 
 
+def test_graph_hooks_refuse_uncapturable_hooks_and_leave_the_env_usable():
+    """AbbPushBox.step builds tensors from Python lists (host-to-device copies): enable_graph_hooks must say so and leave
+    the env on its eager path, not half-captured."""
+    from shifu_amd._lib import BackendError
+    env = _abb(32)
+    env.reset()
+    with pytest.raises(BackendError, match="cannot be captured"):
+        env.enable_graph_hooks()
+    assert getattr(env, "_hook_graphs", None) is None
+    for _ in range(5):
+        obs, _, rew, _, _ = env.step(torch.zeros(env.num_envs, env.num_actions, device=env.device))
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+
+
 def test_abb_rod_pushes_the_cube():
     env = _abb(16)
     env.reset()
