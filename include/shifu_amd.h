@@ -536,6 +536,23 @@ int shf_mlp_panel_forward(const float* x, const void* pack, const float* b, floa
                           int32_t act, void* stream);
 int shf_mlp_panel_backward_input(const float* dy, const float* y_or_null, const void* pack, float* dx, int32_t M, int32_t K,
                                  int32_t N, void* stream);
+/* All layers of an MLP forward in ONE launch (a block carries 32 rows of the batch from the input to the output; the
+ * activations pass from layer to layer through LDS and go to HBM once, where y[l] is given -- every layer for a training
+ * pass, only the last for inference).  dims[0] = input width, dims[l + 1] = width of layer l's output (all <= 512);
+ * pack[l] from shf_mlp_pack_weights(w_l, ., dims[l], dims[l + 1]); bias[l] may be null; act[l] as in forward.  Every
+ * stored value equals what the chain of shf_mlp_linear_forward calls stores, bit for bit. */
+#define SHF_MLP_MAX_CHAIN 6
+typedef struct {
+  int32_t nlayers;
+  int32_t dims[SHF_MLP_MAX_CHAIN + 1];
+  const void* pack[SHF_MLP_MAX_CHAIN];
+  const float* bias[SHF_MLP_MAX_CHAIN];
+  int32_t act[SHF_MLP_MAX_CHAIN];
+  float* y[SHF_MLP_MAX_CHAIN];
+} ShfMlpChain;
+int shf_mlp_chain_forward(const float* x, int32_t M, const ShfMlpChain* chain, void* stream);
+/* 1 if these widths (nlayers, dims) fit the kernel's LDS panels at the current precision, else 0 (run the layers one by one). */
+int shf_mlp_chain_fits(const ShfMlpChain* chain);
 int shf_mlp_backward_weight_workspace(int32_t M, int32_t K, int32_t N, int64_t* floats);
 int shf_mlp_linear_backward_weight(const float* dy, const float* y_or_null, const float* x, float* dw, float* db,
                                    float* workspace, int32_t M, int32_t K, int32_t N, void* stream);

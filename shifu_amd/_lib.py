@@ -55,6 +55,8 @@ _SIGS = {
     "shf_mlp_pack_weights": ([vp, vp, i32, i32, vp], i32),
     "shf_mlp_panel_forward": ([vp, vp, vp, vp, i32, i32, i32, i32, vp], i32),
     "shf_mlp_panel_backward_input": ([vp, vp, vp, vp, i32, i32, i32, vp], i32),
+    "shf_mlp_chain_forward": ([vp, i32, vp, vp], i32),
+    "shf_mlp_chain_fits": ([vp], i32),
     "shf_mlp_set_precision": ([i32], i32),
     "shf_mlp_get_precision": ([], i32),
     "shf_mlp_linear_backward_weight": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], i32),

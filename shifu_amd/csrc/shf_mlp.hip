@@ -657,6 +657,215 @@ __global__ __launch_bounds__(256, 2) void k_mlp_panel(PanelArgs P) {
   MLP_CLOCK(3);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Chained forward: ALL layers of an MLP in one launch.  A block owns 32 rows of the batch from the observation to the
+// output: layer 0 streams its input through LDS like k_mlp_panel; every later layer takes its input from an LDS panel
+// that the previous layer's epilogue wrote (bf16 head + tail of the activated fp32 value -- exactly what the per-layer
+// kernel would have converted after reading it back from HBM), so the activations make one trip to HBM (written once, for
+// the backward pass; not at all for inference) instead of two, and a network pass pays one launch floor instead of four.
+// Two panels, A and B, alternate (layer l reads A when l is odd); the stream buffers of layer 0 share B.  Same k steps,
+// MFMAs and epilogue expressions as the per-layer kernels: every stored value is bit-identical to theirs.
+constexpr int CHAIN_MAX = SHF_MLP_MAX_CHAIN;
+struct ChainArgs {
+  const float* x;
+  int M, nl;
+  int dims[CHAIN_MAX + 1];
+  const uint4* bhi[CHAIN_MAX];
+  const uint4* blo[CHAIN_MAX];
+  const float* bias[CHAIN_MAX];
+  int act[CHAIN_MAX];
+  float* y[CHAIN_MAX];       // where layer l's output goes, or null (inference: only the last)
+  int pa_words, pb_words;    // sizes (uint16) of panel A and of panel B / stream buffers; the epilogue patches follow
+};
+// One layer of the chain for a wave that owns CT column tiles (compile-time, so that the accumulators and the ring of B
+// fragments are register arrays): ring depth 8 / CT k steps -- the block runs two waves per SIMD (its panels
+// fill the LDS), so the L2 latency of the weight fragments has to be covered by the ring alone.
+constexpr int CHAIN_THREADS = 512, CHAIN_WAVES = CHAIN_THREADS / 64;
+template <bool SPLIT, int CT>
+MLP_DEV void chain_layer(const ChainArgs& P, int l, uint16_t* PA, uint16_t* PB, float* T, int r0, int t, int wave, int lane) {
+  constexpr int BM = 32, TS = 36;
+  constexpr int D = 8 / CT;                                 // 64 registers of B fragments in flight (bf16x3)
+  constexpr int BUF = (SPLIT ? 2 : 1) * BM * KCS;
+  constexpr int NV = BM * KC / 4 / CHAIN_THREADS;           // 2 sixteen-byte chunks per thread and K chunk
+  const int red = P.dims[l], cols = P.dims[l + 1];
+  const int redp = (red + 15) & ~15, nks = redp >> 4, nct = (cols + 31) >> 5;
+  const int ct0 = wave * CT;
+  const bool wave_on = ct0 < nct;
+  const uint4* bhi = P.bhi[l];
+  const uint4* blo = P.blo[l];
+  f32x16 acc[CT];
+#pragma unroll
+  for (int j = 0; j < CT; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[j][r] = 0.0f;
+  size_t boff[CT];
+#pragma unroll
+  for (int j = 0; j < CT; j++) boff[j] = (size_t)(ct0 + j < nct ? ct0 + j : nct - 1) * nks * 64 + lane;
+  uint4 rh[D][CT], rl[D][SPLIT ? CT : 1];
+  if (wave_on) {
+#pragma unroll
+    for (int d = 0; d < D; d++)
+      if (d < nks) {
+#pragma unroll
+        for (int j = 0; j < CT; j++) { rh[d][j] = bhi[boff[j] + (size_t)d * 64]; if (SPLIT) rl[d][j] = blo[boff[j] + (size_t)d * 64]; }
+      }
+  }
+  auto kstep = [&](int ks, int d, const uint16_t* Ah, const uint16_t* Al) {
+    bf16x8 bh[CT], bl[CT];
+#pragma unroll
+    for (int j = 0; j < CT; j++) { bh[j] = __builtin_bit_cast(bf16x8, rh[d][j]); if (SPLIT) bl[j] = __builtin_bit_cast(bf16x8, rl[d][j]); }
+    if (ks + D < nks) {
+#pragma unroll
+      for (int j = 0; j < CT; j++) { rh[d][j] = bhi[boff[j] + (size_t)(ks + D) * 64]; if (SPLIT) rl[d][j] = blo[boff[j] + (size_t)(ks + D) * 64]; }
+    }
+    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ah);
+    bf16x8 al;
+    if (SPLIT) al = *reinterpret_cast<const bf16x8*>(Al);
+    // per accumulator the order is tail x head, head x tail, head x head as in the per-layer kernels; across the wave's
+    // accumulators the three rounds are interleaved so that consecutive MFMAs are independent
+    if (SPLIT) {
+#pragma unroll
+      for (int j = 0; j < CT; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < CT; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < CT; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[j], 0, 0, 0);
+  };
+
+  if (l == 0) {
+    // the observation rows stream through two chunk buffers (in panel B's space), as in k_mlp_panel
+    const bool vec = (red & 3) == 0;
+    const int nchunks = (redp + KC - 1) / KC;
+    f32x4 v[NV];
+    auto issue = [&](int kc0) {
+#pragma unroll
+      for (int u = 0; u < NV; u++) {
+        const int idx = t + CHAIN_THREADS * u, row = idx >> 5, k = kc0 + 4 * (idx & 31);
+        const bool rin = r0 + row < P.M;
+        const size_t off = (size_t)(r0 + row) * red + k;
+        v[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (vec) {
+          if (rin && k < red) v[u] = *reinterpret_cast<const f32x4*>(P.x + off);
+        } else if (rin) {
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+            if (k + c < red) v[u][c] = P.x[off + c];
+        }
+      }
+    };
+    auto commit = [&](uint16_t* buf) {
+#pragma unroll
+      for (int u = 0; u < NV; u++) {
+        const int idx = t + CHAIN_THREADS * u, row = idx >> 5, k = 4 * (idx & 31);
+        bf16x4 h, lo;
+#pragma unroll
+        for (int c = 0; c < 4; c++) { h[c] = (__bf16)v[u][c]; if (SPLIT) lo[c] = (__bf16)(v[u][c] - (float)h[c]); }
+        *reinterpret_cast<bf16x4*>(buf + row * KCS + k) = h;
+        if (SPLIT) *reinterpret_cast<bf16x4*>(buf + BM * KCS + row * KCS + k) = lo;
+      }
+    };
+    issue(0);
+    commit(PB);
+    __syncthreads();
+    const int frag = (lane & 31) * KCS + 8 * (lane >> 5);
+    for (int c = 0; c < nchunks; c++) {
+      const uint16_t* Ah = PB + (c & 1) * BUF;
+      if (c + 1 < nchunks) issue((c + 1) * KC);
+      if (wave_on) {
+        const int ks_end = (c + 1) * (KC / 16) < nks ? (c + 1) * (KC / 16) : nks;
+        static_assert((KC / 16) % D == 0, "the ring position of a chunk's first k step must be 0");
+        for (int ks0 = c * (KC / 16); ks0 < ks_end; ks0 += D) {
+#pragma unroll
+          for (int d = 0; d < D; d++) {
+            const int ks = ks0 + d;
+            if (ks >= ks_end) break;
+            const int kl = 16 * (ks - c * (KC / 16));
+            kstep(ks, d, Ah + frag + kl, Ah + BM * KCS + frag + kl);
+          }
+        }
+      }
+      if (c + 1 < nchunks) {
+        commit(PB + ((c + 1) & 1) * BUF);
+        lds_barrier();
+      }
+    }
+  } else if (wave_on) {
+    const int S = ((red + 31) & ~31) + PANEL_PAD;
+    const uint16_t* Xp = (l & 1) ? PA : PB;
+    const int frag = (lane & 31) * S + 8 * (lane >> 5);
+    for (int ks0 = 0; ks0 < nks; ks0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        const int ks = ks0 + d;
+        if (ks >= nks) break;
+        kstep(ks, d, Xp + frag + 16 * ks, Xp + BM * S + frag + 16 * ks);
+      }
+    }
+  }
+
+  // epilogue: bias, activation; through the wave's LDS patch to 16-byte global stores (if this layer's output is kept)
+  // and to the next layer's input panel as bf16 head + tail
+  const bool has_next = l + 1 < P.nl;
+  const int Sn = ((cols + 31) & ~31) + PANEL_PAD;
+  uint16_t* Xn = ((l + 1) & 1) ? PA : PB;
+  float* Y = P.y[l];
+  const bool vec_out = Y && (cols & 3) == 0 && ((uintptr_t)Y & 15u) == 0;
+  if (wave_on) {
+#pragma unroll
+    for (int j = 0; j < CT; j++) {
+      if (ct0 + j >= nct) continue;
+      const int col = 32 * (ct0 + j) + (lane & 31);
+      const float bv = (P.bias[l] && col < cols) ? P.bias[l][col] : 0.0f;
+#pragma unroll
+      for (int reg = 0; reg < 16; reg++) {
+        float v = acc[j][reg] + bv;
+        if (P.act[l] == 1) v = v > 0.0f ? v : __expf(v) - 1.0f;
+        T[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * TS + (lane & 31)] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int tr = (lane >> 3) + 8 * g, row = r0 + tr, c4 = 32 * (ct0 + j) + 4 * (lane & 7);
+        const f32x4 o = *reinterpret_cast<const f32x4*>(T + tr * TS + 4 * (lane & 7));
+        if (Y && row < P.M) {
+          float* dst = Y + (size_t)row * cols + c4;
+          if (vec_out && c4 + 3 < cols) *reinterpret_cast<f32x4*>(dst) = o;
+          else {
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+              if (c4 + c < cols) dst[c] = o[c];
+          }
+        }
+        if (has_next) {
+          bf16x4 h, lo;
+#pragma unroll
+          for (int c = 0; c < 4; c++) { h[c] = (__bf16)o[c]; if (SPLIT) lo[c] = (__bf16)(o[c] - (float)h[c]); }
+          *reinterpret_cast<bf16x4*>(Xn + tr * Sn + c4) = h;
+          if (SPLIT) *reinterpret_cast<bf16x4*>(Xn + BM * Sn + tr * Sn + c4) = lo;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();      // the next layer's input panel is complete; this layer's input may be overwritten from now on
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(CHAIN_THREADS) void k_mlp_chain(ChainArgs P) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t chain_lds[];
+  uint16_t* PA = chain_lds;
+  uint16_t* PB = chain_lds + P.pa_words;
+  const int t = (int)threadIdx.x, wave = t >> 6, lane = t & 63;
+  float* T = reinterpret_cast<float*>(chain_lds + P.pa_words + P.pb_words) + wave * 32 * 36;
+  const int r0 = (int)blockIdx.x * 32;
+  for (int l = 0; l < P.nl; l++) {
+    const int nct = (P.dims[l + 1] + 31) >> 5;               // column tiles per wave: 2 from 9 tiles, else 1
+    if (nct > 8) chain_layer<SPLIT, 2>(P, l, PA, PB, T, r0, t, wave, lane);
+    else chain_layer<SPLIT, 1>(P, l, PA, PB, T, r0, t, wave, lane);
+  }
+}
+
 // W[N, K] (fp32) -> four fragment-ordered bf16 arrays: plain (column = n, reduction = k) head / tail, then transposed
 // (column = k, reduction = n) head / tail.  One thread per 16-byte fragment entry.
 struct PackDims { int nct, nks; size_t entries; };
@@ -1003,6 +1212,68 @@ extern "C" int shf_mlp_panel_backward_input(const float* dy, const float* y_or_n
   PanelArgs P{dy, y_or_null, M, N, q.nks * 16, div_magic(N), th, th + q.entries, dx, K, K, nullptr, 0};
   if (launch_panel((hipStream_t)stream, P)) return 1;
   return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_mlp_panel_backward_input: launch failed");
+}
+
+// LDS of one k_mlp_chain block for these widths at the current precision: panel A, panel B (also layer 0's two chunk
+// buffers), the waves' epilogue patches.  0 = the widths are not chainable at all.
+static size_t chain_lds(const ShfMlpChain* c, size_t* pa_out, size_t* pb_out) {
+  if (c->nlayers < 1 || c->nlayers > SHF_MLP_MAX_CHAIN) return 0;
+  const int planes = g_mlp_precision == SHF_MLP_BF16X3 ? 2 : 1;
+  size_t pa = 0, pb = (size_t)2 * planes * 32 * KCS;
+  for (int l = 0; l <= c->nlayers; l++) {
+    if (c->dims[l] <= 0 || c->dims[l] > 512) return 0;
+    if (l >= 1 && l < c->nlayers) {                       // the input panel of layer l
+      const size_t words = (size_t)planes * 32 * (((c->dims[l] + 31) & ~31) + PANEL_PAD);
+      if (l & 1) pa = words > pa ? words : pa; else pb = words > pb ? words : pb;
+    }
+  }
+  if (pa_out) *pa_out = pa;
+  if (pb_out) *pb_out = pb;
+  return (pa + pb) * 2 + CHAIN_WAVES * 32 * 36 * sizeof(float);
+}
+extern "C" int shf_mlp_chain_fits(const ShfMlpChain* c) {
+  if (!c) return 0;
+  const size_t lds = chain_lds(c, nullptr, nullptr);
+  return lds > 0 && lds <= 160 * 1024 ? 1 : 0;
+}
+extern "C" int shf_mlp_chain_forward(const float* x, int32_t M, const ShfMlpChain* c, void* stream) {
+  if (!x || !c || M <= 0) return mlp_fail("shf_mlp_chain_forward: bad argument");
+  if (c->nlayers < 1 || c->nlayers > SHF_MLP_MAX_CHAIN) return mlp_fail("shf_mlp_chain_forward: 1 .. SHF_MLP_MAX_CHAIN layers");
+  if (((uintptr_t)x & 15u) != 0) return mlp_fail("shf_mlp_chain_forward: x must be 16-byte aligned");
+  const bool split = g_mlp_precision == SHF_MLP_BF16X3;
+  ChainArgs P{};
+  P.x = x; P.M = M; P.nl = c->nlayers;
+  size_t pa = 0, pb = 0;
+  const size_t lds = chain_lds(c, &pa, &pb);
+  if (lds == 0) return mlp_fail("shf_mlp_chain_forward: layer widths must be 1 .. 512");
+  if (lds > 160 * 1024) return mlp_fail("shf_mlp_chain_forward: the panels exceed the LDS (shf_mlp_chain_fits)");
+  for (int l = 0; l <= c->nlayers; l++) P.dims[l] = c->dims[l];
+  if (too_big(M, 512, 512)) return mlp_fail("shf_mlp_chain_forward: batch too large");
+  for (int l = 0; l < c->nlayers; l++) {
+    if (!c->pack[l]) return mlp_fail("shf_mlp_chain_forward: null pack");
+    if (c->act[l] < 0 || c->act[l] > 1) return mlp_fail("shf_mlp_chain_forward: bad activation");
+    const PackDims p = pack_dims(c->dims[l + 1], c->dims[l]);
+    P.bhi[l] = (const uint4*)c->pack[l];
+    P.blo[l] = (const uint4*)c->pack[l] + p.entries;
+    P.bias[l] = c->bias[l]; P.act[l] = c->act[l]; P.y[l] = c->y[l];
+  }
+  if (!c->y[c->nlayers - 1]) return mlp_fail("shf_mlp_chain_forward: the last layer needs an output buffer");
+  P.pa_words = (int)pa; P.pb_words = (int)pb;
+  const dim3 grid((M + 31) / 32);
+#define SHF_CHAIN_GO(SPLITV)                                                                                     \
+  do {                                                                                                           \
+    auto fn = k_mlp_chain<SPLITV>;                                                                               \
+    static bool attr = false;                                                                                    \
+    if (!attr) {                                                                                                 \
+      if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
+        return mlp_fail("k_mlp_chain: cannot raise the dynamic LDS limit");                                      \
+      attr = true;                                                                                               \
+    }                                                                                                            \
+    hipLaunchKernelGGL(fn, grid, dim3(CHAIN_THREADS), lds, (hipStream_t)stream, P);                              \
+  } while (0)
+  if (split) SHF_CHAIN_GO(true); else SHF_CHAIN_GO(false);
+#undef SHF_CHAIN_GO
+  return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_mlp_chain_forward: launch failed");
 }
 
 extern "C" int shf_mlp_backward_weight_workspace(int32_t M, int32_t K, int32_t N, int64_t* floats) {

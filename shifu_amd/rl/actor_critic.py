@@ -26,14 +26,14 @@ def _mlp(n_in: int, hidden: Sequence[int], n_out: int, act: str, backend: str = 
         if act != "elu":
             raise ValueError("mlp_backend='mfma' implements ELU only (the activation of every reference config)")
         # csrc/shf_mlp.hip: bias + ELU fused into the GEMM; an Identity keeps rsl_rl's parameter names (actor.0, actor.2, ...)
-        from .mfma_linear import MfmaLinear
+        from .mfma_linear import MfmaLinear, MfmaMLP
         layers, last = [], n_in
         for h in hidden:
             layers += [MfmaLinear(last, h, elu=True), nn.Identity()]
             last = h
         # the output layer (action means / value: 128 -> 12 / 1, 0.1 % of the flops) stays in fp32
         layers.append(MfmaLinear(last, n_out, elu=False) if _mfma_output_layer() else SplitKLinear(last, n_out))
-        return nn.Sequential(*layers)
+        return MfmaMLP(*layers)      # one chained launch per forward where every layer qualifies (rl/mfma_linear.py)
     layers, last = [], n_in
     for h in hidden:
         layers += [SplitKLinear(last, h), _ACTIVATIONS[act]()]

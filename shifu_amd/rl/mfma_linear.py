@@ -173,6 +173,136 @@ class MfmaLinear(nn.Linear):
         return nn.functional.elu(y) if self.elu else y
 
 
+MAX_CHAIN = 6      # SHF_MLP_MAX_CHAIN
+
+
+class _ShfMlpChain(C.Structure):        # include/shifu_amd.h ShfMlpChain
+    _fields_ = [("nlayers", C.c_int32), ("dims", C.c_int32 * (MAX_CHAIN + 1)), ("pack", C.c_void_p * MAX_CHAIN),
+                ("bias", C.c_void_p * MAX_CHAIN), ("act", C.c_int32 * MAX_CHAIN), ("y", C.c_void_p * MAX_CHAIN)]
+
+
+def _chain_call(x, layers, packs, ys):
+    """shf_mlp_chain_forward over `layers` (MfmaLinear), their packs and per-layer output tensors (None = not kept)."""
+    c = _ShfMlpChain()
+    c.nlayers = len(layers)
+    c.dims[0] = layers[0].in_features
+    for i, (m, pk, y) in enumerate(zip(layers, packs, ys)):
+        c.dims[i + 1] = m.out_features
+        c.pack[i] = pk.data_ptr()
+        c.bias[i] = m.bias.data_ptr() if m.bias is not None else None
+        c.act[i] = 1 if m.elu else 0
+        c.y[i] = y.data_ptr() if y is not None else None
+    with torch.cuda.device(x.device):
+        _check(lib().shf_mlp_chain_forward(_ptr(x), x.shape[0], C.byref(c), _stream(x)))
+
+
+class _MfmaChainFn(torch.autograd.Function):
+    """The whole MLP as one autograd node: forward = ONE launch (k_mlp_chain: the activations stay in LDS between layers
+    and are written once for the backward pass), backward = the per-layer input-gradient / weight-gradient kernels in
+    reverse order.  Same values as the chain of _MfmaLinearFn nodes, bit for bit (tests/test_gpu_mlp.py)."""
+
+    @staticmethod
+    def forward(ctx, x, acts, *params):
+        x = x.contiguous()
+        n = len(params) // 2
+        ws, bs = params[0::2], params[1::2]
+        M = x.shape[0]
+        packs = [_pack_weights(w) for w in ws]
+        ys = [torch.empty(M, w.shape[0], device=x.device, dtype=torch.float32) for w in ws]
+        c = _ShfMlpChain()
+        c.nlayers = n
+        c.dims[0] = ws[0].shape[1]
+        for i in range(n):
+            c.dims[i + 1] = ws[i].shape[0]
+            c.pack[i] = packs[i].data_ptr(); c.bias[i] = bs[i].data_ptr(); c.act[i] = acts[i]; c.y[i] = ys[i].data_ptr()
+        with torch.cuda.device(x.device):
+            _check(lib().shf_mlp_chain_forward(_ptr(x), M, C.byref(c), _stream(x)))
+        ctx.save_for_backward(x, *ws, *ys)
+        ctx.packs, ctx.acts, ctx.n = packs, acts, n
+        return ys[-1]
+
+    @staticmethod
+    def backward(ctx, gy):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        x, ws, ys = saved[0], saved[1:1 + n], saved[1 + n:]
+        g = gy.contiguous()
+        grads = [None] * (2 * n)
+        L = lib()
+        with torch.cuda.device(x.device):
+            for i in range(n - 1, -1, -1):
+                inp = x if i == 0 else ys[i - 1]
+                M, K = inp.shape
+                N = ws[i].shape[0]
+                yp = _ptr(ys[i]) if ctx.acts[i] == 1 else None
+                gx = None
+                if i > 0 or ctx.needs_input_grad[0]:
+                    gx = torch.empty_like(inp)
+                    if PANEL_MIN_ROWS and M >= PANEL_MIN_ROWS and g.data_ptr() % 16 == 0:
+                        _check(L.shf_mlp_panel_backward_input(_ptr(g), yp, _ptr(ctx.packs[i]), _ptr(gx), M, K, N, _stream(x)))
+                    else:
+                        _check(L.shf_mlp_linear_backward_input(_ptr(g), yp, _ptr(ws[i]), _ptr(gx), M, K, N, _stream(x)))
+                if ctx.needs_input_grad[2 + 2 * i] or ctx.needs_input_grad[3 + 2 * i]:
+                    nw = C.c_int64()
+                    _check(L.shf_mlp_backward_weight_workspace(M, K, N, C.byref(nw)))
+                    wsp = torch.empty(nw.value, device=x.device, dtype=torch.float32)
+                    gw, gb = torch.empty_like(ws[i]), torch.empty(N, device=x.device, dtype=torch.float32)
+                    _check(L.shf_mlp_linear_backward_weight(_ptr(g), yp, _ptr(inp), _ptr(gw), _ptr(gb), _ptr(wsp), M, K, N,
+                                                            _stream(x)))
+                    grads[2 * i], grads[2 * i + 1] = gw, gb
+                g = gx
+        return (g if ctx.needs_input_grad[0] else None, None, *grads)
+
+
+# Rows from which an MfmaMLP runs a no-grad forward (kept packs valid) as ONE chained launch (SHIFU_AMD_MLP_CHAIN_ROWS;
+# 0 = never): the rollout's 4096-row inference passes take 29 us per network instead of 41 (profiles/r04_mlp_panel.md).
+CHAIN_MIN_ROWS = int(os.environ.get("SHIFU_AMD_MLP_CHAIN_ROWS", "1024"))
+# The autograd form (_MfmaChainFn: forward chained, every activation kept; backward layer by layer) is bit-identical too but
+# not faster than the row-panel kernels at 24 576 rows with bf16x3 operands (107 vs 103 us; 66 vs 75 with bf16), and it
+# fills the LDS, which costs the update's two streams their overlap: off unless SHIFU_AMD_MLP_CHAIN_TRAIN=1.
+CHAIN_TRAIN = os.environ.get("SHIFU_AMD_MLP_CHAIN_TRAIN", "0") == "1"
+
+
+class MfmaMLP(nn.Sequential):
+    """nn.Sequential of MfmaLinear layers (nn.Identity between them keeps rsl_rl's parameter names) whose forward is one
+    chained launch when every layer is an MfmaLinear of at most 512 units on a CUDA fp32 batch; otherwise -- CPU tensors,
+    small batches, wider layers -- the layers run one by one as in any nn.Sequential."""
+
+    def _chain_layers(self):
+        ls = [m for m in self if not isinstance(m, nn.Identity)]
+        if not ls or len(ls) > MAX_CHAIN or not all(isinstance(m, MfmaLinear) and m.bias is not None for m in ls):
+            return None
+        if any(m.in_features > 512 or m.out_features > 512 for m in ls):
+            return None
+        c = _ShfMlpChain()
+        c.nlayers = len(ls)
+        c.dims[0] = ls[0].in_features
+        for i, m in enumerate(ls):
+            c.dims[i + 1] = m.out_features
+        return ls if lib().shf_mlp_chain_fits(C.byref(c)) else None      # (depends on the precision mode: asked per call)
+
+    def forward(self, x):
+        ls = self._chain_layers() if CHAIN_MIN_ROWS else None
+        if ls is None or not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= CHAIN_MIN_ROWS):
+            return super().forward(x)
+        _apply_env_precision()
+        x = x.contiguous()
+        if x.data_ptr() % 16 != 0:
+            return super().forward(x)
+        if not torch.is_grad_enabled():
+            if all(m._pack_valid for m in ls):          # inference between refresh_packs and invalidate_packs
+                y = torch.empty(x.shape[0], ls[-1].out_features, device=x.device, dtype=torch.float32)
+                _chain_call(x, ls, [m._pack for m in ls], [None] * (len(ls) - 1) + [y])
+                return y
+            return super().forward(x)
+        if not CHAIN_TRAIN:
+            return super().forward(x)
+        params = []
+        for m in ls:
+            params += [m.weight, m.bias]
+        return _MfmaChainFn.apply(x, tuple(1 if m.elu else 0 for m in ls), *params)
+
+
 def refresh_packs(module: nn.Module) -> None:
     """MfmaLinear.refresh_pack on every such layer of `module` (a no-op for other layers)."""
     for m in module.modules():

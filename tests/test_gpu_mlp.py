@@ -114,6 +114,47 @@ def test_row_panel_kernels_equal_the_tiled_kernels_bitwise(M, K, N, elu, precisi
     assert torch.equal(gx1, gx2)
 
 
+@pytest.mark.parametrize("M,dims", [(24576, (259, 512, 256, 128, 12)), (4096, (259, 512, 256, 128, 1)), (1030, (37, 100, 5)),
+                                    (2048, (64, 512, 512, 512, 512, 33))])
+def test_chained_forward_equals_the_layer_by_layer_path_bitwise(M, dims, precision, monkeypatch):
+    """MfmaMLP: the whole network forward as one launch (k_mlp_chain, activations passed through LDS) against the same
+    layers run one by one -- outputs, input gradient and every weight / bias gradient equal bit for bit; inference with
+    kept packs likewise."""
+    _need_gpu()
+    from shifu_amd.rl import mfma_linear as ML
+    torch.manual_seed(11)
+    dev = "cuda:0"
+    layers = []
+    for i in range(len(dims) - 1):
+        layers += [ML.MfmaLinear(dims[i], dims[i + 1], elu=i < len(dims) - 2), torch.nn.Identity()]
+    net = ML.MfmaMLP(*layers[:-1]).to(dev)
+    x = torch.randn(M, dims[0], device=dev) * 1.5
+    g = torch.randn(M, dims[-1], device=dev)
+
+    monkeypatch.setattr(ML, "CHAIN_TRAIN", True)        # (the autograd form is a switch: SHIFU_AMD_MLP_CHAIN_TRAIN)
+
+    def run(chain_rows):
+        monkeypatch.setattr(ML, "CHAIN_MIN_ROWS", chain_rows)
+        for p in net.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        y = net(xi)
+        y.backward(g)
+        return [y.detach().clone(), xi.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+
+    one_by_one, chained = run(0), run(1024)
+    for a, b in zip(one_by_one, chained):
+        assert torch.equal(a, b)
+    with torch.no_grad():
+        monkeypatch.setattr(ML, "CHAIN_MIN_ROWS", 0)
+        ref = net(x)
+        monkeypatch.setattr(ML, "CHAIN_MIN_ROWS", 1024)
+        ML.refresh_packs(net)
+        got = net(x)
+        ML.invalidate_packs(net)
+    assert torch.equal(ref, got) and torch.equal(ref, chained[0])
+
+
 def test_kept_pack_inference_equals_the_per_call_forward(precision):
     """MfmaLinear.refresh_pack: no-grad forwards between a refresh and an invalidate reuse the kept weight layout (the
     rollout's 2 x 24 inference passes); same bits as the per-call path, and stale-proof once invalidated."""

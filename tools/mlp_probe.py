@@ -80,6 +80,18 @@ def main():
         byt_f = 4.0 * (M * K + N * K + M * N)
         out["layers"].append({"K": K, "N": N, "pack_us": round(pk, 1), "fwd_us": round(f, 1), "bwd_input_us": round(bi, 1), "bwd_weight_us": round(bw, 1),
                               "fwd_tflops": round(2.0 * M * K * N / f / 1e6, 1), "fwd_alg_GBps": round(byt_f / f / 1e3, 0)})
+    if not tiled:
+        # the four layers' forward as one chained launch (k_mlp_chain): every activation kept (a training pass) / only the output
+        from shifu_amd.rl import mfma_linear as ML
+        dims = (259, 512, 256, 128, 12)
+        net = ML.MfmaMLP(*[m for i in range(4) for m in (ML.MfmaLinear(dims[i], dims[i + 1], elu=i < 3), torch.nn.Identity())][:-1]).cuda()
+        ls = [m for m in net if isinstance(m, ML.MfmaLinear)]
+        x = torch.randn(M, 259, device="cuda")
+        ML.refresh_packs(net)
+        ys = [torch.empty(M, d, device="cuda") for d in dims[1:]]
+        out["chain_fwd_all_kept_us"] = round(timed(lambda: ML._chain_call(x, ls, [m._pack for m in ls], ys)), 1)
+        out["chain_fwd_output_only_us"] = round(timed(lambda: ML._chain_call(x, ls, [m._pack for m in ls], [None, None, None, ys[-1]])), 1)
+        out["layerwise_fwd_us"] = round(sum(l["fwd_us"] for l in out["layers"]), 1)
     out["total_us"] = round(sum(l["pack_us"] + l["fwd_us"] + l["bwd_input_us"] + l["bwd_weight_us"] for l in out["layers"]), 1)
     print(json.dumps(out))
 
