@@ -659,11 +659,11 @@ __global__ __launch_bounds__(256, 2) void k_mlp_panel(PanelArgs P) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Chained forward: ALL layers of an MLP in one launch.  A block owns 32 rows of the batch from the observation to the
-// output: layer 0 streams its input through LDS like k_mlp_panel; every later layer takes its input from an LDS panel
+// output: layer 0 loads its 32 input rows into an LDS panel; every later layer takes its input from an LDS panel
 // that the previous layer's epilogue wrote (bf16 head + tail of the activated fp32 value -- exactly what the per-layer
 // kernel would have converted after reading it back from HBM), so the activations make one trip to HBM (written once, for
 // the backward pass; not at all for inference) instead of two, and a network pass pays one launch floor instead of four.
-// Two panels, A and B, alternate (layer l reads A when l is odd); the stream buffers of layer 0 share B.  Same k steps,
+// Two panels, A and B, alternate (layer l reads A when l is odd, B when even).  Same k steps,
 // MFMAs and epilogue expressions as the per-layer kernels: every stored value is bit-identical to theirs.
 constexpr int CHAIN_MAX = SHF_MLP_MAX_CHAIN;
 struct ChainArgs {
@@ -685,8 +685,6 @@ template <bool SPLIT, int CT>
 MLP_DEV void chain_layer(const ChainArgs& P, int l, uint16_t* PA, uint16_t* PB, float* T, int r0, int t, int wave, int lane) {
   constexpr int BM = 32, TS = 36;
   constexpr int D = 8 / CT;                                 // 64 registers of B fragments in flight (bf16x3)
-  constexpr int BUF = (SPLIT ? 2 : 1) * BM * KCS;
-  constexpr int NV = BM * KC / 4 / CHAIN_THREADS;           // 2 sixteen-byte chunks per thread and K chunk
   const int red = P.dims[l], cols = P.dims[l + 1];
   const int redp = (red + 15) & ~15, nks = redp >> 4, nct = (cols + 31) >> 5;
   const int ct0 = wave * CT;
@@ -733,66 +731,67 @@ MLP_DEV void chain_layer(const ChainArgs& P, int l, uint16_t* PA, uint16_t* PB, 
     for (int j = 0; j < CT; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[j], 0, 0, 0);
   };
 
+  // this wave's bias values: requested before the reduction so that their round trip is off the epilogue's path
+  float bvs[CT];
+#pragma unroll
+  for (int j = 0; j < CT; j++) {
+    const int col = 32 * (ct0 + j) + (lane & 31);
+    bvs[j] = (P.bias[l] && ct0 + j < nct && col < cols) ? P.bias[l][col] : 0.0f;
+  }
+  const int S = ((red + 31) & ~31) + PANEL_PAD;
+  uint16_t* Xp = (l & 1) ? PA : PB;
   if (l == 0) {
-    // the observation rows stream through two chunk buffers (in panel B's space), as in k_mlp_panel
-    const bool vec = (red & 3) == 0;
-    const int nchunks = (redp + KC - 1) / KC;
-    f32x4 v[NV];
-    auto issue = [&](int kc0) {
+    // the block's 32 input rows -- one contiguous range of memory -- into panel B as bf16 head + tail: every load of the
+    // panel is in flight at once (<= 8 sixteen-byte loads per thread at 512 columns)
+    const int E = BM * red;
+    const float* src = P.x + (size_t)r0 * red;
+    const int Ein = (P.M - r0 < BM ? P.M - r0 : BM) * red;
+    const uint32_t magic = (uint32_t)((1ull << 32) / (uint64_t)red) + 1u;
+    constexpr int NVX = (BM * 512 / 4 + CHAIN_THREADS - 1) / CHAIN_THREADS;
+    f32x4 v[NVX];
 #pragma unroll
-      for (int u = 0; u < NV; u++) {
-        const int idx = t + CHAIN_THREADS * u, row = idx >> 5, k = kc0 + 4 * (idx & 31);
-        const bool rin = r0 + row < P.M;
-        const size_t off = (size_t)(r0 + row) * red + k;
-        v[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (vec) {
-          if (rin && k < red) v[u] = *reinterpret_cast<const f32x4*>(P.x + off);
-        } else if (rin) {
-#pragma unroll
-          for (int c = 0; c < 4; c++)
-            if (k + c < red) v[u][c] = P.x[off + c];
-        }
+    for (int u = 0; u < NVX; u++) {
+      const int e = 4 * (t + CHAIN_THREADS * u);
+      v[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (e + 3 < Ein) v[u] = *reinterpret_cast<const f32x4*>(src + e);
+      else if (e < Ein) {
+        for (int c = 0; c < 4; c++)
+          if (e + c < Ein) v[u][c] = src[e + c];
       }
-    };
-    auto commit = [&](uint16_t* buf) {
+    }
+    const bool vec_store = (red & 3) == 0;
 #pragma unroll
-      for (int u = 0; u < NV; u++) {
-        const int idx = t + CHAIN_THREADS * u, row = idx >> 5, k = 4 * (idx & 31);
+    for (int u = 0; u < NVX; u++) {
+      const int e = 4 * (t + CHAIN_THREADS * u);
+      if (e >= E) continue;
+      int row = (int)__umulhi((uint32_t)e, magic), k = e - row * red;
+      if (vec_store) {
         bf16x4 h, lo;
 #pragma unroll
         for (int c = 0; c < 4; c++) { h[c] = (__bf16)v[u][c]; if (SPLIT) lo[c] = (__bf16)(v[u][c] - (float)h[c]); }
-        *reinterpret_cast<bf16x4*>(buf + row * KCS + k) = h;
-        if (SPLIT) *reinterpret_cast<bf16x4*>(buf + BM * KCS + row * KCS + k) = lo;
-      }
-    };
-    issue(0);
-    commit(PB);
-    __syncthreads();
-    const int frag = (lane & 31) * KCS + 8 * (lane >> 5);
-    for (int c = 0; c < nchunks; c++) {
-      const uint16_t* Ah = PB + (c & 1) * BUF;
-      if (c + 1 < nchunks) issue((c + 1) * KC);
-      if (wave_on) {
-        const int ks_end = (c + 1) * (KC / 16) < nks ? (c + 1) * (KC / 16) : nks;
-        static_assert((KC / 16) % D == 0, "the ring position of a chunk's first k step must be 0");
-        for (int ks0 = c * (KC / 16); ks0 < ks_end; ks0 += D) {
+        *reinterpret_cast<bf16x4*>(Xp + row * S + k) = h;
+        if (SPLIT) *reinterpret_cast<bf16x4*>(Xp + BM * S + row * S + k) = lo;
+      } else {
 #pragma unroll
-          for (int d = 0; d < D; d++) {
-            const int ks = ks0 + d;
-            if (ks >= ks_end) break;
-            const int kl = 16 * (ks - c * (KC / 16));
-            kstep(ks, d, Ah + frag + kl, Ah + BM * KCS + frag + kl);
+        for (int c = 0; c < 4; c++) {
+          if (e + c < E) {
+            const __bf16 h = (__bf16)v[u][c];
+            Xp[row * S + k] = __builtin_bit_cast(uint16_t, h);
+            if (SPLIT) { const __bf16 lo = (__bf16)(v[u][c] - (float)h); Xp[BM * S + row * S + k] = __builtin_bit_cast(uint16_t, lo); }
           }
+          if (++k == red) { k = 0; row++; }
         }
       }
-      if (c + 1 < nchunks) {
-        commit(PB + ((c + 1) & 1) * BUF);
-        lds_barrier();
-      }
     }
-  } else if (wave_on) {
-    const int S = ((red + 31) & ~31) + PANEL_PAD;
-    const uint16_t* Xp = (l & 1) ? PA : PB;
+    const int padw = redp - red;                              // zero columns up to the pack's k extent
+    for (int i = t; i < BM * padw; i += CHAIN_THREADS) {
+      const int row = i / padw, k = red + (i - row * padw);
+      Xp[row * S + k] = 0;
+      if (SPLIT) Xp[BM * S + row * S + k] = 0;
+    }
+    __syncthreads();
+  }
+  if (wave_on) {
     const int frag = (lane & 31) * S + 8 * (lane >> 5);
     for (int ks0 = 0; ks0 < nks; ks0 += D) {
 #pragma unroll
@@ -815,11 +814,9 @@ MLP_DEV void chain_layer(const ChainArgs& P, int l, uint16_t* PA, uint16_t* PB, 
 #pragma unroll
     for (int j = 0; j < CT; j++) {
       if (ct0 + j >= nct) continue;
-      const int col = 32 * (ct0 + j) + (lane & 31);
-      const float bv = (P.bias[l] && col < cols) ? P.bias[l][col] : 0.0f;
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) {
-        float v = acc[j][reg] + bv;
+        float v = acc[j][reg] + bvs[j];
         if (P.act[l] == 1) v = v > 0.0f ? v : __expf(v) - 1.0f;
         T[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * TS + (lane & 31)] = v;
       }
@@ -859,10 +856,16 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_mlp_chain(ChainArgs P) {
   const int t = (int)threadIdx.x, wave = t >> 6, lane = t & 63;
   float* T = reinterpret_cast<float*>(chain_lds + P.pa_words + P.pb_words) + wave * 32 * 36;
   const int r0 = (int)blockIdx.x * 32;
+  MLP_CLOCK(0);
   for (int l = 0; l < P.nl; l++) {
     const int nct = (P.dims[l + 1] + 31) >> 5;               // column tiles per wave: 2 from 9 tiles, else 1
     if (nct > 8) chain_layer<SPLIT, 2>(P, l, PA, PB, T, r0, t, wave, lane);
     else chain_layer<SPLIT, 1>(P, l, PA, PB, T, r0, t, wave, lane);
+#ifdef SHF_MLP_PROBE_CLOCK
+    if (l == 0) MLP_CLOCK(1);          // (probe: end of layers 0, 1 and of the last one)
+    if (l == 1) MLP_CLOCK(2);
+    if (l == P.nl - 1) MLP_CLOCK(3);
+#endif
   }
 }
 
@@ -1214,15 +1217,15 @@ extern "C" int shf_mlp_panel_backward_input(const float* dy, const float* y_or_n
   return hipGetLastError() == hipSuccess ? 0 : mlp_fail("shf_mlp_panel_backward_input: launch failed");
 }
 
-// LDS of one k_mlp_chain block for these widths at the current precision: panel A, panel B (also layer 0's two chunk
-// buffers), the waves' epilogue patches.  0 = the widths are not chainable at all.
+// LDS of one k_mlp_chain block for these widths at the current precision: panel A (inputs of the odd layers), panel B
+// (inputs of the even layers, layer 0's rows of x among them), the waves' epilogue patches.  0 = the widths are not chainable at all.
 static size_t chain_lds(const ShfMlpChain* c, size_t* pa_out, size_t* pb_out) {
   if (c->nlayers < 1 || c->nlayers > SHF_MLP_MAX_CHAIN) return 0;
   const int planes = g_mlp_precision == SHF_MLP_BF16X3 ? 2 : 1;
-  size_t pa = 0, pb = (size_t)2 * planes * 32 * KCS;
+  size_t pa = 0, pb = 0;
   for (int l = 0; l <= c->nlayers; l++) {
     if (c->dims[l] <= 0 || c->dims[l] > 512) return 0;
-    if (l >= 1 && l < c->nlayers) {                       // the input panel of layer l
+    if (l < c->nlayers) {                                 // the input panel of layer l (layer 0: the block's rows of x)
       const size_t words = (size_t)planes * 32 * (((c->dims[l] + 31) & ~31) + PANEL_PAD);
       if (l & 1) pa = words > pa ? words : pa; else pb = words > pb ? words : pb;
     }
