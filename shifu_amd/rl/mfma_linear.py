@@ -269,6 +269,13 @@ class MfmaMLP(nn.Sequential):
     small batches, wider layers -- the layers run one by one as in any nn.Sequential."""
 
     def _chain_layers(self):
+        key = (len(self), get_precision())        # the fit depends on the widths and on the precision mode's LDS planes
+        cached = getattr(self, "_chain_cache", None)
+        if cached is None or cached[0] != key:
+            self._chain_cache = (key, self._chain_layers_uncached())
+        return self._chain_cache[1]
+
+    def _chain_layers_uncached(self):
         ls = [m for m in self if not isinstance(m, nn.Identity)]
         if not ls or len(ls) > MAX_CHAIN or not all(isinstance(m, MfmaLinear) and m.bias is not None for m in ls):
             return None
