@@ -517,6 +517,9 @@ int shf_abb_reset_all(ShfAbbTask* task, void* stream);
  * ---------------------------------------------------------------------- */
 #define SHF_MLP_BF16 0
 #define SHF_MLP_BF16X3 1
+/* bf16x3 for forward and input gradient; the weight gradient's operands rounded once: its sum over the batch rows averages
+ * the rounding (relative error of dW ~ 2^-9 / sqrt(rows)), and it is half of a layer's time (profiles/r04_train.md). */
+#define SHF_MLP_BF16X3_W1 2
 int shf_mlp_set_precision(int32_t mode);
 int shf_mlp_get_precision(void);
 const char* shf_mlp_last_error(void);

@@ -394,7 +394,9 @@ bool vec_ok(const Operand& O, int red, bool red_contig) {
 int g_mlp_precision = SHF_MLP_BF16X3;
 template <int BMT, bool AR, bool BR, bool CS, bool AV, bool BV>
 void launch_gemm_m(dim3 grid, hipStream_t st, const Operand& A, const Operand& B, int red, int per, const Epilogue& E, int rows, int cols) {
-  const bool split = g_mlp_precision == SHF_MLP_BF16X3;
+  // SHF_MLP_BF16X3_W1: the weight gradient (CS: the split reduction over the batch, whose 24 576 products average the
+  // rounding out) takes its operands rounded once, forward and input gradient keep head + tail (profiles/r04_train.md)
+  const bool split = CS ? g_mlp_precision == SHF_MLP_BF16X3 : g_mlp_precision != SHF_MLP_BF16;
   if (A.mask_y) {
     if (split) hipLaunchKernelGGL((k_mlp_gemm<BMT, AR, BR, CS, AV, BV, true, true>), grid, dim3(256), 0, st, A, B, red, per, E, rows, cols);
     else hipLaunchKernelGGL((k_mlp_gemm<BMT, AR, BR, CS, AV, BV, true, false>), grid, dim3(256), 0, st, A, B, red, per, E, rows, cols);
@@ -928,7 +930,7 @@ int launch_panel_bc(hipStream_t st, const PanelArgs& P, bool split, size_t lds) 
 // CT = ceil(column tiles / 4) (1, 2 or 4: every wave holds all its column tiles' accumulators); BM: 64 rows, 32 when the
 // accumulators of 64 would not leave room for two blocks per CU (CT = 4) or the grid would not cover the CUs.
 int launch_panel(hipStream_t st, PanelArgs& P) {
-  const bool split = g_mlp_precision == SHF_MLP_BF16X3;
+  const bool split = g_mlp_precision != SHF_MLP_BF16;
   static const int force_bm = panel_env("SHF_MLP_PANEL_BM");
   const int nct = (P.cols + 31) / 32;
   if (nct > 16) return mlp_fail("k_mlp_panel: more than 512 output columns");
@@ -1152,7 +1154,8 @@ extern "C" int shf_mlp_probe_read(long long* out, int n) {
 #endif
 extern "C" const char* shf_mlp_last_error(void) { return g_mlp_err.c_str(); }
 extern "C" int shf_mlp_set_precision(int32_t mode) {
-  if (mode != SHF_MLP_BF16 && mode != SHF_MLP_BF16X3) return mlp_fail("shf_mlp_set_precision: mode must be SHF_MLP_BF16 or SHF_MLP_BF16X3");
+  if (mode != SHF_MLP_BF16 && mode != SHF_MLP_BF16X3 && mode != SHF_MLP_BF16X3_W1)
+    return mlp_fail("shf_mlp_set_precision: mode must be SHF_MLP_BF16, SHF_MLP_BF16X3 or SHF_MLP_BF16X3_W1");
   g_mlp_precision = mode;
   return 0;
 }
@@ -1221,7 +1224,7 @@ extern "C" int shf_mlp_panel_backward_input(const float* dy, const float* y_or_n
 // (inputs of the even layers, layer 0's rows of x among them), the waves' epilogue patches.  0 = the widths are not chainable at all.
 static size_t chain_lds(const ShfMlpChain* c, size_t* pa_out, size_t* pb_out) {
   if (c->nlayers < 1 || c->nlayers > SHF_MLP_MAX_CHAIN) return 0;
-  const int planes = g_mlp_precision == SHF_MLP_BF16X3 ? 2 : 1;
+  const int planes = g_mlp_precision != SHF_MLP_BF16 ? 2 : 1;
   size_t pa = 0, pb = 0;
   for (int l = 0; l <= c->nlayers; l++) {
     if (c->dims[l] <= 0 || c->dims[l] > 512) return 0;
@@ -1243,7 +1246,7 @@ extern "C" int shf_mlp_chain_forward(const float* x, int32_t M, const ShfMlpChai
   if (!x || !c || M <= 0) return mlp_fail("shf_mlp_chain_forward: bad argument");
   if (c->nlayers < 1 || c->nlayers > SHF_MLP_MAX_CHAIN) return mlp_fail("shf_mlp_chain_forward: 1 .. SHF_MLP_MAX_CHAIN layers");
   if (((uintptr_t)x & 15u) != 0) return mlp_fail("shf_mlp_chain_forward: x must be 16-byte aligned");
-  const bool split = g_mlp_precision == SHF_MLP_BF16X3;
+  const bool split = g_mlp_precision != SHF_MLP_BF16;
   ChainArgs P{};
   P.x = x; P.M = M; P.nl = c->nlayers;
   size_t pa = 0, pb = 0;

@@ -9,7 +9,9 @@ Precision (`set_precision`, env SHIFU_AMD_MFMA_PRECISION): "bf16x3" (default) sp
 head and tail and accumulates three MFMAs per tile pair -- products good to 2^-16, outputs within 1e-4 of the fp32 torch
 reference's scale (tests/test_gpu_mlp.py); "bf16" rounds operands once (2^-9 relative, 2e-2 of scale), one MFMA.  With
 "bf16" two of three 3000-iteration A1 runs lost return late in training (the action-noise std grew faster than with fp32
-layers); "bf16x3" costs a few per cent of the layer time, the layers being HBM-bound."""
+layers); "bf16x3" costs a few per cent of the layer time, the layers being HBM-bound.  "bf16x3-w1" keeps
+head + tail operands for forward and input gradient and rounds the weight gradient's operands once (its sum over the batch
+rows averages the rounding): same outcomes as "bf16x3" over 20 seeds, learn -5 % (profiles/r04_train.md)."""
 import os
 import ctypes as C
 
@@ -19,11 +21,12 @@ import torch.nn as nn
 from .._lib import BackendError, lib
 
 
-PRECISIONS = {"bf16": 0, "bf16x3": 1}
+PRECISIONS = {"bf16": 0, "bf16x3": 1, "bf16x3-w1": 2}
 
 
 def set_precision(mode: str) -> None:
-    """Process-wide operand precision of the MFMA layers: "bf16x3" or "bf16" (include/shifu_amd.h SHF_MLP_*)."""
+    """Process-wide operand precision of the MFMA layers: "bf16x3", "bf16x3-w1" (weight gradient from once-rounded operands)
+    or "bf16" (include/shifu_amd.h SHF_MLP_*)."""
     _check(lib().shf_mlp_set_precision(PRECISIONS[mode]))
 
 
