@@ -160,6 +160,14 @@ class MfmaLinear(nn.Linear):
     def invalidate_pack(self):
         self._pack_valid = False
 
+    def _load_from_state_dict(self, *args, **kwargs):       # a checkpoint load changes the weights behind a kept pack
+        self._pack_valid = False
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):                  # .to(device) / .float() ...: the pack does not follow
+        self._pack_valid = False
+        return super()._apply(fn, *args, **kwargs)
+
     def forward(self, x):
         if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
             _apply_env_precision()

@@ -255,3 +255,24 @@ def test_optimizer_checkpoints_are_interchangeable_with_the_stock_trainer(tmp_pa
     assert g["fused"] is False and g["capturable"] is False          # this trainer's flags for the CPU, whatever the file said
     (net.actor(x).square().mean()).backward()
     alg.optimizer.step()                                               # and it still steps
+
+
+def test_mfma_mlp_keeps_parameter_names_and_drops_kept_packs_on_load():
+    """MfmaMLP is an nn.Sequential (rsl_rl's parameter names actor.0, actor.2, ... stay), runs layer by layer on CPU, and
+    a checkpoint load or a device move invalidates a kept weight pack (rl/mfma_linear.py: refresh_pack)."""
+    import torch
+    from shifu_amd.rl.actor_critic import ActorCritic
+    from shifu_amd.rl.mfma_linear import MfmaLinear, MfmaMLP
+    ac = ActorCritic(7, 7, 3, actor_hidden_dims=(16, 8), critic_hidden_dims=(16, 8), mlp_backend="mfma")
+    ref = ActorCritic(7, 7, 3, actor_hidden_dims=(16, 8), critic_hidden_dims=(16, 8), mlp_backend="torch")
+    assert isinstance(ac.actor, MfmaMLP) and list(ac.state_dict().keys()) == list(ref.state_dict().keys())
+    ref.load_state_dict(ac.state_dict())
+    x = torch.randn(5, 7)
+    assert torch.allclose(ac.act_inference(x), ref.act_inference(x), atol=1e-6)
+    layer = next(m for m in ac.actor if isinstance(m, MfmaLinear))
+    layer._pack_valid = True
+    ac.load_state_dict(ref.state_dict())
+    assert not layer._pack_valid
+    layer._pack_valid = True
+    ac.to("cpu")
+    assert not layer._pack_valid
