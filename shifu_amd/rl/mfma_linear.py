@@ -11,7 +11,7 @@ reference's scale (tests/test_gpu_mlp.py); "bf16" rounds operands once (2^-9 rel
 "bf16" two of three 3000-iteration A1 runs lost return late in training (the action-noise std grew faster than with fp32
 layers); "bf16x3" costs a few per cent of the layer time, the layers being HBM-bound.  "bf16x3-w1" keeps
 head + tail operands for forward and input gradient and rounds the weight gradient's operands once (its sum over the batch
-rows averages the rounding): same outcomes as "bf16x3" over 20 seeds, learn -5 % (profiles/r04_train.md)."""
+rows averages the rounding): same outcomes as "bf16x3" over 30 seeds, learn -6 % (profiles/r04_train.md)."""
 import os
 import ctypes as C
 
