@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SHF_ABI_VERSION 11
+#define SHF_ABI_VERSION 12
 
 #define SHF_MAX_BODIES 32 /* reported rigid bodies per articulation        */
 #define SHF_MAX_DOFS 32
@@ -34,6 +34,8 @@ extern "C" {
 #define SHF_MAX_PAIRS 96    /* capsule pairs tested for self-collision       */
 #define SHF_MAX_SELF_CONTACTS 8 /* simultaneously active self-contacts per env (further ones are dropped, in pair order) */
 #define SHF_MAX_ABOX 16         /* box-shaped collision volumes of the articulation (vs the corners of box actors)   */
+#define SHF_MAX_HARD_CONTACTS 16 /* contact constraints one env's velocity-level solve can hold (ShfSimParams.max_contacts <= this);
+                                  * the deepest are kept, more are dropped and counted (SHF_T_DROPPED)                 */
 #define SHF_MAX_LINK_CONTACTS 16 /* simultaneously active link <-> box-actor contacts per env (further ones are dropped, in
                                   * candidate order, and counted: SHF_T_DROPPED)                                     */
 
@@ -197,9 +199,9 @@ typedef struct ShfScene {
 
 /*
  * Simulation parameters.  Replaces gymapi.SimParams (+.physx)
- * (shifu/configs/env_config.py:38-58).  The PhysX TGS solver settings have
- * no counterpart; the contact model is the linearly-implicit compliant
- * contact described in DESIGN.md and is parameterised here.
+ * (shifu/configs/env_config.py:38-58).  Two contact solvers (field `solver`): the
+ * velocity-level projected Gauss-Seidel solve the PhysX fields configure, and the
+ * linearly-implicit compliant contact of rounds 1-4.
  */
 typedef struct ShfSimParams {
   float dt;
@@ -216,7 +218,32 @@ typedef struct ShfSimParams {
                           * tested, and responds if it would be below the surface at the end of the step
                           * (speculative contact: an impact is stopped at the surface instead of one step later,
                           * v dt deep)                                                                        */
+  /* --- contact solver (ABI v12).  gymapi.SimParams.physx as the reference sets it (shifu/configs/env_config.py:50-58):
+   * solver_type = 1, num_position_iterations = 8, num_velocity_iterations = 1, rest_offset = 0,
+   * bounce_threshold_velocity = 0.5, max_depenetration_velocity = 1.
+   * solver == SHF_SOLVER_COMPLIANT (0; a zero-filled tail reads as this): the linearly-implicit spring-damper law above
+   *   (contact_k, contact_d, friction_vel), one articulated-body solve per sub-step -- rounds 1-4's model, an explicit opt-in
+   *   since round 5.
+   * solver == SHF_SOLVER_PGS (1): rigid unilateral contacts with Coulomb cones at velocity level.  Per sub-step: the free
+   *   articulated-body solve, the contact-space response W = J M^-1 J^T of the env's active contacts by impulse propagation
+   *   through the articulated-body factors, (pos_iters + vel_iters) projected block Gauss-Seidel sweeps over the contacts in
+   *   candidate order (3x3 block solve, cone projection with the normal re-solved when sliding), the impulses applied by one
+   *   more inward / outward pass.  Target normal velocity of a contact with gap phi (measured from rest_offset):
+   *   phi >= 0: -phi / dt (speculative: it may close the gap, no more); phi < 0: min(erp (-phi) / dt, max_depen_vel);
+   *   with restitution > 0 and an approach faster than bounce_threshold: at least -restitution v_n.  contact_k, contact_d,
+   *   friction_vel are unused.  At most max_contacts (<= SHF_MAX_HARD_CONTACTS; 0 reads as 8) constraints per env: the
+   *   candidates with the smallest gap (ties: candidate order), the others dropped and counted in SHF_T_DROPPED. */
+  int32_t solver;
+  int32_t pos_iters;        /* physx.num_position_iterations                                   */
+  int32_t vel_iters;        /* physx.num_velocity_iterations (further sweeps of the same kind)  */
+  int32_t max_contacts;
+  float rest_offset;        /* physx.rest_offset                                               */
+  float bounce_threshold;   /* physx.bounce_threshold_velocity                                 */
+  float restitution;        /* shape restitution (Isaac Gym default 0; terrain.restitution = 0, env_config.py:84) */
+  float erp;                /* share of a penetration removed per sub-step (Baumgarte); 0 reads as 0.2 */
 } ShfSimParams;
+#define SHF_SOLVER_COMPLIANT 0
+#define SHF_SOLVER_PGS 1
 
 typedef struct ShfTerrain {
   int32_t rows, cols; /* height_samples is (rows, cols) int16, x<->row     */

@@ -1,7 +1,7 @@
 """ctypes mirrors of the PODs in include/shifu_amd.h (keep in lock-step)."""
 import ctypes as C
 
-SHF_ABI_VERSION = 11
+SHF_ABI_VERSION = 12
 MAP_BODY, MAP_CHAIN, MAP_CHAIN_SPLIT = 0, 1, 2   # shf_sim_set_mapping
 MAX_BODIES = 32
 MAX_DOFS = 32
@@ -13,6 +13,8 @@ MAX_PAIRS = 96
 MAX_SELF_CONTACTS = 8
 MAX_ABOX = 16
 MAX_LINK_CONTACTS = 16
+MAX_HARD_CONTACTS = 16
+SOLVER_COMPLIANT, SOLVER_PGS = 0, 1
 
 JOINT_ROOT, JOINT_REVOLUTE, JOINT_PRISMATIC, JOINT_WELD = 0, 1, 2, 3
 DOF_MODE_NONE, DOF_MODE_POS, DOF_MODE_VEL, DOF_MODE_EFFORT = 0, 1, 2, 3
@@ -60,7 +62,9 @@ class ShfScene(C.Structure):
 class ShfSimParams(C.Structure):
     _fields_ = [("dt", f32), ("gravity", f32 * 3), ("contact_k", f32), ("contact_d", f32),
                 ("friction_vel", f32), ("limit_k", f32), ("limit_d", f32),
-                ("angular_damping", f32), ("max_ang_vel", f32), ("max_depen_vel", f32), ("contact_offset", f32)]
+                ("angular_damping", f32), ("max_ang_vel", f32), ("max_depen_vel", f32), ("contact_offset", f32),
+                ("solver", i32), ("pos_iters", i32), ("vel_iters", i32), ("max_contacts", i32),
+                ("rest_offset", f32), ("bounce_threshold", f32), ("restitution", f32), ("erp", f32)]
 
 
 class ShfTerrain(C.Structure):

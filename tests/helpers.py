@@ -23,6 +23,16 @@ def sim_params(dt=0.005, gravity=(0.0, 0.0, -9.81), **kw):
     p.max_ang_vel = kw.get("max_ang_vel", 64.0)
     p.max_depen_vel = kw.get("max_depen_vel", 1.0)
     p.contact_offset = kw.get("contact_offset", 0.01)
+    # contact solver (ABI v12): "compliant" = rounds 1-4's law (what the known answers of tests/test_contact_kats.py are about);
+    # "pgs" = the velocity-level solve with the reference's PhysX settings (env_config.py:50-58)
+    if kw.get("solver", "compliant") == "pgs":
+        p.solver = _abi.SOLVER_PGS
+        p.pos_iters, p.vel_iters = kw.get("pos_iters", 8), kw.get("vel_iters", 1)
+        p.max_contacts = kw.get("max_contacts", 8)
+        p.rest_offset = kw.get("rest_offset", 0.0)
+        p.bounce_threshold = kw.get("bounce_threshold", 0.5)
+        p.restitution = kw.get("restitution", 0.0)
+        p.erp = kw.get("erp", 0.2)
     return p
 
 

@@ -25,14 +25,25 @@ A1_Q0 = np.array([0.1, 0.8, -1.5, 0.1, 0.8, -1.5, -0.1, 0.8, -1.5, -0.1, 0.8, -1
 KP, KD = 20.0, 0.5                                                                      # task_config.py:22-23
 
 
-def a1_setup():
+def set_solver(sp, solver):
+    """solver: 'pgs' = the velocity-level solve the reference's PhysX fields configure (env_config.py:50-58: 8 + 1 sweeps), the
+    default since round 5; 'compliant' = rounds 1-4's spring-damper law"""
+    from shifu_amd import _abi
+    if solver == "pgs":
+        sp.solver, sp.pos_iters, sp.vel_iters, sp.max_contacts, sp.erp = _abi.SOLVER_PGS, 8, 1, 16, 0.2
+    else:
+        sp.solver = _abi.SOLVER_COMPLIANT
+    return sp
+
+
+def a1_setup(solver="compliant"):
     from shifu_amd import _abi
     from shifu_amd.model import asset_path, compile_urdf
     from tests.helpers import sim_params
     cm = compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT)
     for d in range(cm.blob.nd):
         cm.blob.damping[d] = 0.5                       # dof_props['damping'] (robot.py:35-37), as FusedA1Env sets it
-    return cm, sim_params(angular_damping=0.0)
+    return cm, set_solver(sim_params(angular_damping=0.0), solver)
 
 
 def a1_targets(kind, k, dt):
@@ -52,18 +63,19 @@ def shipped_step(oracle, m, sp, dof, root, tau):
     oracle.step(m, sp, 1, dof, root, effort=np.ascontiguousarray(tau, np.float64), friction=np.ones(1, np.float32), f64=True)
 
 
-def run_a1(kind, steps):
+def run_a1(kind, steps, solver="compliant"):
     from oracle import pyoracle as oracle
     from oracle.hard_contact_ref import HardContactStepper
     oracle.build()
-    cm, sp = a1_setup()
+    cm, sp = a1_setup(solver)
     m = cm.blob
     dt = sp.dt
     ref = HardContactStepper(m, sp, mu=1.0)
-    # the LOCAL comparison starts from the shipped model's state, whose feet sit m g / 4 k = 0.6 mm in the ground: a stabilised
+    # compliant model: the LOCAL comparison starts from its state, whose feet sit m g / 4 k = 0.6 mm in the ground: a stabilised
     # hard solver would spend its step pushing them out (0.2 x 0.6 mm / 5 ms = 24 mm/s), so the one-step comparison is made
-    # at the velocity level (no Baumgarte term); the accumulated one uses the stabilised solver on its own trajectory
-    ref_local = HardContactStepper(m, sp, mu=1.0, baumgarte=0.0)
+    # at the velocity level (no Baumgarte term); the accumulated one uses the stabilised solver on its own trajectory.
+    # pgs: both sides are the stabilised solve.
+    ref_local = HardContactStepper(m, sp, mu=1.0, baumgarte=0.0 if solver == "compliant" else 0.2)
     # settle the shipped model on its feet first (400 sub-steps of PD hold), so that both start from a state at rest
     dof = np.zeros((m.nd, 2)); dof[:, 0] = A1_Q0
     root = np.zeros((1, 13)); root[0, 2] = 0.33; root[0, 6] = 1.0
@@ -92,7 +104,8 @@ def run_a1(kind, steps):
         weight.append(fz)
     loc, acc = np.array(loc), np.array(acc)
     mass = float(sum(m.mass[b] for b in range(m.nb)))
-    return {"scene": f"A1 {kind}", "steps": steps, "dt": dt,
+    # creep of the shipped model's base over the second half of the run (standing: the feet should stay where they are)
+    return {"scene": f"A1 {kind}", "solver": solver, "steps": steps, "dt": dt,
             "local_dq_max": float(loc[:, 0].max()), "local_dq_mean": float(loc[:, 0].mean()),
             "local_droot_max": float(loc[:, 1].max()), "local_droot_mean": float(loc[:, 1].mean()),
             "local_dqd_max": float(loc[:, 2].max()), "local_dvroot_max": float(loc[:, 3].max()),
@@ -103,7 +116,7 @@ def run_a1(kind, steps):
             "root_z_shipped": float(root[0, 2]), "root_z_hard": float(rr[2])}
 
 
-def run_abb(steps):
+def run_abb(steps, solver="compliant", ensemble=False):
     """The ABB arm sweeps its rod sideways into the cube on the table (joint 1 turns at 0.2 rad/s): implicit POS drives in both."""
     from oracle import pyoracle as oracle
     from oracle.hard_contact_ref import HardContactStepper
@@ -112,7 +125,7 @@ def run_abb(steps):
     oracle.build()
     cm = abb_model(link_contacts=False)
     m = cm.blob
-    sp = default_sim_params(dt=0.02)
+    sp = set_solver(default_sim_params(dt=0.02), solver)
     dt = sp.dt
     boxes = abb_boxes()
     q0 = np.array(ABB_DEFAULT_DOF_POS)
@@ -142,12 +155,28 @@ def run_abb(steps):
     tip = low_end(q0)
     root[2, :3] = (tip[0], tip[1] + 0.025 + rad + 0.03, 0.125)
     ref = HardContactStepper(m, sp, mu=1.0, box={"dim": [0.05, 0.05, 0.05], "mass": 0.1}, box_plane_z=0.1, box_mu=0.5)
-    ref_local = HardContactStepper(m, sp, mu=1.0, box={"dim": [0.05, 0.05, 0.05], "mass": 0.1}, box_plane_z=0.1, box_mu=0.5, baumgarte=0.0)
+    ref_local = HardContactStepper(m, sp, mu=1.0, box={"dim": [0.05, 0.05, 0.05], "mass": 0.1}, box_plane_z=0.1, box_mu=0.5,
+                                   baumgarte=0.0 if solver == "compliant" else 0.2)
     # implicit POS drive in the reference: M~ += dt (kd + dt kp) on the diagonal, exactly the shipped joint law (the -kd qd part
     # of the torque rides on the damping term)
     for r_ in (ref, ref_local):
         r_.A.damping = r_.A.damping + kd + dt * kp
 
+    # The sweep ends with the cube slipping off the turning rod after a rocking, yawing push: WHEN it slips is a bifurcation
+    # (a 10 um shift of the cube's start moves the reference's own answer from 15.7 to 17.5 cm), so the distance travelled is
+    # compared as an ensemble over such shifts, next to the single run
+    start_xy = root[2, :2].copy()
+    ens_ref, ens_shipped = [], []
+    for shift in ((0.0, 1e-5, -1e-5, 2e-5, -2e-5) if ensemble else ()):
+        d2, r2 = dof.copy(), root.copy()
+        r2[2, 1] += shift
+        q, qd, rr, bx = d2[:, 0].copy(), d2[:, 1].copy(), r2[0].copy(), r2[2].copy()
+        for k in range(steps):
+            tgt = q0.copy(); tgt[0] += 0.2 * dt * (k + 1)
+            oracle.scene_step(m, sp, boxes, 1, d2, r2, pos_target=np.ascontiguousarray(tgt, np.float64), friction=np.ones(1, np.float32), f64=True)
+            ref.step(q, qd, rr, kp * (tgt - q), box_state=bx)
+        ens_shipped.append(float(np.linalg.norm(r2[2, :2] - start_xy)))
+        ens_ref.append(float(np.linalg.norm(bx[:2] - start_xy)))
     q, qd, rr, bx = dof[:, 0].copy(), dof[:, 1].copy(), root[0].copy(), root[2].copy()
     loc, acc = [], []
     for k in range(steps):
@@ -159,11 +188,12 @@ def run_abb(steps):
         ref.step(q, qd, rr, kp * (tgt - q), box_state=bx)
         acc.append((np.abs(q - dof[:, 0]).max(), np.linalg.norm(bx[:3] - root[2, :3])))
     loc, acc = np.array(loc), np.array(acc)
-    return {"scene": "ABB rod pushes the cube", "steps": steps, "dt": dt,
+    return {"scene": "ABB rod pushes the cube", "solver": solver, "steps": steps, "dt": dt,
             "local_dq_max": float(loc[:, 0].max()), "local_dq_mean": float(loc[:, 0].mean()),
             "local_dcube_max": float(loc[:, 1].max()), "local_dcube_mean": float(loc[:, 1].mean()),
             "accum_dq": {str(n): float(acc[n - 1, 0]) for n in (1, 10, 100, steps) if n <= steps},
             "accum_dcube": {str(n): float(acc[n - 1, 1]) for n in (1, 10, 100, steps) if n <= steps},
+            "cube_travel_ensemble_shipped": ens_shipped, "cube_travel_ensemble_hard": ens_ref,
             "cube_travel_shipped": float(np.linalg.norm(root[2, :2] - np.array([tip[0], tip[1] + 0.025 + rad + 0.03]))),
             "cube_travel_hard": float(np.linalg.norm(bx[:2] - np.array([tip[0], tip[1] + 0.025 + rad + 0.03])))}
 
@@ -172,8 +202,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--solver", default="both", choices=("pgs", "compliant", "both"))
     args = ap.parse_args()
-    res = [run_a1("stand", args.steps), run_a1("trot", args.steps), run_abb(min(args.steps, 250))]
+    res = []
+    for solver in (("pgs", "compliant") if args.solver == "both" else (args.solver,)):
+        res += [run_a1("stand", args.steps, solver), run_a1("trot", args.steps, solver), run_abb(min(args.steps, 250), solver, ensemble=True)]
     for r in res:
         print(json.dumps(r))
     if args.out:
