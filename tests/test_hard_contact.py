@@ -109,8 +109,8 @@ def test_penetration_is_removed_at_the_baumgarte_rate_capped_by_max_depenetratio
         z.append(root[0, 2] - 0.05)
     z = np.array(z)
     assert abs((z[5] - z[4]) / K.DT - 1.0) < 2e-5                       # capped (regularisation 1e-6 trace(W) = 8e-6 of n.W n here)
-    tail = z[(z > -0.02) & (z < -1e-6)]
-    assert len(tail) > 5 and np.abs(tail[1:] / tail[:-1] - 0.8).max() < 1e-6, tail   # erp 0.2
+    tail = z[(z > -0.02) & (z < -1e-4)]
+    assert len(tail) > 5 and np.abs(tail[1:] / tail[:-1] - 0.8).max() < 1e-5, tail   # erp 0.2
     assert abs(root[0, 9]) < 1e-9 and z[-1] < 1e-6                      # no momentum left behind, never above the surface
 
 
