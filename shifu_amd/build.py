@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libshifu_amd.so")
 SOURCES = ["shf_api.hip", "shf_a1_chain.hip", "shf_glue.hip", "shf_mlp.hip"]
-DEPS = SOURCES + ["shf_device.h", "shf_boxes.h", "shf_task.h", "shf_chain.h", "shf_link.h", "shf_arm.h", os.path.join("..", "..", "include", "shifu_amd.h")]
+DEPS = SOURCES + ["shf_device.h", "shf_boxes.h", "shf_task.h", "shf_chain.h", "shf_chain_hard.h", "shf_link.h", "shf_arm.h", os.path.join("..", "..", "include", "shifu_amd.h")]
 # -fno-slp-vectorize: the SLP vectoriser packs neighbouring scalar f32 ops into v_pk_* pairs plus the
 # v_mov shuffles that feed them -- slower for this kernel (measured -6 % at 2 envs/wave, -25 % at one
 # wavefront per env; cf. MI355X_MICROARCH.md "packed f32 VALU ... an anti-lever").

@@ -3,9 +3,18 @@
 #include <hip/hip_runtime.h>
 
 #include "shf_chain.h"
+#include "shf_chain_hard.h"
 
 template <int G, bool TW, bool SELF = false>
 __global__ __launch_bounds__(256, (G == 32 ? 2 : 1)) void k_a1_chain(A1Args A) { a1_chain_step_body<G, A1Chain, TW, SELF>(A); }
+
+// the same step under the velocity-level contact solve (ShfSimParams.solver == SHF_SOLVER_PGS; csrc/shf_chain_hard.h)
+template <bool TW>
+__global__ __launch_bounds__(256, 2) void k_a1_chain_pgs(A1Args A) { a1_chain_step_body<32, A1Chain, TW, false, true>(A); }
+const void* shf_a1_chain_pgs_kernel(bool warped) {
+  return warped ? reinterpret_cast<const void*>(k_a1_chain_pgs<true>) : reinterpret_cast<const void*>(k_a1_chain_pgs<false>);
+}
+int shf_a1_chain_pgs_max_contacts(void) { return HCK; }
 
 bool shf_a1_chain_matches(const ShfModel& m) { return A1Chain::matches(m); }
 // dynamic LDS of one 256-thread block at G lanes per env

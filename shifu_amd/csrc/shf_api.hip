@@ -61,6 +61,8 @@ struct ShfA1Task {
 bool shf_a1_chain_matches(const ShfModel& m);
 size_t shf_a1_chain_lds_bytes(int G, int nobs, bool self);
 const void* shf_a1_chain_kernel(int G, bool warped, bool self);
+const void* shf_a1_chain_pgs_kernel(bool warped);
+int shf_a1_chain_pgs_max_contacts(void);
 #ifdef SHF_PHASE_CLOCK
 int shf_a1_chain_phase_cycles(unsigned long long* out, int n, int reset);
 #endif
@@ -1287,6 +1289,7 @@ static int launch_ptr(const void* fn, dim3 grid, dim3 block, size_t lds, void* s
 extern "C" int shf_sim_step(ShfSim* sim, void* stream) {
   if (int r = need(sim, {SHF_T_SIM_DOF, SHF_T_SIM_ROOT, SHF_T_SIM_CONTACT, SHF_T_MODEL}, "shf_sim_step")) return r;
   if (sim->terr.rows > 0 && !sim->t[SHF_T_HEIGHTS]) return fail("shf_sim_step: heightfield samples not bound");
+  if (sim->sp.solver == SHF_SOLVER_PGS) return fail("shf_sim_step: ShfSimParams.solver = SHF_SOLVER_PGS is built into the fused A1 step only (shf_a1_step); use SHF_SOLVER_COMPLIANT here");
   SimArgs A = sim_args(sim, true);
   if (sim->force_armed) {
     A.body_force = (const float*)sim->t[SHF_T_BODY_FORCE];
@@ -1548,6 +1551,15 @@ static int a1_step_launch(ShfA1Task* task, const float* raw_actions_dev, void* s
   dim3 grid((s->n + epb - 1) / epb), block(256);
   const size_t lds = sim_lds_bytes(s, TASK_WORDS + STATS_LDS_WORDS, SCR_OBS + nobs);
   int r;
+  if (s->sp.solver == SHF_SOLVER_PGS) {
+    // the velocity-level contact solve: the chain mapping at two envs per wavefront (csrc/shf_chain_hard.h)
+    if (s->mapping != SHF_MAP_CHAIN || s->chain_group != 32 || !shf_a1_chain_matches(s->model))
+      return fail("shf_a1_step: ShfSimParams.solver = SHF_SOLVER_PGS runs on the chain mapping at 32 lanes per env (shf_sim_set_mapping)");
+    if (sim_self(s)) return fail("shf_a1_step: self-collision is not built into the velocity-level solve of the fused A1 step");
+    if (s->sp.max_contacts > shf_a1_chain_pgs_max_contacts()) return fail("shf_a1_step: the fused A1 step's solve holds at most 8 constraints per env (ShfSimParams.max_contacts)");
+    if (s->sp.pos_iters < 1) return fail("shf_a1_step: ShfSimParams.pos_iters must be >= 1 with SHF_SOLVER_PGS");
+    return launch_ptr(shf_a1_chain_pgs_kernel(s->terr.warped != 0), dim3((s->n + 7) / 8), block, shf_a1_chain_lds_bytes(32, nobs, false), stream, A);
+  }
   if (s->mapping == SHF_MAP_CHAIN) {
     if (!shf_a1_chain_matches(s->model)) return fail("shf_a1_step: the articulation does not fit the chain mapping");
     const void* fn = shf_a1_chain_kernel(s->chain_group, s->terr.warped != 0, sim_self(s));
@@ -1689,6 +1701,7 @@ static int abb_step_launch(ShfAbbTask* task, const float* raw_actions_dev, void*
   AbbArgs A;
   if (int r = abb_args(task, raw_actions_dev, "shf_abb_step", A)) return r;
   ShfSim* s = task->sim;
+  if (s->sp.solver == SHF_SOLVER_PGS) return fail("shf_abb_step: ShfSimParams.solver = SHF_SOLVER_PGS is built into the fused A1 step only (shf_a1_step); use SHF_SOLVER_COMPLIANT here");
   const int epb = 256 / s->group;
   dim3 grid((s->n + epb - 1) / epb), block(256);
   const int nbx = s->nboxes, nslots = s->model.np + box_slot_count(nbx, sim_ndyn(s), s->model.nsph) + (sim_link(s) ? 2 * SHF_MAX_LINK_CONTACTS : 0);

@@ -794,7 +794,11 @@ DEV void chain_body_states(const ShfModel* m, const ChainLds& L, int l, const Do
 
 // ShifuVecEnv.step for the A1 task (env.py:85-106) on the chain mapping; the task glue after the physics is shared
 // with the body-mapped kernel (a1_post_step, shf_task.h).
-template <int G, class CD, bool TW, bool SELF = false>
+template <int G, class CD, bool TW>
+DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane& X, const ChainPoints<(CD::NEV + G - 1) / G>& P,
+                            const RowLane& RL, const float* fext, float mu_shape, float* contact_out);   // shf_chain_hard.h
+// HARD: the velocity-level contact solve (ShfSimParams.solver == SHF_SOLVER_PGS, csrc/shf_chain_hard.h)
+template <int G, class CD, bool TW, bool SELF = false, bool HARD = false>
 DEV void a1_chain_step_body(const A1Args& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NLK = CD::NLK, nb = CD::NB, nd = CD::ND, NR = (CD::NEV + G - 1) / G;
@@ -857,13 +861,14 @@ DEV void a1_chain_step_body(const A1Args& A) {
 
   StepCtx C;
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = nullptr;
+  if constexpr (HARD) C.dropped = A.S.dropped ? A.S.dropped + e : nullptr;
   const float mu = A.S.friction[e];
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
   const int dl = l < nd ? l : 0;
   DofLane X = {L.dofb[dl * DOF_STRIDE], L.dofb[dl * DOF_STRIDE + 1], 0.0f};
   const float pg_ = tp.p_gain[dl], dg_ = tp.d_gain[dl], q0_ = tp.default_dof_pos[dl], lim_ = m->effort[dl];
   ChainPoints<NR> LP;
-  chain_points_load<G>(m, CD::NEV, l, C.sp.contact_offset, LP);
+  chain_points_load<G>(m, CD::NEV, l, HARD ? C.sp.contact_offset + C.sp.rest_offset : C.sp.contact_offset, LP);
   // evaluation slots of this body lane's points (lane j < nd: link j; lane nd: the root)
   const int lb = G >= 32 ? (l & 15) : l;
   const int mb = lb < nd ? CD::body(lb / NLK, lb % NLK) : 0;
@@ -876,8 +881,12 @@ DEV void a1_chain_step_body(const A1Args& A) {
       const float t = pg_ * (act + q0_ - X.q) - dg_ * X.qd;
       X.tau = rclampf(t, -lim_, lim_);
     }
-    chain_substep<G, CD, TW, SELF>(C, L, l, X, LP, mine, RL, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
-                             (it == nsub - 1) ? L.xch : nullptr);
+    if constexpr (HARD)
+      chain_substep_hard<G, CD, TW>(C, L, l, X, LP, RL, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
+                                    (it == nsub - 1) ? L.xch : nullptr);
+    else
+      chain_substep<G, CD, TW, SELF>(C, L, l, X, LP, mine, RL, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
+                                     (it == nsub - 1) ? L.xch : nullptr);
   }
   PHASE_RESET();
   if (l < nd) {

@@ -221,12 +221,12 @@ def _compare(sim, task, bufs, tag, exact=True, tol=0.0):
     return worst
 
 
-def _a1_setup(n, rough, seed=5, group=64, env_off=0, cm=None):
+def _a1_setup(n, rough, seed=5, group=64, env_off=0, cm=None, **spkw):
     from shifu_amd.a1_task import a1_task_params
     from shifu_amd.backend import A1Task
     rng = np.random.default_rng(seed)
     cm = cm or H.a1_model()
-    sp = H.sim_params(angular_damping=0.5)
+    sp = H.sim_params(angular_damping=0.5, **spkw)
     tp = a1_task_params(cm, num_rows=4, num_cols=5, env_length=0.8)
     terr, hs = _terrain(rng, rows=80, cols=60, rough=rough)
     bufs = _a1_buffers(cm, tp, n, rng, terr.rows, terr.cols)
@@ -255,6 +255,53 @@ def test_fused_a1_step_matches_oracle_bitwise(oracle, rough, group):
         resets += int(bufs["reset"].sum())
     assert resets > n // 4, "the run must exercise resets (time-outs and base contacts)"
     assert np.isfinite(bufs["obs"]).all()
+
+
+@pytest.mark.parametrize("kmax", [8, 3])
+@pytest.mark.parametrize("rough", [False, True])
+def test_fused_a1_step_with_the_velocity_level_solve_matches_oracle_bitwise(oracle, rough, kmax):
+    """The same step under ShfSimParams.solver = SHF_SOLVER_PGS (the reference's PhysX settings, env_config.py:50-58: 8 + 1
+    sweeps): candidate selection, response matrix by impulse propagation, projected Gauss-Seidel, the two impulse passes --
+    k_a1_chain_pgs against the oracle's hard_solve, every tensor, 120 vec-steps with falls and resets.  kmax = 3: more
+    candidates than the solve holds on most steps (the deepest are kept, the others counted)."""
+    _need_gpu()
+    n = 96
+    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, rough, group="chain32", env_off=1000, solver="pgs", max_contacts=kmax)
+    oracle.dropped(reset=True)
+    resets = 0
+    for it in range(120):
+        raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32) * 1.5
+        slot = task.step(torch.from_numpy(raw).cuda())
+        oracle.a1_step(cm.blob, sp, tp, n, 1000, bufs, raw, terrain=terr, heights=hs)
+        _compare(sim, task, bufs, f"step {it}")
+        stats = task.tensors[_abi.A1_STATS][slot].cpu().numpy()
+        np.testing.assert_array_equal(stats, oracle.a1_stats(tp, n, bufs["done_sums"]), err_msg=f"stats step {it}")
+        resets += int(bufs["reset"].sum())
+    assert resets > n // 4 and np.isfinite(bufs["obs"]).all()
+    assert np.abs(bufs["contact"]).max() > 10.0, "the feet carry the robots"
+    torch.cuda.synchronize()
+    d = oracle.dropped()
+    assert int(sim.tensors[_abi.T_DROPPED].sum()) == d
+    assert d > (20000 if kmax == 3 else 0), d
+
+
+def test_fused_a1_step_with_the_velocity_level_solve_at_full_size(oracle):
+    """... and at BASELINE's env count: 4096 envs x 30 vec-steps, every tensor bit for bit."""
+    _need_gpu()
+    n = 4096
+    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, seed=91, group="chain32", env_off=8192, solver="pgs")
+    bufs["ep_len"][:] = rng.integers(900, 1001, n)
+    _upload(sim, task, bufs)
+    resets = 0
+    for it in range(30):
+        raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32)
+        slot = task.step(torch.from_numpy(raw).cuda())
+        oracle.a1_step(cm.blob, sp, tp, n, 8192, bufs, raw, terrain=terr, heights=hs)
+        if it % 10 == 9:
+            _compare(sim, task, bufs, f"step {it}")
+            np.testing.assert_array_equal(task.tensors[_abi.A1_STATS][slot].cpu().numpy(), oracle.a1_stats(tp, n, bufs["done_sums"]))
+        resets += int(bufs["reset"].sum())
+    assert resets > 100
 
 
 @pytest.mark.parametrize("group", [32, "chain32"])
