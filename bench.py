@@ -48,7 +48,7 @@ WL_NAME = {"terrain": "a1_conditional procedural heightfield 1300x2100 (config 3
 
 
 # ----------------------------------------------------------------------------- CPU oracle workloads --
-def oracle_workload(workload: str, n: int, seed: int = 0):
+def oracle_workload(workload: str, n: int, seed: int = 0, solver_kw=None):
     """The same workload on NumPy buffers for the CPU oracle: returns step(nthreads, count_flops=False) -> None."""
     from oracle import pyoracle
     from shifu_amd import _abi
@@ -91,7 +91,7 @@ def oracle_workload(workload: str, n: int, seed: int = 0):
     m = cm.blob
     for d in range(m.nd):
         m.damping[d] = 0.5                       # dof_props['damping'] as FusedA1Env sets it
-    sp = default_sim_params()
+    sp = default_sim_params(**(solver_kw or {}))
     ct = default_terrain_cfg()
     if workload in ("terrain", "trimesh"):
         state = np.random.get_state()
@@ -134,12 +134,12 @@ def oracle_workload(workload: str, n: int, seed: int = 0):
     return step
 
 
-def count_flops(workload: str, n: int = 64, warm: int = 40, steps: int = 20) -> float:
+def count_flops(workload: str, n: int = 64, warm: int = 40, steps: int = 20, solver_kw=None) -> float:
     """Floating-point operations per env-step of the algorithm (add/sub/mul/div/sqrt = 1, fma = 2), counted by running
     the oracle compiled with a counting real type (oracle/flopcount.cpp) on `n` envs in the workload's steady state
     (robots standing / stumbling on the terrain with random actions, resets included)."""
     from oracle import pyoracle
-    step = oracle_workload(workload, n, seed=1)
+    step = oracle_workload(workload, n, seed=1, solver_kw=solver_kw)
     for _ in range(warm):
         step(1)
     L = pyoracle.flop_lib()
@@ -168,13 +168,13 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(workload: str, seconds_budget: float = 16.0):
+def cpu_baseline(workload: str, seconds_budget: float = 16.0, solver_kw=None):
     """The oracle's fused env step on host cores.  Deterministic thread counts: one thread, and every core this process
     may use (OpenMP over envs, 4096 envs so that each thread has tens of envs per step).  Bounded sample."""
     avail = usable_cores()
 
     def timed(n, threads, budget):
-        step = oracle_workload(workload, n)
+        step = oracle_workload(workload, n, solver_kw=solver_kw)
         for _ in range(3):
             step(threads)          # thread start-up, page faults
         k, t0 = 0, time.perf_counter()
@@ -194,7 +194,7 @@ def cpu_baseline(workload: str, seconds_budget: float = 16.0):
     vall, kall = tried[cores]
     what = "ABB push-box" if workload == "abb" else f"A1 {workload}"
     try:                          # the same oracle, built with a counting real type: flops per env-step of the algorithm
-        flops, flops_src = count_flops(workload), "counted in the cpu_baseline leg: oracle/flopcount.cpp (add/sub/mul/div/sqrt = 1, fma = 2)"
+        flops, flops_src = count_flops(workload, solver_kw=solver_kw), "counted in the cpu_baseline leg: oracle/flopcount.cpp (add/sub/mul/div/sqrt = 1, fma = 2)"
     except Exception as e:        # the counting build needs g++ on the box
         flops, flops_src = None, f"unavailable: {e}"
     return {"value": vall, "flops_per_env_step": flops, "flops_source": flops_src, "unit": "env-steps/s", "cores": cores, "kind": "port", "value_1thread": v1,
@@ -231,6 +231,11 @@ def main():
                     help="A1 workloads: lane = kinematic chain (default, with --self-collision too at 32 lanes per env; csrc/shf_chain.h) "
                          "or lane = rigid body (the general kernels).  Kernel selection only: results are bit-identical")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--solver", choices=["pgs", "compliant"], default="compliant",
+                    help="contact solver (ShfSimParams.solver): pgs = the velocity-level projected Gauss-Seidel solve with the reference's PhysX "
+                         "settings (env_config.py:50-58: 8 + 1 iterations); compliant = rounds 1-4's spring-damper law")
+    ap.add_argument("--pos-iters", type=int, default=8, help="physx.num_position_iterations (pgs)")
+    ap.add_argument("--vel-iters", type=int, default=1, help="physx.num_velocity_iterations (pgs)")
     ap.add_argument("--self-collision", action="store_true",
                     help="A1 workloads: collide the robot's own links (capsule pairs; the reference's collision filter 0, "
                          "units.py:68) -- off in the headline configuration, whose BASELINE entry names height-field contact")
@@ -305,7 +310,8 @@ def main():
         from shifu_amd.gym.a1_fused import FusedA1Env
         env = FusedA1Env(num_envs=args.envs, device=dev, terrain={"terrain": "heightfield", "flat": "flat", "trimesh": "trimesh"}[args.workload],
                          seed=42, rank=rank, world_size=world, group=group, mapping=mapping, decimation=args.decimation,
-                         extra_substep=not args.no_extra_substep, self_collision=args.self_collision)
+                         extra_substep=not args.no_extra_substep, self_collision=args.self_collision, solver=args.solver,
+                         solver_kw={"pos_iters": args.pos_iters, "vel_iters": args.vel_iters})
         stats_t, count_t, kernel = _abi.A1_STATS, _abi.A1_RESET_COUNT, "k_a1_step"
         substeps = args.decimation + (0 if args.no_extra_substep else 1)
     gen = torch.Generator(device=dev)
@@ -464,7 +470,9 @@ def main():
                      "ms_per_step_rank0": rank_elapsed / args.steps * 1e3},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{WL_NAME[args.workload]}, {N} envs/GPU, random actions, {substeps} substeps/env-step "
-                                   f"(dt {'20' if abb else '5'} ms), resets on"
+                                   f"(dt {'20' if abb else '5'} ms), resets on, contact solver: "
+                                   + (f"velocity-level PGS {args.pos_iters} + {args.vel_iters} iterations (the reference's physx settings, env_config.py:50-58)" if (args.solver == "pgs" and not abb)
+                                      else "compliant spring-damper law (rounds 1-4)")
                                    + ((", link contacts ON (arm links + rod vs table / cube / goal pad)" if args.link_contacts else
                                        ", arm collider: the rod against the cube (link contacts OFF, see --link-contacts)") if abb else (", self-collision ON (capsule pairs, the reference's collision filter 0)" if args.self_collision
                                                       else ", self-collision OFF (the reference has it on: units.py:68; see --self-collision)")),
@@ -489,7 +497,7 @@ def main():
                                                  "timed pass): pass-to-pass noise, not a longer kernel; roofline.achieved uses kernel_ms, "
                                                  "the more conservative of the two")
         if not args.no_cpu_baseline and world == 1:
-            cb = out["cpu_baseline"] = cpu_baseline(args.workload)     # the only leg that touches oracle/
+            cb = out["cpu_baseline"] = cpu_baseline(args.workload, solver_kw=(None if abb else {"solver": args.solver, "pos_iters": args.pos_iters, "vel_iters": args.vel_iters}))     # the only leg that touches oracle/
             f_alg = cb["flops_per_env_step"]
             secondary.update({"flops_alg_per_env_step": f_alg, "flops_source": cb["flops_source"]})
             if f_alg is not None:

@@ -34,6 +34,30 @@ def default_sim_params(dt: float = 0.005, gravity=(0.0, 0.0, -9.81), **kw) -> _a
     p.max_ang_vel = kw.get("max_ang_vel", 64.0)          # AssetOptions default [EXT]
     p.max_depen_vel = kw.get("max_depen_vel", 1.0)       # env_config.py:57
     p.contact_offset = kw.get("contact_offset", 0.01)    # env_config.py:54
+    set_solver(p, kw.get("solver", "compliant"), **{k: v for k, v in kw.items() if k in _SOLVER_KEYS})
+    return p
+
+
+_SOLVER_KEYS = ("pos_iters", "vel_iters", "max_contacts", "rest_offset", "bounce_threshold", "restitution", "erp")
+
+
+def set_solver(p: _abi.ShfSimParams, solver: str = "pgs", **kw) -> _abi.ShfSimParams:
+    """Contact solver of a ShfSimParams.  "pgs": the velocity-level projected Gauss-Seidel solve with the PhysX settings
+    the reference configures (shifu/configs/env_config.py:50-58: num_position_iterations 8, num_velocity_iterations 1,
+    rest_offset 0, bounce_threshold_velocity 0.5; max_depenetration_velocity and contact_offset are fields of their own);
+    "compliant": rounds 1-4's linearly-implicit spring-damper law (contact_k, contact_d, friction_vel)."""
+    if solver == "pgs":
+        p.solver = _abi.SOLVER_PGS
+        p.pos_iters, p.vel_iters = kw.get("pos_iters", 8), kw.get("vel_iters", 1)
+        p.max_contacts = kw.get("max_contacts", 8)
+        p.rest_offset = kw.get("rest_offset", 0.0)
+        p.bounce_threshold = kw.get("bounce_threshold", 0.5)
+        p.restitution = kw.get("restitution", 0.0)
+        p.erp = kw.get("erp", 0.2)
+    elif solver == "compliant":
+        p.solver = _abi.SOLVER_COMPLIANT
+    else:
+        raise ValueError("solver must be 'pgs' or 'compliant'")
     return p
 
 
@@ -337,6 +361,8 @@ class A1Task:
         """Mangled-name prefix of the instantiation shf_a1_step launches for this sim (build resource table)."""
         g, warped = self.sim.group, bool(self.sim.terrain.warped)
         mdl = self.sim.model
+        if self.sim.params.solver == _abi.SOLVER_PGS:
+            return f"_Z14k_a1_chain_pgsILb{int(warped)}EE"
         if getattr(self.sim, "mapping", "body") == "chain":
             return f"_Z10k_a1_chainILi{g}ELb{int(warped)}ELb{int(bool(mdl.self_collide and mdl.npair > 0))}EE"
         a1 = mdl.nb == 17 and mdl.nd == 12 and mdl.np == 76

@@ -22,13 +22,15 @@ def main():
     ap.add_argument("--terrain", default="heightfield", choices=["heightfield", "trimesh", "flat"])
     ap.add_argument("--traj", default=None)
     ap.add_argument("--self-collision", action="store_true", help="collide the robot's own links, as in training with the same flag")
+    ap.add_argument("--solver", choices=["pgs", "compliant"], default=None, help="contact solver (FusedA1Env(solver=...)); default: the env's")
     args = ap.parse_args()
     from examples.a1_conditional.task_config import A1PPOConfig
     from shifu_amd.checkpoint import TrajectoryRecorder
     from shifu_amd.gym.a1_fused import FusedA1Env
     from shifu_amd.rl import OnPolicyRunner
     from shifu_amd.runner.utils import class_to_dict
-    env = FusedA1Env(num_envs=args.envs, terrain=args.terrain, seed=7, self_collision=args.self_collision)
+    env = FusedA1Env(num_envs=args.envs, terrain=args.terrain, seed=7, self_collision=args.self_collision,
+                     **({} if args.solver is None else {"solver": args.solver}))
     runner = OnPolicyRunner(env, class_to_dict(A1PPOConfig()), log_dir=None, device="cuda:0")
     runner.load(args.checkpoint, load_optimizer=False)
     policy = runner.get_inference_policy()

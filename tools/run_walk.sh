@@ -7,14 +7,15 @@ set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 ITERS=${1:-3000}
 MLP=${2:-torch}        # torch: stock fp32 GEMMs; mfma: csrc/shf_mlp.hip layers + captured PPO update
-OUT=$REPO/gpurun_out/train_a1_r04_$MLP
+SOLVER=${3:-pgs}       # contact solver: pgs (the reference's PhysX settings) | compliant (rounds 1-4)
+OUT=$REPO/gpurun_out/train_a1_r05_${MLP}_$SOLVER
 mkdir -p "$OUT" /tmp/train_a1
 cd "$REPO"
-python tools/train_a1.py --iters "$ITERS" --graph --quiet --mlp "$MLP" --log /tmp/train_a1 > "$OUT/train_summary.json" 2> "$OUT/train.err"
+python tools/train_a1.py --iters "$ITERS" --graph --quiet --mlp "$MLP" --solver "$SOLVER" --log /tmp/train_a1 > "$OUT/train_summary.json" 2> "$OUT/train.err"
 cp /tmp/train_a1/progress.jsonl "$OUT/progress.jsonl"
 cp /tmp/train_a1/model_"$ITERS".pt "$OUT/model_$ITERS.pt"
 for T in heightfield flat trimesh; do
-  python tools/play_a1.py "$OUT/model_$ITERS.pt" --envs 1024 --steps 500 --terrain $T > "$OUT/play_$T.json" 2>> "$OUT/train.err"
+  python tools/play_a1.py "$OUT/model_$ITERS.pt" --envs 1024 --steps 500 --terrain $T --solver "$SOLVER" > "$OUT/play_$T.json" 2>> "$OUT/train.err"
 done
 cat "$OUT/train_summary.json" | cut -c1-600
 cat "$OUT"/play_*.json

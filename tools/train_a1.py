@@ -34,6 +34,7 @@ def main():
                     help="terrain collision form (trimesh = what the reference's A1EnvConfig effectively builds, SURVEY Q5)")
     ap.add_argument("--seed", type=int, default=None, help="override A1PPOConfig.seed")
     ap.add_argument("--self-collision", action="store_true", help="collide the robot's own links (reference collision filter 0)")
+    ap.add_argument("--solver", choices=["pgs", "compliant"], default=None, help="contact solver (FusedA1Env(solver=...)); default: the env's")
     args = ap.parse_args()
     import torch.distributed as dist
     world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
@@ -65,7 +66,7 @@ def main():
     else:
         from shifu_amd.gym.a1_fused import FusedA1Env
         env = FusedA1Env(num_envs=args.envs, device=dev, rank=rank, world_size=world, self_collision=args.self_collision,
-                         terrain=args.terrain,
+                         terrain=args.terrain, **({} if args.solver is None else {"solver": args.solver}),
                          **({} if args.seed is None else {"seed": args.seed}))
     log_dir = args.log or os.path.join("gpurun_out", "train_a1")
     runner = OnPolicyRunner(env, cfg, log_dir=log_dir, device=str(dev))
