@@ -231,9 +231,10 @@ def main():
                     help="A1 workloads: lane = kinematic chain (default, with --self-collision too at 32 lanes per env; csrc/shf_chain.h) "
                          "or lane = rigid body (the general kernels).  Kernel selection only: results are bit-identical")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--solver", choices=["pgs", "compliant"], default="compliant",
+    ap.add_argument("--solver", choices=["pgs", "compliant"], default=None,
                     help="contact solver (ShfSimParams.solver): pgs = the velocity-level projected Gauss-Seidel solve with the reference's PhysX "
-                         "settings (env_config.py:50-58: 8 + 1 iterations); compliant = rounds 1-4's spring-damper law")
+                         "settings (env_config.py:50-58: 8 + 1 iterations), the default of the A1 workloads (without --self-collision, chain "
+                         "mapping at 32 lanes); compliant = rounds 1-4's spring-damper law (config 5 / abb: the only one built)")
     ap.add_argument("--pos-iters", type=int, default=8, help="physx.num_position_iterations (pgs)")
     ap.add_argument("--vel-iters", type=int, default=1, help="physx.num_velocity_iterations (pgs)")
     ap.add_argument("--self-collision", action="store_true",
@@ -314,6 +315,7 @@ def main():
                          solver_kw={"pos_iters": args.pos_iters, "vel_iters": args.vel_iters})
         stats_t, count_t, kernel = _abi.A1_STATS, _abi.A1_RESET_COUNT, "k_a1_step"
         substeps = args.decimation + (0 if args.no_extra_substep else 1)
+        args.solver = env.solver
     gen = torch.Generator(device=dev)
     gen.manual_seed(42 + rank)
     N, A = env.num_envs, env.num_actions
@@ -421,7 +423,7 @@ def main():
         value = total_envs * args.steps / elapsed
         b_alg = B_ALG[args.workload]
         achieved = b_alg * N / (kern_ms * 1e-3) / 1e9
-        prof = committed_profile(f"{kernel}_{args.workload}_g{group}" + ("_" + mapping if mapping != "body" else "") + ("_link" if (abb and args.link_contacts) else "")) if (N == 4096 and not args.self_collision) else None
+        prof = committed_profile(f"{kernel}_{args.workload}_g{group}" + ("_" + mapping if mapping != "body" else "") + ("_pgs" if (args.solver == "pgs" and not abb) else "") + ("_link" if (abb and args.link_contacts) else "")) if (N == 4096 and not args.self_collision) else None
         res = {}
         try:
             res = json.load(open(os.path.join(ROOT, "shifu_amd", "libshifu_amd.resources.json")))
@@ -486,7 +488,7 @@ def main():
                          "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
                          "traffic": None if not prof else prof.get("traffic_bytes"),
                          "traffic_source": None if not prof else prof.get("source"),
-                         "kernel": ("k_a1_chain" if (kernel == "k_a1_step" and mapping == "chain") else "k_abb_step_ws" if (kernel == "k_abb_step" and mapping == "split") else kernel), "kernel_ms": kern_ms, "alg_bytes_per_env_step": b_alg,
+                         "kernel": ("k_a1_chain_pgs" if (kernel == "k_a1_step" and args.solver == "pgs") else "k_a1_chain" if (kernel == "k_a1_step" and mapping == "chain") else "k_abb_step_ws" if (kernel == "k_abb_step" and mapping == "split") else kernel), "kernel_ms": kern_ms, "alg_bytes_per_env_step": b_alg,
                          "note": "latency/ALU-bound by design: a few KB of compulsory traffic per env-step (DESIGN.md 5)",
                          "secondary": secondary},
         }

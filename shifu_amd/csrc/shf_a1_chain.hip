@@ -16,6 +16,49 @@ const void* shf_a1_chain_pgs_kernel(bool warped) {
 }
 int shf_a1_chain_pgs_max_contacts(void) { return HCK; }
 
+// gym.simulate (examples/a1_conditional/a1_conditional.py:69, shifu/gym/isaac_gym.py:140) of the hook path under the
+// velocity-level solve, for an A1-shaped articulation on its own (no box actors): one chain_substep_hard per call.
+// Forces at the centres of mass.
+template <bool TW>
+__global__ __launch_bounds__(256, 2) void k_sim_step_chain_pgs(SimArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  typedef A1Chain CD;
+  constexpr int G = 32, nb = CD::NB, nd = CD::ND, NR = (CD::NEV + G - 1) / G;
+  const int es = threadIdx.x / G, l = threadIdx.x % G;
+  const int e = blockIdx.x * (256 / G) + es;
+  stage_block<CHAIN_MODEL_BYTES>(A.model, smem);
+  __syncthreads();
+  const ShfModel* m = reinterpret_cast<const ShfModel*>(smem);
+  if (e >= A.n) return;
+  ChainLds L = chain_lds_carve<CD>(smem + CHAIN_MODEL_WORDS + es * chain_lds_words<CD>(0, false));
+  const float* dof = A.dof + (size_t)e * nd * 2;
+  const float* root = A.root + (size_t)e * 13;
+  for (int i = l; i < 2 * nd; i += G) L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)] = dof[i];
+  if (l < 13) L.root[l] = root[l];
+  GROUP_SYNC();
+  StepCtx C;
+  C.m = m; C.sp = A.sp; C.terr.t = A.terr; C.terr.h = A.heights; C.scene = nullptr;
+  C.dropped = A.dropped ? A.dropped + e : nullptr;
+  const float mu = A.friction ? A.friction[e] : 1.0f;
+  const int dl = l < nd ? l : 0;
+  DofLane X = {L.dofb[dl * DOF_STRIDE], L.dofb[dl * DOF_STRIDE + 1], (A.effort && l < nd) ? A.effort[(size_t)e * nd + l] : 0.0f,
+               (A.pos_tgt && l < nd) ? A.pos_tgt[(size_t)e * nd + l] : 0.0f, (A.vel_tgt && l < nd) ? A.vel_tgt[(size_t)e * nd + l] : 0.0f};
+  ChainPoints<NR> LP;
+  chain_points_load<G>(m, CD::NEV, l, C.sp.contact_offset + C.sp.rest_offset, LP);
+  const RowLane RL = row_lane_load<CD>(l);
+  chain_substep_hard<G, CD, TW>(C, L, l, X, LP, RL, A.body_force ? A.body_force + (size_t)e * nb * 3 : nullptr, mu, L.xch);
+  if (l < nd) {
+    A.dof[((size_t)e * nd + l) * 2] = X.q;
+    A.dof[((size_t)e * nd + l) * 2 + 1] = X.qd;
+  }
+  if (l < 13) A.root[(size_t)e * 13 + l] = L.root[l];
+  for (int i = l; i < 3 * nb; i += G) A.contact[(size_t)e * nb * 3 + i] = L.xch[i];
+}
+const void* shf_sim_step_chain_pgs_kernel(bool warped) {
+  return warped ? reinterpret_cast<const void*>(k_sim_step_chain_pgs<true>) : reinterpret_cast<const void*>(k_sim_step_chain_pgs<false>);
+}
+size_t shf_sim_step_chain_pgs_lds_bytes(void) { return ((size_t)CHAIN_MODEL_WORDS + 8 * (size_t)chain_lds_words<A1Chain>(0, false)) * 4; }
+
 bool shf_a1_chain_matches(const ShfModel& m) { return A1Chain::matches(m); }
 // dynamic LDS of one 256-thread block at G lanes per env
 size_t shf_a1_chain_lds_bytes(int G, int nobs, bool self) {

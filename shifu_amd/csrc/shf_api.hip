@@ -63,6 +63,8 @@ size_t shf_a1_chain_lds_bytes(int G, int nobs, bool self);
 const void* shf_a1_chain_kernel(int G, bool warped, bool self);
 const void* shf_a1_chain_pgs_kernel(bool warped);
 int shf_a1_chain_pgs_max_contacts(void);
+const void* shf_sim_step_chain_pgs_kernel(bool warped);
+size_t shf_sim_step_chain_pgs_lds_bytes(void);
 #ifdef SHF_PHASE_CLOCK
 int shf_a1_chain_phase_cycles(unsigned long long* out, int n, int reset);
 #endif
@@ -1026,6 +1028,11 @@ extern "C" int shf_sim_create(const ShfSimParams* params, ShfSim** out) {
   *out = s;
   return 0;
 }
+extern "C" int shf_model_pgs_supported(const ShfModel* model, int32_t nboxes) {
+  if (!model || nboxes != 0) return 0;
+  if (model->self_collide && model->npair > 0) return 0;
+  return shf_a1_chain_matches(*model) ? 1 : 0;
+}
 extern "C" int shf_sim_destroy(ShfSim* sim) {
   delete sim;
   return 0;
@@ -1289,11 +1296,20 @@ static int launch_ptr(const void* fn, dim3 grid, dim3 block, size_t lds, void* s
 extern "C" int shf_sim_step(ShfSim* sim, void* stream) {
   if (int r = need(sim, {SHF_T_SIM_DOF, SHF_T_SIM_ROOT, SHF_T_SIM_CONTACT, SHF_T_MODEL}, "shf_sim_step")) return r;
   if (sim->terr.rows > 0 && !sim->t[SHF_T_HEIGHTS]) return fail("shf_sim_step: heightfield samples not bound");
-  if (sim->sp.solver == SHF_SOLVER_PGS) return fail("shf_sim_step: ShfSimParams.solver = SHF_SOLVER_PGS is built into the fused A1 step only (shf_a1_step); use SHF_SOLVER_COMPLIANT here");
   SimArgs A = sim_args(sim, true);
   if (sim->force_armed) {
     A.body_force = (const float*)sim->t[SHF_T_BODY_FORCE];
     if (sim->force_at_pos) A.body_force_pos = (const float*)sim->t[SHF_T_BODY_FORCE_POS];
+  }
+  if (sim->sp.solver == SHF_SOLVER_PGS) {
+    // the velocity-level contact solve: built for A1-shaped articulations on their own (csrc/shf_chain_hard.h)
+    if (sim->nboxes > 0 || !shf_a1_chain_matches(sim->model) || sim_self(sim))
+      return fail("shf_sim_step: ShfSimParams.solver = SHF_SOLVER_PGS is built for a single A1-shaped articulation without self-collision; use SHF_SOLVER_COMPLIANT for this scene");
+    if (A.body_force_pos) return fail("shf_sim_step: SHF_SOLVER_PGS applies body forces at the centres of mass only");
+    if (sim->sp.max_contacts > shf_a1_chain_pgs_max_contacts() || sim->sp.pos_iters < 1) return fail("shf_sim_step: SHF_SOLVER_PGS needs pos_iters >= 1 and max_contacts <= 8");
+    sim->force_armed = false;
+    sim->force_at_pos = false;
+    return launch_ptr(shf_sim_step_chain_pgs_kernel(sim->terr.warped != 0), dim3((sim->n + 7) / 8), dim3(256), shf_sim_step_chain_pgs_lds_bytes(), stream, A);
   }
   sim->force_armed = false;
   sim->force_at_pos = false;

@@ -130,7 +130,7 @@ DEV void chain_ext_force(const float* F, const float* com, const float* Rw, cons
 }
 
 // joint-space effort of one dof: explicit part t0 and implicit diagonal de (oracle substep(), "joint-space efforts")
-DEV void chain_dof_effort(const StepCtx& C, int d, float q, float qd, float tau_cmd, float* t0o, float* deo) {
+DEV void chain_dof_effort(const StepCtx& C, int d, float q, float qd, float tau_cmd, float* t0o, float* deo, float tq = 0.0f, float tv_in = 0.0f) {
   const ShfModel* m = C.m;
   const float dt = C.sp.dt;
   float t0 = 0.0f, de = m->armature[d];
@@ -138,9 +138,10 @@ DEV void chain_dof_effort(const StepCtx& C, int d, float q, float qd, float tau_
   if (mode == SHF_DOF_MODE_EFFORT) {
     t0 = tau_cmd;
   } else if (mode == SHF_DOF_MODE_POS || mode == SHF_DOF_MODE_VEL) {
-    // the fused A1 step sets no drive targets (they read as zero, like the body-mapped kernel's null target pointers)
+    // the fused A1 step sets no drive targets (they read as zero, like the body-mapped kernel's null target pointers); the
+    // hook path's simulate hands them in (tq; tv counts in VEL mode only, oracle substep())
     float kp = mode == SHF_DOF_MODE_POS ? m->kp[d] : 0.0f, kd = m->kd[d];
-    const float tq = 0.0f, tv = 0.0f;
+    const float tv = mode == SHF_DOF_MODE_VEL ? tv_in : 0.0f;
     const float est = fmaf(kp, tq - q, kd * (tv - qd));
     const float lim = m->effort[d];
     if (lim > 0.0f && fabsf(est) > lim) { const float sc = lim / fabsf(est); kp *= sc; kd *= sc; }
@@ -250,6 +251,7 @@ DEV SlotList<MAXPT> slot_list_load(const ShfModel* m, int i0, int n) {
 // Per-lane state that lives across the sub-steps of one env step: lane j < ND is dof j.
 struct DofLane {
   float q, qd, tau;   // joint position, velocity, commanded (explicit) effort
+  float tq, tv;       // POS / VEL drive targets (hook path; zero in the fused step)
 };
 
 // Row lanes of the inward pass at 32 lanes per env: lane 8 c + i (i < 6) holds row i of chain c's 6x6 articulated inertia.

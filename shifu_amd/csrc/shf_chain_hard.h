@@ -204,7 +204,7 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
   if (isdof) {
     float* rec = L.jrec + l * JREC_STRIDE;
     float Rl[9], t0, de;
-    chain_dof_effort(C, l, X.q, X.qd, X.tau, &t0, &de);
+    chain_dof_effort(C, l, X.q, X.qd, X.tau, &t0, &de, X.tq, X.tv);
     joint_local_rotation(m->trot[myb], m->axis[myb], X.q, Rl);
 #pragma unroll
     for (int k = 0; k < 9; k++) rec[k] = Rl[k];

@@ -66,7 +66,7 @@ class FusedA1Env:
                  terrain_seed: int = 42, send_timeouts: bool = True, extra_substep: bool = True,
                  model_edit=None, task_overrides: Optional[dict] = None, dof_stiffness: float = 20.0,
                  dof_damping: float = 0.5, self_collision: bool = False, mapping: Optional[str] = None,
-                 solver: str = "compliant", solver_kw: Optional[dict] = None):
+                 solver: Optional[str] = None, solver_kw: Optional[dict] = None):
         self.device = torch.device(device)
         self.num_envs = num_envs
         self.rank, self.world_size = rank, world_size
@@ -85,7 +85,10 @@ class FusedA1Env:
         if model_edit is not None:        # experiments: e.g. other joint damping / armature
             model_edit(self.cm)
         # solver: "pgs" = the velocity-level contact solve with the reference's PhysX settings (env_config.py:50-58;
-        # csrc/shf_chain_hard.h: chain mapping at 32 lanes per env, no self-collision), "compliant" = rounds 1-4's law
+        # csrc/shf_chain_hard.h: chain mapping at 32 lanes per env, no self-collision) -- the default where it is built;
+        # "compliant" = rounds 1-4's spring-damper law (the default with self-collision or another lane mapping)
+        if solver is None:
+            solver = "pgs" if (not self_collision and mapping in (None, "chain") and group in (None, 32)) else "compliant"
         self.solver = solver if sim_params is None else ("pgs" if sim_params.solver == _abi.SOLVER_PGS else "compliant")
         self.sim_params = sim_params or default_sim_params(dt=dt, solver=solver, **(solver_kw or {}))
         self.dt = dt * decimation                                         # isaac_gym.py:26

@@ -18,6 +18,7 @@ Semantics kept from Isaac Gym:
 from __future__ import annotations
 
 import copy
+import ctypes as C
 import os
 from typing import Dict, List, Optional
 
@@ -244,15 +245,17 @@ class Gym:
     # max_depenetration_velocity ARE used (ShfSimParams); the ones below are accepted and ignored -- said once, at
     # create_sim, instead of only in a document.
     IGNORED_PHYSX_FIELDS = {
-        "solver_type": "there is one solver: ABA with implicit contact, no TGS / PGS choice",
-        "num_position_iterations": "contacts are solved in one linear-implicit ABA pass, not iteratively",
-        "num_velocity_iterations": "contacts are solved in one linear-implicit ABA pass, not iteratively",
-        "rest_offset": "shapes rest where their compliant contact balances the load (0.6 mm sag per A1 foot)",
-        "bounce_threshold_velocity": "restitution is not modelled: every contact is inelastic",
-        "max_gpu_contact_pairs": "contact slots are fixed per articulation (SHF_MAX_POINTS), no pair buffer",
+        "max_gpu_contact_pairs": "contact candidates are fixed per articulation (SHF_MAX_POINTS), no pair buffer",
         "default_buffer_size_multiplier": "no PhysX buffers",
     }
+    # honoured since round 5 (ShfSimParams.solver = SHF_SOLVER_PGS, the velocity-level contact solve): solver_type (PGS and TGS
+    # both map to the projected Gauss-Seidel solve -- TGS is PhysX's sub-stepped variant of it), num_position_iterations,
+    # num_velocity_iterations, contact_offset, rest_offset, bounce_threshold_velocity, max_depenetration_velocity
+    # (shifu/configs/env_config.py:50-58).  Scenes the solve is not built for yet (box actors, self-collision, other tree
+    # shapes) keep rounds 1-4's compliant law and say so once at prepare_sim.
+    SOLVER_PHYSX_FIELDS = ("solver_type", "num_position_iterations", "num_velocity_iterations", "rest_offset", "bounce_threshold_velocity")
     _warned_physx = False
+    _warned_compliant = False
 
     def create_sim(self, compute_device=0, graphics_device=0, physics_engine=SIM_PHYSX, params: SimParams = None):
         params = params or SimParams()
@@ -398,10 +401,30 @@ class Gym:
     def prepare_sim(self, sim: SimHandle):
         import torch
         from ..backend import Sim, default_sim_params
+        from .._lib import lib
         p = sim.params
+        # the contact solver: the physx settings as they are (SHF_SOLVER_PGS) where the velocity-level solve is built for the
+        # scene, else the compliant law (SHIFU_AMD_SOLVER=compliant forces it: A/B runs)
+        env0 = sim.envs[0]
+        arts = [a for a in env0.actors if a.asset.kind == "articulation"]
+        probe = copy.deepcopy(arts[0].asset.model.blob) if len(arts) == 1 else None
+        if probe is not None:
+            probe.self_collide = int(bool(getattr(arts[0], "self_collide", False)) and probe.npair > 0 and
+                                     os.environ.get("SHIFU_AMD_SELF_COLLISION", "1") != "0")
+        pgs = (probe is not None and os.environ.get("SHIFU_AMD_SOLVER", "pgs") != "compliant" and
+               lib().shf_model_pgs_supported(C.byref(probe), len(env0.actors) - 1) == 1 and int(p.physx.num_position_iterations) >= 1)
+        solver_kw = dict(solver="pgs", pos_iters=int(p.physx.num_position_iterations), vel_iters=int(p.physx.num_velocity_iterations),
+                         rest_offset=float(p.physx.rest_offset), bounce_threshold=float(p.physx.bounce_threshold_velocity)) if pgs else {}
+        if not pgs and not Gym._warned_compliant:
+            Gym._warned_compliant = True
+            import warnings
+            warnings.warn("shifu_amd: this scene runs the compliant contact law of rounds 1-4 -- the velocity-level solve that honours "
+                          "sim_params.physx." + " / ".join(Gym.SOLVER_PHYSX_FIELDS) + " is built for a single A1-shaped articulation "
+                          "without box actors or self-collision (csrc/shf_chain_hard.h)", stacklevel=2)
+        sim.solver = "pgs" if pgs else "compliant"
         sp = default_sim_params(dt=p.dt, gravity=tuple(p.gravity),
                                 max_depen_vel=min(float(p.physx.max_depenetration_velocity), 10.0),
-                                contact_offset=float(p.physx.contact_offset))
+                                contact_offset=float(p.physx.contact_offset), **solver_kw)
         dev = torch.device("cuda", sim.device_id if isinstance(sim.device_id, int) and sim.device_id >= 0 else 0)
         be = Sim(sp, dev)
         if sim.terrain is None or sim.terrain[0] == "plane":

@@ -155,25 +155,46 @@ def test_add_triangle_mesh_without_hints_recovers_the_grid_exactly():
         terrain_utils.heightfield_from_trimesh(ter.vertices, t)
 
 
-def test_create_sim_names_the_ignored_physx_settings_once():
-    """shifu's config sets PhysX solver parameters (shifu/configs/env_config.py:46-58) that this backend's contact model
-    has no use for: the facade says so at create_sim -- once per process -- rather than staying silent."""
+def test_create_sim_honours_the_physx_solver_settings_and_names_the_ignored_ones_once():
+    """shifu's config sets PhysX solver parameters (shifu/configs/env_config.py:46-58).  Since round 5 the solver fields
+    (solver_type, num_position_iterations, num_velocity_iterations, rest_offset, bounce_threshold_velocity) configure the
+    velocity-level contact solve and are not reported any more; the two buffer-size fields have no counterpart and the
+    facade says so at create_sim -- once per process -- rather than staying silent."""
     import warnings
     from shifu_amd.isaacgym import gymapi
     gymapi.Gym._warned_physx = False
     gym = gymapi.acquire_gym()
     sp = gymapi.SimParams()
+    sp.physx.solver_type = 1                      # env_config.py:50
     sp.physx.num_position_iterations = 8          # env_config.py:51
     sp.physx.bounce_threshold_velocity = 0.5      # env_config.py:56
-    sp.physx.contact_offset = 0.01                # used (ShfSimParams.contact_offset): must not be reported
+    sp.physx.contact_offset = 0.01                # env_config.py:54
+    sp.physx.max_gpu_contact_pairs = 2 ** 23      # env_config.py:58
+    sp.physx.default_buffer_size_multiplier = 5   # env_config.py:59
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         gym.create_sim(0, 0, gymapi.SIM_PHYSX, sp)
         gym.create_sim(0, 0, gymapi.SIM_PHYSX, sp)
     msgs = [str(x.message) for x in w]
-    assert sum("num_position_iterations" in m for m in msgs) == 1
-    assert sum("bounce_threshold_velocity" in m for m in msgs) == 1
-    assert not any("contact_offset" in m for m in msgs)
+    assert sum("max_gpu_contact_pairs" in m for m in msgs) == 1
+    assert sum("default_buffer_size_multiplier" in m for m in msgs) == 1
+    for honoured in ("solver_type", "num_position_iterations", "bounce_threshold_velocity", "contact_offset"):
+        assert not any(honoured in m for m in msgs), honoured
+
+
+def test_pgs_support_query():
+    """shf_model_pgs_supported: the A1 on its own, without self-collision -- yes; with box actors, with self-collision, the
+    ABB arm -- no (the facade then keeps the compliant law and says so)."""
+    import ctypes as C
+    from shifu_amd._lib import lib
+    from shifu_amd.abb_task import abb_model
+    from tests.helpers import a1_model
+    a1 = a1_model().blob
+    assert lib().shf_model_pgs_supported(C.byref(a1), 0) == 1
+    assert lib().shf_model_pgs_supported(C.byref(a1), 1) == 0
+    a1s = a1_model(self_collision=True).blob
+    assert lib().shf_model_pgs_supported(C.byref(a1s), 0) == 0
+    assert lib().shf_model_pgs_supported(C.byref(abb_model(link_contacts=False).blob), 0) == 0
 
 
 def test_trimesh_recovery_with_sparse_height_levels_and_shifted_border():
