@@ -362,7 +362,7 @@ class A1Task:
         g, warped = self.sim.group, bool(self.sim.terrain.warped)
         mdl = self.sim.model
         if self.sim.params.solver == _abi.SOLVER_PGS:
-            return f"_Z14k_a1_chain_pgsILb{int(warped)}EE"
+            return f"_Z14k_a1_chain_pgsILb{int(warped)}ELb{int(bool(mdl.self_collide and mdl.npair > 0))}EE"
         if getattr(self.sim, "mapping", "body") == "chain":
             return f"_Z10k_a1_chainILi{g}ELb{int(warped)}ELb{int(bool(mdl.self_collide and mdl.npair > 0))}EE"
         a1 = mdl.nb == 17 and mdl.nd == 12 and mdl.np == 76

@@ -9,17 +9,18 @@ template <int G, bool TW, bool SELF = false>
 __global__ __launch_bounds__(256, (G == 32 ? 2 : 1)) void k_a1_chain(A1Args A) { a1_chain_step_body<G, A1Chain, TW, SELF>(A); }
 
 // the same step under the velocity-level contact solve (ShfSimParams.solver == SHF_SOLVER_PGS; csrc/shf_chain_hard.h)
-template <bool TW>
-__global__ __launch_bounds__(256, 2) void k_a1_chain_pgs(A1Args A) { a1_chain_step_body<32, A1Chain, TW, false, true>(A); }
-const void* shf_a1_chain_pgs_kernel(bool warped) {
-  return warped ? reinterpret_cast<const void*>(k_a1_chain_pgs<true>) : reinterpret_cast<const void*>(k_a1_chain_pgs<false>);
+template <bool TW, bool SELF>
+__global__ __launch_bounds__(256, 2) void k_a1_chain_pgs(A1Args A) { a1_chain_step_body<32, A1Chain, TW, SELF, true>(A); }
+const void* shf_a1_chain_pgs_kernel(bool warped, bool self) {
+  if (self) return warped ? reinterpret_cast<const void*>(k_a1_chain_pgs<true, true>) : reinterpret_cast<const void*>(k_a1_chain_pgs<false, true>);
+  return warped ? reinterpret_cast<const void*>(k_a1_chain_pgs<true, false>) : reinterpret_cast<const void*>(k_a1_chain_pgs<false, false>);
 }
 int shf_a1_chain_pgs_max_contacts(void) { return HCK; }
 
 // gym.simulate (examples/a1_conditional/a1_conditional.py:69, shifu/gym/isaac_gym.py:140) of the hook path under the
 // velocity-level solve, for an A1-shaped articulation on its own (no box actors): one chain_substep_hard per call.
 // Forces at the centres of mass.
-template <bool TW>
+template <bool TW, bool SELF>
 __global__ __launch_bounds__(256, 2) void k_sim_step_chain_pgs(SimArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   typedef A1Chain CD;
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256, 2) void k_sim_step_chain_pgs(SimArgs A) {
   __syncthreads();
   const ShfModel* m = reinterpret_cast<const ShfModel*>(smem);
   if (e >= A.n) return;
-  ChainLds L = chain_lds_carve<CD>(smem + CHAIN_MODEL_WORDS + es * chain_lds_words<CD>(0, false));
+  ChainLds L = chain_lds_carve<CD>(smem + CHAIN_MODEL_WORDS + es * chain_lds_words<CD>(0, SELF));
   const float* dof = A.dof + (size_t)e * nd * 2;
   const float* root = A.root + (size_t)e * 13;
   for (int i = l; i < 2 * nd; i += G) L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)] = dof[i];
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256, 2) void k_sim_step_chain_pgs(SimArgs A) {
   ChainPoints<NR> LP;
   chain_points_load<G>(m, CD::NEV, l, C.sp.contact_offset + C.sp.rest_offset, LP);
   const RowLane RL = row_lane_load<CD>(l);
-  chain_substep_hard<G, CD, TW>(C, L, l, X, LP, RL, A.body_force ? A.body_force + (size_t)e * nb * 3 : nullptr, mu, L.xch);
+  chain_substep_hard<G, CD, TW, SELF>(C, L, l, X, LP, RL, A.body_force ? A.body_force + (size_t)e * nb * 3 : nullptr, mu, L.xch);
   if (l < nd) {
     A.dof[((size_t)e * nd + l) * 2] = X.q;
     A.dof[((size_t)e * nd + l) * 2 + 1] = X.qd;
@@ -54,10 +55,11 @@ __global__ __launch_bounds__(256, 2) void k_sim_step_chain_pgs(SimArgs A) {
   if (l < 13) A.root[(size_t)e * 13 + l] = L.root[l];
   for (int i = l; i < 3 * nb; i += G) A.contact[(size_t)e * nb * 3 + i] = L.xch[i];
 }
-const void* shf_sim_step_chain_pgs_kernel(bool warped) {
-  return warped ? reinterpret_cast<const void*>(k_sim_step_chain_pgs<true>) : reinterpret_cast<const void*>(k_sim_step_chain_pgs<false>);
+const void* shf_sim_step_chain_pgs_kernel(bool warped, bool self) {
+  if (self) return warped ? reinterpret_cast<const void*>(k_sim_step_chain_pgs<true, true>) : reinterpret_cast<const void*>(k_sim_step_chain_pgs<false, true>);
+  return warped ? reinterpret_cast<const void*>(k_sim_step_chain_pgs<true, false>) : reinterpret_cast<const void*>(k_sim_step_chain_pgs<false, false>);
 }
-size_t shf_sim_step_chain_pgs_lds_bytes(void) { return ((size_t)CHAIN_MODEL_WORDS + 8 * (size_t)chain_lds_words<A1Chain>(0, false)) * 4; }
+size_t shf_sim_step_chain_pgs_lds_bytes(bool self) { return ((size_t)CHAIN_MODEL_WORDS + 8 * (size_t)chain_lds_words<A1Chain>(0, self)) * 4; }
 
 bool shf_a1_chain_matches(const ShfModel& m) { return A1Chain::matches(m); }
 // dynamic LDS of one 256-thread block at G lanes per env

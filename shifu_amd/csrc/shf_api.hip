@@ -61,10 +61,10 @@ struct ShfA1Task {
 bool shf_a1_chain_matches(const ShfModel& m);
 size_t shf_a1_chain_lds_bytes(int G, int nobs, bool self);
 const void* shf_a1_chain_kernel(int G, bool warped, bool self);
-const void* shf_a1_chain_pgs_kernel(bool warped);
+const void* shf_a1_chain_pgs_kernel(bool warped, bool self);
 int shf_a1_chain_pgs_max_contacts(void);
-const void* shf_sim_step_chain_pgs_kernel(bool warped);
-size_t shf_sim_step_chain_pgs_lds_bytes(void);
+const void* shf_sim_step_chain_pgs_kernel(bool warped, bool self);
+size_t shf_sim_step_chain_pgs_lds_bytes(bool self);
 #ifdef SHF_PHASE_CLOCK
 int shf_a1_chain_phase_cycles(unsigned long long* out, int n, int reset);
 #endif
@@ -1030,7 +1030,6 @@ extern "C" int shf_sim_create(const ShfSimParams* params, ShfSim** out) {
 }
 extern "C" int shf_model_pgs_supported(const ShfModel* model, int32_t nboxes) {
   if (!model || nboxes != 0) return 0;
-  if (model->self_collide && model->npair > 0) return 0;
   return shf_a1_chain_matches(*model) ? 1 : 0;
 }
 extern "C" int shf_sim_destroy(ShfSim* sim) {
@@ -1303,13 +1302,13 @@ extern "C" int shf_sim_step(ShfSim* sim, void* stream) {
   }
   if (sim->sp.solver == SHF_SOLVER_PGS) {
     // the velocity-level contact solve: built for A1-shaped articulations on their own (csrc/shf_chain_hard.h)
-    if (sim->nboxes > 0 || !shf_a1_chain_matches(sim->model) || sim_self(sim))
-      return fail("shf_sim_step: ShfSimParams.solver = SHF_SOLVER_PGS is built for a single A1-shaped articulation without self-collision; use SHF_SOLVER_COMPLIANT for this scene");
+    if (sim->nboxes > 0 || !shf_a1_chain_matches(sim->model))
+      return fail("shf_sim_step: ShfSimParams.solver = SHF_SOLVER_PGS is built for a single A1-shaped articulation; use SHF_SOLVER_COMPLIANT for this scene");
     if (A.body_force_pos) return fail("shf_sim_step: SHF_SOLVER_PGS applies body forces at the centres of mass only");
     if (sim->sp.max_contacts > shf_a1_chain_pgs_max_contacts() || sim->sp.pos_iters < 1) return fail("shf_sim_step: SHF_SOLVER_PGS needs pos_iters >= 1 and max_contacts <= 8");
     sim->force_armed = false;
     sim->force_at_pos = false;
-    return launch_ptr(shf_sim_step_chain_pgs_kernel(sim->terr.warped != 0), dim3((sim->n + 7) / 8), dim3(256), shf_sim_step_chain_pgs_lds_bytes(), stream, A);
+    return launch_ptr(shf_sim_step_chain_pgs_kernel(sim->terr.warped != 0, sim_self(sim)), dim3((sim->n + 7) / 8), dim3(256), shf_sim_step_chain_pgs_lds_bytes(sim_self(sim)), stream, A);
   }
   sim->force_armed = false;
   sim->force_at_pos = false;
@@ -1571,10 +1570,9 @@ static int a1_step_launch(ShfA1Task* task, const float* raw_actions_dev, void* s
     // the velocity-level contact solve: the chain mapping at two envs per wavefront (csrc/shf_chain_hard.h)
     if (s->mapping != SHF_MAP_CHAIN || s->chain_group != 32 || !shf_a1_chain_matches(s->model))
       return fail("shf_a1_step: ShfSimParams.solver = SHF_SOLVER_PGS runs on the chain mapping at 32 lanes per env (shf_sim_set_mapping)");
-    if (sim_self(s)) return fail("shf_a1_step: self-collision is not built into the velocity-level solve of the fused A1 step");
     if (s->sp.max_contacts > shf_a1_chain_pgs_max_contacts()) return fail("shf_a1_step: the fused A1 step's solve holds at most 8 constraints per env (ShfSimParams.max_contacts)");
     if (s->sp.pos_iters < 1) return fail("shf_a1_step: ShfSimParams.pos_iters must be >= 1 with SHF_SOLVER_PGS");
-    return launch_ptr(shf_a1_chain_pgs_kernel(s->terr.warped != 0), dim3((s->n + 7) / 8), block, shf_a1_chain_lds_bytes(32, nobs, false), stream, A);
+    return launch_ptr(shf_a1_chain_pgs_kernel(s->terr.warped != 0, sim_self(s)), dim3((s->n + 7) / 8), block, shf_a1_chain_lds_bytes(32, nobs, sim_self(s)), stream, A);
   }
   if (s->mapping == SHF_MAP_CHAIN) {
     if (!shf_a1_chain_matches(s->model)) return fail("shf_a1_step: the articulation does not fit the chain mapping");

@@ -61,9 +61,23 @@ DEV bool corner_next(unsigned& pl, unsigned long long& bx, unsigned& ed, int* c,
 }
 
 // slot layout in LDS (PT_STRIDE floats): r[3] n[3] f0[3] ct bn on (PT_* offsets, shf_device.h)
+// ShfSimParams.solver == SHF_SOLVER_PGS (oracle: slot_eval with kc < 0): the slot only records the candidate constraint --
+// location, normal, gap from rest_offset (`beta` carries it) in PT_F, friction in PT_F + 1; `offset` arrives as
+// contact_offset + rest_offset.
 DEV void slot_eval(float* o, float phi, const float* n, const float* r, const float* vs, const float* vp, float mu, float kc,
                    float beta, float veps, float vdep, float dt, float offset) {
   float on = 0.0f;
+  if (kc < 0.0f) {
+    if (phi < offset) {
+      on = 1.0f;
+      o[PT_CT] = 0.0f; o[PT_BN] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { o[PT_R + k] = r[k]; o[PT_N + k] = n[k]; }
+      o[PT_F] = phi - beta; o[PT_F + 1] = mu; o[PT_F + 2] = 0.0f;
+    }
+    o[PT_ON] = on;
+    return;
+  }
   if (phi < offset) {
     const float vn = dot3(n, vp);
     const float pen = rminf(-kc * phi, beta * vdep);
@@ -678,9 +692,10 @@ DEV bool box_box_edge(const float* RA, const float* cA, const float* hA, const f
 template <int G>
 DEV int self_contacts_eval(const StepCtx& C, const EnvLds& L, int l, int slot0, float mu_shape) {
   const ShfModel* m = C.m;
-  const float dt = C.sp.dt, kc = C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
-  const float offset = C.sp.contact_offset;
-  const float beta = fmaf(kc, dt, C.sp.contact_d);
+  const bool hard = C.sp.solver == SHF_SOLVER_PGS;     // candidates only (slot_eval)
+  const float dt = C.sp.dt, kc = hard ? -1.0f : C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
+  const float offset = hard ? C.sp.contact_offset + C.sp.rest_offset : C.sp.contact_offset;
+  const float beta = hard ? C.sp.rest_offset : fmaf(kc, dt, C.sp.contact_d);
   const int lane0 = (int)(threadIdx.x & 63u) - l;
   const unsigned long long gmask = G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
   const int npair = m->npair;

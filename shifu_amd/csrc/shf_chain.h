@@ -796,7 +796,7 @@ DEV void chain_body_states(const ShfModel* m, const ChainLds& L, int l, const Do
 
 // ShifuVecEnv.step for the A1 task (env.py:85-106) on the chain mapping; the task glue after the physics is shared
 // with the body-mapped kernel (a1_post_step, shf_task.h).
-template <int G, class CD, bool TW>
+template <int G, class CD, bool TW, bool SELF>
 DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane& X, const ChainPoints<(CD::NEV + G - 1) / G>& P,
                             const RowLane& RL, const float* fext, float mu_shape, float* contact_out);   // shf_chain_hard.h
 // HARD: the velocity-level contact solve (ShfSimParams.solver == SHF_SOLVER_PGS, csrc/shf_chain_hard.h)
@@ -884,7 +884,7 @@ DEV void a1_chain_step_body(const A1Args& A) {
       X.tau = rclampf(t, -lim_, lim_);
     }
     if constexpr (HARD)
-      chain_substep_hard<G, CD, TW>(C, L, l, X, LP, RL, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
+      chain_substep_hard<G, CD, TW, SELF>(C, L, l, X, LP, RL, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
                                     (it == nsub - 1) ? L.xch : nullptr);
     else
       chain_substep<G, CD, TW, SELF>(C, L, l, X, LP, mine, RL, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,

@@ -23,7 +23,7 @@
 #include "shf_chain.h"
 
 #define HCK 8           /* constraints one env's solve holds on this kernel (ShfSimParams.max_contacts <= HCK) */
-#define HC_STRIDE 16    /* r[3] n[3] phi mu body rep p[3] . . .  */
+#define HC_STRIDE 16    /* r[3] n[3] phi mu body rep p[3] bodyb repb .  (bodyb / repb: the other side of a self-contact, else -1) */
 #define HC_R 0
 #define HC_N 3
 #define HC_PHI 6
@@ -31,10 +31,13 @@
 #define HC_BODY 8
 #define HC_REP 9
 #define HC_P 10
+#define HC_BODYB 13
+#define HC_REPB 14
 #define UF_STRIDE 8     /* U[6] invD . per link */
 template <class CD>
 struct HardTail {
-  static constexpr int HC = 0, W = HCK * HC_STRIDE, UF = W + HCK * HCK * 9, PHI = UF + CD::ND * UF_STRIDE, END = PHI + ((CD::NEV + 3) & ~3);
+  static constexpr int HC = 0, W = HCK * HC_STRIDE, UF = W + HCK * HCK * 9, PHI = UF + CD::ND * UF_STRIDE, NEVP = (CD::NEV + 3) & ~3,
+                       END = PHI + NEVP + SHF_MAX_SELF_CONTACTS;
 };
 
 // point velocity of the spatial velocity v6 (about O) at r
@@ -81,6 +84,66 @@ DEV void root_factors_apply(const float* o, const float* pA, float* x) {   // ld
   }
 }
 
+// Response of the articulation to the impulse e at r on its moving body bs (0: the root): the root's velocity change and the
+// joint terms of the links on bs's chain up to bs (oracle: hc_impulse) ...
+template <class CD>
+struct HardResp { int cs, ks; float ub[CD::NLK], dv0[6]; };
+template <class CD>
+DEV void hard_impulse(const ChainLds& L, const float* tail, int bs, const float* r, const float* e, HardResp<CD>& q) {
+  constexpr int NLK = CD::NLK;
+  typedef HardTail<CD> T;
+  q.cs = bs > 0 ? (bs - 1) / (NLK + 1) : 0;
+  q.ks = bs > 0 ? (bs - 1) % (NLK + 1) : -1;
+  float p6[6], t[3];
+  cross3(r, e, t);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { p6[k] = -t[k]; p6[3 + k] = -e[k]; }
+#pragma unroll
+  for (int k = NLK - 1; k >= 0; k--) {
+    q.ub[k] = 0.0f;
+    if (k <= q.ks) {
+      const int li = q.cs * NLK + k;
+      const float* rec = L.jrec + li * JREC_STRIDE;
+      const float* uf = tail + T::UF + li * UF_STRIDE;
+      float sp = rec[JREC_S] * p6[0];
+#pragma unroll
+      for (int j = 1; j < 6; j++) sp = fmaf(rec[JREC_S + j], p6[j], sp);
+      q.ub[k] = -sp;
+      const float tt = q.ub[k] * uf[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) p6[j] = fmaf(uf[j], tt, p6[j]);
+    }
+  }
+  root_factors_apply(L.xroot, p6, q.dv0);
+}
+// ... and the velocity change of the point r of moving body bt under it (oracle: hc_velocity); bt < 0: nothing moves
+template <class CD>
+DEV void hard_velocity(const ChainLds& L, const float* tail, const HardResp<CD>& q, int bt, const float* r, float* vel) {
+  constexpr int NLK = CD::NLK;
+  typedef HardTail<CD> T;
+  if (bt < 0) { vel[0] = 0.0f; vel[1] = 0.0f; vel[2] = 0.0f; return; }
+  const int ct = bt > 0 ? (bt - 1) / (NLK + 1) : 0, kt = bt > 0 ? (bt - 1) % (NLK + 1) : -1;
+  float dv[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) dv[j] = q.dv0[j];
+#pragma unroll
+  for (int k = 0; k < NLK; k++) {
+    if (k <= kt) {
+      const int li = ct * NLK + k;
+      const float* rec = L.jrec + li * JREC_STRIDE;
+      const float* uf = tail + T::UF + li * UF_STRIDE;
+      const float ubk = (ct == q.cs && k <= q.ks) ? q.ub[k] : 0.0f;
+      float ua = uf[0] * dv[0];
+#pragma unroll
+      for (int j = 1; j < 6; j++) ua = fmaf(uf[j], dv[j], ua);
+      const float dq = (ubk - ua) * uf[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) dv[j] = fmaf(rec[JREC_S + j], dq, dv[j]);
+    }
+  }
+  hard_point(dv, r, vel);
+}
+
 // Per-lane state of the solve that outlives a phase.
 struct HardOwner {     // the owner lane of contact c
   float n[3], mu, u[3], p[3], tgt, tgt_v, Wn[3], iwnn, Ti[9], rt;
@@ -97,13 +160,19 @@ DEV void chain_hard_apply(const ShfModel* m, const ChainLds& L, float* tail, int
   if (isbody_h0) {
     for (int c = 0; c < K; c++) {
       const float* h = tail + T::HC + c * HC_STRIDE;
-      if (__float_as_int(h[HC_BODY]) != myb) continue;
+      const bool ona = __float_as_int(h[HC_BODY]) == myb, onb = __float_as_int(h[HC_BODYB]) == myb;
+      if (!ona && !onb) continue;
       const float r[3] = {h[HC_R], h[HC_R + 1], h[HC_R + 2]};
       const float f[3] = {h[HC_P] * idt, h[HC_P + 1] * idt, h[HC_P + 2] * idt};
       float t[3];
       cross3(r, f, t);
+      if (ona) {
 #pragma unroll
-      for (int k = 0; k < 3; k++) { pcr[k] -= t[k]; pcr[3 + k] -= f[k]; }
+        for (int k = 0; k < 3; k++) { pcr[k] -= t[k]; pcr[3 + k] -= f[k]; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { pcr[k] += t[k]; pcr[3 + k] += f[k]; }
+      }
     }
     if (islink) {
       float* o = L.xch + lb * XCH_STRIDE + 21;
@@ -176,7 +245,7 @@ DEV void chain_hard_apply(const ShfModel* m, const ChainLds& L, float* tail, int
 }
 
 // One gym.simulate() for one env under the velocity-level contact solve; lane roles as chain_substep at 32 lanes per env.
-template <int G, class CD, bool TW>
+template <int G, class CD, bool TW, bool SELF>
 DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane& X, const ChainPoints<(CD::NEV + G - 1) / G>& P,
                             const RowLane& RL, const float* fext, float mu_shape, float* contact_out) {
   static_assert(G == 32, "the velocity-level solve is written for two envs per wavefront");
@@ -335,13 +404,25 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
       const unsigned long long bits = (__ballot(cand[k]) >> lane0) & ((1ull << G) - 1ull);
       if (k * G < 64) act.w[0] |= bits << ((k * G) & 63); else act.w[1] |= bits << ((k * G - 64) & 63);
     }
-    int total = __popcll(act.w[0]) + __popcll(act.w[1]);
+    // self-collision (ShfModel.self_collide): capsule pairs, the active ones (<= SHF_MAX_SELF_CONTACTS, pair order) in the slots
+    // behind the contact-slot region; candidates after the sample points', in that order.  Lane k < nself speaks for self-contact k.
+    int nself = 0;
+    if constexpr (SELF) nself = self_contacts_eval<G>(C, L, l, CD::NPC, mu_shape);
+    if constexpr (SELF) GROUP_SYNC();
+    const float* sslot = L.pt + (CD::NPC + (l < nself ? l : 0)) * PT_STRIDE;
+    bool scand = SELF && l < nself;
+    const float sph = scand ? sslot[PT_F] : 0.0f;
+    const int npts = __popcll(act.w[0]) + __popcll(act.w[1]);
+    int total = npts + nself;
+    unsigned smask = nself >= 32 ? ~0u : ((1u << nself) - 1u);      // selected self-contacts of this env
     if (__ballot(total > kmax) != 0ull) {
-      // more candidates than the solve holds (somewhere in this wavefront): keep the kmax with the smallest gap, ties by slot
+      // more candidates than the solve holds (somewhere in this wavefront): keep the kmax with the smallest gap, ties by
+      // candidate order (slots, then self-contacts)
       float* phis = tail + T::PHI;
 #pragma unroll
       for (int k = 0; k < NR; k++)
         if (cand[k]) phis[l + k * G] = ph[k];
+      if (scand) phis[T::NEVP + l] = sph;
       GROUP_SYNC();
       if (total > kmax) {
 #pragma unroll
@@ -358,7 +439,21 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
               rank += (pj < ph[k] || (pj == ph[k] && j < s)) ? 1 : 0;
             }
           }
+          for (int j = 0; j < nself; j++) rank += phis[T::NEVP + j] < ph[k] ? 1 : 0;
           cand[k] = rank < kmax;
+        }
+        if (scand) {
+          int rank = 0;
+          for (int wd = 0; wd < 2; wd++) {
+            unsigned long long bits = act.w[wd];
+            while (bits) {
+              const int j = __builtin_ctzll(bits) + 64 * wd;
+              bits &= bits - 1ull;
+              rank += phis[j] <= sph ? 1 : 0;
+            }
+          }
+          for (int j = 0; j < nself; j++) { const float pj = phis[T::NEVP + j]; rank += (pj < sph || (pj == sph && j < l)) ? 1 : 0; }
+          scand = rank < kmax;
         }
         if (l == 0 && C.dropped) *C.dropped += total - kmax;
       }
@@ -368,10 +463,22 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
         const unsigned long long bits = (__ballot(cand[k]) >> lane0) & ((1ull << G) - 1ull);
         if (k * G < 64) act.w[0] |= bits << ((k * G) & 63); else act.w[1] |= bits << ((k * G - 64) & 63);
       }
+      smask = (unsigned)((__ballot(scand) >> lane0) & ((1ull << G) - 1ull));
       total = total > kmax ? kmax : total;
       GROUP_SYNC();
     }
     K = total;
+    const int nps = __popcll(act.w[0]) + __popcll(act.w[1]);        // selected sample points: the self-contacts follow them
+    if (SELF && scand) {
+      float* h = tail + T::HC + (nps + __popc(smask & ((1u << l) - 1u))) * HC_STRIDE;
+      const int pr = (int)sslot[PT_ON] - 1;
+      const int ba = m->cap_body[m->pair_a[pr]], bb = m->cap_body[m->pair_b[pr]];
+#pragma unroll
+      for (int j = 0; j < 3; j++) { h[HC_R + j] = sslot[PT_R + j]; h[HC_N + j] = sslot[PT_N + j]; }
+      h[HC_PHI] = sph; h[HC_MU] = sslot[PT_F + 1];
+      h[HC_BODY] = __int_as_float(m->dyn[ba]); h[HC_REP] = __int_as_float(ba);
+      h[HC_BODYB] = __int_as_float(m->dyn[bb]); h[HC_REPB] = __int_as_float(bb);
+    }
 #pragma unroll
     for (int k = 0; k < NR; k++) {
       if (!cand[k]) continue;
@@ -382,6 +489,7 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
       for (int j = 0; j < 3; j++) { h[HC_R + j] = r[k][j]; h[HC_N + j] = nn[k][j]; }
       h[HC_PHI] = ph[k]; h[HC_MU] = mu;
       h[HC_BODY] = __int_as_float(m->dyn[P.body[k]]); h[HC_REP] = __int_as_float(P.body[k]);
+      h[HC_BODYB] = __int_as_float(-1); h[HC_REPB] = __int_as_float(-1);
     }
   }
   GROUP_SYNC();
@@ -516,58 +624,33 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
       const bool col = l < 3 * K;
       const float* hj = tail + T::HC + (col ? j : 0) * HC_STRIDE;
       const float rj[3] = {hj[HC_R], hj[HC_R + 1], hj[HC_R + 2]};
-      const int bs = col ? __float_as_int(hj[HC_BODY]) : 0;
-      const int cs = bs > 0 ? (bs - 1) / (NLK + 1) : 0, ks = bs > 0 ? (bs - 1) % (NLK + 1) : -1;
+      const int bsa = col ? __float_as_int(hj[HC_BODY]) : 0;
+      const int bsb = (SELF && col) ? __float_as_int(hj[HC_BODYB]) : -1;
       const float e[3] = {ax == 0 ? 1.0f : 0.0f, ax == 1 ? 1.0f : 0.0f, ax == 2 ? 1.0f : 0.0f};
-      float p6[6], t[3], ub[NLK], dv0[6];
-      cross3(rj, e, t);
-#pragma unroll
-      for (int k = 0; k < 3; k++) { p6[k] = -t[k]; p6[3 + k] = -e[k]; }
-#pragma unroll
-      for (int k = NLK - 1; k >= 0; k--) {
-        ub[k] = 0.0f;
-        if (k <= ks) {
-          const int li = cs * NLK + k;
-          const float* rec = L.jrec + li * JREC_STRIDE;
-          const float* uf = tail + T::UF + li * UF_STRIDE;
-          float sp = rec[JREC_S] * p6[0];
-#pragma unroll
-          for (int q = 1; q < 6; q++) sp = fmaf(rec[JREC_S + q], p6[q], sp);
-          ub[k] = -sp;
-          const float tt = ub[k] * uf[6];
-#pragma unroll
-          for (int q = 0; q < 6; q++) p6[q] = fmaf(uf[q], tt, p6[q]);
-        }
+      HardResp<CD> qa, qb;
+      hard_impulse<CD>(L, tail, bsa, rj, e, qa);
+      if constexpr (SELF) {
+        if (__ballot(bsb >= 0) != 0ull) hard_impulse<CD>(L, tail, bsb >= 0 ? bsb : 0, rj, e, qb);
       }
-      root_factors_apply(L.xroot, p6, dv0);
       for (int i = 0; i < HCK; i++) {
         if (__ballot(i < K) == 0ull) break;
         if (!(col && i < K)) continue;
         const float* hi = tail + T::HC + i * HC_STRIDE;
         const float ri[3] = {hi[HC_R], hi[HC_R + 1], hi[HC_R + 2]};
-        const int bt = __float_as_int(hi[HC_BODY]);
-        const int ct = bt > 0 ? (bt - 1) / (NLK + 1) : 0, kt = bt > 0 ? (bt - 1) % (NLK + 1) : -1;
-        float dv[6], vel[3];
-#pragma unroll
-        for (int q = 0; q < 6; q++) dv[q] = dv0[q];
-#pragma unroll
-        for (int k = 0; k < NLK; k++) {
-          if (k <= kt) {
-            const int li = ct * NLK + k;
-            const float* rec = L.jrec + li * JREC_STRIDE;
-            const float* uf = tail + T::UF + li * UF_STRIDE;
-            const float ubk = (ct == cs && k <= ks) ? ub[k] : 0.0f;
-            float ua = uf[0] * dv[0];
-#pragma unroll
-            for (int q = 1; q < 6; q++) ua = fmaf(uf[q], dv[q], ua);
-            const float dq = (ubk - ua) * uf[6];
-#pragma unroll
-            for (int q = 0; q < 6; q++) dv[q] = fmaf(rec[JREC_S + q], dq, dv[q]);
+        const int bta = __float_as_int(hi[HC_BODY]);
+        float aa[3], ab[3] = {0.0f, 0.0f, 0.0f}, ba[3] = {0.0f, 0.0f, 0.0f}, bb[3] = {0.0f, 0.0f, 0.0f};
+        hard_velocity<CD>(L, tail, qa, bta, ri, aa);
+        if constexpr (SELF) {
+          const int btb = __float_as_int(hi[HC_BODYB]);
+          hard_velocity<CD>(L, tail, qa, btb, ri, ab);
+          if (bsb >= 0) {
+            hard_velocity<CD>(L, tail, qb, bta, ri, ba);
+            hard_velocity<CD>(L, tail, qb, btb, ri, bb);
           }
         }
-        hard_point(dv, ri, vel);
         float* Wb = tail + T::W + (j * HCK + i) * 9 + ax;   // block (i, j), column ax
-        Wb[0] = vel[0]; Wb[3] = vel[1]; Wb[6] = vel[2];
+#pragma unroll
+        for (int r = 0; r < 3; r++) Wb[3 * r] = (aa[r] - ab[r]) - (ba[r] - bb[r]);
       }
     }
     GROUP_SYNC();
@@ -584,13 +667,24 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
       const int b = own ? __float_as_int(h[HC_BODY]) : 0;
       const float* pb = L.pose + b * POSE_STRIDE + 12;
       const float* D = L.acc + b * 6;
-      float v[6], v6[6], vs[3], vf[3];
+      float v[6], v6[6], vs[3], vf[3], vsb[3] = {0.0f, 0.0f, 0.0f}, vfb[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int k = 0; k < 6; k++) { v[k] = pb[k]; v6[k] = fmaf(dt, D[k], v[k]); }
       hard_point(v, r, vs);
       hard_point(v6, r, vf);
+      if constexpr (SELF) {
+        const int b2 = own ? __float_as_int(h[HC_BODYB]) : -1;
+        if (b2 >= 0) {
+          const float* pb2 = L.pose + b2 * POSE_STRIDE + 12;
+          const float* D2 = L.acc + b2 * 6;
 #pragma unroll
-      for (int k = 0; k < 3; k++) O.u[k] = vf[k];
+          for (int k = 0; k < 6; k++) { v[k] = pb2[k]; v6[k] = fmaf(dt, D2[k], v[k]); }
+          hard_point(v, r, vsb);
+          hard_point(v6, r, vfb);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 3; k++) { O.u[k] = vf[k] - vfb[k]; vs[k] = vs[k] - vsb[k]; }
       const float phi = h[HC_PHI];
       const float erp = C.sp.erp > 0.0f ? C.sp.erp : 0.2f;
       float tg = phi >= 0.0f ? -(phi * idt) : rminf(erp * -(phi) * idt, C.sp.max_depen_vel);
@@ -759,9 +853,11 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
       float f[3] = {0.0f, 0.0f, 0.0f}, fw[3] = {0.0f, 0.0f, 0.0f};
       for (int c = 0; c < K; c++) {
         const float* h = tail + T::HC + c * HC_STRIDE;
-        const int rep = __float_as_int(h[HC_REP]);
+        const int rep = __float_as_int(h[HC_REP]), repb = __float_as_int(h[HC_REPB]);
         if (rep == myb) { f[0] += h[HC_P] * idt; f[1] += h[HC_P + 1] * idt; f[2] += h[HC_P + 2] * idt; }
         else if (last && rep == myb + 1) { fw[0] += h[HC_P] * idt; fw[1] += h[HC_P + 1] * idt; fw[2] += h[HC_P + 2] * idt; }
+        if (repb == myb) { f[0] -= h[HC_P] * idt; f[1] -= h[HC_P + 1] * idt; f[2] -= h[HC_P + 2] * idt; }
+        else if (last && repb == myb + 1) { fw[0] -= h[HC_P] * idt; fw[1] -= h[HC_P + 1] * idt; fw[2] -= h[HC_P + 2] * idt; }
       }
       contact_out[3 * myb] = f[0]; contact_out[3 * myb + 1] = f[1]; contact_out[3 * myb + 2] = f[2];
       if (last) { contact_out[3 * (myb + 1)] = fw[0]; contact_out[3 * (myb + 1) + 1] = fw[1]; contact_out[3 * (myb + 1) + 2] = fw[2]; }

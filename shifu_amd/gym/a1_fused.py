@@ -85,10 +85,10 @@ class FusedA1Env:
         if model_edit is not None:        # experiments: e.g. other joint damping / armature
             model_edit(self.cm)
         # solver: "pgs" = the velocity-level contact solve with the reference's PhysX settings (env_config.py:50-58;
-        # csrc/shf_chain_hard.h: chain mapping at 32 lanes per env, no self-collision) -- the default where it is built;
-        # "compliant" = rounds 1-4's spring-damper law (the default with self-collision or another lane mapping)
+        # csrc/shf_chain_hard.h: chain mapping at 32 lanes per env) -- the default where it is built;
+        # "compliant" = rounds 1-4's spring-damper law (the default on another lane mapping / width)
         if solver is None:
-            solver = "pgs" if (not self_collision and mapping in (None, "chain") and group in (None, 32)) else "compliant"
+            solver = "pgs" if (mapping in (None, "chain") and group in (None, 32)) else "compliant"
         self.solver = solver if sim_params is None else ("pgs" if sim_params.solver == _abi.SOLVER_PGS else "compliant")
         self.sim_params = sim_params or default_sim_params(dt=dt, solver=solver, **(solver_kw or {}))
         self.dt = dt * decimation                                         # isaac_gym.py:26

@@ -251,7 +251,7 @@ class Gym:
     # honoured since round 5 (ShfSimParams.solver = SHF_SOLVER_PGS, the velocity-level contact solve): solver_type (PGS and TGS
     # both map to the projected Gauss-Seidel solve -- TGS is PhysX's sub-stepped variant of it), num_position_iterations,
     # num_velocity_iterations, contact_offset, rest_offset, bounce_threshold_velocity, max_depenetration_velocity
-    # (shifu/configs/env_config.py:50-58).  Scenes the solve is not built for yet (box actors, self-collision, other tree
+    # (shifu/configs/env_config.py:50-58).  Scenes the solve is not built for yet (box actors, other tree
     # shapes) keep rounds 1-4's compliant law and say so once at prepare_sim.
     SOLVER_PHYSX_FIELDS = ("solver_type", "num_position_iterations", "num_velocity_iterations", "rest_offset", "bounce_threshold_velocity")
     _warned_physx = False
@@ -420,7 +420,7 @@ class Gym:
             import warnings
             warnings.warn("shifu_amd: this scene runs the compliant contact law of rounds 1-4 -- the velocity-level solve that honours "
                           "sim_params.physx." + " / ".join(Gym.SOLVER_PHYSX_FIELDS) + " is built for a single A1-shaped articulation "
-                          "without box actors or self-collision (csrc/shf_chain_hard.h)", stacklevel=2)
+                          "without box actors (csrc/shf_chain_hard.h)", stacklevel=2)
         sim.solver = "pgs" if pgs else "compliant"
         sp = default_sim_params(dt=p.dt, gravity=tuple(p.gravity),
                                 max_depen_vel=min(float(p.physx.max_depenetration_velocity), 10.0),

@@ -183,8 +183,8 @@ def test_create_sim_honours_the_physx_solver_settings_and_names_the_ignored_ones
 
 
 def test_pgs_support_query():
-    """shf_model_pgs_supported: the A1 on its own, without self-collision -- yes; with box actors, with self-collision, the
-    ABB arm -- no (the facade then keeps the compliant law and says so)."""
+    """shf_model_pgs_supported: the A1 on its own, with or without self-collision -- yes; with box actors, the ABB arm -- no
+    (the facade then keeps the compliant law and says so)."""
     import ctypes as C
     from shifu_amd._lib import lib
     from shifu_amd.abb_task import abb_model
@@ -193,7 +193,7 @@ def test_pgs_support_query():
     assert lib().shf_model_pgs_supported(C.byref(a1), 0) == 1
     assert lib().shf_model_pgs_supported(C.byref(a1), 1) == 0
     a1s = a1_model(self_collision=True).blob
-    assert lib().shf_model_pgs_supported(C.byref(a1s), 0) == 0
+    assert lib().shf_model_pgs_supported(C.byref(a1s), 0) == 1
     assert lib().shf_model_pgs_supported(C.byref(abb_model(link_contacts=False).blob), 0) == 0
 
 

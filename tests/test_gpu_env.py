@@ -95,6 +95,8 @@ def test_hook_env_matches_fused_env_through_resets(replayed):
     (spawn xy, command, push) are then copied into the hook env and the comparison goes on, bit for bit in state."""
     n = 64
     hook, fused = _envs(n)
+    # both run the reference's contact settings (env_config.py:50-58) through the velocity-level solve, self-collision on
+    assert hook.isg_env.sim.solver == "pgs" and fused.solver == "pgs" and fused.sim_params.pos_iters == 8 and fused.sim_params.vel_iters == 1
     if replayed:
         # ShifuVecEnv.enable_graph_hooks: the shape-static hooks replayed from two hipGraphs, reset_idx eager in between --
         # the same step, launched differently; held to the fused kernel exactly like the eager mode

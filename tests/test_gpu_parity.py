@@ -841,7 +841,7 @@ def test_ragged_env_counts(oracle, n, group):
     _compare(sim, task, bufs, f"n={n}")
 
 
-@pytest.mark.parametrize("kind", ["a1", "a1-chain", "abb-split", "abb-levels"])
+@pytest.mark.parametrize("kind", ["a1", "a1-chain", "a1-pgs", "abb-split", "abb-levels"])
 def test_random_action_step_matches_oracle_bitwise(oracle, kind):
     """shf_a1_step_random / shf_abb_step_random -- run_policy('random') with the U(-1, 1) actions drawn inside the launch
     (Philox4x32-10, counter = global env id, vec-step index, dof) -- against the oracle fed with the actions the oracle's
@@ -851,7 +851,8 @@ def test_random_action_step_matches_oracle_bitwise(oracle, kind):
     n, off = 21, 4096
     if kind.startswith("a1"):
         from shifu_amd.gym.a1_fused import FusedA1Env
-        env = FusedA1Env(num_envs=n, rank=1, world_size=2, seed=9, group=32, mapping="chain" if kind.endswith("chain") else "body")
+        solver = "pgs" if kind.endswith("pgs") else "compliant"
+        env = FusedA1Env(num_envs=n, rank=1, world_size=2, seed=9, group=32, mapping="body" if kind == "a1" else "chain", solver=solver)
         off = env.env_id_offset
         env.reset()
     else:
@@ -878,7 +879,7 @@ def test_random_action_step_matches_oracle_bitwise(oracle, kind):
         return
     # A1: two envs built alike -- one stepped with in-kernel actions, the other fed the oracle's actions through the
     # tensor entry point (itself held to the oracle by the tests above): identical tensors
-    ref = FusedA1Env(num_envs=n, rank=1, world_size=2, seed=9, group=32, mapping="body")
+    ref = FusedA1Env(num_envs=n, rank=1, world_size=2, seed=9, group=32, mapping="chain" if solver == "pgs" else "body", solver=solver)
     ref.reset()
     for it in range(25):
         step = env.task.step_index
@@ -1178,6 +1179,61 @@ def test_self_collision_matches_oracle_bitwise(oracle, group, dyn):
         assert task.kernel_symbol() == "_Z10k_a1_chainILi32ELb0ELb1EE"
     else:
         assert "self" in task.kernel_symbol() and ("DynDims" in task.kernel_symbol()) == dyn
+
+
+@pytest.mark.parametrize("selfc", [False, True])
+def test_velocity_level_solve_simulate_and_self_collision_match_oracle_bitwise(oracle, selfc):
+    """ShfSimParams.solver = SHF_SOLVER_PGS through gym.simulate (k_sim_step_chain_pgs: the hook path's sub-step) from thrown,
+    folded states with random efforts and pushes -- ground contacts and, with self-collision, capsule-pair constraints between
+    two bodies of the tree (impulses on both sides of the response matrix) -- then the fused step with self-collision on the
+    trimesh-free rough terrain: every tensor, bit for bit."""
+    _need_gpu()
+    from shifu_amd.model import asset_path, compile_urdf
+    cm = compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT, self_collision=selfc)
+    m = cm.blob
+    for d in range(m.nd):
+        m.damping[d] = 0.5
+    rng = np.random.default_rng(33)
+    sp = H.sim_params(angular_damping=0.5, solver="pgs")
+    n = 48
+    terr, hs = _terrain(rng, rough=True)
+    dof, root = _random_states(m, n, rng, z_lo=0.1, z_hi=0.5)
+    lo, up = np.array(m.lower[:m.nd]), np.array(m.upper[:m.nd])
+    dof[:, 0] = rng.uniform(lo, up, (n, m.nd)).astype(np.float32).reshape(-1)
+    dof[:, 1] = rng.uniform(-6, 6, n * m.nd)
+    fr = rng.uniform(0.5, 1.25, n).astype(np.float32)
+    sim = _make_sim(cm, sp, n, terr, hs, group=32)
+    T = sim.tensors
+    T[_abi.T_SIM_DOF].copy_(torch.from_numpy(dof))
+    T[_abi.T_SIM_ROOT].copy_(torch.from_numpy(root))
+    T[_abi.T_FRICTION].copy_(torch.from_numpy(fr))
+    hits = 0
+    for it in range(60):
+        eff = rng.uniform(-25, 25, n * m.nd).astype(np.float32)
+        push = np.zeros((n * m.nb, 3), np.float32)
+        push[::m.nb] = rng.uniform(-20, 20, (n, 3))
+        sim.set_dof_command(_abi.T_EFFORT, torch.from_numpy(eff).cuda())
+        sim.apply_body_force(torch.from_numpy(push).cuda())
+        sim.step()
+        sim.refresh(_abi.REFRESH_ALL)
+        contact, bstate = oracle.step(m, sp, n, dof, root, effort=eff, friction=fr, body_force=push, terrain=terr, heights=hs,
+                                      want_contact=True, want_body_state=True)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(T[_abi.T_DOF_STATE].cpu().numpy(), dof, err_msg=f"dof step {it}")
+        np.testing.assert_array_equal(T[_abi.T_ROOT_STATE].cpu().numpy(), root, err_msg=f"root step {it}")
+        np.testing.assert_array_equal(T[_abi.T_CONTACT].cpu().numpy(), contact, err_msg=f"contact step {it}")
+        hits += int((np.abs(contact).sum(1) > 0).sum())
+    assert hits > 500 and np.isfinite(root).all(), hits
+    sim.destroy()
+    if not selfc:
+        return
+    cm2, sp2, tp, terr, hs, bufs, sim, task, rng = _a1_setup(64, True, group="chain32", cm=cm, solver="pgs")
+    for it in range(60):
+        raw = (2 * rng.random((64, m.nd)) - 1).astype(np.float32) * 2.0
+        task.step(torch.from_numpy(raw).cuda())
+        oracle.a1_step(m, sp2, tp, 64, 0, bufs, raw, terrain=terr, heights=hs)
+        _compare(sim, task, bufs, f"fused self-collision step {it}")
+    assert task.kernel_symbol().startswith("_Z14k_a1_chain_pgsILb0ELb1E")
 
 
 def test_velocity_drive_matches_oracle_bitwise(oracle):
