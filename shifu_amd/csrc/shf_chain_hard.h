@@ -23,7 +23,8 @@
 #include "shf_chain.h"
 
 #define HCK 8           /* constraints one env's solve holds on this kernel (ShfSimParams.max_contacts <= HCK) */
-#define HC_STRIDE 16    /* r[3] n[3] phi mu body rep p[3] bodyb repb .  (bodyb / repb: the other side of a self-contact, else -1) */
+#define HC_STRIDE 24    /* r[3] n[3] phi mu body rep p[3] bodyb repb . t1[3] t2[3] . .  (bodyb / repb: the other side of a self-contact,
+                           else -1; p: the impulse after the position iterations in world axes; t1, t2: the tangents of the contact frame) */
 #define HC_R 0
 #define HC_N 3
 #define HC_PHI 6
@@ -33,11 +34,17 @@
 #define HC_P 10
 #define HC_BODYB 13
 #define HC_REPB 14
+#define HC_T1 16
+#define HC_T2 19
+#define HC_PV0 15       /* the impulse after the velocity iterations, world axes (three spare words) */
+#define HC_PV1 22
+#define HC_PV2 23
 #define UF_STRIDE 8     /* U[6] invD . per link */
 template <class CD>
 struct HardTail {
-  static constexpr int HC = 0, W = HCK * HC_STRIDE, UF = W + HCK * HCK * 9, PHI = UF + CD::ND * UF_STRIDE, NEVP = (CD::NEV + 3) & ~3,
-                       END = PHI + NEVP + SHF_MAX_SELF_CONTACTS;
+  // (PHI: the candidates' gaps while the deepest are selected -- before W exists, in its place)
+  static constexpr int HC = 0, W = HCK * HC_STRIDE, UF = W + HCK * HCK * 9, PHI = W, NEVP = (CD::NEV + 3) & ~3, END = UF + CD::ND * UF_STRIDE;
+  static_assert(NEVP + SHF_MAX_SELF_CONTACTS <= HCK * HCK * 9, "the gaps fit the response matrix's place");
 };
 
 // point velocity of the spatial velocity v6 (about O) at r
@@ -46,6 +53,21 @@ DEV void hard_point(const float* v6, const float* r, float* o) {
   cross3(v6, r, t);
 #pragma unroll
   for (int k = 0; k < 3; k++) o[k] = v6[3 + k] + t[k];
+}
+DEV float hard_readlane(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
+// the tangents of a contact frame: t1 = (x or y) cross n normalised -- x unless n leans on it; t2 = n cross t1 (oracle: hard_solve)
+DEV void hard_frame(const float* n, float* t1, float* t2) {
+  float t[3];
+  if (fabsf(n[0]) < 0.7f) { t[0] = 0.0f; t[1] = -n[2]; t[2] = n[1]; }
+  else { t[0] = n[2]; t[1] = 0.0f; t[2] = -n[0]; }
+  const float il = rsqrt_spec(dot3(t, t));
+  float a[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) a[k] = t[k] * il;
+  float b[3];
+  cross3(n, a, b);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { t1[k] = a[k]; t2[k] = b[k]; }
 }
 DEV void mat3_inv_spd(const float* A, float* Ai) {
   const float c00 = fmaf(A[4], A[8], -(A[5] * A[7])), c01 = fmaf(A[5], A[6], -(A[3] * A[8])), c02 = fmaf(A[3], A[7], -(A[4] * A[6]));
@@ -84,6 +106,20 @@ DEV void root_factors_apply(const float* o, const float* pA, float* x) {   // ld
   }
 }
 
+// The link record of the solve (the joint record once the free outward pass is through with it, JREC_STRIDE words, 16-byte
+// aligned): S[6] U[6] 1/D -- four 16-byte LDS reads.
+#define LREC_U 6
+#define LREC_INVD 12
+struct HardLink { float S[6], U[6], invD; };
+DEV HardLink hard_link_load(const float* rec) {
+  const float4* r4 = reinterpret_cast<const float4*>(rec);
+  const float4 a = r4[0], b = r4[1], c = r4[2], d = r4[3];
+  HardLink K;
+  K.S[0] = a.x; K.S[1] = a.y; K.S[2] = a.z; K.S[3] = a.w; K.S[4] = b.x; K.S[5] = b.y;
+  K.U[0] = b.z; K.U[1] = b.w; K.U[2] = c.x; K.U[3] = c.y; K.U[4] = c.z; K.U[5] = c.w;
+  K.invD = d.x;
+  return K;
+}
 // Response of the articulation to the impulse e at r on its moving body bs (0: the root): the root's velocity change and the
 // joint terms of the links on bs's chain up to bs (oracle: hc_impulse) ...
 template <class CD>
@@ -102,16 +138,14 @@ DEV void hard_impulse(const ChainLds& L, const float* tail, int bs, const float*
   for (int k = NLK - 1; k >= 0; k--) {
     q.ub[k] = 0.0f;
     if (k <= q.ks) {
-      const int li = q.cs * NLK + k;
-      const float* rec = L.jrec + li * JREC_STRIDE;
-      const float* uf = tail + T::UF + li * UF_STRIDE;
-      float sp = rec[JREC_S] * p6[0];
+      const HardLink Lk = hard_link_load(L.jrec + (q.cs * NLK + k) * JREC_STRIDE);
+      float sp = Lk.S[0] * p6[0];
 #pragma unroll
-      for (int j = 1; j < 6; j++) sp = fmaf(rec[JREC_S + j], p6[j], sp);
+      for (int j = 1; j < 6; j++) sp = fmaf(Lk.S[j], p6[j], sp);
       q.ub[k] = -sp;
-      const float tt = q.ub[k] * uf[6];
+      const float tt = q.ub[k] * Lk.invD;
 #pragma unroll
-      for (int j = 0; j < 6; j++) p6[j] = fmaf(uf[j], tt, p6[j]);
+      for (int j = 0; j < 6; j++) p6[j] = fmaf(Lk.U[j], tt, p6[j]);
     }
   }
   root_factors_apply(L.xroot, p6, q.dv0);
@@ -129,116 +163,141 @@ DEV void hard_velocity(const ChainLds& L, const float* tail, const HardResp<CD>&
 #pragma unroll
   for (int k = 0; k < NLK; k++) {
     if (k <= kt) {
-      const int li = ct * NLK + k;
-      const float* rec = L.jrec + li * JREC_STRIDE;
-      const float* uf = tail + T::UF + li * UF_STRIDE;
+      const HardLink Lk = hard_link_load(L.jrec + (ct * NLK + k) * JREC_STRIDE);
       const float ubk = (ct == q.cs && k <= q.ks) ? q.ub[k] : 0.0f;
-      float ua = uf[0] * dv[0];
+      float ua = Lk.U[0] * dv[0];
 #pragma unroll
-      for (int j = 1; j < 6; j++) ua = fmaf(uf[j], dv[j], ua);
-      const float dq = (ubk - ua) * uf[6];
+      for (int j = 1; j < 6; j++) ua = fmaf(Lk.U[j], dv[j], ua);
+      const float dq = (ubk - ua) * Lk.invD;
 #pragma unroll
-      for (int j = 0; j < 6; j++) dv[j] = fmaf(rec[JREC_S + j], dq, dv[j]);
+      for (int j = 0; j < 6; j++) dv[j] = fmaf(Lk.S[j], dq, dv[j]);
     }
   }
   hard_point(dv, r, vel);
 }
 
 // Per-lane state of the solve that outlives a phase.
-struct HardOwner {     // the owner lane of contact c
-  float n[3], mu, u[3], p[3], tgt, tgt_v, Wn[3], iwnn, Ti[9], rt;
+struct HardOwner {     // the owner lane of contact c; velocity u and impulse p in the contact frame (n, t1, t2)
+  float mu, u[3], p[3], tgt, tgt_v, w10, w20, iwnn, Ti[3], rt;
 };
 
-// H4: the impulses in the constraint records as forces on their bodies -> what they add to the accelerations: joint
-// accelerations to dofb[.][slot], the root's to `ac0` (root lane).  oracle: hc_apply.
-template <class CD>
+// H4: the impulses in the constraint records as forces on their bodies -> what they add to the accelerations.  Both
+// impulse sets in one pass through the tree: q = 0 the impulses after the position iterations (HC_P), q = 1 after the
+// velocity iterations (HC_PV; NQ = 1: there are none) -- joint accelerations to dofb[.][2 + q], the root's to ac0[q]
+// (root lane).  Per set the operations of the oracle's hc_apply.
+template <class CD, int NQ>
 DEV void chain_hard_apply(const ShfModel* m, const ChainLds& L, float* tail, int l, int K, float idt, bool isbody_h0, bool islink, bool isroot,
-                          bool ischain, int ci, int lb, int myb, int slot, float* ac0) {
+                          bool ischain, int ci, int lb, int myb, float (*ac0)[6]) {
   constexpr int NCH = CD::NCH, NLK = CD::NLK;
   typedef HardTail<CD> T;
-  float pcr[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  float pcr[NQ][6];
+#pragma unroll
+  for (int q = 0; q < NQ; q++)
+#pragma unroll
+    for (int j = 0; j < 6; j++) pcr[q][j] = 0.0f;
   if (isbody_h0) {
     for (int c = 0; c < K; c++) {
       const float* h = tail + T::HC + c * HC_STRIDE;
       const bool ona = __float_as_int(h[HC_BODY]) == myb, onb = __float_as_int(h[HC_BODYB]) == myb;
       if (!ona && !onb) continue;
       const float r[3] = {h[HC_R], h[HC_R + 1], h[HC_R + 2]};
-      const float f[3] = {h[HC_P] * idt, h[HC_P + 1] * idt, h[HC_P + 2] * idt};
-      float t[3];
-      cross3(r, f, t);
-      if (ona) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) { pcr[k] -= t[k]; pcr[3 + k] -= f[k]; }
-      } else {
+      for (int q = 0; q < NQ; q++) {
+        const float f[3] = {h[q == 0 ? HC_P : HC_PV0] * idt, h[q == 0 ? HC_P + 1 : HC_PV1] * idt, h[q == 0 ? HC_P + 2 : HC_PV2] * idt};
+        float t[3];
+        cross3(r, f, t);
+        if (ona) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) { pcr[k] += t[k]; pcr[3 + k] += f[k]; }
+          for (int k = 0; k < 3; k++) { pcr[q][k] -= t[k]; pcr[q][3 + k] -= f[k]; }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 3; k++) { pcr[q][k] += t[k]; pcr[q][3 + k] += f[k]; }
+        }
       }
     }
     if (islink) {
-      float* o = L.xch + lb * XCH_STRIDE + 21;
+      // (the exchange slot's inertia words are free by now: set 0 in the bias words 21-26, set 1 in words 8-13)
+      float* o = L.xch + lb * XCH_STRIDE;
 #pragma unroll
-      for (int j = 0; j < 6; j++) o[j] = pcr[j];
+      for (int q = 0; q < NQ; q++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) o[(q == 0 ? 21 : 8) + j] = pcr[q][j];
     }
   }
   GROUP_SYNC();
-  float ucl[NLK];
+  float ucl[NQ][NLK];
   if (ischain) {
-    float pl[6];
+    float pl[NQ][6];
 #pragma unroll
     for (int k = NLK - 1; k >= 0; k--) {
       const int li = ci * NLK + k;
-      const float* o = L.xch + li * XCH_STRIDE + 21;
-      const float* rec = L.jrec + li * JREC_STRIDE;
-      const float* uf = tail + T::UF + li * UF_STRIDE;
-      if (k == NLK - 1) {
+      const float* o = L.xch + li * XCH_STRIDE;
+      const HardLink Lk = hard_link_load(L.jrec + li * JREC_STRIDE);
+      const float* S = Lk.S; const float* U = Lk.U;
+      const float invD = Lk.invD;
 #pragma unroll
-        for (int j = 0; j < 6; j++) pl[j] = o[j];
-      } else {
+      for (int q = 0; q < NQ; q++) {
+        if (k == NLK - 1) {
 #pragma unroll
-        for (int j = 0; j < 6; j++) pl[j] = o[j] + pl[j];
+          for (int j = 0; j < 6; j++) pl[q][j] = o[(q == 0 ? 21 : 8) + j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 6; j++) pl[q][j] = o[(q == 0 ? 21 : 8) + j] + pl[q][j];
+        }
+        float sp = S[0] * pl[q][0];
+#pragma unroll
+        for (int j = 1; j < 6; j++) sp = fmaf(S[j], pl[q][j], sp);
+        ucl[q][k] = -sp;
+        const float tt = ucl[q][k] * invD;
+#pragma unroll
+        for (int j = 0; j < 6; j++) pl[q][j] = fmaf(U[j], tt, pl[q][j]);
       }
-      float sp = rec[JREC_S] * pl[0];
-#pragma unroll
-      for (int j = 1; j < 6; j++) sp = fmaf(rec[JREC_S + j], pl[j], sp);
-      ucl[k] = -sp;
-      const float tt = ucl[k] * uf[6];
-#pragma unroll
-      for (int j = 0; j < 6; j++) pl[j] = fmaf(uf[j], tt, pl[j]);
     }
-    float* o = L.xch + (ci * NLK) * XCH_STRIDE + 21;
+    float* o = L.xch + (ci * NLK) * XCH_STRIDE;
 #pragma unroll
-    for (int j = 0; j < 6; j++) o[j] = pl[j];
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+      for (int j = 0; j < 6; j++) o[(q == 0 ? 21 : 8) + j] = pl[q][j];
   }
   GROUP_SYNC();
   if (isroot) {
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
-      float v = pcr[j];
+    for (int q = 0; q < NQ; q++) {
 #pragma unroll
-      for (int c = 0; c < NCH; c++) v += L.xch[(c * NLK) * XCH_STRIDE + 21 + j];
-      pcr[j] = v;
+      for (int j = 0; j < 6; j++) {
+        float v = pcr[q][j];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) v += L.xch[(c * NLK) * XCH_STRIDE + (q == 0 ? 21 : 8) + j];
+        pcr[q][j] = v;
+      }
+      root_factors_apply(L.xroot, pcr[q], ac0[q]);
+#pragma unroll
+      for (int j = 0; j < 6; j++) L.acc[6 * q + j] = ac0[q][j];
     }
-    root_factors_apply(L.xroot, pcr, ac0);
-#pragma unroll
-    for (int j = 0; j < 6; j++) L.acc[j] = ac0[j];
   }
   GROUP_SYNC();
   if (ischain) {
-    float ac[6];
+    float ac[NQ][6];
 #pragma unroll
-    for (int j = 0; j < 6; j++) ac[j] = L.acc[j];
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+      for (int j = 0; j < 6; j++) ac[q][j] = L.acc[6 * q + j];
 #pragma unroll
     for (int k = 0; k < NLK; k++) {
       const int li = ci * NLK + k;
-      const float* rec = L.jrec + li * JREC_STRIDE;
-      const float* uf = tail + T::UF + li * UF_STRIDE;
-      float ua = uf[0] * ac[0];
+      const HardLink Lk = hard_link_load(L.jrec + li * JREC_STRIDE);
+      const float* S = Lk.S; const float* U = Lk.U;
+      const float invD = Lk.invD;
 #pragma unroll
-      for (int j = 1; j < 6; j++) ua = fmaf(uf[j], ac[j], ua);
-      const float qc = (ucl[k] - ua) * uf[6];
+      for (int q = 0; q < NQ; q++) {
+        float ua = U[0] * ac[q][0];
 #pragma unroll
-      for (int j = 0; j < 6; j++) ac[j] = fmaf(rec[JREC_S + j], qc, ac[j]);
-      L.dofb[li * DOF_STRIDE + slot] = qc;
+        for (int j = 1; j < 6; j++) ua = fmaf(U[j], ac[q][j], ua);
+        const float qc = (ucl[q][k] - ua) * invD;
+#pragma unroll
+        for (int j = 0; j < 6; j++) ac[q][j] = fmaf(S[j], qc, ac[q][j]);
+        L.dofb[li * DOF_STRIDE + 2 + q] = qc;
+      }
     }
   }
   GROUP_SYNC();
@@ -478,6 +537,8 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
       h[HC_PHI] = sph; h[HC_MU] = sslot[PT_F + 1];
       h[HC_BODY] = __int_as_float(m->dyn[ba]); h[HC_REP] = __int_as_float(ba);
       h[HC_BODYB] = __int_as_float(m->dyn[bb]); h[HC_REPB] = __int_as_float(bb);
+      const float ns[3] = {sslot[PT_N], sslot[PT_N + 1], sslot[PT_N + 2]};
+      hard_frame(ns, h + HC_T1, h + HC_T2);
     }
 #pragma unroll
     for (int k = 0; k < NR; k++) {
@@ -490,6 +551,7 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
       h[HC_PHI] = ph[k]; h[HC_MU] = mu;
       h[HC_BODY] = __int_as_float(m->dyn[P.body[k]]); h[HC_REP] = __int_as_float(P.body[k]);
       h[HC_BODYB] = __int_as_float(-1); h[HC_REPB] = __int_as_float(-1);
+      hard_frame(nn[k], h + HC_T1, h + HC_T2);
     }
   }
   GROUP_SYNC();
@@ -609,13 +671,18 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
 #pragma unroll
       for (int j = 0; j < 6; j++) { ap[j] = fmaf(Sk[j], qdd, ap[j]); dl[j] = fmaf(Sk[j], qdd, dl[j]); o[j] = dl[j]; }
       L.dofb[li * DOF_STRIDE + 4] = qdd;
+      // the joint record becomes the solve's link record: U and 1/D take the place of the velocity-product term and the efforts
+      float* recw = L.jrec + li * JREC_STRIDE;
+#pragma unroll
+      for (int j = 0; j < 6; j++) recw[LREC_U + j] = uf[j];
+      recw[LREC_INVD] = uf[6];
     }
   }
   GROUP_SYNC();
   PHASE_MARK(8);
 
   // ---- H. the contact solve.  Loops over contacts run while any env of the wavefront has one left (wave-uniform bounds)
-  float ac0p[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, ac0v[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  float ac0[2][6] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};   // the contacts' share of the root's acceleration: poses / velocities
   const int npos = C.sp.pos_iters > 0 ? C.sp.pos_iters : 0, nvel = C.sp.vel_iters > 0 ? C.sp.vel_iters : 0;
   if (__ballot(K > 0) != 0ull) {
     // H1. column lanes: contact j = l / 3, axis l % 3
@@ -626,7 +693,8 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
       const float rj[3] = {hj[HC_R], hj[HC_R + 1], hj[HC_R + 2]};
       const int bsa = col ? __float_as_int(hj[HC_BODY]) : 0;
       const int bsb = (SELF && col) ? __float_as_int(hj[HC_BODYB]) : -1;
-      const float e[3] = {ax == 0 ? 1.0f : 0.0f, ax == 1 ? 1.0f : 0.0f, ax == 2 ? 1.0f : 0.0f};
+      const float* ej = hj + (ax == 0 ? HC_N : (ax == 1 ? HC_T1 : HC_T2));     // axis ax of contact j's frame
+      const float e[3] = {ej[0], ej[1], ej[2]};
       HardResp<CD> qa, qb;
       hard_impulse<CD>(L, tail, bsa, rj, e, qa);
       if constexpr (SELF) {
@@ -648,21 +716,25 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
             hard_velocity<CD>(L, tail, qb, btb, ri, bb);
           }
         }
-        float* Wb = tail + T::W + (j * HCK + i) * 9 + ax;   // block (i, j), column ax
+        float vw[3];
 #pragma unroll
-        for (int r = 0; r < 3; r++) Wb[3 * r] = (aa[r] - ab[r]) - (ba[r] - bb[r]);
+        for (int r = 0; r < 3; r++) vw[r] = (aa[r] - ab[r]) - (ba[r] - bb[r]);
+        float* Wb = tail + T::W + (j * HCK + i) * 9 + ax;   // block (i, j), column ax: the velocity in contact i's frame
+        Wb[0] = dot3(hi + HC_N, vw); Wb[3] = dot3(hi + HC_T1, vw); Wb[6] = dot3(hi + HC_T2, vw);
       }
     }
     GROUP_SYNC();
+    PHASE_MARK(5);
 
-    // H2. owner lanes: free velocity, targets, the regularised diagonal block and its inverses
+    // H2. owner lanes: free velocity (contact frame), targets, the regularised diagonal block and its inverses
     HardOwner O;
     const bool own = l < K;
     {
       const float* h = tail + T::HC + (own ? l : 0) * HC_STRIDE;
       const float r[3] = {h[HC_R], h[HC_R + 1], h[HC_R + 2]};
+      const float n[3] = {h[HC_N], h[HC_N + 1], h[HC_N + 2]};
 #pragma unroll
-      for (int k = 0; k < 3; k++) { O.n[k] = h[HC_N + k]; O.p[k] = 0.0f; }
+      for (int k = 0; k < 3; k++) O.p[k] = 0.0f;
       O.mu = h[HC_MU];
       const int b = own ? __float_as_int(h[HC_BODY]) : 0;
       const float* pb = L.pose + b * POSE_STRIDE + 12;
@@ -684,12 +756,13 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
         }
       }
 #pragma unroll
-      for (int k = 0; k < 3; k++) { O.u[k] = vf[k] - vfb[k]; vs[k] = vs[k] - vsb[k]; }
+      for (int k = 0; k < 3; k++) { vf[k] = vf[k] - vfb[k]; vs[k] = vs[k] - vsb[k]; }
+      O.u[0] = dot3(n, vf); O.u[1] = dot3(h + HC_T1, vf); O.u[2] = dot3(h + HC_T2, vf);
       const float phi = h[HC_PHI];
       const float erp = C.sp.erp > 0.0f ? C.sp.erp : 0.2f;
       float tg = phi >= 0.0f ? -(phi * idt) : rminf(erp * -(phi) * idt, C.sp.max_depen_vel);
       float tv = phi >= 0.0f ? tg : 0.0f;
-      const float vn0 = dot3(O.n, vs);
+      const float vn0 = dot3(n, vs);
       if (C.sp.restitution > 0.0f && vn0 < -C.sp.bounce_threshold) { tg = rmaxf(tg, -(C.sp.restitution * vn0)); tv = rmaxf(tv, -(C.sp.restitution * vn0)); }
       O.tgt = tg; O.tgt_v = tv;
       float* Wd = tail + T::W + ((own ? l : 0) * HCK + (own ? l : 0)) * 9;
@@ -704,85 +777,79 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
 #pragma unroll
         for (int k = 0; k < 9; k++) Wd[k] = A[k];
       }
-      mv3(A, O.n, O.Wn);
-      O.iwnn = rcp_spec(dot3(O.n, O.Wn));
-      float PW[9], B[9];
-#pragma unroll
-      for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-        for (int q = 0; q < 3; q++) PW[3 * rr + q] = fmaf(-O.n[rr], O.Wn[q], A[3 * rr + q]);
-#pragma unroll
-      for (int rr = 0; rr < 3; rr++) {
-        const float pwn = dot3(PW + 3 * rr, O.n);
-#pragma unroll
-        for (int q = 0; q < 3; q++) B[3 * rr + q] = fmaf(O.n[rr], O.n[q], fmaf(-pwn, O.n[q], PW[3 * rr + q]));
-      }
-      const float b01 = 0.5f * (B[1] + B[3]), b02 = 0.5f * (B[2] + B[6]), b12 = 0.5f * (B[5] + B[7]);
-      B[1] = b01; B[3] = b01; B[2] = b02; B[6] = b02; B[5] = b12; B[7] = b12;
-      mat3_inv_spd(B, O.Ti);
-      O.rt = rcp_spec(((B[0] + B[4]) + B[8]) - 1.0f);
+      O.iwnn = rcp_spec(A[0]);
+      O.w10 = A[3]; O.w20 = A[6];
+      const float id = rcp_spec(fmaf(A[4], A[8], -(A[5] * A[5])));
+      O.Ti[0] = A[8] * id; O.Ti[1] = -(A[5] * id); O.Ti[2] = A[4] * id;
+      O.rt = rcp_spec(A[4] + A[8]);
     }
     GROUP_SYNC();
+    PHASE_MARK(10);
 
     // H3 / H4. position iterations -> poses; velocity iterations -> velocities
+    int Kw = 0;      // the larger constraint count of the wavefront's envs (wave-uniform)
+#pragma unroll
+    for (int c = 0; c < HCK; c++)
+      if (__ballot(c < K) != 0ull) Kw = c + 1;
+    const bool hi = lane0 != 0;
+    const float* Wcol = tail + T::W + (own ? l : 0) * 9;     // block (l, c) sits at Wcol + c * HCK * 9
 #pragma unroll 1
     for (int phase = 0; phase < 2; phase++) {
       const int sweeps = phase == 0 ? npos : nvel;
       const float tg = phase == 0 ? O.tgt : O.tgt_v;
 #pragma unroll 1
       for (int it = 0; it < sweeps; it++) {
-#pragma unroll 1
+#pragma unroll
         for (int c = 0; c < HCK; c++) {
-          if (__ballot(c < K) == 0ull) break;
-          // every owner lane computes its own update; lane c's is the one that counts
-          const float pn0 = dot3(O.n, O.p);
-          const float pn = rmaxf(fmaf(-(dot3(O.n, O.u) - tg), O.iwnn, pn0), 0.0f);
+          if (c >= Kw) break;
+          // this lane's block of column c: in flight while the update is computed
+          float Wb[9];
+#pragma unroll
+          for (int k = 0; k < 9; k++) Wb[k] = Wcol[c * HCK * 9 + k];
+          // every owner lane computes its own update; lane c's is the one that counts (oracle: hard_solve, sweeps)
+          const float pn0 = O.p[0];
+          const float pn = rmaxf(fmaf(-(O.u[0] - tg), O.iwnn, pn0), 0.0f);
           const float dn = pn - pn0;
-          float un3[3], ut[3], pt[3], ps[3];
-#pragma unroll
-          for (int r = 0; r < 3; r++) un3[r] = fmaf(dn, O.Wn[r], O.u[r]);
-          const float un = dot3(O.n, un3);
-#pragma unroll
-          for (int r = 0; r < 3; r++) { ut[r] = fmaf(-un, O.n[r], un3[r]); pt[r] = fmaf(-pn0, O.n[r], O.p[r]); }
-#pragma unroll
-          for (int r = 0; r < 3; r++) ps[r] = pt[r] - fmaf(O.Ti[3 * r + 2], ut[2], fmaf(O.Ti[3 * r + 1], ut[1], O.Ti[3 * r] * ut[0]));
-          const float lim = O.mu * pn;
-          if (dot3(ps, ps) > lim * lim) {
-#pragma unroll
-            for (int r = 0; r < 3; r++) ps[r] = fmaf(-O.rt, ut[r], pt[r]);
-            const float nt2 = dot3(ps, ps);
-            const float sc1 = nt2 > lim * lim ? lim * rsqrt_spec(nt2) : 1.0f;
-#pragma unroll
-            for (int r = 0; r < 3; r++) ps[r] *= sc1;
+          const float ut1 = fmaf(dn, O.w10, O.u[1]), ut2 = fmaf(dn, O.w20, O.u[2]);
+          float ps1 = O.p[1] - fmaf(O.Ti[1], ut2, O.Ti[0] * ut1), ps2 = O.p[2] - fmaf(O.Ti[2], ut2, O.Ti[1] * ut1);
+          const float lim = O.mu * pn, lim2 = lim * lim;
+          if (fmaf(ps2, ps2, ps1 * ps1) > lim2) {
+            ps1 = fmaf(-O.rt, ut1, O.p[1]); ps2 = fmaf(-O.rt, ut2, O.p[2]);
+            const float nt2 = fmaf(ps2, ps2, ps1 * ps1);
+            const float sc1 = nt2 > lim2 ? lim * rsqrt_spec(nt2) : 1.0f;
+            ps1 *= sc1; ps2 *= sc1;
           }
           const bool commit = l == c && c < K;
-          float dp[3];
-#pragma unroll
-          for (int r = 0; r < 3; r++) {
-            const float pnew = fmaf(pn, O.n[r], ps[r]);
-            dp[r] = commit ? pnew - O.p[r] : 0.0f;
-            if (commit) O.p[r] = pnew;
+          float dp0 = dn, dp1 = ps1 - O.p[1], dp2 = ps2 - O.p[2];
+          if (commit) { O.p[0] = pn; O.p[1] = ps1; O.p[2] = ps2; }
+          // the change of contact c's impulse, from its owner lane (lane c of each env: wave lanes c and 32 + c) to every lane
+          {
+            const float a0 = hard_readlane(dp0, c), a1 = hard_readlane(dp1, c), a2 = hard_readlane(dp2, c);
+            const float b0 = hard_readlane(dp0, 32 + c), b1 = hard_readlane(dp1, 32 + c), b2 = hard_readlane(dp2, 32 + c);
+            dp0 = hi ? b0 : a0; dp1 = hi ? b1 : a1; dp2 = hi ? b2 : a2;
           }
-          // the change of contact c's impulse, from its owner lane to every lane of the env
-#pragma unroll
-          for (int r = 0; r < 3; r++) dp[r] = __shfl(dp[r], lane0 + c);
           if (own && c < K) {
-            const float* Wb = tail + T::W + (c * HCK + l) * 9;   // block (l, c)
 #pragma unroll
-            for (int r = 0; r < 3; r++) O.u[r] = fmaf(Wb[3 * r + 2], dp[2], fmaf(Wb[3 * r + 1], dp[1], fmaf(Wb[3 * r], dp[0], O.u[r])));
+            for (int r = 0; r < 3; r++) O.u[r] = fmaf(Wb[3 * r + 2], dp2, fmaf(Wb[3 * r + 1], dp1, fmaf(Wb[3 * r], dp0, O.u[r])));
           }
         }
       }
       if (phase == 1 && nvel == 0) break;
       if (own) {
+        // the impulses of this phase in world axes, for the pass through the tree
         float* h = tail + T::HC + l * HC_STRIDE;
+        float pw[3];
 #pragma unroll
-        for (int r = 0; r < 3; r++) h[HC_P + r] = O.p[r];
+        for (int r = 0; r < 3; r++) pw[r] = fmaf(O.p[2], h[HC_T2 + r], fmaf(O.p[1], h[HC_T1 + r], O.p[0] * h[HC_N + r]));
+        if (phase == 0) { h[HC_P] = pw[0]; h[HC_P + 1] = pw[1]; h[HC_P + 2] = pw[2]; }
+        else { h[HC_PV0] = pw[0]; h[HC_PV1] = pw[1]; h[HC_PV2] = pw[2]; }
       }
-      GROUP_SYNC();
-      chain_hard_apply<CD>(m, L, tail, l, K, idt, isbody && half == 0, islink, isroot, ischain, ci, lb, myb, phase == 0 ? 2 : 3,
-                           phase == 0 ? ac0p : ac0v);
     }
+    PHASE_MARK(17);
+    GROUP_SYNC();
+    if (nvel > 0) chain_hard_apply<CD, 2>(m, L, tail, l, K, idt, isbody && half == 0, islink, isroot, ischain, ci, lb, myb, ac0);
+    else chain_hard_apply<CD, 1>(m, L, tail, l, K, idt, isbody && half == 0, islink, isroot, ischain, ci, lb, myb, ac0);
+    PHASE_MARK(18);
   } else {
     if (isdof) { L.dofb[l * DOF_STRIDE + 2] = 0.0f; L.dofb[l * DOF_STRIDE + 3] = 0.0f; }
   }
@@ -804,9 +871,9 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
     float av[6], apz[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-      const float cv = nvel > 0 ? ac0v[j] : ac0p[j];
+      const float cv = nvel > 0 ? ac0[1][j] : ac0[0][j];
       av[j] = K > 0 ? a0[j] + cv : a0[j];
-      apz[j] = K > 0 ? a0[j] + ac0p[j] : a0[j];
+      apz[j] = K > 0 ? a0[j] + ac0[0][j] : a0[j];
     }
     float* Rt = L.root;
     float ang[3] = {Rt[10], Rt[11], Rt[12]}, lin[3] = {Rt[7], Rt[8], Rt[9]}, wxv[3];
@@ -854,10 +921,11 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
       for (int c = 0; c < K; c++) {
         const float* h = tail + T::HC + c * HC_STRIDE;
         const int rep = __float_as_int(h[HC_REP]), repb = __float_as_int(h[HC_REPB]);
-        if (rep == myb) { f[0] += h[HC_P] * idt; f[1] += h[HC_P + 1] * idt; f[2] += h[HC_P + 2] * idt; }
-        else if (last && rep == myb + 1) { fw[0] += h[HC_P] * idt; fw[1] += h[HC_P + 1] * idt; fw[2] += h[HC_P + 2] * idt; }
-        if (repb == myb) { f[0] -= h[HC_P] * idt; f[1] -= h[HC_P + 1] * idt; f[2] -= h[HC_P + 2] * idt; }
-        else if (last && repb == myb + 1) { fw[0] -= h[HC_P] * idt; fw[1] -= h[HC_P + 1] * idt; fw[2] -= h[HC_P + 2] * idt; }
+        const float pf[3] = {(nvel > 0 ? h[HC_PV0] : h[HC_P]) * idt, (nvel > 0 ? h[HC_PV1] : h[HC_P + 1]) * idt, (nvel > 0 ? h[HC_PV2] : h[HC_P + 2]) * idt};
+        if (rep == myb) { f[0] += pf[0]; f[1] += pf[1]; f[2] += pf[2]; }
+        else if (last && rep == myb + 1) { fw[0] += pf[0]; fw[1] += pf[1]; fw[2] += pf[2]; }
+        if (repb == myb) { f[0] -= pf[0]; f[1] -= pf[1]; f[2] -= pf[2]; }
+        else if (last && repb == myb + 1) { fw[0] -= pf[0]; fw[1] -= pf[1]; fw[2] -= pf[2]; }
       }
       contact_out[3 * myb] = f[0]; contact_out[3 * myb + 1] = f[1]; contact_out[3 * myb + 2] = f[2];
       if (last) { contact_out[3 * (myb + 1)] = fw[0]; contact_out[3 * (myb + 1) + 1] = fw[1]; contact_out[3 * (myb + 1) + 2] = fw[2]; }

@@ -35,7 +35,10 @@ def main():
     levels = "--levels" in sys.argv   # --abb: the level-by-level sub-step instead of the arm's recursions on one lane
     split = "--split" in sys.argv     # --abb: arm and boxes on different waves (k_abb_step_ws); marks 24-29 are the arm wave's
     link = "--link" in sys.argv       # --abb: with link contacts (the run-time-shaped kernel)
-    argv = [a for a in sys.argv if a not in ("--abb", "--chain", "--levels", "--split", "--link")]
+    pgs = "--pgs" in sys.argv         # --chain: the velocity-level contact solve (k_a1_chain_pgs, csrc/shf_chain_hard.h)
+    selfc = "--self" in sys.argv      # --chain: with self-collision
+    terrain = "trimesh" if "--trimesh" in sys.argv else "heightfield"
+    argv = [a for a in sys.argv if a not in ("--abb", "--chain", "--levels", "--split", "--link", "--pgs", "--self", "--trimesh")]
     G = int(argv[1]) if len(argv) > 1 else 32
     steps = int(argv[2]) if len(argv) > 2 else 100
     from shifu_amd import build as b
@@ -49,11 +52,18 @@ def main():
     from shifu_amd.gym.abb_fused import FusedAbbEnv
     # --abb: the sub-step phases (0-10) of the push-box env; its kernel has no marks outside the sub-steps
     env = (FusedAbbEnv(num_envs=4096, group=G, link_contacts=link, mapping="split" if split else ("body" if (levels or link) else "chain")) if abb else
-           FusedA1Env(num_envs=4096, group=G, mapping="chain" if chain else "body"))
+           FusedA1Env(num_envs=4096, group=G, mapping="chain" if chain else "body", solver="pgs" if pgs else "compliant",
+                      self_collision=selfc, terrain=terrain))
     if chain:
-        NAMES[1] = "chain: kinematics + inertias"; NAMES[0] = NAMES[2] = NAMES[5] = "(unused on the chain mapping)"
+        NAMES[0] = "dof lanes: drive efforts + local joint rotations"; NAMES[1] = "chain lanes: poses, velocities, motion subspaces"
+        NAMES[2] = "body lanes: rigid inertias + external forces"; NAMES[5] = "(unused on the chain mapping)"
         NAMES[6] = "chain: dof efforts + inward"; NAMES[7] = "root: add hips + 6x6 solve"; NAMES[8] = "chain: outward + integrate"
         NAMES[10] = "root: integrate"
+    if pgs:
+        NAMES[3] = "points -> candidate constraints, selection"; NAMES[4] = "contact solve: H1-H4 (marks 5, 10, 17, 18 are its parts)"
+        NAMES[5] = "  H1 response matrix W (column lanes)"; NAMES[10] = "  H2 owner setup (u0, targets, block inverses)"
+        NAMES[6] = "free inward pass (row lanes)"; NAMES[7] = "root: sum, LDL^T, free acceleration"; NAMES[8] = "free outward pass + velocity rates"
+        NAMES[9] = "integration + contact force out"
     lib = _lib.lib()
     fn = lib.shf_debug_phase_cycles
     fn.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_int]
@@ -70,6 +80,8 @@ def main():
     assert fn(buf, 32, 0) == 0
     tot = sum(buf[:17]) if not split else sum(buf[11:17]) + sum(buf[24:30])  # (marks 17-23: inside phase 4 for the box scene)
     print(f"G={G}: {tot / steps:.0f} cycles per env-step in block 0 / wave 0 (s_memtime ticks)")
+    if pgs:
+        tot = sum(buf[:4]) + sum(buf[5:19])      # mark 4 is what is left of H after its parts
     extra_names = ['box: corner slots', 'box: sphere slots', 'box: fold', 'fold: box lane corners', 'fold: pair law', 'fold: sync', 'fold: arm lanes', 'split: arm wave before S1', 'split: wait at S1', 'split: arm wave S1 -> S4', 'split: wait at S4', 'split: arm wave after S4', 'split: final barrier']
     if link and split:
         # k_abb_step_ws<512, true>: marks 17-22 are the BOX wave's own clock (its first lane), 24-28 the arm wave's
@@ -79,6 +91,8 @@ def main():
     if link and not split:
         print(f"  link contacts: {buf[29] / max(buf[31], 1):.2f} live (body, box) pairs per wavefront and sub-step, "
               f"{buf[30] / max(buf[31], 1):.2f} in its first env; stage 0 (broad phase) = mark 24")
+    if pgs:
+        extra_names[0:2] = ['  H3 sweeps (position + velocity iterations)', '  H4 impulse passes (inward / root / outward, x2)']
     for k, nme in enumerate(NAMES + extra_names):
         print(f"  {k:2d} {nme:52s} {buf[k] / steps:9.0f}  {100.0 * buf[k] / tot:5.1f} %")
 
