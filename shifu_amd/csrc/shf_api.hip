@@ -1739,6 +1739,9 @@ static int abb_step_launch(ShfAbbTask* task, const float* raw_actions_dev, void*
       default: return launch(k_abb_step<16, AbbLinkDims, AbbScene, true>, grid, block, lds, stream, A);
     }
   }
+  if (sim_link(s) && s->mapping == SHF_MAP_CHAIN)
+    return fail("shf_abb_step: the chain mapping (arm recursions on one lane) is compiled without link contacts -- with link contacts use "
+                "the split mapping (shf_sim_set_mapping(SHF_MAP_CHAIN_SPLIT), 16 lanes) or the body mapping");
   if (sim_link(s)) {
     switch (s->group) {
       case 64: return launch(k_abb_step<64, DynDims, DynScene, true>, grid, block, lds, stream, A);

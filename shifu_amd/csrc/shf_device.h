@@ -66,6 +66,15 @@ __device__ unsigned long long g_phase_cycles[32];
 
 // 1/x (x > 0) and 1/sqrt(x) (x > 0) by Newton's iteration from an integer seed: the fixed operation sequences of the
 // oracle's rcp_spec / rsqrt_spec (7 and 12 dependent operations; IEEE `1.0f / x` and `sqrtf` are 11 and ~20 on gfx950).
+// DOMAIN: normal positive floats, 1e-30 <= x <= 1e30 (relative error <= 1.0 / 2.4 units of 2^-24 there,
+// tests/test_oracle_physics.py).  Outside it: zero and denormals give nan / inf (they propagate, as IEEE's inf would), a
+// negative argument of rcp_spec its negative reciprocal, rsqrt_spec of a negative number -inf (pinned by the same test).
+// Every call site feeds a quantity that is positive
+// by construction: the ABA's D = S^T IA S + armature + dt (damping + ...) and the LDL^T pivots of an articulated inertia
+// (positive definite: rigid inertias with mass > 0, model.py refuses massless moving bodies; contact terms only add
+// positive semi-definite parts), 1 + |grad h|^2, |q|^2 of a unit-ish quaternion, max(|v_t|^2, v_eps^2), the regularised
+// diagonal blocks of the contact-space response (SPD + 1e-6 trace), squared lengths guarded by explicit thresholds
+// (box_box_edge: l2 > 1e-4).  A non-positive pivot would mean a broken model, not a reachable state.
 DEV float rcp_spec(float x) {
   float y = __uint_as_float(0x7EF311C7u - __float_as_uint(x));
 #pragma unroll

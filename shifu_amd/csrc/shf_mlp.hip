@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <string>
 
@@ -385,6 +386,12 @@ __global__ void k_mlp_reduce_slices(const float* part_w, float* dw, int nw, cons
 
 thread_local std::string g_mlp_err;
 int mlp_fail(const std::string& m) { g_mlp_err = m; return 1; }
+// bit of the current HIP device in the per-kernel "dynamic LDS limit raised" masks (hipFuncSetAttribute is per device)
+static uint64_t mlp_device_bit() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  return 1ull << (dev & 63);
+}
 bool too_big(int64_t M, int64_t K, int64_t N) { return M * K >= (1ll << 32) || M * N >= (1ll << 32) || N * K >= (1ll << 32); }
 bool vec_ok(const Operand& O, int red, bool red_contig) {
   // 16-byte chunks must be whole: aligned rows, and the extent along the contiguous index a multiple of 4
@@ -913,11 +920,12 @@ int launch_panel_bc(hipStream_t st, const PanelArgs& P, bool split, size_t lds) 
 #define SHF_PANEL_GO(MASKV, SPLITV)                                                                              \
   do {                                                                                                           \
     auto fn = k_mlp_panel<BM, CT, MASKV, SPLITV>;                                                                \
-    static bool attr = false;                                                                                    \
-    if (!attr) {                                                                                                 \
+    static std::atomic<uint64_t> attr{0};        /* one bit per device: the opt-in is per device, not per process */ \
+    const uint64_t dbit = mlp_device_bit();                                                                      \
+    if (!(attr.load(std::memory_order_relaxed) & dbit)) {                                                        \
       if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
         return mlp_fail("k_mlp_panel: cannot raise the dynamic LDS limit");                                      \
-      attr = true;                                                                                               \
+      attr.fetch_or(dbit, std::memory_order_relaxed);                                                            \
     }                                                                                                            \
     hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, P);                                                         \
   } while (0)
@@ -1269,11 +1277,12 @@ extern "C" int shf_mlp_chain_forward(const float* x, int32_t M, const ShfMlpChai
 #define SHF_CHAIN_GO(SPLITV)                                                                                     \
   do {                                                                                                           \
     auto fn = k_mlp_chain<SPLITV>;                                                                               \
-    static bool attr = false;                                                                                    \
-    if (!attr) {                                                                                                 \
+    static std::atomic<uint64_t> attr{0};        /* one bit per device */                                        \
+    const uint64_t dbit = mlp_device_bit();                                                                      \
+    if (!(attr.load(std::memory_order_relaxed) & dbit)) {                                                        \
       if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
         return mlp_fail("k_mlp_chain: cannot raise the dynamic LDS limit");                                      \
-      attr = true;                                                                                               \
+      attr.fetch_or(dbit, std::memory_order_relaxed);                                                            \
     }                                                                                                            \
     hipLaunchKernelGGL(fn, grid, dim3(CHAIN_THREADS), lds, (hipStream_t)stream, P);                              \
   } while (0)

@@ -42,8 +42,12 @@ class FusedAbbEnv:
             # With link contacts 'split' exists too (the link passes run on the box wave; 0.166 vs 0.186 ms for 'body').
             scene = not extra_boxes
             mapping = "split" if (scene and group == 16) else "chain" if (scene and not link_contacts and group == 32) else "body"
+        if mapping == "chain" and self.link_contacts:
+            raise ValueError("FusedAbbEnv: mapping='chain' is compiled for the rod-only scene; with link_contacts=True use "
+                             "mapping='split' (16 lanes per env) or 'body'")
         self.mapping = mapping
-        self.sim_params = default_sim_params(dt=dt)
+        # (config 5 keeps the compliant contact law: the velocity-level solve is not built for scenes with box actors yet)
+        self.sim_params = default_sim_params(dt=dt, solver="compliant")
         self.sim = Sim(self.sim_params, self.device)
         self.sim.set_plane(1.0)
         self.sim.set_articulation(self.cm.blob)

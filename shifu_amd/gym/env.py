@@ -108,7 +108,10 @@ class ShifuVecEnv:
         Contract for the hooks (the shipped examples keep it): between steps they may update tensors IN PLACE (index
         assignment, `+=`, ...) but must not rebind an attribute that a captured hook reads to a NEW tensor (`self.x =
         torch.zeros(...)` inside `reset_idx`), draw no random numbers and take no data-dependent Python branches inside the
-        captured hooks.  Call after construction and before `reset()`: the capture runs the hooks a few times on whatever
+        captured hooks; and an attribute that the second graph's hooks (observations, sensors, history) REBIND must not be
+        read by the first graph's hooks (control loop, termination, rewards) of the next step -- the capture holds the
+        address of the tensor the warm-up bound, not the one the last replay wrote.  `step` returns copies of the
+        observation and reset tensors (they are fixed graph buffers underneath, overwritten by the next replay).  Call after construction and before `reset()`: the capture runs the hooks a few times on whatever
         state is there.  Not the default: a misbehaving hook fails silently under replay, and graph replays have misbehaved
         on this stack before (profiles/r03_graph_replay.md) -- tests/test_gpu_env.py holds this mode to the fused kernel."""
         assert self.obs_buf.is_cuda, "graph replay needs the GPU path"
@@ -137,7 +140,7 @@ class ShifuVecEnv:
         try:
             with torch.cuda.graph(g1):
                 before()
-            with torch.cuda.graph(g2, pool=g1.pool()):
+            with torch.cuda.graph(g2):      # its own memory pool: g1's transient buffers must not alias g2's live outputs
                 after()
         except Exception as exc:      # a hook copied from the host, synchronised or branched on device data
             self.common_step_counter = counter
@@ -156,7 +159,16 @@ class ShifuVecEnv:
         env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()       # (the host sync of env.py:101, as in eager mode)
         self.reset_idx(env_ids)
         g2.replay()
-        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+        # obs_buf / reset_buf / time_out_buf are fixed graph-pool buffers here, overwritten in place by the next replay; the
+        # eager path binds fresh tensors every step (compute_observations, torch.clip, compute_termination), and callers rely
+        # on it -- rsl_rl's PPO.act keeps `transition.observations = obs` by reference until after the next env.step.  So the
+        # step hands out copies; the attributes stay bound to the static buffers (what get_observations() returns is
+        # overwritten by the next step, as rew_buf is on the eager path too).
+        obs = self.obs_buf.clone()
+        priv = None if self.privileged_obs_buf is None else self.privileged_obs_buf.clone()
+        if torch.is_tensor(self.extras.get("time_outs")):
+            self.extras["time_outs"] = self.extras["time_outs"].clone()
+        return obs, priv, self.rew_buf, self.reset_buf.clone(), self.extras
 
     def reset(self):
         self.reset_idx(torch.arange(self.num_envs, device=self.device))

@@ -300,8 +300,12 @@ class MfmaMLP(nn.Sequential):
         return ls if lib().shf_mlp_chain_fits(C.byref(c)) else None      # (depends on the precision mode: asked per call)
 
     def forward(self, x):
-        ls = self._chain_layers() if CHAIN_MIN_ROWS else None
-        if ls is None or not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= CHAIN_MIN_ROWS):
+        # the cheap tensor checks first: a CPU / small / non-fp32 batch takes the layers one by one (stock ops on CPU) and
+        # must not touch the native library, which _chain_layers() does (get_precision, shf_mlp_chain_fits)
+        if not (CHAIN_MIN_ROWS and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= CHAIN_MIN_ROWS):
+            return super().forward(x)
+        ls = self._chain_layers()
+        if ls is None:
             return super().forward(x)
         _apply_env_precision()
         x = x.contiguous()

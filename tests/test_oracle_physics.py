@@ -171,6 +171,22 @@ def test_spec_sincos_exp_accuracy(oracle):
     assert (np.abs(e - ref) / ref).max() < 3e-7
 
 
+def test_spec_rcp_rsqrt_domain_edges(oracle):
+    """the stated domain of rcp_spec / rsqrt_spec (csrc/shf_device.h) -- normal positive floats, 1e-30 .. 1e30 --
+    holds its accuracy to the edges.  Outside it the results are pinned here so that nobody has to guess: zero and
+    denormals give nan / inf (which propagate visibly, like IEEE's inf would), a negative argument of rcp_spec gives the
+    negative reciprocal (the seed subtraction carries the sign bit), rsqrt_spec of a negative number -inf."""
+    x = np.array([1e-30, 3e-30, 1e-20, 1e20, 3e29, 1e30], np.float32)
+    r, q = oracle.rcp_rsqrt(x)
+    xd = x.astype(np.float64)
+    assert np.abs(r * xd - 1.0).max() < 1.01 * 2.0 ** -24 and np.abs(q * np.sqrt(xd) - 1.0).max() < 2.5 * 2.0 ** -24
+    bad = np.array([0.0, -1.0, 1e-42], np.float32)
+    with np.errstate(all="ignore"):
+        r, q = oracle.rcp_rsqrt(bad)
+    assert np.isnan(r[0]) and np.isnan(q[0]) and not np.isfinite(r[2]) and not np.isfinite(q[2])   # 0 and denormals: nan / inf
+    assert r[1] == -1.0 and q[1] == -np.inf
+
+
 def test_spec_rcp_rsqrt_accuracy(oracle):
     """rcp_spec / rsqrt_spec (Newton from an integer seed, shared operation for operation with the HIP kernels): within
     1.01 and 2.5 units of 2^-24 of 1/x and 1/sqrt(x) over twelve decades -- what replaces IEEE division / sqrt on the sub-step's

@@ -276,3 +276,20 @@ def test_mfma_mlp_keeps_parameter_names_and_drops_kept_packs_on_load():
     layer._pack_valid = True
     ac.to("cpu")
     assert not layer._pack_valid
+
+
+def test_mfma_actor_critic_runs_on_cpu_without_the_native_library(monkeypatch):
+    """a CPU forward of an mlp_backend='mfma' ActorCritic must take the stock layer-by-layer path without loading
+    libshifu_amd.so (a host without the built library can still evaluate a checkpoint): with the library path pointing at a
+    missing file the forward works, large batches included, and nothing raises BackendError."""
+    import torch
+    from shifu_amd import _lib
+    from shifu_amd.rl.actor_critic import ActorCritic
+    monkeypatch.setattr(_lib, "_PATH", "/nonexistent/libshifu_amd.so")
+    monkeypatch.setattr(_lib, "_lib", None)
+    ac = ActorCritic(7, 7, 3, actor_hidden_dims=(16, 8), critic_hidden_dims=(16, 8), mlp_backend="mfma")
+    for rows in (5, 4096):
+        y = ac.act_inference(torch.randn(rows, 7))
+        assert y.shape == (rows, 3) and torch.isfinite(y).all()
+    with pytest.raises(_lib.BackendError):
+        _lib.lib()                       # (the library really is out of reach in this test)
