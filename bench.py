@@ -254,15 +254,10 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # started bare: become the launcher (a child process per rank; nothing here has touched the GPU yet)
-        import socket
-        import subprocess
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            port = s.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.call(cmd))
+        # started bare: become the launcher (a child process per rank; nothing here has touched the GPU yet).  A rank that
+        # exits non-zero fails the whole job with it (shifu_amd/parallel.py: launch_ranks)
+        from shifu_amd.parallel import launch_ranks
+        raise SystemExit(launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -271,6 +266,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("SHIFU_AMD_TEST_FAIL_RANK") == str(rank) and world > 1:
+        raise SystemExit(3)      # tests/test_gpu_bench.py: a rank that dies must fail the whole job
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the backend has no CPU fallback")
     # one rank per GPU; SHIFU_AMD_DIST_BACKEND=gloo (testing only) lets several ranks share a GPU to exercise the
@@ -282,14 +279,10 @@ def main():
     # SHIFU_AMD_FORCE_DIST=1 (testing only): take the N>1 code path -- process group, barriers, the all-gather of episode
     # statistics, the MAX all-reduce of the elapsed time -- with a single rank, e.g. to exercise RCCL on a 1-GPU box
     use_dist = world > 1 or os.environ.get("SHIFU_AMD_FORCE_DIST", "0") == "1"
-    if use_dist:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
     from shifu_amd import _abi
-    from shifu_amd.parallel import gather_episode_stats
+    from shifu_amd.parallel import device_identity, gather_episode_stats, gather_rank_reports, init_ranks
+    if use_dist:
+        init_ranks(dev, backend)       # finite timeout: a rank that never arrives fails the job instead of hanging it
 
     abb = args.workload == "abb"
     if abb:
@@ -346,11 +339,19 @@ def main():
     use_graph = args.graph
     gathers = {"warmup": 0, "timed": 0}
 
+    gather_events = []          # HIP events around every timed all-gather: its latency on this rank's stream
+
     def maybe_gather(global_step, slot, phase):
         # extras["episode"] logging cadence (policy_config.py:36: num_steps_per_env = 24), counted from the first step of
         # the run so that the driver's shape (--warmup 5 --steps 20) times exactly one all-gather
         if use_dist and (global_step + 1) % args.log_interval == 0:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if phase == "timed" else None
+            if ev:
+                ev[0].record()
             gather_episode_stats(env.task.tensors[stats_t][slot][:env.task.num_sums])
+            if ev:
+                ev[1].record()
+                gather_events.append(ev)
             gathers[phase] += 1
 
     for i in range(args.warmup):
@@ -415,6 +416,11 @@ def main():
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         dist_world = dist.get_world_size()
     elapsed, elapsed_min = float(t.item()), float(tmin.item())
+    # every rank's own report, on rank 0's line: which GPU it ran on, its own clock, what its all-gathers cost
+    gather_ms = [a.elapsed_time(b) for a, b in gather_events]
+    reports = gather_rank_reports({"rank": rank, "local_rank": local_rank, "device": device_identity(dev), "pid": os.getpid(),
+                                   "ms_per_step": rank_elapsed / args.steps * 1e3,
+                                   "all_gather_ms": gather_ms, "all_gather_ms_mean": (sum(gather_ms) / len(gather_ms) if gather_ms else None)})
     finite = bool(torch.isfinite(env.obs_buf).all().item())
     resets = int(env.task.tensors[count_t].sum().item())
 
@@ -469,7 +475,12 @@ def main():
             "rccl_world_size": (dist_world if (use_dist and backend == "nccl") else None),
             "dist": {"backend": (backend if use_dist else None), "world_size": dist_world,
                      "ms_per_step_rank_min": elapsed_min / args.steps * 1e3, "ms_per_step_rank_max": elapsed / args.steps * 1e3,
-                     "ms_per_step_rank0": rank_elapsed / args.steps * 1e3},
+                     "ms_per_step_rank0": rank_elapsed / args.steps * 1e3,
+                     # one entry per rank (all_gather_object): distinct devices prove that N GPUs ran; all_gather_ms = HIP
+                     # events around each timed all-gather of the episode statistics on that rank's stream
+                     "ranks": reports,
+                     "distinct_devices": len({r["device"] for r in reports}),
+                     "all_gather_ms_max": max([x for r in reports for x in r["all_gather_ms"]], default=None)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{WL_NAME[args.workload]}, {N} envs/GPU, random actions, {substeps} substeps/env-step "
                                    f"(dt {'20' if abb else '5'} ms), resets on, contact solver: "

@@ -104,3 +104,55 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src)
+
+
+# ---- launching one process per GPU (bench.py --gpus N, tools/train_a1.py --gpus N) ----
+def launch_ranks(script: str, argv: List[str], nproc: int) -> int:
+    """Start `script` once per GPU through torch.distributed.run (rendezvous on 127.0.0.1, a free port) as CHILD processes and
+    return the launcher's exit code: torchrun tears the other ranks down when one fails and exits non-zero, so a rank that
+    dies takes the job's exit status with it instead of leaving the others waiting in a collective.  Call this before
+    anything in the calling process has touched the GPU (the children initialise it themselves; a process that has
+    initialised the GPU must never exec another program on this pool)."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    return subprocess.call(cmd)
+
+
+def init_ranks(device: torch.device, backend: str = "nccl", timeout_s: float = 300.0) -> None:
+    """init_process_group with a finite timeout: a rank that never arrives makes the others fail (non-zero exit through the
+    launcher) after `timeout_s` instead of hanging the node.  SHIFU_AMD_DIST_TIMEOUT_S overrides it."""
+    import datetime
+    import os
+    t = datetime.timedelta(seconds=float(os.environ.get("SHIFU_AMD_DIST_TIMEOUT_S", timeout_s)))
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=device, timeout=t)
+    else:
+        dist.init_process_group(backend, timeout=t)
+
+
+def device_identity(device: torch.device) -> str:
+    """What tells one GPU of a node from another in a log line: the PCI bus id where torch exposes it, else the UUID, else
+    the ordinal."""
+    p = torch.cuda.get_device_properties(device)
+    for attr in ("pci_bus_id", "uuid"):
+        v = getattr(p, attr, None)
+        if v is not None:
+            if attr == "pci_bus_id":
+                return "pci %04x:%02x:%02x.0" % (int(getattr(p, "pci_domain_id", 0)), int(v), int(getattr(p, "pci_device_id", 0)))
+            return f"uuid {v}"
+    return f"cuda:{device.index}"
+
+
+def gather_rank_reports(report: dict) -> List[dict]:
+    """Every rank's small report dict on every rank, rank order (all_gather_object; a single process: [report])."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [report]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, report)
+    return out

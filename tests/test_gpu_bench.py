@@ -51,6 +51,39 @@ def test_bench_two_ranks_in_child_processes_over_gloo():
     # the process group's own count and the spread of the per-rank clocks
     assert out["dist"]["backend"] == "gloo" and out["dist"]["world_size"] == 2 and out["rccl_world_size"] is None
     assert out["dist"]["ms_per_step_rank_min"] <= out["dist"]["ms_per_step_rank_max"] == out["ms_per_step"]
+    # every rank's own report: which device it ran on, its clock, what its timed all-gathers cost
+    ranks = out["dist"]["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and len({r["pid"] for r in ranks}) == 2
+    assert all(r["device"] and r["ms_per_step"] > 0 and len(r["all_gather_ms"]) >= 1 for r in ranks)
+    assert out["dist"]["distinct_devices"] == 1, "two gloo ranks share the test box's one GPU"
+    assert max(r["ms_per_step"] for r in ranks) == pytest.approx(out["ms_per_step"])
+    assert out["dist"]["all_gather_ms_max"] > 0
+
+
+def test_bench_two_ranks_over_rccl_on_two_gpus():
+    """The real thing where the box has two GPUs (skipped on the one-GPU test box): two ranks over RCCL, each on its own
+    device -- distinct PCI ids in the line, rccl_world_size 2."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    out = _run_bench(["--gpus", "2", "--steps", "30", "--warmup", "5", "--no-cpu-baseline"], {}, "2rank_rccl")
+    assert out["n_gpus"] == 2 and out["rccl_world_size"] == 2 and out["dist"]["backend"] == "nccl"
+    assert out["dist"]["distinct_devices"] == 2 and out["config"]["total_envs"] == 2 * 4096
+    assert all(len(r["all_gather_ms"]) >= 1 for r in out["dist"]["ranks"])
+
+
+def test_a_failing_rank_fails_the_job():
+    """A rank that dies must take the job's exit status with it (no hang, no silent success): rank 1 is made to exit with
+    status 3 before the process group forms; the launcher returns non-zero within the rendezvous timeout."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    env = dict(os.environ)
+    env.update({"SHIFU_AMD_DIST_BACKEND": "gloo", "SHIFU_AMD_TEST_FAIL_RANK": "1", "SHIFU_AMD_DIST_TIMEOUT_S": "60"})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")], "no result line from a job that lost a rank"
 
 
 def test_bench_one_rank_over_rccl():

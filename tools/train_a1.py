@@ -35,7 +35,12 @@ def main():
     ap.add_argument("--seed", type=int, default=None, help="override A1PPOConfig.seed")
     ap.add_argument("--self-collision", action="store_true", help="collide the robot's own links (reference collision filter 0)")
     ap.add_argument("--solver", choices=["pgs", "compliant"], default=None, help="contact solver (FusedA1Env(solver=...)); default: the env's")
+    ap.add_argument("--gpus", type=int, default=1, help="started bare with --gpus N: becomes the launcher of N ranks (one per GPU, RCCL), like bench.py")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # data-parallel PPO on a node: one child process per GPU (nothing here has touched the GPU yet); a failing rank fails the job
+        from shifu_amd.parallel import launch_ranks
+        raise SystemExit(launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     import torch.distributed as dist
     world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
     backend = os.environ.get("SHIFU_AMD_DIST_BACKEND", "nccl")     # gloo: several ranks on one GPU (testing only)
@@ -43,10 +48,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or os.environ.get("SHIFU_AMD_FORCE_DIST", "0") == "1":    # FORCE_DIST: one-rank RCCL walk-through (testing)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        from shifu_amd.parallel import init_ranks
+        init_ranks(dev, backend)
     from examples.a1_conditional.task_config import A1PPOConfig
     from shifu_amd.rl import OnPolicyRunner
     from shifu_amd.runner.utils import class_to_dict, set_seed
