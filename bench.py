@@ -59,7 +59,7 @@ def oracle_workload(workload: str, n: int, seed: int = 0, solver_kw=None):
         from shifu_amd.abb_task import ABB_BASE_POS, abb_boxes, abb_model, abb_task_params
         cm = abb_model()
         m, boxes = cm.blob, abb_boxes()
-        sp = default_sim_params(dt=0.02)
+        sp = default_sim_params(dt=0.02, **(solver_kw or {}))
         tp = abb_task_params(cm)
         nb, nd, A = m.nb, m.nd, 4
         B = nb + 3
@@ -297,7 +297,8 @@ def main():
     if abb:
         from shifu_amd.gym.abb_fused import FusedAbbEnv
         env = FusedAbbEnv(num_envs=args.envs, device=dev, seed=42, rank=rank, world_size=world, group=group,
-                          link_contacts=args.link_contacts, mapping=mapping)
+                          link_contacts=args.link_contacts, mapping=mapping, **({} if args.solver is None else {"solver": args.solver}))
+        args.solver, group, mapping = env.solver, env.sim.group, env.mapping
         stats_t, count_t, kernel = _abi.ABB_STATS, _abi.ABB_RESET_COUNT, "k_abb_step"
         substeps = 6
     else:
@@ -429,7 +430,7 @@ def main():
         value = total_envs * args.steps / elapsed
         b_alg = B_ALG[args.workload]
         achieved = b_alg * N / (kern_ms * 1e-3) / 1e9
-        prof = committed_profile(f"{kernel}_{args.workload}_g{group}" + ("_" + mapping if mapping != "body" else "") + ("_pgs" if (args.solver == "pgs" and not abb) else "") + ("_link" if (abb and args.link_contacts) else "")) if (N == 4096 and not args.self_collision) else None
+        prof = committed_profile(f"{kernel}_{args.workload}_g{group}" + ("_" + mapping if mapping != "body" else "") + ("_pgs" if args.solver == "pgs" else "") + ("_link" if (abb and args.link_contacts) else "")) if (N == 4096 and not args.self_collision) else None
         res = {}
         try:
             res = json.load(open(os.path.join(ROOT, "shifu_amd", "libshifu_amd.resources.json")))
@@ -484,7 +485,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{WL_NAME[args.workload]}, {N} envs/GPU, random actions, {substeps} substeps/env-step "
                                    f"(dt {'20' if abb else '5'} ms), resets on, contact solver: "
-                                   + (f"velocity-level PGS {args.pos_iters} + {args.vel_iters} iterations (the reference's physx settings, env_config.py:50-58)" if (args.solver == "pgs" and not abb)
+                                   + (f"velocity-level PGS {args.pos_iters} + {args.vel_iters} iterations (the reference's physx settings, env_config.py:50-58)" if args.solver == "pgs"
                                       else "compliant spring-damper law (rounds 1-4)")
                                    + ((", link contacts ON (arm links + rod vs table / cube / goal pad)" if args.link_contacts else
                                        ", arm collider: the rod against the cube (link contacts OFF, see --link-contacts)") if abb else (", self-collision ON (capsule pairs, the reference's collision filter 0)" if args.self_collision
@@ -510,7 +511,7 @@ def main():
                                                  "timed pass): pass-to-pass noise, not a longer kernel; roofline.achieved uses kernel_ms, "
                                                  "the more conservative of the two")
         if not args.no_cpu_baseline and world == 1:
-            cb = out["cpu_baseline"] = cpu_baseline(args.workload, solver_kw=(None if abb else {"solver": args.solver, "pos_iters": args.pos_iters, "vel_iters": args.vel_iters}))     # the only leg that touches oracle/
+            cb = out["cpu_baseline"] = cpu_baseline(args.workload, solver_kw={"solver": args.solver, "pos_iters": args.pos_iters, "vel_iters": args.vel_iters})     # the only leg that touches oracle/
             f_alg = cb["flops_per_env_step"]
             secondary.update({"flops_alg_per_env_step": f_alg, "flops_source": cb["flops_source"]})
             if f_alg is not None:

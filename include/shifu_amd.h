@@ -323,10 +323,11 @@ int shf_sim_set_articulation(ShfSim* sim, const ShfModel* model);
  * shf_sim_bind(SHF_T_MODEL, ptr) writes that copy into the bound buffer, so a binding never has to call this; it is
  * exported for tools that inspect the derived data. */
 int shf_model_bounds(ShfModel* model);
-/* 1 if a scene of this articulation and `nboxes` box actors can run under ShfSimParams.solver = SHF_SOLVER_PGS (round 5: a
- * single A1-shaped articulation -- floating root, four serial chains of three revolute links ending in a welded body --
- * without self-collision and without box actors; csrc/shf_chain_hard.h), else 0: create the sim with SHF_SOLVER_COMPLIANT.
- * Host only.  The gym facade asks this before gym.create_sim's physx settings (env_config.py:50-58) become a ShfSimParams. */
+/* 1 if a scene of this articulation and `nboxes` box actors can run under ShfSimParams.solver = SHF_SOLVER_PGS: an A1-shaped
+ * articulation on its own takes the chain-mapped kernels (csrc/shf_chain_hard.h); any other scene the body-per-lane
+ * sub-step with the generic solve at 32 lanes per env (csrc/shf_hard.h: at most 32 bodies + box actors, trees of at most 8
+ * levels); else 0: create the sim with SHF_SOLVER_COMPLIANT.  Host only.  The gym facade asks this before gym.create_sim's
+ * physx settings (env_config.py:50-58) become a ShfSimParams. */
 int shf_model_pgs_supported(const ShfModel* model, int32_t nboxes);
 /* gym.create_box + create_actor (object.py:28-39) */
 int shf_sim_add_box(ShfSim* sim, const ShfBoxDesc* box);

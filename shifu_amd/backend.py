@@ -444,17 +444,19 @@ class AbbTask:
         link = bool(mdl.link_collide and self.sim.nboxes > 0)
         fixed = mdl.nb == 7 and mdl.np == (59 if link else 3) and self.sim.nboxes == 3
         pre = f"_Z10k_abb_stepILi{self.sim.group}E"
+        if self.sim.params.solver == _abi.SOLVER_PGS:    # the generic velocity-level solve: run-time shapes, 32 lanes per env
+            return f"_Z10k_abb_stepILi32E7DynDims8DynSceneLb{int(link)}ELi0ELb1EE"
         if not fixed:
             return pre + "7DynDims"
         if link:    # the shipped arm with its link volumes in the shipped scene (AbbLinkDims, AbbScene)
             if getattr(self.sim, "mapping", "body") == "split":
                 return "_Z13k_abb_step_wsILi512ELb1EE"
-            return pre + "9FixedDimsILi7ELi6ELi59ELi6ELi6EE10FixedSceneILi3ELi1ELi2EELb1ELi0EE"
+            return pre + "9FixedDimsILi7ELi6ELi59ELi6ELi6EE10FixedSceneILi3ELi1ELi2EELb1ELi0ELb0EE"
         mp = getattr(self.sim, "mapping", "body")
         if mp == "split":
             return "_Z13k_abb_step_wsILi256ELb0EE"
         arm = 6 if mp == "chain" else 0
-        return pre + f"9FixedDimsILi7ELi6ELi3ELi6ELi6EE10FixedSceneILi3ELi1ELi2EELb0ELi{arm}EE"
+        return pre + f"9FixedDimsILi7ELi6ELi3ELi6ELi6EE10FixedSceneILi3ELi1ELi2EELb0ELi{arm}ELb0EE"
 
     @_on_device
     def reset_all(self):

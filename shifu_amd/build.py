@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libshifu_amd.so")
 SOURCES = ["shf_api.hip", "shf_a1_chain.hip", "shf_glue.hip", "shf_mlp.hip"]
-DEPS = SOURCES + ["shf_device.h", "shf_boxes.h", "shf_task.h", "shf_chain.h", "shf_chain_hard.h", "shf_link.h", "shf_arm.h", os.path.join("..", "..", "include", "shifu_amd.h")]
+DEPS = SOURCES + ["shf_device.h", "shf_boxes.h", "shf_task.h", "shf_chain.h", "shf_chain_hard.h", "shf_hard.h", "shf_link.h", "shf_arm.h", os.path.join("..", "..", "include", "shifu_amd.h")]
 # -fno-slp-vectorize: the SLP vectoriser packs neighbouring scalar f32 ops into v_pk_* pairs plus the
 # v_mov shuffles that feed them -- slower for this kernel (measured -6 % at 2 envs/wave, -25 % at one
 # wavefront per env; cf. MI355X_MICROARCH.md "packed f32 VALU ... an anti-lever").
@@ -54,7 +54,7 @@ BUDGETS = [("_Z16k_a1_step_a1_g32", 256, 0),          # default: A1, two envs pe
            # FusedAbbEnv's default since round 4: the arm with link contacts at 16 lanes per env, one wave per SIMD (all 4096 envs
            # resident: 16 envs per CU share the 160 KB of LDS) -- 512 registers, and the 20 B of scratch every body-mapped
            # ABB instantiation has had since round 3
-           ("_Z10k_abb_stepILi16E9FixedDimsILi7ELi6ELi59ELi6ELi6EE10FixedSceneILi3ELi1ELi2EELb1ELi0EE", 512, 32),
+           ("_Z10k_abb_stepILi16E9FixedDimsILi7ELi6ELi59ELi6ELi6EE10FixedSceneILi3ELi1ELi2EELb1ELi0ELb0EE", 512, 32),
            # ... and its arm-wave / box-wave form, the default at 16 lanes: two waves per SIMD, so 256 registers, of which the
            # link passes spill some (120 B of scratch at the end of round 4; 496 B cost 19 %)
            ("_Z13k_abb_step_wsILi512ELb1EE", 256, 160)]

@@ -74,7 +74,9 @@ extern "C" int shf_abi_version(void) { return SHF_ABI_VERSION; }
 
 
 // gym.simulate: one sub-step for every env
-template <int G, bool BOX, bool SELF, bool LINK = false>
+// HARD: the velocity-level contact solve (ShfSimParams.solver == SHF_SOLVER_PGS; csrc/shf_hard.h): 32 lanes per env, and
+// HG_WORDS more LDS words per env behind the contact slots (constraint records + response matrix)
+template <int G, bool BOX, bool SELF, bool LINK = false, bool HARD = false>
 __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const ShfScene* scene = BOX ? stage_scene(A.scene, smem + MODEL_WORDS) : nullptr;
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
   const int nbx = BOX ? A.nboxes : 0, actors = 1 + nbx;
   const int nb = m->nb, nd = m->nd, nbt = nb + nbx;
   const int nslots = m->np + (BOX ? box_slots(slot_lay<DynScene>(m, scene)) : 0) + (SELF ? SHF_MAX_SELF_CONTACTS : 0) + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0);
-  EnvLds L = env_lds_carve(smem + MODEL_WORDS + (BOX ? SCENE_WORDS : 0) + es * env_lds_words(nbt, nd, nslots, 0, actors),
+  EnvLds L = env_lds_carve(smem + MODEL_WORDS + (BOX ? SCENE_WORDS : 0) + es * env_lds_words(nbt, nd, nslots + (HARD ? HG_WORDS / PT_STRIDE : 0), 0, actors),
                            nbt, nd, nslots, actors);
   float* dof = A.dof + (size_t)e * nd * 2;
   float* root = A.root + (size_t)e * actors * 13;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
   LaneModel M;
   lane_model_load<DynDims>(m, l, M);
   LanePoints<1> P;   // unused: point count only known at run time
-  substep<G, BOX, DynDims, !BOX, LaneModel, DynScene, SELF, LINK>(C, L, l, M, P, A.pos_tgt ? A.pos_tgt + (size_t)e * nd : nullptr,
+  substep<G, BOX, DynDims, !BOX, LaneModel, DynScene, SELF, LINK, HARD>(C, L, l, M, P, A.pos_tgt ? A.pos_tgt + (size_t)e * nd : nullptr,
                   A.vel_tgt ? A.vel_tgt + (size_t)e * nd : nullptr, A.body_force ? A.body_force + (size_t)e * nbt * 3 : nullptr, mu, L.xch,
                   BoxLane(), (A.body_force && A.body_force_pos) ? A.body_force_pos + (size_t)e * nbt * 3 : nullptr);
   GROUP_SYNC();
@@ -581,7 +583,7 @@ DEV void abb_post_step(const AbbArgs& A, const ShfAbbTaskParams& tp, const ShfMo
 #define ABB_TGT_WORDS(nd) (((nd) + 2 + 3) & ~3)                     /* POS targets + the end effector's x, y */
 #define WS_LINK_STASH_WORDS 32   /* k_abb_step_ws<512, true>: the free box's (IA, pA) and its corner ballots, parked per env */
 #define ABB_TAIL_WORDS(nslots, nd) ((nslots) * PT_STRIDE + ABB_TGT_WORDS(nd) + ARM_KREC_WORDS(SHF_ARM_MAX_LINKS) + 4)
-template <int G, class DM, class SC, bool LINK = false, int ARM = 0>
+template <int G, class DM, class SC, bool LINK = false, int ARM = 0, bool HARD = false>
 __global__ __launch_bounds__(256, (G >= 32 && SC::NBX > 0) ? 2 : 1) void k_abb_step(AbbArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   PHASE_BEGIN();
@@ -603,9 +605,10 @@ __global__ __launch_bounds__(256, (G >= 32 && SC::NBX > 0) ? 2 : 1) void k_abb_s
   const int nbx = SC::NBX > 0 ? SC::NBX : A.S.nboxes, actors = 1 + nbx;
   const int nb = DM::nb(m), nd = DM::nd(m), nbt = nb + nbx;
   const int nslots = DM::np(m) + box_slots(slot_lay<SC>(m, scene)) + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0);
-  const int env_words = env_lds_words(nbt, nd, nslots, ABB_TAIL_WORDS(nslots, nd), actors);
-  EnvLds L = env_lds_carve(smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS + es * env_words, nbt, nd, nslots, actors);
-  float* tgtl = L.pt + nslots * PT_STRIDE;  // POS targets of this env step
+  const int nslots_all = nslots + (HARD ? HG_WORDS / PT_STRIDE : 0);   // HARD: the solve's records and response matrix behind the slots
+  const int env_words = env_lds_words(nbt, nd, nslots_all, ABB_TAIL_WORDS(nslots_all, nd), actors);
+  EnvLds L = env_lds_carve(smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS + es * env_words, nbt, nd, nslots_all, actors);
+  float* tgtl = L.pt + nslots_all * PT_STRIDE;  // POS targets of this env step
   float* krec = tgtl + ABB_TGT_WORDS(nd);
 
   float* dof = A.S.dof + (size_t)e * nd * 2;
@@ -636,7 +639,7 @@ __global__ __launch_bounds__(256, (G >= 32 && SC::NBX > 0) ? 2 : 1) void k_abb_s
     if constexpr (ARM > 0)
       arm_substep<G, DM, SC, ARM>(C, L, krec, l, M, P, tgtl, mu, it == nsub - 1 ? L.xch : nullptr, BL);
     else
-      substep<G, true, DM, false, LaneModel, SC, false, LINK>(C, L, l, M, P, tgtl, nullptr, nullptr, mu, it == nsub - 1 ? L.xch : nullptr, BL);
+      substep<G, true, DM, false, LaneModel, SC, false, LINK, HARD>(C, L, l, M, P, tgtl, nullptr, nullptr, mu, it == nsub - 1 ? L.xch : nullptr, BL);
   }
   abb_after_physics<G, DM>(A, tp, m, L, l, e, epb, nbx, tgtl, stats_lds, stats_step);
 }
@@ -1013,7 +1016,7 @@ static size_t sim_lds_bytes(const ShfSim* s, int head_words, int min_tail, bool 
   const int epb = 256 / s->group;
   const int nbx = boxes ? s->nboxes : 0;
   const int nslots = s->model.np + (boxes ? box_slot_count(nbx, sim_ndyn(s), s->model.nsph) : 0) + (sim_self(s) ? SHF_MAX_SELF_CONTACTS : 0) +
-                     ((boxes && sim_link(s)) ? 2 * SHF_MAX_LINK_CONTACTS : 0);
+                     ((boxes && sim_link(s)) ? 2 * SHF_MAX_LINK_CONTACTS : 0) + (s->sp.solver == SHF_SOLVER_PGS ? HG_WORDS / PT_STRIDE : 0);
   return ((size_t)MODEL_WORDS + head_words + (boxes ? SCENE_WORDS : 0) +
           (size_t)epb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, min_tail, 1 + (boxes ? nbx : s->nboxes))) * 4;
 }
@@ -1029,8 +1032,9 @@ extern "C" int shf_sim_create(const ShfSimParams* params, ShfSim** out) {
   return 0;
 }
 extern "C" int shf_model_pgs_supported(const ShfModel* model, int32_t nboxes) {
-  if (!model || nboxes != 0) return 0;
-  return shf_a1_chain_matches(*model) ? 1 : 0;
+  if (!model || nboxes < 0 || nboxes > SHF_MAX_BOXES) return 0;
+  if (nboxes == 0 && shf_a1_chain_matches(*model)) return 1;
+  return (model->nlevels <= HG_LEV && model->nb + nboxes <= 32) ? 1 : 0;
 }
 extern "C" int shf_sim_destroy(ShfSim* sim) {
   delete sim;
@@ -1302,13 +1306,28 @@ extern "C" int shf_sim_step(ShfSim* sim, void* stream) {
   }
   if (sim->sp.solver == SHF_SOLVER_PGS) {
     // the velocity-level contact solve: built for A1-shaped articulations on their own (csrc/shf_chain_hard.h)
-    if (sim->nboxes > 0 || !shf_a1_chain_matches(sim->model))
-      return fail("shf_sim_step: ShfSimParams.solver = SHF_SOLVER_PGS is built for a single A1-shaped articulation; use SHF_SOLVER_COMPLIANT for this scene");
-    if (A.body_force_pos) return fail("shf_sim_step: SHF_SOLVER_PGS applies body forces at the centres of mass only");
     if (sim->sp.max_contacts > shf_a1_chain_pgs_max_contacts() || sim->sp.pos_iters < 1) return fail("shf_sim_step: SHF_SOLVER_PGS needs pos_iters >= 1 and max_contacts <= 8");
     sim->force_armed = false;
     sim->force_at_pos = false;
-    return launch_ptr(shf_sim_step_chain_pgs_kernel(sim->terr.warped != 0, sim_self(sim)), dim3((sim->n + 7) / 8), dim3(256), shf_sim_step_chain_pgs_lds_bytes(sim_self(sim)), stream, A);
+    if (sim->nboxes == 0 && shf_a1_chain_matches(sim->model) && !A.body_force_pos)
+      return launch_ptr(shf_sim_step_chain_pgs_kernel(sim->terr.warped != 0, sim_self(sim)), dim3((sim->n + 7) / 8), dim3(256), shf_sim_step_chain_pgs_lds_bytes(sim_self(sim)), stream, A);
+    // any other articulation / a scene with box actors: the body-per-lane sub-step with the generic solve (csrc/shf_hard.h), 32 lanes per env
+    if (sim->model.nlevels > HG_LEV) return fail("shf_sim_step: SHF_SOLVER_PGS walks trees of at most 8 levels");
+    if (sim->model.nb + sim->nboxes > 32) return fail("shf_sim_step: SHF_SOLVER_PGS runs at 32 lanes per env: at most 32 bodies + box actors");
+    if (sim->terr.warped && sim->nboxes > 0) return fail("shf_sim_step: trimesh terrain with box actors is not supported");
+    const int keep = sim->group;
+    sim->group = 32;
+    const size_t hlds = sim_lds_bytes(sim, 0, 0, sim->nboxes > 0);
+    sim->group = keep;
+    const dim3 hgrid((sim->n + 7) / 8), hblock(256);
+    if (sim->nboxes > 0) {
+      if (sim_link(sim)) return sim_self(sim) ? launch(k_sim_step<32, true, true, true, true>, hgrid, hblock, hlds, stream, A)
+                                              : launch(k_sim_step<32, true, false, true, true>, hgrid, hblock, hlds, stream, A);
+      return sim_self(sim) ? launch(k_sim_step<32, true, true, false, true>, hgrid, hblock, hlds, stream, A)
+                           : launch(k_sim_step<32, true, false, false, true>, hgrid, hblock, hlds, stream, A);
+    }
+    return sim_self(sim) ? launch(k_sim_step<32, false, true, false, true>, hgrid, hblock, hlds, stream, A)
+                         : launch(k_sim_step<32, false, false, false, true>, hgrid, hblock, hlds, stream, A);
   }
   sim->force_armed = false;
   sim->force_at_pos = false;
@@ -1715,7 +1734,18 @@ static int abb_step_launch(ShfAbbTask* task, const float* raw_actions_dev, void*
   AbbArgs A;
   if (int r = abb_args(task, raw_actions_dev, "shf_abb_step", A)) return r;
   ShfSim* s = task->sim;
-  if (s->sp.solver == SHF_SOLVER_PGS) return fail("shf_abb_step: ShfSimParams.solver = SHF_SOLVER_PGS is built into the fused A1 step only (shf_a1_step); use SHF_SOLVER_COMPLIANT here");
+  if (s->sp.solver == SHF_SOLVER_PGS) {
+    // the velocity-level contact solve: the run-time-shaped body-per-lane step at 32 lanes per env (csrc/shf_hard.h)
+    if (s->sp.max_contacts > HCK || s->sp.pos_iters < 1) return fail("shf_abb_step: SHF_SOLVER_PGS needs pos_iters >= 1 and max_contacts <= 8");
+    if (s->model.nlevels > HG_LEV || s->model.nb + s->nboxes > 32) return fail("shf_abb_step: SHF_SOLVER_PGS: at most 8 tree levels and 32 bodies + box actors");
+    const int nbx = s->nboxes;
+    const int nslots = s->model.np + box_slot_count(nbx, sim_ndyn(s), s->model.nsph) + (sim_link(s) ? 2 * SHF_MAX_LINK_CONTACTS : 0) + HG_WORDS / PT_STRIDE;
+    const size_t lds = ((size_t)MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS +
+                        (size_t)8 * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, ABB_TAIL_WORDS(nslots, s->model.nd), 1 + nbx)) * 4;
+    const dim3 hgrid((s->n + 7) / 8), hblock(256);
+    return sim_link(s) ? launch(k_abb_step<32, DynDims, DynScene, true, 0, true>, hgrid, hblock, lds, stream, A)
+                       : launch(k_abb_step<32, DynDims, DynScene, false, 0, true>, hgrid, hblock, lds, stream, A);
+  }
   const int epb = 256 / s->group;
   dim3 grid((s->n + epb - 1) / epb), block(256);
   const int nbx = s->nboxes, nslots = s->model.np + box_slot_count(nbx, sim_ndyn(s), s->model.nsph) + (sim_link(s) ? 2 * SHF_MAX_LINK_CONTACTS : 0);

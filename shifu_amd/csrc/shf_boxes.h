@@ -952,9 +952,10 @@ DEV int link_contacts(const StepCtx& C, const EnvLds& L, int l, int slot0, float
   const ShfModel* m = C.m;
   const SceneDev* S = C.scene;
   const int nb = m->nb, nbx = S->nboxes;
-  const float dt = C.sp.dt, kc = C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
-  const float offset = C.sp.contact_offset;
-  const float beta = fmaf(kc, dt, C.sp.contact_d);
+  const bool hard = C.sp.solver == SHF_SOLVER_PGS;     // candidates only (slot_eval); family B by signed distance
+  const float dt = C.sp.dt, kc = hard ? -1.0f : C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
+  const float offset = hard ? C.sp.contact_offset + C.sp.rest_offset : C.sp.contact_offset;
+  const float beta = hard ? C.sp.rest_offset : fmaf(kc, dt, C.sp.contact_d);
   const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
   PHASE_BEGIN();
   LinkCtx X = {C, L, l, (int)(threadIdx.x & 63u) - l, slot0, 0, G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull), (1ull << l) - 1ull,
@@ -1171,11 +1172,20 @@ DEV int link_contacts(const StepCtx& C, const EnvLds& L, int l, int slot0, float
           const float rel[3] = {r[0] - ac[0], r[1] - ac[1], r[2] - ac[2]};
           float phi, n[3];
           bool inside = !(dot3(rel, rel) > fmaf(dot3(ah, ah), 1.01f, 1e-8f));   // outside the volume's bounding sphere: outside the volume
+          if (hard) {     // ... or further from it than the contact offset (velocity-level solve: the corner's signed distance)
+            const float reach = sqrtf(dot3(ah, ah)) + offset + 1e-4f;
+            inside = !(dot3(rel, rel) > reach * reach * 1.01f);
+          }
           if (inside) {
 #pragma unroll
             for (int k = 0; k < 9; k++) lr[k] = m->abox_rot[jb][k];
             mm3(Rb, lr, ar);
-            inside = point_in_box(ar, ac, ah, r, &phi, n);
+            if (hard) {
+              float rc[3];
+              sphere_vs_box(ar, ac, ah, r, 0.0f, &phi, n, rc);
+            } else {
+              inside = point_in_box(ar, ac, ah, r, &phi, n);
+            }
           }
           if (inside) {
             float ta[3], nn[3], vrel[3], vrs[3];
@@ -1575,7 +1585,9 @@ DEV void boxes_contacts_fixed(const StepCtx& C, const EnvLds& L, int l, BodyRegs
 }
 
 // Evaluate every box contact slot (one lane each), then fold them into the owning bodies.
-template <int G, class SC, bool LINK = false>
+// HARD (ShfSimParams.solver == SHF_SOLVER_PGS): the slots only record candidate constraints (slot_eval), a corner's gap to a
+// fixed box is its signed distance (a constraint needs the gap of a corner still outside), and nothing is folded.
+template <int G, class SC, bool LINK = false, bool HARD = false>
 DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, float mu_shape, const float* g_art,
                         const BoxLane& BL, BoxMasks& BM, int link_slot0 = 0) {
   if constexpr (SC::NBX > 0) { boxes_contacts_fixed<G, SC, LINK>(C, L, l, B, mu_shape, g_art, BL, BM, link_slot0); return; }
@@ -1583,9 +1595,9 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
   const SceneDev* S = C.scene;
   const SlotLay Q = slot_lay<SC>(m, S);
   const int nb = m->nb, nbx = S->nboxes, T = 1 + nbx;
-  const float dt = C.sp.dt, kc = C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
-  const float offset = C.sp.contact_offset;
-  const float beta = fmaf(kc, dt, C.sp.contact_d);
+  const float dt = C.sp.dt, kc = HARD ? -1.0f : C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
+  const float offset = HARD ? C.sp.contact_offset + C.sp.rest_offset : C.sp.contact_offset;
+  const float beta = HARD ? C.sp.rest_offset : fmaf(kc, dt, C.sp.contact_d);
   const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
   PHASE_BEGIN();
   // corner slots
@@ -1621,7 +1633,12 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
       float Rs[9], hh[3] = {0.5f * bs.dim[0], 0.5f * bs.dim[1], 0.5f * bs.dim[2]}, bpos[3] = {ps[9], ps[10], ps[11]};
 #pragma unroll
       for (int i = 0; i < 9; i++) Rs[i] = ps[i];
-      if (!point_in_box(Rs, bpos, hh, r, &phi, n)) continue;
+      if constexpr (HARD) {
+        float rc[3];
+        sphere_vs_box(Rs, bpos, hh, r, 0.0f, &phi, n, rc);
+      } else {
+        if (!point_in_box(Rs, bpos, hh, r, &phi, n)) continue;
+      }
       slot_eval(o, phi, n, r, vs, vp, 0.5f * (bd.friction + bs.friction), kc, beta, veps, vdep, dt, offset);
     }
   }
@@ -1688,6 +1705,7 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
   BM.nlink = nlink;
   GROUP_SYNC();
   PHASE_MARK(20);
+  if constexpr (HARD) return;       // substep_hard_finish gathers the slots as constraints
   // fold (as the fixed-scene path: box lanes first, with the pair laws; then the articulation's lanes)
   const int kd = l - nb;
   if (kd >= 0 && kd < nbx && box_is_dynamic(S->box[kd])) {

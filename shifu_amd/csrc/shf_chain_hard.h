@@ -22,23 +22,6 @@
 #pragma once
 #include "shf_chain.h"
 
-#define HCK 8           /* constraints one env's solve holds on this kernel (ShfSimParams.max_contacts <= HCK) */
-#define HC_STRIDE 24    /* r[3] n[3] phi mu body rep p[3] bodyb repb . t1[3] t2[3] . .  (bodyb / repb: the other side of a self-contact,
-                           else -1; p: the impulse after the position iterations in world axes; t1, t2: the tangents of the contact frame) */
-#define HC_R 0
-#define HC_N 3
-#define HC_PHI 6
-#define HC_MU 7
-#define HC_BODY 8
-#define HC_REP 9
-#define HC_P 10
-#define HC_BODYB 13
-#define HC_REPB 14
-#define HC_T1 16
-#define HC_T2 19
-#define HC_PV0 15       /* the impulse after the velocity iterations, world axes (three spare words) */
-#define HC_PV1 22
-#define HC_PV2 23
 #define UF_STRIDE 8     /* U[6] invD . per link */
 template <class CD>
 struct HardTail {
@@ -47,28 +30,6 @@ struct HardTail {
   static_assert(NEVP + SHF_MAX_SELF_CONTACTS <= HCK * HCK * 9, "the gaps fit the response matrix's place");
 };
 
-// point velocity of the spatial velocity v6 (about O) at r
-DEV void hard_point(const float* v6, const float* r, float* o) {
-  float t[3];
-  cross3(v6, r, t);
-#pragma unroll
-  for (int k = 0; k < 3; k++) o[k] = v6[3 + k] + t[k];
-}
-DEV float hard_readlane(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
-// the tangents of a contact frame: t1 = (x or y) cross n normalised -- x unless n leans on it; t2 = n cross t1 (oracle: hard_solve)
-DEV void hard_frame(const float* n, float* t1, float* t2) {
-  float t[3];
-  if (fabsf(n[0]) < 0.7f) { t[0] = 0.0f; t[1] = -n[2]; t[2] = n[1]; }
-  else { t[0] = n[2]; t[1] = 0.0f; t[2] = -n[0]; }
-  const float il = rsqrt_spec(dot3(t, t));
-  float a[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) a[k] = t[k] * il;
-  float b[3];
-  cross3(n, a, b);
-#pragma unroll
-  for (int k = 0; k < 3; k++) { t1[k] = a[k]; t2[k] = b[k]; }
-}
 DEV void mat3_inv_spd(const float* A, float* Ai) {
   const float c00 = fmaf(A[4], A[8], -(A[5] * A[7])), c01 = fmaf(A[5], A[6], -(A[3] * A[8])), c02 = fmaf(A[3], A[7], -(A[4] * A[6]));
   const float id = rcp_spec(fmaf(A[0], c00, fmaf(A[1], c01, A[2] * c02)));
@@ -76,36 +37,6 @@ DEV void mat3_inv_spd(const float* A, float* Ai) {
   Ai[3] = c01 * id; Ai[4] = fmaf(A[0], A[8], -(A[2] * A[6])) * id; Ai[5] = fmaf(A[2], A[3], -(A[0] * A[5])) * id;
   Ai[6] = c02 * id; Ai[7] = fmaf(A[1], A[6], -(A[0] * A[7])) * id; Ai[8] = fmaf(A[0], A[4], -(A[1] * A[3])) * id;
 }
-// the root's LDL^T factors in LDS: L below the diagonal row by row (15), then 1/D (6)
-DEV void root_factors_store(const Ldlt6& F, float* o) {
-  int q = 0;
-#pragma unroll
-  for (int i = 1; i < 6; i++)
-#pragma unroll
-    for (int j = 0; j < i; j++) o[q++] = F.Lm[i][j];
-#pragma unroll
-  for (int j = 0; j < 6; j++) o[15 + j] = F.iD[j];
-}
-DEV void root_factors_apply(const float* o, const float* pA, float* x) {   // ldlt_substitute6 from the LDS copy
-  float y[6];
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-    float v = -pA[i];
-#pragma unroll
-    for (int k = 0; k < i; k++) v = fmaf(-o[i * (i - 1) / 2 + k], y[k], v);
-    y[i] = v;
-  }
-#pragma unroll
-  for (int i = 0; i < 6; i++) y[i] = y[i] * o[15 + i];
-#pragma unroll
-  for (int i = 5; i >= 0; i--) {
-    float v = y[i];
-#pragma unroll
-    for (int k = i + 1; k < 6; k++) v = fmaf(-o[k * (k - 1) / 2 + i], x[k], v);
-    x[i] = v;
-  }
-}
-
 // The link record of the solve (the joint record once the free outward pass is through with it, JREC_STRIDE words, 16-byte
 // aligned): S[6] U[6] 1/D -- four 16-byte LDS reads.
 #define LREC_U 6
@@ -175,11 +106,6 @@ DEV void hard_velocity(const ChainLds& L, const float* tail, const HardResp<CD>&
   }
   hard_point(dv, r, vel);
 }
-
-// Per-lane state of the solve that outlives a phase.
-struct HardOwner {     // the owner lane of contact c; velocity u and impulse p in the contact frame (n, t1, t2)
-  float mu, u[3], p[3], tgt, tgt_v, w10, w20, iwnn, Ti[3], rt;
-};
 
 // H4: the impulses in the constraint records as forces on their bodies -> what they add to the accelerations.  Both
 // impulse sets in one pass through the tree: q = 0 the impulses after the position iterations (HC_P), q = 1 after the

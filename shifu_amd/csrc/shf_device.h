@@ -911,16 +911,24 @@ DEV void contact_force_final(float* o, const float* ab, float dt) {
   }
 }
 
+#include "shf_hard.h"
+
 // One gym.simulate() for one env, executed by the G lanes of its group.
+//   HARD: the velocity-level contact solve (ShfSimParams.solver == SHF_SOLVER_PGS; shf_hard.h): the contact passes only record
+//   candidate constraints, the articulated-body solve runs free, substep_hard_finish solves and integrates.
 //   dofb[d]: q, qd in;  tau_cmd (explicit effort), pos/vel targets via pt_tgt/vt_tgt (LDS, may be null)
 //   fext: world force per reported body (global memory, this env) or nullptr; fpos: its world point of application or nullptr (CoM)
 //   contact_out: LDS/global float[nb*3] written by body lanes (may be nullptr)
 #define LANE_ROUNDS(G, DM) ((DM::NPC + (G) - 1) / (G) > 0 ? (DM::NPC + (G) - 1) / (G) : 1)
+template <int G, bool BOX, class DM, class LM, class SC, bool SELF, bool LINK>
+DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM& M, BodyRegs& B, const float* g, float* a, int nself,
+                             int self_slot0, int link_slot0, int nlink, float* contact_out);
 template <int G, bool BOX = false, class DM = DynDims, bool TW = false, class LM = LaneModel, class SC = DynScene,
-          bool SELF = false, bool LINK = false>
+          bool SELF = false, bool LINK = false, bool HARD = false>
 DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const LanePoints<LANE_ROUNDS(G, DM)>& P,
                  const float* pos_tgt, const float* vel_tgt, const float* fext, float mu_shape, float* contact_out,
                  const BoxLane& BL = BoxLane(), const float* fpos = nullptr) {
+  static_assert(!HARD || (DM::NPC == 0 && SC::NBX == 0 && G == 32), "the generic velocity-level solve: run-time shapes, 32 lanes per env");
   const ShfModel* m = C.m;
   const int nb = DM::nb(m), nd = DM::nd(m), np = DM::np(m);
   const float dt = C.sp.dt;
@@ -1019,7 +1027,17 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
       const float phi = fmaf(L.root[2] + r[2] - h, n[2], -rad);
       float* o = L.pt + i * PT_STRIDE;
       float on = 0.0f;
-      if (phi < K.offset) on = contact_point_response(K, pb, r, n, rad, phi, o);
+      if constexpr (HARD) {
+        // candidate constraint: gap from rest_offset inside the contact offset (oracle: substep, hard point loop)
+        if (phi < C.sp.contact_offset + C.sp.rest_offset) {
+          on = 1.0f;
+#pragma unroll
+          for (int k = 0; k < 3; k++) { o[PT_R + k] = fmaf(-rad, n[k], r[k]); o[PT_N + k] = n[k]; }
+          o[PT_F] = phi - C.sp.rest_offset; o[PT_F + 1] = mu; o[PT_F + 2] = 0.0f; o[PT_CT] = 0.0f; o[PT_BN] = 0.0f;
+        }
+      } else {
+        if (phi < K.offset) on = contact_point_response(K, pb, r, n, rad, phi, o);
+      }
       o[PT_ON] = on;
     }
   }
@@ -1041,7 +1059,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
         }
       }
     }
-  } else {
+  } else if constexpr (!HARD) {
     if (isdyn) {
       const int i0 = M.pt0, i1 = i0 + M.npt;
       for (int i = i0; i < i1; i++) {
@@ -1055,10 +1073,10 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
   // self-collision slots sit behind the articulation's sample points and the box slots
   int nself = 0;
   const int self_slot0 = np + (BOX ? box_slots(slot_lay<SC>(m, C.scene)) : 0);
-  if constexpr (SELF) nself = self_contacts<G>(C, L, l, isdyn, self_slot0, B, mu_shape);
+  if constexpr (SELF) nself = HARD ? self_contacts_eval<G>(C, L, l, self_slot0, mu_shape) : self_contacts<G>(C, L, l, isdyn, self_slot0, B, mu_shape);
   BoxMasks BM;
   const int link_slot0 = self_slot0 + (SELF ? SHF_MAX_SELF_CONTACTS : 0);   // 2 x SHF_MAX_LINK_CONTACTS slots when LINK
-  if (BOX) boxes_contacts<G, SC, LINK && BOX>(C, L, l, B, mu_shape, g, BL, BM, link_slot0);
+  if (BOX) boxes_contacts<G, SC, LINK && BOX, HARD>(C, L, l, B, mu_shape, g, BL, BM, link_slot0);
   PHASE_MARK(4);
 
   // joint-space efforts: one lane per dof
@@ -1203,6 +1221,10 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
   GROUP_SYNC();
   PHASE_MARK(8);
 
+  if constexpr (HARD) {
+    substep_hard_finish<G, BOX, DM, LM, SC, SELF, LINK>(C, L, l, M, B, g, a, nself, self_slot0, link_slot0, BM.nlink, contact_out);
+    return;
+  }
   // net contact force per reported body
   if (contact_out) {
     if constexpr (DM::NPC > 0 && G < 64) {

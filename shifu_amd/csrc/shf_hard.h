@@ -1,0 +1,724 @@
+// shf_hard.h -- the velocity-level contact solve (ShfSimParams.solver == SHF_SOLVER_PGS) for the body-per-lane kernels: any
+// articulation, with box actors, self-collision and link contacts.  What gymapi.SimParams.physx configures in the reference
+// (shifu/configs/env_config.py:50-58) and gym.simulate runs under (shifu/units/robot.py:69, shifu/gym/isaac_gym.py:140).
+// The chain-mapped A1 kernels have their own lane mapping of the same solve (shf_chain_hard.h); the pieces both share --
+// the constraint record, the contact frame, the sweep's arithmetic -- are defined here.
+//
+// ARITHMETIC: the operations of oracle/shf_oracle.c (substep with hard = 1, hard_solve, hc_apply) in the same order on the
+// same values; tests/test_gpu_parity.py holds the kernels to the oracle bit for bit.
+//
+// Per env (32 lanes; two envs per wavefront), after the FREE articulated-body solve of substep():
+//   records   body lane b -> S, U, 1/D and the velocity rate Dl of its body in its exchange slot; the root's / the free boxes'
+//             LDL^T factors in theirs
+//   gather    every active candidate slot of the sub-step (sample points, self-contacts, box corners / edges, rounded
+//             shapes, link contacts: slot_eval recorded location, normal, gap, friction) in the oracle's candidate order;
+//             the K <= 8 with the smallest gap become constraint records
+//   columns   W = J M^-1 J^T, a lane per (contact, axis of its frame): impulse up the tree, root solve, down to every
+//             constrained body; a free box answers with its own inverse inertia
+//   sweeps    projected Gauss-Seidel, a lane per contact (hard_sweeps)
+//   apply     the impulses (after the position iterations / after the velocity iterations) through the tree, level by level
+#pragma once
+
+#define HCK 8           /* constraints one env's solve holds (ShfSimParams.max_contacts <= HCK) */
+#define HC_STRIDE 24    /* r[3] n[3] phi mu body rep p[3] bodyb repb pv0 t1[3] t2[3] pv1 pv2 */
+#define HC_R 0
+#define HC_N 3
+#define HC_PHI 6
+#define HC_MU 7
+#define HC_BODY 8       /* solver body that receives +p: a moving body of the articulation, nb + k for free box k */
+#define HC_REP 9        /* reported body the force is logged on */
+#define HC_P 10         /* impulse after the position iterations, world axes */
+#define HC_BODYB 13     /* solver body that receives -p, or -1 (terrain, fixed box) */
+#define HC_REPB 14
+#define HC_T1 16        /* tangents of the contact frame */
+#define HC_T2 19
+#define HC_PV0 15       /* impulse after the velocity iterations, world axes (three spare words) */
+#define HC_PV1 22
+#define HC_PV2 23
+#define HG_LEV 8        /* deepest tree the generic solve walks (ShfModel.nlevels) */
+#define HG_WORDS (HCK * HC_STRIDE + HCK * HCK * 9)   /* extra LDS words per env: records + response matrix */
+// body record in the body's exchange slot (XCH_STRIDE words)
+#define HB_S 0
+#define HB_U 6
+#define HB_INVD 12
+#define HB_DL 14        /* velocity rate; after the owners' setup: impulse-pass words of set 1 */
+#define HB_PC 20        /* impulse-pass words of set 0 */
+#define HB_FDL 21       /* root / box record: LDL^T factors in words 0..20, then the velocity rate */
+
+DEV float hard_readlane(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
+// point velocity of the spatial velocity v6 (about O) at r
+DEV void hard_point(const float* v6, const float* r, float* o) {
+  float t[3];
+  cross3(v6, r, t);
+#pragma unroll
+  for (int k = 0; k < 3; k++) o[k] = v6[3 + k] + t[k];
+}
+// the tangents of a contact frame: t1 = (x or y) cross n normalised -- x unless n leans on it; t2 = n cross t1 (oracle: hard_solve)
+DEV void hard_frame(const float* n, float* t1, float* t2) {
+  float t[3];
+  if (fabsf(n[0]) < 0.7f) { t[0] = 0.0f; t[1] = -n[2]; t[2] = n[1]; }
+  else { t[0] = n[2]; t[1] = 0.0f; t[2] = -n[0]; }
+  const float il = rsqrt_spec(dot3(t, t));
+  float a[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) a[k] = t[k] * il;
+  float b[3];
+  cross3(n, a, b);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { t1[k] = a[k]; t2[k] = b[k]; }
+}
+// LDL^T factors of a 6x6 in LDS: L below the diagonal row by row (15), then 1/D (6)
+DEV void root_factors_store(const Ldlt6& F, float* o) {
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j < i; j++) o[q++] = F.Lm[i][j];
+#pragma unroll
+  for (int j = 0; j < 6; j++) o[15 + j] = F.iD[j];
+}
+DEV void root_factors_apply(const float* o, const float* pA, float* x) {   // ldlt_substitute6 from the LDS copy
+  float y[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    float v = -pA[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) v = fmaf(-o[i * (i - 1) / 2 + k], y[k], v);
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) y[i] = y[i] * o[15 + i];
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    float v = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) v = fmaf(-o[k * (k - 1) / 2 + i], x[k], v);
+    x[i] = v;
+  }
+}
+
+// Per-lane state of the solve: the owner lane of contact c; velocity u and impulse p in the contact frame (n, t1, t2)
+struct HardOwner {
+  float mu, u[3], p[3], tgt, tgt_v, w10, w20, iwnn, Ti[3], rt;
+};
+// owner lane: targets from the gap, the regularised diagonal block of W (written back) and its inverses (oracle: hard_solve,
+// "free velocities, targets, block inverses").  vs: start-of-step relative velocity, vf: under v_free (world axes).
+DEV void hard_owner_setup(const ShfSimParams& sp, const float* h, const float* vs, const float* vf, float* Wd, bool own, float idt, HardOwner& O) {
+  const float n[3] = {h[HC_N], h[HC_N + 1], h[HC_N + 2]};
+#pragma unroll
+  for (int k = 0; k < 3; k++) O.p[k] = 0.0f;
+  O.mu = h[HC_MU];
+  O.u[0] = dot3(n, vf); O.u[1] = dot3(h + HC_T1, vf); O.u[2] = dot3(h + HC_T2, vf);
+  const float phi = h[HC_PHI];
+  const float erp = sp.erp > 0.0f ? sp.erp : 0.2f;
+  float tg = phi >= 0.0f ? -(phi * idt) : rminf(erp * -(phi) * idt, sp.max_depen_vel);
+  float tv = phi >= 0.0f ? tg : 0.0f;
+  const float vn0 = dot3(n, vs);
+  if (sp.restitution > 0.0f && vn0 < -sp.bounce_threshold) { tg = rmaxf(tg, -(sp.restitution * vn0)); tv = rmaxf(tv, -(sp.restitution * vn0)); }
+  O.tgt = tg; O.tgt_v = tv;
+  float A[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) A[k] = Wd[k];
+  const float cfm = 1e-6f * ((A[0] + A[4]) + A[8]);
+  A[0] += cfm; A[4] += cfm; A[8] += cfm;
+  const float s01 = 0.5f * (A[1] + A[3]), s02 = 0.5f * (A[2] + A[6]), s12 = 0.5f * (A[5] + A[7]);
+  A[1] = s01; A[3] = s01; A[2] = s02; A[6] = s02; A[5] = s12; A[7] = s12;
+  if (own) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) Wd[k] = A[k];
+  }
+  O.iwnn = rcp_spec(A[0]);
+  O.w10 = A[3]; O.w20 = A[6];
+  const float id = rcp_spec(fmaf(A[4], A[8], -(A[5] * A[5])));
+  O.Ti[0] = A[8] * id; O.Ti[1] = -(A[5] * id); O.Ti[2] = A[4] * id;
+  O.rt = rcp_spec(A[4] + A[8]);
+}
+// Projected Gauss-Seidel at 32 lanes per env (two envs per wavefront): lane c < K owns contact c.  Position iterations,
+// then velocity iterations; after each phase the owner writes its impulse in world axes into the record (HC_P / HC_PV).
+// W: blocks (i, j) at W + (j * HCK + i) * 9.  oracle: hard_solve, "sweeps".
+DEV void hard_sweeps(HardOwner& O, float* hc, const float* W, int l, int K, int npos, int nvel) {
+  const int lane0 = (int)(threadIdx.x & 63u) - l;
+  const bool own = l < K;
+  int Kw = 0;      // the larger constraint count of the wavefront's envs (wave-uniform)
+#pragma unroll
+  for (int c = 0; c < HCK; c++)
+    if (__ballot(c < K) != 0ull) Kw = c + 1;
+  const bool hi = lane0 != 0;
+  const float* Wcol = W + (own ? l : 0) * 9;     // block (l, c) sits at Wcol + c * HCK * 9
+#pragma unroll 1
+  for (int phase = 0; phase < 2; phase++) {
+    const int sweeps = phase == 0 ? npos : nvel;
+    const float tg = phase == 0 ? O.tgt : O.tgt_v;
+#pragma unroll 1
+    for (int it = 0; it < sweeps; it++) {
+#pragma unroll 1
+      for (int c = 0; c < Kw; c++) {
+        // this lane's block of column c: in flight while the update is computed
+        float Wb[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) Wb[k] = Wcol[c * HCK * 9 + k];
+        // every owner lane computes its own update; lane c's is the one that counts
+        const float pn0 = O.p[0];
+        const float pn = rmaxf(fmaf(-(O.u[0] - tg), O.iwnn, pn0), 0.0f);
+        const float dn = pn - pn0;
+        const float ut1 = fmaf(dn, O.w10, O.u[1]), ut2 = fmaf(dn, O.w20, O.u[2]);
+        float ps1 = O.p[1] - fmaf(O.Ti[1], ut2, O.Ti[0] * ut1), ps2 = O.p[2] - fmaf(O.Ti[2], ut2, O.Ti[1] * ut1);
+        const float lim = O.mu * pn, lim2 = lim * lim;
+        if (fmaf(ps2, ps2, ps1 * ps1) > lim2) {
+          ps1 = fmaf(-O.rt, ut1, O.p[1]); ps2 = fmaf(-O.rt, ut2, O.p[2]);
+          const float nt2 = fmaf(ps2, ps2, ps1 * ps1);
+          const float sc1 = nt2 > lim2 ? lim * rsqrt_spec(nt2) : 1.0f;
+          ps1 *= sc1; ps2 *= sc1;
+        }
+        const bool commit = l == c && c < K;
+        float dp0 = dn, dp1 = ps1 - O.p[1], dp2 = ps2 - O.p[2];
+        if (commit) { O.p[0] = pn; O.p[1] = ps1; O.p[2] = ps2; }
+        // the change of contact c's impulse, from its owner lane (lane c of each env: wave lanes c and 32 + c) to every lane
+        {
+          const float a0 = hard_readlane(dp0, c), a1 = hard_readlane(dp1, c), a2 = hard_readlane(dp2, c);
+          const float b0 = hard_readlane(dp0, 32 + c), b1 = hard_readlane(dp1, 32 + c), b2 = hard_readlane(dp2, 32 + c);
+          dp0 = hi ? b0 : a0; dp1 = hi ? b1 : a1; dp2 = hi ? b2 : a2;
+        }
+        if (own && c < K) {
+#pragma unroll
+          for (int r = 0; r < 3; r++) O.u[r] = fmaf(Wb[3 * r + 2], dp2, fmaf(Wb[3 * r + 1], dp1, fmaf(Wb[3 * r], dp0, O.u[r])));
+        }
+      }
+    }
+    if (phase == 1 && nvel == 0) break;
+    if (own) {
+      float* h = hc + l * HC_STRIDE;
+      float pw[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) pw[r] = fmaf(O.p[2], h[HC_T2 + r], fmaf(O.p[1], h[HC_T1 + r], O.p[0] * h[HC_N + r]));
+      if (phase == 0) { h[HC_P] = pw[0]; h[HC_P + 1] = pw[1]; h[HC_P + 2] = pw[2]; }
+      else { h[HC_PV0] = pw[0]; h[HC_PV1] = pw[1]; h[HC_PV2] = pw[2]; }
+    }
+  }
+}
+
+// ============================================================ the generic (body-per-lane) form ============================
+// Response to the impulse e at r on solver body `src`: an articulation body (walk up its ancestors, root solve) or a free
+// box (its inverse inertia).  oracle: hc_impulse / hc_box_impulse.
+struct HgResp { int src, slev, spath[HG_LEV + 1]; float ub[HG_LEV + 1], dv0[6]; };
+DEV void hg_impulse(const ShfModel* m, const EnvLds& L, int nb, int src, const float* r, const float* e, HgResp& q) {
+  float p6[6], t[3];
+  cross3(r, e, t);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { p6[k] = -t[k]; p6[3 + k] = -e[k]; }
+  q.src = src; q.slev = 0;
+  if (src >= nb) { root_factors_apply(L.xch + src * XCH_STRIDE, p6, q.dv0); return; }
+  q.slev = m->level[src];
+  int b = src;
+#pragma unroll
+  for (int lev = HG_LEV; lev >= 1; lev--) {
+    q.ub[lev] = 0.0f; q.spath[lev] = -1;
+    if (lev <= q.slev) {
+      const float* rec = L.xch + b * XCH_STRIDE;
+      float sp = rec[HB_S] * p6[0];
+#pragma unroll
+      for (int j = 1; j < 6; j++) sp = fmaf(rec[HB_S + j], p6[j], sp);
+      q.ub[lev] = -sp;
+      q.spath[lev] = b;
+      const float tt = q.ub[lev] * rec[HB_INVD];
+#pragma unroll
+      for (int j = 0; j < 6; j++) p6[j] = fmaf(rec[HB_U + j], tt, p6[j]);
+      b = m->dyn[m->parent[b]];
+    }
+  }
+  if (m->fixed_base) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) q.dv0[k] = 0.0f;
+  } else {
+    root_factors_apply(L.xch, p6, q.dv0);
+  }
+}
+// velocity change of the point r of solver body `tgt` under that response (oracle: hc_cross)
+DEV void hg_velocity(const ShfModel* m, const EnvLds& L, int nb, const HgResp& q, int tgt, const float* r, float* vel) {
+  vel[0] = 0.0f; vel[1] = 0.0f; vel[2] = 0.0f;
+  if (tgt < 0 || q.src < 0) return;
+  if (q.src >= nb) { if (tgt == q.src) hard_point(q.dv0, r, vel); return; }
+  if (tgt >= nb) return;
+  const int lt = m->level[tgt];
+  int path[HG_LEV + 1];
+  int b = tgt;
+#pragma unroll
+  for (int lev = HG_LEV; lev >= 1; lev--) {
+    path[lev] = -1;
+    if (lev <= lt) { path[lev] = b; b = m->dyn[m->parent[b]]; }
+  }
+  float dv[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) dv[k] = q.dv0[k];
+#pragma unroll
+  for (int lev = 1; lev <= HG_LEV; lev++) {
+    if (lev <= lt) {
+      const float* rec = L.xch + path[lev] * XCH_STRIDE;
+      const float ubk = (lev <= q.slev && q.spath[lev] == path[lev]) ? q.ub[lev] : 0.0f;
+      float ua = rec[HB_U] * dv[0];
+#pragma unroll
+      for (int j = 1; j < 6; j++) ua = fmaf(rec[HB_U + j], dv[j], ua);
+      const float dq = (ubk - ua) * rec[HB_INVD];
+#pragma unroll
+      for (int j = 0; j < 6; j++) dv[j] = fmaf(rec[HB_S + j], dq, dv[j]);
+    }
+  }
+  hard_point(dv, r, vel);
+}
+
+// Candidate slots of one sub-step in the oracle's candidate order: evaluation slots of the sample points, self-contacts,
+// the free boxes' corner / edge slots, rounded shapes x boxes, link contacts.  Element `idx` of that sequence -> its slot
+// (nullptr: no such slot) and the constraint's bodies.
+struct HgSeq {
+  int nev, nself, nbx, T, nsph, nlink, self_slot0, link_slot0, P1, P2, P3, P4;
+};
+DEV const float* hg_slot_raw(const ShfModel* m, const SceneDev* S, const EnvLds& L, const SlotLay& Q, const HgSeq& H, int idx,
+                             int* ba, int* bb, int* ra, int* rb);
+// ... with the root of a fixed-base articulation as what it is to the solve: immovable, like terrain or a fixed box (-1); a
+// contact between two immovable things is no constraint (oracle: hc_offer)
+DEV const float* hg_slot(const ShfModel* m, const SceneDev* S, const EnvLds& L, const SlotLay& Q, const HgSeq& H, int idx,
+                         int* ba, int* bb, int* ra, int* rb) {
+  const float* o = hg_slot_raw(m, S, L, Q, H, idx, ba, bb, ra, rb);
+  if (o == nullptr) return nullptr;
+  if (m->fixed_base && *ba == 0) *ba = -1;
+  if (m->fixed_base && *bb == 0) *bb = -1;
+  return (*ba < 0 && *bb < 0) ? nullptr : o;
+}
+DEV const float* hg_slot_raw(const ShfModel* m, const SceneDev* S, const EnvLds& L, const SlotLay& Q, const HgSeq& H, int idx,
+                             int* ba, int* bb, int* ra, int* rb) {
+  const int nb = m->nb;
+  *bb = -1; *rb = -1;
+  if (idx < H.nev) {
+    const int i = m->neval > 0 ? m->pt_eval[idx] : idx;
+    if (i < 0) return nullptr;
+    *ra = m->pt_body[i]; *ba = m->dyn[*ra];
+    return L.pt + i * PT_STRIDE;
+  }
+  if (idx < H.P1) {
+    const float* o = L.pt + (H.self_slot0 + (idx - H.nev)) * PT_STRIDE;
+    const int pr = (int)o[PT_ON] - 1;
+    if (pr < 0) return nullptr;
+    *ra = m->cap_body[m->pair_a[pr]]; *rb = m->cap_body[m->pair_b[pr]];
+    *ba = m->dyn[*ra]; *bb = m->dyn[*rb];
+    return o;
+  }
+  if (idx < H.P2) {
+    const int j = idx - H.P1, kd = j / (8 * H.T), c = (j / H.T) % 8, tg = j % H.T;
+    if (!box_is_dynamic(S->box[kd])) return nullptr;
+    *ba = nb + kd; *ra = nb + kd;
+    return L.pt + corner_slot(Q, kd, c, tg) * PT_STRIDE;
+  }
+  if (idx < H.P3) {
+    const int j = idx - H.P2, si = j / H.nbx, kd = j % H.nbx;
+    if (!box_is_dynamic(S->box[kd])) return nullptr;
+    *ra = m->sph_body[si]; *ba = m->dyn[*ra];
+    *bb = nb + kd; *rb = nb + kd;
+    return L.pt + sphere_slot(Q, si, kd) * PT_STRIDE;
+  }
+  const float* o = L.pt + (H.link_slot0 + (idx - H.P3)) * PT_STRIDE;
+  if (o[PT_ON] == 0.0f) return nullptr;
+  const int body = link_code_body(o[PT_ON]), box = link_code_box(o[PT_ON]);
+  *ra = body; *ba = m->dyn[body];
+  if (box_is_dynamic(S->box[box])) { *bb = nb + box; *rb = nb + box; }
+  return o;
+}
+
+// gather: the K <= kmax candidates with the smallest gap (ties: candidate order), in candidate order, as constraint records.
+// Returns K.  oracle: hc_offer / hc_finish.
+template <int G>
+DEV int hg_gather(const StepCtx& C, const EnvLds& L, const SlotLay& Q, const HgSeq& H, int l, float* hc, int kmax) {
+  const ShfModel* m = C.m;
+  const SceneDev* S = C.scene;
+  const int lane0 = (int)(threadIdx.x & 63u) - l;
+  const unsigned long long gmask = G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
+  // pass 1: how many candidates
+  int total = 0;
+  for (int base = 0; base < H.P4; base += G) {
+    const int idx = base + l;
+    int ba, bb, ra, rb;
+    const float* o = idx < H.P4 ? hg_slot(m, S, L, Q, H, idx, &ba, &bb, &ra, &rb) : nullptr;
+    const bool on = o != nullptr && o[PT_ON] != 0.0f;
+    total += __builtin_popcountll((__ballot(on) >> lane0) & gmask);
+  }
+  const bool overflow = total > kmax;
+  if (overflow && l == 0 && C.dropped) *C.dropped += total - kmax;
+  // pass 2: the selected ones (all of them, or those with fewer than kmax candidates ahead in (gap, order)), numbered in order
+  int count = 0;
+  for (int base = 0; base < H.P4; base += G) {
+    const int idx = base + l;
+    int ba = -1, bb = -1, ra = -1, rb = -1;
+    const float* o = idx < H.P4 ? hg_slot(m, S, L, Q, H, idx, &ba, &bb, &ra, &rb) : nullptr;
+    bool sel = o != nullptr && o[PT_ON] != 0.0f;
+    if (__ballot(overflow && sel) != 0ull) {
+      // rank by a scan over every candidate: only when an env of the wavefront holds more than the solve does
+      int rank = 0;
+      const float ph = sel ? o[PT_F] : 0.0f;
+      if (overflow && sel) {
+        for (int j = 0; j < H.P4; j++) {
+          int a0, a1, a2, a3;
+          const float* oj = hg_slot(m, S, L, Q, H, j, &a0, &a1, &a2, &a3);
+          if (oj == nullptr || oj[PT_ON] == 0.0f) continue;
+          const float pj = oj[PT_F];
+          rank += (pj < ph || (pj == ph && j < idx)) ? 1 : 0;
+        }
+        sel = rank < kmax;
+      }
+    }
+    const unsigned long long mask = (__ballot(sel) >> lane0) & gmask;
+    if (sel) {
+      const int k = count + __builtin_popcountll(mask & ((1ull << l) - 1ull));
+      float* h = hc + k * HC_STRIDE;
+#pragma unroll
+      for (int j = 0; j < 3; j++) { h[HC_R + j] = o[PT_R + j]; h[HC_N + j] = o[PT_N + j]; }
+      h[HC_PHI] = o[PT_F]; h[HC_MU] = o[PT_F + 1];
+      h[HC_BODY] = __int_as_float(ba); h[HC_REP] = __int_as_float(ra);
+      h[HC_BODYB] = __int_as_float(bb); h[HC_REPB] = __int_as_float(rb);
+      const float n[3] = {o[PT_N], o[PT_N + 1], o[PT_N + 2]};
+      hard_frame(n, h + HC_T1, h + HC_T2);
+    }
+    count += __builtin_popcountll(mask);
+  }
+  return count;
+}
+
+// columns of W (oracle: hard_solve, "columns"): lane = 3 j + axis
+template <int G>
+DEV void hg_columns(const ShfModel* m, const EnvLds& L, int nb, int l, int K, const float* hc, float* W) {
+  static_assert(G >= 3 * HCK, "a lane per column");
+  const int j = (l * 11) >> 5, ax = l - 3 * j;
+  const bool col = l < 3 * K;
+  const float* hj = hc + (col ? j : 0) * HC_STRIDE;
+  const float rj[3] = {hj[HC_R], hj[HC_R + 1], hj[HC_R + 2]};
+  const int bsa = col ? __float_as_int(hj[HC_BODY]) : -1, bsb = col ? __float_as_int(hj[HC_BODYB]) : -1;
+  const float* ej = hj + (ax == 0 ? HC_N : (ax == 1 ? HC_T1 : HC_T2));
+  const float e[3] = {ej[0], ej[1], ej[2]};
+  HgResp qa, qb;
+  qa.src = -1; qb.src = -1;
+  if (bsa >= 0) hg_impulse(m, L, nb, bsa, rj, e, qa);
+  if (bsb >= 0) hg_impulse(m, L, nb, bsb, rj, e, qb);
+  for (int i = 0; i < HCK; i++) {
+    if (__ballot(i < K) == 0ull) break;
+    if (!(col && i < K)) continue;
+    const float* hi = hc + i * HC_STRIDE;
+    const float ri[3] = {hi[HC_R], hi[HC_R + 1], hi[HC_R + 2]};
+    const int bta = __float_as_int(hi[HC_BODY]), btb = __float_as_int(hi[HC_BODYB]);
+    float aa[3], ab[3], ba[3], bb[3], vw[3];
+    hg_velocity(m, L, nb, qa, bta, ri, aa);
+    hg_velocity(m, L, nb, qa, btb, ri, ab);
+    hg_velocity(m, L, nb, qb, bta, ri, ba);
+    hg_velocity(m, L, nb, qb, btb, ri, bb);
+#pragma unroll
+    for (int r = 0; r < 3; r++) vw[r] = (aa[r] - ab[r]) - (ba[r] - bb[r]);
+    float* Wb = W + (j * HCK + i) * 9 + ax;
+    Wb[0] = dot3(hi + HC_N, vw); Wb[3] = dot3(hi + HC_T1, vw); Wb[6] = dot3(hi + HC_T2, vw);
+  }
+}
+
+// start-of-step and free velocity of the point r of solver body `body` (oracle: hc_body_point)
+DEV void hg_body_point(const EnvLds& L, int nb, int body, const float* r, float dt, float* vs, float* vf) {
+  vs[0] = vs[1] = vs[2] = 0.0f; vf[0] = vf[1] = vf[2] = 0.0f;
+  if (body < 0) return;
+  const float* pv = L.pose + body * POSE_STRIDE + 12;
+  const float* D = L.xch + body * XCH_STRIDE + ((body == 0 || body >= nb) ? HB_FDL : HB_DL);
+  float v[6], v6[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) { v[k] = pv[k]; v6[k] = fmaf(dt, D[k], v[k]); }
+  hard_point(v, r, vs);
+  hard_point(v6, r, vf);
+}
+
+// where the accelerations the impulses add travel down the tree: set 0 in the acceleration array, set 1 in words of the
+// exchange slots that are dead by then (the body records after the columns; the root's / boxes' velocity-rate words)
+DEV float* hg_ac(const EnvLds& L, int q, int b) {
+  return q == 0 ? L.acc + b * 6 : (b == 0 ? L.xch + HB_FDL : L.xch + b * XCH_STRIDE + HB_S);
+}
+
+// The velocity-level solve of the body-per-lane sub-step, after its FREE articulated-body solve: records, gather, columns,
+// owners, sweeps, the impulse passes, integration (poses with the accelerations after the position iterations, velocities
+// after the velocity iterations), net contact forces.  `a`: lane 0 holds the root's free acceleration.
+template <int G, bool BOX, class DM, class LM, class SC, bool SELF, bool LINK>
+DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM& M, BodyRegs& B, const float* g, float* a, int nself,
+                             int self_slot0, int link_slot0, int nlink, float* contact_out) {
+  static_assert(G == 32, "two envs per wavefront (hard_sweeps)");
+  const ShfModel* m = C.m;
+  const SceneDev* S = C.scene;
+  const int nb = DM::nb(m), nd = DM::nd(m), nbx = BOX ? S->nboxes : 0, nbt = nb + nbx;
+  const float dt = C.sp.dt, idt = 1.0f / dt;
+  const bool isdyn = M.isdyn, moving = M.moving;
+  const int mylevel = M.level(), nl = DM::nlevels(m);
+  const int kd = l - nb;
+  const bool dynbox = BOX && kd >= 0 && kd < nbx && box_is_dynamic(S->box[kd]);
+  const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
+  float* hc = L.pt + (link_slot0 + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0)) * PT_STRIDE;
+  float* W = hc + HCK * HC_STRIDE;
+  const int npos = C.sp.pos_iters > 0 ? C.sp.pos_iters : 0, nvel = C.sp.vel_iters > 0 ? C.sp.vel_iters : 0;
+  const int kmax = C.sp.max_contacts > 0 ? (C.sp.max_contacts < HCK ? C.sp.max_contacts : HCK) : HCK;
+
+  // ---- records
+  float abox[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};      // a free box's free acceleration (its lane)
+  if (moving) {
+    float* rec = L.xch + l * XCH_STRIDE;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { rec[HB_S + k] = B.S[k]; rec[HB_U + k] = B.U[k]; }
+    rec[HB_INVD] = B.invD;
+  }
+  if (l == 0) {
+    float* rec = L.xch;
+    if (m->fixed_base) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) rec[HB_FDL + k] = 0.0f;
+    } else {
+      Ldlt6 F;
+      ldlt_factor6(B.IA, F);
+      root_factors_store(F, rec);
+      const float ang[3] = {L.root[10], L.root[11], L.root[12]}, lin[3] = {L.root[7], L.root[8], L.root[9]};
+      float wxv[3];
+      cross3(ang, lin, wxv);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { rec[HB_FDL + k] = a[k]; rec[HB_FDL + 3 + k] = (a[3 + k] + g[k]) + wxv[k]; }
+    }
+  }
+  if (dynbox) {
+    float* rec = L.xch + l * XCH_STRIDE;
+    Ldlt6 F;
+    ldlt_factor6(B.IA, F);
+    ldlt_substitute6(F, B.pA, abox);
+    root_factors_store(F, rec);
+    const float* row = L.root + 13 * (1 + kd);
+    const float ang[3] = {row[10], row[11], row[12]}, lin[3] = {row[7], row[8], row[9]};
+    float wxv[3];
+    cross3(ang, lin, wxv);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { rec[HB_FDL + k] = abox[k]; rec[HB_FDL + 3 + k] = (abox[3 + k] + gb[k]) + wxv[k]; }
+  }
+  // velocity rates down the tree: Dl = S qdd + Dl(parent)
+  for (int lev = 1; lev <= nl; lev++) {
+    GROUP_SYNC();
+    if (moving && mylevel == lev) {
+      const int pd = M.dynpar();
+      const float* dp = L.xch + pd * XCH_STRIDE + (pd == 0 ? HB_FDL : HB_DL);
+      const float qdd = L.dofb[M.dofi() * DOF_STRIDE + 4];
+      float* rec = L.xch + l * XCH_STRIDE;
+#pragma unroll
+      for (int k = 0; k < 6; k++) rec[HB_DL + k] = fmaf(B.S[k], qdd, dp[k]);
+    }
+  }
+  GROUP_SYNC();
+
+  // ---- gather
+  const SlotLay Q = BOX ? slot_lay<SC>(m, S) : SlotLay();
+  HgSeq H;
+  H.nev = m->neval > 0 ? m->neval : DM::np(m);
+  H.nself = SELF ? nself : 0; H.nbx = nbx; H.T = 1 + nbx; H.nsph = BOX ? m->nsph : 0; H.nlink = LINK ? nlink : 0;
+  H.self_slot0 = self_slot0; H.link_slot0 = link_slot0;
+  H.P1 = H.nev + H.nself; H.P2 = H.P1 + nbx * 8 * H.T; H.P3 = H.P2 + H.nsph * nbx; H.P4 = H.P3 + H.nlink;
+  const int K = hg_gather<G>(C, L, Q, H, l, hc, kmax);
+  GROUP_SYNC();
+
+  float ac0[2][6] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};   // root lane / box lanes: what the contacts add
+  if (__ballot(K > 0) != 0ull) {
+    // ---- columns
+    hg_columns<G>(m, L, nb, l, K, hc, W);
+    GROUP_SYNC();
+    // ---- owners
+    HardOwner O;
+    const bool own = l < K;
+    {
+      const float* h = hc + (own ? l : 0) * HC_STRIDE;
+      const float r[3] = {h[HC_R], h[HC_R + 1], h[HC_R + 2]};
+      const int ba = own ? __float_as_int(h[HC_BODY]) : -1, bb = own ? __float_as_int(h[HC_BODYB]) : -1;
+      float vsa[3], vfa[3], vsb[3], vfb[3], vs[3], vf[3];
+      hg_body_point(L, nb, ba, r, dt, vsa, vfa);
+      hg_body_point(L, nb, bb, r, dt, vsb, vfb);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { vf[k] = vfa[k] - vfb[k]; vs[k] = vsa[k] - vsb[k]; }
+      const int oi = own ? l : 0;
+      hard_owner_setup(C.sp, h, vs, vf, W + (oi * HCK + oi) * 9, own, idt, O);
+    }
+    GROUP_SYNC();
+    // ---- sweeps
+    hard_sweeps(O, hc, W, l, K, npos, nvel);
+    GROUP_SYNC();
+    // ---- the impulses through the tree, both sets (oracle: hc_apply)
+    const int NQ = nvel > 0 ? 2 : 1;
+    float pc[2][6] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};
+    if (isdyn || dynbox) {
+      for (int c = 0; c < K; c++) {
+        const float* h = hc + c * HC_STRIDE;
+        const bool ona = __float_as_int(h[HC_BODY]) == l, onb = __float_as_int(h[HC_BODYB]) == l;
+        if (!ona && !onb) continue;
+        const float r[3] = {h[HC_R], h[HC_R + 1], h[HC_R + 2]};
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const float f[3] = {h[q == 0 ? HC_P : HC_PV0] * idt, h[q == 0 ? HC_P + 1 : HC_PV1] * idt, h[q == 0 ? HC_P + 2 : HC_PV2] * idt};
+          float t[3];
+          cross3(r, f, t);
+          if (ona) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { pc[q][k] -= t[k]; pc[q][3 + k] -= f[k]; }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { pc[q][k] += t[k]; pc[q][3 + k] += f[k]; }
+          }
+        }
+      }
+    }
+    float uc[2] = {0.0f, 0.0f};
+    for (int lev = nl; lev >= 1; lev--) {
+      if (moving && mylevel == lev) {
+        float* rec = L.xch + l * XCH_STRIDE;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          float sp = B.S[0] * pc[q][0];
+#pragma unroll
+          for (int j = 1; j < 6; j++) sp = fmaf(B.S[j], pc[q][j], sp);
+          uc[q] = -sp;
+          const float tt = uc[q] * B.invD;
+#pragma unroll
+          for (int j = 0; j < 6; j++) { pc[q][j] = fmaf(B.U[j], tt, pc[q][j]); rec[(q == 0 ? HB_PC : HB_DL) + j] = pc[q][j]; }
+        }
+      }
+      GROUP_SYNC();
+      if (isdyn && mylevel == lev - 1) {
+        for (int kk = 0; kk < M.nchild; kk++) {
+          const int cb = kk < LANE_CHILDREN ? M.child[kk < LANE_CHILDREN ? kk : 0] : m->child_list[M.child0 + kk];
+          const float* o = L.xch + cb * XCH_STRIDE;
+#pragma unroll
+          for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int j = 0; j < 6; j++) pc[q][j] += o[(q == 0 ? HB_PC : HB_DL) + j];
+        }
+      }
+    }
+    if (l == 0) {
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        if (m->fixed_base) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) ac0[q][k] = 0.0f;
+        } else {
+          root_factors_apply(L.xch, pc[q], ac0[q]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        float* o = hg_ac(L, q, 0);
+#pragma unroll
+        for (int k = 0; k < 6; k++) o[k] = ac0[q][k];
+      }
+    }
+    if (dynbox) {
+#pragma unroll
+      for (int q = 0; q < 2; q++) root_factors_apply(L.xch + l * XCH_STRIDE, pc[q], ac0[q]);
+    }
+    for (int lev = 1; lev <= nl; lev++) {
+      GROUP_SYNC();
+      if (moving && mylevel == lev) {
+        const int pd = M.dynpar();
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const float* pa = hg_ac(L, q, pd);
+          float acp[6];
+#pragma unroll
+          for (int j = 0; j < 6; j++) acp[j] = pa[j];
+          float ua = B.U[0] * acp[0];
+#pragma unroll
+          for (int j = 1; j < 6; j++) ua = fmaf(B.U[j], acp[j], ua);
+          const float qc = (uc[q] - ua) * B.invD;
+          float* o = hg_ac(L, q, l);
+#pragma unroll
+          for (int j = 0; j < 6; j++) o[j] = fmaf(B.S[j], qc, acp[j]);
+          L.dofb[M.dofi() * DOF_STRIDE + 2 + q] = qc;
+        }
+      }
+    }
+    GROUP_SYNC();
+    (void)NQ;
+  }
+
+  // ---- integration (oracle substep(), "semi-implicit Euler" with hard = 1)
+  const int vq = nvel > 0 ? 1 : 0;      // the set the velocities take
+  if (l < nd) {
+    float* D = L.dofb + l * DOF_STRIDE;
+    const float vl = M.vel_limit;
+    const float qf = D[4];
+    const float qdv = K > 0 ? qf + D[2 + vq] : qf, qdp = K > 0 ? qf + D[2] : qf;
+    const float qd = rclampf(fmaf(dt, qdv, D[1]), -vl, vl);
+    const float qp = rclampf(fmaf(dt, qdp, D[1]), -vl, vl);
+    D[0] = fmaf(dt, qp, D[0]);
+    D[1] = qd;
+  }
+  if ((l == 0 && !m->fixed_base) || dynbox) {
+    // a free body: the root (its origin is O: p = 0) or a box at B.p
+    float* Rt = l == 0 ? L.root : L.root + 13 * (1 + kd);
+    const float* af = l == 0 ? a : abox;
+    const float* gg = l == 0 ? g : gb;
+    float av[6], apz[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      av[j] = K > 0 ? af[j] + ac0[vq][j] : af[j];
+      apz[j] = K > 0 ? af[j] + ac0[0][j] : af[j];
+    }
+    const float ang[3] = {Rt[10], Rt[11], Rt[12]}, lin[3] = {Rt[7], Rt[8], Rt[9]};
+    const float pp[3] = {l == 0 ? 0.0f : B.p[0], l == 0 ? 0.0f : B.p[1], l == 0 ? 0.0f : B.p[2]};
+    float wxv[3], axp[3], axq[3];
+    cross3(ang, lin, wxv);
+    cross3(av, pp, axp);
+    cross3(apz, pp, axq);
+    const float damp = 1.0f / fmaf(dt, C.sp.angular_damping, 1.0f);
+    float wn[3], vn[3], wp[3], vp[3];
+    const float wmax = C.sp.max_ang_vel;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      wn[k] = fmaf(dt, av[k], ang[k]) * damp;
+      wp[k] = fmaf(dt, apz[k], ang[k]) * damp;
+      if (l == 0) {
+        vn[k] = fmaf(dt, av[3 + k] + gg[k] + wxv[k], lin[k]);
+        vp[k] = fmaf(dt, apz[3 + k] + gg[k] + wxv[k], lin[k]);
+      } else {
+        vn[k] = fmaf(dt, av[3 + k] + gg[k] + axp[k] + wxv[k], lin[k]);
+        vp[k] = fmaf(dt, apz[3 + k] + gg[k] + axq[k] + wxv[k], lin[k]);
+      }
+    }
+    const float w2 = dot3(wn, wn);
+    if (w2 > wmax * wmax) {
+      const float sc2 = wmax * rsqrt_spec(w2);
+#pragma unroll
+      for (int k = 0; k < 3; k++) wn[k] *= sc2;
+    }
+    const float p2 = dot3(wp, wp);
+    if (p2 > wmax * wmax) {
+      const float sc2 = wmax * rsqrt_spec(p2);
+#pragma unroll
+      for (int k = 0; k < 3; k++) wp[k] *= sc2;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { Rt[10 + k] = wn[k]; Rt[7 + k] = vn[k]; Rt[k] = fmaf(dt, vp[k], Rt[k]); }
+    const float hx = 0.5f * dt * wp[0], hy = 0.5f * dt * wp[1], hz = 0.5f * dt * wp[2];
+    const float x = Rt[3], y = Rt[4], z = Rt[5], ww = Rt[6];
+    const float nx = x + fmaf(hx, ww, fmaf(hy, z, -(hz * y)));
+    const float ny = y + fmaf(hy, ww, fmaf(hz, x, -(hx * z)));
+    const float nz = z + fmaf(hz, ww, fmaf(hx, y, -(hy * x)));
+    const float nw = ww - fmaf(hx, x, fmaf(hy, y, hz * z));
+    const float inv = rsqrt_spec(fmaf(nw, nw, fmaf(nz, nz, fmaf(ny, ny, nx * nx))));
+    Rt[3] = nx * inv; Rt[4] = ny * inv; Rt[5] = nz * inv; Rt[6] = nw * inv;
+  }
+  // ---- net contact force per reported body and box actor: the final impulses / dt, constraint order (oracle: hc_forces)
+  if (contact_out) {
+    GROUP_SYNC();
+    float f[3] = {0.0f, 0.0f, 0.0f};
+    if (l < nbt) {
+      for (int c = 0; c < K; c++) {
+        const float* h = hc + c * HC_STRIDE;
+        const int rep = __float_as_int(h[HC_REP]), repb = __float_as_int(h[HC_REPB]);
+        if (rep != l && repb != l) continue;
+        const float pf[3] = {(nvel > 0 ? h[HC_PV0] : h[HC_P]) * idt, (nvel > 0 ? h[HC_PV1] : h[HC_P + 1]) * idt, (nvel > 0 ? h[HC_PV2] : h[HC_P + 2]) * idt};
+        if (rep == l) { f[0] += pf[0]; f[1] += pf[1]; f[2] += pf[2]; }
+        else { f[0] -= pf[0]; f[1] -= pf[1]; f[2] -= pf[2]; }
+      }
+    }
+    GROUP_SYNC();
+    if (l < nbt) { contact_out[3 * l] = f[0]; contact_out[3 * l + 1] = f[1]; contact_out[3 * l + 2] = f[2]; }
+  }
+  GROUP_SYNC();
+}

@@ -16,7 +16,7 @@ REWARD_NAMES = ["reward_reaching", "reward_success"]   # build_reward_functions 
 class FusedAbbEnv:
     def __init__(self, num_envs: int = 4096, device="cuda:0", seed: int = 42, rank: int = 0, world_size: int = 1,
                  group: int = None, dt: float = 0.02, decimation: int = 5, episode_length_s: float = 20.0,
-                 extra_boxes=(), link_contacts: bool = None, mapping: str = None):
+                 extra_boxes=(), link_contacts: bool = None, mapping: str = None, solver: str = None):
         self.device = torch.device(device)
         self.num_envs = num_envs
         self.env_id_offset = rank * num_envs
@@ -42,12 +42,20 @@ class FusedAbbEnv:
             # With link contacts 'split' exists too (the link passes run on the box wave; 0.166 vs 0.186 ms for 'body').
             scene = not extra_boxes
             mapping = "split" if (scene and group == 16) else "chain" if (scene and not link_contacts and group == 32) else "body"
+        # solver: "pgs" = the velocity-level contact solve with the reference's PhysX settings (env_config.py:50-58) -- the default,
+        # on the run-time-shaped body-per-lane kernel at 32 lanes per env (csrc/shf_hard.h; round 5: correct, not yet fast:
+        # 1.5 ms per vec-step); "compliant" = rounds 1-4's spring-damper law on the kernels compiled for this scene (0.15 ms).
+        # Asking for a lane mapping / width that only the compliant kernels have selects them.
+        if solver is None:
+            solver = "pgs" if (mapping in (None, "body") and group in (None, 32)) else "compliant"
+        self.solver = solver
+        if solver == "pgs":
+            group, mapping = 32, "body"
         if mapping == "chain" and self.link_contacts:
             raise ValueError("FusedAbbEnv: mapping='chain' is compiled for the rod-only scene; with link_contacts=True use "
                              "mapping='split' (16 lanes per env) or 'body'")
         self.mapping = mapping
-        # (config 5 keeps the compliant contact law: the velocity-level solve is not built for scenes with box actors yet)
-        self.sim_params = default_sim_params(dt=dt, solver="compliant")
+        self.sim_params = default_sim_params(dt=dt, solver=solver)
         self.sim = Sim(self.sim_params, self.device)
         self.sim.set_plane(1.0)
         self.sim.set_articulation(self.cm.blob)

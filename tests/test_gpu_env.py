@@ -255,7 +255,9 @@ def test_fused_abb_env_tracks_hook_env():
     from shifu_amd.gym.abb_fused import FusedAbbEnv
     n = 32
     hook = _abb(n)
-    fused = FusedAbbEnv(num_envs=n, seed=5, link_contacts=True, group=64)    # the facade turns link contacts on (units.py:68) and runs 64 lanes per env
+    # the facade turns link contacts on (units.py:68) and the physx settings into the velocity-level solve (env_config.py:50-58)
+    fused = FusedAbbEnv(num_envs=n, seed=5, link_contacts=True, solver="pgs")
+    assert hook.isg_env.sim.solver == "pgs"
     be = hook.isg_env.sim.backend
     S = fused.sim.tensors
     for tid in (_abi.T_DOF_STATE, _abi.T_ROOT_STATE, _abi.T_BODY_STATE, _abi.T_JACOBIAN, _abi.T_CONTACT):

@@ -366,14 +366,14 @@ def test_fused_a1_env_on_the_benchmark_scene_matches_oracle_bitwise_at_full_size
 
 
 def test_long_differential_run_of_every_kernel_form(oracle):
-    """tools/fuzz_parity.py trimmed to fit the suite: 320 vec-steps x 192 envs (64 with link contacts) of all twelve kernel
-    forms of both tasks against the oracle, every tensor compared every 80 steps, through hundreds of resets
+    """tools/fuzz_parity.py trimmed to fit the suite: 320 vec-steps x 192 envs (64 with link contacts) of all fifteen kernel
+    forms of both tasks -- twelve of the compliant law, three of the velocity-level solve -- against the oracle, every tensor compared every 80 steps, through hundreds of resets
     (the 2000-step run is profiles/r03_fuzz_parity.txt)."""
     _need_gpu()
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_parity
     out = fuzz_parity.run(steps=320, envs=192, every=80, link_envs=64)
-    assert len(out) == 12 and all(r["equal"] for r in out)
+    assert len(out) == 15 and all(r["equal"] for r in out)
     assert sum(r["resets"] for r in out if r["task"] == "a1") > 300 and sum(r["resets"] for r in out if r["task"] == "abb") > 300
 
 
@@ -762,6 +762,126 @@ def test_abb_scene_with_link_contacts_matches_oracle_bitwise(oracle):
     assert np.isfinite(root).all() and np.isfinite(dof).all()
 
 
+@pytest.mark.parametrize("link", [False, True])
+def test_abb_scene_under_the_velocity_level_solve_matches_oracle_bitwise(oracle, link):
+    """The config-5 scene under ShfSimParams.solver = SHF_SOLVER_PGS through gym.simulate: the body-per-lane sub-step with the
+    generic solve (csrc/shf_hard.h, k_sim_step<32, BOX, SELF, LINK, HARD>) -- the free cube as a solver body of its own (its
+    corners against the table by signed distance, the rod's capsule ends against the cube with impulses on both sides), with
+    link contacts the arm's volumes and points against table / cube / pad -- every tensor, bit for bit, 90 sub-steps of the
+    blind joint ramp that presses rod and links onto cube and table."""
+    _need_gpu()
+    from shifu_amd.abb_task import ABB_BASE_POS, ABB_DEFAULT_DOF_POS, abb_boxes, abb_model
+    rng = np.random.default_rng(17)
+    cm = abb_model(link_contacts=link)
+    m = cm.blob
+    sp = H.sim_params(dt=0.02, angular_damping=0.5, solver="pgs")
+    boxes = abb_boxes()
+    n, A, B = 24, 4, m.nb + 3
+    sim, dof, root = _scene_on_gpu(cm, sp, boxes, [b.pos for b in boxes], n, 32)
+    dof[:, 0] = np.tile(np.array(ABB_DEFAULT_DOF_POS, np.float32), n) + rng.uniform(-0.05, 0.05, n * m.nd)
+    root[0::A, :3] = ABB_BASE_POS
+    root[2::A, :3] = np.stack([rng.uniform(0.03, 0.08, n), rng.uniform(-0.03, 0.03, n), rng.uniform(0.125, 0.14, n)], 1)
+    yaw = rng.uniform(-np.pi, np.pi, n)
+    root[2::A, 5], root[2::A, 6] = np.sin(yaw / 2), np.cos(yaw / 2)
+    sim.tensors[_abi.T_SIM_DOF].copy_(torch.from_numpy(dof))
+    sim.tensors[_abi.T_SIM_ROOT].copy_(torch.from_numpy(root))
+    fr = np.ones(n, np.float32)
+    tgt = dof[:, 0].copy()
+    touched = cube_held = False
+    oracle.dropped(reset=True)
+    for it in range(90):
+        if it % 6 == 0:
+            tgt = dof[:, 0].copy()
+            tgt[1::m.nd] += 0.02
+            tgt[2::m.nd] -= 0.01
+        sim.set_dof_command(_abi.T_POS_TARGET, torch.from_numpy(tgt).cuda())
+        sim.step()
+        sim.refresh(_abi.REFRESH_ALL)
+        contact, bstate, jac = oracle.scene_step(m, sp, boxes, n, dof, root, pos_target=tgt, friction=fr, want_jacobian=True)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(sim.tensors[_abi.T_DOF_STATE].cpu().numpy(), dof, err_msg=f"dof step {it}")
+        np.testing.assert_array_equal(sim.tensors[_abi.T_ROOT_STATE].cpu().numpy(), root, err_msg=f"root step {it}")
+        np.testing.assert_array_equal(sim.tensors[_abi.T_CONTACT].cpu().numpy(), contact, err_msg=f"contact step {it}")
+        np.testing.assert_array_equal(sim.tensors[_abi.T_BODY_STATE].cpu().numpy(), bstate, err_msg=f"body step {it}")
+        c = contact.reshape(n, B, 3)
+        assert np.isfinite(c).all() and np.isfinite(dof).all(), f"step {it}"      # (assert_array_equal counts nan == nan)
+        touched |= bool(np.abs(c[:, :m.nb]).sum() > 0)
+        cube_held |= bool((np.abs(c[:, m.nb + 1, 2] - 0.981) < 0.05).mean() > 0.5)
+    assert touched, "the arm met a cube / the table"
+    assert cube_held, "the table carries the cubes' weight"
+    assert np.isfinite(root).all() and np.isfinite(dof).all()
+    torch.cuda.synchronize()
+    assert int(sim.tensors[_abi.T_DROPPED].sum()) == oracle.dropped()
+
+
+def test_generic_articulation_under_the_velocity_level_solve_matches_oracle_bitwise(oracle):
+    """An articulation that is NOT the A1's shape -- the 13-body variant (feet merged into the shanks), self-collision on,
+    thrown onto rough terrain -- through gym.simulate under SHF_SOLVER_PGS: the generic solve without box actors (floating
+    root: its LDL^T factors answer every column), capsule-pair constraints between two bodies of the tree."""
+    _need_gpu()
+    from shifu_amd.model import asset_path, compile_urdf
+    cm = compile_urdf(asset_path("a1.urdf"), honour_dont_collapse=False, default_dof_drive_mode=_abi.DOF_MODE_EFFORT, self_collision=True)
+    m = cm.blob
+    assert m.nb == 13
+    for d in range(m.nd):
+        m.damping[d] = 0.5
+    rng = np.random.default_rng(34)
+    sp = H.sim_params(angular_damping=0.5, solver="pgs")
+    n = 40
+    terr, hs = _terrain(rng, rough=True)
+    dof, root = _random_states(m, n, rng, z_lo=0.1, z_hi=0.5)
+    lo, up = np.array(m.lower[:m.nd]), np.array(m.upper[:m.nd])
+    dof[:, 0] = rng.uniform(lo, up, (n, m.nd)).astype(np.float32).reshape(-1)
+    dof[:, 1] = rng.uniform(-6, 6, n * m.nd)
+    fr = rng.uniform(0.5, 1.25, n).astype(np.float32)
+    sim = _make_sim(cm, sp, n, terr, hs, group=32)
+    T = sim.tensors
+    T[_abi.T_SIM_DOF].copy_(torch.from_numpy(dof))
+    T[_abi.T_SIM_ROOT].copy_(torch.from_numpy(root))
+    T[_abi.T_FRICTION].copy_(torch.from_numpy(fr))
+    hits = 0
+    for it in range(60):
+        eff = rng.uniform(-25, 25, n * m.nd).astype(np.float32)
+        sim.set_dof_command(_abi.T_EFFORT, torch.from_numpy(eff).cuda())
+        sim.step()
+        sim.refresh(_abi.REFRESH_ALL)
+        contact, bstate = oracle.step(m, sp, n, dof, root, effort=eff, friction=fr, terrain=terr, heights=hs, want_contact=True,
+                                      want_body_state=True)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(T[_abi.T_DOF_STATE].cpu().numpy(), dof, err_msg=f"dof step {it}")
+        np.testing.assert_array_equal(T[_abi.T_ROOT_STATE].cpu().numpy(), root, err_msg=f"root step {it}")
+        np.testing.assert_array_equal(T[_abi.T_CONTACT].cpu().numpy(), contact, err_msg=f"contact step {it}")
+        hits += int((np.abs(contact).sum(1) > 0).sum())
+    assert hits > 500 and np.isfinite(root).all()
+    sim.destroy()
+
+
+@pytest.mark.parametrize("link", [False, True])
+def test_fused_abb_step_under_the_velocity_level_solve_matches_oracle_bitwise(oracle, link):
+    """ShifuVecEnv.step for AbbPushBox with FusedAbbEnv(solver='pgs') -- k_abb_step<32, DynDims, DynScene, LINK, 0, HARD> --
+    against the oracle: 120 vec-steps with re-spawns, every tensor."""
+    _need_gpu()
+    from shifu_amd.gym.abb_fused import FusedAbbEnv
+    n = 48
+    env = FusedAbbEnv(num_envs=n, seed=11, link_contacts=link, solver="pgs")
+    assert env.sim_params.solver == _abi.SOLVER_PGS and "Lb1EE" in env.task.kernel_symbol()
+    bufs = {k: env.sim.tensors[t].cpu().numpy().copy() for k, t in _ABB_SIM_T.items()}
+    bufs.update({k: env.task.tensors[t].cpu().numpy().copy() for k, t in _ABB_T.items()})
+    rng = np.random.default_rng(2)
+    resets = 0
+    for it in range(120):
+        raw = (2 * rng.random((n, 3)) - 1).astype(np.float32) * 1.3
+        env.task.step(torch.from_numpy(raw).cuda())
+        oracle.abb_step(env.cm.blob, env.sim_params, env.boxes, env.task_params, n, 0, bufs, raw)
+        if it % 10 == 9 or it < 3:
+            torch.cuda.synchronize()
+            for k, t in list(_ABB_SIM_T.items()) + list(_ABB_T.items()):
+                got = (env.sim.tensors if k in _ABB_SIM_T else env.task.tensors)[t].cpu().numpy().reshape(bufs[k].shape)
+                np.testing.assert_array_equal(got, bufs[k], err_msg=f"{k} step {it}")
+        resets += int(bufs["reset"].sum())
+    assert np.isfinite(bufs["obs"]).all()
+
+
 _ABB_SIM_T = {"dof_state": _abi.T_DOF_STATE, "root_state": _abi.T_ROOT_STATE, "body_state": _abi.T_BODY_STATE,
               "contact": _abi.T_CONTACT, "jacobian": _abi.T_JACOBIAN, "friction": _abi.T_FRICTION}
 _ABB_T = {"actions": _abi.ABB_ACTIONS, "obs": _abi.ABB_OBS, "rew": _abi.ABB_REW, "reset": _abi.ABB_RESET,
@@ -799,11 +919,12 @@ def test_fused_abb_step_matches_oracle_bitwise(oracle, group, generic):
     generic = generic is True or link_generic
     extra = [box_desc([0.05, 0.05, 0.02], 0.0, 0.5, True, [0.25, 0.25, 0.11])] if generic else []
     env = FusedAbbEnv(num_envs=n, seed=11, group=group, extra_boxes=extra, link_contacts=link,
-                      mapping="body" if (levels or (link and not link_split)) else ("chain" if chain else ("split" if link_split else None)))
+                      mapping="body" if (levels or (link and not link_split)) else ("chain" if chain else ("split" if link_split else None)),
+                      solver="compliant")       # (the kernel forms of the compliant law; the velocity-level solve has its own tests)
     assert env.mapping == ("split" if (split or link_split) else "chain" if (not generic and not link and not levels and group < 64) else "body")
     assert ("FixedDims" in env.task.kernel_symbol() or split or link_split) != bool(generic)
-    assert ("Lb1ELi0EE" in env.task.kernel_symbol()) == (link and not generic and not link_split)
-    assert env.task.kernel_symbol().endswith("Li6EE") == (env.mapping == "chain")
+    assert ("Lb1ELi0ELb0EE" in env.task.kernel_symbol()) == (link and not generic and not link_split)
+    assert env.task.kernel_symbol().endswith("Li6ELb0EE") == (env.mapping == "chain")
     env.task.tensors[_abi.ABB_EP_LEN].copy_(torch.randint(0, 200, (n,)))   # staggered time-outs
     torch.cuda.synchronize()
     bufs = {k: env.sim.tensors[t].cpu().numpy().copy() for k, t in _ABB_SIM_T.items()}

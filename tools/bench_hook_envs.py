@@ -47,7 +47,7 @@ def main():
     # refuses: enable_graph_hooks is for hooks that are pure tensor code, like A1Conditional's)
     from shifu_amd.gym.abb_fused import FusedAbbEnv
     for g in (() if args.only_hooks else (64, 32, 16)):
-        v, ms = run(FusedAbbEnv(num_envs=args.envs, group=g, link_contacts=False), args.steps * 5)
+        v, ms = run(FusedAbbEnv(num_envs=args.envs, group=g, link_contacts=False, solver="compliant"), args.steps * 5)
         print(json.dumps({"env": "FusedAbbEnv (config 5, fused single launch, lanes/env=%d)" % g, "envs": args.envs,
                           "env_steps_per_s": v, "ms_per_step": ms}))
     from examples.a1_conditional.a1_conditional import A1Conditional

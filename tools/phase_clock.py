@@ -51,7 +51,8 @@ def main():
     from shifu_amd.gym.a1_fused import FusedA1Env
     from shifu_amd.gym.abb_fused import FusedAbbEnv
     # --abb: the sub-step phases (0-10) of the push-box env; its kernel has no marks outside the sub-steps
-    env = (FusedAbbEnv(num_envs=4096, group=G, link_contacts=link, mapping="split" if split else ("body" if (levels or link) else "chain")) if abb else
+    env = (FusedAbbEnv(num_envs=4096, group=G, link_contacts=link, mapping="split" if split else ("body" if (levels or link) else "chain"),
+                       solver="pgs" if pgs else "compliant") if abb else
            FusedA1Env(num_envs=4096, group=G, mapping="chain" if chain else "body", solver="pgs" if pgs else "compliant",
                       self_collision=selfc, terrain=terrain))
     if chain:
