@@ -183,18 +183,20 @@ def test_create_sim_honours_the_physx_solver_settings_and_names_the_ignored_ones
 
 
 def test_pgs_support_query():
-    """shf_model_pgs_supported: the A1 on its own, with or without self-collision -- yes; with box actors, the ABB arm -- no
-    (the facade then keeps the compliant law and says so)."""
+    """shf_model_pgs_supported: the A1 on its own (chain-mapped kernels), the ABB arm with its three box actors and any other
+    scene of at most 32 bodies + boxes (the generic solve, csrc/shf_hard.h) -- yes; more box actors than the scene holds -- no
+    (the facade would then keep the compliant law and say so)."""
     import ctypes as C
     from shifu_amd._lib import lib
     from shifu_amd.abb_task import abb_model
     from tests.helpers import a1_model
     a1 = a1_model().blob
     assert lib().shf_model_pgs_supported(C.byref(a1), 0) == 1
-    assert lib().shf_model_pgs_supported(C.byref(a1), 1) == 0
-    a1s = a1_model(self_collision=True).blob
-    assert lib().shf_model_pgs_supported(C.byref(a1s), 0) == 1
-    assert lib().shf_model_pgs_supported(C.byref(abb_model(link_contacts=False).blob), 0) == 0
+    assert lib().shf_model_pgs_supported(C.byref(a1), 1) == 1
+    assert lib().shf_model_pgs_supported(C.byref(a1_model(self_collision=True).blob), 0) == 1
+    abb = abb_model(link_contacts=True).blob
+    assert lib().shf_model_pgs_supported(C.byref(abb), 3) == 1
+    assert lib().shf_model_pgs_supported(C.byref(abb), 5) == 0 and lib().shf_model_pgs_supported(None, 0) == 0
 
 
 def test_trimesh_recovery_with_sparse_height_levels_and_shifted_border():
