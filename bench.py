@@ -289,8 +289,13 @@ def main():
         if args.link_contacts and (args.no_link_contacts or args.mapping == "chain"):
             raise SystemExit("bench.py: --link-contacts contradicts --no-link-contacts / --mapping chain (compiled for the rod-only scene)")
         args.link_contacts = not (args.no_link_contacts or args.mapping == "chain")
-        mapping = args.mapping or ("split" if (args.group or 16) == 16 else ("chain" if (not args.link_contacts and (args.group or 16) == 32) else "body"))
-        group = args.group or 16
+        if args.solver is None and args.mapping is None and args.group is None:
+            args.solver = "pgs"      # FusedAbbEnv's own default: the reference's PhysX settings (generic kernel, 32 lanes per env)
+        if args.solver == "pgs":
+            mapping, group = "body", 32
+        else:
+            mapping = args.mapping or ("split" if (args.group or 16) == 16 else ("chain" if (not args.link_contacts and (args.group or 16) == 32) else "body"))
+            group = args.group or 16
     else:    # the fused A1 env's own default: the chain-per-lane kernel at 32 lanes when there is no self-collision
         mapping = args.mapping or ("chain" if ((args.group or 32) == 32 or ((args.group or 32) == 16 and not args.self_collision)) else "body")
         group = args.group or 32
@@ -501,7 +506,9 @@ def main():
                          "traffic": None if not prof else prof.get("traffic_bytes"),
                          "traffic_source": None if not prof else prof.get("source"),
                          "kernel": ("k_a1_chain_pgs" if (kernel == "k_a1_step" and args.solver == "pgs") else "k_a1_chain" if (kernel == "k_a1_step" and mapping == "chain") else "k_abb_step_ws" if (kernel == "k_abb_step" and mapping == "split") else kernel), "kernel_ms": kern_ms, "alg_bytes_per_env_step": b_alg,
-                         "note": "latency/ALU-bound by design: a few KB of compulsory traffic per env-step (DESIGN.md 5)",
+                         "note": "latency/ALU-bound by design: a few KB of compulsory traffic per env-step (DESIGN.md 5)" +
+                                 ("; alg_bytes counts the env's own tensors (state in, state / body_state / contact / Jacobian / obs out): link contacts "
+                                  "add work on the LDS-resident model and scene, not tensors, so B_alg is the rod-only scene's" if (abb and args.link_contacts) else ""),
                          "secondary": secondary},
         }
         if kern_ms > out["ms_per_step"]:

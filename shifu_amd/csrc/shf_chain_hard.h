@@ -718,6 +718,9 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
     for (int c = 0; c < HCK; c++)
       if (__ballot(c < K) != 0ull) Kw = c + 1;
     const bool hi = lane0 != 0;
+#ifdef SHF_PHASE_CLOCK
+    if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_phase_cycles[20 + Kw], 1ull);     // histogram of the wavefronts' constraint counts
+#endif
     const float* Wcol = tail + T::W + (own ? l : 0) * 9;     // block (l, c) sits at Wcol + c * HCK * 9
 #pragma unroll 1
     for (int phase = 0; phase < 2; phase++) {
@@ -728,6 +731,10 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
 #pragma unroll
         for (int c = 0; c < HCK; c++) {
           if (c >= Kw) break;
+          // an open, unloaded contact whose normal velocity keeps it open asks for nothing (oracle: the same test): when that
+          // is so for contact c of both envs of the wavefront the visit is skipped
+          const bool act = !(O.p[0] == 0.0f && O.p[1] == 0.0f && O.p[2] == 0.0f && !(O.u[0] < tg));
+          if (__ballot(l == c && c < K && act) == 0ull) continue;
           // this lane's block of column c: in flight while the update is computed
           float Wb[9];
 #pragma unroll
@@ -745,8 +752,8 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
             const float sc1 = nt2 > lim2 ? lim * rsqrt_spec(nt2) : 1.0f;
             ps1 *= sc1; ps2 *= sc1;
           }
-          const bool commit = l == c && c < K;
-          float dp0 = dn, dp1 = ps1 - O.p[1], dp2 = ps2 - O.p[2];
+          const bool commit = l == c && c < K && act;
+          float dp0 = commit ? dn : 0.0f, dp1 = commit ? ps1 - O.p[1] : 0.0f, dp2 = commit ? ps2 - O.p[2] : 0.0f;
           if (commit) { O.p[0] = pn; O.p[1] = ps1; O.p[2] = ps2; }
           // the change of contact c's impulse, from its owner lane (lane c of each env: wave lanes c and 32 + c) to every lane
           {

@@ -153,6 +153,10 @@ DEV void hard_sweeps(HardOwner& O, float* hc, const float* W, int l, int K, int 
     for (int it = 0; it < sweeps; it++) {
 #pragma unroll 1
       for (int c = 0; c < Kw; c++) {
+        // an open, unloaded contact whose normal velocity keeps it open asks for nothing (oracle: the same test): when that is
+        // so for contact c of every env of the wavefront the visit is skipped
+        const bool act = !(O.p[0] == 0.0f && O.p[1] == 0.0f && O.p[2] == 0.0f && !(O.u[0] < tg));
+        if (__ballot(l == c && c < K && act) == 0ull) continue;
         // this lane's block of column c: in flight while the update is computed
         float Wb[9];
 #pragma unroll
@@ -170,8 +174,8 @@ DEV void hard_sweeps(HardOwner& O, float* hc, const float* W, int l, int K, int 
           const float sc1 = nt2 > lim2 ? lim * rsqrt_spec(nt2) : 1.0f;
           ps1 *= sc1; ps2 *= sc1;
         }
-        const bool commit = l == c && c < K;
-        float dp0 = dn, dp1 = ps1 - O.p[1], dp2 = ps2 - O.p[2];
+        const bool commit = l == c && c < K && act;
+        float dp0 = commit ? dn : 0.0f, dp1 = commit ? ps1 - O.p[1] : 0.0f, dp2 = commit ? ps2 - O.p[2] : 0.0f;
         if (commit) { O.p[0] = pn; O.p[1] = ps1; O.p[2] = ps2; }
         // the change of contact c's impulse, from its owner lane (lane c of each env: wave lanes c and 32 + c) to every lane
         {

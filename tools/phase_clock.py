@@ -94,6 +94,8 @@ def main():
               f"{buf[30] / max(buf[31], 1):.2f} in its first env; stage 0 (broad phase) = mark 24")
     if pgs:
         extra_names[0:2] = ['  H3 sweeps (position + velocity iterations)', '  H4 impulse passes (inward / root / outward, x2)']
+        hist = [buf[20 + k] for k in range(9)]
+        print("  wavefronts by constraint count Kw = 0..8 (all blocks, per sub-step): " + " ".join(f"{100.0 * h / max(sum(hist), 1):.1f}%" for h in hist))
     for k, nme in enumerate(NAMES + extra_names):
         print(f"  {k:2d} {nme:52s} {buf[k] / steps:9.0f}  {100.0 * buf[k] / tot:5.1f} %")
 
