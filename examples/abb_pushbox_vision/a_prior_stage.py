@@ -31,10 +31,19 @@ class RandPosBox(Box):
         self.euler_range = {"low": [0, 0, -np.pi], "high": [0, 0, np.pi]}
 
     def _reset_root_state(self, env_ids):
+        # The reference draws one np.random.uniform per env in a Python loop (a_prior_stage.py:39-51: 1.8 of AbbPushBox's
+        # 2.1 ms per vec-step on this backend's hook path, profiles/r04_hook_path.md); this example draws the same
+        # distributions -- U(low, high) per component -- for all reset envs at once, on the device.  (Not the same numbers:
+        # torch's generator instead of NumPy's.)
         rows = self.root_indices[env_ids]
-        pos = to_torch(np.array([np.random.uniform(**self.pos_range) for _ in env_ids]), dtype=torch.float,
-                       device=self.device)
-        eul = to_torch(np.array([np.random.uniform(**self.euler_range) for _ in env_ids]), device=self.device)
+        if getattr(self, "_pos_lo", None) is None:
+            self._pos_lo = to_torch(self.pos_range["low"], dtype=torch.float, device=self.device)
+            self._pos_hi = to_torch(self.pos_range["high"], dtype=torch.float, device=self.device)
+            self._eul_lo = to_torch(self.euler_range["low"], dtype=torch.float, device=self.device)
+            self._eul_hi = to_torch(self.euler_range["high"], dtype=torch.float, device=self.device)
+        n = len(env_ids)
+        pos = self._pos_lo + (self._pos_hi - self._pos_lo) * torch.rand(n, 3, device=self.device)
+        eul = self._eul_lo + (self._eul_hi - self._eul_lo) * torch.rand(n, 3, device=self.device)
         self.env.root_state[rows, :3] = pos
         self.env.root_state[rows, 3:7] = quat_from_euler_xyz(eul[:, 0], eul[:, 1], eul[:, 2])
         self.env.root_state[rows, 7:13] = 0.
@@ -53,11 +62,14 @@ class AbbRobot(ArmRobot):
         super().init_buffers()
         self.min_ee_pos = to_torch(self.cfg.min_ee_pos, device=self.device)
         self.max_ee_pos = to_torch(self.cfg.max_ee_pos, device=self.device)
+        # the constant target orientation, built once (the reference rebuilds it from a Python list every step,
+        # a_prior_stage.py:70: a host-to-device copy per step, which also keeps the hook out of a hipGraph capture)
+        self.tar_quat = torch.tensor([0., 1., 0., 0.], device=self.device).repeat((self.env.num_envs, 1))
 
     def step(self, actions):
         tar_pos = self.ee_pose[:, 0, :3] + actions * self.end_effector_velocity * self.env.dt
         tar_pos = torch.clip(tar_pos, self.min_ee_pos, self.max_ee_pos)
-        tar_quat = torch.tensor([0., 1., 0., 0.], device=self.device).repeat((self.env.num_envs, 1))
+        tar_quat = self.tar_quat
         self.dof_targets[:] = self.inverse_kinematics(torch.cat([tar_pos, tar_quat], dim=1))
         self.apply_dof_targets(self.dof_targets)
 

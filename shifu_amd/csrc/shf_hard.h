@@ -458,6 +458,7 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
   const int npos = C.sp.pos_iters > 0 ? C.sp.pos_iters : 0, nvel = C.sp.vel_iters > 0 ? C.sp.vel_iters : 0;
   const int kmax = C.sp.max_contacts > 0 ? (C.sp.max_contacts < HCK ? C.sp.max_contacts : HCK) : HCK;
 
+  PHASE_BEGIN();
   // ---- records
   float abox[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};      // a free box's free acceleration (its lane)
   if (moving) {
@@ -508,6 +509,7 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
     }
   }
   GROUP_SYNC();
+  PHASE_MARK(24);
 
   // ---- gather
   const SlotLay Q = BOX ? slot_lay<SC>(m, S) : SlotLay();
@@ -518,12 +520,14 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
   H.P1 = H.nev + H.nself; H.P2 = H.P1 + nbx * 8 * H.T; H.P3 = H.P2 + H.nsph * nbx; H.P4 = H.P3 + H.nlink;
   const int K = hg_gather<G>(C, L, Q, H, l, hc, kmax);
   GROUP_SYNC();
+  PHASE_MARK(25);
 
   float ac0[2][6] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};   // root lane / box lanes: what the contacts add
   if (__ballot(K > 0) != 0ull) {
     // ---- columns
     hg_columns<G>(m, L, nb, l, K, hc, W);
     GROUP_SYNC();
+    PHASE_MARK(26);
     // ---- owners
     HardOwner O;
     const bool own = l < K;
@@ -541,8 +545,10 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
     }
     GROUP_SYNC();
     // ---- sweeps
+    PHASE_MARK(27);
     hard_sweeps(O, hc, W, l, K, npos, nvel);
     GROUP_SYNC();
+    PHASE_MARK(28);
     // ---- the impulses through the tree, both sets (oracle: hc_apply)
     const int NQ = nvel > 0 ? 2 : 1;
     float pc[2][6] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};
@@ -638,6 +644,7 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
     }
     GROUP_SYNC();
     (void)NQ;
+    PHASE_MARK(29);
   }
 
   // ---- integration (oracle substep(), "semi-implicit Euler" with hard = 1)

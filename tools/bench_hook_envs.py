@@ -43,8 +43,17 @@ def main():
     v, ms = run(AbbPushBox(cfg), args.steps)
     print(json.dumps({"env": "AbbPushBox (config 5, hook path, 6 sub-steps of 20 ms)", "envs": args.envs,
                       "env_steps_per_s": v, "ms_per_step": ms}))
-    # (AbbPushBox's hooks build tensors from Python lists inside `step` -- host-to-device copies, which a stream capture
-    # refuses: enable_graph_hooks is for hooks that are pure tensor code, like A1Conditional's)
+    if args.graph_hooks:
+        # (this repo's example builds its constant tensors once and re-spawns the boxes with one vectorised draw, so its hooks
+        # are pure tensor code and can be replayed; the reference's own file rebuilds a tensor from a Python list per step)
+        try:
+            env = AbbPushBox(cfg)
+            env.enable_graph_hooks()
+            v, ms = run(env, args.steps)
+            print(json.dumps({"env": "AbbPushBox (config 5, hook path, hooks replayed from hipGraphs)", "envs": args.envs,
+                              "env_steps_per_s": v, "ms_per_step": ms}))
+        except Exception as exc:          # noqa: BLE001 -- report and go on with the other envs
+            print(json.dumps({"env": "AbbPushBox graph hooks", "error": str(exc)[:300]}))
     from shifu_amd.gym.abb_fused import FusedAbbEnv
     for g in (() if args.only_hooks else (64, 32, 16)):
         v, ms = run(FusedAbbEnv(num_envs=args.envs, group=g, link_contacts=False, solver="compliant"), args.steps * 5)

@@ -96,6 +96,10 @@ def main():
         extra_names[0:2] = ['  H3 sweeps (position + velocity iterations)', '  H4 impulse passes (inward / root / outward, x2)']
         hist = [buf[20 + k] for k in range(9)]
         print("  wavefronts by constraint count Kw = 0..8 (all blocks, per sub-step): " + " ".join(f"{100.0 * h / max(sum(hist), 1):.1f}%" for h in hist))
+    if pgs and abb:
+        extra_names[7:13] = ['hard: body records + velocity rates', 'hard: gather candidates', 'hard: response matrix columns',
+                             'hard: owner setup', 'hard: sweeps', 'hard: impulse passes']
+        tot = sum(buf[:30])
     for k, nme in enumerate(NAMES + extra_names):
         print(f"  {k:2d} {nme:52s} {buf[k] / steps:9.0f}  {100.0 * buf[k] / tot:5.1f} %")
 
