@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SHF_ABI_VERSION 12
+#define SHF_ABI_VERSION 13
 
 #define SHF_MAX_BODIES 32 /* reported rigid bodies per articulation        */
 #define SHF_MAX_DOFS 32
@@ -290,7 +290,12 @@ enum {
   SHF_T_DROPPED = 16,    /* (N) i32: contacts dropped since the host last cleared it -- self-contacts beyond
                           * SHF_MAX_SELF_CONTACTS, link contacts beyond SHF_MAX_LINK_CONTACTS (optional binding)   */
   SHF_T_BODY_FORCE_POS = 17, /* (N*B, 3) f32 apply_rigid_body_force_at_pos_tensors: world points of application */
-  SHF_T_COUNT = 18
+  SHF_T_BODY_MASS_SCALE = 18, /* (N, nb) f32, optional binding: per-env factor on the mass and rotational inertia of each of the
+                          * articulation's bodies (centre of mass unchanged) -- gym.set_actor_rigid_body_properties(env, actor,
+                          * props, recomputeInertia=True) with props[b].mass = factor * the asset's (shifu/units/units.py:104-110).
+                          * Read once per launch, in the inertia phase; unbound = 1 everywhere.  Bodies welded to their
+                          * parent carry no mass of their own here (ShfModel.mass is 0 for them): their factor is unused. */
+  SHF_T_COUNT = 19
 };
 
 /* refresh masks: gym.refresh_*_tensor (isaac_gym.py:139-154) */

@@ -3,6 +3,7 @@
 TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg.  The product package (shifu_amd/) never imports it.
 """
+import contextlib
 import ctypes as C
 import os
 import subprocess
@@ -117,6 +118,23 @@ def step(model, params, n, dof_state, root_state, *, nsteps=1, terrain=None, hei
        _p(pos_target, ct), _p(vel_target, ct), _p(body_force, ct), _p(body_force_pos, ct), _p(friction, C.c_float),
        _p(contact, ct), _p(bstate, ct))
     return contact, bstate
+
+
+@contextlib.contextmanager
+def body_mass_scale(scale):
+    """Per-env factors on the bodies' mass and inertia (SHF_T_BODY_MASS_SCALE; gym.set_actor_rigid_body_properties with
+    recomputeInertia=True, shifu/units/units.py:104-110) for the step / a1_step / abb_step calls inside the `with`:
+    scale (n, nb) float32, row = the call's env index."""
+    a = np.ascontiguousarray(scale, np.float32)
+    fns = [getattr(lib(), "shf_oracle_set_body_mass_scale" + sfx) for sfx in ("_f32", "_f64")]
+    for f in fns:
+        f.restype = None
+        f(_p(a, C.c_float))
+    try:
+        yield a
+    finally:
+        for f in fns:
+            f(None)
 
 
 def accel(model, params, dof_state, root_state, effort, f64=True):

@@ -1,7 +1,7 @@
 """ctypes mirrors of the PODs in include/shifu_amd.h (keep in lock-step)."""
 import ctypes as C
 
-SHF_ABI_VERSION = 12
+SHF_ABI_VERSION = 13
 MAP_BODY, MAP_CHAIN, MAP_CHAIN_SPLIT = 0, 1, 2   # shf_sim_set_mapping
 MAX_BODIES = 32
 MAX_DOFS = 32
@@ -102,7 +102,7 @@ class ShfAbbTaskParams(C.Structure):
 
 # tensor ids (shf_sim_*)
 T_DOF_STATE, T_ROOT_STATE, T_BODY_STATE, T_CONTACT, T_JACOBIAN, T_SIM_DOF, T_SIM_ROOT, T_EFFORT, \
-    T_POS_TARGET, T_VEL_TARGET, T_BODY_FORCE, T_FRICTION, T_HEIGHTS, T_MODEL, T_SIM_CONTACT, T_SCENE, T_DROPPED, T_BODY_FORCE_POS, T_COUNT = range(19)
+    T_POS_TARGET, T_VEL_TARGET, T_BODY_FORCE, T_FRICTION, T_HEIGHTS, T_MODEL, T_SIM_CONTACT, T_SCENE, T_DROPPED, T_BODY_FORCE_POS, T_BODY_MASS_SCALE, T_COUNT = range(20)
 
 REFRESH_DOF, REFRESH_ROOT, REFRESH_BODY, REFRESH_CONTACT, REFRESH_JACOBIAN, REFRESH_ALL = 1, 2, 4, 8, 16, 31
 

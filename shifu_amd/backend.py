@@ -186,6 +186,8 @@ class Sim:
         elif group != 64:
             check(lib().shf_sim_set_group(self._h, group))
         for tid in range(_abi.T_COUNT):
+            if tid == _abi.T_BODY_MASS_SCALE:        # optional: bound by set_body_mass_scale()
+                continue
             if tid == _abi.T_HEIGHTS:
                 if self._heights is not None:
                     self.bind(tid, self._heights)
@@ -205,6 +207,21 @@ class Sim:
             if tid == _abi.T_FRICTION:
                 t.fill_(1.0)
             self.bind(tid, t)
+
+    def set_body_mass_scale(self, scale) -> torch.Tensor:
+        """Per-env factors on the mass and inertia tensor of each body of the articulation (centre of mass unchanged):
+        gym.set_actor_rigid_body_properties(env, actor, props, recomputeInertia=True) with props[b].mass = factor x the
+        asset's (shifu/units/units.py:104-110).  scale: (num_envs, nb), > 0; returns the bound tensor -- later edits in place
+        are seen by the next step.  None unbinds (factors 1)."""
+        if scale is None:
+            check(lib().shf_sim_bind(self._h, _abi.T_BODY_MASS_SCALE, None))
+            self.tensors.pop(_abi.T_BODY_MASS_SCALE, None)
+            return None
+        t = torch.as_tensor(scale, dtype=torch.float32).to(self.device).reshape(self.num_envs, self.model.nb).contiguous().clone()
+        if not bool((t > 0).all()):
+            raise ValueError("set_body_mass_scale: factors must be positive")
+        self.bind(_abi.T_BODY_MASS_SCALE, t)
+        return t
 
     # -- launches -----------------------------------------------------------
     # step / refresh / set_dof_command are what a user's control loop calls decimation x 3 times per vec-step

@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256, 2) void k_sim_step_chain_pgs(SimArgs A) {
   StepCtx C;
   C.m = m; C.sp = A.sp; C.terr.t = A.terr; C.terr.h = A.heights; C.scene = nullptr;
   C.dropped = A.dropped ? A.dropped + e : nullptr;
+  C.mscale = A.mscale ? A.mscale + (size_t)e * nb : nullptr;
   const float mu = A.friction ? A.friction[e] : 1.0f;
   const int dl = l < nd ? l : 0;
   DofLane X = {L.dofb[dl * DOF_STRIDE], L.dofb[dl * DOF_STRIDE + 1], (A.effort && l < nd) ? A.effort[(size_t)e * nd + l] : 0.0f,

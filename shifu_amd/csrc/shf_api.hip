@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
   StepCtx C;
   C.m = m; C.sp = A.sp; C.terr.t = A.terr; C.terr.h = A.heights; C.scene = scene;
   C.dropped = A.dropped ? A.dropped + e : nullptr;
+  C.mscale = A.mscale ? A.mscale + (size_t)e * nb : nullptr;
   const float mu = A.friction ? A.friction[e] : 1.0f;
   LaneModel M;
   lane_model_load<DynDims>(m, l, M);
@@ -319,6 +320,7 @@ DEV void a1_step_body(const A1Args& A) {
   StepCtx C;
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = nullptr;
   C.dropped = A.S.dropped ? A.S.dropped + e : nullptr;
+  C.mscale = A.S.mscale ? A.S.mscale + (size_t)e * nb : nullptr;
   const float mu = A.S.friction[e];
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
   // (with self-collision the per-lane model constants stay in LDS: the pair tests need the registers)
@@ -627,6 +629,7 @@ __global__ __launch_bounds__(256, (G >= 32 && SC::NBX > 0) ? 2 : 1) void k_abb_s
   StepCtx C;
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = scene;
   C.dropped = A.S.dropped ? A.S.dropped + e : nullptr;
+  C.mscale = A.S.mscale ? A.S.mscale + (size_t)e * nb : nullptr;
   const float mu = A.S.friction[e];
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
   LaneModel M;
@@ -717,6 +720,7 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
   StepCtx C;
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = scene;
   C.dropped = (LINK && live && !arm && A.S.dropped) ? A.S.dropped + e : nullptr;   // (the box wave counts the dropped link contacts)
+  C.mscale = (live && A.S.mscale) ? A.S.mscale + (size_t)e * DM::nb(m) : nullptr;
   const float mu = live ? A.S.friction[e] : 0.0f;
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
   // Per-lane model constants.  Without link contacts they are loaded once and stay in registers.  With them the kernel has 256
@@ -1184,6 +1188,7 @@ extern "C" int shf_sim_layout(const ShfSim* sim, int32_t id, int64_t shape[4], i
       shape[3] = sim->model.fixed_base ? nd : nd + 6; break;
     case SHF_T_EFFORT: case SHF_T_POS_TARGET: case SHF_T_VEL_TARGET: *ndim = 1; shape[0] = N * nd; break;
     case SHF_T_FRICTION: *ndim = 1; shape[0] = N; break;
+    case SHF_T_BODY_MASS_SCALE: *ndim = 2; shape[0] = N; shape[1] = nb; break;
     case SHF_T_DROPPED: *ndim = 1; shape[0] = N; *dtype = 1; break;
     case SHF_T_HEIGHTS:
       *dtype = 2;
@@ -1242,6 +1247,7 @@ static SimArgs sim_args(const ShfSim* s, bool internal) {
   A.body_force = nullptr;
   A.body_force_pos = nullptr;
   A.friction = (const float*)s->t[SHF_T_FRICTION];
+  A.mscale = (const float*)s->t[SHF_T_BODY_MASS_SCALE];
   A.contact = (float*)s->t[internal ? SHF_T_SIM_CONTACT : SHF_T_CONTACT];
   A.dropped = (int32_t*)s->t[SHF_T_DROPPED];
   return A;

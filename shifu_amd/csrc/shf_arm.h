@@ -138,7 +138,7 @@ struct ArmLane {
       for (int k = 0; k < 3; k++) B.p[k] = pb[9 + k];
 #pragma unroll
       for (int k = 0; k < 6; k++) B.v[k] = pb[12 + k];
-      body_inertia(M, B);
+      body_inertia(M, B, C.mscale, l);
     }
     PHASE_MARK(2);
     const float kc = C.sp.contact_k, dc = C.sp.contact_d, veps = C.sp.friction_vel;

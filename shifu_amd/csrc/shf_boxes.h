@@ -787,7 +787,7 @@ DEV int self_contacts(const StepCtx& C, const EnvLds& L, int l, bool isdyn, int 
       const int p = (int)o[PT_ON] - 1;
       const int da = m->dyn[m->cap_body[m->pair_a[p]]], db = m->dyn[m->cap_body[m->pair_b[p]]];
       // each side implicit in its own acceleration, scaled by 1 + (own mass) / (other mass): see the oracle's self_scales
-      const float ma = m->mass[da], mb = m->mass[db];
+      const float ma = body_mass(C, da), mb = body_mass(C, db);
       if (da == l) slot_accumulate_fb(B.IA, B.pA, o, 1.0f, dt, 1.0f, 1.0f + ma / mb);
       if (db == l) slot_accumulate_fb(B.IA, B.pA, o, -1.0f, dt, 1.0f, 1.0f + mb / ma);
     }
@@ -806,7 +806,7 @@ DEV void self_contact_forces(const StepCtx& C, const EnvLds& L, int l, int slot0
     const float* o = L.pt + (slot0 + k) * PT_STRIDE;
     const int p = (int)o[PT_ON] - 1;
     const int ba = m->cap_body[m->pair_a[p]], bb = m->cap_body[m->pair_b[p]];
-    const float ma = m->mass[m->dyn[ba]], mb = m->mass[m->dyn[bb]];
+    const float ma = body_mass(C, m->dyn[ba]), mb = body_mass(C, m->dyn[bb]);
     if (ba == l) slot_force_fb(o, abr, 1.0f, C.sp.dt, 1.0f, 1.0f + ma / mb, f);
     if (bb == l) slot_force_fb(o, abr, -1.0f, C.sp.dt, 1.0f, 1.0f + mb / ma, f);
   }

@@ -365,7 +365,18 @@ DEV void chain_substep(const StepCtx& C, const ChainLds& L, int l, DofLane& X, c
     for (int k = 0; k < 3; k++) pp[k] = pb[9 + k];
 #pragma unroll
     for (int k = 0; k < 6; k++) vb[k] = pb[12 + k];
-    rigid_inertia_p(m->mass[myb], m->com[myb], m->inertia[myb], Rb, pp, vb, IA, pA);
+    {
+      float mass = m->mass[myb], I6[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) I6[k] = m->inertia[myb][k];
+      if (C.mscale) {     // SHF_T_BODY_MASS_SCALE bound: this env's factor on the body's mass and inertia
+        const float s = C.mscale[myb];
+        mass *= s;
+#pragma unroll
+        for (int k = 0; k < 6; k++) I6[k] *= s;
+      }
+      rigid_inertia_p(mass, m->com[myb], I6, Rb, pp, vb, IA, pA);
+    }
     if (fext) {
       const float F[3] = {fext[3 * myb], fext[3 * myb + 1], fext[3 * myb + 2]};
       chain_ext_force(F, m->com[myb], Rb, pp, pA);
@@ -470,7 +481,7 @@ DEV void chain_substep(const StepCtx& C, const ChainLds& L, int l, DofLane& X, c
         const int p = (int)o[PT_ON] - 1;
         const int da = m->dyn[m->cap_body[m->pair_a[p]]], db = m->dyn[m->cap_body[m->pair_b[p]]];
         if (da != myb && db != myb) continue;
-        const float ma = m->mass[da], mb = m->mass[db];
+        const float ma = body_mass(C, da), mb = body_mass(C, db);
         if constexpr (SPLIT) {
           if (half == 0) {
             if (da == myb) slot_accumulate_fb_half<0>(IA, pA, o, 1.0f, dt, 1.0f, 1.0f + ma / mb);
@@ -864,6 +875,7 @@ DEV void a1_chain_step_body(const A1Args& A) {
   StepCtx C;
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = nullptr;
   if constexpr (HARD) C.dropped = A.S.dropped ? A.S.dropped + e : nullptr;
+  C.mscale = A.S.mscale ? A.S.mscale + (size_t)e * nb : nullptr;
   const float mu = A.S.friction[e];
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
   const int dl = l < nd ? l : 0;

@@ -308,7 +308,18 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
     for (int k = 0; k < 3; k++) pp[k] = pb[9 + k];
 #pragma unroll
     for (int k = 0; k < 6; k++) vb[k] = pb[12 + k];
-    rigid_inertia_p(m->mass[myb], m->com[myb], m->inertia[myb], Rb, pp, vb, IA, pA);
+    {
+      float mass = m->mass[myb], I6[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) I6[k] = m->inertia[myb][k];
+      if (C.mscale) {     // SHF_T_BODY_MASS_SCALE bound: this env's factor on the body's mass and inertia
+        const float s = C.mscale[myb];
+        mass *= s;
+#pragma unroll
+        for (int k = 0; k < 6; k++) I6[k] *= s;
+      }
+      rigid_inertia_p(mass, m->com[myb], I6, Rb, pp, vb, IA, pA);
+    }
     if (fext) {
       const float F[3] = {fext[3 * myb], fext[3 * myb + 1], fext[3 * myb + 2]};
       chain_ext_force(F, m->com[myb], Rb, pp, pA);

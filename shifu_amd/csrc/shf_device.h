@@ -686,8 +686,21 @@ DEV void rigid_inertia_p(float mass, const float* com, const float* I6, const fl
 DEV void rigid_inertia(float mass, const float* com, const float* I6, BodyRegs& B) {
   rigid_inertia_p(mass, com, I6, B.Rw, B.p, B.v, B.IA, B.pA);
 }
+// mscale: this env's row of SHF_T_BODY_MASS_SCALE or null -- the body's mass and inertia tensor times its factor (read here,
+// once per sub-step and only when bound, rather than carried in a register by every launch)
 template <class LM>
-DEV void body_inertia(const LM& M, BodyRegs& B) { rigid_inertia(M.mass, M.com, M.I6, B); }
+DEV void body_inertia(const LM& M, BodyRegs& B, const float* mscale = nullptr, int b = 0) {
+  float mass = M.mass, I6[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) I6[k] = M.I6[k];
+  if (mscale) {
+    const float s = mscale[b];
+    mass *= s;
+#pragma unroll
+    for (int k = 0; k < 6; k++) I6[k] *= s;
+  }
+  rigid_inertia(mass, M.com, I6, B);
+}
 
 typedef ShfScene SceneDev;  // box actors of the scene (gym.create_box), staged in LDS next to the model
 struct StepCtx {
@@ -696,7 +709,10 @@ struct StepCtx {
   TerrainDev terr;
   const SceneDev* scene;  // LDS copy, may be null when the scene has no boxes
   int32_t* dropped = nullptr;   // this env's word of SHF_T_DROPPED (contacts beyond the per-env limits), may be null
+  const float* mscale = nullptr;  // this env's row of SHF_T_BODY_MASS_SCALE (factor on each body's mass and inertia), may be null
 };
+// mass of body b in this env (oracle: body_mass)
+DEV float body_mass(const StepCtx& C, int b) { return C.mscale ? C.m->mass[b] * C.mscale[b] : C.m->mass[b]; }
 
 // solve IA x = -pA for a symmetric positive definite 6x6 in packed storage (LDL^T).  Factorisation and substitution are
 // separate so that several right-hand sides share one factorisation (the pair laws: up to 13 solves with two matrices);
@@ -940,7 +956,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
   BodyRegs B;
   kinematics<G, DM, LM>(m, L, l, M, B);
   PHASE_BEGIN();
-  if (isdyn) body_inertia(M, B);
+  if (isdyn) body_inertia(M, B, C.mscale, l);
   if (BOX) boxes_pose<G>(C, L, l, B);
 
   // external forces on reported bodies -- at the CoM, or at the world point fpos[3 b ..] when given

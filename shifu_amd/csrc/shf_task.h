@@ -22,6 +22,7 @@ struct SimArgs {
   const float* body_force;  // nullptr unless armed
   const float* body_force_pos;  // world points of application, nullptr = at the centres of mass
   const float* friction;
+  const float* mscale;   // (n,nb) per-env factors on the bodies' mass and inertia (SHF_T_BODY_MASS_SCALE), nullptr = 1
   float* contact;  // (n*B,3)
   int32_t* dropped;  // (n) contacts dropped at the per-env limits, accumulated (SHF_T_DROPPED), may be null
 };

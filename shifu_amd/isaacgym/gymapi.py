@@ -207,6 +207,7 @@ class _Actor:
         self.asset, self.pose, self.name, self.sim_index = asset, pose, name, sim_index
         self.friction = float(np.mean([p.friction for p in asset.shape_props]))
         self.mass_override: Optional[float] = None
+        self.mass_scale = None      # articulations: factor per body on the asset's mass and inertia (set_actor_rigid_body_properties)
         self.dof_props = None
 
 
@@ -377,20 +378,31 @@ class Gym:
         a = env.actors[actor_handle]
         if a.asset.model is None:
             return [RigidBodyProperties(a.mass_override or 0.0)]
-        return [RigidBodyProperties(a.asset.model.blob.mass[b]) for b in range(a.asset.num_bodies)]
+        sc = a.mass_scale
+        return [RigidBodyProperties(a.asset.model.blob.mass[b] * (1.0 if sc is None else float(sc[b]))) for b in range(a.asset.num_bodies)]
     def set_actor_rigid_body_properties(self, env, actor_handle, props, recomputeInertia=True):
         a = env.actors[actor_handle]
         if a.asset.model is None:
             a.mass_override = float(props[0].mass)
             return True
-        # per-env link masses of articulations are not supported (the reference's call sites only touch boxes,
-        # object.py:35-37; its mass randomisation of robots is commented out, isaac_gym.py:172-185): unchanged values
-        # are accepted, an actual edit is refused rather than silently dropped
+        # per-env link masses of an articulation (shifu/units/units.py:104-110, recomputeInertia=True): kept on the actor as a
+        # factor per body on the asset's mass and inertia tensor -- uniform density, so the tensor scales with the mass and the
+        # centre of mass stays -- and uploaded by prepare_sim as SHF_T_BODY_MASS_SCALE.  A body welded to its parent carries no
+        # mass of its own here (the compiled model folds it into the parent): an edit of such a body is refused, not dropped.
         blob = a.asset.model.blob
+        scale = np.ones(a.asset.num_bodies, np.float32)
         for b, pr in enumerate(props):
-            if abs(float(pr.mass) - float(blob.mass[b])) > 1e-9 * max(1.0, abs(float(blob.mass[b]))):
-                raise NotImplementedError("set_actor_rigid_body_properties: per-env link masses of an articulation are not "
-                                          "supported by this backend (one compiled model is shared by all envs)")
+            m0, m1 = float(blob.mass[b]), float(pr.mass)
+            if abs(m1 - m0) <= 1e-9 * max(1.0, abs(m0)):
+                continue
+            if not recomputeInertia:
+                raise NotImplementedError("set_actor_rigid_body_properties: recomputeInertia=False (mass without its inertia "
+                                          "tensor) is not supported")
+            if m0 <= 0.0 or m1 <= 0.0:
+                raise NotImplementedError(f"set_actor_rigid_body_properties: body {b} is welded to its parent (its mass is part "
+                                          "of the parent's here) or the new mass is not positive")
+            scale[b] = m1 / m0
+        a.mass_scale = scale if bool((scale != 1.0).any()) else None
         return True
     def set_actor_dof_properties(self, env, actor_handle, props):
         env.actors[actor_handle].dof_props = props
@@ -487,6 +499,9 @@ class Gym:
         for tid in (_abi.T_SIM_ROOT, _abi.T_ROOT_STATE):
             be.tensors[tid].copy_(root)
         be.tensors[_abi.T_FRICTION].copy_(fr.to(dev))
+        if any(env.actors[0].mass_scale is not None for env in sim.envs):
+            one = np.ones(env0.actors[0].asset.num_bodies, np.float32)
+            be.set_body_mass_scale(np.stack([one if env.actors[0].mass_scale is None else env.actors[0].mass_scale for env in sim.envs]))
         sim.backend = be
         return True
 

@@ -1494,3 +1494,98 @@ def test_many_contact_points_generic_path(oracle, tmp_path):
         touched += int((np.abs(contact).sum(1) > 0).sum())
     assert touched > 500 and np.isfinite(root).all()
     sim.destroy()
+
+
+@pytest.mark.parametrize("form", ["chain32-pgs", "chain32-pgs-self", "chain32", "chain16", 32, 64, "32-self"])
+def test_per_env_link_masses_fused_a1_step_matches_oracle_bitwise(oracle, form):
+    """SHF_T_BODY_MASS_SCALE (gym.set_actor_rigid_body_properties(..., recomputeInertia=True), shifu/units/units.py:104-110): each
+    env its own factor per body on mass and inertia tensor, read in the inertia phase of every kernel form of the fused A1 step
+    -- against the oracle given the same rows, every tensor, through falls and resets."""
+    _need_gpu()
+    n = 64
+    selfc = isinstance(form, str) and form.endswith("-self")
+    base = form[:-5] if selfc else form
+    pgs = isinstance(base, str) and base.endswith("-pgs")
+    group = base[:-4] if pgs else base
+    group = int(group) if isinstance(group, str) and group.isdigit() else group
+    cm = H.a1_model(self_collision=True) if selfc else None
+    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, group=group, env_off=300, cm=cm, solver="pgs" if pgs else "compliant")
+    scale = rng.uniform(0.6, 1.6, (n, cm.blob.nb)).astype(np.float32)
+    scale[:4] = 1.0
+    bound = sim.set_body_mass_scale(scale)
+    assert bound.shape == (n, cm.blob.nb)
+    resets = 0
+    with oracle.body_mass_scale(scale):
+        for it in range(80):
+            raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32) * 1.5
+            task.step(torch.from_numpy(raw).cuda())
+            oracle.a1_step(cm.blob, sp, tp, n, 300, bufs, raw, terrain=terr, heights=hs)
+            if it % 8 == 7 or it < 2:
+                _compare(sim, task, bufs, f"{form} step {it}")
+            resets += int(bufs["reset"].sum())
+    assert resets > 4 and np.isfinite(bufs["obs"]).all()
+    # the factors matter: the same run without them ends elsewhere
+    sim.set_body_mass_scale(None)
+    task.step(torch.from_numpy(raw).cuda())
+    oracle.a1_step(cm.blob, sp, tp, n, 300, bufs, raw, terrain=terr, heights=hs)
+    _compare(sim, task, bufs, f"{form} unbound")
+
+@pytest.mark.parametrize("group,solver", [(64, "compliant"), (32, "compliant"), (32, "pgs")])
+def test_per_env_link_masses_simulate_matches_oracle_bitwise(oracle, group, solver):
+    """... and under gym.simulate (k_sim_step, the body-per-lane sub-step; solver 'pgs' on an A1 takes k_sim_step_chain_pgs)."""
+    _need_gpu()
+    rng = np.random.default_rng(12)
+    cm = H.a1_model()
+    m = cm.blob
+    sp = H.sim_params(angular_damping=0.5, solver=solver)
+    n = 64
+    terr, hs = _terrain(rng, rough=True)
+    dof, root = _random_states(m, n, rng)
+    sim = _make_sim(cm, sp, n, terr, hs, group=group)
+    scale = rng.uniform(0.5, 2.0, (n, m.nb)).astype(np.float32)
+    sim.set_body_mass_scale(torch.from_numpy(scale))
+    T = sim.tensors
+    T[_abi.T_SIM_DOF].copy_(torch.from_numpy(dof))
+    T[_abi.T_SIM_ROOT].copy_(torch.from_numpy(root))
+    with oracle.body_mass_scale(scale):
+        for it in range(40):
+            eff = rng.uniform(-25, 25, n * m.nd).astype(np.float32)
+            sim.set_dof_command(_abi.T_EFFORT, torch.from_numpy(eff).cuda())
+            sim.step()
+            sim.refresh(_abi.REFRESH_ALL)
+            contact, bstate = oracle.step(m, sp, n, dof, root, terrain=terr, heights=hs, effort=eff, want_contact=True, want_body_state=True)
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(T[_abi.T_DOF_STATE].cpu().numpy(), dof, err_msg=f"dof_state step {it}")
+            np.testing.assert_array_equal(T[_abi.T_ROOT_STATE].cpu().numpy(), root, err_msg=f"root_state step {it}")
+            np.testing.assert_array_equal(T[_abi.T_CONTACT].cpu().numpy(), contact, err_msg=f"contact step {it}")
+            np.testing.assert_array_equal(T[_abi.T_BODY_STATE].cpu().numpy(), bstate, err_msg=f"body_state step {it}")
+    assert np.isfinite(root).all() and (np.abs(contact).sum(1) > 0).any()
+
+@pytest.mark.parametrize("kw", [dict(solver="pgs", link_contacts=True), dict(solver="pgs", link_contacts=False),
+                                dict(solver="compliant", group=16, link_contacts=True), dict(solver="compliant", group=16, link_contacts=False),
+                                dict(solver="compliant", group=16, mapping="chain"), dict(solver="compliant", group=32, mapping="body", link_contacts=True),
+                                dict(solver="compliant", group=16, mapping="body", link_contacts=False)],
+                         ids=["pgs-link", "pgs", "split-link", "split", "chain16", "body32-link", "levels16"])
+def test_per_env_link_masses_fused_abb_step_matches_oracle_bitwise(oracle, kw):
+    """... and on the arm of the push-box task: every kernel form of the fused ABB step (two waves per env, arm recursions on
+    one lane, body per lane; both solvers) with a factor per env and link."""
+    _need_gpu()
+    from shifu_amd.gym.abb_fused import FusedAbbEnv
+    n = 40
+    env = FusedAbbEnv(num_envs=n, seed=11, **kw)
+    rng = np.random.default_rng(4)
+    scale = rng.uniform(0.5, 2.0, (n, env.cm.blob.nb)).astype(np.float32)
+    env.sim.set_body_mass_scale(scale)
+    bufs = {k: env.sim.tensors[t].cpu().numpy().copy() for k, t in _ABB_SIM_T.items()}
+    bufs.update({k: env.task.tensors[t].cpu().numpy().copy() for k, t in _ABB_T.items()})
+    with oracle.body_mass_scale(scale):
+        for it in range(60):
+            raw = (2 * rng.random((n, 3)) - 1).astype(np.float32) * 1.3
+            env.task.step(torch.from_numpy(raw).cuda())
+            oracle.abb_step(env.cm.blob, env.sim_params, env.boxes, env.task_params, n, 0, bufs, raw)
+            if it % 10 == 9 or it < 3:
+                torch.cuda.synchronize()
+                for k, t in list(_ABB_SIM_T.items()) + list(_ABB_T.items()):
+                    got = (env.sim.tensors if k in _ABB_SIM_T else env.task.tensors)[t].cpu().numpy().reshape(bufs[k].shape)
+                    np.testing.assert_array_equal(got, bufs[k], err_msg=f"{k} step {it}")
+    assert np.isfinite(bufs["obs"]).all()
