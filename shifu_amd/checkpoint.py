@@ -35,6 +35,9 @@ def load_env_state_dict(env, sd: Dict) -> None:
         raise ValueError("checkpoint was taken with a different env count / shard offset")
     for name, src, dst in (("sim", sd["sim"], env.sim.tensors), ("task", sd["task"], env.task.tensors)):
         for k, v in src.items():
+            if name == "sim" and k == _abi.T_BODY_MASS_SCALE and k not in dst:
+                env.sim.set_body_mass_scale(v)        # optional tensor: the checkpointed env had per-env link masses
+                continue
             if k not in dst or dst[k].shape != v.shape or dst[k].dtype != v.dtype:
                 raise ValueError(f"{name} tensor {k}: layout mismatch")
             dst[k].copy_(v)

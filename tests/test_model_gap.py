@@ -1,9 +1,11 @@
-"""The one parity that cannot be pinned -- the shipped compliant contact model against the reference's hard-contact PhysX --
-quantified against a second, independently written solver (oracle/hard_contact_ref.py: joint-space inertia matrix from a
-classical Newton-Euler recursion + projected Gauss-Seidel on rigid contacts, 8 + 1 sweeps, as env_config.py:50-52 sets for
-PhysX).  tools/model_gap.py runs the full scenes (1000 sub-steps; table in DESIGN.md 3, numbers in
-profiles/r04_model_gap.json); this test runs them short and fails if the measured deviations grow.  Not a parity claim: a
-measured distance between two contact models."""
+"""The distance between the COMPLIANT contact law (rounds 1-4, now the opt-in `solver="compliant"`) and a hard-contact solve of
+the class the reference configures, measured against an independently written solver (oracle/hard_contact_ref.py: joint-space
+inertia matrix from a classical Newton-Euler recursion + projected Gauss-Seidel on rigid contacts, 8 + 1 sweeps, as
+env_config.py:50-52 sets for PhysX).  tools/model_gap.py runs the full scenes (1000 sub-steps; table in DESIGN.md 3, numbers
+in profiles/r05_model_gap.json); this test runs them short and fails if the compliant law's deviations grow.  The default
+solver (SHF_SOLVER_PGS) is held to rounding error against the same reference in
+tests/test_hard_contact.py::test_reproduces_the_independent_joint_space_solver.  Not a parity claim with PhysX: a measured
+distance between contact models."""
 import os
 import sys
 
