@@ -1,37 +1,63 @@
 #!/bin/bash
 # On the GPU box (gpurun): everything the round's numbers are quoted from, in one pass -> gpurun_out/final/.
-# Afterwards (here): copy bench_*.json to profiles/r04_bench_*.json, run tools/summarize_prof.py on the prof_* dirs.
+# Afterwards (here): copy bench_*.json to profiles/r05_bench_*.json, run tools/summarize_prof.py on the prof_* dirs.
+# Usage: tools/final_evidence.sh [part ...]   parts: tests bench sweep hooks phase prof  (default: all)
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/final
 mkdir -p "$OUT"
 cd "$REPO"
-python -m pytest tests -m gpu -q 2>&1 | tail -3 > "$OUT/pytest_gpu.txt"
-python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.txt" 2>&1
-for W in terrain flat trimesh abb; do
-  python bench.py --workload $W --steps 500 --warmup 50 > "$OUT/bench_$W.json" 2> "$OUT/bench_$W.err"
-done
-python bench.py --workload abb --no-link-contacts --steps 500 --warmup 50 --no-cpu-baseline > "$OUT/bench_abb_rod_only.json" 2>/dev/null
-python bench.py --self-collision --steps 500 --warmup 50 --no-cpu-baseline > "$OUT/bench_terrain_selfcollision.json" 2>/dev/null
-python bench.py --workload trimesh --self-collision --steps 500 --warmup 50 --no-cpu-baseline > "$OUT/bench_trimesh_selfcollision.json" 2>/dev/null
-python bench.py --workload trimesh --self-collision --mapping body --steps 500 --warmup 50 --no-cpu-baseline > "$OUT/bench_trimesh_selfcollision_body.json" 2>/dev/null
-python bench.py --steps 20 --warmup 5 > "$OUT/bench_terrain_driver_shape.json" 2>/dev/null
-python bench.py --mapping body --group 32 --steps 500 --warmup 50 --no-cpu-baseline > "$OUT/bench_terrain_body_g32.json" 2>/dev/null
-python bench.py --mapping chain --group 16 --steps 500 --warmup 50 --no-cpu-baseline > "$OUT/bench_terrain_chain_g16.json" 2>/dev/null
-python bench.py --workload abb --no-link-contacts --mapping chain --steps 500 --warmup 50 --no-cpu-baseline > "$OUT/bench_abb_rod_only_chain.json" 2>/dev/null
-python bench.py --workload abb --group 32 --steps 300 --warmup 30 --no-cpu-baseline > "$OUT/bench_abb_g32.json" 2>/dev/null
-python tools/mlp_probe.py --check > "$OUT/mlp_probe.json" 2> "$OUT/mlp_probe_check.txt"
-python tools/mlp_probe.py --bf16 > "$OUT/mlp_probe_bf16.json" 2>/dev/null
-python tools/mlp_probe.py --tiled > "$OUT/mlp_probe_tiled.json" 2>/dev/null
-python tools/mlp_probe.py 4096 > "$OUT/mlp_probe_4096.json" 2>/dev/null
-for k in 1 2 3; do python tools/bench_hook_envs.py --steps 300 --graph-hooks 2>/dev/null | grep "^{"; done > "$OUT/hook_envs.txt"
-python tools/phase_clock.py 32 200 --chain > "$OUT/phase_a1_chain_g32.txt" 2>&1
-python tools/phase_clock.py 16 200 --abb --link > "$OUT/phase_abb_link_g16.txt" 2>&1
-python tools/phase_clock.py 16 200 --abb --split > "$OUT/phase_abb_split.txt" 2>&1
-bash tools/profile.sh r04_a1 > /dev/null 2>&1                                       # the default: chain per lane, 32 lanes
-bash tools/profile.sh r04_abb --workload abb > /dev/null 2>&1                        # config 5 as the reference runs it (link contacts)
-bash tools/profile.sh r04_abb_rod_only --workload abb --no-link-contacts > /dev/null 2>&1
-find "$REPO/gpurun_out" -name "*kernel_trace.csv" -size +4M -delete     # keep the merge under gpurun's 64 MiB
-cat "$OUT/pytest_gpu.txt"; tail -2 "$OUT/smoke.txt"
-for W in terrain flat trimesh abb abb_rod_only terrain_selfcollision trimesh_selfcollision trimesh_selfcollision_body terrain_driver_shape terrain_body_g32 terrain_chain_g16 abb_rod_only_chain abb_g32; do echo -n "$W "; tail -1 "$OUT/bench_$W.json" | cut -c80-200; done
+PARTS=${*:-tests bench sweep hooks phase prof}
+has() { [[ " $PARTS " == *" $1 "* ]]; }
+B="--steps 500 --warmup 50"
+if has tests; then
+  python -m pytest tests -m gpu -q 2>&1 | tail -3 > "$OUT/pytest_gpu.txt"
+  python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.txt" 2>&1
+  cat "$OUT/pytest_gpu.txt"; tail -2 "$OUT/smoke.txt"
+fi
+if has bench; then
+  # the default solver (PGS, the reference's PhysX settings) on every workload, with the CPU baseline ...
+  for W in terrain flat trimesh abb; do
+    python bench.py --workload $W $B > "$OUT/bench_$W.json" 2> "$OUT/bench_$W.err"
+  done
+  python bench.py --steps 20 --warmup 5 > "$OUT/bench_terrain_driver_shape.json" 2>/dev/null
+  python bench.py --workload trimesh --self-collision $B --no-cpu-baseline > "$OUT/bench_trimesh_selfcollision.json" 2>/dev/null
+  python bench.py --workload abb --no-link-contacts $B --no-cpu-baseline > "$OUT/bench_abb_rod_only.json" 2>/dev/null
+  # ... and the compliant law of rounds 1-4 (opt-in) on the same
+  for W in terrain flat trimesh abb; do
+    python bench.py --workload $W --solver compliant $B --no-cpu-baseline > "$OUT/bench_${W}_compliant.json" 2>/dev/null
+  done
+  python bench.py --workload trimesh --self-collision --solver compliant $B --no-cpu-baseline > "$OUT/bench_trimesh_selfcollision_compliant.json" 2>/dev/null
+  python bench.py --workload abb --no-link-contacts --solver compliant $B --no-cpu-baseline > "$OUT/bench_abb_rod_only_compliant.json" 2>/dev/null
+  for f in "$OUT"/bench_*.json; do echo -n "$(basename $f .json) "; tail -1 "$f" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], '%.4g' % d['value'], d['roofline'].get('kernel'), d['roofline'].get('kernel_ms'))"; done
+fi
+if has sweep; then
+  # env-count sweep: where the throughput of one GPU saturates, both solvers
+  for S in pgs compliant; do for N in 1024 2048 4096 8192 16384 32768; do
+    python bench.py --envs $N --solver $S --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 |
+      python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$S', $N, d['ms_per_step'], '%.4g' % d['value'])"
+  done; done > "$OUT/env_count_sweep.txt"
+  cat "$OUT/env_count_sweep.txt"
+fi
+if has hooks; then
+  for k in 1 2 3 4 5; do python tools/bench_hook_envs.py --steps 300 --graph-hooks 2>/dev/null | grep "^{"; done > "$OUT/hook_envs.txt"
+  for k in 1 2 3; do SHIFU_AMD_SOLVER=compliant python tools/bench_hook_envs.py --steps 300 --graph-hooks 2>/dev/null | grep "^{"; done > "$OUT/hook_envs_compliant.txt"
+  tail -2 "$OUT/hook_envs.txt" | cut -c1-400
+fi
+if has phase; then
+  python tools/phase_clock.py 32 200 --chain --pgs > "$OUT/phase_a1_chain_pgs.txt" 2>&1
+  python tools/phase_clock.py 32 200 --chain --pgs --self --trimesh > "$OUT/phase_a1_chain_pgs_tw_self.txt" 2>&1
+  python tools/phase_clock.py 32 200 --chain > "$OUT/phase_a1_chain_g32.txt" 2>&1
+  python tools/phase_clock.py 32 100 --abb --link --pgs > "$OUT/phase_abb_pgs_link.txt" 2>&1
+  python tools/phase_clock.py 32 100 --abb --pgs --levels > "$OUT/phase_abb_pgs_rod.txt" 2>&1
+fi
+if has prof; then
+  bash tools/profile.sh r05_a1_pgs > /dev/null 2>&1                                                    # the default: k_a1_chain_pgs<false,false>
+  bash tools/profile.sh r05_a1_pgs_tw_self --workload trimesh --self-collision > /dev/null 2>&1         # the reference's effective scene: <true,true>
+  bash tools/profile.sh r05_a1_tw_self_compliant --workload trimesh --self-collision --solver compliant > /dev/null 2>&1   # k_a1_chain<32,true,true>
+  bash tools/profile.sh r05_a1_compliant --solver compliant > /dev/null 2>&1
+  bash tools/profile.sh r05_abb_pgs --workload abb > /dev/null 2>&1                                     # config 5 under PGS (generic kernel)
+  bash tools/profile.sh r05_abb_compliant --workload abb --solver compliant > /dev/null 2>&1            # k_abb_step_ws<512,true>
+  find "$REPO/gpurun_out" -name "*kernel_trace.csv" -size +4M -delete     # keep the merge under gpurun's 64 MiB
+fi
 du -sh "$REPO/gpurun_out"
