@@ -196,10 +196,24 @@ def test_abb_pushbox_random_run_mode():
 
 
 def test_graph_hooks_refuse_uncapturable_hooks_and_leave_the_env_usable():
-    """AbbPushBox.step builds tensors from Python lists (host-to-device copies): enable_graph_hooks must say so and leave
-    the env on its eager path, not half-captured."""
+    """A user hook that builds a device tensor from a Python list (a host-to-device copy from pageable memory, as the
+    reference's AbbRobot.step does, a_prior_stage.py:72) cannot be captured: enable_graph_hooks must say so and leave the
+    env on its eager path, not half-captured."""
+    from examples.abb_pushbox_vision.a_prior_stage import AbbPushBox
+    from examples.abb_pushbox_vision.task_config import PriorStageEnvConfig
     from shifu_amd._lib import BackendError
-    env = _abb(32)
+
+    class ListObs(AbbPushBox):
+        def compute_observations(self):
+            bias = torch.tensor([0.0, 0.0, 0.0], device=self.device)        # built from a list on every call
+            super().compute_observations()
+            self.obs_buf[:, :3] += bias
+
+    cfg = PriorStageEnvConfig()
+    cfg.num_envs = 32
+    np.random.seed(3)
+    torch.manual_seed(3)
+    env = ListObs(cfg)
     env.reset()
     with pytest.raises(BackendError, match="cannot be captured"):
         env.enable_graph_hooks()
@@ -208,6 +222,28 @@ def test_graph_hooks_refuse_uncapturable_hooks_and_leave_the_env_usable():
         obs, _, rew, _, _ = env.step(torch.zeros(env.num_envs, env.num_actions, device=env.device))
     torch.cuda.synchronize()
     assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+
+
+def test_abb_pushbox_replays_its_hooks_from_graphs():
+    """The repo's AbbPushBox example (box re-spawn vectorised, the end-effector target quaternion built once) is capturable:
+    with enable_graph_hooks it steps from two hipGraphs -- 300 steps with time-outs and re-spawns, the rod reaches the cube.
+    (Replay against eager, bit for bit, is tested on A1Conditional above: a re-spawn inside a graph draws from the graph's own
+    Philox offsets, so the two ABB envs part at their first reset.)"""
+    env = _abb(32)
+    env.reset()
+    env.enable_graph_hooks()
+    assert getattr(env, "_hook_graphs", None) is not None
+    g = torch.Generator().manual_seed(5)
+    dones, best = 0, -1e9
+    for it in range(300):
+        a = (2 * torch.rand(32, env.num_actions, generator=g) - 1).to(env.device)
+        obs, _, rew, done, extras = env.step(a)
+        dones += int(done.sum())
+        best = max(best, float(rew.max()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    assert dones >= 32, dones            # every env timed out or succeeded at least once on average
+    assert "episode" in extras
 
 
 def test_abb_rod_pushes_the_cube():
