@@ -82,11 +82,11 @@ const void* shf_a1_chain_kernel(int G, bool warped, bool self) {
 }
 #ifdef SHF_PHASE_CLOCK
 int shf_a1_chain_phase_cycles(unsigned long long* out, int n, int reset) {
-  unsigned long long h[32];
+  unsigned long long h[48];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_cycles), sizeof h) != hipSuccess) return 1;
-  for (int k = 0; k < n && k < 32; k++) out[k] = h[k];
+  for (int k = 0; k < n && k < 48; k++) out[k] = h[k];
   if (reset) {
-    unsigned long long z[32] = {};
+    unsigned long long z[48] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z) != hipSuccess) return 1;
   }
   return 0;

@@ -1825,17 +1825,17 @@ extern "C" int shf_abb_reset_all(ShfAbbTask* task, void* stream) {
 #ifdef SHF_PHASE_CLOCK
 // debug builds only (tools/phase_clock.py): read / clear the per-phase cycle counters
 extern "C" int shf_debug_phase_cycles(unsigned long long* out, int n, int clear) {
-  unsigned long long tmp[32];
+  unsigned long long tmp[48];
   if (hipMemcpyFromSymbol(tmp, HIP_SYMBOL(g_phase_cycles), sizeof(tmp)) != hipSuccess) return -1;
-  for (int i = 0; i < n && i < 32; i++) out[i] = tmp[i];
+  for (int i = 0; i < n && i < 48; i++) out[i] = tmp[i];
   if (clear) {
     std::memset(tmp, 0, sizeof(tmp));
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), tmp, sizeof(tmp)) != hipSuccess) return -1;
   }
   // the chain-mapped kernels live in their own code object with their own counters: add them
-  unsigned long long ch[32];
-  if (shf_a1_chain_phase_cycles(ch, 32, clear) != 0) return -1;
-  for (int i = 0; i < n && i < 32; i++) out[i] += ch[i];
+  unsigned long long ch[48];
+  if (shf_a1_chain_phase_cycles(ch, 48, clear) != 0) return -1;
+  for (int i = 0; i < n && i < 48; i++) out[i] += ch[i];
   return 0;
 }
 #endif

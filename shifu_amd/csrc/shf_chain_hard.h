@@ -730,7 +730,7 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
       if (__ballot(c < K) != 0ull) Kw = c + 1;
     const bool hi = lane0 != 0;
 #ifdef SHF_PHASE_CLOCK
-    if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_phase_cycles[20 + Kw], 1ull);     // histogram of the wavefronts' constraint counts
+    if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_phase_cycles[38 + Kw], 1ull);     // histogram of the wavefronts' constraint counts
 #endif
     const float* Wcol = tail + T::W + (own ? l : 0) * 9;     // block (l, c) sits at Wcol + c * HCK * 9
 #pragma unroll 1

@@ -39,7 +39,7 @@
 // Per-phase cycle accounting for tools/phase_clock.py (debug builds with -DSHF_PHASE_CLOCK only):
 // thread 0 of block 0 adds the s_memtime delta since the previous mark to g_phase_cycles[k].
 #ifdef SHF_PHASE_CLOCK
-__device__ unsigned long long g_phase_cycles[32];
+__device__ unsigned long long g_phase_cycles[48];   // 0-23 sub-step phases, 24-31 link stages / counters, 32-37 the generic solve, 38-46 constraint-count histogram
 #define PHASE_BEGIN() unsigned long long _pc = clock64()
 #define PHASE_MARK(k)                                                                    \
   do {                                                                                   \

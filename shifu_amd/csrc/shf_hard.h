@@ -509,7 +509,7 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
     }
   }
   GROUP_SYNC();
-  PHASE_MARK(24);
+  PHASE_MARK(32);
 
   // ---- gather
   const SlotLay Q = BOX ? slot_lay<SC>(m, S) : SlotLay();
@@ -520,14 +520,14 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
   H.P1 = H.nev + H.nself; H.P2 = H.P1 + nbx * 8 * H.T; H.P3 = H.P2 + H.nsph * nbx; H.P4 = H.P3 + H.nlink;
   const int K = hg_gather<G>(C, L, Q, H, l, hc, kmax);
   GROUP_SYNC();
-  PHASE_MARK(25);
+  PHASE_MARK(33);
 
   float ac0[2][6] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};   // root lane / box lanes: what the contacts add
   if (__ballot(K > 0) != 0ull) {
     // ---- columns
     hg_columns<G>(m, L, nb, l, K, hc, W);
     GROUP_SYNC();
-    PHASE_MARK(26);
+    PHASE_MARK(34);
     // ---- owners
     HardOwner O;
     const bool own = l < K;
@@ -545,10 +545,10 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
     }
     GROUP_SYNC();
     // ---- sweeps
-    PHASE_MARK(27);
+    PHASE_MARK(35);
     hard_sweeps(O, hc, W, l, K, npos, nvel);
     GROUP_SYNC();
-    PHASE_MARK(28);
+    PHASE_MARK(36);
     // ---- the impulses through the tree, both sets (oracle: hc_apply)
     const int NQ = nvel > 0 ? 2 : 1;
     float pc[2][6] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};
@@ -644,7 +644,7 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
     }
     GROUP_SYNC();
     (void)NQ;
-    PHASE_MARK(29);
+    PHASE_MARK(37);
   }
 
   // ---- integration (oracle substep(), "semi-implicit Euler" with hard = 1)

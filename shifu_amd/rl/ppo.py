@@ -11,7 +11,7 @@ from .storage import RolloutStorage
 class PPO:
     def __init__(self, actor_critic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
                  value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True,
-                 schedule="fixed", desired_kl=0.01, device="cpu", graph_update=False, fused_loss=False):
+                 schedule="fixed", desired_kl=0.01, device="cpu", graph_update=False, fused_loss=True):
         self.device = device
         # graph_update: replay one captured hipGraph per mini-batch step (gather, losses, backward, clip, Adam, lr
         # schedule: ~280 launches) instead of launching it eagerly; bit-identical to the eager update with either layer
@@ -35,11 +35,12 @@ class PPO:
         self.desired_kl, self.schedule = desired_kl, schedule
         self.actor_critic = actor_critic.to(device)
         # fused_loss: the loss block and its gradient as one HIP pass (rl/fused_loss.py) instead of ~100 small autograd
-        # launches: learn 30 -> 23 ms per iteration on the A1 schedule.  Same formulas, sums in another (fixed) order.
-        # Off by default: over 28 seeds of the 3000-iteration schedule the torch expressions ended with 27 walking
-        # policies and the fused pass with 25, mean return 514 vs 498 (profiles/r02_train_seeds.md) -- not distinguishable
-        # at that sample size, but the default stays with the longer-validated form.  PPOConfig.algorithm.fused_loss /
-        # SHIFU_AMD_FUSED_PPO_LOSS=1 select it.
+        # launches: learn 24.5 -> 17.5 ms per iteration on the A1 schedule.  Same formulas -- gradients equal to autograd's to
+        # 2e-5 (tests/test_gpu_mlp.py) -- sums in another (fixed) order.  The default on a GPU since round 5: 44 seeds of the
+        # 3000-iteration schedule per arm (38 under the compliant contact law, rounds 2-4; 6 under PGS, round 5) ended with 41
+        # walking policies against 43 for the torch expressions, mean return 529 vs 516 under PGS (profiles/r05_train.md).
+        # fused_loss=False / SHIFU_AMD_FUSED_PPO_LOSS=0 / tools/train_a1.py --torch-loss select the torch expressions (always
+        # used for CPU tensors).
         want = os.environ.get("SHIFU_AMD_FUSED_PPO_LOSS")
         self.fused_loss = torch.device(device).type == "cuda" and (want == "1" if want in ("0", "1") else bool(fused_loss))
         self.storage = None

@@ -221,6 +221,12 @@ def _compare(sim, task, bufs, tag, exact=True, tol=0.0):
     return worst
 
 
+def _pgs_group(group):
+    """'pgs' in a group parametrisation: the chain kernel at 32 lanes under SHF_SOLVER_PGS (k_a1_chain_pgs), the default of the
+    fused A1 env since round 5 -> (group, sim_params keywords)."""
+    return ("chain32", {"solver": "pgs"}) if group == "pgs" else (group, {})
+
+
 def _a1_setup(n, rough, seed=5, group=64, env_off=0, cm=None, **spkw):
     from shifu_amd.a1_task import a1_task_params
     from shifu_amd.backend import A1Task
@@ -405,13 +411,14 @@ def test_fused_abb_step_matches_oracle_bitwise_at_full_size(oracle, link):
     assert resets > 100
 
 
-@pytest.mark.parametrize("group", [32, "chain16", "chain32"])
+@pytest.mark.parametrize("group", [32, "chain16", "chain32", "pgs"])
 def test_fused_a1_step_push_on_every_body(oracle, group):
     """rand_force_buf is (N, bodies, 3) (a1_conditional.py:82-87): a user may push any body, welded feet included --
     forces on every reported body, folded into its moving body in body order, on both lane mappings."""
     _need_gpu()
     n = 40
-    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, seed=77, group=group)
+    group, kw = _pgs_group(group)
+    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, seed=77, group=group, **kw)
     bufs["push"][:] = rng.uniform(-4, 4, bufs["push"].shape).astype(np.float32)
     bufs["push"][::3, 5] = 0.0          # some bodies of some envs unpushed (skipped, not added as zeros)
     _upload(sim, task, bufs)
@@ -423,13 +430,14 @@ def test_fused_a1_step_push_on_every_body(oracle, group):
     assert np.isfinite(bufs["obs"]).all()
 
 
-@pytest.mark.parametrize("group", [64, "chain16"])
+@pytest.mark.parametrize("group", [64, "chain16", "pgs"])
 def test_a1_1000_steps_vs_oracle_at_north_star_tolerance(oracle, group):
     """Per-step dof_pos / dof_vel / root_state within the north-star's 1e-4 relative over 1000 steps -- of the ORACLE
     (Isaac Gym itself is a closed binary that is absent).  Checked every 50 steps."""
     _need_gpu()
     n = 32
-    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, seed=9, group=group)
+    group, kw = _pgs_group(group)
+    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, seed=9, group=group, **kw)
     worst = 0.0
     for it in range(1000):
         raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32)
@@ -949,12 +957,14 @@ def test_fused_abb_step_matches_oracle_bitwise(oracle, group, generic):
     assert cube_moved
 
 
-@pytest.mark.parametrize("group", [32, "chain16"])
+@pytest.mark.parametrize("group", [32, "chain16", "pgs"])
 @pytest.mark.parametrize("n", [1, 5, 37])
 def test_ragged_env_counts(oracle, n, group):
-    """Env counts that do not fill a block (4, 8 or 16 envs per 256-thread block): no out-of-range lanes."""
+    """Env counts that do not fill a block (4, 8 or 16 envs per 256-thread block; an odd count leaves half a wavefront of the
+    two-envs-per-wave kernels empty): no out-of-range lanes."""
     _need_gpu()
-    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, seed=30 + n, group=group)
+    group, kw = _pgs_group(group)
+    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, seed=30 + n, group=group, **kw)
     for it in range(8):
         raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32)
         task.step(torch.from_numpy(raw).cuda())
@@ -1060,7 +1070,7 @@ def test_split_mapping_is_refused_for_other_shapes():
         env.task.step(torch.zeros(8, 3, device="cuda"))
 
 
-@pytest.mark.parametrize("group", [32, "chain"])
+@pytest.mark.parametrize("group", [32, "chain", "pgs"])
 def test_full_size_determinism_and_shard_invariance(group):
     """BASELINE size (4096 envs, procedural 1300x2100 height map): two runs are bit-identical, and
     two 2048-env shards with global-id offsets reproduce the 4096-env run env for env.  32: the body-per-lane kernel;
@@ -1072,8 +1082,9 @@ def test_full_size_determinism_and_shard_invariance(group):
 
     def run(num, rank, world, acts=None):
         env = (FusedA1Env(num_envs=num, rank=rank, world_size=world, seed=42, mapping="chain", group=16) if group == "chain" else
+               FusedA1Env(num_envs=num, rank=rank, world_size=world, seed=42) if group == "pgs" else      # the env's defaults: k_a1_chain_pgs
                FusedA1Env(num_envs=num, rank=rank, world_size=world, seed=42, group=group, mapping="body"))
-        assert env.mapping == ("chain" if group == "chain" else "body")
+        assert env.mapping == ("body" if group == 32 else "chain") and (env.sim_params.solver == _abi.SOLVER_PGS) == (group == "pgs")
         env.reset()
         out = []
         for k in range(steps):
@@ -1118,7 +1129,7 @@ def test_fused_step_generic_dimension_path(oracle, group):
     assert np.isfinite(bufs["obs"]).all()
 
 
-@pytest.mark.parametrize("group", [32, 16, "chain16", "chain32", "chain32-self"])
+@pytest.mark.parametrize("group", [32, 16, "chain16", "chain32", "chain32-self", "pgs", "pgs-self"])
 def test_trimesh_terrain_matches_oracle_bitwise(oracle, group):
     """the trimesh form of the terrain (vertical risers at steep steps; ShfTerrain.warped) -- simulate
     and the fused step against the oracle, on a terrain whose plateau and noise shift many vertices."""
@@ -1130,8 +1141,9 @@ def test_trimesh_terrain_matches_oracle_bitwise(oracle, group):
     rng = np.random.default_rng(31)
     # "chain32-self": the reference's effective A1 scene -- trimesh terrain (task_config.py:53) with every link colliding
     # (units.py:68) -- on the chain-per-lane kernel
-    selfc = group == "chain32-self"
-    if selfc:
+    pgs = group in ("pgs", "pgs-self")          # ... and under the velocity-level solve: k_a1_chain_pgs<true, SELF>
+    selfc = group in ("chain32-self", "pgs-self")
+    if selfc or pgs:
         group = "chain32"
     if selfc:
         cm = compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT, self_collision=True)
@@ -1141,7 +1153,7 @@ def test_trimesh_terrain_matches_oracle_bitwise(oracle, group):
         cm = H.a1_model()
     else:
         cm = compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT, honour_dont_collapse=False)
-    sp = H.sim_params(angular_damping=0.5)
+    sp = H.sim_params(angular_damping=0.5, solver="pgs" if pgs else "compliant")
     tp = a1_task_params(cm, num_rows=4, num_cols=5, env_length=0.8)
     terr, hs = _terrain(rng, rows=80, cols=60, rough=True)
     warp = trimesh_warp_map(hs, terr.hscale, terr.vscale, 0.75)
@@ -1153,8 +1165,8 @@ def test_trimesh_terrain_matches_oracle_bitwise(oracle, group):
     sim = _make_sim(cm, sp, n, terr, hs, group=group, warp=warp)
     assert sim.terrain.warped == 1 and sim.tensors[_abi.T_HEIGHTS].numel() == packed.size
     task = A1Task(sim, tp)
-    if selfc:
-        assert task.kernel_symbol() == "_Z10k_a1_chainILi32ELb1ELb1EE"
+    if selfc or pgs:
+        assert task.kernel_symbol() == ("_Z14k_a1_chain_pgsILb1ELb%dEE" % int(selfc) if pgs else "_Z10k_a1_chainILi32ELb1ELb1EE")
     _upload(sim, task, bufs)
     for it in range(60):
         raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32) * (2.0 if selfc else 1.5)

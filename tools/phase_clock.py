@@ -60,7 +60,10 @@ def main():
         NAMES[2] = "body lanes: rigid inertias + external forces"; NAMES[5] = "(unused on the chain mapping)"
         NAMES[6] = "chain: dof efforts + inward"; NAMES[7] = "root: add hips + 6x6 solve"; NAMES[8] = "chain: outward + integrate"
         NAMES[10] = "root: integrate"
-    if pgs:
+    if pgs and abb:
+        NAMES[3] = "contact eval: candidate gaps of the terrain points"; NAMES[4] = "candidates of the box / link families + the solve (marks 17-20, 32-37 are its parts)"
+        NAMES[9] = "integration + contact force out"
+    if pgs and not abb:
         NAMES[3] = "points -> candidate constraints, selection"; NAMES[4] = "contact solve: H1-H4 (marks 5, 10, 17, 18 are its parts)"
         NAMES[5] = "  H1 response matrix W (column lanes)"; NAMES[10] = "  H2 owner setup (u0, targets, block inverses)"
         NAMES[6] = "free inward pass (row lanes)"; NAMES[7] = "root: sum, LDL^T, free acceleration"; NAMES[8] = "free outward pass + velocity rates"
@@ -68,21 +71,23 @@ def main():
     lib = _lib.lib()
     fn = lib.shf_debug_phase_cycles
     fn.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_int]
-    buf = (ctypes.c_uint64 * 32)()
+    buf = (ctypes.c_uint64 * 48)()
     env.reset()
     act = torch.empty(env.num_envs, env.num_actions, device=env.device)
     for _ in range(20):
         env.step(act.uniform_(-1, 1))
     torch.cuda.synchronize()
-    assert fn(buf, 32, 1) == 0
+    assert fn(buf, 48, 1) == 0
     for _ in range(steps):
         env.step(act.uniform_(-1, 1))
     torch.cuda.synchronize()
-    assert fn(buf, 32, 0) == 0
+    assert fn(buf, 48, 0) == 0
     tot = sum(buf[:17]) if not split else sum(buf[11:17]) + sum(buf[24:30])  # (marks 17-23: inside phase 4 for the box scene)
+    if pgs and not abb:
+        tot = sum(buf[:19])                       # chain kernel: the solve's parts are marks 5, 10, 17, 18
+    if pgs and abb:
+        tot = sum(buf[:24]) + sum(buf[32:38]) + (sum(buf[24:29]) if link else 0)    # generic kernel: every mark is its own interval
     print(f"G={G}: {tot / steps:.0f} cycles per env-step in block 0 / wave 0 (s_memtime ticks)")
-    if pgs:
-        tot = sum(buf[:4]) + sum(buf[5:19])      # mark 4 is what is left of H after its parts
     extra_names = ['box: corner slots', 'box: sphere slots', 'box: fold', 'fold: box lane corners', 'fold: pair law', 'fold: sync', 'fold: arm lanes', 'split: arm wave before S1', 'split: wait at S1', 'split: arm wave S1 -> S4', 'split: wait at S4', 'split: arm wave after S4', 'split: final barrier']
     if link and split:
         # k_abb_step_ws<512, true>: marks 17-22 are the BOX wave's own clock (its first lane), 24-28 the arm wave's
@@ -92,16 +97,19 @@ def main():
     if link and not split:
         print(f"  link contacts: {buf[29] / max(buf[31], 1):.2f} live (body, box) pairs per wavefront and sub-step, "
               f"{buf[30] / max(buf[31], 1):.2f} in its first env; stage 0 (broad phase) = mark 24")
-    if pgs:
+    if pgs and not abb:
         extra_names[0:2] = ['  H3 sweeps (position + velocity iterations)', '  H4 impulse passes (inward / root / outward, x2)']
-        hist = [buf[20 + k] for k in range(9)]
+        hist = [buf[38 + k] for k in range(9)]
         print("  wavefronts by constraint count Kw = 0..8 (all blocks, per sub-step): " + " ".join(f"{100.0 * h / max(sum(hist), 1):.1f}%" for h in hist))
+    hard_names = []
     if pgs and abb:
-        extra_names[7:13] = ['hard: body records + velocity rates', 'hard: gather candidates', 'hard: response matrix columns',
-                             'hard: owner setup', 'hard: sweeps', 'hard: impulse passes']
-        tot = sum(buf[:30])
+        # the generic solve on the body-per-lane sub-step (csrc/shf_hard.h): its parts are marks 32-37
+        hard_names = ['hard: body records + velocity rates', 'hard: gather candidates', 'hard: response matrix columns',
+                      'hard: owner setup', 'hard: sweeps', 'hard: impulse passes']
     for k, nme in enumerate(NAMES + extra_names):
         print(f"  {k:2d} {nme:52s} {buf[k] / steps:9.0f}  {100.0 * buf[k] / tot:5.1f} %")
+    for k, nme in enumerate(hard_names):
+        print(f"  {32 + k:2d} {nme:52s} {buf[32 + k] / steps:9.0f}  {100.0 * buf[32 + k] / tot:5.1f} %")
 
 
 if __name__ == "__main__":

@@ -29,7 +29,9 @@ def main():
                     help="ActorCritic layers: stock fp32 library GEMMs, or the hand-written MFMA kernels (csrc/shf_mlp.hip)")
     ap.add_argument("--eager-update", action="store_true", help="with --graph: capture the rollout only, launch the PPO update eagerly")
     ap.add_argument("--graph-update", action="store_true", help="capture the PPO update only (debugging)")
-    ap.add_argument("--fused-loss", action="store_true", help="PPO loss + gradient as one HIP pass (rl/fused_loss.py, shf_ppo_loss)")
+    ap.add_argument("--fused-loss", action="store_true", help="(the default since round 5; accepted for old command lines)")
+    ap.add_argument("--torch-loss", action="store_true", help="the PPO loss as torch expressions + autograd instead of the one HIP pass "
+                                                              "(rl/fused_loss.py, shf_ppo_loss): rounds 1-4's default")
     ap.add_argument("--terrain", default="heightfield", choices=["heightfield", "trimesh", "flat"],
                     help="terrain collision form (trimesh = what the reference's A1EnvConfig effectively builds, SURVEY Q5)")
     ap.add_argument("--seed", type=int, default=None, help="override A1PPOConfig.seed")
@@ -56,7 +58,7 @@ def main():
     cfg = class_to_dict(A1PPOConfig())
     cfg["runner"]["graph_rollout"] = args.graph
     cfg["algorithm"]["graph_update"] = (args.graph or args.graph_update) and not args.eager_update   # PPO.graph_update
-    cfg["algorithm"]["fused_loss"] = args.fused_loss
+    cfg["algorithm"]["fused_loss"] = not args.torch_loss
     if args.mlp:
         cfg["policy"]["mlp_backend"] = args.mlp
     set_seed((A1PPOConfig.seed if args.seed is None else args.seed) + rank)
