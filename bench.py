@@ -235,6 +235,9 @@ def main():
                     help="contact solver (ShfSimParams.solver): pgs = the velocity-level projected Gauss-Seidel solve with the reference's PhysX "
                          "settings (env_config.py:50-58: 8 + 1 iterations), the default of the A1 workloads (without --self-collision, chain "
                          "mapping at 32 lanes); compliant = rounds 1-4's spring-damper law (config 5 / abb: the only one built)")
+    ap.add_argument("--no-other-solver", action="store_true",
+                    help="skip the `other_solver` leg (N = 1, --solver not given: the same workload under the solver that is NOT the "
+                         "default, timed the same way after the main measurement and reported beside it)")
     ap.add_argument("--pos-iters", type=int, default=8, help="physx.num_position_iterations (pgs)")
     ap.add_argument("--vel-iters", type=int, default=1, help="physx.num_velocity_iterations (pgs)")
     ap.add_argument("--self-collision", action="store_true",
@@ -284,6 +287,7 @@ def main():
     if use_dist:
         init_ranks(dev, backend)       # finite timeout: a rank that never arrives fails the job instead of hanging it
 
+    solver_given = args.solver is not None or args.mapping is not None or args.group is not None
     abb = args.workload == "abb"
     if abb:
         if args.link_contacts and (args.no_link_contacts or args.mapping == "chain"):
@@ -517,6 +521,30 @@ def main():
             out["roofline"]["kernel_ms_note"] = ("kernel_ms (HIP events, second pass of K launches) reads above ms_per_step (host clock, "
                                                  "timed pass): pass-to-pass noise, not a longer kernel; roofline.achieved uses kernel_ms, "
                                                  "the more conservative of the two")
+        if world == 1 and not solver_given and not args.no_other_solver and args.actions == "kernel" and graph is None:
+            # the driver runs the default command only: the opt-in compliant law of rounds 1-4 on the same workload, same K and
+            # W, same clock, so that one line carries both (a fresh env; the main measurement above is already taken)
+            other = "compliant" if args.solver == "pgs" else "pgs"
+            if abb:
+                env2 = FusedAbbEnv(num_envs=args.envs, device=dev, seed=42, link_contacts=args.link_contacts, solver=other)
+            else:
+                env2 = FusedA1Env(num_envs=args.envs, device=dev, terrain={"terrain": "heightfield", "flat": "flat", "trimesh": "trimesh"}[args.workload],
+                                  seed=42, decimation=args.decimation, extra_substep=not args.no_extra_substep,
+                                  self_collision=args.self_collision, solver=other)
+            env2.reset()
+            for _ in range(args.warmup):
+                env2.task.step_random()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                env2.task.step_random()
+            torch.cuda.synchronize()
+            e2 = time.perf_counter() - t1
+            out["other_solver"] = {"solver": env2.solver, "ms_per_step": e2 / args.steps * 1e3, "value": N * args.steps / e2, "unit": "env-steps/s",
+                                   "kernel_symbol": env2.task.kernel_symbol(), "lanes_per_env": env2.sim.group, "lane_mapping": env2.mapping,
+                                   "obs_finite": bool(torch.isfinite(env2.obs_buf).all().item()),
+                                   "note": "the same workload under the solver that is not the default, timed the same way (host clock, K steps after W "
+                                           "warm-up steps); compliant = the spring-damper law of rounds 1-4 (opt-in: --solver compliant)"}
         if not args.no_cpu_baseline and world == 1:
             cb = out["cpu_baseline"] = cpu_baseline(args.workload, solver_kw={"solver": args.solver, "pos_iters": args.pos_iters, "vel_iters": args.vel_iters})     # the only leg that touches oracle/
             f_alg = cb["flops_per_env_step"]

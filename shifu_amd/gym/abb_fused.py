@@ -30,6 +30,13 @@ class FusedAbbEnv:
             link_contacts = mapping != "chain"
         self.link_contacts = bool(link_contacts)
         self.cm = abb_model(link_contacts=link_contacts)
+        # solver: "pgs" = the velocity-level contact solve with the reference's PhysX settings (env_config.py:50-58) -- the default,
+        # on the run-time-shaped body-per-lane kernel at 32 lanes per env (csrc/shf_hard.h; round 5: correct, not yet fast:
+        # 1.5 ms per vec-step); "compliant" = rounds 1-4's spring-damper law on the kernels compiled for this scene (0.16 ms).
+        # Asking for a lane mapping / width that only the compliant kernels have selects them.  (Decided from what the caller
+        # passed, before the compliant kernels' own defaults for `group` and `mapping` are filled in below.)
+        if solver is None:
+            solver = "pgs" if (mapping in (None, "body") and group in (None, 32)) else "compliant"
         if group is None:
             # 16 lanes per env: sixteen envs per workgroup share one LDS copy of the model, and 4096 envs are resident at once
             # -- with link contacts too, now that only the free box owns corner slots (9.2 KB of LDS per env, was 12.6)
@@ -42,12 +49,6 @@ class FusedAbbEnv:
             # With link contacts 'split' exists too (the link passes run on the box wave; 0.166 vs 0.186 ms for 'body').
             scene = not extra_boxes
             mapping = "split" if (scene and group == 16) else "chain" if (scene and not link_contacts and group == 32) else "body"
-        # solver: "pgs" = the velocity-level contact solve with the reference's PhysX settings (env_config.py:50-58) -- the default,
-        # on the run-time-shaped body-per-lane kernel at 32 lanes per env (csrc/shf_hard.h; round 5: correct, not yet fast:
-        # 1.5 ms per vec-step); "compliant" = rounds 1-4's spring-damper law on the kernels compiled for this scene (0.15 ms).
-        # Asking for a lane mapping / width that only the compliant kernels have selects them.
-        if solver is None:
-            solver = "pgs" if (mapping in (None, "body") and group in (None, 32)) else "compliant"
         self.solver = solver
         if solver == "pgs":
             group, mapping = 32, "body"

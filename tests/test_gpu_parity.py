@@ -383,16 +383,23 @@ def test_long_differential_run_of_every_kernel_form(oracle):
     assert sum(r["resets"] for r in out if r["task"] == "a1") > 300 and sum(r["resets"] for r in out if r["task"] == "abb") > 300
 
 
+@pytest.mark.parametrize("solver", ["pgs", "compliant"])
 @pytest.mark.parametrize("link", [True, False])
-def test_fused_abb_step_matches_oracle_bitwise_at_full_size(oracle, link):
+def test_fused_abb_step_matches_oracle_bitwise_at_full_size(oracle, link, solver):
     """The same for config 5 -- the reference's scene, every link colliding (the default of FusedAbbEnv and of
-    bench.py --workload abb), and the rod-only scene on the arm wave + box wave kernel: 4096 envs, 30 vec-steps."""
+    bench.py --workload abb), and the rod-only scene -- at 4096 envs, 30 vec-steps: under the default solver (PGS: the
+    run-time-shaped body-per-lane kernel with the generic solve) and under the compliant law (the arm wave + box wave kernel)."""
     _need_gpu()
     from shifu_amd.gym.abb_fused import FusedAbbEnv
     n = 4096
-    env = FusedAbbEnv(num_envs=n, seed=23, link_contacts=link)
-    assert env.mapping == "split" and env.link_contacts == link and env.sim.group == 16
-    assert env.task.kernel_symbol() == ("_Z13k_abb_step_wsILi512ELb1EE" if link else "_Z13k_abb_step_wsILi256ELb0EE")
+    env = FusedAbbEnv(num_envs=n, seed=23, link_contacts=link, **({} if solver == "pgs" else {"solver": solver}))
+    assert env.solver == solver and env.link_contacts == link
+    if solver == "pgs":
+        assert env.mapping == "body" and env.sim.group == 32 and env.sim_params.solver == _abi.SOLVER_PGS
+        assert env.task.kernel_symbol() == "_Z10k_abb_stepILi32E7DynDims8DynSceneLb%dELi0ELb1EE" % int(link)
+    else:
+        assert env.mapping == "split" and env.sim.group == 16
+        assert env.task.kernel_symbol() == ("_Z13k_abb_step_wsILi512ELb1EE" if link else "_Z13k_abb_step_wsILi256ELb0EE")
     env.task.tensors[_abi.ABB_EP_LEN].copy_(torch.randint(150, 201, (n,)))
     torch.cuda.synchronize()
     bufs = {k: env.sim.tensors[t].cpu().numpy().copy() for k, t in _ABB_SIM_T.items()}
