@@ -330,31 +330,77 @@ DEV const float* hg_slot_raw(const ShfModel* m, const SceneDev* S, const EnvLds&
 // gather: the K <= kmax candidates with the smallest gap (ties: candidate order), in candidate order, as constraint records.
 // Returns K.  oracle: hc_offer / hc_finish.
 template <int G>
-DEV int hg_gather(const StepCtx& C, const EnvLds& L, const SlotLay& Q, const HgSeq& H, int l, float* hc, int kmax) {
+DEV int hg_gather(const StepCtx& C, const EnvLds& L, const SlotLay& Q, const HgSeq& H, int l, float* hc, int kmax, float* scratch) {
   const ShfModel* m = C.m;
   const SceneDev* S = C.scene;
   const int lane0 = (int)(threadIdx.x & 63u) - l;
   const unsigned long long gmask = G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
-  // pass 1: how many candidates
+  // pass 1: how many candidates -- and their (gap, candidate number) pairs, in candidate order, in `scratch` (the response
+  // matrix's place, not yet in use: HCK * HCK * 9 words) for the ranking below
+  constexpr int LISTMAX = HCK * HCK * 9 / 2;
   int total = 0;
   for (int base = 0; base < H.P4; base += G) {
     const int idx = base + l;
     int ba, bb, ra, rb;
     const float* o = idx < H.P4 ? hg_slot(m, S, L, Q, H, idx, &ba, &bb, &ra, &rb) : nullptr;
     const bool on = o != nullptr && o[PT_ON] != 0.0f;
-    total += __builtin_popcountll((__ballot(on) >> lane0) & gmask);
+    const unsigned long long mask = (__ballot(on) >> lane0) & gmask;
+    if (on) {
+      const int k = total + __builtin_popcountll(mask & ((1ull << l) - 1ull));
+      if (k < LISTMAX) { scratch[2 * k] = o[PT_F]; scratch[2 * k + 1] = __int_as_float(idx); }
+    }
+    total += __builtin_popcountll(mask);
   }
   const bool overflow = total > kmax;
   if (overflow && l == 0 && C.dropped) *C.dropped += total - kmax;
+  GROUP_SYNC();
+  auto record = [&](int k, const float* o, int ba, int bb, int ra, int rb) {
+    float* h = hc + k * HC_STRIDE;
+#pragma unroll
+    for (int j = 0; j < 3; j++) { h[HC_R + j] = o[PT_R + j]; h[HC_N + j] = o[PT_N + j]; }
+    h[HC_PHI] = o[PT_F]; h[HC_MU] = o[PT_F + 1];
+    h[HC_BODY] = __int_as_float(ba); h[HC_REP] = __int_as_float(ra);
+    h[HC_BODYB] = __int_as_float(bb); h[HC_REPB] = __int_as_float(rb);
+    const float n[3] = {o[PT_N], o[PT_N + 1], o[PT_N + 2]};
+    hard_frame(n, h + HC_T1, h + HC_T2);
+  };
   // pass 2: the selected ones (all of them, or those with fewer than kmax candidates ahead in (gap, order)), numbered in order
   int count = 0;
+  if (__ballot(total > LISTMAX) == 0ull) {
+    // ... walking the list: a lane per candidate (one round for up to G of them, instead of one per G slots)
+    for (int base = 0; __ballot(base < total) != 0ull; base += G) {
+      const int k0 = base + l;
+      const bool cand = k0 < total;
+      const float ph = cand ? scratch[2 * k0] : 0.0f;
+      const int idx = cand ? __float_as_int(scratch[2 * k0 + 1]) : 0;
+      bool sel = cand;
+      if (overflow && cand) {
+        int rank = 0;
+        for (int j = 0; j < total; j++) {
+          const float pj = scratch[2 * j];
+          const int ij = __float_as_int(scratch[2 * j + 1]);
+          rank += (pj < ph || (pj == ph && ij < idx)) ? 1 : 0;
+        }
+        sel = rank < kmax;
+      }
+      const unsigned long long mask = (__ballot(sel) >> lane0) & gmask;
+      if (sel) {
+        int ba = -1, bb = -1, ra = -1, rb = -1;
+        const float* o = hg_slot(m, S, L, Q, H, idx, &ba, &bb, &ra, &rb);
+        record(count + __builtin_popcountll(mask & ((1ull << l) - 1ull)), o, ba, bb, ra, rb);
+      }
+      count += __builtin_popcountll(mask);
+    }
+    GROUP_SYNC();       // (the list's place becomes the response matrix)
+    return count;
+  }
+  // (more candidates than the list holds in some env of the wavefront: slot by slot, ranking by a scan over every slot)
   for (int base = 0; base < H.P4; base += G) {
     const int idx = base + l;
     int ba = -1, bb = -1, ra = -1, rb = -1;
     const float* o = idx < H.P4 ? hg_slot(m, S, L, Q, H, idx, &ba, &bb, &ra, &rb) : nullptr;
     bool sel = o != nullptr && o[PT_ON] != 0.0f;
     if (__ballot(overflow && sel) != 0ull) {
-      // rank by a scan over every candidate: only when an env of the wavefront holds more than the solve does
       int rank = 0;
       const float ph = sel ? o[PT_F] : 0.0f;
       if (overflow && sel) {
@@ -369,17 +415,7 @@ DEV int hg_gather(const StepCtx& C, const EnvLds& L, const SlotLay& Q, const HgS
       }
     }
     const unsigned long long mask = (__ballot(sel) >> lane0) & gmask;
-    if (sel) {
-      const int k = count + __builtin_popcountll(mask & ((1ull << l) - 1ull));
-      float* h = hc + k * HC_STRIDE;
-#pragma unroll
-      for (int j = 0; j < 3; j++) { h[HC_R + j] = o[PT_R + j]; h[HC_N + j] = o[PT_N + j]; }
-      h[HC_PHI] = o[PT_F]; h[HC_MU] = o[PT_F + 1];
-      h[HC_BODY] = __int_as_float(ba); h[HC_REP] = __int_as_float(ra);
-      h[HC_BODYB] = __int_as_float(bb); h[HC_REPB] = __int_as_float(rb);
-      const float n[3] = {o[PT_N], o[PT_N + 1], o[PT_N + 2]};
-      hard_frame(n, h + HC_T1, h + HC_T2);
-    }
+    if (sel) record(count + __builtin_popcountll(mask & ((1ull << l) - 1ull)), o, ba, bb, ra, rb);
     count += __builtin_popcountll(mask);
   }
   return count;
@@ -518,7 +554,7 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
   H.nself = SELF ? nself : 0; H.nbx = nbx; H.T = 1 + nbx; H.nsph = BOX ? m->nsph : 0; H.nlink = LINK ? nlink : 0;
   H.self_slot0 = self_slot0; H.link_slot0 = link_slot0;
   H.P1 = H.nev + H.nself; H.P2 = H.P1 + nbx * 8 * H.T; H.P3 = H.P2 + H.nsph * nbx; H.P4 = H.P3 + H.nlink;
-  const int K = hg_gather<G>(C, L, Q, H, l, hc, kmax);
+  const int K = hg_gather<G>(C, L, Q, H, l, hc, kmax, W);
   GROUP_SYNC();
   PHASE_MARK(33);
 
