@@ -1,13 +1,13 @@
 #!/bin/bash
 # On the GPU box (gpurun): everything the round's numbers are quoted from, in one pass -> gpurun_out/final/.
 # Afterwards (here): copy bench_*.json to profiles/r05_bench_*.json, run tools/summarize_prof.py on the prof_* dirs.
-# Usage: tools/final_evidence.sh [part ...]   parts: tests bench sweep hooks phase prof  (default: all)
+# Usage: tools/final_evidence.sh [part ...]   parts: tests bench sweep hooks phase prof prof_abb soak  (default: all but prof_abb)
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/final
 mkdir -p "$OUT"
 cd "$REPO"
-PARTS=${*:-tests bench sweep hooks phase prof}
+PARTS=${*:-tests bench sweep hooks phase prof soak}
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 B="--steps 500 --warmup 50"
 if has tests; then
@@ -21,7 +21,7 @@ if has bench; then
     python bench.py --workload $W $B > "$OUT/bench_$W.json" 2> "$OUT/bench_$W.err"
   done
   python bench.py --steps 20 --warmup 5 > "$OUT/bench_terrain_driver_shape.json" 2>/dev/null
-  python bench.py --workload trimesh --self-collision $B --no-cpu-baseline > "$OUT/bench_trimesh_selfcollision.json" 2>/dev/null
+  python bench.py --workload trimesh --self-collision $B --no-cpu-baseline --no-other-solver > "$OUT/bench_trimesh_selfcollision.json" 2>/dev/null
   python bench.py --workload abb --no-link-contacts $B --no-cpu-baseline > "$OUT/bench_abb_rod_only.json" 2>/dev/null
   # ... and the compliant law of rounds 1-4 (opt-in) on the same
   for W in terrain flat trimesh abb; do
@@ -51,6 +51,10 @@ if has phase; then
   python tools/phase_clock.py 32 100 --abb --link --pgs > "$OUT/phase_abb_pgs_link.txt" 2>&1
   python tools/phase_clock.py 32 100 --abb --pgs --levels > "$OUT/phase_abb_pgs_rod.txt" 2>&1
 fi
+if has prof_abb; then
+  bash tools/profile.sh r05_abb_pgs --workload abb > /dev/null 2>&1
+  find "$REPO/gpurun_out" -name "*kernel_trace.csv" -size +4M -delete
+fi
 if has prof; then
   bash tools/profile.sh r05_a1_pgs > /dev/null 2>&1                                                    # the default: k_a1_chain_pgs<false,false>
   bash tools/profile.sh r05_a1_pgs_tw_self --workload trimesh --self-collision > /dev/null 2>&1         # the reference's effective scene: <true,true>
@@ -59,5 +63,9 @@ if has prof; then
   bash tools/profile.sh r05_abb_pgs --workload abb > /dev/null 2>&1                                     # config 5 under PGS (generic kernel)
   bash tools/profile.sh r05_abb_compliant --workload abb --solver compliant > /dev/null 2>&1            # k_abb_step_ws<512,true>
   find "$REPO/gpurun_out" -name "*kernel_trace.csv" -size +4M -delete     # keep the merge under gpurun's 64 MiB
+fi
+if has soak; then
+  python tools/soak.py 5000 > "$OUT/soak.txt" 2>&1
+  grep done "$OUT/soak.txt"
 fi
 du -sh "$REPO/gpurun_out"
