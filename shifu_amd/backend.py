@@ -212,7 +212,8 @@ class Sim:
         """Per-env factors on the mass and inertia tensor of each body of the articulation (centre of mass unchanged):
         gym.set_actor_rigid_body_properties(env, actor, props, recomputeInertia=True) with props[b].mass = factor x the
         asset's (shifu/units/units.py:104-110).  scale: (num_envs, nb), > 0; returns the bound tensor -- later edits in place
-        are seen by the next step.  None unbinds (factors 1)."""
+        are seen by the next step.  None unbinds (factors 1).  Bind before capturing a step into a hipGraph: the kernels take the
+        tensor's address as a launch argument, and a graph captured earlier keeps replaying with the address it saw (none)."""
         if scale is None:
             check(lib().shf_sim_bind(self._h, _abi.T_BODY_MASS_SCALE, None))
             self.tensors.pop(_abi.T_BODY_MASS_SCALE, None)

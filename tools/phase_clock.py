@@ -95,6 +95,10 @@ def main():
                             'box wave: wait at S0\'', 'box wave: link passes', 'box wave: idle from its link passes to S4']
         extra_names[12] = '(debug counter, not a time)'
     if link and not split:
+        # the link passes' own clock (csrc/shf_boxes.h: link_contacts): marks 24-28; mark 20 then spans all of them once more
+        extra_names[7:12] = ['link: broad phase (body, box) pairs', 'link: pair set-up', 'link: sample points vs the box (family A)',
+                             'link: capsule / rounded shapes', 'link: box volumes vs the box (corners, edges: family B / E)']
+        extra_names[3] = 'all link passes (marks 24-28 once more) + sync'
         print(f"  link contacts: {buf[29] / max(buf[31], 1):.2f} live (body, box) pairs per wavefront and sub-step, "
               f"{buf[30] / max(buf[31], 1):.2f} in its first env; stage 0 (broad phase) = mark 24")
     if pgs and not abb:
