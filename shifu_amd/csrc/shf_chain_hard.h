@@ -122,10 +122,20 @@ DEV void chain_hard_apply(const ShfModel* m, const ChainLds& L, float* tail, int
 #pragma unroll
     for (int j = 0; j < 6; j++) pcr[q][j] = 0.0f;
   if (isbody_h0) {
-    for (int c = 0; c < K; c++) {
+    // which constraints act on this body: the ids of all of them in flight at once (a load per iteration behind its own
+    // branch would serialise eight LDS round trips)
+    unsigned mine_a = 0u, mine_b = 0u;
+#pragma unroll
+    for (int c = 0; c < HCK; c++) {
       const float* h = tail + T::HC + c * HC_STRIDE;
-      const bool ona = __float_as_int(h[HC_BODY]) == myb, onb = __float_as_int(h[HC_BODYB]) == myb;
-      if (!ona && !onb) continue;
+      const int ia = __float_as_int(h[HC_BODY]), ib = __float_as_int(h[HC_BODYB]);
+      if (c < K && ia == myb) mine_a |= 1u << c;
+      if (c < K && ib == myb) mine_b |= 1u << c;
+    }
+    for (unsigned bits = mine_a | mine_b; bits; bits &= bits - 1u) {
+      const int c = __builtin_ctz(bits);
+      const float* h = tail + T::HC + c * HC_STRIDE;
+      const bool ona = (mine_a >> c) & 1u;
       const float r[3] = {h[HC_R], h[HC_R + 1], h[HC_R + 2]};
 #pragma unroll
       for (int q = 0; q < NQ; q++) {

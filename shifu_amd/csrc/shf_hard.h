@@ -589,10 +589,19 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
     const int NQ = nvel > 0 ? 2 : 1;
     float pc[2][6] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};
     if (isdyn || dynbox) {
-      for (int c = 0; c < K; c++) {
+      // which constraints act on this body: the ids of all of them in flight at once (not a load per iteration behind its branch)
+      unsigned mine_a = 0u, mine_b = 0u;
+#pragma unroll
+      for (int c = 0; c < HCK; c++) {
         const float* h = hc + c * HC_STRIDE;
-        const bool ona = __float_as_int(h[HC_BODY]) == l, onb = __float_as_int(h[HC_BODYB]) == l;
-        if (!ona && !onb) continue;
+        const int ia = __float_as_int(h[HC_BODY]), ib = __float_as_int(h[HC_BODYB]);
+        if (c < K && ia == l) mine_a |= 1u << c;
+        if (c < K && ib == l) mine_b |= 1u << c;
+      }
+      for (unsigned bits = mine_a | mine_b; bits; bits &= bits - 1u) {
+        const int c = __builtin_ctz(bits);
+        const float* h = hc + c * HC_STRIDE;
+        const bool ona = (mine_a >> c) & 1u;
         const float r[3] = {h[HC_R], h[HC_R + 1], h[HC_R + 2]};
 #pragma unroll
         for (int q = 0; q < 2; q++) {
