@@ -647,16 +647,24 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
       if constexpr (SELF) {
         if (__ballot(bsb >= 0) != 0ull) hard_impulse<CD>(L, tail, bsb >= 0 ? bsb : 0, rj, e, qb);
       }
+      // (the targets' body ids first, all in flight at once: each iteration's link reads then do not wait behind its own record read)
+      int btas[HCK], btbs[HCK];
+#pragma unroll
+      for (int i = 0; i < HCK; i++) {
+        btas[i] = __float_as_int(tail[T::HC + i * HC_STRIDE + HC_BODY]);
+        btbs[i] = SELF ? __float_as_int(tail[T::HC + i * HC_STRIDE + HC_BODYB]) : -1;
+      }
+#pragma unroll
       for (int i = 0; i < HCK; i++) {
         if (__ballot(i < K) == 0ull) break;
         if (!(col && i < K)) continue;
         const float* hi = tail + T::HC + i * HC_STRIDE;
         const float ri[3] = {hi[HC_R], hi[HC_R + 1], hi[HC_R + 2]};
-        const int bta = __float_as_int(hi[HC_BODY]);
+        const int bta = btas[i];
         float aa[3], ab[3] = {0.0f, 0.0f, 0.0f}, ba[3] = {0.0f, 0.0f, 0.0f}, bb[3] = {0.0f, 0.0f, 0.0f};
         hard_velocity<CD>(L, tail, qa, bta, ri, aa);
         if constexpr (SELF) {
-          const int btb = __float_as_int(hi[HC_BODYB]);
+          const int btb = btbs[i];
           hard_velocity<CD>(L, tail, qa, btb, ri, ab);
           if (bsb >= 0) {
             hard_velocity<CD>(L, tail, qb, bta, ri, ba);
