@@ -1,7 +1,7 @@
 #!/bin/bash
 # On the GPU box (gpurun): everything the round's numbers are quoted from, in one pass -> gpurun_out/final/.
 # Afterwards (here): copy bench_*.json to profiles/r05_bench_*.json, run tools/summarize_prof.py on the prof_* dirs.
-# Usage: tools/final_evidence.sh [part ...]   parts: tests bench sweep hooks phase prof prof_abb soak  (default: all but prof_abb)
+# Usage: tools/final_evidence.sh [part ...]   parts: tests bench sweep hooks phase prof prof_a1 prof_abb soak fuzz  (default: all but prof_a1 / prof_abb / fuzz)
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/final
@@ -50,6 +50,15 @@ if has phase; then
   python tools/phase_clock.py 32 200 --chain > "$OUT/phase_a1_chain_g32.txt" 2>&1
   python tools/phase_clock.py 32 100 --abb --link --pgs > "$OUT/phase_abb_pgs_link.txt" 2>&1
   python tools/phase_clock.py 32 100 --abb --pgs --levels > "$OUT/phase_abb_pgs_rod.txt" 2>&1
+fi
+if has prof_a1; then
+  bash tools/profile.sh r05_a1_pgs > /dev/null 2>&1
+  bash tools/profile.sh r05_a1_pgs_tw_self --workload trimesh --self-collision > /dev/null 2>&1
+  find "$REPO/gpurun_out" -name "*kernel_trace.csv" -size +4M -delete
+fi
+if has fuzz; then
+  python tools/fuzz_parity.py --steps 2000 --envs 384 2>&1 | grep "^{" > "$OUT/fuzz.txt"
+  wc -l "$OUT/fuzz.txt"
 fi
 if has prof_abb; then
   bash tools/profile.sh r05_abb_pgs --workload abb > /dev/null 2>&1
