@@ -424,43 +424,38 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
     if (__ballot(total > kmax) != 0ull) {
       // more candidates than the solve holds (somewhere in this wavefront): keep the kmax with the smallest gap, ties by
       // candidate order (slots, then self-contacts)
-      float* phis = tail + T::PHI;
+      // The gaps as a compact list in candidate order (sample-point slots ascending, then the self-contacts): a candidate's rank
+      // is the number of entries that come before it in (gap, position).  Read four entries at a time -- a list walked one LDS
+      // round trip per entry was most of this phase for the wavefronts that overflow.
+      float* lp = tail + T::PHI;
+      int pos[NR];
 #pragma unroll
-      for (int k = 0; k < NR; k++)
-        if (cand[k]) phis[l + k * G] = ph[k];
-      if (scand) phis[T::NEVP + l] = sph;
+      for (int k = 0; k < NR; k++) {
+        const int sl = l + k * G;
+        pos[k] = sl < 64 ? __popcll(act.w[0] & ((1ull << sl) - 1ull)) : __popcll(act.w[0]) + __popcll(act.w[1] & ((1ull << (sl - 64)) - 1ull));
+        if (cand[k]) lp[pos[k]] = ph[k];
+      }
+      const int spos = npts + l;
+      if (scand) lp[spos] = sph;
+      if (l < 4) lp[total + l] = 3.0e38f;          // padding to a multiple of four: behind every gap
       GROUP_SYNC();
       if (total > kmax) {
+        int rank[NR], srank = 0;
 #pragma unroll
-        for (int k = 0; k < NR; k++) {
-          if (!cand[k]) continue;
-          const int s = l + k * G;
-          int rank = 0;
-          for (int wd = 0; wd < 2; wd++) {
-            unsigned long long bits = act.w[wd];
-            while (bits) {
-              const int j = __builtin_ctzll(bits) + 64 * wd;
-              bits &= bits - 1ull;
-              const float pj = phis[j];
-              rank += (pj < ph[k] || (pj == ph[k] && j < s)) ? 1 : 0;
-            }
+        for (int k = 0; k < NR; k++) rank[k] = 0;
+        for (int j4 = 0; j4 < total; j4 += 4) {
+          const float4 pj4 = *reinterpret_cast<const float4*>(lp + j4);
+          const float pj[4] = {pj4.x, pj4.y, pj4.z, pj4.w};
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+#pragma unroll
+            for (int k = 0; k < NR; k++) rank[k] += (pj[e] < ph[k] || (pj[e] == ph[k] && j4 + e < pos[k])) ? 1 : 0;
+            if constexpr (SELF) srank += (pj[e] < sph || (pj[e] == sph && j4 + e < spos)) ? 1 : 0;
           }
-          for (int j = 0; j < nself; j++) rank += phis[T::NEVP + j] < ph[k] ? 1 : 0;
-          cand[k] = rank < kmax;
         }
-        if (scand) {
-          int rank = 0;
-          for (int wd = 0; wd < 2; wd++) {
-            unsigned long long bits = act.w[wd];
-            while (bits) {
-              const int j = __builtin_ctzll(bits) + 64 * wd;
-              bits &= bits - 1ull;
-              rank += phis[j] <= sph ? 1 : 0;
-            }
-          }
-          for (int j = 0; j < nself; j++) { const float pj = phis[T::NEVP + j]; rank += (pj < sph || (pj == sph && j < l)) ? 1 : 0; }
-          scand = rank < kmax;
-        }
+#pragma unroll
+        for (int k = 0; k < NR; k++) cand[k] = cand[k] && rank[k] < kmax;
+        if constexpr (SELF) scand = scand && srank < kmax;
         if (l == 0 && C.dropped) *C.dropped += total - kmax;
       }
       act.w[0] = 0ull; act.w[1] = 0ull;
