@@ -875,9 +875,10 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
     if (isbody && half == 0) {
       const bool last = islink && (lb % NLK) == NLK - 1;
       float f[3] = {0.0f, 0.0f, 0.0f}, fw[3] = {0.0f, 0.0f, 0.0f};
-      for (int c = 0; c < K; c++) {
+#pragma unroll
+      for (int c = 0; c < HCK; c++) {      // (unrolled: the records of all constraints in flight at once)
         const float* h = tail + T::HC + c * HC_STRIDE;
-        const int rep = __float_as_int(h[HC_REP]), repb = __float_as_int(h[HC_REPB]);
+        const int rep = c < K ? __float_as_int(h[HC_REP]) : -9, repb = c < K ? __float_as_int(h[HC_REPB]) : -9;
         const float pf[3] = {(nvel > 0 ? h[HC_PV0] : h[HC_P]) * idt, (nvel > 0 ? h[HC_PV1] : h[HC_P + 1]) * idt, (nvel > 0 ? h[HC_PV2] : h[HC_P + 2]) * idt};
         if (rep == myb) { f[0] += pf[0]; f[1] += pf[1]; f[2] += pf[2]; }
         else if (last && rep == myb + 1) { fw[0] += pf[0]; fw[1] += pf[1]; fw[2] += pf[2]; }
