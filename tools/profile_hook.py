@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--abb", action="store_true")
     ap.add_argument("--top", type=int, default=45)
+    ap.add_argument("--graph-hooks", action="store_true", help="env.enable_graph_hooks(): the hooks replayed from two hipGraphs")
     args = ap.parse_args()
     np.random.seed(0); torch.manual_seed(0)
     if args.abb:
@@ -31,6 +32,8 @@ def main():
     cfg = Cfg(); cfg.num_envs = args.envs
     env = Env(cfg)
     env.reset()
+    if args.graph_hooks:
+        env.enable_graph_hooks()
     n, a = env.num_envs, env.num_actions
     acts = [2 * torch.rand(n, a, device=env.device) - 1 for _ in range(8)]
     for i in range(20):
