@@ -1608,3 +1608,37 @@ def test_per_env_link_masses_fused_abb_step_matches_oracle_bitwise(oracle, kw):
                     got = (env.sim.tensors if k in _ABB_SIM_T else env.task.tensors)[t].cpu().numpy().reshape(bufs[k].shape)
                     np.testing.assert_array_equal(got, bufs[k], err_msg=f"{k} step {it}")
     assert np.isfinite(bufs["obs"]).all()
+
+
+def test_velocity_level_solve_keeps_every_net_contact_force_in_the_friction_cone_at_full_size():
+    """A size-independent property of the solve at BASELINE's size (4096 envs, flat ground, random actions, falls and resets):
+    every constraint's impulse leaves the sweeps inside its Coulomb cone (the last visit projects it), the cone is convex and
+    on flat ground all of a body's contacts share the normal, so the NET contact force on every body pushes up and
+    |F_xy| <= mu F_z -- with mu = (shape friction of the env + terrain friction) / 2.  Under the compliant law this does not
+    hold (its friction is a viscous law capped per point), which the last lines check as a control."""
+    _need_gpu()
+    from shifu_amd.gym.a1_fused import FusedA1Env
+    n = 4096
+    worst = {}
+    for solver in ("pgs", "compliant"):
+        env = FusedA1Env(num_envs=n, terrain="flat", seed=7, solver=solver)
+        assert env.solver == solver
+        env.reset()
+        mu = 0.5 * (env.sim.tensors[_abi.T_FRICTION].view(n, 1) + float(env.sim.terrain.friction if env.sim.terrain is not None else 1.0))
+        g = torch.Generator(device="cuda:0").manual_seed(3)
+        loaded, w = 0, 0.0
+        for it in range(60):
+            env.step(2 * torch.rand(n, 12, device="cuda:0", generator=g) - 1)
+            F = env.contact_state.view(n, -1, 3)
+            fz, fxy = F[:, :, 2], F[:, :, :2].norm(dim=-1)
+            assert torch.isfinite(F).all()
+            if solver == "pgs":
+                assert float(fz.min()) >= -1e-4, (it, float(fz.min()))
+            excess = (fxy - mu * fz.clamp_min(0.0)) / (1.0 + fz.abs())
+            w = max(w, float(excess.max()))
+            loaded += int((fz > 1.0).sum())
+        worst[solver] = w
+        assert loaded > 10 * n, "the run must put weight on the ground"
+        env.destroy()
+    assert worst["pgs"] <= 1e-4, worst
+    assert worst["compliant"] > 1e-3, worst       # the control: the property is the solver's, not the scene's
