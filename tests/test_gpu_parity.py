@@ -1642,3 +1642,86 @@ def test_velocity_level_solve_keeps_every_net_contact_force_in_the_friction_cone
         env.destroy()
     assert worst["pgs"] <= 1e-4, worst
     assert worst["compliant"] > 1e-3, worst       # the control: the property is the solver's, not the scene's
+
+
+@pytest.mark.parametrize("pos_iters,vel_iters,kmax", [(4, 0, 8), (1, 2, 5), (8, 1, 1), (2, 0, 3), (12, 3, 8)])
+def test_velocity_level_solve_other_iteration_counts_match_oracle_bitwise(oracle, pos_iters, vel_iters, kmax):
+    """physx.num_position_iterations / num_velocity_iterations / the constraint limit away from the reference's 8 + 1 / 8: no
+    velocity iterations at all (one impulse set through the tree, poses and velocities from it), several, a single
+    constraint per env -- the fused A1 step (k_a1_chain_pgs) and gym.simulate on a generic articulation (k_sim_step<32,..,HARD>
+    through a 13-body A1) against the oracle, every tensor."""
+    _need_gpu()
+    n = 64
+    kw = dict(solver="pgs", pos_iters=pos_iters, vel_iters=vel_iters, max_contacts=kmax)
+    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, group="chain32", env_off=50, **kw)
+    assert sp.pos_iters == pos_iters and sp.vel_iters == vel_iters and sp.max_contacts == kmax
+    for it in range(60):
+        raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32) * 1.5
+        task.step(torch.from_numpy(raw).cuda())
+        oracle.a1_step(cm.blob, sp, tp, n, 50, bufs, raw, terrain=terr, heights=hs)
+        if it % 6 == 5 or it < 2:
+            _compare(sim, task, bufs, f"a1 step {it}")
+    assert np.isfinite(bufs["obs"]).all() and np.abs(bufs["contact"]).max() > 5.0
+    # the run-time-shaped kernel: the A1 with its feet merged into the shanks (13 bodies: not the chain kernel's shape)
+    from shifu_amd.model import asset_path, compile_urdf
+    cg = compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT, honour_dont_collapse=False)
+    m = cg.blob
+    assert m.nb == 13
+    spg = H.sim_params(angular_damping=0.5, **kw)
+    rng = np.random.default_rng(8)
+    terr, hs = _terrain(rng, rough=True)
+    dof, root = _random_states(m, n, rng)
+    simg = _make_sim(cg, spg, n, terr, hs, group=32)
+    T = simg.tensors
+    T[_abi.T_SIM_DOF].copy_(torch.from_numpy(dof))
+    T[_abi.T_SIM_ROOT].copy_(torch.from_numpy(root))
+    for it in range(40):
+        eff = rng.uniform(-20, 20, n * m.nd).astype(np.float32)
+        simg.set_dof_command(_abi.T_EFFORT, torch.from_numpy(eff).cuda())
+        simg.step()
+        simg.refresh(_abi.REFRESH_ALL)
+        contact, bstate = oracle.step(m, spg, n, dof, root, terrain=terr, heights=hs, effort=eff, want_contact=True, want_body_state=True)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(T[_abi.T_DOF_STATE].cpu().numpy(), dof, err_msg=f"generic dof step {it}")
+        np.testing.assert_array_equal(T[_abi.T_ROOT_STATE].cpu().numpy(), root, err_msg=f"generic root step {it}")
+        np.testing.assert_array_equal(T[_abi.T_CONTACT].cpu().numpy(), contact, err_msg=f"generic contact step {it}")
+    assert np.isfinite(root).all() and (np.abs(contact).sum(1) > 0).any()
+
+
+def test_velocity_level_solve_other_contact_parameters_match_oracle_bitwise(oracle):
+    """The other physx / material fields away from their defaults -- rest_offset, contact_offset, bounce_threshold_velocity with
+    a restitution > 0 (robots dropped from 0.5 m bounce), max_depenetration_velocity, the Baumgarte factor -- on the fused A1
+    step and on gym.simulate of the 13-body variant, against the oracle."""
+    _need_gpu()
+    n = 64
+    kw = dict(solver="pgs", rest_offset=0.002, contact_offset=0.02, bounce_threshold=0.2, restitution=0.5, erp=0.3, max_depen_vel=0.5)
+    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, group="chain32", env_off=9, **kw)
+    assert abs(sp.restitution - 0.5) < 1e-7 and abs(sp.rest_offset - 0.002) < 1e-9
+    for it in range(60):
+        raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32) * 1.5
+        task.step(torch.from_numpy(raw).cuda())
+        oracle.a1_step(cm.blob, sp, tp, n, 9, bufs, raw, terrain=terr, heights=hs)
+        if it % 6 == 5 or it < 2:
+            _compare(sim, task, bufs, f"a1 step {it}")
+    assert np.isfinite(bufs["obs"]).all()
+    from shifu_amd.model import asset_path, compile_urdf
+    cg = compile_urdf(asset_path("a1.urdf"), default_dof_drive_mode=_abi.DOF_MODE_EFFORT, honour_dont_collapse=False)
+    m = cg.blob
+    spg = H.sim_params(angular_damping=0.5, **kw)
+    rng = np.random.default_rng(18)
+    dof, root = _random_states(m, n, rng, z_lo=0.4, z_hi=0.6)
+    simg = _make_sim(cg, spg, n, group=32)
+    T = simg.tensors
+    T[_abi.T_SIM_DOF].copy_(torch.from_numpy(dof))
+    T[_abi.T_SIM_ROOT].copy_(torch.from_numpy(root))
+    up = False
+    for it in range(120):
+        simg.step()
+        simg.refresh(_abi.REFRESH_ALL)
+        contact, bstate = oracle.step(m, spg, n, dof, root, want_contact=True, want_body_state=True)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(T[_abi.T_DOF_STATE].cpu().numpy(), dof, err_msg=f"generic dof step {it}")
+        np.testing.assert_array_equal(T[_abi.T_ROOT_STATE].cpu().numpy(), root, err_msg=f"generic root step {it}")
+        np.testing.assert_array_equal(T[_abi.T_CONTACT].cpu().numpy(), contact, err_msg=f"generic contact step {it}")
+        up |= bool(((np.abs(contact).reshape(n, m.nb, 3).sum((1, 2)) == 0) & (root[:, 9] > 0.2)).any() and it > 40)
+    assert np.isfinite(root).all() and up, "some robot left the ground again after its first impact (restitution)"
