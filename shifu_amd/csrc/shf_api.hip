@@ -75,7 +75,7 @@ extern "C" int shf_abi_version(void) { return SHF_ABI_VERSION; }
 
 // gym.simulate: one sub-step for every env
 // HARD: the velocity-level contact solve (ShfSimParams.solver == SHF_SOLVER_PGS; csrc/shf_hard.h): 32 lanes per env, and
-// HG_WORDS more LDS words per env behind the contact slots (constraint records + response matrix)
+// hard_total_slots() contact slots per env (the solve's records and response matrix live inside the slot region, csrc/shf_hard.h)
 template <int G, bool BOX, bool SELF, bool LINK = false, bool HARD = false>
 __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
   const int nbx = BOX ? A.nboxes : 0, actors = 1 + nbx;
   const int nb = m->nb, nd = m->nd, nbt = nb + nbx;
   const int nslots = m->np + (BOX ? box_slots(slot_lay<DynScene>(m, scene)) : 0) + (SELF ? SHF_MAX_SELF_CONTACTS : 0) + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0);
-  EnvLds L = env_lds_carve(smem + MODEL_WORDS + (BOX ? SCENE_WORDS : 0) + es * env_lds_words(nbt, nd, nslots + (HARD ? HG_WORDS / PT_STRIDE : 0), 0, actors),
+  EnvLds L = env_lds_carve(smem + MODEL_WORDS + (BOX ? SCENE_WORDS : 0) + es * env_lds_words(nbt, nd, HARD ? hard_total_slots(nslots, LINK) : nslots, 0, actors),
                            nbt, nd, nslots, actors);
   float* dof = A.dof + (size_t)e * nd * 2;
   float* root = A.root + (size_t)e * actors * 13;
@@ -585,8 +585,9 @@ DEV void abb_post_step(const AbbArgs& A, const ShfAbbTaskParams& tp, const ShfMo
 #define ABB_TGT_WORDS(nd) (((nd) + 2 + 3) & ~3)                     /* POS targets + the end effector's x, y */
 #define WS_LINK_STASH_WORDS 32   /* k_abb_step_ws<512, true>: the free box's (IA, pA) and its corner ballots, parked per env */
 #define ABB_TAIL_WORDS(nslots, nd) ((nslots) * PT_STRIDE + ABB_TGT_WORDS(nd) + ARM_KREC_WORDS(SHF_ARM_MAX_LINKS) + 4)
+#define ABB_TAIL_WORDS_NOARM(nslots, nd) ((nslots) * PT_STRIDE + ABB_TGT_WORDS(nd) + 4)   /* (ARM = 0 and HARD: no link records of the arm recursions) */
 template <int G, class DM, class SC, bool LINK = false, int ARM = 0, bool HARD = false>
-__global__ __launch_bounds__(256, (G >= 32 && SC::NBX > 0) ? 2 : 1) void k_abb_step(AbbArgs A) {
+__global__ __launch_bounds__(256, ((G >= 32 && SC::NBX > 0) || (HARD && !LINK)) ? 2 : 1) void k_abb_step(AbbArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   PHASE_BEGIN();
   float* stats_lds = smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS;
@@ -607,8 +608,8 @@ __global__ __launch_bounds__(256, (G >= 32 && SC::NBX > 0) ? 2 : 1) void k_abb_s
   const int nbx = SC::NBX > 0 ? SC::NBX : A.S.nboxes, actors = 1 + nbx;
   const int nb = DM::nb(m), nd = DM::nd(m), nbt = nb + nbx;
   const int nslots = DM::np(m) + box_slots(slot_lay<SC>(m, scene)) + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0);
-  const int nslots_all = nslots + (HARD ? HG_WORDS / PT_STRIDE : 0);   // HARD: the solve's records and response matrix behind the slots
-  const int env_words = env_lds_words(nbt, nd, nslots_all, ABB_TAIL_WORDS(nslots_all, nd), actors);
+  const int nslots_all = HARD ? hard_total_slots(nslots, LINK) : nslots;   // HARD: the solve's records and response matrix inside the slot region
+  const int env_words = env_lds_words(nbt, nd, nslots_all, HARD ? ABB_TAIL_WORDS_NOARM(nslots_all, nd) : ABB_TAIL_WORDS(nslots_all, nd), actors);
   EnvLds L = env_lds_carve(smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS + es * env_words, nbt, nd, nslots_all, actors);
   float* tgtl = L.pt + nslots_all * PT_STRIDE;  // POS targets of this env step
   float* krec = tgtl + ABB_TGT_WORDS(nd);
@@ -1019,8 +1020,9 @@ static int sim_ndyn(const ShfSim* s) {   // free boxes: the only ones that own c
 static size_t sim_lds_bytes(const ShfSim* s, int head_words, int min_tail, bool boxes = false) {
   const int epb = 256 / s->group;
   const int nbx = boxes ? s->nboxes : 0;
-  const int nslots = s->model.np + (boxes ? box_slot_count(nbx, sim_ndyn(s), s->model.nsph) : 0) + (sim_self(s) ? SHF_MAX_SELF_CONTACTS : 0) +
-                     ((boxes && sim_link(s)) ? 2 * SHF_MAX_LINK_CONTACTS : 0) + (s->sp.solver == SHF_SOLVER_PGS ? HG_WORDS / PT_STRIDE : 0);
+  int nslots = s->model.np + (boxes ? box_slot_count(nbx, sim_ndyn(s), s->model.nsph) : 0) + (sim_self(s) ? SHF_MAX_SELF_CONTACTS : 0) +
+               ((boxes && sim_link(s)) ? 2 * SHF_MAX_LINK_CONTACTS : 0);
+  if (s->sp.solver == SHF_SOLVER_PGS) nslots = hard_total_slots(nslots, boxes && sim_link(s));
   return ((size_t)MODEL_WORDS + head_words + (boxes ? SCENE_WORDS : 0) +
           (size_t)epb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, min_tail, 1 + (boxes ? nbx : s->nboxes))) * 4;
 }
@@ -1745,9 +1747,9 @@ static int abb_step_launch(ShfAbbTask* task, const float* raw_actions_dev, void*
     if (s->sp.max_contacts > HCK || s->sp.pos_iters < 1) return fail("shf_abb_step: SHF_SOLVER_PGS needs pos_iters >= 1 and max_contacts <= 8");
     if (s->model.nlevels > HG_LEV || s->model.nb + s->nboxes > 32) return fail("shf_abb_step: SHF_SOLVER_PGS: at most 8 tree levels and 32 bodies + box actors");
     const int nbx = s->nboxes;
-    const int nslots = s->model.np + box_slot_count(nbx, sim_ndyn(s), s->model.nsph) + (sim_link(s) ? 2 * SHF_MAX_LINK_CONTACTS : 0) + HG_WORDS / PT_STRIDE;
+    const int nslots = hard_total_slots(s->model.np + box_slot_count(nbx, sim_ndyn(s), s->model.nsph) + (sim_link(s) ? 2 * SHF_MAX_LINK_CONTACTS : 0), sim_link(s));
     const size_t lds = ((size_t)MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS +
-                        (size_t)8 * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, ABB_TAIL_WORDS(nslots, s->model.nd), 1 + nbx)) * 4;
+                        (size_t)8 * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, ABB_TAIL_WORDS_NOARM(nslots, s->model.nd), 1 + nbx)) * 4;
     const dim3 hgrid((s->n + 7) / 8), hblock(256);
     return sim_link(s) ? launch(k_abb_step<32, DynDims, DynScene, true, 0, true>, hgrid, hblock, lds, stream, A)
                        : launch(k_abb_step<32, DynDims, DynScene, false, 0, true>, hgrid, hblock, lds, stream, A);

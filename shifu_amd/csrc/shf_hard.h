@@ -36,7 +36,24 @@
 #define HC_PV1 22
 #define HC_PV2 23
 #define HG_LEV 8        /* deepest tree the generic solve walks (ShfModel.nlevels) */
-#define HG_WORDS (HCK * HC_STRIDE + HCK * HCK * 9)   /* extra LDS words per env: records + response matrix */
+// LDS of the generic solve inside the env's contact-slot region (PT_STRIDE-word slots; `nbase` = the scene's own slots: sample
+// points, box slots, self slots and, with link contacts, 2 x SHF_MAX_LINK_CONTACTS link slots):
+//   W (HCK x HCK blocks of 9 words = 48 slots)  in the place of slots [0, 48): every slot is dead once the constraints are gathered
+//   constraint records (HCK x HC_STRIDE words = 16 slots)  from slot hc0 >= 48 on: the link slots' pair-record half (the compliant
+//     pair laws' second records, unused here) when there are link contacts, else behind the scene's slots
+//   the gather's candidate list: words PT_CT, PT_BN of slot k < hc0 (written as zeros by the evaluation, read by nobody here)
+#define HARD_W_SLOTS ((HCK * HCK * 9) / PT_STRIDE)
+#define HARD_HC_SLOTS ((HCK * HC_STRIDE) / PT_STRIDE)
+static_assert((HCK * HCK * 9) % PT_STRIDE == 0 && (HCK * HC_STRIDE) % PT_STRIDE == 0, "the solve's LDS in whole contact slots");
+static_assert(HARD_HC_SLOTS == SHF_MAX_LINK_CONTACTS, "the constraint records fill the link slots' pair-record half");
+__host__ __device__ inline int hard_hc_slot0(int nbase, bool link) {
+  const int want = link ? nbase - SHF_MAX_LINK_CONTACTS : nbase;
+  return want < HARD_W_SLOTS ? HARD_W_SLOTS : want;
+}
+__host__ __device__ inline int hard_total_slots(int nbase, bool link) {   // contact slots of an env under the solve
+  const int t = hard_hc_slot0(nbase, link) + HARD_HC_SLOTS;
+  return t > nbase ? t : nbase;
+}
 // body record in the body's exchange slot (XCH_STRIDE words)
 #define HB_S 0
 #define HB_U 6
@@ -330,14 +347,15 @@ DEV const float* hg_slot_raw(const ShfModel* m, const SceneDev* S, const EnvLds&
 // gather: the K <= kmax candidates with the smallest gap (ties: candidate order), in candidate order, as constraint records.
 // Returns K.  oracle: hc_offer / hc_finish.
 template <int G>
-DEV int hg_gather(const StepCtx& C, const EnvLds& L, const SlotLay& Q, const HgSeq& H, int l, float* hc, int kmax, float* scratch) {
+DEV int hg_gather(const StepCtx& C, const EnvLds& L, const SlotLay& Q, const HgSeq& H, int l, float* hc, int kmax, int LISTMAX) {
   const ShfModel* m = C.m;
   const SceneDev* S = C.scene;
   const int lane0 = (int)(threadIdx.x & 63u) - l;
   const unsigned long long gmask = G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
-  // pass 1: how many candidates -- and their (gap, candidate number) pairs, in candidate order, in `scratch` (the response
-  // matrix's place, not yet in use: HCK * HCK * 9 words) for the ranking below
-  constexpr int LISTMAX = HCK * HCK * 9 / 2;
+  // pass 1: how many candidates -- and their (gap, candidate number) pairs, in candidate order, for the ranking below: entry k in
+  // the words PT_CT, PT_BN of slot k (k < LISTMAX = the first slot of the constraint records)
+  float* scratch = L.pt + PT_CT;
+  constexpr int LS = PT_STRIDE;
   int total = 0;
   for (int base = 0; base < H.P4; base += G) {
     const int idx = base + l;
@@ -347,7 +365,7 @@ DEV int hg_gather(const StepCtx& C, const EnvLds& L, const SlotLay& Q, const HgS
     const unsigned long long mask = (__ballot(on) >> lane0) & gmask;
     if (on) {
       const int k = total + __builtin_popcountll(mask & ((1ull << l) - 1ull));
-      if (k < LISTMAX) { scratch[2 * k] = o[PT_F]; scratch[2 * k + 1] = __int_as_float(idx); }
+      if (k < LISTMAX) { scratch[LS * k] = o[PT_F]; scratch[LS * k + 1] = __int_as_float(idx); }
     }
     total += __builtin_popcountll(mask);
   }
@@ -371,14 +389,14 @@ DEV int hg_gather(const StepCtx& C, const EnvLds& L, const SlotLay& Q, const HgS
     for (int base = 0; __ballot(base < total) != 0ull; base += G) {
       const int k0 = base + l;
       const bool cand = k0 < total;
-      const float ph = cand ? scratch[2 * k0] : 0.0f;
-      const int idx = cand ? __float_as_int(scratch[2 * k0 + 1]) : 0;
+      const float ph = cand ? scratch[LS * k0] : 0.0f;
+      const int idx = cand ? __float_as_int(scratch[LS * k0 + 1]) : 0;
       bool sel = cand;
       if (overflow && cand) {
         int rank = 0;
         for (int j = 0; j < total; j++) {
-          const float pj = scratch[2 * j];
-          const int ij = __float_as_int(scratch[2 * j + 1]);
+          const float pj = scratch[LS * j];
+          const int ij = __float_as_int(scratch[LS * j + 1]);
           rank += (pj < ph || (pj == ph && ij < idx)) ? 1 : 0;
         }
         sel = rank < kmax;
@@ -391,7 +409,7 @@ DEV int hg_gather(const StepCtx& C, const EnvLds& L, const SlotLay& Q, const HgS
       }
       count += __builtin_popcountll(mask);
     }
-    GROUP_SYNC();       // (the list's place becomes the response matrix)
+    GROUP_SYNC();       // (the slots' place becomes the response matrix)
     return count;
   }
   // (more candidates than the list holds in some env of the wavefront: slot by slot, ranking by a scan over every slot)
@@ -489,8 +507,9 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
   const int kd = l - nb;
   const bool dynbox = BOX && kd >= 0 && kd < nbx && box_is_dynamic(S->box[kd]);
   const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
-  float* hc = L.pt + (link_slot0 + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0)) * PT_STRIDE;
-  float* W = hc + HCK * HC_STRIDE;
+  const int hc0 = hard_hc_slot0(link_slot0 + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0), LINK);
+  float* hc = L.pt + hc0 * PT_STRIDE;
+  float* W = L.pt;           // (in the place of the first 48 slots, from the columns on: see hard_hc_slot0)
   const int npos = C.sp.pos_iters > 0 ? C.sp.pos_iters : 0, nvel = C.sp.vel_iters > 0 ? C.sp.vel_iters : 0;
   const int kmax = C.sp.max_contacts > 0 ? (C.sp.max_contacts < HCK ? C.sp.max_contacts : HCK) : HCK;
 
@@ -554,7 +573,7 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
   H.nself = SELF ? nself : 0; H.nbx = nbx; H.T = 1 + nbx; H.nsph = BOX ? m->nsph : 0; H.nlink = LINK ? nlink : 0;
   H.self_slot0 = self_slot0; H.link_slot0 = link_slot0;
   H.P1 = H.nev + H.nself; H.P2 = H.P1 + nbx * 8 * H.T; H.P3 = H.P2 + H.nsph * nbx; H.P4 = H.P3 + H.nlink;
-  const int K = hg_gather<G>(C, L, Q, H, l, hc, kmax, W);
+  const int K = hg_gather<G>(C, L, Q, H, l, hc, kmax, hc0);
   GROUP_SYNC();
   PHASE_MARK(33);
 
