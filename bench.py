@@ -509,7 +509,7 @@ def main():
                          "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
                          "traffic": None if not prof else prof.get("traffic_bytes"),
                          "traffic_source": None if not prof else prof.get("source"),
-                         "kernel": ("k_a1_chain_pgs" if (kernel == "k_a1_step" and args.solver == "pgs") else "k_a1_chain" if (kernel == "k_a1_step" and mapping == "chain") else "k_abb_step_ws" if (kernel == "k_abb_step" and mapping == "split") else kernel), "kernel_ms": kern_ms, "alg_bytes_per_env_step": b_alg,
+                         "kernel": ("k_a1_chain_pgs" if (kernel == "k_a1_step" and args.solver == "pgs") else "k_a1_chain" if (kernel == "k_a1_step" and mapping == "chain") else "k_abb_step_ws" if (kernel == "k_abb_step" and mapping == "split") else "k_abb_step_pgs_wide" if (abb and "pgs_wide" in env.task.kernel_symbol()) else kernel), "kernel_ms": kern_ms, "alg_bytes_per_env_step": b_alg,
                          "note": "latency/ALU-bound by design: a few KB of compulsory traffic per env-step (DESIGN.md 5)" +
                                  ("; alg_bytes counts the env's own tensors (state in, state / body_state / contact / Jacobian / obs out): link contacts "
                                   "add work on the LDS-resident model and scene, not tensors, so B_alg is the rod-only scene's" if (abb and args.link_contacts) else ""),

@@ -537,6 +537,9 @@ int shf_abb_bind(ShfAbbTask* task, int32_t id, void* device_ptr);
 int shf_abb_step(ShfAbbTask* task, const float* raw_actions_dev, void* stream);
 /* run_policy('random') for the ABB task: as shf_a1_step_random (three end-effector action components per env). */
 int shf_abb_step_random(ShfAbbTask* task, void* stream);
+/* Introspection (resource tables, tests): 1 when shf_abb_step runs this task under SHF_SOLVER_PGS on the 512-thread form of the
+ * run-time-shaped kernel (sixteen envs per workgroup: chosen where their LDS fits one CU), else 0. */
+int shf_abb_step_pgs_is_wide(const ShfAbbTask* task);
 /* reset_idx(arange(N)) (env.py:108-112). */
 int shf_abb_reset_all(ShfAbbTask* task, void* stream);
 

@@ -19,6 +19,7 @@ _SIGS = {
     "shf_sim_set_articulation": ([vp, C.POINTER(_abi.ShfModel)], i32),
     "shf_model_bounds": ([C.POINTER(_abi.ShfModel)], i32),
     "shf_model_pgs_supported": ([C.POINTER(_abi.ShfModel), i32], i32),
+    "shf_abb_step_pgs_is_wide": ([vp], i32),
     "shf_sim_add_box": ([vp, C.POINTER(_abi.ShfBoxDesc)], i32),
     "shf_sim_finalize": ([vp, i32, i64], i32),
     "shf_sim_set_group": ([vp, i32], i32),

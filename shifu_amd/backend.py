@@ -463,6 +463,8 @@ class AbbTask:
         fixed = mdl.nb == 7 and mdl.np == (59 if link else 3) and self.sim.nboxes == 3
         pre = f"_Z10k_abb_stepILi{self.sim.group}E"
         if self.sim.params.solver == _abi.SOLVER_PGS:    # the generic velocity-level solve: run-time shapes, 32 lanes per env
+            if lib().shf_abb_step_pgs_is_wide(self._h):   # sixteen envs per workgroup of 512 threads
+                return f"_Z19k_abb_step_pgs_wideILb{int(link)}EE"
             return f"_Z10k_abb_stepILi32E7DynDims8DynSceneLb{int(link)}ELi0ELb1EE"
         if not fixed:
             return pre + "7DynDims"

@@ -586,8 +586,9 @@ DEV void abb_post_step(const AbbArgs& A, const ShfAbbTaskParams& tp, const ShfMo
 #define WS_LINK_STASH_WORDS 32   /* k_abb_step_ws<512, true>: the free box's (IA, pA) and its corner ballots, parked per env */
 #define ABB_TAIL_WORDS(nslots, nd) ((nslots) * PT_STRIDE + ABB_TGT_WORDS(nd) + ARM_KREC_WORDS(SHF_ARM_MAX_LINKS) + 4)
 #define ABB_TAIL_WORDS_NOARM(nslots, nd) ((nslots) * PT_STRIDE + ABB_TGT_WORDS(nd) + 4)   /* (ARM = 0 and HARD: no link records of the arm recursions) */
-template <int G, class DM, class SC, bool LINK = false, int ARM = 0, bool HARD = false>
-__global__ __launch_bounds__(256, ((G >= 32 && SC::NBX > 0) || (HARD && !LINK)) ? 2 : 1) void k_abb_step(AbbArgs A) {
+// (WT threads per workgroup: 256, or 512 for k_abb_step_pgs_wide below)
+template <int G, class DM, class SC, bool LINK, int ARM, bool HARD, int WT>
+DEV void abb_step_body(const AbbArgs& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   PHASE_BEGIN();
   float* stats_lds = smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS;
@@ -596,12 +597,12 @@ __global__ __launch_bounds__(256, ((G >= 32 && SC::NBX > 0) || (HARD && !LINK)) 
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(A.tp);
     uint32_t* dst = reinterpret_cast<uint32_t*>(smem + MODEL_WORDS + SCENE_WORDS);
-    stage_block<(int)sizeof(ShfAbbTaskParams)>(src, reinterpret_cast<float*>(dst));
+    stage_block<(int)sizeof(ShfAbbTaskParams), WT>(src, reinterpret_cast<float*>(dst));
   }
-  const ShfScene* scene = stage_scene(A.S.scene, smem + MODEL_WORDS);
-  const ShfModel* m = stage_model(A.S.model, smem);
+  const ShfScene* scene = stage_scene<WT>(A.S.scene, smem + MODEL_WORDS);
+  const ShfModel* m = stage_model<WT>(A.S.model, smem);
   const ShfAbbTaskParams& tp = *reinterpret_cast<const ShfAbbTaskParams*>(smem + MODEL_WORDS + SCENE_WORDS);
-  const int epb = 256 / G, es = threadIdx.x / G, l = threadIdx.x % G;
+  const int epb = WT / G, es = threadIdx.x / G, l = threadIdx.x % G;
   const int e = blockIdx.x * epb + es;
   const int n = A.S.n;
   if (e >= n) return;
@@ -646,6 +647,17 @@ __global__ __launch_bounds__(256, ((G >= 32 && SC::NBX > 0) || (HARD && !LINK)) 
       substep<G, true, DM, false, LaneModel, SC, false, LINK, HARD>(C, L, l, M, P, tgtl, nullptr, nullptr, mu, it == nsub - 1 ? L.xch : nullptr, BL);
   }
   abb_after_physics<G, DM>(A, tp, m, L, l, e, epb, nbx, tgtl, stats_lds, stats_step);
+}
+template <int G, class DM, class SC, bool LINK = false, int ARM = 0, bool HARD = false>
+__global__ __launch_bounds__(256, ((G >= 32 && SC::NBX > 0) || (HARD && !LINK)) ? 2 : 1) void k_abb_step(AbbArgs A) {
+  abb_step_body<G, DM, SC, LINK, ARM, HARD, 256>(A);
+}
+// The run-time-shaped step under the velocity-level solve with link contacts, 16 envs per workgroup of 512 threads: one staged
+// model for sixteen envs leaves each 8.7 KB of LDS (csrc/shf_hard.h keeps the solve inside the contact-slot region), so that
+// 4096 envs are resident at once -- two wavefronts per SIMD, 256 registers each -- instead of taking two rounds.
+template <bool LINK>
+__global__ __launch_bounds__(512) void k_abb_step_pgs_wide(AbbArgs A) {
+  abb_step_body<32, DynDims, DynScene, LINK, 0, true, 512>(A);
 }
 
 // Wave-specialised form of the shipped ABB step (AbbDims arm, AbbScene boxes, 16 lanes per env).  A single wave issues
@@ -1738,6 +1750,22 @@ extern "C" int shf_abb_step(ShfAbbTask* task, const float* raw_actions_dev, void
   return abb_step_launch(task, raw_actions_dev, stream);
 }
 extern "C" int shf_abb_step_random(ShfAbbTask* task, void* stream) { return abb_step_launch(task, nullptr, stream); }
+// The generic velocity-level step of config 5: sixteen envs per workgroup of 512 threads (k_abb_step_pgs_wide) where their LDS
+// fits one CU and eight would leave a CU to a single workgroup (the shipped scene with link contacts: 8.7 KB per env); else
+// eight per workgroup of 256 (the rod-only scene: two workgroups per CU).
+static bool abb_pgs_wide(const ShfSim* s, size_t* env_bytes, size_t* head_bytes) {
+  const int nbx = s->nboxes;
+  const int nslots = hard_total_slots(s->model.np + box_slot_count(nbx, sim_ndyn(s), s->model.nsph) + (sim_link(s) ? 2 * SHF_MAX_LINK_CONTACTS : 0), sim_link(s));
+  *env_bytes = (size_t)env_lds_words(s->model.nb + nbx, s->model.nd, nslots, ABB_TAIL_WORDS_NOARM(nslots, s->model.nd), 1 + nbx) * 4;
+  *head_bytes = ((size_t)MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS) * 4;
+  const size_t cu = (size_t)160 * 1024;
+  return *head_bytes + 16 * *env_bytes <= cu && 2 * (*head_bytes + 8 * *env_bytes) > cu;
+}
+extern "C" int shf_abb_step_pgs_is_wide(const ShfAbbTask* task) {
+  if (!task || !task->sim || task->sim->sp.solver != SHF_SOLVER_PGS) return 0;
+  size_t a, b;
+  return abb_pgs_wide(task->sim, &a, &b) ? 1 : 0;
+}
 static int abb_step_launch(ShfAbbTask* task, const float* raw_actions_dev, void* stream) {
   AbbArgs A;
   if (int r = abb_args(task, raw_actions_dev, "shf_abb_step", A)) return r;
@@ -1746,10 +1774,13 @@ static int abb_step_launch(ShfAbbTask* task, const float* raw_actions_dev, void*
     // the velocity-level contact solve: the run-time-shaped body-per-lane step at 32 lanes per env (csrc/shf_hard.h)
     if (s->sp.max_contacts > HCK || s->sp.pos_iters < 1) return fail("shf_abb_step: SHF_SOLVER_PGS needs pos_iters >= 1 and max_contacts <= 8");
     if (s->model.nlevels > HG_LEV || s->model.nb + s->nboxes > 32) return fail("shf_abb_step: SHF_SOLVER_PGS: at most 8 tree levels and 32 bodies + box actors");
-    const int nbx = s->nboxes;
-    const int nslots = hard_total_slots(s->model.np + box_slot_count(nbx, sim_ndyn(s), s->model.nsph) + (sim_link(s) ? 2 * SHF_MAX_LINK_CONTACTS : 0), sim_link(s));
-    const size_t lds = ((size_t)MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS +
-                        (size_t)8 * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, ABB_TAIL_WORDS_NOARM(nslots, s->model.nd), 1 + nbx)) * 4;
+    size_t env_bytes, head_bytes;
+    if (abb_pgs_wide(s, &env_bytes, &head_bytes)) {
+      const dim3 wgrid((s->n + 15) / 16), wblock(512);
+      return sim_link(s) ? launch(k_abb_step_pgs_wide<true>, wgrid, wblock, head_bytes + 16 * env_bytes, stream, A)
+                         : launch(k_abb_step_pgs_wide<false>, wgrid, wblock, head_bytes + 16 * env_bytes, stream, A);
+    }
+    const size_t lds = head_bytes + 8 * env_bytes;
     const dim3 hgrid((s->n + 7) / 8), hblock(256);
     return sim_link(s) ? launch(k_abb_step<32, DynDims, DynScene, true, 0, true>, hgrid, hblock, lds, stream, A)
                        : launch(k_abb_step<32, DynDims, DynScene, false, 0, true>, hgrid, hblock, lds, stream, A);
