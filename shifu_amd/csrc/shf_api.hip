@@ -76,12 +76,13 @@ extern "C" int shf_abi_version(void) { return SHF_ABI_VERSION; }
 // gym.simulate: one sub-step for every env
 // HARD: the velocity-level contact solve (ShfSimParams.solver == SHF_SOLVER_PGS; csrc/shf_hard.h): 32 lanes per env, and
 // hard_total_slots() contact slots per env (the solve's records and response matrix live inside the slot region, csrc/shf_hard.h)
-template <int G, bool BOX, bool SELF, bool LINK = false, bool HARD = false>
-__global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
+// (WT threads per workgroup: 256, or 512 for k_sim_step_pgs_wide below)
+template <int G, bool BOX, bool SELF, bool LINK, bool HARD, int WT>
+DEV void sim_step_body(const SimArgs& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const ShfScene* scene = BOX ? stage_scene(A.scene, smem + MODEL_WORDS) : nullptr;
-  const ShfModel* m = stage_model(A.model, smem);
-  const int epb = 256 / G, es = threadIdx.x / G, l = threadIdx.x % G;
+  const ShfScene* scene = BOX ? stage_scene<WT>(A.scene, smem + MODEL_WORDS) : nullptr;
+  const ShfModel* m = stage_model<WT>(A.model, smem);
+  const int epb = WT / G, es = threadIdx.x / G, l = threadIdx.x % G;
   const int e = blockIdx.x * epb + es;
   if (e >= A.n) return;
   const int nbx = BOX ? A.nboxes : 0, actors = 1 + nbx;
@@ -110,6 +111,16 @@ __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
   for (int i = l; i < 2 * nd; i += G) dof[i] = L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)];
   for (int i = l; i < 13 * actors; i += G) root[i] = L.root[i];
   for (int i = l; i < 3 * nbt; i += G) A.contact[(size_t)e * nbt * 3 + i] = L.xch[i];
+}
+template <int G, bool BOX, bool SELF, bool LINK = false, bool HARD = false>
+__global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
+  sim_step_body<G, BOX, SELF, LINK, HARD, 256>(A);
+}
+// gym.simulate under the velocity-level solve for a scene with box actors and link contacts, sixteen envs per workgroup of 512
+// threads (as k_abb_step_pgs_wide: where their LDS fits one CU and eight envs would leave the CU to one workgroup)
+template <bool SELF>
+__global__ __launch_bounds__(512) void k_sim_step_pgs_wide(SimArgs A) {
+  sim_step_body<32, true, SELF, true, true, 512>(A);
 }
 
 // gym.refresh_rigid_body_state_tensor (+ refresh_jacobian_tensors for fixed bases) for one env:
@@ -1340,6 +1351,14 @@ extern "C" int shf_sim_step(ShfSim* sim, void* stream) {
     const size_t hlds = sim_lds_bytes(sim, 0, 0, sim->nboxes > 0);
     sim->group = keep;
     const dim3 hgrid((sim->n + 7) / 8), hblock(256);
+    if (sim->nboxes > 0 && sim_link(sim)) {
+      const size_t head = ((size_t)MODEL_WORDS + SCENE_WORDS) * 4, env8 = hlds - head, cu = (size_t)160 * 1024;
+      if (head + 2 * env8 <= cu && 2 * hlds > cu) {      // sixteen envs per workgroup fit a CU, two workgroups of eight do not
+        const dim3 wgrid((sim->n + 15) / 16), wblock(512);
+        return sim_self(sim) ? launch(k_sim_step_pgs_wide<true>, wgrid, wblock, head + 2 * env8, stream, A)
+                             : launch(k_sim_step_pgs_wide<false>, wgrid, wblock, head + 2 * env8, stream, A);
+      }
+    }
     if (sim->nboxes > 0) {
       if (sim_link(sim)) return sim_self(sim) ? launch(k_sim_step<32, true, true, true, true>, hgrid, hblock, hlds, stream, A)
                                               : launch(k_sim_step<32, true, false, true, true>, hgrid, hblock, hlds, stream, A);
