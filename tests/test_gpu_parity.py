@@ -1038,14 +1038,20 @@ def test_random_action_step_matches_oracle_bitwise(oracle, kind):
     assert int(ref.task.tensors[_abi.A1_RESET_COUNT].sum()) >= 0
 
 
-@pytest.mark.parametrize("mapping,group", [("split", 16), ("chain", 16), ("chain", 32)])
-@pytest.mark.parametrize("n", [1, 5, 13])
+@pytest.mark.parametrize("mapping,group", [("split", 16), ("chain", 16), ("chain", 32), ("pgs-link", 32), ("pgs", 32)])
+@pytest.mark.parametrize("n", [1, 5, 13, 37])
 def test_ragged_env_counts_abb(oracle, n, mapping, group):
     """The fused ABB step with env counts that leave lanes -- and, in the two-wave kernel, whole waves -- without an env
-    (8 envs per workgroup there: the waves of dead envs still have to meet every workgroup barrier)."""
+    (8 envs per workgroup there: the waves of dead envs still have to meet every workgroup barrier).  "pgs-link": the
+    velocity-level solve at sixteen envs per 512-thread workgroup (k_abb_step_pgs_wide); "pgs": rod-only, eight per workgroup."""
     _need_gpu()
     from shifu_amd.gym.abb_fused import FusedAbbEnv
-    env = FusedAbbEnv(num_envs=n, seed=17 + n, group=group, mapping=mapping)
+    if mapping.startswith("pgs"):
+        env = FusedAbbEnv(num_envs=n, seed=17 + n, solver="pgs", link_contacts=mapping == "pgs-link")
+        assert ("pgs_wide" in env.task.kernel_symbol()) == (mapping == "pgs-link")
+        mapping = "body"
+    else:
+        env = FusedAbbEnv(num_envs=n, seed=17 + n, group=group, mapping=mapping)
     assert env.mapping == mapping
     bufs = {k: env.sim.tensors[t].cpu().numpy().copy() for k, t in _ABB_SIM_T.items()}
     bufs.update({k: env.task.tensors[t].cpu().numpy().copy() for k, t in _ABB_T.items()})
