@@ -1736,3 +1736,30 @@ def test_velocity_level_solve_other_contact_parameters_match_oracle_bitwise(orac
         np.testing.assert_array_equal(T[_abi.T_CONTACT].cpu().numpy(), contact, err_msg=f"generic contact step {it}")
         up |= bool(((np.abs(contact).reshape(n, m.nb, 3).sum((1, 2)) == 0) & (root[:, 9] > 0.2)).any() and it > 40)
     assert np.isfinite(root).all() and up, "some robot left the ground again after its first impact (restitution)"
+
+
+def test_hard_contact_kats_on_the_gpu(oracle):
+    """tests/test_hard_contact.py's known answers on the HIP path -- a free block / sphere without joints: the run-time-shaped
+    kernel with the generic solve on an articulation of ONE body and zero dofs (zero-sized dof tensors) -- bit for bit against
+    the float oracle, and the closed forms asserted on what the GPU produced: no creep below the friction angle, Coulomb
+    acceleration g (sin - mu cos) above it, mu g deceleration to a dead stop, a dropped sphere that stops at the surface."""
+    _need_gpu()
+    from tests import kat_models as K
+    blk = K.block_model()
+    nodof = np.zeros((0, 2), np.float32)
+
+    def block(theta, mu_shape, steps, lin=(0, 0, 0)):
+        sp = H.sim_params(gravity=(K.G * np.sin(theta), 0.0, -K.G * np.cos(theta)), solver="pgs")
+        return _kat_run(oracle, blk, sp, nodof, K.root_row((0, 0, 0.05), lin=lin), steps, mu_shape, group=32)[0]
+    tr = block(np.arctan(0.3), 0.2, 400)                       # mu = (0.2 + 1) / 2 = 0.6 > tan(theta): holds, no creep
+    assert np.abs(tr[-100:, 7:13]).max() < 2e-5 and abs(tr[-1, 0]) < 400 * K.DT * 2e-5 + 1e-6
+    th = np.arctan(1.0)
+    tr = block(th, 0.2, 200)
+    a = K.G * (np.sin(th) - 0.6 * np.cos(th))
+    assert abs((tr[-1, 7] - tr[99, 7]) / (100 * K.DT) - a) < 0.01 * a
+    tr = block(0.0, 0.6, 200, lin=(1.0, 0, 0))                 # mu = 0.8: stops after v0^2 / (2 mu g), then stays
+    d = 1.0 / (2 * 0.8 * K.G)
+    assert abs(tr[-1, 0] - d) < 1.0 * K.DT and np.abs(tr[-1, 7:10]).max() < 1e-5     # (within one step's travel of the continuous answer)
+    tr = _kat_run(oracle, K.ball_model(), H.sim_params(solver="pgs"), nodof, K.root_row((0, 0, 0.55)), 400, group=32)[0]
+    z, vz = tr[:, 2] - 0.05, tr[:, 9]
+    assert abs(z[-1]) < 1e-4 and np.abs(vz[-50:]).max() < 1e-5 and z.min() > -2e-3       # rests ON the surface: no sag
