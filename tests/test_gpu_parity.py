@@ -1387,7 +1387,8 @@ def test_velocity_level_solve_simulate_and_self_collision_match_oracle_bitwise(o
     assert task.kernel_symbol().startswith("_Z14k_a1_chain_pgsILb0ELb1E")
 
 
-def test_velocity_drive_matches_oracle_bitwise(oracle):
+@pytest.mark.parametrize("solver", ["compliant", "pgs"])
+def test_velocity_drive_matches_oracle_bitwise(oracle, solver):
     """Robot._internal_motor_step's DOF_MODE_VEL branch (reference shifu/units/robot.py:55-64; no shipped config uses it):
     an implicit velocity drive (kd (v* - qd), effort-limited) on the ABB arm, targets through
     gym.set_dof_velocity_target_tensor, HIP against the oracle; the joints reach the commanded speeds."""
@@ -1398,7 +1399,7 @@ def test_velocity_drive_matches_oracle_bitwise(oracle):
     m = cm.blob
     for d in range(m.nd):
         m.drive_mode[d] = _abi.DOF_MODE_VEL
-    sp = H.sim_params(dt=0.02)
+    sp = H.sim_params(dt=0.02, solver=solver)        # ("pgs": a fixed-base arm on the run-time-shaped kernel with the generic solve)
     n = 24
     dof = np.zeros((n * m.nd, 2), np.float32)
     dof[:, 0] = np.tile(np.array(ABB_DEFAULT_DOF_POS, np.float32), n)
