@@ -645,7 +645,10 @@ DEV void abb_step_body(const AbbArgs& A) {
   C.mscale = A.S.mscale ? A.S.mscale + (size_t)e * nb : nullptr;
   const float mu = A.S.friction[e];
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
-  LaneModel M;
+  // (the 512-thread form has 256 registers at two wavefronts per SIMD and spills: its per-lane model constants stay in the
+  // LDS model -- read where they are used -- instead of in registers that would go to scratch)
+  typedef LaneModelT<!HARD> LM;
+  LM M;
   lane_model_load<DM>(m, l, M);
   LanePoints<LANE_ROUNDS(G, DM)> P;
   if constexpr (DM::NPC > 0) lane_points_load<G>(m, DM::np(m), l, P);
@@ -655,7 +658,7 @@ DEV void abb_step_body(const AbbArgs& A) {
     if constexpr (ARM > 0)
       arm_substep<G, DM, SC, ARM>(C, L, krec, l, M, P, tgtl, mu, it == nsub - 1 ? L.xch : nullptr, BL);
     else
-      substep<G, true, DM, false, LaneModel, SC, false, LINK, HARD>(C, L, l, M, P, tgtl, nullptr, nullptr, mu, it == nsub - 1 ? L.xch : nullptr, BL);
+      substep<G, true, DM, false, LM, SC, false, LINK, HARD>(C, L, l, M, P, tgtl, nullptr, nullptr, mu, it == nsub - 1 ? L.xch : nullptr, BL);
   }
   abb_after_physics<G, DM>(A, tp, m, L, l, e, epb, nbx, tgtl, stats_lds, stats_step);
 }
