@@ -32,7 +32,7 @@ class FusedAbbEnv:
         self.cm = abb_model(link_contacts=link_contacts)
         # solver: "pgs" = the velocity-level contact solve with the reference's PhysX settings (env_config.py:50-58) -- the default,
         # on the run-time-shaped body-per-lane kernel at 32 lanes per env (csrc/shf_hard.h; round 5: correct, not yet fast:
-        # 0.53 ms per vec-step); "compliant" = rounds 1-4's spring-damper law on the kernels compiled for this scene (0.16 ms).
+        # 0.49 ms per vec-step); "compliant" = rounds 1-4's spring-damper law on the kernels compiled for this scene (0.16 ms).
         # Asking for a lane mapping / width that only the compliant kernels have selects them.  (Decided from what the caller
         # passed, before the compliant kernels' own defaults for `group` and `mapping` are filled in below.)
         if solver is None:
