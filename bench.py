@@ -387,6 +387,10 @@ def main():
         return slot
 
     torch.cuda.synchronize()
+    # constraints / contacts beyond the per-env limits (SHF_T_DROPPED: counted by the kernels, never cleared here): the count
+    # before the timed region, read again after it -- one D2H on each side, outside the clock
+    dropped_t = env.sim.tensors.get(_abi.T_DROPPED)
+    dropped0 = int(dropped_t.sum().item()) if dropped_t is not None else None
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -398,6 +402,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    dropped1 = int(dropped_t.sum().item()) if dropped_t is not None else None
+    envs_dropping = int((dropped_t > 0).sum().item()) if dropped_t is not None else None
 
     # duration of the fused kernel alone: HIP events on the launch stream around each of K eager launches
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -503,12 +509,22 @@ def main():
                        "lanes_per_env": group, "lane_mapping": mapping, "self_collision": bool(args.self_collision) and not abb, "vec_step": "hipGraph replay of [uniform_, fused step]" if graph is not None else ("one launch: fused step with the U(-1,1) actions of run_policy('random') drawn in-kernel (counter-based, keyed by global env id and vec-step)" if args.actions == "kernel" else "two eager launches: torch uniform_ + fused step"),
                        "parallelism": f"env-sharded x{world}, all-gather of episode stats every {args.log_interval} steps",
                        "substeps_per_s": value * substeps, "obs_finite": finite, "episodes_reset_rank0": resets,
+                       # candidates beyond ShfSimParams.max_contacts (PGS) / the self- and link-contact slot limits, per env and vec-step
+                       # over the timed region on rank 0 (SHF_T_DROPPED deltas); envs_ever_dropping: envs whose counter is non-zero
+                       "max_contacts": (int(env.sim_params.max_contacts) or 8) if args.solver == "pgs" else None,
+                       "dropped_constraints_per_env_step": None if dropped0 is None else (dropped1 - dropped0) / float(N * args.steps),
+                       "envs_ever_dropping_frac": None if envs_dropping is None else envs_dropping / float(N),
                        "gathers_in_timed_region": gathers["timed"], "gathers_in_warmup": gathers["warmup"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
                          "traffic": None if not prof else prof.get("traffic_bytes"),
                          "traffic_source": None if not prof else prof.get("source"),
+                         # the loaded kernel's machine-code hash (shifu_amd/build.py: kernel_code_hashes) against the one the replayed
+                         # counters were collected from: true = the counters describe another build of this kernel (re-profile)
+                         "kernel_symbol": entry, "kernel_code_sha": None if vg is None else vg.get("code_sha"),
+                         "counters_kernel_sha": None if not prof else prof.get("kernel_code_sha"),
+                         "counters_stale": None if not prof else (prof.get("kernel_code_sha") is None or vg is None or prof.get("kernel_code_sha") != vg.get("code_sha")),
                          "kernel": ("k_a1_chain_pgs" if (kernel == "k_a1_step" and args.solver == "pgs") else "k_a1_chain" if (kernel == "k_a1_step" and mapping == "chain") else "k_abb_step_ws" if (kernel == "k_abb_step" and mapping == "split") else "k_abb_step_pgs_wide" if (abb and "pgs_wide" in env.task.kernel_symbol()) else kernel), "kernel_ms": kern_ms, "alg_bytes_per_env_step": b_alg,
                          "note": "latency/ALU-bound by design: a few KB of compulsory traffic per env-step (DESIGN.md 5)" +
                                  ("; alg_bytes counts the env's own tensors (state in, state / body_state / contact / Jacobian / obs out): link contacts "

@@ -17,6 +17,18 @@ import numpy as np
 from . import _abi
 
 _SIM_CONST = (_abi.T_HEIGHTS, _abi.T_MODEL, _abi.T_SCENE)        # replicated read-only data, rebuilt by the env
+# ShfSimParams fields a replay depends on: the contact solver and its settings decide the arithmetic of every sub-step.  A
+# checkpoint without them predates the velocity-level solve (rounds 1-4) and reads as the compliant law with that round's values.
+_SOLVER_FIELDS = ("solver", "pos_iters", "vel_iters", "max_contacts", "erp", "rest_offset", "bounce_threshold", "restitution", "dt",
+                  "contact_k", "contact_d", "friction_vel", "contact_offset", "max_depen_vel")
+
+
+def _sim_params_dict(sp) -> Dict:
+    return {k: (int(getattr(sp, k)) if isinstance(getattr(sp, k), int) else float(getattr(sp, k))) for k in _SOLVER_FIELDS}
+
+
+def _kernel_form(env) -> Dict:
+    return {"mapping": getattr(env, "mapping", None), "group": getattr(env, "group", None)}
 
 
 def env_state_dict(env) -> Dict:
@@ -25,7 +37,8 @@ def env_state_dict(env) -> Dict:
     task = {k: v.detach().cpu().clone() for k, v in env.task.tensors.items()}
     return {"format": 1, "kind": type(env).__name__, "num_envs": env.num_envs,
             "env_id_offset": getattr(env, "env_id_offset", 0), "step_index": env.task.step_index,
-            "common_step_counter": getattr(env, "common_step_counter", 0), "sim": sim, "task": task}
+            "common_step_counter": getattr(env, "common_step_counter", 0), "sim": sim, "task": task,
+            "sim_params": _sim_params_dict(env.sim_params), "kernel_form": _kernel_form(env)}
 
 
 def load_env_state_dict(env, sd: Dict) -> None:
@@ -33,6 +46,17 @@ def load_env_state_dict(env, sd: Dict) -> None:
         raise ValueError(f"checkpoint of a {sd.get('kind')} (format {sd.get('format')}) cannot restore a {type(env).__name__}")
     if sd["num_envs"] != env.num_envs or sd["env_id_offset"] != getattr(env, "env_id_offset", 0):
         raise ValueError("checkpoint was taken with a different env count / shard offset")
+    # the contact solver and its settings: a state taken under one law does not replay under another (it would load without a
+    # complaint and diverge from the first sub-step).  Absent = a checkpoint of rounds 1-4: the compliant law.
+    have, want = _sim_params_dict(env.sim_params), sd.get("sim_params")
+    if want is None:
+        if have["solver"] != _abi.SOLVER_COMPLIANT:
+            raise ValueError("checkpoint predates the velocity-level contact solve (no sim_params recorded: compliant law); this env runs "
+                             "solver=pgs -- construct it with solver='compliant' to replay it")
+    else:
+        diff = {k: (want.get(k), have[k]) for k in _SOLVER_FIELDS if k in want and want[k] != have[k]}
+        if diff:
+            raise ValueError("checkpoint was taken under other contact-solver settings (checkpoint, env): " + repr(diff))
     for name, src, dst in (("sim", sd["sim"], env.sim.tensors), ("task", sd["task"], env.task.tensors)):
         for k, v in src.items():
             if name == "sim" and k == _abi.T_BODY_MASS_SCALE and k not in dst:

@@ -237,6 +237,12 @@ class OnPolicyRunner:
 
     # ------------------------------------------------------------ checkpoints
     def save(self, path, infos=None):
+        # the contact solver the policy was trained under travels with it (a policy trained on the compliant law plays differently
+        # under the velocity-level solve): tools/play_a1.py warns on a mismatch
+        solver = getattr(self.env, "solver", None)
+        if solver is not None:
+            infos = dict(infos or {})
+            infos.setdefault("contact_solver", solver)
         torch.save({"model_state_dict": self.alg.actor_critic.state_dict(),
                     "optimizer_state_dict": self.alg.optimizer_state_dict(),
                     "iter": self.current_learning_iteration, "infos": infos}, path)

@@ -76,6 +76,30 @@ def test_register_budgets_of_the_fused_step():
     build.check_budgets(res)
     k = [v for n, v in res.items() if n.startswith("_Z16k_a1_step_a1_g32")][0]
     assert k["spill"] == 0 and k["vgprs"] <= 256
+    # the kernels that are the defaults since round 5 (velocity-level solve) are under the same guard
+    guarded = [p for p, _, _ in build.BUDGETS]
+    for fam in ("_Z14k_a1_chain_pgs", "_Z20k_sim_step_chain_pgs", "_Z19k_abb_step_pgs_wide", "_Z19k_sim_step_pgs_wide"):
+        assert any(p.startswith(fam) for p in guarded), fam
+    pgs = [v for n, v in res.items() if n.startswith("_Z14k_a1_chain_pgsILb0ELb0EE")][0]
+    assert pgs["spill"] == 0 and pgs["scratch"] == 0 and pgs["vgprs"] + pgs["agprs"] <= 256
+
+
+def test_a_bloated_default_kernel_fails_the_budget_check():
+    """A 257th register or new scratch in the headline kernel must not build green (shifu_amd/build.py: check_budgets)."""
+    import copy
+    import json
+    from shifu_amd import build
+    build.build_native()
+    res = json.load(open(build.RESOURCES))
+    name = [n for n in res if n.startswith("_Z14k_a1_chain_pgsILb0ELb0EE")][0]
+    for field, value in (("vgprs", 257), ("scratch", 16), ("agprs", 64)):
+        bad = copy.deepcopy(res)
+        bad[name][field] = value
+        with pytest.raises(RuntimeError, match="register budget"):
+            build.check_budgets(bad)
+    missing = {k: v for k, v in res.items() if not k.startswith("_Z14k_a1_chain_pgs")}
+    with pytest.raises(RuntimeError, match="missing"):
+        build.check_budgets(missing)
 
 
 def test_empty_and_oversize_inputs_are_refused_on_the_host(libpath):

@@ -32,7 +32,12 @@ def main():
     env = FusedA1Env(num_envs=args.envs, terrain=args.terrain, seed=7, self_collision=args.self_collision,
                      **({} if args.solver is None else {"solver": args.solver}))
     runner = OnPolicyRunner(env, class_to_dict(A1PPOConfig()), log_dir=None, device="cuda:0")
-    runner.load(args.checkpoint, load_optimizer=False)
+    infos = runner.load(args.checkpoint, load_optimizer=False)
+    trained = (infos or {}).get("contact_solver") if isinstance(infos, dict) else None
+    if trained is None:
+        print(f"play_a1: the checkpoint does not record its contact solver (rounds 1-4: compliant); playing under {env.solver}", file=sys.stderr)
+    elif trained != env.solver:
+        print(f"play_a1: WARNING the policy was trained under solver={trained}, this env runs solver={env.solver} (pass --solver {trained})", file=sys.stderr)
     policy = runner.get_inference_policy()
     rec = TrajectoryRecorder(env, num_envs=8, bodies=True) if args.traj else None
     env.reset()

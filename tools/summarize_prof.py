@@ -31,9 +31,11 @@ def main(src, dst, key=None, kern="k_a1_step"):
            "Command: `tools/profile.sh` (rocprofv3 --kernel-trace --stats, then separate --pmc passes) around",
            "`python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline ...`; 4096 envs, 1x MI355X.", ""]
     bj = os.path.join(src, "bench_stats.json")
+    kernel_sha = kernel_symbol = None
     if os.path.exists(bj):
         try:
             b = json.loads(open(bj).read().strip().splitlines()[-1])
+            kernel_sha, kernel_symbol = b["roofline"].get("kernel_code_sha"), b["roofline"].get("kernel_symbol")
             out += ["bench.py line under the profiler: value = %.3e env-steps/s, kernel_ms (HIP events) = %.4f" %
                     (b["value"], b["roofline"]["kernel_ms"]), ""]
         except Exception:
@@ -69,6 +71,9 @@ def main(src, dst, key=None, kern="k_a1_step"):
         tj = os.path.join(os.path.dirname(dst) or ".", "traffic.json")
         db = json.load(open(tj)) if os.path.exists(tj) else {}
         ent = {"fetch_kib": fetch, "write_kib": write, "traffic_bytes": traffic,
+               # machine-code hash of the kernel these counters were collected from (the bench line under the profiler carries it):
+               # bench.py prints counters_stale when the library it runs holds another build of the kernel
+               "kernel_code_sha": kernel_sha, "kernel_symbol": kernel_symbol,
                "source": "profiles/%s_summary.md: rocprofv3 --pmc passes of this bench command (2 x FETCH_SIZE + WRITE_SIZE, "
                          "gfx950 correction), replayed by bench.py -- not measured in the run that prints it" % os.path.basename(dst)}
         sq = {}
