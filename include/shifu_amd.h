@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SHF_ABI_VERSION 13
+#define SHF_ABI_VERSION 14
 
 #define SHF_MAX_BODIES 32 /* reported rigid bodies per articulation        */
 #define SHF_MAX_DOFS 32
@@ -38,6 +38,13 @@ extern "C" {
                                   * the deepest are kept, more are dropped and counted (SHF_T_DROPPED)                 */
 #define SHF_MAX_LINK_CONTACTS 16 /* simultaneously active link <-> box-actor contacts per env (further ones are dropped, in
                                   * candidate order, and counted: SHF_T_DROPPED)                                     */
+
+#define SHF_MAX_HULLS 8             /* convex-hull collision shapes (mesh colliders) of an articulation that meet the box actors */
+#define SHF_HULL_MAX_VERTS 32       /* per hull, after the model compiler's reduction (PhysX cooks <= 64 [EXT]) */
+#define SHF_HULL_MAX_FACES 40       /* polygonal faces (coplanar triangles merged)                               */
+#define SHF_HULL_MAX_EDGES 64
+#define SHF_HULL_MAX_FACE_VERTS 8   /* vertices of one face's loop                                              */
+#define SHF_HULL_MAX_LOOP 160       /* all face loops of a hull together                                        */
 
 /* joint types of a reported body's inboard joint */
 enum { SHF_JOINT_ROOT = 0, SHF_JOINT_REVOLUTE = 1, SHF_JOINT_PRISMATIC = 2, SHF_JOINT_WELD = 3 };
@@ -158,7 +165,7 @@ typedef struct ShfModel {
   int32_t link_collide;
   int32_t nabox;
   int32_t bounds_ok; /* SHF_BOUNDS_MAGIC once shf_model_bounds() has filled bbox; anything else: the kernels test every candidate */
-  int32_t pad_lc;
+  int32_t nhull;     /* convex hulls of this articulation in the sim's ShfHullSet (shf_sim_set_hulls; 0: none) -- family (H) below */
   int32_t abox_body[SHF_MAX_ABOX];
   float abox_pos[SHF_MAX_ABOX][3];
   float abox_rot[SHF_MAX_ABOX][9]; /* row-major rotation body <- box */
@@ -179,6 +186,36 @@ typedef struct ShfModel {
 } ShfModel;
 #define SHF_BOUNDS_MAGIC 0x42534831 /* "BSH1" */
 
+/* Convex-hull collision shapes of the articulation (the reference's links collide through <mesh> colliders,
+ * asset/urdf/abb_rod_description/urdf/abb_rod_isaac.urdf:38-113, which PhysX cooks into convex hulls [EXT]; every shape of an
+ * env collides with every other: create_actor(..., group, 0), shifu/units/units.py:68).  The model compiler
+ * (shifu_amd/model.py: reduce_hull) reduces a mesh to a convex polytope within the limits above: vertices, outward face
+ * planes n.x <= d with their vertex loops (counter-clockwise seen from outside), and the edges with the two faces that meet
+ * in each.  With ShfModel.link_collide and nhull > 0 every hull meets every box actor -- family (H) of the link contacts,
+ * after A / C / B / E of its (body, box actor) pair, hulls ascending: the separating-axis test over the hull's face normals,
+ * the box's face normals and the edge pairs that span a face of the Minkowski difference (D. Gregorius, "The separating axis
+ * test between convex polyhedra", GDC 2013); the axis of largest separation decides -- an edge pair (by a clear margin) gives
+ * ONE contact where the two edges cross; a face gives the clipped face manifold: the other body's most anti-parallel face
+ * clipped against the side planes of the reference face, the vertices of what is left within the contact offset of the
+ * reference plane, reduced to at most four (the deepest, the farthest from it, the two that span the largest area).
+ * Kept outside ShfModel (which the kernels stage in LDS): a device copy is bound as SHF_T_HULLS. */
+typedef struct ShfHull {
+  int32_t body;                 /* reported body the hull is fixed to */
+  int32_t nv, nf, ne;
+  float centroid[3];            /* a point strictly inside (body frame): orients the edge axes */
+  float pad0;
+  float vert[SHF_HULL_MAX_VERTS][3];   /* body frame */
+  float plane[SHF_HULL_MAX_FACES][4];  /* outward unit normal, offset */
+  uint8_t face_start[SHF_HULL_MAX_FACES], face_count[SHF_HULL_MAX_FACES];   /* the face's loop in face_loop */
+  uint8_t face_loop[SHF_HULL_MAX_LOOP];
+  uint8_t edge[SHF_HULL_MAX_EDGES][4]; /* vertex, vertex, face, face */
+} ShfHull;
+typedef struct ShfHullSet {
+  int32_t nhull;
+  int32_t pad[3];
+  ShfHull hull[SHF_MAX_HULLS];
+} ShfHullSet;
+
 /* A single-body box actor (gym.create_box, object.py:28-39). */
 typedef struct ShfBoxDesc {
   float dim[3];
@@ -193,7 +230,12 @@ typedef struct ShfBoxDesc {
  * SHF_T_SCENE). */
 typedef struct ShfScene {
   int32_t nboxes;
-  int32_t pad[3];
+  int32_t flags;   /* SHF_SCENE_FACE_MANIFOLD: a free box and a fixed box (and, with link contacts, a box volume of the articulation
+                    * and a box actor) that touch without any vertex or edge-crossing contact -- an edge or a face lying flat on a
+                    * face, no corner of either inside the other -- get the clipped face manifold of the same narrow phase as the
+                    * hulls (<= 4 points, in the slots corners 0..3 would have).  0 (default): rounds 1-5's families only.  The
+                    * compile-time-shaped kernels are built for flags == 0; a scene with flags runs on the run-time-shaped ones. */
+  int32_t pad[2];
   ShfBoxDesc box[SHF_MAX_BOXES];
 } ShfScene;
 
@@ -242,6 +284,7 @@ typedef struct ShfSimParams {
   float restitution;        /* shape restitution (Isaac Gym default 0; terrain.restitution = 0, env_config.py:84) */
   float erp;                /* share of a penetration removed per sub-step (Baumgarte); 0 reads as 0.2 */
 } ShfSimParams;
+#define SHF_SCENE_FACE_MANIFOLD 1
 #define SHF_SOLVER_COMPLIANT 0
 #define SHF_SOLVER_PGS 1
 
@@ -295,7 +338,8 @@ enum {
                           * props, recomputeInertia=True) with props[b].mass = factor * the asset's (shifu/units/units.py:104-110).
                           * Read once per launch, in the inertia phase; unbound = 1 everywhere.  Bodies welded to their
                           * parent carry no mass of their own here (ShfModel.mass is 0 for them): their factor is unused. */
-  SHF_T_COUNT = 19
+  SHF_T_HULLS = 19,      /* sizeof(ShfHullSet) bytes, device copy of shf_sim_set_hulls' argument (needed when ShfModel.nhull > 0) */
+  SHF_T_COUNT = 20
 };
 
 /* refresh masks: gym.refresh_*_tensor (isaac_gym.py:139-154) */
@@ -334,6 +378,12 @@ int shf_model_bounds(ShfModel* model);
  * levels); else 0: create the sim with SHF_SOLVER_COMPLIANT.  Host only.  The gym facade asks this before gym.create_sim's
  * physx settings (env_config.py:50-58) become a ShfSimParams. */
 int shf_model_pgs_supported(const ShfModel* model, int32_t nboxes);
+/* Part of gym.load_asset for an asset with <mesh> colliders (units.py:73): the articulation's convex hulls (ShfHullSet; call after
+ * shf_sim_set_articulation with a model whose nhull equals hulls->nhull, before shf_sim_finalize).  Host copy; the device copy is
+ * bound as SHF_T_HULLS.  Refused: counts beyond the SHF_HULL_* limits, a body index outside the model. */
+int shf_sim_set_hulls(ShfSim* sim, const ShfHullSet* hulls);
+/* ShfScene.flags for the scene built by shf_sim_add_box (before shf_sim_finalize). */
+int shf_sim_set_scene_flags(ShfSim* sim, int32_t flags);
 /* gym.create_box + create_actor (object.py:28-39) */
 int shf_sim_add_box(ShfSim* sim, const ShfBoxDesc* box);
 /* gym.create_env x N + prepare_sim (isaac_gym.py:94-104).  env_id_offset is

@@ -74,6 +74,42 @@ def box_box_edge(RA, cA, hA, RB, cB, hB, offset=0.01, f64=True):
     return bool(o[0]), float(o[1]), o[2:5].copy(), o[5:8].copy()
 
 
+def convex_manifold(Ra, pa, Rb, pb, ha=None, hb=None, hull_a=None, hull_b=None, offset=0.01, f64=True, seps=False):
+    """convex_manifold of the oracle: polytope A (receives +f) = ShfHull `hull_a` on pose (Ra, pa) or the box of half extents
+    `ha`; B likewise.  Returns (n (3,), [(r (3,), phi), ...]) with at most four contacts; n points from B towards A."""
+    from shifu_amd import _abi
+    dt, ct, suf = (np.float64, C.c_double, "f64") if f64 else (np.float32, C.c_float, "f32")
+    z = np.zeros(3)
+    a = np.concatenate([np.asarray(Ra, dt).reshape(9), np.asarray(pa, dt), np.asarray(z if ha is None else ha, dt),
+                        np.asarray(Rb, dt).reshape(9), np.asarray(pb, dt), np.asarray(z if hb is None else hb, dt)]).astype(dt).reshape(1, 30)
+    out = np.zeros((1, 24), dt)
+    fn = getattr(lib(), "shf_oracle_convex_manifold_" + suf)
+    fn.restype = None
+    fn(C.c_int(1), None if hull_a is None else C.byref(hull_a), None if hull_b is None else C.byref(hull_b), _p(a, ct), ct(offset), _p(out, ct))
+    o = out[0]
+    if seps:
+        return o[1:4].copy(), [(o[4 + 4 * q:7 + 4 * q].copy(), float(o[7 + 4 * q])) for q in range(int(o[0]))], o[20:23].copy()
+    return o[1:4].copy(), [(o[4 + 4 * q:7 + 4 * q].copy(), float(o[7 + 4 * q])) for q in range(int(o[0]))]
+
+
+@contextlib.contextmanager
+def scene_extras(hulls=None, flags: int = 0):
+    """The articulation's convex hulls (ShfHullSet, ShfModel.nhull > 0) and ShfScene.flags for the scene_step / abb_step calls
+    inside the `with` (process-wide, like body_mass_scale)."""
+    L = lib()
+    for sfx in ("_f32", "_f64"):
+        f, g = getattr(L, "shf_oracle_set_hulls" + sfx), getattr(L, "shf_oracle_set_scene_flags" + sfx)
+        f.restype = g.restype = None
+        f(None if hulls is None else C.byref(hulls))
+        g(C.c_int(flags))
+    try:
+        yield
+    finally:
+        for sfx in ("_f32", "_f64"):
+            getattr(L, "shf_oracle_set_hulls" + sfx)(None)
+            getattr(L, "shf_oracle_set_scene_flags" + sfx)(C.c_int(0))
+
+
 def point_in_box(bR, bpos, h, pt):
     return box_primitives(bR, bpos, h, pt)[0]
 

@@ -1,7 +1,7 @@
 """ctypes mirrors of the PODs in include/shifu_amd.h (keep in lock-step)."""
 import ctypes as C
 
-SHF_ABI_VERSION = 13
+SHF_ABI_VERSION = 14
 MAP_BODY, MAP_CHAIN, MAP_CHAIN_SPLIT = 0, 1, 2   # shf_sim_set_mapping
 MAX_BODIES = 32
 MAX_DOFS = 32
@@ -14,6 +14,8 @@ MAX_SELF_CONTACTS = 8
 MAX_ABOX = 16
 MAX_LINK_CONTACTS = 16
 MAX_HARD_CONTACTS = 16
+MAX_HULLS, HULL_MAX_VERTS, HULL_MAX_FACES, HULL_MAX_EDGES, HULL_MAX_FACE_VERTS, HULL_MAX_LOOP = 8, 32, 40, 64, 8, 160
+SCENE_FACE_MANIFOLD = 1
 SOLVER_COMPLIANT, SOLVER_PGS = 0, 1
 
 JOINT_ROOT, JOINT_REVOLUTE, JOINT_PRISMATIC, JOINT_WELD = 0, 1, 2, 3
@@ -43,7 +45,7 @@ class ShfModel(C.Structure):
         ("self_collide", i32), ("ncap", i32), ("npair", i32), ("neval", i32),
         ("cap_body", i32 * MAX_CAPSULES), ("cap_a", (f32 * 3) * MAX_CAPSULES), ("cap_b", (f32 * 3) * MAX_CAPSULES),
         ("cap_radius", f32 * MAX_CAPSULES), ("pair_a", C.c_uint8 * MAX_PAIRS), ("pair_b", C.c_uint8 * MAX_PAIRS),
-        ("link_collide", i32), ("nabox", i32), ("bounds_ok", i32), ("pad_lc", i32), ("abox_body", i32 * MAX_ABOX),
+        ("link_collide", i32), ("nabox", i32), ("bounds_ok", i32), ("nhull", i32), ("abox_body", i32 * MAX_ABOX),
         ("abox_pos", (f32 * 3) * MAX_ABOX), ("abox_rot", (f32 * 9) * MAX_ABOX), ("abox_half", (f32 * 3) * MAX_ABOX),
         ("bbox", (f32 * 6) * MAX_BODIES),
         ("lc_range", (C.c_int16 * 4) * MAX_BODIES), ("lc_pt", C.c_int16 * MAX_POINTS), ("lc_abox", C.c_int16 * MAX_ABOX),
@@ -56,7 +58,18 @@ class ShfBoxDesc(C.Structure):
 
 
 class ShfScene(C.Structure):
-    _fields_ = [("nboxes", i32), ("pad", i32 * 3), ("box", ShfBoxDesc * MAX_BOXES)]
+    _fields_ = [("nboxes", i32), ("flags", i32), ("pad", i32 * 2), ("box", ShfBoxDesc * MAX_BOXES)]
+
+
+class ShfHull(C.Structure):
+    _fields_ = [("body", i32), ("nv", i32), ("nf", i32), ("ne", i32), ("centroid", f32 * 3), ("pad0", f32),
+                ("vert", (f32 * 3) * HULL_MAX_VERTS), ("plane", (f32 * 4) * HULL_MAX_FACES),
+                ("face_start", C.c_uint8 * HULL_MAX_FACES), ("face_count", C.c_uint8 * HULL_MAX_FACES),
+                ("face_loop", C.c_uint8 * HULL_MAX_LOOP), ("edge", (C.c_uint8 * 4) * HULL_MAX_EDGES)]
+
+
+class ShfHullSet(C.Structure):
+    _fields_ = [("nhull", i32), ("pad", i32 * 3), ("hull", ShfHull * MAX_HULLS)]
 
 
 class ShfSimParams(C.Structure):
@@ -102,7 +115,7 @@ class ShfAbbTaskParams(C.Structure):
 
 # tensor ids (shf_sim_*)
 T_DOF_STATE, T_ROOT_STATE, T_BODY_STATE, T_CONTACT, T_JACOBIAN, T_SIM_DOF, T_SIM_ROOT, T_EFFORT, \
-    T_POS_TARGET, T_VEL_TARGET, T_BODY_FORCE, T_FRICTION, T_HEIGHTS, T_MODEL, T_SIM_CONTACT, T_SCENE, T_DROPPED, T_BODY_FORCE_POS, T_BODY_MASS_SCALE, T_COUNT = range(20)
+    T_POS_TARGET, T_VEL_TARGET, T_BODY_FORCE, T_FRICTION, T_HEIGHTS, T_MODEL, T_SIM_CONTACT, T_SCENE, T_DROPPED, T_BODY_FORCE_POS, T_BODY_MASS_SCALE, T_HULLS, T_COUNT = range(21)
 
 REFRESH_DOF, REFRESH_ROOT, REFRESH_BODY, REFRESH_CONTACT, REFRESH_JACOBIAN, REFRESH_ALL = 1, 2, 4, 8, 16, 31
 

@@ -104,6 +104,7 @@ class CompiledModel:
     body_names: List[str]
     dof_names: List[str]
     total_mass: float
+    hulls: Optional["_abi.ShfHullSet"] = None     # the articulation's convex hulls (blob.nhull of them), for Sim.set_hulls
 
     @property
     def rigid_body_dict(self) -> Dict[str, int]:
@@ -227,6 +228,133 @@ def _hull_inertial(v: np.ndarray, t: np.ndarray, density: float) -> "_Inertial":
     C = second - vol * np.outer(com, com)                     # covariance about the centre of mass
     I = density * (np.trace(C) * np.eye(3) - C)
     return _Inertial(density * vol, com, I)
+
+
+def _sphere_directions(n: int) -> np.ndarray:
+    """A fixed set of unit directions: the 26 axis / face-diagonal / cube-diagonal directions first (a box-like hull keeps its
+    eight corners and a resting face stays flat), then a Fibonacci spiral."""
+    d = [np.array(v, float) for v in
+         [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)] +
+         [(sx, sy, sz) for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)] +
+         [(sx, sy, 0) for sx in (-1, 1) for sy in (-1, 1)] + [(sx, 0, sz) for sx in (-1, 1) for sz in (-1, 1)] +
+         [(0, sy, sz) for sy in (-1, 1) for sz in (-1, 1)]]
+    k = 0
+    while len(d) < n:
+        z = 1.0 - (2.0 * k + 1.0) / max(n, 1)
+        r, ph = np.sqrt(max(0.0, 1.0 - z * z)), k * np.pi * (3.0 - np.sqrt(5.0))
+        d.append(np.array([r * np.cos(ph), r * np.sin(ph), z]))
+        k += 1
+    return np.array([v / np.linalg.norm(v) for v in d[:n]])
+
+
+def reduce_hull(pts: np.ndarray, max_verts: int = _abi.HULL_MAX_VERTS) -> dict:
+    """A mesh collider as the convex polytope the narrow phase collides (include/shifu_amd.h: ShfHull): the convex hull of
+    `pts`, reduced to at most `max_verts` of its vertices -- the support points along a fixed set of directions, so the result
+    is inscribed in the true hull -- with coplanar triangles merged into polygonal faces; fewer vertices are taken until the
+    face / edge / loop limits hold too ([EXT] PhysX cooks a convex mesh of at most 64 vertices and polygons the same way).
+    Returns dict(verts (nv,3), planes (nf,4), loops [list of vertex indices, counter-clockwise from outside], edges (ne,4)
+    = v0, v1, face, face, centroid)."""
+    from scipy.spatial import ConvexHull
+    v0, _ = _convex_hull(np.asarray(pts, float))
+    n = min(max_verts, len(v0))
+    while n >= 4:
+        if len(v0) > n:
+            idx = []
+            for d in _sphere_directions(4 * n):
+                k = int(np.argmax(v0 @ d))
+                if k not in idx:
+                    idx.append(k)
+                if len(idx) >= n:
+                    break
+            v = v0[idx]
+        else:
+            v = v0.copy()
+        v = np.asarray(v, np.float32).astype(float)                 # the planes are those of the stored (float32) vertices
+        v, tri = _convex_hull(v)
+        c = v.mean(0)
+        # triangle normals; merge coplanar neighbours
+        nrm = np.cross(v[tri[:, 1]] - v[tri[:, 0]], v[tri[:, 2]] - v[tri[:, 0]])
+        nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+        off = np.einsum("ij,ij->i", nrm, v[tri[:, 0]])
+        group = -np.ones(len(tri), int)
+        edge_tris = {}
+        for t, (a, b, d) in enumerate(tri):
+            for e in ((a, b), (b, d), (d, a)):
+                edge_tris.setdefault(tuple(sorted(e)), []).append(t)
+        ng = 0
+        for t in range(len(tri)):
+            if group[t] >= 0:
+                continue
+            group[t] = ng
+            stack = [t]
+            while stack:
+                u = stack.pop()
+                for e in ((tri[u][0], tri[u][1]), (tri[u][1], tri[u][2]), (tri[u][2], tri[u][0])):
+                    for w in edge_tris[tuple(sorted(e))]:
+                        if group[w] < 0 and np.dot(nrm[w], nrm[t]) > 1.0 - 1e-7 and abs(off[w] - off[t]) < 1e-6:
+                            group[w] = ng
+                            stack.append(w)
+            ng += 1
+        loops, planes, ok = [], [], True
+        for g in range(ng):
+            ts = np.nonzero(group == g)[0]
+            directed = {}
+            for t in ts:
+                a, b, d = tri[t]
+                for e in ((a, b), (b, d), (d, a)):
+                    if len([w for w in edge_tris[tuple(sorted(e))] if group[w] == g]) == 1:      # a boundary edge of the face
+                        directed[int(e[0])] = int(e[1])
+            start = min(directed)
+            loop, cur = [start], directed[start]
+            while cur != start and len(loop) <= len(directed):
+                loop.append(cur)
+                cur = directed[cur]
+            if len(loop) != len(directed) or len(loop) > _abi.HULL_MAX_FACE_VERTS:
+                ok = False
+                break
+            nn = nrm[ts].mean(0)
+            nn /= np.linalg.norm(nn)
+            planes.append(list(nn) + [float(np.max(v[loop] @ nn))])
+            loops.append(loop)
+        edges = []
+        if ok:
+            face_of = {}
+            for f, loop in enumerate(loops):
+                for i in range(len(loop)):
+                    face_of.setdefault(tuple(sorted((loop[i], loop[(i + 1) % len(loop)]))), []).append(f)
+            ok = all(len(fs) == 2 for fs in face_of.values())
+            edges = [[a, b, fs[0], fs[1]] for (a, b), fs in sorted(face_of.items())] if ok else []
+        if ok and len(loops) <= _abi.HULL_MAX_FACES and len(edges) <= _abi.HULL_MAX_EDGES and sum(map(len, loops)) <= _abi.HULL_MAX_LOOP:
+            return dict(verts=v, planes=np.array(planes), loops=loops, edges=np.array(edges, int), centroid=c)
+        n -= 2
+    raise ValueError("collision mesh cannot be reduced to a convex polytope within the SHF_HULL_* limits")
+
+
+def hull_record(h: dict, body: int, p: np.ndarray, R: np.ndarray) -> "_abi.ShfHull":
+    """ShfHull of reduce_hull()'s polytope fixed to reported body `body` at (p, R) in the body frame."""
+    o = _abi.ShfHull()
+    o.body, o.nv, o.nf, o.ne = body, len(h["verts"]), len(h["loops"]), len(h["edges"])
+    cw = p + R @ h["centroid"]
+    for k in range(3):
+        o.centroid[k] = cw[k]
+    for i, q in enumerate(h["verts"]):
+        w = p + R @ q
+        for k in range(3):
+            o.vert[i][k] = w[k]
+    k0 = 0
+    for f, (pl, loop) in enumerate(zip(h["planes"], h["loops"])):
+        nw = R @ pl[:3]
+        for k in range(3):
+            o.plane[f][k] = nw[k]
+        o.plane[f][3] = pl[3] + float(nw @ p)
+        o.face_start[f], o.face_count[f] = k0, len(loop)
+        for i in loop:
+            o.face_loop[k0] = i
+            k0 += 1
+    for e, rec in enumerate(h["edges"]):
+        for k in range(4):
+            o.edge[e][k] = int(rec[k])
+    return o
 
 
 def parse_urdf(path: str, meshes: str = "error", **_unused) -> Tuple[Dict[str, _Link], List[_Joint]]:
