@@ -382,6 +382,12 @@ int shf_model_pgs_supported(const ShfModel* model, int32_t nboxes);
  * shf_sim_set_articulation with a model whose nhull equals hulls->nhull, before shf_sim_finalize).  Host copy; the device copy is
  * bound as SHF_T_HULLS.  Refused: counts beyond the SHF_HULL_* limits, a body index outside the model. */
 int shf_sim_set_hulls(ShfSim* sim, const ShfHullSet* hulls);
+/* The convex narrow phase on its own (tests, tools): for each of n pairs -- pairs_dev (n, 30) = Ra[9] pa[3] hA[3] Rb[9] pb[3] hB[3]:
+ * polytope A = the hull *hull_a_dev (device memory) on the pose (Ra, pa), or, when NULL, the box of half extents hA; B the box hB on
+ * (Rb, pb) -- the contacts of A with B as the env steps compute them, `lanes` (16 / 32 / 64) lanes sharing the axes of a pair:
+ * out_dev (n, 20) = count, normal[3] (from B towards A), then per contact r[3], gap. */
+int shf_convex_manifold(int32_t n, const float* pairs_dev, const ShfHull* hull_a_dev_or_null, float offset, int32_t lanes,
+                        float* out_dev, void* stream);
 /* ShfScene.flags for the scene built by shf_sim_add_box (before shf_sim_finalize). */
 int shf_sim_set_scene_flags(ShfSim* sim, int32_t flags);
 /* gym.create_box + create_actor (object.py:28-39) */

@@ -21,6 +21,9 @@ _SIGS = {
     "shf_model_pgs_supported": ([C.POINTER(_abi.ShfModel), i32], i32),
     "shf_abb_step_pgs_is_wide": ([vp], i32),
     "shf_sim_add_box": ([vp, C.POINTER(_abi.ShfBoxDesc)], i32),
+    "shf_sim_set_hulls": ([vp, C.POINTER(_abi.ShfHullSet)], i32),
+    "shf_sim_set_scene_flags": ([vp, i32], i32),
+    "shf_convex_manifold": ([i32, vp, vp, C.c_float, i32, vp, vp], i32),
     "shf_sim_finalize": ([vp, i32, i64], i32),
     "shf_sim_set_group": ([vp, i32], i32),
     "shf_sim_set_mapping": ([vp, i32], i32),

@@ -24,14 +24,28 @@ def abb_link_boxes():
         return [tuple(b) for b in json.load(f)["boxes"]]
 
 
-def abb_model(kp=800.0, kd=40.0, link_contacts=False):
+def abb_link_hulls():
+    """The reference's mesh colliders of the arm's links as reduced convex hulls (<= 32 vertices each, link frame):
+    tools/make_link_hulls.py."""
+    import json
+    with open(asset_path("abb_link_hulls.json")) as f:
+        return [(name, verts) for name, verts in json.load(f)["hulls"]]
+
+
+def abb_model(kp=800.0, kd=40.0, link_contacts=False, link_shapes="box"):
     """link_contacts: the arm's links collide with the table, the cube and the goal pad (SURVEY 8f f3;
     ShfModel.link_collide) through box stand-ins for their mesh colliders -- off for the fused / benchmarked scene, whose
     only arm collider is the rod (BASELINE config 5), on for `AbbPushBox` through the gym facade (every shape of an env
     collides there: create_actor(..., group, 0), units.py:68)."""
+    if link_shapes not in ("box", "hull"):
+        raise ValueError("link_shapes must be 'box' or 'hull'")
+    hull = link_contacts and link_shapes == "hull"
+    # link_shapes="hull": the links collide as the convex hulls of the reference's collision meshes (reduced to <= 32 vertices,
+    # shifu_amd/assets/abb_link_hulls.json) through the convex narrow phase; "box": their bounding boxes (rounds 3-5)
     cm = compile_urdf(asset_path("abb_rod.urdf"), fix_base_link=True, disable_gravity=True,
                       default_dof_drive_mode=_abi.DOF_MODE_POS, extra_spheres=ROD_CAPSULE, link_contacts=link_contacts,
-                      extra_boxes=abb_link_boxes() if link_contacts else ())
+                      extra_boxes=abb_link_boxes() if (link_contacts and not hull) else (),
+                      extra_hulls=abb_link_hulls() if hull else (), hull_contacts=hull)
     for d in range(cm.blob.nd):
         cm.blob.kp[d], cm.blob.kd[d] = kp, kd
     return cm

@@ -152,6 +152,17 @@ class Sim:
         self.model = model
         check(lib().shf_sim_set_articulation(self._h, C.byref(model)))
 
+    def set_hulls(self, hulls: "_abi.ShfHullSet"):
+        """The articulation's convex hulls (mesh colliders; CompiledModel.hulls) -- after set_articulation, before finalize."""
+        check(lib().shf_sim_set_hulls(self._h, C.byref(hulls)))
+        self.hulls = hulls
+
+    def set_scene_flags(self, flags: int):
+        """ShfScene.flags (SCENE_FACE_MANIFOLD: the clipped face manifold for box pairs that touch without a vertex or an
+        edge crossing) -- before finalize."""
+        check(lib().shf_sim_set_scene_flags(self._h, int(flags)))
+        self.scene_flags = int(flags)
+
     def add_box(self, box: _abi.ShfBoxDesc):
         check(lib().shf_sim_add_box(self._h, C.byref(box)))
         self.boxes.append(box)
@@ -188,6 +199,10 @@ class Sim:
         for tid in range(_abi.T_COUNT):
             if tid == _abi.T_BODY_MASS_SCALE:        # optional: bound by set_body_mass_scale()
                 continue
+            if tid == _abi.T_HULLS:                  # only for an articulation with convex hulls (set_hulls)
+                if getattr(self, "hulls", None) is not None and self.model.nhull > 0:
+                    self.bind(tid, _struct_to_device(self.hulls, self.device))
+                continue
             if tid == _abi.T_HEIGHTS:
                 if self._heights is not None:
                     self.bind(tid, self._heights)
@@ -198,6 +213,7 @@ class Sim:
             if tid == _abi.T_SCENE:
                 sc = _abi.ShfScene()
                 sc.nboxes = self.nboxes
+                sc.flags = getattr(self, "scene_flags", 0)
                 for k, b in enumerate(self.boxes):
                     sc.box[k] = b
                 self.bind(tid, _struct_to_device(sc, self.device))
@@ -462,21 +478,24 @@ class AbbTask:
         link = bool(mdl.link_collide and self.sim.nboxes > 0)
         fixed = mdl.nb == 7 and mdl.np == (59 if link else 3) and self.sim.nboxes == 3
         pre = f"_Z10k_abb_stepILi{self.sim.group}E"
+        if mdl.nhull > 0 or getattr(self.sim, "scene_flags", 0):     # the convex narrow phase compiled in (csrc/shf_hull.h): run-time shapes
+            hard = int(self.sim.params.solver == _abi.SOLVER_PGS)
+            return f"_Z10k_abb_stepILi{32 if hard else self.sim.group}E7DynDims8DynSceneLb1ELi0ELb{hard}ELb1EE"
         if self.sim.params.solver == _abi.SOLVER_PGS:    # the generic velocity-level solve: run-time shapes, 32 lanes per env
             if lib().shf_abb_step_pgs_is_wide(self._h):   # sixteen envs per workgroup of 512 threads
                 return f"_Z19k_abb_step_pgs_wideILb{int(link)}EE"
-            return f"_Z10k_abb_stepILi32E7DynDims8DynSceneLb{int(link)}ELi0ELb1EE"
+            return f"_Z10k_abb_stepILi32E7DynDims8DynSceneLb{int(link)}ELi0ELb1ELb0EE"
         if not fixed:
             return pre + "7DynDims"
         if link:    # the shipped arm with its link volumes in the shipped scene (AbbLinkDims, AbbScene)
             if getattr(self.sim, "mapping", "body") == "split":
                 return "_Z13k_abb_step_wsILi512ELb1EE"
-            return pre + "9FixedDimsILi7ELi6ELi59ELi6ELi6EE10FixedSceneILi3ELi1ELi2EELb1ELi0ELb0EE"
+            return pre + "9FixedDimsILi7ELi6ELi59ELi6ELi6EE10FixedSceneILi3ELi1ELi2EELb1ELi0ELb0ELb0EE"
         mp = getattr(self.sim, "mapping", "body")
         if mp == "split":
             return "_Z13k_abb_step_wsILi256ELb0EE"
         arm = 6 if mp == "chain" else 0
-        return pre + f"9FixedDimsILi7ELi6ELi3ELi6ELi6EE10FixedSceneILi3ELi1ELi2EELb0ELi{arm}ELb0EE"
+        return pre + f"9FixedDimsILi7ELi6ELi3ELi6ELi6EE10FixedSceneILi3ELi1ELi2EELb0ELi{arm}ELb0ELb0EE"
 
     @_on_device
     def reset_all(self):

@@ -14,11 +14,11 @@ LIB = os.path.join(HERE, "libshifu_amd.so")
 # shf_api.hip holds the C ABI and the launches; the kernel families of shf_kernels.h are instantiated by the shf_k_*.hip units
 # (csrc/shf_kernel_list.h) so that they compile side by side -- as one unit the library took 4.5 minutes to build.
 KERNEL_UNITS = ["shf_k_sim.hip", "shf_k_sim_link.hip", "shf_k_sim_hard.hip", "shf_k_sim_hard_wide.hip", "shf_k_a1.hip", "shf_k_abb.hip",
-                "shf_k_abb_link.hip", "shf_k_abb_hard.hip", "shf_k_abb_ws.hip"]
-UNITY_SOURCES = ["shf_api.hip", "shf_a1_chain.hip", "shf_glue.hip", "shf_mlp.hip"]      # with -DSHF_UNITY: shf_api.hip instantiates every kernel
-SOURCES = UNITY_SOURCES + KERNEL_UNITS
+                "shf_k_abb_link.hip", "shf_k_abb_hard.hip", "shf_k_abb_ws.hip", "shf_k_sim_ext.hip", "shf_k_abb_ext.hip", "shf_k_hull_test.hip"]
+UNITY_SOURCES = ["shf_api.hip", "shf_a1_chain.hip", "shf_glue.hip", "shf_mlp.hip", "shf_k_hull_test.hip"]      # with -DSHF_UNITY: shf_api.hip instantiates every kernel
+SOURCES = UNITY_SOURCES + [u for u in KERNEL_UNITS if u not in UNITY_SOURCES]
 HEADERS = ["shf_device.h", "shf_boxes.h", "shf_task.h", "shf_chain.h", "shf_chain_hard.h", "shf_hard.h", "shf_link.h", "shf_arm.h", "shf_kernels.h",
-           "shf_kernel_list.h", os.path.join("..", "..", "include", "shifu_amd.h")]
+           "shf_kernel_list.h", "shf_hull.h", os.path.join("..", "..", "include", "shifu_amd.h")]
 DEPS = SOURCES + HEADERS
 # -fno-slp-vectorize: the SLP vectoriser packs neighbouring scalar f32 ops into v_pk_* pairs plus the
 # v_mov shuffles that feed them -- slower for this kernel (measured -6 % at 2 envs/wave, -25 % at one
@@ -61,7 +61,7 @@ BUDGETS = [("_Z16k_a1_step_a1_g32", 256, 0),          # default: A1, two envs pe
            # FusedAbbEnv's default since round 4: the arm with link contacts at 16 lanes per env, one wave per SIMD (all 4096 envs
            # resident: 16 envs per CU share the 160 KB of LDS) -- 512 registers, and the 20 B of scratch every body-mapped
            # ABB instantiation has had since round 3
-           ("_Z10k_abb_stepILi16E9FixedDimsILi7ELi6ELi59ELi6ELi6EE10FixedSceneILi3ELi1ELi2EELb1ELi0ELb0EE", 512, 32),
+           ("_Z10k_abb_stepILi16E9FixedDimsILi7ELi6ELi59ELi6ELi6EE10FixedSceneILi3ELi1ELi2EELb1ELi0ELb0ELb0EE", 512, 32),
            # ... and its arm-wave / box-wave form, the default at 16 lanes: two waves per SIMD, so 256 registers, of which the
            # link passes spill some (120 B of scratch at the end of round 4; 496 B cost 19 %)
            ("_Z13k_abb_step_wsILi512ELb1EE", 256, 160),
@@ -74,7 +74,7 @@ BUDGETS = [("_Z16k_a1_step_a1_g32", 256, 0),          # default: A1, two envs pe
            # config 5 under that solve: the wave-specialised step on compile-time shapes (round 6) without spills; the run-time-shaped
            # generic kernels (any articulation / scene) as they stand: sixteen envs per 512-thread workgroup at 256 registers
            ("_Z19k_abb_step_pgs_wide", 256, 224), ("_Z19k_sim_step_pgs_wide", 256, 48),
-           ("_Z10k_sim_stepILi32ELb0ELb0ELb0ELb1EE", 168, 0), ("_Z10k_sim_stepILi32ELb1ELb0ELb1ELb1EE", 256, 32)]
+           ("_Z10k_sim_stepILi32ELb0ELb0ELb0ELb1ELb0EE", 168, 0), ("_Z10k_sim_stepILi32ELb1ELb0ELb1ELb1ELb0EE", 256, 32)]
 
 
 def parse_resources(remarks: str) -> dict:

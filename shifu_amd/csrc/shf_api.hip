@@ -48,6 +48,9 @@ struct ShfSim {
   int mapping = SHF_MAP_BODY;
   int mapping_split = 0;   // SHF_MAP_CHAIN_SPLIT: threads per block of the wave-specialised arm step (256 / 512), else 0
   int chain_group = 16;  // lanes per env of the chain-mapped fused A1 step (the other kernels keep `group`)
+  ShfHullSet hulls;      // the articulation's convex hulls (shf_sim_set_hulls), model.nhull of them
+  bool has_hulls = false;
+  int scene_flags = 0;   // ShfScene.flags
 };
 
 struct ShfA1Task {
@@ -91,6 +94,8 @@ extern "C" int shf_abi_version(void) { return SHF_ABI_VERSION; }
 // ---------------------------------------------------------------- C ABI --
 static bool sim_self(const ShfSim* s) { return s->model.self_collide != 0 && s->model.npair > 0; }
 static bool sim_link(const ShfSim* s) { return s->model.link_collide != 0 && s->nboxes > 0; }
+// the compile-time-shaped kernels are built for scenes without the face-manifold family and without hulls: such a scene runs on the run-time-shaped ones
+static bool sim_plain(const ShfSim* s) { return s->scene_flags == 0 && s->model.nhull == 0; }
 static int sim_ndyn(const ShfSim* s) {   // free boxes: the only ones that own contact slots (SlotLay)
   int n = 0;
   for (int k = 0; k < s->nboxes; k++) n += (!s->boxes[k].fixed && s->boxes[k].mass > 0.0f) ? 1 : 0;
@@ -146,7 +151,10 @@ extern "C" int shf_sim_set_articulation(ShfSim* sim, const ShfModel* model) {
 }
 // ShfModel.bbox: the bounding box (body frame) of everything a body contributes to link contacts -- sample points grown
 // by their radii, the rounded shapes' segments grown by theirs, the eight vertices of each box volume -- rounded outwards
-extern "C" int shf_model_bounds(ShfModel* m) {
+static int model_bounds(ShfModel* m, const ShfHullSet* hs);
+extern "C" int shf_model_bounds(ShfModel* m) { return model_bounds(m, nullptr); }
+// (hs: the articulation's convex hulls, whose vertices count towards their bodies' boxes)
+static int model_bounds(ShfModel* m, const ShfHullSet* hs) {
   if (!m) return fail("shf_model_bounds: null model");
   if (m->nb < 1 || m->nb > SHF_MAX_BODIES || m->np < 0 || m->np > SHF_MAX_POINTS || m->nsph < 0 || m->nsph > SHF_MAX_SPHERES ||
       m->nabox < 0 || m->nabox > SHF_MAX_ABOX)
@@ -166,6 +174,8 @@ extern "C" int shf_model_bounds(ShfModel* m) {
         b.c[r] = m->abox_pos[j][r] + m->abox_rot[j][3 * r] * lc[0] + m->abox_rot[j][3 * r + 1] * lc[1] + m->abox_rot[j][3 * r + 2] * lc[2];
       balls.push_back(b);
     }
+  for (int j = 0; hs && j < hs->nhull; j++)
+    for (int i = 0; i < hs->hull[j].nv; i++) balls.push_back({{hs->hull[j].vert[i][0], hs->hull[j].vert[i][1], hs->hull[j].vert[i][2]}, 0.0, hs->hull[j].body});
   for (int b = 0; b < SHF_MAX_BODIES; b++) {
     double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};
     bool any = false;
@@ -195,6 +205,37 @@ extern "C" int shf_model_bounds(ShfModel* m) {
   for (int i = npt; i < SHF_MAX_POINTS; i++) m->lc_pt[i] = 0;
   for (int j = nab; j < SHF_MAX_ABOX; j++) m->lc_abox[j] = 0;
   m->bounds_ok = SHF_BOUNDS_MAGIC;
+  return 0;
+}
+extern "C" int shf_sim_set_hulls(ShfSim* sim, const ShfHullSet* hs) {
+  if (!sim || !hs) return fail("shf_sim_set_hulls: null argument");
+  if (!sim->has_model) return fail("shf_sim_set_hulls: before shf_sim_set_articulation");
+  if (sim->finalized) return fail("shf_sim_set_hulls: after shf_sim_finalize");
+  if (hs->nhull < 0 || hs->nhull > SHF_MAX_HULLS || hs->nhull != sim->model.nhull)
+    return fail("shf_sim_set_hulls: nhull must equal ShfModel.nhull (<= SHF_MAX_HULLS)");
+  for (int j = 0; j < hs->nhull; j++) {
+    const ShfHull& h = hs->hull[j];
+    if (h.body < 0 || h.body >= sim->model.nb) return fail("shf_sim_set_hulls: hull on a body outside the model");
+    if (h.nv < 4 || h.nv > SHF_HULL_MAX_VERTS || h.nf < 4 || h.nf > SHF_HULL_MAX_FACES || h.ne < 6 || h.ne > SHF_HULL_MAX_EDGES)
+      return fail("shf_sim_set_hulls: hull exceeds the SHF_HULL_* limits");
+    for (int f = 0; f < h.nf; f++) {
+      if (h.face_count[f] < 3 || h.face_count[f] > SHF_HULL_MAX_FACE_VERTS || h.face_start[f] + h.face_count[f] > SHF_HULL_MAX_LOOP)
+        return fail("shf_sim_set_hulls: bad face loop");
+      for (int k = 0; k < h.face_count[f]; k++)
+        if (h.face_loop[h.face_start[f] + k] >= h.nv) return fail("shf_sim_set_hulls: face loop names a vertex beyond nv");
+    }
+    for (int e = 0; e < h.ne; e++)
+      if (h.edge[e][0] >= h.nv || h.edge[e][1] >= h.nv || h.edge[e][2] >= h.nf || h.edge[e][3] >= h.nf) return fail("shf_sim_set_hulls: bad edge record");
+  }
+  sim->hulls = *hs;
+  sim->has_hulls = hs->nhull > 0;
+  return model_bounds(&sim->model, &sim->hulls);       // the bodies' broad-phase boxes now hold the hulls too
+}
+extern "C" int shf_sim_set_scene_flags(ShfSim* sim, int32_t flags) {
+  if (!sim) return fail("shf_sim_set_scene_flags: null sim");
+  if (sim->finalized) return fail("shf_sim_set_scene_flags: after shf_sim_finalize");
+  if (flags & ~SHF_SCENE_FACE_MANIFOLD) return fail("shf_sim_set_scene_flags: unknown flag");
+  sim->scene_flags = flags;
   return 0;
 }
 extern "C" int shf_sim_add_box(ShfSim* sim, const ShfBoxDesc* box) {
@@ -282,6 +323,7 @@ extern "C" int shf_sim_layout(const ShfSim* sim, int32_t id, int64_t shape[4], i
       break;
     case SHF_T_MODEL: *ndim = 1; shape[0] = sizeof(ShfModel); *dtype = 3; break;
     case SHF_T_SCENE: *ndim = 1; shape[0] = sizeof(ShfScene); *dtype = 3; break;
+    case SHF_T_HULLS: *ndim = 1; shape[0] = sizeof(ShfHullSet); *dtype = 3; break;
     default: return fail("shf_sim_layout: unknown tensor id");
   }
   return 0;
@@ -294,6 +336,11 @@ extern "C" int shf_sim_bind(ShfSim* sim, int32_t id, void* device_ptr) {
     if (!sim->has_model) return fail("shf_sim_bind: SHF_T_MODEL before shf_sim_set_articulation");
     if (hipMemcpy(device_ptr, &sim->model, sizeof(ShfModel), hipMemcpyHostToDevice) != hipSuccess)
       return fail("shf_sim_bind: could not write the model to the bound SHF_T_MODEL buffer");
+  }
+  if (id == SHF_T_HULLS && device_ptr) {
+    if (!sim->has_hulls) return fail("shf_sim_bind: SHF_T_HULLS before shf_sim_set_hulls");
+    if (hipMemcpy(device_ptr, &sim->hulls, sizeof(ShfHullSet), hipMemcpyHostToDevice) != hipSuccess)
+      return fail("shf_sim_bind: could not write the hulls to the bound SHF_T_HULLS buffer");
   }
   sim->t[id] = device_ptr;
   return 0;
@@ -331,6 +378,7 @@ static SimArgs sim_args(const ShfSim* s, bool internal) {
   A.mscale = (const float*)s->t[SHF_T_BODY_MASS_SCALE];
   A.contact = (float*)s->t[internal ? SHF_T_SIM_CONTACT : SHF_T_CONTACT];
   A.dropped = (int32_t*)s->t[SHF_T_DROPPED];
+  A.hulls = (s->model.nhull > 0 && s->model.link_collide != 0) ? (const ShfHullSet*)s->t[SHF_T_HULLS] : nullptr;
   return A;
 }
 
@@ -385,11 +433,37 @@ static int launch_ptr(const void* fn, dim3 grid, dim3 block, size_t lds, void* s
 
 extern "C" int shf_sim_step(ShfSim* sim, void* stream) {
   if (int r = need(sim, {SHF_T_SIM_DOF, SHF_T_SIM_ROOT, SHF_T_SIM_CONTACT, SHF_T_MODEL}, "shf_sim_step")) return r;
+  if (sim->model.nhull > 0 && sim->model.link_collide != 0 && sim->nboxes > 0 && !sim->t[SHF_T_HULLS]) return fail("shf_sim_step: the articulation's hulls (SHF_T_HULLS) are not bound");
   if (sim->terr.rows > 0 && !sim->t[SHF_T_HEIGHTS]) return fail("shf_sim_step: heightfield samples not bound");
   SimArgs A = sim_args(sim, true);
   if (sim->force_armed) {
     A.body_force = (const float*)sim->t[SHF_T_BODY_FORCE];
     if (sim->force_at_pos) A.body_force_pos = (const float*)sim->t[SHF_T_BODY_FORCE_POS];
+  }
+  if (!sim_plain(sim) && sim->nboxes > 0) {
+    // a scene with ShfScene.flags or hulls: the run-time-shaped kernels with the convex narrow phase compiled in (csrc/shf_hull.h)
+    if (!sim_link(sim) || sim_self(sim)) return fail("shf_sim_step: scene flags / hulls need link contacts (ShfModel.link_collide) and no self-collision");
+    if (sim->terr.warped) return fail("shf_sim_step: trimesh terrain with box actors is not supported");
+    if (sim->sp.solver == SHF_SOLVER_PGS) {
+      if (sim->sp.max_contacts > HCK || sim->sp.pos_iters < 1) return fail("shf_sim_step: SHF_SOLVER_PGS needs pos_iters >= 1 and max_contacts <= 8");
+      if (sim->model.nlevels > HG_LEV || sim->model.nb + sim->nboxes > 32) return fail("shf_sim_step: SHF_SOLVER_PGS: at most 8 tree levels and 32 bodies + box actors");
+      sim->force_armed = false; sim->force_at_pos = false;
+      const int keep = sim->group;
+      sim->group = 32;
+      const size_t hlds = sim_lds_bytes(sim, 0, 0, true);
+      sim->group = keep;
+      return launch(k_sim_step<32, true, false, true, true, true>, dim3((sim->n + 7) / 8), dim3(256), hlds, stream, A);
+    }
+    sim->force_armed = false; sim->force_at_pos = false;
+    if (sim->model.nb + sim->nboxes > sim->group) return fail("shf_sim_step: bodies + boxes exceed the lane group");
+    const int epb = 256 / sim->group;
+    const dim3 grid((sim->n + epb - 1) / epb), block(256);
+    const size_t lds = sim_lds_bytes(sim, 0, 0, true);
+    switch (sim->group) {
+      case 64: return launch(k_sim_step<64, true, false, true, false, true>, grid, block, lds, stream, A);
+      case 32: return launch(k_sim_step<32, true, false, true, false, true>, grid, block, lds, stream, A);
+      default: return launch(k_sim_step<16, true, false, true, false, true>, grid, block, lds, stream, A);
+    }
   }
   if (sim->sp.solver == SHF_SOLVER_PGS) {
     // the velocity-level contact solve: built for A1-shaped articulations on their own (csrc/shf_chain_hard.h)
@@ -798,6 +872,7 @@ static int abb_args(ShfAbbTask* task, const float* raw_actions_dev, const char* 
     return r;
   for (int id = 0; id < SHF_ABB_COUNT; id++)
     if (!task->t[id]) return fail(std::string(who) + ": task tensor " + std::to_string(id) + " not bound");
+  if (s->model.nhull > 0 && s->model.link_collide != 0 && !s->t[SHF_T_HULLS]) return fail(std::string(who) + ": the articulation's hulls (SHF_T_HULLS) are not bound");
   if (s->model.nb + s->nboxes > s->group) return fail(std::string(who) + ": bodies + boxes exceed the lane group");
   A.S = sim_args(s, false);
   A.tp = (const ShfAbbTaskParams*)task->t[SHF_ABB_PARAMS];
@@ -845,6 +920,28 @@ static int abb_step_launch(ShfAbbTask* task, const float* raw_actions_dev, void*
   AbbArgs A;
   if (int r = abb_args(task, raw_actions_dev, "shf_abb_step", A)) return r;
   ShfSim* s = task->sim;
+  if (!sim_plain(s)) {
+    // a scene with ShfScene.flags or hulls: the run-time-shaped step with the convex narrow phase compiled in (csrc/shf_hull.h)
+    if (!sim_link(s)) return fail("shf_abb_step: scene flags / hulls need link contacts (ShfModel.link_collide)");
+    if (s->mapping != SHF_MAP_BODY) return fail("shf_abb_step: scene flags / hulls run on the body mapping (shf_sim_set_mapping(SHF_MAP_BODY))");
+    if (s->sp.solver == SHF_SOLVER_PGS) {
+      if (s->sp.max_contacts > HCK || s->sp.pos_iters < 1) return fail("shf_abb_step: SHF_SOLVER_PGS needs pos_iters >= 1 and max_contacts <= 8");
+      if (s->model.nlevels > HG_LEV || s->model.nb + s->nboxes > 32) return fail("shf_abb_step: SHF_SOLVER_PGS: at most 8 tree levels and 32 bodies + box actors");
+      size_t env_bytes, head_bytes;
+      abb_pgs_wide(s, &env_bytes, &head_bytes);
+      return launch(k_abb_step<32, DynDims, DynScene, true, 0, true, true>, dim3((s->n + 7) / 8), dim3(256), head_bytes + 8 * env_bytes, stream, A);
+    }
+    const int epbx = 256 / s->group;
+    const dim3 gridx((s->n + epbx - 1) / epbx), blockx(256);
+    const int nbxx = s->nboxes, nslotsx = s->model.np + box_slot_count(nbxx, sim_ndyn(s), s->model.nsph) + 2 * SHF_MAX_LINK_CONTACTS;
+    const size_t ldsx = ((size_t)MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS +
+                         (size_t)epbx * env_lds_words(s->model.nb + nbxx, s->model.nd, nslotsx, ABB_TAIL_WORDS(nslotsx, s->model.nd), 1 + nbxx)) * 4;
+    switch (s->group) {
+      case 64: return launch(k_abb_step<64, DynDims, DynScene, true, 0, false, true>, gridx, blockx, ldsx, stream, A);
+      case 32: return launch(k_abb_step<32, DynDims, DynScene, true, 0, false, true>, gridx, blockx, ldsx, stream, A);
+      default: return launch(k_abb_step<16, DynDims, DynScene, true, 0, false, true>, gridx, blockx, ldsx, stream, A);
+    }
+  }
   if (s->sp.solver == SHF_SOLVER_PGS) {
     // the velocity-level contact solve: the run-time-shaped body-per-lane step at 32 lanes per env (csrc/shf_hard.h)
     if (s->sp.max_contacts > HCK || s->sp.pos_iters < 1) return fail("shf_abb_step: SHF_SOLVER_PGS needs pos_iters >= 1 and max_contacts <= 8");
@@ -867,7 +964,7 @@ static int abb_step_launch(ShfAbbTask* task, const float* raw_actions_dev, void*
                       (size_t)epb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, ABB_TAIL_WORDS(nslots, s->model.nd), 1 + nbx)) * 4;
   if (sim_link(s) && s->mapping == SHF_MAP_CHAIN && s->mapping_split) {
     // arm wave + box wave with the link contacts on the box wave: 512 threads = 16 envs per workgroup
-    if (!ArmChain<6>::matches(s->model) || !AbbLinkDims::matches(s->model) || !AbbScene::matches(s->nboxes, s->boxes, s->model.nsph) || s->group != 16)
+    if (!ArmChain<6>::matches(s->model) || !AbbLinkDims::matches(s->model) || !(sim_plain(s) && AbbScene::matches(s->nboxes, s->boxes, s->model.nsph)) || s->group != 16)
       return fail("shf_abb_step: the split mapping with link contacts needs the shipped arm (59 sample points), the table / cube / pad "
                   "scene and 16 lanes per env");
     const int wt = 512, wepb = wt / 32;
@@ -875,7 +972,7 @@ static int abb_step_launch(ShfAbbTask* task, const float* raw_actions_dev, void*
                          (size_t)wepb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, ABB_TAIL_WORDS(nslots, s->model.nd) + WS_LINK_STASH_WORDS, 1 + nbx)) * 4;
     return launch(k_abb_step_ws<512, true>, dim3((s->n + wepb - 1) / wepb), dim3(wt), wlds, stream, A);
   }
-  if (sim_link(s) && s->mapping != SHF_MAP_CHAIN && AbbLinkDims::matches(s->model) && AbbScene::matches(s->nboxes, s->boxes, s->model.nsph)) {
+  if (sim_link(s) && s->mapping != SHF_MAP_CHAIN && AbbLinkDims::matches(s->model) && (sim_plain(s) && AbbScene::matches(s->nboxes, s->boxes, s->model.nsph))) {
     // the shipped arm with its link volumes in the shipped scene: compile-time loop bounds, ballot-driven folds
     switch (s->group) {
       case 64: return launch(k_abb_step<64, AbbLinkDims, AbbScene, true>, grid, block, lds, stream, A);
@@ -896,7 +993,7 @@ static int abb_step_launch(ShfAbbTask* task, const float* raw_actions_dev, void*
   if (s->mapping == SHF_MAP_CHAIN) {
     // the arm's recursions on one lane (shf_arm.h): compiled for the shipped arm in the shipped scene only
     if (sim_link(s) || !ArmChain<6>::matches(s->model) || !AbbDims::matches(s->model) ||
-        !AbbScene::matches(s->nboxes, s->boxes, s->model.nsph) || s->group == 64)
+        !(sim_plain(s) && AbbScene::matches(s->nboxes, s->boxes, s->model.nsph)) || s->group == 64)
       return fail("shf_abb_step: the chain mapping needs the 6-link arm with 3 sample points and one capsule, the table / cube / pad "
                   "scene, no link contacts, and 16 or 32 lanes per env");
     if (s->mapping_split && s->group != 16) return fail("shf_abb_step: the split chain mapping runs at 16 lanes per env");
@@ -911,7 +1008,7 @@ static int abb_step_launch(ShfAbbTask* task, const float* raw_actions_dev, void*
     return s->group == 32 ? launch(k_abb_step<32, AbbDims, AbbScene, false, 6>, grid, block, lds, stream, A)
                           : launch(k_abb_step<16, AbbDims, AbbScene, false, 6>, grid, block, lds, stream, A);
   }
-  if (AbbDims::matches(s->model) && AbbScene::matches(s->nboxes, s->boxes, s->model.nsph)) {
+  if (AbbDims::matches(s->model) && (sim_plain(s) && AbbScene::matches(s->nboxes, s->boxes, s->model.nsph))) {
     switch (s->group) {
       case 64: return launch(k_abb_step<64, AbbDims, AbbScene>, grid, block, lds, stream, A);
       case 32: return launch(k_abb_step<32, AbbDims, AbbScene>, grid, block, lds, stream, A);

@@ -906,6 +906,8 @@ DEV unsigned body_sphere_flags(const ShfModel* m, const EnvLds& L, const SlotLay
   return bits;
 }
 
+#include "shf_hull.h"   // the convex narrow phase (hulls, face manifolds): uses segment_closest above
+
 // ------------------------------------------------------------ link contacts --
 // ShfModel.link_collide (include/shifu_amd.h; oracle boxes_pre "link contacts"): the articulation's collision shapes
 // against the box actors of its env beyond the rounded-shape pair slots -- (A) sample points x boxes, (C) rounded shapes
@@ -947,7 +949,9 @@ DEV void link_append(LinkCtx& X, const float* slot, int body, int box) {
   }
   X.count += __builtin_popcountll(mask);
 }
-template <int G>
+// EXT: with the families (F) and (H) of the convex narrow phase compiled in (csrc/shf_hull.h) -- the run-time-shaped kernels of
+// scenes with ShfScene.flags or hulls; the other instantiations are rounds 1-5's code
+template <int G, bool EXT = false>
 DEV int link_contacts(const StepCtx& C, const EnvLds& L, int l, int slot0, float mu_shape, const float* g_art) {
   const ShfModel* m = C.m;
   const SceneDev* S = C.scene;
@@ -1228,6 +1232,70 @@ DEV int link_contacts(const StepCtx& C, const EnvLds& L, int l, int slot0, float
         }
         if (__ballot(slot[PT_ON] != 0.0f) != 0ull) link_append(X, slot, b, kd);
         if (__ballot(slotE[PT_ON] != 0.0f) != 0ull) link_append(X, slotE, b, kd);
+      }
+      // (F) ShfScene.flags & SHF_SCENE_FACE_MANIFOLD: a pair without any contact of the families above gets the clipped face manifold
+      // of each of the body's box volumes with the box actor; (H) the body's convex hulls (SHF_T_HULLS) against the box actor: the
+      // convex narrow phase (csrc/shf_hull.h), the lanes of the env sharing its axes; up to four contacts each, on lanes 0..3
+      if constexpr (EXT) {
+        const bool flagF = (S->flags & SHF_SCENE_FACE_MANIFOLD) != 0;
+        const int nh = (m->nhull > 0 && C.hulls != nullptr) ? C.hulls->nhull : 0;
+        const bool wantF = flagF && mine && X.count == count0;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; pass++) {
+          const int count = pass == 0 ? ((flagF && __ballot(wantF) != 0ull) ? an : 0) : nh;
+#pragma unroll 1
+          for (int j = 0; j < count; j++) {
+            if (pass == 1 && C.hulls->hull[j].body != b) continue;
+            const bool active = pass == 0 ? wantF : mine;
+            if (__ballot(active) == 0ull) continue;
+            PolyDev PA, PB;
+            if (pass == 0) {
+              const int jb = m->lc_abox[a0 + j];
+              float lr[9];
+#pragma unroll
+              for (int k = 0; k < 9; k++) lr[k] = m->abox_rot[jb][k];
+              const float lp[3] = {m->abox_pos[jb][0], m->abox_pos[jb][1], m->abox_pos[jb][2]};
+              mm3(Rb, lr, PA.R);
+              mv3(Rb, lp, PA.p);
+#pragma unroll
+              for (int k = 0; k < 3; k++) { PA.p[k] += pb[9 + k]; PA.hx[k] = m->abox_half[jb][k]; }
+              PA.h = nullptr;
+            } else {
+              PA.h = &C.hulls->hull[j];
+#pragma unroll
+              for (int k = 0; k < 9; k++) PA.R[k] = Rb[k];
+#pragma unroll
+              for (int k = 0; k < 3; k++) { PA.p[k] = pb[9 + k]; PA.hx[k] = 0.0f; }
+            }
+            PB.h = nullptr;
+#pragma unroll
+            for (int k = 0; k < 9; k++) PB.R[k] = Rk[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { PB.p[k] = bpos[k]; PB.hx[k] = hh[k]; }
+            float mr[4][3], mn[3] = {0.0f, 0.0f, 0.0f}, mphi[4];
+            int nc = convex_manifold_dev<G>(PA, PB, offset, l, mr, mn, mphi);
+            if (!active) nc = 0;
+            float slot[PT_STRIDE];
+            slot[PT_ON] = 0.0f;
+            if (l < nc) {
+              float rq[3] = {mr[0][0], mr[0][1], mr[0][2]}, ph = mphi[0];
+#pragma unroll
+              for (int q = 1; q < 4; q++)
+                if (l == q) { rq[0] = mr[q][0]; rq[1] = mr[q][1]; rq[2] = mr[q][2]; ph = mphi[q]; }
+              float ta[3], tb[3], vrel[3], vrs[3];
+              cross3(va, rq, ta);
+              cross3(vbx, rq, tb);
+#pragma unroll
+              for (int k = 0; k < 3; k++) {
+                const float pa = vla[k] + ta[k], pq = vlb[k] + tb[k];
+                vrs[k] = pa - pq;
+                vrel[k] = fmaf(dt, g_art[k], pa) - (dynb ? fmaf(dt, gb[k], pq) : pq);
+              }
+              slot_eval(slot, ph, mn, rq, vrs, vrel, mu_pair, kc, beta, veps, vdep, dt, offset);
+            }
+            if (__ballot(slot[PT_ON] != 0.0f) != 0ull) link_append(X, slot, b, kd);
+          }
+        }
       }
       PHASE_MARK(28);
     }
@@ -1587,9 +1655,10 @@ DEV void boxes_contacts_fixed(const StepCtx& C, const EnvLds& L, int l, BodyRegs
 // Evaluate every box contact slot (one lane each), then fold them into the owning bodies.
 // HARD (ShfSimParams.solver == SHF_SOLVER_PGS): the slots only record candidate constraints (slot_eval), a corner's gap to a
 // fixed box is its signed distance (a constraint needs the gap of a corner still outside), and nothing is folded.
-template <int G, class SC, bool LINK = false, bool HARD = false>
+template <int G, class SC, bool LINK = false, bool HARD = false, bool EXT = false>
 DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, float mu_shape, const float* g_art,
                         const BoxLane& BL, BoxMasks& BM, int link_slot0 = 0) {
+  static_assert(!EXT || SC::NBX == 0, "the convex narrow phase is compiled into the run-time-shaped scene path only");
   if constexpr (SC::NBX > 0) { boxes_contacts_fixed<G, SC, LINK>(C, L, l, B, mu_shape, g_art, BL, BM, link_slot0); return; }
   const ShfModel* m = C.m;
   const SceneDev* S = C.scene;
@@ -1670,6 +1739,48 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
     for (int i = 0; i < 3; i++) { vs[i] = pk[15 + i] + t[i]; vp[i] = fmaf(dt, gb[i], vs[i]); }
     slot_eval(o, phi, n, re, vs, vp, 0.5f * (bd.friction + bs.friction), kc, beta, veps, vdep, dt, offset);
   }
+  // ShfScene.flags & SHF_SCENE_FACE_MANIFOLD (oracle boxes_pre): a fixed box that a free box touches with neither a corner nor an
+  // edge crossing gets the clipped face manifold (csrc/shf_hull.h), its <= 4 points in the slots corners 0..3 would have against it
+  if constexpr (EXT) if (S->flags & SHF_SCENE_FACE_MANIFOLD) {
+    GROUP_SYNC();
+#pragma unroll 1
+    for (int kd = 0; kd < nbx; kd++) {
+#pragma unroll 1
+      for (int ks = 0; ks < nbx && ks < 8; ks++) {
+        const ShfBoxDesc& bd = S->box[kd];
+        const ShfBoxDesc& bs = S->box[ks];
+        if (ks == kd || !box_is_dynamic(bd) || box_is_dynamic(bs)) continue;
+        bool any = L.pt[corner_slot(Q, kd, ks, 1 + kd) * PT_STRIDE + PT_ON] != 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; c++) any = any || L.pt[corner_slot(Q, kd, c, 1 + ks) * PT_STRIDE + PT_ON] != 0.0f;
+        if (__ballot(!any) == 0ull) continue;
+        const float* pk = L.pose + (nb + kd) * POSE_STRIDE;
+        const float* ps = L.pose + (nb + ks) * POSE_STRIDE;
+        PolyDev PA, PB;
+        PA.h = nullptr; PB.h = nullptr;
+#pragma unroll
+        for (int i = 0; i < 9; i++) { PA.R[i] = pk[i]; PB.R[i] = ps[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; i++) { PA.p[i] = pk[9 + i]; PB.p[i] = ps[9 + i]; PA.hx[i] = 0.5f * bd.dim[i]; PB.hx[i] = 0.5f * bs.dim[i]; }
+        float mr[4][3], mn[3] = {0.0f, 0.0f, 0.0f}, mphi[4];
+        int nc = convex_manifold_dev<G>(PA, PB, offset, l, mr, mn, mphi);
+        if (any) nc = 0;
+        if (l < nc) {
+          float rq[3] = {mr[0][0], mr[0][1], mr[0][2]}, ph = mphi[0];
+#pragma unroll
+          for (int q = 1; q < 4; q++)
+            if (l == q) { rq[0] = mr[q][0]; rq[1] = mr[q][1]; rq[2] = mr[q][2]; ph = mphi[q]; }
+          const float vb[3] = {pk[12], pk[13], pk[14]};
+          float t[3], vs[3], vp[3];
+          cross3(vb, rq, t);
+#pragma unroll
+          for (int i = 0; i < 3; i++) { vs[i] = pk[15 + i] + t[i]; vp[i] = fmaf(dt, gb[i], vs[i]); }
+          slot_eval(L.pt + corner_slot(Q, kd, l, 1 + ks) * PT_STRIDE, ph, mn, rq, vs, vp, 0.5f * (bd.friction + bs.friction), kc, beta, veps, vdep, dt, offset);
+        }
+        GROUP_SYNC();
+      }
+    }
+  }
   PHASE_MARK(17);
   // sphere slots
   for (int idx = l; idx < m->nsph * nbx; idx += G) {
@@ -1701,7 +1812,7 @@ DEV void boxes_contacts(const StepCtx& C, const EnvLds& L, int l, BodyRegs& B, f
   }
   int nlink = 0;
   PHASE_MARK(18);
-  if constexpr (LINK) nlink = link_contacts<G>(C, L, l, link_slot0, mu_shape, g_art);
+  if constexpr (LINK) nlink = link_contacts<G, EXT>(C, L, l, link_slot0, mu_shape, g_art);
   BM.nlink = nlink;
   GROUP_SYNC();
   PHASE_MARK(20);

@@ -710,6 +710,7 @@ struct StepCtx {
   const SceneDev* scene;  // LDS copy, may be null when the scene has no boxes
   int32_t* dropped = nullptr;   // this env's word of SHF_T_DROPPED (contacts beyond the per-env limits), may be null
   const float* mscale = nullptr;  // this env's row of SHF_T_BODY_MASS_SCALE (factor on each body's mass and inertia), may be null
+  const ShfHullSet* hulls = nullptr;   // the articulation's convex hulls (global memory), may be null
 };
 // mass of body b in this env (oracle: body_mass)
 DEV float body_mass(const StepCtx& C, int b) { return C.mscale ? C.m->mass[b] * C.mscale[b] : C.m->mass[b]; }
@@ -940,7 +941,7 @@ template <int G, bool BOX, class DM, class LM, class SC, bool SELF, bool LINK>
 DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM& M, BodyRegs& B, const float* g, float* a, int nself,
                              int self_slot0, int link_slot0, int nlink, float* contact_out);
 template <int G, bool BOX = false, class DM = DynDims, bool TW = false, class LM = LaneModel, class SC = DynScene,
-          bool SELF = false, bool LINK = false, bool HARD = false>
+          bool SELF = false, bool LINK = false, bool HARD = false, bool EXT = false>
 DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const LanePoints<LANE_ROUNDS(G, DM)>& P,
                  const float* pos_tgt, const float* vel_tgt, const float* fext, float mu_shape, float* contact_out,
                  const BoxLane& BL = BoxLane(), const float* fpos = nullptr) {
@@ -1092,7 +1093,7 @@ DEV void substep(const StepCtx& C, const EnvLds& L, int l, const LM& M, const La
   if constexpr (SELF) nself = HARD ? self_contacts_eval<G>(C, L, l, self_slot0, mu_shape) : self_contacts<G>(C, L, l, isdyn, self_slot0, B, mu_shape);
   BoxMasks BM;
   const int link_slot0 = self_slot0 + (SELF ? SHF_MAX_SELF_CONTACTS : 0);   // 2 x SHF_MAX_LINK_CONTACTS slots when LINK
-  if (BOX) boxes_contacts<G, SC, LINK && BOX, HARD>(C, L, l, B, mu_shape, g, BL, BM, link_slot0);
+  if (BOX) boxes_contacts<G, SC, LINK && BOX, HARD, EXT && LINK && BOX>(C, L, l, B, mu_shape, g, BL, BM, link_slot0);
   PHASE_MARK(4);
 
   // joint-space efforts: one lane per dof

@@ -11,7 +11,8 @@
 // HARD: the velocity-level contact solve (ShfSimParams.solver == SHF_SOLVER_PGS; csrc/shf_hard.h): 32 lanes per env, and
 // hard_total_slots() contact slots per env (the solve's records and response matrix live inside the slot region, csrc/shf_hard.h)
 // (WT threads per workgroup: 256, or 512 for k_sim_step_pgs_wide below)
-template <int G, bool BOX, bool SELF, bool LINK, bool HARD, int WT>
+// EXT: the convex narrow phase compiled in (hulls, face manifolds: csrc/shf_hull.h) -- scenes with ShfScene.flags or hulls
+template <int G, bool BOX, bool SELF, bool LINK, bool HARD, int WT, bool EXT = false>
 DEV void sim_step_body(const SimArgs& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const ShfScene* scene = BOX ? stage_scene<WT>(A.scene, smem + MODEL_WORDS) : nullptr;
@@ -34,11 +35,12 @@ DEV void sim_step_body(const SimArgs& A) {
   C.m = m; C.sp = A.sp; C.terr.t = A.terr; C.terr.h = A.heights; C.scene = scene;
   C.dropped = A.dropped ? A.dropped + e : nullptr;
   C.mscale = A.mscale ? A.mscale + (size_t)e * nb : nullptr;
+  C.hulls = A.hulls;
   const float mu = A.friction ? A.friction[e] : 1.0f;
   LaneModel M;
   lane_model_load<DynDims>(m, l, M);
   LanePoints<1> P;   // unused: point count only known at run time
-  substep<G, BOX, DynDims, !BOX, LaneModel, DynScene, SELF, LINK, HARD>(C, L, l, M, P, A.pos_tgt ? A.pos_tgt + (size_t)e * nd : nullptr,
+  substep<G, BOX, DynDims, !BOX, LaneModel, DynScene, SELF, LINK, HARD, EXT>(C, L, l, M, P, A.pos_tgt ? A.pos_tgt + (size_t)e * nd : nullptr,
                   A.vel_tgt ? A.vel_tgt + (size_t)e * nd : nullptr, A.body_force ? A.body_force + (size_t)e * nbt * 3 : nullptr, mu, L.xch,
                   BoxLane(), (A.body_force && A.body_force_pos) ? A.body_force_pos + (size_t)e * nbt * 3 : nullptr);
   GROUP_SYNC();
@@ -46,9 +48,9 @@ DEV void sim_step_body(const SimArgs& A) {
   for (int i = l; i < 13 * actors; i += G) root[i] = L.root[i];
   for (int i = l; i < 3 * nbt; i += G) A.contact[(size_t)e * nbt * 3 + i] = L.xch[i];
 }
-template <int G, bool BOX, bool SELF, bool LINK = false, bool HARD = false>
+template <int G, bool BOX, bool SELF, bool LINK = false, bool HARD = false, bool EXT = false>
 __global__ __launch_bounds__(256) void k_sim_step(SimArgs A) {
-  sim_step_body<G, BOX, SELF, LINK, HARD, 256>(A);
+  sim_step_body<G, BOX, SELF, LINK, HARD, 256, EXT>(A);
 }
 // gym.simulate under the velocity-level solve for a scene with box actors and link contacts, sixteen envs per workgroup of 512
 // threads (as k_abb_step_pgs_wide: where their LDS fits one CU and eight envs would leave the CU to one workgroup)
@@ -280,6 +282,7 @@ DEV void a1_step_body(const A1Args& A) {
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = nullptr;
   C.dropped = A.S.dropped ? A.S.dropped + e : nullptr;
   C.mscale = A.S.mscale ? A.S.mscale + (size_t)e * nb : nullptr;
+  C.hulls = A.S.hulls;
   const float mu = A.S.friction[e];
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
   // (with self-collision the per-lane model constants stay in LDS: the pair tests need the registers)
@@ -556,7 +559,7 @@ DEV void abb_post_step(const AbbArgs& A, const ShfAbbTaskParams& tp, const ShfMo
 #define ABB_TAIL_WORDS(nslots, nd) ((nslots) * PT_STRIDE + ABB_TGT_WORDS(nd) + ARM_KREC_WORDS(SHF_ARM_MAX_LINKS) + 4)
 #define ABB_TAIL_WORDS_NOARM(nslots, nd) ((nslots) * PT_STRIDE + ABB_TGT_WORDS(nd) + 4)   /* (ARM = 0 and HARD: no link records of the arm recursions) */
 // (WT threads per workgroup: 256, or 512 for k_abb_step_pgs_wide below)
-template <int G, class DM, class SC, bool LINK, int ARM, bool HARD, int WT>
+template <int G, class DM, class SC, bool LINK, int ARM, bool HARD, int WT, bool EXT = false>
 DEV void abb_step_body(const AbbArgs& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   PHASE_BEGIN();
@@ -601,6 +604,7 @@ DEV void abb_step_body(const AbbArgs& A) {
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = scene;
   C.dropped = A.S.dropped ? A.S.dropped + e : nullptr;
   C.mscale = A.S.mscale ? A.S.mscale + (size_t)e * nb : nullptr;
+  C.hulls = A.S.hulls;
   const float mu = A.S.friction[e];
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
   // (the 512-thread form has 256 registers at two wavefronts per SIMD and spills: its per-lane model constants stay in the
@@ -616,13 +620,13 @@ DEV void abb_step_body(const AbbArgs& A) {
     if constexpr (ARM > 0)
       arm_substep<G, DM, SC, ARM>(C, L, krec, l, M, P, tgtl, mu, it == nsub - 1 ? L.xch : nullptr, BL);
     else
-      substep<G, true, DM, false, LM, SC, false, LINK, HARD>(C, L, l, M, P, tgtl, nullptr, nullptr, mu, it == nsub - 1 ? L.xch : nullptr, BL);
+      substep<G, true, DM, false, LM, SC, false, LINK, HARD, EXT>(C, L, l, M, P, tgtl, nullptr, nullptr, mu, it == nsub - 1 ? L.xch : nullptr, BL);
   }
   abb_after_physics<G, DM>(A, tp, m, L, l, e, epb, nbx, tgtl, stats_lds, stats_step);
 }
-template <int G, class DM, class SC, bool LINK = false, int ARM = 0, bool HARD = false>
+template <int G, class DM, class SC, bool LINK = false, int ARM = 0, bool HARD = false, bool EXT = false>
 __global__ __launch_bounds__(256, ((G >= 32 && SC::NBX > 0) || (HARD && !LINK)) ? 2 : 1) void k_abb_step(AbbArgs A) {
-  abb_step_body<G, DM, SC, LINK, ARM, HARD, 256>(A);
+  abb_step_body<G, DM, SC, LINK, ARM, HARD, 256, EXT>(A);
 }
 // The run-time-shaped step under the velocity-level solve with link contacts, 16 envs per workgroup of 512 threads: one staged
 // model for sixteen envs leaves each 8.7 KB of LDS (csrc/shf_hard.h keeps the solve inside the contact-slot region), so that

@@ -25,6 +25,7 @@ struct SimArgs {
   const float* mscale;   // (n,nb) per-env factors on the bodies' mass and inertia (SHF_T_BODY_MASS_SCALE), nullptr = 1
   float* contact;  // (n*B,3)
   int32_t* dropped;  // (n) contacts dropped at the per-env limits, accumulated (SHF_T_DROPPED), may be null
+  const ShfHullSet* hulls;   // device copy of the articulation's convex hulls (SHF_T_HULLS), nullptr = none
 };
 
 // Cooperative global -> LDS copy of a fixed-size parameter block by the 256 threads of a block: all loads

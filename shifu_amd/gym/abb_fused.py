@@ -16,7 +16,8 @@ REWARD_NAMES = ["reward_reaching", "reward_success"]   # build_reward_functions 
 class FusedAbbEnv:
     def __init__(self, num_envs: int = 4096, device="cuda:0", seed: int = 42, rank: int = 0, world_size: int = 1,
                  group: int = None, dt: float = 0.02, decimation: int = 5, episode_length_s: float = 20.0,
-                 extra_boxes=(), link_contacts: bool = None, mapping: str = None, solver: str = None):
+                 extra_boxes=(), link_contacts: bool = None, mapping: str = None, solver: str = None,
+                 link_shapes: str = "box", face_manifold: bool = None):
         self.device = torch.device(device)
         self.num_envs = num_envs
         self.env_id_offset = rank * num_envs
@@ -29,7 +30,21 @@ class FusedAbbEnv:
         if link_contacts is None:
             link_contacts = mapping != "chain"
         self.link_contacts = bool(link_contacts)
-        self.cm = abb_model(link_contacts=link_contacts)
+        # link_shapes: "box" = the links as the bounding boxes of their mesh colliders (rounds 3-5; the kernels compiled for this
+        # scene); "hull" = as the convex hulls of the reference's collision meshes (abb_rod_isaac.urdf:38-113), reduced to <= 32
+        # vertices, through the convex narrow phase (csrc/shf_hull.h) on the run-time-shaped kernels.  face_manifold
+        # (ShfScene.flags): box pairs that touch without a vertex or an edge crossing -- an edge or a face lying flat on a face --
+        # get the clipped face manifold too; on with the hulls unless said otherwise.
+        if link_shapes == "hull" and not self.link_contacts:
+            raise ValueError("FusedAbbEnv: link_shapes='hull' needs link_contacts=True")
+        self.link_shapes = link_shapes
+        self.face_manifold = bool(link_shapes == "hull" if face_manifold is None else face_manifold)
+        ext = link_shapes == "hull" or self.face_manifold
+        if ext and mapping not in (None, "body"):
+            raise ValueError("FusedAbbEnv: hulls / the face manifold run on mapping='body' (the run-time-shaped kernels)")
+        if ext:
+            mapping = "body"
+        self.cm = abb_model(link_contacts=link_contacts, link_shapes=link_shapes)
         # solver: "pgs" = the velocity-level contact solve with the reference's PhysX settings (env_config.py:50-58) -- the default,
         # on the run-time-shaped body-per-lane kernel at 32 lanes per env (csrc/shf_hard.h; round 5: correct, not yet fast:
         # 0.49 ms per vec-step); "compliant" = rounds 1-4's spring-damper law on the kernels compiled for this scene (0.16 ms).
@@ -60,6 +75,10 @@ class FusedAbbEnv:
         self.sim = Sim(self.sim_params, self.device)
         self.sim.set_plane(1.0)
         self.sim.set_articulation(self.cm.blob)
+        if self.cm.hulls is not None:
+            self.sim.set_hulls(self.cm.hulls)
+        if self.face_manifold:
+            self.sim.set_scene_flags(_abi.SCENE_FACE_MANIFOLD)
         # extra_boxes: further (fixed) box actors after table / cube / goal -- the scene then no longer matches the
         # compile-time ABB scene and the step runs on the run-time-shaped kernel instantiation (tests use this)
         self.boxes = abb_boxes() + list(extra_boxes)

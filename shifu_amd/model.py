@@ -561,7 +561,7 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
                  armature: float = 0.0, honour_dont_collapse: bool = True,
                  extra_spheres: Sequence[tuple] = (), density: float = 1000.0,
                  self_collision: bool = False, meshes: str = "error", link_contacts: bool = False,
-                 extra_boxes: Sequence[tuple] = ()) -> CompiledModel:
+                 extra_boxes: Sequence[tuple] = (), extra_hulls: Sequence[tuple] = (), hull_contacts: bool = False) -> CompiledModel:
     """Compile `path` with the AssetOptions the reference passes (asset_config.py:32-46).
 
     meshes: <mesh> collision geometry becomes the convex hull of the STL file ("error": a missing file is refused;
@@ -574,10 +574,24 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
     extra_boxes: (link name, xyz, rpy, size) box collision shapes added to links before compilation -- the box-shaped
     stand-ins for mesh colliders whose files do not ship (shifu_amd/assets/abb_link_boxes.json: the bounding boxes of the
     reference's ABB link hulls).
+    extra_hulls: (link name, vertices (n, 3) in that link's frame) convex mesh colliders added to links before compilation --
+    the reduced hulls of mesh files that do not ship (shifu_amd/assets/abb_link_hulls.json, tools/make_link_hulls.py).
+    hull_contacts: mesh colliders meet the box actors as convex polytopes (include/shifu_amd.h: ShfHull; needs link_contacts):
+    each hull shape becomes a record of CompiledModel.hulls (ShfModel.nhull) for the convex narrow phase -- separating-axis
+    test and clipped face manifold -- instead of eight sample vertices and a bounding-box volume; its sample points stay for
+    ground contact but are left out of the link contacts' vertex family.
     link_contacts: ShfModel.link_collide -- every collision shape of the articulation also meets the box actors of its env
     (SURVEY 8f f3): sample points against boxes, box corners against the articulation's box volumes (abox_*: the <box>
     primitives and, for hulls, their bounding boxes in the shape frame)."""
     links, joints = parse_urdf(path, meshes=meshes)
+    for (lname, verts) in extra_hulls:
+        if lname not in links:
+            raise ValueError(f"extra_hulls: no link '{lname}'")
+        hv, ht = _convex_hull(np.asarray(verts, float))
+        links[lname].shapes.append(_Shape("hull", np.ones(3), np.zeros(3), np.eye(3), hv, ht))
+    if hull_contacts and not link_contacts:
+        raise ValueError("hull_contacts needs link_contacts=True")
+    hull_recs: List = []          # (body, reduced polytope, p, R)
     for (lname, xyz, rpy, size) in extra_boxes:
         if lname not in links:
             raise ValueError(f"extra_boxes: no link '{lname}'")
@@ -609,6 +623,13 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
         inert[body] = inert[body].merged(link.inertial.transformed(p, R))
         link_frame[link.name] = (body, p.copy(), R.copy())
         for s in link.shapes:
+            if s.kind == "hull" and hull_contacts:
+                # the convex narrow phase takes this shape against the box actors (no sample points: they would meet the boxes a
+                # second time as family A; a fixed-base arm has no ground to touch)
+                hull_recs.append((body, reduce_hull(s.verts), p + R @ s.pos, R @ s.rot))
+                for ca, cb, rad in _shape_capsules(s):
+                    capsules.append((body, p + R @ ca, p + R @ cb, rad))
+                continue
             for q, rad in _shape_points(s):
                 points.append((body, p + R @ q, rad))
             for ca, cb, rad in _shape_capsules(s):
@@ -875,7 +896,16 @@ def compile_urdf(path: str, *, fix_base_link: bool = False, disable_gravity: boo
     for k, (i, j) in enumerate(pairs):
         m.pair_a[k], m.pair_b[k] = i, j
 
-    return CompiledModel(m, names, dof_names, float(sum(t.mass for t in merged)))
+    hulls = None
+    m.nhull = 0
+    if hull_recs:
+        if len(hull_recs) > _abi.MAX_HULLS:
+            raise ValueError(f"{len(hull_recs)} convex hulls > SHF_MAX_HULLS = {_abi.MAX_HULLS}")
+        hulls = _abi.ShfHullSet()
+        hulls.nhull = m.nhull = len(hull_recs)
+        for j, (b, h, hp, hR) in enumerate(sorted(hull_recs, key=lambda t: t[0])):
+            hulls.hull[j] = hull_record(h, b, hp, hR)
+    return CompiledModel(m, names, dof_names, float(sum(t.mass for t in merged)), hulls)
 
 
 def asset_path(name: str) -> str:

@@ -90,3 +90,18 @@ def box_pusher_model(size=(0.06, 0.06, 0.06), centre=(0.0, 0.0, 0.05), axis="1 0
                   extra_spheres=[("ram",) + tuple(capsule)] if capsule else ())
     cm.blob.kd[0] = kd
     return cm
+
+
+def hull_pusher_model(verts, axis="0 0 -1", kd=2000.0):
+    """The rail-mounted ram carrying ONE convex mesh collider (vertices in the ram's frame): the convex narrow phase (hulls against
+    box actors: ShfModel.nhull, include/shifu_amd.h ShfHull) in its simplest setting.  Velocity drive on the slide."""
+    cm = _compile(BOX_PUSHER_URDF.format(shapes="", axis=axis), fix_base_link=True, disable_gravity=True,
+                  default_dof_drive_mode=_abi.DOF_MODE_VEL, link_contacts=True, extra_hulls=[("ram", np.asarray(verts, float))],
+                  hull_contacts=True)
+    cm.blob.kd[0] = kd
+    return cm
+
+
+def prism_verts(a=0.1, b=0.06, top=0.5, h=0.08, z0=0.4):
+    """A frustum: bottom rectangle 2a x 2b at z0, top rectangle scaled by `top` at z0 + h (eight vertices, six faces)."""
+    return [[sx * a, sy * b, z0] for sx in (-1, 1) for sy in (-1, 1)] + [[sx * a * top, sy * b * top, z0 + h] for sx in (-1, 1) for sy in (-1, 1)]

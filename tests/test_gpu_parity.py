@@ -401,7 +401,7 @@ def test_fused_abb_step_matches_oracle_bitwise_at_full_size(oracle, link, solver
         assert env.mapping == "body" and env.sim.group == 32 and env.sim_params.solver == _abi.SOLVER_PGS
         # link contacts: sixteen envs per workgroup of 512 threads (8.7 KB of LDS per env: 4096 envs resident at once); the rod-only
         # scene: eight per workgroup of 256, two workgroups per CU
-        assert env.task.kernel_symbol() == ("_Z19k_abb_step_pgs_wideILb1EE" if link else "_Z10k_abb_stepILi32E7DynDims8DynSceneLb0ELi0ELb1EE")
+        assert env.task.kernel_symbol() == ("_Z19k_abb_step_pgs_wideILb1EE" if link else "_Z10k_abb_stepILi32E7DynDims8DynSceneLb0ELi0ELb1ELb0EE")
     else:
         assert env.mapping == "split" and env.sim.group == 16
         assert env.task.kernel_symbol() == ("_Z13k_abb_step_wsILi512ELb1EE" if link else "_Z13k_abb_step_wsILi256ELb0EE")
@@ -884,7 +884,7 @@ def test_fused_abb_step_under_the_velocity_level_solve_matches_oracle_bitwise(or
     from shifu_amd.gym.abb_fused import FusedAbbEnv
     n = 48
     env = FusedAbbEnv(num_envs=n, seed=11, link_contacts=link, solver="pgs")
-    assert env.sim_params.solver == _abi.SOLVER_PGS and ("Lb1EE" in env.task.kernel_symbol() or "pgs_wide" in env.task.kernel_symbol())
+    assert env.sim_params.solver == _abi.SOLVER_PGS and ("Lb1ELb0EE" in env.task.kernel_symbol() or "pgs_wide" in env.task.kernel_symbol())
     bufs = {k: env.sim.tensors[t].cpu().numpy().copy() for k, t in _ABB_SIM_T.items()}
     bufs.update({k: env.task.tensors[t].cpu().numpy().copy() for k, t in _ABB_T.items()})
     rng = np.random.default_rng(2)
@@ -943,8 +943,8 @@ def test_fused_abb_step_matches_oracle_bitwise(oracle, group, generic):
                       solver="compliant")       # (the kernel forms of the compliant law; the velocity-level solve has its own tests)
     assert env.mapping == ("split" if (split or link_split) else "chain" if (not generic and not link and not levels and group < 64) else "body")
     assert ("FixedDims" in env.task.kernel_symbol() or split or link_split) != bool(generic)
-    assert ("Lb1ELi0ELb0EE" in env.task.kernel_symbol()) == (link and not generic and not link_split)
-    assert env.task.kernel_symbol().endswith("Li6ELb0EE") == (env.mapping == "chain")
+    assert ("Lb1ELi0ELb0ELb0EE" in env.task.kernel_symbol()) == (link and not generic and not link_split)
+    assert env.task.kernel_symbol().endswith("Li6ELb0ELb0EE") == (env.mapping == "chain")
     env.task.tensors[_abi.ABB_EP_LEN].copy_(torch.randint(0, 200, (n,)))   # staggered time-outs
     torch.cuda.synchronize()
     bufs = {k: env.sim.tensors[t].cpu().numpy().copy() for k, t in _ABB_SIM_T.items()}
