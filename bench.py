@@ -48,7 +48,7 @@ WL_NAME = {"terrain": "a1_conditional procedural heightfield 1300x2100 (config 3
 
 
 # ----------------------------------------------------------------------------- CPU oracle workloads --
-def oracle_workload(workload: str, n: int, seed: int = 0, solver_kw=None):
+def oracle_workload(workload: str, n: int, seed: int = 0, solver_kw=None, link_contacts: bool = True, link_shapes: str = "box"):
     """The same workload on NumPy buffers for the CPU oracle: returns step(nthreads, count_flops=False) -> None."""
     from oracle import pyoracle
     from shifu_amd import _abi
@@ -57,8 +57,9 @@ def oracle_workload(workload: str, n: int, seed: int = 0, solver_kw=None):
     rng = np.random.default_rng(seed)
     if workload == "abb":
         from shifu_amd.abb_task import ABB_BASE_POS, abb_boxes, abb_model, abb_task_params
-        cm = abb_model()
+        cm = abb_model(link_contacts=link_contacts, link_shapes=link_shapes)      # the scene the GPU leg runs
         m, boxes = cm.blob, abb_boxes()
+        flags = _abi.SCENE_FACE_MANIFOLD if (link_contacts and link_shapes == "hull") else 0
         sp = default_sim_params(dt=0.02, **(solver_kw or {}))
         tp = abb_task_params(cm)
         nb, nd, A = m.nb, m.nd, 4
@@ -81,7 +82,8 @@ def oracle_workload(workload: str, n: int, seed: int = 0, solver_kw=None):
 
         def step(nthreads, count_flops=False):
             raw = (2 * rng.random((n, 3)) - 1).astype(np.float32)
-            pyoracle.abb_step(m, sp, boxes, tp, n, 0, bufs, raw, nthreads=nthreads, count_flops=count_flops)
+            with pyoracle.scene_extras(hulls=cm.hulls, flags=flags):
+                pyoracle.abb_step(m, sp, boxes, tp, n, 0, bufs, raw, nthreads=nthreads, count_flops=count_flops)
         return step
     from shifu_amd.a1_task import a1_task_params, height_points
     from shifu_amd.gym.a1_fused import default_terrain_cfg
@@ -134,12 +136,14 @@ def oracle_workload(workload: str, n: int, seed: int = 0, solver_kw=None):
     return step
 
 
-def count_flops(workload: str, n: int = 64, warm: int = 40, steps: int = 20, solver_kw=None) -> float:
+def count_flops(workload: str, n: int = 64, warm: int = 40, steps: int = 20, solver_kw=None, **scene) -> float:
     """Floating-point operations per env-step of the algorithm (add/sub/mul/div/sqrt = 1, fma = 2), counted by running
     the oracle compiled with a counting real type (oracle/flopcount.cpp) on `n` envs in the workload's steady state
     (robots standing / stumbling on the terrain with random actions, resets included)."""
     from oracle import pyoracle
-    step = oracle_workload(workload, n, seed=1, solver_kw=solver_kw)
+    if scene.get("link_shapes") == "hull":
+        raise RuntimeError("the counting build has no hull entry points")
+    step = oracle_workload(workload, n, seed=1, solver_kw=solver_kw, **scene)
     for _ in range(warm):
         step(1)
     L = pyoracle.flop_lib()
@@ -168,13 +172,13 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(workload: str, seconds_budget: float = 16.0, solver_kw=None):
+def cpu_baseline(workload: str, seconds_budget: float = 16.0, solver_kw=None, **scene):
     """The oracle's fused env step on host cores.  Deterministic thread counts: one thread, and every core this process
     may use (OpenMP over envs, 4096 envs so that each thread has tens of envs per step).  Bounded sample."""
     avail = usable_cores()
 
     def timed(n, threads, budget):
-        step = oracle_workload(workload, n, solver_kw=solver_kw)
+        step = oracle_workload(workload, n, solver_kw=solver_kw, **scene)
         for _ in range(3):
             step(threads)          # thread start-up, page faults
         k, t0 = 0, time.perf_counter()
@@ -194,7 +198,7 @@ def cpu_baseline(workload: str, seconds_budget: float = 16.0, solver_kw=None):
     vall, kall = tried[cores]
     what = "ABB push-box" if workload == "abb" else f"A1 {workload}"
     try:                          # the same oracle, built with a counting real type: flops per env-step of the algorithm
-        flops, flops_src = count_flops(workload, solver_kw=solver_kw), "counted in the cpu_baseline leg: oracle/flopcount.cpp (add/sub/mul/div/sqrt = 1, fma = 2)"
+        flops, flops_src = count_flops(workload, solver_kw=solver_kw, **scene), "counted in the cpu_baseline leg: oracle/flopcount.cpp (add/sub/mul/div/sqrt = 1, fma = 2)"
     except Exception as e:        # the counting build needs g++ on the box
         flops, flops_src = None, f"unavailable: {e}"
     return {"value": vall, "flops_per_env_step": flops, "flops_source": flops_src, "unit": "env-steps/s", "cores": cores, "kind": "port", "value_1thread": v1,
@@ -249,6 +253,10 @@ def main():
     ap.add_argument("--link-contacts", action="store_true",
                     help="abb workload: the arm's links (box stand-ins for their mesh colliders) and the rod also collide with the "
                          "table, the cube and the goal pad (SURVEY 8f f3, ShfModel.link_collide) -- the default for this workload since round 4 (the flag is kept for old command lines)")
+    ap.add_argument("--link-shapes", choices=["box", "hull"], default="box",
+                    help="abb workload: the arm's links as the bounding boxes of their mesh colliders (default: the kernels compiled for this scene) or "
+                         "as the convex hulls of the reference's collision meshes, reduced to <= 32 vertices (abb_rod_isaac.urdf:38-113), through the "
+                         "convex narrow phase with the clipped face manifold on (csrc/shf_hull.h; run-time-shaped kernels)")
     ap.add_argument("--graph", action="store_true", help="(experiments: slower, and back-to-back graph replays are not trustworthy on this stack, profiles/r02_mlp_probe.md) replay the vec-step from a captured hipGraph instead of launching it "
                     "eagerly (measured slower on ROCm 7.2: 84.7 vs 73.9 us per vec-step, profiles/r02_bench_*.json)")
     ap.add_argument("--decimation", type=int, default=4, help="(experiments only) control.decimation")
@@ -287,7 +295,7 @@ def main():
     if use_dist:
         init_ranks(dev, backend)       # finite timeout: a rank that never arrives fails the job instead of hanging it
 
-    solver_given = args.solver is not None or args.mapping is not None or args.group is not None
+    solver_given = args.solver is not None or args.mapping is not None or args.group is not None or args.link_shapes != "box"
     abb = args.workload == "abb"
     if abb:
         if args.link_contacts and (args.no_link_contacts or args.mapping == "chain"):
@@ -300,13 +308,16 @@ def main():
         else:
             mapping = args.mapping or ("split" if (args.group or 16) == 16 else ("chain" if (not args.link_contacts and (args.group or 16) == 32) else "body"))
             group = args.group or 16
+            if args.link_shapes == "hull":
+                mapping = "body"          # the convex narrow phase lives in the run-time-shaped kernels
     else:    # the fused A1 env's own default: the chain-per-lane kernel at 32 lanes when there is no self-collision
         mapping = args.mapping or ("chain" if ((args.group or 32) == 32 or ((args.group or 32) == 16 and not args.self_collision)) else "body")
         group = args.group or 32
     if abb:
         from shifu_amd.gym.abb_fused import FusedAbbEnv
         env = FusedAbbEnv(num_envs=args.envs, device=dev, seed=42, rank=rank, world_size=world, group=group,
-                          link_contacts=args.link_contacts, mapping=mapping, **({} if args.solver is None else {"solver": args.solver}))
+                          link_contacts=args.link_contacts, mapping=mapping, link_shapes=args.link_shapes,
+                          **({} if args.solver is None else {"solver": args.solver}))
         args.solver, group, mapping = env.solver, env.sim.group, env.mapping
         stats_t, count_t, kernel = _abi.ABB_STATS, _abi.ABB_RESET_COUNT, "k_abb_step"
         substeps = 6
@@ -502,7 +513,7 @@ def main():
                                    f"(dt {'20' if abb else '5'} ms), resets on, contact solver: "
                                    + (f"velocity-level PGS {args.pos_iters} + {args.vel_iters} iterations (the reference's physx settings, env_config.py:50-58)" if args.solver == "pgs"
                                       else "compliant spring-damper law (rounds 1-4)")
-                                   + ((", link contacts ON (arm links + rod vs table / cube / goal pad)" if args.link_contacts else
+                                   + (((", link contacts ON (arm links as the reduced convex hulls of their collision meshes + rod vs table / cube / goal pad; clipped face manifolds on)" if args.link_shapes == "hull" else ", link contacts ON (arm links + rod vs table / cube / goal pad)") if args.link_contacts else
                                        ", arm collider: the rod against the cube (link contacts OFF, see --link-contacts)") if abb else (", self-collision ON (capsule pairs, the reference's collision filter 0)" if args.self_collision
                                                       else ", self-collision OFF (the reference has it on: units.py:68; see --self-collision)")),
                        "envs_per_gpu": N, "total_envs": total_envs, "substeps_per_env_step": substeps,
@@ -542,7 +553,7 @@ def main():
             # W, same clock, so that one line carries both (a fresh env; the main measurement above is already taken)
             other = "compliant" if args.solver == "pgs" else "pgs"
             if abb:
-                env2 = FusedAbbEnv(num_envs=args.envs, device=dev, seed=42, link_contacts=args.link_contacts, solver=other)
+                env2 = FusedAbbEnv(num_envs=args.envs, device=dev, seed=42, link_contacts=args.link_contacts, solver=other, link_shapes=args.link_shapes)
             else:
                 env2 = FusedA1Env(num_envs=args.envs, device=dev, terrain={"terrain": "heightfield", "flat": "flat", "trimesh": "trimesh"}[args.workload],
                                   seed=42, decimation=args.decimation, extra_substep=not args.no_extra_substep,
@@ -562,7 +573,8 @@ def main():
                                    "note": "the same workload under the solver that is not the default, timed the same way (host clock, K steps after W "
                                            "warm-up steps); compliant = the spring-damper law of rounds 1-4 (opt-in: --solver compliant)"}
         if not args.no_cpu_baseline and world == 1:
-            cb = out["cpu_baseline"] = cpu_baseline(args.workload, solver_kw={"solver": args.solver, "pos_iters": args.pos_iters, "vel_iters": args.vel_iters})     # the only leg that touches oracle/
+            scene_kw = {"link_contacts": bool(args.link_contacts), "link_shapes": args.link_shapes} if abb else {}
+            cb = out["cpu_baseline"] = cpu_baseline(args.workload, solver_kw={"solver": args.solver, "pos_iters": args.pos_iters, "vel_iters": args.vel_iters}, **scene_kw)     # the only leg that touches oracle/
             f_alg = cb["flops_per_env_step"]
             secondary.update({"flops_alg_per_env_step": f_alg, "flops_source": cb["flops_source"]})
             if f_alg is not None:
