@@ -433,6 +433,18 @@ def main():
         torch.cuda.synchronize()
         kern_ms = sum(a.elapsed_time(b) for a, b in events) / args.steps
 
+    # candidate constraints per env and sub-step BEFORE the max_contacts cap (SHF_T_CONTACT_HIST), from a third, untimed pass of
+    # up to 100 steps with the histogram bound (binding it costs the kernel one read-modify-write per env and sub-step: kept out of
+    # the timed region and of the kernel_ms pass)
+    cand_hist = None
+    if args.solver == "pgs" and graph is None:
+        ht = env.sim.bind_contact_hist(True)
+        for i in range(min(args.steps, 100)):
+            eager_step()
+        torch.cuda.synchronize()
+        cand_hist = ht[:, :-1].sum(0).cpu().numpy().astype(np.float64)
+        env.sim.bind_contact_hist(False)
+
     # every rank's own elapsed time: the MAX is the job's time (the contract), MIN / MAX together show the spread
     rank_elapsed = elapsed
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -525,6 +537,11 @@ def main():
                        "max_contacts": (int(env.sim_params.max_contacts) or 8) if args.solver == "pgs" else None,
                        "dropped_constraints_per_env_step": None if dropped0 is None else (dropped1 - dropped0) / float(N * args.steps),
                        "envs_ever_dropping_frac": None if envs_dropping is None else envs_dropping / float(N),
+                       # share of (env, sub-step) pairs that offered k candidate constraints to the solve, k = 0 .. 24, last bin: more
+                       # (rank 0, an untimed pass with SHF_T_CONTACT_HIST bound); mean; share above the cap
+                       "candidates_per_substep_hist": None if cand_hist is None else [round(float(x), 5) for x in cand_hist / max(cand_hist.sum(), 1.0)],
+                       "candidates_per_substep_mean": None if cand_hist is None else float((cand_hist * np.arange(len(cand_hist))).sum() / max(cand_hist.sum(), 1.0)),
+                       "substeps_above_cap_frac": None if cand_hist is None else float(cand_hist[((int(env.sim_params.max_contacts) or 8) + 1):].sum() / max(cand_hist.sum(), 1.0)),
                        "gathers_in_timed_region": gathers["timed"], "gathers_in_warmup": gathers["warmup"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

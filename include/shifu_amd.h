@@ -339,8 +339,13 @@ enum {
                           * Read once per launch, in the inertia phase; unbound = 1 everywhere.  Bodies welded to their
                           * parent carry no mass of their own here (ShfModel.mass is 0 for them): their factor is unused. */
   SHF_T_HULLS = 19,      /* sizeof(ShfHullSet) bytes, device copy of shf_sim_set_hulls' argument (needed when ShfModel.nhull > 0) */
-  SHF_T_COUNT = 20
+  SHF_T_CONTACT_HIST = 20, /* (N, SHF_CONTACT_HIST_BINS + 1) i32, optional binding (SHF_SOLVER_PGS): per env, how many sub-steps offered k
+                          * candidate constraints to the solve, BEFORE the max_contacts cap -- column k for k < BINS - 1, column BINS - 1
+                          * for more; the LAST column is the env's drop counter: while this tensor is bound the kernels count dropped
+                          * contacts here and leave SHF_T_DROPPED alone (one more read-modify-write per env and sub-step; unbound: none) */
+  SHF_T_COUNT = 21
 };
+#define SHF_CONTACT_HIST_BINS 26
 
 /* refresh masks: gym.refresh_*_tensor (isaac_gym.py:139-154) */
 enum {

@@ -16,6 +16,7 @@ MAX_LINK_CONTACTS = 16
 MAX_HARD_CONTACTS = 16
 MAX_HULLS, HULL_MAX_VERTS, HULL_MAX_FACES, HULL_MAX_EDGES, HULL_MAX_FACE_VERTS, HULL_MAX_LOOP = 8, 32, 40, 64, 8, 160
 SCENE_FACE_MANIFOLD = 1
+CONTACT_HIST_BINS = 26
 SOLVER_COMPLIANT, SOLVER_PGS = 0, 1
 
 JOINT_ROOT, JOINT_REVOLUTE, JOINT_PRISMATIC, JOINT_WELD = 0, 1, 2, 3
@@ -115,7 +116,7 @@ class ShfAbbTaskParams(C.Structure):
 
 # tensor ids (shf_sim_*)
 T_DOF_STATE, T_ROOT_STATE, T_BODY_STATE, T_CONTACT, T_JACOBIAN, T_SIM_DOF, T_SIM_ROOT, T_EFFORT, \
-    T_POS_TARGET, T_VEL_TARGET, T_BODY_FORCE, T_FRICTION, T_HEIGHTS, T_MODEL, T_SIM_CONTACT, T_SCENE, T_DROPPED, T_BODY_FORCE_POS, T_BODY_MASS_SCALE, T_HULLS, T_COUNT = range(21)
+    T_POS_TARGET, T_VEL_TARGET, T_BODY_FORCE, T_FRICTION, T_HEIGHTS, T_MODEL, T_SIM_CONTACT, T_SCENE, T_DROPPED, T_BODY_FORCE_POS, T_BODY_MASS_SCALE, T_HULLS, T_CONTACT_HIST, T_COUNT = range(22)
 
 REFRESH_DOF, REFRESH_ROOT, REFRESH_BODY, REFRESH_CONTACT, REFRESH_JACOBIAN, REFRESH_ALL = 1, 2, 4, 8, 16, 31
 

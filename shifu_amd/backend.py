@@ -50,6 +50,10 @@ def set_solver(p: _abi.ShfSimParams, solver: str = "pgs", **kw) -> _abi.ShfSimPa
         p.solver = _abi.SOLVER_PGS
         p.pos_iters, p.vel_iters = kw.get("pos_iters", 8), kw.get("vel_iters", 1)
         p.max_contacts = kw.get("max_contacts", 8)
+        # (fail here, not at the first step: the chain-mapped A1 kernels hold up to MAX_HARD_CONTACTS = 16 constraints per env, the
+        # run-time-shaped kernels of other scenes 8 -- those refuse more at launch, shf_sim_step / shf_abb_step)
+        if not (1 <= p.pos_iters) or p.vel_iters < 0 or not (0 <= p.max_contacts <= _abi.MAX_HARD_CONTACTS):
+            raise ValueError(f"set_solver: pos_iters >= 1, vel_iters >= 0 and 0 <= max_contacts <= {_abi.MAX_HARD_CONTACTS} (0 reads as 8)")
         p.rest_offset = kw.get("rest_offset", 0.0)
         p.bounce_threshold = kw.get("bounce_threshold", 0.5)
         p.restitution = kw.get("restitution", 0.0)
@@ -197,7 +201,7 @@ class Sim:
         elif group != 64:
             check(lib().shf_sim_set_group(self._h, group))
         for tid in range(_abi.T_COUNT):
-            if tid == _abi.T_BODY_MASS_SCALE:        # optional: bound by set_body_mass_scale()
+            if tid in (_abi.T_BODY_MASS_SCALE, _abi.T_CONTACT_HIST):        # optional: bound by set_body_mass_scale() / bind_contact_hist()
                 continue
             if tid == _abi.T_HULLS:                  # only for an articulation with convex hulls (set_hulls)
                 if getattr(self, "hulls", None) is not None and self.model.nhull > 0:
@@ -223,6 +227,19 @@ class Sim:
             if tid == _abi.T_FRICTION:
                 t.fill_(1.0)
             self.bind(tid, t)
+
+    def bind_contact_hist(self, on: bool = True):
+        """SHF_T_CONTACT_HIST (velocity-level solve): per env, how many sub-steps offered k candidate constraints before the
+        max_contacts cap -- (num_envs, CONTACT_HIST_BINS + 1) int32 (last column: the env's drop counter, which
+        T_DROPPED does not receive meanwhile), accumulated by the step kernels while bound.  Returns the tensor
+        (None after unbinding).  Bind before capturing a step into a hipGraph."""
+        if not on:
+            check(lib().shf_sim_bind(self._h, _abi.T_CONTACT_HIST, None))
+            self.tensors.pop(_abi.T_CONTACT_HIST, None)
+            return None
+        t = torch.zeros(self.num_envs, _abi.CONTACT_HIST_BINS + 1, dtype=torch.int32, device=self.device)   # last column: the drop counters
+        self.bind(_abi.T_CONTACT_HIST, t)
+        return t
 
     def set_body_mass_scale(self, scale) -> torch.Tensor:
         """Per-env factors on the mass and inertia tensor of each body of the articulation (centre of mass unchanged):
@@ -396,7 +413,8 @@ class A1Task:
         g, warped = self.sim.group, bool(self.sim.terrain.warped)
         mdl = self.sim.model
         if self.sim.params.solver == _abi.SOLVER_PGS:
-            return f"_Z14k_a1_chain_pgsILb{int(warped)}ELb{int(bool(mdl.self_collide and mdl.npair > 0))}EE"
+            k16 = int(self.sim.params.max_contacts) > 8      # up to 16 constraints per env: the packed-response-matrix kernel
+            return f"{'_Z16k_a1_chain_pgs16' if k16 else '_Z14k_a1_chain_pgs'}ILb{int(warped)}ELb{int(bool(mdl.self_collide and mdl.npair > 0))}EE"
         if getattr(self.sim, "mapping", "body") == "chain":
             return f"_Z10k_a1_chainILi{g}ELb{int(warped)}ELb{int(bool(mdl.self_collide and mdl.npair > 0))}EE"
         a1 = mdl.nb == 17 and mdl.nd == 12 and mdl.np == 76

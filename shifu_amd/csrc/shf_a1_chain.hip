@@ -11,17 +11,24 @@ __global__ __launch_bounds__(256, (G == 32 ? 2 : 1)) void k_a1_chain(A1Args A) {
 // the same step under the velocity-level contact solve (ShfSimParams.solver == SHF_SOLVER_PGS; csrc/shf_chain_hard.h)
 template <bool TW, bool SELF>
 __global__ __launch_bounds__(256, 2) void k_a1_chain_pgs(A1Args A) { a1_chain_step_body<32, A1Chain, TW, SELF, true>(A); }
-const void* shf_a1_chain_pgs_kernel(bool warped, bool self) {
+// ... holding up to 16 constraints per env (ShfSimParams.max_contacts > 8): the response matrix's upper triangle, packed
+template <bool TW, bool SELF>
+__global__ __launch_bounds__(256, 2) void k_a1_chain_pgs16(A1Args A) { a1_chain_step_body<32, A1Chain, TW, SELF, true, 16>(A); }
+const void* shf_a1_chain_pgs_kernel(bool warped, bool self, bool k16) {
+  if (k16) {
+    if (self) return warped ? reinterpret_cast<const void*>(k_a1_chain_pgs16<true, true>) : reinterpret_cast<const void*>(k_a1_chain_pgs16<false, true>);
+    return warped ? reinterpret_cast<const void*>(k_a1_chain_pgs16<true, false>) : reinterpret_cast<const void*>(k_a1_chain_pgs16<false, false>);
+  }
   if (self) return warped ? reinterpret_cast<const void*>(k_a1_chain_pgs<true, true>) : reinterpret_cast<const void*>(k_a1_chain_pgs<false, true>);
   return warped ? reinterpret_cast<const void*>(k_a1_chain_pgs<true, false>) : reinterpret_cast<const void*>(k_a1_chain_pgs<false, false>);
 }
-int shf_a1_chain_pgs_max_contacts(void) { return HCK; }
+int shf_a1_chain_pgs_max_contacts(void) { return 16; }
 
 // gym.simulate (examples/a1_conditional/a1_conditional.py:69, shifu/gym/isaac_gym.py:140) of the hook path under the
 // velocity-level solve, for an A1-shaped articulation on its own (no box actors): one chain_substep_hard per call.
 // Forces at the centres of mass.
-template <bool TW, bool SELF>
-__global__ __launch_bounds__(256, 2) void k_sim_step_chain_pgs(SimArgs A) {
+template <bool TW, bool SELF, int KC>
+DEV void sim_step_chain_pgs_body(const SimArgs& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   typedef A1Chain CD;
   constexpr int G = 32, nb = CD::NB, nd = CD::ND, NR = (CD::NEV + G - 1) / G;
@@ -39,7 +46,7 @@ __global__ __launch_bounds__(256, 2) void k_sim_step_chain_pgs(SimArgs A) {
   GROUP_SYNC();
   StepCtx C;
   C.m = m; C.sp = A.sp; C.terr.t = A.terr; C.terr.h = A.heights; C.scene = nullptr;
-  C.dropped = A.dropped ? A.dropped + e : nullptr;
+  C.dropped = env_dropped(A.dropped, A.sp, e);
   C.mscale = A.mscale ? A.mscale + (size_t)e * nb : nullptr;
   const float mu = A.friction ? A.friction[e] : 1.0f;
   const int dl = l < nd ? l : 0;
@@ -48,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void k_sim_step_chain_pgs(SimArgs A) {
   ChainPoints<NR> LP;
   chain_points_load<G>(m, CD::NEV, l, C.sp.contact_offset + C.sp.rest_offset, LP);
   const RowLane RL = row_lane_load<CD>(l);
-  chain_substep_hard<G, CD, TW, SELF>(C, L, l, X, LP, RL, A.body_force ? A.body_force + (size_t)e * nb * 3 : nullptr, mu, L.xch);
+  chain_substep_hard<G, CD, TW, SELF, KC>(C, L, l, X, LP, RL, A.body_force ? A.body_force + (size_t)e * nb * 3 : nullptr, mu, L.xch);
   if (l < nd) {
     A.dof[((size_t)e * nd + l) * 2] = X.q;
     A.dof[((size_t)e * nd + l) * 2 + 1] = X.qd;
@@ -56,7 +63,15 @@ __global__ __launch_bounds__(256, 2) void k_sim_step_chain_pgs(SimArgs A) {
   if (l < 13) A.root[(size_t)e * 13 + l] = L.root[l];
   for (int i = l; i < 3 * nb; i += G) A.contact[(size_t)e * nb * 3 + i] = L.xch[i];
 }
-const void* shf_sim_step_chain_pgs_kernel(bool warped, bool self) {
+template <bool TW, bool SELF>
+__global__ __launch_bounds__(256, 2) void k_sim_step_chain_pgs(SimArgs A) { sim_step_chain_pgs_body<TW, SELF, 8>(A); }
+template <bool TW, bool SELF>
+__global__ __launch_bounds__(256, 2) void k_sim_step_chain_pgs16(SimArgs A) { sim_step_chain_pgs_body<TW, SELF, 16>(A); }
+const void* shf_sim_step_chain_pgs_kernel(bool warped, bool self, bool k16) {
+  if (k16) {
+    if (self) return warped ? reinterpret_cast<const void*>(k_sim_step_chain_pgs16<true, true>) : reinterpret_cast<const void*>(k_sim_step_chain_pgs16<false, true>);
+    return warped ? reinterpret_cast<const void*>(k_sim_step_chain_pgs16<true, false>) : reinterpret_cast<const void*>(k_sim_step_chain_pgs16<false, false>);
+  }
   if (self) return warped ? reinterpret_cast<const void*>(k_sim_step_chain_pgs<true, true>) : reinterpret_cast<const void*>(k_sim_step_chain_pgs<false, true>);
   return warped ? reinterpret_cast<const void*>(k_sim_step_chain_pgs<true, false>) : reinterpret_cast<const void*>(k_sim_step_chain_pgs<false, false>);
 }

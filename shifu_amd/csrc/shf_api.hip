@@ -64,9 +64,9 @@ struct ShfA1Task {
 bool shf_a1_chain_matches(const ShfModel& m);
 size_t shf_a1_chain_lds_bytes(int G, int nobs, bool self);
 const void* shf_a1_chain_kernel(int G, bool warped, bool self);
-const void* shf_a1_chain_pgs_kernel(bool warped, bool self);
+const void* shf_a1_chain_pgs_kernel(bool warped, bool self, bool k16);
 int shf_a1_chain_pgs_max_contacts(void);
-const void* shf_sim_step_chain_pgs_kernel(bool warped, bool self);
+const void* shf_sim_step_chain_pgs_kernel(bool warped, bool self, bool k16);
 size_t shf_sim_step_chain_pgs_lds_bytes(bool self);
 #ifdef SHF_PHASE_CLOCK
 int shf_a1_chain_phase_cycles(unsigned long long* out, int n, int reset);
@@ -324,6 +324,7 @@ extern "C" int shf_sim_layout(const ShfSim* sim, int32_t id, int64_t shape[4], i
     case SHF_T_MODEL: *ndim = 1; shape[0] = sizeof(ShfModel); *dtype = 3; break;
     case SHF_T_SCENE: *ndim = 1; shape[0] = sizeof(ShfScene); *dtype = 3; break;
     case SHF_T_HULLS: *ndim = 1; shape[0] = sizeof(ShfHullSet); *dtype = 3; break;
+    case SHF_T_CONTACT_HIST: *ndim = 2; shape[0] = N; shape[1] = SHF_CONTACT_HIST_BINS + 1; *dtype = 1; break;
     default: return fail("shf_sim_layout: unknown tensor id");
   }
   return 0;
@@ -379,6 +380,10 @@ static SimArgs sim_args(const ShfSim* s, bool internal) {
   A.contact = (float*)s->t[internal ? SHF_T_SIM_CONTACT : SHF_T_CONTACT];
   A.dropped = (int32_t*)s->t[SHF_T_DROPPED];
   A.hulls = (s->model.nhull > 0 && s->model.link_collide != 0) ? (const ShfHullSet*)s->t[SHF_T_HULLS] : nullptr;
+  if (s->t[SHF_T_CONTACT_HIST]) {       // the histogram rows carry the drop counters while bound (csrc/shf_task.h: SHF_HIST_FLAG)
+    A.dropped = (int32_t*)s->t[SHF_T_CONTACT_HIST];
+    A.sp.max_contacts = (A.sp.max_contacts & 0xff) | SHF_HIST_FLAG;
+  }
   return A;
 }
 
@@ -467,11 +472,12 @@ extern "C" int shf_sim_step(ShfSim* sim, void* stream) {
   }
   if (sim->sp.solver == SHF_SOLVER_PGS) {
     // the velocity-level contact solve: built for A1-shaped articulations on their own (csrc/shf_chain_hard.h)
-    if (sim->sp.max_contacts > shf_a1_chain_pgs_max_contacts() || sim->sp.pos_iters < 1) return fail("shf_sim_step: SHF_SOLVER_PGS needs pos_iters >= 1 and max_contacts <= 8");
+    if (sim->sp.max_contacts > shf_a1_chain_pgs_max_contacts() || sim->sp.pos_iters < 1) return fail("shf_sim_step: SHF_SOLVER_PGS needs pos_iters >= 1 and max_contacts <= 16");
     sim->force_armed = false;
     sim->force_at_pos = false;
     if (sim->nboxes == 0 && shf_a1_chain_matches(sim->model) && !A.body_force_pos)
-      return launch_ptr(shf_sim_step_chain_pgs_kernel(sim->terr.warped != 0, sim_self(sim)), dim3((sim->n + 7) / 8), dim3(256), shf_sim_step_chain_pgs_lds_bytes(sim_self(sim)), stream, A);
+      return launch_ptr(shf_sim_step_chain_pgs_kernel(sim->terr.warped != 0, sim_self(sim), sim->sp.max_contacts > HCK), dim3((sim->n + 7) / 8), dim3(256), shf_sim_step_chain_pgs_lds_bytes(sim_self(sim)), stream, A);
+    if (sim->sp.max_contacts > HCK) return fail("shf_sim_step: more than 8 constraints per env (ShfSimParams.max_contacts) are held by the chain-mapped A1 kernels only");
     // any other articulation / a scene with box actors: the body-per-lane sub-step with the generic solve (csrc/shf_hard.h), 32 lanes per env
     if (sim->model.nlevels > HG_LEV) return fail("shf_sim_step: SHF_SOLVER_PGS walks trees of at most 8 levels");
     if (sim->model.nb + sim->nboxes > 32) return fail("shf_sim_step: SHF_SOLVER_PGS runs at 32 lanes per env: at most 32 bodies + box actors");
@@ -758,9 +764,9 @@ static int a1_step_launch(ShfA1Task* task, const float* raw_actions_dev, void* s
     // the velocity-level contact solve: the chain mapping at two envs per wavefront (csrc/shf_chain_hard.h)
     if (s->mapping != SHF_MAP_CHAIN || s->chain_group != 32 || !shf_a1_chain_matches(s->model))
       return fail("shf_a1_step: ShfSimParams.solver = SHF_SOLVER_PGS runs on the chain mapping at 32 lanes per env (shf_sim_set_mapping)");
-    if (s->sp.max_contacts > shf_a1_chain_pgs_max_contacts()) return fail("shf_a1_step: the fused A1 step's solve holds at most 8 constraints per env (ShfSimParams.max_contacts)");
+    if (s->sp.max_contacts > shf_a1_chain_pgs_max_contacts()) return fail("shf_a1_step: the fused A1 step's solve holds at most 16 constraints per env (ShfSimParams.max_contacts)");
     if (s->sp.pos_iters < 1) return fail("shf_a1_step: ShfSimParams.pos_iters must be >= 1 with SHF_SOLVER_PGS");
-    return launch_ptr(shf_a1_chain_pgs_kernel(s->terr.warped != 0, sim_self(s)), dim3((s->n + 7) / 8), block, shf_a1_chain_lds_bytes(32, nobs, sim_self(s)), stream, A);
+    return launch_ptr(shf_a1_chain_pgs_kernel(s->terr.warped != 0, sim_self(s), s->sp.max_contacts > HCK), dim3((s->n + 7) / 8), block, shf_a1_chain_lds_bytes(32, nobs, sim_self(s)), stream, A);
   }
   if (s->mapping == SHF_MAP_CHAIN) {
     if (!shf_a1_chain_matches(s->model)) return fail("shf_a1_step: the articulation does not fit the chain mapping");

@@ -807,11 +807,12 @@ DEV void chain_body_states(const ShfModel* m, const ChainLds& L, int l, const Do
 
 // ShifuVecEnv.step for the A1 task (env.py:85-106) on the chain mapping; the task glue after the physics is shared
 // with the body-mapped kernel (a1_post_step, shf_task.h).
-template <int G, class CD, bool TW, bool SELF>
+template <int G, class CD, bool TW, bool SELF, int KC>
 DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane& X, const ChainPoints<(CD::NEV + G - 1) / G>& P,
                             const RowLane& RL, const float* fext, float mu_shape, float* contact_out);   // shf_chain_hard.h
 // HARD: the velocity-level contact solve (ShfSimParams.solver == SHF_SOLVER_PGS, csrc/shf_chain_hard.h)
-template <int G, class CD, bool TW, bool SELF = false, bool HARD = false>
+// KC: constraints the solve holds per env (8: response matrix in full inside the contact-slot region; 16: its upper triangle, packed)
+template <int G, class CD, bool TW, bool SELF = false, bool HARD = false, int KC = 8>
 DEV void a1_chain_step_body(const A1Args& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NLK = CD::NLK, nb = CD::NB, nd = CD::ND, NR = (CD::NEV + G - 1) / G;
@@ -874,7 +875,7 @@ DEV void a1_chain_step_body(const A1Args& A) {
 
   StepCtx C;
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = nullptr;
-  if constexpr (HARD) C.dropped = A.S.dropped ? A.S.dropped + e : nullptr;
+  if constexpr (HARD) C.dropped = env_dropped(A.S.dropped, A.S.sp, e);
   C.mscale = A.S.mscale ? A.S.mscale + (size_t)e * nb : nullptr;
   const float mu = A.S.friction[e];
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
@@ -896,7 +897,7 @@ DEV void a1_chain_step_body(const A1Args& A) {
       X.tau = rclampf(t, -lim_, lim_);
     }
     if constexpr (HARD)
-      chain_substep_hard<G, CD, TW, SELF>(C, L, l, X, LP, RL, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
+      chain_substep_hard<G, CD, TW, SELF, KC>(C, L, l, X, LP, RL, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
                                     (it == nsub - 1) ? L.xch : nullptr);
     else
       chain_substep<G, CD, TW, SELF>(C, L, l, X, LP, mine, RL, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,

@@ -23,12 +23,36 @@
 #include "shf_chain.h"
 
 #define UF_STRIDE 8     /* U[6] invD . per link */
-template <class CD>
+// LDS of the solve, KC = the constraints it holds (ShfSimParams.max_contacts <= KC):
+//   KC = 8  everything inside the contact-slot region: constraint records | W, KC x KC blocks of 9 words | U, 1/D per link
+//   KC = 16 W is symmetric (block (j, i) = block (i, j)^T: oracle hard_solve), so only its upper triangle is kept -- KC (KC + 1) / 2
+//           = 136 blocks, block (i, j), i <= j, at number j (j + 1) / 2 + i: the first NB0 behind the constraint records in the
+//           contact-slot region, the others over the pose / velocity-rate / exchange slots (contiguous: ChainLds), which are dead
+//           between the free outward pass and the impulse passes once the owners have read their points' velocities (H2a).  U, 1/D
+//           and the gap list of the selection sit where the first blocks of W will be written (dead by then).
+template <class CD, int KC>
 struct HardTail {
-  // (PHI: the candidates' gaps while the deepest are selected -- before W exists, in its place)
-  static constexpr int HC = 0, W = HCK * HC_STRIDE, UF = W + HCK * HCK * 9, PHI = W, NEVP = (CD::NEV + 3) & ~3, END = UF + CD::ND * UF_STRIDE;
-  static_assert(NEVP + SHF_MAX_SELF_CONTACTS <= HCK * HCK * 9, "the gaps fit the response matrix's place");
+  static constexpr int HC = 0, W = KC * HC_STRIDE, NEVP = (CD::NEV + 3) & ~3;
+  static constexpr bool PACKED = KC > 8;
+  static constexpr int NBLK = PACKED ? KC * (KC + 1) / 2 : KC * KC;
+  static constexpr int NB0 = PACKED ? (CD::NPC * PT_STRIDE - W) / 9 : NBLK;          // blocks of W in the contact-slot region
+  static constexpr int UF = PACKED ? W : W + KC * KC * 9, PHI = W, END = PACKED ? W + NB0 * 9 : UF + CD::ND * UF_STRIDE;
+  static constexpr int SPARE = CD::NB * POSE_STRIDE + ((CD::NB * 6 + 3) & ~3) + CD::ND * XCH_STRIDE;   // pose | acc | xch words
+  static_assert(NEVP + SHF_MAX_SELF_CONTACTS <= NB0 * 9 && CD::ND * UF_STRIDE <= NB0 * 9, "the gap list / U, 1/D fit the response matrix's place");
+  static_assert(!PACKED || (NBLK - NB0) * 9 <= SPARE, "the rest of the packed response matrix fits the pose / rate / exchange slots");
+  static_assert(KC <= 16, "owner lanes, 16-bit constraint masks");
 };
+// block number and address of W's block (i, j) as stored (PACKED: i <= j)
+template <class CD, int KC>
+DEV float* hard_wblock(const ChainLds& L, float* tail, int i, int j) {
+  typedef HardTail<CD, KC> T;
+  if constexpr (T::PACKED) {
+    const int b = ((j * (j + 1)) >> 1) + i;
+    return b < T::NB0 ? tail + T::W + b * 9 : L.pose + (b - T::NB0) * 9;
+  } else {
+    return tail + T::W + (j * KC + i) * 9;
+  }
+}
 
 DEV void mat3_inv_spd(const float* A, float* Ai) {
   const float c00 = fmaf(A[4], A[8], -(A[5] * A[7])), c01 = fmaf(A[5], A[6], -(A[3] * A[8])), c02 = fmaf(A[3], A[7], -(A[4] * A[6]));
@@ -58,7 +82,6 @@ struct HardResp { int cs, ks; float ub[CD::NLK], dv0[6]; };
 template <class CD>
 DEV void hard_impulse(const ChainLds& L, const float* tail, int bs, const float* r, const float* e, HardResp<CD>& q) {
   constexpr int NLK = CD::NLK;
-  typedef HardTail<CD> T;
   q.cs = bs > 0 ? (bs - 1) / (NLK + 1) : 0;
   q.ks = bs > 0 ? (bs - 1) % (NLK + 1) : -1;
   float p6[6], t[3];
@@ -85,7 +108,6 @@ DEV void hard_impulse(const ChainLds& L, const float* tail, int bs, const float*
 template <class CD>
 DEV void hard_velocity(const ChainLds& L, const float* tail, const HardResp<CD>& q, int bt, const float* r, float* vel) {
   constexpr int NLK = CD::NLK;
-  typedef HardTail<CD> T;
   if (bt < 0) { vel[0] = 0.0f; vel[1] = 0.0f; vel[2] = 0.0f; return; }
   const int ct = bt > 0 ? (bt - 1) / (NLK + 1) : 0, kt = bt > 0 ? (bt - 1) % (NLK + 1) : -1;
   float dv[6];
@@ -111,11 +133,11 @@ DEV void hard_velocity(const ChainLds& L, const float* tail, const HardResp<CD>&
 // impulse sets in one pass through the tree: q = 0 the impulses after the position iterations (HC_P), q = 1 after the
 // velocity iterations (HC_PV; NQ = 1: there are none) -- joint accelerations to dofb[.][2 + q], the root's to ac0[q]
 // (root lane).  Per set the operations of the oracle's hc_apply.
-template <class CD, int NQ>
+template <class CD, int NQ, int KC>
 DEV void chain_hard_apply(const ShfModel* m, const ChainLds& L, float* tail, int l, int K, float idt, bool isbody_h0, bool islink, bool isroot,
                           bool ischain, int ci, int lb, int myb, float (*ac0)[6]) {
   constexpr int NCH = CD::NCH, NLK = CD::NLK;
-  typedef HardTail<CD> T;
+  typedef HardTail<CD, KC> T;
   float pcr[NQ][6];
 #pragma unroll
   for (int q = 0; q < NQ; q++)
@@ -126,7 +148,7 @@ DEV void chain_hard_apply(const ShfModel* m, const ChainLds& L, float* tail, int
     // branch would serialise eight LDS round trips)
     unsigned mine_a = 0u, mine_b = 0u;
 #pragma unroll
-    for (int c = 0; c < HCK; c++) {
+    for (int c = 0; c < KC; c++) {
       const float* h = tail + T::HC + c * HC_STRIDE;
       const int ia = __float_as_int(h[HC_BODY]), ib = __float_as_int(h[HC_BODYB]);
       if (c < K && ia == myb) mine_a |= 1u << c;
@@ -240,14 +262,14 @@ DEV void chain_hard_apply(const ShfModel* m, const ChainLds& L, float* tail, int
 }
 
 // One gym.simulate() for one env under the velocity-level contact solve; lane roles as chain_substep at 32 lanes per env.
-template <int G, class CD, bool TW, bool SELF>
+template <int G, class CD, bool TW, bool SELF, int KC>
 DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane& X, const ChainPoints<(CD::NEV + G - 1) / G>& P,
                             const RowLane& RL, const float* fext, float mu_shape, float* contact_out) {
   static_assert(G == 32, "the velocity-level solve is written for two envs per wavefront");
   constexpr int NCH = CD::NCH, NLK = CD::NLK, NB = CD::NB, ND = CD::ND, NR = (CD::NEV + G - 1) / G;
-  typedef HardTail<CD> T;
+  typedef HardTail<CD, KC> T;
   static_assert(T::END <= CD::NPC * PT_STRIDE, "the solve's LDS fits the contact-slot region");
-  static_assert(3 * HCK <= G && ND < 16, "a lane per column of the response matrix");
+  static_assert((KC == 8 || KC == 16) && KC <= G / 2 + 8 && ND < 16, "owner lanes; a lane per column of the response matrix, in one or two passes");
   const ShfModel* m = C.m;
   const float dt = C.sp.dt, idt = 1.0f / dt;
   const float gon = (float)m->gravity_on;
@@ -361,7 +383,7 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
   // ---- P. sample points -> candidate constraints (gap from rest_offset inside the contact offset), evaluation-slot order
   const float rest = C.sp.rest_offset, offs = C.sp.contact_offset + rest;
   const float mu = 0.5f * (mu_shape + C.terr.t.friction);
-  const int kmax = C.sp.max_contacts > 0 ? (C.sp.max_contacts < HCK ? C.sp.max_contacts : HCK) : HCK;
+  const int kmax = hard_kmax_of(C.sp, KC);
   SlotBits act = {{0ull, 0ull}};
   int K;
   {
@@ -420,6 +442,7 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
     const float sph = scand ? sslot[PT_F] : 0.0f;
     const int npts = __popcll(act.w[0]) + __popcll(act.w[1]);
     int total = npts + nself;
+    contact_hist_count(C, l, total);
     unsigned smask = nself >= 32 ? ~0u : ((1u << nself) - 1u);      // selected self-contacts of this env
     if (__ballot(total > kmax) != 0ull) {
       // more candidates than the solve holds (somewhere in this wavefront): keep the kmax with the smallest gap, ties by
@@ -627,59 +650,11 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
   float ac0[2][6] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};   // the contacts' share of the root's acceleration: poses / velocities
   const int npos = C.sp.pos_iters > 0 ? C.sp.pos_iters : 0, nvel = C.sp.vel_iters > 0 ? C.sp.vel_iters : 0;
   if (__ballot(K > 0) != 0ull) {
-    // H1. column lanes: contact j = l / 3, axis l % 3
-    {
-      const int j = (l * 11) >> 5, ax = l - 3 * j;
-      const bool col = l < 3 * K;
-      const float* hj = tail + T::HC + (col ? j : 0) * HC_STRIDE;
-      const float rj[3] = {hj[HC_R], hj[HC_R + 1], hj[HC_R + 2]};
-      const int bsa = col ? __float_as_int(hj[HC_BODY]) : 0;
-      const int bsb = (SELF && col) ? __float_as_int(hj[HC_BODYB]) : -1;
-      const float* ej = hj + (ax == 0 ? HC_N : (ax == 1 ? HC_T1 : HC_T2));     // axis ax of contact j's frame
-      const float e[3] = {ej[0], ej[1], ej[2]};
-      HardResp<CD> qa, qb;
-      hard_impulse<CD>(L, tail, bsa, rj, e, qa);
-      if constexpr (SELF) {
-        if (__ballot(bsb >= 0) != 0ull) hard_impulse<CD>(L, tail, bsb >= 0 ? bsb : 0, rj, e, qb);
-      }
-      // (the targets' body ids first, all in flight at once: each iteration's link reads then do not wait behind its own record read)
-      int btas[HCK], btbs[HCK];
-#pragma unroll
-      for (int i = 0; i < HCK; i++) {
-        btas[i] = __float_as_int(tail[T::HC + i * HC_STRIDE + HC_BODY]);
-        btbs[i] = SELF ? __float_as_int(tail[T::HC + i * HC_STRIDE + HC_BODYB]) : -1;
-      }
-#pragma unroll
-      for (int i = 0; i < HCK; i++) {
-        if (__ballot(i < K) == 0ull) break;
-        if (!(col && i < K)) continue;
-        const float* hi = tail + T::HC + i * HC_STRIDE;
-        const float ri[3] = {hi[HC_R], hi[HC_R + 1], hi[HC_R + 2]};
-        const int bta = btas[i];
-        float aa[3], ab[3] = {0.0f, 0.0f, 0.0f}, ba[3] = {0.0f, 0.0f, 0.0f}, bb[3] = {0.0f, 0.0f, 0.0f};
-        hard_velocity<CD>(L, tail, qa, bta, ri, aa);
-        if constexpr (SELF) {
-          const int btb = btbs[i];
-          hard_velocity<CD>(L, tail, qa, btb, ri, ab);
-          if (bsb >= 0) {
-            hard_velocity<CD>(L, tail, qb, bta, ri, ba);
-            hard_velocity<CD>(L, tail, qb, btb, ri, bb);
-          }
-        }
-        float vw[3];
-#pragma unroll
-        for (int r = 0; r < 3; r++) vw[r] = (aa[r] - ab[r]) - (ba[r] - bb[r]);
-        float* Wb = tail + T::W + (j * HCK + i) * 9 + ax;   // block (i, j), column ax: the velocity in contact i's frame
-        Wb[0] = dot3(hi + HC_N, vw); Wb[3] = dot3(hi + HC_T1, vw); Wb[6] = dot3(hi + HC_T2, vw);
-      }
-    }
-    GROUP_SYNC();
-    PHASE_MARK(5);
-
-    // H2. owner lanes: free velocity (contact frame), targets, the regularised diagonal block and its inverses
+    // H2a. owner lanes: the contact's bodies' velocities at its point -- free velocity in the contact frame, targets.  (With the packed
+    // response matrix before the columns: the poses and velocity rates read here are overwritten by it; KC = 8 keeps round 5's order.)
     HardOwner O;
     const bool own = l < K;
-    {
+    auto owner_velocities = [&]() {
       const float* h = tail + T::HC + (own ? l : 0) * HC_STRIDE;
       const float r[3] = {h[HC_R], h[HC_R + 1], h[HC_R + 2]};
       const float n[3] = {h[HC_N], h[HC_N + 1], h[HC_N + 2]};
@@ -715,7 +690,70 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
       const float vn0 = dot3(n, vs);
       if (C.sp.restitution > 0.0f && vn0 < -C.sp.bounce_threshold) { tg = rmaxf(tg, -(C.sp.restitution * vn0)); tv = rmaxf(tv, -(C.sp.restitution * vn0)); }
       O.tgt = tg; O.tgt_v = tv;
-      float* Wd = tail + T::W + ((own ? l : 0) * HCK + (own ? l : 0)) * 9;
+    };
+    if constexpr (T::PACKED) owner_velocities();
+    if constexpr (T::PACKED) GROUP_SYNC();     // (every owner has read its poses and rates: their place may take blocks of W)
+    // H1. column lanes: column q = 3 j + axis of contact j's frame; the upper triangle of W (oracle: hard_solve, "columns"): block
+    // (i, j), i <= j -- block (j, i) is its transpose, written as such (KC = 8) or left to the readers (packed)
+#pragma unroll 1
+    for (int q0 = 0; q0 < 3 * KC; q0 += G) {
+      const int q = q0 + l;
+      if (__ballot(q < 3 * K) == 0ull) break;
+      const int j = (q * 43) >> 7, ax = q - 3 * j;
+      const bool col = q < 3 * K;
+      const float* hj = tail + T::HC + (col ? j : 0) * HC_STRIDE;
+      const float rj[3] = {hj[HC_R], hj[HC_R + 1], hj[HC_R + 2]};
+      const int bsa = col ? __float_as_int(hj[HC_BODY]) : 0;
+      const int bsb = (SELF && col) ? __float_as_int(hj[HC_BODYB]) : -1;
+      const float* ej = hj + (ax == 0 ? HC_N : (ax == 1 ? HC_T1 : HC_T2));     // axis ax of contact j's frame
+      const float e[3] = {ej[0], ej[1], ej[2]};
+      HardResp<CD> qa, qb;
+      hard_impulse<CD>(L, tail, bsa, rj, e, qa);
+      if constexpr (SELF) {
+        if (__ballot(bsb >= 0) != 0ull) hard_impulse<CD>(L, tail, bsb >= 0 ? bsb : 0, rj, e, qb);
+      }
+      // (the targets' body ids first, all in flight at once: each iteration's link reads then do not wait behind its own record read)
+      int btas[KC], btbs[KC];
+#pragma unroll
+      for (int i = 0; i < KC; i++) {
+        btas[i] = __float_as_int(tail[T::HC + i * HC_STRIDE + HC_BODY]);
+        btbs[i] = SELF ? __float_as_int(tail[T::HC + i * HC_STRIDE + HC_BODYB]) : -1;
+      }
+#pragma unroll
+      for (int i = 0; i < KC; i++) {
+        if (__ballot(i < K) == 0ull) break;
+        if (!(col && i <= j)) continue;     // the upper triangle: block (i, j), i <= j; block (j, i) is its transpose (oracle: hard_solve)
+        const float* hi = tail + T::HC + i * HC_STRIDE;
+        const float ri[3] = {hi[HC_R], hi[HC_R + 1], hi[HC_R + 2]};
+        const int bta = btas[i];
+        float aa[3], ab[3] = {0.0f, 0.0f, 0.0f}, ba[3] = {0.0f, 0.0f, 0.0f}, bb[3] = {0.0f, 0.0f, 0.0f};
+        hard_velocity<CD>(L, tail, qa, bta, ri, aa);
+        if constexpr (SELF) {
+          const int btb = btbs[i];
+          hard_velocity<CD>(L, tail, qa, btb, ri, ab);
+          if (bsb >= 0) {
+            hard_velocity<CD>(L, tail, qb, bta, ri, ba);
+            hard_velocity<CD>(L, tail, qb, btb, ri, bb);
+          }
+        }
+        float vw[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) vw[r] = (aa[r] - ab[r]) - (ba[r] - bb[r]);
+        float* Wb = hard_wblock<CD, KC>(L, tail, i, j) + ax;   // block (i, j), column ax: the velocity in contact i's frame
+        const float w0 = dot3(hi + HC_N, vw), w1 = dot3(hi + HC_T1, vw), w2 = dot3(hi + HC_T2, vw);
+        Wb[0] = w0; Wb[3] = w1; Wb[6] = w2;
+        if constexpr (!T::PACKED) {
+          if (i < j) { float* Wt = hard_wblock<CD, KC>(L, tail, j, i) + 3 * ax; Wt[0] = w0; Wt[1] = w1; Wt[2] = w2; }     // row ax of block (j, i)
+        }
+      }
+    }
+    GROUP_SYNC();
+    PHASE_MARK(5);
+
+    // H2b. owner lanes: the regularised diagonal block and its inverses
+    if constexpr (!T::PACKED) owner_velocities();
+    {
+      float* Wd = hard_wblock<CD, KC>(L, tail, own ? l : 0, own ? l : 0);
       float A[9];
 #pragma unroll
       for (int k = 0; k < 9; k++) A[k] = Wd[k];
@@ -739,55 +777,78 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
     // H3 / H4. position iterations -> poses; velocity iterations -> velocities
     int Kw = 0;      // the larger constraint count of the wavefront's envs (wave-uniform)
 #pragma unroll
-    for (int c = 0; c < HCK; c++)
+    for (int c = 0; c < KC; c++)
       if (__ballot(c < K) != 0ull) Kw = c + 1;
     const bool hi = lane0 != 0;
 #ifdef SHF_PHASE_CLOCK
-    if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_phase_cycles[38 + Kw], 1ull);     // histogram of the wavefronts' constraint counts
+    if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_phase_cycles[38 + (Kw < 8 ? Kw : 8)], 1ull);     // histogram of the wavefronts' constraint counts
 #endif
-    const float* Wcol = tail + T::W + (own ? l : 0) * 9;     // block (l, c) sits at Wcol + c * HCK * 9
+    const float* Wcol = tail + T::W + (own ? l : 0) * 9;     // (KC = 8) block (l, c) sits at Wcol + c * KC * 9
+    const int li = own ? l : 0;
+    // one visit of the sweep: contact c (oracle: hard_solve, sweeps)
+    auto visit = [&](int c, float tg) {
+      // an open, unloaded contact whose normal velocity keeps it open asks for nothing (oracle: the same test): when that
+      // is so for contact c of both envs of the wavefront the visit is skipped
+      const bool act = !(O.p[0] == 0.0f && O.p[1] == 0.0f && O.p[2] == 0.0f && !(O.u[0] < tg));
+      if (__ballot(l == c && c < K && act) == 0ull) return;
+      // this lane's block of column c: in flight while the update is computed
+      float Wb[9];
+      if constexpr (T::PACKED) {
+        // block (l, c) from the upper triangle: as stored when l <= c, else the transpose of block (c, l)
+        const bool tr = li > c;
+        const float* blk = hard_wblock<CD, KC>(L, tail, tr ? c : li, tr ? li : c);
+        float Ws[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) Ws[k] = blk[k];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int k = 0; k < 3; k++) Wb[3 * r + k] = tr ? Ws[3 * k + r] : Ws[3 * r + k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) Wb[k] = Wcol[c * KC * 9 + k];
+      }
+      // every owner lane computes its own update; lane c's is the one that counts
+      const float pn0 = O.p[0];
+      const float pn = rmaxf(fmaf(-(O.u[0] - tg), O.iwnn, pn0), 0.0f);
+      const float dn = pn - pn0;
+      const float ut1 = fmaf(dn, O.w10, O.u[1]), ut2 = fmaf(dn, O.w20, O.u[2]);
+      float ps1 = O.p[1] - fmaf(O.Ti[1], ut2, O.Ti[0] * ut1), ps2 = O.p[2] - fmaf(O.Ti[2], ut2, O.Ti[1] * ut1);
+      const float lim = O.mu * pn, lim2 = lim * lim;
+      if (fmaf(ps2, ps2, ps1 * ps1) > lim2) {
+        ps1 = fmaf(-O.rt, ut1, O.p[1]); ps2 = fmaf(-O.rt, ut2, O.p[2]);
+        const float nt2 = fmaf(ps2, ps2, ps1 * ps1);
+        const float sc1 = nt2 > lim2 ? lim * rsqrt_spec(nt2) : 1.0f;
+        ps1 *= sc1; ps2 *= sc1;
+      }
+      const bool commit = l == c && c < K && act;
+      float dp0 = commit ? dn : 0.0f, dp1 = commit ? ps1 - O.p[1] : 0.0f, dp2 = commit ? ps2 - O.p[2] : 0.0f;
+      if (commit) { O.p[0] = pn; O.p[1] = ps1; O.p[2] = ps2; }
+      // the change of contact c's impulse, from its owner lane (lane c of each env: wave lanes c and 32 + c) to every lane
+      {
+        const float a0 = hard_readlane(dp0, c), a1 = hard_readlane(dp1, c), a2 = hard_readlane(dp2, c);
+        const float b0 = hard_readlane(dp0, 32 + c), b1 = hard_readlane(dp1, 32 + c), b2 = hard_readlane(dp2, 32 + c);
+        dp0 = hi ? b0 : a0; dp1 = hi ? b1 : a1; dp2 = hi ? b2 : a2;
+      }
+      if (own && c < K) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) O.u[r] = fmaf(Wb[3 * r + 2], dp2, fmaf(Wb[3 * r + 1], dp1, fmaf(Wb[3 * r], dp0, O.u[r])));
+      }
+    };
 #pragma unroll 1
     for (int phase = 0; phase < 2; phase++) {
       const int sweeps = phase == 0 ? npos : nvel;
       const float tg = phase == 0 ? O.tgt : O.tgt_v;
 #pragma unroll 1
       for (int it = 0; it < sweeps; it++) {
+        if constexpr (T::PACKED) {
+#pragma unroll 1
+          for (int c = 0; c < Kw; c++) visit(c, tg);       // (a loop: sixteen unrolled visits would not fit the instruction cache)
+        } else {
 #pragma unroll
-        for (int c = 0; c < HCK; c++) {
-          if (c >= Kw) break;
-          // an open, unloaded contact whose normal velocity keeps it open asks for nothing (oracle: the same test): when that
-          // is so for contact c of both envs of the wavefront the visit is skipped
-          const bool act = !(O.p[0] == 0.0f && O.p[1] == 0.0f && O.p[2] == 0.0f && !(O.u[0] < tg));
-          if (__ballot(l == c && c < K && act) == 0ull) continue;
-          // this lane's block of column c: in flight while the update is computed
-          float Wb[9];
-#pragma unroll
-          for (int k = 0; k < 9; k++) Wb[k] = Wcol[c * HCK * 9 + k];
-          // every owner lane computes its own update; lane c's is the one that counts (oracle: hard_solve, sweeps)
-          const float pn0 = O.p[0];
-          const float pn = rmaxf(fmaf(-(O.u[0] - tg), O.iwnn, pn0), 0.0f);
-          const float dn = pn - pn0;
-          const float ut1 = fmaf(dn, O.w10, O.u[1]), ut2 = fmaf(dn, O.w20, O.u[2]);
-          float ps1 = O.p[1] - fmaf(O.Ti[1], ut2, O.Ti[0] * ut1), ps2 = O.p[2] - fmaf(O.Ti[2], ut2, O.Ti[1] * ut1);
-          const float lim = O.mu * pn, lim2 = lim * lim;
-          if (fmaf(ps2, ps2, ps1 * ps1) > lim2) {
-            ps1 = fmaf(-O.rt, ut1, O.p[1]); ps2 = fmaf(-O.rt, ut2, O.p[2]);
-            const float nt2 = fmaf(ps2, ps2, ps1 * ps1);
-            const float sc1 = nt2 > lim2 ? lim * rsqrt_spec(nt2) : 1.0f;
-            ps1 *= sc1; ps2 *= sc1;
-          }
-          const bool commit = l == c && c < K && act;
-          float dp0 = commit ? dn : 0.0f, dp1 = commit ? ps1 - O.p[1] : 0.0f, dp2 = commit ? ps2 - O.p[2] : 0.0f;
-          if (commit) { O.p[0] = pn; O.p[1] = ps1; O.p[2] = ps2; }
-          // the change of contact c's impulse, from its owner lane (lane c of each env: wave lanes c and 32 + c) to every lane
-          {
-            const float a0 = hard_readlane(dp0, c), a1 = hard_readlane(dp1, c), a2 = hard_readlane(dp2, c);
-            const float b0 = hard_readlane(dp0, 32 + c), b1 = hard_readlane(dp1, 32 + c), b2 = hard_readlane(dp2, 32 + c);
-            dp0 = hi ? b0 : a0; dp1 = hi ? b1 : a1; dp2 = hi ? b2 : a2;
-          }
-          if (own && c < K) {
-#pragma unroll
-            for (int r = 0; r < 3; r++) O.u[r] = fmaf(Wb[3 * r + 2], dp2, fmaf(Wb[3 * r + 1], dp1, fmaf(Wb[3 * r], dp0, O.u[r])));
+          for (int c = 0; c < KC; c++) {
+            if (c >= Kw) break;
+            visit(c, tg);
           }
         }
       }
@@ -804,8 +865,8 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
     }
     PHASE_MARK(17);
     GROUP_SYNC();
-    if (nvel > 0) chain_hard_apply<CD, 2>(m, L, tail, l, K, idt, isbody && half == 0, islink, isroot, ischain, ci, lb, myb, ac0);
-    else chain_hard_apply<CD, 1>(m, L, tail, l, K, idt, isbody && half == 0, islink, isroot, ischain, ci, lb, myb, ac0);
+    if (nvel > 0) chain_hard_apply<CD, 2, KC>(m, L, tail, l, K, idt, isbody && half == 0, islink, isroot, ischain, ci, lb, myb, ac0);
+    else chain_hard_apply<CD, 1, KC>(m, L, tail, l, K, idt, isbody && half == 0, islink, isroot, ischain, ci, lb, myb, ac0);
     PHASE_MARK(18);
   } else {
     if (isdof) { L.dofb[l * DOF_STRIDE + 2] = 0.0f; L.dofb[l * DOF_STRIDE + 3] = 0.0f; }
@@ -876,7 +937,7 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
       const bool last = islink && (lb % NLK) == NLK - 1;
       float f[3] = {0.0f, 0.0f, 0.0f}, fw[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int c = 0; c < HCK; c++) {      // (unrolled: the records of all constraints in flight at once)
+      for (int c = 0; c < KC; c++) {      // (unrolled: the records of all constraints in flight at once)
         const float* h = tail + T::HC + c * HC_STRIDE;
         const int rep = c < K ? __float_as_int(h[HC_REP]) : -9, repb = c < K ? __float_as_int(h[HC_REPB]) : -9;
         const float pf[3] = {(nvel > 0 ? h[HC_PV0] : h[HC_P]) * idt, (nvel > 0 ? h[HC_PV1] : h[HC_P + 1]) * idt, (nvel > 0 ? h[HC_PV2] : h[HC_P + 2]) * idt};

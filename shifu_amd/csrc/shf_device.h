@@ -712,6 +712,25 @@ struct StepCtx {
   const float* mscale = nullptr;  // this env's row of SHF_T_BODY_MASS_SCALE (factor on each body's mass and inertia), may be null
   const ShfHullSet* hulls = nullptr;   // the articulation's convex hulls (global memory), may be null
 };
+// SHF_T_CONTACT_HIST bound: SimArgs.dropped points at it instead of SHF_T_DROPPED -- rows of SHF_CONTACT_HIST_BINS + 1 words, the
+// histogram and, in the last word, the env's drop counter -- and this bit is set in the launch's copy of sp.max_contacts (the
+// kernels read the cap through hard_kmax()).  No kernel argument of its own: the fused A1 step is at its scalar-register limit.
+#define SHF_HIST_FLAG 0x100
+// this env's drop counter from the launch's `dropped` argument: a word of SHF_T_DROPPED, or the last word of the env's row of
+// SHF_T_CONTACT_HIST when that is bound (SHF_HIST_FLAG in the launch's max_contacts)
+DEV int32_t* env_dropped(int32_t* base, const ShfSimParams& sp, int e) {
+  if (!base) return nullptr;
+  return (sp.max_contacts & SHF_HIST_FLAG) ? base + (size_t)e * (SHF_CONTACT_HIST_BINS + 1) + SHF_CONTACT_HIST_BINS : base + e;
+}
+// one sub-step offered `total` candidate constraints (before the cap): this env's histogram row, when bound
+DEV void contact_hist_count(const StepCtx& C, int l, int total) {
+  if (l == 0 && C.dropped && (C.sp.max_contacts & SHF_HIST_FLAG))
+    C.dropped[(total < SHF_CONTACT_HIST_BINS - 1 ? total : SHF_CONTACT_HIST_BINS - 1) - SHF_CONTACT_HIST_BINS] += 1;
+}
+DEV int hard_kmax_of(const ShfSimParams& sp, int cap) {
+  const int mc = sp.max_contacts & 0xff;
+  return mc > 0 ? (mc < cap ? mc : cap) : cap;
+}
 // mass of body b in this env (oracle: body_mass)
 DEV float body_mass(const StepCtx& C, int b) { return C.mscale ? C.m->mass[b] * C.mscale[b] : C.m->mass[b]; }
 

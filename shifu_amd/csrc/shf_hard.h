@@ -369,6 +369,7 @@ DEV int hg_gather(const StepCtx& C, const EnvLds& L, const SlotLay& Q, const HgS
     }
     total += __builtin_popcountll(mask);
   }
+  contact_hist_count(C, l, total);
   const bool overflow = total > kmax;
   if (overflow && l == 0 && C.dropped) *C.dropped += total - kmax;
   GROUP_SYNC();
@@ -456,7 +457,7 @@ DEV void hg_columns(const ShfModel* m, const EnvLds& L, int nb, int l, int K, co
   if (bsb >= 0) hg_impulse(m, L, nb, bsb, rj, e, qb);
   for (int i = 0; i < HCK; i++) {
     if (__ballot(i < K) == 0ull) break;
-    if (!(col && i < K)) continue;
+    if (!(col && i <= j)) continue;       // the upper triangle: block (i, j), i <= j; block (j, i) is its transpose (oracle: hard_solve)
     const float* hi = hc + i * HC_STRIDE;
     const float ri[3] = {hi[HC_R], hi[HC_R + 1], hi[HC_R + 2]};
     const int bta = __float_as_int(hi[HC_BODY]), btb = __float_as_int(hi[HC_BODYB]);
@@ -468,7 +469,9 @@ DEV void hg_columns(const ShfModel* m, const EnvLds& L, int nb, int l, int K, co
 #pragma unroll
     for (int r = 0; r < 3; r++) vw[r] = (aa[r] - ab[r]) - (ba[r] - bb[r]);
     float* Wb = W + (j * HCK + i) * 9 + ax;
-    Wb[0] = dot3(hi + HC_N, vw); Wb[3] = dot3(hi + HC_T1, vw); Wb[6] = dot3(hi + HC_T2, vw);
+    const float w0 = dot3(hi + HC_N, vw), w1 = dot3(hi + HC_T1, vw), w2 = dot3(hi + HC_T2, vw);
+    Wb[0] = w0; Wb[3] = w1; Wb[6] = w2;
+    if (i < j) { float* Wt = W + (i * HCK + j) * 9 + 3 * ax; Wt[0] = w0; Wt[1] = w1; Wt[2] = w2; }     // row ax of block (j, i)
   }
 }
 
@@ -511,7 +514,7 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
   float* hc = L.pt + hc0 * PT_STRIDE;
   float* W = L.pt;           // (in the place of the first 48 slots, from the columns on: see hard_hc_slot0)
   const int npos = C.sp.pos_iters > 0 ? C.sp.pos_iters : 0, nvel = C.sp.vel_iters > 0 ? C.sp.vel_iters : 0;
-  const int kmax = C.sp.max_contacts > 0 ? (C.sp.max_contacts < HCK ? C.sp.max_contacts : HCK) : HCK;
+  const int kmax = hard_kmax_of(C.sp, HCK);
 
   PHASE_BEGIN();
   // ---- records

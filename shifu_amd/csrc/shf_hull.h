@@ -172,7 +172,12 @@ template <int G>
 __device__ __noinline__ int convex_manifold_dev(const PolyDev& A, const PolyDev& B, float offset, int l, float (*r)[3], float* n, float* phi) {
   int fa, fb, ea, eb;
   float axis[3];
-  const float sa = hull_face_query<G>(A, B, l, &fa), sb = hull_face_query<G>(B, A, l, &fb);
+  // (a face that separates the pair by the contact offset or more ends the test: the oracle computes all three queries and returns
+  // nothing in that case too -- most live pairs of the broad phase end here, before the edge pairs, the expensive query)
+  const float sb = hull_face_query<G>(B, A, l, &fb);
+  if (!(sb < offset)) return 0;
+  const float sa = hull_face_query<G>(A, B, l, &fa);
+  if (!(sa < offset)) return 0;
   const float se = hull_edge_query<G>(A, B, l, &ea, &eb, axis);
   const float sface = rmaxf(sa, sb);
   if (!(sface < offset) || !(se < offset)) return 0;

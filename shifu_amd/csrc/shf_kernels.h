@@ -33,7 +33,7 @@ DEV void sim_step_body(const SimArgs& A) {
   GROUP_SYNC();
   StepCtx C;
   C.m = m; C.sp = A.sp; C.terr.t = A.terr; C.terr.h = A.heights; C.scene = scene;
-  C.dropped = A.dropped ? A.dropped + e : nullptr;
+  C.dropped = env_dropped(A.dropped, A.sp, e);
   C.mscale = A.mscale ? A.mscale + (size_t)e * nb : nullptr;
   C.hulls = A.hulls;
   const float mu = A.friction ? A.friction[e] : 1.0f;
@@ -280,7 +280,7 @@ DEV void a1_step_body(const A1Args& A) {
 
   StepCtx C;
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = nullptr;
-  C.dropped = A.S.dropped ? A.S.dropped + e : nullptr;
+  C.dropped = env_dropped(A.S.dropped, A.S.sp, e);
   C.mscale = A.S.mscale ? A.S.mscale + (size_t)e * nb : nullptr;
   C.hulls = A.S.hulls;
   const float mu = A.S.friction[e];
@@ -602,7 +602,7 @@ DEV void abb_step_body(const AbbArgs& A) {
 
   StepCtx C;
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = scene;
-  C.dropped = A.S.dropped ? A.S.dropped + e : nullptr;
+  C.dropped = env_dropped(A.S.dropped, A.S.sp, e);
   C.mscale = A.S.mscale ? A.S.mscale + (size_t)e * nb : nullptr;
   C.hulls = A.S.hulls;
   const float mu = A.S.friction[e];
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
 
   StepCtx C;
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = scene;
-  C.dropped = (LINK && live && !arm && A.S.dropped) ? A.S.dropped + e : nullptr;   // (the box wave counts the dropped link contacts)
+  C.dropped = (LINK && live && !arm) ? env_dropped(A.S.dropped, A.S.sp, e) : nullptr;   // (the box wave counts the dropped link contacts)
   C.mscale = (live && A.S.mscale) ? A.S.mscale + (size_t)e * DM::nb(m) : nullptr;
   const float mu = live ? A.S.friction[e] : 0.0f;
   const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);

@@ -27,6 +27,7 @@ struct SimArgs {
   int32_t* dropped;  // (n) contacts dropped at the per-env limits, accumulated (SHF_T_DROPPED), may be null
   const ShfHullSet* hulls;   // device copy of the articulation's convex hulls (SHF_T_HULLS), nullptr = none
 };
+// (SHF_T_CONTACT_HIST bound: `dropped` points at its rows -- csrc/shf_device.h: SHF_HIST_FLAG, env_dropped)
 
 // Cooperative global -> LDS copy of a fixed-size parameter block by the 256 threads of a block: all loads
 // are issued before the first store (one memory round trip instead of one per loop iteration).

@@ -443,3 +443,38 @@ def test_facade_uploads_per_env_link_masses():
     assert np.isfinite(fz).all()
     np.testing.assert_allclose(fz[::2], total * 9.81, rtol=0.05)
     np.testing.assert_allclose(fz[1::2], (total + extra) * 9.81, rtol=0.05)
+
+
+@pytest.mark.gpu
+def test_contact_histogram_counts_every_substep_and_carries_the_drop_counter():
+    """SHF_T_CONTACT_HIST (include/shifu_amd.h): while bound, every env adds one count per sub-step to the bin of its candidate
+    count (before the max_contacts cap), the last column takes the dropped contacts -- exactly sum_k max(k - cap, 0) x bin k --
+    and SHF_T_DROPPED stands still; unbound, SHF_T_DROPPED counts again.  Fused A1 step (chain kernel) and the hook path."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from shifu_amd import _abi
+    from shifu_amd.gym.a1_fused import FusedA1Env
+    n, steps = 256, 30
+    env = FusedA1Env(num_envs=n, seed=3)
+    assert env.solver == "pgs"
+    env.reset()
+    for _ in range(10):
+        env.task.step_random()
+    torch.cuda.synchronize()
+    d0 = env.sim.tensors[_abi.T_DROPPED].clone()
+    ht = env.sim.bind_contact_hist(True)
+    for _ in range(steps):
+        env.task.step_random()
+    torch.cuda.synchronize()
+    h = ht.cpu().numpy().astype(np.int64)
+    bins = _abi.CONTACT_HIST_BINS
+    assert (h[:, :bins].sum(1) == steps * 5).all()                      # 4 control sub-steps + the refresh sub-step, every env
+    assert h[:, bins - 1].sum() == 0                                      # nobody beyond the last bin here
+    want = (np.maximum(np.arange(bins) - 8, 0)[None, :] * h[:, :bins]).sum(1)
+    np.testing.assert_array_equal(h[:, bins], want)
+    assert want.sum() > 0 and torch.equal(env.sim.tensors[_abi.T_DROPPED], d0)
+    env.sim.bind_contact_hist(False)
+    for _ in range(5):
+        env.task.step_random()
+    torch.cuda.synchronize()
+    assert int((env.sim.tensors[_abi.T_DROPPED] - d0).sum()) > 0

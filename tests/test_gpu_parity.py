@@ -266,16 +266,19 @@ def test_fused_a1_step_matches_oracle_bitwise(oracle, rough, group):
     assert np.isfinite(bufs["obs"]).all()
 
 
-@pytest.mark.parametrize("kmax", [8, 3])
+@pytest.mark.parametrize("kmax", [8, 3, 16, 12])
 @pytest.mark.parametrize("rough", [False, True])
 def test_fused_a1_step_with_the_velocity_level_solve_matches_oracle_bitwise(oracle, rough, kmax):
     """The same step under ShfSimParams.solver = SHF_SOLVER_PGS (the reference's PhysX settings, env_config.py:50-58: 8 + 1
     sweeps): candidate selection, response matrix by impulse propagation, projected Gauss-Seidel, the two impulse passes --
     k_a1_chain_pgs against the oracle's hard_solve, every tensor, 120 vec-steps with falls and resets.  kmax = 3: more
-    candidates than the solve holds on most steps (the deepest are kept, the others counted)."""
+    candidates than the solve holds on most steps (the deepest are kept, the others counted).  kmax = 16 / 12 (round 6): up to
+    sixteen constraints per env on k_a1_chain_pgs16 -- the response matrix's upper triangle, packed over the contact slots and the
+    pose / rate / exchange slots."""
     _need_gpu()
     n = 96
     cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, rough, group="chain32", env_off=1000, solver="pgs", max_contacts=kmax)
+    assert task.kernel_symbol().startswith("_Z16k_a1_chain_pgs16" if kmax > 8 else "_Z14k_a1_chain_pgsI")
     oracle.dropped(reset=True)
     resets = 0
     for it in range(120):
@@ -292,13 +295,16 @@ def test_fused_a1_step_with_the_velocity_level_solve_matches_oracle_bitwise(orac
     d = oracle.dropped()
     assert int(sim.tensors[_abi.T_DROPPED].sum()) == d
     assert d > (20000 if kmax == 3 else 0), d
+    if kmax > 8:      # the cap at 8 would have dropped far more on the same run (the stumbling robots offer 9 .. 16 candidates)
+        assert d < 200, d
 
 
-def test_fused_a1_step_with_the_velocity_level_solve_at_full_size(oracle):
-    """... and at BASELINE's env count: 4096 envs x 30 vec-steps, every tensor bit for bit."""
+@pytest.mark.parametrize("kmax", [8, 16])
+def test_fused_a1_step_with_the_velocity_level_solve_at_full_size(oracle, kmax):
+    """... and at BASELINE's env count: 4096 envs x 30 vec-steps, every tensor bit for bit (8 and 16 constraints per env)."""
     _need_gpu()
     n = 4096
-    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, seed=91, group="chain32", env_off=8192, solver="pgs")
+    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, seed=91, group="chain32", env_off=8192, solver="pgs", max_contacts=kmax)
     bufs["ep_len"][:] = rng.integers(900, 1001, n)
     _upload(sim, task, bufs)
     resets = 0
@@ -1332,8 +1338,9 @@ def test_self_collision_matches_oracle_bitwise(oracle, group, dyn):
         assert "self" in task.kernel_symbol() and ("DynDims" in task.kernel_symbol()) == dyn
 
 
+@pytest.mark.parametrize("kmax", [8, 16])
 @pytest.mark.parametrize("selfc", [False, True])
-def test_velocity_level_solve_simulate_and_self_collision_match_oracle_bitwise(oracle, selfc):
+def test_velocity_level_solve_simulate_and_self_collision_match_oracle_bitwise(oracle, selfc, kmax):
     """ShfSimParams.solver = SHF_SOLVER_PGS through gym.simulate (k_sim_step_chain_pgs: the hook path's sub-step) from thrown,
     folded states with random efforts and pushes -- ground contacts and, with self-collision, capsule-pair constraints between
     two bodies of the tree (impulses on both sides of the response matrix) -- then the fused step with self-collision on the
@@ -1345,7 +1352,7 @@ def test_velocity_level_solve_simulate_and_self_collision_match_oracle_bitwise(o
     for d in range(m.nd):
         m.damping[d] = 0.5
     rng = np.random.default_rng(33)
-    sp = H.sim_params(angular_damping=0.5, solver="pgs")
+    sp = H.sim_params(angular_damping=0.5, solver="pgs", max_contacts=kmax)
     n = 48
     terr, hs = _terrain(rng, rough=True)
     dof, root = _random_states(m, n, rng, z_lo=0.1, z_hi=0.5)
@@ -1378,13 +1385,13 @@ def test_velocity_level_solve_simulate_and_self_collision_match_oracle_bitwise(o
     sim.destroy()
     if not selfc:
         return
-    cm2, sp2, tp, terr, hs, bufs, sim, task, rng = _a1_setup(64, True, group="chain32", cm=cm, solver="pgs")
+    cm2, sp2, tp, terr, hs, bufs, sim, task, rng = _a1_setup(64, True, group="chain32", cm=cm, solver="pgs", max_contacts=kmax)
     for it in range(60):
         raw = (2 * rng.random((64, m.nd)) - 1).astype(np.float32) * 2.0
         task.step(torch.from_numpy(raw).cuda())
         oracle.a1_step(m, sp2, tp, 64, 0, bufs, raw, terrain=terr, heights=hs)
         _compare(sim, task, bufs, f"fused self-collision step {it}")
-    assert task.kernel_symbol().startswith("_Z14k_a1_chain_pgsILb0ELb1E")
+    assert task.kernel_symbol().startswith("_Z16k_a1_chain_pgs16ILb0ELb1E" if kmax > 8 else "_Z14k_a1_chain_pgsILb0ELb1E")
 
 
 @pytest.mark.parametrize("solver", ["compliant", "pgs"])
