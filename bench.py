@@ -244,6 +244,9 @@ def main():
                          "default, timed the same way after the main measurement and reported beside it)")
     ap.add_argument("--pos-iters", type=int, default=8, help="physx.num_position_iterations (pgs)")
     ap.add_argument("--vel-iters", type=int, default=1, help="physx.num_velocity_iterations (pgs)")
+    ap.add_argument("--max-contacts", type=int, default=None,
+                    help="ShfSimParams.max_contacts (pgs): constraints the solve holds per env and sub-step, the deepest candidates -- 8 (default) "
+                         "on k_a1_chain_pgs, up to 16 on k_a1_chain_pgs16 (A1 workloads)")
     ap.add_argument("--self-collision", action="store_true",
                     help="A1 workloads: collide the robot's own links (capsule pairs; the reference's collision filter 0, "
                          "units.py:68) -- off in the headline configuration, whose BASELINE entry names height-field contact")
@@ -295,7 +298,7 @@ def main():
     if use_dist:
         init_ranks(dev, backend)       # finite timeout: a rank that never arrives fails the job instead of hanging it
 
-    solver_given = args.solver is not None or args.mapping is not None or args.group is not None or args.link_shapes != "box"
+    solver_given = args.solver is not None or args.mapping is not None or args.group is not None or args.link_shapes != "box" or args.max_contacts is not None
     abb = args.workload == "abb"
     if abb:
         if args.link_contacts and (args.no_link_contacts or args.mapping == "chain"):
@@ -326,7 +329,7 @@ def main():
         env = FusedA1Env(num_envs=args.envs, device=dev, terrain={"terrain": "heightfield", "flat": "flat", "trimesh": "trimesh"}[args.workload],
                          seed=42, rank=rank, world_size=world, group=group, mapping=mapping, decimation=args.decimation,
                          extra_substep=not args.no_extra_substep, self_collision=args.self_collision, solver=args.solver,
-                         solver_kw={"pos_iters": args.pos_iters, "vel_iters": args.vel_iters})
+                         solver_kw={"pos_iters": args.pos_iters, "vel_iters": args.vel_iters, **({} if args.max_contacts is None else {"max_contacts": args.max_contacts})})
         stats_t, count_t, kernel = _abi.A1_STATS, _abi.A1_RESET_COUNT, "k_a1_step"
         substeps = args.decimation + (0 if args.no_extra_substep else 1)
         args.solver = env.solver
@@ -523,7 +526,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{WL_NAME[args.workload]}, {N} envs/GPU, random actions, {substeps} substeps/env-step "
                                    f"(dt {'20' if abb else '5'} ms), resets on, contact solver: "
-                                   + (f"velocity-level PGS {args.pos_iters} + {args.vel_iters} iterations (the reference's physx settings, env_config.py:50-58)" if args.solver == "pgs"
+                                   + (f"velocity-level PGS {args.pos_iters} + {args.vel_iters} iterations (the reference's physx settings, env_config.py:50-58), at most {int(env.sim_params.max_contacts) or 8} constraints per env" if args.solver == "pgs"
                                       else "compliant spring-damper law (rounds 1-4)")
                                    + (((", link contacts ON (arm links as the reduced convex hulls of their collision meshes + rod vs table / cube / goal pad; clipped face manifolds on)" if args.link_shapes == "hull" else ", link contacts ON (arm links + rod vs table / cube / goal pad)") if args.link_contacts else
                                        ", arm collider: the rod against the cube (link contacts OFF, see --link-contacts)") if abb else (", self-collision ON (capsule pairs, the reference's collision filter 0)" if args.self_collision
@@ -591,7 +594,7 @@ def main():
                                            "warm-up steps); compliant = the spring-damper law of rounds 1-4 (opt-in: --solver compliant)"}
         if not args.no_cpu_baseline and world == 1:
             scene_kw = {"link_contacts": bool(args.link_contacts), "link_shapes": args.link_shapes} if abb else {}
-            cb = out["cpu_baseline"] = cpu_baseline(args.workload, solver_kw={"solver": args.solver, "pos_iters": args.pos_iters, "vel_iters": args.vel_iters}, **scene_kw)     # the only leg that touches oracle/
+            cb = out["cpu_baseline"] = cpu_baseline(args.workload, solver_kw={"solver": args.solver, "pos_iters": args.pos_iters, "vel_iters": args.vel_iters, **({} if args.max_contacts is None else {"max_contacts": args.max_contacts})}, **scene_kw)     # the only leg that touches oracle/
             f_alg = cb["flops_per_env_step"]
             secondary.update({"flops_alg_per_env_step": f_alg, "flops_source": cb["flops_source"]})
             if f_alg is not None:
