@@ -235,7 +235,7 @@ def main():
                     help="A1 workloads: lane = kinematic chain (default, with --self-collision too at 32 lanes per env; csrc/shf_chain.h) "
                          "or lane = rigid body (the general kernels).  Kernel selection only: results are bit-identical")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--solver", choices=["pgs", "compliant"], default=None,
+    ap.add_argument("--solver", choices=["pgs", "tgs", "compliant"], default=None,
                     help="contact solver (ShfSimParams.solver): pgs = the velocity-level projected Gauss-Seidel solve with the reference's PhysX "
                          "settings (env_config.py:50-58: 8 + 1 iterations), the default of the A1 workloads (without --self-collision, chain "
                          "mapping at 32 lanes); compliant = rounds 1-4's spring-damper law (config 5 / abb: the only one built)")
@@ -306,7 +306,7 @@ def main():
         args.link_contacts = not (args.no_link_contacts or args.mapping == "chain")
         if args.solver is None and args.mapping is None and args.group is None:
             args.solver = "pgs"      # FusedAbbEnv's own default: the reference's PhysX settings (generic kernel, 32 lanes per env)
-        if args.solver == "pgs":
+        if args.solver in ("pgs", "tgs"):
             mapping, group = "body", 32
         else:
             mapping = args.mapping or ("split" if (args.group or 16) == 16 else ("chain" if (not args.link_contacts and (args.group or 16) == 32) else "body"))
@@ -440,7 +440,8 @@ def main():
     # up to 100 steps with the histogram bound (binding it costs the kernel one read-modify-write per env and sub-step: kept out of
     # the timed region and of the kernel_ms pass)
     cand_hist = None
-    if args.solver == "pgs" and graph is None:
+    hard = args.solver in ("pgs", "tgs")
+    if hard and graph is None:
         ht = env.sim.bind_contact_hist(True)
         for i in range(min(args.steps, 100)):
             eager_step()
@@ -471,7 +472,7 @@ def main():
         value = total_envs * args.steps / elapsed
         b_alg = B_ALG[args.workload]
         achieved = b_alg * N / (kern_ms * 1e-3) / 1e9
-        prof = committed_profile(f"{kernel}_{args.workload}_g{group}" + ("_" + mapping if mapping != "body" else "") + ("_pgs" if args.solver == "pgs" else "") + ("_link" if (abb and args.link_contacts) else "")) if (N == 4096 and not args.self_collision) else None
+        prof = committed_profile(f"{kernel}_{args.workload}_g{group}" + ("_" + mapping if mapping != "body" else "") + ("_" + args.solver if args.solver in ("pgs", "tgs") else "") + ("_link" if (abb and args.link_contacts) else "")) if (N == 4096 and not args.self_collision) else None
         res = {}
         try:
             res = json.load(open(os.path.join(ROOT, "shifu_amd", "libshifu_amd.resources.json")))
@@ -526,7 +527,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{WL_NAME[args.workload]}, {N} envs/GPU, random actions, {substeps} substeps/env-step "
                                    f"(dt {'20' if abb else '5'} ms), resets on, contact solver: "
-                                   + (f"velocity-level PGS {args.pos_iters} + {args.vel_iters} iterations (the reference's physx settings, env_config.py:50-58), at most {int(env.sim_params.max_contacts) or 8} constraints per env" if args.solver == "pgs"
+                                   + (f"velocity-level {'TGS (physx.solver_type = 1: sub-stepped sweeps)' if args.solver == 'tgs' else 'PGS (physx.solver_type = 0)'} {args.pos_iters} + {args.vel_iters} iterations (the reference's physx settings, env_config.py:50-58), at most {int(env.sim_params.max_contacts) or 8} constraints per env" if args.solver in ("pgs", "tgs")
                                       else "compliant spring-damper law (rounds 1-4)")
                                    + (((", link contacts ON (arm links as the reduced convex hulls of their collision meshes + rod vs table / cube / goal pad; clipped face manifolds on)" if args.link_shapes == "hull" else ", link contacts ON (arm links + rod vs table / cube / goal pad)") if args.link_contacts else
                                        ", arm collider: the rod against the cube (link contacts OFF, see --link-contacts)") if abb else (", self-collision ON (capsule pairs, the reference's collision filter 0)" if args.self_collision
@@ -537,7 +538,7 @@ def main():
                        "substeps_per_s": value * substeps, "obs_finite": finite, "episodes_reset_rank0": resets,
                        # candidates beyond ShfSimParams.max_contacts (PGS) / the self- and link-contact slot limits, per env and vec-step
                        # over the timed region on rank 0 (SHF_T_DROPPED deltas); envs_ever_dropping: envs whose counter is non-zero
-                       "max_contacts": (int(env.sim_params.max_contacts) or 8) if args.solver == "pgs" else None,
+                       "max_contacts": (int(env.sim_params.max_contacts) or 8) if args.solver in ("pgs", "tgs") else None,
                        "dropped_constraints_per_env_step": None if dropped0 is None else (dropped1 - dropped0) / float(N * args.steps),
                        "envs_ever_dropping_frac": None if envs_dropping is None else envs_dropping / float(N),
                        # share of (env, sub-step) pairs that offered k candidate constraints to the solve, k = 0 .. 24, last bin: more
@@ -556,7 +557,7 @@ def main():
                          "kernel_symbol": entry, "kernel_code_sha": None if vg is None else vg.get("code_sha"),
                          "counters_kernel_sha": None if not prof else prof.get("kernel_code_sha"),
                          "counters_stale": None if not prof else (prof.get("kernel_code_sha") is None or vg is None or prof.get("kernel_code_sha") != vg.get("code_sha")),
-                         "kernel": ("k_a1_chain_pgs" if (kernel == "k_a1_step" and args.solver == "pgs") else "k_a1_chain" if (kernel == "k_a1_step" and mapping == "chain") else "k_abb_step_ws" if (kernel == "k_abb_step" and mapping == "split") else "k_abb_step_pgs_wide" if (abb and "pgs_wide" in env.task.kernel_symbol()) else kernel), "kernel_ms": kern_ms, "alg_bytes_per_env_step": b_alg,
+                         "kernel": (("k_a1_chain_" + args.solver + ("16" if int(env.sim_params.max_contacts) > 8 else "")) if (kernel == "k_a1_step" and args.solver in ("pgs", "tgs")) else "k_a1_chain" if (kernel == "k_a1_step" and mapping == "chain") else "k_abb_step_ws" if (kernel == "k_abb_step" and mapping == "split") else "k_abb_step_pgs_wide" if (abb and "pgs_wide" in env.task.kernel_symbol()) else kernel), "kernel_ms": kern_ms, "alg_bytes_per_env_step": b_alg,
                          "note": "latency/ALU-bound by design: a few KB of compulsory traffic per env-step (DESIGN.md 5)" +
                                  ("; alg_bytes counts the env's own tensors (state in, state / body_state / contact / Jacobian / obs out): link contacts "
                                   "add work on the LDS-resident model and scene, not tensors, so B_alg is the rod-only scene's" if (abb and args.link_contacts) else ""),
@@ -571,7 +572,7 @@ def main():
         if world == 1 and not solver_given and not args.no_other_solver and args.actions == "kernel" and graph is None:
             # the driver runs the default command only: the opt-in compliant law of rounds 1-4 on the same workload, same K and
             # W, same clock, so that one line carries both (a fresh env; the main measurement above is already taken)
-            other = "compliant" if args.solver == "pgs" else "pgs"
+            other = "compliant" if args.solver in ("pgs", "tgs") else "pgs"
             if abb:
                 env2 = FusedAbbEnv(num_envs=args.envs, device=dev, seed=42, link_contacts=args.link_contacts, solver=other, link_shapes=args.link_shapes)
             else:

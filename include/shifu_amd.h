@@ -274,7 +274,8 @@ typedef struct ShfSimParams {
    *   phi >= 0: -phi / dt (speculative: it may close the gap, no more); phi < 0: min(erp (-phi) / dt, max_depen_vel);
    *   with restitution > 0 and an approach faster than bounce_threshold: at least -restitution v_n.  contact_k, contact_d,
    *   friction_vel are unused.  At most max_contacts (<= SHF_MAX_HARD_CONTACTS; 0 reads as 8) constraints per env: the
-   *   candidates with the smallest gap (ties: candidate order), the others dropped and counted in SHF_T_DROPPED. */
+   *   candidates with the smallest gap (ties: candidate order), the others dropped and counted in SHF_T_DROPPED.
+   * solver == SHF_SOLVER_TGS (2): the same solve as sub-stepped sweeps -- see the define below. */
   int32_t solver;
   int32_t pos_iters;        /* physx.num_position_iterations                                   */
   int32_t vel_iters;        /* physx.num_velocity_iterations (further sweeps of the same kind)  */
@@ -287,6 +288,16 @@ typedef struct ShfSimParams {
 #define SHF_SCENE_FACE_MANIFOLD 1
 #define SHF_SOLVER_COMPLIANT 0
 #define SHF_SOLVER_PGS 1
+/* solver == SHF_SOLVER_TGS (2): physx.solver_type = 1, what the reference sets (shifu/configs/env_config.py:50): temporal
+ * Gauss-Seidel -- the sweeps of SHF_SOLVER_PGS as pos_iters sub-iterations of length h = dt / pos_iters.  Per sub-iteration the
+ * constraint errors are re-evaluated from the advanced relative motion (gap_c += h u_n,c after each sweep: no new collision
+ * detection, like PhysX), the targets take the sub-step's horizon (open gap: -gap / h, it may close within this sub-iteration;
+ * penetration: min(erp (-gap) / h, max_depen_vel)), and the poses advance with each sub-iteration's velocities: they are
+ * integrated with the MEAN of the impulses after the pos_iters sweeps, the velocities with the impulses after the velocity
+ * iterations (target of an open gap there: -gap / dt with the gap that is left).  External and drive forces are not sub-stepped:
+ * one articulated-body solve per dt, as under SHF_SOLVER_PGS.  (M. Macklin et al., "Small steps in physics simulation", 2019;
+ * PhysX 5 "TGS" [EXT].) */
+#define SHF_SOLVER_TGS 2
 
 typedef struct ShfTerrain {
   int32_t rows, cols; /* height_samples is (rows, cols) int16, x<->row     */

@@ -164,7 +164,7 @@ class Articulation:
 class HardContactStepper:
     """One articulation (+ optionally one free box) under rigid contacts; step() advances dt."""
 
-    def __init__(self, model, params, mu=1.0, sweeps=(8, 1), baumgarte=0.2, box=None, box_plane_z=None, box_mu=0.5):
+    def __init__(self, model, params, mu=1.0, sweeps=(8, 1), baumgarte=0.2, box=None, box_plane_z=None, box_mu=0.5, tgs=False):
         self.A = Articulation(model)
         self.dt = float(params.dt)
         self.g = np.array(params.gravity[:], float)
@@ -172,6 +172,10 @@ class HardContactStepper:
         self.vdep = float(params.max_depen_vel)
         self.ang_damp = float(params.angular_damping)
         self.mu, self.npos, self.nvel, self.beta = mu, int(sweeps[0]), int(sweeps[1]), baumgarte
+        # tgs: physx.solver_type = 1 (shifu/configs/env_config.py:50) as sub-stepped sweeps -- the position iterations are
+        # sub-iterations of h = dt / npos: targets from the gaps as they stand (horizon h), gaps advanced by the normal velocity
+        # each sweep leaves, the poses moved by the mean of the impulses after the sweeps; velocity iterations against what is left
+        self.tgs = bool(tgs)
         self.box = box          # dict(dim, mass) or None
         self.box_plane_z, self.box_mu = box_plane_z, box_mu
 
@@ -266,13 +270,25 @@ class HardContactStepper:
                 if gaps[c] <= 0.0:
                     target_v[3 * c] = 0.0
             pimp = np.zeros(3 * k)
+            tgs = self.tgs and self.npos > 0
+            h = dt / self.npos if tgs else dt
+            gap_now = np.array(gaps, float)
+            psum = np.zeros(3 * k)
             for phase, (nsweep, tg) in enumerate(((self.npos, target), (self.nvel, target_v))):
                 # Sequential impulses with a friction cone (E. Catto 2005): per contact the normal impulse first (clamped at
                 # zero), then the tangential impulse that stops the sliding under it if that lies inside the cone mu p_n, else a
                 # projected step against the sliding velocity.  (Round 4's sweep solved the 3x3 block for sticking and
                 # projected THAT onto the cone: in steady sliding its friction came out at 0.44 N for mu = 0.6 on a block on an
                 # incline -- tests/test_hard_contact.py now holds both solvers to Coulomb's law.)
+                if tgs and phase == 1:
+                    tg = np.zeros(3 * k)
+                    for c in range(k):
+                        tg[3 * c] = -gap_now[c] / dt if gap_now[c] >= 0.0 else 0.0
                 for it in range(nsweep):
+                    if tgs and phase == 0:
+                        tg = np.zeros(3 * k)
+                        for c in range(k):
+                            tg[3 * c] = -gap_now[c] / h if gap_now[c] >= 0.0 else min(self.beta * (-gap_now[c]) / h, self.vdep)
                     for c in range(k):
                         sl = slice(3 * c, 3 * c + 3)
                         Wcc = W[sl, sl] + 1e-6 * np.trace(W[sl, sl]) * np.eye(3)     # the same regularisation as oracle/shf_oracle.c hard_solve
@@ -289,8 +305,13 @@ class HardContactStepper:
                             if nt > lim:
                                 pt = pt * (lim / nt)
                         pimp[sl] = [pn, pt[0], pt[1]]
+                    if tgs and phase == 0:
+                        un = (u0 + W @ pimp)[0::3]
+                        un = un + 1e-6 * np.array([np.trace(W[3 * c:3 * c + 3, 3 * c:3 * c + 3]) for c in range(k)]) * pimp[0::3]
+                        gap_now = gap_now + h * un
+                        psum += pimp
                 if phase == 0:
-                    vpos = vfree + Minv @ (J.T @ pimp)
+                    vpos = vfree + Minv @ (J.T @ (psum / self.npos if tgs else pimp))
             vnew = vfree + Minv @ (J.T @ pimp)
             imp_n = float(sum(pimp[3 * c] for c in range(narm))) / dt
         # semi-implicit Euler: poses with the velocities of the position iterations, state velocities from the velocity iterations

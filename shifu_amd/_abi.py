@@ -17,7 +17,7 @@ MAX_HARD_CONTACTS = 16
 MAX_HULLS, HULL_MAX_VERTS, HULL_MAX_FACES, HULL_MAX_EDGES, HULL_MAX_FACE_VERTS, HULL_MAX_LOOP = 8, 32, 40, 64, 8, 160
 SCENE_FACE_MANIFOLD = 1
 CONTACT_HIST_BINS = 26
-SOLVER_COMPLIANT, SOLVER_PGS = 0, 1
+SOLVER_COMPLIANT, SOLVER_PGS, SOLVER_TGS = 0, 1, 2
 
 JOINT_ROOT, JOINT_REVOLUTE, JOINT_PRISMATIC, JOINT_WELD = 0, 1, 2, 3
 DOF_MODE_NONE, DOF_MODE_POS, DOF_MODE_VEL, DOF_MODE_EFFORT = 0, 1, 2, 3

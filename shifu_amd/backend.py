@@ -46,8 +46,10 @@ def set_solver(p: _abi.ShfSimParams, solver: str = "pgs", **kw) -> _abi.ShfSimPa
     the reference configures (shifu/configs/env_config.py:50-58: num_position_iterations 8, num_velocity_iterations 1,
     rest_offset 0, bounce_threshold_velocity 0.5; max_depenetration_velocity and contact_offset are fields of their own);
     "compliant": rounds 1-4's linearly-implicit spring-damper law (contact_k, contact_d, friction_vel)."""
-    if solver == "pgs":
-        p.solver = _abi.SOLVER_PGS
+    if solver in ("pgs", "tgs"):
+        # "tgs": physx.solver_type = 1, the reference's value (env_config.py:50): the same sweeps as sub-iterations of dt / pos_iters
+        # whose constraint errors follow the advanced motion (include/shifu_amd.h: SHF_SOLVER_TGS); "pgs": solver_type = 0
+        p.solver = _abi.SOLVER_TGS if solver == "tgs" else _abi.SOLVER_PGS
         p.pos_iters, p.vel_iters = kw.get("pos_iters", 8), kw.get("vel_iters", 1)
         p.max_contacts = kw.get("max_contacts", 8)
         # (fail here, not at the first step: the chain-mapped A1 kernels hold up to MAX_HARD_CONTACTS = 16 constraints per env, the
@@ -61,7 +63,7 @@ def set_solver(p: _abi.ShfSimParams, solver: str = "pgs", **kw) -> _abi.ShfSimPa
     elif solver == "compliant":
         p.solver = _abi.SOLVER_COMPLIANT
     else:
-        raise ValueError("solver must be 'pgs' or 'compliant'")
+        raise ValueError("solver must be 'pgs', 'tgs' or 'compliant'")
     return p
 
 
@@ -412,9 +414,10 @@ class A1Task:
         """Mangled-name prefix of the instantiation shf_a1_step launches for this sim (build resource table)."""
         g, warped = self.sim.group, bool(self.sim.terrain.warped)
         mdl = self.sim.model
-        if self.sim.params.solver == _abi.SOLVER_PGS:
+        if self.sim.params.solver != _abi.SOLVER_COMPLIANT:
             k16 = int(self.sim.params.max_contacts) > 8      # up to 16 constraints per env: the packed-response-matrix kernel
-            return f"{'_Z16k_a1_chain_pgs16' if k16 else '_Z14k_a1_chain_pgs'}ILb{int(warped)}ELb{int(bool(mdl.self_collide and mdl.npair > 0))}EE"
+            name = ("k_a1_chain_tgs" if self.sim.params.solver == _abi.SOLVER_TGS else "k_a1_chain_pgs") + ("16" if k16 else "")
+            return f"_Z{len(name)}{name}ILb{int(warped)}ELb{int(bool(mdl.self_collide and mdl.npair > 0))}EE"
         if getattr(self.sim, "mapping", "body") == "chain":
             return f"_Z10k_a1_chainILi{g}ELb{int(warped)}ELb{int(bool(mdl.self_collide and mdl.npair > 0))}EE"
         a1 = mdl.nb == 17 and mdl.nd == 12 and mdl.np == 76
@@ -497,9 +500,9 @@ class AbbTask:
         fixed = mdl.nb == 7 and mdl.np == (59 if link else 3) and self.sim.nboxes == 3
         pre = f"_Z10k_abb_stepILi{self.sim.group}E"
         if mdl.nhull > 0 or getattr(self.sim, "scene_flags", 0):     # the convex narrow phase compiled in (csrc/shf_hull.h): run-time shapes
-            hard = int(self.sim.params.solver == _abi.SOLVER_PGS)
+            hard = int(self.sim.params.solver != _abi.SOLVER_COMPLIANT)
             return f"_Z10k_abb_stepILi{32 if hard else self.sim.group}E7DynDims8DynSceneLb1ELi0ELb{hard}ELb1EE"
-        if self.sim.params.solver == _abi.SOLVER_PGS:    # the generic velocity-level solve: run-time shapes, 32 lanes per env
+        if self.sim.params.solver != _abi.SOLVER_COMPLIANT:    # the generic velocity-level solve: run-time shapes, 32 lanes per env
             if lib().shf_abb_step_pgs_is_wide(self._h):   # sixteen envs per workgroup of 512 threads
                 return f"_Z19k_abb_step_pgs_wideILb{int(link)}EE"
             return f"_Z10k_abb_stepILi32E7DynDims8DynSceneLb{int(link)}ELi0ELb1ELb0EE"

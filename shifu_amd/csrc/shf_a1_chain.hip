@@ -8,26 +8,28 @@
 template <int G, bool TW, bool SELF = false>
 __global__ __launch_bounds__(256, (G == 32 ? 2 : 1)) void k_a1_chain(A1Args A) { a1_chain_step_body<G, A1Chain, TW, SELF>(A); }
 
-// the same step under the velocity-level contact solve (ShfSimParams.solver == SHF_SOLVER_PGS; csrc/shf_chain_hard.h)
+// the same step under the velocity-level contact solve (ShfSimParams.solver == SHF_SOLVER_PGS / SHF_SOLVER_TGS; csrc/shf_chain_hard.h):
+// k_a1_chain_pgs / _tgs hold 8 constraints per env, ..16 up to 16 (ShfSimParams.max_contacts > 8: the response matrix's upper triangle, packed)
 template <bool TW, bool SELF>
 __global__ __launch_bounds__(256, 2) void k_a1_chain_pgs(A1Args A) { a1_chain_step_body<32, A1Chain, TW, SELF, true>(A); }
-// ... holding up to 16 constraints per env (ShfSimParams.max_contacts > 8): the response matrix's upper triangle, packed
 template <bool TW, bool SELF>
 __global__ __launch_bounds__(256, 2) void k_a1_chain_pgs16(A1Args A) { a1_chain_step_body<32, A1Chain, TW, SELF, true, 16>(A); }
-const void* shf_a1_chain_pgs_kernel(bool warped, bool self, bool k16) {
-  if (k16) {
-    if (self) return warped ? reinterpret_cast<const void*>(k_a1_chain_pgs16<true, true>) : reinterpret_cast<const void*>(k_a1_chain_pgs16<false, true>);
-    return warped ? reinterpret_cast<const void*>(k_a1_chain_pgs16<true, false>) : reinterpret_cast<const void*>(k_a1_chain_pgs16<false, false>);
-  }
-  if (self) return warped ? reinterpret_cast<const void*>(k_a1_chain_pgs<true, true>) : reinterpret_cast<const void*>(k_a1_chain_pgs<false, true>);
-  return warped ? reinterpret_cast<const void*>(k_a1_chain_pgs<true, false>) : reinterpret_cast<const void*>(k_a1_chain_pgs<false, false>);
+template <bool TW, bool SELF>
+__global__ __launch_bounds__(256, 2) void k_a1_chain_tgs(A1Args A) { a1_chain_step_body<32, A1Chain, TW, SELF, true, 8, true>(A); }
+template <bool TW, bool SELF>
+__global__ __launch_bounds__(256, 2) void k_a1_chain_tgs16(A1Args A) { a1_chain_step_body<32, A1Chain, TW, SELF, true, 16, true>(A); }
+#define SHF_PICK4(K, warped, self) ((self) ? ((warped) ? reinterpret_cast<const void*>(K<true, true>) : reinterpret_cast<const void*>(K<false, true>)) \
+                                           : ((warped) ? reinterpret_cast<const void*>(K<true, false>) : reinterpret_cast<const void*>(K<false, false>)))
+const void* shf_a1_chain_pgs_kernel(bool warped, bool self, bool k16, bool tgs) {
+  if (tgs) return k16 ? SHF_PICK4(k_a1_chain_tgs16, warped, self) : SHF_PICK4(k_a1_chain_tgs, warped, self);
+  return k16 ? SHF_PICK4(k_a1_chain_pgs16, warped, self) : SHF_PICK4(k_a1_chain_pgs, warped, self);
 }
 int shf_a1_chain_pgs_max_contacts(void) { return 16; }
 
 // gym.simulate (examples/a1_conditional/a1_conditional.py:69, shifu/gym/isaac_gym.py:140) of the hook path under the
 // velocity-level solve, for an A1-shaped articulation on its own (no box actors): one chain_substep_hard per call.
 // Forces at the centres of mass.
-template <bool TW, bool SELF, int KC>
+template <bool TW, bool SELF, int KC, bool TGS>
 DEV void sim_step_chain_pgs_body(const SimArgs& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   typedef A1Chain CD;
@@ -55,7 +57,7 @@ DEV void sim_step_chain_pgs_body(const SimArgs& A) {
   ChainPoints<NR> LP;
   chain_points_load<G>(m, CD::NEV, l, C.sp.contact_offset + C.sp.rest_offset, LP);
   const RowLane RL = row_lane_load<CD>(l);
-  chain_substep_hard<G, CD, TW, SELF, KC>(C, L, l, X, LP, RL, A.body_force ? A.body_force + (size_t)e * nb * 3 : nullptr, mu, L.xch);
+  chain_substep_hard<G, CD, TW, SELF, KC, TGS>(C, L, l, X, LP, RL, A.body_force ? A.body_force + (size_t)e * nb * 3 : nullptr, mu, L.xch);
   if (l < nd) {
     A.dof[((size_t)e * nd + l) * 2] = X.q;
     A.dof[((size_t)e * nd + l) * 2 + 1] = X.qd;
@@ -64,16 +66,16 @@ DEV void sim_step_chain_pgs_body(const SimArgs& A) {
   for (int i = l; i < 3 * nb; i += G) A.contact[(size_t)e * nb * 3 + i] = L.xch[i];
 }
 template <bool TW, bool SELF>
-__global__ __launch_bounds__(256, 2) void k_sim_step_chain_pgs(SimArgs A) { sim_step_chain_pgs_body<TW, SELF, 8>(A); }
+__global__ __launch_bounds__(256, 2) void k_sim_step_chain_pgs(SimArgs A) { sim_step_chain_pgs_body<TW, SELF, 8, false>(A); }
 template <bool TW, bool SELF>
-__global__ __launch_bounds__(256, 2) void k_sim_step_chain_pgs16(SimArgs A) { sim_step_chain_pgs_body<TW, SELF, 16>(A); }
-const void* shf_sim_step_chain_pgs_kernel(bool warped, bool self, bool k16) {
-  if (k16) {
-    if (self) return warped ? reinterpret_cast<const void*>(k_sim_step_chain_pgs16<true, true>) : reinterpret_cast<const void*>(k_sim_step_chain_pgs16<false, true>);
-    return warped ? reinterpret_cast<const void*>(k_sim_step_chain_pgs16<true, false>) : reinterpret_cast<const void*>(k_sim_step_chain_pgs16<false, false>);
-  }
-  if (self) return warped ? reinterpret_cast<const void*>(k_sim_step_chain_pgs<true, true>) : reinterpret_cast<const void*>(k_sim_step_chain_pgs<false, true>);
-  return warped ? reinterpret_cast<const void*>(k_sim_step_chain_pgs<true, false>) : reinterpret_cast<const void*>(k_sim_step_chain_pgs<false, false>);
+__global__ __launch_bounds__(256, 2) void k_sim_step_chain_pgs16(SimArgs A) { sim_step_chain_pgs_body<TW, SELF, 16, false>(A); }
+template <bool TW, bool SELF>
+__global__ __launch_bounds__(256, 2) void k_sim_step_chain_tgs(SimArgs A) { sim_step_chain_pgs_body<TW, SELF, 8, true>(A); }
+template <bool TW, bool SELF>
+__global__ __launch_bounds__(256, 2) void k_sim_step_chain_tgs16(SimArgs A) { sim_step_chain_pgs_body<TW, SELF, 16, true>(A); }
+const void* shf_sim_step_chain_pgs_kernel(bool warped, bool self, bool k16, bool tgs) {
+  if (tgs) return k16 ? SHF_PICK4(k_sim_step_chain_tgs16, warped, self) : SHF_PICK4(k_sim_step_chain_tgs, warped, self);
+  return k16 ? SHF_PICK4(k_sim_step_chain_pgs16, warped, self) : SHF_PICK4(k_sim_step_chain_pgs, warped, self);
 }
 size_t shf_sim_step_chain_pgs_lds_bytes(bool self) { return ((size_t)CHAIN_MODEL_WORDS + 8 * (size_t)chain_lds_words<A1Chain>(0, self)) * 4; }
 

@@ -64,9 +64,9 @@ struct ShfA1Task {
 bool shf_a1_chain_matches(const ShfModel& m);
 size_t shf_a1_chain_lds_bytes(int G, int nobs, bool self);
 const void* shf_a1_chain_kernel(int G, bool warped, bool self);
-const void* shf_a1_chain_pgs_kernel(bool warped, bool self, bool k16);
+const void* shf_a1_chain_pgs_kernel(bool warped, bool self, bool k16, bool tgs);
 int shf_a1_chain_pgs_max_contacts(void);
-const void* shf_sim_step_chain_pgs_kernel(bool warped, bool self, bool k16);
+const void* shf_sim_step_chain_pgs_kernel(bool warped, bool self, bool k16, bool tgs);
 size_t shf_sim_step_chain_pgs_lds_bytes(bool self);
 #ifdef SHF_PHASE_CLOCK
 int shf_a1_chain_phase_cycles(unsigned long long* out, int n, int reset);
@@ -106,7 +106,7 @@ static size_t sim_lds_bytes(const ShfSim* s, int head_words, int min_tail, bool 
   const int nbx = boxes ? s->nboxes : 0;
   int nslots = s->model.np + (boxes ? box_slot_count(nbx, sim_ndyn(s), s->model.nsph) : 0) + (sim_self(s) ? SHF_MAX_SELF_CONTACTS : 0) +
                ((boxes && sim_link(s)) ? 2 * SHF_MAX_LINK_CONTACTS : 0);
-  if (s->sp.solver == SHF_SOLVER_PGS) nslots = hard_total_slots(nslots, boxes && sim_link(s));
+  if (s->sp.solver != SHF_SOLVER_COMPLIANT) nslots = hard_total_slots(nslots, boxes && sim_link(s));
   return ((size_t)MODEL_WORDS + head_words + (boxes ? SCENE_WORDS : 0) +
           (size_t)epb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, min_tail, 1 + (boxes ? nbx : s->nboxes))) * 4;
 }
@@ -449,7 +449,7 @@ extern "C" int shf_sim_step(ShfSim* sim, void* stream) {
     // a scene with ShfScene.flags or hulls: the run-time-shaped kernels with the convex narrow phase compiled in (csrc/shf_hull.h)
     if (!sim_link(sim) || sim_self(sim)) return fail("shf_sim_step: scene flags / hulls need link contacts (ShfModel.link_collide) and no self-collision");
     if (sim->terr.warped) return fail("shf_sim_step: trimesh terrain with box actors is not supported");
-    if (sim->sp.solver == SHF_SOLVER_PGS) {
+    if (sim->sp.solver != SHF_SOLVER_COMPLIANT) {
       if (sim->sp.max_contacts > HCK || sim->sp.pos_iters < 1) return fail("shf_sim_step: SHF_SOLVER_PGS needs pos_iters >= 1 and max_contacts <= 8");
       if (sim->model.nlevels > HG_LEV || sim->model.nb + sim->nboxes > 32) return fail("shf_sim_step: SHF_SOLVER_PGS: at most 8 tree levels and 32 bodies + box actors");
       sim->force_armed = false; sim->force_at_pos = false;
@@ -470,13 +470,13 @@ extern "C" int shf_sim_step(ShfSim* sim, void* stream) {
       default: return launch(k_sim_step<16, true, false, true, false, true>, grid, block, lds, stream, A);
     }
   }
-  if (sim->sp.solver == SHF_SOLVER_PGS) {
+  if (sim->sp.solver != SHF_SOLVER_COMPLIANT) {
     // the velocity-level contact solve: built for A1-shaped articulations on their own (csrc/shf_chain_hard.h)
     if (sim->sp.max_contacts > shf_a1_chain_pgs_max_contacts() || sim->sp.pos_iters < 1) return fail("shf_sim_step: SHF_SOLVER_PGS needs pos_iters >= 1 and max_contacts <= 16");
     sim->force_armed = false;
     sim->force_at_pos = false;
     if (sim->nboxes == 0 && shf_a1_chain_matches(sim->model) && !A.body_force_pos)
-      return launch_ptr(shf_sim_step_chain_pgs_kernel(sim->terr.warped != 0, sim_self(sim), sim->sp.max_contacts > HCK), dim3((sim->n + 7) / 8), dim3(256), shf_sim_step_chain_pgs_lds_bytes(sim_self(sim)), stream, A);
+      return launch_ptr(shf_sim_step_chain_pgs_kernel(sim->terr.warped != 0, sim_self(sim), sim->sp.max_contacts > HCK, sim->sp.solver == SHF_SOLVER_TGS), dim3((sim->n + 7) / 8), dim3(256), shf_sim_step_chain_pgs_lds_bytes(sim_self(sim)), stream, A);
     if (sim->sp.max_contacts > HCK) return fail("shf_sim_step: more than 8 constraints per env (ShfSimParams.max_contacts) are held by the chain-mapped A1 kernels only");
     // any other articulation / a scene with box actors: the body-per-lane sub-step with the generic solve (csrc/shf_hard.h), 32 lanes per env
     if (sim->model.nlevels > HG_LEV) return fail("shf_sim_step: SHF_SOLVER_PGS walks trees of at most 8 levels");
@@ -760,13 +760,13 @@ static int a1_step_launch(ShfA1Task* task, const float* raw_actions_dev, void* s
   dim3 grid((s->n + epb - 1) / epb), block(256);
   const size_t lds = sim_lds_bytes(s, TASK_WORDS + STATS_LDS_WORDS, SCR_OBS + nobs);
   int r;
-  if (s->sp.solver == SHF_SOLVER_PGS) {
+  if (s->sp.solver != SHF_SOLVER_COMPLIANT) {
     // the velocity-level contact solve: the chain mapping at two envs per wavefront (csrc/shf_chain_hard.h)
     if (s->mapping != SHF_MAP_CHAIN || s->chain_group != 32 || !shf_a1_chain_matches(s->model))
       return fail("shf_a1_step: ShfSimParams.solver = SHF_SOLVER_PGS runs on the chain mapping at 32 lanes per env (shf_sim_set_mapping)");
     if (s->sp.max_contacts > shf_a1_chain_pgs_max_contacts()) return fail("shf_a1_step: the fused A1 step's solve holds at most 16 constraints per env (ShfSimParams.max_contacts)");
     if (s->sp.pos_iters < 1) return fail("shf_a1_step: ShfSimParams.pos_iters must be >= 1 with SHF_SOLVER_PGS");
-    return launch_ptr(shf_a1_chain_pgs_kernel(s->terr.warped != 0, sim_self(s), s->sp.max_contacts > HCK), dim3((s->n + 7) / 8), block, shf_a1_chain_lds_bytes(32, nobs, sim_self(s)), stream, A);
+    return launch_ptr(shf_a1_chain_pgs_kernel(s->terr.warped != 0, sim_self(s), s->sp.max_contacts > HCK, s->sp.solver == SHF_SOLVER_TGS), dim3((s->n + 7) / 8), block, shf_a1_chain_lds_bytes(32, nobs, sim_self(s)), stream, A);
   }
   if (s->mapping == SHF_MAP_CHAIN) {
     if (!shf_a1_chain_matches(s->model)) return fail("shf_a1_step: the articulation does not fit the chain mapping");
@@ -918,7 +918,7 @@ static bool abb_pgs_wide(const ShfSim* s, size_t* env_bytes, size_t* head_bytes)
   return *head_bytes + 16 * *env_bytes <= cu && 2 * (*head_bytes + 8 * *env_bytes) > cu;
 }
 extern "C" int shf_abb_step_pgs_is_wide(const ShfAbbTask* task) {
-  if (!task || !task->sim || task->sim->sp.solver != SHF_SOLVER_PGS) return 0;
+  if (!task || !task->sim || task->sim->sp.solver == SHF_SOLVER_COMPLIANT) return 0;
   size_t a, b;
   return abb_pgs_wide(task->sim, &a, &b) ? 1 : 0;
 }
@@ -930,7 +930,7 @@ static int abb_step_launch(ShfAbbTask* task, const float* raw_actions_dev, void*
     // a scene with ShfScene.flags or hulls: the run-time-shaped step with the convex narrow phase compiled in (csrc/shf_hull.h)
     if (!sim_link(s)) return fail("shf_abb_step: scene flags / hulls need link contacts (ShfModel.link_collide)");
     if (s->mapping != SHF_MAP_BODY) return fail("shf_abb_step: scene flags / hulls run on the body mapping (shf_sim_set_mapping(SHF_MAP_BODY))");
-    if (s->sp.solver == SHF_SOLVER_PGS) {
+    if (s->sp.solver != SHF_SOLVER_COMPLIANT) {
       if (s->sp.max_contacts > HCK || s->sp.pos_iters < 1) return fail("shf_abb_step: SHF_SOLVER_PGS needs pos_iters >= 1 and max_contacts <= 8");
       if (s->model.nlevels > HG_LEV || s->model.nb + s->nboxes > 32) return fail("shf_abb_step: SHF_SOLVER_PGS: at most 8 tree levels and 32 bodies + box actors");
       size_t env_bytes, head_bytes;
@@ -948,7 +948,7 @@ static int abb_step_launch(ShfAbbTask* task, const float* raw_actions_dev, void*
       default: return launch(k_abb_step<16, DynDims, DynScene, true, 0, false, true>, gridx, blockx, ldsx, stream, A);
     }
   }
-  if (s->sp.solver == SHF_SOLVER_PGS) {
+  if (s->sp.solver != SHF_SOLVER_COMPLIANT) {
     // the velocity-level contact solve: the run-time-shaped body-per-lane step at 32 lanes per env (csrc/shf_hard.h)
     if (s->sp.max_contacts > HCK || s->sp.pos_iters < 1) return fail("shf_abb_step: SHF_SOLVER_PGS needs pos_iters >= 1 and max_contacts <= 8");
     if (s->model.nlevels > HG_LEV || s->model.nb + s->nboxes > 32) return fail("shf_abb_step: SHF_SOLVER_PGS: at most 8 tree levels and 32 bodies + box actors");

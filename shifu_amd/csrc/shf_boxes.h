@@ -692,7 +692,7 @@ DEV bool box_box_edge(const float* RA, const float* cA, const float* hA, const f
 template <int G>
 DEV int self_contacts_eval(const StepCtx& C, const EnvLds& L, int l, int slot0, float mu_shape) {
   const ShfModel* m = C.m;
-  const bool hard = C.sp.solver == SHF_SOLVER_PGS;     // candidates only (slot_eval)
+  const bool hard = C.sp.solver != SHF_SOLVER_COMPLIANT;     // candidates only (slot_eval)
   const float dt = C.sp.dt, kc = hard ? -1.0f : C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
   const float offset = hard ? C.sp.contact_offset + C.sp.rest_offset : C.sp.contact_offset;
   const float beta = hard ? C.sp.rest_offset : fmaf(kc, dt, C.sp.contact_d);
@@ -956,7 +956,7 @@ DEV int link_contacts(const StepCtx& C, const EnvLds& L, int l, int slot0, float
   const ShfModel* m = C.m;
   const SceneDev* S = C.scene;
   const int nb = m->nb, nbx = S->nboxes;
-  const bool hard = C.sp.solver == SHF_SOLVER_PGS;     // candidates only (slot_eval); family B by signed distance
+  const bool hard = C.sp.solver != SHF_SOLVER_COMPLIANT;     // candidates only (slot_eval); family B by signed distance
   const float dt = C.sp.dt, kc = hard ? -1.0f : C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
   const float offset = hard ? C.sp.contact_offset + C.sp.rest_offset : C.sp.contact_offset;
   const float beta = hard ? C.sp.rest_offset : fmaf(kc, dt, C.sp.contact_d);

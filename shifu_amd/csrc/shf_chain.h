@@ -807,12 +807,13 @@ DEV void chain_body_states(const ShfModel* m, const ChainLds& L, int l, const Do
 
 // ShifuVecEnv.step for the A1 task (env.py:85-106) on the chain mapping; the task glue after the physics is shared
 // with the body-mapped kernel (a1_post_step, shf_task.h).
-template <int G, class CD, bool TW, bool SELF, int KC>
+template <int G, class CD, bool TW, bool SELF, int KC, bool TGS>
 DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane& X, const ChainPoints<(CD::NEV + G - 1) / G>& P,
                             const RowLane& RL, const float* fext, float mu_shape, float* contact_out);   // shf_chain_hard.h
 // HARD: the velocity-level contact solve (ShfSimParams.solver == SHF_SOLVER_PGS, csrc/shf_chain_hard.h)
 // KC: constraints the solve holds per env (8: response matrix in full inside the contact-slot region; 16: its upper triangle, packed)
-template <int G, class CD, bool TW, bool SELF = false, bool HARD = false, int KC = 8>
+// TGS: ShfSimParams.solver = SHF_SOLVER_TGS, the sub-stepped sweeps (its own instantiations: the PGS kernels keep their code)
+template <int G, class CD, bool TW, bool SELF = false, bool HARD = false, int KC = 8, bool TGS = false>
 DEV void a1_chain_step_body(const A1Args& A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NLK = CD::NLK, nb = CD::NB, nd = CD::ND, NR = (CD::NEV + G - 1) / G;
@@ -897,7 +898,7 @@ DEV void a1_chain_step_body(const A1Args& A) {
       X.tau = rclampf(t, -lim_, lim_);
     }
     if constexpr (HARD)
-      chain_substep_hard<G, CD, TW, SELF, KC>(C, L, l, X, LP, RL, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
+      chain_substep_hard<G, CD, TW, SELF, KC, TGS>(C, L, l, X, LP, RL, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,
                                     (it == nsub - 1) ? L.xch : nullptr);
     else
       chain_substep<G, CD, TW, SELF>(C, L, l, X, LP, mine, RL, (it == tp.decimation) ? A.push + (size_t)e * nb * 3 : nullptr, mu,

@@ -262,7 +262,7 @@ DEV void chain_hard_apply(const ShfModel* m, const ChainLds& L, float* tail, int
 }
 
 // One gym.simulate() for one env under the velocity-level contact solve; lane roles as chain_substep at 32 lanes per env.
-template <int G, class CD, bool TW, bool SELF, int KC>
+template <int G, class CD, bool TW, bool SELF, int KC, bool TGS>
 DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane& X, const ChainPoints<(CD::NEV + G - 1) / G>& P,
                             const RowLane& RL, const float* fext, float mu_shape, float* contact_out) {
   static_assert(G == 32, "the velocity-level solve is written for two envs per wavefront");
@@ -690,6 +690,8 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
       const float vn0 = dot3(n, vs);
       if (C.sp.restitution > 0.0f && vn0 < -C.sp.bounce_threshold) { tg = rmaxf(tg, -(C.sp.restitution * vn0)); tv = rmaxf(tv, -(C.sp.restitution * vn0)); }
       O.tgt = tg; O.tgt_v = tv;
+      O.gap = phi;
+      O.rfloor = (C.sp.restitution > 0.0f && vn0 < -C.sp.bounce_threshold) ? -(C.sp.restitution * vn0) : -1e30f;
     };
     if constexpr (T::PACKED) owner_velocities();
     if constexpr (T::PACKED) GROUP_SYNC();     // (every owner has read its poses and rates: their place may take blocks of W)
@@ -835,12 +837,16 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
         for (int r = 0; r < 3; r++) O.u[r] = fmaf(Wb[3 * r + 2], dp2, fmaf(Wb[3 * r + 1], dp1, fmaf(Wb[3 * r], dp0, O.u[r])));
       }
     };
+    const HardTgs TG = hard_tgs(C.sp, npos);      // SHF_SOLVER_TGS: sub-stepped sweeps (csrc/shf_hard.h); compiled in when TGS
+    float psum[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll 1
     for (int phase = 0; phase < 2; phase++) {
       const int sweeps = phase == 0 ? npos : nvel;
-      const float tg = phase == 0 ? O.tgt : O.tgt_v;
+      float tg = phase == 0 ? O.tgt : O.tgt_v;
+      if constexpr (TGS) { if (phase == 1) tg = hard_tgs_target_vel(TG, O); }
 #pragma unroll 1
       for (int it = 0; it < sweeps; it++) {
+        if constexpr (TGS) { if (phase == 0) tg = hard_tgs_target_pos(TG, O); }
         if constexpr (T::PACKED) {
 #pragma unroll 1
           for (int c = 0; c < Kw; c++) visit(c, tg);       // (a loop: sixteen unrolled visits would not fit the instruction cache)
@@ -851,14 +857,23 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
             visit(c, tg);
           }
         }
+        if constexpr (TGS) {
+          if (phase == 0) {
+            O.gap = fmaf(TG.hN, O.u[0], O.gap);
+#pragma unroll
+            for (int r = 0; r < 3; r++) psum[r] += O.p[r];
+          }
+        }
       }
       if (phase == 1 && nvel == 0) break;
       if (own) {
         // the impulses of this phase in world axes, for the pass through the tree
         float* h = tail + T::HC + l * HC_STRIDE;
         float pw[3];
+        const bool mean = TGS && phase == 0;
+        const float q0 = mean ? psum[0] * TG.inv_n : O.p[0], q1 = mean ? psum[1] * TG.inv_n : O.p[1], q2 = mean ? psum[2] * TG.inv_n : O.p[2];
 #pragma unroll
-        for (int r = 0; r < 3; r++) pw[r] = fmaf(O.p[2], h[HC_T2 + r], fmaf(O.p[1], h[HC_T1 + r], O.p[0] * h[HC_N + r]));
+        for (int r = 0; r < 3; r++) pw[r] = fmaf(q2, h[HC_T2 + r], fmaf(q1, h[HC_T1 + r], q0 * h[HC_N + r]));
         if (phase == 0) { h[HC_P] = pw[0]; h[HC_P + 1] = pw[1]; h[HC_P + 2] = pw[2]; }
         else { h[HC_PV0] = pw[0]; h[HC_PV1] = pw[1]; h[HC_PV2] = pw[2]; }
       }

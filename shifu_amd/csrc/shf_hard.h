@@ -117,7 +117,28 @@ DEV void root_factors_apply(const float* o, const float* pA, float* x) {   // ld
 // Per-lane state of the solve: the owner lane of contact c; velocity u and impulse p in the contact frame (n, t1, t2)
 struct HardOwner {
   float mu, u[3], p[3], tgt, tgt_v, w10, w20, iwnn, Ti[3], rt;
+  float gap, rfloor;      // SHF_SOLVER_TGS: the contact's gap as the sub-iterations advance it; the restitution floor of its target (or -1e30)
 };
+// SHF_SOLVER_TGS (physx.solver_type = 1, shifu/configs/env_config.py:50; oracle: hard_solve "tgs"): the position iterations as
+// sub-iterations of h = dt / npos -- targets from the gaps as they stand (horizon h), gaps advanced by the normal velocities each
+// sweep leaves, the poses moved by the mean of the impulses after the sweeps; velocity iterations against what is left (horizon dt).
+struct HardTgs { bool on; float hN, ihN, inv_n, idt, erp, vdep; };
+DEV HardTgs hard_tgs(const ShfSimParams& sp, int npos) {
+  HardTgs T;
+  T.on = sp.solver == SHF_SOLVER_TGS && npos > 0;
+  const float dt = sp.dt, idt = 1.0f / dt;
+  T.hN = T.on ? dt / (float)npos : dt;
+  T.ihN = T.on ? (float)npos * idt : idt;
+  T.inv_n = T.on ? 1.0f / (float)npos : 1.0f;
+  T.idt = idt;
+  T.erp = sp.erp > 0.0f ? sp.erp : 0.2f;
+  T.vdep = sp.max_depen_vel;
+  return T;
+}
+DEV float hard_tgs_target_pos(const HardTgs& T, const HardOwner& O) {
+  return rmaxf(O.gap >= 0.0f ? -(O.gap * T.ihN) : rminf(T.erp * -(O.gap) * T.ihN, T.vdep), O.rfloor);
+}
+DEV float hard_tgs_target_vel(const HardTgs& T, const HardOwner& O) { return rmaxf(O.gap >= 0.0f ? -(O.gap * T.idt) : 0.0f, O.rfloor); }
 // owner lane: targets from the gap, the regularised diagonal block of W (written back) and its inverses (oracle: hard_solve,
 // "free velocities, targets, block inverses").  vs: start-of-step relative velocity, vf: under v_free (world axes).
 DEV void hard_owner_setup(const ShfSimParams& sp, const float* h, const float* vs, const float* vf, float* Wd, bool own, float idt, HardOwner& O) {
@@ -133,6 +154,8 @@ DEV void hard_owner_setup(const ShfSimParams& sp, const float* h, const float* v
   const float vn0 = dot3(n, vs);
   if (sp.restitution > 0.0f && vn0 < -sp.bounce_threshold) { tg = rmaxf(tg, -(sp.restitution * vn0)); tv = rmaxf(tv, -(sp.restitution * vn0)); }
   O.tgt = tg; O.tgt_v = tv;
+  O.gap = phi;
+  O.rfloor = (sp.restitution > 0.0f && vn0 < -sp.bounce_threshold) ? -(sp.restitution * vn0) : -1e30f;
   float A[9];
 #pragma unroll
   for (int k = 0; k < 9; k++) A[k] = Wd[k];
@@ -153,7 +176,9 @@ DEV void hard_owner_setup(const ShfSimParams& sp, const float* h, const float* v
 // Projected Gauss-Seidel at 32 lanes per env (two envs per wavefront): lane c < K owns contact c.  Position iterations,
 // then velocity iterations; after each phase the owner writes its impulse in world axes into the record (HC_P / HC_PV).
 // W: blocks (i, j) at W + (j * HCK + i) * 9.  oracle: hard_solve, "sweeps".
-DEV void hard_sweeps(HardOwner& O, float* hc, const float* W, int l, int K, int npos, int nvel) {
+DEV void hard_sweeps(HardOwner& O, float* hc, const float* W, int l, int K, int npos, int nvel, const ShfSimParams& sp) {
+  const HardTgs TG = hard_tgs(sp, npos);
+  float psum[3] = {0.0f, 0.0f, 0.0f};
   const int lane0 = (int)(threadIdx.x & 63u) - l;
   const bool own = l < K;
   int Kw = 0;      // the larger constraint count of the wavefront's envs (wave-uniform)
@@ -165,9 +190,11 @@ DEV void hard_sweeps(HardOwner& O, float* hc, const float* W, int l, int K, int 
 #pragma unroll 1
   for (int phase = 0; phase < 2; phase++) {
     const int sweeps = phase == 0 ? npos : nvel;
-    const float tg = phase == 0 ? O.tgt : O.tgt_v;
+    float tg = phase == 0 ? O.tgt : O.tgt_v;
+    if (TG.on && phase == 1) tg = hard_tgs_target_vel(TG, O);
 #pragma unroll 1
     for (int it = 0; it < sweeps; it++) {
+      if (TG.on && phase == 0) tg = hard_tgs_target_pos(TG, O);
 #pragma unroll 1
       for (int c = 0; c < Kw; c++) {
         // an open, unloaded contact whose normal velocity keeps it open asks for nothing (oracle: the same test): when that is
@@ -205,13 +232,20 @@ DEV void hard_sweeps(HardOwner& O, float* hc, const float* W, int l, int K, int 
           for (int r = 0; r < 3; r++) O.u[r] = fmaf(Wb[3 * r + 2], dp2, fmaf(Wb[3 * r + 1], dp1, fmaf(Wb[3 * r], dp0, O.u[r])));
         }
       }
+      if (TG.on && phase == 0) {
+        O.gap = fmaf(TG.hN, O.u[0], O.gap);
+#pragma unroll
+        for (int r = 0; r < 3; r++) psum[r] += O.p[r];
+      }
     }
     if (phase == 1 && nvel == 0) break;
     if (own) {
       float* h = hc + l * HC_STRIDE;
       float pw[3];
+      const bool mean = TG.on && phase == 0;
+      const float q0 = mean ? psum[0] * TG.inv_n : O.p[0], q1 = mean ? psum[1] * TG.inv_n : O.p[1], q2 = mean ? psum[2] * TG.inv_n : O.p[2];
 #pragma unroll
-      for (int r = 0; r < 3; r++) pw[r] = fmaf(O.p[2], h[HC_T2 + r], fmaf(O.p[1], h[HC_T1 + r], O.p[0] * h[HC_N + r]));
+      for (int r = 0; r < 3; r++) pw[r] = fmaf(q2, h[HC_T2 + r], fmaf(q1, h[HC_T1 + r], q0 * h[HC_N + r]));
       if (phase == 0) { h[HC_P] = pw[0]; h[HC_P + 1] = pw[1]; h[HC_P + 2] = pw[2]; }
       else { h[HC_PV0] = pw[0]; h[HC_PV1] = pw[1]; h[HC_PV2] = pw[2]; }
     }
@@ -604,7 +638,7 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
     GROUP_SYNC();
     // ---- sweeps
     PHASE_MARK(35);
-    hard_sweeps(O, hc, W, l, K, npos, nvel);
+    hard_sweeps(O, hc, W, l, K, npos, nvel, C.sp);
     GROUP_SYNC();
     PHASE_MARK(36);
     // ---- the impulses through the tree, both sets (oracle: hc_apply)

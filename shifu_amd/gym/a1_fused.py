@@ -89,7 +89,7 @@ class FusedA1Env:
         # "compliant" = rounds 1-4's spring-damper law (the default on another lane mapping / width)
         if solver is None:
             solver = "pgs" if (mapping in (None, "chain") and group in (None, 32)) else "compliant"
-        self.solver = solver if sim_params is None else ("pgs" if sim_params.solver == _abi.SOLVER_PGS else "compliant")
+        self.solver = solver if sim_params is None else {_abi.SOLVER_PGS: "pgs", _abi.SOLVER_TGS: "tgs"}.get(sim_params.solver, "compliant")
         self.sim_params = sim_params or default_sim_params(dt=dt, solver=solver, **(solver_kw or {}))
         self.dt = dt * decimation                                         # isaac_gym.py:26
         self.sim = Sim(self.sim_params, self.device)

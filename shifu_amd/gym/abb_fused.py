@@ -65,7 +65,7 @@ class FusedAbbEnv:
             scene = not extra_boxes
             mapping = "split" if (scene and group == 16) else "chain" if (scene and not link_contacts and group == 32) else "body"
         self.solver = solver
-        if solver == "pgs":
+        if solver in ("pgs", "tgs"):
             group, mapping = 32, "body"
         if mapping == "chain" and self.link_contacts:
             raise ValueError("FusedAbbEnv: mapping='chain' is compiled for the rod-only scene; with link_contacts=True use "

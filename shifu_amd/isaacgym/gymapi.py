@@ -249,11 +249,11 @@ class Gym:
         "max_gpu_contact_pairs": "contact candidates are fixed per articulation (SHF_MAX_POINTS), no pair buffer",
         "default_buffer_size_multiplier": "no PhysX buffers",
     }
-    # honoured since round 5 (ShfSimParams.solver = SHF_SOLVER_PGS, the velocity-level contact solve): solver_type (PGS and TGS
-    # both map to the projected Gauss-Seidel solve -- TGS is PhysX's sub-stepped variant of it), num_position_iterations,
-    # num_velocity_iterations, contact_offset, rest_offset, bounce_threshold_velocity, max_depenetration_velocity
-    # (shifu/configs/env_config.py:50-58).  Scenes the solve is not built for yet (box actors, other tree
-    # shapes) keep rounds 1-4's compliant law and say so once at prepare_sim.
+    # honoured (the velocity-level contact solve, include/shifu_amd.h): solver_type (1 = TGS -> SHF_SOLVER_TGS, the sub-stepped
+    # sweeps, round 6; 0 = PGS -> SHF_SOLVER_PGS), num_position_iterations, num_velocity_iterations, contact_offset, rest_offset,
+    # bounce_threshold_velocity, max_depenetration_velocity (shifu/configs/env_config.py:50-58).  A scene beyond the solve's
+    # limits (more than 32 bodies + box actors, trees deeper than 8 levels, several articulations) keeps rounds 1-4's compliant
+    # law and says so once at prepare_sim, with the reason.
     SOLVER_PHYSX_FIELDS = ("solver_type", "num_position_iterations", "num_velocity_iterations", "rest_offset", "bounce_threshold_velocity")
     _warned_physx = False
     _warned_compliant = False
@@ -423,17 +423,32 @@ class Gym:
         if probe is not None:
             probe.self_collide = int(bool(getattr(arts[0], "self_collide", False)) and probe.npair > 0 and
                                      os.environ.get("SHIFU_AMD_SELF_COLLISION", "1") != "0")
-        pgs = (probe is not None and os.environ.get("SHIFU_AMD_SOLVER", "pgs") != "compliant" and
-               lib().shf_model_pgs_supported(C.byref(probe), len(env0.actors) - 1) == 1 and int(p.physx.num_position_iterations) >= 1)
-        solver_kw = dict(solver="pgs", pos_iters=int(p.physx.num_position_iterations), vel_iters=int(p.physx.num_velocity_iterations),
-                         rest_offset=float(p.physx.rest_offset), bounce_threshold=float(p.physx.bounce_threshold_velocity)) if pgs else {}
+        # physx.solver_type: 1 = temporal Gauss-Seidel, the reference's value (env_config.py:50) -> SHF_SOLVER_TGS; 0 -> SHF_SOLVER_PGS;
+        # SHIFU_AMD_SOLVER = tgs | pgs | compliant overrides.  The compliant law is the fallback, with the actual reason said once.
+        want = os.environ.get("SHIFU_AMD_SOLVER", "tgs" if int(getattr(p.physx, "solver_type", 1)) == 1 else "pgs")
+        reason = None
+        if want == "compliant":
+            reason = "SHIFU_AMD_SOLVER=compliant"
+        elif probe is None:
+            reason = f"{len(arts)} articulations per env (the solve is built for one)"
+        elif int(p.physx.num_position_iterations) < 1:
+            reason = f"physx.num_position_iterations = {int(p.physx.num_position_iterations)} (the solve needs at least one)"
+        elif lib().shf_model_pgs_supported(C.byref(probe), len(env0.actors) - 1) != 1:
+            reason = (f"{probe.nb} bodies + {len(env0.actors) - 1} box actors, {probe.nlevels} tree levels: beyond the generic solve's limits "
+                      "(32 bodies + box actors, 8 levels; csrc/shf_hard.h)")
+        pgs = reason is None
+        # max_contacts is not a PhysX field: the 8 deepest candidates per env everywhere by default (a walking A1 offers more in 1e-6 of
+        # its sub-steps, profiles/r06_play_a1_*.json); SHIFU_AMD_MAX_CONTACTS raises it to up to 16 for an A1 on its own
+        solver_kw = dict(solver=("tgs" if want == "tgs" else "pgs"), pos_iters=int(p.physx.num_position_iterations),
+                         vel_iters=int(p.physx.num_velocity_iterations), rest_offset=float(p.physx.rest_offset),
+                         bounce_threshold=float(p.physx.bounce_threshold_velocity),
+                         max_contacts=int(os.environ.get("SHIFU_AMD_MAX_CONTACTS", "8"))) if pgs else {}
         if not pgs and not Gym._warned_compliant:
             Gym._warned_compliant = True
             import warnings
-            warnings.warn("shifu_amd: this scene runs the compliant contact law of rounds 1-4 -- the velocity-level solve that honours "
-                          "sim_params.physx." + " / ".join(Gym.SOLVER_PHYSX_FIELDS) + " is built for a single A1-shaped articulation "
-                          "without box actors (csrc/shf_chain_hard.h)", stacklevel=2)
-        sim.solver = "pgs" if pgs else "compliant"
+            warnings.warn("shifu_amd: this scene runs the compliant contact law of rounds 1-4 instead of the velocity-level solve that "
+                          "honours sim_params.physx." + " / ".join(Gym.SOLVER_PHYSX_FIELDS) + ": " + reason, stacklevel=2)
+        sim.solver = solver_kw["solver"] if pgs else "compliant"
         sp = default_sim_params(dt=p.dt, gravity=tuple(p.gravity),
                                 max_depen_vel=min(float(p.physx.max_depenetration_velocity), 10.0),
                                 contact_offset=float(p.physx.contact_offset), **solver_kw)

@@ -25,8 +25,8 @@ def sim_params(dt=0.005, gravity=(0.0, 0.0, -9.81), **kw):
     p.contact_offset = kw.get("contact_offset", 0.01)
     # contact solver (ABI v12): "compliant" = rounds 1-4's law (what the known answers of tests/test_contact_kats.py are about);
     # "pgs" = the velocity-level solve with the reference's PhysX settings (env_config.py:50-58)
-    if kw.get("solver", "compliant") == "pgs":
-        p.solver = _abi.SOLVER_PGS
+    if kw.get("solver", "compliant") in ("pgs", "tgs"):
+        p.solver = _abi.SOLVER_TGS if kw.get("solver") == "tgs" else _abi.SOLVER_PGS
         p.pos_iters, p.vel_iters = kw.get("pos_iters", 8), kw.get("vel_iters", 1)
         p.max_contacts = kw.get("max_contacts", 8)
         p.rest_offset = kw.get("rest_offset", 0.0)

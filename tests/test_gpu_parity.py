@@ -1771,3 +1771,78 @@ def test_hard_contact_kats_on_the_gpu(oracle):
     tr = _kat_run(oracle, K.ball_model(), H.sim_params(solver="pgs"), nodof, K.root_row((0, 0, 0.55)), 400, group=32)[0]
     z, vz = tr[:, 2] - 0.05, tr[:, 9]
     assert abs(z[-1]) < 1e-4 and np.abs(vz[-50:]).max() < 1e-5 and z.min() > -2e-3       # rests ON the surface: no sag
+
+
+@pytest.mark.parametrize("kmax", [8, 16])
+@pytest.mark.parametrize("rough", [False, True])
+def test_fused_a1_step_under_tgs_matches_oracle_bitwise(oracle, rough, kmax):
+    """ShfSimParams.solver = SHF_SOLVER_TGS (physx.solver_type = 1, the reference's value: shifu/configs/env_config.py:50): the
+    sweeps as sub-iterations of dt / 8 -- targets from the gaps as they stand, gaps advanced after every sweep, the poses moved by
+    the mean of the impulses -- on the chain-mapped A1 kernels (8 and 16 constraints per env) against the oracle: every tensor,
+    120 vec-steps with falls and resets."""
+    _need_gpu()
+    n = 96
+    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, rough, group="chain32", env_off=2000, solver="tgs", max_contacts=kmax)
+    assert sp.solver == _abi.SOLVER_TGS and task.kernel_symbol().startswith("_Z16k_a1_chain_tgs16" if kmax > 8 else "_Z14k_a1_chain_tgsI")
+    resets = 0
+    for it in range(120):
+        raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32) * 1.5
+        slot = task.step(torch.from_numpy(raw).cuda())
+        oracle.a1_step(cm.blob, sp, tp, n, 2000, bufs, raw, terrain=terr, heights=hs)
+        _compare(sim, task, bufs, f"step {it}")
+        np.testing.assert_array_equal(task.tensors[_abi.A1_STATS][slot].cpu().numpy(), oracle.a1_stats(tp, n, bufs["done_sums"]), err_msg=f"stats step {it}")
+        resets += int(bufs["reset"].sum())
+    assert resets > n // 4 and np.isfinite(bufs["obs"]).all() and np.abs(bufs["contact"]).max() > 10.0
+    # ... and it is a different computation from SHF_SOLVER_PGS on the same inputs
+    cm2, sp2, tp2, terr2, hs2, bufs2, sim2, task2, rng2 = _a1_setup(n, rough, group="chain32", env_off=2000, solver="pgs", max_contacts=kmax)
+    raw = (2 * rng2.random((n, cm.blob.nd)) - 1).astype(np.float32)
+    b_t, b_p = {k: v.copy() for k, v in bufs.items()}, {k: v.copy() for k, v in bufs.items()}      # (from the run's end state: feet on the ground)
+    oracle.a1_step(cm.blob, sp, tp, n, 2000, b_t, raw, terrain=terr, heights=hs)
+    oracle.a1_step(cm.blob, sp2, tp, n, 2000, b_p, raw, terrain=terr, heights=hs)
+    assert not np.array_equal(b_t["root_state"], b_p["root_state"])
+
+
+def test_fused_a1_step_under_tgs_at_full_size(oracle):
+    """... at BASELINE's env count: 4096 envs x 30 vec-steps under SHF_SOLVER_TGS, every tensor bit for bit."""
+    _need_gpu()
+    n = 4096
+    cm, sp, tp, terr, hs, bufs, sim, task, rng = _a1_setup(n, True, seed=91, group="chain32", env_off=8192, solver="tgs")
+    bufs["ep_len"][:] = rng.integers(900, 1001, n)
+    _upload(sim, task, bufs)
+    resets = 0
+    for it in range(30):
+        raw = (2 * rng.random((n, cm.blob.nd)) - 1).astype(np.float32)
+        slot = task.step(torch.from_numpy(raw).cuda())
+        oracle.a1_step(cm.blob, sp, tp, n, 8192, bufs, raw, terrain=terr, heights=hs)
+        if it % 10 == 9:
+            _compare(sim, task, bufs, f"step {it}")
+            np.testing.assert_array_equal(task.tensors[_abi.A1_STATS][slot].cpu().numpy(), oracle.a1_stats(tp, n, bufs["done_sums"]))
+        resets += int(bufs["reset"].sum())
+    assert resets > 100
+
+
+@pytest.mark.parametrize("link", [False, True])
+def test_fused_abb_step_under_tgs_matches_oracle_bitwise(oracle, link):
+    """... and the generic solve of the body-per-lane kernels (config 5: box actors as solver bodies, link contacts, a fixed base)
+    under SHF_SOLVER_TGS: FusedAbbEnv(solver='tgs'), 256 envs x 60 vec-steps with re-spawns, every tensor."""
+    _need_gpu()
+    from shifu_amd.gym.abb_fused import FusedAbbEnv
+    n = 256
+    env = FusedAbbEnv(num_envs=n, seed=12, link_contacts=link, solver="tgs")
+    assert env.sim_params.solver == _abi.SOLVER_TGS and env.solver == "tgs"
+    env.task.tensors[_abi.ABB_EP_LEN].copy_(torch.randint(150, 201, (n,)))
+    torch.cuda.synchronize()
+    bufs = {k: env.sim.tensors[t].cpu().numpy().copy() for k, t in _ABB_SIM_T.items()}
+    bufs.update({k: env.task.tensors[t].cpu().numpy().copy() for k, t in _ABB_T.items()})
+    rng = np.random.default_rng(6)
+    resets = 0
+    for it in range(60):
+        raw = (2 * rng.random((n, 3)) - 1).astype(np.float32)
+        env.task.step(torch.from_numpy(raw).cuda())
+        oracle.abb_step(env.cm.blob, env.sim_params, env.boxes, env.task_params, n, 0, bufs, raw)
+        resets += int(bufs["reset"].sum())
+    torch.cuda.synchronize()
+    for k, t in list(_ABB_SIM_T.items()) + list(_ABB_T.items()):
+        got = (env.sim.tensors if k in _ABB_SIM_T else env.task.tensors)[t].cpu().numpy().reshape(bufs[k].shape)
+        np.testing.assert_array_equal(got, bufs[k], err_msg=k)
+    assert resets > 20

@@ -29,8 +29,8 @@ def set_solver(sp, solver):
     """solver: 'pgs' = the velocity-level solve the reference's PhysX fields configure (env_config.py:50-58: 8 + 1 sweeps), the
     default since round 5; 'compliant' = rounds 1-4's spring-damper law"""
     from shifu_amd import _abi
-    if solver == "pgs":
-        sp.solver, sp.pos_iters, sp.vel_iters, sp.max_contacts, sp.erp = _abi.SOLVER_PGS, 8, 1, 16, 0.2
+    if solver in ("pgs", "tgs"):      # "tgs": physx.solver_type = 1, the sub-stepped sweeps (include/shifu_amd.h: SHF_SOLVER_TGS)
+        sp.solver, sp.pos_iters, sp.vel_iters, sp.max_contacts, sp.erp = (_abi.SOLVER_TGS if solver == "tgs" else _abi.SOLVER_PGS), 8, 1, 16, 0.2
     else:
         sp.solver = _abi.SOLVER_COMPLIANT
     return sp
@@ -70,12 +70,12 @@ def run_a1(kind, steps, solver="compliant"):
     cm, sp = a1_setup(solver)
     m = cm.blob
     dt = sp.dt
-    ref = HardContactStepper(m, sp, mu=1.0)
+    ref = HardContactStepper(m, sp, mu=1.0, tgs=solver == "tgs")
     # compliant model: the LOCAL comparison starts from its state, whose feet sit m g / 4 k = 0.6 mm in the ground: a stabilised
     # hard solver would spend its step pushing them out (0.2 x 0.6 mm / 5 ms = 24 mm/s), so the one-step comparison is made
     # at the velocity level (no Baumgarte term); the accumulated one uses the stabilised solver on its own trajectory.
     # pgs: both sides are the stabilised solve.
-    ref_local = HardContactStepper(m, sp, mu=1.0, baumgarte=0.0 if solver == "compliant" else 0.2)
+    ref_local = HardContactStepper(m, sp, mu=1.0, baumgarte=0.0 if solver == "compliant" else 0.2, tgs=solver == "tgs")
     # settle the shipped model on its feet first (400 sub-steps of PD hold), so that both start from a state at rest
     dof = np.zeros((m.nd, 2)); dof[:, 0] = A1_Q0
     root = np.zeros((1, 13)); root[0, 2] = 0.33; root[0, 6] = 1.0
@@ -154,8 +154,8 @@ def run_abb(steps, solver="compliant", ensemble=False):
     dof[:, 0] = q0
     tip = low_end(q0)
     root[2, :3] = (tip[0], tip[1] + 0.025 + rad + 0.03, 0.125)
-    ref = HardContactStepper(m, sp, mu=1.0, box={"dim": [0.05, 0.05, 0.05], "mass": 0.1}, box_plane_z=0.1, box_mu=0.5)
-    ref_local = HardContactStepper(m, sp, mu=1.0, box={"dim": [0.05, 0.05, 0.05], "mass": 0.1}, box_plane_z=0.1, box_mu=0.5,
+    ref = HardContactStepper(m, sp, mu=1.0, box={"dim": [0.05, 0.05, 0.05], "mass": 0.1}, box_plane_z=0.1, box_mu=0.5, tgs=solver == "tgs")
+    ref_local = HardContactStepper(m, sp, mu=1.0, box={"dim": [0.05, 0.05, 0.05], "mass": 0.1}, box_plane_z=0.1, box_mu=0.5, tgs=solver == "tgs",
                                    baumgarte=0.0 if solver == "compliant" else 0.2)
     # implicit POS drive in the reference: M~ += dt (kd + dt kp) on the diagonal, exactly the shipped joint law (the -kd qd part
     # of the torque rides on the damping term)
@@ -202,7 +202,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--out", default=None)
-    ap.add_argument("--solver", default="both", choices=("pgs", "compliant", "both"))
+    ap.add_argument("--solver", default="both", choices=("pgs", "tgs", "compliant", "both"))
     args = ap.parse_args()
     res = []
     for solver in (("pgs", "compliant") if args.solver == "both" else (args.solver,)):

@@ -22,7 +22,8 @@ def main():
     ap.add_argument("--terrain", default="heightfield", choices=["heightfield", "trimesh", "flat"])
     ap.add_argument("--traj", default=None)
     ap.add_argument("--self-collision", action="store_true", help="collide the robot's own links, as in training with the same flag")
-    ap.add_argument("--solver", choices=["pgs", "compliant"], default=None, help="contact solver (FusedA1Env(solver=...)); default: the env's")
+    ap.add_argument("--solver", choices=["pgs", "tgs", "compliant"], default=None, help="contact solver (FusedA1Env(solver=...)); default: the env's")
+    ap.add_argument("--max-contacts", type=int, default=None, help="ShfSimParams.max_contacts (pgs): 8 (default) .. 16")
     args = ap.parse_args()
     from examples.a1_conditional.task_config import A1PPOConfig
     from shifu_amd.checkpoint import TrajectoryRecorder
@@ -30,7 +31,8 @@ def main():
     from shifu_amd.rl import OnPolicyRunner
     from shifu_amd.runner.utils import class_to_dict
     env = FusedA1Env(num_envs=args.envs, terrain=args.terrain, seed=7, self_collision=args.self_collision,
-                     **({} if args.solver is None else {"solver": args.solver}))
+                     **({} if args.solver is None else {"solver": args.solver}),
+                     **({} if args.max_contacts is None else {"solver_kw": {"max_contacts": args.max_contacts}}))
     runner = OnPolicyRunner(env, class_to_dict(A1PPOConfig()), log_dir=None, device="cuda:0")
     infos = runner.load(args.checkpoint, load_optimizer=False)
     trained = (infos or {}).get("contact_solver") if isinstance(infos, dict) else None
@@ -42,6 +44,8 @@ def main():
     rec = TrajectoryRecorder(env, num_envs=8, bodies=True) if args.traj else None
     env.reset()
     obs = env.get_observations()
+    # candidate constraints per env and sub-step before the max_contacts cap, and what the cap drops (SHF_T_CONTACT_HIST)
+    hist = env.sim.bind_contact_hist(True) if env.solver in ("pgs", "tgs") else None
     lin_err = ang_err = along = speed = cmdn = 0.0
     falls = 0
     with torch.no_grad():
@@ -66,6 +70,15 @@ def main():
            "mean_lin_vel_error_m_s": lin_err / n, "mean_yaw_rate_error_rad_s": ang_err / n,
            "falls_per_env_per_1000_steps": falls / args.envs / n * 1000.0,
            "mean_reward_per_step": float(rew.mean()), "terrain_levels_mean": float(env.terrain_levels.float().mean())}
+    if hist is not None:
+        import numpy as np
+        h = hist.sum(0).cpu().numpy().astype(np.float64)
+        bins, tot = h[:-1], max(h[:-1].sum(), 1.0)
+        cap = int(env.sim_params.max_contacts) or 8
+        out.update({"max_contacts": cap, "candidates_per_substep_hist": [round(float(x), 5) for x in bins / tot],
+                    "candidates_per_substep_mean": float((bins * np.arange(len(bins))).sum() / tot),
+                    "substeps_above_cap_frac": float(bins[cap + 1:].sum() / tot),
+                    "dropped_constraints_per_env_step": float(h[-1]) / float(args.envs * args.steps)})
     if rec:
         out["trajectory"] = rec.save(args.traj)
     print(json.dumps(out))

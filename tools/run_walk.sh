@@ -10,7 +10,7 @@ MLP=${2:-torch}        # torch: stock fp32 GEMMs; mfma: csrc/shf_mlp.hip layers 
 SOLVER=${3:-pgs}       # contact solver: pgs (the reference's PhysX settings) | compliant (rounds 1-4)
 EXTRA=${4:-}            # further tools/train_a1.py flags (e.g. --torch-loss)
 TAG=$(echo "$EXTRA" | tr -d ' -')
-OUT=$REPO/gpurun_out/train_a1_r05_${MLP}_$SOLVER${TAG:+_$TAG}
+OUT=$REPO/gpurun_out/train_a1_r06_${MLP}_$SOLVER${TAG:+_$TAG}
 mkdir -p "$OUT" /tmp/train_a1
 cd "$REPO"
 python tools/train_a1.py --iters "$ITERS" --graph --quiet --mlp "$MLP" --solver "$SOLVER" $EXTRA --log /tmp/train_a1 > "$OUT/train_summary.json" 2> "$OUT/train.err"

@@ -36,7 +36,7 @@ def main():
                     help="terrain collision form (trimesh = what the reference's A1EnvConfig effectively builds, SURVEY Q5)")
     ap.add_argument("--seed", type=int, default=None, help="override A1PPOConfig.seed")
     ap.add_argument("--self-collision", action="store_true", help="collide the robot's own links (reference collision filter 0)")
-    ap.add_argument("--solver", choices=["pgs", "compliant"], default=None, help="contact solver (FusedA1Env(solver=...)); default: the env's")
+    ap.add_argument("--solver", choices=["pgs", "tgs", "compliant"], default=None, help="contact solver (FusedA1Env(solver=...)); default: the env's")
     ap.add_argument("--gpus", type=int, default=1, help="started bare with --gpus N: becomes the launcher of N ranks (one per GPU, RCCL), like bench.py")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
