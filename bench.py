@@ -305,7 +305,7 @@ def main():
             raise SystemExit("bench.py: --link-contacts contradicts --no-link-contacts / --mapping chain (compiled for the rod-only scene)")
         args.link_contacts = not (args.no_link_contacts or args.mapping == "chain")
         if args.solver is None and args.mapping is None and args.group is None:
-            args.solver = "pgs"      # FusedAbbEnv's own default: the reference's PhysX settings (generic kernel, 32 lanes per env)
+            args.solver = "tgs"      # FusedAbbEnv's own default: the reference's PhysX settings, solver_type = 1 (generic kernel, 32 lanes per env)
         if args.solver in ("pgs", "tgs"):
             mapping, group = "body", 32
         else:

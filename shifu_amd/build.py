@@ -73,7 +73,7 @@ BUDGETS = [("_Z16k_a1_step_a1_g32", 256, 0),          # default: A1, two envs pe
            ("_Z20k_sim_step_chain_pgs", 168, 0),
            # config 5 under that solve: the wave-specialised step on compile-time shapes (round 6) without spills; the run-time-shaped
            # generic kernels (any articulation / scene) as they stand: sixteen envs per 512-thread workgroup at 256 registers
-           ("_Z19k_abb_step_pgs_wide", 256, 256), ("_Z19k_sim_step_pgs_wide", 256, 48),
+           ("_Z19k_abb_step_pgs_wide", 256, 272), ("_Z19k_sim_step_pgs_wide", 256, 48),
            ("_Z10k_sim_stepILi32ELb0ELb0ELb0ELb1ELb0EE", 168, 0), ("_Z10k_sim_stepILi32ELb1ELb0ELb1ELb1ELb0EE", 256, 32)]
 
 

@@ -34,13 +34,15 @@ template <class CD, int KC>
 struct HardTail {
   static constexpr int HC = 0, W = KC * HC_STRIDE, NEVP = (CD::NEV + 3) & ~3;
   static constexpr bool PACKED = KC > 8;
+  static constexpr int WS = PACKED ? 9 : 10;       // words per block (KC = 8: padded to ten, so that a block is four 8-byte reads and one word)
   static constexpr int NBLK = PACKED ? KC * (KC + 1) / 2 : KC * KC;
   static constexpr int NB0 = PACKED ? (CD::NPC * PT_STRIDE - W) / 9 : NBLK;          // blocks of W in the contact-slot region
-  static constexpr int UF = PACKED ? W : W + KC * KC * 9, PHI = W, END = PACKED ? W + NB0 * 9 : UF + CD::ND * UF_STRIDE;
+  // U, 1/D per link (phases E - G) and the selection's gap list (phase P) sit where W will be written (H1): both dead by then
+  static constexpr int UF = W, PHI = W, END = W + NB0 * WS;
   static constexpr int SPARE = CD::NB * POSE_STRIDE + ((CD::NB * 6 + 3) & ~3) + CD::ND * XCH_STRIDE;   // pose | acc | xch words
-  static_assert(NEVP + SHF_MAX_SELF_CONTACTS <= NB0 * 9 && CD::ND * UF_STRIDE <= NB0 * 9, "the gap list / U, 1/D fit the response matrix's place");
+  static_assert(NEVP + SHF_MAX_SELF_CONTACTS <= NB0 * WS && CD::ND * UF_STRIDE <= NB0 * WS, "the gap list / U, 1/D fit the response matrix's place");
   static_assert(!PACKED || (NBLK - NB0) * 9 <= SPARE, "the rest of the packed response matrix fits the pose / rate / exchange slots");
-  static_assert(KC <= 16, "owner lanes, 16-bit constraint masks");
+  static_assert(KC <= 16 && (W % 2) == 0, "owner lanes, 16-bit constraint masks; 8-byte aligned blocks");
 };
 // block number and address of W's block (i, j) as stored (PACKED: i <= j)
 template <class CD, int KC>
@@ -50,7 +52,7 @@ DEV float* hard_wblock(const ChainLds& L, float* tail, int i, int j) {
     const int b = ((j * (j + 1)) >> 1) + i;
     return b < T::NB0 ? tail + T::W + b * 9 : L.pose + (b - T::NB0) * 9;
   } else {
-    return tail + T::W + (j * KC + i) * 9;
+    return tail + T::W + (j * KC + i) * T::WS;
   }
 }
 
@@ -714,24 +716,22 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
       if constexpr (SELF) {
         if (__ballot(bsb >= 0) != 0ull) hard_impulse<CD>(L, tail, bsb >= 0 ? bsb : 0, rj, e, qb);
       }
-      // (the targets' body ids first, all in flight at once: each iteration's link reads then do not wait behind its own record read)
-      int btas[KC], btbs[KC];
-#pragma unroll
-      for (int i = 0; i < KC; i++) {
-        btas[i] = __float_as_int(tail[T::HC + i * HC_STRIDE + HC_BODY]);
-        btbs[i] = SELF ? __float_as_int(tail[T::HC + i * HC_STRIDE + HC_BODYB]) : -1;
-      }
-#pragma unroll
-      for (int i = 0; i < KC; i++) {
-        if (__ballot(i < K) == 0ull) break;
-        if (!(col && i <= j)) continue;     // the upper triangle: block (i, j), i <= j; block (j, i) is its transpose (oracle: hard_solve)
+      // One block of every symmetric pair (oracle: hard_solve, "columns"): block (i, j) from this column for i = j, j - 1, .. j - K / 2
+      // (modulo K; for even K the pair at distance K / 2 belongs to the columns j >= K / 2): K / 2 + 1 targets per lane at most
+#pragma unroll 1
+      for (int d = 0; 2 * d <= KC; d++) {
+        if (__ballot(2 * d <= K) == 0ull) break;
+        const bool todo = col && 2 * d <= K && d < K && !(d > 0 && 2 * d == K && 2 * j < K);
+        int i = j - d;
+        if (i < 0) i += K;
+        if (!todo) continue;
         const float* hi = tail + T::HC + i * HC_STRIDE;
         const float ri[3] = {hi[HC_R], hi[HC_R + 1], hi[HC_R + 2]};
-        const int bta = btas[i];
+        const int bta = __float_as_int(hi[HC_BODY]);
         float aa[3], ab[3] = {0.0f, 0.0f, 0.0f}, ba[3] = {0.0f, 0.0f, 0.0f}, bb[3] = {0.0f, 0.0f, 0.0f};
         hard_velocity<CD>(L, tail, qa, bta, ri, aa);
         if constexpr (SELF) {
-          const int btb = btbs[i];
+          const int btb = __float_as_int(hi[HC_BODYB]);
           hard_velocity<CD>(L, tail, qa, btb, ri, ab);
           if (bsb >= 0) {
             hard_velocity<CD>(L, tail, qb, bta, ri, ba);
@@ -741,11 +741,15 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
         float vw[3];
 #pragma unroll
         for (int r = 0; r < 3; r++) vw[r] = (aa[r] - ab[r]) - (ba[r] - bb[r]);
-        float* Wb = hard_wblock<CD, KC>(L, tail, i, j) + ax;   // block (i, j), column ax: the velocity in contact i's frame
-        const float w0 = dot3(hi + HC_N, vw), w1 = dot3(hi + HC_T1, vw), w2 = dot3(hi + HC_T2, vw);
-        Wb[0] = w0; Wb[3] = w1; Wb[6] = w2;
-        if constexpr (!T::PACKED) {
-          if (i < j) { float* Wt = hard_wblock<CD, KC>(L, tail, j, i) + 3 * ax; Wt[0] = w0; Wt[1] = w1; Wt[2] = w2; }     // row ax of block (j, i)
+        const float w0 = dot3(hi + HC_N, vw), w1 = dot3(hi + HC_T1, vw), w2 = dot3(hi + HC_T2, vw);    // column ax of block (i, j): the velocity in contact i's frame
+        if constexpr (T::PACKED) {
+          // the triangle i <= j is kept: block (i, j) as it is, or -- i > j -- as row ax of block (j, i), its transpose
+          if (i <= j) { float* Wb = hard_wblock<CD, KC>(L, tail, i, j) + ax; Wb[0] = w0; Wb[3] = w1; Wb[6] = w2; }
+          else { float* Wt = hard_wblock<CD, KC>(L, tail, j, i) + 3 * ax; Wt[0] = w0; Wt[1] = w1; Wt[2] = w2; }
+        } else {
+          float* Wb = hard_wblock<CD, KC>(L, tail, i, j) + ax;
+          Wb[0] = w0; Wb[3] = w1; Wb[6] = w2;
+          if (i != j) { float* Wt = hard_wblock<CD, KC>(L, tail, j, i) + 3 * ax; Wt[0] = w0; Wt[1] = w1; Wt[2] = w2; }     // row ax of block (j, i)
         }
       }
     }
@@ -785,7 +789,7 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
 #ifdef SHF_PHASE_CLOCK
     if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_phase_cycles[38 + (Kw < 8 ? Kw : 8)], 1ull);     // histogram of the wavefronts' constraint counts
 #endif
-    const float* Wcol = tail + T::W + (own ? l : 0) * 9;     // (KC = 8) block (l, c) sits at Wcol + c * KC * 9
+    const float* Wcol = tail + T::W + (own ? l : 0) * T::WS;     // (KC = 8) block (l, c) sits at Wcol + c * KC * WS
     const int li = own ? l : 0;
     // one visit of the sweep: contact c (oracle: hard_solve, sweeps)
     auto visit = [&](int c, float tg) {
@@ -807,8 +811,10 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
 #pragma unroll
           for (int k = 0; k < 3; k++) Wb[3 * r + k] = tr ? Ws[3 * k + r] : Ws[3 * r + k];
       } else {
-#pragma unroll
-        for (int k = 0; k < 9; k++) Wb[k] = Wcol[c * KC * 9 + k];
+        const float2* b2 = reinterpret_cast<const float2*>(Wcol + c * KC * T::WS);      // (8-byte aligned: W and WS are even)
+        const float2 w01 = b2[0], w23 = b2[1], w45 = b2[2], w67 = b2[3];
+        Wb[0] = w01.x; Wb[1] = w01.y; Wb[2] = w23.x; Wb[3] = w23.y; Wb[4] = w45.x; Wb[5] = w45.y; Wb[6] = w67.x; Wb[7] = w67.y;
+        Wb[8] = Wcol[c * KC * T::WS + 8];
       }
       // every owner lane computes its own update; lane c's is the one that counts
       const float pn0 = O.p[0];
@@ -817,13 +823,15 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
       const float ut1 = fmaf(dn, O.w10, O.u[1]), ut2 = fmaf(dn, O.w20, O.u[2]);
       float ps1 = O.p[1] - fmaf(O.Ti[1], ut2, O.Ti[0] * ut1), ps2 = O.p[2] - fmaf(O.Ti[2], ut2, O.Ti[1] * ut1);
       const float lim = O.mu * pn, lim2 = lim * lim;
-      if (fmaf(ps2, ps2, ps1 * ps1) > lim2) {
+      const bool commit = l == c && c < K && act;
+      // (the sliding step only where it counts: the other owner lanes' updates are discarded, and the wavefront runs this
+      // branch -- a third of the visit's instructions -- only when contact c of one of its envs really slides)
+      if (commit && fmaf(ps2, ps2, ps1 * ps1) > lim2) {
         ps1 = fmaf(-O.rt, ut1, O.p[1]); ps2 = fmaf(-O.rt, ut2, O.p[2]);
         const float nt2 = fmaf(ps2, ps2, ps1 * ps1);
         const float sc1 = nt2 > lim2 ? lim * rsqrt_spec(nt2) : 1.0f;
         ps1 *= sc1; ps2 *= sc1;
       }
-      const bool commit = l == c && c < K && act;
       float dp0 = commit ? dn : 0.0f, dp1 = commit ? ps1 - O.p[1] : 0.0f, dp2 = commit ? ps2 - O.p[2] : 0.0f;
       if (commit) { O.p[0] = pn; O.p[1] = ps1; O.p[2] = ps2; }
       // the change of contact c's impulse, from its owner lane (lane c of each env: wave lanes c and 32 + c) to every lane

@@ -212,13 +212,13 @@ DEV void hard_sweeps(HardOwner& O, float* hc, const float* W, int l, int K, int 
         const float ut1 = fmaf(dn, O.w10, O.u[1]), ut2 = fmaf(dn, O.w20, O.u[2]);
         float ps1 = O.p[1] - fmaf(O.Ti[1], ut2, O.Ti[0] * ut1), ps2 = O.p[2] - fmaf(O.Ti[2], ut2, O.Ti[1] * ut1);
         const float lim = O.mu * pn, lim2 = lim * lim;
-        if (fmaf(ps2, ps2, ps1 * ps1) > lim2) {
+        const bool commit = l == c && c < K && act;
+        if (commit && fmaf(ps2, ps2, ps1 * ps1) > lim2) {      // (only the committing lanes: the others' updates are discarded)
           ps1 = fmaf(-O.rt, ut1, O.p[1]); ps2 = fmaf(-O.rt, ut2, O.p[2]);
           const float nt2 = fmaf(ps2, ps2, ps1 * ps1);
           const float sc1 = nt2 > lim2 ? lim * rsqrt_spec(nt2) : 1.0f;
           ps1 *= sc1; ps2 *= sc1;
         }
-        const bool commit = l == c && c < K && act;
         float dp0 = commit ? dn : 0.0f, dp1 = commit ? ps1 - O.p[1] : 0.0f, dp2 = commit ? ps2 - O.p[2] : 0.0f;
         if (commit) { O.p[0] = pn; O.p[1] = ps1; O.p[2] = ps2; }
         // the change of contact c's impulse, from its owner lane (lane c of each env: wave lanes c and 32 + c) to every lane
@@ -489,9 +489,14 @@ DEV void hg_columns(const ShfModel* m, const EnvLds& L, int nb, int l, int K, co
   qa.src = -1; qb.src = -1;
   if (bsa >= 0) hg_impulse(m, L, nb, bsa, rj, e, qa);
   if (bsb >= 0) hg_impulse(m, L, nb, bsb, rj, e, qb);
-  for (int i = 0; i < HCK; i++) {
-    if (__ballot(i < K) == 0ull) break;
-    if (!(col && i <= j)) continue;       // the upper triangle: block (i, j), i <= j; block (j, i) is its transpose (oracle: hard_solve)
+  // one block of every symmetric pair (oracle: hard_solve, "columns"): block (i, j) from this column for i = j, j - 1, .. j - K / 2
+  // (modulo K; for even K the pair at distance K / 2 belongs to the columns j >= K / 2): K / 2 + 1 targets per lane at most
+  for (int d = 0; 2 * d <= HCK; d++) {
+    if (__ballot(2 * d <= K) == 0ull) break;
+    const bool todo = col && 2 * d <= K && d < K && !(d > 0 && 2 * d == K && 2 * j < K);
+    int i = j - d;
+    if (i < 0) i += K;
+    if (!todo) continue;
     const float* hi = hc + i * HC_STRIDE;
     const float ri[3] = {hi[HC_R], hi[HC_R + 1], hi[HC_R + 2]};
     const int bta = __float_as_int(hi[HC_BODY]), btb = __float_as_int(hi[HC_BODYB]);
@@ -505,7 +510,7 @@ DEV void hg_columns(const ShfModel* m, const EnvLds& L, int nb, int l, int K, co
     float* Wb = W + (j * HCK + i) * 9 + ax;
     const float w0 = dot3(hi + HC_N, vw), w1 = dot3(hi + HC_T1, vw), w2 = dot3(hi + HC_T2, vw);
     Wb[0] = w0; Wb[3] = w1; Wb[6] = w2;
-    if (i < j) { float* Wt = W + (i * HCK + j) * 9 + 3 * ax; Wt[0] = w0; Wt[1] = w1; Wt[2] = w2; }     // row ax of block (j, i)
+    if (i != j) { float* Wt = W + (i * HCK + j) * 9 + 3 * ax; Wt[0] = w0; Wt[1] = w1; Wt[2] = w2; }     // row ax of block (j, i)
   }
 }
 

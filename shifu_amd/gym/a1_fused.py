@@ -84,11 +84,13 @@ class FusedA1Env:
             self.cm.blob.damping[d] = dof_damping
         if model_edit is not None:        # experiments: e.g. other joint damping / armature
             model_edit(self.cm)
-        # solver: "pgs" = the velocity-level contact solve with the reference's PhysX settings (env_config.py:50-58;
+        # solver: "tgs" (the default where it is built) = physx.solver_type = 1 as the reference sets it (env_config.py:50): the
+        # velocity-level solve as sub-stepped sweeps (SHF_SOLVER_TGS, round 6); "pgs" = solver_type = 0: the same sweeps against the
+        # step's own gaps (round 5's default); both with the reference's other PhysX settings (env_config.py:50-58;
         # csrc/shf_chain_hard.h: chain mapping at 32 lanes per env) -- the default where it is built;
         # "compliant" = rounds 1-4's spring-damper law (the default on another lane mapping / width)
         if solver is None:
-            solver = "pgs" if (mapping in (None, "chain") and group in (None, 32)) else "compliant"
+            solver = "tgs" if (mapping in (None, "chain") and group in (None, 32)) else "compliant"
         self.solver = solver if sim_params is None else {_abi.SOLVER_PGS: "pgs", _abi.SOLVER_TGS: "tgs"}.get(sim_params.solver, "compliant")
         self.sim_params = sim_params or default_sim_params(dt=dt, solver=solver, **(solver_kw or {}))
         self.dt = dt * decimation                                         # isaac_gym.py:26

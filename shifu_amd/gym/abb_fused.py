@@ -51,7 +51,7 @@ class FusedAbbEnv:
         # Asking for a lane mapping / width that only the compliant kernels have selects them.  (Decided from what the caller
         # passed, before the compliant kernels' own defaults for `group` and `mapping` are filled in below.)
         if solver is None:
-            solver = "pgs" if (mapping in (None, "body") and group in (None, 32)) else "compliant"
+            solver = "tgs" if (mapping in (None, "body") and group in (None, 32)) else "compliant"      # physx.solver_type = 1 (env_config.py:50); "pgs": solver_type = 0
         if group is None:
             # 16 lanes per env: sixteen envs per workgroup share one LDS copy of the model, and 4096 envs are resident at once
             # -- with link contacts too, now that only the free box owns corner slots (9.2 KB of LDS per env, was 12.6)

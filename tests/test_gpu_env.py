@@ -96,7 +96,7 @@ def test_hook_env_matches_fused_env_through_resets(replayed):
     n = 64
     hook, fused = _envs(n)
     # both run the reference's contact settings (env_config.py:50-58) through the velocity-level solve, self-collision on
-    assert hook.isg_env.sim.solver == "pgs" and fused.solver == "pgs" and fused.sim_params.pos_iters == 8 and fused.sim_params.vel_iters == 1
+    assert hook.isg_env.sim.solver == "tgs" and fused.solver == "tgs" and fused.sim_params.pos_iters == 8 and fused.sim_params.vel_iters == 1      # (physx.solver_type = 1)
     if replayed:
         # ShifuVecEnv.enable_graph_hooks: the shape-static hooks replayed from two hipGraphs, reset_idx eager in between --
         # the same step, launched differently; held to the fused kernel exactly like the eager mode
@@ -292,8 +292,8 @@ def test_fused_abb_env_tracks_hook_env():
     n = 32
     hook = _abb(n)
     # the facade turns link contacts on (units.py:68) and the physx settings into the velocity-level solve (env_config.py:50-58)
-    fused = FusedAbbEnv(num_envs=n, seed=5, link_contacts=True, solver="pgs")
-    assert hook.isg_env.sim.solver == "pgs"
+    fused = FusedAbbEnv(num_envs=n, seed=5, link_contacts=True, solver="tgs")
+    assert hook.isg_env.sim.solver == "tgs"
     be = hook.isg_env.sim.backend
     S = fused.sim.tensors
     for tid in (_abi.T_DOF_STATE, _abi.T_ROOT_STATE, _abi.T_BODY_STATE, _abi.T_JACOBIAN, _abi.T_CONTACT):
@@ -456,7 +456,7 @@ def test_contact_histogram_counts_every_substep_and_carries_the_drop_counter():
     from shifu_amd.gym.a1_fused import FusedA1Env
     n, steps = 256, 30
     env = FusedA1Env(num_envs=n, seed=3)
-    assert env.solver == "pgs"
+    assert env.solver == "tgs"
     env.reset()
     for _ in range(10):
         env.task.step_random()

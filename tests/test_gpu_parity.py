@@ -392,7 +392,7 @@ def test_long_differential_run_of_every_kernel_form(oracle):
     assert sum(r["resets"] for r in out if r["task"] == "a1") > 300 and sum(r["resets"] for r in out if r["task"] == "abb") > 300
 
 
-@pytest.mark.parametrize("solver", ["pgs", "compliant"])
+@pytest.mark.parametrize("solver", ["tgs", "pgs", "compliant"])
 @pytest.mark.parametrize("link", [True, False])
 def test_fused_abb_step_matches_oracle_bitwise_at_full_size(oracle, link, solver):
     """The same for config 5 -- the reference's scene, every link colliding (the default of FusedAbbEnv and of
@@ -401,10 +401,10 @@ def test_fused_abb_step_matches_oracle_bitwise_at_full_size(oracle, link, solver
     _need_gpu()
     from shifu_amd.gym.abb_fused import FusedAbbEnv
     n = 4096
-    env = FusedAbbEnv(num_envs=n, seed=23, link_contacts=link, **({} if solver == "pgs" else {"solver": solver}))
+    env = FusedAbbEnv(num_envs=n, seed=23, link_contacts=link, solver=solver)
     assert env.solver == solver and env.link_contacts == link
-    if solver == "pgs":
-        assert env.mapping == "body" and env.sim.group == 32 and env.sim_params.solver == _abi.SOLVER_PGS
+    if solver in ("pgs", "tgs"):
+        assert env.mapping == "body" and env.sim.group == 32 and env.sim_params.solver == (_abi.SOLVER_TGS if solver == "tgs" else _abi.SOLVER_PGS)
         # link contacts: sixteen envs per workgroup of 512 threads (8.7 KB of LDS per env: 4096 envs resident at once); the rod-only
         # scene: eight per workgroup of 256, two workgroups per CU
         assert env.task.kernel_symbol() == ("_Z19k_abb_step_pgs_wideILb1EE" if link else "_Z10k_abb_stepILi32E7DynDims8DynSceneLb0ELi0ELb1ELb0EE")
@@ -1108,7 +1108,7 @@ def test_full_size_determinism_and_shard_invariance(group):
         env = (FusedA1Env(num_envs=num, rank=rank, world_size=world, seed=42, mapping="chain", group=16) if group == "chain" else
                FusedA1Env(num_envs=num, rank=rank, world_size=world, seed=42) if group == "pgs" else      # the env's defaults: k_a1_chain_pgs
                FusedA1Env(num_envs=num, rank=rank, world_size=world, seed=42, group=group, mapping="body"))
-        assert env.mapping == ("body" if group == 32 else "chain") and (env.sim_params.solver == _abi.SOLVER_PGS) == (group == "pgs")
+        assert env.mapping == ("body" if group == 32 else "chain") and (env.sim_params.solver == _abi.SOLVER_TGS) == (group == "pgs")      # ("pgs": the env's default solve -- TGS since round 6)
         env.reset()
         out = []
         for k in range(steps):
