@@ -305,9 +305,12 @@ def main():
             raise SystemExit("bench.py: --link-contacts contradicts --no-link-contacts / --mapping chain (compiled for the rod-only scene)")
         args.link_contacts = not (args.no_link_contacts or args.mapping == "chain")
         if args.solver is None and args.mapping is None and args.group is None:
-            args.solver = "tgs"      # FusedAbbEnv's own default: the reference's PhysX settings, solver_type = 1 (generic kernel, 32 lanes per env)
+            args.solver = "tgs"      # FusedAbbEnv's own default: the reference's PhysX settings, solver_type = 1
         if args.solver in ("pgs", "tgs"):
-            mapping, group = "body", 32
+            # the shipped scene: arm wave + box wave, the solve regrouped at 32 lanes per env (k_abb_step_ws_hard); --mapping body
+            # (and hulls): the run-time-shaped kernel at 32 lanes per env
+            mapping = "body" if (args.link_shapes == "hull" or args.mapping == "body" or args.group == 32) else "split"
+            group = 16 if mapping == "split" else 32
         else:
             mapping = args.mapping or ("split" if (args.group or 16) == 16 else ("chain" if (not args.link_contacts and (args.group or 16) == 32) else "body"))
             group = args.group or 16

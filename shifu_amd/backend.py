@@ -502,6 +502,8 @@ class AbbTask:
         if mdl.nhull > 0 or getattr(self.sim, "scene_flags", 0):     # the convex narrow phase compiled in (csrc/shf_hull.h): run-time shapes
             hard = int(self.sim.params.solver != _abi.SOLVER_COMPLIANT)
             return f"_Z10k_abb_stepILi{32 if hard else self.sim.group}E7DynDims8DynSceneLb1ELi0ELb{hard}ELb1EE"
+        if self.sim.params.solver != _abi.SOLVER_COMPLIANT and getattr(self.sim, "mapping", "body") == "split":
+            return f"_Z18k_abb_step_ws_hardILb{int(link)}EE"     # arm wave + box wave, the solve regrouped at 32 lanes per env
         if self.sim.params.solver != _abi.SOLVER_COMPLIANT:    # the generic velocity-level solve: run-time shapes, 32 lanes per env
             if lib().shf_abb_step_pgs_is_wide(self._h):   # sixteen envs per workgroup of 512 threads
                 return f"_Z19k_abb_step_pgs_wideILb{int(link)}EE"

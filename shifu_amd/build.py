@@ -14,7 +14,7 @@ LIB = os.path.join(HERE, "libshifu_amd.so")
 # shf_api.hip holds the C ABI and the launches; the kernel families of shf_kernels.h are instantiated by the shf_k_*.hip units
 # (csrc/shf_kernel_list.h) so that they compile side by side -- as one unit the library took 4.5 minutes to build.
 KERNEL_UNITS = ["shf_k_sim.hip", "shf_k_sim_link.hip", "shf_k_sim_hard.hip", "shf_k_sim_hard_wide.hip", "shf_k_a1.hip", "shf_k_abb.hip",
-                "shf_k_abb_link.hip", "shf_k_abb_hard.hip", "shf_k_abb_ws.hip", "shf_k_sim_ext.hip", "shf_k_abb_ext.hip", "shf_k_hull_test.hip"]
+                "shf_k_abb_link.hip", "shf_k_abb_hard.hip", "shf_k_abb_ws.hip", "shf_k_abb_ws_hard.hip", "shf_k_sim_ext.hip", "shf_k_abb_ext.hip", "shf_k_hull_test.hip"]
 UNITY_SOURCES = ["shf_api.hip", "shf_a1_chain.hip", "shf_glue.hip", "shf_mlp.hip", "shf_k_hull_test.hip"]      # with -DSHF_UNITY: shf_api.hip instantiates every kernel
 SOURCES = UNITY_SOURCES + [u for u in KERNEL_UNITS if u not in UNITY_SOURCES]
 HEADERS = ["shf_device.h", "shf_boxes.h", "shf_task.h", "shf_chain.h", "shf_chain_hard.h", "shf_hard.h", "shf_link.h", "shf_arm.h", "shf_kernels.h",
@@ -74,6 +74,10 @@ BUDGETS = [("_Z16k_a1_step_a1_g32", 256, 0),          # default: A1, two envs pe
            # config 5 under that solve: the wave-specialised step on compile-time shapes (round 6) without spills; the run-time-shaped
            # generic kernels (any articulation / scene) as they stand: sixteen envs per 512-thread workgroup at 256 registers
            ("_Z19k_abb_step_pgs_wide", 256, 272), ("_Z19k_sim_step_pgs_wide", 256, 48),
+           # config 5's default under that solve since round 6 (arm wave + box wave, the solve regrouped at 32 lanes per env): two
+           # waves per SIMD; the link passes and the solve share 256 registers (1184 B of scratch when a struct copy and a pointer
+           # select had put five structs on the stack: 0.50 ms instead of 0.37)
+           ("_Z18k_abb_step_ws_hardILb1EE", 256, 256), ("_Z18k_abb_step_ws_hardILb0EE", 256, 200),
            ("_Z10k_sim_stepILi32ELb0ELb0ELb0ELb1ELb0EE", 168, 0), ("_Z10k_sim_stepILi32ELb1ELb0ELb1ELb1ELb0EE", 256, 32)]
 
 

@@ -952,6 +952,21 @@ static int abb_step_launch(ShfAbbTask* task, const float* raw_actions_dev, void*
     // the velocity-level contact solve: the run-time-shaped body-per-lane step at 32 lanes per env (csrc/shf_hard.h)
     if (s->sp.max_contacts > HCK || s->sp.pos_iters < 1) return fail("shf_abb_step: SHF_SOLVER_PGS needs pos_iters >= 1 and max_contacts <= 8");
     if (s->model.nlevels > HG_LEV || s->model.nb + s->nboxes > 32) return fail("shf_abb_step: SHF_SOLVER_PGS: at most 8 tree levels and 32 bodies + box actors");
+    if (s->mapping == SHF_MAP_CHAIN && s->mapping_split) {
+      // the shipped arm in the shipped scene: arm wave + box wave for the free solve and the candidates, the solve regrouped at 32
+      // lanes per env (k_abb_step_ws_hard): 512 threads = 16 envs per workgroup
+      const bool link = sim_link(s);
+      if (!ArmChain<6>::matches(s->model) || !(link ? AbbLinkDims::matches(s->model) : AbbDims::matches(s->model)) ||
+          !AbbScene::matches(s->nboxes, s->boxes, s->model.nsph) || s->group != 16)
+        return fail("shf_abb_step: the split mapping under SHF_SOLVER_PGS / _TGS needs the shipped arm, the table / cube / pad scene and 16 "
+                    "lanes per env");
+      const int nbx = s->nboxes, wepb = 16;
+      const int nslots = hard_total_slots(s->model.np + box_slot_count(nbx, sim_ndyn(s), s->model.nsph) + (link ? 2 * SHF_MAX_LINK_CONTACTS : 0), link);
+      const size_t wlds = ((size_t)MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS +
+                           (size_t)wepb * env_lds_words(s->model.nb + nbx, s->model.nd, nslots, ABB_TAIL_WORDS(nslots, s->model.nd) + WS_LINK_STASH_WORDS, 1 + nbx)) * 4;
+      const dim3 wgrid((s->n + wepb - 1) / wepb), wblock(512);
+      return link ? launch(k_abb_step_ws_hard<true>, wgrid, wblock, wlds, stream, A) : launch(k_abb_step_ws_hard<false>, wgrid, wblock, wlds, stream, A);
+    }
     size_t env_bytes, head_bytes;
     if (abb_pgs_wide(s, &env_bytes, &head_bytes)) {
       const dim3 wgrid((s->n + 15) / 16), wblock(512);

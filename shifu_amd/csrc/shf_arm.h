@@ -181,6 +181,48 @@ struct ArmLane {
     }
   }
 
+  // C'. the same under the velocity-level solve (ShfSimParams.solver != SHF_SOLVER_COMPLIANT): the links' rigid inertia, and
+  //     the sample points as candidate constraints only (substep<.., HARD>'s point loop: gap from rest_offset inside the contact
+  //     offset) -- nothing is folded, the articulated-body solve runs free
+  DEV void inertia_and_candidates(BodyRegs& B, float mu_shape) const {
+    if (islink) {
+      const float* pb = L.pose + l * POSE_STRIDE;
+#pragma unroll
+      for (int k = 0; k < 9; k++) B.Rw[k] = pb[k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) B.p[k] = pb[9 + k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) B.v[k] = pb[12 + k];
+      body_inertia(M, B, C.mscale, l);
+    }
+    const float mu = 0.5f * (mu_shape + C.terr.t.friction);
+    const float reach = C.sp.contact_offset + C.sp.rest_offset;
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+      const float* pb = L.pose + P.body(k) * POSE_STRIDE;
+      float Rb[9], r[3], n[3], h;
+#pragma unroll
+      for (int j = 0; j < 9; j++) Rb[j] = pb[j];
+      mv3(Rb, P.pos[k], r);
+#pragma unroll
+      for (int j = 0; j < 3; j++) r[j] += pb[9 + j];
+      terrain_query<false>(C.terr, L.root[0] + r[0], L.root[1] + r[1], &h, n);
+      const float rad = P.rad[k];
+      const float phi = fmaf(L.root[2] + r[2] - h, n[2], -rad);
+      if (l + k * G < DM::NPC) {
+        float* o = L.pt + (l + k * G) * PT_STRIDE;
+        float on = 0.0f;
+        if (phi < reach) {
+          on = 1.0f;
+#pragma unroll
+          for (int j = 0; j < 3; j++) { o[PT_R + j] = fmaf(-rad, n[j], r[j]); o[PT_N + j] = n[j]; }
+          o[PT_F] = phi - C.sp.rest_offset; o[PT_F + 1] = mu; o[PT_F + 2] = 0.0f; o[PT_CT] = 0.0f; o[PT_BN] = 0.0f;
+        }
+        o[PT_ON] = on;
+      }
+    }
+  }
+
   // link lanes -> chain lane: (IA, pA) with every contact folded in.  A group sync has to follow.
   DEV void hand_over(const BodyRegs& B) const {
     if (islink) {

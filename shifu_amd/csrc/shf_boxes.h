@@ -1359,7 +1359,9 @@ struct FixedSceneConsts {
 // Corner slots of the free box.  Round(s) 1: corner x other box, one code path for every lane.  Round 2: corner x
 // terrain -- skipped (slots off) when the terrain is the plane z = 0 and the box's bounding sphere clears it by more
 // than the contact offset: every corner's gap then exceeds the offset and slot_eval would switch the slot off.
-template <int G, class SC>
+// HARD (the velocity-level solve): candidate constraints only, with boxes_contacts<.., HARD>'s constants and a corner's signed
+// distance to a fixed box
+template <int G, class SC, bool HARD = false>
 DEV void fixed_corner_slots(const StepCtx& C, const EnvLds& L, int l, BoxMasks& BM) {
   typedef FixedSceneConsts<G, SC> F;
   constexpr int nbx = F::nbx, kd = F::kd, NO = F::NO, NBS = F::NBS;
@@ -1367,9 +1369,9 @@ DEV void fixed_corner_slots(const StepCtx& C, const EnvLds& L, int l, BoxMasks& 
   const SlotLay Q = slot_lay<SC>(m, C.scene);
   const SceneDev* S = C.scene;
   const int nb = m->nb;
-  const float dt = C.sp.dt, kc = C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
-  const float offset = C.sp.contact_offset;
-  const float beta = fmaf(kc, dt, C.sp.contact_d);
+  const float dt = C.sp.dt, kc = HARD ? -1.0f : C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
+  const float offset = HARD ? C.sp.contact_offset + C.sp.rest_offset : C.sp.contact_offset;
+  const float beta = HARD ? C.sp.rest_offset : fmaf(kc, dt, C.sp.contact_d);
   const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
   const int lane0 = F::lane0(l);
   const unsigned long long gmask = F::gmask();
@@ -1408,8 +1410,14 @@ DEV void fixed_corner_slots(const StepCtx& C, const EnvLds& L, int l, BoxMasks& 
       float Rs[9], hh[3] = {0.5f * bs.dim[0], 0.5f * bs.dim[1], 0.5f * bs.dim[2]}, bpos[3] = {ps[9], ps[10], ps[11]};
 #pragma unroll
       for (int i = 0; i < 9; i++) Rs[i] = ps[i];
-      if (point_in_box(Rs, bpos, hh, r, &phi, n))
+      if constexpr (HARD) {
+        float rc[3];
+        sphere_vs_box(Rs, bpos, hh, r, 0.0f, &phi, n, rc);
         slot_eval(o, phi, n, r, vs, vp, 0.5f * (bd.friction + bs.friction), kc, beta, veps, vdep, dt, offset);
+      } else {
+        if (point_in_box(Rs, bpos, hh, r, &phi, n))
+          slot_eval(o, phi, n, r, vs, vp, 0.5f * (bd.friction + bs.friction), kc, beta, veps, vdep, dt, offset);
+      }
       on = o[PT_ON] != 0.0f;
     }
     BM.cbox |= ((__ballot(on) >> lane0) & gmask) << (j * G);
@@ -1473,16 +1481,16 @@ DEV void fixed_corner_slots(const StepCtx& C, const EnvLds& L, int l, BoxMasks& 
   }
 }
 // Rounded shapes of the articulation (sphere / capsule) against the free box: lane si < NSPH
-template <int G, class SC>
+template <int G, class SC, bool HARD = false>
 DEV void fixed_sphere_slots(const StepCtx& C, const EnvLds& L, int l, float mu_shape, const float* g_art, BoxMasks& BM) {
   typedef FixedSceneConsts<G, SC> F;
   constexpr int nbx = F::nbx, kd = F::kd;
   const ShfModel* m = C.m;
   const SlotLay Q = slot_lay<SC>(m, C.scene);
   const int nb = m->nb;
-  const float dt = C.sp.dt, kc = C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
-  const float offset = C.sp.contact_offset;
-  const float beta = fmaf(kc, dt, C.sp.contact_d);
+  const float dt = C.sp.dt, kc = HARD ? -1.0f : C.sp.contact_k, veps = C.sp.friction_vel, vdep = C.sp.max_depen_vel;
+  const float offset = HARD ? C.sp.contact_offset + C.sp.rest_offset : C.sp.contact_offset;
+  const float beta = HARD ? C.sp.rest_offset : fmaf(kc, dt, C.sp.contact_d);
   const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
   const ShfBoxDesc& bd = C.scene->box[kd];
   const float* pk = L.pose + (nb + kd) * POSE_STRIDE;

@@ -768,8 +768,10 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
   if ((l == 0 && !m->fixed_base) || dynbox) {
     // a free body: the root (its origin is O: p = 0) or a box at B.p
     float* Rt = l == 0 ? L.root : L.root + 13 * (1 + kd);
-    const float* af = l == 0 ? a : abox;
-    const float* gg = l == 0 ? g : gb;
+    // (selected by value: a select between pointers to local arrays puts them on the stack)
+    const float af[6] = {l == 0 ? a[0] : abox[0], l == 0 ? a[1] : abox[1], l == 0 ? a[2] : abox[2],
+                         l == 0 ? a[3] : abox[3], l == 0 ? a[4] : abox[4], l == 0 ? a[5] : abox[5]};
+    const float gg[3] = {l == 0 ? g[0] : gb[0], l == 0 ? g[1] : gb[1], l == 0 ? g[2] : gb[2]};
     float av[6], apz[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) {

@@ -660,9 +660,23 @@ __global__ __launch_bounds__(512) void k_abb_step_pgs_wide(AbbArgs A) {
 // S0' behind the arm's chain composition and S1, while the arm wave computes inertias and the 59 points' terrain contacts;
 // the arm wave then folds them with the rod slot.  512 threads = 16 envs per workgroup (one CU holds one: 9.2 KB of LDS per
 // env), two waves per SIMD.
-template <int WT, bool LINK = false>
-__global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
+//
+// HARD (k_abb_step_ws_hard): the same split under the velocity-level contact solve (ShfSimParams.solver = SHF_SOLVER_PGS / _TGS).
+// The contact passes only record candidate constraints and the arm's articulated-body solve runs free, so the two waves need
+// no exchange until both are done:
+//     arm wave                                   |  box wave
+//     joints, drives, chain composition          |  box poses, corner candidates, the free box's rigid (IA, pA) -> LDS
+//   ---- S0': the arm's poses and the boxes' visible to both
+//     inertias, sample-point candidates,         |  rod-capsule candidate, link-contact candidates
+//     free ABA inward / outward                  |
+//   ---- S1: candidates, free accelerations and the per-link (S, U, 1/D) records visible
+//     ALL waves, regrouped at 32 lanes per env (two envs per wave): substep_hard_finish -- gather, response matrix, sweeps,
+//     impulse passes, integration (csrc/shf_hard.h, the code the run-time-shaped kernels run: same values, same bits)
+//   ---- S2
+template <int WT, bool LINK, bool HARD>
+DEV void abb_ws_body(const AbbArgs& A) {
   constexpr int G = 16, NL = 6, HALF = WT / 2, EPB = HALF / G;
+  static_assert(!HARD || WT == 512, "the regrouped solve: sixteen envs x 32 lanes");
   typedef typename std::conditional<LINK, AbbLinkDims, AbbDims>::type DM;
   typedef AbbScene SC;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -682,9 +696,11 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
   const bool live = e < n;                       // no early return: every wave meets every workgroup barrier
   constexpr int nbx = SC::NBX, actors = 1 + nbx, nb = NL + 1, nd = NL, nbt = nb + nbx;
   const int link_slot0 = DM::np(m) + box_slot_count(nbx, 1, m->nsph);   // the fixed scene has one free box
-  const int nslots = link_slot0 + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0);
-  const int env_words = env_lds_words(nbt, nd, nslots, ABB_TAIL_WORDS(nslots, nd) + (LINK ? WS_LINK_STASH_WORDS : 0), actors);
-  EnvLds L = env_lds_carve(smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS + es * env_words, nbt, nd, nslots, actors);
+  const int nslots_own = link_slot0 + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0);
+  const int nslots = HARD ? hard_total_slots(nslots_own, LINK) : nslots_own;   // HARD: the solve's records and response matrix inside the slot region
+  const int env_words = env_lds_words(nbt, nd, nslots, ABB_TAIL_WORDS(nslots, nd) + ((LINK || HARD) ? WS_LINK_STASH_WORDS : 0), actors);
+  float* env_base = smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS;
+  EnvLds L = env_lds_carve(env_base + es * env_words, nbt, nd, nslots, actors);
   float* tgtl = L.pt + nslots * PT_STRIDE;       // POS targets of this env step
   float* krec = tgtl + ABB_TGT_WORDS(nd);
   unsigned* sphere_bits = reinterpret_cast<unsigned*>(krec + ARM_KREC_WORDS(NL));   // the rod slot's ballot, arm wave -> box wave
@@ -718,16 +734,17 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
   constexpr int NRP = LANE_ROUNDS(G, DM);
   LaneModel M;
   LanePoints<NRP> P;
-  if constexpr (!LINK) {
+  if constexpr (!LINK && !HARD) {
     lane_model_load<DM>(m, l, M);
     lane_points_load<G>(m, DM::np(m), l, P);
   }
-#define WS_ARM_LOCALS()                                  \
+#define WS_ARM_LOCALS_AT(lane)                           \
   LaneModel Ml;                                          \
-  lane_model_load<DM>(m, l, Ml);                         \
+  lane_model_load<DM>(m, lane, Ml);                      \
   LanePoints<NRP> Pl;                                    \
-  lane_points_load<G>(m, DM::np(m), l, Pl);              \
-  ArmLane<G, DM, NL> ALl(C, L, krec, l, Ml, Pl)
+  lane_points_load<G>(m, DM::np(m), lane, Pl);           \
+  ArmLane<G, DM, NL> ALl(C, L, krec, lane, Ml, Pl)
+#define WS_ARM_LOCALS() WS_ARM_LOCALS_AT(l)
   const BoxLane BL = box_lane_load(m, l);
   ArmLane<G, DM, NL> AL(C, L, krec, l, M, P);    // (LINK: used for its gravity vector only)
   unsigned long long act[NRP];                   // LINK: the terrain-contact ballots, from the points phase to the force phase
@@ -737,6 +754,98 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
   BoxMasks BM;
   for (int it = 0; it < nsub; it++) {
     float* contact_out = it == nsub - 1 ? L.xch : nullptr;   // reported for the last sub-step only
+    if constexpr (HARD) {
+      // (the lane ids pass through an empty asm once per sub-step: what is derived from them -- LDS addresses, masks, per-lane
+      // constants -- is then recomputed where it is used instead of being hoisted out of the loop as ~100 values, most of
+      // which were spilled)
+      int lq = l, tq = (int)threadIdx.x;
+      asm volatile("" : "+v"(lq), "+v"(tq));
+      if (live) {
+        if (arm) {
+          WS_ARM_LOCALS_AT(lq);
+          ALl.joints_and_drives(tgtl);
+          GROUP_SYNC();
+          ALl.compose();
+          GROUP_SYNC();
+          PHASE_MARK(24);
+        } else {
+          // (body registers and slot ballots local to each phase: nothing of them is carried across the solve)
+          BodyRegs Bb;
+          BoxMasks BMb;
+          boxes_pose<G>(C, L, lq, Bb);
+          fixed_corner_slots<G, SC, true>(C, L, lq, BMb);
+          if (lq == nb + SC::DYN) {              // the free box's rigid inertia, bias force and position: to its lane of the solve
+#pragma unroll
+            for (int k = 0; k < 21; k++) box_stash[k] = Bb.IA[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) box_stash[21 + k] = Bb.pA[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) box_stash[27 + k] = Bb.p[k];
+          }
+        }
+      }
+      __syncthreads();                           // S0'
+      PHASE_MARK(25);
+      if (live) {
+        if (arm) {
+          WS_ARM_LOCALS_AT(lq);
+          BodyRegs Ba;
+          ALl.inertia_and_candidates(Ba, mu);
+          ALl.hand_over(Ba);
+          GROUP_SYNC();
+          ALl.recursions();
+          PHASE_MARK(26);
+        } else {
+          BoxMasks BMb;
+          fixed_sphere_slots<G, SC, true>(C, L, lq, mu, AL.g, BMb);
+          int nl = 0;
+          if constexpr (LINK) nl = link_contacts<G>(C, L, lq, link_slot0, mu, AL.g);
+          if (lq == 0) *link_count = nl;
+        }
+      }
+      __syncthreads();                           // S1
+      PHASE_MARK(27);
+      {
+        // regrouped: thread t -> env t / 32 of the workgroup, lane t % 32
+        constexpr int G2 = 32;
+        const int es2 = tq / G2, l2 = tq % G2;
+        const int e2 = blockIdx.x * EPB + es2;
+        if (e2 < n) {
+          const EnvLds L2 = env_lds_carve(env_base + es2 * env_words, nbt, nd, nslots, actors);
+          const float* krec2 = L2.pt + nslots * PT_STRIDE + ABB_TGT_WORDS(nd);
+          const float* stash2 = krec2 + ARM_KREC_WORDS(NL) + 4;
+          const int nlink2 = *reinterpret_cast<const int*>(krec2 + ARM_KREC_WORDS(NL) + 1);
+          C.dropped = env_dropped(A.S.dropped, A.S.sp, e2);      // (the gather's drop counter and histogram: this lane's env of the solve)
+          typedef LaneModelT<false> LM2;
+          LM2 M2;
+          lane_model_load<DM>(m, l2, M2);
+          BodyRegs B2;
+          if (l2 >= 1 && l2 <= NL) {
+            const float* kr = krec2 + (l2 - 1) * KREC_STRIDE;
+#pragma unroll
+            for (int k = 0; k < 6; k++) { B2.S[k] = kr[k]; B2.U[k] = kr[12 + k]; }
+            B2.invD = kr[18];
+          }
+          if (l2 == nb + SC::DYN) {
+#pragma unroll
+            for (int k = 0; k < 21; k++) B2.IA[k] = stash2[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) B2.pA[k] = stash2[21 + k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) B2.p[k] = stash2[27 + k];
+          }
+          const float g2[3] = {AL.g[0], AL.g[1], AL.g[2]};     // (a local copy: the solve selects between pointers to it and to the boxes' gravity)
+          float a2[6] = {0.0f, 0.0f, 0.0f, -g2[0], -g2[1], -g2[2]};
+          substep_hard_finish<G2, true, DM, LM2, SC, false, LINK>(C, L2, l2, M2, B2, g2, a2, 0, link_slot0, link_slot0, nlink2,
+                                                                   it == nsub - 1 ? L2.xch : nullptr);
+        }
+        C.dropped = (LINK && live && !arm) ? env_dropped(A.S.dropped, A.S.sp, e) : nullptr;
+      }
+      PHASE_MARK(28);
+      __syncthreads();                           // S2: the integrated state for the next sub-step's waves
+      PHASE_MARK(29);
+      continue;
+    }
     if constexpr (!LINK) {
       if (live) {
         if (arm) {
@@ -907,7 +1016,7 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
   if (live && arm) {
     for (int i = l; i < 3 * nbt; i += G) A.S.contact[(size_t)e * nbt * 3 + i] = L.xch[i];
     GROUP_SYNC();
-    if constexpr (LINK) {
+    if constexpr (LINK || HARD) {
       WS_ARM_LOCALS();
       ALl.joints();
       GROUP_SYNC();
@@ -974,6 +1083,15 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
 }
 
 #undef WS_ARM_LOCALS
+#undef WS_ARM_LOCALS_AT
+template <int WT, bool LINK = false>
+__global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
+  abb_ws_body<WT, LINK, false>(A);
+}
+template <bool LINK>
+__global__ __launch_bounds__(512) void k_abb_step_ws_hard(AbbArgs A) {
+  abb_ws_body<512, LINK, true>(A);
+}
 
 #ifdef SHF_DEFINE_SMALL_KERNELS
 __global__ void k_abb_reset_all(AbbArgs A) {

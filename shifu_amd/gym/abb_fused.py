@@ -45,11 +45,13 @@ class FusedAbbEnv:
         if ext:
             mapping = "body"
         self.cm = abb_model(link_contacts=link_contacts, link_shapes=link_shapes)
-        # solver: "pgs" = the velocity-level contact solve with the reference's PhysX settings (env_config.py:50-58) -- the default,
-        # on the run-time-shaped body-per-lane kernel at 32 lanes per env (csrc/shf_hard.h; round 5: correct, not yet fast:
-        # 0.49 ms per vec-step); "compliant" = rounds 1-4's spring-damper law on the kernels compiled for this scene (0.16 ms).
-        # Asking for a lane mapping / width that only the compliant kernels have selects them.  (Decided from what the caller
-        # passed, before the compliant kernels' own defaults for `group` and `mapping` are filled in below.)
+        # solver: "tgs" / "pgs" = the velocity-level contact solve with the reference's PhysX settings (env_config.py:50-58) -- the
+        # default.  In the shipped scene it runs on k_abb_step_ws_hard (mapping 'split', 16 lanes per env: arm wave + box wave for the
+        # free solve and the candidates, the solve regrouped at 32 lanes per env; round 6); otherwise (extra boxes, hulls, or
+        # mapping='body') on the run-time-shaped body-per-lane kernel at 32 lanes per env (csrc/shf_hard.h).  "compliant" = rounds
+        # 1-4's spring-damper law on the kernels compiled for this scene.
+        # Asking, without naming a solver, for a lane mapping / width that only the compliant kernels have selects them.  (Decided
+        # from what the caller passed, before the defaults for `group` and `mapping` are filled in below.)
         if solver is None:
             solver = "tgs" if (mapping in (None, "body") and group in (None, 32)) else "compliant"      # physx.solver_type = 1 (env_config.py:50); "pgs": solver_type = 0
         if group is None:
@@ -65,7 +67,7 @@ class FusedAbbEnv:
             scene = not extra_boxes
             mapping = "split" if (scene and group == 16) else "chain" if (scene and not link_contacts and group == 32) else "body"
         self.solver = solver
-        if solver in ("pgs", "tgs"):
+        if solver in ("pgs", "tgs") and not (mapping == "split" and group == 16):
             group, mapping = 32, "body"
         if mapping == "chain" and self.link_contacts:
             raise ValueError("FusedAbbEnv: mapping='chain' is compiled for the rod-only scene; with link_contacts=True use "

@@ -392,7 +392,7 @@ def test_long_differential_run_of_every_kernel_form(oracle):
     assert sum(r["resets"] for r in out if r["task"] == "a1") > 300 and sum(r["resets"] for r in out if r["task"] == "abb") > 300
 
 
-@pytest.mark.parametrize("solver", ["tgs", "pgs", "compliant"])
+@pytest.mark.parametrize("solver", ["tgs", "pgs", "compliant", "pgs-body"])
 @pytest.mark.parametrize("link", [True, False])
 def test_fused_abb_step_matches_oracle_bitwise_at_full_size(oracle, link, solver):
     """The same for config 5 -- the reference's scene, every link colliding (the default of FusedAbbEnv and of
@@ -401,9 +401,15 @@ def test_fused_abb_step_matches_oracle_bitwise_at_full_size(oracle, link, solver
     _need_gpu()
     from shifu_amd.gym.abb_fused import FusedAbbEnv
     n = 4096
-    env = FusedAbbEnv(num_envs=n, seed=23, link_contacts=link, solver=solver)
+    body = solver.endswith("-body")       # the run-time-shaped kernel (what any other arm / scene runs on) instead of the default
+    solver = solver.split("-")[0]
+    env = FusedAbbEnv(num_envs=n, seed=23, link_contacts=link, solver=solver, **({"mapping": "body"} if body else {}))
     assert env.solver == solver and env.link_contacts == link
-    if solver in ("pgs", "tgs"):
+    if solver in ("pgs", "tgs") and not body:
+        # the default since round 6: arm wave + box wave, the solve regrouped at 32 lanes per env
+        assert env.mapping == "split" and env.sim.group == 16 and env.sim_params.solver == (_abi.SOLVER_TGS if solver == "tgs" else _abi.SOLVER_PGS)
+        assert env.task.kernel_symbol() == f"_Z18k_abb_step_ws_hardILb{int(link)}EE"
+    elif solver in ("pgs", "tgs"):
         assert env.mapping == "body" and env.sim.group == 32 and env.sim_params.solver == (_abi.SOLVER_TGS if solver == "tgs" else _abi.SOLVER_PGS)
         # link contacts: sixteen envs per workgroup of 512 threads (8.7 KB of LDS per env: 4096 envs resident at once); the rod-only
         # scene: eight per workgroup of 256, two workgroups per CU
@@ -882,15 +888,17 @@ def test_generic_articulation_under_the_velocity_level_solve_matches_oracle_bitw
     sim.destroy()
 
 
+@pytest.mark.parametrize("mapping", ["split", "body"])
 @pytest.mark.parametrize("link", [False, True])
-def test_fused_abb_step_under_the_velocity_level_solve_matches_oracle_bitwise(oracle, link):
+def test_fused_abb_step_under_the_velocity_level_solve_matches_oracle_bitwise(oracle, link, mapping):
     """ShifuVecEnv.step for AbbPushBox with FusedAbbEnv(solver='pgs') -- k_abb_step<32, DynDims, DynScene, LINK, 0, HARD> --
     against the oracle: 120 vec-steps with re-spawns, every tensor."""
     _need_gpu()
     from shifu_amd.gym.abb_fused import FusedAbbEnv
     n = 48
-    env = FusedAbbEnv(num_envs=n, seed=11, link_contacts=link, solver="pgs")
-    assert env.sim_params.solver == _abi.SOLVER_PGS and ("Lb1ELb0EE" in env.task.kernel_symbol() or "pgs_wide" in env.task.kernel_symbol())
+    env = FusedAbbEnv(num_envs=n, seed=11, link_contacts=link, solver="pgs", **({"mapping": "body"} if mapping == "body" else {}))
+    assert env.sim_params.solver == _abi.SOLVER_PGS and env.mapping == mapping
+    assert ("Lb1ELb0EE" in env.task.kernel_symbol() or "pgs_wide" in env.task.kernel_symbol()) if mapping == "body" else ("ws_hard" in env.task.kernel_symbol())
     bufs = {k: env.sim.tensors[t].cpu().numpy().copy() for k, t in _ABB_SIM_T.items()}
     bufs.update({k: env.task.tensors[t].cpu().numpy().copy() for k, t in _ABB_T.items()})
     rng = np.random.default_rng(2)
@@ -1047,7 +1055,7 @@ def test_random_action_step_matches_oracle_bitwise(oracle, kind):
     assert int(ref.task.tensors[_abi.A1_RESET_COUNT].sum()) >= 0
 
 
-@pytest.mark.parametrize("mapping,group", [("split", 16), ("chain", 16), ("chain", 32), ("pgs-link", 32), ("pgs", 32)])
+@pytest.mark.parametrize("mapping,group", [("split", 16), ("chain", 16), ("chain", 32), ("pgs-link", 32), ("pgs", 32), ("pgs-link-split", 16), ("pgs-split", 16)])
 @pytest.mark.parametrize("n", [1, 5, 13, 37])
 def test_ragged_env_counts_abb(oracle, n, mapping, group):
     """The fused ABB step with env counts that leave lanes -- and, in the two-wave kernel, whole waves -- without an env
@@ -1055,8 +1063,12 @@ def test_ragged_env_counts_abb(oracle, n, mapping, group):
     velocity-level solve at sixteen envs per 512-thread workgroup (k_abb_step_pgs_wide); "pgs": rod-only, eight per workgroup."""
     _need_gpu()
     from shifu_amd.gym.abb_fused import FusedAbbEnv
-    if mapping.startswith("pgs"):
-        env = FusedAbbEnv(num_envs=n, seed=17 + n, solver="pgs", link_contacts=mapping == "pgs-link")
+    if mapping.endswith("-split"):        # k_abb_step_ws_hard: sixteen envs per workgroup, regrouped for the solve
+        env = FusedAbbEnv(num_envs=n, seed=17 + n, solver="pgs", link_contacts="link" in mapping)
+        assert "ws_hard" in env.task.kernel_symbol()
+        mapping = "split"
+    elif mapping.startswith("pgs"):
+        env = FusedAbbEnv(num_envs=n, seed=17 + n, solver="pgs", link_contacts=mapping == "pgs-link", mapping="body")
         assert ("pgs_wide" in env.task.kernel_symbol()) == (mapping == "pgs-link")
         mapping = "body"
     else:
@@ -1821,15 +1833,17 @@ def test_fused_a1_step_under_tgs_at_full_size(oracle):
     assert resets > 100
 
 
+@pytest.mark.parametrize("mapping", ["split", "body"])
 @pytest.mark.parametrize("link", [False, True])
-def test_fused_abb_step_under_tgs_matches_oracle_bitwise(oracle, link):
+def test_fused_abb_step_under_tgs_matches_oracle_bitwise(oracle, link, mapping):
     """... and the generic solve of the body-per-lane kernels (config 5: box actors as solver bodies, link contacts, a fixed base)
     under SHF_SOLVER_TGS: FusedAbbEnv(solver='tgs'), 256 envs x 60 vec-steps with re-spawns, every tensor."""
     _need_gpu()
     from shifu_amd.gym.abb_fused import FusedAbbEnv
     n = 256
-    env = FusedAbbEnv(num_envs=n, seed=12, link_contacts=link, solver="tgs")
-    assert env.sim_params.solver == _abi.SOLVER_TGS and env.solver == "tgs"
+    env = FusedAbbEnv(num_envs=n, seed=12, link_contacts=link, solver="tgs", **({"mapping": "body"} if mapping == "body" else {}))
+    assert env.sim_params.solver == _abi.SOLVER_TGS and env.solver == "tgs" and env.mapping == mapping
+    assert ("ws_hard" in env.task.kernel_symbol()) == (mapping == "split")
     env.task.tensors[_abi.ABB_EP_LEN].copy_(torch.randint(150, 201, (n,)))
     torch.cuda.synchronize()
     bufs = {k: env.sim.tensors[t].cpu().numpy().copy() for k, t in _ABB_SIM_T.items()}
