@@ -222,6 +222,7 @@ def committed_profile(kernel_key: str):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--test-fail-rank", type=int, default=None, help=argparse.SUPPRESS)     # tests only: this rank exits with status 3
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
@@ -280,8 +281,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if os.environ.get("SHIFU_AMD_TEST_FAIL_RANK") == str(rank) and world > 1:
-        raise SystemExit(3)      # tests/test_gpu_bench.py: a rank that dies must fail the whole job
+    if args.test_fail_rank is not None and args.test_fail_rank == rank and world > 1:
+        raise SystemExit(3)      # tests/test_gpu_bench.py (hidden flag): a rank that dies must fail the whole job
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the backend has no CPU fallback")
     # one rank per GPU; SHIFU_AMD_DIST_BACKEND=gloo (testing only) lets several ranks share a GPU to exercise the

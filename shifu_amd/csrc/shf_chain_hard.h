@@ -829,7 +829,7 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
       if (commit && fmaf(ps2, ps2, ps1 * ps1) > lim2) {
         ps1 = fmaf(-O.rt, ut1, O.p[1]); ps2 = fmaf(-O.rt, ut2, O.p[2]);
         const float nt2 = fmaf(ps2, ps2, ps1 * ps1);
-        const float sc1 = nt2 > lim2 ? lim * rsqrt_spec(nt2) : 1.0f;
+        const float sc1 = nt2 > rmaxf(lim2, 1e-30f) ? lim * rsqrt_spec(nt2) : 1.0f;   // (1e-30: a subnormal |p_t|^2 over a zero cone would make 0 * inf)
         ps1 *= sc1; ps2 *= sc1;
       }
       float dp0 = commit ? dn : 0.0f, dp1 = commit ? ps1 - O.p[1] : 0.0f, dp2 = commit ? ps2 - O.p[2] : 0.0f;

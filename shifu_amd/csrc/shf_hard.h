@@ -216,7 +216,7 @@ DEV void hard_sweeps(HardOwner& O, float* hc, const float* W, int l, int K, int 
         if (commit && fmaf(ps2, ps2, ps1 * ps1) > lim2) {      // (only the committing lanes: the others' updates are discarded)
           ps1 = fmaf(-O.rt, ut1, O.p[1]); ps2 = fmaf(-O.rt, ut2, O.p[2]);
           const float nt2 = fmaf(ps2, ps2, ps1 * ps1);
-          const float sc1 = nt2 > lim2 ? lim * rsqrt_spec(nt2) : 1.0f;
+          const float sc1 = nt2 > rmaxf(lim2, 1e-30f) ? lim * rsqrt_spec(nt2) : 1.0f;   // (1e-30: a subnormal |p_t|^2 over a zero cone would make 0 * inf)
           ps1 *= sc1; ps2 *= sc1;
         }
         float dp0 = commit ? dn : 0.0f, dp1 = commit ? ps1 - O.p[1] : 0.0f, dp2 = commit ? ps2 - O.p[2] : 0.0f;
@@ -247,7 +247,8 @@ DEV void hard_sweeps(HardOwner& O, float* hc, const float* W, int l, int K, int 
 #pragma unroll
       for (int r = 0; r < 3; r++) pw[r] = fmaf(q2, h[HC_T2 + r], fmaf(q1, h[HC_T1 + r], q0 * h[HC_N + r]));
       if (phase == 0) { h[HC_P] = pw[0]; h[HC_P + 1] = pw[1]; h[HC_P + 2] = pw[2]; }
-      else { h[HC_PV0] = pw[0]; h[HC_PV1] = pw[1]; h[HC_PV2] = pw[2]; }
+      // (without velocity iterations the second set is not used, but the impulse passes carry it along: defined values, not stale LDS)
+      if (phase == 1 || nvel == 0) { h[HC_PV0] = pw[0]; h[HC_PV1] = pw[1]; h[HC_PV2] = pw[2]; }
     }
   }
 }

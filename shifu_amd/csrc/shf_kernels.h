@@ -673,6 +673,18 @@ __global__ __launch_bounds__(512) void k_abb_step_pgs_wide(AbbArgs A) {
 //     ALL waves, regrouped at 32 lanes per env (two envs per wave): substep_hard_finish -- gather, response matrix, sweeps,
 //     impulse passes, integration (csrc/shf_hard.h, the code the run-time-shaped kernels run: same values, same bits)
 //   ---- S2
+// Barrier of TWO wavefronts of a workgroup (both resident: same workgroup) on an LDS counter that only grows: the k-th meeting
+// is over when the counter reaches 2 k.  k_abb_step_ws_hard's arm wave j and box wave j + 4 share four envs through all of a
+// sub-step, so they only wait for each other -- not, as with s_barrier, for the slowest of the workgroup's eight waves in each
+// of the three phases (the solve's time varies with the contact count: 14 % of the kernel was spent at the barrier behind it).
+DEV void pair_barrier(int* ctr, int target) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if ((threadIdx.x & 63u) == 0u) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // (bounded: a wave that lost its partner to a fault leaves after ~0.1 s instead of hanging the GPU)
+  for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target; spin++)
+    __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 template <int WT, bool LINK, bool HARD>
 DEV void abb_ws_body(const AbbArgs& A) {
   constexpr int G = 16, NL = 6, HALF = WT / 2, EPB = HALF / G;
@@ -714,6 +726,12 @@ DEV void abb_ws_body(const AbbArgs& A) {
     const float* root = A.S.root + (size_t)e * actors * 13;
     for (int i = l; i < 2 * nd; i += G) L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)] = dof[i];
     for (int i = l; i < 13 * actors; i += G) L.root[i] = root[i];
+  }
+  // HARD: the pair barrier's counter of (arm wave j, box wave j + 4): a spare word of their first env's tail
+  int* pair_ctr = reinterpret_cast<int*>(env_base + (size_t)(es & ~3) * env_words + (tgtl - (env_base + es * env_words)) + ABB_TGT_WORDS(nd) + ARM_KREC_WORDS(NL) + 2);
+  int pair_meet = 0;
+  if constexpr (HARD) {
+    if (arm && (t & 63) == 0) *pair_ctr = 0;
   }
   // AbbRobot.step's inverse kinematics on the box wave, beside the arm wave's loads (it reads the tensors directly)
   if (!arm && live && l == 0)
@@ -784,7 +802,7 @@ DEV void abb_ws_body(const AbbArgs& A) {
           }
         }
       }
-      __syncthreads();                           // S0'
+      pair_barrier(pair_ctr, 2 * ++pair_meet);   // S0' (this wave and its partner only)
       PHASE_MARK(25);
       if (live) {
         if (arm) {
@@ -803,12 +821,14 @@ DEV void abb_ws_body(const AbbArgs& A) {
           if (lq == 0) *link_count = nl;
         }
       }
-      __syncthreads();                           // S1
+      pair_barrier(pair_ctr, 2 * ++pair_meet);   // S1
       PHASE_MARK(27);
       {
-        // regrouped: thread t -> env t / 32 of the workgroup, lane t % 32
+        // regrouped at 32 lanes per env: the four envs of (arm wave j, box wave j + 4) stay with these two waves -- the arm
+        // wave solves its first two, the box wave the other two
         constexpr int G2 = 32;
-        const int es2 = tq / G2, l2 = tq % G2;
+        const int wq = tq >> 6, l2 = tq % G2;
+        const int es2 = 4 * (wq & 3) + 2 * (wq >> 2) + ((tq >> 5) & 1);
         const int e2 = blockIdx.x * EPB + es2;
         if (e2 < n) {
           const EnvLds L2 = env_lds_carve(env_base + es2 * env_words, nbt, nd, nslots, actors);
@@ -842,7 +862,7 @@ DEV void abb_ws_body(const AbbArgs& A) {
         C.dropped = (LINK && live && !arm) ? env_dropped(A.S.dropped, A.S.sp, e) : nullptr;
       }
       PHASE_MARK(28);
-      __syncthreads();                           // S2: the integrated state for the next sub-step's waves
+      pair_barrier(pair_ctr, 2 * ++pair_meet);   // S2: the integrated state for the next sub-step's waves
       PHASE_MARK(29);
       continue;
     }

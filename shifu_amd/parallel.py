@@ -108,19 +108,17 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
 
 # ---- launching one process per GPU (bench.py --gpus N, tools/train_a1.py --gpus N) ----
 def launch_ranks(script: str, argv: List[str], nproc: int) -> int:
-    """Start `script` once per GPU through torch.distributed.run (rendezvous on 127.0.0.1, a free port) as CHILD processes and
+    """Start `script` once per GPU through torch.distributed.run (--standalone: rendezvous on 127.0.0.1, a port the launcher binds itself) as CHILD processes and
     return the launcher's exit code: torchrun tears the other ranks down when one fails and exits non-zero, so a rank that
     dies takes the job's exit status with it instead of leaving the others waiting in a collective.  Call this before
     anything in the calling process has touched the GPU (the children initialise it themselves; a process that has
     initialised the GPU must never exec another program on this pool)."""
-    import socket
     import subprocess
     import sys
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    # --standalone: the launcher binds its own rendezvous port (no pick-a-free-port-then-hand-it-over race between two launches
+    # on one node); --local-addr: the container's hostname may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={nproc}", script] + list(argv)
     return subprocess.call(cmd)
 
 

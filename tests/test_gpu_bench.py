@@ -79,8 +79,9 @@ def test_a_failing_rank_fails_the_job():
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     env = dict(os.environ)
-    env.update({"SHIFU_AMD_DIST_BACKEND": "gloo", "SHIFU_AMD_TEST_FAIL_RANK": "1", "SHIFU_AMD_DIST_TIMEOUT_S": "60"})
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--no-cpu-baseline"],
+    env.update({"SHIFU_AMD_DIST_BACKEND": "gloo", "SHIFU_AMD_DIST_TIMEOUT_S": "60"})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--no-cpu-baseline",
+                        "--test-fail-rank", "1"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")], "no result line from a job that lost a rank"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # On the GPU box (gpurun): everything the round's numbers are quoted from, in one pass -> gpurun_out/final/.
-# Afterwards (here): copy bench_*.json to profiles/r05_bench_*.json, run tools/summarize_prof.py on the prof_* dirs.
+# Afterwards (here): copy bench_*.json to profiles/r06_bench_*.json, run tools/summarize_prof.py on the prof_* dirs.
 # Usage: tools/final_evidence.sh [part ...]   parts: tests bench sweep hooks phase prof prof_a1 prof_abb soak fuzz  (default: all but prof_a1 / prof_abb / fuzz)
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
@@ -16,10 +16,18 @@ if has tests; then
   cat "$OUT/pytest_gpu.txt"; tail -2 "$OUT/smoke.txt"
 fi
 if has bench; then
-  # the default solver (PGS, the reference's PhysX settings) on every workload, with the CPU baseline ...
+  # the default solver (TGS, the reference's PhysX settings: solver_type = 1) on every workload, with the CPU baseline ...
   for W in terrain flat trimesh abb; do
     python bench.py --workload $W $B > "$OUT/bench_$W.json" 2> "$OUT/bench_$W.err"
   done
+  # ... PGS (solver_type = 0) on the same ...
+  for W in terrain flat trimesh abb; do
+    python bench.py --workload $W --solver pgs $B --no-cpu-baseline > "$OUT/bench_${W}_pgs.json" 2>/dev/null
+  done
+  # ... the sixteen-constraint cap, config 5 on the run-time-shaped kernel and with the links as convex hulls
+  python bench.py --max-contacts 16 $B --no-cpu-baseline --no-other-solver > "$OUT/bench_terrain_k16.json" 2>/dev/null
+  python bench.py --workload abb --mapping body $B --no-cpu-baseline --no-other-solver > "$OUT/bench_abb_body.json" 2>/dev/null
+  python bench.py --workload abb --link-shapes hull $B --no-cpu-baseline --no-other-solver > "$OUT/bench_abb_hull.json" 2>/dev/null
   python bench.py --steps 20 --warmup 5 > "$OUT/bench_terrain_driver_shape.json" 2>/dev/null
   python bench.py --workload trimesh --self-collision $B --no-cpu-baseline --no-other-solver > "$OUT/bench_trimesh_selfcollision.json" 2>/dev/null
   python bench.py --workload abb --no-link-contacts $B --no-cpu-baseline > "$OUT/bench_abb_rod_only.json" 2>/dev/null
@@ -33,7 +41,7 @@ if has bench; then
 fi
 if has sweep; then
   # env-count sweep: where the throughput of one GPU saturates, both solvers
-  for S in pgs compliant; do for N in 1024 2048 4096 8192 16384 32768; do
+  for S in tgs pgs compliant; do for N in 1024 2048 4096 8192 16384 32768; do
     python bench.py --envs $N --solver $S --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 |
       python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$S', $N, d['ms_per_step'], '%.4g' % d['value'])"
   done; done > "$OUT/env_count_sweep.txt"
@@ -48,12 +56,12 @@ if has phase; then
   python tools/phase_clock.py 32 200 --chain --pgs > "$OUT/phase_a1_chain_pgs.txt" 2>&1
   python tools/phase_clock.py 32 200 --chain --pgs --self --trimesh > "$OUT/phase_a1_chain_pgs_tw_self.txt" 2>&1
   python tools/phase_clock.py 32 200 --chain > "$OUT/phase_a1_chain_g32.txt" 2>&1
+  python tools/phase_clock.py 16 100 --abb --split --link --pgs > "$OUT/phase_abb_ws_hard.txt" 2>&1
   python tools/phase_clock.py 32 100 --abb --link --pgs > "$OUT/phase_abb_pgs_link.txt" 2>&1
-  python tools/phase_clock.py 32 100 --abb --pgs --levels > "$OUT/phase_abb_pgs_rod.txt" 2>&1
 fi
 if has prof_a1; then
-  bash tools/profile.sh r05_a1_pgs > /dev/null 2>&1
-  bash tools/profile.sh r05_a1_pgs_tw_self --workload trimesh --self-collision > /dev/null 2>&1
+  bash tools/profile.sh r06_a1_tgs > /dev/null 2>&1
+  bash tools/profile.sh r06_a1_pgs --solver pgs > /dev/null 2>&1
   find "$REPO/gpurun_out" -name "*kernel_trace.csv" -size +4M -delete
 fi
 if has fuzz; then
@@ -61,16 +69,17 @@ if has fuzz; then
   wc -l "$OUT/fuzz.txt"
 fi
 if has prof_abb; then
-  bash tools/profile.sh r05_abb_pgs --workload abb > /dev/null 2>&1
+  bash tools/profile.sh r06_abb_tgs --workload abb > /dev/null 2>&1
   find "$REPO/gpurun_out" -name "*kernel_trace.csv" -size +4M -delete
 fi
 if has prof; then
-  bash tools/profile.sh r05_a1_pgs > /dev/null 2>&1                                                    # the default: k_a1_chain_pgs<false,false>
-  bash tools/profile.sh r05_a1_pgs_tw_self --workload trimesh --self-collision > /dev/null 2>&1         # the reference's effective scene: <true,true>
-  bash tools/profile.sh r05_a1_tw_self_compliant --workload trimesh --self-collision --solver compliant > /dev/null 2>&1   # k_a1_chain<32,true,true>
-  bash tools/profile.sh r05_a1_compliant --solver compliant > /dev/null 2>&1
-  bash tools/profile.sh r05_abb_pgs --workload abb > /dev/null 2>&1                                     # config 5 under PGS (generic kernel)
-  bash tools/profile.sh r05_abb_compliant --workload abb --solver compliant > /dev/null 2>&1            # k_abb_step_ws<512,true>
+  bash tools/profile.sh r06_a1_tgs > /dev/null 2>&1                                                    # the default: k_a1_chain_tgs<false,false>
+  bash tools/profile.sh r06_a1_pgs --solver pgs > /dev/null 2>&1                                       # k_a1_chain_pgs<false,false>
+  bash tools/profile.sh r06_a1_tgs_tw_self --workload trimesh --self-collision > /dev/null 2>&1         # the reference's effective scene: <true,true>
+  bash tools/profile.sh r06_a1_compliant --solver compliant > /dev/null 2>&1
+  bash tools/profile.sh r06_abb_tgs --workload abb > /dev/null 2>&1                                     # config 5 under TGS: k_abb_step_ws_hard<true>
+  bash tools/profile.sh r06_abb_pgs --workload abb --solver pgs > /dev/null 2>&1
+  bash tools/profile.sh r06_abb_compliant --workload abb --solver compliant > /dev/null 2>&1            # k_abb_step_ws<512,true>
   find "$REPO/gpurun_out" -name "*kernel_trace.csv" -size +4M -delete     # keep the merge under gpurun's 64 MiB
 fi
 if has soak; then

@@ -87,6 +87,8 @@ def main():
         tot = sum(buf[:19])                       # chain kernel: the solve's parts are marks 5, 10, 17, 18
     if pgs and abb:
         tot = sum(buf[:24]) + sum(buf[32:38]) + (sum(buf[24:29]) if link else 0)    # generic kernel: every mark is its own interval
+    if pgs and abb and split:
+        tot = sum(buf[11:17]) + sum(buf[24:30])     # k_abb_step_ws_hard: the arm wave's intervals (6 and 32-37 lie inside 26 and 28)
     print(f"G={G}: {tot / steps:.0f} cycles per env-step in block 0 / wave 0 (s_memtime ticks)")
     extra_names = ['box: corner slots', 'box: sphere slots', 'box: fold', 'fold: box lane corners', 'fold: pair law', 'fold: sync', 'fold: arm lanes', 'split: arm wave before S1', 'split: wait at S1', 'split: arm wave S1 -> S4', 'split: wait at S4', 'split: arm wave after S4', 'split: final barrier']
     if link and split:
@@ -94,6 +96,12 @@ def main():
         extra_names[0:6] = ['box wave: finish of the sub-step before (+ prologue)', 'box wave: poses + corner / edge slots', 'box wave: parking inertia and ballots',
                             'box wave: wait at S0\'', 'box wave: link passes', 'box wave: idle from its link passes to S4']
         extra_names[12] = '(debug counter, not a time)'
+    if pgs and abb and split:
+        # k_abb_step_ws_hard: marks 24-29 are wave 0's clock (arm wave of envs 0-3, then the solve of envs 0-1)
+        extra_names[0:6] = ['(unused)'] * 6
+        extra_names[7:13] = ['arm wave: joints, drives, chain composition', "arm wave: wait at S0' (box wave: poses, corner candidates)",
+                             'arm wave: inertias, point candidates, free ABA (mark 6 inside)', 'arm wave: wait at S1 (box wave: rod + link candidates)',
+                             'the regrouped solve, integration, forces (marks 32-37 inside)', 'wait at S2 (the partner wave\'s solve)']
     if link and not split:
         # the link passes' own clock (csrc/shf_boxes.h: link_contacts): marks 24-28; mark 20 then spans all of them once more
         extra_names[7:12] = ['link: broad phase (body, box) pairs', 'link: pair set-up', 'link: sample points vs the box (family A)',
