@@ -832,8 +832,11 @@ DEV void chain_substep_hard(const StepCtx& C, const ChainLds& L, int l, DofLane&
         const float sc1 = nt2 > rmaxf(lim2, 1e-30f) ? lim * rsqrt_spec(nt2) : 1.0f;   // (1e-30: a subnormal |p_t|^2 over a zero cone would make 0 * inf)
         ps1 *= sc1; ps2 *= sc1;
       }
-      float dp0 = commit ? dn : 0.0f, dp1 = commit ? ps1 - O.p[1] : 0.0f, dp2 = commit ? ps2 - O.p[2] : 0.0f;
-      if (commit) { O.p[0] = pn; O.p[1] = ps1; O.p[2] = ps2; }
+      // (the committing lane takes the update by selects -- an exec-masked block of moves cost ten instructions per visit --; the
+      // change is new - old: pn - pn0 = dn on that lane, exactly 0 on the others)
+      const float n0 = commit ? pn : O.p[0], n1 = commit ? ps1 : O.p[1], n2 = commit ? ps2 : O.p[2];
+      float dp0 = n0 - O.p[0], dp1 = n1 - O.p[1], dp2 = n2 - O.p[2];
+      O.p[0] = n0; O.p[1] = n1; O.p[2] = n2;
       // the change of contact c's impulse, from its owner lane (lane c of each env: wave lanes c and 32 + c) to every lane
       {
         const float a0 = hard_readlane(dp0, c), a1 = hard_readlane(dp1, c), a2 = hard_readlane(dp2, c);

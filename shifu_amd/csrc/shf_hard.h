@@ -328,21 +328,26 @@ DEV void hg_velocity(const ShfModel* m, const EnvLds& L, int nb, const HgResp& q
 struct HgSeq {
   int nev, nself, nbx, T, nsph, nlink, self_slot0, link_slot0, P1, P2, P3, P4;
 };
+template <class SC>
 DEV const float* hg_slot_raw(const ShfModel* m, const SceneDev* S, const EnvLds& L, const SlotLay& Q, const HgSeq& H, int idx,
                              int* ba, int* bb, int* ra, int* rb);
 // ... with the root of a fixed-base articulation as what it is to the solve: immovable, like terrain or a fixed box (-1); a
 // contact between two immovable things is no constraint (oracle: hc_offer)
+template <class SC>
 DEV const float* hg_slot(const ShfModel* m, const SceneDev* S, const EnvLds& L, const SlotLay& Q, const HgSeq& H, int idx,
                          int* ba, int* bb, int* ra, int* rb) {
-  const float* o = hg_slot_raw(m, S, L, Q, H, idx, ba, bb, ra, rb);
+  const float* o = hg_slot_raw<SC>(m, S, L, Q, H, idx, ba, bb, ra, rb);
   if (o == nullptr) return nullptr;
   if (m->fixed_base && *ba == 0) *ba = -1;
   if (m->fixed_base && *bb == 0) *bb = -1;
   return (*ba < 0 && *bb < 0) ? nullptr : o;
 }
+// (SC: a compile-time scene makes the box count a constant -- the decoding's divisions become shifts and multiplications)
+template <class SC>
 DEV const float* hg_slot_raw(const ShfModel* m, const SceneDev* S, const EnvLds& L, const SlotLay& Q, const HgSeq& H, int idx,
                              int* ba, int* bb, int* ra, int* rb) {
   const int nb = m->nb;
+  const int HT = SC::NBX > 0 ? 1 + SC::NBX : H.T, Hnbx = SC::NBX > 0 ? SC::NBX : H.nbx;
   *bb = -1; *rb = -1;
   if (idx < H.nev) {
     const int i = m->neval > 0 ? m->pt_eval[idx] : idx;
@@ -359,13 +364,13 @@ DEV const float* hg_slot_raw(const ShfModel* m, const SceneDev* S, const EnvLds&
     return o;
   }
   if (idx < H.P2) {
-    const int j = idx - H.P1, kd = j / (8 * H.T), c = (j / H.T) % 8, tg = j % H.T;
+    const int j = idx - H.P1, kd = j / (8 * HT), c = (j / HT) % 8, tg = j % HT;
     if (!box_is_dynamic(S->box[kd])) return nullptr;
     *ba = nb + kd; *ra = nb + kd;
     return L.pt + corner_slot(Q, kd, c, tg) * PT_STRIDE;
   }
   if (idx < H.P3) {
-    const int j = idx - H.P2, si = j / H.nbx, kd = j % H.nbx;
+    const int j = idx - H.P2, si = j / Hnbx, kd = j % Hnbx;
     if (!box_is_dynamic(S->box[kd])) return nullptr;
     *ra = m->sph_body[si]; *ba = m->dyn[*ra];
     *bb = nb + kd; *rb = nb + kd;
@@ -381,7 +386,7 @@ DEV const float* hg_slot_raw(const ShfModel* m, const SceneDev* S, const EnvLds&
 
 // gather: the K <= kmax candidates with the smallest gap (ties: candidate order), in candidate order, as constraint records.
 // Returns K.  oracle: hc_offer / hc_finish.
-template <int G>
+template <int G, class SC>
 DEV int hg_gather(const StepCtx& C, const EnvLds& L, const SlotLay& Q, const HgSeq& H, int l, float* hc, int kmax, int LISTMAX) {
   const ShfModel* m = C.m;
   const SceneDev* S = C.scene;
@@ -395,7 +400,7 @@ DEV int hg_gather(const StepCtx& C, const EnvLds& L, const SlotLay& Q, const HgS
   for (int base = 0; base < H.P4; base += G) {
     const int idx = base + l;
     int ba, bb, ra, rb;
-    const float* o = idx < H.P4 ? hg_slot(m, S, L, Q, H, idx, &ba, &bb, &ra, &rb) : nullptr;
+    const float* o = idx < H.P4 ? hg_slot<SC>(m, S, L, Q, H, idx, &ba, &bb, &ra, &rb) : nullptr;
     const bool on = o != nullptr && o[PT_ON] != 0.0f;
     const unsigned long long mask = (__ballot(on) >> lane0) & gmask;
     if (on) {
@@ -440,7 +445,7 @@ DEV int hg_gather(const StepCtx& C, const EnvLds& L, const SlotLay& Q, const HgS
       const unsigned long long mask = (__ballot(sel) >> lane0) & gmask;
       if (sel) {
         int ba = -1, bb = -1, ra = -1, rb = -1;
-        const float* o = hg_slot(m, S, L, Q, H, idx, &ba, &bb, &ra, &rb);
+        const float* o = hg_slot<SC>(m, S, L, Q, H, idx, &ba, &bb, &ra, &rb);
         record(count + __builtin_popcountll(mask & ((1ull << l) - 1ull)), o, ba, bb, ra, rb);
       }
       count += __builtin_popcountll(mask);
@@ -452,7 +457,7 @@ DEV int hg_gather(const StepCtx& C, const EnvLds& L, const SlotLay& Q, const HgS
   for (int base = 0; base < H.P4; base += G) {
     const int idx = base + l;
     int ba = -1, bb = -1, ra = -1, rb = -1;
-    const float* o = idx < H.P4 ? hg_slot(m, S, L, Q, H, idx, &ba, &bb, &ra, &rb) : nullptr;
+    const float* o = idx < H.P4 ? hg_slot<SC>(m, S, L, Q, H, idx, &ba, &bb, &ra, &rb) : nullptr;
     bool sel = o != nullptr && o[PT_ON] != 0.0f;
     if (__ballot(overflow && sel) != 0ull) {
       int rank = 0;
@@ -460,7 +465,7 @@ DEV int hg_gather(const StepCtx& C, const EnvLds& L, const SlotLay& Q, const HgS
       if (overflow && sel) {
         for (int j = 0; j < H.P4; j++) {
           int a0, a1, a2, a3;
-          const float* oj = hg_slot(m, S, L, Q, H, j, &a0, &a1, &a2, &a3);
+          const float* oj = hg_slot<SC>(m, S, L, Q, H, j, &a0, &a1, &a2, &a3);
           if (oj == nullptr || oj[PT_ON] == 0.0f) continue;
           const float pj = oj[PT_F];
           rank += (pj < ph || (pj == ph && j < idx)) ? 1 : 0;
@@ -534,31 +539,20 @@ DEV float* hg_ac(const EnvLds& L, int q, int b) {
   return q == 0 ? L.acc + b * 6 : (b == 0 ? L.xch + HB_FDL : L.xch + b * XCH_STRIDE + HB_S);
 }
 
-// The velocity-level solve of the body-per-lane sub-step, after its FREE articulated-body solve: records, gather, columns,
-// owners, sweeps, the impulse passes, integration (poses with the accelerations after the position iterations, velocities
-// after the velocity iterations), net contact forces.  `a`: lane 0 holds the root's free acceleration.
-template <int G, bool BOX, class DM, class LM, class SC, bool SELF, bool LINK>
-DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM& M, BodyRegs& B, const float* g, float* a, int nself,
-                             int self_slot0, int link_slot0, int nlink, float* contact_out) {
-  static_assert(G == 32, "two envs per wavefront (hard_sweeps)");
+// records (oracle: the solver bodies' response data): body lane b -> S, U, 1/D in its exchange slot; the root's / the free boxes'
+// LDL^T factors in theirs; then the velocity rates Dl = S qdd + Dl(parent) down the tree.  abox: a free box's free acceleration
+// (its lane; the integration needs it again).  A group sync has to follow.  Its own function since round 6: k_abb_step_ws_hard
+// runs it on the arm wave (16 lanes per env) while the box wave is still busy with the link candidates.
+template <int G, bool BOX, class DM, class LM>
+DEV void hard_records(const StepCtx& C, const EnvLds& L, int l, const LM& M, const BodyRegs& B, const float* g, const float* a, float* abox) {
   const ShfModel* m = C.m;
   const SceneDev* S = C.scene;
-  const int nb = DM::nb(m), nd = DM::nd(m), nbx = BOX ? S->nboxes : 0, nbt = nb + nbx;
-  const float dt = C.sp.dt, idt = 1.0f / dt;
-  const bool isdyn = M.isdyn, moving = M.moving;
+  const int nb = DM::nb(m), nbx = BOX ? S->nboxes : 0;
+  const bool moving = M.moving;
   const int mylevel = M.level(), nl = DM::nlevels(m);
   const int kd = l - nb;
   const bool dynbox = BOX && kd >= 0 && kd < nbx && box_is_dynamic(S->box[kd]);
   const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
-  const int hc0 = hard_hc_slot0(link_slot0 + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0), LINK);
-  float* hc = L.pt + hc0 * PT_STRIDE;
-  float* W = L.pt;           // (in the place of the first 48 slots, from the columns on: see hard_hc_slot0)
-  const int npos = C.sp.pos_iters > 0 ? C.sp.pos_iters : 0, nvel = C.sp.vel_iters > 0 ? C.sp.vel_iters : 0;
-  const int kmax = hard_kmax_of(C.sp, HCK);
-
-  PHASE_BEGIN();
-  // ---- records
-  float abox[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};      // a free box's free acceleration (its lane)
   if (moving) {
     float* rec = L.xch + l * XCH_STRIDE;
 #pragma unroll
@@ -606,6 +600,40 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
       for (int k = 0; k < 6; k++) rec[HB_DL + k] = fmaf(B.S[k], qdd, dp[k]);
     }
   }
+}
+
+// The velocity-level solve of the body-per-lane sub-step, after its FREE articulated-body solve: records, gather, columns,
+// owners, sweeps, the impulse passes, integration (poses with the accelerations after the position iterations, velocities
+// after the velocity iterations), net contact forces.  `a`: lane 0 holds the root's free acceleration.
+template <int G, bool BOX, class DM, class LM, class SC, bool SELF, bool LINK, bool RECORDS>
+DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM& M, BodyRegs& B, const float* g, float* a, int nself,
+                             int self_slot0, int link_slot0, int nlink, float* contact_out) {
+  static_assert(G == 32, "two envs per wavefront (hard_sweeps)");
+  const ShfModel* m = C.m;
+  const SceneDev* S = C.scene;
+  const int nb = DM::nb(m), nd = DM::nd(m), nbx = BOX ? S->nboxes : 0, nbt = nb + nbx;
+  const float dt = C.sp.dt, idt = 1.0f / dt;
+  const bool isdyn = M.isdyn, moving = M.moving;
+  const int mylevel = M.level(), nl = DM::nlevels(m);
+  const int kd = l - nb;
+  const bool dynbox = BOX && kd >= 0 && kd < nbx && box_is_dynamic(S->box[kd]);
+  const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
+  const int hc0 = hard_hc_slot0(link_slot0 + (LINK ? 2 * SHF_MAX_LINK_CONTACTS : 0), LINK);
+  float* hc = L.pt + hc0 * PT_STRIDE;
+  float* W = L.pt;           // (in the place of the first 48 slots, from the columns on: see hard_hc_slot0)
+  const int npos = C.sp.pos_iters > 0 ? C.sp.pos_iters : 0, nvel = C.sp.vel_iters > 0 ? C.sp.vel_iters : 0;
+  const int kmax = hard_kmax_of(C.sp, HCK);
+
+  PHASE_BEGIN();
+  // ---- records
+  float abox[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};      // a free box's free acceleration (its lane)
+  if constexpr (RECORDS) {
+    hard_records<G, BOX, DM, LM>(C, L, l, M, B, g, a, abox);
+  } else if (dynbox) {
+    // (written beside the records by whoever ran hard_records: the box actors' rows of the acceleration array are free)
+#pragma unroll
+    for (int k = 0; k < 6; k++) abox[k] = L.acc[l * 6 + k];
+  }
   GROUP_SYNC();
   PHASE_MARK(32);
 
@@ -616,7 +644,7 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
   H.nself = SELF ? nself : 0; H.nbx = nbx; H.T = 1 + nbx; H.nsph = BOX ? m->nsph : 0; H.nlink = LINK ? nlink : 0;
   H.self_slot0 = self_slot0; H.link_slot0 = link_slot0;
   H.P1 = H.nev + H.nself; H.P2 = H.P1 + nbx * 8 * H.T; H.P3 = H.P2 + H.nsph * nbx; H.P4 = H.P3 + H.nlink;
-  const int K = hg_gather<G>(C, L, Q, H, l, hc, kmax, hc0);
+  const int K = hg_gather<G, SC>(C, L, Q, H, l, hc, kmax, hc0);
   GROUP_SYNC();
   PHASE_MARK(33);
 

@@ -773,11 +773,31 @@ DEV void abb_ws_body(const AbbArgs& A) {
   for (int it = 0; it < nsub; it++) {
     float* contact_out = it == nsub - 1 ? L.xch : nullptr;   // reported for the last sub-step only
     if constexpr (HARD) {
-      // (the lane ids pass through an empty asm once per sub-step: what is derived from them -- LDS addresses, masks, per-lane
-      // constants -- is then recomputed where it is used instead of being hoisted out of the loop as ~100 values, most of
-      // which were spilled)
-      int lq = l, tq = (int)threadIdx.x;
-      asm volatile("" : "+v"(lq), "+v"(tq));
+      // Everything lane-specific of a sub-step is derived here from the thread id passed through an empty asm: LDS addresses,
+      // masks and per-lane constants are then recomputed where they are used instead of being hoisted out of the loop (~100
+      // values, most of them spilled), and nothing but the loop counters has to stay in registers across the solve, whose own
+      // peak is close to the 256 available.  The names shadow the kernel's.
+      int tq = (int)threadIdx.x;
+      asm volatile("" : "+v"(tq));
+      {
+        float dtq = C.sp.dt;                     // (likewise the step: 1 / dt, dt / n, ... are a dozen IEEE divisions' worth of registers)
+        asm volatile("" : "+s"(dtq));
+        C.sp.dt = dtq;
+      }
+      const bool arm = tq < HALF;
+      const int t16 = tq - (arm ? 0 : HALF), esq = t16 / G, lq = t16 % G;
+      const int e = blockIdx.x * EPB + esq;
+      const bool live = e < n;
+      const float mu = live ? A.S.friction[e] : 0.0f;
+      C.dropped = (LINK && live && !arm) ? env_dropped(A.S.dropped, A.S.sp, e) : nullptr;
+      C.mscale = (live && A.S.mscale) ? A.S.mscale + (size_t)e * DM::nb(m) : nullptr;
+      const EnvLds L = env_lds_carve(env_base + esq * env_words, nbt, nd, nslots, actors);
+      float* tgtl = L.pt + nslots * PT_STRIDE;
+      float* krec = tgtl + ABB_TGT_WORDS(nd);
+      int* link_count = reinterpret_cast<int*>(krec + ARM_KREC_WORDS(NL) + 1);
+      float* box_stash = krec + ARM_KREC_WORDS(NL) + 4;
+      int* pair_ctr = reinterpret_cast<int*>(env_base + (size_t)(esq & ~3) * env_words + (tgtl - (env_base + esq * env_words)) + ABB_TGT_WORDS(nd) + ARM_KREC_WORDS(NL) + 2);
+      const float gq[3] = {AL.g[0], AL.g[1], AL.g[2]};
       if (live) {
         if (arm) {
           WS_ARM_LOCALS_AT(lq);
@@ -812,12 +832,38 @@ DEV void abb_ws_body(const AbbArgs& A) {
           ALl.hand_over(Ba);
           GROUP_SYNC();
           ALl.recursions();
+          GROUP_SYNC();
+          // the solve's body records and velocity rates (csrc/shf_hard.h: hard_records) here, on the arm wave, which would
+          // otherwise wait for the box wave's link passes: links from the chain lane's records, the free box (its rigid
+          // inertia parked by the box wave before S0') on the lane of its actor index
+          {
+            BodyRegs Br;
+            if (lq >= 1 && lq <= NL) {
+              const float* kr = krec + (lq - 1) * KREC_STRIDE;
+#pragma unroll
+              for (int k = 0; k < 6; k++) { Br.S[k] = kr[k]; Br.U[k] = kr[12 + k]; }
+              Br.invD = kr[18];
+            }
+            if (lq == nb + SC::DYN) {
+#pragma unroll
+              for (int k = 0; k < 21; k++) Br.IA[k] = box_stash[k];
+#pragma unroll
+              for (int k = 0; k < 6; k++) Br.pA[k] = box_stash[21 + k];
+            }
+            const float a0[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};     // (a fixed base: the root's record is zero)
+            float abox[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            hard_records<G, true, DM, LaneModel>(C, L, lq, Ml, Br, gq, a0, abox);
+            if (lq == nb + SC::DYN) {
+#pragma unroll
+              for (int k = 0; k < 6; k++) L.acc[lq * 6 + k] = abox[k];      // -> the box's lane of the solve
+            }
+          }
           PHASE_MARK(26);
         } else {
           BoxMasks BMb;
-          fixed_sphere_slots<G, SC, true>(C, L, lq, mu, AL.g, BMb);
+          fixed_sphere_slots<G, SC, true>(C, L, lq, mu, gq, BMb);
           int nl = 0;
-          if constexpr (LINK) nl = link_contacts<G>(C, L, lq, link_slot0, mu, AL.g);
+          if constexpr (LINK) nl = link_contacts<G>(C, L, lq, link_slot0, mu, gq);
           if (lq == 0) *link_count = nl;
         }
       }
@@ -848,18 +894,13 @@ DEV void abb_ws_body(const AbbArgs& A) {
           }
           if (l2 == nb + SC::DYN) {
 #pragma unroll
-            for (int k = 0; k < 21; k++) B2.IA[k] = stash2[k];
-#pragma unroll
-            for (int k = 0; k < 6; k++) B2.pA[k] = stash2[21 + k];
-#pragma unroll
             for (int k = 0; k < 3; k++) B2.p[k] = stash2[27 + k];
           }
-          const float g2[3] = {AL.g[0], AL.g[1], AL.g[2]};     // (a local copy: the solve selects between pointers to it and to the boxes' gravity)
+          const float g2[3] = {gq[0], gq[1], gq[2]};     // (a local copy: the solve selects between pointers to it and to the boxes' gravity)
           float a2[6] = {0.0f, 0.0f, 0.0f, -g2[0], -g2[1], -g2[2]};
-          substep_hard_finish<G2, true, DM, LM2, SC, false, LINK>(C, L2, l2, M2, B2, g2, a2, 0, link_slot0, link_slot0, nlink2,
+          substep_hard_finish<G2, true, DM, LM2, SC, false, LINK, false>(C, L2, l2, M2, B2, g2, a2, 0, link_slot0, link_slot0, nlink2,
                                                                    it == nsub - 1 ? L2.xch : nullptr);
         }
-        C.dropped = (LINK && live && !arm) ? env_dropped(A.S.dropped, A.S.sp, e) : nullptr;
       }
       PHASE_MARK(28);
       pair_barrier(pair_ctr, 2 * ++pair_meet);   // S2: the integrated state for the next sub-step's waves

@@ -381,14 +381,15 @@ def test_fused_a1_env_on_the_benchmark_scene_matches_oracle_bitwise_at_full_size
 
 
 def test_long_differential_run_of_every_kernel_form(oracle):
-    """tools/fuzz_parity.py trimmed to fit the suite: 320 vec-steps x 192 envs (64 with link contacts) of all fifteen kernel
-    forms of both tasks -- twelve of the compliant law, three of the velocity-level solve -- against the oracle, every tensor compared every 80 steps, through hundreds of resets
+    """tools/fuzz_parity.py trimmed to fit the suite: 320 vec-steps x 192 envs (64 with link contacts) of all nineteen kernel
+    forms of both tasks -- twelve of the compliant law, seven of the velocity-level solve (A1 chain PGS / TGS, config 5 on the run-time-shaped kernel
+    and on k_abb_step_ws_hard) -- against the oracle, every tensor compared every 80 steps, through hundreds of resets
     (the 2000-step run is profiles/r03_fuzz_parity.txt)."""
     _need_gpu()
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_parity
     out = fuzz_parity.run(steps=320, envs=192, every=80, link_envs=64)
-    assert len(out) == 15 and all(r["equal"] for r in out)
+    assert len(out) == 19 and all(r["equal"] for r in out)
     assert sum(r["resets"] for r in out if r["task"] == "a1") > 300 and sum(r["resets"] for r in out if r["task"] == "abb") > 300
 
 

@@ -78,3 +78,27 @@ def test_global_types_follow_global_env_ids():
     lo, hi = shard_range(total, 5, 8)
     shard = torch.div(torch.arange(lo, hi), total / cols, rounding_mode='floor').long()
     assert torch.equal(full[lo:hi], shard)
+
+
+def test_launch_ranks_owns_its_rendezvous_port(tmp_path):
+    """shifu_amd.parallel.launch_ranks (what `bench.py --gpus N` and tools/train_a1.py become when started bare): two gloo ranks
+    through torch.distributed.run --standalone -- the launcher binds the rendezvous port itself, so two launches at once cannot
+    be handed the same "free" port -- and a rank that exits non-zero fails the job."""
+    import subprocess
+    import sys
+    script = tmp_path / "ranks.py"
+    script.write_text(
+        "import os, sys\n"
+        "import torch.distributed as dist\n"
+        "if len(sys.argv) > 1 and os.environ['RANK'] == sys.argv[1]:\n"
+        "    raise SystemExit(3)\n"
+        "dist.init_process_group('gloo')\n"
+        "assert dist.get_world_size() == 2 and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "dist.barrier()\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import sys; from shifu_amd.parallel import launch_ranks; raise SystemExit(launch_ranks(sys.argv[1], sys.argv[2:], 2))"
+    two = [subprocess.Popen([sys.executable, "-c", code, str(script)], cwd=root, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+           for _ in range(2)]                                     # two launches side by side
+    assert [p.wait(timeout=240) for p in two] == [0, 0]
+    bad = subprocess.run([sys.executable, "-c", code, str(script), "1"], cwd=root, capture_output=True, timeout=240)
+    assert bad.returncode != 0

@@ -28,10 +28,10 @@ def run(steps=2000, envs=384, every=100, link_envs=128):
     import test_gpu_parity as T
     from shifu_amd import _abi
     out = []
-    for group in (32, "chain32", "chain16", "pgs"):       # "pgs": k_a1_chain_pgs, the velocity-level solve (chain mapping, 32 lanes)
+    for group in (32, "chain32", "chain16", "pgs", "tgs"):       # "pgs" / "tgs": k_a1_chain_pgs / _tgs, the velocity-level solve (chain mapping, 32 lanes)
         t0 = time.time()
-        cm, sp, tp, terr, hs, bufs, sim, task, rng = T._a1_setup(args.envs, True, seed=123, group="chain32" if group == "pgs" else group, env_off=777,
-                                                                 **({"solver": "pgs"} if group == "pgs" else {}))
+        cm, sp, tp, terr, hs, bufs, sim, task, rng = T._a1_setup(args.envs, True, seed=123, group="chain32" if group in ("pgs", "tgs") else group, env_off=777,
+                                                                 **({"solver": group} if group in ("pgs", "tgs") else {}))
         resets = 0
         for it in range(args.steps):
             raw = (2 * rng.random((args.envs, cm.blob.nd)) - 1).astype(np.float32) * (1.5 if it % 400 < 200 else 0.3)
@@ -53,7 +53,10 @@ def run(steps=2000, envs=384, every=100, link_envs=128):
                      ("link16", dict(group=16, link_contacts=True)), ("link16-body", dict(group=16, link_contacts=True, mapping="body")),
                      ("link32", dict(group=32, link_contacts=True)),
                      ("link32-generic", dict(group=32, link_contacts=True, extra_boxes=extra)),
-                     ("pgs", dict(link_contacts=False, solver="pgs")), ("pgs-link", dict(link_contacts=True, solver="pgs"))):
+                     ("pgs", dict(link_contacts=False, solver="pgs", mapping="body")), ("pgs-link", dict(link_contacts=True, solver="pgs", mapping="body")),
+                     # k_abb_step_ws_hard (round 6): arm wave + box wave, the solve regrouped at 32 lanes per env
+                     ("pgs-split", dict(link_contacts=False, solver="pgs")), ("pgs-link-split", dict(link_contacts=True, solver="pgs")),
+                     ("tgs-link-split", dict(link_contacts=True, solver="tgs"))):
         kw.setdefault("solver", "compliant")
         t0 = time.time()
         n = args.envs if "link" not in name else min(args.envs, link_envs)
