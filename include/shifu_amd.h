@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SHF_ABI_VERSION 14
+#define SHF_ABI_VERSION 15
 
 #define SHF_MAX_BODIES 32 /* reported rigid bodies per articulation        */
 #define SHF_MAX_DOFS 32
@@ -464,6 +464,12 @@ int shf_sim_commit_root_all(ShfSim* sim, const float* root_dev, void* stream);
 /* gym.set_dof_state_tensor_indexed (robot.py:83-86) */
 int shf_sim_commit_dof_indexed(ShfSim* sim, const float* dof_dev, const int32_t* actor_idx_dev, int32_t n,
                                void* stream);
+/* The three indexed commits of one reset as ONE launch (ABI v15): what IsaacGymEnv.reset_idx (isaac_gym.py:54-73) issues for a
+ * reset set -- Robot._reset_dof_state's gym.set_dof_position_target_tensor_indexed and gym.set_dof_state_tensor_indexed
+ * (robot.py:78-86), then gym.set_actor_root_state_tensor_indexed (isaac_gym.py:70-73) over every actor's rows.  Any part may
+ * be empty (n = 0, pointers NULL); the same result as the three calls above in that order. */
+int shf_sim_commit_reset(ShfSim* sim, const float* root_dev, const int32_t* root_idx_dev, int32_t n_root, const float* dof_dev,
+                         const float* pos_target_dev, const int32_t* dof_actor_idx_dev, int32_t n_dof, void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused A1Conditional env step: everything
@@ -745,6 +751,14 @@ int shf_rows_fill_indexed(float* buf, const int64_t* idx, int32_t n_idx, int64_t
  * device, zero before the first call (the kernel leaves it zero). */
 int shf_episode_log(float* const* sums, int32_t num_keys, const int64_t* env_ids, int32_t n_ids, int64_t num_envs,
                     float episode_length_s, int64_t* workspace17, float* out_means, void* stream);
+/* The buffer part of ShifuVecEnv.reset_idx (shifu/gym/env.py:114-130) for one reset set as ONE launch (ABI v15):
+ * episode_length[env_ids] = 0, reset_buf[env_ids] = 1 (elements of reset_elem_bytes = 1 or 8 bytes: a bool / uint8 or an
+ * int64 tensor), the action history's rows zeroed (HistoryRecorder.reset_idx, train.py:16-17: history_row_words floats per
+ * env) and log_info (env.py:149-158) exactly as shf_episode_log does it.  Every optional tensor may be NULL. */
+int shf_reset_bookkeeping(float* const* sums, int32_t num_keys, const int64_t* env_ids, int32_t n_ids, int64_t num_envs,
+                          float episode_length_s, int64_t* workspace17, float* out_means, int64_t* episode_length_or_null,
+                          void* reset_buf_or_null, int32_t reset_elem_bytes, float* history_or_null, int32_t history_row_words,
+                          void* stream);
 /* Robot._reset_dof_state (shifu/units/robot.py:74-86) ahead of its two indexed commits: for every env id,
  * dof_targets[e, :] = dof_state[e, :, 0] = default_dof_pos, dof_state[e, :, 1] = 0 on the (num_envs, num_dof[, 2])
  * tensors, and actor_ids_out[i] = (int32) root_idx[e] -- the index tensor set_dof_*_tensor_indexed takes. */

@@ -1,7 +1,7 @@
 """ctypes mirrors of the PODs in include/shifu_amd.h (keep in lock-step)."""
 import ctypes as C
 
-SHF_ABI_VERSION = 14
+SHF_ABI_VERSION = 15
 MAP_BODY, MAP_CHAIN, MAP_CHAIN_SPLIT = 0, 1, 2   # shf_sim_set_mapping
 MAX_BODIES = 32
 MAX_DOFS = 32

@@ -39,6 +39,7 @@ _SIGS = {
     "shf_sim_commit_root_indexed": ([vp, vp, vp, i32, vp], i32),
     "shf_sim_commit_root_all": ([vp, vp, vp], i32),
     "shf_sim_commit_dof_indexed": ([vp, vp, vp, i32, vp], i32),
+    "shf_sim_commit_reset": ([vp, vp, vp, i32, vp, vp, vp, i32, vp], i32),
     "shf_a1_create": ([vp, C.POINTER(_abi.ShfA1TaskParams), C.POINTER(vp)], i32),
     "shf_a1_destroy": ([vp], i32),
     "shf_a1_layout": ([vp, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)], i32),
@@ -75,6 +76,7 @@ _SIGS = {
     "shf_history_add": ([vp, vp, i64, i32, vp], i32),
     "shf_rows_fill_indexed": ([vp, vp, i32, i64, i32, C.c_float, vp], i32),
     "shf_episode_log": ([C.POINTER(vp), i32, vp, i32, i64, C.c_float, vp, vp, vp], i32),
+    "shf_reset_bookkeeping": ([C.POINTER(vp), i32, vp, i32, i64, C.c_float, vp, vp, vp, vp, i32, vp, i32, vp], i32),
     "shf_reset_dof_rows": ([vp, vp, vp, vp, i32, i64, i32, vp, vp, vp], i32),
     "shf_ik_dls": ([vp, i64, vp, i32, vp, i64, vp, i32, i32, C.c_float, vp, vp], i32),
     "shf_reward_accumulate": ([C.POINTER(vp), C.POINTER(vp), i32, i64, vp, vp], i32),

@@ -271,7 +271,43 @@ class Sim:
                                   torch._C._cuda_getCurrentRawStream)
         return f
 
+    # -- the commits of one reset as one launch (shf_sim_commit_reset) --------------------------------------------------------
+    # IsaacGymEnv.reset_idx brackets its actors' resets with begin_reset() .. commit_root_indexed(): inside, the dof-state and
+    # position-target commits of Robot._reset_dof_state are held back and go out together with the root rows.  Outside such a
+    # bracket every commit acts at once, as gym.set_*_tensor_indexed does; any other launch flushes what is held first.
+    _defer = False
+    _held = None           # (dof tensor or None, position-target tensor or None, int32 actor ids)
+
+    def begin_reset(self):
+        self._flush_held()
+        self._defer = True
+
+    @_on_device
+    def _flush_held(self):
+        held, self._held, self._defer = self._held, None, False
+        if held is not None:
+            dof, tgt, idx = held
+            check(lib().shf_sim_commit_reset(self._h, None, None, 0, C.c_void_p(dof.data_ptr()) if dof is not None else None,
+                                             C.c_void_p(tgt.data_ptr()) if tgt is not None else None, C.c_void_p(idx.data_ptr()),
+                                             idx.numel(), _stream_ptr(self.device)))
+
+    def _hold(self, dof, tgt, idx) -> bool:
+        """Inside a reset bracket: keep this commit for the root commit's launch.  False: act now."""
+        if not self._defer:
+            return False
+        if self._held is not None:
+            d0, t0, i0 = self._held
+            if i0.data_ptr() != idx.data_ptr() or (dof is not None and d0 is not None) or (tgt is not None and t0 is not None):
+                self._flush_held()            # a second articulation's commits: the first set goes out now
+                self._defer = True
+                d0 = t0 = None
+            dof, tgt = (dof if dof is not None else d0), (tgt if tgt is not None else t0)
+        self._held = (dof, tgt, idx)
+        return True
+
     def step(self):
+        if self._held is not None or self._defer:
+            self._flush_held()
         f_step, _, _, idx, raw_stream = self._fast()
         if torch.cuda.current_device() == idx:
             if f_step(self._h, raw_stream(idx)):
@@ -281,6 +317,8 @@ class Sim:
             check(f_step(self._h, _stream_ptr(self.device)))
 
     def refresh(self, mask: int = _abi.REFRESH_ALL):
+        if self._held is not None or self._defer:
+            self._flush_held()
         _, f_refresh, _, idx, raw_stream = self._fast()
         if torch.cuda.current_device() == idx:
             if f_refresh(self._h, mask, raw_stream(idx)):
@@ -303,6 +341,8 @@ class Sim:
     @_on_device
     def set_pos_target_indexed(self, values: torch.Tensor, idx: torch.Tensor):
         assert idx.dtype == torch.int32
+        if values.is_contiguous() and self._hold(None, values, idx):
+            return
         check(lib().shf_sim_set_pos_target_indexed(self._h, C.c_void_p(values.data_ptr()), C.c_void_p(idx.data_ptr()),
                                                    idx.numel(), _stream_ptr(self.device)))
 
@@ -321,16 +361,27 @@ class Sim:
     @_on_device
     def commit_root_indexed(self, root: torch.Tensor, idx: torch.Tensor):
         assert idx.dtype == torch.int32 and root.is_contiguous()
+        held, self._held, self._defer = self._held, None, False
+        if held is not None:                  # the reset's three commits in one launch
+            dof, tgt, didx = held
+            check(lib().shf_sim_commit_reset(self._h, C.c_void_p(root.data_ptr()), C.c_void_p(idx.data_ptr()), idx.numel(),
+                                             C.c_void_p(dof.data_ptr()) if dof is not None else None,
+                                             C.c_void_p(tgt.data_ptr()) if tgt is not None else None, C.c_void_p(didx.data_ptr()),
+                                             didx.numel(), _stream_ptr(self.device)))
+            return
         check(lib().shf_sim_commit_root_indexed(self._h, C.c_void_p(root.data_ptr()), C.c_void_p(idx.data_ptr()),
                                                 idx.numel(), _stream_ptr(self.device)))
 
     @_on_device
     def commit_root_all(self, root: torch.Tensor):
+        self._flush_held()
         check(lib().shf_sim_commit_root_all(self._h, C.c_void_p(root.data_ptr()), _stream_ptr(self.device)))
 
     @_on_device
     def commit_dof_indexed(self, dof: torch.Tensor, idx: torch.Tensor):
         assert idx.dtype == torch.int32 and dof.is_contiguous()
+        if self._hold(dof, None, idx):
+            return
         check(lib().shf_sim_commit_dof_indexed(self._h, C.c_void_p(dof.data_ptr()), C.c_void_p(idx.data_ptr()),
                                                idx.numel(), _stream_ptr(self.device)))
 

@@ -637,6 +637,18 @@ extern "C" int shf_sim_commit_dof_indexed(ShfSim* sim, const float* dof_dev, con
   return launch(k_commit_rows, dim3(n), dim3(64), 0, stream, dof_dev, (float*)sim->t[SHF_T_SIM_DOF], actor_idx_dev,
                 (int)n, nd * 2, 1 + sim->nboxes, nd * 2, (int)sim->n);
 }
+extern "C" int shf_sim_commit_reset(ShfSim* sim, const float* root_dev, const int32_t* root_idx_dev, int32_t n_root,
+                                    const float* dof_dev, const float* pos_target_dev, const int32_t* dof_actor_idx_dev, int32_t n_dof,
+                                    void* stream) {
+  if (int r = need(sim, {SHF_T_SIM_ROOT, SHF_T_SIM_DOF, SHF_T_POS_TARGET}, "shf_sim_commit_reset")) return r;
+  if (n_root < 0 || n_dof < 0) return fail("shf_sim_commit_reset: negative count");
+  if (n_root > 0 && (!root_dev || !root_idx_dev)) return fail("shf_sim_commit_reset: null root argument");
+  if (n_dof > 0 && (!dof_actor_idx_dev || (!dof_dev && !pos_target_dev))) return fail("shf_sim_commit_reset: null dof argument");
+  if (n_root + 2 * n_dof == 0) return 0;
+  return launch(k_commit_reset, dim3(n_root + 2 * n_dof), dim3(32), 0, stream, root_dev, (float*)sim->t[SHF_T_SIM_ROOT], root_idx_dev,
+                (int)n_root, (int)(sim->n * (1 + sim->nboxes)), dof_dev, (float*)sim->t[SHF_T_SIM_DOF], pos_target_dev,
+                (float*)sim->t[SHF_T_POS_TARGET], dof_actor_idx_dev, (int)n_dof, (int)sim->model.nd, 1 + sim->nboxes, (int)sim->n);
+}
 extern "C" int shf_sim_set_pos_target_indexed(ShfSim* sim, const float* values_dev, const int32_t* actor_idx_dev,
                                               int32_t n, void* stream) {
   if (int r = need(sim, {SHF_T_POS_TARGET}, "shf_sim_set_pos_target_indexed")) return r;

@@ -96,12 +96,21 @@ __global__ void k_rows_fill_indexed(float* buf, const int64_t* idx, int nidx, lo
 // kernels' statistics and oracle a1_stats), so the result does not depend on the order of the atomics.
 #define GLUE_MAX_KEYS 16
 struct GlueKeys { float* p[GLUE_MAX_KEYS]; };
+// (ep_len / reset_buf / history: the rest of ShifuVecEnv.reset_idx's buffer writes for the same ids, shf_reset_bookkeeping; all NULL
+// for shf_episode_log)
 __global__ void k_episode_log(GlueKeys sums, int K, const int64_t* ids, int nids, long long n, float T, unsigned long long* acc,
-                              float* out) {
+                              float* out, int64_t* ep_len, void* reset_buf, int reset_bytes, float* history, int hist_words) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nids) {
     const int64_t e = ids[i];
     if (e >= 0 && e < n) {
+      if (ep_len) ep_len[e] = 0;
+      if (reset_buf) {
+        if (reset_bytes == 8) reinterpret_cast<int64_t*>(reset_buf)[e] = 1;
+        else reinterpret_cast<uint8_t*>(reset_buf)[e] = 1;
+      }
+      if (history)
+        for (int k = 0; k < hist_words; k++) history[e * hist_words + k] = 0.0f;
       for (int k = 0; k < K; k++) {
         const float v = sums.p[k][e];
         sums.p[k][e] = 0.0f;
@@ -326,8 +335,30 @@ extern "C" int shf_episode_log(float* const* sums, int32_t num_keys, const int64
     G.p[k] = sums[k];
   }
   hipLaunchKernelGGL(k_episode_log, dim3((n_ids + 255) / 256), dim3(256), 0, (hipStream_t)stream, G, (int)num_keys, env_ids, (int)n_ids,
-                     (long long)num_envs, episode_length_s, reinterpret_cast<unsigned long long*>(workspace17), out_means);
+                     (long long)num_envs, episode_length_s, reinterpret_cast<unsigned long long*>(workspace17), out_means,
+                     (int64_t*)nullptr, (void*)nullptr, 0, (float*)nullptr, 0);
   return GLUE_LAUNCH_OK("shf_episode_log");
+}
+
+extern "C" int shf_reset_bookkeeping(float* const* sums, int32_t num_keys, const int64_t* env_ids, int32_t n_ids, int64_t num_envs,
+                                     float episode_length_s, int64_t* workspace17, float* out_means, int64_t* episode_length_or_null,
+                                     void* reset_buf_or_null, int32_t reset_elem_bytes, float* history_or_null,
+                                     int32_t history_row_words, void* stream) {
+  if (!sums || !env_ids || !workspace17 || !out_means) return shf_set_error("shf_reset_bookkeeping: null argument");
+  if (num_keys < 1 || num_keys > GLUE_MAX_KEYS) return shf_set_error("shf_reset_bookkeeping: 1..16 keys");
+  if (reset_buf_or_null && reset_elem_bytes != 1 && reset_elem_bytes != 8)
+    return shf_set_error("shf_reset_bookkeeping: reset_buf elements of 1 or 8 bytes");
+  if (history_or_null && history_row_words < 1) return shf_set_error("shf_reset_bookkeeping: history_row_words must be >= 1");
+  if (n_ids <= 0) return 0;
+  GlueKeys G{};
+  for (int k = 0; k < num_keys; k++) {
+    if (!sums[k]) return shf_set_error("shf_reset_bookkeeping: null sums tensor");
+    G.p[k] = sums[k];
+  }
+  hipLaunchKernelGGL(k_episode_log, dim3((n_ids + 255) / 256), dim3(256), 0, (hipStream_t)stream, G, (int)num_keys, env_ids, (int)n_ids,
+                     (long long)num_envs, episode_length_s, reinterpret_cast<unsigned long long*>(workspace17), out_means,
+                     episode_length_or_null, reset_buf_or_null, (int)reset_elem_bytes, history_or_null, (int)history_row_words);
+  return GLUE_LAUNCH_OK("shf_reset_bookkeeping");
 }
 
 extern "C" int shf_reward_accumulate(const float* const* terms, float* const* sums, int32_t num_keys, int64_t num_envs,

@@ -144,9 +144,38 @@ __global__ void k_commit_rows(const float* src, float* dst, const int32_t* idx, 
   const size_t r = (size_t)(a / idx_div) * row_words;
   for (int k = threadIdx.x; k < rows_per_idx_words; k += blockDim.x) dst[r + k] = src[r + k];
 }
+// the three indexed commits of one reset (shf_sim_commit_reset): blocks [0, n_root) copy root rows, the next n_dof the dof-state
+// rows, the last n_dof the position-target rows -- k_commit_rows three times over
+__global__ void k_commit_reset(const float* root_src, float* root_dst, const int32_t* root_idx, int n_root, int root_rows,
+                               const float* dof_src, float* dof_dst, const float* tgt_src, float* tgt_dst, const int32_t* dof_idx,
+                               int n_dof, int nd, int actors, int num_envs) {
+  int i = blockIdx.x;
+  if (i < n_root) {
+    const int32_t a = root_idx[i];
+    if (a < 0 || a >= root_rows) return;
+    const size_t r = (size_t)a * 13;
+    for (int k = threadIdx.x; k < 13; k += blockDim.x) root_dst[r + k] = root_src[r + k];
+    return;
+  }
+  i -= n_root;
+  const bool state = i < n_dof;
+  if (!state) i -= n_dof;
+  if (i >= n_dof) return;
+  const int32_t a = dof_idx[i];
+  if (a < 0 || a / actors >= num_envs) return;
+  const int words = state ? nd * 2 : nd;
+  const float* src = state ? dof_src : tgt_src;
+  float* dst = state ? dof_dst : tgt_dst;
+  if (!src) return;
+  const size_t r = (size_t)(a / actors) * words;
+  for (int k = threadIdx.x; k < words; k += blockDim.x) dst[r + k] = src[r + k];
+}
 #else
 __global__ void k_commit_rows(const float* src, float* dst, const int32_t* idx, int n, int row_words, int idx_div,
                               int rows_per_idx_words, int num_rows);
+__global__ void k_commit_reset(const float* root_src, float* root_dst, const int32_t* root_idx, int n_root, int root_rows,
+                               const float* dof_src, float* dof_dst, const float* tgt_src, float* tgt_dst, const int32_t* dof_idx,
+                               int n_dof, int nd, int actors, int num_envs);
 #endif
 
 #ifdef SHF_DEFINE_SMALL_KERNELS

@@ -79,7 +79,9 @@ class EpisodeLog:
     def __init__(self, device):
         self.ws = torch.zeros(17, dtype=torch.int64, device=device)
 
-    def __call__(self, sums_list, env_ids, episode_length_s):
+    def __call__(self, sums_list, env_ids, episode_length_s, episode_length=None, reset_buf=None, history=None):
+        """episode_length / reset_buf / history given: the rest of ShifuVecEnv.reset_idx's buffer writes for the same ids in the
+        same launch (shf_reset_bookkeeping): episode_length[ids] = 0, reset_buf[ids] = 1, history[ids] = 0."""
         K, dev = len(sums_list), self.ws.device
         if env_ids.numel() == 0:          # torch.mean over an empty selection (the kernel returns before writing)
             return torch.full((K,), float("nan"), dtype=torch.float32, device=dev)
@@ -88,8 +90,17 @@ class EpisodeLog:
         ids = env_ids.contiguous()
         assert ids.dtype == torch.int64
         with torch.cuda.device(dev):
-            check(lib().shf_episode_log(ptrs, K, _vp(ids.data_ptr()), ids.numel(), sums_list[0].numel(), float(episode_length_s),
-                                        _vp(self.ws.data_ptr()), _vp(out.data_ptr()), _stream(dev)))
+            if episode_length is None and reset_buf is None and history is None:
+                check(lib().shf_episode_log(ptrs, K, _vp(ids.data_ptr()), ids.numel(), sums_list[0].numel(), float(episode_length_s),
+                                            _vp(self.ws.data_ptr()), _vp(out.data_ptr()), _stream(dev)))
+            else:
+                n = sums_list[0].numel()
+                check(lib().shf_reset_bookkeeping(
+                    ptrs, K, _vp(ids.data_ptr()), ids.numel(), n, float(episode_length_s), _vp(self.ws.data_ptr()), _vp(out.data_ptr()),
+                    _vp(episode_length.data_ptr()) if episode_length is not None else None,
+                    _vp(reset_buf.data_ptr()) if reset_buf is not None else None, reset_buf.element_size() if reset_buf is not None else 0,
+                    _vp(history.data_ptr()) if history is not None else None, history.numel() // n if history is not None else 0,
+                    _stream(dev)))
         return out
 
 

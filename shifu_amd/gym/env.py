@@ -180,14 +180,43 @@ class ShifuVecEnv:
         if len(env_ids) == 0:
             return
         self.isg_env.reset_idx(env_ids)
-        self.episode_length_buf[env_ids] = 0
-        self.reset_buf[env_ids] = 1
-        if self.cfg.num_actions_history:
-            self.actions_recorder.reset_idx(env_ids)
-        self.extras["episode"] = {}
-        self.log_info(env_ids)
+        if self._reset_buffers_in_one_launch(env_ids):
+            pass        # the five statements of the else-branch as one launch (csrc/shf_glue.hip: shf_reset_bookkeeping)
+        else:
+            self.episode_length_buf[env_ids] = 0
+            self.reset_buf[env_ids] = 1
+            if self.cfg.num_actions_history:
+                self.actions_recorder.reset_idx(env_ids)
+            self.extras["episode"] = {}
+            self.log_info(env_ids)
         if self.cfg.send_timeouts:
             self.extras["time_outs"] = self.time_out_buf
+
+    def _reset_buffers_in_one_launch(self, env_ids) -> bool:
+        """episode_length_buf[ids] = 0, reset_buf[ids] = 1, the action history's rows zeroed and log_info(ids) as ONE launch --
+        when every tensor involved is what the library's kernel takes (CUDA, contiguous, the dtypes this class creates: an int64
+        length buffer, a bool or int64 reset buffer, float32 sums and history); False: nothing was done."""
+        rec = self.actions_recorder.history_buf if self.cfg.num_actions_history else None
+        ok = (torch.is_tensor(env_ids) and env_ids.is_cuda and env_ids.dtype == torch.int64 and 0 < len(self.episode_rewards) <= 16
+              and all(v.is_cuda and v.dtype == torch.float32 and v.is_contiguous() for v in self.episode_rewards.values())
+              and self.episode_length_buf.is_cuda and self.episode_length_buf.dtype == torch.int64 and self.episode_length_buf.is_contiguous()
+              and self.reset_buf.is_cuda and self.reset_buf.is_contiguous() and self.reset_buf.element_size() in (1, 8)
+              and self.reset_buf.dtype in (torch.bool, torch.uint8, torch.int64)
+              and (rec is None or (rec.is_cuda and rec.dtype == torch.float32 and rec.is_contiguous() and rec.shape[0] == self.num_envs))
+              and type(self).log_info is ShifuVecEnv.log_info)          # (a subclass that overrides log_info keeps the statement-by-statement path)
+        if not ok:
+            return False
+        from shifu_amd import glue
+        if getattr(self, "_episode_log", None) is None:
+            self._episode_log = glue.EpisodeLog(env_ids.device)
+        keys = list(self.episode_rewards.keys())
+        means = self._episode_log([self.episode_rewards[k] for k in keys], env_ids, self.max_episode_length_s,
+                                  episode_length=self.episode_length_buf, reset_buf=self.reset_buf, history=rec)
+        self.extras["episode"] = {key: means[i] for i, key in enumerate(keys)}
+        info = self.episode_log(env_ids)
+        if info:
+            self.extras["episode"].update(info)
+        return True
 
     def log_info(self, env_ids):
         if torch.is_tensor(env_ids) and env_ids.is_cuda and env_ids.dtype == torch.int64 and 0 < len(self.episode_rewards) <= 16 \

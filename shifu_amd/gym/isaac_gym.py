@@ -132,6 +132,11 @@ class IsaacGymEnv:
             return
         actors = self._actors if actors is None else actors
         rows = []
+        backend = getattr(self.sim, "backend", None)
+        if backend is not None and hasattr(backend, "begin_reset"):
+            # this backend: the dof / position-target commits of the actors' resets go out with the root commit below as ONE
+            # launch (include/shifu_amd.h: shf_sim_commit_reset); what the reference issues as three gym.set_*_tensor_indexed calls
+            backend.begin_reset()
         for actor in actors:
             actor.reset_idx(env_ids)
             rows.append(actor.root_indices[env_ids])

@@ -66,6 +66,81 @@ def test_indexed_commits_copy_exactly_the_indexed_rows():
         env.destroy()
 
 
+def test_the_commits_of_one_reset_as_one_launch_equal_the_three_calls():
+    """shf_sim_commit_reset (ABI v15): inside Sim.begin_reset() .. commit_root_indexed() the position-target and dof-state
+    commits are held and go out with the root rows in one launch -- the solver-side tensors end up exactly as after the three
+    separate calls (random subsets with repeats and out-of-range entries); a step / refresh / unrelated commit in between
+    flushes what is held; outside a bracket every commit acts at once."""
+    _need_gpu()
+    rng = np.random.default_rng(3)
+    for name, env, A in _sims():
+        sim, S, n, nd = env.sim, env.sim.tensors, env.num_envs, env.sim.model.nd
+        dev = sim.device
+        tids = (_abi.T_SIM_ROOT, _abi.T_SIM_DOF, _abi.T_POS_TARGET)
+        start = {t: torch.randn_like(S[t]) for t in tids}
+        src = {t: torch.randn_like(S[t]) for t in tids}
+        rows = torch.tensor(list(rng.choice(n * A, size=19, replace=False)) + [n * A + 3, -2], dtype=torch.int32, device=dev)
+        ridx = torch.tensor(list(rng.choice(n, size=9, replace=False) * A) + [n * A], dtype=torch.int32, device=dev)
+
+        def load():
+            for t in tids:
+                S[t].copy_(start[t])
+        load()
+        sim.set_pos_target_indexed(src[_abi.T_POS_TARGET], ridx)
+        sim.commit_dof_indexed(src[_abi.T_SIM_DOF], ridx)
+        sim.commit_root_indexed(src[_abi.T_SIM_ROOT], rows)
+        want = {t: S[t].clone() for t in tids}
+        load()
+        sim.begin_reset()
+        sim.set_pos_target_indexed(src[_abi.T_POS_TARGET], ridx)
+        sim.commit_dof_indexed(src[_abi.T_SIM_DOF], ridx[:ridx.numel()])          # (the facade's idx[:n] view: same memory)
+        assert torch.equal(S[_abi.T_SIM_DOF], start[_abi.T_SIM_DOF]) and torch.equal(S[_abi.T_POS_TARGET], start[_abi.T_POS_TARGET]), "held"
+        sim.commit_root_indexed(src[_abi.T_SIM_ROOT], rows)
+        for t in tids:
+            assert torch.equal(S[t], want[t]), (name, t)
+        # held commits leave with the next launch of any other kind
+        load()
+        sim.begin_reset()
+        sim.commit_dof_indexed(src[_abi.T_SIM_DOF], ridx)
+        sim.refresh(_abi.REFRESH_DOF)
+        assert torch.equal(S[_abi.T_SIM_DOF], want[_abi.T_SIM_DOF]) and sim._held is None and not sim._defer, name
+        # ... and outside a bracket nothing is held
+        load()
+        sim.commit_dof_indexed(src[_abi.T_SIM_DOF], ridx)
+        assert torch.equal(S[_abi.T_SIM_DOF], want[_abi.T_SIM_DOF]), name
+        env.destroy()
+
+
+def test_reset_bookkeeping_in_one_launch_equals_the_five_statements():
+    """shf_reset_bookkeeping (ABI v15) against ShifuVecEnv.reset_idx's buffer statements in torch (env.py:114-130, 149-158):
+    episode_length[ids] = 0, reset_buf[ids] = 1 (bool and int64 buffers), history[ids] = 0, extras means and zeroed sums."""
+    _need_gpu()
+    from shifu_amd import glue
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n, K = 4096, 6
+    for reset_dtype in (torch.bool, torch.int64):
+        sums = [(torch.rand(n, generator=g) * 40 - 5).to(dev) for _ in range(K)]
+        ep = torch.randint(1, 900, (n,), generator=g).to(dev)
+        rb = (torch.rand(n, generator=g) < 0.3).to(dev).to(reset_dtype)
+        hist = torch.rand(n, 12, 3, generator=g).to(dev)
+        ids = torch.randperm(n, generator=g)[:777].to(dev)
+        want_means = [float(torch.mean(s[ids].double()) / 20.0) for s in sums]
+        w_sums, w_ep, w_rb, w_hist = [s.clone() for s in sums], ep.clone(), rb.clone(), hist.clone()
+        for s in w_sums:
+            s[ids] = 0.0
+        w_ep[ids] = 0
+        w_rb[ids] = 1
+        w_hist.index_fill_(0, ids, 0.0)
+        log = glue.EpisodeLog(dev)
+        means = log(sums, ids, 20.0, episode_length=ep, reset_buf=rb, history=hist)
+        torch.cuda.synchronize()
+        assert torch.equal(ep, w_ep) and torch.equal(rb, w_rb) and torch.equal(hist, w_hist)
+        assert all(torch.equal(a, b) for a, b in zip(sums, w_sums))
+        np.testing.assert_allclose(means.cpu().numpy(), want_means, rtol=2e-5, atol=1e-6)
+        assert int(log.ws.abs().sum()) == 0, "the workspace is left zero for the next call"
+
+
 def test_indexed_commit_through_the_gym_facade_resets_only_those_envs():
     """IsaacGymEnv.reset_idx + Robot._reset_dof_state on the hook env: after reset_idx(ids) the solver state of `ids`
     is the default pose at the env origin, all other envs keep stepping from where they were."""
