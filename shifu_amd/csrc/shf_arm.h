@@ -31,6 +31,22 @@ struct ArmChain {
     return true;
   }
 };
+// What substep_hard_finish<.., RECORDS = false, ARMNL = NL> asks of its lane's model view (csrc/shf_hard.h) for such an arm: no
+// tree indices, no children -- lane_model_load's fifteen dependent LDS reads per sub-step shrink to one
+struct ArmSolveLane {
+  bool isbody, isdyn, moving;
+  int lev;
+  float vel_limit;
+  DEV int level() const { return lev; }
+  template <int NL>
+  DEV static ArmSolveLane load(const ShfModel* m, int l) {
+    ArmSolveLane M;
+    M.isbody = l <= NL; M.isdyn = M.isbody; M.moving = l >= 1 && l <= NL;     // (ArmChain<NL>::matches: dyn[b] == b, the root fixed)
+    M.lev = M.isbody ? l : -1;
+    M.vel_limit = m->vel_limit[l < NL ? l : 0];
+    return M;
+  }
+};
 #define KREC_STRIDE 20   /* S[6] c[6] U[6] invD u */
 #define ARM_KREC_WORDS(nl) ((nl) * KREC_STRIDE)
 

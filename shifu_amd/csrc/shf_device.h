@@ -956,7 +956,7 @@ DEV void contact_force_final(float* o, const float* ab, float dt) {
 //   fext: world force per reported body (global memory, this env) or nullptr; fpos: its world point of application or nullptr (CoM)
 //   contact_out: LDS/global float[nb*3] written by body lanes (may be nullptr)
 #define LANE_ROUNDS(G, DM) ((DM::NPC + (G) - 1) / (G) > 0 ? (DM::NPC + (G) - 1) / (G) : 1)
-template <int G, bool BOX, class DM, class LM, class SC, bool SELF, bool LINK, bool RECORDS = true>
+template <int G, bool BOX, class DM, class LM, class SC, bool SELF, bool LINK, bool RECORDS = true, int ARMNL = 0>
 DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM& M, BodyRegs& B, const float* g, float* a, int nself,
                              int self_slot0, int link_slot0, int nlink, float* contact_out);
 template <int G, bool BOX = false, class DM = DynDims, bool TW = false, class LM = LaneModel, class SC = DynScene,

@@ -605,7 +605,7 @@ DEV void hard_records(const StepCtx& C, const EnvLds& L, int l, const LM& M, con
 // The velocity-level solve of the body-per-lane sub-step, after its FREE articulated-body solve: records, gather, columns,
 // owners, sweeps, the impulse passes, integration (poses with the accelerations after the position iterations, velocities
 // after the velocity iterations), net contact forces.  `a`: lane 0 holds the root's free acceleration.
-template <int G, bool BOX, class DM, class LM, class SC, bool SELF, bool LINK, bool RECORDS>
+template <int G, bool BOX, class DM, class LM, class SC, bool SELF, bool LINK, bool RECORDS, int ARMNL>
 DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM& M, BodyRegs& B, const float* g, float* a, int nself,
                              int self_slot0, int link_slot0, int nlink, float* contact_out) {
   static_assert(G == 32, "two envs per wavefront (hard_sweeps)");
@@ -708,72 +708,135 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
         }
       }
     }
-    float uc[2] = {0.0f, 0.0f};
-    for (int lev = nl; lev >= 1; lev--) {
-      if (moving && mylevel == lev) {
+    if constexpr (ARMNL > 0) {
+      // A fixed base with ONE serial chain of ARMNL links (ArmChain<ARMNL>::matches: body b's parent is b - 1, its dof b - 1, its
+      // level b): every level holds one body, so the level-by-level passes below are 2 x ARMNL LDS hand-offs with a group
+      // synchronisation each for nothing -- the body lanes publish the impulses they gathered, lane 0 runs both recursions link
+      // after link in registers (the same operations on the same values: own + child's, S . pc, U tt; then U . a, S qc).
+      if (moving) {
         float* rec = L.xch + l * XCH_STRIDE;
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-          float sp = B.S[0] * pc[q][0];
-#pragma unroll
-          for (int j = 1; j < 6; j++) sp = fmaf(B.S[j], pc[q][j], sp);
-          uc[q] = -sp;
-          const float tt = uc[q] * B.invD;
-#pragma unroll
-          for (int j = 0; j < 6; j++) { pc[q][j] = fmaf(B.U[j], tt, pc[q][j]); rec[(q == 0 ? HB_PC : HB_DL) + j] = pc[q][j]; }
-        }
+        for (int j = 0; j < 6; j++) { rec[HB_PC + j] = pc[0][j]; rec[HB_DL + j] = pc[1][j]; }
       }
       GROUP_SYNC();
-      if (isdyn && mylevel == lev - 1) {
-        for (int kk = 0; kk < M.nchild; kk++) {
-          const int cb = kk < LANE_CHILDREN ? M.child[kk < LANE_CHILDREN ? kk : 0] : m->child_list[M.child0 + kk];
-          const float* o = L.xch + cb * XCH_STRIDE;
+      if (l == 0) {
+        float cp[2][6], ucs[ARMNL][2];
 #pragma unroll
-          for (int q = 0; q < 2; q++)
+        for (int b = ARMNL; b >= 1; b--) {
+          const float* rec = L.xch + b * XCH_STRIDE;
+          float Sb[6], Ub[6];
 #pragma unroll
-            for (int j = 0; j < 6; j++) pc[q][j] += o[(q == 0 ? HB_PC : HB_DL) + j];
+          for (int j = 0; j < 6; j++) { Sb[j] = rec[HB_S + j]; Ub[j] = rec[HB_U + j]; }
+          const float iD = rec[HB_INVD];
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            float pb[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+              const float own = rec[(q == 0 ? HB_PC : HB_DL) + j];
+              pb[j] = b == ARMNL ? own : own + cp[q][j];         // (the tip has no child to add)
+            }
+            float sp = Sb[0] * pb[0];
+#pragma unroll
+            for (int j = 1; j < 6; j++) sp = fmaf(Sb[j], pb[j], sp);
+            ucs[b - 1][q] = -sp;
+            const float tt = ucs[b - 1][q] * iD;
+#pragma unroll
+            for (int j = 0; j < 6; j++) cp[q][j] = fmaf(Ub[j], tt, pb[j]);
+          }
+        }
+        float ac[2][6] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};       // the base does not move
+#pragma unroll
+        for (int b = 1; b <= ARMNL; b++) {
+          const float* rec = L.xch + b * XCH_STRIDE;
+          float Sb[6], Ub[6];
+#pragma unroll
+          for (int j = 0; j < 6; j++) { Sb[j] = rec[HB_S + j]; Ub[j] = rec[HB_U + j]; }
+          const float iD = rec[HB_INVD];
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            float ua = Ub[0] * ac[q][0];
+#pragma unroll
+            for (int j = 1; j < 6; j++) ua = fmaf(Ub[j], ac[q][j], ua);
+            const float qc = (ucs[b - 1][q] - ua) * iD;
+#pragma unroll
+            for (int j = 0; j < 6; j++) ac[q][j] = fmaf(Sb[j], qc, ac[q][j]);
+            L.dofb[(b - 1) * DOF_STRIDE + 2 + q] = qc;
+          }
         }
       }
-    }
-    if (l == 0) {
+      if (dynbox) {
 #pragma unroll
-      for (int q = 0; q < 2; q++) {
-        if (m->fixed_base) {
-#pragma unroll
-          for (int k = 0; k < 6; k++) ac0[q][k] = 0.0f;
-        } else {
-          root_factors_apply(L.xch, pc[q], ac0[q]);
+        for (int q = 0; q < 2; q++) root_factors_apply(L.xch + l * XCH_STRIDE, pc[q], ac0[q]);
+      }
+    } else {
+      float uc[2] = {0.0f, 0.0f};
+      for (int lev = nl; lev >= 1; lev--) {
+        if (moving && mylevel == lev) {
+          float* rec = L.xch + l * XCH_STRIDE;
+  #pragma unroll
+          for (int q = 0; q < 2; q++) {
+            float sp = B.S[0] * pc[q][0];
+  #pragma unroll
+            for (int j = 1; j < 6; j++) sp = fmaf(B.S[j], pc[q][j], sp);
+            uc[q] = -sp;
+            const float tt = uc[q] * B.invD;
+  #pragma unroll
+            for (int j = 0; j < 6; j++) { pc[q][j] = fmaf(B.U[j], tt, pc[q][j]); rec[(q == 0 ? HB_PC : HB_DL) + j] = pc[q][j]; }
+          }
+        }
+        GROUP_SYNC();
+        if (isdyn && mylevel == lev - 1) {
+          for (int kk = 0; kk < M.nchild; kk++) {
+            const int cb = kk < LANE_CHILDREN ? M.child[kk < LANE_CHILDREN ? kk : 0] : m->child_list[M.child0 + kk];
+            const float* o = L.xch + cb * XCH_STRIDE;
+  #pragma unroll
+            for (int q = 0; q < 2; q++)
+  #pragma unroll
+              for (int j = 0; j < 6; j++) pc[q][j] += o[(q == 0 ? HB_PC : HB_DL) + j];
+          }
         }
       }
-#pragma unroll
-      for (int q = 0; q < 2; q++) {
-        float* o = hg_ac(L, q, 0);
-#pragma unroll
-        for (int k = 0; k < 6; k++) o[k] = ac0[q][k];
-      }
-    }
-    if (dynbox) {
-#pragma unroll
-      for (int q = 0; q < 2; q++) root_factors_apply(L.xch + l * XCH_STRIDE, pc[q], ac0[q]);
-    }
-    for (int lev = 1; lev <= nl; lev++) {
-      GROUP_SYNC();
-      if (moving && mylevel == lev) {
-        const int pd = M.dynpar();
-#pragma unroll
+      if (l == 0) {
+  #pragma unroll
         for (int q = 0; q < 2; q++) {
-          const float* pa = hg_ac(L, q, pd);
-          float acp[6];
-#pragma unroll
-          for (int j = 0; j < 6; j++) acp[j] = pa[j];
-          float ua = B.U[0] * acp[0];
-#pragma unroll
-          for (int j = 1; j < 6; j++) ua = fmaf(B.U[j], acp[j], ua);
-          const float qc = (uc[q] - ua) * B.invD;
-          float* o = hg_ac(L, q, l);
-#pragma unroll
-          for (int j = 0; j < 6; j++) o[j] = fmaf(B.S[j], qc, acp[j]);
-          L.dofb[M.dofi() * DOF_STRIDE + 2 + q] = qc;
+          if (m->fixed_base) {
+  #pragma unroll
+            for (int k = 0; k < 6; k++) ac0[q][k] = 0.0f;
+          } else {
+            root_factors_apply(L.xch, pc[q], ac0[q]);
+          }
+        }
+  #pragma unroll
+        for (int q = 0; q < 2; q++) {
+          float* o = hg_ac(L, q, 0);
+  #pragma unroll
+          for (int k = 0; k < 6; k++) o[k] = ac0[q][k];
+        }
+      }
+      if (dynbox) {
+  #pragma unroll
+        for (int q = 0; q < 2; q++) root_factors_apply(L.xch + l * XCH_STRIDE, pc[q], ac0[q]);
+      }
+      for (int lev = 1; lev <= nl; lev++) {
+        GROUP_SYNC();
+        if (moving && mylevel == lev) {
+          const int pd = M.dynpar();
+  #pragma unroll
+          for (int q = 0; q < 2; q++) {
+            const float* pa = hg_ac(L, q, pd);
+            float acp[6];
+  #pragma unroll
+            for (int j = 0; j < 6; j++) acp[j] = pa[j];
+            float ua = B.U[0] * acp[0];
+  #pragma unroll
+            for (int j = 1; j < 6; j++) ua = fmaf(B.U[j], acp[j], ua);
+            const float qc = (uc[q] - ua) * B.invD;
+            float* o = hg_ac(L, q, l);
+  #pragma unroll
+            for (int j = 0; j < 6; j++) o[j] = fmaf(B.S[j], qc, acp[j]);
+            L.dofb[M.dofi() * DOF_STRIDE + 2 + q] = qc;
+          }
         }
       }
     }

@@ -911,23 +911,16 @@ DEV void abb_ws_body(const AbbArgs& A) {
           const float* stash2 = krec2 + ARM_KREC_WORDS(NL) + 4;
           const int nlink2 = *reinterpret_cast<const int*>(krec2 + ARM_KREC_WORDS(NL) + 1);
           C.dropped = env_dropped(A.S.dropped, A.S.sp, e2);      // (the gather's drop counter and histogram: this lane's env of the solve)
-          typedef LaneModelT<false> LM2;
-          LM2 M2;
-          lane_model_load<DM>(m, l2, M2);
-          BodyRegs B2;
-          if (l2 >= 1 && l2 <= NL) {
-            const float* kr = krec2 + (l2 - 1) * KREC_STRIDE;
-#pragma unroll
-            for (int k = 0; k < 6; k++) { B2.S[k] = kr[k]; B2.U[k] = kr[12 + k]; }
-            B2.invD = kr[18];
-          }
+          typedef ArmSolveLane LM2;
+          const LM2 M2 = ArmSolveLane::load<NL>(m, l2);
+          BodyRegs B2;                           // (the records are in LDS already: the solve needs the box's position only)
           if (l2 == nb + SC::DYN) {
 #pragma unroll
             for (int k = 0; k < 3; k++) B2.p[k] = stash2[27 + k];
           }
           const float g2[3] = {gq[0], gq[1], gq[2]};     // (a local copy: the solve selects between pointers to it and to the boxes' gravity)
           float a2[6] = {0.0f, 0.0f, 0.0f, -g2[0], -g2[1], -g2[2]};
-          substep_hard_finish<G2, true, DM, LM2, SC, false, LINK, false>(C, L2, l2, M2, B2, g2, a2, 0, link_slot0, link_slot0, nlink2,
+          substep_hard_finish<G2, true, DM, LM2, SC, false, LINK, false, NL>(C, L2, l2, M2, B2, g2, a2, 0, link_slot0, link_slot0, nlink2,
                                                                    it == nsub - 1 ? L2.xch : nullptr);
         }
       }

@@ -26,7 +26,7 @@ if has bench; then
   done
   # ... the sixteen-constraint cap, config 5 on the run-time-shaped kernel and with the links as convex hulls
   python bench.py --max-contacts 16 $B --no-cpu-baseline --no-other-solver > "$OUT/bench_terrain_k16.json" 2>/dev/null
-  python bench.py --workload abb --mapping body $B --no-cpu-baseline --no-other-solver > "$OUT/bench_abb_body.json" 2>/dev/null
+  python bench.py --workload abb --solver tgs --mapping body $B --no-cpu-baseline --no-other-solver > "$OUT/bench_abb_body.json" 2>/dev/null
   python bench.py --workload abb --link-shapes hull $B --no-cpu-baseline --no-other-solver > "$OUT/bench_abb_hull.json" 2>/dev/null
   python bench.py --steps 20 --warmup 5 > "$OUT/bench_terrain_driver_shape.json" 2>/dev/null
   python bench.py --workload trimesh --self-collision $B --no-cpu-baseline --no-other-solver > "$OUT/bench_trimesh_selfcollision.json" 2>/dev/null
