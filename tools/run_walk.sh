@@ -7,7 +7,7 @@ set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 ITERS=${1:-3000}
 MLP=${2:-torch}        # torch: stock fp32 GEMMs; mfma: csrc/shf_mlp.hip layers + captured PPO update
-SOLVER=${3:-pgs}       # contact solver: pgs (the reference's PhysX settings) | compliant (rounds 1-4)
+SOLVER=${3:-tgs}       # contact solver: tgs (the reference's PhysX settings: solver_type = 1) | pgs | compliant (rounds 1-4)
 EXTRA=${4:-}            # further tools/train_a1.py flags (e.g. --torch-loss)
 TAG=$(echo "$EXTRA" | tr -d ' -')
 OUT=$REPO/gpurun_out/train_a1_r06_${MLP}_$SOLVER${TAG:+_$TAG}
