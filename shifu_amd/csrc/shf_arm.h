@@ -53,7 +53,7 @@ struct ArmSolveLane {
 // One lane's view of its env's arm during a sub-step: the phases of the sub-step as members, so that one wave can run
 // them in sequence (arm_substep) or an "arm" wave can run them while a "box" wave of the same workgroup handles the box
 // actors (k_abb_step_ws in shf_api.hip).  krec: ARM_KREC_WORDS(NL) floats of this env's LDS, 16-byte aligned.
-template <int G, class DM, int NL>
+template <int G, class DM, int NL, class LM = LaneModel>      // LM: the lane's model constants in registers (LaneModel) or read from the LDS model at use
 struct ArmLane {
   static_assert(DM::NPC > 0 && G < 64, "compile-time point count; lane groups inside one wavefront");
   static constexpr int nb = NL + 1, nd = NL, NR = LANE_ROUNDS(G, DM);   // NR rounds of one sample point per lane
@@ -61,13 +61,13 @@ struct ArmLane {
   const EnvLds& L;
   float* krec;
   const int l;
-  const LaneModel& M;
+  const LM& M;
   const LanePoints<LANE_ROUNDS(G, DM)>& P;
   float g[3];
   bool islink;
   unsigned long long active[LANE_ROUNDS(G, DM)];   // ballots of this sub-step's terrain contacts (round k, bit j = sample point k G + j)
 
-  DEV ArmLane(const StepCtx& C_, const EnvLds& L_, float* krec_, int l_, const LaneModel& M_, const LanePoints<LANE_ROUNDS(G, DM)>& P_)
+  DEV ArmLane(const StepCtx& C_, const EnvLds& L_, float* krec_, int l_, const LM& M_, const LanePoints<LANE_ROUNDS(G, DM)>& P_)
       : C(C_), L(L_), krec(krec_), l(l_), M(M_), P(P_) {
     const float gon = (float)C.m->gravity_on;
     g[0] = C.sp.gravity[0] * gon; g[1] = C.sp.gravity[1] * gon; g[2] = C.sp.gravity[2] * gon;

@@ -543,7 +543,8 @@ DEV float* hg_ac(const EnvLds& L, int q, int b) {
 // LDL^T factors in theirs; then the velocity rates Dl = S qdd + Dl(parent) down the tree.  abox: a free box's free acceleration
 // (its lane; the integration needs it again).  A group sync has to follow.  Its own function since round 6: k_abb_step_ws_hard
 // runs it on the arm wave (16 lanes per env) while the box wave is still busy with the link candidates.
-template <int G, bool BOX, class DM, class LM>
+// PARTS: 1 = the articulation's lanes (records, root, velocity rates), 2 = the free boxes' lanes, 3 = both.
+template <int G, bool BOX, class DM, class LM, int PARTS = 3>
 DEV void hard_records(const StepCtx& C, const EnvLds& L, int l, const LM& M, const BodyRegs& B, const float* g, const float* a, float* abox) {
   const ShfModel* m = C.m;
   const SceneDev* S = C.scene;
@@ -553,13 +554,13 @@ DEV void hard_records(const StepCtx& C, const EnvLds& L, int l, const LM& M, con
   const int kd = l - nb;
   const bool dynbox = BOX && kd >= 0 && kd < nbx && box_is_dynamic(S->box[kd]);
   const float gb[3] = {C.sp.gravity[0], C.sp.gravity[1], C.sp.gravity[2]};
-  if (moving) {
+  if ((PARTS & 1) && moving) {
     float* rec = L.xch + l * XCH_STRIDE;
 #pragma unroll
     for (int k = 0; k < 6; k++) { rec[HB_S + k] = B.S[k]; rec[HB_U + k] = B.U[k]; }
     rec[HB_INVD] = B.invD;
   }
-  if (l == 0) {
+  if ((PARTS & 1) && l == 0) {
     float* rec = L.xch;
     if (m->fixed_base) {
 #pragma unroll
@@ -575,7 +576,7 @@ DEV void hard_records(const StepCtx& C, const EnvLds& L, int l, const LM& M, con
       for (int k = 0; k < 3; k++) { rec[HB_FDL + k] = a[k]; rec[HB_FDL + 3 + k] = (a[3 + k] + g[k]) + wxv[k]; }
     }
   }
-  if (dynbox) {
+  if ((PARTS & 2) && dynbox) {
     float* rec = L.xch + l * XCH_STRIDE;
     Ldlt6 F;
     ldlt_factor6(B.IA, F);
@@ -588,16 +589,18 @@ DEV void hard_records(const StepCtx& C, const EnvLds& L, int l, const LM& M, con
 #pragma unroll
     for (int k = 0; k < 3; k++) { rec[HB_FDL + k] = abox[k]; rec[HB_FDL + 3 + k] = (abox[3 + k] + gb[k]) + wxv[k]; }
   }
-  // velocity rates down the tree: Dl = S qdd + Dl(parent)
-  for (int lev = 1; lev <= nl; lev++) {
-    GROUP_SYNC();
-    if (moving && mylevel == lev) {
-      const int pd = M.dynpar();
-      const float* dp = L.xch + pd * XCH_STRIDE + (pd == 0 ? HB_FDL : HB_DL);
-      const float qdd = L.dofb[M.dofi() * DOF_STRIDE + 4];
-      float* rec = L.xch + l * XCH_STRIDE;
+  if constexpr ((PARTS & 1) != 0) {
+    // velocity rates down the tree: Dl = S qdd + Dl(parent)
+    for (int lev = 1; lev <= nl; lev++) {
+      GROUP_SYNC();
+      if (moving && mylevel == lev) {
+        const int pd = M.dynpar();
+        const float* dp = L.xch + pd * XCH_STRIDE + (pd == 0 ? HB_FDL : HB_DL);
+        const float qdd = L.dofb[M.dofi() * DOF_STRIDE + 4];
+        float* rec = L.xch + l * XCH_STRIDE;
 #pragma unroll
-      for (int k = 0; k < 6; k++) rec[HB_DL + k] = fmaf(B.S[k], qdd, dp[k]);
+        for (int k = 0; k < 6; k++) rec[HB_DL + k] = fmaf(B.S[k], qdd, dp[k]);
+      }
     }
   }
 }
@@ -774,14 +777,14 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
       for (int lev = nl; lev >= 1; lev--) {
         if (moving && mylevel == lev) {
           float* rec = L.xch + l * XCH_STRIDE;
-  #pragma unroll
+#pragma unroll
           for (int q = 0; q < 2; q++) {
             float sp = B.S[0] * pc[q][0];
-  #pragma unroll
+#pragma unroll
             for (int j = 1; j < 6; j++) sp = fmaf(B.S[j], pc[q][j], sp);
             uc[q] = -sp;
             const float tt = uc[q] * B.invD;
-  #pragma unroll
+#pragma unroll
             for (int j = 0; j < 6; j++) { pc[q][j] = fmaf(B.U[j], tt, pc[q][j]); rec[(q == 0 ? HB_PC : HB_DL) + j] = pc[q][j]; }
           }
         }
@@ -790,50 +793,50 @@ DEV void substep_hard_finish(const StepCtx& C, const EnvLds& L, int l, const LM&
           for (int kk = 0; kk < M.nchild; kk++) {
             const int cb = kk < LANE_CHILDREN ? M.child[kk < LANE_CHILDREN ? kk : 0] : m->child_list[M.child0 + kk];
             const float* o = L.xch + cb * XCH_STRIDE;
-  #pragma unroll
+#pragma unroll
             for (int q = 0; q < 2; q++)
-  #pragma unroll
+#pragma unroll
               for (int j = 0; j < 6; j++) pc[q][j] += o[(q == 0 ? HB_PC : HB_DL) + j];
           }
         }
       }
       if (l == 0) {
-  #pragma unroll
+#pragma unroll
         for (int q = 0; q < 2; q++) {
           if (m->fixed_base) {
-  #pragma unroll
+#pragma unroll
             for (int k = 0; k < 6; k++) ac0[q][k] = 0.0f;
           } else {
             root_factors_apply(L.xch, pc[q], ac0[q]);
           }
         }
-  #pragma unroll
+#pragma unroll
         for (int q = 0; q < 2; q++) {
           float* o = hg_ac(L, q, 0);
-  #pragma unroll
+#pragma unroll
           for (int k = 0; k < 6; k++) o[k] = ac0[q][k];
         }
       }
       if (dynbox) {
-  #pragma unroll
+#pragma unroll
         for (int q = 0; q < 2; q++) root_factors_apply(L.xch + l * XCH_STRIDE, pc[q], ac0[q]);
       }
       for (int lev = 1; lev <= nl; lev++) {
         GROUP_SYNC();
         if (moving && mylevel == lev) {
           const int pd = M.dynpar();
-  #pragma unroll
+#pragma unroll
           for (int q = 0; q < 2; q++) {
             const float* pa = hg_ac(L, q, pd);
             float acp[6];
-  #pragma unroll
+#pragma unroll
             for (int j = 0; j < 6; j++) acp[j] = pa[j];
             float ua = B.U[0] * acp[0];
-  #pragma unroll
+#pragma unroll
             for (int j = 1; j < 6; j++) ua = fmaf(B.U[j], acp[j], ua);
             const float qc = (uc[q] - ua) * B.invD;
             float* o = hg_ac(L, q, l);
-  #pragma unroll
+#pragma unroll
             for (int j = 0; j < 6; j++) o[j] = fmaf(B.S[j], qc, acp[j]);
             L.dofb[M.dofi() * DOF_STRIDE + 2 + q] = qc;
           }

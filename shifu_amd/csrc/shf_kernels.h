@@ -779,6 +779,9 @@ DEV void abb_ws_body(const AbbArgs& A) {
   // registers (two waves per SIMD) and the box wave's link passes need most: the arm wave re-reads its constants from the LDS
   // model at the head of each of its phases (WS_ARM_LOCALS), so that they are not live across the other wave's code.
   constexpr int NRP = LANE_ROUNDS(G, DM);
+  // (HARD: the arm wave's phases read their model constants from the LDS model where they use them -- with them in registers the
+  // phases' own peak, the free ABA recursions on the chain lane, spilled ~90 registers)
+  typedef LaneModelT<!HARD> WsArmModel;
   LaneModel M;
   LanePoints<NRP> P;
   if constexpr (!LINK && !HARD) {
@@ -786,11 +789,11 @@ DEV void abb_ws_body(const AbbArgs& A) {
     lane_points_load<G>(m, DM::np(m), l, P);
   }
 #define WS_ARM_LOCALS_AT(lane)                           \
-  LaneModel Ml;                                          \
+  WsArmModel Ml;                                         \
   lane_model_load<DM>(m, lane, Ml);                      \
   LanePoints<NRP> Pl;                                    \
   lane_points_load<G>(m, DM::np(m), lane, Pl);           \
-  ArmLane<G, DM, NL> ALl(C, L, krec, lane, Ml, Pl)
+  ArmLane<G, DM, NL, WsArmModel> ALl(C, L, krec, lane, Ml, Pl)
 #define WS_ARM_LOCALS() WS_ARM_LOCALS_AT(l)
   const BoxLane BL = box_lane_load(m, l);
   ArmLane<G, DM, NL> AL(C, L, krec, l, M, P);    // (LINK: used for its gravity vector only)
@@ -841,13 +844,18 @@ DEV void abb_ws_body(const AbbArgs& A) {
           BoxMasks BMb;
           boxes_pose<G>(C, L, lq, Bb);
           fixed_corner_slots<G, SC, true>(C, L, lq, BMb);
-          if (lq == nb + SC::DYN) {              // the free box's rigid inertia, bias force and position: to its lane of the solve
+          // the free box's part of the solve's records here, where its rigid inertia is in registers (csrc/shf_hard.h: hard_records):
+          // LDL^T factors and velocity rate into its exchange slot, its free acceleration and position on to its lane of the solve
+          {
+            const float a0[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            float abox[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            hard_records<G, true, DM, ArmSolveLane, 2>(C, L, lq, ArmSolveLane::load<NL>(m, lq), Bb, gq, a0, abox);
+            if (lq == nb + SC::DYN) {
 #pragma unroll
-            for (int k = 0; k < 21; k++) box_stash[k] = Bb.IA[k];
+              for (int k = 0; k < 6; k++) L.acc[lq * 6 + k] = abox[k];
 #pragma unroll
-            for (int k = 0; k < 6; k++) box_stash[21 + k] = Bb.pA[k];
-#pragma unroll
-            for (int k = 0; k < 3; k++) box_stash[27 + k] = Bb.p[k];
+              for (int k = 0; k < 3; k++) box_stash[27 + k] = Bb.p[k];
+            }
           }
         }
       }
@@ -863,8 +871,8 @@ DEV void abb_ws_body(const AbbArgs& A) {
           ALl.recursions();
           GROUP_SYNC();
           // the solve's body records and velocity rates (csrc/shf_hard.h: hard_records) here, on the arm wave, which would
-          // otherwise wait for the box wave's link passes: links from the chain lane's records, the free box (its rigid
-          // inertia parked by the box wave before S0') on the lane of its actor index
+          // otherwise wait for the box wave's link passes: the links' from the chain lane's records (the free box's part is
+          // the box wave's, before S0')
           {
             BodyRegs Br;
             if (lq >= 1 && lq <= NL) {
@@ -873,19 +881,9 @@ DEV void abb_ws_body(const AbbArgs& A) {
               for (int k = 0; k < 6; k++) { Br.S[k] = kr[k]; Br.U[k] = kr[12 + k]; }
               Br.invD = kr[18];
             }
-            if (lq == nb + SC::DYN) {
-#pragma unroll
-              for (int k = 0; k < 21; k++) Br.IA[k] = box_stash[k];
-#pragma unroll
-              for (int k = 0; k < 6; k++) Br.pA[k] = box_stash[21 + k];
-            }
             const float a0[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};     // (a fixed base: the root's record is zero)
-            float abox[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-            hard_records<G, true, DM, LaneModel>(C, L, lq, Ml, Br, gq, a0, abox);
-            if (lq == nb + SC::DYN) {
-#pragma unroll
-              for (int k = 0; k < 6; k++) L.acc[lq * 6 + k] = abox[k];      // -> the box's lane of the solve
-            }
+            float abox[6];
+            hard_records<G, true, DM, WsArmModel, 1>(C, L, lq, Ml, Br, gq, a0, abox);
           }
           PHASE_MARK(26);
         } else {
