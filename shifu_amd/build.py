@@ -77,7 +77,7 @@ BUDGETS = [("_Z16k_a1_step_a1_g32", 256, 0),          # default: A1, two envs pe
            # config 5's default under that solve since round 6 (arm wave + box wave, the solve regrouped at 32 lanes per env): two
            # waves per SIMD; the link passes and the solve share 256 registers (1184 B of scratch when a struct copy and a pointer
            # select had put five structs on the stack: 0.50 ms instead of 0.37)
-           ("_Z18k_abb_step_ws_hardILb1EE", 256, 96), ("_Z18k_abb_step_ws_hardILb0EE", 256, 64),
+           ("_Z18k_abb_step_ws_hardILb1EE", 256, 64), ("_Z18k_abb_step_ws_hardILb0EE", 256, 0),
            ("_Z10k_sim_stepILi32ELb0ELb0ELb0ELb1ELb0EE", 168, 0), ("_Z10k_sim_stepILi32ELb1ELb0ELb1ELb1ELb0EE", 256, 32)]
 
 

@@ -870,20 +870,29 @@ DEV void abb_ws_body(const AbbArgs& A) {
           GROUP_SYNC();
           ALl.recursions();
           GROUP_SYNC();
-          // the solve's body records and velocity rates (csrc/shf_hard.h: hard_records) here, on the arm wave, which would
-          // otherwise wait for the box wave's link passes: the links' from the chain lane's records (the free box's part is
-          // the box wave's, before S0')
-          {
-            BodyRegs Br;
-            if (lq >= 1 && lq <= NL) {
-              const float* kr = krec + (lq - 1) * KREC_STRIDE;
+          // the links' part of the solve's records (csrc/shf_hard.h: hard_records, PARTS 1) here, on the arm wave, which would
+          // otherwise wait for the box wave's link passes -- for this arm in its chain form: link lanes copy (S, U, 1 / D) from the
+          // chain lane's records, the chain lane zeroes the fixed root's rate and runs Dl_b = S_b qdd_b + Dl_(b-1) down the chain
+          // (the same fma on the same values as the level-by-level loop; the free box's part is the box wave's, before S0')
+          if (lq >= 1 && lq <= NL) {
+            const float* kr = krec + (lq - 1) * KREC_STRIDE;
+            float* rec = L.xch + lq * XCH_STRIDE;
 #pragma unroll
-              for (int k = 0; k < 6; k++) { Br.S[k] = kr[k]; Br.U[k] = kr[12 + k]; }
-              Br.invD = kr[18];
+            for (int k = 0; k < 6; k++) { rec[HB_S + k] = kr[k]; rec[HB_U + k] = kr[12 + k]; }
+            rec[HB_INVD] = kr[18];
+          }
+          if (lq == 0) {
+            float Dl[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < 6; k++) L.xch[HB_FDL + k] = 0.0f;
+#pragma unroll
+            for (int b = 1; b <= NL; b++) {
+              const float* kr = krec + (b - 1) * KREC_STRIDE;
+              const float qdd = L.dofb[(b - 1) * DOF_STRIDE + 4];
+              float* rec = L.xch + b * XCH_STRIDE;
+#pragma unroll
+              for (int k = 0; k < 6; k++) { Dl[k] = fmaf(kr[k], qdd, Dl[k]); rec[HB_DL + k] = Dl[k]; }
             }
-            const float a0[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};     // (a fixed base: the root's record is zero)
-            float abox[6];
-            hard_records<G, true, DM, WsArmModel, 1>(C, L, lq, Ml, Br, gq, a0, abox);
           }
           PHASE_MARK(26);
         } else {
