@@ -71,6 +71,10 @@ BUDGETS = [("_Z16k_a1_step_a1_g32", 256, 0),          # default: A1, two envs pe
            ("_Z14k_a1_chain_pgsILb0ELb0EE", 256, 0), ("_Z14k_a1_chain_pgsILb0ELb1EE", 256, 0),
            ("_Z14k_a1_chain_pgsILb1ELb0EE", 256, 0), ("_Z14k_a1_chain_pgsILb1ELb1EE", 256, 0),
            ("_Z20k_sim_step_chain_pgs", 168, 0),
+           # ... and their TGS instantiations, the default since round 6 (physx.solver_type = 1)
+           ("_Z14k_a1_chain_tgsILb0ELb0EE", 256, 0), ("_Z14k_a1_chain_tgsILb0ELb1EE", 256, 0),
+           ("_Z14k_a1_chain_tgsILb1ELb0EE", 256, 0), ("_Z14k_a1_chain_tgsILb1ELb1EE", 256, 0),
+           ("_Z20k_sim_step_chain_tgs", 168, 0),
            # config 5 under that solve: the wave-specialised step on compile-time shapes (round 6) without spills; the run-time-shaped
            # generic kernels (any articulation / scene) as they stand: sixteen envs per 512-thread workgroup at 256 registers
            ("_Z19k_abb_step_pgs_wide", 256, 272), ("_Z19k_sim_step_pgs_wide", 256, 48),

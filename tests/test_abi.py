@@ -78,10 +78,14 @@ def test_register_budgets_of_the_fused_step():
     assert k["spill"] == 0 and k["vgprs"] <= 256
     # the kernels that are the defaults since round 5 (velocity-level solve) are under the same guard
     guarded = [p for p, _, _ in build.BUDGETS]
-    for fam in ("_Z14k_a1_chain_pgs", "_Z20k_sim_step_chain_pgs", "_Z19k_abb_step_pgs_wide", "_Z19k_sim_step_pgs_wide"):
+    for fam in ("_Z14k_a1_chain_pgs", "_Z20k_sim_step_chain_pgs", "_Z19k_abb_step_pgs_wide", "_Z19k_sim_step_pgs_wide",
+                "_Z14k_a1_chain_tgs", "_Z20k_sim_step_chain_tgs", "_Z18k_abb_step_ws_hard"):      # (round 6: the TGS forms, config 5's own kernel)
         assert any(p.startswith(fam) for p in guarded), fam
-    pgs = [v for n, v in res.items() if n.startswith("_Z14k_a1_chain_pgsILb0ELb0EE")][0]
-    assert pgs["spill"] == 0 and pgs["scratch"] == 0 and pgs["vgprs"] + pgs["agprs"] <= 256
+    for sym in ("_Z14k_a1_chain_pgsILb0ELb0EE", "_Z14k_a1_chain_tgsILb0ELb0EE"):       # the default A1 kernel of `solver_type` 0 / 1
+        k = [v for n, v in res.items() if n.startswith(sym)][0]
+        assert k["spill"] == 0 and k["scratch"] == 0 and k["vgprs"] + k["agprs"] <= 256, sym
+    ws = [v for n, v in res.items() if n.startswith("_Z18k_abb_step_ws_hardILb0EE")][0]
+    assert ws["spill"] == 0 and ws["scratch"] == 0
 
 
 def test_a_bloated_default_kernel_fails_the_budget_check():
@@ -91,13 +95,13 @@ def test_a_bloated_default_kernel_fails_the_budget_check():
     from shifu_amd import build
     build.build_native()
     res = json.load(open(build.RESOURCES))
-    name = [n for n in res if n.startswith("_Z14k_a1_chain_pgsILb0ELb0EE")][0]
+    name = [n for n in res if n.startswith("_Z14k_a1_chain_tgsILb0ELb0EE")][0]      # the headline kernel since round 6
     for field, value in (("vgprs", 257), ("scratch", 16), ("agprs", 64)):
         bad = copy.deepcopy(res)
         bad[name][field] = value
         with pytest.raises(RuntimeError, match="register budget"):
             build.check_budgets(bad)
-    missing = {k: v for k, v in res.items() if not k.startswith("_Z14k_a1_chain_pgs")}
+    missing = {k: v for k, v in res.items() if not k.startswith("_Z14k_a1_chain_tgs")}
     with pytest.raises(RuntimeError, match="missing"):
         build.check_budgets(missing)
 
