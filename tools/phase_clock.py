@@ -38,7 +38,8 @@ def main():
     pgs = "--pgs" in sys.argv         # --chain: the velocity-level contact solve (k_a1_chain_pgs, csrc/shf_chain_hard.h)
     selfc = "--self" in sys.argv      # --chain: with self-collision
     terrain = "trimesh" if "--trimesh" in sys.argv else "heightfield"
-    argv = [a for a in sys.argv if a not in ("--abb", "--chain", "--levels", "--split", "--link", "--pgs", "--self", "--trimesh")]
+    hull = "--hull" in sys.argv       # --abb --link: the links as convex hulls (the EXT instantiation of the run-time-shaped kernel)
+    argv = [a for a in sys.argv if a not in ("--abb", "--chain", "--levels", "--split", "--link", "--pgs", "--self", "--trimesh", "--hull")]
     G = int(argv[1]) if len(argv) > 1 else 32
     steps = int(argv[2]) if len(argv) > 2 else 100
     from shifu_amd import build as b
@@ -52,7 +53,7 @@ def main():
     from shifu_amd.gym.abb_fused import FusedAbbEnv
     # --abb: the sub-step phases (0-10) of the push-box env; its kernel has no marks outside the sub-steps
     env = (FusedAbbEnv(num_envs=4096, group=G, link_contacts=link, mapping="split" if split else ("body" if (levels or link) else "chain"),
-                       solver="pgs" if pgs else "compliant") if abb else
+                       solver="pgs" if pgs else "compliant", **({"link_shapes": "hull"} if hull else {})) if abb else
            FusedA1Env(num_envs=4096, group=G, mapping="chain" if chain else "body", solver="pgs" if pgs else "compliant",
                       self_collision=selfc, terrain=terrain))
     if chain:
