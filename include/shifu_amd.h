@@ -464,6 +464,11 @@ int shf_sim_commit_root_all(ShfSim* sim, const float* root_dev, void* stream);
 /* gym.set_dof_state_tensor_indexed (robot.py:83-86) */
 int shf_sim_commit_dof_indexed(ShfSim* sim, const float* dof_dev, const int32_t* actor_idx_dev, int32_t n,
                                void* stream);
+/* 1 when shf_sim_step has the kernel compiled for this sim's arm + scene under its velocity-level solver (the shipped 6-link arm,
+ * table / cube / pad, no velocity drives, no self-collision pairs): shf_sim_set_mapping(sim, SHF_MAP_CHAIN_SPLIT) then selects it
+ * for gym.simulate (robot.py:69, isaac_gym.py:140) -- identical results, ~0.7 x the time of the run-time-shaped kernel.  With
+ * self-collision on (the reference's AbbPushBox: collision filter 0, units.py:68) the answer is 0.  (ABI v15) */
+int shf_sim_step_split_supported(const ShfSim* sim);
 /* The three indexed commits of one reset as ONE launch (ABI v15): what IsaacGymEnv.reset_idx (isaac_gym.py:54-73) issues for a
  * reset set -- Robot._reset_dof_state's gym.set_dof_position_target_tensor_indexed and gym.set_dof_state_tensor_indexed
  * (robot.py:78-86), then gym.set_actor_root_state_tensor_indexed (isaac_gym.py:70-73) over every actor's rows.  Any part may

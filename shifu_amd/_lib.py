@@ -40,6 +40,7 @@ _SIGS = {
     "shf_sim_commit_root_all": ([vp, vp, vp], i32),
     "shf_sim_commit_dof_indexed": ([vp, vp, vp, i32, vp], i32),
     "shf_sim_commit_reset": ([vp, vp, vp, i32, vp, vp, vp, i32, vp], i32),
+    "shf_sim_step_split_supported": ([vp], i32),
     "shf_a1_create": ([vp, C.POINTER(_abi.ShfA1TaskParams), C.POINTER(vp)], i32),
     "shf_a1_destroy": ([vp], i32),
     "shf_a1_layout": ([vp, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)], i32),

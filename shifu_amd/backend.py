@@ -230,6 +230,16 @@ class Sim:
                 t.fill_(1.0)
             self.bind(tid, t)
 
+    def use_split_step(self) -> bool:
+        """gym.simulate on the kernel compiled for this sim's arm + scene, when there is one (shf_sim_step_split_supported: the
+        shipped 6-link arm with table / cube / pad under a velocity-level solver -> k_sim_step_ws_hard; identical results).  The gym
+        facade asks after prepare_sim; False: shf_sim_step stays on the run-time-shaped kernels."""
+        if self.params.solver == _abi.SOLVER_COMPLIANT or not lib().shf_sim_step_split_supported(self._h):
+            return False
+        check(lib().shf_sim_set_mapping(self._h, _abi.MAP_CHAIN_SPLIT))
+        self.mapping = "split"
+        return True
+
     def bind_contact_hist(self, on: bool = True):
         """SHF_T_CONTACT_HIST (velocity-level solve): per env, how many sub-steps offered k candidate constraints before the
         max_contacts cap -- (num_envs, CONTACT_HIST_BINS + 1) int32 (last column: the env's drop counter, which

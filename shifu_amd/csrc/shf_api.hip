@@ -436,6 +436,19 @@ static int launch_ptr(const void* fn, dim3 grid, dim3 block, size_t lds, void* s
   return 0;
 }
 
+// gym.simulate of the shipped arm in the shipped scene under the velocity-level solves has a kernel of its own (k_sim_step_ws_hard:
+// arm wave + box wave, the solve regrouped; csrc/shf_kernels.h) -- chosen with the split mapping.  What it is compiled for:
+static bool sim_ws_hard_ok(const ShfSim* s) {
+  if (!s->finalized || s->sp.solver == SHF_SOLVER_COMPLIANT || s->nboxes == 0 || !sim_plain(s) || sim_self(s) || s->terr.warped) return false;
+  if (s->sp.pos_iters < 1 || s->sp.max_contacts > HCK) return false;
+  if (!ArmChain<6>::matches(s->model) || !AbbScene::matches(s->nboxes, s->boxes, s->model.nsph)) return false;
+  if (!(sim_link(s) ? AbbLinkDims::matches(s->model) : AbbDims::matches(s->model))) return false;
+  for (int d = 0; d < s->model.nd; d++)
+    if (s->model.drive_mode[d] == SHF_DOF_MODE_VEL) return false;      // (the arm lanes' drive law takes position targets and efforts)
+  return true;
+}
+extern "C" int shf_sim_step_split_supported(const ShfSim* sim) { return (sim && sim_ws_hard_ok(sim)) ? 1 : 0; }
+
 extern "C" int shf_sim_step(ShfSim* sim, void* stream) {
   if (int r = need(sim, {SHF_T_SIM_DOF, SHF_T_SIM_ROOT, SHF_T_SIM_CONTACT, SHF_T_MODEL}, "shf_sim_step")) return r;
   if (sim->model.nhull > 0 && sim->model.link_collide != 0 && sim->nboxes > 0 && !sim->t[SHF_T_HULLS]) return fail("shf_sim_step: the articulation's hulls (SHF_T_HULLS) are not bound");
@@ -473,6 +486,15 @@ extern "C" int shf_sim_step(ShfSim* sim, void* stream) {
   if (sim->sp.solver != SHF_SOLVER_COMPLIANT) {
     // the velocity-level contact solve: built for A1-shaped articulations on their own (csrc/shf_chain_hard.h)
     if (sim->sp.max_contacts > shf_a1_chain_pgs_max_contacts() || sim->sp.pos_iters < 1) return fail("shf_sim_step: SHF_SOLVER_PGS needs pos_iters >= 1 and max_contacts <= 16");
+    if (sim->mapping == SHF_MAP_CHAIN && sim->mapping_split && !A.body_force && sim_ws_hard_ok(sim)) {
+      const bool link = sim_link(sim);
+      const int nbx = sim->nboxes, wepb = 16;
+      const int nslots = hard_total_slots(sim->model.np + box_slot_count(nbx, sim_ndyn(sim), sim->model.nsph) + (link ? 2 * SHF_MAX_LINK_CONTACTS : 0), link);
+      const size_t wlds = ((size_t)MODEL_WORDS + SCENE_WORDS + ABB_WORDS + STATS_LDS_WORDS +
+                           (size_t)wepb * env_lds_words(sim->model.nb + nbx, sim->model.nd, nslots, ABB_TAIL_WORDS(nslots, sim->model.nd) + WS_LINK_STASH_WORDS, 1 + nbx)) * 4;
+      const dim3 wgrid((sim->n + wepb - 1) / wepb), wblock(512);
+      return link ? launch(k_sim_step_ws_hard<true>, wgrid, wblock, wlds, stream, A) : launch(k_sim_step_ws_hard<false>, wgrid, wblock, wlds, stream, A);
+    }
     sim->force_armed = false;
     sim->force_at_pos = false;
     if (sim->nboxes == 0 && shf_a1_chain_matches(sim->model) && !A.body_force_pos)

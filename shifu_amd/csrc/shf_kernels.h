@@ -714,22 +714,29 @@ DEV void pair_barrier(int* ctr, int target) {
     __builtin_amdgcn_s_sleep(1);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-template <int WT, bool LINK, bool HARD>
+// SIMONLY (k_sim_step_ws_hard): ONE gym.simulate of that scene for the hook path -- the same sub-step on the solver-side tensors
+// (SimArgs in A.S: state in, state / net contact forces out; position targets and efforts from the command tensors), none of the
+// task's code (inverse kinematics, statistics, state refresh, post_step).
+template <int WT, bool LINK, bool HARD, bool SIMONLY = false>
 DEV void abb_ws_body(const AbbArgs& A) {
   constexpr int G = 16, NL = 6, HALF = WT / 2, EPB = HALF / G;
   static_assert(!HARD || WT == 512, "the regrouped solve: sixteen envs x 32 lanes");
+  static_assert(!SIMONLY || HARD, "the sub-step kernel of the hook path exists under the velocity-level solves");
   typedef typename std::conditional<LINK, AbbLinkDims, AbbDims>::type DM;
   typedef AbbScene SC;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   PHASE_BEGIN();
   PHASE_BEGIN_T();
   float* stats_lds = smem + MODEL_WORDS + SCENE_WORDS + ABB_WORDS;
-  stats_block_init(stats_lds);
-  const unsigned long long stats_step = stats_step_load(A.stats);
-  stage_block<(int)sizeof(ShfAbbTaskParams), WT>(A.tp, smem + MODEL_WORDS + SCENE_WORDS);
+  unsigned long long stats_step = 0ull;
+  if constexpr (!SIMONLY) {
+    stats_block_init(stats_lds);
+    stats_step = stats_step_load(A.stats);
+    stage_block<(int)sizeof(ShfAbbTaskParams), WT>(A.tp, smem + MODEL_WORDS + SCENE_WORDS);
+  }
   const ShfScene* scene = stage_scene<WT>(A.S.scene, smem + MODEL_WORDS);
   const ShfModel* m = stage_model<WT>(A.S.model, smem);
-  const ShfAbbTaskParams& tp = *reinterpret_cast<const ShfAbbTaskParams*>(smem + MODEL_WORDS + SCENE_WORDS);
+  const ShfAbbTaskParams& tp = *reinterpret_cast<const ShfAbbTaskParams*>(smem + MODEL_WORDS + SCENE_WORDS);      // (SIMONLY: not staged, not read)
   const bool arm = (int)threadIdx.x < HALF;
   const int t = (int)threadIdx.x - (arm ? 0 : HALF), es = t / G, l = t % G;
   const int e = blockIdx.x * EPB + es;
@@ -755,6 +762,9 @@ DEV void abb_ws_body(const AbbArgs& A) {
     const float* root = A.S.root + (size_t)e * actors * 13;
     for (int i = l; i < 2 * nd; i += G) L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)] = dof[i];
     for (int i = l; i < 13 * actors; i += G) L.root[i] = root[i];
+    if constexpr (SIMONLY) {
+      if (l < nd) L.dofb[l * DOF_STRIDE + 5] = A.S.effort ? A.S.effort[(size_t)e * nd + l] : 0.0f;     // (EFFORT-mode dofs: sim_step_body)
+    }
   }
   // HARD: the pair barrier's counter of (arm wave j, box wave j + 4): a spare word of their first env's tail
   int* pair_ctr = reinterpret_cast<int*>(env_base + (size_t)(es & ~3) * env_words + (tgtl - (env_base + es * env_words)) + ABB_TGT_WORDS(nd) + ARM_KREC_WORDS(NL) + 2);
@@ -763,9 +773,11 @@ DEV void abb_ws_body(const AbbArgs& A) {
     if (arm && (t & 63) == 0) *pair_ctr = 0;
   }
   // AbbRobot.step's inverse kinematics on the box wave, beside the arm wave's loads (it reads the tensors directly)
-  if (!arm && live && l == 0)
-    abb_ik_targets(A, tp, A.S.dof + (size_t)e * nd * 2, 2, e, nd, A.body_state + (size_t)e * nbt * 13,
-                   A.jacobian + (size_t)e * (nb - 1) * 6 * nd, tgtl, stats_step);
+  if constexpr (!SIMONLY) {
+    if (!arm && live && l == 0)
+      abb_ik_targets(A, tp, A.S.dof + (size_t)e * nd * 2, 2, e, nd, A.body_state + (size_t)e * nbt * 13,
+                     A.jacobian + (size_t)e * (nb - 1) * 6 * nd, tgtl, stats_step);
+  }
   __syncthreads();                               // S0: root rows and POS targets visible to both
   PHASE_MARK(11);
 
@@ -773,8 +785,8 @@ DEV void abb_ws_body(const AbbArgs& A) {
   C.m = m; C.sp = A.S.sp; C.terr.t = A.S.terr; C.terr.h = A.S.heights; C.scene = scene;
   C.dropped = (LINK && live && !arm) ? env_dropped(A.S.dropped, A.S.sp, e) : nullptr;   // (the box wave counts the dropped link contacts)
   C.mscale = (live && A.S.mscale) ? A.S.mscale + (size_t)e * DM::nb(m) : nullptr;
-  const float mu = live ? A.S.friction[e] : 0.0f;
-  const int nsub = tp.decimation + (tp.extra_substep ? 1 : 0);
+  const float mu = live ? (A.S.friction ? A.S.friction[e] : 1.0f) : 0.0f;
+  const int nsub = SIMONLY ? 1 : tp.decimation + (tp.extra_substep ? 1 : 0);
   // Per-lane model constants.  Without link contacts they are loaded once and stay in registers.  With them the kernel has 256
   // registers (two waves per SIMD) and the box wave's link passes need most: the arm wave re-reads its constants from the LDS
   // model at the head of each of its phases (WS_ARM_LOCALS), so that they are not live across the other wave's code.
@@ -820,7 +832,7 @@ DEV void abb_ws_body(const AbbArgs& A) {
       const int t16 = tq - (arm ? 0 : HALF), esq = t16 / G, lq = t16 % G;
       const int e = blockIdx.x * EPB + esq;
       const bool live = e < n;
-      const float mu = live ? A.S.friction[e] : 0.0f;
+      const float mu = live ? (A.S.friction ? A.S.friction[e] : 1.0f) : 0.0f;
       C.dropped = (LINK && live && !arm) ? env_dropped(A.S.dropped, A.S.sp, e) : nullptr;
       C.mscale = (live && A.S.mscale) ? A.S.mscale + (size_t)e * DM::nb(m) : nullptr;
       const EnvLds L = env_lds_carve(env_base + esq * env_words, nbt, nd, nslots, actors);
@@ -830,10 +842,12 @@ DEV void abb_ws_body(const AbbArgs& A) {
       float* box_stash = krec + ARM_KREC_WORDS(NL) + 4;
       int* pair_ctr = reinterpret_cast<int*>(env_base + (size_t)(esq & ~3) * env_words + (tgtl - (env_base + esq * env_words)) + ABB_TGT_WORDS(nd) + ARM_KREC_WORDS(NL) + 2);
       const float gq[3] = {AL.g[0], AL.g[1], AL.g[2]};
+      // POS-drive targets: the fused step's are in LDS (inverse kinematics), gym.simulate's in the command tensor
+      const float* ptq = SIMONLY ? ((live && A.S.pos_tgt) ? A.S.pos_tgt + (size_t)e * nd : nullptr) : tgtl;
       if (live) {
         if (arm) {
           WS_ARM_LOCALS_AT(lq);
-          ALl.joints_and_drives(tgtl);
+          ALl.joints_and_drives(ptq);
           GROUP_SYNC();
           ALl.compose();
           GROUP_SYNC();
@@ -1096,6 +1110,18 @@ DEV void abb_ws_body(const AbbArgs& A) {
       }
     }
   }
+  if constexpr (SIMONLY) {
+    // gym.simulate ends here: the sub-step's state and net contact forces back to the solver-side tensors (sim_step_body's stores)
+    __syncthreads();
+    if (live && arm) {
+      float* dof = A.S.dof + (size_t)e * nd * 2;
+      float* root = A.S.root + (size_t)e * actors * 13;
+      for (int i = l; i < 2 * nd; i += G) dof[i] = L.dofb[(i >> 1) * DOF_STRIDE + (i & 1)];
+      for (int i = l; i < 13 * actors; i += G) root[i] = L.root[i];
+      for (int i = l; i < 3 * nbt; i += G) A.S.contact[(size_t)e * nbt * 3 + i] = L.xch[i];
+    }
+    return;
+  }
   PHASE_MARK(28);
   __syncthreads();                               // the boxes' final root rows and contact rows are in LDS
   PHASE_MARK(29);
@@ -1181,6 +1207,14 @@ __global__ __launch_bounds__(WT) void k_abb_step_ws(AbbArgs A) {
 template <bool LINK>
 __global__ __launch_bounds__(512) void k_abb_step_ws_hard(AbbArgs A) {
   abb_ws_body<512, LINK, true>(A);
+}
+// gym.simulate of the shipped arm in the shipped scene under the velocity-level solves (the hook path's sub-step: shf_sim_step
+// with the split mapping): abb_ws_body's sub-step alone
+template <bool LINK>
+__global__ __launch_bounds__(512) void k_sim_step_ws_hard(SimArgs S) {
+  AbbArgs A = {};
+  A.S = S;
+  abb_ws_body<512, LINK, true, true>(A);
 }
 
 #ifdef SHF_DEFINE_SMALL_KERNELS

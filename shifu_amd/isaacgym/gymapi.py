@@ -502,6 +502,10 @@ class Gym:
         sim.actors_per_env = len(env0.actors)
         n = len(sim.envs)
         be.finalize(n, 0)
+        # the shipped arm + scene under TGS / PGS WITHOUT self-collision has a gym.simulate kernel of its own (k_sim_step_ws_hard); with
+        # self-collision on -- what collision filter 0 means for the reference's AbbPushBox -- this is a no-op and the step stays on
+        # the run-time-shaped kernel
+        be.use_split_step()
         A = sim.actors_per_env
         root = torch.zeros(n * A, 13)
         fr = torch.ones(n)

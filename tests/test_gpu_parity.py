@@ -795,8 +795,9 @@ def test_abb_scene_with_link_contacts_matches_oracle_bitwise(oracle):
     assert np.isfinite(root).all() and np.isfinite(dof).all()
 
 
+@pytest.mark.parametrize("step_kernel", ["body", "split", "split-tgs"])
 @pytest.mark.parametrize("link", [False, True])
-def test_abb_scene_under_the_velocity_level_solve_matches_oracle_bitwise(oracle, link):
+def test_abb_scene_under_the_velocity_level_solve_matches_oracle_bitwise(oracle, link, step_kernel):
     """The config-5 scene under ShfSimParams.solver = SHF_SOLVER_PGS through gym.simulate: the body-per-lane sub-step with the
     generic solve (csrc/shf_hard.h, k_sim_step<32, BOX, SELF, LINK, HARD>) -- the free cube as a solver body of its own (its
     corners against the table by signed distance, the rod's capsule ends against the cube with impulses on both sides), with
@@ -807,10 +808,15 @@ def test_abb_scene_under_the_velocity_level_solve_matches_oracle_bitwise(oracle,
     rng = np.random.default_rng(17)
     cm = abb_model(link_contacts=link)
     m = cm.blob
-    sp = H.sim_params(dt=0.02, angular_damping=0.5, solver="pgs")
+    sp = H.sim_params(dt=0.02, angular_damping=0.5, solver="tgs" if step_kernel.endswith("tgs") else "pgs")
     boxes = abb_boxes()
     n, A, B = 24, 4, m.nb + 3
     sim, dof, root = _scene_on_gpu(cm, sp, boxes, [b.pos for b in boxes], n, 32)
+    # "split": gym.simulate on the kernel compiled for this arm + scene (k_sim_step_ws_hard: arm wave + box wave, the solve
+    # regrouped -- what the gym facade selects after prepare_sim); "body": the run-time-shaped kernel any scene runs on
+    from shifu_amd._lib import lib
+    assert lib().shf_sim_step_split_supported(sim._h) == 1
+    assert sim.use_split_step() if step_kernel.startswith("split") else sim.mapping == "body"
     dof[:, 0] = np.tile(np.array(ABB_DEFAULT_DOF_POS, np.float32), n) + rng.uniform(-0.05, 0.05, n * m.nd)
     root[0::A, :3] = ABB_BASE_POS
     root[2::A, :3] = np.stack([rng.uniform(0.03, 0.08, n), rng.uniform(-0.03, 0.03, n), rng.uniform(0.125, 0.14, n)], 1)
