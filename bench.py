@@ -533,7 +533,7 @@ def main():
                                    f"(dt {'20' if abb else '5'} ms), resets on, contact solver: "
                                    + (f"velocity-level {'TGS (physx.solver_type = 1: sub-stepped sweeps)' if args.solver == 'tgs' else 'PGS (physx.solver_type = 0)'} {args.pos_iters} + {args.vel_iters} iterations (the reference's physx settings, env_config.py:50-58), at most {int(env.sim_params.max_contacts) or 8} constraints per env" if args.solver in ("pgs", "tgs")
                                       else "compliant spring-damper law (rounds 1-4)")
-                                   + (((", link contacts ON (arm links as the reduced convex hulls of their collision meshes + rod vs table / cube / goal pad; clipped face manifolds on)" if args.link_shapes == "hull" else ", link contacts ON (arm links + rod vs table / cube / goal pad)") if args.link_contacts else
+                                   + (((", link contacts ON (arm links as the reduced convex hulls of their collision meshes + rod vs table / cube / goal pad; clipped face manifolds on)" if args.link_shapes == "hull" else ", link contacts ON (arm links + rod vs table / cube / goal pad); the arm's own links do not collide with each other (the reference's collision filter 0 lets them: the gym facade's hook path has those 46 capsule pairs on)") if args.link_contacts else
                                        ", arm collider: the rod against the cube (link contacts OFF, see --link-contacts)") if abb else (", self-collision ON (capsule pairs, the reference's collision filter 0)" if args.self_collision
                                                       else ", self-collision OFF (the reference has it on: units.py:68; see --self-collision)")),
                        "envs_per_gpu": N, "total_envs": total_envs, "substeps_per_env_step": substeps,
