@@ -694,14 +694,18 @@ __global__ __launch_bounds__(512) void k_abb_step_pgs_wide(AbbArgs A) {
 // The contact passes only record candidate constraints and the arm's articulated-body solve runs free, so the two waves need
 // no exchange until both are done:
 //     arm wave                                   |  box wave
-//     joints, drives, chain composition          |  box poses, corner candidates, the free box's rigid (IA, pA) -> LDS
+//     joints, drives, chain composition          |  box poses, corner candidates; the free box's part of the solve's records
+//                                                |  (LDL^T factors, velocity rate, free acceleration) while its inertia is in registers
 //   ---- S0': the arm's poses and the boxes' visible to both
 //     inertias, sample-point candidates,         |  rod-capsule candidate, link-contact candidates
-//     free ABA inward / outward                  |
-//   ---- S1: candidates, free accelerations and the per-link (S, U, 1/D) records visible
-//     ALL waves, regrouped at 32 lanes per env (two envs per wave): substep_hard_finish -- gather, response matrix, sweeps,
-//     impulse passes, integration (csrc/shf_hard.h, the code the run-time-shaped kernels run: same values, same bits)
+//     free ABA inward / outward, the links' part |
+//     of the solve's records (chain form)        |
+//   ---- S1: candidates, free accelerations and the solve's body records visible
+//     BOTH waves, regrouped at 32 lanes per env (two of the pair's four envs each): substep_hard_finish<.., RECORDS = false,
+//     ARMNL = 6> -- gather, response matrix, sweeps, impulse passes (the arm's on the chain lane), integration (csrc/shf_hard.h,
+//     the code the run-time-shaped kernels run: same values, same bits)
 //   ---- S2
+// S0', S1, S2 are barriers of that wave pair only (pair_barrier below); the workgroup's eight waves meet before and after the loop.
 // Barrier of TWO wavefronts of a workgroup (both resident: same workgroup) on an LDS counter that only grows: the k-th meeting
 // is over when the counter reaches 2 k.  k_abb_step_ws_hard's arm wave j and box wave j + 4 share four envs through all of a
 // sub-step, so they only wait for each other -- not, as with s_barrier, for the slowest of the workgroup's eight waves in each
